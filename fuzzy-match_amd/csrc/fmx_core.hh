@@ -1,0 +1,324 @@
+// fmx_core.hh — per-lane building blocks of the match() hot path, shared by every HIP kernel.
+//
+// Everything here is a plain inline function over raw pointers so that the exact code the
+// kernels run per lane can also be compiled for the host by tests/emul (a test-only serial
+// harness that checks the GPU decomposition against the oracle without a GPU).  No product
+// path runs these on the CPU.
+//
+// Float discipline: every expression is parenthesised as in the reference and the library is
+// built with -ffp-contract=off, so each add/mul/div rounds once, like the reference's x86-64
+// SSE build (SURVEY §8a "exact-arithmetic spec").
+#pragma once
+#include <stdint.h>
+#include <float.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define FMX_HD __host__ __device__ __forceinline__
+#else
+#define FMX_HD inline
+#endif
+
+namespace fmx {
+
+// match() arguments (include/fuzzy/fuzzy_match.hh:72-84) + per-index constants the kernels need.
+struct Params {
+  float    fuzzy;
+  uint32_t nmatch;
+  int32_t  no_perfect;
+  int32_t  min_subseq_length;
+  float    min_subseq_ratio;
+  float    idf_penalty;
+  float    ins, del, rep;
+  float    contrast;
+  int32_t  reduce;
+  int32_t  cbuf;        // contrast_buffer after the "-1 => nmatch" rule (src/fuzzy_match.cc:451-452)
+  float    idf_max;     // compute_max_idf_penalty (src/fuzzy_match.cc:367-370) or 0.01 when idf is off
+  uint32_t max_tokens;  // max_tokens_in_pattern (suffix_array_index.hh:15)
+};
+
+// One suffix-array entry as laid out in HBM: everything a compare step or the length filter
+// needs in one 8-byte load.  off = index into the token stream of the suffix's first token
+// (= _sentence_pos[sid] + subsentence_pos), rem = tokens left in the sentence from there,
+// slen = the sentence's length (the reference's _sentence_length cache, suffix_array.hh:61).
+struct SufRec {
+  uint32_t off;
+  uint16_t rem;
+  uint16_t slen;
+};
+
+// candidate / accepted-match record in the per-query segment
+struct Cand {
+  uint32_t sid;
+  uint32_t longest;
+  float    score;
+  float    penalty;
+};
+
+constexpr uint32_t kNoMatchLen = 0xffffffffu;  // query skipped by the guards
+
+// src/fuzzy_match.cc:455-467 — guards and min_subseq_length normalisation.  Returns the
+// unsigned _min_seq_len handed to NGramMatches, or kNoMatchLen when match() returns false early.
+FMX_HD uint32_t min_seq_len(uint32_t p, const Params& prm) {
+  if (p > prm.max_tokens || p == 0) return kNoMatchLen;
+  int ml = prm.min_subseq_length;
+  if ((uint64_t)(int64_t)ml > (uint64_t)p) ml = (int)p;  // (std::size_t)(int) > size
+  const int by_ratio = (int)(prm.min_subseq_ratio * (float)p);
+  if (by_ratio > ml) ml = by_ratio;
+  return (uint32_t)ml;
+}
+
+// length of n-gram whose suffix range seeds the candidates of one start position: the reference
+// never registers unigrams unless p == 1 (src/fuzzy_match.cc:484-493,525,546).
+FMX_HD uint32_t seed_len(uint32_t p, uint32_t msl) {
+  if (p == 1) return 1;
+  return msl < 2 ? 2u : msl;
+}
+
+// Costs::get_normalizer — include/fuzzy/costs.hh:33-47
+FMX_HD float normalizer(uint32_t p, uint32_t s, float ins, float del, float rep) {
+  if (ins == 0.f && del == 0.f && rep == 0.f) return 1.f;
+  if (ins + del <= rep) return (ins * (float)p) + (del * (float)s);
+  if (p <= s) return ((rep - del) * (float)p) + (del * (float)s);
+  return ((rep - ins) * (float)s) + (ins * (float)p);
+}
+
+// NGramMatches::theoretical_rejection — src/ngram_matches.cc:31-39
+FMX_HD bool reject_len(uint32_t p, uint32_t s, const Params& prm) {
+  float d = (float)p - (float)s;
+  d = d < 0.f ? -d : d;
+  const float rc = (p >= s) ? prm.ins : prm.del;
+  const float bound = 1.f - ((rc * d) / normalizer(p, s, prm.ins, prm.del, prm.rep));
+  return ((double)bound + 0.000005) < (double)prm.fuzzy;
+}
+
+// NGramMatches::theoretical_rejection_cover — src/ngram_matches.cc:41-59
+FMX_HD bool reject_cover(uint32_t p, uint32_t s, uint32_t cover, const Params& prm) {
+  float bound;
+  const float norm = normalizer(p, s, prm.ins, prm.del, prm.rep);
+  if (prm.ins + prm.del < prm.rep) {
+    bound = 1.f - (((prm.ins * ((float)s - (float)cover)) + (prm.del * ((float)p - (float)cover))) / norm);
+  } else {
+    const float rc = (p > s) ? prm.ins : prm.del;
+    const float mn = (p > s) ? (float)s : (float)p;
+    const float mx = (p > s) ? (float)p : (float)s;
+    bound = 1.f - (((prm.rep * (mn - (float)cover)) + (rc * (mx - mn))) / norm);
+  }
+  return ((double)bound + 0.000005) < (double)prm.fuzzy;
+}
+
+// score quantisation — src/fuzzy_match.cc:598,651
+FMX_HD float score_from_cost(float cost) {
+  const float t = 10000.f - (cost * 100.f);
+  return (float)((double)(int)t / 10000.0);
+}
+
+// SuffixArray::start_by (src/suffix_array.cc:263-273) for a suffix whose first token is already
+// known to equal ngram[0] (it lives in that token's _quickVocabAccess bucket): compare tokens
+// [from, m).  -1: suffix sorts before every suffix starting with the n-gram (smaller token, or
+// the sentence ends first); 0: starts with it; +1: sorts after.
+FMX_HD int start_by_from(const uint32_t* __restrict__ tok, SufRec r, const uint32_t* __restrict__ ngram,
+                         uint32_t from, uint32_t m) {
+  for (uint32_t k = from; k < m; k++) {
+    if (k >= r.rem) return -1;
+    const uint32_t a = tok[r.off + k], b = ngram[k];
+    if (a < b) return -1;
+    if (a > b) return 1;
+  }
+  return 0;
+}
+
+// Half-open range of suffixes starting with ngram[0..m) — the value SuffixArray::equal_range
+// (src/suffix_array.cc:105-212) converges to, computed as a plain lower bound followed by a
+// galloping upper bound (ranges of long n-grams are short).  m >= 1.
+FMX_HD void mgram_range(const SufRec* __restrict__ suf, const uint32_t* __restrict__ tok,
+                        const uint32_t* __restrict__ qva, uint32_t n_qva,
+                        const uint32_t* __restrict__ ngram, uint32_t m, uint32_t& out_lo, uint32_t& out_hi) {
+  out_lo = out_hi = 0;
+  const uint32_t w0 = ngram[0];
+  if (w0 + 1 >= n_qva) return;
+  uint32_t lo = qva[w0], hi = qva[w0 + 1];
+  if (m == 1 || lo >= hi) { out_lo = lo; out_hi = hi; return; }
+  // lower bound: first i with start_by >= 0
+  uint32_t a = lo, b = hi;
+  while (a < b) {
+    const uint32_t mid = a + ((b - a) >> 1);
+    if (start_by_from(tok, suf[mid], ngram, 1, m) < 0) a = mid + 1; else b = mid;
+  }
+  const uint32_t first = a;
+  if (first >= hi || start_by_from(tok, suf[first], ngram, 1, m) != 0) { out_lo = out_hi = first; return; }
+  // upper bound: gallop from first, then bisect; invariant start_by(a) == 0, start_by(b) > 0 or b == hi
+  uint32_t step = 1;
+  a = first;
+  b = hi;
+  while (a + step < hi) {
+    if (start_by_from(tok, suf[a + step], ngram, 1, m) == 0) { a += step; step <<= 1; }
+    else { b = a + step; break; }
+  }
+  while (b - a > 1) {
+    const uint32_t mid = a + ((b - a) >> 1);
+    if (start_by_from(tok, suf[mid], ngram, 1, m) == 0) a = mid; else b = mid;
+  }
+  out_lo = first;
+  out_hi = b;
+}
+
+// Longest common prefix of a suffix (already known to share `known` tokens) with pat[0..maxlen).
+// This is the match_length the reference's narrowing loop ends up registering for the suffix
+// (src/fuzzy_match.cc:500-550).
+FMX_HD uint32_t lcp_extend(const uint32_t* __restrict__ tok, SufRec r, const uint32_t* __restrict__ pat,
+                           uint32_t known, uint32_t maxlen) {
+  uint32_t lim = r.rem < maxlen ? r.rem : maxlen;
+  uint32_t k = known;
+  while (k < lim && tok[r.off + k] == pat[k]) k++;
+  return k;
+}
+
+// A hit of start `it` on a suffix is dominated when the preceding tokens also agree: start it-1
+// then reaches the same sentence with a strictly longer match and the same length filter, so
+// dropping the hit cannot change max-per-sentence (NGramMatches keeps only the max,
+// src/ngram_matches.cc:79-81).  r.slen - r.rem = tokens before the suffix in its sentence.
+FMX_HD bool dominated_hit(const uint32_t* __restrict__ tok, SufRec r, const uint32_t* __restrict__ pat_at_it,
+                          uint32_t it) {
+  return it > 0 && r.rem < r.slen && tok[r.off - 1] == pat_at_it[-1];
+}
+
+// PatternCoverage::count_covered_words (src/pattern_coverage.cc:15-28): the sum of counts of the
+// distinct pattern words present in the sentence == number of pattern positions whose word
+// occurs in the sentence.
+FMX_HD uint32_t cover_count(const uint32_t* __restrict__ sent, uint32_t s_len, const uint32_t* __restrict__ pat,
+                            uint32_t p) {
+  uint32_t c = 0;
+  for (uint32_t j = 0; j < p; j++) {
+    const uint32_t w = pat[j];
+    bool found = false;
+    for (uint32_t k = 0; k < s_len && !found; k++) found = sent[k] == w;
+    c += found ? 1u : 0u;
+  }
+  return c;
+}
+
+FMX_HD float fmin2(float a, float b) { return b < a ? b : a; }  // std::min(a, b)
+
+// Optional per-candidate side inputs of the full _edit_distance (src/edit_distance.cc:5-77).
+struct DpSide {
+  const uint32_t* s_real;   // sentence real-token ids (bit31 = first byte in "LUMC" or empty), per token slot
+  const uint32_t* p_real;   // pattern real-token ids, per pattern position
+  const uint32_t* s_itok;   // sentence itok ids, slot i in [0, n1]
+  const uint32_t* p_itok;   // pattern itok ids, slot j in [0, n2]
+  const uint16_t* itok_dist;  // (n_itok x n_itok) byte-Levenshtein table, id 0 = no itok
+  uint32_t        n_itok;
+  const float*    p_idf;    // idf_penalty[j] per pattern position (nullptr when idf is off)
+  float           idf_weight;
+};
+
+// Float edit distance between an indexed sentence (rows, n1) and the pattern (columns, n2).
+// Returns `final` = arr[n1][n2]; M = max(max_i rowmin_i, final) is what the reference's
+// row-min early exit compares against its bound (src/edit_distance.cc:73-74,
+// src/fuzzy_match.cc:595): the candidate is rejected iff M > bound.  If a row minimum exceeds
+// `stop_above` the walk stops early and M (> stop_above) is all that is meaningful.
+// Row is any accessor with float& operator[](uint32_t j), j in [0, n2].
+template <bool FULL, class Row>
+FMX_HD float edit_distance(const uint32_t* __restrict__ s1, uint32_t n1, const uint32_t* __restrict__ s2,
+                           uint32_t n2, float ins, float del, float rep, float dw, const DpSide& side,
+                           float stop_above, Row row, float& M_out) {
+  const float del_dw = del * dw, ins_dw = ins * dw, rep_dw = rep * dw;
+  const bool  idf = FULL && side.p_idf != nullptr && side.idf_weight != 0.f;
+  const bool  itk = FULL && side.itok_dist != nullptr;
+  auto T = [&](uint32_t i, uint32_t j) -> float {
+    if (!itk) return 0.f;
+    const uint32_t a = side.s_itok ? side.s_itok[i] : 0u, b = side.p_itok ? side.p_itok[j] : 0u;
+    return (float)side.itok_dist[a * side.n_itok + b];
+  };
+  // row 0
+  float v = FULL ? T(n1, n2) : 0.f;  // arr[0][0]: trailing penalty tokens
+  row[0] = v;
+  for (uint32_t j = 1; j <= n2; j++) {
+    v = (v + ins_dw);
+    if (FULL) {
+      if (itk) v = v + (float)side.itok_dist[side.p_itok ? side.p_itok[j] : 0u];  // sn2[j]
+      if (idf) v = v + (side.p_idf[j - 1] * side.idf_weight);
+    }
+    row[j] = v;
+  }
+  float M = 0.f;
+  float final_v = row[n2];
+  for (uint32_t i = 1; i <= n1; i++) {
+    const uint32_t w = s1[i - 1];
+    float diag = row[0];
+    float left = diag + del_dw;
+    if (FULL && itk) left = left + (float)side.itok_dist[(side.s_itok ? side.s_itok[i] : 0u) * side.n_itok];  // sn1[i]
+    row[0] = left;
+    float mn = FLT_MAX;
+    for (uint32_t j = 1; j <= n2; j++) {
+      const float up = row[j];
+      float pen = 0.f;
+      if (idf) pen = side.p_idf[j - 1] * side.idf_weight;
+      float diff = 0.f;
+      if (w != s2[j - 1]) {
+        diff = FULL ? (rep_dw + pen) : rep_dw;
+      } else if (FULL && side.s_real != nullptr) {
+        const uint32_t r1 = side.s_real[i - 1], r2 = side.p_real[j - 1];
+        if ((r1 & 0x7fffffffu) != r2) diff = (r1 >> 31) ? (rep * 1.f) : (rep * 2.f);
+      }
+      float a, b, c;
+      if (FULL) {
+        a = (up + del_dw) + T(i - 1, j);
+        b = ((left + ins_dw) + T(i, j - 1)) + pen;
+        c = (diag + diff) + T(i - 1, j - 1);
+      } else {
+        a = up + del_dw;
+        b = left + ins_dw;
+        c = diag + diff;
+      }
+      const float d = fmin2(fmin2(a, b), c);
+      row[j] = d;
+      mn = fmin2(mn, d);
+      diag = up;
+      left = d;
+    }
+    if (mn > M) M = mn;
+    final_v = left;
+    if (mn > stop_above) { M_out = M; return mn; }
+  }
+  if (n1 == 0) final_v = row[n2];
+  if (final_v > M) M = final_v;
+  M_out = M;
+  return final_v;
+}
+
+// lowest_costs (std::priority_queue<float>, src/fuzzy_match.cc:567-602) as an ascending array:
+// top() = last element.
+struct CostHeap {
+  float*   v;
+  uint32_t n;
+  FMX_HD float top() const { return v[n - 1]; }
+  FMX_HD void  push(float c) {
+    uint32_t i = n++;
+    while (i > 0 && v[i - 1] > c) { v[i] = v[i - 1]; i--; }
+    v[i] = c;
+  }
+  FMX_HD void pop() { if (n) n--; }
+};
+
+// One turn of the candidate loop (src/fuzzy_match.cc:587-610) given the candidate's DP outcome.
+// Returns true when the candidate becomes a Match (score >= fuzzy); score_out is its score.
+FMX_HD bool replay_candidate(CostHeap& heap, const Params& prm, uint32_t p, uint32_t s_len, float final_cost,
+                             float M, float& score_out) {
+  const float ub = heap.top();
+  if ((prm.no_perfect && final_cost == 0.f && s_len == p) || M > ub) return false;
+  const float score = score_from_cost(final_cost);
+  heap.push(final_cost);
+  if (score < prm.fuzzy || (prm.cbuf > 0 && heap.n > (uint32_t)prm.cbuf)) heap.pop();
+  score_out = score;
+  return score >= prm.fuzzy;
+}
+
+// order-preserving float -> uint32 (ascending)
+FMX_HD uint32_t float_key(float f) {
+  union { float f; uint32_t u; } x;
+  x.f = f;
+  return (x.u & 0x80000000u) ? ~x.u : (x.u | 0x80000000u);
+}
+
+}  // namespace fmx

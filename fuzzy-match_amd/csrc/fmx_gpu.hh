@@ -1,0 +1,76 @@
+// fmx_gpu.hh — host-visible interface of the device side (implemented in fmx_gpu.hip).
+#pragma once
+#include <stdint.h>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "fmx_host.hh"
+
+namespace fmx {
+
+struct GpuError : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+
+constexpr int kNumStages = 7;
+const char* stage_name(int s);
+
+struct Stats {
+  double   ms_total = 0, ms_h2d = 0, ms_d2h = 0;
+  double   ms_kernel[16] = {0};
+  uint64_t launches[16] = {0};
+  uint64_t n_hits = 0, n_kept = 0, n_candidates = 0, n_dp = 0, n_retries = 0;
+};
+
+struct Rec;  // == fmx_match, defined in fmx_kernels.hip.hh
+
+struct HostBatchView {
+  uint64_t        nq = 0;
+  const uint32_t* q_off = nullptr;
+  const uint32_t* q_tok = nullptr;
+  const uint32_t* q_real = nullptr;
+  const uint32_t* q_itok = nullptr;
+};
+
+struct DeviceBatchView {
+  uint64_t        nq = 0;
+  const uint32_t* q_off = nullptr;
+  const uint32_t* q_tok = nullptr;
+  const uint32_t* q_real = nullptr;
+  const uint32_t* q_itok = nullptr;
+  uint32_t        p_max = 0;  // longest pattern of the batch (0 = unknown)
+};
+
+int  gpu_device_count();
+void gpu_suffix_sort(HostIndex& h, int device);
+
+class DeviceIndex {
+ public:
+  struct Impl;
+  DeviceIndex();
+  ~DeviceIndex();
+  DeviceIndex(const DeviceIndex&) = delete;
+  DeviceIndex& operator=(const DeviceIndex&) = delete;
+
+  void     upload(const HostIndex& h, int device);
+  int      device() const;
+  uint64_t bytes() const;
+  void     set_sub_queries(uint32_t n);
+  void     set_initial_segment(uint64_t n);
+
+  // every pointer in HBM of device(); sub_tok_bounds = q_off at each sub-batch boundary (+ q_off[nq])
+  void match_device(const HostIndex& h, const Params& prm, const DeviceBatchView& b, Rec* d_out,
+                    uint32_t* d_out_count, uint32_t* d_out_total, uint32_t cap, void* stream,
+                    const std::vector<uint32_t>& sub_tok_bounds, Stats* st);
+  // host buffers: H2D, match_device, D2H
+  void match_host(const HostIndex& h, const Params& prm, const HostBatchView& b, Rec* out, uint32_t* out_count,
+                  uint32_t* out_total, uint32_t cap, Stats* st);
+  // q_off values at the sub-batch boundaries of a device-resident batch, and its longest pattern
+  std::vector<uint32_t> sub_bounds_from_device(const uint32_t* d_q_off, uint64_t nq, uint32_t* p_max, void* stream);
+
+ private:
+  Impl* impl_;
+};
+
+}  // namespace fmx

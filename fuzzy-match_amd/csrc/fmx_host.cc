@@ -1,0 +1,629 @@
+// fmx_host.cc — host-side index: vocabulary, suffix-array construction, derived SoA arrays and
+// the .fmi (Boost binary archive) reader/writer, all without Boost.
+#include "fmx_host.hh"
+
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <fstream>
+#include <stdexcept>
+#include <thread>
+
+namespace fmx {
+
+// ------------------------------------------------------------------------------------------
+// Sentence / vocabulary
+// ------------------------------------------------------------------------------------------
+
+// Sentence::operator Tokens — src/sentence.cc:7-22,36-38 (a trailing empty part is dropped)
+std::vector<std::string> RealTok::split() const {
+  std::vector<std::string> parts;
+  std::string accu;
+  for (const char c : tokstring) {
+    if (c == '\t') { parts.emplace_back(std::move(accu)); accu.clear(); }
+    else accu += c;
+  }
+  if (!accu.empty()) parts.emplace_back(std::move(accu));
+  return parts;
+}
+
+// VocabIndexer::VocabIndexer — src/vocab_indexer.cc:10-20: id 0 = "" (sentence separator), id 1 = ｟unk｠
+HostIndex::HostIndex() {
+  add_word(std::string());
+  add_word("\xef\xbd\x9funk\xef\xbd\xa0");
+}
+
+uint32_t HostIndex::add_word(const std::string& w) {
+  auto it = form2index.find(w);
+  if (it != form2index.end()) return it->second;
+  const uint32_t id = (uint32_t)forms.size();
+  form2index.emplace(w, id);
+  forms.push_back(w);
+  sfreq.push_back(0);
+  vocab_size = (uint32_t)forms.size();
+  return id;
+}
+
+uint32_t HostIndex::get_index(const std::string& w) const {
+  auto it = form2index.find(w);
+  return it != form2index.end() ? it->second : 1u;  // VOCAB_UNK
+}
+
+static void push_sentence(HostIndex& ix, const uint32_t* toks, uint32_t n) {
+  // SuffixArray::add_sentence — src/suffix_array.cc:9-27
+  const uint32_t sidx = (uint32_t)ix.sent_pos.size();
+  ix.sent_pos.push_back((uint32_t)ix.buf.size());
+  ix.buf.push_back(n);
+  for (uint32_t i = 0; i < n; i++) {
+    ix.buf.push_back(toks[i]);
+    ix.suf_sid.push_back(sidx);
+    ix.suf_pos.push_back((uint16_t)(i + 1));
+  }
+  ix.buf.push_back(0);
+  ix.sorted = false;
+}
+
+int64_t HostIndex::add_tm(const std::string& id, const RealTok& real_tokens, const std::vector<std::string>& norm) {
+  // SuffixArrayIndex::add_tm — src/suffix_array_index.cc:16
+  if (real_tokens.tokstring.empty() || norm.size() > max_tokens || norm.size() > 65535) return -1;
+  // VocabIndexer::addWords — src/vocab_indexer.cc:73-90: sfreq bumped once per distinct word
+  std::vector<uint32_t> wids;
+  wids.reserve(norm.size());
+  for (const auto& w : norm) wids.push_back(add_word(w));
+  std::vector<uint32_t> distinct(wids);
+  std::sort(distinct.begin(), distinct.end());
+  distinct.erase(std::unique(distinct.begin(), distinct.end()), distinct.end());
+  for (uint32_t w : distinct) sfreq[w]++;
+  push_sentence(*this, wids.data(), (uint32_t)wids.size());
+  ids.push_back(id);
+  real.push_back(real_tokens);
+  return (int64_t)sent_pos.size() - 1;
+}
+
+void HostIndex::add_ids_bulk(const uint32_t* off, const uint32_t* toks, uint64_t n_sent, uint32_t vocab_size_) {
+  if (!ids.empty() || !real.empty())
+    throw std::runtime_error("add_ids_bulk: index already holds string-level sentences");
+  if (vocab_size_ > vocab_size) vocab_size = vocab_size_;
+  sfreq.resize(vocab_size, 0);
+  const uint64_t total = off[n_sent] - off[0];
+  buf.reserve(buf.size() + total + 2 * n_sent);
+  suf_sid.reserve(suf_sid.size() + total);
+  suf_pos.reserve(suf_pos.size() + total);
+  sent_pos.reserve(sent_pos.size() + n_sent);
+  std::vector<uint32_t> distinct;
+  for (uint64_t s = 0; s < n_sent; s++) {
+    const uint32_t n = off[s + 1] - off[s];
+    if (n > max_tokens || n > 65535) continue;
+    const uint32_t* t = toks + off[s];
+    distinct.assign(t, t + n);
+    std::sort(distinct.begin(), distinct.end());
+    distinct.erase(std::unique(distinct.begin(), distinct.end()), distinct.end());
+    for (uint32_t w : distinct) {
+      if (w >= vocab_size) { vocab_size = w + 1; sfreq.resize(vocab_size, 0); }
+      sfreq[w]++;
+    }
+    push_sentence(*this, t, n);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// suffix sort (CPU)
+// ------------------------------------------------------------------------------------------
+
+namespace {
+
+struct SortKey {
+  uint64_t prefix;  // tok0 << 32 | tok1 (0 when the suffix has one token): decides most compares
+  uint64_t key;     // sid << 16 | pos
+};
+
+// SuffixArray::comp — src/suffix_array.cc:235-251 (tokens, then shorter first, then sentence id)
+struct SuffixLess {
+  const uint32_t* buf;
+  const uint32_t* sent_pos;
+  bool operator()(const SortKey& a, const SortKey& b) const {
+    if (a.prefix != b.prefix) return a.prefix < b.prefix;
+    const uint32_t sa = (uint32_t)(a.key >> 16), sb = (uint32_t)(b.key >> 16);
+    const uint32_t pa = (uint32_t)(a.key & 0xffff), pb = (uint32_t)(b.key & 0xffff);
+    const uint32_t* ba = buf + sent_pos[sa];
+    const uint32_t* bb = buf + sent_pos[sb];
+    const uint32_t la = ba[0] - (pa - 1), lb = bb[0] - (pb - 1);
+    const uint32_t* ta = ba + pa;
+    const uint32_t* tb = bb + pb;
+    const uint32_t mn = la < lb ? la : lb;
+    for (uint32_t i = 0; i < mn; i++) {
+      if (ta[i] != tb[i]) return ta[i] < tb[i];
+    }
+    if (la != lb) return la < lb;
+    return sa < sb;
+  }
+};
+
+template <class T, class Less>
+void parallel_sort(T* a, uint64_t n, Less less, int nthreads) {
+  if (nthreads <= 1 || n < (1u << 15)) { std::sort(a, a + n, less); return; }
+  int parts = 1;
+  while (parts < nthreads) parts <<= 1;
+  std::vector<uint64_t> bound(parts + 1);
+  for (int i = 0; i <= parts; i++) bound[i] = n * (uint64_t)i / (uint64_t)parts;
+  {
+    std::atomic<int> next{0};
+    std::vector<std::thread> th;
+    auto work = [&]() {
+      for (;;) {
+        int k = next.fetch_add(1);
+        if (k >= parts) break;
+        std::sort(a + bound[k], a + bound[k + 1], less);
+      }
+    };
+    for (int t = 1; t < nthreads; t++) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
+  }
+  for (int width = 1; width < parts; width <<= 1) {
+    std::atomic<int> next{0};
+    const int merges = parts / (2 * width);
+    std::vector<std::thread> th;
+    auto work = [&]() {
+      for (;;) {
+        int k = next.fetch_add(1);
+        if (k >= merges) break;
+        const int lo = k * 2 * width;
+        std::inplace_merge(a + bound[lo], a + bound[lo + width], a + bound[lo + 2 * width], less);
+      }
+    };
+    const int nt = std::min(nthreads, merges);
+    for (int t = 1; t < nt; t++) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
+  }
+}
+
+}  // namespace
+
+void HostIndex::sort(int nthreads) {
+  if (sorted) return;
+  const uint64_t n = suf_sid.size();
+  std::vector<SortKey> keys(n);
+  for (uint64_t i = 0; i < n; i++) {
+    const uint32_t  sid = suf_sid[i], pos = suf_pos[i];
+    const uint32_t* b = buf.data() + sent_pos[sid];
+    const uint32_t  rem = b[0] - (pos - 1);
+    keys[i].prefix = ((uint64_t)b[pos] << 32) | (rem > 1 ? b[pos + 1] : 0u);
+    keys[i].key = ((uint64_t)sid << 16) | pos;
+  }
+  parallel_sort(keys.data(), n, SuffixLess{buf.data(), sent_pos.data()}, nthreads);
+  std::vector<uint64_t> flat(n);
+  for (uint64_t i = 0; i < n; i++) flat[i] = keys[i].key;
+  keys.clear();
+  keys.shrink_to_fit();
+  adopt_sorted(flat.data(), n);
+}
+
+void HostIndex::adopt_sorted(const uint64_t* keys, uint64_t n) {
+  if (n != suf_sid.size()) throw std::runtime_error("adopt_sorted: size mismatch");
+  // _quickVocabAccess — src/suffix_array.cc:76-98: first suffix per first-word id, [vocab_size] = total
+  for (uint64_t i = 0; i < n; i++) {
+    const uint32_t w = buf[sent_pos[(uint32_t)(keys[i] >> 16)] + (uint32_t)(keys[i] & 0xffff)];
+    if (w >= vocab_size) { vocab_size = w + 1; sfreq.resize(vocab_size, 0); }
+  }
+  qva.assign((size_t)vocab_size + 1, 0);
+  for (uint64_t i = 0; i < n; i++) {
+    const uint32_t sid = (uint32_t)(keys[i] >> 16), pos = (uint32_t)(keys[i] & 0xffff);
+    suf_sid[i] = sid;
+    suf_pos[i] = (uint16_t)pos;
+    qva[buf[sent_pos[sid] + pos] + 1]++;
+  }
+  for (uint32_t w = 0; w < vocab_size; w++) qva[w + 1] += qva[w];
+  sorted = true;
+}
+
+void HostIndex::bucket_keys(std::vector<uint64_t>& keys, std::vector<uint64_t>& bucket_off) const {
+  const uint64_t n = suf_sid.size();
+  keys.resize(n);
+  for (uint64_t i = 0; i < n; i++) keys[i] = ((uint64_t)suf_sid[i] << 16) | suf_pos[i];
+  bucket_off.clear();
+}
+
+// ------------------------------------------------------------------------------------------
+// derived arrays
+// ------------------------------------------------------------------------------------------
+
+int edit_distance_char(const char* s1, int n1, const char* s2, int n2) {
+  if (n1 == 0) return n2;
+  if (n2 == 0) return n1;
+  std::vector<int> prev(n2 + 1), curr(n2 + 1);
+  for (int j = 0; j <= n2; j++) prev[j] = j;
+  for (int i = 1; i <= n1; i++) {
+    curr[0] = i;
+    for (int j = 1; j <= n2; j++)
+      curr[j] = std::min({prev[j] + 1, curr[j - 1] + 1, prev[j - 1] + (s1[i - 1] == s2[j - 1] ? 0 : 1)});
+    std::swap(prev, curr);
+  }
+  return prev[n2];
+}
+
+uint32_t HostIndex::intern_itok(const std::string& s) {
+  if (itok_strings.empty()) {
+    itok_strings.emplace_back();
+    itok_intern.emplace(std::string(), 0u);
+    itok_dist.assign(1, 0);
+  }
+  auto it = itok_intern.find(s);
+  if (it != itok_intern.end()) return it->second;
+  const uint32_t id = (uint32_t)itok_strings.size();
+  if (id >= 4096) throw std::runtime_error("too many distinct penalty-token strings (limit 4096)");
+  itok_strings.push_back(s);
+  itok_intern.emplace(s, id);
+  const uint32_t n = id + 1;
+  std::vector<uint16_t> d((size_t)n * n);
+  for (uint32_t a = 0; a < n; a++)
+    for (uint32_t b = 0; b < n; b++) {
+      if (a < n - 1 && b < n - 1) d[(size_t)a * n + b] = itok_dist[(size_t)a * (n - 1) + b];
+      else {
+        const int v = edit_distance_char(itok_strings[a].data(), (int)itok_strings[a].size(),
+                                         itok_strings[b].data(), (int)itok_strings[b].size());
+        d[(size_t)a * n + b] = (uint16_t)std::min(v, 65535);
+      }
+    }
+  itok_dist.swap(d);
+  itok_version++;
+  return id;
+}
+
+uint32_t HostIndex::lookup_real(const std::string& s) const {
+  auto it = real_intern.find(s);
+  return it != real_intern.end() ? it->second : 0x7ffffffeu;
+}
+
+void HostIndex::derive() {
+  if (!sorted) throw std::runtime_error("derive: index is not sorted");
+  const uint64_t n = suf_sid.size();
+  suf_rec.resize(n);
+  for (uint64_t i = 0; i < n; i++) {
+    const uint32_t sp = sent_pos[suf_sid[i]];
+    const uint32_t slen = buf[sp];
+    SufRec r;
+    r.off = sp + suf_pos[i];
+    r.slen = (uint16_t)slen;
+    r.rem = (uint16_t)(slen - (suf_pos[i] - 1u));
+    suf_rec[i] = r;
+  }
+  // compute_idf_penalty / compute_max_idf_penalty — src/fuzzy_match.cc:367-390 (glibc logf / log)
+  const unsigned N = num_sentences();
+  idf.assign(vocab_size, 0.f);
+  for (uint32_t w = 0; w < vocab_size; w++) {
+    const uint32_t f = w < sfreq.size() ? sfreq[w] : 0;
+    idf[w] = logf((float)N / (float)f);
+  }
+  if (vocab_size > 1) idf[1] = 0.f;  // VOCAB_UNK -> unknown_vocab_word_penalty = 0
+  idf_max = (float)log((double)N);
+
+  // real tokens / penalty tokens
+  real_differs = false;
+  real_ids.clear();
+  itok_ids.clear();
+  real_intern.clear();
+  if (!real.empty()) {
+    for (uint32_t s = 0; s < real.size() && !real_differs; s++) {
+      if (!real[s].itoks.empty()) { real_differs = true; break; }
+      const auto parts = real[s].split();
+      const uint32_t sp = sent_pos[s], len = buf[sp];
+      if (parts.size() != len) { real_differs = true; break; }
+      for (uint32_t i = 0; i < len; i++) {
+        const uint32_t w = buf[sp + 1 + i];
+        if (w >= forms.size() || forms[w] != parts[i]) { real_differs = true; break; }
+      }
+    }
+  }
+  if (real_differs) {
+    real_ids.assign(buf.size(), 0);
+    itok_ids.assign(buf.size(), 0);
+    intern_itok(std::string());
+    for (uint32_t s = 0; s < real.size(); s++) {
+      const auto parts = real[s].split();
+      const uint32_t sp = sent_pos[s], len = buf[sp];
+      for (uint32_t i = 0; i < len; i++) {
+        // out-of-range real tokens (trailing empty token dropped by the split) read as ""
+        const std::string tok = i < parts.size() ? parts[i] : std::string();
+        auto it = real_intern.find(tok);
+        uint32_t id;
+        if (it == real_intern.end()) { id = (uint32_t)real_intern.size(); real_intern.emplace(tok, id); }
+        else id = it->second;
+        // strchr("LUMC", tok[0]) — src/edit_distance.cc:57 ('\0' of an empty token matches too)
+        const char c0 = tok.empty() ? '\0' : tok[0];
+        const bool case_only = c0 == '\0' || c0 == 'L' || c0 == 'U' || c0 == 'M' || c0 == 'C';
+        real_ids[sp + 1 + i] = id | (case_only ? 0x80000000u : 0u);
+      }
+      for (const auto& kv : real[s].itoks) {
+        if (kv.first > len) continue;
+        itok_ids[sp + kv.first] = intern_itok(kv.second);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// .fmi reader / writer — layout decoded in SURVEY §8(b); class-info records {u8 tracking; u32 version}
+// appear once per C++ class at first use.
+// ------------------------------------------------------------------------------------------
+
+namespace {
+
+class Reader {
+ public:
+  explicit Reader(std::vector<char>&& d) : d_(std::move(d)) {}
+  template <class T> T get() {
+    T v;
+    need(sizeof(T));
+    memcpy(&v, d_.data() + pos_, sizeof(T));
+    pos_ += sizeof(T);
+    return v;
+  }
+  void raw(void* dst, size_t n) { need(n); memcpy(dst, d_.data() + pos_, n); pos_ += n; }
+  std::string str() {
+    const uint64_t n = get<uint64_t>();
+    need(n);
+    std::string s(d_.data() + pos_, (size_t)n);
+    pos_ += n;
+    return s;
+  }
+  uint32_t class_info() { get<uint8_t>(); return get<uint32_t>(); }  // tracking, version
+  size_t pos() const { return pos_; }
+  size_t size() const { return d_.size(); }
+ private:
+  void need(uint64_t n) const {
+    if (n > d_.size() - pos_) throw std::runtime_error("FMI file truncated or corrupt");
+  }
+  std::vector<char> d_;
+  size_t pos_ = 0;
+};
+
+class Writer {
+ public:
+  template <class T> void put(T v) { const char* p = (const char*)&v; d_.insert(d_.end(), p, p + sizeof(T)); }
+  void raw(const void* p, size_t n) { d_.insert(d_.end(), (const char*)p, (const char*)p + n); }
+  void str(const std::string& s) { put<uint64_t>(s.size()); raw(s.data(), s.size()); }
+  void class_info(uint32_t version) { put<uint8_t>(0); put<uint32_t>(version); }
+  std::vector<char> d_;
+};
+
+template <class T> void read_pod_vector(Reader& r, std::vector<T>& v) {
+  const uint64_t n = r.get<uint64_t>();
+  if (n > r.size() / sizeof(T) + 1) throw std::runtime_error("FMI file corrupt (vector size)");
+  v.resize(n);
+  if (n) r.raw(v.data(), n * sizeof(T));
+}
+
+template <class T> void write_pod_vector(Writer& w, const std::vector<T>& v) {
+  w.put<uint64_t>(v.size());
+  if (!v.empty()) w.raw(v.data(), v.size() * sizeof(T));
+}
+
+}  // namespace
+
+void HostIndex::load_fmi(const std::string& path) {
+  std::ifstream ifs(path, std::ios::binary);
+  if (!ifs) throw std::runtime_error("cannot open FMI file: " + path);
+  ifs.seekg(0, std::ios::end);
+  const std::streamoff fsz = ifs.tellg();
+  ifs.seekg(0);
+  std::vector<char> data((size_t)fsz);
+  if (fsz) ifs.read(data.data(), fsz);
+  if (!ifs) throw std::runtime_error("cannot read FMI file: " + path);
+  Reader r(std::move(data));
+
+  char magic[4];
+  r.raw(magic, 4);
+  // the reference's magic check (fuzzy_matcher_binarization.cc:41) never fires; a wrong magic here is
+  // reported like any other unreadable file
+  if (memcmp(magic, "FMI", 3) != 0) throw std::runtime_error("invalid FMI file format: " + path);
+  if (r.str() != "serialization::archive") throw std::runtime_error("FMI: not a Boost binary archive");
+  const uint16_t lvt = r.get<uint16_t>();
+  if (lvt < 10) throw std::runtime_error("FMI: unsupported Boost archive library version");
+  uint8_t sizes[4];
+  r.raw(sizes, 4);
+  if (sizes[0] != 4 || sizes[1] != 8 || sizes[2] != 4 || sizes[3] != 8 || r.get<uint32_t>() != 1)
+    throw std::runtime_error("FMI: archive written on an incompatible platform");
+
+  r.class_info();                      // FuzzyMatch
+  pt = r.get<int32_t>();
+  r.get<int16_t>();                    // class_id of SuffixArrayIndex (pointer)
+  const uint32_t sai_version = r.class_info();
+  r.get<uint32_t>();                   // object_id
+
+  // VocabIndexer: forms, sfreq, form2index — vocab_indexer.hh:45-52
+  r.class_info();                      // VocabIndexer
+  r.class_info();                      // std::vector<std::string>
+  forms.clear(); sfreq.clear(); form2index.clear();
+  {
+    const uint64_t n = r.get<uint64_t>();
+    r.get<uint32_t>();                 // item_version
+    forms.reserve(n);
+    for (uint64_t i = 0; i < n; i++) forms.push_back(r.str());
+  }
+  read_pod_vector(r, sfreq);
+  r.class_info();                      // std::unordered_map<std::string, unsigned>
+  bool pair_su_seen = false;
+  {
+    const uint64_t n = r.get<uint64_t>();
+    r.get<uint64_t>();                 // bucket_count
+    r.get<uint32_t>();                 // item_version
+    form2index.reserve(n);
+    for (uint64_t i = 0; i < n; i++) {
+      if (!pair_su_seen) { r.class_info(); pair_su_seen = true; }
+      std::string k = r.str();
+      const uint32_t v = r.get<uint32_t>();
+      form2index.emplace(std::move(k), v);
+    }
+  }
+  vocab_size = (uint32_t)forms.size();
+  sfreq.resize(vocab_size, 0);
+
+  // SuffixArray — suffix_array.hxx:55-91
+  const uint32_t sa_version = r.class_info();
+  sorted = r.get<uint8_t>() != 0;
+  suf_sid.clear(); suf_pos.clear();
+  if (sa_version == 1) {
+    r.class_info();                    // std::vector<SuffixView>
+    const uint64_t n = r.get<uint64_t>();
+    r.get<uint32_t>();                 // item_version
+    if (n > r.size()) throw std::runtime_error("FMI file corrupt (suffix count)");
+    suf_sid.resize(n); suf_pos.resize(n);
+    if (n) r.class_info();             // SuffixView
+    for (uint64_t i = 0; i < n; i++) { suf_sid[i] = r.get<uint32_t>(); suf_pos[i] = r.get<uint16_t>(); }
+  } else if (sa_version == 0) {
+    r.class_info();                    // std::vector<std::pair<unsigned, unsigned short>>
+    const uint64_t n = r.get<uint64_t>();
+    if (n > r.size()) throw std::runtime_error("FMI file corrupt (suffix count)");
+    suf_sid.resize(n); suf_pos.resize(n);
+    for (uint64_t i = 0; i < n; i++) {
+      suf_sid[i] = r.get<uint32_t>();
+      suf_pos[i] = r.get<uint16_t>();
+      r.get<uint16_t>();               // struct padding
+    }
+  } else
+    throw std::invalid_argument("Unsupported FMI format");
+  read_pod_vector(r, buf);
+  read_pod_vector(r, sent_pos);
+  read_pod_vector(r, qva);
+
+  // _ids — std::vector<std::string> (class info already emitted)
+  ids.clear();
+  {
+    const uint64_t n = r.get<uint64_t>();
+    r.get<uint32_t>();
+    ids.reserve(n);
+    for (uint64_t i = 0; i < n; i++) ids.push_back(r.str());
+  }
+  // _real_tokens — std::vector<Sentence>, sentence.hxx:23-30
+  real.clear();
+  {
+    r.class_info();                    // std::vector<Sentence>
+    const uint64_t n = r.get<uint64_t>();
+    r.get<uint32_t>();
+    real.resize(n);
+    bool map_seen = false, pair_seen = false;
+    for (uint64_t i = 0; i < n; i++) {
+      if (i == 0) r.class_info();      // Sentence
+      real[i].tokstring = r.str();
+      if (!map_seen) { r.class_info(); map_seen = true; }  // std::unordered_map<size_t, std::string>
+      const uint64_t m = r.get<uint64_t>();
+      r.get<uint64_t>();               // bucket_count
+      r.get<uint32_t>();               // item_version
+      for (uint64_t k = 0; k < m; k++) {
+        if (!pair_seen) { r.class_info(); pair_seen = true; }
+        const uint64_t idx = r.get<uint64_t>();
+        real[i].itoks.emplace_back(idx, r.str());
+      }
+    }
+  }
+  // suffix_array_index.hxx:55-56 — older files keep the default-constructed value
+  max_tokens = 300;
+  if (sai_version >= 1) max_tokens = r.get<uint64_t>();
+  if (r.pos() != r.size()) throw std::runtime_error("FMI: trailing bytes after archive");
+
+  // sanity: everything the kernels index must be in range
+  const uint64_t nb = buf.size();
+  for (uint32_t sp : sent_pos)
+    if (sp >= nb || (uint64_t)sp + buf[sp] + 2 > nb) throw std::runtime_error("FMI file corrupt (sentence_pos)");
+  for (uint64_t i = 0; i < suf_sid.size(); i++) {
+    if (suf_sid[i] >= sent_pos.size()) throw std::runtime_error("FMI file corrupt (suffix sentence id)");
+    const uint32_t len = buf[sent_pos[suf_sid[i]]];
+    if (suf_pos[i] == 0 || suf_pos[i] > len) throw std::runtime_error("FMI file corrupt (suffix position)");
+  }
+  if (!qva.empty() && qva.back() != suf_sid.size() && !suf_sid.empty() && sorted)
+    throw std::runtime_error("FMI file corrupt (quick vocab access)");
+  if (ids.size() != sent_pos.size() || real.size() != sent_pos.size())
+    throw std::runtime_error("FMI file corrupt (ids / real tokens count)");
+}
+
+void HostIndex::save_fmi(const std::string& path) const {
+  Writer w;
+  w.raw("FMI", 3);
+  w.put<char>('1');                    // FuzzyMatch::version — src/fuzzy_match.cc:23
+  w.str("serialization::archive");
+  w.put<uint16_t>(14);                 // same library version as the reference's fixtures
+  const uint8_t sizes[4] = {4, 8, 4, 8};
+  w.raw(sizes, 4);
+  w.put<uint32_t>(1);
+  w.class_info(1);                     // FuzzyMatch v1
+  w.put<int32_t>(pt);
+  w.put<int16_t>(1);                   // class_id
+  w.put<uint8_t>(1);                   // tracking
+  w.put<uint32_t>(1);                  // SuffixArrayIndex v1
+  w.put<uint32_t>(0);                  // object_id
+  w.class_info(0);                     // VocabIndexer
+  w.class_info(0);                     // vector<string>
+  // id-only corpora have no word forms: synthesise stable placeholder spellings so the file is loadable
+  std::vector<std::string> f = forms;
+  if (f.size() < vocab_size) {
+    for (uint32_t k = (uint32_t)f.size(); k < vocab_size; k++) f.push_back("w" + std::to_string(k));
+  }
+  w.put<uint64_t>(f.size());
+  w.put<uint32_t>(0);
+  for (const auto& s : f) w.str(s);
+  std::vector<uint32_t> sf = sfreq;
+  sf.resize(f.size(), 0);
+  write_pod_vector(w, sf);
+  w.class_info(0);                     // unordered_map<string, unsigned>
+  w.put<uint64_t>(f.size());
+  w.put<uint64_t>(f.size() * 2 + 1);
+  w.put<uint32_t>(0);
+  for (uint32_t k = 0; k < f.size(); k++) {
+    if (k == 0) w.class_info(0);       // pair<const string, unsigned>
+    w.str(f[k]);
+    w.put<uint32_t>(k);
+  }
+  w.class_info(1);                     // SuffixArray v1
+  w.put<uint8_t>(sorted ? 1 : 0);
+  w.class_info(0);                     // vector<SuffixView>
+  w.put<uint64_t>(suf_sid.size());
+  w.put<uint32_t>(0);
+  for (uint64_t i = 0; i < suf_sid.size(); i++) {
+    if (i == 0) w.class_info(0);       // SuffixView
+    w.put<uint32_t>(suf_sid[i]);
+    w.put<uint16_t>(suf_pos[i]);
+  }
+  write_pod_vector(w, buf);
+  write_pod_vector(w, sent_pos);
+  write_pod_vector(w, qva);
+  const uint64_t ns = sent_pos.size();
+  w.put<uint64_t>(ns);
+  w.put<uint32_t>(0);
+  for (uint64_t i = 0; i < ns; i++) w.str(i < ids.size() ? ids[i] : std::to_string(i));
+  w.class_info(0);                     // vector<Sentence>
+  w.put<uint64_t>(ns);
+  w.put<uint32_t>(0);
+  bool pair_seen = false;
+  for (uint64_t i = 0; i < ns; i++) {
+    if (i == 0) w.class_info(0);       // Sentence
+    if (i < real.size()) w.str(real[i].tokstring);
+    else {
+      // real tokens = normalised forms (Sentence(const Tokens&), src/sentence.cc:24)
+      std::string ts;
+      const uint32_t sp = sent_pos[i], len = buf[sp];
+      for (uint32_t k = 0; k < len; k++) { if (k) ts += '\t'; ts += f[buf[sp + 1 + k]]; }
+      w.str(ts);
+    }
+    if (i == 0) w.class_info(0);       // unordered_map<size_t, string>
+    const uint64_t m = i < real.size() ? real[i].itoks.size() : 0;
+    w.put<uint64_t>(m);
+    w.put<uint64_t>(m ? m * 2 + 1 : 1);
+    w.put<uint32_t>(0);
+    for (uint64_t k = 0; k < m; k++) {
+      if (!pair_seen) { w.class_info(0); pair_seen = true; }
+      w.put<uint64_t>(real[i].itoks[k].first);
+      w.str(real[i].itoks[k].second);
+    }
+  }
+  w.put<uint64_t>(max_tokens);
+  std::ofstream ofs(path, std::ios::binary);
+  if (!ofs) throw std::runtime_error("cannot open FMI file for writing: " + path);
+  ofs.write(w.d_.data(), (std::streamsize)w.d_.size());
+  if (!ofs) throw std::runtime_error("cannot write FMI file: " + path);
+}
+
+}  // namespace fmx

@@ -1,0 +1,95 @@
+// fmx_host.hh — host-side index model: what SuffixArrayIndex + VocabIndexer + SuffixArray hold in
+// the reference (include/fuzzy/suffix_array_index.hh:50-54), plus the derived SoA arrays that
+// are uploaded to HBM.  Pure C++17, no HIP.
+#pragma once
+#include <stdint.h>
+#include <string>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+#include "fmx_core.hh"
+
+namespace fmx {
+
+// fuzzy::Sentence (include/fuzzy/sentence.hh:24-48)
+struct RealTok {
+  std::string tokstring;                               // real tokens joined by '\t'
+  std::vector<std::pair<uint64_t, std::string>> itoks;  // "index of next real token" -> penalty string
+  std::vector<std::string> split() const;               // Sentence::operator Tokens (src/sentence.cc:7-22)
+};
+
+class HostIndex {
+ public:
+  // FuzzyMatch::_pt, SuffixArrayIndex::_max_tokens_in_pattern
+  int      pt = 0;
+  uint64_t max_tokens = 300;
+
+  // VocabIndexer (include/fuzzy/vocab_indexer.hh:38-41).  For id-only corpora (bulk builder)
+  // forms/form2index stay empty and only vocab_size/sfreq are meaningful.
+  std::vector<std::string>                  forms;
+  std::vector<uint32_t>                     sfreq;
+  std::unordered_map<std::string, uint32_t> form2index;
+  uint32_t                                  vocab_size = 0;
+
+  // SuffixArray (include/fuzzy/suffix_array.hh:50-61)
+  bool                  sorted = false;
+  std::vector<uint32_t> suf_sid;
+  std::vector<uint16_t> suf_pos;
+  std::vector<uint32_t> buf;       // _sentence_buffer: [len, tok x len, 0] per sentence
+  std::vector<uint32_t> sent_pos;  // _sentence_pos
+  std::vector<uint32_t> qva;       // _quickVocabAccess
+
+  // SuffixArrayIndex::_ids / _real_tokens — empty for id-only corpora
+  std::vector<std::string> ids;
+  std::vector<RealTok>     real;
+
+  // ---- derived (derive()) ----
+  std::vector<SufRec>   suf_rec;   // one 8-byte record per suffix, suffix-array order
+  std::vector<float>    idf;       // logf(N / sfreq[w]) per word id (src/fuzzy_match.cc:384)
+  float                 idf_max = 0.01f;
+  bool                  real_differs = false;  // some sentence has real tokens != its normalised tokens, or itoks
+  std::vector<uint32_t> real_ids;  // per token slot of buf: interned real-token id | LUMC flag (bit 31)
+  std::vector<uint32_t> itok_ids;  // per slot of buf (slot sent_pos+i <-> itok index i in [0, len])
+  std::unordered_map<std::string, uint32_t> real_intern;
+  std::vector<std::string>                  itok_strings;  // id 0 = ""
+  std::unordered_map<std::string, uint32_t> itok_intern;
+  std::vector<uint16_t>                     itok_dist;     // n x n byte-Levenshtein, n = itok_strings.size()
+  uint64_t                                  itok_version = 0;
+
+  HostIndex();
+
+  // VocabIndexer::addWord / getIndex (src/vocab_indexer.cc:37-60)
+  uint32_t add_word(const std::string& w);
+  uint32_t get_index(const std::string& w) const;
+
+  // SuffixArrayIndex::add_tm (src/suffix_array_index.cc:10-30): returns the new sentence id or -1
+  // when skipped (empty real tokens, or more than max_tokens normalised tokens).
+  int64_t add_tm(const std::string& id, const RealTok& real_tokens, const std::vector<std::string>& norm);
+  // id-level bulk add (synthetic corpora): CSR token stream with ids >= 2 already assigned.
+  void add_ids_bulk(const uint32_t* off, const uint32_t* toks, uint64_t n_sent, uint32_t vocab_size_);
+
+  // SuffixArray::sort (src/suffix_array.cc:58-102) on the CPU; result identical to the reference's.
+  void sort(int nthreads);
+  // adopt a suffix order computed elsewhere (the GPU builder) — keys = sid << 16 | pos, sorted.
+  void adopt_sorted(const uint64_t* keys, uint64_t n);
+  // unsorted (sid<<16|pos) keys + first-token bucket offsets, for the GPU builder
+  void bucket_keys(std::vector<uint64_t>& keys, std::vector<uint64_t>& bucket_off) const;
+
+  void derive();
+  uint32_t num_sentences() const { return (uint32_t)sent_pos.size(); }
+  uint64_t num_suffixes() const { return suf_sid.size(); }
+
+  // penalty-string interning for query batches; grows itok_dist (not thread safe; callers lock)
+  uint32_t intern_itok(const std::string& s);
+  uint32_t lookup_real(const std::string& s) const;  // 0x7ffffffe when absent
+
+  // .fmi (src/fuzzy_matcher_binarization.cc:16-51 + the per-class save/load templates)
+  void load_fmi(const std::string& path);
+  void save_fmi(const std::string& path) const;
+};
+
+// _edit_distance_char (include/fuzzy/edit_distance.hxx:7-35)
+int edit_distance_char(const char* s1, int n1, const char* s2, int n2);
+
+}  // namespace fmx

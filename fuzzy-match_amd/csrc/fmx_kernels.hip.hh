@@ -1,0 +1,625 @@
+// fmx_kernels.hip.hh — the HIP kernels of the match() hot path for gfx950 (wave64).
+//
+// Stage map:
+//   k_setup   A   guards, min_subseq_length, token -> query map
+//   k_probe   C,D one lane per (query, start): range of the seed n-gram in the suffix array
+//   k_expand  D,E one wave per query: walk the ranges, length filter, LCP, ballot/prefix compaction
+//   k_cand    E,F one wave per query: max per sentence, order (longest desc, s_id asc)
+//   k_score   G,H,I one wave per query: coverage bound, float edit distance (one candidate per
+//                 lane, DP rows in LDS), sequential replay of the lowest_costs bound
+//   k_select  H,J top-N by (score desc, s_id asc) or contrastive rerank
+// All integer/compare/float-scalar work: no MFMA anywhere (HBM-latency bound probe, LDS-bound DP).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "fmx_core.hh"
+
+namespace fmx {
+
+struct DevIndex {
+  const SufRec*   suf;
+  const uint32_t* suf_sid;
+  const uint32_t* tok;
+  const uint32_t* sent_pos;
+  const uint32_t* qva;
+  const float*    idf;
+  const uint32_t* real;       // nullptr unless real tokens differ from normalised tokens
+  const uint32_t* itok;
+  const uint16_t* itok_dist;
+  uint32_t        n_itok;
+  uint32_t        n_qva;
+  uint32_t        n_sent;
+  uint32_t        max_slen;
+  uint64_t        n_suf;
+};
+
+struct DevBatch {
+  const uint32_t* q_off;   // absolute offsets (nq_total + 1)
+  const uint32_t* q_tok;
+  const uint32_t* q_real;
+  const uint32_t* q_itok;
+  uint32_t        q_begin;  // first query of this sub-batch
+  uint32_t        nq;       // queries in this sub-batch
+  uint32_t        t_begin;  // q_off[q_begin]
+  uint32_t        nt;       // tokens in this sub-batch
+};
+
+struct DevWork {
+  uint32_t* q_m;        // nq   seed n-gram length or kNoMatchLen
+  uint32_t* t_q;        // nt   token -> local query
+  uint32_t* t_lo;       // nt   range start per (query, start)
+  uint32_t* t_cnt;      // nt   range size
+  unsigned long long* q_hits;  // nq   hits per query (sum of t_cnt)
+  unsigned long long* q_seg;   // nq+1 exclusive scan of q_hits
+  uint32_t* q_kept;     // nq
+  uint32_t* q_cand;     // nq
+  uint32_t* q_acc;      // nq
+  Cand*     seg;        // capacity seg_cap
+  float*    heap;       // capacity seg_cap + nq (lowest_costs spill)
+  unsigned long long  seg_cap;
+  unsigned long long* counters;  // [0]=hits [1]=kept [2]=cands [3]=dp [4]=overflow flag
+};
+
+constexpr int kWave = 64;
+constexpr uint32_t kLdsSortMax = 1024;   // per-wave LDS sort capacity (keys)
+constexpr uint32_t kHeapLdsMax = 62;     // lowest_costs kept in LDS up to this contrast_buffer
+
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63; }
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+  const uint32_t lane = lane_id();
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t n = __shfl_up(v, d, 64);
+    if (lane >= (uint32_t)d) v += n;
+  }
+  return v;
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_setup — src/fuzzy_match.cc:450-467
+// ---------------------------------------------------------------------------------------------
+__global__ void k_setup(DevBatch b, DevWork w, Params prm) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= b.nq) return;
+  const uint32_t o0 = b.q_off[b.q_begin + q], o1 = b.q_off[b.q_begin + q + 1];
+  const uint32_t p = o1 - o0;
+  const uint32_t msl = min_seq_len(p, prm);
+  w.q_m[q] = msl == kNoMatchLen ? kNoMatchLen : msl;
+  for (uint32_t k = 0; k < p; k++) w.t_q[o0 - b.t_begin + k] = q;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_probe — one lane per (query, start position): the suffix range the reference's narrowing
+// equal_range calls converge to for the seed n-gram (src/suffix_array.cc:105-212,
+// src/fuzzy_match.cc:495-551).  Each compare step is one 8-byte SufRec load + token loads.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_probe(DevIndex ix, DevBatch b, DevWork w) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= b.nt) return;
+  const uint32_t q = w.t_q[t];
+  const uint32_t msl = w.q_m[q];
+  const uint32_t o0 = b.q_off[b.q_begin + q] - b.t_begin;
+  const uint32_t p = b.q_off[b.q_begin + q + 1] - b.t_begin - o0;
+  const uint32_t it = t - o0;
+  uint32_t lo = 0, hi = 0;
+  if (msl != kNoMatchLen) {
+    const uint32_t m = seed_len(p, msl);
+    // register_suffix_range_match ignores match_length < _min_seq_len (src/ngram_matches.cc:65-66);
+    // with p == 1 the only registered length is 1.
+    const bool reachable = (p == 1) ? (msl <= 1) : true;
+    if (reachable && it + m <= p)
+      mgram_range(ix.suf, ix.tok, ix.qva, ix.n_qva, b.q_tok + b.t_begin + t, m, lo, hi);
+  }
+  const uint32_t cnt = hi - lo;
+  w.t_lo[t] = lo;
+  w.t_cnt[t] = cnt;
+  if (cnt) atomicAdd(&w.q_hits[q], (unsigned long long)cnt);
+}
+
+// ---------------------------------------------------------------------------------------------
+// exclusive scan of q_hits -> q_seg (three small kernels; nq <= 8192 * 8192)
+// ---------------------------------------------------------------------------------------------
+constexpr int kScanThreads = 1024;
+constexpr int kScanItems = 8;
+constexpr int kScanTile = kScanThreads * kScanItems;
+
+__device__ __forceinline__ unsigned long long block_excl_scan(unsigned long long v, unsigned long long* total) {
+  __shared__ unsigned long long s_wave[kScanThreads / 64];
+  const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
+  unsigned long long x = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned long long n = __shfl_up(x, d, 64);
+    if (lane >= (uint32_t)d) x += n;
+  }
+  if (lane == 63) s_wave[wv] = x;
+  __syncthreads();
+  if (wv == 0) {
+    unsigned long long y = lane < kScanThreads / 64 ? s_wave[lane] : 0ull;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned long long n = __shfl_up(y, d, 64);
+      if (lane >= (uint32_t)d) y += n;
+    }
+    if (lane < kScanThreads / 64) s_wave[lane] = y;
+  }
+  __syncthreads();
+  const unsigned long long base = wv ? s_wave[wv - 1] : 0ull;
+  *total = s_wave[kScanThreads / 64 - 1];
+  __syncthreads();
+  return base + x - v;
+}
+
+__global__ void __launch_bounds__(kScanThreads) k_scan_tiles(const unsigned long long* in, unsigned long long* out,
+                                                            unsigned long long* tile_sums, uint32_t n) {
+  const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+  unsigned long long v[kScanItems], s = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; k++) { v[k] = base + k < n ? in[base + k] : 0ull; s += v[k]; }
+  unsigned long long total;
+  unsigned long long ex = block_excl_scan(s, &total);
+#pragma unroll
+  for (int k = 0; k < kScanItems; k++) { if (base + k < n) out[base + k] = ex; ex += v[k]; }
+  if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(kScanThreads) k_scan_sums(unsigned long long* tile_sums, uint32_t n_tiles,
+                                                           unsigned long long* grand_total) {
+  // single block; n_tiles <= kScanTile
+  const uint32_t base = threadIdx.x * kScanItems;
+  unsigned long long v[kScanItems], s = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; k++) { v[k] = base + k < n_tiles ? tile_sums[base + k] : 0ull; s += v[k]; }
+  unsigned long long total;
+  unsigned long long ex = block_excl_scan(s, &total);
+#pragma unroll
+  for (int k = 0; k < kScanItems; k++) { if (base + k < n_tiles) tile_sums[base + k] = ex; ex += v[k]; }
+  if (threadIdx.x == 0) *grand_total = total;
+}
+
+__global__ void __launch_bounds__(kScanThreads) k_scan_add(unsigned long long* out, const unsigned long long* tile_sums,
+                                                          uint32_t n) {
+  const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+  const unsigned long long add = tile_sums[blockIdx.x];
+#pragma unroll
+  for (int k = 0; k < kScanItems; k++) if (base + k < n) out[base + k] += add;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_expand — one wave per query.  Walks every hit of every start position (the suffixes the
+// reference's register_suffix_range_match visits, src/ngram_matches.cc:61-83), applies the length
+// filter, drops dominated hits, computes the match length and compacts survivors into the query's
+// segment with wave ballot + prefix popcount (no atomics, deterministic order).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kWave) k_expand(DevIndex ix, DevBatch b, DevWork w, Params prm) {
+  __shared__ uint32_t s_pref[kWave + 1];
+  __shared__ uint32_t s_lo[kWave];
+  const uint32_t q = blockIdx.x;
+  const uint32_t lane = lane_id();
+  const uint32_t msl = w.q_m[q];
+  const unsigned long long hits = w.q_hits[q];
+  if (msl == kNoMatchLen || hits == 0) {
+    if (lane == 0) w.q_kept[q] = 0;
+    return;
+  }
+  const unsigned long long seg0 = w.q_seg[q];
+  if (seg0 + hits > w.seg_cap) {  // workspace too small: host re-runs the sub-batch with a larger one
+    if (lane == 0) { w.q_kept[q] = 0; atomicMax(&w.counters[4], seg0 + hits); }
+    return;
+  }
+  const uint32_t o0 = b.q_off[b.q_begin + q];
+  const uint32_t p = b.q_off[b.q_begin + q + 1] - o0;
+  const uint32_t m = seed_len(p, msl);
+  const uint32_t* pat = b.q_tok + o0;
+  const uint32_t t0 = o0 - b.t_begin;
+  Cand* seg = w.seg + seg0;
+  uint32_t n_out = 0;
+  for (uint32_t c0 = 0; c0 < p; c0 += kWave) {
+    const uint32_t it_l = c0 + lane;
+    const uint32_t mycnt = it_l < p ? w.t_cnt[t0 + it_l] : 0u;
+    const uint32_t incl = wave_incl_scan(mycnt);
+    const uint32_t total = __shfl(incl, 63, 64);
+    __syncthreads();
+    s_pref[lane] = incl - mycnt;
+    s_lo[lane] = it_l < p ? w.t_lo[t0 + it_l] : 0u;
+    if (lane == 0) s_pref[kWave] = total;
+    __syncthreads();
+    for (uint32_t h0 = 0; h0 < total; h0 += kWave) {
+      const uint32_t h = h0 + lane;
+      bool keep = h < total;
+      uint32_t sid = 0, L = 0;
+      if (keep) {
+        // largest j with s_pref[j] <= h (entries with zero count share a prefix value; the last wins)
+        uint32_t a = 0, bnd = kWave;
+        while (bnd - a > 1) {
+          const uint32_t mid = (a + bnd) >> 1;
+          if (s_pref[mid] <= h) a = mid; else bnd = mid;
+        }
+        const uint32_t it = c0 + a;
+        const uint32_t i = s_lo[a] + (h - s_pref[a]);
+        const SufRec r = ix.suf[i];
+        keep = !reject_len(p, r.slen, prm) && !dominated_hit(ix.tok, r, pat + it, it);
+        if (keep) {
+          L = lcp_extend(ix.tok, r, pat + it, m, p - it);
+          sid = ix.suf_sid[i];
+        }
+      }
+      const unsigned long long mask = __ballot(keep);
+      if (keep) {
+        const uint32_t pos = n_out + __popcll(mask & ((1ull << lane) - 1ull));
+        Cand c;
+        c.sid = sid; c.longest = L; c.score = 0.f; c.penalty = 0.f;
+        seg[pos] = c;
+      }
+      n_out += __popcll(mask);
+    }
+  }
+  if (lane == 0) {
+    w.q_kept[q] = n_out;
+    atomicAdd(&w.counters[0], hits);
+    atomicAdd(&w.counters[1], (unsigned long long)n_out);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// bitonic sort of n (power of two) 64-bit keys by one wave; K is any accessor with operator[]
+// ---------------------------------------------------------------------------------------------
+template <class K>
+__device__ __forceinline__ void wave_bitonic_sort(K keys, uint32_t n_pow2) {
+  const uint32_t lane = lane_id();
+  for (uint32_t k = 2; k <= n_pow2; k <<= 1) {
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      for (uint32_t i = lane; i < n_pow2; i += kWave) {
+        const uint32_t ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned long long a = keys[i], c = keys[ixj];
+          const bool up = (i & k) == 0;
+          if ((a > c) == up) { keys[i] = c; keys[ixj] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+struct GlobalKeys {
+  unsigned long long* p;
+  __device__ __forceinline__ unsigned long long& operator[](uint32_t i) const { return p[i]; }
+};
+
+__device__ __forceinline__ uint32_t next_pow2(uint32_t n) {
+  uint32_t v = 1;
+  while (v < n) v <<= 1;
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_cand — one wave per query: LongestMatches semantics (max match length per sentence,
+// src/ngram_matches.cc:79-81) then get_longest_matches order (longest desc, s_id asc,
+// src/ngram_matches.cc:19-29).  Two key sorts: (sid, L) to find each sentence's max, then
+// (~L, sid).  Up to kLdsSortMax hits are sorted in LDS; larger sets spill to the global key
+// scratch `big` (slow path, rare).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kWave) k_cand(DevWork w, unsigned long long* big) {
+  __shared__ unsigned long long s_keys[kLdsSortMax];
+  const uint32_t q = blockIdx.x;
+  const uint32_t lane = lane_id();
+  const uint32_t n = w.q_kept[q];
+  if (n == 0) {
+    if (lane == 0) w.q_cand[q] = 0;
+    return;
+  }
+  Cand* seg = w.seg + w.q_seg[q];
+  const uint32_t np2 = next_pow2(n);
+  const bool in_lds = np2 <= kLdsSortMax;
+  // the global scratch mirrors the segment layout at 2x (pow2 padding): 2 * q_seg[q]
+  unsigned long long* keys = in_lds ? s_keys : big + 2ull * w.q_seg[q];
+  for (uint32_t i = lane; i < np2; i += kWave)
+    keys[i] = i < n ? (((unsigned long long)seg[i].sid << 16) | (seg[i].longest & 0xffffu)) : ~0ull;
+  __syncthreads();
+  if (in_lds) wave_bitonic_sort(s_keys, np2); else wave_bitonic_sort(GlobalKeys{keys}, np2);
+  // keep the last entry of each sentence group (its largest L); rewrite as (0xffff - L, sid)
+  uint32_t kept = 0;
+  for (uint32_t i0 = 0; i0 < np2; i0 += kWave) {
+    const uint32_t i = i0 + lane;
+    unsigned long long k2 = ~0ull;
+    bool keep = false;
+    if (i < n) {
+      const unsigned long long a = keys[i];
+      const unsigned long long nxt = (i + 1 < n) ? keys[i + 1] : ~0ull;
+      keep = (i + 1 >= n) || ((nxt >> 16) != (a >> 16));
+      if (keep) k2 = ((unsigned long long)(0xffffu - (uint32_t)(a & 0xffffu)) << 32) | (a >> 16);
+    }
+    __syncthreads();
+    if (i < np2) keys[i] = k2;
+    kept += __popcll(__ballot(keep));
+    __syncthreads();
+  }
+  if (in_lds) wave_bitonic_sort(s_keys, np2); else wave_bitonic_sort(GlobalKeys{keys}, np2);
+  for (uint32_t i = lane; i < kept; i += kWave) {
+    const unsigned long long a = keys[i];
+    Cand c;
+    c.sid = (uint32_t)(a & 0xffffffffu);
+    c.longest = 0xffffu - (uint32_t)(a >> 32);
+    c.score = 0.f; c.penalty = 0.f;
+    seg[i] = c;
+  }
+  if (lane == 0) {
+    w.q_cand[q] = kept;
+    atomicAdd(&w.counters[2], (unsigned long long)kept);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_score — one wave per query, candidates in reference order, 64 at a time: coverage bound
+// (src/pattern_coverage.cc:15-28, src/ngram_matches.cc:41-59), float edit distance with one
+// candidate per lane and its DP row strided through LDS (bank = lane, conflict free), then lane 0
+// replays the order-dependent lowest_costs logic (src/fuzzy_match.cc:587-610) over the chunk.
+// The bound it leaves is handed to the next chunk as a safe early-exit threshold (the bound never
+// increases).  Accepted matches overwrite the head of the query's segment.
+// Dynamic LDS: pat[p_max] | idf[p_max] | rows[(p_max+1)*64] floats.
+// ---------------------------------------------------------------------------------------------
+struct LdsRow {
+  float* base;
+  __device__ __forceinline__ float& operator[](uint32_t j) const { return base[j * kWave]; }
+};
+
+template <bool FULL>
+__global__ void __launch_bounds__(kWave) k_score(DevIndex ix, DevBatch b, DevWork w, Params prm, uint32_t p_max) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint32_t* s_pat = (uint32_t*)smem;
+  float*    s_idf = (float*)(s_pat + p_max);
+  float*    s_rows = s_idf + p_max;
+  __shared__ float    s_final[kWave], s_M[kWave];
+  __shared__ uint32_t s_sid[kWave], s_L[kWave], s_slen[kWave];
+  __shared__ uint32_t s_pass[kWave];
+  __shared__ float    s_heap[kHeapLdsMax + 2];
+  __shared__ float    s_ub;
+  const uint32_t q = blockIdx.x;
+  const uint32_t lane = lane_id();
+  const uint32_t n_cand = w.q_cand[q];
+  if (n_cand == 0) {
+    if (lane == 0) w.q_acc[q] = 0;
+    return;
+  }
+  const uint32_t o0 = b.q_off[b.q_begin + q];
+  const uint32_t p = b.q_off[b.q_begin + q + 1] - o0;
+  const uint32_t* pat_g = b.q_tok + o0;
+  const bool use_idf = prm.idf_penalty != 0.f;
+  for (uint32_t j = lane; j < p; j += kWave) {
+    const uint32_t wd = pat_g[j];
+    s_pat[j] = wd;
+    // compute_idf_penalty — src/fuzzy_match.cc:381-387 (UNK and out-of-vocabulary ids -> 0)
+    s_idf[j] = (use_idf && wd + 1 < ix.n_qva && wd != 1u) ? ix.idf[wd] : 0.f;
+  }
+  Cand* seg = w.seg + w.q_seg[q];
+  const bool heap_in_lds = prm.cbuf > 0 && prm.cbuf <= (int)kHeapLdsMax;
+  CostHeap heap;
+  heap.v = heap_in_lds ? s_heap : (w.heap + w.q_seg[q] + q);
+  heap.n = 0;
+  if (lane == 0) { heap.push(FLT_MAX); s_ub = FLT_MAX; }
+  __syncthreads();
+  uint32_t acc = 0, n_dp = 0;
+  DpSide side;
+  side.s_real = nullptr; side.p_real = nullptr; side.s_itok = nullptr; side.p_itok = nullptr;
+  side.itok_dist = nullptr; side.n_itok = 0; side.p_idf = nullptr; side.idf_weight = 0.f;
+  for (uint32_t c0 = 0; c0 < n_cand; c0 += kWave) {
+    const uint32_t c = c0 + lane;
+    bool pass = false;
+    float final_cost = 0.f, M = 0.f;
+    uint32_t sid = 0, L = 0, slen = 0;
+    if (c < n_cand) {
+      sid = seg[c].sid;
+      L = seg[c].longest;
+      const uint32_t sp = ix.sent_pos[sid];
+      slen = ix.tok[sp];
+      const uint32_t* sent = ix.tok + sp + 1;
+      const uint32_t cover = L < p ? cover_count(sent, slen, s_pat, p) : p;
+      pass = !reject_cover(p, slen, cover, prm);
+      if (pass) {
+        const float dw = 100.f / normalizer(p, slen, prm.ins, prm.del, prm.rep);
+        if (FULL) {
+          if (ix.real) {
+            side.s_real = ix.real + sp + 1;
+            side.p_real = b.q_real ? b.q_real + o0 : nullptr;
+            if (!side.p_real) side.s_real = nullptr;
+          }
+          if (ix.itok_dist) {
+            side.itok_dist = ix.itok_dist;
+            side.n_itok = ix.n_itok;
+            side.s_itok = ix.itok ? ix.itok + sp : nullptr;
+            side.p_itok = b.q_itok ? b.q_itok + o0 + (b.q_begin + q) : nullptr;
+          }
+          if (use_idf) {
+            side.p_idf = s_idf;
+            side.idf_weight = (dw * prm.idf_penalty) / prm.idf_max;  // src/fuzzy_match.cc:591
+          }
+        }
+        final_cost = edit_distance<FULL>(sent, slen, s_pat, p, prm.ins, prm.del, prm.rep, dw, side, s_ub,
+                                         LdsRow{s_rows + lane}, M);
+        n_dp++;
+      }
+    }
+    s_final[lane] = final_cost; s_M[lane] = M; s_sid[lane] = sid; s_L[lane] = L; s_slen[lane] = slen;
+    s_pass[lane] = pass ? 1u : 0u;
+    __syncthreads();
+    if (lane == 0) {
+      const uint32_t lim = n_cand - c0 < kWave ? n_cand - c0 : kWave;
+      for (uint32_t k = 0; k < lim; k++) {
+        if (!s_pass[k]) continue;
+        float score;
+        if (replay_candidate(heap, prm, p, s_slen[k], s_final[k], s_M[k], score)) {
+          Cand a;
+          a.sid = s_sid[k]; a.longest = s_L[k]; a.score = score; a.penalty = 0.f;
+          seg[acc++] = a;
+        }
+      }
+      s_ub = heap.top();
+    }
+    __syncthreads();
+  }
+  n_dp = wave_sum(n_dp);
+  if (lane == 0) {
+    w.q_acc[q] = acc;
+    atomicAdd(&w.counters[3], (unsigned long long)n_dp);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_select — one wave per query: the `result` priority queue's pop order (score desc, s_id asc;
+// CompareMatch src/fuzzy_match.cc:25-33) via a key/value sort, then either the plain top-N
+// (src/fuzzy_match.cc:670-679) or the contrastive rerank (:614-669) with the ids-only edit
+// distance (src/edit_distance.cc:79-122), one remaining candidate per lane per round.
+// Up to kLdsSortMax accepted matches live in LDS; more spill to global scratch (flat pointers).
+// Dynamic LDS (contrast only): rows[(max_slen+1)*64] floats.
+// ---------------------------------------------------------------------------------------------
+struct Rec {  // == fmx_match
+  float    score;
+  float    penalty;
+  int32_t  max_subseq;
+  uint32_t s_id;
+};
+
+__device__ __forceinline__ void wave_bitonic_sort_kv(unsigned long long* keys, uint32_t* vals, uint32_t n_pow2) {
+  const uint32_t lane = lane_id();
+  for (uint32_t k = 2; k <= n_pow2; k <<= 1) {
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      for (uint32_t i = lane; i < n_pow2; i += kWave) {
+        const uint32_t ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned long long a = keys[i], c = keys[ixj];
+          const bool up = (i & k) == 0;
+          if ((a > c) == up) {
+            keys[i] = c; keys[ixj] = a;
+            const uint32_t va = vals[i], vc = vals[ixj];
+            vals[i] = vc; vals[ixj] = va;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+struct DevScratch {
+  unsigned long long* keys;   // 2 * seg_cap
+  uint32_t*           vals;   // 2 * seg_cap
+  float*              f0;     // seg_cap
+  float*              f1;     // seg_cap
+};
+
+__global__ void __launch_bounds__(kWave) k_select(DevIndex ix, DevBatch b, DevWork w, Params prm, DevScratch sc,
+                                                  uint32_t cap, Rec* out_rec, uint32_t* out_count,
+                                                  uint32_t* out_total) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* s_rows = (float*)smem;
+  __shared__ unsigned long long s_keys[kLdsSortMax];
+  __shared__ uint32_t s_vals[kLdsSortMax];
+  __shared__ float    s_f0[kLdsSortMax], s_f1[kLdsSortMax];
+  const uint32_t q = blockIdx.x;
+  const uint32_t lane = lane_id();
+  const uint32_t gq = b.q_begin + q;
+  const uint32_t n = w.q_acc[q];
+  Rec* out = out_rec + (unsigned long long)gq * cap;
+  if (n == 0) {
+    if (lane == 0) { out_count[gq] = 0; if (out_total) out_total[gq] = 0; }
+    return;
+  }
+  const unsigned long long seg0 = w.q_seg[q];
+  const Cand* seg = w.seg + seg0;
+  const uint32_t np2 = next_pow2(n);
+  const bool in_lds = np2 <= kLdsSortMax;
+  unsigned long long* keys = in_lds ? s_keys : sc.keys + 2ull * seg0;
+  uint32_t* vals = in_lds ? s_vals : sc.vals + 2ull * seg0;
+  // ascending key order = score desc, s_id asc; value = position in the accepted list
+  for (uint32_t i = lane; i < np2; i += kWave) {
+    keys[i] = i < n ? (((unsigned long long)(~float_key(seg[i].score)) << 32) | seg[i].sid) : ~0ull;
+    vals[i] = i;
+  }
+  __syncthreads();
+  wave_bitonic_sort_kv(keys, vals, np2);
+  const uint32_t want = prm.nmatch == 0 ? n : (prm.nmatch < n ? prm.nmatch : n);
+  const uint32_t emit = want < cap ? want : cap;
+  if (!(prm.contrast > 0.f)) {
+    for (uint32_t k = lane; k < emit; k += kWave) {
+      const Cand c = seg[vals[k]];
+      Rec r;
+      r.score = c.score; r.penalty = 0.f; r.max_subseq = (int32_t)c.longest; r.s_id = c.sid;
+      out[k] = r;
+    }
+    if (lane == 0) { out_count[gq] = emit; if (out_total) out_total[gq] = want; }
+    return;
+  }
+  // ---- contrastive rerank; list position k <-> seg[vals[k]] ----
+  float* pen_sum = in_lds ? s_f0 : sc.f0 + seg0;   // running std::accumulate of penalties, pick order
+  float* pen_cur = in_lds ? s_f1 : sc.f1 + seg0;   // Match::penalty (0 before the first round)
+  // reuse the key array as the running max / taken flag store: key <- (taken << 63) | bits(max)
+  for (uint32_t k = lane; k < n; k += kWave) { pen_sum[k] = 0.f; pen_cur[k] = 0.f; keys[k] = 0ull; }
+  __syncthreads();
+  DpSide side;
+  side.s_real = nullptr; side.p_real = nullptr; side.s_itok = nullptr; side.p_itok = nullptr;
+  side.itok_dist = nullptr; side.n_itok = 0; side.p_idf = nullptr; side.idf_weight = 0.f;
+  uint32_t picked = 0;
+  int last = -1;
+  while (picked < n && (prm.nmatch == 0 || picked < prm.nmatch)) {
+    if (last >= 0) {
+      const uint32_t msid = seg[vals[last]].sid;
+      const uint32_t msp = ix.sent_pos[msid];
+      const uint32_t n2 = ix.tok[msp];
+      const uint32_t* s2 = ix.tok + msp + 1;
+      for (uint32_t k = lane; k < n; k += kWave) {
+        if (keys[k] >> 63) continue;
+        const uint32_t csid = seg[vals[k]].sid;
+        const uint32_t csp = ix.sent_pos[csid];
+        const uint32_t n1 = ix.tok[csp];
+        const float dw = 100.f / normalizer(n1, n2, 1.f, 1.f, 1.f);
+        float M;
+        const float ed = edit_distance<false>(ix.tok + csp + 1, n1, s2, n2, 1.f, 1.f, 1.f, dw, side, FLT_MAX,
+                                              LdsRow{s_rows + lane}, M);
+        const float pen = score_from_cost(ed);
+        const float sum = pen_sum[k] + pen;
+        pen_sum[k] = sum;
+        float mx = __uint_as_float((uint32_t)(keys[k] & 0xffffffffull));
+        mx = (picked == 1) ? pen : (mx < pen ? pen : mx);
+        keys[k] = (unsigned long long)__float_as_uint(mx);
+        pen_cur[k] = prm.reduce == 1 ? mx : (sum / (float)picked);
+      }
+      __syncthreads();
+    }
+    // std::max_element over the remaining list: first maximum of score - factor * penalty
+    float best_key = 0.f;
+    int   best = -1;
+    for (uint32_t k = lane; k < n; k += kWave) {
+      if (keys[k] >> 63) continue;
+      const float key = seg[vals[k]].score - (prm.contrast * pen_cur[k]);
+      if (best < 0 || best_key < key) { best = (int)k; best_key = key; }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      const float ok = __shfl_xor(best_key, d, 64);
+      const int   ob = __shfl_xor(best, d, 64);
+      if (ob >= 0 && (best < 0 || best_key < ok || (best_key == ok && ob < best))) { best = ob; best_key = ok; }
+    }
+    if (lane == 0) {
+      if (picked < cap) {
+        const Cand c = seg[vals[best]];
+        Rec r;
+        r.score = c.score; r.penalty = pen_cur[best]; r.max_subseq = (int32_t)c.longest; r.s_id = c.sid;
+        out[picked] = r;
+      }
+      keys[best] |= 1ull << 63;
+    }
+    picked++;
+    last = best;
+    __syncthreads();
+  }
+  if (lane == 0) { out_count[gq] = picked < cap ? picked : cap; if (out_total) out_total[gq] = picked; }
+}
+
+}  // namespace fmx

@@ -1,0 +1,276 @@
+"""ctypes binding of libfmx.so (include/fmx.h) — plumbing for tests and bench.py.
+
+The product is the C-ABI library and the C++ facade; this module only marshals numpy arrays
+into it.  It never computes a match itself and there is no fallback: if libfmx.so is missing
+or no gfx950 device is present, the calls raise.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfmx.so")
+
+FMX_OK = 0
+ARRAYS = {
+    "suf_sid": (0, np.uint32), "suf_pos": (1, np.uint16), "buffer": (2, np.uint32),
+    "sent_pos": (3, np.uint32), "qva": (4, np.uint32), "sfreq": (5, np.uint32),
+    "suf_rec": (6, np.uint64), "idf": (7, np.float32), "real_ids": (8, np.uint32),
+    "itok_ids": (9, np.uint32), "itok_dist": (10, np.uint16),
+}
+
+MATCH_DTYPE = np.dtype([("score", np.float32), ("penalty", np.float32),
+                        ("max_subseq", np.int32), ("s_id", np.uint32)])
+
+
+class Params(C.Structure):
+    """fmx_params — arguments of FuzzyMatch::match (include/fuzzy/fuzzy_match.hh:72-84)."""
+    _fields_ = [("fuzzy", C.c_float), ("nmatch", C.c_uint32), ("no_perfect", C.c_int32),
+                ("min_subseq_length", C.c_int32), ("min_subseq_ratio", C.c_float),
+                ("idf_penalty", C.c_float), ("insert_cost", C.c_float), ("delete_cost", C.c_float),
+                ("replace_cost", C.c_float), ("contrast", C.c_float), ("reduce", C.c_int32),
+                ("contrast_buffer", C.c_int32)]
+
+    def __init__(self, fuzzy=0.8, nmatch=5, no_perfect=False, min_subseq_length=3,
+                 min_subseq_ratio=0.3, idf_penalty=0.0, costs=(1.0, 1.0, 1.0), contrast=0.0,
+                 reduce=0, contrast_buffer=-1):
+        super().__init__(fuzzy, nmatch, int(no_perfect), min_subseq_length, min_subseq_ratio,
+                         idf_penalty, costs[0], costs[1], costs[2], contrast, reduce, contrast_buffer)
+
+
+class Batch(C.Structure):
+    _fields_ = [("nq", C.c_uint64), ("q_off", C.c_void_p), ("q_tok", C.c_void_p),
+                ("q_real", C.c_void_p), ("q_itok", C.c_void_p)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("ms_total", C.c_double), ("ms_h2d", C.c_double), ("ms_d2h", C.c_double),
+                ("ms_kernel", C.c_double * 16), ("launches", C.c_uint64 * 16),
+                ("n_hits", C.c_uint64), ("n_kept", C.c_uint64), ("n_candidates", C.c_uint64),
+                ("n_dp", C.c_uint64), ("n_retries", C.c_uint64)]
+
+
+class Info(C.Structure):
+    _fields_ = [("n_sentences", C.c_uint64), ("n_suffixes", C.c_uint64), ("buffer_size", C.c_uint64),
+                ("vocab_size", C.c_uint64), ("max_tokens_in_pattern", C.c_uint64),
+                ("pt", C.c_int32), ("sorted", C.c_int32), ("finalized", C.c_int32),
+                ("on_device", C.c_int32), ("device", C.c_int32), ("real_differs", C.c_int32),
+                ("n_itok", C.c_uint32), ("idf_max", C.c_float), ("device_bytes", C.c_uint64)]
+
+
+EXPORTS = [
+    "fmx_last_error", "fmx_version", "fmx_stage_name", "fmx_device_count", "fmx_index_create",
+    "fmx_index_free", "fmx_index_load", "fmx_index_save", "fmx_index_add_tm", "fmx_index_add_ids",
+    "fmx_index_sort", "fmx_index_finalize", "fmx_index_to_device", "fmx_vocab_lookup",
+    "fmx_index_lookup_real", "fmx_index_intern_itok", "fmx_index_sentence_id", "fmx_index_array",
+    "fmx_index_get_info", "fmx_match_batch", "fmx_match_batch_device", "fmx_set_option",
+]
+
+_lib = None
+
+
+def build(force=False):
+    """Compile libfmx.so in-tree (hipcc cross-compiles gfx950 without a GPU)."""
+    if force or not os.path.exists(LIB_PATH):
+        subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "-j4"])
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: run `make -C fuzzy-match_amd/csrc` "
+                           "(there is no Python or CPU fallback for the match path)")
+    L = C.CDLL(LIB_PATH)
+    L.fmx_last_error.restype = C.c_char_p
+    L.fmx_version.restype = C.c_char_p
+    L.fmx_stage_name.restype = C.c_char_p
+    L.fmx_stage_name.argtypes = [C.c_int]
+    L.fmx_index_create.restype = C.c_void_p
+    L.fmx_index_create.argtypes = [C.c_int32, C.c_uint64]
+    L.fmx_index_free.argtypes = [C.c_void_p]
+    L.fmx_index_load.restype = C.c_void_p
+    L.fmx_index_load.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+    L.fmx_index_save.argtypes = [C.c_void_p, C.c_char_p]
+    L.fmx_index_add_tm.restype = C.c_int64
+    L.fmx_index_add_tm.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_uint32, C.c_char_p,
+                                   C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_char_p)]
+    L.fmx_index_add_ids.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
+    L.fmx_index_sort.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.fmx_index_finalize.argtypes = [C.c_void_p]
+    L.fmx_index_to_device.argtypes = [C.c_void_p, C.c_int]
+    L.fmx_vocab_lookup.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_uint64, C.c_void_p]
+    L.fmx_index_lookup_real.restype = C.c_uint32
+    L.fmx_index_lookup_real.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    L.fmx_index_intern_itok.restype = C.c_uint32
+    L.fmx_index_intern_itok.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    L.fmx_index_sentence_id.restype = C.c_char_p
+    L.fmx_index_sentence_id.argtypes = [C.c_void_p, C.c_uint32]
+    L.fmx_index_array.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    L.fmx_index_get_info.argtypes = [C.c_void_p, C.POINTER(Info)]
+    L.fmx_match_batch.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Batch), C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_uint32, C.POINTER(Stats)]
+    L.fmx_match_batch_device.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Batch), C.c_uint64, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(Stats)]
+    L.fmx_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+    _lib = L
+    return L
+
+
+class FmxError(RuntimeError):
+    pass
+
+
+def _check(rc):
+    if rc != FMX_OK:
+        raise FmxError(f"fmx error {rc}: {lib().fmx_last_error().decode('utf-8', 'replace')}")
+
+
+def device_count():
+    return lib().fmx_device_count()
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Index:
+    """Handle on an fmx_index (FuzzyMatch + SuffixArrayIndex of the reference)."""
+
+    def __init__(self, handle):
+        if not handle:
+            raise FmxError(lib().fmx_last_error().decode("utf-8", "replace"))
+        self.h = C.c_void_p(handle)
+
+    @classmethod
+    def create(cls, pt=0, max_tokens=300):
+        return cls(lib().fmx_index_create(pt, max_tokens))
+
+    @classmethod
+    def load(cls, path):
+        err = C.create_string_buffer(512)
+        h = lib().fmx_index_load(os.fsencode(path), err, 512)
+        if not h:
+            raise FmxError(err.value.decode("utf-8", "replace"))
+        return cls(h)
+
+    def close(self):
+        if self.h:
+            lib().fmx_index_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def save(self, path):
+        _check(lib().fmx_index_save(self.h, os.fsencode(path)))
+
+    def add_tm(self, sid, norm, real=None, itoks=None):
+        """add_tm(id, Sentence real, Tokens norm): real = list of real tokens or None; itoks = {idx: str}."""
+        arr = (C.c_char_p * len(norm))(*[t.encode("utf-8") for t in norm])
+        real_s = None if real is None else "\t".join(real).encode("utf-8")
+        itoks = itoks or {}
+        n = len(itoks)
+        idx = (C.c_uint64 * max(n, 1))(*list(itoks.keys()))
+        strs = (C.c_char_p * max(n, 1))(*[v.encode("utf-8") for v in itoks.values()])
+        r = lib().fmx_index_add_tm(self.h, sid.encode("utf-8"), arr, len(norm), real_s, n, idx, strs)
+        if r < -1:
+            _check(int(r))
+        return int(r)
+
+    def add_ids(self, off, toks, vocab_size):
+        off = np.ascontiguousarray(off, dtype=np.uint32)
+        toks = np.ascontiguousarray(toks, dtype=np.uint32)
+        _check(lib().fmx_index_add_ids(self.h, _ptr(off), _ptr(toks), len(off) - 1, vocab_size))
+
+    def sort(self, device=-1, nthreads=None):
+        _check(lib().fmx_index_sort(self.h, device, nthreads or os.cpu_count() or 1))
+
+    def finalize(self):
+        _check(lib().fmx_index_finalize(self.h))
+
+    def to_device(self, device=0):
+        _check(lib().fmx_index_to_device(self.h, device))
+
+    def info(self):
+        i = Info()
+        _check(lib().fmx_index_get_info(self.h, C.byref(i)))
+        return i
+
+    def array(self, name):
+        which, dt = ARRAYS[name]
+        p = C.c_void_p()
+        n = C.c_uint64()
+        _check(lib().fmx_index_array(self.h, which, C.byref(p), C.byref(n)))
+        if n.value == 0:
+            return np.zeros(0, dtype=dt)
+        buf = (C.c_char * (n.value * np.dtype(dt).itemsize)).from_address(p.value)
+        return np.frombuffer(buf, dtype=dt).copy()
+
+    def vocab_lookup(self, tokens):
+        arr = (C.c_char_p * len(tokens))(*[t.encode("utf-8") for t in tokens])
+        ids = np.zeros(len(tokens), dtype=np.uint32)
+        _check(lib().fmx_vocab_lookup(self.h, arr, len(tokens), _ptr(ids)))
+        return ids
+
+    def lookup_real(self, s):
+        b = s.encode("utf-8")
+        return lib().fmx_index_lookup_real(self.h, b, len(b))
+
+    def intern_itok(self, s):
+        b = s.encode("utf-8")
+        return lib().fmx_index_intern_itok(self.h, b, len(b))
+
+    def sentence_id(self, s_id):
+        return lib().fmx_index_sentence_id(self.h, s_id).decode("utf-8")
+
+    def set_option(self, name, value):
+        _check(lib().fmx_set_option(self.h, name.encode(), int(value)))
+
+    def match_batch(self, params, q_off, q_tok, q_real=None, q_itok=None, cap=None, want_stats=False):
+        """FuzzyMatch::match over a CSR batch of vocabulary-id patterns (host buffers).
+        Returns (records[nq, cap], counts[nq], totals[nq]) (+ Stats)."""
+        q_off = np.ascontiguousarray(q_off, dtype=np.uint32)
+        q_tok = np.ascontiguousarray(q_tok, dtype=np.uint32)
+        nq = len(q_off) - 1
+        if cap is None:
+            cap = params.nmatch if params.nmatch > 0 else 64
+        out = np.zeros((max(nq, 1), cap), dtype=MATCH_DTYPE)
+        cnt = np.zeros(max(nq, 1), dtype=np.uint32)
+        tot = np.zeros(max(nq, 1), dtype=np.uint32)
+        if q_real is not None:
+            q_real = np.ascontiguousarray(q_real, dtype=np.uint32)
+        if q_itok is not None:
+            q_itok = np.ascontiguousarray(q_itok, dtype=np.uint32)
+        b = Batch(nq, _ptr(q_off), _ptr(q_tok), _ptr(q_real), _ptr(q_itok))
+        st = Stats()
+        _check(lib().fmx_match_batch(self.h, C.byref(params), C.byref(b), _ptr(out), _ptr(cnt), _ptr(tot), cap,
+                                     C.byref(st)))
+        res = (out[:nq], cnt[:nq], tot[:nq])
+        return res + (st,) if want_stats else res
+
+    def match_batch_device(self, params, nq, d_q_off, d_q_tok, total_tokens, d_out, d_count, d_total, cap,
+                           stream=0, d_q_real=0, d_q_itok=0):
+        """Same with raw device pointers (ints) — buffers owned by the caller (e.g. torch tensors)."""
+        b = Batch(nq, d_q_off, d_q_tok, d_q_real or None, d_q_itok or None)
+        st = Stats()
+        _check(lib().fmx_match_batch_device(self.h, C.byref(params), C.byref(b), total_tokens, d_out, d_count,
+                                            d_total or None, cap, stream or None, C.byref(st)))
+        return st
+
+
+def stage_names():
+    names = []
+    for s in range(16):
+        n = lib().fmx_stage_name(s).decode()
+        if not n:
+            break
+        names.append(n)
+    return names

@@ -1,0 +1,182 @@
+/*
+ * fmx.h — C ABI of the MI355X-native fuzzy-match lookup engine (libfmx.so).
+ *
+ * The reference (SYSTRAN/fuzzy-match) has no FFI layer: its boundary is the C++ class
+ * fuzzy::FuzzyMatch in libFuzzyMatch.so.  This header is the C-ABI a binding for that class
+ * would sit on; each entry point cites the reference interface it replaces (paths relative to
+ * the reference checkout).  The C++ facade fuzzy-match_amd/include/fuzzy/fuzzy_match.hh
+ * re-creates the reference's class on top of it; INTEGRATION.md shows the bindings.
+ *
+ * Conventions: plain pointers and sizes, no exceptions across the boundary, every function
+ * returns FMX_OK (0) or a negative fmx_status; fmx_last_error() gives the message for the calling
+ * thread.  Index handles are immutable once fmx_index_finalize() has run and may be shared
+ * between threads; result buffers are caller-owned.  There is no CPU fallback: every match entry
+ * point fails with FMX_E_NO_DEVICE when no gfx950 device is usable.
+ */
+#ifndef FMX_H
+#define FMX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum fmx_status {
+  FMX_OK = 0,
+  FMX_E_INVALID = -1,     /* bad argument */
+  FMX_E_IO = -2,          /* file missing / unreadable / corrupt (import throws in the reference) */
+  FMX_E_NO_DEVICE = -3,   /* no usable GPU, or HIP call failed */
+  FMX_E_NOMEM = -4,
+  FMX_E_STATE = -5,       /* index not sorted / not finalized / not on the device */
+  FMX_E_UNSUPPORTED = -6
+} fmx_status;
+
+typedef struct fmx_index fmx_index;
+
+/* Arguments of FuzzyMatch::match() — include/fuzzy/fuzzy_match.hh:72-84, EditCosts
+ * include/fuzzy/costs.hh:7-29, ContrastReduce fuzzy_match.hh:15 (0 = MEAN, 1 = MAX). */
+typedef struct fmx_params {
+  float    fuzzy;
+  uint32_t nmatch;            /* number_of_matches; 0 = no limit */
+  int32_t  no_perfect;
+  int32_t  min_subseq_length; /* reference defaults: 3 (Sentence/string API), 2 (Tokens API) */
+  float    min_subseq_ratio;  /* 0.3 / 0 */
+  float    idf_penalty;       /* vocab_idf_penalty */
+  float    insert_cost, delete_cost, replace_cost;
+  float    contrast;          /* contrastive_factor */
+  int32_t  reduce;
+  int32_t  contrast_buffer;   /* -1 => nmatch (src/fuzzy_match.cc:451-452) */
+} fmx_params;
+
+/* FuzzyMatch::Match (include/fuzzy/fuzzy_match.hh:32-46) without the host-side members; the facade
+ * fills id / length / s from the host copy of the index. */
+typedef struct fmx_match {
+  float    score;
+  float    penalty;
+  int32_t  max_subseq;
+  uint32_t s_id;
+} fmx_match;
+
+/* A batch of patterns as CSR over vocabulary ids (what VocabIndexer::getIndex returns,
+ * src/vocab_indexer.cc:52-71).  q_real / q_itok carry the `real` Sentence argument of
+ * match(const Sentence&, const Tokens&, ...) and may be NULL (real tokens = normalised tokens, no
+ * penalty tokens):
+ *   q_real[q_off[q] + j]      interned id of the j-th real token (fmx_index_lookup_real)
+ *   q_itok[q_off[q] + q + j]  interned id of the penalty string in front of real token j,
+ *                             j in [0, p] (fmx_index_intern_itok; 0 = none) — nq + T entries. */
+typedef struct fmx_batch {
+  uint64_t        nq;
+  const uint32_t* q_off;  /* nq + 1 offsets into q_tok */
+  const uint32_t* q_tok;
+  const uint32_t* q_real;
+  const uint32_t* q_itok;
+} fmx_batch;
+
+/* per-call measurements (all optional reading) */
+typedef struct fmx_stats {
+  double   ms_total;        /* wall time of the call on the host */
+  double   ms_h2d, ms_d2h;
+  double   ms_kernel[16];   /* HIP-event time per pipeline stage, summed over sub-batches; see fmx_stage_name */
+  uint64_t launches[16];
+  uint64_t n_hits;          /* suffix-array hits visited by the expand stage */
+  uint64_t n_kept;          /* hits that survived the length / dominance filters */
+  uint64_t n_candidates;    /* distinct (query, sentence) candidates */
+  uint64_t n_dp;            /* edit-distance evaluations */
+  uint64_t n_retries;       /* sub-batches re-run with a larger workspace */
+} fmx_stats;
+
+const char* fmx_last_error(void);
+const char* fmx_version(void);
+const char* fmx_stage_name(int stage);
+
+/* ---- devices --------------------------------------------------------------------------- */
+int fmx_device_count(void);                 /* number of usable gfx950 devices, 0 if none */
+
+/* ---- index lifetime ---------------------------------------------------------------------
+ * fuzzy::FuzzyMatch(int pt, size_t max_tokens_in_pattern) — include/fuzzy/fuzzy_match.hh:48-49 */
+fmx_index* fmx_index_create(int32_t pt, uint64_t max_tokens_in_pattern);
+void       fmx_index_free(fmx_index*);
+/* import_binarized_fuzzy_matcher — include/fuzzy/fuzzy_matcher_binarization.hh:9,
+ * src/fuzzy_matcher_binarization.cc:32-51 (the reference throws; here NULL + error text) */
+fmx_index* fmx_index_load(const char* fmi_path, char* err, size_t errlen);
+/* export_binarized_fuzzy_matcher — fuzzy_matcher_binarization.hh:8 */
+int        fmx_index_save(const fmx_index*, const char* fmi_path);
+
+/* FuzzyMatch::add_tm(id, Sentence real, Tokens norm, sort=false) — include/fuzzy/fuzzy_match.hh:52,
+ * src/suffix_array_index.cc:10-30.  real_tokstring = real tokens joined by '\t' (NULL: same as norm,
+ * the Tokens overload fuzzy_match.hh:51).  Returns the sentence id, or -1 when the reference would
+ * have skipped the sentence, or another negative fmx_status. */
+int64_t fmx_index_add_tm(fmx_index*, const char* id, const char* const* norm, uint32_t n_norm,
+                         const char* real_tokstring, uint32_t n_itoks, const uint64_t* itok_idx,
+                         const char* const* itok_str);
+/* Bulk variant on vocabulary ids (>= 2) for corpora that never had string forms (benchmarks). */
+int fmx_index_add_ids(fmx_index*, const uint32_t* off, const uint32_t* toks, uint64_t n_sent,
+                      uint32_t vocab_size);
+/* FuzzyMatch::sort() — include/fuzzy/fuzzy_match.hh:56, src/suffix_array.cc:58-102.
+ * device < 0: CPU build with `nthreads` workers; device >= 0: suffix sort on that GPU.
+ * Both produce exactly the reference's suffix order. */
+int fmx_index_sort(fmx_index*, int device, int nthreads);
+/* derive the SoA arrays (after sort or load) and freeze the index */
+int fmx_index_finalize(fmx_index*);
+/* copy the frozen index into the HBM of `device` (replicated per GPU) */
+int fmx_index_to_device(fmx_index*, int device);
+
+/* ---- index queries (host) ---------------------------------------------------------------- */
+/* VocabIndexer::getIndex — src/vocab_indexer.cc:52-71 (unknown -> 1) */
+int fmx_vocab_lookup(const fmx_index*, const char* const* toks, uint64_t n, uint32_t* ids);
+uint32_t fmx_index_lookup_real(const fmx_index*, const char* s, size_t len);
+uint32_t fmx_index_intern_itok(fmx_index*, const char* s, size_t len);
+/* SuffixArrayIndex::id — src/suffix_array_index.cc:66-70; "" for id-only corpora */
+const char* fmx_index_sentence_id(const fmx_index*, uint32_t s_id);
+
+typedef enum fmx_array {
+  FMX_A_SUF_SID = 0,   /* u32  x n_suffixes   SuffixView::sentence_id, suffix-array order */
+  FMX_A_SUF_POS = 1,   /* u16  x n_suffixes   SuffixView::subsentence_pos (1-based) */
+  FMX_A_BUFFER = 2,    /* u32                 _sentence_buffer */
+  FMX_A_SENT_POS = 3,  /* u32  x n_sentences  _sentence_pos */
+  FMX_A_QVA = 4,       /* u32  x vocab+1      _quickVocabAccess */
+  FMX_A_SFREQ = 5,     /* u32  x vocab        VocabIndexer::sfreq */
+  FMX_A_SUF_REC = 6,   /* 8 B  x n_suffixes   {u32 off; u16 rem; u16 slen} (derived) */
+  FMX_A_IDF = 7,       /* f32  x vocab        (derived) */
+  FMX_A_REAL_IDS = 8,  /* u32  per buffer slot, empty when real tokens == normalised tokens */
+  FMX_A_ITOK_IDS = 9,  /* u32  per buffer slot */
+  FMX_A_ITOK_DIST = 10 /* u16  n_itok x n_itok */
+} fmx_array;
+/* borrowed pointer to a host array of the index, valid until the index changes or is freed */
+int fmx_index_array(const fmx_index*, int which, const void** data, uint64_t* count);
+
+typedef struct fmx_index_info {
+  uint64_t n_sentences, n_suffixes, buffer_size, vocab_size, max_tokens_in_pattern;
+  int32_t  pt, sorted, finalized, on_device, device, real_differs;
+  uint32_t n_itok;
+  float    idf_max;
+  uint64_t device_bytes;
+} fmx_index_info;
+int fmx_index_get_info(const fmx_index*, fmx_index_info*);
+
+/* ---- the hot path ------------------------------------------------------------------------
+ * FuzzyMatch::match(const Sentence&, const Tokens&, ...) — include/fuzzy/fuzzy_match.hh:72-84,
+ * src/fuzzy_match.cc:435-681, for a whole batch of patterns.
+ * out: nq * cap records, out_count: nq entries (matches written per query, <= cap),
+ * out_total (optional): nq entries, the number of matches the reference would return (> cap means
+ * truncated; only possible when nmatch == 0 or nmatch > cap).  Results are in input order and,
+ * per query, in the reference's order. */
+int fmx_match_batch(fmx_index*, const fmx_params*, const fmx_batch* host_batch,
+                    fmx_match* out, uint32_t* out_count, uint32_t* out_total, uint32_t cap,
+                    fmx_stats* stats);
+/* Same with every buffer already in the HBM of the index's device; `stream` is a hipStream_t
+ * (NULL = default stream).  total_tokens = q_off[nq] (saves a device read).  Work is enqueued on
+ * `stream`; the call synchronises that stream before returning. */
+int fmx_match_batch_device(fmx_index*, const fmx_params*, const fmx_batch* device_batch,
+                           uint64_t total_tokens, fmx_match* d_out, uint32_t* d_out_count,
+                           uint32_t* d_out_total, uint32_t cap, void* stream, fmx_stats* stats);
+
+/* tuning knobs (all have sane defaults): queries per sub-batch and initial hit workspace */
+int fmx_set_option(fmx_index*, const char* name, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,28 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (gfx950) device")
+
+
+@pytest.fixture(scope="session")
+def fmx():
+    import fmx_import
+    mod = fmx_import.load().fmx
+    mod.build()
+    return mod
+
+
+@pytest.fixture(scope="session")
+def gpu_device(fmx):
+    """The HIP path must be what runs on a GPU box: no device -> hard failure, not a skip."""
+    n = fmx.device_count()
+    assert n > 0, "no gfx950 device visible to libfmx.so"
+    return 0
