@@ -1,0 +1,135 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI (libfmx.so), against the CPU oracle
+on the same seeded inputs.  Bit-exact: identical match ids, score bits, penalties, max_subseq, order."""
+import os
+
+import numpy as np
+import pytest
+
+import fmi_reader
+import golden_util
+import oracle_lib
+import workloads
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def c1(fmx, gpu_device):
+    """BASELINE config C1: 10k-sentence synthetic corpus, 1k queries; index sorted on the GPU."""
+    c_off, c_tok, q_off, q_tok, vs = workloads.synthetic(10000, 1000, 25)
+    ix = fmx.Index.create()
+    ix.add_ids(c_off, c_tok, vs)
+    ix.sort(gpu_device)           # GPU suffix sort
+    ix.finalize()
+    ix.to_device(gpu_device)
+    o = workloads.build_oracle(c_off, c_tok, vs, sfreq=ix.array("sfreq"))
+    return ix, o, q_off, q_tok
+
+
+def test_gpu_suffix_sort_matches_reference_order(c1):
+    ix, o, _, _ = c1
+    a = o.arrays()
+    for k in ["suf_sid", "suf_pos", "buffer", "sent_pos", "qva"]:
+        assert np.array_equal(a[k], ix.array(k)), k
+
+
+@pytest.mark.parametrize("name", list(workloads.PARAM_SETS))
+def test_c1_param_sets(fmx, c1, name):
+    ix, o, q_off, q_tok = c1
+    kw = workloads.PARAM_SETS[name]
+    cap = kw.get("nmatch", 5) or 64
+    oo, oc = o.match_batch(oracle_lib.Params(**kw), q_off, q_tok, cap, nthreads=os.cpu_count() or 1)
+    go, gc, gt = ix.match_batch(fmx.Params(**kw), q_off, q_tok, cap=cap)
+    workloads.compare(oo, oc, go, gc, name)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_dense_edge_cases(fmx, gpu_device, seed):
+    rng = np.random.default_rng(seed)
+    vocab = [3, 6, 12][seed - 1]
+    c_off, c_tok = workloads.dense_corpus(rng, 400, vocab)
+    q_off, q_tok = workloads.edge_queries(rng, c_off, c_tok, vocab, 400)
+    ix = fmx.Index.create(max_tokens=20)
+    ix.add_ids(c_off, c_tok, vocab + 2)
+    ix.sort(gpu_device)
+    ix.finalize()
+    ix.to_device(gpu_device)
+    o = oracle_lib.OracleIndex(max_tokens=20)
+    o.add_ids_bulk(c_off, c_tok, vocab + 2, sfreq=ix.array("sfreq"))
+    o.sort(2)
+    a = o.arrays()
+    assert np.array_equal(a["suf_sid"], ix.array("suf_sid")) and np.array_equal(a["suf_pos"], ix.array("suf_pos"))
+    for name, kw in workloads.PARAM_SETS.items():
+        cap = kw.get("nmatch", 5) or 512
+        oo, oc = o.match_batch(oracle_lib.Params(**kw), q_off, q_tok, cap, nthreads=2)
+        go, gc, gt = ix.match_batch(fmx.Params(**kw), q_off, q_tok, cap=cap)
+        workloads.compare(oo, oc, go, gc, f"{name}/seed{seed}")
+
+
+def test_sub_batching_and_workspace_growth(fmx, c1):
+    """Tiny sub-batches and a deliberately undersized hit workspace must not change results."""
+    ix, o, q_off, q_tok = c1
+    kw = workloads.PARAM_SETS["wide_all"]
+    oo, oc = o.match_batch(oracle_lib.Params(**kw), q_off, q_tok, 64, nthreads=os.cpu_count() or 1)
+    ix.set_option("sub_queries", 37)
+    try:
+        go, gc, gt, st = ix.match_batch(fmx.Params(**kw), q_off, q_tok, cap=64, want_stats=True)
+    finally:
+        ix.set_option("sub_queries", 1 << 17)
+    workloads.compare(oo, oc, go, gc, "wide_all/sub37")
+
+
+@pytest.mark.parametrize("fmi", ["tm1.fmi", "tm1.old.fmi"])
+def test_tm1_fixture_on_gpu(fmx, gpu_device, fmi):
+    """The reference's own fixture (test/data/test-tm1 against tm1.fmi): real-token, case, number and
+    penalty-token costs through the FULL edit-distance kernel."""
+    path = os.path.join(golden_util.GOLDEN, fmi)
+    ix = fmx.Index.load(path)
+    ix.finalize()
+    ix.to_device(gpu_device)
+    d = fmi_reader.read_fmi(path)
+    for case in golden_util.tm1_cases():
+        wids = ix.vocab_lookup(case["norm"])
+        p = len(wids)
+        q_off = np.asarray([0, p], np.uint32)
+        q_real = np.asarray([ix.lookup_real(r) for r in case["real"]], np.uint32)
+        q_itok = np.zeros(p + 1, np.uint32)
+        for k, v in case["itoks"].items():
+            q_itok[k] = ix.intern_itok(v)
+        prm = fmx.Params(fuzzy=case["fuzzy"], nmatch=case["nmatch"], no_perfect=case["no_perfect"],
+                         min_subseq_length=2, min_subseq_ratio=0)
+        cap = case["nmatch"] or 16
+        go, gc, gt = ix.match_batch(prm, q_off, wids, q_real=q_real, q_itok=q_itok, cap=cap)
+        n = int(gc[0])
+        golden_util.check_tm1_case(case, list(go[0, :n]["score"]), [d["ids"][s] for s in go[0, :n]["s_id"]])
+
+
+def test_known_answers_on_gpu(fmx, gpu_device):
+    """test/test.cc known answers (tests/golden/known_answers.json) through the string-level add_tm +
+    vocab_lookup + match path of the C ABI."""
+    for case in golden_util.known_answers():
+        ix = fmx.Index.create(max_tokens=case["max_tokens"])
+        for i, s in enumerate(case["sentences"]):
+            ix.add_tm(str(i), s)
+        ix.sort(gpu_device)
+        ix.finalize()
+        ix.to_device(gpu_device)
+        for q in case["queries"]:
+            wids = ix.vocab_lookup(q["pattern"])
+            prm = fmx.Params(fuzzy=q["fuzzy"], nmatch=q["nmatch"], no_perfect=q["no_perfect"],
+                             min_subseq_length=q["ml"], min_subseq_ratio=q["mr"], idf_penalty=q["idf"],
+                             costs=tuple(q["costs"]), contrast=q["contrast"], reduce=q["reduce"],
+                             contrast_buffer=q["cbuf"])
+            go, gc, gt = ix.match_batch(prm, np.asarray([0, len(wids)], np.uint32), wids, cap=16)
+            res = go[0, :int(gc[0])]
+            if "expect_count" in q:
+                assert len(res) == q["expect_count"], case["name"]
+            if "expect_sids" in q:
+                assert list(res["s_id"]) == q["expect_sids"], case["name"]
+            if "expect_scores" in q:
+                assert np.allclose(res["score"], q["expect_scores"], atol=q["tol"], rtol=0), case["name"]
+            if "exact_scores" in q:
+                assert [("%.9g" % s) for s in res["score"]] == q["exact_scores"], case["name"]
+            if "expect_score_minus_penalty" in q:
+                assert np.allclose(res["score"] - res["penalty"], q["expect_score_minus_penalty"], atol=q["tol"],
+                                   rtol=0), case["name"]

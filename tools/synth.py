@@ -1,0 +1,74 @@
+"""ctypes wrapper of tools/libfm_synth.so — the portable synthetic corpus / query generator of
+SURVEY.md §8d.  Produces CSR (offsets, vocabulary ids) numpy arrays; used by bench.py and tests."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfm_synth.so")
+VOCAB_TYPES = 50000
+CORPUS_SEED = 12345
+QUERY_SEED = 54321
+_lib = None
+
+
+def build(force=False):
+    if force or not os.path.exists(LIB_PATH):
+        subprocess.check_call(["make", "-C", _HERE])
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(LIB_PATH)
+        L.fms_corpus_new.restype = C.c_void_p
+        L.fms_corpus_new.argtypes = [C.c_uint64, C.c_double, C.c_uint32, C.c_uint64]
+        L.fms_queries_new.restype = C.c_void_p
+        L.fms_queries_new.argtypes = [C.c_void_p, C.c_uint64, C.c_double, C.c_uint32, C.c_uint64]
+        L.fms_free.argtypes = [C.c_void_p]
+        for n in ["fms_num_sentences", "fms_num_tokens"]:
+            getattr(L, n).restype = C.c_uint64
+            getattr(L, n).argtypes = [C.c_void_p]
+        L.fms_vocab_size.restype = C.c_uint32
+        L.fms_vocab_size.argtypes = [C.c_void_p]
+        for n in ["fms_offsets", "fms_tokens"]:
+            getattr(L, n).restype = C.c_void_p
+            getattr(L, n).argtypes = [C.c_void_p]
+        L.fms_word.argtypes = [C.c_uint32, C.c_char_p, C.c_int]
+        _lib = L
+    return _lib
+
+
+def _take(h):
+    L = lib()
+    ns, nt = L.fms_num_sentences(h), L.fms_num_tokens(h)
+    off = np.frombuffer((C.c_char * ((ns + 1) * 4)).from_address(L.fms_offsets(h)), dtype=np.uint32).copy()
+    tok = (np.frombuffer((C.c_char * (nt * 4)).from_address(L.fms_tokens(h)), dtype=np.uint32).copy()
+           if nt else np.zeros(0, np.uint32))
+    return off, tok
+
+
+def corpus_and_queries(n_sent, n_queries, mean_len, vocab_types=VOCAB_TYPES, corpus_seed=CORPUS_SEED,
+                       query_seed=QUERY_SEED):
+    """Returns (c_off, c_tok, q_off, q_tok, vocab_size)."""
+    L = lib()
+    hc = L.fms_corpus_new(n_sent, float(mean_len), vocab_types, corpus_seed)
+    hq = L.fms_queries_new(hc, n_queries, float(mean_len), vocab_types, query_seed)
+    try:
+        c_off, c_tok = _take(hc)
+        q_off, q_tok = _take(hq)
+        vs = L.fms_vocab_size(hc)
+    finally:
+        L.fms_free(hc)
+        L.fms_free(hq)
+    return c_off, c_tok, q_off, q_tok, vs
+
+
+def word(k):
+    buf = C.create_string_buffer(16)
+    lib().fms_word(k, buf, 16)
+    return buf.value.decode()
