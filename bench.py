@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py — query patterns/sec of the match() hot path on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the whole GPU pipeline (probe -> expand -> cand -> score -> select) over one
+batch of synthetic query patterns already resident in HBM, results left in HBM (N > 1: plus the RCCL
+gather of the top-N records to rank 0).  Workload = BASELINE config C3 (5 M-sentence synthetic corpus,
+mean 25 tokens, 1 M queries per GPU per step, fuzzy 0.7, nmatch 5) unless overridden; the index is
+replicated per GPU and queries are sharded by rank (weak scaling).
+
+Prints ONE JSON line on rank 0 with `roofline` (probe kernel, algorithmic bytes of the reference's
+equal_range steps / HIP-event kernel time) and `cpu_baseline` (the oracle timed on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+CONFIGS = {
+    # name: (sentences, mean_len, queries_per_gpu, params)
+    "C1": (10_000, 25, 1_000, dict(fuzzy=0.8, nmatch=5)),
+    "C2": (1_000_000, 20, 100_000, dict(fuzzy=0.7, nmatch=5)),
+    "C3": (5_000_000, 25, 1_000_000, dict(fuzzy=0.7, nmatch=5)),
+    "C4": (5_000_000, 25, 1_000_000, dict(fuzzy=0.5, nmatch=5, min_subseq_ratio=0.5, idf_penalty=1.0)),
+    "C5": (5_000_000, 25, 1_000_000, dict(fuzzy=0.7, nmatch=5, contrast=0.3, contrast_buffer=32)),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="C3", choices=list(CONFIGS))
+    ap.add_argument("--sentences", type=int, default=0)
+    ap.add_argument("--queries", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--verify", type=int, default=2000, help="queries of rank 0 checked against the oracle")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        args.gpus = world
+
+    import torch  # plumbing only: device tensors, streams, torch.distributed
+    import torch.distributed as dist
+    import fmx_import
+    fmx = fmx_import.load().fmx
+    import synth
+
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    n_sent, mean_len, nq, pkw = CONFIGS[args.config]
+    n_sent = args.sentences or n_sent
+    nq = args.queries or nq
+    log = (lambda *a: print(*a, file=sys.stderr, flush=True)) if rank == 0 else (lambda *a: None)
+
+    t0 = time.time()
+    L = synth.lib()
+    hc = L.fms_corpus_new(n_sent, float(mean_len), synth.VOCAB_TYPES, synth.CORPUS_SEED)
+    hq = L.fms_queries_new(hc, nq, float(mean_len), synth.VOCAB_TYPES, synth.QUERY_SEED + rank)
+    c_off, c_tok = synth._take(hc)
+    q_off, q_tok = synth._take(hq)
+    vs = L.fms_vocab_size(hc)
+    L.fms_free(hc)
+    L.fms_free(hq)
+    log(f"[bench] generated {n_sent} sentences / {nq} queries in {time.time() - t0:.1f}s")
+
+    t0 = time.time()
+    ix = fmx.Index.create()
+    ix.add_ids(c_off, c_tok, vs)
+    ix.sort(local_rank)  # suffix sort on the GPU
+    ix.finalize()
+    ix.to_device(local_rank)
+    info = ix.info()
+    log(f"[bench] index built+uploaded in {time.time() - t0:.1f}s: {info.n_suffixes} suffixes, "
+        f"{info.device_bytes / 1e9:.2f} GB in HBM")
+
+    params = fmx.Params(**pkw)
+    cap = params.nmatch or 16
+    dev = torch.device("cuda", local_rank)
+    d_off = torch.from_numpy(q_off.astype(np.int32)).to(dev)
+    d_tok = torch.from_numpy(q_tok.astype(np.int32)).to(dev)
+    d_out = torch.zeros((nq, cap, 4), dtype=torch.int32, device=dev)
+    d_cnt = torch.zeros(nq, dtype=torch.int32, device=dev)
+    gather_out = gather_cnt = None
+    if world > 1 and rank == 0:
+        gather_out = [torch.empty_like(d_out) for _ in range(world)]
+        gather_cnt = [torch.empty_like(d_cnt) for _ in range(world)]
+    stream = torch.cuda.current_stream().cuda_stream
+    total_tokens = int(q_off[-1])
+
+    def step():
+        st = ix.match_batch_device(params, nq, d_off.data_ptr(), d_tok.data_ptr(), total_tokens, d_out.data_ptr(),
+                                   d_cnt.data_ptr(), 0, cap, stream=stream)
+        if world > 1:  # the only collective of the path: top-N records to rank 0 over xGMI
+            dist.gather(d_out, gather_out, dst=0)
+            dist.gather(d_cnt, gather_cnt, dst=0)
+        return st
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    stage_ms = np.zeros(16)
+    launches = np.zeros(16)
+    last = None
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+        stage_ms += np.array(list(last.ms_kernel))
+        launches += np.array(list(last.launches))
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- parity spot check + algorithmic bytes + CPU baseline (rank 0) ----
+    roofline = None
+    cpu_baseline = None
+    parity = None
+    if rank == 0:
+        names = fmx.stage_names()
+        per_stage = {n: float(stage_ms[i] / max(args.steps, 1)) for i, n in enumerate(names)}
+        log(f"[bench] kernel ms/step by stage: { {k: round(v, 3) for k, v in per_stage.items()} }")
+        import oracle_lib
+        t1 = time.time()
+        o = oracle_lib.OracleIndex()
+        o.set_arrays(ix.array("suf_sid"), ix.array("suf_pos"), ix.array("buffer"), ix.array("sent_pos"),
+                     ix.array("qva"), ix.array("sfreq"))
+        log(f"[bench] oracle index ready in {time.time() - t1:.1f}s")
+        oprm = oracle_lib.Params(**pkw)
+        nv = min(args.verify, nq)
+        if nv:
+            oo, oc, ctr = o.match_batch(oprm, q_off[:nv + 1], q_tok[:int(q_off[nv])], cap,
+                                        nthreads=os.cpu_count() or 1, want_counters=True)
+            go = d_out[:nv].cpu().numpy().view(oracle_lib.MATCH_DTYPE).reshape(nv, cap)
+            gc = d_cnt[:nv].cpu().numpy().astype(np.uint32)
+            bad = sum(1 for q in range(nv) if oc[q] != gc[q] or oo[q, :oc[q]].tobytes() != go[q, :gc[q]].tobytes())
+            parity = {"checked": int(nv), "mismatches": int(bad)}
+            d = ctr.as_dict()
+            probe_bytes_per_query = d["probe_bytes"] / max(d["queries"], 1)
+            probe_ms = per_stage.get("probe", 0.0)
+            launches_per_step = launches[names.index("probe")] / max(args.steps, 1)
+            if probe_ms > 0:
+                achieved = probe_bytes_per_query * nq / (probe_ms * 1e-3) / 1e9
+                roofline = {"kernel": "k_probe", "bound": "hbm", "achieved": round(achieved, 2),
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                            "traffic": None, "algorithmic_bytes_per_query": round(probe_bytes_per_query, 1),
+                            "kernel_ms_per_step": round(probe_ms, 4), "launches_per_step": launches_per_step,
+                            "stage_ms_per_step": {k: round(v, 4) for k, v in per_stage.items()}}
+        if not args.no_cpu_baseline and world == 1:
+            cores = os.cpu_count() or 1
+            ns = min(nq, max(2000, 64 * cores))
+            t1 = time.perf_counter()
+            o.match_batch(oprm, q_off[:ns + 1], q_tok[:int(q_off[ns])], cap, nthreads=cores)
+            rate = ns / (time.perf_counter() - t1)
+            ns2 = int(min(nq, max(ns, rate * args.cpu_seconds)))
+            t1 = time.perf_counter()
+            o.match_batch(oprm, q_off[:ns2 + 1], q_tok[:int(q_off[ns2])], cap, nthreads=cores)
+            dt = time.perf_counter() - t1
+            cpu_baseline = {"value": round(ns2 / dt, 1), "unit": "patterns/s", "cores": cores, "kind": "port",
+                            "sample": f"first {ns2} queries of the same {args.config} workload, oracle/fm_oracle.c "
+                                      f"fmo_match_batch with {cores} threads, {dt:.1f}s"}
+        o.close()
+
+    if rank == 0:
+        value = nq * world * args.steps / elapsed
+        line = {
+            "metric": "query patterns/sec @ fuzzy=0.7, 5M-sentence .fmi; 1/2/4/8 GPU + CPU ref",
+            "value": round(value, 1), "unit": "patterns/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u32+f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {n_sent}-sentence synthetic corpus (mean {mean_len} tok, "
+                                   f"near-duplicate families), {nq} queries per GPU per step, "
+                                   + " ".join(f"{k}={v}" for k, v in pkw.items()),
+                       "queries_per_gpu": nq, "sentences": n_sent, "index_bytes_hbm": int(info.device_bytes),
+                       "parallelism": f"queries sharded over {world} GPU(s), index replicated"},
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
