@@ -66,6 +66,9 @@ struct DeviceIndex::Impl {
   DevScratch sc{};
   unsigned long long* tile_sums = nullptr;
   unsigned long long* grand_total = nullptr;
+  WorkItem* items = nullptr;
+  uint32_t  item_cap = 0;
+  uint32_t  s_max = 4096;   // survivors kept per query before a retry with a larger segment
   // staging for the host-batch entry point
   uint32_t *d_qoff = nullptr, *d_qtok = nullptr, *d_qreal = nullptr, *d_qitok = nullptr;
   uint64_t  cap_hq = 0, cap_ht = 0;
@@ -85,7 +88,7 @@ static void free_ws(DeviceIndex::Impl& m) {
   hipFree(m.w.q_seg); hipFree(m.w.q_kept); hipFree(m.w.q_cand); hipFree(m.w.q_acc);
   hipFree(m.w.seg); hipFree(m.w.heap); hipFree(m.w.counters);
   hipFree(m.sc.keys); hipFree(m.sc.vals); hipFree(m.sc.f0); hipFree(m.sc.f1);
-  hipFree(m.tile_sums); hipFree(m.grand_total);
+  hipFree(m.tile_sums); hipFree(m.grand_total); hipFree(m.w.q_cap);
   m.w = DevWork{}; m.sc = DevScratch{};
   m.tile_sums = m.grand_total = nullptr;
   m.cap_q = m.cap_t = m.cap_seg = 0;
@@ -101,7 +104,7 @@ DeviceIndex::~DeviceIndex() {
     hipFree((void*)m.d.itok_dist);
     free_ws(m);
     hipFree(m.d_qoff); hipFree(m.d_qtok); hipFree(m.d_qreal); hipFree(m.d_qitok);
-    hipFree(m.d_out); hipFree(m.d_out_count); hipFree(m.d_out_total);
+    hipFree(m.d_out); hipFree(m.d_out_count); hipFree(m.d_out_total); hipFree(m.items);
     if (m.ev_ok) for (auto& e : m.ev) hipEventDestroy(e);
   }
   delete impl_;
@@ -162,6 +165,7 @@ static void ensure_ws(DeviceIndex::Impl& m, uint64_t nq, uint64_t nt, uint64_t s
     m.w.t_cnt = dev_alloc<uint32_t>(ct);
     m.w.q_hits = dev_alloc<unsigned long long>(cq + 1);
     m.w.q_seg = dev_alloc<unsigned long long>(cq + 1);
+    m.w.q_cap = dev_alloc<unsigned long long>(cq + 1);
     m.w.q_kept = dev_alloc<uint32_t>(cq);
     m.w.q_cand = dev_alloc<uint32_t>(cq);
     m.w.q_acc = dev_alloc<uint32_t>(cq);
@@ -205,8 +209,11 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm_in, const D
     b.t_begin = sub_tok_bounds[sb];
     b.nt = sub_tok_bounds[sb + 1] - sub_tok_bounds[sb];
     uint64_t want_seg = std::max<uint64_t>(m.cap_seg, m.init_seg);
+    uint32_t p_max = (uint32_t)std::min<uint64_t>(prm.max_tokens, std::max<uint32_t>(b.nt, 1));
+    p_max = std::max<uint32_t>(1, std::min<uint32_t>(p_max, bv.p_max ? bv.p_max : p_max));
     for (int attempt = 0;; attempt++) {
       ensure_ws(m, b.nq, std::max<uint32_t>(b.nt, 1), want_seg);
+      if (!m.items) { m.item_cap = 1u << 22; m.items = dev_alloc<WorkItem>(m.item_cap); }
       DevWork w = m.w;
       HIP_TRY(hipMemsetAsync(w.q_hits, 0, (b.nq + 1) * sizeof(unsigned long long), stream));
       HIP_TRY(hipMemsetAsync(w.counters, 0, 8 * sizeof(unsigned long long), stream));
@@ -218,23 +225,25 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm_in, const D
       if (b.nt) hipLaunchKernelGGL(k_probe, dim3((b.nt + 255) / 256), dim3(256), 0, stream, m.d, b, w);
       tick(); tick();
       {
+        hipLaunchKernelGGL(k_caps, dim3((b.nq + 1 + 255) / 256), dim3(256), 0, stream, b, w, m.items, m.item_cap, m.s_max);
         const uint32_t n = b.nq + 1;  // one extra so that q_seg[nq] = total
         const uint32_t tiles = (n + kScanTile - 1) / kScanTile;
         if (tiles > (uint32_t)kScanTile) throw GpuError("sub-batch too large for the scan");
-        hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(kScanThreads), 0, stream, w.q_hits, w.q_seg, m.tile_sums, n);
+        hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(kScanThreads), 0, stream, w.q_cap, w.q_seg, m.tile_sums, n);
         hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanThreads), 0, stream, m.tile_sums, tiles, m.grand_total);
         hipLaunchKernelGGL(k_scan_add, dim3(tiles), dim3(kScanThreads), 0, stream, w.q_seg, m.tile_sums, n);
       }
       tick(); tick();
-      hipLaunchKernelGGL(k_expand, dim3(b.nq), dim3(kWave), 0, stream, m.d, b, w, prm);
+      {
+        const size_t lds = (size_t)p_max * 4;
+        if (lds > 64 * 1024) throw GpuError("patterns too long for the expand kernel's LDS staging");
+        hipLaunchKernelGGL(k_expand, dim3(b.nq + kExpandExtraGrid), dim3(kWave), lds, stream, m.d, b, w, prm,
+                           (const WorkItem*)m.items, m.item_cap);
+      }
       tick(); tick();
       hipLaunchKernelGGL(k_cand, dim3(b.nq), dim3(kWave), 0, stream, w, m.sc.keys);
       tick(); tick();
       {
-        // p_max of the sub-batch bounds the DP row length; patterns longer than max_tokens are skipped
-        // by the guards, so max_tokens is a safe bound and the token count of the sub-batch another.
-        uint32_t p_max = (uint32_t)std::min<uint64_t>(prm.max_tokens, std::max<uint32_t>(b.nt, 1));
-        p_max = std::min<uint32_t>(p_max, bv.p_max ? bv.p_max : p_max);
         const size_t lds = (size_t)p_max * 8 + ((size_t)p_max + 1) * kWave * 4;
         if (lds > 150 * 1024)
           throw GpuError("patterns of " + std::to_string(p_max) + " tokens need more LDS than one CU has (limit ~590)");
@@ -270,9 +279,22 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm_in, const D
           st->launches[s] += 1;
         }
       }
-      if (ctr[4] > m.w.seg_cap) {  // a query's segment did not fit: grow and redo this sub-batch
-        if (attempt >= 3) throw GpuError("hit workspace kept overflowing");
-        want_seg = ctr[4] + ctr[4] / 4;
+      bool retry = false;
+      if (ctr[6] > m.w.seg_cap) { want_seg = ctr[6] + ctr[6] / 4; retry = true; }       // segments did not fit
+      if (ctr[4] > m.s_max) {                                                          // a query had more survivors
+        uint32_t s = m.s_max;
+        while (s < ctr[4]) s <<= 1;
+        m.s_max = s;
+        retry = true;
+      }
+      if (ctr[5] > m.item_cap) {                                                       // work-item list too short
+        hipFree(m.items);
+        m.item_cap = (uint32_t)std::min<unsigned long long>(ctr[5] + ctr[5] / 4, 0xffffffffull);
+        m.items = dev_alloc<WorkItem>(m.item_cap);
+        retry = true;
+      }
+      if (retry) {
+        if (attempt >= 6) throw GpuError("workspace kept overflowing");
         if (st) st->n_retries++;
         continue;
       }

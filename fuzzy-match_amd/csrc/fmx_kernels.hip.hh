@@ -3,10 +3,11 @@
 // Stage map:
 //   k_setup   A   guards, min_subseq_length, token -> query map
 //   k_probe   C,D one lane per (query, start): range of the seed n-gram in the suffix array
-//   k_expand  D,E one wave per query: walk the ranges, length filter, LCP, ballot/prefix compaction
+//   k_expand  D,E,G one wave per (query, 2048-hit chunk): walk the ranges, length filter, LCP, coverage
+//                 bound, ballot/prefix compaction of the survivors
 //   k_cand    E,F one wave per query: max per sentence, order (longest desc, s_id asc)
-//   k_score   G,H,I one wave per query: coverage bound, float edit distance (one candidate per
-//                 lane, DP rows in LDS), sequential replay of the lowest_costs bound
+//   k_score   H,I one wave per query: float edit distance (one candidate per lane, DP rows in
+//                 LDS), sequential replay of the lowest_costs bound
 //   k_select  H,J top-N by (score desc, s_id asc) or contrastive rerank
 // All integer/compare/float-scalar work: no MFMA anywhere (HBM-latency bound probe, LDS-bound DP).
 #pragma once
@@ -49,14 +50,16 @@ struct DevWork {
   uint32_t* t_lo;       // nt   range start per (query, start)
   uint32_t* t_cnt;      // nt   range size
   unsigned long long* q_hits;  // nq   hits per query (sum of t_cnt)
-  unsigned long long* q_seg;   // nq+1 exclusive scan of q_hits
+  unsigned long long* q_cap;   // nq+1 segment capacity per query: min(hits, s_max)
+  unsigned long long* q_seg;   // nq+1 exclusive scan of q_cap
   uint32_t* q_kept;     // nq
   uint32_t* q_cand;     // nq
   uint32_t* q_acc;      // nq
   Cand*     seg;        // capacity seg_cap
   float*    heap;       // capacity seg_cap + nq (lowest_costs spill)
   unsigned long long  seg_cap;
-  unsigned long long* counters;  // [0]=hits [1]=kept [2]=cands [3]=dp [4]=overflow flag
+  unsigned long long* counters;  // [0]=hits [1]=kept [2]=cands [3]=dp [4]=max survivors of a query whose
+                                 // segment overflowed [5]=extra work items [6]=segment space needed
 };
 
 constexpr int kWave = 64;
@@ -192,78 +195,162 @@ __global__ void __launch_bounds__(kScanThreads) k_scan_add(unsigned long long* o
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_expand — one wave per query.  Walks every hit of every start position (the suffixes the
-// reference's register_suffix_range_match visits, src/ngram_matches.cc:61-83), applies the length
-// filter, drops dominated hits, computes the match length and compacts survivors into the query's
-// segment with wave ballot + prefix popcount (no atomics, deterministic order).
+// k_caps — per query: segment capacity min(hits, s_max) (input of the scan) and, for queries with
+// more than kExpandChunk hits, extra work items so that several waves share the walk.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kWave) k_expand(DevIndex ix, DevBatch b, DevWork w, Params prm) {
+constexpr uint32_t kExpandChunk = 2048;  // suffix hits per k_expand work item
+constexpr uint32_t kExpandExtraGrid = 8192;
+
+struct WorkItem {
+  uint32_t q;
+  uint32_t chunk;
+};
+
+__global__ void k_caps(DevBatch b, DevWork w, WorkItem* items, uint32_t item_cap, uint32_t s_max) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q > b.nq) return;
+  if (q == b.nq) { w.q_cap[q] = 0; return; }
+  const unsigned long long hits = w.q_m[q] == kNoMatchLen ? 0ull : w.q_hits[q];
+  w.q_cap[q] = hits < s_max ? hits : (unsigned long long)s_max;
+  w.q_kept[q] = 0;
+  if (hits > kExpandChunk) {
+    const uint32_t n_extra = (uint32_t)((hits + kExpandChunk - 1) / kExpandChunk) - 1;
+    const unsigned long long base = atomicAdd(&w.counters[5], (unsigned long long)n_extra);
+    for (uint32_t k = 0; k < n_extra; k++)
+      if (base + k < item_cap) { WorkItem it; it.q = q; it.chunk = k + 1; items[base + k] = it; }
+  }
+}
+
+// PatternCoverage::count_covered_words (src/pattern_coverage.cc:15-28) with the pattern broadcast
+// from LDS: each lane walks its own sentence once per 64 pattern positions and marks the positions
+// whose word it sees; the marked count equals the reference's sum of per-word counts.
+__device__ __forceinline__ uint32_t cover_lds(const uint32_t* __restrict__ sent, uint32_t slen,
+                                              const uint32_t* s_pat, uint32_t p) {
+  uint32_t cover = 0;
+  for (uint32_t jb = 0; jb < p; jb += 64) {
+    const uint32_t jn = p - jb < 64 ? p - jb : 64;
+    uint32_t m0 = 0, m1 = 0;
+    for (uint32_t k = 0; k < slen; k++) {
+      const uint32_t t = sent[k];
+      const uint32_t j0 = jn < 32 ? jn : 32;
+      for (uint32_t j = 0; j < j0; j++) m0 |= (t == s_pat[jb + j]) ? (1u << j) : 0u;
+      for (uint32_t j = 32; j < jn; j++) m1 |= (t == s_pat[jb + j]) ? (1u << (j - 32)) : 0u;
+    }
+    cover += __popc(m0) + __popc(m1);
+  }
+  return cover;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_expand — one wave per work item (query, chunk of kExpandChunk hits).  Walks the hits (the
+// suffixes the reference's register_suffix_range_match visits, src/ngram_matches.cc:61-83), applies
+// the length filter, drops dominated hits, computes the match length, applies the coverage bound
+// (src/fuzzy_match.cc:576-581 — it does not depend on the match length, so filtering before the
+// per-sentence max is exact) and appends survivors to the query's segment with wave ballot +
+// prefix popcount and one atomic per 64 hits.  Dynamic LDS: pat[p_max].
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kWave) k_expand(DevIndex ix, DevBatch b, DevWork w, Params prm,
+                                                  const WorkItem* items, uint32_t item_cap) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint32_t* s_pat = (uint32_t*)smem;
   __shared__ uint32_t s_pref[kWave + 1];
   __shared__ uint32_t s_lo[kWave];
-  const uint32_t q = blockIdx.x;
   const uint32_t lane = lane_id();
-  const uint32_t msl = w.q_m[q];
-  const unsigned long long hits = w.q_hits[q];
-  if (msl == kNoMatchLen || hits == 0) {
-    if (lane == 0) w.q_kept[q] = 0;
-    return;
-  }
-  const unsigned long long seg0 = w.q_seg[q];
-  if (seg0 + hits > w.seg_cap) {  // workspace too small: host re-runs the sub-batch with a larger one
-    if (lane == 0) { w.q_kept[q] = 0; atomicMax(&w.counters[4], seg0 + hits); }
-    return;
-  }
-  const uint32_t o0 = b.q_off[b.q_begin + q];
-  const uint32_t p = b.q_off[b.q_begin + q + 1] - o0;
-  const uint32_t m = seed_len(p, msl);
-  const uint32_t* pat = b.q_tok + o0;
-  const uint32_t t0 = o0 - b.t_begin;
-  Cand* seg = w.seg + seg0;
-  uint32_t n_out = 0;
-  for (uint32_t c0 = 0; c0 < p; c0 += kWave) {
-    const uint32_t it_l = c0 + lane;
-    const uint32_t mycnt = it_l < p ? w.t_cnt[t0 + it_l] : 0u;
-    const uint32_t incl = wave_incl_scan(mycnt);
-    const uint32_t total = __shfl(incl, 63, 64);
-    __syncthreads();
-    s_pref[lane] = incl - mycnt;
-    s_lo[lane] = it_l < p ? w.t_lo[t0 + it_l] : 0u;
-    if (lane == 0) s_pref[kWave] = total;
-    __syncthreads();
-    for (uint32_t h0 = 0; h0 < total; h0 += kWave) {
-      const uint32_t h = h0 + lane;
-      bool keep = h < total;
-      uint32_t sid = 0, L = 0;
-      if (keep) {
-        // largest j with s_pref[j] <= h (entries with zero count share a prefix value; the last wins)
-        uint32_t a = 0, bnd = kWave;
-        while (bnd - a > 1) {
-          const uint32_t mid = (a + bnd) >> 1;
-          if (s_pref[mid] <= h) a = mid; else bnd = mid;
-        }
-        const uint32_t it = c0 + a;
-        const uint32_t i = s_lo[a] + (h - s_pref[a]);
-        const SufRec r = ix.suf[i];
-        keep = !reject_len(p, r.slen, prm) && !dominated_hit(ix.tok, r, pat + it, it);
-        if (keep) {
-          L = lcp_extend(ix.tok, r, pat + it, m, p - it);
-          sid = ix.suf_sid[i];
-        }
-      }
-      const unsigned long long mask = __ballot(keep);
-      if (keep) {
-        const uint32_t pos = n_out + __popcll(mask & ((1ull << lane) - 1ull));
-        Cand c;
-        c.sid = sid; c.longest = L; c.score = 0.f; c.penalty = 0.f;
-        seg[pos] = c;
-      }
-      n_out += __popcll(mask);
+  uint32_t q, chunk;
+  uint32_t item_idx = 0;
+  const bool extra = blockIdx.x >= b.nq;
+  if (!extra) { q = blockIdx.x; chunk = 0; }
+  else item_idx = blockIdx.x - b.nq;
+  for (;;) {
+    if (extra) {
+      unsigned long long n_items = w.counters[5];
+      if (n_items > item_cap) n_items = item_cap;
+      if (item_idx >= n_items) return;
+      q = items[item_idx].q;
+      chunk = items[item_idx].chunk;
     }
-  }
-  if (lane == 0) {
-    w.q_kept[q] = n_out;
-    atomicAdd(&w.counters[0], hits);
-    atomicAdd(&w.counters[1], (unsigned long long)n_out);
+    const uint32_t msl = w.q_m[q];
+    const unsigned long long hits = msl == kNoMatchLen ? 0ull : w.q_hits[q];
+    if (hits != 0) {
+      const unsigned long long seg0 = w.q_seg[q];
+      const uint32_t cap = (uint32_t)(w.q_seg[q + 1] - seg0);
+      if (seg0 + cap > w.seg_cap) {  // workspace too small: host re-runs the sub-batch with a larger one
+        if (lane == 0) atomicMax(&w.counters[6], w.q_seg[b.nq]);
+      } else {
+        const uint32_t o0 = b.q_off[b.q_begin + q];
+        const uint32_t p = b.q_off[b.q_begin + q + 1] - o0;
+        const uint32_t m = seed_len(p, msl);
+        const uint32_t* pat = b.q_tok + o0;
+        const uint32_t t0 = o0 - b.t_begin;
+        __syncthreads();
+        for (uint32_t j = lane; j < p; j += kWave) s_pat[j] = pat[j];
+        Cand* seg = w.seg + seg0;
+        const unsigned long long h_lo = (unsigned long long)chunk * kExpandChunk;
+        const unsigned long long h_hi = h_lo + kExpandChunk < hits ? h_lo + kExpandChunk : hits;
+        unsigned long long base_h = 0;  // hits of the start positions before c0
+        uint32_t n_out = 0;
+        for (uint32_t c0 = 0; c0 < p && base_h < h_hi; c0 += kWave) {
+          const uint32_t it_l = c0 + lane;
+          const uint32_t mycnt = it_l < p ? w.t_cnt[t0 + it_l] : 0u;
+          const uint32_t incl = wave_incl_scan(mycnt);
+          const uint32_t total = __shfl(incl, 63, 64);
+          __syncthreads();
+          s_pref[lane] = incl - mycnt;
+          s_lo[lane] = it_l < p ? w.t_lo[t0 + it_l] : 0u;
+          if (lane == 0) s_pref[kWave] = total;
+          __syncthreads();
+          // hits [base_h, base_h + total) belong to this block of start positions; clip to the chunk
+          const unsigned long long a0 = h_lo > base_h ? h_lo - base_h : 0ull;
+          const unsigned long long a1 = h_hi - base_h < total ? h_hi - base_h : (unsigned long long)total;
+          for (unsigned long long hh = a0; hh < a1; hh += kWave) {
+            const uint32_t h = (uint32_t)hh + lane;
+            bool keep = h < (uint32_t)a1;
+            uint32_t sid = 0, L = 0;
+            if (keep) {
+              // largest j with s_pref[j] <= h (entries with zero count share a prefix value; the last wins)
+              uint32_t a = 0, bnd = kWave;
+              while (bnd - a > 1) {
+                const uint32_t mid = (a + bnd) >> 1;
+                if (s_pref[mid] <= h) a = mid; else bnd = mid;
+              }
+              const uint32_t it = c0 + a;
+              const uint32_t i = s_lo[a] + (h - s_pref[a]);
+              const SufRec r = ix.suf[i];
+              keep = !reject_len(p, r.slen, prm) && !dominated_hit(ix.tok, r, pat + it, it);
+              if (keep) {
+                L = lcp_extend(ix.tok, r, pat + it, m, p - it);
+                const uint32_t cover = L < p ? cover_lds(ix.tok + (r.off - (uint32_t)(r.slen - r.rem)), r.slen, s_pat, p) : p;
+                keep = !reject_cover(p, r.slen, cover, prm);
+                if (keep) sid = ix.suf_sid[i];
+              }
+            }
+            const unsigned long long mask = __ballot(keep);
+            if (mask) {
+              const uint32_t cnt = __popcll(mask);
+              uint32_t base = 0;
+              if (lane == 0) base = atomicAdd(&w.q_kept[q], cnt);
+              base = __shfl(base, 0, 64);
+              if (keep) {
+                const uint32_t pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+                if (pos < cap) {
+                  Cand c;
+                  c.sid = sid; c.longest = L; c.score = 0.f; c.penalty = 0.f;
+                  seg[pos] = c;
+                }
+              }
+              n_out += cnt;
+            }
+          }
+          base_h += total;
+        }
+        if (lane == 0) {
+          atomicAdd(&w.counters[0], h_hi - h_lo);
+          atomicAdd(&w.counters[1], (unsigned long long)n_out);
+        }
+      }
+    }
+    if (!extra) return;
+    item_idx += kExpandExtraGrid;
   }
 }
 
@@ -315,6 +402,10 @@ __global__ void __launch_bounds__(kWave) k_cand(DevWork w, unsigned long long* b
     if (lane == 0) w.q_cand[q] = 0;
     return;
   }
+  if ((unsigned long long)n > w.q_seg[q + 1] - w.q_seg[q]) {  // more survivors than the segment holds
+    if (lane == 0) { w.q_cand[q] = 0; atomicMax(&w.counters[4], (unsigned long long)n); }
+    return;
+  }
   Cand* seg = w.seg + w.q_seg[q];
   const uint32_t np2 = next_pow2(n);
   const bool in_lds = np2 <= kLdsSortMax;
@@ -357,9 +448,8 @@ __global__ void __launch_bounds__(kWave) k_cand(DevWork w, unsigned long long* b
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_score — one wave per query, candidates in reference order, 64 at a time: coverage bound
-// (src/pattern_coverage.cc:15-28, src/ngram_matches.cc:41-59), float edit distance with one
-// candidate per lane and its DP row strided through LDS (bank = lane, conflict free), then lane 0
+// k_score — one wave per query, candidates in reference order, 64 at a time: float edit distance
+// (src/edit_distance.cc:5-77) with one candidate per lane and its DP row strided through LDS (bank = lane, conflict free), then lane 0
 // replays the order-dependent lowest_costs logic (src/fuzzy_match.cc:587-610) over the chunk.
 // The bound it leaves is handed to the next chunk as a safe early-exit threshold (the bound never
 // increases).  Accepted matches overwrite the head of the query's segment.
@@ -420,9 +510,8 @@ __global__ void __launch_bounds__(kWave) k_score(DevIndex ix, DevBatch b, DevWor
       const uint32_t sp = ix.sent_pos[sid];
       slen = ix.tok[sp];
       const uint32_t* sent = ix.tok + sp + 1;
-      const uint32_t cover = L < p ? cover_count(sent, slen, s_pat, p) : p;
-      pass = !reject_cover(p, slen, cover, prm);
-      if (pass) {
+      pass = true;  // the coverage bound was applied in k_expand
+      {
         const float dw = 100.f / normalizer(p, slen, prm.ins, prm.del, prm.rep);
         if (FULL) {
           if (ix.real) {

@@ -702,7 +702,10 @@ static inline uint32_t int_hash(uint32_t x) { /* IntHash, ngram_matches.hh:9-17 
 }
 
 static void hash_reset(fmo_scratch* s) {
-  if (!s->hcap) {
+  /* a fresh map per query, like the reference's NGramMatches member: a table grown by one wide
+   * query is dropped instead of being cleared for every later query */
+  if (!s->hcap || s->hcap > 4096) {
+    free(s->hkey); free(s->hval);
     s->hcap = 1024;
     s->hkey = (uint32_t*)calloc(s->hcap, sizeof(uint32_t));
     s->hval = (uint32_t*)xrealloc(NULL, s->hcap * sizeof(uint32_t));

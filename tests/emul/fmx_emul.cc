@@ -52,8 +52,12 @@ extern "C" int emul_match_batch(const EmulIndex* ix, const Params* prm_in, uint6
         const SufRec r = ix->suf[i];
         if (reject_len(p, r.slen, prm) || dominated_hit(ix->tok, r, pat + it, it)) continue;
         Cand c;
-        c.sid = ix->suf_sid[i];
         c.longest = lcp_extend(ix->tok, r, pat + it, m, p - it);
+        // coverage bound in k_expand: independent of the match length, so it commutes with the max
+        const uint32_t* sent0 = ix->tok + (r.off - (uint32_t)(r.slen - r.rem));
+        const uint32_t cov = c.longest < p ? cover_count(sent0, r.slen, pat, p) : p;
+        if (reject_cover(p, r.slen, cov, prm)) continue;
+        c.sid = ix->suf_sid[i];
         c.score = c.penalty = 0.f;
         seg.push_back(c);
       }
@@ -99,8 +103,7 @@ extern "C" int emul_match_batch(const EmulIndex* ix, const Params* prm_in, uint6
         const uint32_t sp = ix->sent_pos[c.sid];
         const uint32_t slen = ix->tok[sp];
         const uint32_t* sent = ix->tok + sp + 1;
-        const uint32_t cover = c.longest < p ? cover_count(sent, slen, pat, p) : p;
-        bool pass = !reject_cover(p, slen, cover, prm);
+        bool pass = true;
         float final_cost = 0.f, M = 0.f;
         if (pass) {
           const float dw = 100.f / normalizer(p, slen, prm.ins, prm.del, prm.rep);
