@@ -183,6 +183,19 @@ FMX_HD bool dominated_hit(const uint32_t* __restrict__ tok, SufRec r, const uint
   return it > 0 && r.rem < r.slen && tok[r.off - 1] == pat_at_it[-1];
 }
 
+// 64-bit word signature of a sentence: bit sig_bit(w) is set for every word w of the sentence.  For a
+// pattern, the number of positions whose word's bit is set is an upper bound of
+// PatternCoverage::count_covered_words, and theoretical_rejection_cover is monotone in the cover
+// (for non-negative costs), so a candidate rejected with the upper bound is rejected by the
+// reference too: the exact token scan only runs for the few that pass.
+FMX_HD uint32_t sig_bit(uint32_t w) { return (w * 0x9E3779B1u) >> 26; }
+
+FMX_HD uint32_t sig_cover_upper(unsigned long long sig, const uint8_t* __restrict__ hbit, uint32_t p) {
+  uint32_t c = 0;
+  for (uint32_t j = 0; j < p; j++) c += (uint32_t)((sig >> hbit[j]) & 1ull);
+  return c;
+}
+
 // PatternCoverage::count_covered_words (src/pattern_coverage.cc:15-28): the sum of counts of the
 // distinct pattern words present in the sentence == number of pattern positions whose word
 // occurs in the sentence.

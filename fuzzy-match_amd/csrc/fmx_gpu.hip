@@ -85,7 +85,7 @@ DeviceIndex::DeviceIndex() : impl_(new Impl) {}
 
 static void free_ws(DeviceIndex::Impl& m) {
   hipFree(m.w.q_m); hipFree(m.w.t_q); hipFree(m.w.t_lo); hipFree(m.w.t_cnt); hipFree(m.w.q_hits);
-  hipFree(m.w.q_seg); hipFree(m.w.q_kept); hipFree(m.w.q_cand); hipFree(m.w.q_acc);
+  hipFree(m.w.q_seg); hipFree(m.w.q_kept); hipFree(m.w.q_cand); hipFree(m.w.q_acc); hipFree(m.w.q_dp);
   hipFree(m.w.seg); hipFree(m.w.heap); hipFree(m.w.counters);
   hipFree(m.sc.keys); hipFree(m.sc.vals); hipFree(m.sc.f0); hipFree(m.sc.f1);
   hipFree(m.tile_sums); hipFree(m.grand_total); hipFree(m.w.q_cap);
@@ -99,7 +99,7 @@ DeviceIndex::~DeviceIndex() {
   Impl& m = *impl_;
   if (m.device >= 0) {
     (void)hipSetDevice(m.device);
-    hipFree((void*)m.d.suf); hipFree((void*)m.d.suf_sid); hipFree((void*)m.d.tok); hipFree((void*)m.d.sent_pos);
+    hipFree((void*)m.d.suf); hipFree((void*)m.d.suf_sig); hipFree((void*)m.d.suf_sid); hipFree((void*)m.d.tok); hipFree((void*)m.d.sent_pos);
     hipFree((void*)m.d.qva); hipFree((void*)m.d.idf); hipFree((void*)m.d.real); hipFree((void*)m.d.itok);
     hipFree((void*)m.d.itok_dist);
     free_ws(m);
@@ -132,6 +132,7 @@ void DeviceIndex::upload(const HostIndex& h, int device) {
   m.device = device;
   m.d.suf = dev_upload(h.suf_rec);
   m.d.suf_sid = dev_upload(h.suf_sid);
+  m.d.suf_sig = (const unsigned long long*)dev_upload(h.suf_sig);
   m.d.tok = dev_upload(h.buf);
   m.d.sent_pos = dev_upload(h.sent_pos);
   m.d.qva = dev_upload(h.qva);
@@ -142,7 +143,7 @@ void DeviceIndex::upload(const HostIndex& h, int device) {
   uint32_t mx = 0;
   for (uint32_t sp : h.sent_pos) mx = std::max(mx, h.buf[sp]);
   m.d.max_slen = mx;
-  m.bytes = h.suf_rec.size() * 8 + h.suf_sid.size() * 4 + h.buf.size() * 4 + h.sent_pos.size() * 4 +
+  m.bytes = h.suf_rec.size() * 8 + h.suf_sig.size() * 8 + h.suf_sid.size() * 4 + h.buf.size() * 4 + h.sent_pos.size() * 4 +
             h.qva.size() * 4 + h.idf.size() * 4;
   if (h.real_differs) {
     m.d.real = dev_upload(h.real_ids);
@@ -169,6 +170,7 @@ static void ensure_ws(DeviceIndex::Impl& m, uint64_t nq, uint64_t nt, uint64_t s
     m.w.q_kept = dev_alloc<uint32_t>(cq);
     m.w.q_cand = dev_alloc<uint32_t>(cq);
     m.w.q_acc = dev_alloc<uint32_t>(cq);
+    m.w.q_dp = dev_alloc<uint32_t>(cq);
     m.w.seg = dev_alloc<Cand>(cs);
     m.w.heap = dev_alloc<float>(cs + cq + 1);
     m.w.counters = dev_alloc<unsigned long long>(8);
@@ -235,10 +237,12 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm_in, const D
       }
       tick(); tick();
       {
-        const size_t lds = (size_t)p_max * 4;
+        const size_t lds = (size_t)p_max * 5 + 16;
         if (lds > 64 * 1024) throw GpuError("patterns too long for the expand kernel's LDS staging");
+        // the signature bound needs theoretical_rejection_cover to be monotone in the cover: costs >= 0
+        const int use_sig = prm.ins >= 0.f && prm.del >= 0.f && prm.rep >= 0.f;
         hipLaunchKernelGGL(k_expand, dim3(b.nq + kExpandExtraGrid), dim3(kWave), lds, stream, m.d, b, w, prm,
-                           (const WorkItem*)m.items, m.item_cap);
+                           (const WorkItem*)m.items, m.item_cap, p_max, use_sig);
       }
       tick(); tick();
       hipLaunchKernelGGL(k_cand, dim3(b.nq), dim3(kWave), 0, stream, w, m.sc.keys);
@@ -267,6 +271,7 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm_in, const D
                            d_out_count, d_out_total);
       }
       tick();
+      hipLaunchKernelGGL(k_stats, dim3((b.nq + 255) / 256), dim3(256), 0, stream, w, b.nq);
       HIP_TRY(hipGetLastError());
       unsigned long long ctr[8];
       HIP_TRY(hipMemcpyAsync(ctr, w.counters, sizeof(ctr), hipMemcpyDeviceToHost, stream));

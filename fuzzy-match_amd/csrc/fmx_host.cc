@@ -291,6 +291,17 @@ void HostIndex::derive() {
     r.rem = (uint16_t)(slen - (suf_pos[i] - 1u));
     suf_rec[i] = r;
   }
+  {
+    std::vector<uint64_t> sent_sig(sent_pos.size(), 0);
+    for (size_t sdx = 0; sdx < sent_pos.size(); sdx++) {
+      const uint32_t sp = sent_pos[sdx], len = buf[sp];
+      uint64_t sg = 0;
+      for (uint32_t k = 0; k < len; k++) sg |= 1ull << sig_bit(buf[sp + 1 + k]);
+      sent_sig[sdx] = sg;
+    }
+    suf_sig.resize(n);
+    for (uint64_t i = 0; i < n; i++) suf_sig[i] = sent_sig[suf_sid[i]];
+  }
   // compute_idf_penalty / compute_max_idf_penalty — src/fuzzy_match.cc:367-390 (glibc logf / log)
   const unsigned N = num_sentences();
   idf.assign(vocab_size, 0.f);

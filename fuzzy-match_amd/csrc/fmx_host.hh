@@ -46,6 +46,7 @@ class HostIndex {
 
   // ---- derived (derive()) ----
   std::vector<SufRec>   suf_rec;   // one 8-byte record per suffix, suffix-array order
+  std::vector<uint64_t> suf_sig;   // 64-bit word signature of the suffix's sentence (coverage pre-filter)
   std::vector<float>    idf;       // logf(N / sfreq[w]) per word id (src/fuzzy_match.cc:384)
   float                 idf_max = 0.01f;
   bool                  real_differs = false;  // some sentence has real tokens != its normalised tokens, or itoks

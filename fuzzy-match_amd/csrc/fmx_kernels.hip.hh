@@ -18,6 +18,7 @@ namespace fmx {
 
 struct DevIndex {
   const SufRec*   suf;
+  const unsigned long long* suf_sig;  // word signature of the suffix's sentence
   const uint32_t* suf_sid;
   const uint32_t* tok;
   const uint32_t* sent_pos;
@@ -55,6 +56,7 @@ struct DevWork {
   uint32_t* q_kept;     // nq
   uint32_t* q_cand;     // nq
   uint32_t* q_acc;      // nq
+  uint32_t* q_dp;       // nq   edit distances evaluated (statistics)
   Cand*     seg;        // capacity seg_cap
   float*    heap;       // capacity seg_cap + nq (lowest_costs spill)
   unsigned long long  seg_cap;
@@ -247,12 +249,14 @@ __device__ __forceinline__ uint32_t cover_lds(const uint32_t* __restrict__ sent,
 // the length filter, drops dominated hits, computes the match length, applies the coverage bound
 // (src/fuzzy_match.cc:576-581 — it does not depend on the match length, so filtering before the
 // per-sentence max is exact) and appends survivors to the query's segment with wave ballot +
-// prefix popcount and one atomic per 64 hits.  Dynamic LDS: pat[p_max].
+// prefix popcount and one atomic per 64 hits.  Dynamic LDS: pat[p_max] | hbit[p_max] (u8).
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kWave) k_expand(DevIndex ix, DevBatch b, DevWork w, Params prm,
-                                                  const WorkItem* items, uint32_t item_cap) {
+                                                  const WorkItem* items, uint32_t item_cap, uint32_t p_max,
+                                                  int use_sig) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t* s_pat = (uint32_t*)smem;
+  uint8_t*  s_hbit = (uint8_t*)(s_pat + p_max);
   __shared__ uint32_t s_pref[kWave + 1];
   __shared__ uint32_t s_lo[kWave];
   const uint32_t lane = lane_id();
@@ -283,7 +287,8 @@ __global__ void __launch_bounds__(kWave) k_expand(DevIndex ix, DevBatch b, DevWo
         const uint32_t* pat = b.q_tok + o0;
         const uint32_t t0 = o0 - b.t_begin;
         __syncthreads();
-        for (uint32_t j = lane; j < p; j += kWave) s_pat[j] = pat[j];
+        for (uint32_t j = lane; j < p; j += kWave) { const uint32_t wd = pat[j]; s_pat[j] = wd; s_hbit[j] = (uint8_t)sig_bit(wd); }
+        __syncthreads();
         Cand* seg = w.seg + seg0;
         const unsigned long long h_lo = (unsigned long long)chunk * kExpandChunk;
         const unsigned long long h_hi = h_lo + kExpandChunk < hits ? h_lo + kExpandChunk : hits;
@@ -316,7 +321,10 @@ __global__ void __launch_bounds__(kWave) k_expand(DevIndex ix, DevBatch b, DevWo
               const uint32_t it = c0 + a;
               const uint32_t i = s_lo[a] + (h - s_pref[a]);
               const SufRec r = ix.suf[i];
-              keep = !reject_len(p, r.slen, prm) && !dominated_hit(ix.tok, r, pat + it, it);
+              keep = !reject_len(p, r.slen, prm);
+              // coverage bound with the signature's upper bound first: no token is touched for most hits
+              if (keep && use_sig) keep = !reject_cover(p, r.slen, sig_cover_upper(ix.suf_sig[i], s_hbit, p), prm);
+              if (keep) keep = !dominated_hit(ix.tok, r, pat + it, it);
               if (keep) {
                 L = lcp_extend(ix.tok, r, pat + it, m, p - it);
                 const uint32_t cover = L < p ? cover_lds(ix.tok + (r.off - (uint32_t)(r.slen - r.rem)), r.slen, s_pat, p) : p;
@@ -343,10 +351,7 @@ __global__ void __launch_bounds__(kWave) k_expand(DevIndex ix, DevBatch b, DevWo
           }
           base_h += total;
         }
-        if (lane == 0) {
-          atomicAdd(&w.counters[0], h_hi - h_lo);
-          atomicAdd(&w.counters[1], (unsigned long long)n_out);
-        }
+        (void)n_out;
       }
     }
     if (!extra) return;
@@ -355,17 +360,19 @@ __global__ void __launch_bounds__(kWave) k_expand(DevIndex ix, DevBatch b, DevWo
 }
 
 // ---------------------------------------------------------------------------------------------
-// bitonic sort of n (power of two) 64-bit keys by one wave; K is any accessor with operator[]
+// bitonic sorts by one wave.  The key/value storage is a template parameter so that the LDS
+// instantiation compiles to ds_read/ds_write: selecting between an LDS and a global pointer at
+// run time would turn every access into a (slow) flat operation.
 // ---------------------------------------------------------------------------------------------
 template <class K>
-__device__ __forceinline__ void wave_bitonic_sort(K keys, uint32_t n_pow2) {
+__device__ __forceinline__ void wave_bitonic_sort(K* keys, uint32_t n_pow2) {
   const uint32_t lane = lane_id();
   for (uint32_t k = 2; k <= n_pow2; k <<= 1) {
     for (uint32_t j = k >> 1; j > 0; j >>= 1) {
       for (uint32_t i = lane; i < n_pow2; i += kWave) {
         const uint32_t ixj = i ^ j;
         if (ixj > i) {
-          const unsigned long long a = keys[i], c = keys[ixj];
+          const K a = keys[i], c = keys[ixj];
           const bool up = (i & k) == 0;
           if ((a > c) == up) { keys[i] = c; keys[ixj] = a; }
         }
@@ -375,10 +382,27 @@ __device__ __forceinline__ void wave_bitonic_sort(K keys, uint32_t n_pow2) {
   }
 }
 
-struct GlobalKeys {
-  unsigned long long* p;
-  __device__ __forceinline__ unsigned long long& operator[](uint32_t i) const { return p[i]; }
-};
+template <class K, class V>
+__device__ __forceinline__ void wave_bitonic_sort_kv(K* keys, V* vals, uint32_t n_pow2) {
+  const uint32_t lane = lane_id();
+  for (uint32_t k = 2; k <= n_pow2; k <<= 1) {
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      for (uint32_t i = lane; i < n_pow2; i += kWave) {
+        const uint32_t ixj = i ^ j;
+        if (ixj > i) {
+          const K a = keys[i], c = keys[ixj];
+          const bool up = (i & k) == 0;
+          if ((a > c) == up) {
+            keys[i] = c; keys[ixj] = a;
+            const V va = vals[i], vc = vals[ixj];
+            vals[i] = vc; vals[ixj] = va;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
 
 __device__ __forceinline__ uint32_t next_pow2(uint32_t n) {
   uint32_t v = 1;
@@ -390,31 +414,15 @@ __device__ __forceinline__ uint32_t next_pow2(uint32_t n) {
 // k_cand — one wave per query: LongestMatches semantics (max match length per sentence,
 // src/ngram_matches.cc:79-81) then get_longest_matches order (longest desc, s_id asc,
 // src/ngram_matches.cc:19-29).  Two key sorts: (sid, L) to find each sentence's max, then
-// (~L, sid).  Up to kLdsSortMax hits are sorted in LDS; larger sets spill to the global key
-// scratch `big` (slow path, rare).
+// (~L, sid).  Up to kLdsSortMax survivors are sorted in LDS; larger sets use the global key
+// scratch (slow path, rare: the coverage bound has already run).
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kWave) k_cand(DevWork w, unsigned long long* big) {
-  __shared__ unsigned long long s_keys[kLdsSortMax];
-  const uint32_t q = blockIdx.x;
+__device__ __forceinline__ uint32_t cand_body(unsigned long long* keys, Cand* seg, uint32_t n, uint32_t np2) {
   const uint32_t lane = lane_id();
-  const uint32_t n = w.q_kept[q];
-  if (n == 0) {
-    if (lane == 0) w.q_cand[q] = 0;
-    return;
-  }
-  if ((unsigned long long)n > w.q_seg[q + 1] - w.q_seg[q]) {  // more survivors than the segment holds
-    if (lane == 0) { w.q_cand[q] = 0; atomicMax(&w.counters[4], (unsigned long long)n); }
-    return;
-  }
-  Cand* seg = w.seg + w.q_seg[q];
-  const uint32_t np2 = next_pow2(n);
-  const bool in_lds = np2 <= kLdsSortMax;
-  // the global scratch mirrors the segment layout at 2x (pow2 padding): 2 * q_seg[q]
-  unsigned long long* keys = in_lds ? s_keys : big + 2ull * w.q_seg[q];
   for (uint32_t i = lane; i < np2; i += kWave)
     keys[i] = i < n ? (((unsigned long long)seg[i].sid << 16) | (seg[i].longest & 0xffffu)) : ~0ull;
   __syncthreads();
-  if (in_lds) wave_bitonic_sort(s_keys, np2); else wave_bitonic_sort(GlobalKeys{keys}, np2);
+  wave_bitonic_sort(keys, np2);
   // keep the last entry of each sentence group (its largest L); rewrite as (0xffff - L, sid)
   uint32_t kept = 0;
   for (uint32_t i0 = 0; i0 < np2; i0 += kWave) {
@@ -432,7 +440,7 @@ __global__ void __launch_bounds__(kWave) k_cand(DevWork w, unsigned long long* b
     kept += __popcll(__ballot(keep));
     __syncthreads();
   }
-  if (in_lds) wave_bitonic_sort(s_keys, np2); else wave_bitonic_sort(GlobalKeys{keys}, np2);
+  wave_bitonic_sort(keys, np2);
   for (uint32_t i = lane; i < kept; i += kWave) {
     const unsigned long long a = keys[i];
     Cand c;
@@ -441,24 +449,117 @@ __global__ void __launch_bounds__(kWave) k_cand(DevWork w, unsigned long long* b
     c.score = 0.f; c.penalty = 0.f;
     seg[i] = c;
   }
-  if (lane == 0) {
-    w.q_cand[q] = kept;
-    atomicAdd(&w.counters[2], (unsigned long long)kept);
+  return kept;
+}
+
+__global__ void __launch_bounds__(kWave) k_cand(DevWork w, unsigned long long* big) {
+  __shared__ unsigned long long s_keys[kLdsSortMax];
+  const uint32_t q = blockIdx.x;
+  const uint32_t lane = lane_id();
+  const uint32_t n = w.q_kept[q];
+  if (n == 0) {
+    if (lane == 0) w.q_cand[q] = 0;
+    return;
   }
+  if ((unsigned long long)n > w.q_seg[q + 1] - w.q_seg[q]) {  // more survivors than the segment holds
+    if (lane == 0) { w.q_cand[q] = 0; atomicMax(&w.counters[4], (unsigned long long)n); }
+    return;
+  }
+  Cand* seg = w.seg + w.q_seg[q];
+  const uint32_t np2 = next_pow2(n);
+  uint32_t kept;
+  // the global scratch mirrors the segment layout at 2x (pow2 padding): 2 * q_seg[q]
+  if (np2 <= kLdsSortMax) kept = cand_body(s_keys, seg, n, np2);
+  else kept = cand_body(big + 2ull * w.q_seg[q], seg, n, np2);
+  if (lane == 0) w.q_cand[q] = kept;
 }
 
 // ---------------------------------------------------------------------------------------------
 // k_score — one wave per query, candidates in reference order, 64 at a time: float edit distance
-// (src/edit_distance.cc:5-77) with one candidate per lane and its DP row strided through LDS (bank = lane, conflict free), then lane 0
-// replays the order-dependent lowest_costs logic (src/fuzzy_match.cc:587-610) over the chunk.
-// The bound it leaves is handed to the next chunk as a safe early-exit threshold (the bound never
-// increases).  Accepted matches overwrite the head of the query's segment.
-// Dynamic LDS: pat[p_max] | idf[p_max] | rows[(p_max+1)*64] floats.
+// (src/edit_distance.cc:5-77) with one candidate per lane and its DP row strided through LDS
+// (bank = lane, conflict free), then lane 0 replays the order-dependent lowest_costs logic
+// (src/fuzzy_match.cc:587-610) over the chunk.  The bound it leaves is handed to the next chunk as
+// a safe early-exit threshold (the bound never increases).  Accepted matches overwrite the head of
+// the query's segment.  Dynamic LDS: pat[p_max] | idf[p_max] | rows[(p_max+1)*64] floats.
 // ---------------------------------------------------------------------------------------------
 struct LdsRow {
   float* base;
   __device__ __forceinline__ float& operator[](uint32_t j) const { return base[j * kWave]; }
 };
+
+struct ScoreShared {
+  float    final_cost[kWave], M[kWave];
+  uint32_t sid[kWave], L[kWave], slen[kWave];
+  float    ub;
+};
+
+template <bool FULL>
+__device__ __forceinline__ uint32_t score_body(const DevIndex& ix, const DevBatch& b, const Params& prm, uint32_t q,
+                                               uint32_t o0, uint32_t p, uint32_t n_cand, Cand* seg, float* heap_store,
+                                               const uint32_t* s_pat, const float* s_idf, float* s_rows,
+                                               ScoreShared& sh, uint32_t& n_dp_out) {
+  const uint32_t lane = lane_id();
+  const bool use_idf = prm.idf_penalty != 0.f;
+  CostHeap heap;
+  heap.v = heap_store;
+  heap.n = 0;
+  if (lane == 0) { heap.push(FLT_MAX); sh.ub = FLT_MAX; }
+  __syncthreads();
+  uint32_t acc = 0, n_dp = 0;
+  DpSide side;
+  side.s_real = nullptr; side.p_real = nullptr; side.s_itok = nullptr; side.p_itok = nullptr;
+  side.itok_dist = nullptr; side.n_itok = 0; side.p_idf = nullptr; side.idf_weight = 0.f;
+  for (uint32_t c0 = 0; c0 < n_cand; c0 += kWave) {
+    const uint32_t c = c0 + lane;
+    float final_cost = 0.f, M = 0.f;
+    uint32_t sid = 0, L = 0, slen = 0;
+    if (c < n_cand) {  // the coverage bound was applied in k_expand: every candidate gets its DP
+      sid = seg[c].sid;
+      L = seg[c].longest;
+      const uint32_t sp = ix.sent_pos[sid];
+      slen = ix.tok[sp];
+      const uint32_t* sent = ix.tok + sp + 1;
+      const float dw = 100.f / normalizer(p, slen, prm.ins, prm.del, prm.rep);
+      if (FULL) {
+        if (ix.real) {
+          side.s_real = ix.real + sp + 1;
+          side.p_real = b.q_real ? b.q_real + o0 : nullptr;
+          if (!side.p_real) side.s_real = nullptr;
+        }
+        if (ix.itok_dist) {
+          side.itok_dist = ix.itok_dist;
+          side.n_itok = ix.n_itok;
+          side.s_itok = ix.itok ? ix.itok + sp : nullptr;
+          side.p_itok = b.q_itok ? b.q_itok + o0 + (b.q_begin + q) : nullptr;
+        }
+        if (use_idf) {
+          side.p_idf = s_idf;
+          side.idf_weight = (dw * prm.idf_penalty) / prm.idf_max;  // src/fuzzy_match.cc:591
+        }
+      }
+      final_cost = edit_distance<FULL>(sent, slen, s_pat, p, prm.ins, prm.del, prm.rep, dw, side, sh.ub,
+                                       LdsRow{s_rows + lane}, M);
+      n_dp++;
+    }
+    sh.final_cost[lane] = final_cost; sh.M[lane] = M; sh.sid[lane] = sid; sh.L[lane] = L; sh.slen[lane] = slen;
+    __syncthreads();
+    if (lane == 0) {
+      const uint32_t lim = n_cand - c0 < kWave ? n_cand - c0 : kWave;
+      for (uint32_t k = 0; k < lim; k++) {
+        float score;
+        if (replay_candidate(heap, prm, p, sh.slen[k], sh.final_cost[k], sh.M[k], score)) {
+          Cand a;
+          a.sid = sh.sid[k]; a.longest = sh.L[k]; a.score = score; a.penalty = 0.f;
+          seg[acc++] = a;
+        }
+      }
+      sh.ub = heap.top();
+    }
+    __syncthreads();
+  }
+  n_dp_out = n_dp;
+  return acc;
+}
 
 template <bool FULL>
 __global__ void __launch_bounds__(kWave) k_score(DevIndex ix, DevBatch b, DevWork w, Params prm, uint32_t p_max) {
@@ -466,16 +567,13 @@ __global__ void __launch_bounds__(kWave) k_score(DevIndex ix, DevBatch b, DevWor
   uint32_t* s_pat = (uint32_t*)smem;
   float*    s_idf = (float*)(s_pat + p_max);
   float*    s_rows = s_idf + p_max;
-  __shared__ float    s_final[kWave], s_M[kWave];
-  __shared__ uint32_t s_sid[kWave], s_L[kWave], s_slen[kWave];
-  __shared__ uint32_t s_pass[kWave];
-  __shared__ float    s_heap[kHeapLdsMax + 2];
-  __shared__ float    s_ub;
+  __shared__ ScoreShared sh;
+  __shared__ float s_heap[kHeapLdsMax + 2];
   const uint32_t q = blockIdx.x;
   const uint32_t lane = lane_id();
   const uint32_t n_cand = w.q_cand[q];
   if (n_cand == 0) {
-    if (lane == 0) w.q_acc[q] = 0;
+    if (lane == 0) { w.q_acc[q] = 0; w.q_dp[q] = 0; }
     return;
   }
   const uint32_t o0 = b.q_off[b.q_begin + q];
@@ -489,75 +587,13 @@ __global__ void __launch_bounds__(kWave) k_score(DevIndex ix, DevBatch b, DevWor
     s_idf[j] = (use_idf && wd + 1 < ix.n_qva && wd != 1u) ? ix.idf[wd] : 0.f;
   }
   Cand* seg = w.seg + w.q_seg[q];
-  const bool heap_in_lds = prm.cbuf > 0 && prm.cbuf <= (int)kHeapLdsMax;
-  CostHeap heap;
-  heap.v = heap_in_lds ? s_heap : (w.heap + w.q_seg[q] + q);
-  heap.n = 0;
-  if (lane == 0) { heap.push(FLT_MAX); s_ub = FLT_MAX; }
-  __syncthreads();
-  uint32_t acc = 0, n_dp = 0;
-  DpSide side;
-  side.s_real = nullptr; side.p_real = nullptr; side.s_itok = nullptr; side.p_itok = nullptr;
-  side.itok_dist = nullptr; side.n_itok = 0; side.p_idf = nullptr; side.idf_weight = 0.f;
-  for (uint32_t c0 = 0; c0 < n_cand; c0 += kWave) {
-    const uint32_t c = c0 + lane;
-    bool pass = false;
-    float final_cost = 0.f, M = 0.f;
-    uint32_t sid = 0, L = 0, slen = 0;
-    if (c < n_cand) {
-      sid = seg[c].sid;
-      L = seg[c].longest;
-      const uint32_t sp = ix.sent_pos[sid];
-      slen = ix.tok[sp];
-      const uint32_t* sent = ix.tok + sp + 1;
-      pass = true;  // the coverage bound was applied in k_expand
-      {
-        const float dw = 100.f / normalizer(p, slen, prm.ins, prm.del, prm.rep);
-        if (FULL) {
-          if (ix.real) {
-            side.s_real = ix.real + sp + 1;
-            side.p_real = b.q_real ? b.q_real + o0 : nullptr;
-            if (!side.p_real) side.s_real = nullptr;
-          }
-          if (ix.itok_dist) {
-            side.itok_dist = ix.itok_dist;
-            side.n_itok = ix.n_itok;
-            side.s_itok = ix.itok ? ix.itok + sp : nullptr;
-            side.p_itok = b.q_itok ? b.q_itok + o0 + (b.q_begin + q) : nullptr;
-          }
-          if (use_idf) {
-            side.p_idf = s_idf;
-            side.idf_weight = (dw * prm.idf_penalty) / prm.idf_max;  // src/fuzzy_match.cc:591
-          }
-        }
-        final_cost = edit_distance<FULL>(sent, slen, s_pat, p, prm.ins, prm.del, prm.rep, dw, side, s_ub,
-                                         LdsRow{s_rows + lane}, M);
-        n_dp++;
-      }
-    }
-    s_final[lane] = final_cost; s_M[lane] = M; s_sid[lane] = sid; s_L[lane] = L; s_slen[lane] = slen;
-    s_pass[lane] = pass ? 1u : 0u;
-    __syncthreads();
-    if (lane == 0) {
-      const uint32_t lim = n_cand - c0 < kWave ? n_cand - c0 : kWave;
-      for (uint32_t k = 0; k < lim; k++) {
-        if (!s_pass[k]) continue;
-        float score;
-        if (replay_candidate(heap, prm, p, s_slen[k], s_final[k], s_M[k], score)) {
-          Cand a;
-          a.sid = s_sid[k]; a.longest = s_L[k]; a.score = score; a.penalty = 0.f;
-          seg[acc++] = a;
-        }
-      }
-      s_ub = heap.top();
-    }
-    __syncthreads();
-  }
+  uint32_t n_dp = 0, acc;
+  if (prm.cbuf > 0 && prm.cbuf <= (int)kHeapLdsMax)
+    acc = score_body<FULL>(ix, b, prm, q, o0, p, n_cand, seg, s_heap, s_pat, s_idf, s_rows, sh, n_dp);
+  else
+    acc = score_body<FULL>(ix, b, prm, q, o0, p, n_cand, seg, w.heap + w.q_seg[q] + q, s_pat, s_idf, s_rows, sh, n_dp);
   n_dp = wave_sum(n_dp);
-  if (lane == 0) {
-    w.q_acc[q] = acc;
-    atomicAdd(&w.counters[3], (unsigned long long)n_dp);
-  }
+  if (lane == 0) { w.q_acc[q] = acc; w.q_dp[q] = n_dp; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -565,7 +601,7 @@ __global__ void __launch_bounds__(kWave) k_score(DevIndex ix, DevBatch b, DevWor
 // CompareMatch src/fuzzy_match.cc:25-33) via a key/value sort, then either the plain top-N
 // (src/fuzzy_match.cc:670-679) or the contrastive rerank (:614-669) with the ids-only edit
 // distance (src/edit_distance.cc:79-122), one remaining candidate per lane per round.
-// Up to kLdsSortMax accepted matches live in LDS; more spill to global scratch (flat pointers).
+// Up to kLdsSortMax accepted matches live in LDS; more use the global scratch.
 // Dynamic LDS (contrast only): rows[(max_slen+1)*64] floats.
 // ---------------------------------------------------------------------------------------------
 struct Rec {  // == fmx_match
@@ -575,27 +611,6 @@ struct Rec {  // == fmx_match
   uint32_t s_id;
 };
 
-__device__ __forceinline__ void wave_bitonic_sort_kv(unsigned long long* keys, uint32_t* vals, uint32_t n_pow2) {
-  const uint32_t lane = lane_id();
-  for (uint32_t k = 2; k <= n_pow2; k <<= 1) {
-    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-      for (uint32_t i = lane; i < n_pow2; i += kWave) {
-        const uint32_t ixj = i ^ j;
-        if (ixj > i) {
-          const unsigned long long a = keys[i], c = keys[ixj];
-          const bool up = (i & k) == 0;
-          if ((a > c) == up) {
-            keys[i] = c; keys[ixj] = a;
-            const uint32_t va = vals[i], vc = vals[ixj];
-            vals[i] = vc; vals[ixj] = va;
-          }
-        }
-      }
-      __syncthreads();
-    }
-  }
-}
-
 struct DevScratch {
   unsigned long long* keys;   // 2 * seg_cap
   uint32_t*           vals;   // 2 * seg_cap
@@ -603,29 +618,11 @@ struct DevScratch {
   float*              f1;     // seg_cap
 };
 
-__global__ void __launch_bounds__(kWave) k_select(DevIndex ix, DevBatch b, DevWork w, Params prm, DevScratch sc,
-                                                  uint32_t cap, Rec* out_rec, uint32_t* out_count,
-                                                  uint32_t* out_total) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* s_rows = (float*)smem;
-  __shared__ unsigned long long s_keys[kLdsSortMax];
-  __shared__ uint32_t s_vals[kLdsSortMax];
-  __shared__ float    s_f0[kLdsSortMax], s_f1[kLdsSortMax];
-  const uint32_t q = blockIdx.x;
+__device__ __forceinline__ void select_body(const DevIndex& ix, const Params& prm, const Cand* seg, uint32_t n,
+                                            uint32_t np2, unsigned long long* keys, uint32_t* vals, float* pen_sum,
+                                            float* pen_cur, float* s_rows, uint32_t cap, Rec* out,
+                                            uint32_t& out_count, uint32_t& out_total) {
   const uint32_t lane = lane_id();
-  const uint32_t gq = b.q_begin + q;
-  const uint32_t n = w.q_acc[q];
-  Rec* out = out_rec + (unsigned long long)gq * cap;
-  if (n == 0) {
-    if (lane == 0) { out_count[gq] = 0; if (out_total) out_total[gq] = 0; }
-    return;
-  }
-  const unsigned long long seg0 = w.q_seg[q];
-  const Cand* seg = w.seg + seg0;
-  const uint32_t np2 = next_pow2(n);
-  const bool in_lds = np2 <= kLdsSortMax;
-  unsigned long long* keys = in_lds ? s_keys : sc.keys + 2ull * seg0;
-  uint32_t* vals = in_lds ? s_vals : sc.vals + 2ull * seg0;
   // ascending key order = score desc, s_id asc; value = position in the accepted list
   for (uint32_t i = lane; i < np2; i += kWave) {
     keys[i] = i < n ? (((unsigned long long)(~float_key(seg[i].score)) << 32) | seg[i].sid) : ~0ull;
@@ -642,13 +639,13 @@ __global__ void __launch_bounds__(kWave) k_select(DevIndex ix, DevBatch b, DevWo
       r.score = c.score; r.penalty = 0.f; r.max_subseq = (int32_t)c.longest; r.s_id = c.sid;
       out[k] = r;
     }
-    if (lane == 0) { out_count[gq] = emit; if (out_total) out_total[gq] = want; }
+    out_count = emit;
+    out_total = want;
     return;
   }
   // ---- contrastive rerank; list position k <-> seg[vals[k]] ----
-  float* pen_sum = in_lds ? s_f0 : sc.f0 + seg0;   // running std::accumulate of penalties, pick order
-  float* pen_cur = in_lds ? s_f1 : sc.f1 + seg0;   // Match::penalty (0 before the first round)
-  // reuse the key array as the running max / taken flag store: key <- (taken << 63) | bits(max)
+  // pen_sum: running std::accumulate of penalties in pick order; pen_cur: Match::penalty (0 before the
+  // first round); the key array is reused as running max / taken flag: (taken << 63) | bits(max)
   for (uint32_t k = lane; k < n; k += kWave) { pen_sum[k] = 0.f; pen_cur[k] = 0.f; keys[k] = 0ull; }
   __syncthreads();
   DpSide side;
@@ -708,7 +705,50 @@ __global__ void __launch_bounds__(kWave) k_select(DevIndex ix, DevBatch b, DevWo
     last = best;
     __syncthreads();
   }
-  if (lane == 0) { out_count[gq] = picked < cap ? picked : cap; if (out_total) out_total[gq] = picked; }
+  out_count = picked < cap ? picked : cap;
+  out_total = picked;
+}
+
+__global__ void __launch_bounds__(kWave) k_select(DevIndex ix, DevBatch b, DevWork w, Params prm, DevScratch sc,
+                                                  uint32_t cap, Rec* out_rec, uint32_t* out_count,
+                                                  uint32_t* out_total) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* s_rows = (float*)smem;
+  __shared__ unsigned long long s_keys[kLdsSortMax];
+  __shared__ uint32_t s_vals[kLdsSortMax];
+  __shared__ float    s_f0[kLdsSortMax], s_f1[kLdsSortMax];
+  const uint32_t q = blockIdx.x;
+  const uint32_t lane = lane_id();
+  const uint32_t gq = b.q_begin + q;
+  const uint32_t n = w.q_acc[q];
+  Rec* out = out_rec + (unsigned long long)gq * cap;
+  uint32_t cnt = 0, tot = 0;
+  if (n != 0) {
+    const unsigned long long seg0 = w.q_seg[q];
+    const Cand* seg = w.seg + seg0;
+    const uint32_t np2 = next_pow2(n);
+    if (np2 <= kLdsSortMax) select_body(ix, prm, seg, n, np2, s_keys, s_vals, s_f0, s_f1, s_rows, cap, out, cnt, tot);
+    else select_body(ix, prm, seg, n, np2, sc.keys + 2ull * seg0, sc.vals + 2ull * seg0, sc.f0 + seg0, sc.f1 + seg0,
+                     s_rows, cap, out, cnt, tot);
+  }
+  if (lane == 0) { out_count[gq] = cnt; if (out_total) out_total[gq] = tot; }
+}
+
+// per-call statistics from the per-query arrays (kept out of the hot kernels: one shared atomic
+// per query costs more than the kernels' real work)
+__global__ void __launch_bounds__(256) k_stats(DevWork w, uint32_t nq) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long v[4] = {0, 0, 0, 0};
+  if (q < nq) {
+    v[0] = w.q_m[q] == kNoMatchLen ? 0ull : w.q_hits[q];
+    v[1] = w.q_kept[q]; v[2] = w.q_cand[q]; v[3] = w.q_dp[q];
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v[k] += __shfl_xor(v[k], d, 64);
+    if ((threadIdx.x & 63) == 0 && v[k]) atomicAdd(&w.counters[k], v[k]);
+  }
 }
 
 }  // namespace fmx

@@ -16,7 +16,7 @@ using namespace fmx;
 struct Rec { float score; float penalty; int32_t max_subseq; uint32_t s_id; };
 
 struct EmulIndex {
-  const SufRec* suf; const uint32_t* suf_sid; const uint32_t* tok; const uint32_t* sent_pos; const uint32_t* qva;
+  const SufRec* suf; const uint64_t* suf_sig; const uint32_t* suf_sid; const uint32_t* tok; const uint32_t* sent_pos; const uint32_t* qva;
   const float* idf; const uint32_t* real; const uint32_t* itok; const uint16_t* itok_dist;
   uint32_t n_itok, n_qva;
 };
@@ -44,13 +44,18 @@ extern "C" int emul_match_batch(const EmulIndex* ix, const Params* prm_in, uint6
     const bool reachable = (p == 1) ? (msl <= 1) : true;
     // k_probe + k_expand
     seg.clear();
+    std::vector<uint8_t> hbit(p);
+    for (uint32_t j = 0; j < p; j++) hbit[j] = (uint8_t)sig_bit(pat[j]);
+    const bool use_sig = prm.ins >= 0.f && prm.del >= 0.f && prm.rep >= 0.f;
     for (uint32_t it = 0; it < p; it++) {
       uint32_t lo = 0, hi = 0;
       if (reachable && it + m <= p) mgram_range(ix->suf, ix->tok, ix->qva, ix->n_qva, pat + it, m, lo, hi);
       if (stats) stats[0] += hi - lo;
       for (uint32_t i = lo; i < hi; i++) {
         const SufRec r = ix->suf[i];
-        if (reject_len(p, r.slen, prm) || dominated_hit(ix->tok, r, pat + it, it)) continue;
+        if (reject_len(p, r.slen, prm)) continue;
+        if (use_sig && reject_cover(p, r.slen, sig_cover_upper(ix->suf_sig[i], hbit.data(), p), prm)) continue;
+        if (dominated_hit(ix->tok, r, pat + it, it)) continue;
         Cand c;
         c.longest = lcp_extend(ix->tok, r, pat + it, m, p - it);
         // coverage bound in k_expand: independent of the match length, so it commutes with the max
