@@ -66,6 +66,7 @@ struct DeviceIndex::Impl {
   DevScratch sc{};
   unsigned long long* tile_sums = nullptr;
   unsigned long long* grand_total = nullptr;
+  uint32_t* big_list = nullptr;
   WorkItem* items = nullptr;
   uint32_t  item_cap = 0;
   uint32_t  s_max = 4096;   // survivors kept per query before a retry with a larger segment
@@ -85,7 +86,7 @@ DeviceIndex::DeviceIndex() : impl_(new Impl) {}
 
 static void free_ws(DeviceIndex::Impl& m) {
   hipFree(m.w.q_m); hipFree(m.w.t_q); hipFree(m.w.t_lo); hipFree(m.w.t_cnt); hipFree(m.w.q_hits);
-  hipFree(m.w.q_seg); hipFree(m.w.q_kept); hipFree(m.w.q_cand); hipFree(m.w.q_acc); hipFree(m.w.q_dp);
+  hipFree(m.w.q_seg); hipFree(m.w.q_kept); hipFree(m.w.q_cand); hipFree(m.w.q_acc); hipFree(m.w.c_in); hipFree(m.w.c_off); hipFree(m.w.t_idf); hipFree(m.big_list); m.big_list = nullptr;
   hipFree(m.w.seg); hipFree(m.w.heap); hipFree(m.w.counters);
   hipFree(m.sc.keys); hipFree(m.sc.vals); hipFree(m.sc.f0); hipFree(m.sc.f1);
   hipFree(m.tile_sums); hipFree(m.grand_total); hipFree(m.w.q_cap);
@@ -170,7 +171,10 @@ static void ensure_ws(DeviceIndex::Impl& m, uint64_t nq, uint64_t nt, uint64_t s
     m.w.q_kept = dev_alloc<uint32_t>(cq);
     m.w.q_cand = dev_alloc<uint32_t>(cq);
     m.w.q_acc = dev_alloc<uint32_t>(cq);
-    m.w.q_dp = dev_alloc<uint32_t>(cq);
+    m.w.c_in = dev_alloc<unsigned long long>(cq + 1);
+    m.w.c_off = dev_alloc<unsigned long long>(cq + 1);
+    m.w.t_idf = dev_alloc<float>(ct);
+    m.big_list = dev_alloc<uint32_t>(cq);
     m.w.seg = dev_alloc<Cand>(cs);
     m.w.heap = dev_alloc<float>(cs + cq + 1);
     m.w.counters = dev_alloc<unsigned long long>(8);
@@ -186,7 +190,7 @@ static void ensure_ws(DeviceIndex::Impl& m, uint64_t nq, uint64_t nt, uint64_t s
 }
 
 const char* stage_name(int s) {
-  static const char* names[kNumStages] = {"setup", "probe", "scan", "expand", "cand", "score", "select"};
+  static const char* names[kNumStages] = {"setup", "probe", "scan", "expand", "cand", "dp", "finish"};
   return (s >= 0 && s < kNumStages) ? names[s] : "";
 }
 
@@ -222,7 +226,7 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm_in, const D
       int e = 0;
       auto tick = [&]() { HIP_TRY(hipEventRecord(m.ev[e++], stream)); };
       tick();
-      hipLaunchKernelGGL(k_setup, dim3((b.nq + 255) / 256), dim3(256), 0, stream, b, w, prm);
+      hipLaunchKernelGGL(k_setup, dim3((b.nq + 255) / 256), dim3(256), 0, stream, m.d, b, w, prm);
       tick(); tick();
       if (b.nt) hipLaunchKernelGGL(k_probe, dim3((b.nt + 255) / 256), dim3(256), 0, stream, m.d, b, w);
       tick(); tick();
@@ -245,18 +249,29 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm_in, const D
                            (const WorkItem*)m.items, m.item_cap, p_max, use_sig);
       }
       tick(); tick();
-      hipLaunchKernelGGL(k_cand, dim3(b.nq), dim3(kWave), 0, stream, w, m.sc.keys);
+      hipLaunchKernelGGL(k_cand, dim3(b.nq), dim3(kWave), 0, stream, w, m.big_list);
+      hipLaunchKernelGGL(k_cand_big, dim3(kBigGrid), dim3(kBigThreads), 0, stream, w, m.sc.keys, (const uint32_t*)m.big_list);
+      {
+        // flat candidate list: c_off = exclusive scan of q_cand
+        const uint32_t n = b.nq + 1;
+        const uint32_t tiles = (n + kScanTile - 1) / kScanTile;
+        hipLaunchKernelGGL(k_widen, dim3((n + 255) / 256), dim3(256), 0, stream, (const uint32_t*)w.q_cand, w.c_in, b.nq, n);
+        hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(kScanThreads), 0, stream, w.c_in, w.c_off, m.tile_sums, n);
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanThreads), 0, stream, m.tile_sums, tiles, m.grand_total);
+        hipLaunchKernelGGL(k_scan_add, dim3(tiles), dim3(kScanThreads), 0, stream, w.c_off, m.tile_sums, n);
+      }
       tick(); tick();
       {
-        const size_t lds = (size_t)p_max * 8 + ((size_t)p_max + 1) * kWave * 4;
+        const size_t lds = ((size_t)p_max + 1) * kWave * 4;
         if (lds > 150 * 1024)
           throw GpuError("patterns of " + std::to_string(p_max) + " tokens need more LDS than one CU has (limit ~590)");
+        const unsigned grid = 256 * 16;  // grid-stride over the flat candidate list
         if (full) {
-          HIP_TRY(hipFuncSetAttribute((const void*)k_score<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-          hipLaunchKernelGGL(k_score<true>, dim3(b.nq), dim3(kWave), lds, stream, m.d, b, w, prm, p_max);
+          HIP_TRY(hipFuncSetAttribute((const void*)k_dp<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          hipLaunchKernelGGL(k_dp<true>, dim3(grid), dim3(kWave), lds, stream, m.d, b, w, prm);
         } else {
-          HIP_TRY(hipFuncSetAttribute((const void*)k_score<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-          hipLaunchKernelGGL(k_score<false>, dim3(b.nq), dim3(kWave), lds, stream, m.d, b, w, prm, p_max);
+          HIP_TRY(hipFuncSetAttribute((const void*)k_dp<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          hipLaunchKernelGGL(k_dp<false>, dim3(grid), dim3(kWave), lds, stream, m.d, b, w, prm);
         }
       }
       tick(); tick();
@@ -265,9 +280,9 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm_in, const D
         if (prm.contrast > 0.f) {
           lds = ((size_t)m.d.max_slen + 1) * kWave * 4;
           if (lds > 120 * 1024) throw GpuError("contrastive rerank: indexed sentences too long for the LDS DP rows");
-          HIP_TRY(hipFuncSetAttribute((const void*)k_select, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          HIP_TRY(hipFuncSetAttribute((const void*)k_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         }
-        hipLaunchKernelGGL(k_select, dim3(b.nq), dim3(kWave), lds, stream, m.d, b, w, prm, m.sc, cap, d_out,
+        hipLaunchKernelGGL(k_finish, dim3(b.nq), dim3(kWave), lds, stream, m.d, b, w, prm, m.sc, cap, d_out,
                            d_out_count, d_out_total);
       }
       tick();

@@ -56,12 +56,15 @@ struct DevWork {
   uint32_t* q_kept;     // nq
   uint32_t* q_cand;     // nq
   uint32_t* q_acc;      // nq
-  uint32_t* q_dp;       // nq   edit distances evaluated (statistics)
+  unsigned long long* c_in;    // nq+1 q_cand widened (scan input)
+  unsigned long long* c_off;   // nq+1 exclusive scan of q_cand: flat candidate list
+  float*    t_idf;      // nt   idf_penalty per pattern position (src/fuzzy_match.cc:372-390)
   Cand*     seg;        // capacity seg_cap
   float*    heap;       // capacity seg_cap + nq (lowest_costs spill)
   unsigned long long  seg_cap;
   unsigned long long* counters;  // [0]=hits [1]=kept [2]=cands [3]=dp [4]=max survivors of a query whose
                                  // segment overflowed [5]=extra work items [6]=segment space needed
+                                 // [7]=queries queued for k_cand_big
 };
 
 constexpr int kWave = 64;
@@ -89,14 +92,20 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 // ---------------------------------------------------------------------------------------------
 // k_setup — src/fuzzy_match.cc:450-467
 // ---------------------------------------------------------------------------------------------
-__global__ void k_setup(DevBatch b, DevWork w, Params prm) {
+__global__ void k_setup(DevIndex ix, DevBatch b, DevWork w, Params prm) {
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= b.nq) return;
   const uint32_t o0 = b.q_off[b.q_begin + q], o1 = b.q_off[b.q_begin + q + 1];
   const uint32_t p = o1 - o0;
   const uint32_t msl = min_seq_len(p, prm);
   w.q_m[q] = msl == kNoMatchLen ? kNoMatchLen : msl;
-  for (uint32_t k = 0; k < p; k++) w.t_q[o0 - b.t_begin + k] = q;
+  const bool use_idf = prm.idf_penalty != 0.f;
+  for (uint32_t k = 0; k < p; k++) {
+    w.t_q[o0 - b.t_begin + k] = q;
+    // compute_idf_penalty — src/fuzzy_match.cc:381-387 (UNK and out-of-vocabulary ids -> 0)
+    const uint32_t wd = b.q_tok[o0 + k];
+    w.t_idf[o0 - b.t_begin + k] = (use_idf && wd + 1 < ix.n_qva && wd != 1u) ? ix.idf[wd] : 0.f;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -360,16 +369,16 @@ __global__ void __launch_bounds__(kWave) k_expand(DevIndex ix, DevBatch b, DevWo
 }
 
 // ---------------------------------------------------------------------------------------------
-// bitonic sorts by one wave.  The key/value storage is a template parameter so that the LDS
-// instantiation compiles to ds_read/ds_write: selecting between an LDS and a global pointer at
-// run time would turn every access into a (slow) flat operation.
+// bitonic sorts by one workgroup (one wave for the per-query kernels, 1024 threads for the big-set
+// kernel).  The key/value storage is a typed pointer so that the LDS instantiation compiles to
+// ds_read/ds_write: selecting between an LDS and a global pointer at run time would turn every
+// access into a (slow) flat operation.
 // ---------------------------------------------------------------------------------------------
 template <class K>
-__device__ __forceinline__ void wave_bitonic_sort(K* keys, uint32_t n_pow2) {
-  const uint32_t lane = lane_id();
+__device__ __forceinline__ void block_bitonic_sort(K* keys, uint32_t n_pow2) {
   for (uint32_t k = 2; k <= n_pow2; k <<= 1) {
     for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-      for (uint32_t i = lane; i < n_pow2; i += kWave) {
+      for (uint32_t i = threadIdx.x; i < n_pow2; i += blockDim.x) {
         const uint32_t ixj = i ^ j;
         if (ixj > i) {
           const K a = keys[i], c = keys[ixj];
@@ -383,11 +392,10 @@ __device__ __forceinline__ void wave_bitonic_sort(K* keys, uint32_t n_pow2) {
 }
 
 template <class K, class V>
-__device__ __forceinline__ void wave_bitonic_sort_kv(K* keys, V* vals, uint32_t n_pow2) {
-  const uint32_t lane = lane_id();
+__device__ __forceinline__ void block_bitonic_sort_kv(K* keys, V* vals, uint32_t n_pow2) {
   for (uint32_t k = 2; k <= n_pow2; k <<= 1) {
     for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-      for (uint32_t i = lane; i < n_pow2; i += kWave) {
+      for (uint32_t i = threadIdx.x; i < n_pow2; i += blockDim.x) {
         const uint32_t ixj = i ^ j;
         if (ixj > i) {
           const K a = keys[i], c = keys[ixj];
@@ -411,22 +419,23 @@ __device__ __forceinline__ uint32_t next_pow2(uint32_t n) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_cand — one wave per query: LongestMatches semantics (max match length per sentence,
+// k_cand / k_cand_big — LongestMatches semantics (max match length per sentence,
 // src/ngram_matches.cc:79-81) then get_longest_matches order (longest desc, s_id asc,
 // src/ngram_matches.cc:19-29).  Two key sorts: (sid, L) to find each sentence's max, then
-// (~L, sid).  Up to kLdsSortMax survivors are sorted in LDS; larger sets use the global key
-// scratch (slow path, rare: the coverage bound has already run).
+// (~L, sid).  k_cand: one wave per query, up to kLdsSortMax survivors sorted in LDS; larger sets
+// (rare: the coverage bound has already run) are queued for k_cand_big, 1024 threads per query
+// over the global key scratch.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t cand_body(unsigned long long* keys, Cand* seg, uint32_t n, uint32_t np2) {
-  const uint32_t lane = lane_id();
-  for (uint32_t i = lane; i < np2; i += kWave)
+__device__ __forceinline__ uint32_t cand_body(unsigned long long* keys, Cand* seg, uint32_t n, uint32_t np2,
+                                              uint32_t* s_count) {
+  if (threadIdx.x == 0) *s_count = 0;
+  for (uint32_t i = threadIdx.x; i < np2; i += blockDim.x)
     keys[i] = i < n ? (((unsigned long long)seg[i].sid << 16) | (seg[i].longest & 0xffffu)) : ~0ull;
   __syncthreads();
-  wave_bitonic_sort(keys, np2);
+  block_bitonic_sort(keys, np2);
   // keep the last entry of each sentence group (its largest L); rewrite as (0xffff - L, sid)
-  uint32_t kept = 0;
-  for (uint32_t i0 = 0; i0 < np2; i0 += kWave) {
-    const uint32_t i = i0 + lane;
+  for (uint32_t i0 = 0; i0 < np2; i0 += blockDim.x) {
+    const uint32_t i = i0 + threadIdx.x;
     unsigned long long k2 = ~0ull;
     bool keep = false;
     if (i < n) {
@@ -437,11 +446,13 @@ __device__ __forceinline__ uint32_t cand_body(unsigned long long* keys, Cand* se
     }
     __syncthreads();
     if (i < np2) keys[i] = k2;
-    kept += __popcll(__ballot(keep));
+    const uint32_t c = __popcll(__ballot(keep));
+    if (lane_id() == 0 && c) atomicAdd(s_count, c);
     __syncthreads();
   }
-  wave_bitonic_sort(keys, np2);
-  for (uint32_t i = lane; i < kept; i += kWave) {
+  block_bitonic_sort(keys, np2);
+  const uint32_t kept = *s_count;
+  for (uint32_t i = threadIdx.x; i < kept; i += blockDim.x) {
     const unsigned long long a = keys[i];
     Cand c;
     c.sid = (uint32_t)(a & 0xffffffffu);
@@ -452,8 +463,9 @@ __device__ __forceinline__ uint32_t cand_body(unsigned long long* keys, Cand* se
   return kept;
 }
 
-__global__ void __launch_bounds__(kWave) k_cand(DevWork w, unsigned long long* big) {
+__global__ void __launch_bounds__(kWave) k_cand(DevWork w, uint32_t* big_list) {
   __shared__ unsigned long long s_keys[kLdsSortMax];
+  __shared__ uint32_t s_count;
   const uint32_t q = blockIdx.x;
   const uint32_t lane = lane_id();
   const uint32_t n = w.q_kept[q];
@@ -465,143 +477,109 @@ __global__ void __launch_bounds__(kWave) k_cand(DevWork w, unsigned long long* b
     if (lane == 0) { w.q_cand[q] = 0; atomicMax(&w.counters[4], (unsigned long long)n); }
     return;
   }
-  Cand* seg = w.seg + w.q_seg[q];
   const uint32_t np2 = next_pow2(n);
-  uint32_t kept;
-  // the global scratch mirrors the segment layout at 2x (pow2 padding): 2 * q_seg[q]
-  if (np2 <= kLdsSortMax) kept = cand_body(s_keys, seg, n, np2);
-  else kept = cand_body(big + 2ull * w.q_seg[q], seg, n, np2);
+  if (np2 > kLdsSortMax) {  // queue for the 1024-thread kernel
+    if (lane == 0) { w.q_cand[q] = 0; big_list[atomicAdd(&w.counters[7], 1ull)] = q; }
+    return;
+  }
+  const uint32_t kept = cand_body(s_keys, w.seg + w.q_seg[q], n, np2, &s_count);
   if (lane == 0) w.q_cand[q] = kept;
 }
 
+constexpr int kBigThreads = 1024;
+constexpr int kBigGrid = 512;
+
+__global__ void __launch_bounds__(kBigThreads) k_cand_big(DevWork w, unsigned long long* big, const uint32_t* big_list) {
+  __shared__ uint32_t s_count;
+  const unsigned long long n_big = w.counters[7];
+  for (unsigned long long idx = blockIdx.x; idx < n_big; idx += gridDim.x) {
+    const uint32_t q = big_list[idx];
+    const uint32_t n = w.q_kept[q];
+    // the global scratch mirrors the segment layout at 2x (pow2 padding): 2 * q_seg[q]
+    const uint32_t kept = cand_body(big + 2ull * w.q_seg[q], w.seg + w.q_seg[q], n, next_pow2(n), &s_count);
+    if (threadIdx.x == 0) w.q_cand[q] = kept;
+    __syncthreads();
+  }
+}
+
+// q_cand (u32) -> u64 for the scan that lays the candidates of all queries out as one flat list
+__global__ void k_widen(const uint32_t* in, unsigned long long* out, uint32_t n, uint32_t n_pad) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_pad) out[i] = i < n ? in[i] : 0ull;
+}
+
 // ---------------------------------------------------------------------------------------------
-// k_score — one wave per query, candidates in reference order, 64 at a time: float edit distance
-// (src/edit_distance.cc:5-77) with one candidate per lane and its DP row strided through LDS
-// (bank = lane, conflict free), then lane 0 replays the order-dependent lowest_costs logic
-// (src/fuzzy_match.cc:587-610) over the chunk.  The bound it leaves is handed to the next chunk as
-// a safe early-exit threshold (the bound never increases).  Accepted matches overwrite the head of
-// the query's segment.  Dynamic LDS: pat[p_max] | idf[p_max] | rows[(p_max+1)*64] floats.
+// k_dp — the float edit distance (src/edit_distance.cc:5-77), flattened over every (query,
+// candidate) pair of the sub-batch: one candidate per lane whatever its query, so a query with
+// ten thousand candidates is spread over the whole chip and a query with three does not idle 61
+// lanes.  DP rows are strided through LDS (bank = lane, conflict free).  Writes final cost and
+// M = max(row minima, final) into the candidate record; the order-dependent acceptance
+// (src/fuzzy_match.cc:587-610) is replayed afterwards by k_finish.
+// Dynamic LDS: rows[(p_max+1)*64] floats.
 // ---------------------------------------------------------------------------------------------
 struct LdsRow {
   float* base;
   __device__ __forceinline__ float& operator[](uint32_t j) const { return base[j * kWave]; }
 };
 
-struct ScoreShared {
-  float    final_cost[kWave], M[kWave];
-  uint32_t sid[kWave], L[kWave], slen[kWave];
-  float    ub;
-};
-
 template <bool FULL>
-__device__ __forceinline__ uint32_t score_body(const DevIndex& ix, const DevBatch& b, const Params& prm, uint32_t q,
-                                               uint32_t o0, uint32_t p, uint32_t n_cand, Cand* seg, float* heap_store,
-                                               const uint32_t* s_pat, const float* s_idf, float* s_rows,
-                                               ScoreShared& sh, uint32_t& n_dp_out) {
-  const uint32_t lane = lane_id();
-  const bool use_idf = prm.idf_penalty != 0.f;
-  CostHeap heap;
-  heap.v = heap_store;
-  heap.n = 0;
-  if (lane == 0) { heap.push(FLT_MAX); sh.ub = FLT_MAX; }
-  __syncthreads();
-  uint32_t acc = 0, n_dp = 0;
-  DpSide side;
-  side.s_real = nullptr; side.p_real = nullptr; side.s_itok = nullptr; side.p_itok = nullptr;
-  side.itok_dist = nullptr; side.n_itok = 0; side.p_idf = nullptr; side.idf_weight = 0.f;
-  for (uint32_t c0 = 0; c0 < n_cand; c0 += kWave) {
-    const uint32_t c = c0 + lane;
-    float final_cost = 0.f, M = 0.f;
-    uint32_t sid = 0, L = 0, slen = 0;
-    if (c < n_cand) {  // the coverage bound was applied in k_expand: every candidate gets its DP
-      sid = seg[c].sid;
-      L = seg[c].longest;
-      const uint32_t sp = ix.sent_pos[sid];
-      slen = ix.tok[sp];
-      const uint32_t* sent = ix.tok + sp + 1;
-      const float dw = 100.f / normalizer(p, slen, prm.ins, prm.del, prm.rep);
-      if (FULL) {
-        if (ix.real) {
-          side.s_real = ix.real + sp + 1;
-          side.p_real = b.q_real ? b.q_real + o0 : nullptr;
-          if (!side.p_real) side.s_real = nullptr;
-        }
-        if (ix.itok_dist) {
-          side.itok_dist = ix.itok_dist;
-          side.n_itok = ix.n_itok;
-          side.s_itok = ix.itok ? ix.itok + sp : nullptr;
-          side.p_itok = b.q_itok ? b.q_itok + o0 + (b.q_begin + q) : nullptr;
-        }
-        if (use_idf) {
-          side.p_idf = s_idf;
-          side.idf_weight = (dw * prm.idf_penalty) / prm.idf_max;  // src/fuzzy_match.cc:591
-        }
-      }
-      final_cost = edit_distance<FULL>(sent, slen, s_pat, p, prm.ins, prm.del, prm.rep, dw, side, sh.ub,
-                                       LdsRow{s_rows + lane}, M);
-      n_dp++;
-    }
-    sh.final_cost[lane] = final_cost; sh.M[lane] = M; sh.sid[lane] = sid; sh.L[lane] = L; sh.slen[lane] = slen;
-    __syncthreads();
-    if (lane == 0) {
-      const uint32_t lim = n_cand - c0 < kWave ? n_cand - c0 : kWave;
-      for (uint32_t k = 0; k < lim; k++) {
-        float score;
-        if (replay_candidate(heap, prm, p, sh.slen[k], sh.final_cost[k], sh.M[k], score)) {
-          Cand a;
-          a.sid = sh.sid[k]; a.longest = sh.L[k]; a.score = score; a.penalty = 0.f;
-          seg[acc++] = a;
-        }
-      }
-      sh.ub = heap.top();
-    }
-    __syncthreads();
-  }
-  n_dp_out = n_dp;
-  return acc;
-}
-
-template <bool FULL>
-__global__ void __launch_bounds__(kWave) k_score(DevIndex ix, DevBatch b, DevWork w, Params prm, uint32_t p_max) {
+__global__ void __launch_bounds__(kWave) k_dp(DevIndex ix, DevBatch b, DevWork w, Params prm) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  uint32_t* s_pat = (uint32_t*)smem;
-  float*    s_idf = (float*)(s_pat + p_max);
-  float*    s_rows = s_idf + p_max;
-  __shared__ ScoreShared sh;
-  __shared__ float s_heap[kHeapLdsMax + 2];
-  const uint32_t q = blockIdx.x;
+  float* s_rows = (float*)smem;
   const uint32_t lane = lane_id();
-  const uint32_t n_cand = w.q_cand[q];
-  if (n_cand == 0) {
-    if (lane == 0) { w.q_acc[q] = 0; w.q_dp[q] = 0; }
-    return;
-  }
-  const uint32_t o0 = b.q_off[b.q_begin + q];
-  const uint32_t p = b.q_off[b.q_begin + q + 1] - o0;
-  const uint32_t* pat_g = b.q_tok + o0;
+  const unsigned long long total = w.c_off[b.nq];
   const bool use_idf = prm.idf_penalty != 0.f;
-  for (uint32_t j = lane; j < p; j += kWave) {
-    const uint32_t wd = pat_g[j];
-    s_pat[j] = wd;
-    // compute_idf_penalty — src/fuzzy_match.cc:381-387 (UNK and out-of-vocabulary ids -> 0)
-    s_idf[j] = (use_idf && wd + 1 < ix.n_qva && wd != 1u) ? ix.idf[wd] : 0.f;
+  for (unsigned long long j = (unsigned long long)blockIdx.x * kWave + lane; j < total;
+       j += (unsigned long long)gridDim.x * kWave) {
+    // query of flat candidate j: last q with c_off[q] <= j
+    uint32_t a = 0, bnd = b.nq;
+    while (bnd - a > 1) {
+      const uint32_t mid = (a + bnd) >> 1;
+      if (w.c_off[mid] <= j) a = mid; else bnd = mid;
+    }
+    const uint32_t q = a;
+    Cand* cd = w.seg + w.q_seg[q] + (j - w.c_off[q]);
+    const uint32_t sid = cd->sid;
+    const uint32_t o0 = b.q_off[b.q_begin + q];
+    const uint32_t p = b.q_off[b.q_begin + q + 1] - o0;
+    const uint32_t* pat = b.q_tok + o0;
+    const uint32_t sp = ix.sent_pos[sid];
+    const uint32_t slen = ix.tok[sp];
+    const uint32_t* sent = ix.tok + sp + 1;
+    const float dw = 100.f / normalizer(p, slen, prm.ins, prm.del, prm.rep);
+    DpSide side;
+    side.s_real = nullptr; side.p_real = nullptr; side.s_itok = nullptr; side.p_itok = nullptr;
+    side.itok_dist = nullptr; side.n_itok = 0; side.p_idf = nullptr; side.idf_weight = 0.f;
+    if (FULL) {
+      if (ix.real && b.q_real) { side.s_real = ix.real + sp + 1; side.p_real = b.q_real + o0; }
+      if (ix.itok_dist) {
+        side.itok_dist = ix.itok_dist;
+        side.n_itok = ix.n_itok;
+        side.s_itok = ix.itok ? ix.itok + sp : nullptr;
+        side.p_itok = b.q_itok ? b.q_itok + o0 + (b.q_begin + q) : nullptr;
+      }
+      if (use_idf) {
+        side.p_idf = w.t_idf + (o0 - b.t_begin);
+        side.idf_weight = (dw * prm.idf_penalty) / prm.idf_max;  // src/fuzzy_match.cc:591
+      }
+    }
+    float M;
+    const float final_cost = edit_distance<FULL>(sent, slen, pat, p, prm.ins, prm.del, prm.rep, dw, side, FLT_MAX,
+                                                 LdsRow{s_rows + lane}, M);
+    cd->score = final_cost;
+    cd->penalty = M;
+    cd->longest = (cd->longest & 0xffffu) | (slen << 16);
   }
-  Cand* seg = w.seg + w.q_seg[q];
-  uint32_t n_dp = 0, acc;
-  if (prm.cbuf > 0 && prm.cbuf <= (int)kHeapLdsMax)
-    acc = score_body<FULL>(ix, b, prm, q, o0, p, n_cand, seg, s_heap, s_pat, s_idf, s_rows, sh, n_dp);
-  else
-    acc = score_body<FULL>(ix, b, prm, q, o0, p, n_cand, seg, w.heap + w.q_seg[q] + q, s_pat, s_idf, s_rows, sh, n_dp);
-  n_dp = wave_sum(n_dp);
-  if (lane == 0) { w.q_acc[q] = acc; w.q_dp[q] = n_dp; }
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_select — one wave per query: the `result` priority queue's pop order (score desc, s_id asc;
-// CompareMatch src/fuzzy_match.cc:25-33) via a key/value sort, then either the plain top-N
-// (src/fuzzy_match.cc:670-679) or the contrastive rerank (:614-669) with the ids-only edit
-// distance (src/edit_distance.cc:79-122), one remaining candidate per lane per round.
-// Up to kLdsSortMax accepted matches live in LDS; more use the global scratch.
+// k_finish — one wave per query.  Lane 0 replays the candidate loop's order-dependent acceptance
+// (lowest_costs bound, src/fuzzy_match.cc:587-610) over the candidates in reference order, 64 staged
+// through LDS at a time; accepted matches overwrite the head of the query's segment.  Then the
+// `result` priority queue's pop order (score desc, s_id asc; CompareMatch src/fuzzy_match.cc:25-33)
+// via a key/value sort, and either the plain top-N (:670-679) or the contrastive rerank (:614-669)
+// with the ids-only edit distance (src/edit_distance.cc:79-122), one remaining candidate per lane
+// per round.  Up to kLdsSortMax accepted matches live in LDS; more use the global scratch.
 // Dynamic LDS (contrast only): rows[(max_slen+1)*64] floats.
 // ---------------------------------------------------------------------------------------------
 struct Rec {  // == fmx_match
@@ -618,6 +596,44 @@ struct DevScratch {
   float*              f1;     // seg_cap
 };
 
+struct ReplayShared {
+  float    final_cost[kWave], M[kWave];
+  uint32_t sid[kWave], L[kWave], slen[kWave];
+};
+
+__device__ __forceinline__ uint32_t replay_body(const Params& prm, uint32_t p, uint32_t n_cand, Cand* seg,
+                                                float* heap_store, ReplayShared& sh) {
+  const uint32_t lane = lane_id();
+  CostHeap heap;
+  heap.v = heap_store;
+  heap.n = 0;
+  if (lane == 0) heap.push(FLT_MAX);
+  uint32_t acc = 0;
+  for (uint32_t c0 = 0; c0 < n_cand; c0 += kWave) {
+    const uint32_t c = c0 + lane;
+    __syncthreads();
+    if (c < n_cand) {
+      const Cand cd = seg[c];
+      sh.final_cost[lane] = cd.score; sh.M[lane] = cd.penalty; sh.sid[lane] = cd.sid;
+      sh.L[lane] = cd.longest & 0xffffu; sh.slen[lane] = cd.longest >> 16;
+    }
+    __syncthreads();
+    if (lane == 0) {
+      const uint32_t lim = n_cand - c0 < kWave ? n_cand - c0 : kWave;
+      for (uint32_t k = 0; k < lim; k++) {
+        float score;
+        if (replay_candidate(heap, prm, p, sh.slen[k], sh.final_cost[k], sh.M[k], score)) {
+          Cand a;
+          a.sid = sh.sid[k]; a.longest = sh.L[k]; a.score = score; a.penalty = 0.f;
+          seg[acc++] = a;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  return __shfl(acc, 0, 64);
+}
+
 __device__ __forceinline__ void select_body(const DevIndex& ix, const Params& prm, const Cand* seg, uint32_t n,
                                             uint32_t np2, unsigned long long* keys, uint32_t* vals, float* pen_sum,
                                             float* pen_cur, float* s_rows, uint32_t cap, Rec* out,
@@ -629,7 +645,7 @@ __device__ __forceinline__ void select_body(const DevIndex& ix, const Params& pr
     vals[i] = i;
   }
   __syncthreads();
-  wave_bitonic_sort_kv(keys, vals, np2);
+  block_bitonic_sort_kv(keys, vals, np2);
   const uint32_t want = prm.nmatch == 0 ? n : (prm.nmatch < n ? prm.nmatch : n);
   const uint32_t emit = want < cap ? want : cap;
   if (!(prm.contrast > 0.f)) {
@@ -709,7 +725,7 @@ __device__ __forceinline__ void select_body(const DevIndex& ix, const Params& pr
   out_total = picked;
 }
 
-__global__ void __launch_bounds__(kWave) k_select(DevIndex ix, DevBatch b, DevWork w, Params prm, DevScratch sc,
+__global__ void __launch_bounds__(kWave) k_finish(DevIndex ix, DevBatch b, DevWork w, Params prm, DevScratch sc,
                                                   uint32_t cap, Rec* out_rec, uint32_t* out_count,
                                                   uint32_t* out_total) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -717,20 +733,30 @@ __global__ void __launch_bounds__(kWave) k_select(DevIndex ix, DevBatch b, DevWo
   __shared__ unsigned long long s_keys[kLdsSortMax];
   __shared__ uint32_t s_vals[kLdsSortMax];
   __shared__ float    s_f0[kLdsSortMax], s_f1[kLdsSortMax];
+  __shared__ ReplayShared sh;
+  __shared__ float s_heap[kHeapLdsMax + 2];
   const uint32_t q = blockIdx.x;
   const uint32_t lane = lane_id();
   const uint32_t gq = b.q_begin + q;
-  const uint32_t n = w.q_acc[q];
+  const uint32_t n_cand = w.q_cand[q];
   Rec* out = out_rec + (unsigned long long)gq * cap;
   uint32_t cnt = 0, tot = 0;
-  if (n != 0) {
+  if (n_cand != 0) {
     const unsigned long long seg0 = w.q_seg[q];
-    const Cand* seg = w.seg + seg0;
-    const uint32_t np2 = next_pow2(n);
-    if (np2 <= kLdsSortMax) select_body(ix, prm, seg, n, np2, s_keys, s_vals, s_f0, s_f1, s_rows, cap, out, cnt, tot);
-    else select_body(ix, prm, seg, n, np2, sc.keys + 2ull * seg0, sc.vals + 2ull * seg0, sc.f0 + seg0, sc.f1 + seg0,
-                     s_rows, cap, out, cnt, tot);
-  }
+    Cand* seg = w.seg + seg0;
+    const uint32_t p = b.q_off[gq + 1] - b.q_off[gq];
+    uint32_t n;
+    if (prm.cbuf > 0 && prm.cbuf <= (int)kHeapLdsMax) n = replay_body(prm, p, n_cand, seg, s_heap, sh);
+    else n = replay_body(prm, p, n_cand, seg, w.heap + seg0 + q, sh);
+    if (lane == 0) w.q_acc[q] = n;
+    if (n != 0) {
+      const uint32_t np2 = next_pow2(n);
+      if (np2 <= kLdsSortMax) select_body(ix, prm, seg, n, np2, s_keys, s_vals, s_f0, s_f1, s_rows, cap, out, cnt, tot);
+      else select_body(ix, prm, seg, n, np2, sc.keys + 2ull * seg0, sc.vals + 2ull * seg0, sc.f0 + seg0, sc.f1 + seg0,
+                       s_rows, cap, out, cnt, tot);
+    }
+  } else if (lane == 0)
+    w.q_acc[q] = 0;
   if (lane == 0) { out_count[gq] = cnt; if (out_total) out_total[gq] = tot; }
 }
 
@@ -741,7 +767,7 @@ __global__ void __launch_bounds__(256) k_stats(DevWork w, uint32_t nq) {
   unsigned long long v[4] = {0, 0, 0, 0};
   if (q < nq) {
     v[0] = w.q_m[q] == kNoMatchLen ? 0ull : w.q_hits[q];
-    v[1] = w.q_kept[q]; v[2] = w.q_cand[q]; v[3] = w.q_dp[q];
+    v[1] = w.q_kept[q]; v[2] = w.q_cand[q]; v[3] = w.q_cand[q];
   }
 #pragma unroll
   for (int k = 0; k < 4; k++) {

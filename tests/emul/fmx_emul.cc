@@ -146,7 +146,7 @@ extern "C" int emul_match_batch(const EmulIndex* ix, const Params* prm_in, uint6
           seg[acc++] = a;
         }
       }
-      s_ub = heap.top();
+      // k_dp evaluates every candidate without a bound (flattened over queries); the bound only acts in the replay
     }
     // k_select
     const uint32_t n = acc;
