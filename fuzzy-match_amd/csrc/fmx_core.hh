@@ -196,6 +196,19 @@ FMX_HD uint32_t sig_cover_upper(unsigned long long sig, const uint8_t* __restric
   return c;
 }
 
+// smallest cover that passes theoretical_rejection_cover for a sentence of s tokens (the bound is
+// monotone in the cover for non-negative costs), 0xffff when the length filter
+// (theoretical_rejection) or every cover up to p rejects.
+FMX_HD uint32_t cover_threshold(uint32_t p, uint32_t s, const Params& prm) {
+  if (reject_len(p, s, prm) || reject_cover(p, s, p, prm)) return 0xffffu;
+  uint32_t lo = 0, hi = p;  // invariant: hi passes
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (reject_cover(p, s, mid, prm)) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
 // PatternCoverage::count_covered_words (src/pattern_coverage.cc:15-28): the sum of counts of the
 // distinct pattern words present in the sentence == number of pattern positions whose word
 // occurs in the sentence.

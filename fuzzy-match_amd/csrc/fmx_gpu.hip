@@ -241,7 +241,7 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm_in, const D
       }
       tick(); tick();
       {
-        const size_t lds = (size_t)p_max * 5 + 16;
+        const size_t lds = (size_t)p_max * 4 + kCminTab * 2;
         if (lds > 64 * 1024) throw GpuError("patterns too long for the expand kernel's LDS staging");
         // the signature bound needs theoretical_rejection_cover to be monotone in the cover: costs >= 0
         const int use_sig = prm.ins >= 0.f && prm.del >= 0.f && prm.rep >= 0.f;
@@ -250,7 +250,9 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm_in, const D
       }
       tick(); tick();
       hipLaunchKernelGGL(k_cand, dim3(b.nq), dim3(kWave), 0, stream, w, m.big_list);
-      hipLaunchKernelGGL(k_cand_big, dim3(kBigGrid), dim3(kBigThreads), 0, stream, w, m.sc.keys, (const uint32_t*)m.big_list);
+      HIP_TRY(hipFuncSetAttribute((const void*)k_cand_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kBigLdsKeys * 8)));
+      hipLaunchKernelGGL(k_cand_big, dim3(kBigGrid), dim3(kBigThreads), kBigLdsKeys * 8, stream, w, m.sc.keys,
+                         (const uint32_t*)m.big_list);
       {
         // flat candidate list: c_off = exclusive scan of q_cand
         const uint32_t n = b.nq + 1;

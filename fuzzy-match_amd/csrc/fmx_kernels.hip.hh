@@ -252,22 +252,35 @@ __device__ __forceinline__ uint32_t cover_lds(const uint32_t* __restrict__ sent,
   return cover;
 }
 
+constexpr uint32_t kCminTab = 1024;   // sentence lengths covered by the per-query threshold table
+constexpr uint32_t kMaxPlanes = 17;   // bit planes of the per-bucket position counts (p < 2^17)
+
 // ---------------------------------------------------------------------------------------------
 // k_expand — one wave per work item (query, chunk of kExpandChunk hits).  Walks the hits (the
 // suffixes the reference's register_suffix_range_match visits, src/ngram_matches.cc:61-83), applies
 // the length filter, drops dominated hits, computes the match length, applies the coverage bound
 // (src/fuzzy_match.cc:576-581 — it does not depend on the match length, so filtering before the
 // per-sentence max is exact) and appends survivors to the query's segment with wave ballot +
-// prefix popcount and one atomic per 64 hits.  Dynamic LDS: pat[p_max] | hbit[p_max] (u8).
+// prefix popcount and one atomic per 64 hits.
+//
+// Per-hit cost is what matters here (2e9 hits per million queries at 5 M sentences), so everything
+// that depends only on (pattern, sentence length) is tabulated once per work item in LDS:
+//   s_cmin[s]   minimal cover a sentence of s tokens needs (0xffff = rejected by its length alone)
+//   planes      bit planes of "pattern positions per signature bucket": the upper bound of the cover
+//               from the sentence's 64-bit word signature is sum_k popcount(sig & plane_k) << k
+// so most hits are decided by one 8-byte record load, one 8-byte signature load and ~20 ALU ops.
+// Dynamic LDS: pat[p_max] u32 | cmin[kCminTab] u16.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kWave) k_expand(DevIndex ix, DevBatch b, DevWork w, Params prm,
                                                   const WorkItem* items, uint32_t item_cap, uint32_t p_max,
                                                   int use_sig) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t* s_pat = (uint32_t*)smem;
-  uint8_t*  s_hbit = (uint8_t*)(s_pat + p_max);
-  __shared__ uint32_t s_pref[kWave + 1];
-  __shared__ uint32_t s_lo[kWave];
+  uint16_t* s_cmin = (uint16_t*)(s_pat + p_max);
+  __shared__ uint32_t s_npref[kWave + 1];  // exclusive hit prefix of the non-empty start positions
+  __shared__ uint32_t s_nlo[kWave];
+  __shared__ uint32_t s_nit[kWave];
+  __shared__ uint32_t s_bucket[kWave];
   const uint32_t lane = lane_id();
   uint32_t q, chunk;
   uint32_t item_idx = 0;
@@ -296,48 +309,81 @@ __global__ void __launch_bounds__(kWave) k_expand(DevIndex ix, DevBatch b, DevWo
         const uint32_t* pat = b.q_tok + o0;
         const uint32_t t0 = o0 - b.t_begin;
         __syncthreads();
-        for (uint32_t j = lane; j < p; j += kWave) { const uint32_t wd = pat[j]; s_pat[j] = wd; s_hbit[j] = (uint8_t)sig_bit(wd); }
+        // ---- per-item tables ----
+        s_bucket[lane] = 0;
         __syncthreads();
+        for (uint32_t j = lane; j < p; j += kWave) {
+          const uint32_t wd = pat[j];
+          s_pat[j] = wd;
+          atomicAdd(&s_bucket[sig_bit(wd)], 1u);
+        }
+        const uint32_t tab_n = ix.max_slen + 1 < kCminTab ? ix.max_slen + 1 : kCminTab;
+        for (uint32_t sl = lane; sl < tab_n; sl += kWave)
+          s_cmin[sl] = use_sig ? (uint16_t)cover_threshold(p, sl, prm) : (uint16_t)(reject_len(p, sl, prm) ? 0xffffu : 0u);
+        __syncthreads();
+        unsigned long long planes[kMaxPlanes];
+        uint32_t n_planes = 0;
+        {
+          const uint32_t mycnt = s_bucket[lane];
+#pragma unroll
+          for (uint32_t k = 0; k < kMaxPlanes; k++) {
+            planes[k] = __ballot((mycnt >> k) & 1u);
+            if (planes[k]) n_planes = k + 1;
+          }
+        }
         Cand* seg = w.seg + seg0;
         const unsigned long long h_lo = (unsigned long long)chunk * kExpandChunk;
         const unsigned long long h_hi = h_lo + kExpandChunk < hits ? h_lo + kExpandChunk : hits;
         unsigned long long base_h = 0;  // hits of the start positions before c0
-        uint32_t n_out = 0;
         for (uint32_t c0 = 0; c0 < p && base_h < h_hi; c0 += kWave) {
           const uint32_t it_l = c0 + lane;
           const uint32_t mycnt = it_l < p ? w.t_cnt[t0 + it_l] : 0u;
           const uint32_t incl = wave_incl_scan(mycnt);
           const uint32_t total = __shfl(incl, 63, 64);
+          // compact the non-empty start positions: their prefixes are strictly increasing
+          const unsigned long long nz = __ballot(mycnt != 0);
+          const uint32_t n_nz = __popcll(nz);
           __syncthreads();
-          s_pref[lane] = incl - mycnt;
-          s_lo[lane] = it_l < p ? w.t_lo[t0 + it_l] : 0u;
-          if (lane == 0) s_pref[kWave] = total;
+          if (mycnt != 0) {
+            const uint32_t k = __popcll(nz & ((1ull << lane) - 1ull));
+            s_npref[k] = incl - mycnt;
+            s_nlo[k] = w.t_lo[t0 + it_l];
+            s_nit[k] = it_l;
+          }
+          if (lane == 0) s_npref[n_nz] = total;
           __syncthreads();
           // hits [base_h, base_h + total) belong to this block of start positions; clip to the chunk
           const unsigned long long a0 = h_lo > base_h ? h_lo - base_h : 0ull;
           const unsigned long long a1 = h_hi - base_h < total ? h_hi - base_h : (unsigned long long)total;
+          uint32_t k = 0;  // this lane's current start position (index into the compacted list)
           for (unsigned long long hh = a0; hh < a1; hh += kWave) {
             const uint32_t h = (uint32_t)hh + lane;
             bool keep = h < (uint32_t)a1;
             uint32_t sid = 0, L = 0;
             if (keep) {
-              // largest j with s_pref[j] <= h (entries with zero count share a prefix value; the last wins)
-              uint32_t a = 0, bnd = kWave;
-              while (bnd - a > 1) {
-                const uint32_t mid = (a + bnd) >> 1;
-                if (s_pref[mid] <= h) a = mid; else bnd = mid;
-              }
-              const uint32_t it = c0 + a;
-              const uint32_t i = s_lo[a] + (h - s_pref[a]);
+              while (s_npref[k + 1] <= h) k++;  // amortised: each lane advances at most n_nz times per block
+              const uint32_t it = s_nit[k];
+              const uint32_t i = s_nlo[k] + (h - s_npref[k]);
               const SufRec r = ix.suf[i];
-              keep = !reject_len(p, r.slen, prm);
-              // coverage bound with the signature's upper bound first: no token is touched for most hits
-              if (keep && use_sig) keep = !reject_cover(p, r.slen, sig_cover_upper(ix.suf_sig[i], s_hbit, p), prm);
+              const uint32_t sl = r.slen;
+              uint32_t cmin;
+              if (sl < tab_n) cmin = s_cmin[sl];
+              else cmin = use_sig ? cover_threshold(p, sl, prm) : (reject_len(p, sl, prm) ? 0xffffu : 0u);
+              keep = cmin != 0xffffu;
+              if (keep && use_sig) {
+                // upper bound of the cover from the word signature: no token is touched for most hits
+                const unsigned long long sig = ix.suf_sig[i];
+                uint32_t ub = 0;
+#pragma unroll
+                for (uint32_t kk = 0; kk < kMaxPlanes; kk++)
+                  if (kk < n_planes) ub += (uint32_t)__popcll(sig & planes[kk]) << kk;
+                keep = ub >= cmin;
+              }
               if (keep) keep = !dominated_hit(ix.tok, r, pat + it, it);
               if (keep) {
                 L = lcp_extend(ix.tok, r, pat + it, m, p - it);
-                const uint32_t cover = L < p ? cover_lds(ix.tok + (r.off - (uint32_t)(r.slen - r.rem)), r.slen, s_pat, p) : p;
-                keep = !reject_cover(p, r.slen, cover, prm);
+                const uint32_t cover = L < p ? cover_lds(ix.tok + (r.off - (uint32_t)(r.slen - r.rem)), sl, s_pat, p) : p;
+                keep = use_sig ? cover >= cmin : !reject_cover(p, sl, cover, prm);
                 if (keep) sid = ix.suf_sid[i];
               }
             }
@@ -355,12 +401,10 @@ __global__ void __launch_bounds__(kWave) k_expand(DevIndex ix, DevBatch b, DevWo
                   seg[pos] = c;
                 }
               }
-              n_out += cnt;
             }
           }
           base_h += total;
         }
-        (void)n_out;
       }
     }
     if (!extra) return;
@@ -489,14 +533,22 @@ __global__ void __launch_bounds__(kWave) k_cand(DevWork w, uint32_t* big_list) {
 constexpr int kBigThreads = 1024;
 constexpr int kBigGrid = 512;
 
+constexpr uint32_t kBigLdsKeys = 16384;  // 128 KB of keys: one workgroup per CU
+
 __global__ void __launch_bounds__(kBigThreads) k_cand_big(DevWork w, unsigned long long* big, const uint32_t* big_list) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned long long* s_keys = (unsigned long long*)smem;
   __shared__ uint32_t s_count;
   const unsigned long long n_big = w.counters[7];
   for (unsigned long long idx = blockIdx.x; idx < n_big; idx += gridDim.x) {
     const uint32_t q = big_list[idx];
     const uint32_t n = w.q_kept[q];
-    // the global scratch mirrors the segment layout at 2x (pow2 padding): 2 * q_seg[q]
-    const uint32_t kept = cand_body(big + 2ull * w.q_seg[q], w.seg + w.q_seg[q], n, next_pow2(n), &s_count);
+    const uint32_t np2 = next_pow2(n);
+    uint32_t kept;
+    // beyond the LDS capacity the global scratch is used; it mirrors the segment layout at 2x (pow2
+    // padding): 2 * q_seg[q]
+    if (np2 <= kBigLdsKeys) kept = cand_body(s_keys, w.seg + w.q_seg[q], n, np2, &s_count);
+    else kept = cand_body(big + 2ull * w.q_seg[q], w.seg + w.q_seg[q], n, np2, &s_count);
     if (threadIdx.x == 0) w.q_cand[q] = kept;
     __syncthreads();
   }
@@ -599,6 +651,7 @@ struct DevScratch {
 struct ReplayShared {
   float    final_cost[kWave], M[kWave];
   uint32_t sid[kWave], L[kWave], slen[kWave];
+  float    ub;
 };
 
 __device__ __forceinline__ uint32_t replay_body(const Params& prm, uint32_t p, uint32_t n_cand, Cand* seg,
@@ -609,18 +662,27 @@ __device__ __forceinline__ uint32_t replay_body(const Params& prm, uint32_t p, u
   heap.n = 0;
   if (lane == 0) heap.push(FLT_MAX);
   uint32_t acc = 0;
+  if (lane == 0) sh.ub = FLT_MAX;
   for (uint32_t c0 = 0; c0 < n_cand; c0 += kWave) {
     const uint32_t c = c0 + lane;
     __syncthreads();
+    // The bound never increases, so a candidate the bound left by the previous chunk already rejects
+    // (or the no_perfect rule) cannot change the state: all 64 lanes test that in parallel and lane 0
+    // only walks the few that may still be accepted, in order.
+    bool maybe = false;
     if (c < n_cand) {
       const Cand cd = seg[c];
+      const uint32_t slen = cd.longest >> 16;
       sh.final_cost[lane] = cd.score; sh.M[lane] = cd.penalty; sh.sid[lane] = cd.sid;
-      sh.L[lane] = cd.longest & 0xffffu; sh.slen[lane] = cd.longest >> 16;
+      sh.L[lane] = cd.longest & 0xffffu; sh.slen[lane] = slen;
+      maybe = !((prm.no_perfect && cd.score == 0.f && slen == p) || cd.penalty > sh.ub);
     }
+    unsigned long long todo = __ballot(maybe);
     __syncthreads();
     if (lane == 0) {
-      const uint32_t lim = n_cand - c0 < kWave ? n_cand - c0 : kWave;
-      for (uint32_t k = 0; k < lim; k++) {
+      while (todo) {
+        const uint32_t k = (uint32_t)__ffsll((long long)todo) - 1u;
+        todo &= todo - 1ull;
         float score;
         if (replay_candidate(heap, prm, p, sh.slen[k], sh.final_cost[k], sh.M[k], score)) {
           Cand a;
@@ -628,6 +690,7 @@ __device__ __forceinline__ uint32_t replay_body(const Params& prm, uint32_t p, u
           seg[acc++] = a;
         }
       }
+      sh.ub = heap.top();
     }
   }
   __syncthreads();

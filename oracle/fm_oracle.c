@@ -664,6 +664,7 @@ typedef struct fmo_scratch {
   /* LongestMatches (ngram_matches.hh:20) as an open-addressing table keyed by sid+1 */
   uint32_t*  hkey;
   uint32_t*  hval;
+  uint32_t*  hused;     /* slots occupied by the current query, for O(count) clearing */
   uint64_t   hcap, hcount;
   cand*      cands;
   uint64_t   cap_cands;
@@ -688,7 +689,7 @@ typedef struct fmo_scratch {
 } fmo_scratch;
 
 static void scratch_free(fmo_scratch* s) {
-  free(s->hkey); free(s->hval); free(s->cands); free(s->heap); free(s->result); free(s->idf);
+  free(s->hkey); free(s->hval); free(s->hused); free(s->cands); free(s->heap); free(s->result); free(s->idf);
   free(s->cov_word); free(s->cov_count); free((void*)s->st2); free(s->sn2); free(s->real2);
   free(s->dp.arr); free(s->dp.tag); free((void*)s->dp.st1); free(s->dp.sn1); free(s->dp.real1);
   free(s->memo); free(s->pen_sum); free(s->pen_max); free(s->pen_cnt);
@@ -702,15 +703,16 @@ static inline uint32_t int_hash(uint32_t x) { /* IntHash, ngram_matches.hh:9-17 
 }
 
 static void hash_reset(fmo_scratch* s) {
-  /* a fresh map per query, like the reference's NGramMatches member: a table grown by one wide
-   * query is dropped instead of being cleared for every later query */
-  if (!s->hcap || s->hcap > 4096) {
-    free(s->hkey); free(s->hval);
+  /* a fresh map per query, like the reference's NGramMatches member.  Only the slots the previous
+   * query touched are cleared: a table grown by one wide query must not cost a full memset (or an
+   * mmap/munmap pair, which serialises all worker threads in the kernel) for every later query. */
+  if (!s->hcap) {
     s->hcap = 1024;
     s->hkey = (uint32_t*)calloc(s->hcap, sizeof(uint32_t));
     s->hval = (uint32_t*)xrealloc(NULL, s->hcap * sizeof(uint32_t));
-  } else if (s->hcount) {
-    memset(s->hkey, 0, s->hcap * sizeof(uint32_t));
+    s->hused = (uint32_t*)xrealloc(NULL, s->hcap * sizeof(uint32_t));
+  } else {
+    for (uint64_t i = 0; i < s->hcount; i++) s->hkey[s->hused[i]] = 0;
   }
   s->hcount = 0;
 }
@@ -721,12 +723,15 @@ static void hash_grow(fmo_scratch* s) {
   s->hcap = oc * 2;
   s->hkey = (uint32_t*)calloc(s->hcap, sizeof(uint32_t));
   s->hval = (uint32_t*)xrealloc(NULL, s->hcap * sizeof(uint32_t));
+  s->hused = (uint32_t*)xrealloc(s->hused, s->hcap * sizeof(uint32_t));
+  uint64_t n = 0;
   for (uint64_t i = 0; i < oc; i++) {
     if (!ok[i]) continue;
     uint64_t h = int_hash(ok[i] - 1) & (s->hcap - 1);
     while (s->hkey[h]) h = (h + 1) & (s->hcap - 1);
     s->hkey[h] = ok[i];
     s->hval[h] = ov[i];
+    s->hused[n++] = (uint32_t)h;
   }
   free(ok); free(ov);
 }
@@ -739,7 +744,7 @@ static inline void hash_upsert_max(fmo_scratch* s, uint32_t sid, uint32_t L) {
   if (!s->hkey[h]) {
     s->hkey[h] = sid + 1;
     s->hval[h] = L;
-    s->hcount++;
+    s->hused[s->hcount++] = (uint32_t)h;
   } else if (s->hval[h] < L)
     s->hval[h] = L;
 }
@@ -891,8 +896,10 @@ static int64_t match_impl(const fmo_index* ix, const fmo_params* prm, const uint
     sc->cands = (cand*)xrealloc(sc->cands, sc->cap_cands * sizeof(cand));
   }
   uint64_t n_cands = 0;
-  for (uint64_t h = 0; h < sc->hcap && n_cands < sc->hcount; h++)
-    if (sc->hkey[h]) { sc->cands[n_cands].sid = sc->hkey[h] - 1; sc->cands[n_cands].longest = sc->hval[h]; n_cands++; }
+  for (uint64_t k = 0; k < sc->hcount; k++) {
+    const uint32_t h = sc->hused[k];
+    sc->cands[n_cands].sid = sc->hkey[h] - 1; sc->cands[n_cands].longest = sc->hval[h]; n_cands++;
+  }
   qsort(sc->cands, n_cands, sizeof(cand), cand_comp);
 
   /* PatternCoverage ctor — src/pattern_coverage.cc:8-13 */

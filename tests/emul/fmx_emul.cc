@@ -54,14 +54,16 @@ extern "C" int emul_match_batch(const EmulIndex* ix, const Params* prm_in, uint6
       for (uint32_t i = lo; i < hi; i++) {
         const SufRec r = ix->suf[i];
         if (reject_len(p, r.slen, prm)) continue;
-        if (use_sig && reject_cover(p, r.slen, sig_cover_upper(ix->suf_sig[i], hbit.data(), p), prm)) continue;
+        // the kernel tabulates cover_threshold per sentence length and compares the signature's upper bound
+        const uint32_t cmin = use_sig ? cover_threshold(p, r.slen, prm) : 0u;
+        if (use_sig && (cmin == 0xffffu || sig_cover_upper(ix->suf_sig[i], hbit.data(), p) < cmin)) continue;
         if (dominated_hit(ix->tok, r, pat + it, it)) continue;
         Cand c;
         c.longest = lcp_extend(ix->tok, r, pat + it, m, p - it);
         // coverage bound in k_expand: independent of the match length, so it commutes with the max
         const uint32_t* sent0 = ix->tok + (r.off - (uint32_t)(r.slen - r.rem));
         const uint32_t cov = c.longest < p ? cover_count(sent0, r.slen, pat, p) : p;
-        if (reject_cover(p, r.slen, cov, prm)) continue;
+        if (use_sig ? cov < cmin : reject_cover(p, r.slen, cov, prm)) continue;
         c.sid = ix->suf_sid[i];
         c.score = c.penalty = 0.f;
         seg.push_back(c);
