@@ -255,6 +255,50 @@ __device__ __forceinline__ uint32_t cover_lds(const uint32_t* __restrict__ sent,
 constexpr uint32_t kCminTab = 1024;   // sentence lengths covered by the per-query threshold table
 constexpr uint32_t kMaxPlanes = 17;   // bit planes of the per-bucket position counts (p < 2^17)
 
+constexpr uint32_t kQueue = 128;  // LDS ring of hits that passed the cheap tests (power of two >= 2 * 64)
+
+// phase B of k_expand for up to 64 queued hits (one per lane): dominance, match length, exact
+// coverage count, then ballot/prefix append of the survivors to the query's segment.
+__device__ __forceinline__ void expand_phase_b(const DevIndex& ix, const Params& prm, const DevWork& w, uint32_t q,
+                                               Cand* seg, uint32_t cap, const uint32_t* pat, const uint32_t* s_pat,
+                                               const uint16_t* s_cmin, uint32_t tab_n, uint32_t p, uint32_t m,
+                                               int use_sig, const uint32_t* s_qi, const uint32_t* s_qit,
+                                               uint32_t head, uint32_t n_take) {
+  const uint32_t lane = lane_id();
+  bool keep = lane < n_take;
+  uint32_t sid = 0, L = 0;
+  if (keep) {
+    const uint32_t slot = (head + lane) & (kQueue - 1);
+    const uint32_t i = s_qi[slot], it = s_qit[slot];
+    const SufRec r = ix.suf[i];
+    keep = !dominated_hit(ix.tok, r, pat + it, it);
+    if (keep) {
+      L = lcp_extend(ix.tok, r, pat + it, m, p - it);
+      const uint32_t sl = r.slen;
+      const uint32_t cover = L < p ? cover_lds(ix.tok + (r.off - (uint32_t)(r.slen - r.rem)), sl, s_pat, p) : p;
+      if (use_sig) keep = cover >= (sl < tab_n ? (uint32_t)s_cmin[sl] : cover_threshold(p, sl, prm));
+      else keep = !reject_cover(p, sl, cover, prm);
+      if (keep) sid = ix.suf_sid[i];
+    }
+  }
+  const unsigned long long mask = __ballot(keep);
+  if (mask) {
+    const uint32_t cnt = __popcll(mask);
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&w.q_kept[q], cnt);
+    base = __shfl(base, 0, 64);
+    if (keep) {
+      const uint32_t pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+      if (pos < cap) {
+        Cand c;
+        c.sid = sid; c.longest = L; c.score = 0.f; c.penalty = 0.f;
+        seg[pos] = c;
+      }
+    }
+  }
+  __syncthreads();
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_expand — one wave per work item (query, chunk of kExpandChunk hits).  Walks the hits (the
 // suffixes the reference's register_suffix_range_match visits, src/ngram_matches.cc:61-83), applies
@@ -281,6 +325,7 @@ __global__ void __launch_bounds__(kWave) k_expand(DevIndex ix, DevBatch b, DevWo
   __shared__ uint32_t s_nlo[kWave];
   __shared__ uint32_t s_nit[kWave];
   __shared__ uint32_t s_bucket[kWave];
+  __shared__ uint32_t s_qi[kQueue], s_qit[kQueue];
   const uint32_t lane = lane_id();
   uint32_t q, chunk;
   uint32_t item_idx = 0;
@@ -335,6 +380,7 @@ __global__ void __launch_bounds__(kWave) k_expand(DevIndex ix, DevBatch b, DevWo
         const unsigned long long h_lo = (unsigned long long)chunk * kExpandChunk;
         const unsigned long long h_hi = h_lo + kExpandChunk < hits ? h_lo + kExpandChunk : hits;
         unsigned long long base_h = 0;  // hits of the start positions before c0
+        uint32_t q_head = 0, q_tail = 0;  // ring of hits waiting for phase B
         for (uint32_t c0 = 0; c0 < p && base_h < h_hi; c0 += kWave) {
           const uint32_t it_l = c0 + lane;
           const uint32_t mycnt = it_l < p ? w.t_cnt[t0 + it_l] : 0u;
@@ -359,13 +405,12 @@ __global__ void __launch_bounds__(kWave) k_expand(DevIndex ix, DevBatch b, DevWo
           for (unsigned long long hh = a0; hh < a1; hh += kWave) {
             const uint32_t h = (uint32_t)hh + lane;
             bool keep = h < (uint32_t)a1;
-            uint32_t sid = 0, L = 0;
+            uint32_t i = 0, it = 0;
             if (keep) {
               while (s_npref[k + 1] <= h) k++;  // amortised: each lane advances at most n_nz times per block
-              const uint32_t it = s_nit[k];
-              const uint32_t i = s_nlo[k] + (h - s_npref[k]);
-              const SufRec r = ix.suf[i];
-              const uint32_t sl = r.slen;
+              it = s_nit[k];
+              i = s_nlo[k] + (h - s_npref[k]);
+              const uint32_t sl = ix.suf[i].slen;
               uint32_t cmin;
               if (sl < tab_n) cmin = s_cmin[sl];
               else cmin = use_sig ? cover_threshold(p, sl, prm) : (reject_len(p, sl, prm) ? 0xffffu : 0u);
@@ -379,32 +424,26 @@ __global__ void __launch_bounds__(kWave) k_expand(DevIndex ix, DevBatch b, DevWo
                   if (kk < n_planes) ub += (uint32_t)__popcll(sig & planes[kk]) << kk;
                 keep = ub >= cmin;
               }
-              if (keep) keep = !dominated_hit(ix.tok, r, pat + it, it);
-              if (keep) {
-                L = lcp_extend(ix.tok, r, pat + it, m, p - it);
-                const uint32_t cover = L < p ? cover_lds(ix.tok + (r.off - (uint32_t)(r.slen - r.rem)), sl, s_pat, p) : p;
-                keep = use_sig ? cover >= cmin : !reject_cover(p, sl, cover, prm);
-                if (keep) sid = ix.suf_sid[i];
-              }
             }
+            // phase A -> queue: hits that need their tokens looked at are compacted through LDS so that
+            // the expensive phase B always runs with (nearly) all 64 lanes busy
             const unsigned long long mask = __ballot(keep);
-            if (mask) {
-              const uint32_t cnt = __popcll(mask);
-              uint32_t base = 0;
-              if (lane == 0) base = atomicAdd(&w.q_kept[q], cnt);
-              base = __shfl(base, 0, 64);
-              if (keep) {
-                const uint32_t pos = base + __popcll(mask & ((1ull << lane) - 1ull));
-                if (pos < cap) {
-                  Cand c;
-                  c.sid = sid; c.longest = L; c.score = 0.f; c.penalty = 0.f;
-                  seg[pos] = c;
-                }
-              }
+            if (keep) {
+              const uint32_t slot = (q_tail + __popcll(mask & ((1ull << lane) - 1ull))) & (kQueue - 1);
+              s_qi[slot] = i;
+              s_qit[slot] = it;
+            }
+            q_tail += __popcll(mask);
+            __syncthreads();
+            while (q_tail - q_head >= kWave) {
+              expand_phase_b(ix, prm, w, q, seg, cap, pat, s_pat, s_cmin, tab_n, p, m, use_sig, s_qi, s_qit, q_head, kWave);
+              q_head += kWave;
             }
           }
           base_h += total;
         }
+        if (q_tail != q_head)
+          expand_phase_b(ix, prm, w, q, seg, cap, pat, s_pat, s_cmin, tab_n, p, m, use_sig, s_qi, s_qit, q_head, q_tail - q_head);
       }
     }
     if (!extra) return;
