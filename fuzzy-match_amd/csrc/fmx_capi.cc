@@ -241,7 +241,7 @@ static void copy_stats(const Stats& s, fmx_stats* o) {
   o->ms_total = s.ms_total; o->ms_h2d = s.ms_h2d; o->ms_d2h = s.ms_d2h;
   for (int i = 0; i < 16; i++) { o->ms_kernel[i] = s.ms_kernel[i]; o->launches[i] = s.launches[i]; }
   o->n_hits = s.n_hits; o->n_kept = s.n_kept; o->n_candidates = s.n_candidates; o->n_dp = s.n_dp;
-  o->n_retries = s.n_retries;
+  o->n_retries = s.n_retries; o->n_big = s.n_big; o->n_phase_b = s.n_phase_b; o->max_kept = s.max_kept;
 }
 
 int fmx_match_batch(fmx_index* ix, const fmx_params* params, const fmx_batch* hb, fmx_match* out,

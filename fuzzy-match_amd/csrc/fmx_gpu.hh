@@ -13,14 +13,14 @@ struct GpuError : std::runtime_error {
   using std::runtime_error::runtime_error;
 };
 
-constexpr int kNumStages = 7;
+constexpr int kNumStages = 9;
 const char* stage_name(int s);
 
 struct Stats {
   double   ms_total = 0, ms_h2d = 0, ms_d2h = 0;
   double   ms_kernel[16] = {0};
   uint64_t launches[16] = {0};
-  uint64_t n_hits = 0, n_kept = 0, n_candidates = 0, n_dp = 0, n_retries = 0;
+  uint64_t n_hits = 0, n_kept = 0, n_candidates = 0, n_dp = 0, n_retries = 0, n_big = 0, n_phase_b = 0, max_kept = 0;
 };
 
 struct Rec;  // == fmx_match, defined in fmx_kernels.hip.hh

@@ -86,7 +86,7 @@ DeviceIndex::DeviceIndex() : impl_(new Impl) {}
 
 static void free_ws(DeviceIndex::Impl& m) {
   hipFree(m.w.q_m); hipFree(m.w.t_q); hipFree(m.w.t_lo); hipFree(m.w.t_cnt); hipFree(m.w.q_hits);
-  hipFree(m.w.q_seg); hipFree(m.w.q_kept); hipFree(m.w.q_cand); hipFree(m.w.q_acc); hipFree(m.w.c_in); hipFree(m.w.c_off); hipFree(m.w.t_idf); hipFree(m.big_list); m.big_list = nullptr;
+  hipFree(m.w.q_seg); hipFree(m.w.q_kept); hipFree(m.w.q_cand); hipFree(m.w.q_acc); hipFree(m.w.q_pb); hipFree(m.w.c_in); hipFree(m.w.c_off); hipFree(m.w.t_idf); hipFree(m.big_list); m.big_list = nullptr;
   hipFree(m.w.seg); hipFree(m.w.heap); hipFree(m.w.counters);
   hipFree(m.sc.keys); hipFree(m.sc.vals); hipFree(m.sc.f0); hipFree(m.sc.f1);
   hipFree(m.tile_sums); hipFree(m.grand_total); hipFree(m.w.q_cap);
@@ -171,13 +171,14 @@ static void ensure_ws(DeviceIndex::Impl& m, uint64_t nq, uint64_t nt, uint64_t s
     m.w.q_kept = dev_alloc<uint32_t>(cq);
     m.w.q_cand = dev_alloc<uint32_t>(cq);
     m.w.q_acc = dev_alloc<uint32_t>(cq);
+    m.w.q_pb = dev_alloc<uint32_t>(cq);
     m.w.c_in = dev_alloc<unsigned long long>(cq + 1);
     m.w.c_off = dev_alloc<unsigned long long>(cq + 1);
     m.w.t_idf = dev_alloc<float>(ct);
     m.big_list = dev_alloc<uint32_t>(cq);
     m.w.seg = dev_alloc<Cand>(cs);
     m.w.heap = dev_alloc<float>(cs + cq + 1);
-    m.w.counters = dev_alloc<unsigned long long>(8);
+    m.w.counters = dev_alloc<unsigned long long>(16);
     m.w.seg_cap = cs;
     m.sc.keys = dev_alloc<unsigned long long>(2 * cs);
     m.sc.vals = dev_alloc<uint32_t>(2 * cs);
@@ -190,7 +191,7 @@ static void ensure_ws(DeviceIndex::Impl& m, uint64_t nq, uint64_t nt, uint64_t s
 }
 
 const char* stage_name(int s) {
-  static const char* names[kNumStages] = {"setup", "probe", "scan", "expand", "cand", "dp", "finish"};
+  static const char* names[kNumStages] = {"setup", "probe", "scan", "expand", "cand", "cand_big", "cand_scan", "dp", "finish"};
   return (s >= 0 && s < kNumStages) ? names[s] : "";
 }
 
@@ -222,7 +223,8 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm_in, const D
       if (!m.items) { m.item_cap = 1u << 22; m.items = dev_alloc<WorkItem>(m.item_cap); }
       DevWork w = m.w;
       HIP_TRY(hipMemsetAsync(w.q_hits, 0, (b.nq + 1) * sizeof(unsigned long long), stream));
-      HIP_TRY(hipMemsetAsync(w.counters, 0, 8 * sizeof(unsigned long long), stream));
+      HIP_TRY(hipMemsetAsync(w.counters, 0, 16 * sizeof(unsigned long long), stream));
+      HIP_TRY(hipMemsetAsync(w.q_pb, 0, b.nq * sizeof(uint32_t), stream));
       int e = 0;
       auto tick = [&]() { HIP_TRY(hipEventRecord(m.ev[e++], stream)); };
       tick();
@@ -250,9 +252,11 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm_in, const D
       }
       tick(); tick();
       hipLaunchKernelGGL(k_cand, dim3(b.nq), dim3(kWave), 0, stream, w, m.big_list);
+      tick(); tick();
       HIP_TRY(hipFuncSetAttribute((const void*)k_cand_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kBigLdsKeys * 8)));
       hipLaunchKernelGGL(k_cand_big, dim3(kBigGrid), dim3(kBigThreads), kBigLdsKeys * 8, stream, w, m.sc.keys,
                          (const uint32_t*)m.big_list);
+      tick(); tick();
       {
         // flat candidate list: c_off = exclusive scan of q_cand
         const uint32_t n = b.nq + 1;
@@ -290,7 +294,7 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm_in, const D
       tick();
       hipLaunchKernelGGL(k_stats, dim3((b.nq + 255) / 256), dim3(256), 0, stream, w, b.nq);
       HIP_TRY(hipGetLastError());
-      unsigned long long ctr[8];
+      unsigned long long ctr[16];
       HIP_TRY(hipMemcpyAsync(ctr, w.counters, sizeof(ctr), hipMemcpyDeviceToHost, stream));
       HIP_TRY(hipStreamSynchronize(stream));
       if (st) {
@@ -320,7 +324,10 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm_in, const D
         if (st) st->n_retries++;
         continue;
       }
-      if (st) { st->n_hits += ctr[0]; st->n_kept += ctr[1]; st->n_candidates += ctr[2]; st->n_dp += ctr[3]; }
+      if (st) {
+        st->n_hits += ctr[0]; st->n_kept += ctr[1]; st->n_candidates += ctr[2]; st->n_dp += ctr[3];
+        st->n_big += ctr[7]; st->n_phase_b += ctr[8]; st->max_kept = std::max<uint64_t>(st->max_kept, ctr[9]);
+      }
       break;
     }
   }

@@ -56,6 +56,7 @@ struct DevWork {
   uint32_t* q_kept;     // nq
   uint32_t* q_cand;     // nq
   uint32_t* q_acc;      // nq
+  uint32_t* q_pb;       // nq   hits that reached the token-touching phase of k_expand (statistics)
   unsigned long long* c_in;    // nq+1 q_cand widened (scan input)
   unsigned long long* c_off;   // nq+1 exclusive scan of q_cand: flat candidate list
   float*    t_idf;      // nt   idf_penalty per pattern position (src/fuzzy_match.cc:372-390)
@@ -442,6 +443,7 @@ __global__ void __launch_bounds__(kWave) k_expand(DevIndex ix, DevBatch b, DevWo
           }
           base_h += total;
         }
+        if (lane == 0 && q_tail) atomicAdd(&w.q_pb[q], q_tail);
         if (q_tail != q_head)
           expand_phase_b(ix, prm, w, q, seg, cap, pat, s_pat, s_cmin, tab_n, p, m, use_sig, s_qi, s_qit, q_head, q_tail - q_head);
       }
@@ -866,17 +868,23 @@ __global__ void __launch_bounds__(kWave) k_finish(DevIndex ix, DevBatch b, DevWo
 // per query costs more than the kernels' real work)
 __global__ void __launch_bounds__(256) k_stats(DevWork w, uint32_t nq) {
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-  unsigned long long v[4] = {0, 0, 0, 0};
+  unsigned long long v[5] = {0, 0, 0, 0, 0};
+  unsigned long long mx = 0;
   if (q < nq) {
     v[0] = w.q_m[q] == kNoMatchLen ? 0ull : w.q_hits[q];
-    v[1] = w.q_kept[q]; v[2] = w.q_cand[q]; v[3] = w.q_cand[q];
+    v[1] = w.q_kept[q]; v[2] = w.q_cand[q]; v[3] = w.q_cand[q]; v[4] = w.q_pb[q];
+    mx = w.q_kept[q];
   }
+  const int slot[5] = {0, 1, 2, 3, 8};
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
+  for (int k = 0; k < 5; k++) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v[k] += __shfl_xor(v[k], d, 64);
-    if ((threadIdx.x & 63) == 0 && v[k]) atomicAdd(&w.counters[k], v[k]);
+    if ((threadIdx.x & 63) == 0 && v[k]) atomicAdd(&w.counters[slot[k]], v[k]);
   }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { const unsigned long long o = __shfl_xor(mx, d, 64); mx = o > mx ? o : mx; }
+  if ((threadIdx.x & 63) == 0 && mx) atomicMax(&w.counters[9], mx);
 }
 
 }  // namespace fmx

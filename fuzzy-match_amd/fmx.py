@@ -49,7 +49,8 @@ class Stats(C.Structure):
     _fields_ = [("ms_total", C.c_double), ("ms_h2d", C.c_double), ("ms_d2h", C.c_double),
                 ("ms_kernel", C.c_double * 16), ("launches", C.c_uint64 * 16),
                 ("n_hits", C.c_uint64), ("n_kept", C.c_uint64), ("n_candidates", C.c_uint64),
-                ("n_dp", C.c_uint64), ("n_retries", C.c_uint64)]
+                ("n_dp", C.c_uint64), ("n_retries", C.c_uint64), ("n_big", C.c_uint64),
+                ("n_phase_b", C.c_uint64), ("max_kept", C.c_uint64)]
 
 
 class Info(C.Structure):

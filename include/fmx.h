@@ -85,6 +85,9 @@ typedef struct fmx_stats {
   uint64_t n_candidates;    /* distinct (query, sentence) candidates */
   uint64_t n_dp;            /* edit-distance evaluations */
   uint64_t n_retries;       /* sub-batches re-run with a larger workspace */
+  uint64_t n_big;           /* queries whose survivor set needed the 1024-thread sorter */
+  uint64_t n_phase_b;       /* hits that passed the length + signature tests (tokens were read) */
+  uint64_t max_kept;        /* largest survivor set of a single query */
 } fmx_stats;
 
 const char* fmx_last_error(void);
