@@ -253,9 +253,13 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm_in, const D
       tick(); tick();
       hipLaunchKernelGGL(k_cand, dim3(b.nq), dim3(kWave), 0, stream, w, m.big_list);
       tick(); tick();
-      HIP_TRY(hipFuncSetAttribute((const void*)k_cand_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kBigLdsKeys * 8)));
-      hipLaunchKernelGGL(k_cand_big, dim3(kBigGrid), dim3(kBigThreads), kBigLdsKeys * 8, stream, w, m.sc.keys,
-                         (const uint32_t*)m.big_list);
+      {
+        // radix passes needed: sentence ids < n_sent, match lengths <= longest pattern
+        uint32_t sid_bytes = 1, len_bytes = p_max < 255 ? 1u : 2u;
+        while (sid_bytes < 4 && (m.d.n_sent >> (8 * sid_bytes)) != 0) sid_bytes++;
+        hipLaunchKernelGGL(k_cand_big, dim3(kBigGrid), dim3(kBigThreads), 0, stream, w, m.sc.keys,
+                           (const uint32_t*)m.big_list, sid_bytes, len_bytes);
+      }
       tick(); tick();
       {
         // flat candidate list: c_off = exclusive scan of q_cand

@@ -256,6 +256,7 @@ __device__ __forceinline__ uint32_t cover_lds(const uint32_t* __restrict__ sent,
 constexpr uint32_t kCminTab = 1024;   // sentence lengths covered by the per-query threshold table
 constexpr uint32_t kMaxPlanes = 17;   // bit planes of the per-bucket position counts (p < 2^17)
 
+constexpr int kUnroll = 4;        // hits per lane per phase-A iteration
 constexpr uint32_t kQueue = 128;  // LDS ring of hits that passed the cheap tests (power of two >= 2 * 64)
 
 // phase B of k_expand for up to 64 queued hits (one per lane): dominance, match length, exact
@@ -403,42 +404,64 @@ __global__ void __launch_bounds__(kWave) k_expand(DevIndex ix, DevBatch b, DevWo
           const unsigned long long a0 = h_lo > base_h ? h_lo - base_h : 0ull;
           const unsigned long long a1 = h_hi - base_h < total ? h_hi - base_h : (unsigned long long)total;
           uint32_t k = 0;  // this lane's current start position (index into the compacted list)
-          for (unsigned long long hh = a0; hh < a1; hh += kWave) {
-            const uint32_t h = (uint32_t)hh + lane;
-            bool keep = h < (uint32_t)a1;
-            uint32_t i = 0, it = 0;
-            if (keep) {
-              while (s_npref[k + 1] <= h) k++;  // amortised: each lane advances at most n_nz times per block
-              it = s_nit[k];
-              i = s_nlo[k] + (h - s_npref[k]);
-              const uint32_t sl = ix.suf[i].slen;
-              uint32_t cmin;
-              if (sl < tab_n) cmin = s_cmin[sl];
-              else cmin = use_sig ? cover_threshold(p, sl, prm) : (reject_len(p, sl, prm) ? 0xffffu : 0u);
-              keep = cmin != 0xffffu;
-              if (keep && use_sig) {
-                // upper bound of the cover from the word signature: no token is touched for most hits
-                const unsigned long long sig = ix.suf_sig[i];
-                uint32_t ub = 0;
+          for (unsigned long long hh = a0; hh < a1; hh += kWave * kUnroll) {
+            // kUnroll independent hits per lane: their record/signature loads are all in flight before the
+            // first one is consumed (this loop is bound by HBM latency, not by instruction issue)
+            uint32_t hi_[kUnroll], hit_[kUnroll];
+            bool hv[kUnroll];
 #pragma unroll
-                for (uint32_t kk = 0; kk < kMaxPlanes; kk++)
-                  if (kk < n_planes) ub += (uint32_t)__popcll(sig & planes[kk]) << kk;
-                keep = ub >= cmin;
+            for (int u = 0; u < kUnroll; u++) {
+              const uint32_t h = (uint32_t)hh + u * kWave + lane;
+              hv[u] = h < (uint32_t)a1;
+              hi_[u] = 0; hit_[u] = 0;
+              if (hv[u]) {
+                while (s_npref[k + 1] <= h) k++;  // amortised: each lane advances at most n_nz times per block
+                hit_[u] = s_nit[k];
+                hi_[u] = s_nlo[k] + (h - s_npref[k]);
               }
             }
-            // phase A -> queue: hits that need their tokens looked at are compacted through LDS so that
-            // the expensive phase B always runs with (nearly) all 64 lanes busy
-            const unsigned long long mask = __ballot(keep);
-            if (keep) {
-              const uint32_t slot = (q_tail + __popcll(mask & ((1ull << lane) - 1ull))) & (kQueue - 1);
-              s_qi[slot] = i;
-              s_qit[slot] = it;
+            uint32_t hsl[kUnroll];
+            unsigned long long hsig[kUnroll];
+#pragma unroll
+            for (int u = 0; u < kUnroll; u++) {
+              hsl[u] = ix.suf[hi_[u]].slen;
+              hsig[u] = use_sig ? ix.suf_sig[hi_[u]] : 0ull;
             }
-            q_tail += __popcll(mask);
-            __syncthreads();
-            while (q_tail - q_head >= kWave) {
-              expand_phase_b(ix, prm, w, q, seg, cap, pat, s_pat, s_cmin, tab_n, p, m, use_sig, s_qi, s_qit, q_head, kWave);
-              q_head += kWave;
+#pragma unroll
+            for (int u = 0; u < kUnroll; u++) {
+              if ((uint32_t)hh + u * kWave >= (uint32_t)a1) break;  // uniform
+              bool keep = hv[u];
+              if (keep) {
+                const uint32_t sl = hsl[u];
+                uint32_t cmin;
+                if (sl < tab_n) cmin = s_cmin[sl];
+                else cmin = use_sig ? cover_threshold(p, sl, prm) : (reject_len(p, sl, prm) ? 0xffffu : 0u);
+                keep = cmin != 0xffffu;
+                if (keep && use_sig) {
+                  // upper bound of the cover from the word signature: no token is touched for most hits
+                  uint32_t ub = 0;
+#pragma unroll
+                  for (uint32_t kk = 0; kk < kMaxPlanes; kk++)
+                    if (kk < n_planes) ub += (uint32_t)__popcll(hsig[u] & planes[kk]) << kk;
+                  keep = ub >= cmin;
+                }
+              }
+              // phase A -> queue: hits that need their tokens looked at are compacted through LDS so that
+              // the expensive phase B always runs with (nearly) all 64 lanes busy
+              const unsigned long long mask = __ballot(keep);
+              if (mask) {
+                if (keep) {
+                  const uint32_t slot = (q_tail + __popcll(mask & ((1ull << lane) - 1ull))) & (kQueue - 1);
+                  s_qi[slot] = hi_[u];
+                  s_qit[slot] = hit_[u];
+                }
+                q_tail += __popcll(mask);
+                __syncthreads();
+                while (q_tail - q_head >= kWave) {
+                  expand_phase_b(ix, prm, w, q, seg, cap, pat, s_pat, s_cmin, tab_n, p, m, use_sig, s_qi, s_qit, q_head, kWave);
+                  q_head += kWave;
+                }
+              }
             }
           }
           base_h += total;
@@ -572,24 +595,143 @@ __global__ void __launch_bounds__(kWave) k_cand(DevWork w, uint32_t* big_list) {
 }
 
 constexpr int kBigThreads = 1024;
+constexpr int kBigWaves = kBigThreads / 64;
 constexpr int kBigGrid = 512;
 
-constexpr uint32_t kBigLdsKeys = 16384;  // 128 KB of keys: one workgroup per CU
+__device__ __forceinline__ uint32_t block_excl_scan_u32(uint32_t v, uint32_t* s_wsum) {
+  const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
+  uint32_t x = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t n = __shfl_up(x, d, 64);
+    if (lane >= (uint32_t)d) x += n;
+  }
+  if (lane == 63) s_wsum[wv] = x;
+  __syncthreads();
+  if (wv == 0) {
+    uint32_t y = lane < (uint32_t)kBigWaves ? s_wsum[lane] : 0u;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t n = __shfl_up(y, d, 64);
+      if (lane >= (uint32_t)d) y += n;
+    }
+    if (lane < (uint32_t)kBigWaves) s_wsum[lane] = y;
+  }
+  __syncthreads();
+  const uint32_t base = wv ? s_wsum[wv - 1] : 0u;
+  __syncthreads();
+  return base + x - v;
+}
 
-__global__ void __launch_bounds__(kBigThreads) k_cand_big(DevWork w, unsigned long long* big, const uint32_t* big_list) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned long long* s_keys = (unsigned long long*)smem;
+// One stable LSD radix pass (8-bit digit at `shift`) over n 64-bit keys, src -> dst, by a 1024-thread
+// workgroup.  Each wave owns a contiguous chunk; s_hist[wave][digit] first counts, then (after an
+// exclusive scan in digit-major, wave-minor order) holds the running output position.  Within a wave
+// the rank among equal digits comes from eight ballots, so the pass is stable.
+__device__ __forceinline__ void block_radix_pass(const unsigned long long* src, unsigned long long* dst, uint32_t n,
+                                                 uint32_t shift, uint32_t* s_hist, uint32_t* s_wsum) {
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  uint32_t len = (n + kBigWaves - 1) / kBigWaves;
+  len = (len + 63u) & ~63u;
+  const uint32_t beg = wv * len < n ? wv * len : n;
+  const uint32_t end = beg + len < n ? beg + len : n;
+  for (uint32_t i = tid; i < kBigWaves * 256; i += kBigThreads) s_hist[i] = 0;
+  __syncthreads();
+  for (uint32_t i = beg + lane; i < end; i += 64) atomicAdd(&s_hist[wv * 256 + (uint32_t)((src[i] >> shift) & 255ull)], 1u);
+  __syncthreads();
+  {
+    // entry e = digit * kBigWaves + wave; each thread owns 4 consecutive entries (kBigWaves * 256 / 1024)
+    constexpr int per = kBigWaves * 256 / kBigThreads;
+    uint32_t v[per], sum = 0;
+#pragma unroll
+    for (int k = 0; k < per; k++) {
+      const uint32_t e = tid * per + k;
+      v[k] = s_hist[(e % kBigWaves) * 256 + e / kBigWaves];
+      sum += v[k];
+    }
+    uint32_t ex = block_excl_scan_u32(sum, s_wsum);
+#pragma unroll
+    for (int k = 0; k < per; k++) {
+      const uint32_t e = tid * per + k;
+      s_hist[(e % kBigWaves) * 256 + e / kBigWaves] = ex;
+      ex += v[k];
+    }
+  }
+  __syncthreads();
+  for (uint32_t i0 = beg; i0 < end; i0 += 64) {
+    const uint32_t i = i0 + lane;
+    const bool valid = i < end;
+    const unsigned long long key = valid ? src[i] : 0ull;
+    const uint32_t d = (uint32_t)((key >> shift) & 255ull);
+    unsigned long long same = __ballot(valid);
+#pragma unroll
+    for (int bit = 0; bit < 8; bit++) {
+      const bool one = (d >> bit) & 1u;
+      const unsigned long long bal = __ballot(valid && one);
+      same &= one ? bal : ~bal;
+    }
+    if (valid) {
+      const uint32_t rank = __popcll(same & ((1ull << lane) - 1ull));
+      const uint32_t base = s_hist[wv * 256 + d];
+      dst[base + rank] = key;
+      if (rank == 0) s_hist[wv * 256 + d] = base + __popcll(same);
+    }
+  }
+  __syncthreads();
+}
+
+// k_cand_big — survivor sets beyond the LDS sorter: LSD radix sort by sentence id, per-sentence max
+// of the match length, then a stable radix sort by (0xffff - L): the reference's (longest desc, s_id
+// asc).  `big` is the global key scratch laid out like the segments at 2x: two buffers of n keys.
+__global__ void __launch_bounds__(kBigThreads) k_cand_big(DevWork w, unsigned long long* big, const uint32_t* big_list,
+                                                          uint32_t sid_bytes, uint32_t len_bytes) {
+  __shared__ uint32_t s_hist[kBigWaves * 256];
+  __shared__ uint32_t s_wsum[kBigWaves];
   __shared__ uint32_t s_count;
   const unsigned long long n_big = w.counters[7];
   for (unsigned long long idx = blockIdx.x; idx < n_big; idx += gridDim.x) {
     const uint32_t q = big_list[idx];
     const uint32_t n = w.q_kept[q];
-    const uint32_t np2 = next_pow2(n);
-    uint32_t kept;
-    // beyond the LDS capacity the global scratch is used; it mirrors the segment layout at 2x (pow2
-    // padding): 2 * q_seg[q]
-    if (np2 <= kBigLdsKeys) kept = cand_body(s_keys, w.seg + w.q_seg[q], n, np2, &s_count);
-    else kept = cand_body(big + 2ull * w.q_seg[q], w.seg + w.q_seg[q], n, np2, &s_count);
+    Cand* seg = w.seg + w.q_seg[q];
+    unsigned long long* A = big + 2ull * w.q_seg[q];
+    unsigned long long* B = A + n;
+    if (threadIdx.x == 0) s_count = 0;
+    for (uint32_t i = threadIdx.x; i < n; i += kBigThreads)
+      A[i] = ((unsigned long long)seg[i].sid << 16) | (seg[i].longest & 0xffffu);
+    __syncthreads();
+    unsigned long long *src = A, *dst = B;
+    for (uint32_t k = 0; k < sid_bytes; k++) {
+      block_radix_pass(src, dst, n, 16 + 8 * k, s_hist, s_wsum);
+      unsigned long long* t = src; src = dst; dst = t;
+    }
+    // per-sentence max: among the entries of one sentence keep the largest L (first one on ties)
+    uint32_t my_kept = 0;
+    for (uint32_t i = threadIdx.x; i < n; i += kBigThreads) {
+      const unsigned long long a = src[i];
+      const unsigned long long sid = a >> 16;
+      const uint32_t L = (uint32_t)(a & 0xffffu);
+      bool keep = true;
+      for (uint32_t j = i; j > 0 && (src[j - 1] >> 16) == sid;) { j--; if ((uint32_t)(src[j] & 0xffffu) >= L) keep = false; }
+      for (uint32_t j = i; j + 1 < n && (src[j + 1] >> 16) == sid;) { j++; if ((uint32_t)(src[j] & 0xffffu) > L) keep = false; }
+      dst[i] = keep ? (((unsigned long long)(0xffffu - L) << 32) | sid) : ~0ull;
+      my_kept += keep ? 1u : 0u;
+    }
+    my_kept = wave_sum(my_kept);
+    if (lane_id() == 0 && my_kept) atomicAdd(&s_count, my_kept);
+    __syncthreads();
+    { unsigned long long* t = src; src = dst; dst = t; }
+    for (uint32_t k = 0; k < len_bytes; k++) {
+      block_radix_pass(src, dst, n, 32 + 8 * k, s_hist, s_wsum);
+      unsigned long long* t = src; src = dst; dst = t;
+    }
+    const uint32_t kept = s_count;
+    for (uint32_t i = threadIdx.x; i < kept; i += kBigThreads) {
+      const unsigned long long a = src[i];
+      Cand c;
+      c.sid = (uint32_t)(a & 0xffffffffu);
+      c.longest = 0xffffu - (uint32_t)((a >> 32) & 0xffffu);
+      c.score = 0.f; c.penalty = 0.f;
+      seg[i] = c;
+    }
     if (threadIdx.x == 0) w.q_cand[q] = kept;
     __syncthreads();
   }

@@ -773,6 +773,39 @@ static int cand_comp(const void* pa, const void* pb) {
   return a->sid < b->sid ? -1 : a->sid > b->sid;
 }
 
+/* in-place sort of the candidate list (heapsort): glibc's qsort() mallocs a merge buffer, which for the
+ * wide queries means an mmap/munmap pair per query and serialises the worker threads in the kernel */
+static inline int cand_less(const cand* a, const cand* b) { return cand_comp(a, b) < 0; }
+
+static void cand_sift(cand* a, size_t root, size_t n) {
+  for (;;) {
+    size_t l = 2 * root + 1, r = l + 1, mx = root;
+    if (l < n && cand_less(&a[mx], &a[l])) mx = l;
+    if (r < n && cand_less(&a[mx], &a[r])) mx = r;
+    if (mx == root) return;
+    cand t = a[mx]; a[mx] = a[root]; a[root] = t;
+    root = mx;
+  }
+}
+
+static void cand_sort(cand* a, size_t n) {
+  if (n < 2) return;
+  if (n <= 16) {
+    for (size_t i = 1; i < n; i++) {
+      cand v = a[i];
+      size_t j = i;
+      while (j > 0 && cand_less(&v, &a[j - 1])) { a[j] = a[j - 1]; j--; }
+      a[j] = v;
+    }
+    return;
+  }
+  for (size_t i = n / 2; i-- > 0;) cand_sift(a, i, n);
+  for (size_t e = n - 1; e > 0; e--) {
+    cand t = a[0]; a[0] = a[e]; a[e] = t;
+    cand_sift(a, 0, e);
+  }
+}
+
 /* std::priority_queue<float> — max-heap */
 static void heap_push(fmo_scratch* s, float v) {
   if (s->heap_n + 1 > s->heap_cap) {
@@ -900,7 +933,7 @@ static int64_t match_impl(const fmo_index* ix, const fmo_params* prm, const uint
     const uint32_t h = sc->hused[k];
     sc->cands[n_cands].sid = sc->hkey[h] - 1; sc->cands[n_cands].longest = sc->hval[h]; n_cands++;
   }
-  qsort(sc->cands, n_cands, sizeof(cand), cand_comp);
+  cand_sort(sc->cands, n_cands);
 
   /* PatternCoverage ctor — src/pattern_coverage.cc:8-13 */
   uint64_t n_cov = 0;

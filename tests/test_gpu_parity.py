@@ -133,3 +133,29 @@ def test_known_answers_on_gpu(fmx, gpu_device):
             if "expect_score_minus_penalty" in q:
                 assert np.allclose(res["score"] - res["penalty"], q["expect_score_minus_penalty"], atol=q["tol"],
                                    rtol=0), case["name"]
+
+
+def test_big_candidate_sets(fmx, gpu_device):
+    """Thousands of surviving candidates per query: the 1024-thread radix sorter (k_cand_big), multi-chunk
+    replay and the global-scratch select path, plus s_max / workspace growth retries."""
+    rng = np.random.default_rng(7)
+    vocab = 8
+    c_off, c_tok = workloads.dense_corpus(rng, 30000, vocab, min_len=4, max_len=10)
+    q_off, q_tok = workloads.edge_queries(rng, c_off, c_tok, vocab, 48)
+    ix = fmx.Index.create(max_tokens=40)
+    ix.add_ids(c_off, c_tok, vocab + 2)
+    ix.sort(gpu_device)
+    ix.finalize()
+    ix.to_device(gpu_device)
+    o = oracle_lib.OracleIndex(max_tokens=40)
+    o.add_ids_bulk(c_off, c_tok, vocab + 2, sfreq=ix.array("sfreq"))
+    o.sort(os.cpu_count() or 1)
+    for name, kw in [("all", dict(fuzzy=0.2, nmatch=0, min_subseq_length=2, min_subseq_ratio=0)),
+                     ("top10_idf", dict(fuzzy=0.0, nmatch=10, min_subseq_length=2, min_subseq_ratio=0, idf_penalty=0.7)),
+                     ("contrast", dict(fuzzy=0.3, nmatch=6, min_subseq_length=2, min_subseq_ratio=0, contrast=0.4,
+                                       contrast_buffer=0))]:
+        cap = 128
+        oo, oc = o.match_batch(oracle_lib.Params(**kw), q_off, q_tok, cap, nthreads=os.cpu_count() or 1)
+        go, gc, gt, st = ix.match_batch(fmx.Params(**kw), q_off, q_tok, cap=cap, want_stats=True)
+        workloads.compare(oo, oc, go, gc, name)
+        assert st.n_big > 0 and st.max_kept > 1024, (name, st.n_big, st.max_kept)
