@@ -151,13 +151,70 @@ FMX_HD void mgram_range(const SufRec* __restrict__ suf, const uint32_t* __restri
   uint32_t step = 1;
   a = first;
   b = hi;
-  while (a + step < hi) {
+  while ((unsigned long long)a + step < hi) {
     if (start_by_from(tok, suf[a + step], ngram, 1, m) == 0) { a += step; step <<= 1; }
     else { b = a + step; break; }
   }
   while (b - a > 1) {
     const uint32_t mid = a + ((b - a) >> 1);
     if (start_by_from(tok, suf[mid], ngram, 1, m) == 0) a = mid; else b = mid;
+  }
+  out_lo = first;
+  out_hi = b;
+}
+
+// The four tokens that follow a suffix's first token, stored next to the suffix (0 past the end of the
+// sentence): a compare step of the binary search is one 16-byte load instead of record -> tokens.
+struct SufKey {
+  uint32_t t[4];
+};
+constexpr uint32_t kKeyTokens = 4;
+
+// start_by for the keyed layout: tokens [1, min(m, 5)) from the key, the rest (rare: the key already
+// narrowed the range to a handful of suffixes) from the token stream.  Requires ngram[k] != 0 for the
+// keyed positions, because a key token 0 means "sentence ended" (id 0 is also the empty word; callers
+// fall back to mgram_range when the pattern contains it).
+FMX_HD int start_by_keyed(const SufKey* __restrict__ key, const SufRec* __restrict__ suf, const uint32_t* __restrict__ tok,
+                          uint32_t i, const uint32_t* __restrict__ ngram, uint32_t m) {
+  const SufKey kk = key[i];
+  const uint32_t lim = m - 1 < kKeyTokens ? m - 1 : kKeyTokens;
+  for (uint32_t k = 0; k < lim; k++) {
+    const uint32_t a = kk.t[k], b = ngram[k + 1];
+    if (a < b) return -1;  // smaller token, or the sentence ended (0)
+    if (a > b) return 1;
+  }
+  if (m - 1 <= kKeyTokens) return 0;
+  return start_by_from(tok, suf[i], ngram, kKeyTokens + 1, m);
+}
+
+// mgram_range over the keyed layout; same result.
+FMX_HD void mgram_range_keyed(const SufKey* __restrict__ key, const SufRec* __restrict__ suf,
+                              const uint32_t* __restrict__ tok, const uint32_t* __restrict__ qva, uint32_t n_qva,
+                              const uint32_t* __restrict__ ngram, uint32_t m, uint32_t& out_lo, uint32_t& out_hi) {
+  for (uint32_t k = 1; k < m && k <= kKeyTokens; k++)
+    if (ngram[k] == 0) { mgram_range(suf, tok, qva, n_qva, ngram, m, out_lo, out_hi); return; }
+  out_lo = out_hi = 0;
+  const uint32_t w0 = ngram[0];
+  if (w0 + 1 >= n_qva) return;
+  uint32_t lo = qva[w0], hi = qva[w0 + 1];
+  if (m == 1 || lo >= hi) { out_lo = lo; out_hi = hi; return; }
+  uint32_t a = lo, b = hi;
+  while (a < b) {
+    const uint32_t mid = a + ((b - a) >> 1);
+    if (start_by_keyed(key, suf, tok, mid, ngram, m) < 0) a = mid + 1; else b = mid;
+  }
+  const uint32_t first = a;
+  if (first >= hi || start_by_keyed(key, suf, tok, first, ngram, m) != 0) { out_lo = out_hi = first; return; }
+  uint32_t step = 1;
+  a = first;
+  b = hi;
+  while ((unsigned long long)a + step < hi) {
+    if (start_by_keyed(key, suf, tok, a + step, ngram, m) == 0) { a += step; step <<= 1; }
+    else { b = a + step; break; }
+  }
+  while (b - a > 1) {
+    const uint32_t mid = a + ((b - a) >> 1);
+    if (start_by_keyed(key, suf, tok, mid, ngram, m) == 0) a = mid; else b = mid;
   }
   out_lo = first;
   out_hi = b;
@@ -183,12 +240,16 @@ FMX_HD bool dominated_hit(const uint32_t* __restrict__ tok, SufRec r, const uint
   return it > 0 && r.rem < r.slen && tok[r.off - 1] == pat_at_it[-1];
 }
 
-// 64-bit word signature of a sentence: bit sig_bit(w) is set for every word w of the sentence.  For a
+// 48-bit word signature of a sentence: bit sig_bit(w) is set for every word w of the sentence.  For a
 // pattern, the number of positions whose word's bit is set is an upper bound of
 // PatternCoverage::count_covered_words, and theoretical_rejection_cover is monotone in the cover
 // (for non-negative costs), so a candidate rejected with the upper bound is rejected by the
 // reference too: the exact token scan only runs for the few that pass.
-FMX_HD uint32_t sig_bit(uint32_t w) { return (w * 0x9E3779B1u) >> 26; }
+constexpr uint32_t kSigBits = 48;  // the other 16 bits of the packed word hold the sentence length
+FMX_HD uint32_t sig_bit(uint32_t w) { return (uint32_t)(((unsigned long long)(w * 0x9E3779B1u) * kSigBits) >> 32); }
+FMX_HD unsigned long long sig_pack(uint32_t slen, unsigned long long sig) { return ((unsigned long long)slen << kSigBits) | sig; }
+FMX_HD uint32_t sig_slen(unsigned long long packed) { return (uint32_t)(packed >> kSigBits); }
+FMX_HD unsigned long long sig_bits(unsigned long long packed) { return packed & ((1ull << kSigBits) - 1ull); }
 
 FMX_HD uint32_t sig_cover_upper(unsigned long long sig, const uint8_t* __restrict__ hbit, uint32_t p) {
   uint32_t c = 0;

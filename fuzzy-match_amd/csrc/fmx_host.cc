@@ -300,7 +300,13 @@ void HostIndex::derive() {
       sent_sig[sdx] = sg;
     }
     suf_sig.resize(n);
-    for (uint64_t i = 0; i < n; i++) suf_sig[i] = sent_sig[suf_sid[i]];
+    suf_key.resize(n);
+    for (uint64_t i = 0; i < n; i++) {
+      suf_sig[i] = sig_pack(suf_rec[i].slen, sent_sig[suf_sid[i]]);
+      SufKey k;
+      for (uint32_t t = 0; t < kKeyTokens; t++) k.t[t] = t + 1 < suf_rec[i].rem ? buf[suf_rec[i].off + 1 + t] : 0u;
+      suf_key[i] = k;
+    }
   }
   // compute_idf_penalty / compute_max_idf_penalty — src/fuzzy_match.cc:367-390 (glibc logf / log)
   const unsigned N = num_sentences();

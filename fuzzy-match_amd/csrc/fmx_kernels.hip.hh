@@ -18,7 +18,8 @@ namespace fmx {
 
 struct DevIndex {
   const SufRec*   suf;
-  const unsigned long long* suf_sig;  // word signature of the suffix's sentence
+  const unsigned long long* suf_sig;  // sentence length << 48 | 48-bit word signature
+  const SufKey*   suf_key;    // four tokens after the first, per suffix
   const uint32_t* suf_sid;
   const uint32_t* tok;
   const uint32_t* sent_pos;
@@ -129,7 +130,7 @@ __global__ void __launch_bounds__(256) k_probe(DevIndex ix, DevBatch b, DevWork 
     // with p == 1 the only registered length is 1.
     const bool reachable = (p == 1) ? (msl <= 1) : true;
     if (reachable && it + m <= p)
-      mgram_range(ix.suf, ix.tok, ix.qva, ix.n_qva, b.q_tok + b.t_begin + t, m, lo, hi);
+      mgram_range_keyed(ix.suf_key, ix.suf, ix.tok, ix.qva, ix.n_qva, b.q_tok + b.t_begin + t, m, lo, hi);
   }
   const uint32_t cnt = hi - lo;
   w.t_lo[t] = lo;
@@ -424,8 +425,9 @@ __global__ void __launch_bounds__(kWave) k_expand(DevIndex ix, DevBatch b, DevWo
             unsigned long long hsig[kUnroll];
 #pragma unroll
             for (int u = 0; u < kUnroll; u++) {
-              hsl[u] = ix.suf[hi_[u]].slen;
-              hsig[u] = use_sig ? ix.suf_sig[hi_[u]] : 0ull;
+              const unsigned long long packed = ix.suf_sig[hi_[u]];  // the only HBM read of phase A: 8 B per hit
+              hsl[u] = sig_slen(packed);
+              hsig[u] = sig_bits(packed);
             }
 #pragma unroll
             for (int u = 0; u < kUnroll; u++) {

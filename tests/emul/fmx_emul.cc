@@ -16,7 +16,7 @@ using namespace fmx;
 struct Rec { float score; float penalty; int32_t max_subseq; uint32_t s_id; };
 
 struct EmulIndex {
-  const SufRec* suf; const uint64_t* suf_sig; const uint32_t* suf_sid; const uint32_t* tok; const uint32_t* sent_pos; const uint32_t* qva;
+  const SufRec* suf; const uint64_t* suf_sig; const SufKey* suf_key; const uint32_t* suf_sid; const uint32_t* tok; const uint32_t* sent_pos; const uint32_t* qva;
   const float* idf; const uint32_t* real; const uint32_t* itok; const uint16_t* itok_dist;
   uint32_t n_itok, n_qva;
 };
@@ -49,14 +49,18 @@ extern "C" int emul_match_batch(const EmulIndex* ix, const Params* prm_in, uint6
     const bool use_sig = prm.ins >= 0.f && prm.del >= 0.f && prm.rep >= 0.f;
     for (uint32_t it = 0; it < p; it++) {
       uint32_t lo = 0, hi = 0;
-      if (reachable && it + m <= p) mgram_range(ix->suf, ix->tok, ix->qva, ix->n_qva, pat + it, m, lo, hi);
+      if (reachable && it + m <= p) mgram_range_keyed(ix->suf_key, ix->suf, ix->tok, ix->qva, ix->n_qva, pat + it, m, lo, hi);
       if (stats) stats[0] += hi - lo;
       for (uint32_t i = lo; i < hi; i++) {
         const SufRec r = ix->suf[i];
-        if (reject_len(p, r.slen, prm)) continue;
+        // phase A reads only the packed (sentence length, signature) word
+        const unsigned long long packed = ix->suf_sig[i];
+        const uint32_t sl = sig_slen(packed);
+        if (sl != r.slen) return -2;
+        if (reject_len(p, sl, prm)) continue;
         // the kernel tabulates cover_threshold per sentence length and compares the signature's upper bound
-        const uint32_t cmin = use_sig ? cover_threshold(p, r.slen, prm) : 0u;
-        if (use_sig && (cmin == 0xffffu || sig_cover_upper(ix->suf_sig[i], hbit.data(), p) < cmin)) continue;
+        const uint32_t cmin = use_sig ? cover_threshold(p, sl, prm) : 0u;
+        if (use_sig && (cmin == 0xffffu || sig_cover_upper(sig_bits(packed), hbit.data(), p) < cmin)) continue;
         if (dominated_hit(ix->tok, r, pat + it, it)) continue;
         Cand c;
         c.longest = lcp_extend(ix->tok, r, pat + it, m, p - it);

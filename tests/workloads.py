@@ -47,7 +47,7 @@ def edge_queries(rng, c_off, c_tok, vocab, n):
     offs, toks = [0], []
     ns = len(c_off) - 1
     for i in range(n):
-        kind = i % 8
+        kind = i % 9
         if kind == 0:
             s = int(rng.integers(0, ns))
             t = list(c_tok[c_off[s]:c_off[s + 1]])
@@ -72,8 +72,12 @@ def edge_queries(rng, c_off, c_tok, vocab, n):
             a = list(c_tok[c_off[s]:c_off[s + 1]])
             s2 = int(rng.integers(0, ns))
             t = a + list(c_tok[c_off[s2]:c_off[s2 + 1]])
-        else:
+        elif kind == 7:
             t = [1, 1, 1]
+        else:  # the empty word (id 0, also the sentence separator) inside a pattern
+            s = int(rng.integers(0, ns))
+            t = list(c_tok[c_off[s]:c_off[s + 1]])
+            t.insert(int(rng.integers(0, len(t) + 1)), 0)
         toks.extend(int(x) for x in t)
         offs.append(len(toks))
     return np.asarray(offs, np.uint32), np.asarray(toks, np.uint32)
