@@ -211,7 +211,7 @@ __global__ void __launch_bounds__(kScanThreads) k_scan_add(unsigned long long* o
 // k_caps — per query: segment capacity min(hits, s_max) (input of the scan) and, for queries with
 // more than kExpandChunk hits, extra work items so that several waves share the walk.
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t kExpandChunk = 2048;  // suffix hits per k_expand work item
+constexpr uint32_t kExpandChunk = 4096;  // suffix hits per k_expand work item
 constexpr uint32_t kExpandExtraGrid = 8192;
 
 struct WorkItem {
@@ -255,7 +255,79 @@ __device__ __forceinline__ uint32_t cover_lds(const uint32_t* __restrict__ sent,
 }
 
 constexpr uint32_t kCminTab = 1024;   // sentence lengths covered by the per-query threshold table
-constexpr uint32_t kMaxPlanes = 17;   // bit planes of the per-bucket position counts (p < 2^17)
+constexpr uint32_t kMaxPlanes = 8;    // bit planes of the per-bucket position counts (counts < 256)
+
+// Per-work-item hash set of the pattern's distinct words (p <= 64): slot -> distinct index, and the number
+// of pattern positions per distinct word.  count_covered_words becomes one LDS probe per sentence token.
+constexpr uint32_t kHashSlots = 128;
+constexpr uint32_t kHashEmpty = 0xffffffffu;
+
+struct PatHash {
+  uint32_t key[kHashSlots];
+  uint32_t idx[kHashSlots];
+  uint32_t cnt[kWave];
+};
+
+__device__ __forceinline__ uint32_t pat_hash_slot(uint32_t w) { return (w * 0x85EBCA6Bu) >> 25; }
+
+// one wave, p <= 64
+__device__ __forceinline__ void pat_hash_build(PatHash& ph, const uint32_t* s_pat, uint32_t p) {
+  const uint32_t lane = lane_id();
+  ph.key[lane] = kHashEmpty; ph.key[lane + 64] = kHashEmpty;
+  ph.cnt[lane] = 0;
+  __syncthreads();
+  if (lane < p) {
+    const uint32_t wd = s_pat[lane];
+    uint32_t h = pat_hash_slot(wd);
+    for (;;) {
+      const uint32_t old = atomicCAS(&ph.key[h], kHashEmpty, wd);
+      if (old == kHashEmpty || old == wd) break;
+      h = (h + 1) & (kHashSlots - 1);
+    }
+  }
+  __syncthreads();
+  // distinct indices: rank of the occupied slots
+  uint32_t base = 0;
+#pragma unroll
+  for (int half = 0; half < 2; half++) {
+    const bool occ = ph.key[lane + 64 * half] != kHashEmpty;
+    const unsigned long long m = __ballot(occ);
+    if (occ) ph.idx[lane + 64 * half] = base + __popcll(m & ((1ull << lane) - 1ull));
+    base += __popcll(m);
+  }
+  __syncthreads();
+  if (lane < p) {
+    const uint32_t wd = s_pat[lane];
+    uint32_t h = pat_hash_slot(wd);
+    while (ph.key[h] != wd) h = (h + 1) & (kHashSlots - 1);
+    atomicAdd(&ph.cnt[ph.idx[h]], 1u);
+  }
+  __syncthreads();
+}
+
+// does the sentence cover at least `need` pattern positions?  (PatternCoverage::count_covered_words
+// compared with the threshold; stops as soon as the answer is yes)
+__device__ __forceinline__ bool cover_at_least(const PatHash& ph, const uint32_t* __restrict__ sent, uint32_t slen,
+                                               uint32_t need) {
+  unsigned long long seen = 0;
+  uint32_t cover = 0;
+  if (need == 0) return true;
+  for (uint32_t k = 0; k < slen; k++) {
+    const uint32_t t = sent[k];
+    uint32_t h = pat_hash_slot(t);
+    uint32_t key = ph.key[h];
+    while (key != t && key != kHashEmpty) { h = (h + 1) & (kHashSlots - 1); key = ph.key[h]; }
+    if (key == t) {
+      const uint32_t d = ph.idx[h];
+      if (!((seen >> d) & 1ull)) {
+        seen |= 1ull << d;
+        cover += ph.cnt[d];
+        if (cover >= need) return true;
+      }
+    }
+  }
+  return false;
+}
 
 constexpr int kUnroll = 4;        // hits per lane per phase-A iteration
 constexpr uint32_t kQueue = 128;  // LDS ring of hits that passed the cheap tests (power of two >= 2 * 64)
@@ -265,8 +337,8 @@ constexpr uint32_t kQueue = 128;  // LDS ring of hits that passed the cheap test
 __device__ __forceinline__ void expand_phase_b(const DevIndex& ix, const Params& prm, const DevWork& w, uint32_t q,
                                                Cand* seg, uint32_t cap, const uint32_t* pat, const uint32_t* s_pat,
                                                const uint16_t* s_cmin, uint32_t tab_n, uint32_t p, uint32_t m,
-                                               int use_sig, const uint32_t* s_qi, const uint32_t* s_qit,
-                                               uint32_t head, uint32_t n_take) {
+                                               int use_sig, const PatHash& ph, const uint32_t* s_qi,
+                                               const uint32_t* s_qit, uint32_t head, uint32_t n_take) {
   const uint32_t lane = lane_id();
   bool keep = lane < n_take;
   uint32_t sid = 0, L = 0;
@@ -278,9 +350,16 @@ __device__ __forceinline__ void expand_phase_b(const DevIndex& ix, const Params&
     if (keep) {
       L = lcp_extend(ix.tok, r, pat + it, m, p - it);
       const uint32_t sl = r.slen;
-      const uint32_t cover = L < p ? cover_lds(ix.tok + (r.off - (uint32_t)(r.slen - r.rem)), sl, s_pat, p) : p;
-      if (use_sig) keep = cover >= (sl < tab_n ? (uint32_t)s_cmin[sl] : cover_threshold(p, sl, prm));
-      else keep = !reject_cover(p, sl, cover, prm);
+      const uint32_t* sent = ix.tok + (r.off - (uint32_t)(r.slen - r.rem));
+      if (use_sig) {
+        const uint32_t need = sl < tab_n ? (uint32_t)s_cmin[sl] : cover_threshold(p, sl, prm);
+        if (L >= p) keep = p >= need;
+        else if (p <= kWave) keep = cover_at_least(ph, sent, sl, need);
+        else keep = cover_lds(sent, sl, s_pat, p) >= need;
+      } else {
+        const uint32_t cover = L < p ? cover_lds(sent, sl, s_pat, p) : p;
+        keep = !reject_cover(p, sl, cover, prm);
+      }
       if (keep) sid = ix.suf_sid[i];
     }
   }
@@ -329,6 +408,7 @@ __global__ void __launch_bounds__(kWave) k_expand(DevIndex ix, DevBatch b, DevWo
   __shared__ uint32_t s_nit[kWave];
   __shared__ uint32_t s_bucket[kWave];
   __shared__ uint32_t s_qi[kQueue], s_qit[kQueue];
+  __shared__ PatHash ph;
   const uint32_t lane = lane_id();
   uint32_t q, chunk;
   uint32_t item_idx = 0;
@@ -366,18 +446,29 @@ __global__ void __launch_bounds__(kWave) k_expand(DevIndex ix, DevBatch b, DevWo
           atomicAdd(&s_bucket[sig_bit(wd)], 1u);
         }
         const uint32_t tab_n = ix.max_slen + 1 < kCminTab ? ix.max_slen + 1 : kCminTab;
-        for (uint32_t sl = lane; sl < tab_n; sl += kWave)
-          s_cmin[sl] = use_sig ? (uint16_t)cover_threshold(p, sl, prm) : (uint16_t)(reject_len(p, sl, prm) ? 0xffffu : 0u);
+        for (uint32_t sl = lane; sl < tab_n; sl += kWave) {
+          // the length filter first (one evaluation); the threshold search only for lengths that pass it
+          uint32_t c = reject_len(p, sl, prm) ? 0xffffu : 0u;
+          if (c == 0u && use_sig) c = cover_threshold(p, sl, prm);
+          s_cmin[sl] = (uint16_t)c;
+        }
         __syncthreads();
+        if (use_sig && p <= kWave) pat_hash_build(ph, s_pat, p);
         unsigned long long planes[kMaxPlanes];
         uint32_t n_planes = 0;
+        bool sig_off = false;
         {
           const uint32_t mycnt = s_bucket[lane];
+          // a bucket with >= 2^kMaxPlanes pattern positions (p >= 256) would overflow the planes: the
+          // signature bound is then replaced by its trivial value p (always passes)
+          const bool overflow = __ballot(mycnt >> kMaxPlanes) != 0ull;
 #pragma unroll
           for (uint32_t k = 0; k < kMaxPlanes; k++) {
-            planes[k] = __ballot((mycnt >> k) & 1u);
+            planes[k] = overflow ? (k == 0 ? ~0ull : 0ull) : __ballot((mycnt >> k) & 1u);
             if (planes[k]) n_planes = k + 1;
           }
+          if (overflow) { planes[0] = 0ull; n_planes = 0; }
+          sig_off = overflow;
         }
         Cand* seg = w.seg + seg0;
         const unsigned long long h_lo = (unsigned long long)chunk * kExpandChunk;
@@ -439,7 +530,7 @@ __global__ void __launch_bounds__(kWave) k_expand(DevIndex ix, DevBatch b, DevWo
                 if (sl < tab_n) cmin = s_cmin[sl];
                 else cmin = use_sig ? cover_threshold(p, sl, prm) : (reject_len(p, sl, prm) ? 0xffffu : 0u);
                 keep = cmin != 0xffffu;
-                if (keep && use_sig) {
+                if (keep && use_sig && !sig_off) {
                   // upper bound of the cover from the word signature: no token is touched for most hits
                   uint32_t ub = 0;
 #pragma unroll
@@ -460,7 +551,7 @@ __global__ void __launch_bounds__(kWave) k_expand(DevIndex ix, DevBatch b, DevWo
                 q_tail += __popcll(mask);
                 __syncthreads();
                 while (q_tail - q_head >= kWave) {
-                  expand_phase_b(ix, prm, w, q, seg, cap, pat, s_pat, s_cmin, tab_n, p, m, use_sig, s_qi, s_qit, q_head, kWave);
+                  expand_phase_b(ix, prm, w, q, seg, cap, pat, s_pat, s_cmin, tab_n, p, m, use_sig, ph, s_qi, s_qit, q_head, kWave);
                   q_head += kWave;
                 }
               }
@@ -470,7 +561,7 @@ __global__ void __launch_bounds__(kWave) k_expand(DevIndex ix, DevBatch b, DevWo
         }
         if (lane == 0 && q_tail) atomicAdd(&w.q_pb[q], q_tail);
         if (q_tail != q_head)
-          expand_phase_b(ix, prm, w, q, seg, cap, pat, s_pat, s_cmin, tab_n, p, m, use_sig, s_qi, s_qit, q_head, q_tail - q_head);
+          expand_phase_b(ix, prm, w, q, seg, cap, pat, s_pat, s_cmin, tab_n, p, m, use_sig, ph, s_qi, s_qit, q_head, q_tail - q_head);
       }
     }
     if (!extra) return;
