@@ -98,19 +98,16 @@ def main():
     d_tok = torch.from_numpy(q_tok.astype(np.int32)).to(dev)
     d_out = torch.zeros((nq, cap, 4), dtype=torch.int32, device=dev)
     d_cnt = torch.zeros(nq, dtype=torch.int32, device=dev)
-    gather_out = gather_cnt = None
-    if world > 1 and rank == 0:
-        gather_out = [torch.empty_like(d_out) for _ in range(world)]
-        gather_cnt = [torch.empty_like(d_cnt) for _ in range(world)]
+    shard = fmx_import.load().shard
+    max_len = int(np.diff(q_off).max()) if nq else 0
     stream = torch.cuda.current_stream().cuda_stream
     total_tokens = int(q_off[-1])
 
     def step():
         st = ix.match_batch_device(params, nq, d_off.data_ptr(), d_tok.data_ptr(), total_tokens, d_out.data_ptr(),
-                                   d_cnt.data_ptr(), 0, cap, stream=stream)
+                                   d_cnt.data_ptr(), 0, cap, stream=stream, max_len=max_len)
         if world > 1:  # the only collective of the path: top-N records to rank 0 over xGMI
-            dist.gather(d_out, gather_out, dst=0)
-            dist.gather(d_cnt, gather_cnt, dst=0)
+            shard.gather_records(d_out, d_cnt, dst=0)
         return st
 
     def sync():

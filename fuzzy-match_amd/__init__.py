@@ -6,3 +6,4 @@ The directory name is not a Python identifier; import it through `fmx_import.loa
 (registers it as `fuzzy_match_amd`).
 """
 from . import fmx  # noqa: F401
+from . import shard  # noqa: F401

@@ -290,7 +290,7 @@ int fmx_match_batch_device(fmx_index* ix, const fmx_params* params, const fmx_ba
     std::lock_guard<std::mutex> lk(ix->mu);
     DeviceBatchView v;
     v.nq = db->nq; v.q_off = db->q_off; v.q_tok = db->q_tok; v.q_real = db->q_real; v.q_itok = db->q_itok;
-    v.p_max = 0;
+    v.p_max = db->max_len;
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<uint32_t> bounds = ix->dev->sub_bounds_from_device(db->q_off, db->nq, &v.p_max, stream);
     if (v.p_max == 0) v.p_max = 1;

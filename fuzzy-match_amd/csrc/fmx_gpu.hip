@@ -279,10 +279,15 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm_in, const D
         const unsigned grid = 256 * 16;  // grid-stride over the flat candidate list
         if (full) {
           HIP_TRY(hipFuncSetAttribute((const void*)k_dp<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-          hipLaunchKernelGGL(k_dp<true>, dim3(grid), dim3(kWave), lds, stream, m.d, b, w, prm);
+          hipLaunchKernelGGL(k_dp<true>, dim3(grid), dim3(kWave), lds, stream, m.d, b, w, prm, 0u);
         } else {
-          HIP_TRY(hipFuncSetAttribute((const void*)k_dp<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-          hipLaunchKernelGGL(k_dp<false>, dim3(grid), dim3(kWave), lds, stream, m.d, b, w, prm);
+          // patterns up to 64 tokens: row and pattern in registers; longer ones: rows in LDS
+          hipLaunchKernelGGL(k_dp_reg<32>, dim3(grid), dim3(kWave), 0, stream, m.d, b, w, prm);
+          if (p_max > 32) hipLaunchKernelGGL(k_dp_reg<64>, dim3(grid), dim3(kWave), 0, stream, m.d, b, w, prm);
+          if (p_max > 64) {
+            HIP_TRY(hipFuncSetAttribute((const void*)k_dp<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k_dp<false>, dim3(grid), dim3(kWave), lds, stream, m.d, b, w, prm, 64u);
+          }
         }
       }
       tick(); tick();
@@ -297,7 +302,7 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm_in, const D
                            d_out_count, d_out_total);
       }
       tick();
-      hipLaunchKernelGGL(k_stats, dim3((b.nq + 255) / 256), dim3(256), 0, stream, w, b.nq);
+      hipLaunchKernelGGL(k_stats, dim3((b.nq + 1023) / 1024), dim3(1024), 0, stream, w, b.nq);
       HIP_TRY(hipGetLastError());
       unsigned long long ctr[16];
       HIP_TRY(hipMemcpyAsync(ctr, w.counters, sizeof(ctr), hipMemcpyDeviceToHost, stream));

@@ -851,7 +851,7 @@ struct LdsRow {
 };
 
 template <bool FULL>
-__global__ void __launch_bounds__(kWave) k_dp(DevIndex ix, DevBatch b, DevWork w, Params prm) {
+__global__ void __launch_bounds__(kWave) k_dp(DevIndex ix, DevBatch b, DevWork w, Params prm, uint32_t skip_up_to) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* s_rows = (float*)smem;
   const uint32_t lane = lane_id();
@@ -870,6 +870,7 @@ __global__ void __launch_bounds__(kWave) k_dp(DevIndex ix, DevBatch b, DevWork w
     const uint32_t sid = cd->sid;
     const uint32_t o0 = b.q_off[b.q_begin + q];
     const uint32_t p = b.q_off[b.q_begin + q + 1] - o0;
+    if (p <= skip_up_to) continue;  // done by k_dp_reg
     const uint32_t* pat = b.q_tok + o0;
     const uint32_t sp = ix.sent_pos[sid];
     const uint32_t slen = ix.tok[sp];
@@ -894,6 +895,81 @@ __global__ void __launch_bounds__(kWave) k_dp(DevIndex ix, DevBatch b, DevWork w
     float M;
     const float final_cost = edit_distance<FULL>(sent, slen, pat, p, prm.ins, prm.del, prm.rep, dw, side, FLT_MAX,
                                                  LdsRow{s_rows + lane}, M);
+    cd->score = final_cost;
+    cd->penalty = M;
+    cd->longest = (cd->longest & 0xffffu) | (slen << 16);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_dp_reg — the ids-only edit distance (no real-token / penalty-token / idf terms) for patterns of up
+// to 64 tokens with the DP row and the pattern held in registers: every loop over the pattern is fully
+// unrolled, columns beyond the pattern length compute don't-care values that never feed a valid cell
+// (dependencies only run left to right), and no LDS or memory access remains in the cell update.
+// Same operations in the same order as edit_distance<false>, so the results are bit-identical.
+// ---------------------------------------------------------------------------------------------
+template <int P>
+__device__ __forceinline__ float edit_distance_reg(const uint32_t* __restrict__ sent, uint32_t n1,
+                                                   const uint32_t* __restrict__ pat, uint32_t n2, float ins,
+                                                   float del, float rep, float dw, float& M_out) {
+  const float del_dw = del * dw, ins_dw = ins * dw, rep_dw = rep * dw;
+  float    row[P + 1];
+  uint32_t pt[P];
+#pragma unroll
+  for (int j = 0; j < P; j++) pt[j] = (uint32_t)j < n2 ? pat[j] : 0xffffffffu;
+  row[0] = 0.f;
+#pragma unroll
+  for (int j = 1; j <= P; j++) row[j] = row[j - 1] + ins_dw;
+  float M = 0.f, final_v = 0.f;
+  for (uint32_t i = 1; i <= n1; i++) {
+    const uint32_t wd = sent[i - 1];
+    float diag = row[0];
+    float left = diag + del_dw;
+    row[0] = left;
+    float mn = FLT_MAX;
+#pragma unroll
+    for (int j = 1; j <= P; j++) {
+      const float up = row[j];
+      const float diff = (wd != pt[j - 1]) ? rep_dw : 0.f;
+      const float d = fmin2(fmin2(up + del_dw, left + ins_dw), diag + diff);
+      row[j] = d;
+      const float mn2 = fmin2(mn, d);
+      mn = (uint32_t)j <= n2 ? mn2 : mn;
+      final_v = (uint32_t)j == n2 ? d : final_v;
+      diag = up;
+      left = d;
+    }
+    if (mn > M) M = mn;
+  }
+  if (final_v > M) M = final_v;
+  M_out = M;
+  return final_v;
+}
+
+template <int P>
+__global__ void __launch_bounds__(kWave) k_dp_reg(DevIndex ix, DevBatch b, DevWork w, Params prm) {
+  const uint32_t lane = lane_id();
+  const unsigned long long total = w.c_off[b.nq];
+  for (unsigned long long j = (unsigned long long)blockIdx.x * kWave + lane; j < total;
+       j += (unsigned long long)gridDim.x * kWave) {
+    uint32_t a = 0, bnd = b.nq;
+    while (bnd - a > 1) {
+      const uint32_t mid = (a + bnd) >> 1;
+      if (w.c_off[mid] <= j) a = mid; else bnd = mid;
+    }
+    const uint32_t q = a;
+    const uint32_t o0 = b.q_off[b.q_begin + q];
+    const uint32_t p = b.q_off[b.q_begin + q + 1] - o0;
+    if (p > (uint32_t)P || (P == 64 && p <= 32)) continue;  // other lengths: k_dp_reg<32>, k_dp<false>
+    Cand* cd = w.seg + w.q_seg[q] + (j - w.c_off[q]);
+    const uint32_t sid = cd->sid;
+    const uint32_t* pat = b.q_tok + o0;
+    const uint32_t sp = ix.sent_pos[sid];
+    const uint32_t slen = ix.tok[sp];
+    const uint32_t* sent = ix.tok + sp + 1;
+    const float dw = 100.f / normalizer(p, slen, prm.ins, prm.del, prm.rep);
+    float M;
+    const float final_cost = edit_distance_reg<P>(sent, slen, pat, p, prm.ins, prm.del, prm.rep, dw, M);
     cd->score = final_cost;
     cd->penalty = M;
     cd->longest = (cd->longest & 0xffffu) | (slen << 16);
@@ -1101,7 +1177,10 @@ __global__ void __launch_bounds__(kWave) k_finish(DevIndex ix, DevBatch b, DevWo
 
 // per-call statistics from the per-query arrays (kept out of the hot kernels: one shared atomic
 // per query costs more than the kernels' real work)
-__global__ void __launch_bounds__(256) k_stats(DevWork w, uint32_t nq) {
+__global__ void __launch_bounds__(1024) k_stats(DevWork w, uint32_t nq) {
+  __shared__ unsigned long long s_v[6];
+  if (threadIdx.x < 6) s_v[threadIdx.x] = 0;
+  __syncthreads();
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long v[5] = {0, 0, 0, 0, 0};
   unsigned long long mx = 0;
@@ -1110,16 +1189,19 @@ __global__ void __launch_bounds__(256) k_stats(DevWork w, uint32_t nq) {
     v[1] = w.q_kept[q]; v[2] = w.q_cand[q]; v[3] = w.q_cand[q]; v[4] = w.q_pb[q];
     mx = w.q_kept[q];
   }
-  const int slot[5] = {0, 1, 2, 3, 8};
 #pragma unroll
   for (int k = 0; k < 5; k++) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v[k] += __shfl_xor(v[k], d, 64);
-    if ((threadIdx.x & 63) == 0 && v[k]) atomicAdd(&w.counters[slot[k]], v[k]);
+    if ((threadIdx.x & 63) == 0 && v[k]) atomicAdd(&s_v[k], v[k]);
   }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) { const unsigned long long o = __shfl_xor(mx, d, 64); mx = o > mx ? o : mx; }
-  if ((threadIdx.x & 63) == 0 && mx) atomicMax(&w.counters[9], mx);
+  if ((threadIdx.x & 63) == 0 && mx) atomicMax(&s_v[5], mx);
+  __syncthreads();
+  const int slot[5] = {0, 1, 2, 3, 8};
+  if (threadIdx.x < 5 && s_v[threadIdx.x]) atomicAdd(&w.counters[slot[threadIdx.x]], s_v[threadIdx.x]);
+  if (threadIdx.x == 5 && s_v[5]) atomicMax(&w.counters[9], s_v[5]);
 }
 
 }  // namespace fmx

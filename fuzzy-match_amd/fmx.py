@@ -42,7 +42,7 @@ class Params(C.Structure):
 
 class Batch(C.Structure):
     _fields_ = [("nq", C.c_uint64), ("q_off", C.c_void_p), ("q_tok", C.c_void_p),
-                ("q_real", C.c_void_p), ("q_itok", C.c_void_p)]
+                ("q_real", C.c_void_p), ("q_itok", C.c_void_p), ("max_len", C.c_uint32)]
 
 
 class Stats(C.Structure):
@@ -250,7 +250,7 @@ class Index:
             q_real = np.ascontiguousarray(q_real, dtype=np.uint32)
         if q_itok is not None:
             q_itok = np.ascontiguousarray(q_itok, dtype=np.uint32)
-        b = Batch(nq, _ptr(q_off), _ptr(q_tok), _ptr(q_real), _ptr(q_itok))
+        b = Batch(nq, _ptr(q_off), _ptr(q_tok), _ptr(q_real), _ptr(q_itok), 0)
         st = Stats()
         _check(lib().fmx_match_batch(self.h, C.byref(params), C.byref(b), _ptr(out), _ptr(cnt), _ptr(tot), cap,
                                      C.byref(st)))
@@ -258,9 +258,9 @@ class Index:
         return res + (st,) if want_stats else res
 
     def match_batch_device(self, params, nq, d_q_off, d_q_tok, total_tokens, d_out, d_count, d_total, cap,
-                           stream=0, d_q_real=0, d_q_itok=0):
+                           stream=0, d_q_real=0, d_q_itok=0, max_len=0):
         """Same with raw device pointers (ints) — buffers owned by the caller (e.g. torch tensors)."""
-        b = Batch(nq, d_q_off, d_q_tok, d_q_real or None, d_q_itok or None)
+        b = Batch(nq, d_q_off, d_q_tok, d_q_real or None, d_q_itok or None, max_len)
         st = Stats()
         _check(lib().fmx_match_batch_device(self.h, C.byref(params), C.byref(b), total_tokens, d_out, d_count,
                                             d_total or None, cap, stream or None, C.byref(st)))

@@ -169,6 +169,7 @@ class FuzzyMatch {
     b.nq = 1; b.q_off = q_off; b.q_tok = wids.data();
     b.q_real = q_real.empty() ? nullptr : q_real.data();
     b.q_itok = q_itok.empty() ? nullptr : q_itok.data();
+    b.max_len = p;
     uint32_t cap = number_of_matches ? number_of_matches : 64;
     std::vector<fmx_match> out;
     uint32_t count = 0, total = 0;

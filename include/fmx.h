@@ -72,6 +72,7 @@ typedef struct fmx_batch {
   const uint32_t* q_tok;
   const uint32_t* q_real;
   const uint32_t* q_itok;
+  uint32_t        max_len; /* longest pattern of the batch if known, else 0 (computed on the device) */
 } fmx_batch;
 
 /* per-call measurements (all optional reading) */
