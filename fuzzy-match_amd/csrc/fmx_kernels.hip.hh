@@ -60,6 +60,7 @@ struct DevWork {
   uint32_t* q_pb;       // nq   hits that reached the token-touching phase of k_expand (statistics)
   unsigned long long* c_in;    // nq+1 q_cand widened (scan input)
   unsigned long long* c_off;   // nq+1 exclusive scan of q_cand: flat candidate list
+  uint32_t* c_q;        // seg_cap  query of each flat candidate
   float*    t_idf;      // nt   idf_penalty per pattern position (src/fuzzy_match.cc:372-390)
   Cand*     seg;        // capacity seg_cap
   float*    heap;       // capacity seg_cap + nq (lowest_costs spill)
@@ -836,6 +837,14 @@ __global__ void k_widen(const uint32_t* in, unsigned long long* out, uint32_t n,
   if (i < n_pad) out[i] = i < n ? in[i] : 0ull;
 }
 
+// flat candidate j -> its query (one wave per query writes its slice of the map)
+__global__ void __launch_bounds__(kWave) k_cmap(DevWork w) {
+  const uint32_t q = blockIdx.x;
+  const uint32_t n = w.q_cand[q];
+  const unsigned long long base = w.c_off[q];
+  for (uint32_t i = lane_id(); i < n; i += kWave) w.c_q[base + i] = q;
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_dp — the float edit distance (src/edit_distance.cc:5-77), flattened over every (query,
 // candidate) pair of the sub-batch: one candidate per lane whatever its query, so a query with
@@ -859,13 +868,7 @@ __global__ void __launch_bounds__(kWave) k_dp(DevIndex ix, DevBatch b, DevWork w
   const bool use_idf = prm.idf_penalty != 0.f;
   for (unsigned long long j = (unsigned long long)blockIdx.x * kWave + lane; j < total;
        j += (unsigned long long)gridDim.x * kWave) {
-    // query of flat candidate j: last q with c_off[q] <= j
-    uint32_t a = 0, bnd = b.nq;
-    while (bnd - a > 1) {
-      const uint32_t mid = (a + bnd) >> 1;
-      if (w.c_off[mid] <= j) a = mid; else bnd = mid;
-    }
-    const uint32_t q = a;
+    const uint32_t q = w.c_q[j];
     Cand* cd = w.seg + w.q_seg[q] + (j - w.c_off[q]);
     const uint32_t sid = cd->sid;
     const uint32_t o0 = b.q_off[b.q_begin + q];
@@ -921,8 +924,10 @@ __device__ __forceinline__ float edit_distance_reg(const uint32_t* __restrict__ 
 #pragma unroll
   for (int j = 1; j <= P; j++) row[j] = row[j - 1] + ins_dw;
   float M = 0.f, final_v = 0.f;
+  uint32_t wd_next = n1 ? sent[0] : 0u;
   for (uint32_t i = 1; i <= n1; i++) {
-    const uint32_t wd = sent[i - 1];
+    const uint32_t wd = wd_next;
+    wd_next = i < n1 ? sent[i] : 0u;  // next row's token is in flight while this row is computed
     float diag = row[0];
     float left = diag + del_dw;
     row[0] = left;
@@ -952,15 +957,10 @@ __global__ void __launch_bounds__(kWave) k_dp_reg(DevIndex ix, DevBatch b, DevWo
   const unsigned long long total = w.c_off[b.nq];
   for (unsigned long long j = (unsigned long long)blockIdx.x * kWave + lane; j < total;
        j += (unsigned long long)gridDim.x * kWave) {
-    uint32_t a = 0, bnd = b.nq;
-    while (bnd - a > 1) {
-      const uint32_t mid = (a + bnd) >> 1;
-      if (w.c_off[mid] <= j) a = mid; else bnd = mid;
-    }
-    const uint32_t q = a;
+    const uint32_t q = w.c_q[j];
     const uint32_t o0 = b.q_off[b.q_begin + q];
     const uint32_t p = b.q_off[b.q_begin + q + 1] - o0;
-    if (p > (uint32_t)P || (P == 64 && p <= 32)) continue;  // other lengths: k_dp_reg<32>, k_dp<false>
+    if (p > (uint32_t)P) continue;  // longer patterns: k_dp<false>
     Cand* cd = w.seg + w.q_seg[q] + (j - w.c_off[q]);
     const uint32_t sid = cd->sid;
     const uint32_t* pat = b.q_tok + o0;
