@@ -86,7 +86,7 @@ DeviceIndex::DeviceIndex() : impl_(new Impl) {}
 
 static void free_ws(DeviceIndex::Impl& m) {
   hipFree(m.w.q_m); hipFree(m.w.t_q); hipFree(m.w.t_lo); hipFree(m.w.t_cnt); hipFree(m.w.q_hits);
-  hipFree(m.w.q_seg); hipFree(m.w.q_kept); hipFree(m.w.q_cand); hipFree(m.w.q_acc); hipFree(m.w.q_pb); hipFree(m.w.c_in); hipFree(m.w.c_off); hipFree(m.w.t_idf); hipFree(m.w.c_q); hipFree(m.big_list); m.big_list = nullptr;
+  hipFree(m.w.q_seg); hipFree(m.w.q_kept); hipFree(m.w.q_cand); hipFree(m.w.q_acc); hipFree(m.w.q_pb); hipFree(m.w.c_in); hipFree(m.w.c_off); hipFree(m.w.t_idf); hipFree(m.w.c_qi); hipFree(m.big_list); m.big_list = nullptr;
   hipFree(m.w.seg); hipFree(m.w.heap); hipFree(m.w.counters);
   hipFree(m.sc.keys); hipFree(m.sc.vals); hipFree(m.sc.f0); hipFree(m.sc.f1);
   hipFree(m.tile_sums); hipFree(m.grand_total); hipFree(m.w.q_cap);
@@ -173,10 +173,10 @@ static void ensure_ws(DeviceIndex::Impl& m, uint64_t nq, uint64_t nt, uint64_t s
     m.w.q_cand = dev_alloc<uint32_t>(cq);
     m.w.q_acc = dev_alloc<uint32_t>(cq);
     m.w.q_pb = dev_alloc<uint32_t>(cq);
-    m.w.c_in = dev_alloc<unsigned long long>(cq + 1);
-    m.w.c_off = dev_alloc<unsigned long long>(cq + 1);
+    m.w.c_in = dev_alloc<unsigned long long>(3 * (cq + 1));
+    m.w.c_off = dev_alloc<unsigned long long>(3 * (cq + 1));
     m.w.t_idf = dev_alloc<float>(ct);
-    m.w.c_q = dev_alloc<uint32_t>(cs);
+    m.w.c_qi = dev_alloc<unsigned long long>(cs);
     m.big_list = dev_alloc<uint32_t>(cq);
     m.w.seg = dev_alloc<Cand>(cs);
     m.w.heap = dev_alloc<float>(cs + cq + 1);
@@ -264,14 +264,17 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm_in, const D
       }
       tick(); tick();
       {
-        // flat candidate list: c_off = exclusive scan of q_cand
+        // dense per-class candidate lists: three exclusive scans of the per-query candidate counts
         const uint32_t n = b.nq + 1;
         const uint32_t tiles = (n + kScanTile - 1) / kScanTile;
-        hipLaunchKernelGGL(k_widen, dim3((n + 255) / 256), dim3(256), 0, stream, (const uint32_t*)w.q_cand, w.c_in, b.nq, n);
-        hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(kScanThreads), 0, stream, w.c_in, w.c_off, m.tile_sums, n);
-        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanThreads), 0, stream, m.tile_sums, tiles, m.grand_total);
-        hipLaunchKernelGGL(k_scan_add, dim3(tiles), dim3(kScanThreads), 0, stream, w.c_off, m.tile_sums, n);
-        hipLaunchKernelGGL(k_cmap, dim3(b.nq), dim3(kWave), 0, stream, w);
+        hipLaunchKernelGGL(k_classify, dim3((n + 255) / 256), dim3(256), 0, stream, b, w, full ? 1 : 0);
+        for (int c = 0; c < 3; c++) {
+          hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(kScanThreads), 0, stream, w.c_in + (size_t)c * n,
+                             w.c_off + (size_t)c * n, m.tile_sums, n);
+          hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanThreads), 0, stream, m.tile_sums, tiles, m.grand_total);
+          hipLaunchKernelGGL(k_scan_add, dim3(tiles), dim3(kScanThreads), 0, stream, w.c_off + (size_t)c * n, m.tile_sums, n);
+        }
+        hipLaunchKernelGGL(k_cmap, dim3(b.nq), dim3(kWave), 0, stream, b, w, full ? 1 : 0);
       }
       tick(); tick();
       {
@@ -281,13 +284,14 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm_in, const D
         const unsigned grid = 256 * 16;  // grid-stride over the flat candidate list
         if (full) {
           HIP_TRY(hipFuncSetAttribute((const void*)k_dp<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-          hipLaunchKernelGGL(k_dp<true>, dim3(grid), dim3(kWave), lds, stream, m.d, b, w, prm, 0u);
+          hipLaunchKernelGGL(k_dp<true>, dim3(grid), dim3(kWave), lds, stream, m.d, b, w, prm);
         } else {
-          // patterns up to 32 tokens: row and pattern in registers; longer ones: rows in LDS
+          // by pattern length: row + pattern in 32 or 64 registers, longer ones with the row in LDS
           hipLaunchKernelGGL(k_dp_reg<32>, dim3(grid), dim3(kWave), 0, stream, m.d, b, w, prm);
-          if (p_max > 32) {
+          if (p_max > 32) hipLaunchKernelGGL(k_dp_reg<64>, dim3(grid), dim3(kWave), 0, stream, m.d, b, w, prm);
+          if (p_max > 64) {
             HIP_TRY(hipFuncSetAttribute((const void*)k_dp<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(k_dp<false>, dim3(grid), dim3(kWave), lds, stream, m.d, b, w, prm, 32u);
+            hipLaunchKernelGGL(k_dp<false>, dim3(grid), dim3(kWave), lds, stream, m.d, b, w, prm);
           }
         }
       }

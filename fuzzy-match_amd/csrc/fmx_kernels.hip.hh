@@ -58,9 +58,9 @@ struct DevWork {
   uint32_t* q_cand;     // nq
   uint32_t* q_acc;      // nq
   uint32_t* q_pb;       // nq   hits that reached the token-touching phase of k_expand (statistics)
-  unsigned long long* c_in;    // nq+1 q_cand widened (scan input)
-  unsigned long long* c_off;   // nq+1 exclusive scan of q_cand: flat candidate list
-  uint32_t* c_q;        // seg_cap  query of each flat candidate
+  unsigned long long* c_in;    // 3 x (nq+1) candidates per query, one array per length class (scan input)
+  unsigned long long* c_off;   // 3 x (nq+1) exclusive scans: dense per-class candidate lists
+  unsigned long long* c_qi;    // seg_cap  (query << 32 | candidate index), dense per length class
   float*    t_idf;      // nt   idf_penalty per pattern position (src/fuzzy_match.cc:372-390)
   Cand*     seg;        // capacity seg_cap
   float*    heap;       // capacity seg_cap + nq (lowest_costs spill)
@@ -831,18 +831,44 @@ __global__ void __launch_bounds__(kBigThreads) k_cand_big(DevWork w, unsigned lo
   }
 }
 
-// q_cand (u32) -> u64 for the scan that lays the candidates of all queries out as one flat list
-__global__ void k_widen(const uint32_t* in, unsigned long long* out, uint32_t n, uint32_t n_pad) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n_pad) out[i] = i < n ? in[i] : 0ull;
+// Candidates are laid out as three dense lists by pattern-length class so that every edit-distance kernel
+// runs with full waves: class 0 = up to 32 pattern tokens (row in 32 registers), 1 = up to 64, 2 = longer
+// or any query that needs the FULL cost model (rows in LDS).  k_classify feeds three scans; k_cmap then
+// writes (query, candidate index) pairs, class 0 first, class 1 after it, class 2 last.
+__device__ __forceinline__ uint32_t dp_class(uint32_t p, int full) { return full ? 2u : (p <= 32 ? 0u : (p <= 64 ? 1u : 2u)); }
+
+__global__ void k_classify(DevBatch b, DevWork w, int full) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q > b.nq) return;
+  unsigned long long v[3] = {0, 0, 0};
+  if (q < b.nq) {
+    const uint32_t p = b.q_off[b.q_begin + q + 1] - b.q_off[b.q_begin + q];
+    v[dp_class(p, full)] = w.q_cand[q];
+  }
+  const size_t stride = (size_t)b.nq + 1;
+  w.c_in[q] = v[0]; w.c_in[stride + q] = v[1]; w.c_in[2 * stride + q] = v[2];
 }
 
-// flat candidate j -> its query (one wave per query writes its slice of the map)
-__global__ void __launch_bounds__(kWave) k_cmap(DevWork w) {
+__global__ void __launch_bounds__(kWave) k_cmap(DevBatch b, DevWork w, int full) {
   const uint32_t q = blockIdx.x;
   const uint32_t n = w.q_cand[q];
-  const unsigned long long base = w.c_off[q];
-  for (uint32_t i = lane_id(); i < n; i += kWave) w.c_q[base + i] = q;
+  if (n == 0) return;
+  const size_t stride = (size_t)b.nq + 1;
+  const uint32_t p = b.q_off[b.q_begin + q + 1] - b.q_off[b.q_begin + q];
+  const uint32_t cls = dp_class(p, full);
+  unsigned long long base = w.c_off[cls * stride + q];
+  if (cls >= 1) base += w.c_off[b.nq];
+  if (cls >= 2) base += w.c_off[stride + b.nq];
+  for (uint32_t i = lane_id(); i < n; i += kWave) w.c_qi[base + i] = ((unsigned long long)q << 32) | i;
+}
+
+// [begin, end) of a class in the dense candidate list
+__device__ __forceinline__ void dp_class_range(const DevBatch& b, const DevWork& w, uint32_t cls, unsigned long long& lo,
+                                               unsigned long long& hi) {
+  const size_t stride = (size_t)b.nq + 1;
+  const unsigned long long t0 = w.c_off[b.nq], t1 = w.c_off[stride + b.nq], t2 = w.c_off[2 * stride + b.nq];
+  lo = cls == 0 ? 0ull : (cls == 1 ? t0 : t0 + t1);
+  hi = lo + (cls == 0 ? t0 : (cls == 1 ? t1 : t2));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -860,20 +886,21 @@ struct LdsRow {
 };
 
 template <bool FULL>
-__global__ void __launch_bounds__(kWave) k_dp(DevIndex ix, DevBatch b, DevWork w, Params prm, uint32_t skip_up_to) {
+__global__ void __launch_bounds__(kWave) k_dp(DevIndex ix, DevBatch b, DevWork w, Params prm) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* s_rows = (float*)smem;
   const uint32_t lane = lane_id();
-  const unsigned long long total = w.c_off[b.nq];
+  unsigned long long j_lo, j_hi;
+  dp_class_range(b, w, 2, j_lo, j_hi);
   const bool use_idf = prm.idf_penalty != 0.f;
-  for (unsigned long long j = (unsigned long long)blockIdx.x * kWave + lane; j < total;
+  for (unsigned long long j = j_lo + (unsigned long long)blockIdx.x * kWave + lane; j < j_hi;
        j += (unsigned long long)gridDim.x * kWave) {
-    const uint32_t q = w.c_q[j];
-    Cand* cd = w.seg + w.q_seg[q] + (j - w.c_off[q]);
+    const unsigned long long qi = w.c_qi[j];
+    const uint32_t q = (uint32_t)(qi >> 32);
+    Cand* cd = w.seg + w.q_seg[q] + (uint32_t)qi;
     const uint32_t sid = cd->sid;
     const uint32_t o0 = b.q_off[b.q_begin + q];
     const uint32_t p = b.q_off[b.q_begin + q + 1] - o0;
-    if (p <= skip_up_to) continue;  // done by k_dp_reg
     const uint32_t* pat = b.q_tok + o0;
     const uint32_t sp = ix.sent_pos[sid];
     const uint32_t slen = ix.tok[sp];
@@ -936,9 +963,10 @@ __device__ __forceinline__ float edit_distance_reg(const uint32_t* __restrict__ 
     for (int j = 1; j <= P; j++) {
       const float up = row[j];
       const float diff = (wd != pt[j - 1]) ? rep_dw : 0.f;
-      const float d = fmin2(fmin2(up + del_dw, left + ins_dw), diag + diff);
+      // v_min_f32: same value as std::min for the finite, non-negative costs of this path
+      const float d = __builtin_fminf(__builtin_fminf(up + del_dw, left + ins_dw), diag + diff);
       row[j] = d;
-      const float mn2 = fmin2(mn, d);
+      const float mn2 = __builtin_fminf(mn, d);
       mn = (uint32_t)j <= n2 ? mn2 : mn;
       final_v = (uint32_t)j == n2 ? d : final_v;
       diag = up;
@@ -954,14 +982,15 @@ __device__ __forceinline__ float edit_distance_reg(const uint32_t* __restrict__ 
 template <int P>
 __global__ void __launch_bounds__(kWave) k_dp_reg(DevIndex ix, DevBatch b, DevWork w, Params prm) {
   const uint32_t lane = lane_id();
-  const unsigned long long total = w.c_off[b.nq];
-  for (unsigned long long j = (unsigned long long)blockIdx.x * kWave + lane; j < total;
+  unsigned long long j_lo, j_hi;
+  dp_class_range(b, w, P == 32 ? 0u : 1u, j_lo, j_hi);
+  for (unsigned long long j = j_lo + (unsigned long long)blockIdx.x * kWave + lane; j < j_hi;
        j += (unsigned long long)gridDim.x * kWave) {
-    const uint32_t q = w.c_q[j];
+    const unsigned long long qi = w.c_qi[j];
+    const uint32_t q = (uint32_t)(qi >> 32);
     const uint32_t o0 = b.q_off[b.q_begin + q];
     const uint32_t p = b.q_off[b.q_begin + q + 1] - o0;
-    if (p > (uint32_t)P) continue;  // longer patterns: k_dp<false>
-    Cand* cd = w.seg + w.q_seg[q] + (j - w.c_off[q]);
+    Cand* cd = w.seg + w.q_seg[q] + (uint32_t)qi;
     const uint32_t sid = cd->sid;
     const uint32_t* pat = b.q_tok + o0;
     const uint32_t sp = ix.sent_pos[sid];
