@@ -155,7 +155,7 @@ def main():
         nv = min(args.verify, nq)
         if nv:
             oo, oc, ctr = o.match_batch(oprm, q_off[:nv + 1], q_tok[:int(q_off[nv])], cap,
-                                        nthreads=os.cpu_count() or 1, want_counters=True)
+                                        nthreads=oracle_lib.effective_cpus(), want_counters=True)
             go = d_out[:nv].cpu().numpy().view(oracle_lib.MATCH_DTYPE).reshape(nv, cap)
             gc = d_cnt[:nv].cpu().numpy().astype(np.uint32)
             bad = sum(1 for q in range(nv) if oc[q] != gc[q] or oo[q, :oc[q]].tobytes() != go[q, :gc[q]].tobytes())
@@ -172,7 +172,7 @@ def main():
                             "kernel_ms_per_step": round(probe_ms, 4), "launches_per_step": launches_per_step,
                             "stage_ms_per_step": {k: round(v, 4) for k, v in per_stage.items()}}
         if not args.no_cpu_baseline and world == 1:
-            cores = os.cpu_count() or 1
+            cores = oracle_lib.effective_cpus()  # cgroup CPU quota, not the 256 hardware threads of the host
             ns = min(nq, max(2000, 64 * cores))
             t1 = time.perf_counter()
             o.match_batch(oprm, q_off[:ns + 1], q_tok[:int(q_off[ns])], cap, nthreads=cores)
@@ -183,7 +183,8 @@ def main():
             dt = time.perf_counter() - t1
             cpu_baseline = {"value": round(ns2 / dt, 1), "unit": "patterns/s", "cores": cores, "kind": "port",
                             "sample": f"first {ns2} queries of the same {args.config} workload, oracle/fm_oracle.c "
-                                      f"fmo_match_batch with {cores} threads, {dt:.1f}s"}
+                                      f"fmo_match_batch with {cores} threads (= usable CPUs: min(affinity, cgroup cpu.max) of "
+                                      f"{os.cpu_count()} hardware threads), {dt:.1f}s"}
         o.close()
 
     if rank == 0:

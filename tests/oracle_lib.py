@@ -45,6 +45,24 @@ class Counters(C.Structure):
 _lib = None
 
 
+def effective_cpus():
+    """Hardware threads this process may really use: min(affinity, cgroup CPU quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return n
+
+
 def build(force=False):
     if force or not os.path.exists(LIB_PATH):
         subprocess.check_call(["make", "-C", ORACLE_DIR])
@@ -167,7 +185,7 @@ class OracleIndex:
         else:
             sf = np.asarray(self.vocab.sfreq, dtype=np.uint32)
             self.L.fmo_index_set_vocab(self.h, len(sf), _ptr(sf))
-        self.L.fmo_index_sort(self.h, nthreads or os.cpu_count() or 1)
+        self.L.fmo_index_sort(self.h, nthreads or effective_cpus())
 
     def set_arrays(self, suf_sid, suf_pos, buffer, sent_pos, qva, sfreq):
         a = [np.ascontiguousarray(suf_sid, np.uint32), np.ascontiguousarray(suf_pos, np.uint16),

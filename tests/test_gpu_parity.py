@@ -38,7 +38,7 @@ def test_c1_param_sets(fmx, c1, name):
     ix, o, q_off, q_tok = c1
     kw = workloads.PARAM_SETS[name]
     cap = kw.get("nmatch", 5) or 64
-    oo, oc = o.match_batch(oracle_lib.Params(**kw), q_off, q_tok, cap, nthreads=os.cpu_count() or 1)
+    oo, oc = o.match_batch(oracle_lib.Params(**kw), q_off, q_tok, cap, nthreads=oracle_lib.effective_cpus())
     go, gc, gt = ix.match_batch(fmx.Params(**kw), q_off, q_tok, cap=cap)
     workloads.compare(oo, oc, go, gc, name)
 
@@ -70,7 +70,7 @@ def test_sub_batching_and_workspace_growth(fmx, c1):
     """Tiny sub-batches and a deliberately undersized hit workspace must not change results."""
     ix, o, q_off, q_tok = c1
     kw = workloads.PARAM_SETS["wide_all"]
-    oo, oc = o.match_batch(oracle_lib.Params(**kw), q_off, q_tok, 64, nthreads=os.cpu_count() or 1)
+    oo, oc = o.match_batch(oracle_lib.Params(**kw), q_off, q_tok, 64, nthreads=oracle_lib.effective_cpus())
     ix.set_option("sub_queries", 37)
     try:
         go, gc, gt, st = ix.match_batch(fmx.Params(**kw), q_off, q_tok, cap=64, want_stats=True)
@@ -149,13 +149,13 @@ def test_big_candidate_sets(fmx, gpu_device):
     ix.to_device(gpu_device)
     o = oracle_lib.OracleIndex(max_tokens=40)
     o.add_ids_bulk(c_off, c_tok, vocab + 2, sfreq=ix.array("sfreq"))
-    o.sort(os.cpu_count() or 1)
+    o.sort(oracle_lib.effective_cpus())
     for name, kw in [("all", dict(fuzzy=0.2, nmatch=0, min_subseq_length=2, min_subseq_ratio=0)),
                      ("top10_idf", dict(fuzzy=0.0, nmatch=10, min_subseq_length=2, min_subseq_ratio=0, idf_penalty=0.7)),
                      ("contrast", dict(fuzzy=0.3, nmatch=6, min_subseq_length=2, min_subseq_ratio=0, contrast=0.4,
                                        contrast_buffer=0))]:
         cap = 128
-        oo, oc = o.match_batch(oracle_lib.Params(**kw), q_off, q_tok, cap, nthreads=os.cpu_count() or 1)
+        oo, oc = o.match_batch(oracle_lib.Params(**kw), q_off, q_tok, cap, nthreads=oracle_lib.effective_cpus())
         go, gc, gt, st = ix.match_batch(fmx.Params(**kw), q_off, q_tok, cap=cap, want_stats=True)
         workloads.compare(oo, oc, go, gc, name)
         assert st.n_big > 0 and st.max_kept > 1024, (name, st.n_big, st.max_kept)

@@ -86,7 +86,7 @@ def edge_queries(rng, c_off, c_tok, vocab, n):
 def build_oracle(c_off, c_tok, vocab_size, sfreq=None, nthreads=None):
     o = oracle_lib.OracleIndex()
     o.add_ids_bulk(c_off, c_tok, vocab_size, sfreq=sfreq)
-    o.sort(nthreads or os.cpu_count() or 1)
+    o.sort(nthreads or oracle_lib.effective_cpus())
     return o
 
 
