@@ -207,8 +207,11 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm_in, const D
   upload_itok_table(m, h);
   Params prm = prm_in;
   if (cap == 0) throw GpuError("cap must be > 0");
-  const bool full = (m.d.real && bv.q_real) || (bv.q_itok != nullptr) || (m.d.itok != nullptr) ||
-                    prm.idf_penalty != 0.f;
+  // cost model: real-token / penalty-token terms need the general kernel (rows in LDS); idf alone has a
+  // register kernel
+  const bool side_terms = (m.d.real && bv.q_real) || (bv.q_itok != nullptr) || (m.d.itok != nullptr);
+  const bool use_idf = prm.idf_penalty != 0.f;
+  const bool full = side_terms;
   const uint32_t n_sub = (uint32_t)sub_tok_bounds.size() - 1;
   for (uint32_t sb = 0; sb < n_sub; sb++) {
     DevBatch b;
@@ -287,24 +290,42 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm_in, const D
           hipLaunchKernelGGL(k_dp<true>, dim3(grid), dim3(kWave), lds, stream, m.d, b, w, prm);
         } else {
           // by pattern length: row + pattern in 32 or 64 registers, longer ones with the row in LDS
-          hipLaunchKernelGGL(k_dp_reg<32>, dim3(grid), dim3(kWave), 0, stream, m.d, b, w, prm);
-          if (p_max > 32) hipLaunchKernelGGL(k_dp_reg<64>, dim3(grid), dim3(kWave), 0, stream, m.d, b, w, prm);
+          if (use_idf) {
+            hipLaunchKernelGGL((k_dp_reg<32, true>), dim3(grid), dim3(kWave), 0, stream, m.d, b, w, prm);
+            if (p_max > 32) hipLaunchKernelGGL((k_dp_reg<64, true>), dim3(grid), dim3(kWave), 0, stream, m.d, b, w, prm);
+          } else {
+            hipLaunchKernelGGL((k_dp_reg<32, false>), dim3(grid), dim3(kWave), 0, stream, m.d, b, w, prm);
+            if (p_max > 32) hipLaunchKernelGGL((k_dp_reg<64, false>), dim3(grid), dim3(kWave), 0, stream, m.d, b, w, prm);
+          }
           if (p_max > 64) {
-            HIP_TRY(hipFuncSetAttribute((const void*)k_dp<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(k_dp<false>, dim3(grid), dim3(kWave), lds, stream, m.d, b, w, prm);
+            if (use_idf) {
+              HIP_TRY(hipFuncSetAttribute((const void*)k_dp<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+              hipLaunchKernelGGL(k_dp<true>, dim3(grid), dim3(kWave), lds, stream, m.d, b, w, prm);
+            } else {
+              HIP_TRY(hipFuncSetAttribute((const void*)k_dp<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+              hipLaunchKernelGGL(k_dp<false>, dim3(grid), dim3(kWave), lds, stream, m.d, b, w, prm);
+            }
           }
         }
       }
       tick(); tick();
       {
-        size_t lds = 0;
+        hipLaunchKernelGGL(k_finish, dim3(b.nq), dim3(kWave), 0, stream, m.d, b, w, prm, m.sc, cap, d_out, d_out_count,
+                           d_out_total);
         if (prm.contrast > 0.f) {
-          lds = ((size_t)m.d.max_slen + 1) * kWave * 4;
-          if (lds > 120 * 1024) throw GpuError("contrastive rerank: indexed sentences too long for the LDS DP rows");
-          HIP_TRY(hipFuncSetAttribute((const void*)k_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          hipLaunchKernelGGL(k_contrast<0>, dim3(b.nq), dim3(kWave), 0, stream, m.d, b, w, prm, m.sc, cap, d_out,
+                             d_out_count, d_out_total);
+          if (m.d.max_slen > 32)
+            hipLaunchKernelGGL(k_contrast<1>, dim3(b.nq), dim3(kWave), 0, stream, m.d, b, w, prm, m.sc, cap, d_out,
+                               d_out_count, d_out_total);
+          if (m.d.max_slen > 64) {
+            const size_t lds = ((size_t)m.d.max_slen + 1) * kWave * 4;
+            if (lds > 120 * 1024) throw GpuError("contrastive rerank: indexed sentences too long for the LDS DP rows");
+            HIP_TRY(hipFuncSetAttribute((const void*)k_contrast<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k_contrast<2>, dim3(b.nq), dim3(kWave), lds, stream, m.d, b, w, prm, m.sc, cap, d_out,
+                               d_out_count, d_out_total);
+          }
         }
-        hipLaunchKernelGGL(k_finish, dim3(b.nq), dim3(kWave), lds, stream, m.d, b, w, prm, m.sc, cap, d_out,
-                           d_out_count, d_out_total);
       }
       tick();
       hipLaunchKernelGGL(k_stats, dim3((b.nq + 1023) / 1024), dim3(1024), 0, stream, w, b.nq);

@@ -938,18 +938,27 @@ __global__ void __launch_bounds__(kWave) k_dp(DevIndex ix, DevBatch b, DevWork w
 // (dependencies only run left to right), and no LDS or memory access remains in the cell update.
 // Same operations in the same order as edit_distance<false>, so the results are bit-identical.
 // ---------------------------------------------------------------------------------------------
-template <int P>
+template <int P, bool IDF = false>
 __device__ __forceinline__ float edit_distance_reg(const uint32_t* __restrict__ sent, uint32_t n1,
                                                    const uint32_t* __restrict__ pat, uint32_t n2, float ins,
-                                                   float del, float rep, float dw, float& M_out) {
+                                                   float del, float rep, float dw, float& M_out,
+                                                   const float* __restrict__ p_idf = nullptr, float idf_weight = 0.f) {
   const float del_dw = del * dw, ins_dw = ins * dw, rep_dw = rep * dw;
   float    row[P + 1];
   uint32_t pt[P];
+  float    pen[IDF ? P : 1];
 #pragma unroll
-  for (int j = 0; j < P; j++) pt[j] = (uint32_t)j < n2 ? pat[j] : 0xffffffffu;
+  for (int j = 0; j < P; j++) {
+    pt[j] = (uint32_t)j < n2 ? pat[j] : 0xffffffffu;
+    if (IDF) pen[j] = (uint32_t)j < n2 ? p_idf[j] * idf_weight : 0.f;  // idf_penalty[j] * idf_weight, edit_distance.cc:36,49
+  }
   row[0] = 0.f;
 #pragma unroll
-  for (int j = 1; j <= P; j++) row[j] = row[j - 1] + ins_dw;
+  for (int j = 1; j <= P; j++) {
+    float v = row[j - 1] + ins_dw;
+    if (IDF) v = v + pen[j - 1];
+    row[j] = v;
+  }
   float M = 0.f, final_v = 0.f;
   uint32_t wd_next = n1 ? sent[0] : 0u;
   for (uint32_t i = 1; i <= n1; i++) {
@@ -962,9 +971,14 @@ __device__ __forceinline__ float edit_distance_reg(const uint32_t* __restrict__ 
 #pragma unroll
     for (int j = 1; j <= P; j++) {
       const float up = row[j];
-      const float diff = (wd != pt[j - 1]) ? rep_dw : 0.f;
+      float bb = left + ins_dw;
+      float diff = (wd != pt[j - 1]) ? rep_dw : 0.f;
+      if (IDF) {
+        bb = bb + pen[j - 1];
+        diff = (wd != pt[j - 1]) ? (rep_dw + pen[j - 1]) : 0.f;
+      }
       // v_min_f32: same value as std::min for the finite, non-negative costs of this path
-      const float d = __builtin_fminf(__builtin_fminf(up + del_dw, left + ins_dw), diag + diff);
+      const float d = __builtin_fminf(__builtin_fminf(up + del_dw, bb), diag + diff);
       row[j] = d;
       const float mn2 = __builtin_fminf(mn, d);
       mn = (uint32_t)j <= n2 ? mn2 : mn;
@@ -979,7 +993,7 @@ __device__ __forceinline__ float edit_distance_reg(const uint32_t* __restrict__ 
   return final_v;
 }
 
-template <int P>
+template <int P, bool IDF>
 __global__ void __launch_bounds__(kWave) k_dp_reg(DevIndex ix, DevBatch b, DevWork w, Params prm) {
   const uint32_t lane = lane_id();
   unsigned long long j_lo, j_hi;
@@ -998,7 +1012,9 @@ __global__ void __launch_bounds__(kWave) k_dp_reg(DevIndex ix, DevBatch b, DevWo
     const uint32_t* sent = ix.tok + sp + 1;
     const float dw = 100.f / normalizer(p, slen, prm.ins, prm.del, prm.rep);
     float M;
-    const float final_cost = edit_distance_reg<P>(sent, slen, pat, p, prm.ins, prm.del, prm.rep, dw, M);
+    const float final_cost = edit_distance_reg<P, IDF>(sent, slen, pat, p, prm.ins, prm.del, prm.rep, dw, M,
+                                                       w.t_idf + (o0 - b.t_begin),
+                                                       (dw * prm.idf_penalty) / prm.idf_max);  // src/fuzzy_match.cc:591
     cd->score = final_cost;
     cd->penalty = M;
     cd->longest = (cd->longest & 0xffffu) | (slen << 16);
@@ -1078,6 +1094,9 @@ __device__ __forceinline__ uint32_t replay_body(const Params& prm, uint32_t p, u
   return __shfl(acc, 0, 64);
 }
 
+// MODE: -1 plain top-N only; 0 / 1 contrastive rerank with the picked sentence in 32 / 64 registers;
+// 2 contrastive rerank with DP rows in LDS (sentences longer than 64 tokens)
+template <int MODE>
 __device__ __forceinline__ void select_body(const DevIndex& ix, const Params& prm, const Cand* seg, uint32_t n,
                                             uint32_t np2, unsigned long long* keys, uint32_t* vals, float* pen_sum,
                                             float* pen_cur, float* s_rows, uint32_t cap, Rec* out,
@@ -1092,7 +1111,7 @@ __device__ __forceinline__ void select_body(const DevIndex& ix, const Params& pr
   block_bitonic_sort_kv(keys, vals, np2);
   const uint32_t want = prm.nmatch == 0 ? n : (prm.nmatch < n ? prm.nmatch : n);
   const uint32_t emit = want < cap ? want : cap;
-  if (!(prm.contrast > 0.f)) {
+  if (MODE < 0 || !(prm.contrast > 0.f)) {
     for (uint32_t k = lane; k < emit; k += kWave) {
       const Cand c = seg[vals[k]];
       Rec r;
@@ -1125,9 +1144,11 @@ __device__ __forceinline__ void select_body(const DevIndex& ix, const Params& pr
         const uint32_t csp = ix.sent_pos[csid];
         const uint32_t n1 = ix.tok[csp];
         const float dw = 100.f / normalizer(n1, n2, 1.f, 1.f, 1.f);
-        float M;
-        const float ed = edit_distance<false>(ix.tok + csp + 1, n1, s2, n2, 1.f, 1.f, 1.f, dw, side, FLT_MAX,
-                                              LdsRow{s_rows + lane}, M);
+        float M, ed;
+        if (MODE == 0) ed = edit_distance_reg<32>(ix.tok + csp + 1, n1, s2, n2, 1.f, 1.f, 1.f, dw, M);
+        else if (MODE == 1) ed = edit_distance_reg<64>(ix.tok + csp + 1, n1, s2, n2, 1.f, 1.f, 1.f, dw, M);
+        else ed = edit_distance<false>(ix.tok + csp + 1, n1, s2, n2, 1.f, 1.f, 1.f, dw, side, FLT_MAX,
+                                       LdsRow{s_rows + lane}, M);
         const float pen = score_from_cost(ed);
         const float sum = pen_sum[k] + pen;
         pen_sum[k] = sum;
@@ -1172,11 +1193,8 @@ __device__ __forceinline__ void select_body(const DevIndex& ix, const Params& pr
 __global__ void __launch_bounds__(kWave) k_finish(DevIndex ix, DevBatch b, DevWork w, Params prm, DevScratch sc,
                                                   uint32_t cap, Rec* out_rec, uint32_t* out_count,
                                                   uint32_t* out_total) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* s_rows = (float*)smem;
   __shared__ unsigned long long s_keys[kLdsSortMax];
   __shared__ uint32_t s_vals[kLdsSortMax];
-  __shared__ float    s_f0[kLdsSortMax], s_f1[kLdsSortMax];
   __shared__ ReplayShared sh;
   __shared__ float s_heap[kHeapLdsMax + 2];
   const uint32_t q = blockIdx.x;
@@ -1185,6 +1203,7 @@ __global__ void __launch_bounds__(kWave) k_finish(DevIndex ix, DevBatch b, DevWo
   const uint32_t n_cand = w.q_cand[q];
   Rec* out = out_rec + (unsigned long long)gq * cap;
   uint32_t cnt = 0, tot = 0;
+  const bool contrast = prm.contrast > 0.f;
   if (n_cand != 0) {
     const unsigned long long seg0 = w.q_seg[q];
     Cand* seg = w.seg + seg0;
@@ -1193,14 +1212,54 @@ __global__ void __launch_bounds__(kWave) k_finish(DevIndex ix, DevBatch b, DevWo
     if (prm.cbuf > 0 && prm.cbuf <= (int)kHeapLdsMax) n = replay_body(prm, p, n_cand, seg, s_heap, sh);
     else n = replay_body(prm, p, n_cand, seg, w.heap + seg0 + q, sh);
     if (lane == 0) w.q_acc[q] = n;
-    if (n != 0) {
+    if (n != 0 && !contrast) {
       const uint32_t np2 = next_pow2(n);
-      if (np2 <= kLdsSortMax) select_body(ix, prm, seg, n, np2, s_keys, s_vals, s_f0, s_f1, s_rows, cap, out, cnt, tot);
-      else select_body(ix, prm, seg, n, np2, sc.keys + 2ull * seg0, sc.vals + 2ull * seg0, sc.f0 + seg0, sc.f1 + seg0,
-                       s_rows, cap, out, cnt, tot);
+      if (np2 <= kLdsSortMax) select_body<-1>(ix, prm, seg, n, np2, s_keys, s_vals, nullptr, nullptr, nullptr, cap, out, cnt, tot);
+      else select_body<-1>(ix, prm, seg, n, np2, sc.keys + 2ull * seg0, sc.vals + 2ull * seg0, nullptr, nullptr, nullptr,
+                           cap, out, cnt, tot);
     }
   } else if (lane == 0)
     w.q_acc[q] = 0;
+  // with a contrastive factor the accepted list is handed to k_contrast, which writes the output
+  if (lane == 0 && !(contrast && n_cand != 0)) { out_count[gq] = cnt; if (out_total) out_total[gq] = tot; }
+}
+
+// k_contrast<MODE> — contrastive rerank (src/fuzzy_match.cc:614-669) of the accepted matches k_finish left in
+// the query's segment.  Three launches partition the queries by their longest accepted sentence (MODE 0:
+// <= 32 tokens, 1: <= 64, 2: longer), so the common case keeps the picked sentence and the DP row in registers.
+template <int MODE>
+__global__ void __launch_bounds__(kWave) k_contrast(DevIndex ix, DevBatch b, DevWork w, Params prm, DevScratch sc,
+                                                    uint32_t cap, Rec* out_rec, uint32_t* out_count,
+                                                    uint32_t* out_total) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* s_rows = (float*)smem;
+  __shared__ unsigned long long s_keys[kLdsSortMax];
+  __shared__ uint32_t s_vals[kLdsSortMax];
+  __shared__ float    s_f0[kLdsSortMax], s_f1[kLdsSortMax];
+  const uint32_t q = blockIdx.x;
+  const uint32_t lane = lane_id();
+  const uint32_t gq = b.q_begin + q;
+  if (w.q_cand[q] == 0) return;  // k_finish already wrote an empty result
+  const uint32_t n = w.q_acc[q];
+  const unsigned long long seg0 = w.q_seg[q];
+  const Cand* seg = w.seg + seg0;
+  uint32_t mx = 0;
+  for (uint32_t k = lane; k < n; k += kWave) {
+    const uint32_t len = ix.tok[ix.sent_pos[seg[k].sid]];
+    mx = len > mx ? len : mx;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(mx, d, 64); mx = o > mx ? o : mx; }
+  const int cls = mx <= 32 ? 0 : (mx <= 64 ? 1 : 2);
+  if (cls != MODE) return;
+  Rec* out = out_rec + (unsigned long long)gq * cap;
+  uint32_t cnt = 0, tot = 0;
+  if (n != 0) {
+    const uint32_t np2 = next_pow2(n);
+    if (np2 <= kLdsSortMax) select_body<MODE>(ix, prm, seg, n, np2, s_keys, s_vals, s_f0, s_f1, s_rows, cap, out, cnt, tot);
+    else select_body<MODE>(ix, prm, seg, n, np2, sc.keys + 2ull * seg0, sc.vals + 2ull * seg0, sc.f0 + seg0, sc.f1 + seg0,
+                           s_rows, cap, out, cnt, tot);
+  }
   if (lane == 0) { out_count[gq] = cnt; if (out_total) out_total[gq] = tot; }
 }
 
