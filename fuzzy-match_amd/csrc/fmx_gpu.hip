@@ -67,6 +67,7 @@ struct DeviceIndex::Impl {
   unsigned long long* tile_sums = nullptr;
   unsigned long long* grand_total = nullptr;
   uint32_t* big_list = nullptr;
+  uint32_t* contrast_list = nullptr;  // 2 x cap_q
   WorkItem* items = nullptr;
   uint32_t  item_cap = 0;
   uint32_t  s_max = 4096;   // survivors kept per query before a retry with a larger segment
@@ -86,7 +87,7 @@ DeviceIndex::DeviceIndex() : impl_(new Impl) {}
 
 static void free_ws(DeviceIndex::Impl& m) {
   hipFree(m.w.q_m); hipFree(m.w.t_q); hipFree(m.w.t_lo); hipFree(m.w.t_cnt); hipFree(m.w.q_hits);
-  hipFree(m.w.q_seg); hipFree(m.w.q_kept); hipFree(m.w.q_cand); hipFree(m.w.q_acc); hipFree(m.w.q_pb); hipFree(m.w.c_in); hipFree(m.w.c_off); hipFree(m.w.t_idf); hipFree(m.w.c_qi); hipFree(m.big_list); m.big_list = nullptr;
+  hipFree(m.w.q_seg); hipFree(m.w.q_kept); hipFree(m.w.q_cand); hipFree(m.w.q_acc); hipFree(m.w.q_pb); hipFree(m.w.c_in); hipFree(m.w.c_off); hipFree(m.w.t_idf); hipFree(m.w.c_qi); hipFree(m.big_list); m.big_list = nullptr; hipFree(m.contrast_list); m.contrast_list = nullptr;
   hipFree(m.w.seg); hipFree(m.w.heap); hipFree(m.w.counters);
   hipFree(m.sc.keys); hipFree(m.sc.vals); hipFree(m.sc.f0); hipFree(m.sc.f1);
   hipFree(m.tile_sums); hipFree(m.grand_total); hipFree(m.w.q_cap);
@@ -178,6 +179,7 @@ static void ensure_ws(DeviceIndex::Impl& m, uint64_t nq, uint64_t nt, uint64_t s
     m.w.t_idf = dev_alloc<float>(ct);
     m.w.c_qi = dev_alloc<unsigned long long>(cs);
     m.big_list = dev_alloc<uint32_t>(cq);
+    m.contrast_list = dev_alloc<uint32_t>(2 * cq);
     m.w.seg = dev_alloc<Cand>(cs);
     m.w.heap = dev_alloc<float>(cs + cq + 1);
     m.w.counters = dev_alloc<unsigned long long>(16);
@@ -311,19 +313,20 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm_in, const D
       tick(); tick();
       {
         hipLaunchKernelGGL(k_finish, dim3(b.nq), dim3(kWave), 0, stream, m.d, b, w, prm, m.sc, cap, d_out, d_out_count,
-                           d_out_total);
+                           d_out_total, m.contrast_list);
         if (prm.contrast > 0.f) {
+          const uint32_t* cl = m.contrast_list;
           hipLaunchKernelGGL(k_contrast<0>, dim3(b.nq), dim3(kWave), 0, stream, m.d, b, w, prm, m.sc, cap, d_out,
-                             d_out_count, d_out_total);
+                             d_out_count, d_out_total, cl);
           if (m.d.max_slen > 32)
-            hipLaunchKernelGGL(k_contrast<1>, dim3(b.nq), dim3(kWave), 0, stream, m.d, b, w, prm, m.sc, cap, d_out,
-                               d_out_count, d_out_total);
+            hipLaunchKernelGGL(k_contrast<1>, dim3(2048), dim3(kWave), 0, stream, m.d, b, w, prm, m.sc, cap, d_out,
+                               d_out_count, d_out_total, cl);
           if (m.d.max_slen > 64) {
             const size_t lds = ((size_t)m.d.max_slen + 1) * kWave * 4;
             if (lds > 120 * 1024) throw GpuError("contrastive rerank: indexed sentences too long for the LDS DP rows");
             HIP_TRY(hipFuncSetAttribute((const void*)k_contrast<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(k_contrast<2>, dim3(b.nq), dim3(kWave), lds, stream, m.d, b, w, prm, m.sc, cap, d_out,
-                               d_out_count, d_out_total);
+            hipLaunchKernelGGL(k_contrast<2>, dim3(512), dim3(kWave), lds, stream, m.d, b, w, prm, m.sc, cap, d_out,
+                               d_out_count, d_out_total, cl);
           }
         }
       }

@@ -67,7 +67,8 @@ struct DevWork {
   unsigned long long  seg_cap;
   unsigned long long* counters;  // [0]=hits [1]=kept [2]=cands [3]=dp [4]=max survivors of a query whose
                                  // segment overflowed [5]=extra work items [6]=segment space needed
-                                 // [7]=queries queued for k_cand_big
+                                 // [7]=queries queued for k_cand_big [8]=phase-B hits [9]=max kept
+                                 // [10],[11]=queries queued for k_contrast<1>, <2>
 };
 
 constexpr int kWave = 64;
@@ -1052,7 +1053,8 @@ struct ReplayShared {
 };
 
 __device__ __forceinline__ uint32_t replay_body(const Params& prm, uint32_t p, uint32_t n_cand, Cand* seg,
-                                                float* heap_store, ReplayShared& sh) {
+                                                float* heap_store, ReplayShared& sh, uint32_t& max_slen_out) {
+  uint32_t max_slen = 0;
   const uint32_t lane = lane_id();
   CostHeap heap;
   heap.v = heap_store;
@@ -1085,12 +1087,14 @@ __device__ __forceinline__ uint32_t replay_body(const Params& prm, uint32_t p, u
           Cand a;
           a.sid = sh.sid[k]; a.longest = sh.L[k]; a.score = score; a.penalty = 0.f;
           seg[acc++] = a;
+          max_slen = sh.slen[k] > max_slen ? sh.slen[k] : max_slen;
         }
       }
       sh.ub = heap.top();
     }
   }
   __syncthreads();
+  max_slen_out = __shfl(max_slen, 0, 64);
   return __shfl(acc, 0, 64);
 }
 
@@ -1192,7 +1196,7 @@ __device__ __forceinline__ void select_body(const DevIndex& ix, const Params& pr
 
 __global__ void __launch_bounds__(kWave) k_finish(DevIndex ix, DevBatch b, DevWork w, Params prm, DevScratch sc,
                                                   uint32_t cap, Rec* out_rec, uint32_t* out_count,
-                                                  uint32_t* out_total) {
+                                                  uint32_t* out_total, uint32_t* contrast_list) {
   __shared__ unsigned long long s_keys[kLdsSortMax];
   __shared__ uint32_t s_vals[kLdsSortMax];
   __shared__ ReplayShared sh;
@@ -1208,10 +1212,19 @@ __global__ void __launch_bounds__(kWave) k_finish(DevIndex ix, DevBatch b, DevWo
     const unsigned long long seg0 = w.q_seg[q];
     Cand* seg = w.seg + seg0;
     const uint32_t p = b.q_off[gq + 1] - b.q_off[gq];
-    uint32_t n;
-    if (prm.cbuf > 0 && prm.cbuf <= (int)kHeapLdsMax) n = replay_body(prm, p, n_cand, seg, s_heap, sh);
-    else n = replay_body(prm, p, n_cand, seg, w.heap + seg0 + q, sh);
-    if (lane == 0) w.q_acc[q] = n;
+    uint32_t n, mx;
+    if (prm.cbuf > 0 && prm.cbuf <= (int)kHeapLdsMax) n = replay_body(prm, p, n_cand, seg, s_heap, sh, mx);
+    else n = replay_body(prm, p, n_cand, seg, w.heap + seg0 + q, sh, mx);
+    if (lane == 0) {
+      w.q_acc[q] = n;
+      // contrastive rerank: queries whose accepted sentences are longer than 32 / 64 tokens are queued for the
+      // wider kernels; everything else is done by k_contrast<0> in place
+      if (contrast && n != 0 && mx > 32) {
+        const uint32_t cls = mx <= 64 ? 1u : 2u;
+        contrast_list[(size_t)(cls - 1) * b.nq + atomicAdd(&w.counters[9 + cls], 1ull)] = q;
+        w.q_acc[q] = n | 0x80000000u;  // not for k_contrast<0>
+      }
+    }
     if (n != 0 && !contrast) {
       const uint32_t np2 = next_pow2(n);
       if (np2 <= kLdsSortMax) select_body<-1>(ix, prm, seg, n, np2, s_keys, s_vals, nullptr, nullptr, nullptr, cap, out, cnt, tot);
@@ -1227,40 +1240,41 @@ __global__ void __launch_bounds__(kWave) k_finish(DevIndex ix, DevBatch b, DevWo
 // k_contrast<MODE> — contrastive rerank (src/fuzzy_match.cc:614-669) of the accepted matches k_finish left in
 // the query's segment.  Three launches partition the queries by their longest accepted sentence (MODE 0:
 // <= 32 tokens, 1: <= 64, 2: longer), so the common case keeps the picked sentence and the DP row in registers.
+constexpr uint32_t kContrastLds = 256;
+
 template <int MODE>
 __global__ void __launch_bounds__(kWave) k_contrast(DevIndex ix, DevBatch b, DevWork w, Params prm, DevScratch sc,
                                                     uint32_t cap, Rec* out_rec, uint32_t* out_count,
-                                                    uint32_t* out_total) {
+                                                    uint32_t* out_total, const uint32_t* contrast_list) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* s_rows = (float*)smem;
-  __shared__ unsigned long long s_keys[kLdsSortMax];
-  __shared__ uint32_t s_vals[kLdsSortMax];
-  __shared__ float    s_f0[kLdsSortMax], s_f1[kLdsSortMax];
-  const uint32_t q = blockIdx.x;
+  // small LDS footprint (the accepted list is rarely longer than the contrast buffer): more waves per CU
+  __shared__ unsigned long long s_keys[kContrastLds];
+  __shared__ uint32_t s_vals[kContrastLds];
+  __shared__ float    s_f0[kContrastLds], s_f1[kContrastLds];
   const uint32_t lane = lane_id();
-  const uint32_t gq = b.q_begin + q;
-  if (w.q_cand[q] == 0) return;  // k_finish already wrote an empty result
-  const uint32_t n = w.q_acc[q];
-  const unsigned long long seg0 = w.q_seg[q];
-  const Cand* seg = w.seg + seg0;
-  uint32_t mx = 0;
-  for (uint32_t k = lane; k < n; k += kWave) {
-    const uint32_t len = ix.tok[ix.sent_pos[seg[k].sid]];
-    mx = len > mx ? len : mx;
+  // MODE 0: one wave per query of the sub-batch; MODE 1 / 2: grid-stride over the queue k_finish filled
+  const unsigned long long n_items = MODE == 0 ? (unsigned long long)b.nq : w.counters[9 + MODE];
+  for (unsigned long long item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const uint32_t q = MODE == 0 ? (uint32_t)item : contrast_list[(size_t)(MODE - 1) * b.nq + item];
+    const uint32_t gq = b.q_begin + q;
+    if (w.q_cand[q] == 0) continue;  // k_finish already wrote an empty result
+    const uint32_t acc = w.q_acc[q];
+    if (MODE == 0 && (acc & 0x80000000u)) continue;  // queued for a wider kernel
+    const uint32_t n = acc & 0x7fffffffu;
+    const unsigned long long seg0 = w.q_seg[q];
+    const Cand* seg = w.seg + seg0;
+    Rec* out = out_rec + (unsigned long long)gq * cap;
+    uint32_t cnt = 0, tot = 0;
+    if (n != 0) {
+      const uint32_t np2 = next_pow2(n);
+      if (np2 <= kContrastLds) select_body<MODE>(ix, prm, seg, n, np2, s_keys, s_vals, s_f0, s_f1, s_rows, cap, out, cnt, tot);
+      else select_body<MODE>(ix, prm, seg, n, np2, sc.keys + 2ull * seg0, sc.vals + 2ull * seg0, sc.f0 + seg0, sc.f1 + seg0,
+                             s_rows, cap, out, cnt, tot);
+    }
+    if (lane == 0) { out_count[gq] = cnt; if (out_total) out_total[gq] = tot; }
+    __syncthreads();
   }
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(mx, d, 64); mx = o > mx ? o : mx; }
-  const int cls = mx <= 32 ? 0 : (mx <= 64 ? 1 : 2);
-  if (cls != MODE) return;
-  Rec* out = out_rec + (unsigned long long)gq * cap;
-  uint32_t cnt = 0, tot = 0;
-  if (n != 0) {
-    const uint32_t np2 = next_pow2(n);
-    if (np2 <= kLdsSortMax) select_body<MODE>(ix, prm, seg, n, np2, s_keys, s_vals, s_f0, s_f1, s_rows, cap, out, cnt, tot);
-    else select_body<MODE>(ix, prm, seg, n, np2, sc.keys + 2ull * seg0, sc.vals + 2ull * seg0, sc.f0 + seg0, sc.f1 + seg0,
-                           s_rows, cap, out, cnt, tot);
-  }
-  if (lane == 0) { out_count[gq] = cnt; if (out_total) out_total[gq] = tot; }
 }
 
 // per-call statistics from the per-query arrays (kept out of the hot kernels: one shared atomic
