@@ -1106,16 +1106,16 @@ __device__ __forceinline__ void select_body(const DevIndex& ix, const Params& pr
                                             float* pen_cur, float* s_rows, uint32_t cap, Rec* out,
                                             uint32_t& out_count, uint32_t& out_total) {
   const uint32_t lane = lane_id();
-  // ascending key order = score desc, s_id asc; value = position in the accepted list
-  for (uint32_t i = lane; i < np2; i += kWave) {
-    keys[i] = i < n ? (((unsigned long long)(~float_key(seg[i].score)) << 32) | seg[i].sid) : ~0ull;
-    vals[i] = i;
-  }
-  __syncthreads();
-  block_bitonic_sort_kv(keys, vals, np2);
   const uint32_t want = prm.nmatch == 0 ? n : (prm.nmatch < n ? prm.nmatch : n);
   const uint32_t emit = want < cap ? want : cap;
   if (MODE < 0 || !(prm.contrast > 0.f)) {
+    // ascending key order = score desc, s_id asc; value = position in the accepted list
+    for (uint32_t i = lane; i < np2; i += kWave) {
+      keys[i] = i < n ? (((unsigned long long)(~float_key(seg[i].score)) << 32) | seg[i].sid) : ~0ull;
+      vals[i] = i;
+    }
+    __syncthreads();
+    block_bitonic_sort_kv(keys, vals, np2);
     for (uint32_t k = lane; k < emit; k += kWave) {
       const Cand c = seg[vals[k]];
       Rec r;
@@ -1126,9 +1126,14 @@ __device__ __forceinline__ void select_body(const DevIndex& ix, const Params& pr
     out_total = want;
     return;
   }
-  // ---- contrastive rerank; list position k <-> seg[vals[k]] ----
+  // ---- contrastive rerank ----
+  // The reference drains `result` into a list ordered (score desc, s_id asc) and repeatedly takes the
+  // first maximum of score - factor * penalty.  "First in list order" among equal keys is the entry with
+  // the higher score, then the smaller s_id, so the list never has to be materialised: the accepted
+  // matches stay where the replay left them and ties are broken on (score, s_id) directly.
   // pen_sum: running std::accumulate of penalties in pick order; pen_cur: Match::penalty (0 before the
-  // first round); the key array is reused as running max / taken flag: (taken << 63) | bits(max)
+  // first round); keys: (taken << 63) | bits(running max)
+  (void)vals;
   for (uint32_t k = lane; k < n; k += kWave) { pen_sum[k] = 0.f; pen_cur[k] = 0.f; keys[k] = 0ull; }
   __syncthreads();
   DpSide side;
@@ -1138,13 +1143,13 @@ __device__ __forceinline__ void select_body(const DevIndex& ix, const Params& pr
   int last = -1;
   while (picked < n && (prm.nmatch == 0 || picked < prm.nmatch)) {
     if (last >= 0) {
-      const uint32_t msid = seg[vals[last]].sid;
+      const uint32_t msid = seg[last].sid;
       const uint32_t msp = ix.sent_pos[msid];
       const uint32_t n2 = ix.tok[msp];
       const uint32_t* s2 = ix.tok + msp + 1;
       for (uint32_t k = lane; k < n; k += kWave) {
         if (keys[k] >> 63) continue;
-        const uint32_t csid = seg[vals[k]].sid;
+        const uint32_t csid = seg[k].sid;
         const uint32_t csp = ix.sent_pos[csid];
         const uint32_t n1 = ix.tok[csp];
         const float dw = 100.f / normalizer(n1, n2, 1.f, 1.f, 1.f);
@@ -1164,22 +1169,33 @@ __device__ __forceinline__ void select_body(const DevIndex& ix, const Params& pr
       __syncthreads();
     }
     // std::max_element over the remaining list: first maximum of score - factor * penalty
-    float best_key = 0.f;
-    int   best = -1;
+    float best_key = 0.f, best_score = 0.f;
+    uint32_t best_sid = 0;
+    int best = -1;
+    auto better = [](float key, float score, uint32_t sid, float bkey, float bscore, uint32_t bsid) {
+      return bkey < key || (bkey == key && (bscore < score || (bscore == score && sid < bsid)));
+    };
     for (uint32_t k = lane; k < n; k += kWave) {
       if (keys[k] >> 63) continue;
-      const float key = seg[vals[k]].score - (prm.contrast * pen_cur[k]);
-      if (best < 0 || best_key < key) { best = (int)k; best_key = key; }
+      const Cand c = seg[k];
+      const float key = c.score - (prm.contrast * pen_cur[k]);
+      if (best < 0 || better(key, c.score, c.sid, best_key, best_score, best_sid)) {
+        best = (int)k; best_key = key; best_score = c.score; best_sid = c.sid;
+      }
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
       const float ok = __shfl_xor(best_key, d, 64);
+      const float os = __shfl_xor(best_score, d, 64);
+      const uint32_t oi = __shfl_xor(best_sid, d, 64);
       const int   ob = __shfl_xor(best, d, 64);
-      if (ob >= 0 && (best < 0 || best_key < ok || (best_key == ok && ob < best))) { best = ob; best_key = ok; }
+      if (ob >= 0 && (best < 0 || better(ok, os, oi, best_key, best_score, best_sid))) {
+        best = ob; best_key = ok; best_score = os; best_sid = oi;
+      }
     }
     if (lane == 0) {
       if (picked < cap) {
-        const Cand c = seg[vals[best]];
+        const Cand c = seg[best];
         Rec r;
         r.score = c.score; r.penalty = pen_cur[best]; r.max_subseq = (int32_t)c.longest; r.s_id = c.sid;
         out[picked] = r;
