@@ -220,6 +220,81 @@ FMX_HD void mgram_range_keyed(const SufKey* __restrict__ key, const SufRec* __re
   out_hi = b;
 }
 
+// Trigram table: (w0, w1, w2) -> the suffix range of that trigram, open addressing, 16-byte entries.
+// w0 is implied by the range (it lies inside w0's _quickVocabAccess bucket).  One or two random reads
+// replace the ~20 dependent compare steps of the search through a large first-word bucket; the remaining
+// tokens of the seed n-gram are resolved by bisecting the (small) trigram range.
+struct GramEntry {
+  uint32_t w1, w2, lo, cnt;
+};
+constexpr uint32_t kGramEmpty = 0xffffffffu;
+
+FMX_HD uint32_t gram_hash(uint32_t w0, uint32_t w1, uint32_t w2) {
+  uint32_t h = w0 * 0x9E3779B1u;
+  h = (h ^ (h >> 15)) + w1 * 0x85EBCA6Bu;
+  h = (h ^ (h >> 13)) + w2 * 0xC2B2AE35u;
+  return h ^ (h >> 16);
+}
+
+// start_by for tokens [from, m) with from in [3, 5]: the first `from` tokens are known to match
+FMX_HD int start_by_keyed_from(const SufKey* __restrict__ key, const SufRec* __restrict__ suf,
+                               const uint32_t* __restrict__ tok, uint32_t i, const uint32_t* __restrict__ ngram,
+                               uint32_t from, uint32_t m) {
+  const SufKey kk = key[i];
+  const uint32_t lim = m - 1 < kKeyTokens ? m - 1 : kKeyTokens;
+  for (uint32_t k = from - 1; k < lim; k++) {
+    const uint32_t a = kk.t[k], b = ngram[k + 1];
+    if (a < b) return -1;
+    if (a > b) return 1;
+  }
+  if (m - 1 <= kKeyTokens) return 0;
+  return start_by_from(tok, suf[i], ngram, kKeyTokens + 1, m);
+}
+
+// mgram_range through the trigram table; same result as mgram_range / mgram_range_keyed.
+FMX_HD void mgram_range_hashed(const GramEntry* __restrict__ gram, uint32_t gram_mask, const SufKey* __restrict__ key,
+                               const SufRec* __restrict__ suf, const uint32_t* __restrict__ tok,
+                               const uint32_t* __restrict__ qva, uint32_t n_qva, const uint32_t* __restrict__ ngram,
+                               uint32_t m, uint32_t& out_lo, uint32_t& out_hi) {
+  bool usable = gram != nullptr && m >= 3;
+  for (uint32_t k = 1; usable && k < m && k <= kKeyTokens; k++) usable = ngram[k] != 0;
+  if (!usable) { mgram_range_keyed(key, suf, tok, qva, n_qva, ngram, m, out_lo, out_hi); return; }
+  out_lo = out_hi = 0;
+  const uint32_t w0 = ngram[0];
+  if (w0 + 1 >= n_qva) return;
+  const uint32_t blo = qva[w0], bhi = qva[w0 + 1];
+  if (blo >= bhi) return;
+  uint32_t slot = gram_hash(w0, ngram[1], ngram[2]) & gram_mask;
+  uint32_t lo, hi;
+  for (;;) {
+    const GramEntry e = gram[slot];
+    if (e.lo == kGramEmpty) return;  // no suffix starts with this trigram
+    if (e.w1 == ngram[1] && e.w2 == ngram[2] && e.lo >= blo && e.lo < bhi) { lo = e.lo; hi = e.lo + e.cnt; break; }
+    slot = (slot + 1) & gram_mask;
+  }
+  if (m == 3) { out_lo = lo; out_hi = hi; return; }
+  uint32_t a = lo, b = hi;
+  while (a < b) {
+    const uint32_t mid = a + ((b - a) >> 1);
+    if (start_by_keyed_from(key, suf, tok, mid, ngram, 3, m) < 0) a = mid + 1; else b = mid;
+  }
+  const uint32_t first = a;
+  if (first >= hi || start_by_keyed_from(key, suf, tok, first, ngram, 3, m) != 0) { out_lo = out_hi = first; return; }
+  uint32_t step = 1;
+  a = first;
+  b = hi;
+  while ((unsigned long long)a + step < hi) {
+    if (start_by_keyed_from(key, suf, tok, a + step, ngram, 3, m) == 0) { a += step; step <<= 1; }
+    else { b = a + step; break; }
+  }
+  while (b - a > 1) {
+    const uint32_t mid = a + ((b - a) >> 1);
+    if (start_by_keyed_from(key, suf, tok, mid, ngram, 3, m) == 0) a = mid; else b = mid;
+  }
+  out_lo = first;
+  out_hi = b;
+}
+
 // Longest common prefix of a suffix (already known to share `known` tokens) with pat[0..maxlen).
 // This is the match_length the reference's narrowing loop ends up registering for the suffix
 // (src/fuzzy_match.cc:500-550).

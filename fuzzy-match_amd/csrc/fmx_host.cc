@@ -245,6 +245,63 @@ int edit_distance_char(const char* s1, int n1, const char* s2, int n2) {
   return prev[n2];
 }
 
+// Trigram table (fmx_core.hh: GramEntry): one entry per distinct (w0, w1, w2) that starts at least one
+// suffix with three or more tokens.  Groups are contiguous in the suffix array; built in parallel with
+// CAS inserts, load factor <= 0.5.
+void HostIndex::build_gram_table(int nthreads) {
+  gram.clear();
+  const uint64_t n = suf_rec.size();
+  if (n == 0) return;
+  if (nthreads < 1) nthreads = 1;
+  auto w0_of = [&](uint64_t i) { return buf[suf_rec[i].off]; };
+  auto is_start = [&](uint64_t i) {
+    if (suf_rec[i].rem < 3) return false;
+    if (i == 0 || suf_rec[i - 1].rem < 3) return true;
+    return w0_of(i) != w0_of(i - 1) || suf_key[i].t[0] != suf_key[i - 1].t[0] || suf_key[i].t[1] != suf_key[i - 1].t[1];
+  };
+  std::vector<uint64_t> part_count(nthreads, 0);
+  auto run = [&](auto fn) {
+    std::vector<std::thread> th;
+    for (int t = 1; t < nthreads; t++) th.emplace_back(fn, t);
+    fn(0);
+    for (auto& x : th) x.join();
+  };
+  run([&](int t) {
+    const uint64_t a = n * (uint64_t)t / (uint64_t)nthreads, b = n * (uint64_t)(t + 1) / (uint64_t)nthreads;
+    uint64_t c = 0;
+    for (uint64_t i = a; i < b; i++) c += is_start(i) ? 1 : 0;
+    part_count[t] = c;
+  });
+  uint64_t groups = 0;
+  for (auto c : part_count) groups += c;
+  if (groups == 0) return;
+  uint64_t cap = 16;
+  while (cap < groups * 2) cap <<= 1;
+  if (cap > (1ull << 31)) return;  // would not fit 32-bit slot arithmetic: the keyed search is used instead
+  GramEntry empty;
+  empty.w1 = empty.w2 = 0; empty.lo = kGramEmpty; empty.cnt = 0;
+  gram.assign(cap, empty);
+  const uint32_t mask = (uint32_t)(cap - 1);
+  run([&](int t) {
+    const uint64_t a = n * (uint64_t)t / (uint64_t)nthreads, b = n * (uint64_t)(t + 1) / (uint64_t)nthreads;
+    for (uint64_t i = a; i < b; i++) {
+      if (!is_start(i)) continue;
+      uint64_t e = i + 1;  // the group may extend into the next thread's slice
+      const uint32_t w0 = w0_of(i), w1 = suf_key[i].t[0], w2 = suf_key[i].t[1];
+      while (e < n && suf_rec[e].rem >= 3 && w0_of(e) == w0 && suf_key[e].t[0] == w1 && suf_key[e].t[1] == w2) e++;
+      uint32_t slot = gram_hash(w0, w1, w2) & mask;
+      for (;;) {
+        uint32_t expect = kGramEmpty;
+        if (__atomic_compare_exchange_n(&gram[slot].lo, &expect, (uint32_t)i, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE)) {
+          gram[slot].w1 = w1; gram[slot].w2 = w2; gram[slot].cnt = (uint32_t)(e - i);
+          break;
+        }
+        slot = (slot + 1) & mask;
+      }
+    }
+  });
+}
+
 uint32_t HostIndex::intern_itok(const std::string& s) {
   if (itok_strings.empty()) {
     itok_strings.emplace_back();
@@ -307,6 +364,10 @@ void HostIndex::derive() {
       for (uint32_t t = 0; t < kKeyTokens; t++) k.t[t] = t + 1 < suf_rec[i].rem ? buf[suf_rec[i].off + 1 + t] : 0u;
       suf_key[i] = k;
     }
+  }
+  {
+    unsigned hw = std::thread::hardware_concurrency();
+    build_gram_table((int)std::min<unsigned>(hw ? hw : 1, 32));
   }
   // compute_idf_penalty / compute_max_idf_penalty — src/fuzzy_match.cc:367-390 (glibc logf / log)
   const unsigned N = num_sentences();

@@ -48,6 +48,8 @@ class HostIndex {
   std::vector<SufRec>   suf_rec;   // one 8-byte record per suffix, suffix-array order
   std::vector<uint64_t> suf_sig;   // sentence length << 48 | 48-bit word signature of the suffix's sentence
   std::vector<SufKey>   suf_key;   // the four tokens after each suffix's first token (0-padded)
+  std::vector<GramEntry> gram;     // trigram -> suffix range hash table (power-of-two size, empty if tiny index)
+  void build_gram_table(int nthreads);
   std::vector<float>    idf;       // logf(N / sfreq[w]) per word id (src/fuzzy_match.cc:384)
   float                 idf_max = 0.01f;
   bool                  real_differs = false;  // some sentence has real tokens != its normalised tokens, or itoks

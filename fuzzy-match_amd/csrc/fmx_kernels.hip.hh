@@ -20,6 +20,8 @@ struct DevIndex {
   const SufRec*   suf;
   const unsigned long long* suf_sig;  // sentence length << 48 | 48-bit word signature
   const SufKey*   suf_key;    // four tokens after the first, per suffix
+  const GramEntry* gram;      // trigram -> suffix range hash table (nullptr if absent)
+  uint32_t        gram_mask;
   const uint32_t* suf_sid;
   const uint32_t* tok;
   const uint32_t* sent_pos;
@@ -132,7 +134,8 @@ __global__ void __launch_bounds__(256) k_probe(DevIndex ix, DevBatch b, DevWork 
     // with p == 1 the only registered length is 1.
     const bool reachable = (p == 1) ? (msl <= 1) : true;
     if (reachable && it + m <= p)
-      mgram_range_keyed(ix.suf_key, ix.suf, ix.tok, ix.qva, ix.n_qva, b.q_tok + b.t_begin + t, m, lo, hi);
+      mgram_range_hashed(ix.gram, ix.gram_mask, ix.suf_key, ix.suf, ix.tok, ix.qva, ix.n_qva, b.q_tok + b.t_begin + t, m,
+                         lo, hi);
   }
   const uint32_t cnt = hi - lo;
   w.t_lo[t] = lo;
