@@ -69,6 +69,7 @@ struct DeviceIndex::Impl {
   uint32_t* big_list = nullptr;
   uint32_t* contrast_list = nullptr;  // 2 x cap_q
   WorkItem* items = nullptr;
+  WorkItem* items_b = nullptr;
   uint32_t  item_cap = 0;
   uint32_t  s_max = 4096;   // survivors kept per query before a retry with a larger segment
   // staging for the host-batch entry point
@@ -88,7 +89,7 @@ DeviceIndex::DeviceIndex() : impl_(new Impl) {}
 static void free_ws(DeviceIndex::Impl& m) {
   hipFree(m.w.q_m); hipFree(m.w.t_q); hipFree(m.w.t_lo); hipFree(m.w.t_cnt); hipFree(m.w.q_hits);
   hipFree(m.w.q_seg); hipFree(m.w.q_kept); hipFree(m.w.q_cand); hipFree(m.w.q_acc); hipFree(m.w.q_pb); hipFree(m.w.c_in); hipFree(m.w.c_off); hipFree(m.w.t_idf); hipFree(m.w.c_qi); hipFree(m.big_list); m.big_list = nullptr; hipFree(m.contrast_list); m.contrast_list = nullptr;
-  hipFree(m.w.seg); hipFree(m.w.heap); hipFree(m.w.counters);
+  hipFree(m.w.seg); hipFree(m.w.qb); hipFree(m.w.heap); hipFree(m.w.counters);
   hipFree(m.sc.keys); hipFree(m.sc.vals); hipFree(m.sc.f0); hipFree(m.sc.f1);
   hipFree(m.tile_sums); hipFree(m.grand_total); hipFree(m.w.q_cap);
   m.w = DevWork{}; m.sc = DevScratch{};
@@ -106,7 +107,7 @@ DeviceIndex::~DeviceIndex() {
     hipFree((void*)m.d.itok_dist);
     free_ws(m);
     hipFree(m.d_qoff); hipFree(m.d_qtok); hipFree(m.d_qreal); hipFree(m.d_qitok);
-    hipFree(m.d_out); hipFree(m.d_out_count); hipFree(m.d_out_total); hipFree(m.items);
+    hipFree(m.d_out); hipFree(m.d_out_count); hipFree(m.d_out_total); hipFree(m.items); hipFree(m.items_b);
     if (m.ev_ok) for (auto& e : m.ev) hipEventDestroy(e);
   }
   delete impl_;
@@ -183,6 +184,7 @@ static void ensure_ws(DeviceIndex::Impl& m, uint64_t nq, uint64_t nt, uint64_t s
     m.big_list = dev_alloc<uint32_t>(cq);
     m.contrast_list = dev_alloc<uint32_t>(2 * cq);
     m.w.seg = dev_alloc<Cand>(cs);
+    m.w.qb = dev_alloc<QHit>(cs);
     m.w.heap = dev_alloc<float>(cs + cq + 1);
     m.w.counters = dev_alloc<unsigned long long>(16);
     m.w.seg_cap = cs;
@@ -229,7 +231,7 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm_in, const D
     p_max = std::max<uint32_t>(1, std::min<uint32_t>(p_max, bv.p_max ? bv.p_max : p_max));
     for (int attempt = 0;; attempt++) {
       ensure_ws(m, b.nq, std::max<uint32_t>(b.nt, 1), want_seg);
-      if (!m.items) { m.item_cap = 1u << 22; m.items = dev_alloc<WorkItem>(m.item_cap); }
+      if (!m.items) { m.item_cap = 1u << 22; m.items = dev_alloc<WorkItem>(m.item_cap); m.items_b = dev_alloc<WorkItem>(m.item_cap); }
       DevWork w = m.w;
       HIP_TRY(hipMemsetAsync(w.q_hits, 0, (b.nq + 1) * sizeof(unsigned long long), stream));
       HIP_TRY(hipMemsetAsync(w.counters, 0, 16 * sizeof(unsigned long long), stream));
@@ -252,12 +254,15 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm_in, const D
       }
       tick(); tick();
       {
-        const size_t lds = (size_t)p_max * 4 + kCminTab * 2;
-        if (lds > 64 * 1024) throw GpuError("patterns too long for the expand kernel's LDS staging");
         // the signature bound needs theoretical_rejection_cover to be monotone in the cover: costs >= 0
         const int use_sig = prm.ins >= 0.f && prm.del >= 0.f && prm.rep >= 0.f;
-        hipLaunchKernelGGL(k_expand, dim3(b.nq + kExpandExtraGrid), dim3(kWave), lds, stream, m.d, b, w, prm,
-                           (const WorkItem*)m.items, m.item_cap, p_max, use_sig);
+        hipLaunchKernelGGL(k_expand_a, dim3(b.nq + kExpandExtraGrid), dim3(kWave), kCminTab * 2, stream, m.d, b, w, prm,
+                           (const WorkItem*)m.items, m.item_cap, use_sig);
+        hipLaunchKernelGGL(k_caps_b, dim3((b.nq + 255) / 256), dim3(256), 0, stream, b, w, m.items_b, m.item_cap);
+        const size_t lds = (size_t)p_max * 4;
+        if (lds > 64 * 1024) throw GpuError("patterns too long for the expand kernel's LDS staging");
+        hipLaunchKernelGGL(k_expand_b, dim3(b.nq + kExpandExtraGrid), dim3(kWave), lds, stream, m.d, b, w, prm,
+                           (const WorkItem*)m.items_b, m.item_cap);
       }
       tick(); tick();
       hipLaunchKernelGGL(k_cand, dim3(b.nq), dim3(kWave), 0, stream, w, m.big_list);
@@ -354,10 +359,12 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm_in, const D
         m.s_max = s;
         retry = true;
       }
-      if (ctr[5] > m.item_cap) {                                                       // work-item list too short
-        hipFree(m.items);
-        m.item_cap = (uint32_t)std::min<unsigned long long>(ctr[5] + ctr[5] / 4, 0xffffffffull);
+      if (std::max(ctr[5], ctr[12]) > m.item_cap) {                                    // work-item list too short
+        hipFree(m.items); hipFree(m.items_b);
+        const unsigned long long need = std::max(ctr[5], ctr[12]);
+        m.item_cap = (uint32_t)std::min<unsigned long long>(need + need / 4, 0xffffffffull);
         m.items = dev_alloc<WorkItem>(m.item_cap);
+        m.items_b = dev_alloc<WorkItem>(m.item_cap);
         retry = true;
       }
       if (retry) {

@@ -48,6 +48,8 @@ struct DevBatch {
   uint32_t        nt;       // tokens in this sub-batch
 };
 
+struct QHit;
+
 struct DevWork {
   uint32_t* q_m;        // nq   seed n-gram length or kNoMatchLen
   uint32_t* t_q;        // nt   token -> local query
@@ -65,12 +67,13 @@ struct DevWork {
   unsigned long long* c_qi;    // seg_cap  (query << 32 | candidate index), dense per length class
   float*    t_idf;      // nt   idf_penalty per pattern position (src/fuzzy_match.cc:372-390)
   Cand*     seg;        // capacity seg_cap
+  QHit*     qb;      // capacity seg_cap: per-query queues between the two expand phases
   float*    heap;       // capacity seg_cap + nq (lowest_costs spill)
   unsigned long long  seg_cap;
   unsigned long long* counters;  // [0]=hits [1]=kept [2]=cands [3]=dp [4]=max survivors of a query whose
                                  // segment overflowed [5]=extra work items [6]=segment space needed
                                  // [7]=queries queued for k_cand_big [8]=phase-B hits [9]=max kept
-                                 // [10],[11]=queries queued for k_contrast<1>, <2>
+                                 // [10],[11]=queries queued for k_contrast<1>, <2> [12]=extra k_expand_b items
 };
 
 constexpr int kWave = 64;
@@ -336,84 +339,39 @@ __device__ __forceinline__ bool cover_at_least(const PatHash& ph, const uint32_t
 
 constexpr int kUnroll = 4;        // hits per lane per phase-A iteration
 constexpr uint32_t kQueue = 128;  // LDS ring of hits that passed the cheap tests (power of two >= 2 * 64)
+constexpr uint32_t kPhaseBChunk = 1024;  // queued hits per k_expand_b work item
+constexpr uint32_t kNeedExact = 0xfffeu; // "no tabulated threshold": phase B evaluates the bound itself
 
-// phase B of k_expand for up to 64 queued hits (one per lane): dominance, match length, exact
-// coverage count, then ballot/prefix append of the survivors to the query's segment.
-__device__ __forceinline__ void expand_phase_b(const DevIndex& ix, const Params& prm, const DevWork& w, uint32_t q,
-                                               Cand* seg, uint32_t cap, const uint32_t* pat, const uint32_t* s_pat,
-                                               const uint16_t* s_cmin, uint32_t tab_n, uint32_t p, uint32_t m,
-                                               int use_sig, const PatHash& ph, const uint32_t* s_qi,
-                                               const uint32_t* s_qit, uint32_t head, uint32_t n_take) {
-  const uint32_t lane = lane_id();
-  bool keep = lane < n_take;
-  uint32_t sid = 0, L = 0;
-  if (keep) {
-    const uint32_t slot = (head + lane) & (kQueue - 1);
-    const uint32_t i = s_qi[slot], it = s_qit[slot];
-    const SufRec r = ix.suf[i];
-    keep = !dominated_hit(ix.tok, r, pat + it, it);
-    if (keep) {
-      L = lcp_extend(ix.tok, r, pat + it, m, p - it);
-      const uint32_t sl = r.slen;
-      const uint32_t* sent = ix.tok + (r.off - (uint32_t)(r.slen - r.rem));
-      if (use_sig) {
-        const uint32_t need = sl < tab_n ? (uint32_t)s_cmin[sl] : cover_threshold(p, sl, prm);
-        if (L >= p) keep = p >= need;
-        else if (p <= kWave) keep = cover_at_least(ph, sent, sl, need);
-        else keep = cover_lds(sent, sl, s_pat, p) >= need;
-      } else {
-        const uint32_t cover = L < p ? cover_lds(sent, sl, s_pat, p) : p;
-        keep = !reject_cover(p, sl, cover, prm);
-      }
-      if (keep) sid = ix.suf_sid[i];
-    }
-  }
-  const unsigned long long mask = __ballot(keep);
-  if (mask) {
-    const uint32_t cnt = __popcll(mask);
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(&w.q_kept[q], cnt);
-    base = __shfl(base, 0, 64);
-    if (keep) {
-      const uint32_t pos = base + __popcll(mask & ((1ull << lane) - 1ull));
-      if (pos < cap) {
-        Cand c;
-        c.sid = sid; c.longest = L; c.score = 0.f; c.penalty = 0.f;
-        seg[pos] = c;
-      }
-    }
-  }
-  __syncthreads();
-}
+// a hit that passed the cheap tests of phase A, queued for phase B
+struct QHit {
+  uint32_t i;        // suffix index
+  uint32_t it_need;  // start position << 16 | minimal cover (or kNeedExact)
+};
 
 // ---------------------------------------------------------------------------------------------
-// k_expand — one wave per work item (query, chunk of kExpandChunk hits).  Walks the hits (the
-// suffixes the reference's register_suffix_range_match visits, src/ngram_matches.cc:61-83), applies
-// the length filter, drops dominated hits, computes the match length, applies the coverage bound
-// (src/fuzzy_match.cc:576-581 — it does not depend on the match length, so filtering before the
-// per-sentence max is exact) and appends survivors to the query's segment with wave ballot +
-// prefix popcount and one atomic per 64 hits.
-//
-// Per-hit cost is what matters here (2e9 hits per million queries at 5 M sentences), so everything
-// that depends only on (pattern, sentence length) is tabulated once per work item in LDS:
-//   s_cmin[s]   minimal cover a sentence of s tokens needs (0xffff = rejected by its length alone)
-//   planes      bit planes of "pattern positions per signature bucket": the upper bound of the cover
-//               from the sentence's 64-bit word signature is sum_k popcount(sig & plane_k) << k
-// so most hits are decided by one 8-byte record load, one 8-byte signature load and ~20 ALU ops.
-// Dynamic LDS: pat[p_max] u32 | cmin[kCminTab] u16.
+// k_expand_a — phase A of the hit walk: one wave per work item (query, chunk of kExpandChunk hits).
+// Walks the hits (the suffixes the reference's register_suffix_range_match visits,
+// src/ngram_matches.cc:61-83) reading 8 bytes per hit — sentence length and 48-bit word signature —
+// and decides most of them without touching a token:
+//   s_cmin[s]   per work item, in LDS: minimal cover a sentence of s tokens needs to pass
+//               theoretical_rejection_cover (0xffff = rejected by theoretical_rejection, the length
+//               filter); monotone in the cover for non-negative costs
+//   planes      bit planes of "pattern positions per signature bucket": an upper bound of the cover is
+//               sum_k popcount(sig & plane_k) << k
+// The ~2.5 % that pass are compacted through an LDS ring and appended, 64 at a time with one atomic, to
+// the query's queue for k_expand_b.  The kernel is deliberately small (few registers, no token access):
+// it is bound by HBM latency, so what matters is how many waves are resident.
+// Dynamic LDS: cmin[kCminTab] u16.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kWave) k_expand(DevIndex ix, DevBatch b, DevWork w, Params prm,
-                                                  const WorkItem* items, uint32_t item_cap, uint32_t p_max,
-                                                  int use_sig) {
+__global__ void __launch_bounds__(kWave) k_expand_a(DevIndex ix, DevBatch b, DevWork w, Params prm,
+                                                    const WorkItem* items, uint32_t item_cap, int use_sig) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  uint32_t* s_pat = (uint32_t*)smem;
-  uint16_t* s_cmin = (uint16_t*)(s_pat + p_max);
+  uint16_t* s_cmin = (uint16_t*)smem;
   __shared__ uint32_t s_npref[kWave + 1];  // exclusive hit prefix of the non-empty start positions
   __shared__ uint32_t s_nlo[kWave];
   __shared__ uint32_t s_nit[kWave];
   __shared__ uint32_t s_bucket[kWave];
-  __shared__ uint32_t s_qi[kQueue], s_qit[kQueue];
-  __shared__ PatHash ph;
+  __shared__ QHit s_q[kQueue];
   const uint32_t lane = lane_id();
   uint32_t q, chunk;
   uint32_t item_idx = 0;
@@ -438,30 +396,24 @@ __global__ void __launch_bounds__(kWave) k_expand(DevIndex ix, DevBatch b, DevWo
       } else {
         const uint32_t o0 = b.q_off[b.q_begin + q];
         const uint32_t p = b.q_off[b.q_begin + q + 1] - o0;
-        const uint32_t m = seed_len(p, msl);
         const uint32_t* pat = b.q_tok + o0;
         const uint32_t t0 = o0 - b.t_begin;
         __syncthreads();
         // ---- per-item tables ----
         s_bucket[lane] = 0;
         __syncthreads();
-        for (uint32_t j = lane; j < p; j += kWave) {
-          const uint32_t wd = pat[j];
-          s_pat[j] = wd;
-          atomicAdd(&s_bucket[sig_bit(wd)], 1u);
-        }
+        for (uint32_t j = lane; j < p; j += kWave) atomicAdd(&s_bucket[sig_bit(pat[j])], 1u);
         const uint32_t tab_n = ix.max_slen + 1 < kCminTab ? ix.max_slen + 1 : kCminTab;
         for (uint32_t sl = lane; sl < tab_n; sl += kWave) {
           // the length filter first (one evaluation); the threshold search only for lengths that pass it
-          uint32_t c = reject_len(p, sl, prm) ? 0xffffu : 0u;
-          if (c == 0u && use_sig) c = cover_threshold(p, sl, prm);
+          uint32_t c = reject_len(p, sl, prm) ? 0xffffu : kNeedExact;
+          if (c == kNeedExact && use_sig) c = cover_threshold(p, sl, prm);
           s_cmin[sl] = (uint16_t)c;
         }
         __syncthreads();
-        if (use_sig && p <= kWave) pat_hash_build(ph, s_pat, p);
         unsigned long long planes[kMaxPlanes];
         uint32_t n_planes = 0;
-        bool sig_off = false;
+        bool sig_off = !use_sig;
         {
           const uint32_t mycnt = s_bucket[lane];
           // a bucket with >= 2^kMaxPlanes pattern positions (p >= 256) would overflow the planes: the
@@ -469,17 +421,24 @@ __global__ void __launch_bounds__(kWave) k_expand(DevIndex ix, DevBatch b, DevWo
           const bool overflow = __ballot(mycnt >> kMaxPlanes) != 0ull;
 #pragma unroll
           for (uint32_t k = 0; k < kMaxPlanes; k++) {
-            planes[k] = overflow ? (k == 0 ? ~0ull : 0ull) : __ballot((mycnt >> k) & 1u);
+            planes[k] = __ballot((mycnt >> k) & 1u);
             if (planes[k]) n_planes = k + 1;
           }
-          if (overflow) { planes[0] = 0ull; n_planes = 0; }
-          sig_off = overflow;
+          if (overflow) { n_planes = 0; sig_off = true; }
         }
-        Cand* seg = w.seg + seg0;
+        QHit* qb = w.qb + seg0;
         const unsigned long long h_lo = (unsigned long long)chunk * kExpandChunk;
         const unsigned long long h_hi = h_lo + kExpandChunk < hits ? h_lo + kExpandChunk : hits;
         unsigned long long base_h = 0;  // hits of the start positions before c0
-        uint32_t q_head = 0, q_tail = 0;  // ring of hits waiting for phase B
+        uint32_t q_head = 0, q_tail = 0;  // ring of hits waiting to be flushed to the query's queue
+        auto flush = [&](uint32_t n_take) {
+          uint32_t base = 0;
+          if (lane == 0) base = atomicAdd(&w.q_pb[q], n_take);
+          base = __shfl(base, 0, 64);
+          if (lane < n_take && base + lane < cap) qb[base + lane] = s_q[(q_head + lane) & (kQueue - 1)];
+          q_head += n_take;
+          __syncthreads();
+        };
         for (uint32_t c0 = 0; c0 < p && base_h < h_hi; c0 += kWave) {
           const uint32_t it_l = c0 + lane;
           const uint32_t mycnt = it_l < p ? w.t_cnt[t0 + it_l] : 0u;
@@ -502,8 +461,7 @@ __global__ void __launch_bounds__(kWave) k_expand(DevIndex ix, DevBatch b, DevWo
           const unsigned long long a1 = h_hi - base_h < total ? h_hi - base_h : (unsigned long long)total;
           uint32_t k = 0;  // this lane's current start position (index into the compacted list)
           for (unsigned long long hh = a0; hh < a1; hh += kWave * kUnroll) {
-            // kUnroll independent hits per lane: their record/signature loads are all in flight before the
-            // first one is consumed (this loop is bound by HBM latency, not by instruction issue)
+            // kUnroll independent hits per lane: their loads are all in flight before the first is consumed
             uint32_t hi_[kUnroll], hit_[kUnroll];
             bool hv[kUnroll];
 #pragma unroll
@@ -517,56 +475,149 @@ __global__ void __launch_bounds__(kWave) k_expand(DevIndex ix, DevBatch b, DevWo
                 hi_[u] = s_nlo[k] + (h - s_npref[k]);
               }
             }
-            uint32_t hsl[kUnroll];
-            unsigned long long hsig[kUnroll];
+            unsigned long long hpk[kUnroll];
 #pragma unroll
-            for (int u = 0; u < kUnroll; u++) {
-              const unsigned long long packed = ix.suf_sig[hi_[u]];  // the only HBM read of phase A: 8 B per hit
-              hsl[u] = sig_slen(packed);
-              hsig[u] = sig_bits(packed);
-            }
+            for (int u = 0; u < kUnroll; u++) hpk[u] = ix.suf_sig[hi_[u]];  // the only HBM read: 8 B per hit
 #pragma unroll
             for (int u = 0; u < kUnroll; u++) {
               if ((uint32_t)hh + u * kWave >= (uint32_t)a1) break;  // uniform
               bool keep = hv[u];
+              uint32_t cmin = 0;
               if (keep) {
-                const uint32_t sl = hsl[u];
-                uint32_t cmin;
+                const uint32_t sl = sig_slen(hpk[u]);
                 if (sl < tab_n) cmin = s_cmin[sl];
-                else cmin = use_sig ? cover_threshold(p, sl, prm) : (reject_len(p, sl, prm) ? 0xffffu : 0u);
+                else cmin = reject_len(p, sl, prm) ? 0xffffu : (use_sig ? cover_threshold(p, sl, prm) : kNeedExact);
                 keep = cmin != 0xffffu;
-                if (keep && use_sig && !sig_off) {
+                if (keep && !sig_off) {
                   // upper bound of the cover from the word signature: no token is touched for most hits
+                  const unsigned long long sig = sig_bits(hpk[u]);
                   uint32_t ub = 0;
 #pragma unroll
                   for (uint32_t kk = 0; kk < kMaxPlanes; kk++)
-                    if (kk < n_planes) ub += (uint32_t)__popcll(hsig[u] & planes[kk]) << kk;
+                    if (kk < n_planes) ub += (uint32_t)__popcll(sig & planes[kk]) << kk;
                   keep = ub >= cmin;
                 }
               }
-              // phase A -> queue: hits that need their tokens looked at are compacted through LDS so that
-              // the expensive phase B always runs with (nearly) all 64 lanes busy
               const unsigned long long mask = __ballot(keep);
               if (mask) {
                 if (keep) {
-                  const uint32_t slot = (q_tail + __popcll(mask & ((1ull << lane) - 1ull))) & (kQueue - 1);
-                  s_qi[slot] = hi_[u];
-                  s_qit[slot] = hit_[u];
+                  QHit e;
+                  e.i = hi_[u];
+                  e.it_need = (hit_[u] << 16) | cmin;
+                  s_q[(q_tail + __popcll(mask & ((1ull << lane) - 1ull))) & (kQueue - 1)] = e;
                 }
                 q_tail += __popcll(mask);
                 __syncthreads();
-                while (q_tail - q_head >= kWave) {
-                  expand_phase_b(ix, prm, w, q, seg, cap, pat, s_pat, s_cmin, tab_n, p, m, use_sig, ph, s_qi, s_qit, q_head, kWave);
-                  q_head += kWave;
-                }
+                if (q_tail - q_head >= kWave) flush(kWave);
               }
             }
           }
           base_h += total;
         }
-        if (lane == 0 && q_tail) atomicAdd(&w.q_pb[q], q_tail);
-        if (q_tail != q_head)
-          expand_phase_b(ix, prm, w, q, seg, cap, pat, s_pat, s_cmin, tab_n, p, m, use_sig, ph, s_qi, s_qit, q_head, q_tail - q_head);
+        if (q_tail != q_head) flush(q_tail - q_head);
+      }
+    }
+    if (!extra) return;
+    item_idx += kExpandExtraGrid;
+  }
+}
+
+// work items of k_expand_b for queries with more than kPhaseBChunk queued hits
+__global__ void k_caps_b(DevBatch b, DevWork w, WorkItem* items, uint32_t item_cap) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= b.nq) return;
+  const uint32_t cap = (uint32_t)(w.q_seg[q + 1] - w.q_seg[q]);
+  const uint32_t n = w.q_pb[q];
+  if (n > cap) { atomicMax(&w.counters[4], (unsigned long long)n); return; }  // queue overflow: retry with a larger s_max
+  if (n > kPhaseBChunk) {
+    const uint32_t n_extra = (n + kPhaseBChunk - 1) / kPhaseBChunk - 1;
+    const unsigned long long base = atomicAdd(&w.counters[12], (unsigned long long)n_extra);
+    for (uint32_t k = 0; k < n_extra; k++)
+      if (base + k < item_cap) { WorkItem it; it.q = q; it.chunk = k + 1; items[base + k] = it; }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_expand_b — phase B: one wave per (query, chunk of kPhaseBChunk queued hits), one hit per lane:
+// dominance test (the previous start position reaches the same sentence with a longer match), match
+// length, exact coverage test through a per-item hash set of the pattern's words, then ballot/prefix
+// append of the survivors to the query's segment.  Dynamic LDS: pat[p_max].
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kWave) k_expand_b(DevIndex ix, DevBatch b, DevWork w, Params prm,
+                                                    const WorkItem* items, uint32_t item_cap) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint32_t* s_pat = (uint32_t*)smem;
+  __shared__ PatHash ph;
+  const uint32_t lane = lane_id();
+  uint32_t q, chunk;
+  uint32_t item_idx = 0;
+  const bool extra = blockIdx.x >= b.nq;
+  if (!extra) { q = blockIdx.x; chunk = 0; }
+  else item_idx = blockIdx.x - b.nq;
+  for (;;) {
+    if (extra) {
+      unsigned long long n_items = w.counters[12];
+      if (n_items > item_cap) n_items = item_cap;
+      if (item_idx >= n_items) return;
+      q = items[item_idx].q;
+      chunk = items[item_idx].chunk;
+    }
+    const unsigned long long seg0 = w.q_seg[q];
+    const uint32_t cap = (uint32_t)(w.q_seg[q + 1] - seg0);
+    const uint32_t n_q = w.q_pb[q];
+    if (n_q != 0 && n_q <= cap && seg0 + cap <= w.seg_cap) {
+      const uint32_t msl = w.q_m[q];
+      const uint32_t o0 = b.q_off[b.q_begin + q];
+      const uint32_t p = b.q_off[b.q_begin + q + 1] - o0;
+      const uint32_t m = seed_len(p, msl);
+      const uint32_t* pat = b.q_tok + o0;
+      __syncthreads();
+      for (uint32_t j = lane; j < p; j += kWave) s_pat[j] = pat[j];
+      __syncthreads();
+      if (p <= kWave) pat_hash_build(ph, s_pat, p);
+      const QHit* qb = w.qb + seg0;
+      Cand* seg = w.seg + seg0;
+      const uint32_t e_lo = chunk * kPhaseBChunk;
+      const uint32_t e_hi = e_lo + kPhaseBChunk < n_q ? e_lo + kPhaseBChunk : n_q;
+      for (uint32_t e0 = e_lo; e0 < e_hi; e0 += kWave) {
+        const uint32_t e = e0 + lane;
+        bool keep = e < e_hi;
+        uint32_t sid = 0, L = 0;
+        if (keep) {
+          const QHit hq = qb[e];
+          const uint32_t i = hq.i, it = hq.it_need >> 16, need = hq.it_need & 0xffffu;
+          const SufRec r = ix.suf[i];
+          keep = !dominated_hit(ix.tok, r, pat + it, it);
+          if (keep) {
+            L = lcp_extend(ix.tok, r, pat + it, m, p - it);
+            const uint32_t sl = r.slen;
+            const uint32_t* sent = ix.tok + (r.off - (uint32_t)(r.slen - r.rem));
+            if (need != kNeedExact) {
+              if (L >= p) keep = p >= need;
+              else if (p <= kWave) keep = cover_at_least(ph, sent, sl, need);
+              else keep = cover_lds(sent, sl, s_pat, p) >= need;
+            } else {
+              const uint32_t cover = L < p ? cover_lds(sent, sl, s_pat, p) : p;
+              keep = !reject_cover(p, sl, cover, prm);
+            }
+            if (keep) sid = ix.suf_sid[i];
+          }
+        }
+        const unsigned long long mask = __ballot(keep);
+        if (mask) {
+          const uint32_t cnt = __popcll(mask);
+          uint32_t base = 0;
+          if (lane == 0) base = atomicAdd(&w.q_kept[q], cnt);
+          base = __shfl(base, 0, 64);
+          if (keep) {
+            const uint32_t pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+            if (pos < cap) {
+              Cand c;
+              c.sid = sid; c.longest = L; c.score = 0.f; c.penalty = 0.f;
+              seg[pos] = c;
+            }
+          }
+        }
       }
     }
     if (!extra) return;
