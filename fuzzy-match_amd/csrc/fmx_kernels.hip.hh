@@ -320,17 +320,24 @@ __device__ __forceinline__ bool cover_at_least(const PatHash& ph, const uint32_t
   unsigned long long seen = 0;
   uint32_t cover = 0;
   if (need == 0) return true;
-  for (uint32_t k = 0; k < slen; k++) {
-    const uint32_t t = sent[k];
-    uint32_t h = pat_hash_slot(t);
-    uint32_t key = ph.key[h];
-    while (key != t && key != kHashEmpty) { h = (h + 1) & (kHashSlots - 1); key = ph.key[h]; }
-    if (key == t) {
-      const uint32_t d = ph.idx[h];
-      if (!((seen >> d) & 1ull)) {
-        seen |= 1ull << d;
-        cover += ph.cnt[d];
-        if (cover >= need) return true;
+  // four tokens per step: their loads are issued together (the walk is bound by load latency)
+  for (uint32_t k0 = 0; k0 < slen; k0 += 4) {
+    uint32_t t[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) t[u] = k0 + u < slen ? sent[k0 + u] : kHashEmpty;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (k0 + u >= slen) break;
+      uint32_t h = pat_hash_slot(t[u]);
+      uint32_t key = ph.key[h];
+      while (key != t[u] && key != kHashEmpty) { h = (h + 1) & (kHashSlots - 1); key = ph.key[h]; }
+      if (key == t[u]) {
+        const uint32_t d = ph.idx[h];
+        if (!((seen >> d) & 1ull)) {
+          seen |= 1ull << d;
+          cover += ph.cnt[d];
+          if (cover >= need) return true;
+        }
       }
     }
   }
@@ -363,7 +370,7 @@ struct QHit {
 // it is bound by HBM latency, so what matters is how many waves are resident.
 // Dynamic LDS: cmin[kCminTab] u16.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kWave) k_expand_a(DevIndex ix, DevBatch b, DevWork w, Params prm,
+__global__ void __launch_bounds__(kWave, 8) k_expand_a(DevIndex ix, DevBatch b, DevWork w, Params prm,
                                                     const WorkItem* items, uint32_t item_cap, int use_sig) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint16_t* s_cmin = (uint16_t*)smem;
