@@ -166,9 +166,15 @@ def main():
             launches_per_step = launches[names.index("probe")] / max(args.steps, 1)
             if probe_ms > 0:
                 achieved = probe_bytes_per_query * nq / (probe_ms * 1e-3) / 1e9
+                # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same workload
+                traffic = None
+                tpath = os.path.join(ROOT, "profiles", "r01_c3_probe_traffic.json")
+                if args.config == "C3" and not args.sentences and not args.queries and os.path.exists(tpath):
+                    traffic = json.load(open(tpath)).get("traffic_bytes_per_launch")
                 roofline = {"kernel": "k_probe", "bound": "hbm", "achieved": round(achieved, 2),
                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                            "traffic": None, "algorithmic_bytes_per_query": round(probe_bytes_per_query, 1),
+                            "traffic": traffic,
+                            "algorithmic_bytes_per_launch": round(probe_bytes_per_query * nq / max(launches_per_step, 1)), "algorithmic_bytes_per_query": round(probe_bytes_per_query, 1),
                             "kernel_ms_per_step": round(probe_ms, 4), "launches_per_step": launches_per_step,
                             "stage_ms_per_step": {k: round(v, 4) for k, v in per_stage.items()}}
         if not args.no_cpu_baseline and world == 1:
