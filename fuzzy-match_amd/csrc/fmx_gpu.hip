@@ -88,7 +88,7 @@ DeviceIndex::DeviceIndex() : impl_(new Impl) {}
 
 static void free_ws(DeviceIndex::Impl& m) {
   hipFree(m.w.q_m); hipFree(m.w.t_q); hipFree(m.w.t_lo); hipFree(m.w.t_cnt); hipFree(m.w.q_hits);
-  hipFree(m.w.q_seg); hipFree(m.w.q_kept); hipFree(m.w.q_cand); hipFree(m.w.q_acc); hipFree(m.w.q_pb); hipFree(m.w.c_in); hipFree(m.w.c_off); hipFree(m.w.t_idf); hipFree(m.w.c_qi); hipFree(m.big_list); m.big_list = nullptr; hipFree(m.contrast_list); m.contrast_list = nullptr;
+  hipFree(m.w.q_seg); hipFree(m.w.q_kept); hipFree(m.w.q_cand); hipFree(m.w.q_acc); hipFree(m.w.q_pb); hipFree(m.w.q_aux); hipFree(m.w.c_in); hipFree(m.w.c_off); hipFree(m.w.t_idf); hipFree(m.w.c_qi); hipFree(m.big_list); m.big_list = nullptr; hipFree(m.contrast_list); m.contrast_list = nullptr;
   hipFree(m.w.seg); hipFree(m.w.qb); hipFree(m.w.heap); hipFree(m.w.counters);
   hipFree(m.sc.keys); hipFree(m.sc.vals); hipFree(m.sc.f0); hipFree(m.sc.f1);
   hipFree(m.tile_sums); hipFree(m.grand_total); hipFree(m.w.q_cap);
@@ -177,6 +177,7 @@ static void ensure_ws(DeviceIndex::Impl& m, uint64_t nq, uint64_t nt, uint64_t s
     m.w.q_cand = dev_alloc<uint32_t>(cq);
     m.w.q_acc = dev_alloc<uint32_t>(cq);
     m.w.q_pb = dev_alloc<uint32_t>(cq);
+    m.w.q_aux = dev_alloc<uint32_t>(cq);
     m.w.c_in = dev_alloc<unsigned long long>(3 * (cq + 1));
     m.w.c_off = dev_alloc<unsigned long long>(3 * (cq + 1));
     m.w.t_idf = dev_alloc<float>(ct);
@@ -323,8 +324,24 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm_in, const D
                            d_out_total, m.contrast_list);
         if (prm.contrast > 0.f) {
           const uint32_t* cl = m.contrast_list;
-          hipLaunchKernelGGL(k_contrast<0>, dim3(b.nq), dim3(kWave), 0, stream, m.d, b, w, prm, m.sc, cap, d_out,
-                             d_out_count, d_out_total, cl);
+          if (prm.nmatch >= 1 && prm.nmatch <= kMaxFlatRounds) {
+            // flattened rounds: pick, then one edit distance per remaining accepted match of any query
+            const uint32_t n = b.nq + 1;
+            const uint32_t tiles = (n + kScanTile - 1) / kScanTile;
+            hipLaunchKernelGGL(k_cacc, dim3((n + 255) / 256), dim3(256), 0, stream, b, w);
+            hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(kScanThreads), 0, stream, w.c_in, w.c_off, m.tile_sums, n);
+            hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanThreads), 0, stream, m.tile_sums, tiles, m.grand_total);
+            hipLaunchKernelGGL(k_scan_add, dim3(tiles), dim3(kScanThreads), 0, stream, w.c_off, m.tile_sums, n);
+            hipLaunchKernelGGL(k_camap, dim3(b.nq), dim3(kWave), 0, stream, b, w, m.sc);
+            for (uint32_t r = 0; r < prm.nmatch; r++) {
+              if (r) hipLaunchKernelGGL(k_cdp, dim3(256 * 16), dim3(kWave), 0, stream, m.d, b, w, prm, m.sc, r);
+              hipLaunchKernelGGL(k_cpick, dim3(b.nq), dim3(kWave), 0, stream, b, w, prm, m.sc, r, cap, d_out, d_out_count,
+                                 d_out_total);
+            }
+          } else {
+            hipLaunchKernelGGL(k_contrast<0>, dim3(b.nq), dim3(kWave), 0, stream, m.d, b, w, prm, m.sc, cap, d_out,
+                               d_out_count, d_out_total, cl);
+          }
           if (m.d.max_slen > 32)
             hipLaunchKernelGGL(k_contrast<1>, dim3(2048), dim3(kWave), 0, stream, m.d, b, w, prm, m.sc, cap, d_out,
                                d_out_count, d_out_total, cl);

@@ -61,7 +61,8 @@ struct DevWork {
   uint32_t* q_kept;     // nq
   uint32_t* q_cand;     // nq
   uint32_t* q_acc;      // nq
-  uint32_t* q_pb;       // nq   hits that reached the token-touching phase of k_expand (statistics)
+  uint32_t* q_pb;       // nq   hits queued by k_expand_a for k_expand_b
+  uint32_t* q_aux;      // nq   contrastive rerank: the match picked last
   unsigned long long* c_in;    // 3 x (nq+1) candidates per query, one array per length class (scan input)
   unsigned long long* c_off;   // 3 x (nq+1) exclusive scans: dense per-class candidate lists
   unsigned long long* c_qi;    // seg_cap  (query << 32 | candidate index), dense per length class
@@ -1351,6 +1352,124 @@ __global__ void __launch_bounds__(kWave) k_contrast(DevIndex ix, DevBatch b, Dev
     }
     if (lane == 0) { out_count[gq] = cnt; if (out_total) out_total[gq] = tot; }
     __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Flattened contrastive rerank for the common case (every accepted sentence <= 32 tokens, 1 <= nmatch <=
+// kMaxFlatRounds): one k_cpick (a wave per query picks the first maximum of score - factor * penalty and
+// emits it) and one k_cdp (one lane per still-unpicked accepted match of ANY query computes its ids-only
+// edit distance to the match its query picked last) per round.  A per-query kernel would run the DP with a
+// handful of busy lanes; here every wave is full.  State per accepted match lives in the global scratch
+// (pen_sum = sc.f0, Match::penalty = sc.f1, taken flag | running max = sc.keys), indexed by segment slot.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t kMaxFlatRounds = 16;
+
+__global__ void k_cacc(DevBatch b, DevWork w) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q > b.nq) return;
+  unsigned long long v = 0;
+  if (q < b.nq && w.q_cand[q] != 0) {
+    const uint32_t acc = w.q_acc[q];
+    if (!(acc & 0x80000000u)) v = acc;
+  }
+  w.c_in[q] = v;
+}
+
+__global__ void __launch_bounds__(kWave) k_camap(DevBatch b, DevWork w, DevScratch sc) {
+  const uint32_t q = blockIdx.x;
+  if (w.q_cand[q] == 0) return;
+  const uint32_t acc = w.q_acc[q];
+  if (acc & 0x80000000u) return;
+  const unsigned long long base = w.c_off[q], seg0 = w.q_seg[q];
+  for (uint32_t k = lane_id(); k < acc; k += kWave) {
+    w.c_qi[base + k] = ((unsigned long long)q << 32) | k;
+    sc.f0[seg0 + k] = 0.f; sc.f1[seg0 + k] = 0.f; sc.keys[2ull * seg0 + k] = 0ull;
+  }
+}
+
+__global__ void __launch_bounds__(kWave) k_cpick(DevBatch b, DevWork w, Params prm, DevScratch sc, uint32_t round,
+                                                 uint32_t cap, Rec* out_rec, uint32_t* out_count, uint32_t* out_total) {
+  const uint32_t q = blockIdx.x;
+  const uint32_t lane = lane_id();
+  if (w.q_cand[q] == 0) return;  // k_finish wrote the empty result
+  const uint32_t n = w.q_acc[q];
+  if (n & 0x80000000u) return;   // queued for a wide k_contrast kernel
+  const uint32_t gq = b.q_begin + q;
+  const uint32_t want = prm.nmatch < n ? prm.nmatch : n;
+  if (n == 0 && round == 0 && lane == 0) { out_count[gq] = 0; if (out_total) out_total[gq] = 0; }
+  if (round >= want) return;
+  const unsigned long long seg0 = w.q_seg[q];
+  const Cand* seg = w.seg + seg0;
+  unsigned long long* keys = sc.keys + 2ull * seg0;
+  const float* pen_cur = sc.f1 + seg0;
+  // std::max_element over the remaining list (score desc, s_id asc): first maximum of score - factor * penalty
+  float best_key = 0.f, best_score = 0.f;
+  uint32_t best_sid = 0;
+  int best = -1;
+  auto better = [](float key, float score, uint32_t sid, float bkey, float bscore, uint32_t bsid) {
+    return bkey < key || (bkey == key && (bscore < score || (bscore == score && sid < bsid)));
+  };
+  for (uint32_t k = lane; k < n; k += kWave) {
+    if (keys[k] >> 63) continue;
+    const Cand c = seg[k];
+    const float key = c.score - (prm.contrast * pen_cur[k]);
+    if (best < 0 || better(key, c.score, c.sid, best_key, best_score, best_sid)) {
+      best = (int)k; best_key = key; best_score = c.score; best_sid = c.sid;
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const float ok = __shfl_xor(best_key, d, 64);
+    const float os = __shfl_xor(best_score, d, 64);
+    const uint32_t oi = __shfl_xor(best_sid, d, 64);
+    const int   ob = __shfl_xor(best, d, 64);
+    if (ob >= 0 && (best < 0 || better(ok, os, oi, best_key, best_score, best_sid))) {
+      best = ob; best_key = ok; best_score = os; best_sid = oi;
+    }
+  }
+  if (lane == 0) {
+    if (round < cap) {
+      const Cand c = seg[best];
+      Rec r;
+      r.score = c.score; r.penalty = pen_cur[best]; r.max_subseq = (int32_t)c.longest; r.s_id = c.sid;
+      out_rec[(unsigned long long)gq * cap + round] = r;
+    }
+    keys[best] |= 1ull << 63;
+    w.q_aux[q] = (uint32_t)best;
+    if (round + 1 == want) { out_count[gq] = want < cap ? want : cap; if (out_total) out_total[gq] = want; }
+  }
+}
+
+__global__ void __launch_bounds__(kWave) k_cdp(DevIndex ix, DevBatch b, DevWork w, Params prm, DevScratch sc,
+                                               uint32_t round) {
+  const uint32_t lane = lane_id();
+  const unsigned long long total = w.c_off[b.nq];
+  for (unsigned long long j = (unsigned long long)blockIdx.x * kWave + lane; j < total;
+       j += (unsigned long long)gridDim.x * kWave) {
+    const unsigned long long qi = w.c_qi[j];
+    const uint32_t q = (uint32_t)(qi >> 32), k = (uint32_t)qi;
+    const uint32_t n = w.q_acc[q];
+    const uint32_t want = prm.nmatch < n ? prm.nmatch : n;
+    if (round >= want) continue;  // this query has emitted everything it will emit
+    const unsigned long long seg0 = w.q_seg[q];
+    unsigned long long* keys = sc.keys + 2ull * seg0;
+    if (keys[k] >> 63) continue;
+    const Cand* seg = w.seg + seg0;
+    const uint32_t msp = ix.sent_pos[seg[w.q_aux[q]].sid];
+    const uint32_t n2 = ix.tok[msp];
+    const uint32_t csp = ix.sent_pos[seg[k].sid];
+    const uint32_t n1 = ix.tok[csp];
+    const float dw = 100.f / normalizer(n1, n2, 1.f, 1.f, 1.f);
+    float M;
+    const float ed = edit_distance_reg<32>(ix.tok + csp + 1, n1, ix.tok + msp + 1, n2, 1.f, 1.f, 1.f, dw, M);
+    const float pen = score_from_cost(ed);
+    const float sum = sc.f0[seg0 + k] + pen;
+    sc.f0[seg0 + k] = sum;
+    float mx = __uint_as_float((uint32_t)(keys[k] & 0xffffffffull));
+    mx = (round == 1) ? pen : (mx < pen ? pen : mx);
+    keys[k] = (unsigned long long)__float_as_uint(mx);
+    sc.f1[seg0 + k] = prm.reduce == 1 ? mx : (sum / (float)round);
   }
 }
 
