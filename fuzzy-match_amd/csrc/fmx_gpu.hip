@@ -329,12 +329,19 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm_in, const D
             const uint32_t n = b.nq + 1;
             const uint32_t tiles = (n + kScanTile - 1) / kScanTile;
             hipLaunchKernelGGL(k_cacc, dim3((n + 255) / 256), dim3(256), 0, stream, b, w);
-            hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(kScanThreads), 0, stream, w.c_in, w.c_off, m.tile_sums, n);
-            hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanThreads), 0, stream, m.tile_sums, tiles, m.grand_total);
-            hipLaunchKernelGGL(k_scan_add, dim3(tiles), dim3(kScanThreads), 0, stream, w.c_off, m.tile_sums, n);
+            for (int c = 0; c < 2; c++) {
+              hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(kScanThreads), 0, stream, w.c_in + (size_t)c * n,
+                                 w.c_off + (size_t)c * n, m.tile_sums, n);
+              hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanThreads), 0, stream, m.tile_sums, tiles, m.grand_total);
+              hipLaunchKernelGGL(k_scan_add, dim3(tiles), dim3(kScanThreads), 0, stream, w.c_off + (size_t)c * n, m.tile_sums, n);
+            }
             hipLaunchKernelGGL(k_camap, dim3(b.nq), dim3(kWave), 0, stream, b, w, m.sc);
             for (uint32_t r = 0; r < prm.nmatch; r++) {
-              if (r) hipLaunchKernelGGL(k_cdp, dim3(256 * 16), dim3(kWave), 0, stream, m.d, b, w, prm, m.sc, r);
+              if (r) {
+                hipLaunchKernelGGL(k_cdp<32>, dim3(256 * 16), dim3(kWave), 0, stream, m.d, b, w, prm, m.sc, r);
+                if (m.d.max_slen > 32)
+                  hipLaunchKernelGGL(k_cdp<64>, dim3(256 * 8), dim3(kWave), 0, stream, m.d, b, w, prm, m.sc, r);
+              }
               hipLaunchKernelGGL(k_cpick, dim3(b.nq), dim3(kWave), 0, stream, b, w, prm, m.sc, r, cap, d_out, d_out_count,
                                  d_out_total);
             }
@@ -342,7 +349,8 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm_in, const D
             hipLaunchKernelGGL(k_contrast<0>, dim3(b.nq), dim3(kWave), 0, stream, m.d, b, w, prm, m.sc, cap, d_out,
                                d_out_count, d_out_total, cl);
           }
-          if (m.d.max_slen > 32)
+          const bool flat = prm.nmatch >= 1 && prm.nmatch <= kMaxFlatRounds;
+          if (m.d.max_slen > 32 && !flat)
             hipLaunchKernelGGL(k_contrast<1>, dim3(2048), dim3(kWave), 0, stream, m.d, b, w, prm, m.sc, cap, d_out,
                                d_out_count, d_out_total, cl);
           if (m.d.max_slen > 64) {

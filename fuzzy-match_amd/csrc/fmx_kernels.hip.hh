@@ -1300,7 +1300,7 @@ __global__ void __launch_bounds__(kWave) k_finish(DevIndex ix, DevBatch b, DevWo
       if (contrast && n != 0 && mx > 32) {
         const uint32_t cls = mx <= 64 ? 1u : 2u;
         contrast_list[(size_t)(cls - 1) * b.nq + atomicAdd(&w.counters[9 + cls], 1ull)] = q;
-        w.q_acc[q] = n | 0x80000000u;  // not for k_contrast<0>
+        w.q_acc[q] = n | (cls << 30);  // length class of the accepted sentences (0: <= 32, 1: <= 64, 2: longer)
       }
     }
     if (n != 0 && !contrast) {
@@ -1338,8 +1338,8 @@ __global__ void __launch_bounds__(kWave) k_contrast(DevIndex ix, DevBatch b, Dev
     const uint32_t gq = b.q_begin + q;
     if (w.q_cand[q] == 0) continue;  // k_finish already wrote an empty result
     const uint32_t acc = w.q_acc[q];
-    if (MODE == 0 && (acc & 0x80000000u)) continue;  // queued for a wider kernel
-    const uint32_t n = acc & 0x7fffffffu;
+    if (MODE == 0 && (acc >> 30)) continue;  // queued for a wider kernel
+    const uint32_t n = acc & 0x3fffffffu;
     const unsigned long long seg0 = w.q_seg[q];
     const Cand* seg = w.seg + seg0;
     Rec* out = out_rec + (unsigned long long)gq * cap;
@@ -1365,24 +1365,33 @@ __global__ void __launch_bounds__(kWave) k_contrast(DevIndex ix, DevBatch b, Dev
 // ---------------------------------------------------------------------------------------------
 constexpr uint32_t kMaxFlatRounds = 16;
 
+// flat_cls_max: highest length class handled by the flattened path (1 normally; 0 when class 1 is left to
+// k_contrast<1>)
 __global__ void k_cacc(DevBatch b, DevWork w) {
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q > b.nq) return;
-  unsigned long long v = 0;
+  unsigned long long v[2] = {0, 0};
   if (q < b.nq && w.q_cand[q] != 0) {
     const uint32_t acc = w.q_acc[q];
-    if (!(acc & 0x80000000u)) v = acc;
+    const uint32_t cls = acc >> 30;
+    if (cls < 2) v[cls] = acc & 0x3fffffffu;
   }
-  w.c_in[q] = v;
+  const size_t stride = (size_t)b.nq + 1;
+  w.c_in[q] = v[0];
+  w.c_in[stride + q] = v[1];
 }
 
 __global__ void __launch_bounds__(kWave) k_camap(DevBatch b, DevWork w, DevScratch sc) {
   const uint32_t q = blockIdx.x;
   if (w.q_cand[q] == 0) return;
   const uint32_t acc = w.q_acc[q];
-  if (acc & 0x80000000u) return;
-  const unsigned long long base = w.c_off[q], seg0 = w.q_seg[q];
-  for (uint32_t k = lane_id(); k < acc; k += kWave) {
+  const uint32_t cls = acc >> 30, n = acc & 0x3fffffffu;
+  if (cls >= 2) return;
+  const size_t stride = (size_t)b.nq + 1;
+  unsigned long long base = w.c_off[cls * stride + q];
+  if (cls == 1) base += w.c_off[b.nq];
+  const unsigned long long seg0 = w.q_seg[q];
+  for (uint32_t k = lane_id(); k < n; k += kWave) {
     w.c_qi[base + k] = ((unsigned long long)q << 32) | k;
     sc.f0[seg0 + k] = 0.f; sc.f1[seg0 + k] = 0.f; sc.keys[2ull * seg0 + k] = 0ull;
   }
@@ -1393,8 +1402,9 @@ __global__ void __launch_bounds__(kWave) k_cpick(DevBatch b, DevWork w, Params p
   const uint32_t q = blockIdx.x;
   const uint32_t lane = lane_id();
   if (w.q_cand[q] == 0) return;  // k_finish wrote the empty result
-  const uint32_t n = w.q_acc[q];
-  if (n & 0x80000000u) return;   // queued for a wide k_contrast kernel
+  const uint32_t acc = w.q_acc[q];
+  if ((acc >> 30) >= 2) return;  // queued for k_contrast<2>
+  const uint32_t n = acc & 0x3fffffffu;
   const uint32_t gq = b.q_begin + q;
   const uint32_t want = prm.nmatch < n ? prm.nmatch : n;
   if (n == 0 && round == 0 && lane == 0) { out_count[gq] = 0; if (out_total) out_total[gq] = 0; }
@@ -1441,15 +1451,18 @@ __global__ void __launch_bounds__(kWave) k_cpick(DevBatch b, DevWork w, Params p
   }
 }
 
+template <int P>
 __global__ void __launch_bounds__(kWave) k_cdp(DevIndex ix, DevBatch b, DevWork w, Params prm, DevScratch sc,
                                                uint32_t round) {
   const uint32_t lane = lane_id();
-  const unsigned long long total = w.c_off[b.nq];
-  for (unsigned long long j = (unsigned long long)blockIdx.x * kWave + lane; j < total;
+  const size_t stride = (size_t)b.nq + 1;
+  const unsigned long long t0 = w.c_off[b.nq], t1 = w.c_off[stride + b.nq];
+  const unsigned long long j_lo = P == 32 ? 0ull : t0, j_hi = P == 32 ? t0 : t0 + t1;
+  for (unsigned long long j = j_lo + (unsigned long long)blockIdx.x * kWave + lane; j < j_hi;
        j += (unsigned long long)gridDim.x * kWave) {
     const unsigned long long qi = w.c_qi[j];
     const uint32_t q = (uint32_t)(qi >> 32), k = (uint32_t)qi;
-    const uint32_t n = w.q_acc[q];
+    const uint32_t n = w.q_acc[q] & 0x3fffffffu;
     const uint32_t want = prm.nmatch < n ? prm.nmatch : n;
     if (round >= want) continue;  // this query has emitted everything it will emit
     const unsigned long long seg0 = w.q_seg[q];
@@ -1462,7 +1475,7 @@ __global__ void __launch_bounds__(kWave) k_cdp(DevIndex ix, DevBatch b, DevWork 
     const uint32_t n1 = ix.tok[csp];
     const float dw = 100.f / normalizer(n1, n2, 1.f, 1.f, 1.f);
     float M;
-    const float ed = edit_distance_reg<32>(ix.tok + csp + 1, n1, ix.tok + msp + 1, n2, 1.f, 1.f, 1.f, dw, M);
+    const float ed = edit_distance_reg<P>(ix.tok + csp + 1, n1, ix.tok + msp + 1, n2, 1.f, 1.f, 1.f, dw, M);
     const float pen = score_from_cost(ed);
     const float sum = sc.f0[seg0 + k] + pen;
     sc.f0[seg0 + k] = sum;
