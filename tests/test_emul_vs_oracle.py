@@ -56,3 +56,29 @@ def test_emul_dense_edge_cases(fmx, seed):
         oo, oc = o.match_batch(oracle_lib.Params(**kw), q_off, q_tok, cap, nthreads=2)
         eo, ec, _ = em.match_batch(fmx.Params(**kw), q_off, q_tok, cap=cap)
         workloads.compare(oo, oc, eo, ec, f"{name}/seed{seed}")
+
+
+def test_emul_tm1_fixture_full_cost_model(fmx):
+    """The reference's test-tm1 fixture through the emulated pipeline: real-token, case, number and
+    penalty-token costs (edit_distance<true>), with the interned ids the C ABI hands to the kernels."""
+    import os
+    import fmi_reader
+    import golden_util
+    path = os.path.join(golden_util.GOLDEN, "tm1.fmi")
+    ix = fmx.Index.load(path)
+    ix.finalize()
+    d = fmi_reader.read_fmi(path)
+    for case in golden_util.tm1_cases():
+        wids = ix.vocab_lookup(case["norm"])
+        p = len(wids)
+        q_real = np.asarray([ix.lookup_real(r) for r in case["real"]], np.uint32)
+        q_itok = np.zeros(p + 1, np.uint32)
+        for k, v in case["itoks"].items():
+            q_itok[k] = ix.intern_itok(v)
+        prm = fmx.Params(fuzzy=case["fuzzy"], nmatch=case["nmatch"], no_perfect=case["no_perfect"],
+                         min_subseq_length=2, min_subseq_ratio=0)
+        cap = case["nmatch"] or 16
+        eo, ec, _ = emul_lib.Emul(ix).match_batch(prm, np.asarray([0, p], np.uint32), wids, q_real=q_real, q_itok=q_itok,
+                                                  cap=cap)
+        n = int(ec[0])
+        golden_util.check_tm1_case(case, list(eo[0, :n]["score"]), [d["ids"][s] for s in eo[0, :n]["s_id"]])

@@ -1,0 +1,118 @@
+"""Full-size checks (BASELINE config C2: 1 M-sentence corpus, 100 k queries) through size-independent
+properties, plus an oracle sample.  Runs in a few seconds on an MI355X (the index is sorted on the GPU)."""
+import numpy as np
+import pytest
+
+import oracle_lib
+import workloads
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def c2(fmx, gpu_device):
+    c_off, c_tok, q_off, q_tok, vs = workloads.synthetic(1_000_000, 100_000, 20)
+    ix = fmx.Index.create()
+    ix.add_ids(c_off, c_tok, vs)
+    ix.sort(gpu_device)
+    ix.finalize()
+    ix.to_device(gpu_device)
+    return ix, c_off, c_tok, q_off, q_tok, vs
+
+
+def _csr_take(off, tok, idx):
+    lens = (off[1:] - off[:-1])[idx]
+    new_off = np.zeros(len(idx) + 1, np.uint32)
+    new_off[1:] = np.cumsum(lens)
+    parts = [tok[off[i]:off[i + 1]] for i in idx]
+    return new_off, (np.concatenate(parts) if parts else np.zeros(0, np.uint32)).astype(np.uint32)
+
+
+def test_suffix_array_is_sorted_and_complete(c2):
+    """Every suffix appears once and adjacent suffixes are in SuffixArray::comp order (sampled)."""
+    ix, c_off, c_tok, *_ = c2
+    sid, pos = ix.array("suf_sid"), ix.array("suf_pos")
+    assert len(sid) == len(c_tok)
+    key = sid.astype(np.uint64) << np.uint64(16) | pos.astype(np.uint64)
+    assert len(np.unique(key)) == len(key)
+    buf, sp = ix.array("buffer"), ix.array("sent_pos")
+    rng = np.random.default_rng(0)
+    for i in rng.integers(0, len(sid) - 1, size=20000):
+        a = buf[sp[sid[i]] + pos[i]: sp[sid[i]] + 1 + buf[sp[sid[i]]]]
+        b = buf[sp[sid[i + 1]] + pos[i + 1]: sp[sid[i + 1]] + 1 + buf[sp[sid[i + 1]]]]
+        n = min(len(a), len(b))
+        d = np.nonzero(a[:n] != b[:n])[0]
+        if len(d):
+            assert a[d[0]] < b[d[0]]
+        elif len(a) != len(b):
+            assert len(a) < len(b)
+        else:
+            assert sid[i] < sid[i + 1]
+
+
+def test_indexed_sentences_match_themselves(fmx, c2):
+    """A pattern that is an indexed sentence has that sentence (or an identical one) as a score-1 match."""
+    ix, c_off, c_tok, *_ = c2
+    rng = np.random.default_rng(1)
+    idx = rng.integers(0, len(c_off) - 1, size=20000)
+    q_off, q_tok = _csr_take(c_off, c_tok, idx)
+    out, cnt, _ = ix.match_batch(fmx.Params(fuzzy=1.0, nmatch=1), q_off, q_tok, cap=1)
+    assert (cnt == 1).all()
+    assert (out[:, 0]["score"] == 1.0).all()
+    hit = out[:, 0]["s_id"]
+    for k in rng.integers(0, len(idx), size=2000):
+        a = c_tok[c_off[idx[k]]:c_off[idx[k] + 1]]
+        b = c_tok[c_off[hit[k]]:c_off[hit[k] + 1]]
+        assert np.array_equal(a, b) and hit[k] <= idx[k]  # ties go to the smaller s_id
+
+
+def test_batch_permutation_and_sub_batching_invariance(fmx, c2):
+    """Results are a function of the pattern alone: shuffling the batch, or cutting it into tiny
+    sub-batches with a tiny hit workspace, permutes / leaves the records unchanged."""
+    ix, _, _, q_off, q_tok, _ = c2
+    prm = fmx.Params(fuzzy=0.7, nmatch=5)
+    base_out, base_cnt, _ = ix.match_batch(prm, q_off, q_tok, cap=5)
+    again_out, again_cnt, _ = ix.match_batch(prm, q_off, q_tok, cap=5)
+    assert np.array_equal(base_cnt, again_cnt) and base_out.tobytes() == again_out.tobytes()  # idempotent
+    perm = np.random.default_rng(2).permutation(len(base_cnt))
+    p_off, p_tok = _csr_take(q_off, q_tok, perm)
+    ix.set_option("sub_queries", 4099)
+    try:
+        p_out, p_cnt, _ = ix.match_batch(prm, p_off, p_tok, cap=5)
+    finally:
+        ix.set_option("sub_queries", 1 << 17)
+    assert np.array_equal(p_cnt, base_cnt[perm])
+    for k in range(len(perm)):
+        n = int(p_cnt[k])
+        assert p_out[k, :n].tobytes() == base_out[perm[k], :n].tobytes()
+
+
+def test_threshold_monotonicity_and_order(fmx, c2):
+    """Raising the threshold can only remove matches; matches come sorted by (score desc, s_id asc)."""
+    ix, _, _, q_off, q_tok, _ = c2
+    lo_out, lo_cnt, _ = ix.match_batch(fmx.Params(fuzzy=0.6, nmatch=0), q_off[:20001], q_tok[:int(q_off[20000])], cap=64)
+    hi_out, hi_cnt, _ = ix.match_batch(fmx.Params(fuzzy=0.8, nmatch=0), q_off[:20001], q_tok[:int(q_off[20000])], cap=64)
+    assert (hi_cnt <= lo_cnt).all()
+    for q in range(20000):
+        n = int(lo_cnt[q])
+        s, i = lo_out[q, :n]["score"], lo_out[q, :n]["s_id"]
+        assert (s >= np.float32(0.6)).all()
+        assert all((s[k] > s[k + 1]) or (s[k] == s[k + 1] and i[k] < i[k + 1]) for k in range(n - 1))
+        m = int(hi_cnt[q])
+        hs = set(hi_out[q, :m]["s_id"].tolist())
+        assert hs <= set(i.tolist()) or n == 64
+
+
+def test_oracle_sample_at_scale(fmx, c2):
+    """3000 of the 100 k queries against the oracle on the full 1 M-sentence index, every BASELINE parameter set."""
+    ix, c_off, c_tok, q_off, q_tok, vs = c2
+    o = oracle_lib.OracleIndex()
+    o.set_arrays(ix.array("suf_sid"), ix.array("suf_pos"), ix.array("buffer"), ix.array("sent_pos"), ix.array("qva"),
+                 ix.array("sfreq"))
+    n = 3000
+    so, st = q_off[:n + 1], q_tok[:int(q_off[n])]
+    for name in ["C3", "C4", "C5"]:
+        kw = workloads.PARAM_SETS[name]
+        oo, oc = o.match_batch(oracle_lib.Params(**kw), so, st, 5, nthreads=oracle_lib.effective_cpus())
+        go, gc, _ = ix.match_batch(fmx.Params(**kw), so, st, cap=5)
+        workloads.compare(oo, oc, go, gc, name)
