@@ -67,6 +67,8 @@ struct DeviceIndex::Impl {
   unsigned long long* tile_sums = nullptr;
   unsigned long long* grand_total = nullptr;
   uint32_t* big_list = nullptr;
+  uint32_t* mid_list = nullptr;
+  uint32_t* fin_list = nullptr;
   uint32_t* contrast_list = nullptr;  // 2 x cap_q
   WorkItem* items = nullptr;
   WorkItem* items_b = nullptr;
@@ -88,7 +90,7 @@ DeviceIndex::DeviceIndex() : impl_(new Impl) {}
 
 static void free_ws(DeviceIndex::Impl& m) {
   hipFree(m.w.q_m); hipFree(m.w.t_q); hipFree(m.w.t_lo); hipFree(m.w.t_cnt); hipFree(m.w.q_hits);
-  hipFree(m.w.q_seg); hipFree(m.w.q_kept); hipFree(m.w.q_cand); hipFree(m.w.q_acc); hipFree(m.w.q_pb); hipFree(m.w.q_aux); hipFree(m.w.c_in); hipFree(m.w.c_off); hipFree(m.w.t_idf); hipFree(m.w.c_qi); hipFree(m.big_list); m.big_list = nullptr; hipFree(m.contrast_list); m.contrast_list = nullptr;
+  hipFree(m.w.q_seg); hipFree(m.w.q_kept); hipFree(m.w.q_cand); hipFree(m.w.q_acc); hipFree(m.w.q_pb); hipFree(m.w.q_aux); hipFree(m.w.c_in); hipFree(m.w.c_off); hipFree(m.w.t_idf); hipFree(m.w.c_qi); hipFree(m.big_list); m.big_list = nullptr; hipFree(m.mid_list); m.mid_list = nullptr; hipFree(m.fin_list); m.fin_list = nullptr; hipFree(m.contrast_list); m.contrast_list = nullptr;
   hipFree(m.w.seg); hipFree(m.w.qb); hipFree(m.w.heap); hipFree(m.w.counters);
   hipFree(m.sc.keys); hipFree(m.sc.vals); hipFree(m.sc.f0); hipFree(m.sc.f1);
   hipFree(m.tile_sums); hipFree(m.grand_total); hipFree(m.w.q_cap);
@@ -183,6 +185,8 @@ static void ensure_ws(DeviceIndex::Impl& m, uint64_t nq, uint64_t nt, uint64_t s
     m.w.t_idf = dev_alloc<float>(ct);
     m.w.c_qi = dev_alloc<unsigned long long>(cs);
     m.big_list = dev_alloc<uint32_t>(cq);
+    m.mid_list = dev_alloc<uint32_t>(cq);
+    m.fin_list = dev_alloc<uint32_t>(cq);
     m.contrast_list = dev_alloc<uint32_t>(2 * cq);
     m.w.seg = dev_alloc<Cand>(cs);
     m.w.qb = dev_alloc<QHit>(cs);
@@ -266,7 +270,8 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm_in, const D
                            (const WorkItem*)m.items_b, m.item_cap);
       }
       tick(); tick();
-      hipLaunchKernelGGL(k_cand, dim3(b.nq), dim3(kWave), 0, stream, w, m.big_list);
+      hipLaunchKernelGGL(k_cand, dim3((b.nq + 3) / 4), dim3(256), 0, stream, b, w, m.big_list, m.mid_list);
+      hipLaunchKernelGGL(k_cand_mid, dim3(2048), dim3(kWave), 0, stream, w, (const uint32_t*)m.mid_list);
       tick(); tick();
       {
         // radix passes needed: sentence ids < n_sent, match lengths <= longest pattern
@@ -320,8 +325,10 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm_in, const D
       }
       tick(); tick();
       {
-        hipLaunchKernelGGL(k_finish, dim3(b.nq), dim3(kWave), 0, stream, m.d, b, w, prm, m.sc, cap, d_out, d_out_count,
-                           d_out_total, m.contrast_list);
+        hipLaunchKernelGGL((k_finish<64, false>), dim3(b.nq), dim3(kWave), 0, stream, m.d, b, w, prm, m.sc, cap, d_out,
+                           d_out_count, d_out_total, m.contrast_list, m.fin_list);
+        hipLaunchKernelGGL((k_finish<kLdsSortMax, true>), dim3(2048), dim3(kWave), 0, stream, m.d, b, w, prm, m.sc, cap,
+                           d_out, d_out_count, d_out_total, m.contrast_list, m.fin_list);
         if (prm.contrast > 0.f) {
           const uint32_t* cl = m.contrast_list;
           if (prm.nmatch >= 1 && prm.nmatch <= kMaxFlatRounds) {

@@ -75,6 +75,7 @@ struct DevWork {
                                  // segment overflowed [5]=extra work items [6]=segment space needed
                                  // [7]=queries queued for k_cand_big [8]=phase-B hits [9]=max kept
                                  // [10],[11]=queries queued for k_contrast<1>, <2> [12]=extra k_expand_b items
+                                 // [13]=queries queued for k_cand_mid [14]=queries queued for the large k_finish
 };
 
 constexpr int kWave = 64;
@@ -113,8 +114,10 @@ __global__ void k_setup(DevIndex ix, DevBatch b, DevWork w, Params prm) {
   for (uint32_t k = 0; k < p; k++) {
     w.t_q[o0 - b.t_begin + k] = q;
     // compute_idf_penalty — src/fuzzy_match.cc:381-387 (UNK and out-of-vocabulary ids -> 0)
-    const uint32_t wd = b.q_tok[o0 + k];
-    w.t_idf[o0 - b.t_begin + k] = (use_idf && wd + 1 < ix.n_qva && wd != 1u) ? ix.idf[wd] : 0.f;
+    if (use_idf) {
+      const uint32_t wd = b.q_tok[o0 + k];
+      w.t_idf[o0 - b.t_begin + k] = (wd + 1 < ix.n_qva && wd != 1u) ? ix.idf[wd] : 0.f;
+    }
   }
 }
 
@@ -728,10 +731,29 @@ __device__ __forceinline__ uint32_t cand_body(unsigned long long* keys, Cand* se
   return kept;
 }
 
-__global__ void __launch_bounds__(kWave) k_cand(DevWork w, uint32_t* big_list) {
-  __shared__ unsigned long long s_keys[kLdsSortMax];
-  __shared__ uint32_t s_count;
-  const uint32_t q = blockIdx.x;
+// ascending sort of one 64-bit key per lane across the wave: bitonic network on shuffles, no LDS, no barrier
+__device__ __forceinline__ unsigned long long wave_sort64(unsigned long long key) {
+  const uint32_t lane = lane_id();
+#pragma unroll
+  for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const uint32_t lo = __shfl_xor((uint32_t)key, j, 64), hi = __shfl_xor((uint32_t)(key >> 32), j, 64);
+      const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+      const bool take_min = ((lane & k) == 0) == ((lane & j) == 0);
+      const unsigned long long mn = key < other ? key : other, mx = key < other ? other : key;
+      key = take_min ? mn : mx;
+    }
+  }
+  return key;
+}
+
+// k_cand — four queries per 256-thread workgroup, one wave each.  Up to 64 survivors (the common case: the
+// coverage bound has already run) are de-duplicated and ordered entirely in registers; 65..1024 are queued
+// for k_cand_mid (LDS bitonic), more for k_cand_big (block radix sort).
+__global__ void __launch_bounds__(256) k_cand(DevBatch b, DevWork w, uint32_t* big_list, uint32_t* mid_list) {
+  const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= b.nq) return;
   const uint32_t lane = lane_id();
   const uint32_t n = w.q_kept[q];
   if (n == 0) {
@@ -742,13 +764,46 @@ __global__ void __launch_bounds__(kWave) k_cand(DevWork w, uint32_t* big_list) {
     if (lane == 0) { w.q_cand[q] = 0; atomicMax(&w.counters[4], (unsigned long long)n); }
     return;
   }
-  const uint32_t np2 = next_pow2(n);
-  if (np2 > kLdsSortMax) {  // queue for the 1024-thread kernel
-    if (lane == 0) { w.q_cand[q] = 0; big_list[atomicAdd(&w.counters[7], 1ull)] = q; }
+  if (n > kWave) {
+    if (lane == 0) {
+      w.q_cand[q] = 0;
+      if (n > kLdsSortMax) big_list[atomicAdd(&w.counters[7], 1ull)] = q;
+      else mid_list[atomicAdd(&w.counters[13], 1ull)] = q;
+    }
     return;
   }
-  const uint32_t kept = cand_body(s_keys, w.seg + w.q_seg[q], n, np2, &s_count);
+  Cand* seg = w.seg + w.q_seg[q];
+  unsigned long long key = ~0ull;
+  if (lane < n) key = ((unsigned long long)seg[lane].sid << 16) | (seg[lane].longest & 0xffffu);
+  key = wave_sort64(key);
+  // keep the last entry of each sentence group (its largest L); rewrite as (0xffff - L, sid)
+  const uint32_t nlo = __shfl_down((uint32_t)key, 1, 64), nhi = __shfl_down((uint32_t)(key >> 32), 1, 64);
+  const unsigned long long nxt = lane == 63 ? ~0ull : (((unsigned long long)nhi << 32) | nlo);
+  const bool keep = lane < n && (nxt >> 16) != (key >> 16);
+  unsigned long long k2 = keep ? (((unsigned long long)(0xffffu - (uint32_t)(key & 0xffffu)) << 32) | (key >> 16)) : ~0ull;
+  const uint32_t kept = __popcll(__ballot(keep));
+  k2 = wave_sort64(k2);
+  if (lane < kept) {
+    Cand c;
+    c.sid = (uint32_t)(k2 & 0xffffffffu);
+    c.longest = 0xffffu - (uint32_t)(k2 >> 32);
+    c.score = 0.f; c.penalty = 0.f;
+    seg[lane] = c;
+  }
   if (lane == 0) w.q_cand[q] = kept;
+}
+
+__global__ void __launch_bounds__(kWave) k_cand_mid(DevWork w, const uint32_t* mid_list) {
+  __shared__ unsigned long long s_keys[kLdsSortMax];
+  __shared__ uint32_t s_count;
+  const unsigned long long n_mid = w.counters[13];
+  for (unsigned long long idx = blockIdx.x; idx < n_mid; idx += gridDim.x) {
+    const uint32_t q = mid_list[idx];
+    const uint32_t n = w.q_kept[q];
+    const uint32_t kept = cand_body(s_keys, w.seg + w.q_seg[q], n, next_pow2(n), &s_count);
+    if (lane_id() == 0) w.q_cand[q] = kept;
+    __syncthreads();
+  }
 }
 
 constexpr int kBigThreads = 1024;
@@ -1272,47 +1327,59 @@ __device__ __forceinline__ void select_body(const DevIndex& ix, const Params& pr
   out_total = picked;
 }
 
+// LIST = false: one wave per query of the sub-batch, handles the queries with at most 64 candidates (tiny
+// LDS footprint -> full occupancy) and queues the others; LIST = true: grid-stride over that queue with
+// the large LDS sorter.
+template <uint32_t SORT_CAP, bool LIST>
 __global__ void __launch_bounds__(kWave) k_finish(DevIndex ix, DevBatch b, DevWork w, Params prm, DevScratch sc,
                                                   uint32_t cap, Rec* out_rec, uint32_t* out_count,
-                                                  uint32_t* out_total, uint32_t* contrast_list) {
-  __shared__ unsigned long long s_keys[kLdsSortMax];
-  __shared__ uint32_t s_vals[kLdsSortMax];
+                                                  uint32_t* out_total, uint32_t* contrast_list, uint32_t* fin_list) {
+  __shared__ unsigned long long s_keys[SORT_CAP];
+  __shared__ uint32_t s_vals[SORT_CAP];
   __shared__ ReplayShared sh;
   __shared__ float s_heap[kHeapLdsMax + 2];
-  const uint32_t q = blockIdx.x;
   const uint32_t lane = lane_id();
-  const uint32_t gq = b.q_begin + q;
-  const uint32_t n_cand = w.q_cand[q];
-  Rec* out = out_rec + (unsigned long long)gq * cap;
-  uint32_t cnt = 0, tot = 0;
   const bool contrast = prm.contrast > 0.f;
-  if (n_cand != 0) {
-    const unsigned long long seg0 = w.q_seg[q];
-    Cand* seg = w.seg + seg0;
-    const uint32_t p = b.q_off[gq + 1] - b.q_off[gq];
-    uint32_t n, mx;
-    if (prm.cbuf > 0 && prm.cbuf <= (int)kHeapLdsMax) n = replay_body(prm, p, n_cand, seg, s_heap, sh, mx);
-    else n = replay_body(prm, p, n_cand, seg, w.heap + seg0 + q, sh, mx);
-    if (lane == 0) {
-      w.q_acc[q] = n;
-      // contrastive rerank: queries whose accepted sentences are longer than 32 / 64 tokens are queued for the
-      // wider kernels; everything else is done by k_contrast<0> in place
-      if (contrast && n != 0 && mx > 32) {
-        const uint32_t cls = mx <= 64 ? 1u : 2u;
-        contrast_list[(size_t)(cls - 1) * b.nq + atomicAdd(&w.counters[9 + cls], 1ull)] = q;
-        w.q_acc[q] = n | (cls << 30);  // length class of the accepted sentences (0: <= 32, 1: <= 64, 2: longer)
+  const unsigned long long n_items = LIST ? w.counters[14] : (unsigned long long)b.nq;
+  for (unsigned long long item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const uint32_t q = LIST ? fin_list[item] : (uint32_t)item;
+    const uint32_t gq = b.q_begin + q;
+    const uint32_t n_cand = w.q_cand[q];
+    if (!LIST && n_cand > kWave) {  // needs the large sorter / multi-chunk replay
+      if (lane == 0) fin_list[atomicAdd(&w.counters[14], 1ull)] = q;
+      continue;
+    }
+    Rec* out = out_rec + (unsigned long long)gq * cap;
+    uint32_t cnt = 0, tot = 0;
+    if (n_cand != 0) {
+      const unsigned long long seg0 = w.q_seg[q];
+      Cand* seg = w.seg + seg0;
+      const uint32_t p = b.q_off[gq + 1] - b.q_off[gq];
+      uint32_t n, mx;
+      if (prm.cbuf > 0 && prm.cbuf <= (int)kHeapLdsMax) n = replay_body(prm, p, n_cand, seg, s_heap, sh, mx);
+      else n = replay_body(prm, p, n_cand, seg, w.heap + seg0 + q, sh, mx);
+      if (lane == 0) {
+        w.q_acc[q] = n;
+        // contrastive rerank: queries whose accepted sentences are longer than 32 / 64 tokens are queued for the
+        // wider kernels; everything else is done by k_contrast<0> in place
+        if (contrast && n != 0 && mx > 32) {
+          const uint32_t cls = mx <= 64 ? 1u : 2u;
+          contrast_list[(size_t)(cls - 1) * b.nq + atomicAdd(&w.counters[9 + cls], 1ull)] = q;
+          w.q_acc[q] = n | (cls << 30);  // length class of the accepted sentences (0: <= 32, 1: <= 64, 2: longer)
+        }
       }
-    }
-    if (n != 0 && !contrast) {
-      const uint32_t np2 = next_pow2(n);
-      if (np2 <= kLdsSortMax) select_body<-1>(ix, prm, seg, n, np2, s_keys, s_vals, nullptr, nullptr, nullptr, cap, out, cnt, tot);
-      else select_body<-1>(ix, prm, seg, n, np2, sc.keys + 2ull * seg0, sc.vals + 2ull * seg0, nullptr, nullptr, nullptr,
-                           cap, out, cnt, tot);
-    }
-  } else if (lane == 0)
-    w.q_acc[q] = 0;
-  // with a contrastive factor the accepted list is handed to k_contrast, which writes the output
-  if (lane == 0 && !(contrast && n_cand != 0)) { out_count[gq] = cnt; if (out_total) out_total[gq] = tot; }
+      if (n != 0 && !contrast) {
+        const uint32_t np2 = next_pow2(n);
+        if (np2 <= SORT_CAP) select_body<-1>(ix, prm, seg, n, np2, s_keys, s_vals, nullptr, nullptr, nullptr, cap, out, cnt, tot);
+        else select_body<-1>(ix, prm, seg, n, np2, sc.keys + 2ull * seg0, sc.vals + 2ull * seg0, nullptr, nullptr, nullptr,
+                             cap, out, cnt, tot);
+      }
+    } else if (lane == 0)
+      w.q_acc[q] = 0;
+    // with a contrastive factor the accepted list is handed to the rerank kernels, which write the output
+    if (lane == 0 && !(contrast && n_cand != 0)) { out_count[gq] = cnt; if (out_total) out_total[gq] = tot; }
+    __syncthreads();
+  }
 }
 
 // k_contrast<MODE> — contrastive rerank (src/fuzzy_match.cc:614-669) of the accepted matches k_finish left in
