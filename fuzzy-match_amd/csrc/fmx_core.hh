@@ -251,12 +251,48 @@ FMX_HD int start_by_keyed_from(const SufKey* __restrict__ key, const SufRec* __r
   return start_by_from(tok, suf[i], ngram, kKeyTokens + 1, m);
 }
 
-// mgram_range through the trigram table; same result as mgram_range / mgram_range_keyed.
-FMX_HD void mgram_range_hashed(const GramEntry* __restrict__ gram, uint32_t gram_mask, const SufKey* __restrict__ key,
+// Second level: the distinct 5-grams of every trigram whose range holds more than kDeepGramMin suffixes,
+// keyed by (start of the trigram range, w3, w4).  It caps the length of the dependent-read chain of a
+// probe: without it one lane that has to bisect a 100 000-suffix trigram range keeps its whole wave waiting.
+constexpr uint32_t kDeepGramMin = 64;
+
+struct GramTables {
+  const GramEntry* g3;
+  const GramEntry* g5;
+  uint32_t         mask3, mask5;
+};
+
+// [lo, hi) -> the sub-range whose suffixes compare equal under cmp (cmp(i) < 0: before, 0: inside, > 0: after)
+template <class Cmp>
+FMX_HD void bisect_equal_range(uint32_t lo, uint32_t hi, Cmp cmp, uint32_t& out_lo, uint32_t& out_hi) {
+  uint32_t a = lo, b = hi;
+  while (a < b) {
+    const uint32_t mid = a + ((b - a) >> 1);
+    if (cmp(mid) < 0) a = mid + 1; else b = mid;
+  }
+  const uint32_t first = a;
+  if (first >= hi || cmp(first) != 0) { out_lo = out_hi = first; return; }
+  uint32_t step = 1;
+  a = first;
+  b = hi;
+  while ((unsigned long long)a + step < hi) {
+    if (cmp(a + step) == 0) { a += step; step <<= 1; }
+    else { b = a + step; break; }
+  }
+  while (b - a > 1) {
+    const uint32_t mid = a + ((b - a) >> 1);
+    if (cmp(mid) == 0) a = mid; else b = mid;
+  }
+  out_lo = first;
+  out_hi = b;
+}
+
+// mgram_range through the n-gram tables; same result as mgram_range / mgram_range_keyed.
+FMX_HD void mgram_range_hashed(const GramTables& gt, const SufKey* __restrict__ key,
                                const SufRec* __restrict__ suf, const uint32_t* __restrict__ tok,
                                const uint32_t* __restrict__ qva, uint32_t n_qva, const uint32_t* __restrict__ ngram,
                                uint32_t m, uint32_t& out_lo, uint32_t& out_hi) {
-  bool usable = gram != nullptr && m >= 3;
+  bool usable = gt.g3 != nullptr && m >= 3;
   for (uint32_t k = 1; usable && k < m && k <= kKeyTokens; k++) usable = ngram[k] != 0;
   if (!usable) { mgram_range_keyed(key, suf, tok, qva, n_qva, ngram, m, out_lo, out_hi); return; }
   out_lo = out_hi = 0;
@@ -264,35 +300,28 @@ FMX_HD void mgram_range_hashed(const GramEntry* __restrict__ gram, uint32_t gram
   if (w0 + 1 >= n_qva) return;
   const uint32_t blo = qva[w0], bhi = qva[w0 + 1];
   if (blo >= bhi) return;
-  uint32_t slot = gram_hash(w0, ngram[1], ngram[2]) & gram_mask;
+  uint32_t slot = gram_hash(w0, ngram[1], ngram[2]) & gt.mask3;
   uint32_t lo, hi;
   for (;;) {
-    const GramEntry e = gram[slot];
+    const GramEntry e = gt.g3[slot];
     if (e.lo == kGramEmpty) return;  // no suffix starts with this trigram
     if (e.w1 == ngram[1] && e.w2 == ngram[2] && e.lo >= blo && e.lo < bhi) { lo = e.lo; hi = e.lo + e.cnt; break; }
-    slot = (slot + 1) & gram_mask;
+    slot = (slot + 1) & gt.mask3;
   }
   if (m == 3) { out_lo = lo; out_hi = hi; return; }
-  uint32_t a = lo, b = hi;
-  while (a < b) {
-    const uint32_t mid = a + ((b - a) >> 1);
-    if (start_by_keyed_from(key, suf, tok, mid, ngram, 3, m) < 0) a = mid + 1; else b = mid;
+  if (m >= 5 && gt.g5 != nullptr && hi - lo > kDeepGramMin) {
+    slot = gram_hash(lo, ngram[3], ngram[4]) & gt.mask5;
+    for (;;) {
+      const GramEntry e = gt.g5[slot];
+      if (e.lo == kGramEmpty) return;  // no suffix of this trigram continues with (w3, w4)
+      if (e.w1 == ngram[3] && e.w2 == ngram[4] && e.lo >= lo && e.lo < hi) { lo = e.lo; hi = e.lo + e.cnt; break; }
+      slot = (slot + 1) & gt.mask5;
+    }
+    if (m == 5) { out_lo = lo; out_hi = hi; return; }
+    bisect_equal_range(lo, hi, [&](uint32_t i) { return start_by_from(tok, suf[i], ngram, 5, m); }, out_lo, out_hi);
+    return;
   }
-  const uint32_t first = a;
-  if (first >= hi || start_by_keyed_from(key, suf, tok, first, ngram, 3, m) != 0) { out_lo = out_hi = first; return; }
-  uint32_t step = 1;
-  a = first;
-  b = hi;
-  while ((unsigned long long)a + step < hi) {
-    if (start_by_keyed_from(key, suf, tok, a + step, ngram, 3, m) == 0) { a += step; step <<= 1; }
-    else { b = a + step; break; }
-  }
-  while (b - a > 1) {
-    const uint32_t mid = a + ((b - a) >> 1);
-    if (start_by_keyed_from(key, suf, tok, mid, ngram, 3, m) == 0) a = mid; else b = mid;
-  }
-  out_lo = first;
-  out_hi = b;
+  bisect_equal_range(lo, hi, [&](uint32_t i) { return start_by_keyed_from(key, suf, tok, i, ngram, 3, m); }, out_lo, out_hi);
 }
 
 // Longest common prefix of a suffix (already known to share `known` tokens) with pat[0..maxlen).

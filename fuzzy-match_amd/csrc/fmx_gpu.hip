@@ -104,7 +104,7 @@ DeviceIndex::~DeviceIndex() {
   Impl& m = *impl_;
   if (m.device >= 0) {
     (void)hipSetDevice(m.device);
-    hipFree((void*)m.d.suf); hipFree((void*)m.d.suf_sig); hipFree((void*)m.d.suf_key); hipFree((void*)m.d.gram); hipFree((void*)m.d.suf_sid); hipFree((void*)m.d.tok); hipFree((void*)m.d.sent_pos);
+    hipFree((void*)m.d.suf); hipFree((void*)m.d.suf_sig); hipFree((void*)m.d.suf_key); hipFree((void*)m.d.gram.g3); hipFree((void*)m.d.gram.g5); hipFree((void*)m.d.suf_sid); hipFree((void*)m.d.tok); hipFree((void*)m.d.sent_pos);
     hipFree((void*)m.d.qva); hipFree((void*)m.d.idf); hipFree((void*)m.d.real); hipFree((void*)m.d.itok);
     hipFree((void*)m.d.itok_dist);
     free_ws(m);
@@ -139,8 +139,10 @@ void DeviceIndex::upload(const HostIndex& h, int device) {
   m.d.suf_sid = dev_upload(h.suf_sid);
   m.d.suf_sig = (const unsigned long long*)dev_upload(h.suf_sig);
   m.d.suf_key = dev_upload(h.suf_key);
-  m.d.gram = h.gram.empty() ? nullptr : dev_upload(h.gram);
-  m.d.gram_mask = h.gram.empty() ? 0u : (uint32_t)(h.gram.size() - 1);
+  m.d.gram.g3 = h.gram.empty() ? nullptr : dev_upload(h.gram);
+  m.d.gram.mask3 = h.gram.empty() ? 0u : (uint32_t)(h.gram.size() - 1);
+  m.d.gram.g5 = h.gram5.empty() ? nullptr : dev_upload(h.gram5);
+  m.d.gram.mask5 = h.gram5.empty() ? 0u : (uint32_t)(h.gram5.size() - 1);
   m.d.tok = dev_upload(h.buf);
   m.d.sent_pos = dev_upload(h.sent_pos);
   m.d.qva = dev_upload(h.qva);
@@ -151,7 +153,7 @@ void DeviceIndex::upload(const HostIndex& h, int device) {
   uint32_t mx = 0;
   for (uint32_t sp : h.sent_pos) mx = std::max(mx, h.buf[sp]);
   m.d.max_slen = mx;
-  m.bytes = h.suf_rec.size() * 8 + h.suf_sig.size() * 8 + h.suf_key.size() * 16 + h.gram.size() * 16 + h.suf_sid.size() * 4 + h.buf.size() * 4 + h.sent_pos.size() * 4 +
+  m.bytes = h.suf_rec.size() * 8 + h.suf_sig.size() * 8 + h.suf_key.size() * 16 + h.gram.size() * 16 + h.gram5.size() * 16 + h.suf_sid.size() * 4 + h.buf.size() * 4 + h.sent_pos.size() * 4 +
             h.qva.size() * 4 + h.idf.size() * 4;
   if (h.real_differs) {
     m.d.real = dev_upload(h.real_ids);
@@ -271,7 +273,7 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm_in, const D
       }
       tick(); tick();
       hipLaunchKernelGGL(k_cand, dim3((b.nq + 3) / 4), dim3(256), 0, stream, b, w, m.big_list, m.mid_list);
-      hipLaunchKernelGGL(k_cand_mid, dim3(2048), dim3(kWave), 0, stream, w, (const uint32_t*)m.mid_list);
+      hipLaunchKernelGGL(k_cand_mid, dim3(1024), dim3(256), 0, stream, w, (const uint32_t*)m.mid_list);
       tick(); tick();
       {
         // radix passes needed: sentence ids < n_sent, match lengths <= longest pattern

@@ -300,6 +300,49 @@ void HostIndex::build_gram_table(int nthreads) {
       }
     }
   });
+
+  // second level: distinct 5-grams of the trigrams with more than kDeepGramMin suffixes
+  gram5.clear();
+  auto for_deep_groups = [&](int t, auto fn) {
+    const uint64_t a = n * (uint64_t)t / (uint64_t)nthreads, b = n * (uint64_t)(t + 1) / (uint64_t)nthreads;
+    for (uint64_t i = a; i < b; i++) {
+      if (!is_start(i)) continue;
+      uint64_t e = i + 1;
+      const uint32_t w0 = w0_of(i), w1 = suf_key[i].t[0], w2 = suf_key[i].t[1];
+      while (e < n && suf_rec[e].rem >= 3 && w0_of(e) == w0 && suf_key[e].t[0] == w1 && suf_key[e].t[1] == w2) e++;
+      if (e - i <= kDeepGramMin) continue;
+      for (uint64_t j = i; j < e;) {  // 5-gram groups inside [i, e)
+        if (suf_rec[j].rem < 5) { j++; continue; }
+        uint64_t g = j + 1;
+        while (g < e && suf_rec[g].rem >= 5 && suf_key[g].t[2] == suf_key[j].t[2] && suf_key[g].t[3] == suf_key[j].t[3]) g++;
+        fn((uint32_t)i, suf_key[j].t[2], suf_key[j].t[3], (uint32_t)j, (uint32_t)(g - j));
+        j = g;
+      }
+    }
+  };
+  std::fill(part_count.begin(), part_count.end(), 0);
+  run([&](int t) { uint64_t c = 0; for_deep_groups(t, [&](uint32_t, uint32_t, uint32_t, uint32_t, uint32_t) { c++; }); part_count[t] = c; });
+  uint64_t groups5 = 0;
+  for (auto c : part_count) groups5 += c;
+  if (groups5 == 0) return;
+  uint64_t cap5 = 16;
+  while (cap5 < groups5 * 2) cap5 <<= 1;
+  if (cap5 > (1ull << 31)) return;
+  gram5.assign(cap5, empty);
+  const uint32_t mask5 = (uint32_t)(cap5 - 1);
+  run([&](int t) {
+    for_deep_groups(t, [&](uint32_t lo3, uint32_t w3, uint32_t w4, uint32_t lo5, uint32_t cnt5) {
+      uint32_t slot = gram_hash(lo3, w3, w4) & mask5;
+      for (;;) {
+        uint32_t expect = kGramEmpty;
+        if (__atomic_compare_exchange_n(&gram5[slot].lo, &expect, lo5, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE)) {
+          gram5[slot].w1 = w3; gram5[slot].w2 = w4; gram5[slot].cnt = cnt5;
+          break;
+        }
+        slot = (slot + 1) & mask5;
+      }
+    });
+  });
 }
 
 uint32_t HostIndex::intern_itok(const std::string& s) {

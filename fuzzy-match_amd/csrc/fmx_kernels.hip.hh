@@ -20,8 +20,7 @@ struct DevIndex {
   const SufRec*   suf;
   const unsigned long long* suf_sig;  // sentence length << 48 | 48-bit word signature
   const SufKey*   suf_key;    // four tokens after the first, per suffix
-  const GramEntry* gram;      // trigram -> suffix range hash table (nullptr if absent)
-  uint32_t        gram_mask;
+  GramTables      gram;       // trigram table + 5-gram table of the heavy trigrams (null if absent)
   const uint32_t* suf_sid;
   const uint32_t* tok;
   const uint32_t* sent_pos;
@@ -141,8 +140,7 @@ __global__ void __launch_bounds__(256) k_probe(DevIndex ix, DevBatch b, DevWork 
     // with p == 1 the only registered length is 1.
     const bool reachable = (p == 1) ? (msl <= 1) : true;
     if (reachable && it + m <= p)
-      mgram_range_hashed(ix.gram, ix.gram_mask, ix.suf_key, ix.suf, ix.tok, ix.qva, ix.n_qva, b.q_tok + b.t_begin + t, m,
-                         lo, hi);
+      mgram_range_hashed(ix.gram, ix.suf_key, ix.suf, ix.tok, ix.qva, ix.n_qva, b.q_tok + b.t_begin + t, m, lo, hi);
   }
   const uint32_t cnt = hi - lo;
   w.t_lo[t] = lo;
@@ -793,7 +791,7 @@ __global__ void __launch_bounds__(256) k_cand(DevBatch b, DevWork w, uint32_t* b
   if (lane == 0) w.q_cand[q] = kept;
 }
 
-__global__ void __launch_bounds__(kWave) k_cand_mid(DevWork w, const uint32_t* mid_list) {
+__global__ void __launch_bounds__(256) k_cand_mid(DevWork w, const uint32_t* mid_list) {
   __shared__ unsigned long long s_keys[kLdsSortMax];
   __shared__ uint32_t s_count;
   const unsigned long long n_mid = w.counters[13];
@@ -801,7 +799,7 @@ __global__ void __launch_bounds__(kWave) k_cand_mid(DevWork w, const uint32_t* m
     const uint32_t q = mid_list[idx];
     const uint32_t n = w.q_kept[q];
     const uint32_t kept = cand_body(s_keys, w.seg + w.q_seg[q], n, next_pow2(n), &s_count);
-    if (lane_id() == 0) w.q_cand[q] = kept;
+    if (threadIdx.x == 0) w.q_cand[q] = kept;
     __syncthreads();
   }
 }

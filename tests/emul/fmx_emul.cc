@@ -16,9 +16,9 @@ using namespace fmx;
 struct Rec { float score; float penalty; int32_t max_subseq; uint32_t s_id; };
 
 struct EmulIndex {
-  const SufRec* suf; const uint64_t* suf_sig; const SufKey* suf_key; const GramEntry* gram; const uint32_t* suf_sid; const uint32_t* tok; const uint32_t* sent_pos; const uint32_t* qva;
+  const SufRec* suf; const uint64_t* suf_sig; const SufKey* suf_key; const GramEntry* gram; const GramEntry* gram5; const uint32_t* suf_sid; const uint32_t* tok; const uint32_t* sent_pos; const uint32_t* qva;
   const float* idf; const uint32_t* real; const uint32_t* itok; const uint16_t* itok_dist;
-  uint32_t n_itok, n_qva, gram_mask;
+  uint32_t n_itok, n_qva, gram_mask, gram5_mask;
 };
 
 struct VecRow {
@@ -49,7 +49,7 @@ extern "C" int emul_match_batch(const EmulIndex* ix, const Params* prm_in, uint6
     const bool use_sig = prm.ins >= 0.f && prm.del >= 0.f && prm.rep >= 0.f;
     for (uint32_t it = 0; it < p; it++) {
       uint32_t lo = 0, hi = 0;
-      if (reachable && it + m <= p) mgram_range_hashed(ix->gram, ix->gram_mask, ix->suf_key, ix->suf, ix->tok, ix->qva, ix->n_qva, pat + it, m, lo, hi);
+      if (reachable && it + m <= p) mgram_range_hashed(GramTables{ix->gram, ix->gram5, ix->gram_mask, ix->gram5_mask}, ix->suf_key, ix->suf, ix->tok, ix->qva, ix->n_qva, pat + it, m, lo, hi);
       if (stats) stats[0] += hi - lo;
       for (uint32_t i = lo; i < hi; i++) {
         const SufRec r = ix->suf[i];
