@@ -87,6 +87,8 @@ def main():
     ix.sort(local_rank)  # suffix sort on the GPU
     ix.finalize()
     ix.to_device(local_rank)
+    if os.environ.get("FMX_SUB_QUERIES"):
+        ix.set_option("sub_queries", int(os.environ["FMX_SUB_QUERIES"]))
     info = ix.info()
     log(f"[bench] index built+uploaded in {time.time() - t0:.1f}s: {info.n_suffixes} suffixes, "
         f"{info.device_bytes / 1e9:.2f} GB in HBM")

@@ -82,7 +82,7 @@ struct DeviceIndex::Impl {
   uint64_t  cap_out = 0, cap_outq = 0;
   hipEvent_t ev[2 * kNumStages]{};
   bool       ev_ok = false;
-  uint32_t   sub_queries = 1u << 17;
+  uint32_t   sub_queries = 1u << 20;  // queries per pipeline pass: large passes amortise the ~40 launches and their tails
   uint64_t   init_seg = 1ull << 24;
 };
 

@@ -144,8 +144,7 @@ __global__ void __launch_bounds__(256) k_probe(DevIndex ix, DevBatch b, DevWork 
   }
   const uint32_t cnt = hi - lo;
   w.t_lo[t] = lo;
-  w.t_cnt[t] = cnt;
-  if (cnt) atomicAdd(&w.q_hits[q], (unsigned long long)cnt);
+  w.t_cnt[t] = cnt;  // summed per query by k_caps (an atomic per start position here costs more than the search)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -233,7 +232,12 @@ __global__ void k_caps(DevBatch b, DevWork w, WorkItem* items, uint32_t item_cap
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q > b.nq) return;
   if (q == b.nq) { w.q_cap[q] = 0; return; }
-  const unsigned long long hits = w.q_m[q] == kNoMatchLen ? 0ull : w.q_hits[q];
+  unsigned long long hits = 0;
+  if (w.q_m[q] != kNoMatchLen) {
+    const uint32_t o0 = b.q_off[b.q_begin + q] - b.t_begin, o1 = b.q_off[b.q_begin + q + 1] - b.t_begin;
+    for (uint32_t t = o0; t < o1; t++) hits += w.t_cnt[t];
+  }
+  w.q_hits[q] = hits;
   w.q_cap[q] = hits < s_max ? hits : (unsigned long long)s_max;
   w.q_kept[q] = 0;
   if (hits > kExpandChunk) {

@@ -61,7 +61,9 @@ extern "C" int emul_match_batch(const EmulIndex* ix, const Params* prm_in, uint6
         // the kernel tabulates cover_threshold per sentence length and compares the signature's upper bound
         const uint32_t cmin = use_sig ? cover_threshold(p, sl, prm) : 0u;
         if (use_sig && (cmin == 0xffffu || sig_cover_upper(sig_bits(packed), hbit.data(), p) < cmin)) continue;
+        if (stats) stats[4]++;  // queued for phase B
         if (dominated_hit(ix->tok, r, pat + it, it)) continue;
+        if (stats) stats[5]++;  // not dominated
         Cand c;
         c.longest = lcp_extend(ix->tok, r, pat + it, m, p - it);
         // coverage bound in k_expand: independent of the match length, so it commutes with the max

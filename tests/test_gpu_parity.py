@@ -75,7 +75,7 @@ def test_sub_batching_and_workspace_growth(fmx, c1):
     try:
         go, gc, gt, st = ix.match_batch(fmx.Params(**kw), q_off, q_tok, cap=64, want_stats=True)
     finally:
-        ix.set_option("sub_queries", 1 << 17)
+        ix.set_option("sub_queries", 1 << 20)
     workloads.compare(oo, oc, go, gc, "wide_all/sub37")
 
 

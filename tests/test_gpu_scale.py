@@ -80,7 +80,7 @@ def test_batch_permutation_and_sub_batching_invariance(fmx, c2):
     try:
         p_out, p_cnt, _ = ix.match_batch(prm, p_off, p_tok, cap=5)
     finally:
-        ix.set_option("sub_queries", 1 << 17)
+        ix.set_option("sub_queries", 1 << 20)
     assert np.array_equal(p_cnt, base_cnt[perm])
     for k in range(len(perm)):
         n = int(p_cnt[k])
