@@ -220,7 +220,13 @@ __global__ void __launch_bounds__(kScanThreads) k_scan_add(unsigned long long* o
 // k_caps — per query: segment capacity min(hits, s_max) (input of the scan) and, for queries with
 // more than kExpandChunk hits, extra work items so that several waves share the walk.
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t kExpandChunk = 4096;  // suffix hits per k_expand work item
+#ifndef FMX_EXPAND_CHUNK
+#define FMX_EXPAND_CHUNK 16384
+#endif
+#ifndef FMX_UNROLL
+#define FMX_UNROLL 4
+#endif
+constexpr uint32_t kExpandChunk = FMX_EXPAND_CHUNK;  // suffix hits per k_expand work item
 constexpr uint32_t kExpandExtraGrid = 8192;
 
 struct WorkItem {
@@ -350,7 +356,7 @@ __device__ __forceinline__ bool cover_at_least(const PatHash& ph, const uint32_t
   return false;
 }
 
-constexpr int kUnroll = 4;        // hits per lane per phase-A iteration
+constexpr int kUnroll = FMX_UNROLL;  // hits per lane per phase-A iteration
 constexpr uint32_t kQueue = 128;  // LDS ring of hits that passed the cheap tests (power of two >= 2 * 64)
 constexpr uint32_t kPhaseBChunk = 1024;  // queued hits per k_expand_b work item
 constexpr uint32_t kNeedExact = 0xfffeu; // "no tabulated threshold": phase B evaluates the bound itself

@@ -11,7 +11,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfmx.so")
+LIB_PATH = os.environ.get("FMX_LIB") or os.path.join(_HERE, "libfmx.so")  # FMX_LIB: tuning experiments only
 
 FMX_OK = 0
 ARRAYS = {
