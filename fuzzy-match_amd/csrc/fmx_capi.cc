@@ -195,6 +195,7 @@ int fmx_index_array(const fmx_index* ix, int which, const void** data, uint64_t*
     case FMX_A_SUF_KEY: *data = h.suf_key.data(); *count = h.suf_key.size(); break;
     case FMX_A_GRAM: *data = h.gram.data(); *count = h.gram.size(); break;
     case FMX_A_GRAM5: *data = h.gram5.data(); *count = h.gram5.size(); break;
+    case FMX_A_SUF_B: *data = h.suf_b.data(); *count = h.suf_b.size(); break;
     default: return fail(FMX_E_INVALID, "unknown array id");
   }
   return FMX_OK;

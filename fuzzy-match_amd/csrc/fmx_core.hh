@@ -344,6 +344,20 @@ FMX_HD bool dominated_hit(const uint32_t* __restrict__ tok, SufRec r, const uint
   return it > 0 && r.rem < r.slen && tok[r.off - 1] == pat_at_it[-1];
 }
 
+// Phase-B record: SufRec plus the token in front of the suffix and the sentence id, so that one 16-byte
+// load decides the dominance test and names the survivor (two dependent random reads fewer per queued hit).
+struct SufRecB {
+  uint32_t off;
+  uint16_t rem;
+  uint16_t slen;
+  uint32_t prev;  // token before the suffix in its sentence (unspecified when the suffix starts the sentence)
+  uint32_t sid;
+};
+
+FMX_HD bool dominated_hit_b(const SufRecB& r, const uint32_t* __restrict__ pat_at_it, uint32_t it) {
+  return it > 0 && r.rem < r.slen && r.prev == pat_at_it[-1];
+}
+
 // 48-bit word signature of a sentence: bit sig_bit(w) is set for every word w of the sentence.  For a
 // pattern, the number of positions whose word's bit is set is an upper bound of
 // PatternCoverage::count_covered_words, and theoretical_rejection_cover is monotone in the cover

@@ -104,7 +104,7 @@ DeviceIndex::~DeviceIndex() {
   Impl& m = *impl_;
   if (m.device >= 0) {
     (void)hipSetDevice(m.device);
-    hipFree((void*)m.d.suf); hipFree((void*)m.d.suf_sig); hipFree((void*)m.d.suf_key); hipFree((void*)m.d.gram.g3); hipFree((void*)m.d.gram.g5); hipFree((void*)m.d.suf_sid); hipFree((void*)m.d.tok); hipFree((void*)m.d.sent_pos);
+    hipFree((void*)m.d.suf); hipFree((void*)m.d.suf_sig); hipFree((void*)m.d.suf_key); hipFree((void*)m.d.gram.g3); hipFree((void*)m.d.gram.g5); hipFree((void*)m.d.suf_b); hipFree((void*)m.d.tok); hipFree((void*)m.d.sent_pos);
     hipFree((void*)m.d.qva); hipFree((void*)m.d.idf); hipFree((void*)m.d.real); hipFree((void*)m.d.itok);
     hipFree((void*)m.d.itok_dist);
     free_ws(m);
@@ -136,7 +136,7 @@ void DeviceIndex::upload(const HostIndex& h, int device) {
   HIP_TRY(hipSetDevice(device));
   m.device = device;
   m.d.suf = dev_upload(h.suf_rec);
-  m.d.suf_sid = dev_upload(h.suf_sid);
+  m.d.suf_b = dev_upload(h.suf_b);
   m.d.suf_sig = (const unsigned long long*)dev_upload(h.suf_sig);
   m.d.suf_key = dev_upload(h.suf_key);
   m.d.gram.g3 = h.gram.empty() ? nullptr : dev_upload(h.gram);
@@ -153,7 +153,7 @@ void DeviceIndex::upload(const HostIndex& h, int device) {
   uint32_t mx = 0;
   for (uint32_t sp : h.sent_pos) mx = std::max(mx, h.buf[sp]);
   m.d.max_slen = mx;
-  m.bytes = h.suf_rec.size() * 8 + h.suf_sig.size() * 8 + h.suf_key.size() * 16 + h.gram.size() * 16 + h.gram5.size() * 16 + h.suf_sid.size() * 4 + h.buf.size() * 4 + h.sent_pos.size() * 4 +
+  m.bytes = h.suf_rec.size() * 8 + h.suf_sig.size() * 8 + h.suf_key.size() * 16 + h.gram.size() * 16 + h.gram5.size() * 16 + h.suf_b.size() * 16 + h.buf.size() * 4 + h.sent_pos.size() * 4 +
             h.qva.size() * 4 + h.idf.size() * 4;
   if (h.real_differs) {
     m.d.real = dev_upload(h.real_ids);

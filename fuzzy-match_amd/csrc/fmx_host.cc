@@ -401,7 +401,13 @@ void HostIndex::derive() {
     }
     suf_sig.resize(n);
     suf_key.resize(n);
+    suf_b.resize(n);
     for (uint64_t i = 0; i < n; i++) {
+      SufRecB rb;
+      rb.off = suf_rec[i].off; rb.rem = suf_rec[i].rem; rb.slen = suf_rec[i].slen;
+      rb.prev = suf_rec[i].rem < suf_rec[i].slen ? buf[suf_rec[i].off - 1] : 0u;
+      rb.sid = suf_sid[i];
+      suf_b[i] = rb;
       suf_sig[i] = sig_pack(suf_rec[i].slen, sent_sig[suf_sid[i]]);
       SufKey k;
       for (uint32_t t = 0; t < kKeyTokens; t++) k.t[t] = t + 1 < suf_rec[i].rem ? buf[suf_rec[i].off + 1 + t] : 0u;

@@ -48,6 +48,7 @@ class HostIndex {
   std::vector<SufRec>   suf_rec;   // one 8-byte record per suffix, suffix-array order
   std::vector<uint64_t> suf_sig;   // sentence length << 48 | 48-bit word signature of the suffix's sentence
   std::vector<SufKey>   suf_key;   // the four tokens after each suffix's first token (0-padded)
+  std::vector<SufRecB>  suf_b;     // phase-B record: SufRec + previous token + sentence id
   std::vector<GramEntry> gram;     // trigram -> suffix range hash table (power-of-two size, empty if tiny index)
   std::vector<GramEntry> gram5;    // (trigram range start, w3, w4) -> 5-gram range, for trigrams with > kDeepGramMin suffixes
   void build_gram_table(int nthreads);

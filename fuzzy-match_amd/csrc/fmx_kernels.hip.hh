@@ -21,7 +21,7 @@ struct DevIndex {
   const unsigned long long* suf_sig;  // sentence length << 48 | 48-bit word signature
   const SufKey*   suf_key;    // four tokens after the first, per suffix
   GramTables      gram;       // trigram table + 5-gram table of the heavy trigrams (null if absent)
-  const uint32_t* suf_sid;
+  const SufRecB*  suf_b;      // phase-B record: SufRec + previous token + sentence id
   const uint32_t* tok;
   const uint32_t* sent_pos;
   const uint32_t* qva;
@@ -625,8 +625,10 @@ __global__ void __launch_bounds__(kWave) k_expand_b(DevIndex ix, DevBatch b, Dev
         if (keep) {
           const QHit hq = qb[e];
           const uint32_t i = hq.i, it = hq.it_need >> 16, need = hq.it_need & 0xffffu;
-          const SufRec r = ix.suf[i];
-          keep = !dominated_hit(ix.tok, r, pat + it, it);
+          const SufRecB rb = ix.suf_b[i];  // one 16-byte load: dominance test and sentence id included
+          SufRec r;
+          r.off = rb.off; r.rem = rb.rem; r.slen = rb.slen;
+          keep = !dominated_hit_b(rb, pat + it, it);
           if (keep) {
             L = lcp_extend(ix.tok, r, pat + it, m, p - it);
             const uint32_t sl = r.slen;
@@ -639,7 +641,7 @@ __global__ void __launch_bounds__(kWave) k_expand_b(DevIndex ix, DevBatch b, Dev
               const uint32_t cover = L < p ? cover_lds(sent, sl, s_pat, p) : p;
               keep = !reject_cover(p, sl, cover, prm);
             }
-            if (keep) sid = ix.suf_sid[i];
+            if (keep) sid = rb.sid;
           }
         }
         const unsigned long long mask = __ballot(keep);

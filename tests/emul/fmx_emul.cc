@@ -16,7 +16,7 @@ using namespace fmx;
 struct Rec { float score; float penalty; int32_t max_subseq; uint32_t s_id; };
 
 struct EmulIndex {
-  const SufRec* suf; const uint64_t* suf_sig; const SufKey* suf_key; const GramEntry* gram; const GramEntry* gram5; const uint32_t* suf_sid; const uint32_t* tok; const uint32_t* sent_pos; const uint32_t* qva;
+  const SufRec* suf; const uint64_t* suf_sig; const SufKey* suf_key; const GramEntry* gram; const GramEntry* gram5; const SufRecB* suf_b; const uint32_t* tok; const uint32_t* sent_pos; const uint32_t* qva;
   const float* idf; const uint32_t* real; const uint32_t* itok; const uint16_t* itok_dist;
   uint32_t n_itok, n_qva, gram_mask, gram5_mask;
 };
@@ -62,7 +62,10 @@ extern "C" int emul_match_batch(const EmulIndex* ix, const Params* prm_in, uint6
         const uint32_t cmin = use_sig ? cover_threshold(p, sl, prm) : 0u;
         if (use_sig && (cmin == 0xffffu || sig_cover_upper(sig_bits(packed), hbit.data(), p) < cmin)) continue;
         if (stats) stats[4]++;  // queued for phase B
-        if (dominated_hit(ix->tok, r, pat + it, it)) continue;
+        const SufRecB rb = ix->suf_b[i];
+        if (rb.off != r.off || rb.rem != r.rem || rb.slen != r.slen) return -3;
+        if (dominated_hit_b(rb, pat + it, it) != dominated_hit(ix->tok, r, pat + it, it)) return -4;
+        if (dominated_hit_b(rb, pat + it, it)) continue;
         if (stats) stats[5]++;  // not dominated
         Cand c;
         c.longest = lcp_extend(ix->tok, r, pat + it, m, p - it);
@@ -70,7 +73,7 @@ extern "C" int emul_match_batch(const EmulIndex* ix, const Params* prm_in, uint6
         const uint32_t* sent0 = ix->tok + (r.off - (uint32_t)(r.slen - r.rem));
         const uint32_t cov = c.longest < p ? cover_count(sent0, r.slen, pat, p) : p;
         if (use_sig ? cov < cmin : reject_cover(p, r.slen, cov, prm)) continue;
-        c.sid = ix->suf_sid[i];
+        c.sid = rb.sid;
         c.score = c.penalty = 0.f;
         seg.push_back(c);
       }

@@ -21,7 +21,7 @@ class CoreParams(C.Structure):
 
 
 class EmulIndex(C.Structure):
-    _fields_ = [("suf", C.c_void_p), ("suf_sig", C.c_void_p), ("suf_key", C.c_void_p), ("gram", C.c_void_p), ("gram5", C.c_void_p), ("suf_sid", C.c_void_p), ("tok", C.c_void_p), ("sent_pos", C.c_void_p),
+    _fields_ = [("suf", C.c_void_p), ("suf_sig", C.c_void_p), ("suf_key", C.c_void_p), ("gram", C.c_void_p), ("gram5", C.c_void_p), ("suf_b", C.c_void_p), ("tok", C.c_void_p), ("sent_pos", C.c_void_p),
                 ("qva", C.c_void_p), ("idf", C.c_void_p), ("real", C.c_void_p), ("itok", C.c_void_p),
                 ("itok_dist", C.c_void_p), ("n_itok", C.c_uint32), ("n_qva", C.c_uint32), ("gram_mask", C.c_uint32), ("gram5_mask", C.c_uint32)]
 
@@ -50,7 +50,7 @@ class Emul:
         self.ix = fmx_index
         info = fmx_index.info()
         self.info = info
-        self.a = {n: fmx_index.array(n) for n in ["suf_rec", "suf_sig", "suf_key", "gram", "gram5", "suf_sid", "buffer", "sent_pos", "qva", "idf"]}
+        self.a = {n: fmx_index.array(n) for n in ["suf_rec", "suf_sig", "suf_key", "gram", "gram5", "suf_b", "buffer", "sent_pos", "qva", "idf"]}
         self.a["real_ids"] = fmx_index.array("real_ids") if info.real_differs else None
         self.a["itok_ids"] = fmx_index.array("itok_ids") if info.real_differs else None
 
@@ -58,7 +58,7 @@ class Emul:
         """p: the fmx Params (fmx_params layout)."""
         info = self.ix.info()
         dist = self.ix.array("itok_dist") if info.n_itok else None
-        e = EmulIndex(_p(self.a["suf_rec"]), _p(self.a["suf_sig"]), _p(self.a["suf_key"]), _p(self.a["gram"]), _p(self.a["gram5"]), _p(self.a["suf_sid"]), _p(self.a["buffer"]), _p(self.a["sent_pos"]),
+        e = EmulIndex(_p(self.a["suf_rec"]), _p(self.a["suf_sig"]), _p(self.a["suf_key"]), _p(self.a["gram"]), _p(self.a["gram5"]), _p(self.a["suf_b"]), _p(self.a["buffer"]), _p(self.a["sent_pos"]),
                       _p(self.a["qva"]), _p(self.a["idf"]),
                       _p(self.a["real_ids"]) if self.a["real_ids"] is not None else None,
                       _p(self.a["itok_ids"]) if self.a["itok_ids"] is not None else None,
