@@ -357,7 +357,7 @@ __device__ __forceinline__ bool cover_at_least(const PatHash& ph, const uint32_t
 }
 
 constexpr int kUnroll = FMX_UNROLL;  // hits per lane per phase-A iteration
-constexpr uint32_t kQueue = 128;  // LDS ring of hits that passed the cheap tests (power of two >= 2 * 64)
+constexpr uint32_t kQueue = 256;  // LDS ring of hits that passed the cheap tests (power of two >= 64 + 2 * 64)
 constexpr uint32_t kPhaseBChunk = 1024;  // queued hits per k_expand_b work item
 constexpr uint32_t kNeedExact = 0xfffeu; // "no tabulated threshold": phase B evaluates the bound itself
 
@@ -384,7 +384,7 @@ struct QHit {
 // The ~2.5 % that pass are compacted through an LDS ring and appended, 64 at a time with one atomic, to
 // the query's queue for k_expand_b.  The kernel is deliberately small (few registers, no token access):
 // it is bound by HBM latency, so what matters is how many waves are resident.
-// Dynamic LDS: cmin[kCminTab] u16.
+// Dynamic LDS: cmin[tab_n + 1] u16, tab_n = min(max_slen + 1, kCminTab).
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kWave, 8) k_expand_a(DevIndex ix, DevBatch b, DevWork w, Params prm,
                                                     const WorkItem* items, uint32_t item_cap, int use_sig) {
@@ -433,6 +433,7 @@ __global__ void __launch_bounds__(kWave, 8) k_expand_a(DevIndex ix, DevBatch b, 
           if (c == kNeedExact && use_sig) c = cover_threshold(p, sl, prm);
           s_cmin[sl] = (uint16_t)c;
         }
+        if (lane == 0) s_cmin[tab_n] = 0;  // lengths outside the table: always queued, phase B decides
         __syncthreads();
         unsigned long long planes[kMaxPlanes];
         uint32_t n_planes = 0;
@@ -448,7 +449,13 @@ __global__ void __launch_bounds__(kWave, 8) k_expand_a(DevIndex ix, DevBatch b, 
             if (planes[k]) n_planes = k + 1;
           }
           if (overflow) { n_planes = 0; sig_off = true; }
+          if (sig_off) {
+#pragma unroll
+            for (uint32_t k = 0; k < kMaxPlanes; k++) planes[k] = 0;
+            n_planes = 0;
+          }
         }
+        const uint32_t ub_or = sig_off ? 0x10000u : 0u;  // signature bound disabled: every threshold passes
         QHit* qb = w.qb + seg0;
         const unsigned long long h_lo = (unsigned long long)chunk * kExpandChunk;
         const unsigned long long h_hi = h_lo + kExpandChunk < hits ? h_lo + kExpandChunk : hits;
@@ -483,10 +490,74 @@ __global__ void __launch_bounds__(kWave, 8) k_expand_a(DevIndex ix, DevBatch b, 
           const unsigned long long a0 = h_lo > base_h ? h_lo - base_h : 0ull;
           const unsigned long long a1 = h_hi - base_h < total ? h_hi - base_h : (unsigned long long)total;
           uint32_t k = 0;  // this lane's current start position (index into the compacted list)
+          // One hit, branch-free per lane: the tabulated threshold of the sentence length (0xffff = rejected
+          // by the length filter, 0 = length outside the table: phase B evaluates everything) against the
+          // upper bound of the cover from the word signature.  No token is touched for most hits.
+          auto test = [&](bool valid, unsigned long long pk, uint32_t& cmin) -> bool {
+            const uint32_t sl = sig_slen(pk);
+            cmin = s_cmin[sl < tab_n ? sl : tab_n];
+            const unsigned long long sig = sig_bits(pk);
+            uint32_t ub = (uint32_t)__popcll(sig & planes[0]) | ub_or;
+            if (n_planes > 1) {
+              ub += (uint32_t)__popcll(sig & planes[1]) << 1;
+              if (n_planes > 2) {
+#pragma unroll
+                for (uint32_t kk2 = 2; kk2 < kMaxPlanes; kk2++)
+                  if (kk2 < n_planes) ub += (uint32_t)__popcll(sig & planes[kk2]) << kk2;
+              }
+            }
+            return valid & (cmin != 0xffffu) & (ub >= cmin);
+          };
+          // survivors of two hits per lane go to the LDS ring with one uniform branch
+          auto push2 = [&](bool k0, uint32_t i0, uint32_t n0, bool k1, uint32_t i1, uint32_t n1) {
+            const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1);
+            if (m0 | m1) {
+              const unsigned long long below = (1ull << lane) - 1ull;
+              const uint32_t c0 = __popcll(m0);
+              if (k0) { QHit e; e.i = i0; e.it_need = n0; s_q[(q_tail + __popcll(m0 & below)) & (kQueue - 1)] = e; }
+              if (k1) { QHit e; e.i = i1; e.it_need = n1; s_q[(q_tail + c0 + __popcll(m1 & below)) & (kQueue - 1)] = e; }
+              q_tail += c0 + __popcll(m1);
+              if (q_tail - q_head >= kWave) {
+                __syncthreads();
+                do flush(kWave); while (q_tail - q_head >= kWave);
+              }
+            }
+          };
           for (unsigned long long hh = a0; hh < a1; hh += kWave * kUnroll) {
             // kUnroll hits per lane as kUnroll/2 pairs of consecutive hits: inside a range the pair is one
             // 16-byte load (8-byte loads reach only ~0.6 of the streaming rate), and all loads of the
             // iteration are in flight before the first is consumed
+            const uint32_t blk_end = hh + kWave * kUnroll < a1 ? (uint32_t)hh + kWave * kUnroll : (uint32_t)a1;
+            uint32_t k0 = __builtin_amdgcn_readfirstlane(k);
+            while (s_npref[k0 + 1] <= (uint32_t)hh) k0++;
+            if (s_npref[k0 + 1] >= blk_end) {
+              // fast path (most hits: the long ranges): the whole block lies inside one start position's
+              // range, so the suffix index is linear in the hit number and the start position is uniform
+              k = k0;
+              const uint32_t it_hi = s_nit[k0] << 16;
+              const uint32_t i_base = s_nlo[k0] - s_npref[k0];
+              unsigned long long hpk[kUnroll];
+#pragma unroll
+              for (int u = 0; u < kUnroll / 2; u++) {
+                const uint32_t h = (uint32_t)hh + u * 2 * kWave + 2 * lane;
+                hpk[2 * u] = 0; hpk[2 * u + 1] = 0;
+                if (h + 1 < blk_end) {
+                  const SigPair v = *reinterpret_cast<const SigPair*>(ix.suf_sig + (i_base + h));
+                  hpk[2 * u] = v.a; hpk[2 * u + 1] = v.b;
+                } else if (h < blk_end) {
+                  hpk[2 * u] = ix.suf_sig[i_base + h];
+                }
+              }
+#pragma unroll
+              for (int u = 0; u < kUnroll / 2; u++) {
+                const uint32_t h = (uint32_t)hh + u * 2 * kWave + 2 * lane;
+                uint32_t c0, c1;
+                const bool keep0 = test(h < blk_end, hpk[2 * u], c0);
+                const bool keep1 = test(h + 1 < blk_end, hpk[2 * u + 1], c1);
+                push2(keep0, i_base + h, it_hi | c0, keep1, i_base + h + 1, it_hi | c1);
+              }
+              continue;
+            }
             uint32_t hi_[kUnroll], hit_[kUnroll];
             bool hv[kUnroll], adj[kUnroll / 2];
 #pragma unroll
@@ -519,36 +590,11 @@ __global__ void __launch_bounds__(kWave, 8) k_expand_a(DevIndex ix, DevBatch b, 
               }
             }
 #pragma unroll
-            for (int u = 0; u < kUnroll; u++) {
-              bool keep = hv[u];
-              uint32_t cmin = 0;
-              if (keep) {
-                const uint32_t sl = sig_slen(hpk[u]);
-                if (sl < tab_n) cmin = s_cmin[sl];
-                else cmin = reject_len(p, sl, prm) ? 0xffffu : (use_sig ? cover_threshold(p, sl, prm) : kNeedExact);
-                keep = cmin != 0xffffu;
-                if (keep && !sig_off) {
-                  // upper bound of the cover from the word signature: no token is touched for most hits
-                  const unsigned long long sig = sig_bits(hpk[u]);
-                  uint32_t ub = 0;
-#pragma unroll
-                  for (uint32_t kk2 = 0; kk2 < kMaxPlanes; kk2++)
-                    if (kk2 < n_planes) ub += (uint32_t)__popcll(sig & planes[kk2]) << kk2;
-                  keep = ub >= cmin;
-                }
-              }
-              const unsigned long long mask = __ballot(keep);
-              if (mask) {
-                if (keep) {
-                  QHit e;
-                  e.i = hi_[u];
-                  e.it_need = (hit_[u] << 16) | cmin;
-                  s_q[(q_tail + __popcll(mask & ((1ull << lane) - 1ull))) & (kQueue - 1)] = e;
-                }
-                q_tail += __popcll(mask);
-                __syncthreads();
-                if (q_tail - q_head >= kWave) flush(kWave);
-              }
+            for (int u = 0; u < kUnroll / 2; u++) {
+              uint32_t c0, c1;
+              const bool keep0 = test(hv[2 * u], hpk[2 * u], c0);
+              const bool keep1 = test(hv[2 * u + 1], hpk[2 * u + 1], c1);
+              push2(keep0, hi_[2 * u], (hit_[2 * u] << 16) | c0, keep1, hi_[2 * u + 1], (hit_[2 * u + 1] << 16) | c1);
             }
           }
           base_h += total;
@@ -633,13 +679,14 @@ __global__ void __launch_bounds__(kWave) k_expand_b(DevIndex ix, DevBatch b, Dev
             L = lcp_extend(ix.tok, r, pat + it, m, p - it);
             const uint32_t sl = r.slen;
             const uint32_t* sent = ix.tok + (r.off - (uint32_t)(r.slen - r.rem));
-            if (need != kNeedExact) {
+            if (need != kNeedExact && need != 0) {
               if (L >= p) keep = p >= need;
               else if (p <= kWave) keep = cover_at_least(ph, sent, sl, need);
               else keep = cover_lds(sent, sl, s_pat, p) >= need;
             } else {
               const uint32_t cover = L < p ? cover_lds(sent, sl, s_pat, p) : p;
-              keep = !reject_cover(p, sl, cover, prm);
+              // need == 0: sentence length outside phase A's table, the length filter is still to be applied
+              keep = !reject_len(p, sl, prm) && !reject_cover(p, sl, cover, prm);
             }
             if (keep) sid = rb.sid;
           }

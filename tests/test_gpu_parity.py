@@ -159,3 +159,49 @@ def test_big_candidate_sets(fmx, gpu_device):
         go, gc, gt, st = ix.match_batch(fmx.Params(**kw), q_off, q_tok, cap=cap, want_stats=True)
         workloads.compare(oo, oc, go, gc, name)
         assert st.n_big > 0 and st.max_kept > 1024, (name, st.n_big, st.max_kept)
+
+
+def test_long_sentences_beyond_threshold_table(fmx, gpu_device):
+    """Sentences longer than phase A's 1024-entry length table (decided by phase B instead) and patterns
+    longer than 256 tokens (signature planes overflow; DP rows through LDS)."""
+    long_hit = False
+    rng = np.random.default_rng(11)
+    vocab = 40
+    lens = np.concatenate([rng.integers(1000, 1600, 40), rng.integers(200, 400, 40), rng.integers(3, 30, 200)])
+    rng.shuffle(lens)
+    c_off = np.zeros(len(lens) + 1, np.uint32)
+    c_off[1:] = np.cumsum(lens)
+    c_tok = rng.integers(2, vocab + 2, int(c_off[-1])).astype(np.uint32)
+    # queries: noisy copies of whole sentences and of long slices
+    qs = []
+    for s in rng.integers(0, len(lens), 120):
+        t = c_tok[c_off[s]:c_off[s + 1]].copy()
+        if len(t) > 50 and rng.random() < 0.5:
+            a = int(rng.integers(0, len(t) // 3))
+            t = t[a:a + int(rng.integers(len(t) // 2, len(t) - a + 1))]
+        t = t[:550]  # documented limit of the DP kernels: ~590 pattern tokens (LDS rows)
+        n_edit = int(rng.integers(0, max(1, len(t) // 10) + 1))
+        t[rng.integers(0, len(t), n_edit)] = rng.integers(2, vocab + 2, n_edit)
+        qs.append(t)
+    q_off = np.zeros(len(qs) + 1, np.uint32)
+    q_off[1:] = np.cumsum([len(t) for t in qs])
+    q_tok = np.concatenate(qs).astype(np.uint32)
+    ix = fmx.Index.create(max_tokens=2000)
+    ix.add_ids(c_off, c_tok, vocab + 2)
+    ix.sort(gpu_device)
+    ix.finalize()
+    ix.to_device(gpu_device)
+    o = oracle_lib.OracleIndex(max_tokens=2000)
+    o.add_ids_bulk(c_off, c_tok, vocab + 2, sfreq=ix.array("sfreq"))
+    o.sort(oracle_lib.effective_cpus())
+    for name, kw in [("f05", dict(fuzzy=0.5, nmatch=5)), ("f02_all", dict(fuzzy=0.2, nmatch=0, min_subseq_ratio=0.05)),
+                     ("idf", dict(fuzzy=0.4, nmatch=8, idf_penalty=0.5)),
+                     ("costs", dict(fuzzy=0.3, nmatch=5, insert_cost=0.2, delete_cost=0.2, replace_cost=0.7))]:
+        cap = 64
+        oo, oc = o.match_batch(oracle_lib.Params(**kw), q_off, q_tok, cap, nthreads=oracle_lib.effective_cpus())
+        go, gc, gt = ix.match_batch(fmx.Params(**kw), q_off, q_tok, cap=cap)
+        workloads.compare(oo, oc, go, gc, name)
+        assert int(np.sum(oc)) > 0, name
+        for q in range(len(qs)):
+            long_hit |= bool(np.any(lens[oo["s_id"][q, :oc[q]]] > 1024))
+    assert long_hit  # at least one accepted match is a sentence outside the table
