@@ -196,7 +196,7 @@ def test_long_sentences_beyond_threshold_table(fmx, gpu_device):
     o.sort(oracle_lib.effective_cpus())
     for name, kw in [("f05", dict(fuzzy=0.5, nmatch=5)), ("f02_all", dict(fuzzy=0.2, nmatch=0, min_subseq_ratio=0.05)),
                      ("idf", dict(fuzzy=0.4, nmatch=8, idf_penalty=0.5)),
-                     ("costs", dict(fuzzy=0.3, nmatch=5, insert_cost=0.2, delete_cost=0.2, replace_cost=0.7))]:
+                     ("costs", dict(fuzzy=0.3, nmatch=5, costs=(0.2, 0.2, 0.7)))]:
         cap = 64
         oo, oc = o.match_batch(oracle_lib.Params(**kw), q_off, q_tok, cap, nthreads=oracle_lib.effective_cpus())
         go, gc, gt = ix.match_batch(fmx.Params(**kw), q_off, q_tok, cap=cap)
