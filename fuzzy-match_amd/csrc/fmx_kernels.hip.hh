@@ -257,6 +257,15 @@ __global__ void k_caps(DevBatch b, DevWork w, WorkItem* items, uint32_t item_cap
 // PatternCoverage::count_covered_words (src/pattern_coverage.cc:15-28) with the pattern broadcast
 // from LDS: each lane walks its own sentence once per 64 pattern positions and marks the positions
 // whose word it sees; the marked count equals the reference's sum of per-word counts.
+// Ordering point for LDS traffic inside a single-wave workgroup: the LDS executes one wave's requests in
+// program order, so only the compiler has to be kept from moving accesses across; no memory-counter wait and
+// no s_barrier (outstanding global loads stay in flight, unlike __syncthreads()).
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ uint32_t cover_lds(const uint32_t* __restrict__ sent, uint32_t slen,
                                               const uint32_t* s_pat, uint32_t p) {
   uint32_t cover = 0;
@@ -295,7 +304,7 @@ __device__ __forceinline__ void pat_hash_build(PatHash& ph, const uint32_t* s_pa
   const uint32_t lane = lane_id();
   ph.key[lane] = kHashEmpty; ph.key[lane + 64] = kHashEmpty;
   ph.cnt[lane] = 0;
-  __syncthreads();
+  wave_lds_sync();
   if (lane < p) {
     const uint32_t wd = s_pat[lane];
     uint32_t h = pat_hash_slot(wd);
@@ -305,7 +314,7 @@ __device__ __forceinline__ void pat_hash_build(PatHash& ph, const uint32_t* s_pa
       h = (h + 1) & (kHashSlots - 1);
     }
   }
-  __syncthreads();
+  wave_lds_sync();
   // distinct indices: rank of the occupied slots
   uint32_t base = 0;
 #pragma unroll
@@ -315,14 +324,14 @@ __device__ __forceinline__ void pat_hash_build(PatHash& ph, const uint32_t* s_pa
     if (occ) ph.idx[lane + 64 * half] = base + __popcll(m & ((1ull << lane) - 1ull));
     base += __popcll(m);
   }
-  __syncthreads();
+  wave_lds_sync();
   if (lane < p) {
     const uint32_t wd = s_pat[lane];
     uint32_t h = pat_hash_slot(wd);
     while (ph.key[h] != wd) h = (h + 1) & (kHashSlots - 1);
     atomicAdd(&ph.cnt[ph.idx[h]], 1u);
   }
-  __syncthreads();
+  wave_lds_sync();
 }
 
 // does the sentence cover at least `need` pattern positions?  (PatternCoverage::count_covered_words
@@ -360,6 +369,16 @@ constexpr int kUnroll = FMX_UNROLL;  // hits per lane per phase-A iteration
 constexpr uint32_t kQueue = 256;  // LDS ring of hits that passed the cheap tests (power of two >= 64 + 2 * 64)
 constexpr uint32_t kPhaseBChunk = 1024;  // queued hits per k_expand_b work item
 constexpr uint32_t kNeedExact = 0xfffeu; // "no tabulated threshold": phase B evaluates the bound itself
+
+constexpr int kBUnroll = 2;  // queued hits per lane per phase-B block (their records are loaded together)
+
+// a queued hit that passed phase B's dominance test, waiting in LDS for the token work
+struct __attribute__((aligned(16))) SurvB {
+  uint32_t off;       // token offset of the suffix
+  uint32_t rem_slen;  // tokens left | sentence length << 16
+  uint32_t sid;
+  uint32_t it_need;
+};
 
 struct __attribute__((aligned(8))) SigPair {  // two consecutive suf_sig words: one global_load_dwordx4
   unsigned long long a, b;
@@ -628,11 +647,12 @@ __global__ void k_caps_b(DevBatch b, DevWork w, WorkItem* items, uint32_t item_c
 // length, exact coverage test through a per-item hash set of the pattern's words, then ballot/prefix
 // append of the survivors to the query's segment.  Dynamic LDS: pat[p_max].
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kWave) k_expand_b(DevIndex ix, DevBatch b, DevWork w, Params prm,
-                                                    const WorkItem* items, uint32_t item_cap) {
+__global__ void __launch_bounds__(kWave, 8) k_expand_b(DevIndex ix, DevBatch b, DevWork w, Params prm,
+                                                       const WorkItem* items, uint32_t item_cap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t* s_pat = (uint32_t*)smem;
   __shared__ PatHash ph;
+  __shared__ SurvB s_surv[kWave * (kBUnroll + 1)];
   const uint32_t lane = lane_id();
   uint32_t q, chunk;
   uint32_t item_idx = 0;
@@ -647,56 +667,86 @@ __global__ void __launch_bounds__(kWave) k_expand_b(DevIndex ix, DevBatch b, Dev
       q = items[item_idx].q;
       chunk = items[item_idx].chunk;
     }
+    // The kernel is a chain of dependent memory latencies per query (most queries queue a few dozen hits),
+    // so everything that can be requested together is: level 1 = all per-query scalars.
     const unsigned long long seg0 = w.q_seg[q];
-    const uint32_t cap = (uint32_t)(w.q_seg[q + 1] - seg0);
+    const unsigned long long seg1 = w.q_seg[q + 1];
     const uint32_t n_q = w.q_pb[q];
+    const uint32_t msl = w.q_m[q];
+    const uint32_t o0 = b.q_off[b.q_begin + q];
+    const uint32_t p = b.q_off[b.q_begin + q + 1] - o0;
+    const uint32_t cap = (uint32_t)(seg1 - seg0);
     if (n_q != 0 && n_q <= cap && seg0 + cap <= w.seg_cap) {
-      const uint32_t msl = w.q_m[q];
-      const uint32_t o0 = b.q_off[b.q_begin + q];
-      const uint32_t p = b.q_off[b.q_begin + q + 1] - o0;
       const uint32_t m = seed_len(p, msl);
       const uint32_t* pat = b.q_tok + o0;
-      __syncthreads();
-      for (uint32_t j = lane; j < p; j += kWave) s_pat[j] = pat[j];
-      __syncthreads();
-      if (p <= kWave) pat_hash_build(ph, s_pat, p);
       const QHit* qb = w.qb + seg0;
       Cand* seg = w.seg + seg0;
       const uint32_t e_lo = chunk * kPhaseBChunk;
       const uint32_t e_hi = e_lo + kPhaseBChunk < n_q ? e_lo + kPhaseBChunk : n_q;
-      for (uint32_t e0 = e_lo; e0 < e_hi; e0 += kWave) {
-        const uint32_t e = e0 + lane;
-        bool keep = e < e_hi;
+      const bool sole = n_q <= kPhaseBChunk;  // this wave is the query's only phase-B worker: no atomics needed
+      uint32_t n_out = 0;
+      QHit hq[kBUnroll];
+      SufRecB rb[kBUnroll];
+      bool v[kBUnroll];
+      auto load_hits = [&](uint32_t e0) {
+#pragma unroll
+        for (int u = 0; u < kBUnroll; u++) {
+          const uint32_t e = e0 + u * kWave + lane;
+          v[u] = e < e_hi;
+          hq[u].i = 0; hq[u].it_need = 0;
+          if (v[u]) hq[u] = qb[e];
+        }
+      };
+      auto load_recs = [&]() {
+#pragma unroll
+        for (int u = 0; u < kBUnroll; u++) {
+          rb[u].off = 0; rb[u].rem = 0; rb[u].slen = 0; rb[u].prev = 0; rb[u].sid = 0;
+          if (v[u]) rb[u] = ix.suf_b[hq[u].i];
+        }
+      };
+      // level 2: the first block of queued hits together with the pattern; level 3: their 16-byte records,
+      // in flight while the pattern's hash set is built (wave-level LDS ordering, no memory waits)
+      load_hits(e_lo);
+      wave_lds_sync();
+      for (uint32_t j = lane; j < p; j += kWave) s_pat[j] = pat[j];
+      load_recs();
+      wave_lds_sync();
+      if (p <= kWave) pat_hash_build(ph, s_pat, p);
+      // Two stages per block of kWave * kBUnroll queued hits.  Stage 1: the dominance test (about two thirds
+      // of the queued hits fail it) compacts the survivors into LDS.  Stage 2: full waves of survivors do
+      // the token work (match length + exact coverage), not diluted by dominated hits.
+      uint32_t n_s = 0;
+      auto heavy = [&](uint32_t j0, bool active) {
+        bool keep = active;
         uint32_t sid = 0, L = 0;
         if (keep) {
-          const QHit hq = qb[e];
-          const uint32_t i = hq.i, it = hq.it_need >> 16, need = hq.it_need & 0xffffu;
-          const SufRecB rb = ix.suf_b[i];  // one 16-byte load: dominance test and sentence id included
+          const SurvB sv = s_surv[j0 + lane];
+          const uint32_t it = sv.it_need >> 16, need = sv.it_need & 0xffffu;
           SufRec r;
-          r.off = rb.off; r.rem = rb.rem; r.slen = rb.slen;
-          keep = !dominated_hit_b(rb, pat + it, it);
-          if (keep) {
-            L = lcp_extend(ix.tok, r, pat + it, m, p - it);
-            const uint32_t sl = r.slen;
-            const uint32_t* sent = ix.tok + (r.off - (uint32_t)(r.slen - r.rem));
-            if (need != kNeedExact && need != 0) {
-              if (L >= p) keep = p >= need;
-              else if (p <= kWave) keep = cover_at_least(ph, sent, sl, need);
-              else keep = cover_lds(sent, sl, s_pat, p) >= need;
-            } else {
-              const uint32_t cover = L < p ? cover_lds(sent, sl, s_pat, p) : p;
-              // need == 0: sentence length outside phase A's table, the length filter is still to be applied
-              keep = !reject_len(p, sl, prm) && !reject_cover(p, sl, cover, prm);
-            }
-            if (keep) sid = rb.sid;
+          r.off = sv.off; r.rem = (uint16_t)(sv.rem_slen & 0xffffu); r.slen = (uint16_t)(sv.rem_slen >> 16);
+          L = lcp_extend(ix.tok, r, s_pat + it, m, p - it);
+          const uint32_t sl = r.slen;
+          const uint32_t* sent = ix.tok + (r.off - (uint32_t)(r.slen - r.rem));
+          if (need != kNeedExact && need != 0) {
+            if (L >= p) keep = p >= need;
+            else if (p <= kWave) keep = cover_at_least(ph, sent, sl, need);
+            else keep = cover_lds(sent, sl, s_pat, p) >= need;
+          } else {
+            const uint32_t cover = L < p ? cover_lds(sent, sl, s_pat, p) : p;
+            // need == 0: sentence length outside phase A's table, the length filter is still to be applied
+            keep = !reject_len(p, sl, prm) && !reject_cover(p, sl, cover, prm);
           }
+          sid = sv.sid;
         }
         const unsigned long long mask = __ballot(keep);
         if (mask) {
           const uint32_t cnt = __popcll(mask);
-          uint32_t base = 0;
-          if (lane == 0) base = atomicAdd(&w.q_kept[q], cnt);
-          base = __shfl(base, 0, 64);
+          uint32_t base = n_out;
+          if (!sole) {
+            if (lane == 0) base = atomicAdd(&w.q_kept[q], cnt);
+            base = __shfl(base, 0, 64);
+          }
+          n_out += cnt;
           if (keep) {
             const uint32_t pos = base + __popcll(mask & ((1ull << lane) - 1ull));
             if (pos < cap) {
@@ -706,7 +756,44 @@ __global__ void __launch_bounds__(kWave) k_expand_b(DevIndex ix, DevBatch b, Dev
             }
           }
         }
+      };
+      for (uint32_t e0 = e_lo; e0 < e_hi;) {
+#pragma unroll
+        for (int u = 0; u < kBUnroll; u++) {
+          const uint32_t it = hq[u].it_need >> 16;
+          const bool dominated = it > 0 && rb[u].rem < rb[u].slen && rb[u].prev == s_pat[it ? it - 1 : 0];
+          const bool keep = v[u] && !dominated;
+          const unsigned long long mask = __ballot(keep);
+          if (keep) {
+            SurvB sv;
+            sv.off = rb[u].off; sv.rem_slen = (uint32_t)rb[u].rem | ((uint32_t)rb[u].slen << 16);
+            sv.sid = rb[u].sid; sv.it_need = hq[u].it_need;
+            s_surv[n_s + __popcll(mask & ((1ull << lane) - 1ull))] = sv;
+          }
+          n_s += __popcll(mask);
+        }
+        e0 += kWave * kBUnroll;
+        const bool more = e0 < e_hi;
+        if (more) { load_hits(e0); load_recs(); }  // next block's loads overlap this block's token work
+        wave_lds_sync();
+        uint32_t j0 = 0;
+        for (; j0 + kWave <= n_s; j0 += kWave) heavy(j0, true);
+        const uint32_t rest = n_s - j0;
+        if (!more) {
+          if (rest) heavy(j0, lane < rest);
+          n_s = 0;
+        } else {
+          if (j0) {  // carry the incomplete wave of survivors to the front of the list
+            SurvB tmp;
+            if (lane < rest) tmp = s_surv[j0 + lane];
+            wave_lds_sync();
+            if (lane < rest) s_surv[lane] = tmp;
+            wave_lds_sync();
+          }
+          n_s = rest;
+        }
       }
+      if (sole && lane == 0) w.q_kept[q] = n_out;
     }
     if (!extra) return;
     item_idx += kExpandExtraGrid;
