@@ -163,14 +163,15 @@ FMX_HD void mgram_range(const SufRec* __restrict__ suf, const uint32_t* __restri
   out_hi = b;
 }
 
-// The four tokens that follow a suffix's first token, stored next to the suffix (0 past the end of the
-// sentence): a compare step of the binary search is one 16-byte load instead of record -> tokens.
-struct SufKey {
-  uint32_t t[4];
+// The eight tokens that follow a suffix's first token, stored next to the suffix (0 past the end of the
+// sentence): a compare step of the binary search is one 32-byte load instead of record -> tokens for seed
+// n-grams of up to nine tokens (patterns of up to ~30 tokens at the default min_subseq_ratio).
+constexpr uint32_t kKeyTokens = 8;
+struct __attribute__((aligned(32))) SufKey {
+  uint32_t t[kKeyTokens];
 };
-constexpr uint32_t kKeyTokens = 4;
 
-// start_by for the keyed layout: tokens [1, min(m, 5)) from the key, the rest (rare: the key already
+// start_by for the keyed layout: tokens [1, min(m, 9)) from the key, the rest (rare: the key already
 // narrowed the range to a handful of suffixes) from the token stream.  Requires ngram[k] != 0 for the
 // keyed positions, because a key token 0 means "sentence ended" (id 0 is also the empty word; callers
 // fall back to mgram_range when the pattern contains it).
@@ -178,12 +179,15 @@ FMX_HD int start_by_keyed(const SufKey* __restrict__ key, const SufRec* __restri
                           uint32_t i, const uint32_t* __restrict__ ngram, uint32_t m) {
   const SufKey kk = key[i];
   const uint32_t lim = m - 1 < kKeyTokens ? m - 1 : kKeyTokens;
-  for (uint32_t k = 0; k < lim; k++) {
-    const uint32_t a = kk.t[k], b = ngram[k + 1];
-    if (a < b) return -1;  // smaller token, or the sentence ended (0)
-    if (a > b) return 1;
+  int r = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < kKeyTokens; k++) {
+    if (k < lim && r == 0) {
+      const uint32_t a = kk.t[k], b = ngram[k + 1];
+      r = a < b ? -1 : (a > b ? 1 : 0);  // -1: smaller token, or the sentence ended (0)
+    }
   }
-  if (m - 1 <= kKeyTokens) return 0;
+  if (r != 0 || m - 1 <= kKeyTokens) return r;
   return start_by_from(tok, suf[i], ngram, kKeyTokens + 1, m);
 }
 
@@ -236,21 +240,6 @@ FMX_HD uint32_t gram_hash(uint32_t w0, uint32_t w1, uint32_t w2) {
   return h ^ (h >> 16);
 }
 
-// start_by for tokens [from, m) with from in [3, 5]: the first `from` tokens are known to match
-FMX_HD int start_by_keyed_from(const SufKey* __restrict__ key, const SufRec* __restrict__ suf,
-                               const uint32_t* __restrict__ tok, uint32_t i, const uint32_t* __restrict__ ngram,
-                               uint32_t from, uint32_t m) {
-  const SufKey kk = key[i];
-  const uint32_t lim = m - 1 < kKeyTokens ? m - 1 : kKeyTokens;
-  for (uint32_t k = from - 1; k < lim; k++) {
-    const uint32_t a = kk.t[k], b = ngram[k + 1];
-    if (a < b) return -1;
-    if (a > b) return 1;
-  }
-  if (m - 1 <= kKeyTokens) return 0;
-  return start_by_from(tok, suf[i], ngram, kKeyTokens + 1, m);
-}
-
 // Second level: the distinct 5-grams of every trigram whose range holds more than kDeepGramMin suffixes,
 // keyed by (start of the trigram range, w3, w4).  It caps the length of the dependent-read chain of a
 // probe: without it one lane that has to bisect a 100 000-suffix trigram range keeps its whole wave waiting.
@@ -287,41 +276,86 @@ FMX_HD void bisect_equal_range(uint32_t lo, uint32_t hi, Cmp cmp, uint32_t& out_
   out_hi = b;
 }
 
+// Key tokens [from-1, lim) against the n-gram held in registers (ng[k] = ngram[k] for k < m, anything
+// beyond): -1 / 0 / 1 like start_by.  Fully unrolled, no memory access.
+FMX_HD int key_cmp(const SufKey& kk, const uint32_t (&ng)[kKeyTokens + 1], uint32_t from, uint32_t lim) {
+  int r = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < kKeyTokens; k++) {
+    const uint32_t a = kk.t[k], b = ng[k + 1];
+    const int c = a < b ? -1 : (a > b ? 1 : 0);
+    if (k + 1 >= from && k < lim && r == 0) r = c;
+  }
+  return r;
+}
+
 // mgram_range through the n-gram tables; same result as mgram_range / mgram_range_keyed.
+//
+// The probe is a chain of dependent random reads, and each level costs a full memory latency for the whole
+// wave, so the chain is kept short: the first-word bucket and the trigram entry are requested together, the
+// n-gram lives in registers, and the lower and the upper end of the equal range are bisected in lockstep
+// (two independent key loads per level) instead of one after the other.
 FMX_HD void mgram_range_hashed(const GramTables& gt, const SufKey* __restrict__ key,
                                const SufRec* __restrict__ suf, const uint32_t* __restrict__ tok,
                                const uint32_t* __restrict__ qva, uint32_t n_qva, const uint32_t* __restrict__ ngram,
                                uint32_t m, uint32_t& out_lo, uint32_t& out_hi) {
-  bool usable = gt.g3 != nullptr && m >= 3;
-  for (uint32_t k = 1; usable && k < m && k <= kKeyTokens; k++) usable = ngram[k] != 0;
+  uint32_t ng[kKeyTokens + 1];
+#pragma unroll
+  for (uint32_t k = 0; k <= kKeyTokens; k++) ng[k] = k < m ? ngram[k] : 0u;
+  bool usable = gt.g3 != nullptr && m >= 3 && n_qva >= 2;
+#pragma unroll
+  for (uint32_t k = 1; k <= kKeyTokens; k++) usable = usable && (k >= m || ng[k] != 0);
   if (!usable) { mgram_range_keyed(key, suf, tok, qva, n_qva, ngram, m, out_lo, out_hi); return; }
   out_lo = out_hi = 0;
-  const uint32_t w0 = ngram[0];
-  if (w0 + 1 >= n_qva) return;
-  const uint32_t blo = qva[w0], bhi = qva[w0 + 1];
-  if (blo >= bhi) return;
-  uint32_t slot = gram_hash(w0, ngram[1], ngram[2]) & gt.mask3;
+  const uint32_t w0 = ng[0];
+  const bool w_ok = w0 + 1 < n_qva;
+  const uint32_t wi = w_ok ? w0 : 0u;
+  uint32_t slot = gram_hash(w0, ng[1], ng[2]) & gt.mask3;
+  GramEntry e = gt.g3[slot];  // requested together with the bucket bounds
+  const uint32_t blo = qva[wi], bhi = qva[wi + 1];
+  if (!w_ok || blo >= bhi) return;
   uint32_t lo, hi;
   for (;;) {
-    const GramEntry e = gt.g3[slot];
     if (e.lo == kGramEmpty) return;  // no suffix starts with this trigram
-    if (e.w1 == ngram[1] && e.w2 == ngram[2] && e.lo >= blo && e.lo < bhi) { lo = e.lo; hi = e.lo + e.cnt; break; }
+    if (e.w1 == ng[1] && e.w2 == ng[2] && e.lo >= blo && e.lo < bhi) { lo = e.lo; hi = e.lo + e.cnt; break; }
     slot = (slot + 1) & gt.mask3;
+    e = gt.g3[slot];
   }
   if (m == 3) { out_lo = lo; out_hi = hi; return; }
+  uint32_t from = 3;
   if (m >= 5 && gt.g5 != nullptr && hi - lo > kDeepGramMin) {
-    slot = gram_hash(lo, ngram[3], ngram[4]) & gt.mask5;
+    slot = gram_hash(lo, ng[3], ng[4]) & gt.mask5;
     for (;;) {
-      const GramEntry e = gt.g5[slot];
-      if (e.lo == kGramEmpty) return;  // no suffix of this trigram continues with (w3, w4)
-      if (e.w1 == ngram[3] && e.w2 == ngram[4] && e.lo >= lo && e.lo < hi) { lo = e.lo; hi = e.lo + e.cnt; break; }
+      const GramEntry e5 = gt.g5[slot];
+      if (e5.lo == kGramEmpty) return;  // no suffix of this trigram continues with (w3, w4)
+      if (e5.w1 == ng[3] && e5.w2 == ng[4] && e5.lo >= lo && e5.lo < hi) { lo = e5.lo; hi = e5.lo + e5.cnt; break; }
       slot = (slot + 1) & gt.mask5;
     }
     if (m == 5) { out_lo = lo; out_hi = hi; return; }
-    bisect_equal_range(lo, hi, [&](uint32_t i) { return start_by_from(tok, suf[i], ngram, 5, m); }, out_lo, out_hi);
-    return;
+    from = 5;
   }
-  bisect_equal_range(lo, hi, [&](uint32_t i) { return start_by_keyed_from(key, suf, tok, i, ngram, 3, m); }, out_lo, out_hi);
+  // equal range of the remaining tokens inside [lo, hi): a1 -> first suffix >= n-gram, a2 -> first suffix > n-gram
+  const uint32_t lim = m - 1 < kKeyTokens ? m - 1 : kKeyTokens;
+  const bool deep = m - 1 > kKeyTokens;  // tokens beyond the key come from the token stream
+  uint32_t a1 = lo, b1 = hi, a2 = lo, b2 = hi;
+  while (a1 < b1 || a2 < b2) {
+    const bool act1 = a1 < b1, act2 = a2 < b2;
+    uint32_t m1 = a1 + ((b1 - a1) >> 1), m2 = a2 + ((b2 - a2) >> 1);
+    if (!act1) m1 = m2;
+    if (!act2) m2 = m1;
+    const SufKey k1 = key[m1];
+    const SufKey k2 = key[m2];
+    int c1 = key_cmp(k1, ng, from, lim);
+    int c2 = key_cmp(k2, ng, from, lim);
+    if (deep) {
+      if (c1 == 0) c1 = start_by_from(tok, suf[m1], ngram, kKeyTokens + 1, m);
+      if (c2 == 0) c2 = m2 == m1 ? c1 : start_by_from(tok, suf[m2], ngram, kKeyTokens + 1, m);
+    }
+    if (act1) { if (c1 < 0) a1 = m1 + 1; else b1 = m1; }
+    if (act2) { if (c2 <= 0) a2 = m2 + 1; else b2 = m2; }
+  }
+  out_lo = a1;
+  out_hi = a2 > a1 ? a2 : a1;
 }
 
 // Longest common prefix of a suffix (already known to share `known` tokens) with pat[0..maxlen).

@@ -153,7 +153,7 @@ void DeviceIndex::upload(const HostIndex& h, int device) {
   uint32_t mx = 0;
   for (uint32_t sp : h.sent_pos) mx = std::max(mx, h.buf[sp]);
   m.d.max_slen = mx;
-  m.bytes = h.suf_rec.size() * 8 + h.suf_sig.size() * 8 + h.suf_key.size() * 16 + h.gram.size() * 16 + h.gram5.size() * 16 + h.suf_b.size() * 16 + h.buf.size() * 4 + h.sent_pos.size() * 4 +
+  m.bytes = h.suf_rec.size() * 8 + h.suf_sig.size() * 8 + h.suf_key.size() * sizeof(SufKey) + h.gram.size() * 16 + h.gram5.size() * 16 + h.suf_b.size() * 16 + h.buf.size() * 4 + h.sent_pos.size() * 4 +
             h.qva.size() * 4 + h.idf.size() * 4;
   if (h.real_differs) {
     m.d.real = dev_upload(h.real_ids);

@@ -47,7 +47,7 @@ class HostIndex {
   // ---- derived (derive()) ----
   std::vector<SufRec>   suf_rec;   // one 8-byte record per suffix, suffix-array order
   std::vector<uint64_t> suf_sig;   // sentence length << 48 | 48-bit word signature of the suffix's sentence
-  std::vector<SufKey>   suf_key;   // the four tokens after each suffix's first token (0-padded)
+  std::vector<SufKey>   suf_key;   // the eight tokens after each suffix's first token (0-padded)
   std::vector<SufRecB>  suf_b;     // phase-B record: SufRec + previous token + sentence id
   std::vector<GramEntry> gram;     // trigram -> suffix range hash table (power-of-two size, empty if tiny index)
   std::vector<GramEntry> gram5;    // (trigram range start, w3, w4) -> 5-gram range, for trigrams with > kDeepGramMin suffixes

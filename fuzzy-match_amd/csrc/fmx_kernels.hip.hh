@@ -19,7 +19,7 @@ namespace fmx {
 struct DevIndex {
   const SufRec*   suf;
   const unsigned long long* suf_sig;  // sentence length << 48 | 48-bit word signature
-  const SufKey*   suf_key;    // four tokens after the first, per suffix
+  const SufKey*   suf_key;    // eight tokens after the first, per suffix
   GramTables      gram;       // trigram table + 5-gram table of the heavy trigrams (null if absent)
   const SufRecB*  suf_b;      // phase-B record: SufRec + previous token + sentence id
   const uint32_t* tok;

@@ -18,7 +18,7 @@ ARRAYS = {
     "suf_sid": (0, np.uint32), "suf_pos": (1, np.uint16), "buffer": (2, np.uint32),
     "sent_pos": (3, np.uint32), "qva": (4, np.uint32), "sfreq": (5, np.uint32),
     "suf_rec": (6, np.uint64), "idf": (7, np.float32), "real_ids": (8, np.uint32),
-    "itok_ids": (9, np.uint32), "itok_dist": (10, np.uint16), "suf_sig": (11, np.uint64), "suf_key": (12, np.dtype([("t", np.uint32, 4)])),
+    "itok_ids": (9, np.uint32), "itok_dist": (10, np.uint16), "suf_sig": (11, np.uint64), "suf_key": (12, np.dtype([("t", np.uint32, 8)])),
     "gram": (13, np.dtype([("w1", np.uint32), ("w2", np.uint32), ("lo", np.uint32), ("cnt", np.uint32)])),
     "suf_b": (15, np.dtype([("off", np.uint32), ("rem", np.uint16), ("slen", np.uint16), ("prev", np.uint32), ("sid", np.uint32)])),
     "gram5": (14, np.dtype([("w1", np.uint32), ("w2", np.uint32), ("lo", np.uint32), ("cnt", np.uint32)])),
