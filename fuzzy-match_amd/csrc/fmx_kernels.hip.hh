@@ -257,6 +257,14 @@ __global__ void k_caps(DevBatch b, DevWork w, WorkItem* items, uint32_t item_cap
 // PatternCoverage::count_covered_words (src/pattern_coverage.cc:15-28) with the pattern broadcast
 // from LDS: each lane walks its own sentence once per 64 pattern positions and marks the positions
 // whose word it sees; the marked count equals the reference's sum of per-word counts.
+// A wave-uniform value loaded through the vector memory path, moved to scalar registers (frees VGPRs and
+// lets address arithmetic on it run on the scalar unit).
+__device__ __forceinline__ uint32_t uni(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ unsigned long long uni(unsigned long long x) {
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)x), hi = __builtin_amdgcn_readfirstlane((uint32_t)(x >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+
 // Ordering point for LDS traffic inside a single-wave workgroup: the LDS executes one wave's requests in
 // program order, so only the compiler has to be kept from moving accesses across; no memory-counter wait and
 // no s_barrier (outstanding global loads stay in flight, unlike __syncthreads()).
@@ -425,19 +433,20 @@ __global__ void __launch_bounds__(kWave, 8) k_expand_a(DevIndex ix, DevBatch b, 
       unsigned long long n_items = w.counters[5];
       if (n_items > item_cap) n_items = item_cap;
       if (item_idx >= n_items) return;
-      q = items[item_idx].q;
-      chunk = items[item_idx].chunk;
+      // wave-uniform by construction: keep everything derived from them in scalar registers
+      q = __builtin_amdgcn_readfirstlane(items[item_idx].q);
+      chunk = __builtin_amdgcn_readfirstlane(items[item_idx].chunk);
     }
-    const uint32_t msl = w.q_m[q];
-    const unsigned long long hits = msl == kNoMatchLen ? 0ull : w.q_hits[q];
+    const uint32_t msl = uni(w.q_m[q]);
+    const unsigned long long hits = msl == kNoMatchLen ? 0ull : uni(w.q_hits[q]);
     if (hits != 0) {
-      const unsigned long long seg0 = w.q_seg[q];
-      const uint32_t cap = (uint32_t)(w.q_seg[q + 1] - seg0);
+      const unsigned long long seg0 = uni(w.q_seg[q]);
+      const uint32_t cap = (uint32_t)(uni(w.q_seg[q + 1]) - seg0);
       if (seg0 + cap > w.seg_cap) {  // workspace too small: host re-runs the sub-batch with a larger one
         if (lane == 0) atomicMax(&w.counters[6], w.q_seg[b.nq]);
       } else {
-        const uint32_t o0 = b.q_off[b.q_begin + q];
-        const uint32_t p = b.q_off[b.q_begin + q + 1] - o0;
+        const uint32_t o0 = uni(b.q_off[b.q_begin + q]);
+        const uint32_t p = uni(b.q_off[b.q_begin + q + 1]) - o0;
         const uint32_t* pat = b.q_tok + o0;
         const uint32_t t0 = o0 - b.t_begin;
         __syncthreads();
@@ -506,8 +515,8 @@ __global__ void __launch_bounds__(kWave, 8) k_expand_a(DevIndex ix, DevBatch b, 
           if (lane == 0) s_npref[n_nz] = total;
           __syncthreads();
           // hits [base_h, base_h + total) belong to this block of start positions; clip to the chunk
-          const unsigned long long a0 = h_lo > base_h ? h_lo - base_h : 0ull;
-          const unsigned long long a1 = h_hi - base_h < total ? h_hi - base_h : (unsigned long long)total;
+          const uint32_t a0 = h_lo > base_h ? (uint32_t)(h_lo - base_h) : 0u;  // both <= total (32 bits)
+          const uint32_t a1 = h_hi - base_h < total ? (uint32_t)(h_hi - base_h) : total;
           uint32_t k = 0;  // this lane's current start position (index into the compacted list)
           // One hit, branch-free per lane: the tabulated threshold of the sentence length (0xffff = rejected
           // by the length filter, 0 = length outside the table: phase B evaluates everything) against the
@@ -542,11 +551,11 @@ __global__ void __launch_bounds__(kWave, 8) k_expand_a(DevIndex ix, DevBatch b, 
               }
             }
           };
-          for (unsigned long long hh = a0; hh < a1; hh += kWave * kUnroll) {
+          for (uint32_t hh = a0; hh < a1; hh += kWave * kUnroll) {
             // kUnroll hits per lane as kUnroll/2 pairs of consecutive hits: inside a range the pair is one
             // 16-byte load (8-byte loads reach only ~0.6 of the streaming rate), and all loads of the
             // iteration are in flight before the first is consumed
-            const uint32_t blk_end = hh + kWave * kUnroll < a1 ? (uint32_t)hh + kWave * kUnroll : (uint32_t)a1;
+            const uint32_t blk_end = a1 - hh > kWave * kUnroll ? hh + kWave * kUnroll : a1;
             uint32_t k0 = __builtin_amdgcn_readfirstlane(k);
             while (s_npref[k0 + 1] <= (uint32_t)hh) k0++;
             if (s_npref[k0 + 1] >= blk_end) {
@@ -664,17 +673,18 @@ __global__ void __launch_bounds__(kWave, 8) k_expand_b(DevIndex ix, DevBatch b, 
       unsigned long long n_items = w.counters[12];
       if (n_items > item_cap) n_items = item_cap;
       if (item_idx >= n_items) return;
-      q = items[item_idx].q;
-      chunk = items[item_idx].chunk;
+      // wave-uniform by construction: keep everything derived from them in scalar registers
+      q = __builtin_amdgcn_readfirstlane(items[item_idx].q);
+      chunk = __builtin_amdgcn_readfirstlane(items[item_idx].chunk);
     }
     // The kernel is a chain of dependent memory latencies per query (most queries queue a few dozen hits),
     // so everything that can be requested together is: level 1 = all per-query scalars.
-    const unsigned long long seg0 = w.q_seg[q];
-    const unsigned long long seg1 = w.q_seg[q + 1];
-    const uint32_t n_q = w.q_pb[q];
-    const uint32_t msl = w.q_m[q];
-    const uint32_t o0 = b.q_off[b.q_begin + q];
-    const uint32_t p = b.q_off[b.q_begin + q + 1] - o0;
+    const unsigned long long seg0 = uni(w.q_seg[q]);
+    const unsigned long long seg1 = uni(w.q_seg[q + 1]);
+    const uint32_t n_q = uni(w.q_pb[q]);
+    const uint32_t msl = uni(w.q_m[q]);
+    const uint32_t o0 = uni(b.q_off[b.q_begin + q]);
+    const uint32_t p = uni(b.q_off[b.q_begin + q + 1]) - o0;
     const uint32_t cap = (uint32_t)(seg1 - seg0);
     if (n_q != 0 && n_q <= cap && seg0 + cap <= w.seg_cap) {
       const uint32_t m = seed_len(p, msl);
