@@ -90,7 +90,7 @@ DeviceIndex::DeviceIndex() : impl_(new Impl) {}
 
 static void free_ws(DeviceIndex::Impl& m) {
   hipFree(m.w.q_m); hipFree(m.w.t_q); hipFree(m.w.t_lo); hipFree(m.w.t_cnt); hipFree(m.w.q_hits);
-  hipFree(m.w.q_seg); hipFree(m.w.q_kept); hipFree(m.w.q_cand); hipFree(m.w.q_acc); hipFree(m.w.q_pb); hipFree(m.w.q_aux); hipFree(m.w.c_in); hipFree(m.w.c_off); hipFree(m.w.t_idf); hipFree(m.w.c_qi); hipFree(m.big_list); m.big_list = nullptr; hipFree(m.mid_list); m.mid_list = nullptr; hipFree(m.fin_list); m.fin_list = nullptr; hipFree(m.contrast_list); m.contrast_list = nullptr;
+  hipFree(m.w.q_seg); hipFree(m.w.q_kept); hipFree(m.w.q_cand); hipFree(m.w.q_acc); hipFree(m.w.q_pb); hipFree(m.w.q_aux); hipFree(m.w.q_rank); hipFree(m.w.p_hist); hipFree(m.w.c_in); hipFree(m.w.c_off); hipFree(m.w.t_idf); hipFree(m.w.c_qi); hipFree(m.big_list); m.big_list = nullptr; hipFree(m.mid_list); m.mid_list = nullptr; hipFree(m.fin_list); m.fin_list = nullptr; hipFree(m.contrast_list); m.contrast_list = nullptr;
   hipFree(m.w.seg); hipFree(m.w.qb); hipFree(m.w.heap); hipFree(m.w.counters);
   hipFree(m.sc.keys); hipFree(m.sc.vals); hipFree(m.sc.f0); hipFree(m.sc.f1);
   hipFree(m.tile_sums); hipFree(m.grand_total); hipFree(m.w.q_cap);
@@ -182,6 +182,8 @@ static void ensure_ws(DeviceIndex::Impl& m, uint64_t nq, uint64_t nt, uint64_t s
     m.w.q_acc = dev_alloc<uint32_t>(cq);
     m.w.q_pb = dev_alloc<uint32_t>(cq);
     m.w.q_aux = dev_alloc<uint32_t>(cq);
+    m.w.q_rank = dev_alloc<uint32_t>(cq);
+    m.w.p_hist = dev_alloc<uint32_t>(2 * kPBins);
     m.w.c_in = dev_alloc<unsigned long long>(3 * (cq + 1));
     m.w.c_off = dev_alloc<unsigned long long>(3 * (cq + 1));
     m.w.t_idf = dev_alloc<float>(ct);
@@ -247,6 +249,12 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm_in, const D
       auto tick = [&]() { HIP_TRY(hipEventRecord(m.ev[e++], stream)); };
       tick();
       hipLaunchKernelGGL(k_setup, dim3((b.nq + 255) / 256), dim3(256), 0, stream, m.d, b, w, prm);
+      HIP_TRY(hipMemsetAsync(w.p_hist, 0, 2 * kPBins * sizeof(uint32_t), stream));
+      {
+        const uint32_t per_block = kRankThreads * kRankPer;
+        hipLaunchKernelGGL(k_phist, dim3((b.nq + per_block - 1) / per_block), dim3(kRankThreads), 0, stream, b, w);
+        hipLaunchKernelGGL(k_prank, dim3((b.nq + per_block - 1) / per_block), dim3(kRankThreads), 0, stream, b, w);
+      }
       tick(); tick();
       if (b.nt) hipLaunchKernelGGL(k_probe, dim3((b.nt + 255) / 256), dim3(256), 0, stream, m.d, b, w);
       tick(); tick();

@@ -62,6 +62,8 @@ struct DevWork {
   uint32_t* q_acc;      // nq
   uint32_t* q_pb;       // nq   hits queued by k_expand_a for k_expand_b
   uint32_t* q_aux;      // nq   contrastive rerank: the match picked last
+  uint32_t* q_rank;     // nq   position of the query in pattern-length order (DP lists are built in that order)
+  uint32_t* p_hist;     // 2 x kPBins: queries per pattern length, then the placement cursors
   unsigned long long* c_in;    // 3 x (nq+1) candidates per query, one array per length class (scan input)
   unsigned long long* c_off;   // 3 x (nq+1) exclusive scans: dense per-class candidate lists
   unsigned long long* c_qi;    // seg_cap  (query << 32 | candidate index), dense per length class
@@ -1127,6 +1129,56 @@ __global__ void __launch_bounds__(kBigThreads) k_cand_big(DevWork w, unsigned lo
 // runs with full waves: class 0 = up to 32 pattern tokens (row in 32 registers), 1 = up to 64, 2 = longer
 // or any query that needs the FULL cost model (rows in LDS).  k_classify feeds three scans; k_cmap then
 // writes (query, candidate index) pairs, class 0 first, class 1 after it, class 2 last.
+// Pattern-length order of the queries.  The DP candidate lists are laid out in this order, so the 64
+// consecutive candidates of a wave almost always share one pattern length and the register DP can run the
+// variant compiled for exactly that length (no padding columns, no per-column guards).
+constexpr uint32_t kPBins = 66;  // lengths 0..64 one bin each, longer patterns the last bin
+__device__ __forceinline__ uint32_t p_bin(uint32_t p) { return p < kPBins - 1 ? p : kPBins - 1; }
+
+constexpr uint32_t kRankThreads = 1024, kRankPer = 4;  // queries per block = 4096: few global atomics per bin
+
+__global__ void __launch_bounds__(kRankThreads) k_phist(DevBatch b, DevWork w) {
+  __shared__ uint32_t s_h[kPBins];
+  if (threadIdx.x < kPBins) s_h[threadIdx.x] = 0;
+  __syncthreads();
+#pragma unroll
+  for (uint32_t u = 0; u < kRankPer; u++) {
+    const uint32_t q = (blockIdx.x * kRankPer + u) * kRankThreads + threadIdx.x;
+    if (q < b.nq) atomicAdd(&s_h[p_bin(b.q_off[b.q_begin + q + 1] - b.q_off[b.q_begin + q])], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < kPBins && s_h[threadIdx.x]) atomicAdd(&w.p_hist[threadIdx.x], s_h[threadIdx.x]);
+}
+
+__global__ void __launch_bounds__(kRankThreads) k_prank(DevBatch b, DevWork w) {
+  __shared__ uint32_t s_cnt[kPBins], s_base[kPBins];
+  if (threadIdx.x < kPBins) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  uint32_t bin[kRankPer], local[kRankPer];
+#pragma unroll
+  for (uint32_t u = 0; u < kRankPer; u++) {
+    const uint32_t q = (blockIdx.x * kRankPer + u) * kRankThreads + threadIdx.x;
+    bin[u] = 0; local[u] = 0;
+    if (q < b.nq) {
+      bin[u] = p_bin(b.q_off[b.q_begin + q + 1] - b.q_off[b.q_begin + q]);
+      local[u] = atomicAdd(&s_cnt[bin[u]], 1u);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < kPBins) {
+    uint32_t base = 0;
+    for (uint32_t k = 0; k < threadIdx.x; k++) base += w.p_hist[k];
+    const uint32_t mine = s_cnt[threadIdx.x];
+    s_base[threadIdx.x] = base + (mine ? atomicAdd(&w.p_hist[kPBins + threadIdx.x], mine) : 0u);
+  }
+  __syncthreads();
+#pragma unroll
+  for (uint32_t u = 0; u < kRankPer; u++) {
+    const uint32_t q = (blockIdx.x * kRankPer + u) * kRankThreads + threadIdx.x;
+    if (q < b.nq) w.q_rank[q] = s_base[bin[u]] + local[u];  // order inside one length is irrelevant
+  }
+}
+
 __device__ __forceinline__ uint32_t dp_class(uint32_t p, int full) { return full ? 2u : (p <= 32 ? 0u : (p <= 64 ? 1u : 2u)); }
 
 __global__ void k_classify(DevBatch b, DevWork w, int full) {
@@ -1138,7 +1190,8 @@ __global__ void k_classify(DevBatch b, DevWork w, int full) {
     v[dp_class(p, full)] = w.q_cand[q];
   }
   const size_t stride = (size_t)b.nq + 1;
-  w.c_in[q] = v[0]; w.c_in[stride + q] = v[1]; w.c_in[2 * stride + q] = v[2];
+  const uint32_t r = q < b.nq ? w.q_rank[q] : b.nq;  // list position: pattern-length order
+  w.c_in[r] = v[0]; w.c_in[stride + r] = v[1]; w.c_in[2 * stride + r] = v[2];
 }
 
 __global__ void __launch_bounds__(kWave) k_cmap(DevBatch b, DevWork w, int full) {
@@ -1148,7 +1201,7 @@ __global__ void __launch_bounds__(kWave) k_cmap(DevBatch b, DevWork w, int full)
   const size_t stride = (size_t)b.nq + 1;
   const uint32_t p = b.q_off[b.q_begin + q + 1] - b.q_off[b.q_begin + q];
   const uint32_t cls = dp_class(p, full);
-  unsigned long long base = w.c_off[cls * stride + q];
+  unsigned long long base = w.c_off[cls * stride + w.q_rank[q]];
   if (cls >= 1) base += w.c_off[b.nq];
   if (cls >= 2) base += w.c_off[stride + b.nq];
   for (uint32_t i = lane_id(); i < n; i += kWave) w.c_qi[base + i] = ((unsigned long long)q << 32) | i;
@@ -1230,7 +1283,7 @@ __global__ void __launch_bounds__(kWave) k_dp(DevIndex ix, DevBatch b, DevWork w
 // (dependencies only run left to right), and no LDS or memory access remains in the cell update.
 // Same operations in the same order as edit_distance<false>, so the results are bit-identical.
 // ---------------------------------------------------------------------------------------------
-template <int P, bool IDF = false>
+template <int P, bool IDF = false, bool EXACT = false>
 __device__ __forceinline__ float edit_distance_reg(const uint32_t* __restrict__ sent, uint32_t n1,
                                                    const uint32_t* __restrict__ pat, uint32_t n2, float ins,
                                                    float del, float rep, float dw, float& M_out,
@@ -1241,8 +1294,8 @@ __device__ __forceinline__ float edit_distance_reg(const uint32_t* __restrict__ 
   float    pen[IDF ? P : 1];
 #pragma unroll
   for (int j = 0; j < P; j++) {
-    pt[j] = (uint32_t)j < n2 ? pat[j] : 0xffffffffu;
-    if (IDF) pen[j] = (uint32_t)j < n2 ? p_idf[j] * idf_weight : 0.f;  // idf_penalty[j] * idf_weight, edit_distance.cc:36,49
+    pt[j] = (EXACT || (uint32_t)j < n2) ? pat[j] : 0xffffffffu;  // EXACT: n2 == P for every lane of the wave
+    if (IDF) pen[j] = (EXACT || (uint32_t)j < n2) ? p_idf[j] * idf_weight : 0.f;  // idf_penalty[j] * idf_weight, edit_distance.cc:36,49
   }
   row[0] = 0.f;
 #pragma unroll
@@ -1273,8 +1326,13 @@ __device__ __forceinline__ float edit_distance_reg(const uint32_t* __restrict__ 
       const float d = __builtin_fminf(__builtin_fminf(up + del_dw, bb), diag + diff);
       row[j] = d;
       const float mn2 = __builtin_fminf(mn, d);
-      mn = (uint32_t)j <= n2 ? mn2 : mn;
-      final_v = (uint32_t)j == n2 ? d : final_v;
+      if (EXACT) {
+        mn = mn2;
+        if (j == P) final_v = d;
+      } else {
+        mn = (uint32_t)j <= n2 ? mn2 : mn;
+        final_v = (uint32_t)j == n2 ? d : final_v;
+      }
       diag = up;
       left = d;
     }
@@ -1283,6 +1341,22 @@ __device__ __forceinline__ float edit_distance_reg(const uint32_t* __restrict__ 
   if (final_v > M) M = final_v;
   M_out = M;
   return final_v;
+}
+
+// Dispatch on the wave's common pattern length: the variant compiled for exactly that length.
+template <int LO, int HI, bool IDF>
+__device__ __forceinline__ float edit_distance_exact_dispatch(uint32_t p_u, const uint32_t* __restrict__ sent, uint32_t n1,
+                                                              const uint32_t* __restrict__ pat, float ins, float del,
+                                                              float rep, float dw, float& M, const float* p_idf,
+                                                              float idf_weight) {
+  if constexpr (LO == HI) {
+    return edit_distance_reg<LO, IDF, true>(sent, n1, pat, (uint32_t)LO, ins, del, rep, dw, M, p_idf, idf_weight);
+  } else {
+    constexpr int MID = (LO + HI) / 2;
+    if (p_u <= (uint32_t)MID)
+      return edit_distance_exact_dispatch<LO, MID, IDF>(p_u, sent, n1, pat, ins, del, rep, dw, M, p_idf, idf_weight);
+    return edit_distance_exact_dispatch<MID + 1, HI, IDF>(p_u, sent, n1, pat, ins, del, rep, dw, M, p_idf, idf_weight);
+  }
 }
 
 template <int P, bool IDF>
@@ -1303,10 +1377,16 @@ __global__ void __launch_bounds__(kWave) k_dp_reg(DevIndex ix, DevBatch b, DevWo
     const uint32_t slen = ix.tok[sp];
     const uint32_t* sent = ix.tok + sp + 1;
     const float dw = 100.f / normalizer(p, slen, prm.ins, prm.del, prm.rep);
-    float M;
-    const float final_cost = edit_distance_reg<P, IDF>(sent, slen, pat, p, prm.ins, prm.del, prm.rep, dw, M,
-                                                       w.t_idf + (o0 - b.t_begin),
-                                                       (dw * prm.idf_penalty) / prm.idf_max);  // src/fuzzy_match.cc:591
+    const float* p_idf = w.t_idf + (o0 - b.t_begin);
+    const float idf_weight = (dw * prm.idf_penalty) / prm.idf_max;  // src/fuzzy_match.cc:591
+    float M, final_cost;
+    // the list is in pattern-length order: all active lanes of a wave normally share one length
+    const uint32_t p_u = __builtin_amdgcn_readfirstlane(p);
+    if (__ballot(p != p_u) == 0ull)
+      final_cost = edit_distance_exact_dispatch<(P == 32 ? 1 : 33), P, IDF>(p_u, sent, slen, pat, prm.ins, prm.del, prm.rep,
+                                                                          dw, M, p_idf, idf_weight);
+    else
+      final_cost = edit_distance_reg<P, IDF>(sent, slen, pat, p, prm.ins, prm.del, prm.rep, dw, M, p_idf, idf_weight);
     cd->score = final_cost;
     cd->penalty = M;
     cd->longest = (cd->longest & 0xffffu) | (slen << 16);
