@@ -397,10 +397,16 @@ FMX_HD bool dominated_hit_b(const SufRecB& r, const uint32_t* __restrict__ pat_a
 // PatternCoverage::count_covered_words, and theoretical_rejection_cover is monotone in the cover
 // (for non-negative costs), so a candidate rejected with the upper bound is rejected by the
 // reference too: the exact token scan only runs for the few that pass.
-constexpr uint32_t kSigBits = 48;  // the other 16 bits of the packed word hold the sentence length
+// Packed word: [ sentence length : 8, 255 = "255 tokens or more" | signature : 56 ].  The signature's false
+// positive rate falls quickly with the number of buckets (queued hits at C3: 40 buckets 2.5x, 48 buckets
+// 1x), so the length gets only the bits the length filter needs; clamped lengths are decided in phase B.
+constexpr uint32_t kSigBits = 56;
+constexpr uint32_t kSigLenClamp = 255;
 FMX_HD uint32_t sig_bit(uint32_t w) { return (uint32_t)(((unsigned long long)(w * 0x9E3779B1u) * kSigBits) >> 32); }
-FMX_HD unsigned long long sig_pack(uint32_t slen, unsigned long long sig) { return ((unsigned long long)slen << kSigBits) | sig; }
-FMX_HD uint32_t sig_slen(unsigned long long packed) { return (uint32_t)(packed >> kSigBits); }
+FMX_HD unsigned long long sig_pack(uint32_t slen, unsigned long long sig) {
+  return ((unsigned long long)(slen < kSigLenClamp ? slen : kSigLenClamp) << kSigBits) | sig;
+}
+FMX_HD uint32_t sig_slen(unsigned long long packed) { return (uint32_t)(packed >> kSigBits); }  // clamped at 255
 FMX_HD unsigned long long sig_bits(unsigned long long packed) { return packed & ((1ull << kSigBits) - 1ull); }
 
 FMX_HD uint32_t sig_cover_upper(unsigned long long sig, const uint8_t* __restrict__ hbit, uint32_t p) {

@@ -271,7 +271,7 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm_in, const D
       {
         // the signature bound needs theoretical_rejection_cover to be monotone in the cover: costs >= 0
         const int use_sig = prm.ins >= 0.f && prm.del >= 0.f && prm.rep >= 0.f;
-        hipLaunchKernelGGL(k_expand_a, dim3(b.nq + kExpandExtraGrid), dim3(kWave), ((m.d.max_slen + 1 < kCminTab ? m.d.max_slen + 1 : kCminTab) + 1) * 2, stream, m.d, b, w, prm,
+        hipLaunchKernelGGL(k_expand_a, dim3(b.nq + kExpandExtraGrid), dim3(kWave), 0, stream, m.d, b, w, prm,
                            (const WorkItem*)m.items, m.item_cap, use_sig);
         hipLaunchKernelGGL(k_caps_b, dim3((b.nq + 255) / 256), dim3(256), 0, stream, b, w, m.items_b, m.item_cap);
         const size_t lds = (size_t)p_max * 4;

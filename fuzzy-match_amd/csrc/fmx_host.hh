@@ -46,7 +46,7 @@ class HostIndex {
 
   // ---- derived (derive()) ----
   std::vector<SufRec>   suf_rec;   // one 8-byte record per suffix, suffix-array order
-  std::vector<uint64_t> suf_sig;   // sentence length << 48 | 48-bit word signature of the suffix's sentence
+  std::vector<uint64_t> suf_sig;   // sentence length (8 bits, clamped) << 56 | 56-bit word signature of the suffix's sentence
   std::vector<SufKey>   suf_key;   // the eight tokens after each suffix's first token (0-padded)
   std::vector<SufRecB>  suf_b;     // phase-B record: SufRec + previous token + sentence id
   std::vector<GramEntry> gram;     // trigram -> suffix range hash table (power-of-two size, empty if tiny index)

@@ -18,7 +18,7 @@ namespace fmx {
 
 struct DevIndex {
   const SufRec*   suf;
-  const unsigned long long* suf_sig;  // sentence length << 48 | 48-bit word signature
+  const unsigned long long* suf_sig;  // sentence length (8 bits, clamped) << 56 | 56-bit word signature
   const SufKey*   suf_key;    // eight tokens after the first, per suffix
   GramTables      gram;       // trigram table + 5-gram table of the heavy trigrams (null if absent)
   const SufRecB*  suf_b;      // phase-B record: SufRec + previous token + sentence id
@@ -293,7 +293,7 @@ __device__ __forceinline__ uint32_t cover_lds(const uint32_t* __restrict__ sent,
   return cover;
 }
 
-constexpr uint32_t kCminTab = 1024;   // sentence lengths covered by the per-query threshold table
+constexpr uint32_t kCminTab = 256;    // one entry per stored sentence length (8 bits, the last = "255 or longer")
 constexpr uint32_t kMaxPlanes = 8;    // bit planes of the per-bucket position counts (counts < 256)
 
 // Per-work-item hash set of the pattern's distinct words (p <= 64): slot -> distinct index, and the number
@@ -413,12 +413,10 @@ struct QHit {
 // The ~2.5 % that pass are compacted through an LDS ring and appended, 64 at a time with one atomic, to
 // the query's queue for k_expand_b.  The kernel is deliberately small (few registers, no token access):
 // it is bound by HBM latency, so what matters is how many waves are resident.
-// Dynamic LDS: cmin[tab_n + 1] u16, tab_n = min(max_slen + 1, kCminTab).
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kWave, 8) k_expand_a(DevIndex ix, DevBatch b, DevWork w, Params prm,
                                                     const WorkItem* items, uint32_t item_cap, int use_sig) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  uint16_t* s_cmin = (uint16_t*)smem;
+  __shared__ uint16_t s_cmin[kCminTab];    // per stored sentence length: minimal cover, 0xffff = rejected, 0 = phase B decides
   __shared__ uint32_t s_npref[kWave + 1];  // exclusive hit prefix of the non-empty start positions
   __shared__ uint32_t s_nlo[kWave];
   __shared__ uint32_t s_nit[kWave];
@@ -456,14 +454,13 @@ __global__ void __launch_bounds__(kWave, 8) k_expand_a(DevIndex ix, DevBatch b, 
         s_bucket[lane] = 0;
         __syncthreads();
         for (uint32_t j = lane; j < p; j += kWave) atomicAdd(&s_bucket[sig_bit(pat[j])], 1u);
-        const uint32_t tab_n = ix.max_slen + 1 < kCminTab ? ix.max_slen + 1 : kCminTab;
-        for (uint32_t sl = lane; sl < tab_n; sl += kWave) {
+        for (uint32_t sl = lane; sl < kCminTab; sl += kWave) {
           // the length filter first (one evaluation); the threshold search only for lengths that pass it
-          uint32_t c = reject_len(p, sl, prm) ? 0xffffu : kNeedExact;
-          if (c == kNeedExact && use_sig) c = cover_threshold(p, sl, prm);
+          uint32_t c = 0xffffu;
+          if (sl == kSigLenClamp) c = ix.max_slen >= kSigLenClamp ? 0u : 0xffffu;  // clamped lengths: phase B decides
+          else if (sl <= ix.max_slen && !reject_len(p, sl, prm)) c = use_sig ? cover_threshold(p, sl, prm) : kNeedExact;
           s_cmin[sl] = (uint16_t)c;
         }
-        if (lane == 0) s_cmin[tab_n] = 0;  // lengths outside the table: always queued, phase B decides
         __syncthreads();
         unsigned long long planes[kMaxPlanes];
         uint32_t n_planes = 0;
@@ -524,8 +521,7 @@ __global__ void __launch_bounds__(kWave, 8) k_expand_a(DevIndex ix, DevBatch b, 
           // by the length filter, 0 = length outside the table: phase B evaluates everything) against the
           // upper bound of the cover from the word signature.  No token is touched for most hits.
           auto test = [&](bool valid, unsigned long long pk, uint32_t& cmin) -> bool {
-            const uint32_t sl = sig_slen(pk);
-            cmin = s_cmin[sl < tab_n ? sl : tab_n];
+            cmin = s_cmin[sig_slen(pk)];
             const unsigned long long sig = sig_bits(pk);
             uint32_t ub = (uint32_t)__popcll(sig & planes[0]) | ub_or;
             if (n_planes > 1) {

@@ -147,7 +147,7 @@ typedef enum fmx_array {
   FMX_A_REAL_IDS = 8,  /* u32  per buffer slot, empty when real tokens == normalised tokens */
   FMX_A_ITOK_IDS = 9,  /* u32  per buffer slot */
   FMX_A_ITOK_DIST = 10,/* u16  n_itok x n_itok */
-  FMX_A_SUF_SIG = 11,  /* u64  x n_suffixes   sentence length << 48 | 48-bit word signature (derived) */
+  FMX_A_SUF_SIG = 11,  /* 8 B x n_suffixes    min(sentence length, 255) << 56 | 56-bit word signature of the sentence (derived) */
   FMX_A_SUF_KEY = 12,  /* 32 B x n_suffixes   the eight tokens after the suffix's first token (derived) */
   FMX_A_GRAM = 13,     /* 16 B x 2^k          trigram -> suffix range hash table {w1, w2, lo, cnt} (derived) */
   FMX_A_GRAM5 = 14,    /* 16 B x 2^k          5-gram table of the heavy trigrams {w3, w4, lo, cnt} (derived) */

@@ -55,13 +55,19 @@ extern "C" int emul_match_batch(const EmulIndex* ix, const Params* prm_in, uint6
         const SufRec r = ix->suf[i];
         // phase A reads only the packed (sentence length, signature) word
         const unsigned long long packed = ix->suf_sig[i];
-        const uint32_t sl = sig_slen(packed);
-        if (sl != r.slen) return -2;
-        if (reject_len(p, sl, prm)) continue;
+        if (sig_slen(packed) != (r.slen < kSigLenClamp ? r.slen : kSigLenClamp)) return -2;
+        const bool clamped = sig_slen(packed) == kSigLenClamp;  // the kernel's table entry 0: phase B evaluates everything
+        const uint32_t sl = r.slen;
+        if (!clamped && reject_len(p, sl, prm)) continue;
         // the kernel tabulates cover_threshold per sentence length and compares the signature's upper bound
-        const uint32_t cmin = use_sig ? cover_threshold(p, sl, prm) : 0u;
-        if (use_sig && (cmin == 0xffffu || sig_cover_upper(sig_bits(packed), hbit.data(), p) < cmin)) continue;
+        uint32_t cmin = (use_sig && !clamped) ? cover_threshold(p, sl, prm) : 0u;
+        if (use_sig && !clamped && (cmin == 0xffffu || sig_cover_upper(sig_bits(packed), hbit.data(), p) < cmin)) continue;
         if (stats) stats[4]++;  // queued for phase B
+        if (clamped) {
+          if (reject_len(p, sl, prm)) continue;
+          cmin = use_sig ? cover_threshold(p, sl, prm) : 0u;
+          if (use_sig && cmin == 0xffffu) continue;
+        }
         const SufRecB rb = ix->suf_b[i];
         if (rb.off != r.off || rb.rem != r.rem || rb.slen != r.slen) return -3;
         if (dominated_hit_b(rb, pat + it, it) != dominated_hit(ix->tok, r, pat + it, it)) return -4;
