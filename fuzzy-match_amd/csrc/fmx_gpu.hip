@@ -302,7 +302,7 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm_in, const D
           hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanThreads), 0, stream, m.tile_sums, tiles, m.grand_total);
           hipLaunchKernelGGL(k_scan_add, dim3(tiles), dim3(kScanThreads), 0, stream, w.c_off + (size_t)c * n, m.tile_sums, n);
         }
-        hipLaunchKernelGGL(k_cmap, dim3(b.nq), dim3(kWave), 0, stream, b, w, full ? 1 : 0);
+        hipLaunchKernelGGL(k_cmap, dim3((b.nq + 255) / 256), dim3(256), 0, stream, b, w, full ? 1 : 0);
       }
       tick(); tick();
       {

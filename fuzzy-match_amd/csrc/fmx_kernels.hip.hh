@@ -380,6 +380,10 @@ constexpr uint32_t kQueue = 256;  // LDS ring of hits that passed the cheap test
 constexpr uint32_t kPhaseBChunk = 1024;  // queued hits per k_expand_b work item
 constexpr uint32_t kNeedExact = 0xfffeu; // "no tabulated threshold": phase B evaluates the bound itself
 
+// q_kept flag: phase B already reduced the query's survivors to candidates (k_cand has nothing to do)
+constexpr uint32_t kKeptReduced = 0x80000000u;
+__device__ __forceinline__ unsigned long long wave_sort64(unsigned long long key);
+
 constexpr int kBUnroll = 2;  // queued hits per lane per phase-B block (their records are loaded together)
 
 // a queued hit that passed phase B's dominance test, waiting in LDS for the token work
@@ -660,6 +664,7 @@ __global__ void __launch_bounds__(kWave, 8) k_expand_b(DevIndex ix, DevBatch b, 
   uint32_t* s_pat = (uint32_t*)smem;
   __shared__ PatHash ph;
   __shared__ SurvB s_surv[kWave * (kBUnroll + 1)];
+  __shared__ unsigned long long s_out[kWave];  // survivors (sentence id << 16 | match length) while they fit one wave
   const uint32_t lane = lane_id();
   uint32_t q, chunk;
   uint32_t item_idx = 0;
@@ -692,6 +697,7 @@ __global__ void __launch_bounds__(kWave, 8) k_expand_b(DevIndex ix, DevBatch b, 
       const uint32_t e_lo = chunk * kPhaseBChunk;
       const uint32_t e_hi = e_lo + kPhaseBChunk < n_q ? e_lo + kPhaseBChunk : n_q;
       const bool sole = n_q <= kPhaseBChunk;  // this wave is the query's only phase-B worker: no atomics needed
+      bool in_lds = sole;                     // ... and up to 64 survivors stay in LDS and are reduced right here
       uint32_t n_out = 0;
       QHit hq[kBUnroll];
       SufRecB rb[kBUnroll];
@@ -749,20 +755,30 @@ __global__ void __launch_bounds__(kWave, 8) k_expand_b(DevIndex ix, DevBatch b, 
         const unsigned long long mask = __ballot(keep);
         if (mask) {
           const uint32_t cnt = __popcll(mask);
-          uint32_t base = n_out;
-          if (!sole) {
-            if (lane == 0) base = atomicAdd(&w.q_kept[q], cnt);
-            base = __shfl(base, 0, 64);
+          const uint32_t rank = __popcll(mask & ((1ull << lane) - 1ull));
+          if (in_lds && n_out + cnt > kWave) {  // does not fit one wave any more: continue in the segment
+            if (lane < n_out) {
+              Cand c;
+              c.sid = (uint32_t)(s_out[lane] >> 16); c.longest = (uint32_t)(s_out[lane] & 0xffffu); c.score = 0.f; c.penalty = 0.f;
+              seg[lane] = c;
+            }
+            in_lds = false;
           }
-          n_out += cnt;
-          if (keep) {
-            const uint32_t pos = base + __popcll(mask & ((1ull << lane) - 1ull));
-            if (pos < cap) {
+          if (in_lds) {
+            if (keep) s_out[n_out + rank] = ((unsigned long long)sid << 16) | (L & 0xffffu);
+          } else {
+            uint32_t base = n_out;
+            if (!sole) {
+              if (lane == 0) base = atomicAdd(&w.q_kept[q], cnt);
+              base = __shfl(base, 0, 64);
+            }
+            if (keep && base + rank < cap) {
               Cand c;
               c.sid = sid; c.longest = L; c.score = 0.f; c.penalty = 0.f;
-              seg[pos] = c;
+              seg[base + rank] = c;
             }
           }
+          n_out += cnt;
         }
       };
       for (uint32_t e0 = e_lo; e0 < e_hi;) {
@@ -801,7 +817,29 @@ __global__ void __launch_bounds__(kWave, 8) k_expand_b(DevIndex ix, DevBatch b, 
           n_s = rest;
         }
       }
-      if (sole && lane == 0) w.q_kept[q] = n_out;
+      if (in_lds) {
+        // what k_cand does for sets of up to 64 survivors: one candidate per sentence with its longest
+        // match, ordered by (longest desc, sentence id asc)
+        wave_lds_sync();
+        unsigned long long key = lane < n_out ? s_out[lane] : ~0ull;
+        key = wave_sort64(key);
+        const uint32_t nlo = __shfl_down((uint32_t)key, 1, 64), nhi = __shfl_down((uint32_t)(key >> 32), 1, 64);
+        const unsigned long long nxt = lane == 63 ? ~0ull : (((unsigned long long)nhi << 32) | nlo);
+        const bool last = lane < n_out && (nxt >> 16) != (key >> 16);
+        unsigned long long k2 = last ? (((unsigned long long)(0xffffu - (uint32_t)(key & 0xffffu)) << 32) | (key >> 16)) : ~0ull;
+        const uint32_t n_cand = __popcll(__ballot(last));
+        k2 = wave_sort64(k2);
+        if (lane < n_cand) {
+          Cand c;
+          c.sid = (uint32_t)(k2 & 0xffffffffu);
+          c.longest = 0xffffu - (uint32_t)(k2 >> 32);
+          c.score = 0.f; c.penalty = 0.f;
+          seg[lane] = c;
+        }
+        if (lane == 0) { w.q_cand[q] = n_cand; w.q_kept[q] = n_out | kKeptReduced; }
+      } else if (sole && lane == 0) {
+        w.q_kept[q] = n_out;
+      }
     }
     if (!extra) return;
     item_idx += kExpandExtraGrid;
@@ -928,6 +966,7 @@ __global__ void __launch_bounds__(256) k_cand(DevBatch b, DevWork w, uint32_t* b
   if (q >= b.nq) return;
   const uint32_t lane = lane_id();
   const uint32_t n = w.q_kept[q];
+  if (n & kKeptReduced) return;  // k_expand_b already wrote the candidates and q_cand
   if (n == 0) {
     if (lane == 0) w.q_cand[q] = 0;
     return;
@@ -1190,17 +1229,34 @@ __global__ void k_classify(DevBatch b, DevWork w, int full) {
   w.c_in[r] = v[0]; w.c_in[stride + r] = v[1]; w.c_in[2 * stride + r] = v[2];
 }
 
-__global__ void __launch_bounds__(kWave) k_cmap(DevBatch b, DevWork w, int full) {
-  const uint32_t q = blockIdx.x;
-  const uint32_t n = w.q_cand[q];
-  if (n == 0) return;
-  const size_t stride = (size_t)b.nq + 1;
-  const uint32_t p = b.q_off[b.q_begin + q + 1] - b.q_off[b.q_begin + q];
-  const uint32_t cls = dp_class(p, full);
-  unsigned long long base = w.c_off[cls * stride + w.q_rank[q]];
-  if (cls >= 1) base += w.c_off[b.nq];
-  if (cls >= 2) base += w.c_off[stride + b.nq];
-  for (uint32_t i = lane_id(); i < n; i += kWave) w.c_qi[base + i] = ((unsigned long long)q << 32) | i;
+// lane per query: small candidate sets are written by their own lane, large ones by the whole wave
+constexpr uint32_t kCmapSmall = 16;
+__global__ void __launch_bounds__(256) k_cmap(DevBatch b, DevWork w, int full) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t lane = lane_id();
+  uint32_t n = 0;
+  unsigned long long base = 0;
+  if (q < b.nq) {
+    n = w.q_cand[q];
+    if (n) {
+      const size_t stride = (size_t)b.nq + 1;
+      const uint32_t p = b.q_off[b.q_begin + q + 1] - b.q_off[b.q_begin + q];
+      const uint32_t cls = dp_class(p, full);
+      base = w.c_off[cls * stride + w.q_rank[q]];
+      if (cls >= 1) base += w.c_off[b.nq];
+      if (cls >= 2) base += w.c_off[stride + b.nq];
+    }
+  }
+  if (n <= kCmapSmall)
+    for (uint32_t i = 0; i < n; i++) w.c_qi[base + i] = ((unsigned long long)q << 32) | i;
+  unsigned long long big = __ballot(n > kCmapSmall);
+  while (big) {
+    const int l = __ffsll((long long)big) - 1;
+    big &= big - 1ull;
+    const uint32_t qb = __shfl(q, l, 64), nb = __shfl(n, l, 64);
+    const unsigned long long bb = ((unsigned long long)__shfl((uint32_t)(base >> 32), l, 64) << 32) | __shfl((uint32_t)base, l, 64);
+    for (uint32_t i = lane; i < nb; i += kWave) w.c_qi[bb + i] = ((unsigned long long)qb << 32) | i;
+  }
 }
 
 // [begin, end) of a class in the dense candidate list
@@ -1814,8 +1870,8 @@ __global__ void __launch_bounds__(1024) k_stats(DevWork w, uint32_t nq) {
   unsigned long long mx = 0;
   if (q < nq) {
     v[0] = w.q_m[q] == kNoMatchLen ? 0ull : w.q_hits[q];
-    v[1] = w.q_kept[q]; v[2] = w.q_cand[q]; v[3] = w.q_cand[q]; v[4] = w.q_pb[q];
-    mx = w.q_kept[q];
+    v[1] = w.q_kept[q] & ~kKeptReduced; v[2] = w.q_cand[q]; v[3] = w.q_cand[q]; v[4] = w.q_pb[q];
+    mx = w.q_kept[q] & ~kKeptReduced;
   }
 #pragma unroll
   for (int k = 0; k < 5; k++) {
