@@ -249,6 +249,7 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm_in, const D
       auto tick = [&]() { HIP_TRY(hipEventRecord(m.ev[e++], stream)); };
       tick();
       hipLaunchKernelGGL(k_setup, dim3((b.nq + 255) / 256), dim3(256), 0, stream, m.d, b, w, prm);
+      if (prm.idf_penalty != 0.f) hipLaunchKernelGGL(k_tidf, dim3((b.nt + 255) / 256), dim3(256), 0, stream, m.d, b, w);
       HIP_TRY(hipMemsetAsync(w.p_hist, 0, 2 * kPBins * sizeof(uint32_t), stream));
       {
         const uint32_t per_block = kRankThreads * kRankPer;

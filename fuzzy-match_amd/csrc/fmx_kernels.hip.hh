@@ -111,15 +111,16 @@ __global__ void k_setup(DevIndex ix, DevBatch b, DevWork w, Params prm) {
   const uint32_t p = o1 - o0;
   const uint32_t msl = min_seq_len(p, prm);
   w.q_m[q] = msl == kNoMatchLen ? kNoMatchLen : msl;
-  const bool use_idf = prm.idf_penalty != 0.f;
-  for (uint32_t k = 0; k < p; k++) {
-    w.t_q[o0 - b.t_begin + k] = q;
-    // compute_idf_penalty — src/fuzzy_match.cc:381-387 (UNK and out-of-vocabulary ids -> 0)
-    if (use_idf) {
-      const uint32_t wd = b.q_tok[o0 + k];
-      w.t_idf[o0 - b.t_begin + k] = (wd + 1 < ix.n_qva && wd != 1u) ? ix.idf[wd] : 0.f;
-    }
-  }
+  for (uint32_t k = 0; k < p; k++) w.t_q[o0 - b.t_begin + k] = q;
+}
+
+// compute_idf_penalty — src/fuzzy_match.cc:381-387 (UNK and out-of-vocabulary ids -> 0), one thread per
+// pattern token of the pass
+__global__ void k_tidf(DevIndex ix, DevBatch b, DevWork w) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= b.nt) return;
+  const uint32_t wd = b.q_tok[b.t_begin + t];
+  w.t_idf[t] = (wd + 1 < ix.n_qva && wd != 1u) ? ix.idf[wd] : 0.f;
 }
 
 // ---------------------------------------------------------------------------------------------
