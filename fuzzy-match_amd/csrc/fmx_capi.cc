@@ -311,6 +311,7 @@ int fmx_set_option(fmx_index* ix, const char* name, int64_t value) {
   if (!ix->dev) return fail(FMX_E_STATE, "index is not on a device");
   const std::string n(name);
   if (n == "sub_queries") ix->dev->set_sub_queries((uint32_t)std::max<int64_t>(value, 1));
+  else if (n == "host_sub_queries") ix->dev->set_host_sub_queries((uint32_t)std::max<int64_t>(value, 1));
   else if (n == "initial_segment") ix->dev->set_initial_segment((uint64_t)std::max<int64_t>(value, 1024));
   else return fail(FMX_E_INVALID, "unknown option " + n);
   return FMX_OK;

@@ -57,6 +57,7 @@ class DeviceIndex {
   int      device() const;
   uint64_t bytes() const;
   void     set_sub_queries(uint32_t n);
+  void     set_host_sub_queries(uint32_t n);
   void     set_initial_segment(uint64_t n);
 
   // every pointer in HBM of device(); sub_tok_bounds = q_off at each sub-batch boundary (+ q_off[nq])

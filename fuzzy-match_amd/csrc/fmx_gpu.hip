@@ -12,6 +12,7 @@
 
 #include <string.h>
 #include <cstring>
+#include <functional>
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
 
@@ -83,6 +84,9 @@ struct DeviceIndex::Impl {
   hipEvent_t ev[2 * kNumStages]{};
   bool       ev_ok = false;
   uint32_t   sub_queries = 1u << 20;  // queries per pipeline pass: large passes amortise the ~40 launches and their tails
+  uint32_t   host_sub_queries = 1u << 18;  // pass size of the host-buffer entry point: result copies overlap the next pass
+  hipStream_t copy_stream = nullptr;       // D2H of finished passes (non-blocking stream)
+  std::function<void(uint32_t)> on_launched;  // match_host's hook: pass `sb` is enqueued, passes < sb are complete
   uint64_t   init_seg = 1ull << 24;
 };
 
@@ -110,6 +114,7 @@ DeviceIndex::~DeviceIndex() {
     free_ws(m);
     hipFree(m.d_qoff); hipFree(m.d_qtok); hipFree(m.d_qreal); hipFree(m.d_qitok);
     hipFree(m.d_out); hipFree(m.d_out_count); hipFree(m.d_out_total); hipFree(m.items); hipFree(m.items_b);
+    if (m.copy_stream) { hipStreamDestroy(m.copy_stream); m.copy_stream = nullptr; }
     if (m.ev_ok) for (auto& e : m.ev) hipEventDestroy(e);
   }
   delete impl_;
@@ -118,6 +123,7 @@ DeviceIndex::~DeviceIndex() {
 int      DeviceIndex::device() const { return impl_->device; }
 uint64_t DeviceIndex::bytes() const { return impl_->bytes; }
 void     DeviceIndex::set_sub_queries(uint32_t n) { impl_->sub_queries = std::max<uint32_t>(n, 1); }
+void     DeviceIndex::set_host_sub_queries(uint32_t n) { impl_->host_sub_queries = std::max<uint32_t>(n, 1); }
 void     DeviceIndex::set_initial_segment(uint64_t n) { impl_->init_seg = std::max<uint64_t>(n, 1024); }
 
 static void upload_itok_table(DeviceIndex::Impl& m, const HostIndex& h) {
@@ -383,6 +389,7 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm_in, const D
       tick();
       hipLaunchKernelGGL(k_stats, dim3((b.nq + 1023) / 1024), dim3(1024), 0, stream, w, b.nq);
       HIP_TRY(hipGetLastError());
+      if (m.on_launched) m.on_launched(sb);  // host-buffer path: copy out finished passes while this one runs
       unsigned long long ctr[16];
       HIP_TRY(hipMemcpyAsync(ctr, w.counters, sizeof(ctr), hipMemcpyDeviceToHost, stream));
       HIP_TRY(hipStreamSynchronize(stream));
@@ -465,19 +472,44 @@ void DeviceIndex::match_host(const HostIndex& h, const Params& prm, const HostBa
   uint32_t p_max = 0;
   for (uint64_t q = 0; q < nq; q++) p_max = std::max(p_max, hb.q_off[q + 1] - hb.q_off[q]);
   bv.p_max = std::max<uint32_t>(p_max, 1);
+  // Passes of host_sub_queries queries: the results of pass i travel to the host on their own stream while
+  // pass i + 1 computes, so only the last pass's copy is exposed.
+  const uint32_t saved_sub = m.sub_queries;
+  m.sub_queries = std::min(saved_sub, m.host_sub_queries);
   std::vector<uint32_t> bounds;
   for (uint64_t q = 0; q < nq; q += m.sub_queries) bounds.push_back(hb.q_off[q]);
   bounds.push_back(hb.q_off[nq]);
-  match_device(h, prm, bv, m.d_out, m.d_out_count, m.d_out_total, cap, nullptr, bounds, st);
-  const auto h2 = std::chrono::steady_clock::now();
-  HIP_TRY(hipMemcpy(out, m.d_out, nq * cap * sizeof(Rec), hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(out_count, m.d_out_count, nq * 4, hipMemcpyDeviceToHost));
-  if (out_total) HIP_TRY(hipMemcpy(out_total, m.d_out_total, nq * 4, hipMemcpyDeviceToHost));
+  if (!m.copy_stream) HIP_TRY(hipStreamCreateWithFlags(&m.copy_stream, hipStreamNonBlocking));
+  uint64_t copied_q = 0;
+  double ms_copy = 0.0;
+  auto copy_upto = [&](uint64_t q_end) {
+    if (q_end <= copied_q) return;
+    const auto c0 = std::chrono::steady_clock::now();
+    const uint64_t n = q_end - copied_q;
+    HIP_TRY(hipMemcpyAsync(out + copied_q * cap, m.d_out + copied_q * cap, n * cap * sizeof(Rec), hipMemcpyDeviceToHost, m.copy_stream));
+    HIP_TRY(hipMemcpyAsync(out_count + copied_q, m.d_out_count + copied_q, n * 4, hipMemcpyDeviceToHost, m.copy_stream));
+    if (out_total) HIP_TRY(hipMemcpyAsync(out_total + copied_q, m.d_out_total + copied_q, n * 4, hipMemcpyDeviceToHost, m.copy_stream));
+    HIP_TRY(hipStreamSynchronize(m.copy_stream));
+    copied_q = q_end;
+    ms_copy += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - c0).count();
+  };
+  const uint32_t sub = m.sub_queries;
+  m.on_launched = [&](uint32_t sb) { copy_upto(std::min<uint64_t>((uint64_t)sb * sub, nq)); };
+  try {
+    match_device(h, prm, bv, m.d_out, m.d_out_count, m.d_out_total, cap, nullptr, bounds, st);
+  } catch (...) {
+    m.on_launched = nullptr;
+    m.sub_queries = saved_sub;
+    throw;
+  }
+  m.on_launched = nullptr;
+  m.sub_queries = saved_sub;
+  copy_upto(nq);
   const auto h3 = std::chrono::steady_clock::now();
   if (st) {
     auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     st->ms_h2d += ms(h0, h1);
-    st->ms_d2h += ms(h2, h3);
+    st->ms_d2h += ms_copy;  // mostly hidden behind the following pass
     st->ms_total += ms(t0, h3);
   }
 }

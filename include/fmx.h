@@ -182,7 +182,11 @@ int fmx_match_batch_device(fmx_index*, const fmx_params*, const fmx_batch* devic
                            uint64_t total_tokens, fmx_match* d_out, uint32_t* d_out_count,
                            uint32_t* d_out_total, uint32_t cap, void* stream, fmx_stats* stats);
 
-/* tuning knobs (all have sane defaults): queries per sub-batch and initial hit workspace */
+/* tuning knobs (all have sane defaults):
+ *   "sub_queries"       queries per pipeline pass (default 1 048 576)
+ *   "host_sub_queries"  pass size of fmx_match_batch (host buffers, default 262 144): the results of a pass are
+ *                       copied to the host while the next pass computes
+ *   "initial_segment"   initial capacity of the hit workspace (grows on demand) */
 int fmx_set_option(fmx_index*, const char* name, int64_t value);
 
 #ifdef __cplusplus
