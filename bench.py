@@ -98,21 +98,26 @@ def main():
     dev = torch.device("cuda", local_rank)
     d_off = torch.from_numpy(q_off.astype(np.int32)).to(dev)
     d_tok = torch.from_numpy(q_tok.astype(np.int32)).to(dev)
-    d_out = torch.zeros((nq, cap, 4), dtype=torch.int32, device=dev)
-    d_cnt = torch.zeros(nq, dtype=torch.int32, device=dev)
     shard = fmx_import.load().shard
+    # double-buffered result slots; for N > 1 the gather of step i to rank 0 (the path's only collective,
+    # SURVEY §8e) runs on RCCL's stream over xGMI while step i + 1 computes into the other slot
+    rg = shard.RecordGather(nq, cap, dev, dst=0)
+    step_no = [0]
     max_len = int(np.diff(q_off).max()) if nq else 0
     stream = torch.cuda.current_stream().cuda_stream
     total_tokens = int(q_off[-1])
 
     def step():
+        i = step_no[0]
+        step_no[0] += 1
+        d_out, d_cnt = rg.buffers(i)  # waits (in stream order) for the gather that last used this slot
         st = ix.match_batch_device(params, nq, d_off.data_ptr(), d_tok.data_ptr(), total_tokens, d_out.data_ptr(),
                                    d_cnt.data_ptr(), 0, cap, stream=stream, max_len=max_len)
-        if world > 1:  # the only collective of the path: top-N records to rank 0 over xGMI
-            shard.gather_records(d_out, d_cnt, dst=0)
+        rg.launch(i)
         return st
 
     def sync():
+        rg.wait_all()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -168,6 +173,7 @@ def main():
         if nv:
             oo, oc, ctr = o.match_batch(oprm, q_off[:nv + 1], q_tok[:int(q_off[nv])], cap,
                                         nthreads=oracle_lib.effective_cpus(), want_counters=True)
+            d_out, d_cnt = rg.buffers(step_no[0] - 1)  # this rank's records of the last step
             go = d_out[:nv].cpu().numpy().view(oracle_lib.MATCH_DTYPE).reshape(nv, cap)
             gc = d_cnt[:nv].cpu().numpy().astype(np.uint32)
             bad = sum(1 for q in range(nv) if oc[q] != gc[q] or oo[q, :oc[q]].tobytes() != go[q, :gc[q]].tobytes())

@@ -345,11 +345,14 @@ FMX_HD void mgram_range_hashed(const GramTables& gt, const SufKey* __restrict__ 
     if (!act2) m2 = m1;
     const SufKey k1 = key[m1];
     const SufKey k2 = key[m2];
+    SufRec r1, r2;
+    r1.off = 0; r1.rem = 0; r1.slen = 0; r2 = r1;
+    if (deep) { r1 = suf[m1]; r2 = suf[m2]; }  // requested with the keys: a tie costs one more level, not two
     int c1 = key_cmp(k1, ng, from, lim);
     int c2 = key_cmp(k2, ng, from, lim);
     if (deep) {
-      if (c1 == 0) c1 = start_by_from(tok, suf[m1], ngram, kKeyTokens + 1, m);
-      if (c2 == 0) c2 = m2 == m1 ? c1 : start_by_from(tok, suf[m2], ngram, kKeyTokens + 1, m);
+      if (c1 == 0) c1 = start_by_from(tok, r1, ngram, kKeyTokens + 1, m);
+      if (c2 == 0) c2 = m2 == m1 ? c1 : start_by_from(tok, r2, ngram, kKeyTokens + 1, m);
     }
     if (act1) { if (c1 < 0) a1 = m1 + 1; else b1 = m1; }
     if (act2) { if (c2 <= 0) a2 = m2 + 1; else b2 = m2; }

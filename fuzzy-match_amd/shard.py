@@ -44,3 +44,73 @@ def gather_records(out, cnt, dst=0):
         return None, None
     return (torch.cat([g_out[r][:sizes[r]] for r in range(world)]),
             torch.cat([g_cnt[r][:sizes[r]] for r in range(world)]))
+
+
+class RecordGather:
+    """Persistent, double-buffered gather of the top-N records for a stream of equally shaped steps.
+
+    Step i's kernels write into `buffers(i)`; `launch(i)` starts the gather of those buffers to rank `dst`
+    asynchronously (RCCL runs it on its own stream over the point-to-point xGMI links), so it overlaps the
+    compute of step i + 1, which uses the other slot.  A slot is only handed out again after its previous
+    gather has completed (stream-ordered wait, no host sync).  Sizes are exchanged once, not per step."""
+
+    def __init__(self, nq_local, cap, device, dst=0, depth=2):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.dst, self.nq, self.cap = dst, nq_local, cap
+        if self.world > 1:
+            n = torch.tensor([nq_local], dtype=torch.int64, device=device)
+            sizes = [torch.zeros_like(n) for _ in range(self.world)]
+            dist.all_gather(sizes, n)
+            self.sizes = [int(x.item()) for x in sizes]
+        else:
+            self.sizes = [nq_local]
+        self.mx = max(self.sizes + [1])
+        self.slots = []
+        for _ in range(depth):
+            slot = {"out": torch.zeros((self.mx, cap, 4), dtype=torch.int32, device=device),
+                    "cnt": torch.zeros((self.mx,), dtype=torch.int32, device=device), "work": [], "g_out": None, "g_cnt": None}
+            if self.world > 1 and self.rank == dst:
+                slot["g_out"] = torch.zeros((self.world, self.mx, cap, 4), dtype=torch.int32, device=device)
+                slot["g_cnt"] = torch.zeros((self.world, self.mx), dtype=torch.int32, device=device)
+            self.slots.append(slot)
+
+    def _wait(self, slot):
+        for w in slot["work"]:
+            w.wait()
+        slot["work"] = []
+
+    def buffers(self, i):
+        """(records, counts) tensors of step i for this rank's queries; safe to overwrite when returned."""
+        slot = self.slots[i % len(self.slots)]
+        self._wait(slot)
+        return slot["out"][:self.nq], slot["cnt"][:self.nq]
+
+    def launch(self, i):
+        """Starts the gather of step i's buffers (call after the step's kernels are enqueued)."""
+        if self.world == 1:
+            return
+        slot = self.slots[i % len(self.slots)]
+        on_dst = self.rank == self.dst
+        slot["work"] = [
+            self.dist.gather(slot["out"], list(slot["g_out"].unbind(0)) if on_dst else None, dst=self.dst, async_op=True),
+            self.dist.gather(slot["cnt"], list(slot["g_cnt"].unbind(0)) if on_dst else None, dst=self.dst, async_op=True)]
+
+    def wait_all(self):
+        for slot in self.slots:
+            self._wait(slot)
+
+    def result(self, i):
+        """On `dst`: (records, counts) of step i in global query order (after its gather completed)."""
+        slot = self.slots[i % len(self.slots)]
+        self._wait(slot)
+        if self.world == 1:
+            return slot["out"][:self.nq], slot["cnt"][:self.nq]
+        if self.rank != self.dst:
+            return None, None
+        t = self.torch
+        return (t.cat([slot["g_out"][r, :self.sizes[r]] for r in range(self.world)]),
+                t.cat([slot["g_cnt"][r, :self.sizes[r]] for r in range(self.world)]))

@@ -25,6 +25,21 @@ out, cnt = o.match_batch(prm, off, tok, 5, nthreads=2)
 t_out = torch.from_numpy(out.view(np.int32).reshape(len(cnt), 5, 4).copy())
 t_cnt = torch.from_numpy(cnt.astype(np.int32))
 g_out, g_cnt = shard.gather_records(t_out, t_cnt, dst=0)
+# the persistent double-buffered gather bench.py uses: three "steps" through two slots, step i's
+# gather still in flight while step i + 1 fills the other slot
+rg = shard.RecordGather(len(cnt), 5, torch.device("cpu"), dst=0)
+for i in range(3):
+    b_out, b_cnt = rg.buffers(i)
+    b_out.copy_(t_out + i); b_cnt.copy_(t_cnt)   # step i's results (records offset by i to tell steps apart)
+    rg.launch(i)
+rg.wait_all()
+r_out, r_cnt = rg.result(2)
+if rank == 0:
+    assert torch.equal(r_out, g_out + 2) and torch.equal(r_cnt, g_cnt)
+    r1, _ = rg.result(1)
+    assert torch.equal(r1, g_out + 1)
+else:
+    assert r_out is None
 if rank == 0:
     full_out, full_cnt = o.match_batch(prm, q_off, q_tok, 5, nthreads=2)
     assert g_out.shape[0] == len(full_cnt) == 301
