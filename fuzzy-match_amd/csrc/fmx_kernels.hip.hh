@@ -383,7 +383,7 @@ constexpr uint32_t kNeedExact = 0xfffeu; // "no tabulated threshold": phase B ev
 
 // q_kept flag: phase B already reduced the query's survivors to candidates (k_cand has nothing to do)
 constexpr uint32_t kKeptReduced = 0x80000000u;
-__device__ __forceinline__ unsigned long long wave_sort64(unsigned long long key);
+__device__ __forceinline__ unsigned long long wave_sort64_upto(unsigned long long key, uint32_t n);
 
 constexpr int kBUnroll = 2;  // queued hits per lane per phase-B block (their records are loaded together)
 
@@ -823,13 +823,13 @@ __global__ void __launch_bounds__(kWave, 8) k_expand_b(DevIndex ix, DevBatch b, 
         // match, ordered by (longest desc, sentence id asc)
         wave_lds_sync();
         unsigned long long key = lane < n_out ? s_out[lane] : ~0ull;
-        key = wave_sort64(key);
+        key = wave_sort64_upto(key, n_out);
         const uint32_t nlo = __shfl_down((uint32_t)key, 1, 64), nhi = __shfl_down((uint32_t)(key >> 32), 1, 64);
         const unsigned long long nxt = lane == 63 ? ~0ull : (((unsigned long long)nhi << 32) | nlo);
         const bool last = lane < n_out && (nxt >> 16) != (key >> 16);
         unsigned long long k2 = last ? (((unsigned long long)(0xffffu - (uint32_t)(key & 0xffffu)) << 32) | (key >> 16)) : ~0ull;
         const uint32_t n_cand = __popcll(__ballot(last));
-        k2 = wave_sort64(k2);
+        k2 = wave_sort64_upto(k2, n_out);
         if (lane < n_cand) {
           Cand c;
           c.sid = (uint32_t)(k2 & 0xffffffffu);
@@ -943,6 +943,32 @@ __device__ __forceinline__ uint32_t cand_body(unsigned long long* keys, Cand* se
 }
 
 // ascending sort of one 64-bit key per lane across the wave: bitonic network on shuffles, no LDS, no barrier
+// N-lane variant: sorts every aligned group of N lanes; with the live keys in lanes [0, n), n <= N, and ~0 in
+// all other lanes this is the full sort at a fraction of the 21 compare-exchange stages.
+template <int N>
+__device__ __forceinline__ unsigned long long wave_sort64_n(unsigned long long key) {
+  const uint32_t lane = lane_id();
+#pragma unroll
+  for (int k = 2; k <= N; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const uint32_t lo = __shfl_xor((uint32_t)key, j, 64), hi = __shfl_xor((uint32_t)(key >> 32), j, 64);
+      const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+      const bool take_min = ((lane & k) == 0) == ((lane & j) == 0);
+      const unsigned long long mn = key < other ? key : other, mx = key < other ? other : key;
+      key = take_min ? mn : mx;
+    }
+  }
+  return key;
+}
+// n (wave-uniform) live keys in the first lanes, ~0 elsewhere
+__device__ __forceinline__ unsigned long long wave_sort64_upto(unsigned long long key, uint32_t n) {
+  if (n <= 8) return wave_sort64_n<8>(key);
+  if (n <= 16) return wave_sort64_n<16>(key);
+  if (n <= 32) return wave_sort64_n<32>(key);
+  return wave_sort64_n<64>(key);
+}
+
 __device__ __forceinline__ unsigned long long wave_sort64(unsigned long long key) {
   const uint32_t lane = lane_id();
 #pragma unroll
