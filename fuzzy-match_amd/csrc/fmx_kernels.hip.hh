@@ -961,6 +961,32 @@ __device__ __forceinline__ unsigned long long wave_sort64_n(unsigned long long k
   }
   return key;
 }
+// key + 32-bit payload
+template <int N>
+__device__ __forceinline__ void wave_sort64_kv_n(unsigned long long& key, uint32_t& val) {
+  const uint32_t lane = lane_id();
+#pragma unroll
+  for (int k = 2; k <= N; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const uint32_t lo = __shfl_xor((uint32_t)key, j, 64), hi = __shfl_xor((uint32_t)(key >> 32), j, 64);
+      const uint32_t ov = __shfl_xor(val, j, 64);
+      const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+      const bool take_min = ((lane & k) == 0) == ((lane & j) == 0);
+      const bool other_less = other < key;  // keys are distinct (or both ~0): no tie handling needed
+      const bool take_other = take_min ? other_less : !other_less && other != key;
+      key = take_other ? other : key;
+      val = take_other ? ov : val;
+    }
+  }
+}
+__device__ __forceinline__ void wave_sort64_kv_upto(unsigned long long& key, uint32_t& val, uint32_t n) {
+  if (n <= 8) wave_sort64_kv_n<8>(key, val);
+  else if (n <= 16) wave_sort64_kv_n<16>(key, val);
+  else if (n <= 32) wave_sort64_kv_n<32>(key, val);
+  else wave_sort64_kv_n<64>(key, val);
+}
+
 // n (wave-uniform) live keys in the first lanes, ~0 elsewhere
 __device__ __forceinline__ unsigned long long wave_sort64_upto(unsigned long long key, uint32_t n) {
   if (n <= 8) return wave_sort64_n<8>(key);
@@ -1550,6 +1576,43 @@ __device__ __forceinline__ uint32_t replay_body(const Params& prm, uint32_t p, u
 
 // MODE: -1 plain top-N only; 0 / 1 contrastive rerank with the picked sentence in 32 / 64 registers;
 // 2 contrastive rerank with DP rows in LDS (sentences longer than 64 tokens)
+// The same replay for a candidate set that fits one wave (the common case), without the detour through
+// global memory: accepted candidates are flagged in a mask and their scores replace the costs in LDS.
+// Single-wave workgroup: LDS ordering by wave_lds_sync, no barriers.
+__device__ __forceinline__ unsigned long long replay_small(const Params& prm, uint32_t p, uint32_t n_cand, const Cand* seg,
+                                                           float* heap_store, ReplayShared& sh) {
+  const uint32_t lane = lane_id();
+  CostHeap heap;
+  heap.v = heap_store;
+  heap.n = 0;
+  bool maybe = false;
+  if (lane < n_cand) {
+    const Cand cd = seg[lane];
+    const uint32_t slen = cd.longest >> 16;
+    sh.final_cost[lane] = cd.score; sh.M[lane] = cd.penalty; sh.sid[lane] = cd.sid;
+    sh.L[lane] = cd.longest & 0xffffu; sh.slen[lane] = slen;
+    maybe = !(prm.no_perfect && cd.score == 0.f && slen == p);
+  }
+  unsigned long long todo = __ballot(maybe);
+  wave_lds_sync();
+  unsigned long long acc = 0;
+  if (lane == 0) {
+    heap.push(FLT_MAX);
+    while (todo) {
+      const uint32_t k = (uint32_t)__ffsll((long long)todo) - 1u;
+      todo &= todo - 1ull;
+      float score;
+      if (replay_candidate(heap, prm, p, sh.slen[k], sh.final_cost[k], sh.M[k], score)) {
+        sh.final_cost[k] = score;
+        acc |= 1ull << k;
+      }
+    }
+  }
+  wave_lds_sync();
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)acc), hi = __builtin_amdgcn_readfirstlane((uint32_t)(acc >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+
 template <int MODE>
 __device__ __forceinline__ void select_body(const DevIndex& ix, const Params& prm, const Cand* seg, uint32_t n,
                                             uint32_t np2, unsigned long long* keys, uint32_t* vals, float* pen_sum,
@@ -1684,6 +1747,28 @@ __global__ void __launch_bounds__(kWave) k_finish(DevIndex ix, DevBatch b, DevWo
     }
     Rec* out = out_rec + (unsigned long long)gq * cap;
     uint32_t cnt = 0, tot = 0;
+    if (!LIST && !contrast && n_cand != 0 && prm.cbuf > 0 && prm.cbuf <= (int)kHeapLdsMax) {
+      // one wave holds the whole candidate set: replay, rank and emit from registers / LDS
+      const unsigned long long seg0 = uni(w.q_seg[q]);
+      const uint32_t p = uni(b.q_off[gq + 1]) - uni(b.q_off[gq]);
+      const unsigned long long acc = replay_small(prm, p, n_cand, w.seg + seg0, s_heap, sh);
+      const uint32_t n = (uint32_t)__popcll(acc);
+      const uint32_t want = prm.nmatch == 0 ? n : (prm.nmatch < n ? prm.nmatch : n);
+      const uint32_t emit = want < cap ? want : cap;
+      const bool mine = (acc >> lane) & 1ull;
+      // ascending key = score desc, s_id asc (sentence ids are unique within a candidate set)
+      unsigned long long key = mine ? (((unsigned long long)(~float_key(sh.final_cost[lane])) << 32) | sh.sid[lane]) : ~0ull;
+      uint32_t idx = lane;
+      wave_sort64_kv_upto(key, idx, n_cand);
+      if (lane < emit) {
+        Rec r;
+        r.score = sh.final_cost[idx]; r.penalty = 0.f; r.max_subseq = (int32_t)sh.L[idx]; r.s_id = sh.sid[idx];
+        out[lane] = r;
+      }
+      if (lane == 0) { w.q_acc[q] = n; out_count[gq] = emit; if (out_total) out_total[gq] = want; }
+      wave_lds_sync();
+      continue;
+    }
     if (n_cand != 0) {
       const unsigned long long seg0 = w.q_seg[q];
       Cand* seg = w.seg + seg0;
