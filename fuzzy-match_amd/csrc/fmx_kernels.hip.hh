@@ -1530,6 +1530,7 @@ struct ReplayShared {
 
 __device__ __forceinline__ uint32_t replay_body(const Params& prm, uint32_t p, uint32_t n_cand, Cand* seg,
                                                 float* heap_store, ReplayShared& sh, uint32_t& max_slen_out) {
+  constexpr int kAhead = 4;  // chunks whose candidates are requested together (the loop is a latency chain)
   uint32_t max_slen = 0;
   const uint32_t lane = lane_id();
   CostHeap heap;
@@ -1538,35 +1539,48 @@ __device__ __forceinline__ uint32_t replay_body(const Params& prm, uint32_t p, u
   if (lane == 0) heap.push(FLT_MAX);
   uint32_t acc = 0;
   if (lane == 0) sh.ub = FLT_MAX;
-  for (uint32_t c0 = 0; c0 < n_cand; c0 += kWave) {
-    const uint32_t c = c0 + lane;
-    __syncthreads();
-    // The bound never increases, so a candidate the bound left by the previous chunk already rejects
-    // (or the no_perfect rule) cannot change the state: all 64 lanes test that in parallel and lane 0
-    // only walks the few that may still be accepted, in order.
-    bool maybe = false;
-    if (c < n_cand) {
-      const Cand cd = seg[c];
-      const uint32_t slen = cd.longest >> 16;
-      sh.final_cost[lane] = cd.score; sh.M[lane] = cd.penalty; sh.sid[lane] = cd.sid;
-      sh.L[lane] = cd.longest & 0xffffu; sh.slen[lane] = slen;
-      maybe = !((prm.no_perfect && cd.score == 0.f && slen == p) || cd.penalty > sh.ub);
+  for (uint32_t g0 = 0; g0 < n_cand; g0 += kWave * kAhead) {
+    Cand cds[kAhead];
+#pragma unroll
+    for (int u = 0; u < kAhead; u++) {
+      const uint32_t c = g0 + u * kWave + lane;
+      cds[u].sid = 0; cds[u].longest = 0; cds[u].score = 0.f; cds[u].penalty = 0.f;
+      if (c < n_cand) cds[u] = seg[c];
     }
-    unsigned long long todo = __ballot(maybe);
-    __syncthreads();
-    if (lane == 0) {
-      while (todo) {
-        const uint32_t k = (uint32_t)__ffsll((long long)todo) - 1u;
-        todo &= todo - 1ull;
-        float score;
-        if (replay_candidate(heap, prm, p, sh.slen[k], sh.final_cost[k], sh.M[k], score)) {
-          Cand a;
-          a.sid = sh.sid[k]; a.longest = sh.L[k]; a.score = score; a.penalty = 0.f;
-          seg[acc++] = a;
-          max_slen = sh.slen[k] > max_slen ? sh.slen[k] : max_slen;
-        }
+#pragma unroll
+    for (int u = 0; u < kAhead; u++) {
+      const uint32_t c0 = g0 + u * kWave;
+      if (c0 >= n_cand) break;
+      const uint32_t c = c0 + lane;
+      __syncthreads();
+      // The bound never increases, so a candidate the bound left by the previous chunk already rejects
+      // (or the no_perfect rule) cannot change the state: all 64 lanes test that in parallel and lane 0
+      // only walks the few that may still be accepted, in order.  (Accepted matches are written to
+      // seg[acc++], acc <= c0: never ahead of the chunks already held in registers.)
+      bool maybe = false;
+      if (c < n_cand) {
+        const Cand cd = cds[u];
+        const uint32_t slen = cd.longest >> 16;
+        sh.final_cost[lane] = cd.score; sh.M[lane] = cd.penalty; sh.sid[lane] = cd.sid;
+        sh.L[lane] = cd.longest & 0xffffu; sh.slen[lane] = slen;
+        maybe = !((prm.no_perfect && cd.score == 0.f && slen == p) || cd.penalty > sh.ub);
       }
-      sh.ub = heap.top();
+      unsigned long long todo = __ballot(maybe);
+      __syncthreads();
+      if (lane == 0) {
+        while (todo) {
+          const uint32_t k = (uint32_t)__ffsll((long long)todo) - 1u;
+          todo &= todo - 1ull;
+          float score;
+          if (replay_candidate(heap, prm, p, sh.slen[k], sh.final_cost[k], sh.M[k], score)) {
+            Cand a;
+            a.sid = sh.sid[k]; a.longest = sh.L[k]; a.score = score; a.penalty = 0.f;
+            seg[acc++] = a;
+            max_slen = sh.slen[k] > max_slen ? sh.slen[k] : max_slen;
+          }
+        }
+        sh.ub = heap.top();
+      }
     }
   }
   __syncthreads();
@@ -1574,8 +1588,6 @@ __device__ __forceinline__ uint32_t replay_body(const Params& prm, uint32_t p, u
   return __shfl(acc, 0, 64);
 }
 
-// MODE: -1 plain top-N only; 0 / 1 contrastive rerank with the picked sentence in 32 / 64 registers;
-// 2 contrastive rerank with DP rows in LDS (sentences longer than 64 tokens)
 // The same replay for a candidate set that fits one wave (the common case), without the detour through
 // global memory: accepted candidates are flagged in a mask and their scores replace the costs in LDS.
 // Single-wave workgroup: LDS ordering by wave_lds_sync, no barriers.
