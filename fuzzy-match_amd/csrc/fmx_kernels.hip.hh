@@ -1112,7 +1112,15 @@ __device__ __forceinline__ void block_radix_pass(const unsigned long long* src, 
   const uint32_t end = beg + len < n ? beg + len : n;
   for (uint32_t i = tid; i < kBigWaves * 256; i += kBigThreads) s_hist[i] = 0;
   __syncthreads();
-  for (uint32_t i = beg + lane; i < end; i += 64) atomicAdd(&s_hist[wv * 256 + (uint32_t)((src[i] >> shift) & 255ull)], 1u);
+  constexpr int kRU = 4;  // keys requested together: both loops are chains of global-load latencies otherwise
+  for (uint32_t i0 = beg; i0 < end; i0 += 64 * kRU) {
+    unsigned long long kk[kRU];
+#pragma unroll
+    for (int u = 0; u < kRU; u++) { const uint32_t i = i0 + u * 64 + lane; kk[u] = i < end ? src[i] : 0ull; }
+#pragma unroll
+    for (int u = 0; u < kRU; u++)
+      if (i0 + u * 64 + lane < end) atomicAdd(&s_hist[wv * 256 + (uint32_t)((kk[u] >> shift) & 255ull)], 1u);
+  }
   __syncthreads();
   {
     // entry e = digit * kBigWaves + wave; each thread owns 4 consecutive entries (kBigWaves * 256 / 1024)
@@ -1133,10 +1141,17 @@ __device__ __forceinline__ void block_radix_pass(const unsigned long long* src, 
     }
   }
   __syncthreads();
-  for (uint32_t i0 = beg; i0 < end; i0 += 64) {
+  for (uint32_t g0 = beg; g0 < end; g0 += 64 * kRU) {
+    unsigned long long kk[kRU];
+#pragma unroll
+    for (int u = 0; u < kRU; u++) { const uint32_t i = g0 + u * 64 + lane; kk[u] = i < end ? src[i] : 0ull; }
+#pragma unroll
+    for (int u = 0; u < kRU; u++) {
+    const uint32_t i0 = g0 + u * 64;
+    if (i0 >= end) break;
     const uint32_t i = i0 + lane;
     const bool valid = i < end;
-    const unsigned long long key = valid ? src[i] : 0ull;
+    const unsigned long long key = kk[u];
     const uint32_t d = (uint32_t)((key >> shift) & 255ull);
     unsigned long long same = __ballot(valid);
 #pragma unroll
@@ -1150,6 +1165,7 @@ __device__ __forceinline__ void block_radix_pass(const unsigned long long* src, 
       const uint32_t base = s_hist[wv * 256 + d];
       dst[base + rank] = key;
       if (rank == 0) s_hist[wv * 256 + d] = base + __popcll(same);
+    }
     }
   }
   __syncthreads();
@@ -1171,8 +1187,17 @@ __global__ void __launch_bounds__(kBigThreads) k_cand_big(DevWork w, unsigned lo
     unsigned long long* A = big + 2ull * w.q_seg[q];
     unsigned long long* B = A + n;
     if (threadIdx.x == 0) s_count = 0;
-    for (uint32_t i = threadIdx.x; i < n; i += kBigThreads)
-      A[i] = ((unsigned long long)seg[i].sid << 16) | (seg[i].longest & 0xffffu);
+    for (uint32_t i0 = threadIdx.x; i0 < n; i0 += kBigThreads * 4) {
+      unsigned long long kk[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const uint32_t i = i0 + u * kBigThreads;
+        kk[u] = 0;
+        if (i < n) { const Cand c = seg[i]; kk[u] = ((unsigned long long)c.sid << 16) | (c.longest & 0xffffu); }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) { const uint32_t i = i0 + u * kBigThreads; if (i < n) A[i] = kk[u]; }
+    }
     __syncthreads();
     unsigned long long *src = A, *dst = B;
     for (uint32_t k = 0; k < sid_bytes; k++) {
@@ -1200,13 +1225,21 @@ __global__ void __launch_bounds__(kBigThreads) k_cand_big(DevWork w, unsigned lo
       unsigned long long* t = src; src = dst; dst = t;
     }
     const uint32_t kept = s_count;
-    for (uint32_t i = threadIdx.x; i < kept; i += kBigThreads) {
-      const unsigned long long a = src[i];
-      Cand c;
-      c.sid = (uint32_t)(a & 0xffffffffu);
-      c.longest = 0xffffu - (uint32_t)((a >> 32) & 0xffffu);
-      c.score = 0.f; c.penalty = 0.f;
-      seg[i] = c;
+    for (uint32_t i0 = threadIdx.x; i0 < kept; i0 += kBigThreads * 4) {
+      unsigned long long kk[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { const uint32_t i = i0 + u * kBigThreads; kk[u] = i < kept ? src[i] : 0ull; }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const uint32_t i = i0 + u * kBigThreads;
+        if (i < kept) {
+          Cand c;
+          c.sid = (uint32_t)(kk[u] & 0xffffffffu);
+          c.longest = 0xffffu - (uint32_t)((kk[u] >> 32) & 0xffffu);
+          c.score = 0.f; c.penalty = 0.f;
+          seg[i] = c;
+        }
+      }
     }
     if (threadIdx.x == 0) w.q_cand[q] = kept;
     __syncthreads();
