@@ -731,28 +731,8 @@ __global__ void __launch_bounds__(kWave, 8) k_expand_b(DevIndex ix, DevBatch b, 
       // of the queued hits fail it) compacts the survivors into LDS.  Stage 2: full waves of survivors do
       // the token work (match length + exact coverage), not diluted by dominated hits.
       uint32_t n_s = 0;
-      auto heavy = [&](uint32_t j0, bool active) {
-        bool keep = active;
-        uint32_t sid = 0, L = 0;
-        if (keep) {
-          const SurvB sv = s_surv[j0 + lane];
-          const uint32_t it = sv.it_need >> 16, need = sv.it_need & 0xffffu;
-          SufRec r;
-          r.off = sv.off; r.rem = (uint16_t)(sv.rem_slen & 0xffffu); r.slen = (uint16_t)(sv.rem_slen >> 16);
-          L = lcp_extend(ix.tok, r, s_pat + it, m, p - it);
-          const uint32_t sl = r.slen;
-          const uint32_t* sent = ix.tok + (r.off - (uint32_t)(r.slen - r.rem));
-          if (need != kNeedExact && need != 0) {
-            if (L >= p) keep = p >= need;
-            else if (p <= kWave) keep = cover_at_least(ph, sent, sl, need);
-            else keep = cover_lds(sent, sl, s_pat, p) >= need;
-          } else {
-            const uint32_t cover = L < p ? cover_lds(sent, sl, s_pat, p) : p;
-            // need == 0: sentence length outside phase A's table, the length filter is still to be applied
-            keep = !reject_len(p, sl, prm) && !reject_cover(p, sl, cover, prm);
-          }
-          sid = sv.sid;
-        }
+      // survivors of the token work go to the LDS set (while they fit one wave) or to the query's segment
+      auto append = [&](bool keep, uint32_t sid, uint32_t L) {
         const unsigned long long mask = __ballot(keep);
         if (mask) {
           const uint32_t cnt = __popcll(mask);
@@ -782,6 +762,100 @@ __global__ void __launch_bounds__(kWave, 8) k_expand_b(DevIndex ix, DevBatch b, 
           n_out += cnt;
         }
       };
+      // patterns longer than one wave: one lane per survivor, pattern compared from LDS
+      auto heavy = [&](uint32_t j0, bool active) {
+        bool keep = active;
+        uint32_t sid = 0, L = 0;
+        if (keep) {
+          const SurvB sv = s_surv[j0 + lane];
+          const uint32_t it = sv.it_need >> 16, need = sv.it_need & 0xffffu;
+          SufRec r;
+          r.off = sv.off; r.rem = (uint16_t)(sv.rem_slen & 0xffffu); r.slen = (uint16_t)(sv.rem_slen >> 16);
+          L = lcp_extend(ix.tok, r, s_pat + it, m, p - it);
+          const uint32_t sl = r.slen;
+          const uint32_t* sent = ix.tok + (r.off - (uint32_t)(r.slen - r.rem));
+          const uint32_t cover = L < p ? cover_lds(sent, sl, s_pat, p) : p;
+          if (need != kNeedExact && need != 0) keep = cover >= need;
+          // need == 0: sentence length outside phase A's table, the length filter is still to be applied
+          else keep = !reject_len(p, sl, prm) && !reject_cover(p, sl, cover, prm);
+          sid = sv.sid;
+        }
+        append(keep, sid, L);
+      };
+      // patterns of up to 64 tokens (hash set built): kSubLanes lanes per survivor share the token work, so
+      // a typical query's dozen survivors fill the wave instead of a fifth of it.  The lanes of a group
+      // compare / probe interleaved tokens; the match length is the first mismatch any of them sees, the
+      // coverage the weighted popcount of the union of their "distinct pattern words seen" masks.
+      constexpr uint32_t kSubLanes = 4, kSubSurv = kWave / kSubLanes;
+      unsigned long long cplanes[7];
+      uint32_t n_cpl = 0;
+      if (p <= kWave) {
+        const uint32_t mycnt = ph.cnt[lane];  // positions per distinct pattern word (0 beyond the distinct count)
+#pragma unroll
+        for (uint32_t k = 0; k < 7; k++) {
+          cplanes[k] = __ballot((mycnt >> k) & 1u);
+          if (cplanes[k]) n_cpl = k + 1;
+        }
+      }
+      auto heavy4 = [&](uint32_t j0, uint32_t n_act) {
+        const uint32_t sub = lane / kSubLanes, part = lane % kSubLanes;
+        const bool act = sub < n_act;
+        SurvB sv;
+        sv.off = 0; sv.rem_slen = 0; sv.sid = 0; sv.it_need = 0;
+        if (act) sv = s_surv[j0 + sub];
+        const uint32_t it = sv.it_need >> 16, need = sv.it_need & 0xffffu;
+        const uint32_t rem = sv.rem_slen & 0xffffu, sl = sv.rem_slen >> 16;
+        // match length: kSubLanes tokens per step, a position at or beyond the limit counts as a mismatch
+        const uint32_t lim = act ? (rem < p - it ? rem : p - it) : 0u;
+        uint32_t L = m < lim ? m : lim;
+        bool done = !act || m >= lim;
+        uint32_t k0 = m;
+        while (__ballot(!done)) {
+          const uint32_t k = k0 + part;
+          const bool mism = !done && (k >= lim || ix.tok[sv.off + k] != s_pat[it + k]);
+          const uint32_t g = (uint32_t)(__ballot(mism) >> (sub * kSubLanes)) & ((1u << kSubLanes) - 1u);
+          if (!done) {
+            if (g) { L = k0 + (uint32_t)__ffs((int)g) - 1u; done = true; }
+            else k0 += kSubLanes;
+          }
+        }
+        // coverage: distinct pattern words present in the sentence
+        unsigned long long seen = 0;
+        if (act && L < p) {
+          const uint32_t* sent = ix.tok + (sv.off - (sl - rem));
+          for (uint32_t kb = part; kb < sl; kb += 4 * kSubLanes) {
+            uint32_t t[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) t[u] = kb + u * kSubLanes < sl ? sent[kb + u * kSubLanes] : kHashEmpty;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              if (kb + u * kSubLanes >= sl) break;
+              uint32_t h = pat_hash_slot(t[u]);
+              uint32_t key = ph.key[h];
+              while (key != t[u] && key != kHashEmpty) { h = (h + 1) & (kHashSlots - 1); key = ph.key[h]; }
+              if (key == t[u]) seen |= 1ull << ph.idx[h];
+            }
+          }
+        }
+#pragma unroll
+        for (uint32_t d = 1; d < kSubLanes; d <<= 1) {
+          const uint32_t lo = __shfl_xor((uint32_t)seen, d, 64), hi = __shfl_xor((uint32_t)(seen >> 32), d, 64);
+          seen |= ((unsigned long long)hi << 32) | lo;
+        }
+        uint32_t cover = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 7; k++)
+          if (k < n_cpl) cover += (uint32_t)__popcll(seen & cplanes[k]) << k;
+        if (L >= p) cover = p;
+        bool keep = act && part == 0;
+        if (keep) {
+          if (need != kNeedExact && need != 0) keep = cover >= need;
+          // need == 0: sentence length outside phase A's table, the length filter is still to be applied
+          else keep = !reject_len(p, sl, prm) && !reject_cover(p, sl, cover, prm);
+        }
+        append(keep, sv.sid, L);
+      };
+      const uint32_t pass = p <= kWave ? kSubSurv : kWave;  // survivors per pass of the token work
       for (uint32_t e0 = e_lo; e0 < e_hi;) {
 #pragma unroll
         for (int u = 0; u < kBUnroll; u++) {
@@ -802,10 +876,11 @@ __global__ void __launch_bounds__(kWave, 8) k_expand_b(DevIndex ix, DevBatch b, 
         if (more) { load_hits(e0); load_recs(); }  // next block's loads overlap this block's token work
         wave_lds_sync();
         uint32_t j0 = 0;
-        for (; j0 + kWave <= n_s; j0 += kWave) heavy(j0, true);
+        if (p <= kWave) for (; j0 + pass <= n_s; j0 += pass) heavy4(j0, pass);
+        else for (; j0 + pass <= n_s; j0 += pass) heavy(j0, true);
         const uint32_t rest = n_s - j0;
         if (!more) {
-          if (rest) heavy(j0, lane < rest);
+          if (rest) { if (p <= kWave) heavy4(j0, rest); else heavy(j0, lane < rest); }
           n_s = 0;
         } else {
           if (j0) {  // carry the incomplete wave of survivors to the front of the list
