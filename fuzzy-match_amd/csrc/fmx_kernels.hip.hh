@@ -237,15 +237,28 @@ struct WorkItem {
   uint32_t chunk;
 };
 
-__global__ void k_caps(DevBatch b, DevWork w, WorkItem* items, uint32_t item_cap, uint32_t s_max) {
+__global__ void __launch_bounds__(256) k_caps(DevBatch b, DevWork w, WorkItem* items, uint32_t item_cap, uint32_t s_max) {
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  // hits of the query = sum of its start positions' range sizes.  The block's queries own one contiguous
+  // token span: it is read coalesced by the whole block and summed per query through LDS.
+  __shared__ unsigned long long s_hits[256];
+  __shared__ uint32_t s_span[2];
+  s_hits[threadIdx.x] = 0;
+  if (threadIdx.x == 0) {
+    const uint32_t q0 = blockIdx.x * blockDim.x;
+    const uint32_t q1 = q0 + blockDim.x < b.nq ? q0 + blockDim.x : b.nq;
+    s_span[0] = b.q_off[b.q_begin + q0] - b.t_begin;
+    s_span[1] = b.q_off[b.q_begin + q1] - b.t_begin;
+  }
+  __syncthreads();
+  for (uint32_t t = s_span[0] + threadIdx.x; t < s_span[1]; t += blockDim.x) {
+    const uint32_t c = w.t_cnt[t];
+    if (c) atomicAdd(&s_hits[w.t_q[t] - blockIdx.x * blockDim.x], (unsigned long long)c);
+  }
+  __syncthreads();
   if (q > b.nq) return;
   if (q == b.nq) { w.q_cap[q] = 0; return; }
-  unsigned long long hits = 0;
-  if (w.q_m[q] != kNoMatchLen) {
-    const uint32_t o0 = b.q_off[b.q_begin + q] - b.t_begin, o1 = b.q_off[b.q_begin + q + 1] - b.t_begin;
-    for (uint32_t t = o0; t < o1; t++) hits += w.t_cnt[t];
-  }
+  const unsigned long long hits = w.q_m[q] != kNoMatchLen ? s_hits[threadIdx.x] : 0ull;
   w.q_hits[q] = hits;
   w.q_cap[q] = hits < s_max ? hits : (unsigned long long)s_max;
   w.q_kept[q] = 0;
