@@ -86,6 +86,8 @@ struct DeviceIndex::Impl {
   uint32_t   sub_queries = 1u << 20;  // queries per pipeline pass: large passes amortise the ~40 launches and their tails
   uint32_t   host_sub_queries = 1u << 18;  // pass size of the host-buffer entry point: result copies overlap the next pass
   hipStream_t copy_stream = nullptr;       // D2H of finished passes (non-blocking stream)
+  uint16_t*  cmin_tab = nullptr;           // threshold table of k_cmin, (cmin_rows) x 256
+  uint32_t   cmin_rows = 0;
   std::function<void(uint32_t)> on_launched;  // match_host's hook: pass `sb` is enqueued, passes < sb are complete
   uint64_t   init_seg = 1ull << 24;
 };
@@ -115,6 +117,7 @@ DeviceIndex::~DeviceIndex() {
     hipFree(m.d_qoff); hipFree(m.d_qtok); hipFree(m.d_qreal); hipFree(m.d_qitok);
     hipFree(m.d_out); hipFree(m.d_out_count); hipFree(m.d_out_total); hipFree(m.items); hipFree(m.items_b);
     if (m.copy_stream) { hipStreamDestroy(m.copy_stream); m.copy_stream = nullptr; }
+    hipFree(m.cmin_tab); m.cmin_tab = nullptr; m.cmin_rows = 0;
     if (m.ev_ok) for (auto& e : m.ev) hipEventDestroy(e);
   }
   delete impl_;
@@ -278,6 +281,13 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm_in, const D
       {
         // the signature bound needs theoretical_rejection_cover to be monotone in the cover: costs >= 0
         const int use_sig = prm.ins >= 0.f && prm.del >= 0.f && prm.rep >= 0.f;
+        if (p_max + 1 > m.cmin_rows) {
+          hipFree(m.cmin_tab);
+          m.cmin_rows = p_max + 1;
+          m.cmin_tab = dev_alloc<uint16_t>((size_t)m.cmin_rows * 256);
+        }
+        w.cmin_tab = m.cmin_tab;
+        hipLaunchKernelGGL(k_cmin, dim3(p_max + 1), dim3(256), 0, stream, m.d.max_slen, prm, use_sig, m.cmin_tab);
         hipLaunchKernelGGL(k_expand_a, dim3(b.nq + kExpandExtraGrid), dim3(kWave), 0, stream, m.d, b, w, prm,
                            (const WorkItem*)m.items, m.item_cap, use_sig);
         hipLaunchKernelGGL(k_caps_b, dim3((b.nq + 255) / 256), dim3(256), 0, stream, b, w, m.items_b, m.item_cap);

@@ -64,6 +64,7 @@ struct DevWork {
   uint32_t* q_aux;      // nq   contrastive rerank: the match picked last
   uint32_t* q_rank;     // nq   position of the query in pattern-length order (DP lists are built in that order)
   uint32_t* p_hist;     // 2 x kPBins: queries per pattern length, then the placement cursors
+  const uint16_t* cmin_tab;  // (p_max + 1) x kCminTab: per (pattern length, stored sentence length) the phase-A threshold
   unsigned long long* c_in;    // 3 x (nq+1) candidates per query, one array per length class (scan input)
   unsigned long long* c_off;   // 3 x (nq+1) exclusive scans: dense per-class candidate lists
   unsigned long long* c_qi;    // seg_cap  (query << 32 | candidate index), dense per length class
@@ -392,7 +393,10 @@ __device__ __forceinline__ bool cover_at_least(const PatHash& ph, const uint32_t
 constexpr int kUnroll = FMX_UNROLL;  // hits per lane per phase-A iteration
 constexpr uint32_t kQueue = 256;  // LDS ring of hits that passed the cheap tests (power of two >= 64 + 2 * 64)
 constexpr uint32_t kPhaseBChunk = 1024;  // queued hits per k_expand_b work item
-constexpr uint32_t kNeedExact = 0xfffeu; // "no tabulated threshold": phase B evaluates the bound itself
+// "no tabulated threshold": phase B evaluates the bound itself.  Table values are ordered so that phase A
+// needs one compare per hit: thresholds (< 0x8000) <= kNeedExact <= the bound with the signature disabled
+// (0x8000 | count) < 0xffff = rejected by the length filter.
+constexpr uint32_t kNeedExact = 0x8000u;
 
 // q_kept flag: phase B already reduced the query's survivors to candidates (k_cand has nothing to do)
 constexpr uint32_t kKeptReduced = 0x80000000u;
@@ -411,6 +415,22 @@ struct __attribute__((aligned(16))) SurvB {
 struct __attribute__((aligned(8))) SigPair {  // two consecutive suf_sig words: one global_load_dwordx4
   unsigned long long a, b;
 };
+
+// ---------------------------------------------------------------------------------------------
+// k_cmin — the phase-A threshold table.  It depends on the pattern length and the parameters only, so it is
+// computed once per pass for every length (block = pattern length, thread = stored sentence length) instead
+// of by every work item of k_expand_a (where the searches were a third of the kernel's instructions):
+// 0xffff = rejected by the length filter (theoretical_rejection), 0 = clamped length, phase B decides,
+// kNeedExact = no signature bound (negative costs), else the minimal cover that passes
+// theoretical_rejection_cover.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_cmin(uint32_t max_slen, Params prm, int use_sig, uint16_t* tab) {
+  const uint32_t p = blockIdx.x, sl = threadIdx.x;
+  uint32_t c = 0xffffu;
+  if (sl == kSigLenClamp) c = max_slen >= kSigLenClamp ? 0u : 0xffffu;
+  else if (sl <= max_slen && !reject_len(p, sl, prm)) c = use_sig ? cover_threshold(p, sl, prm) : kNeedExact;
+  tab[(size_t)p * 256 + sl] = (uint16_t)c;
+}
 
 // a hit that passed the cheap tests of phase A, queued for phase B
 struct QHit {
@@ -434,7 +454,7 @@ struct QHit {
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kWave, 8) k_expand_a(DevIndex ix, DevBatch b, DevWork w, Params prm,
                                                     const WorkItem* items, uint32_t item_cap, int use_sig) {
-  __shared__ uint16_t s_cmin[kCminTab];    // per stored sentence length: minimal cover, 0xffff = rejected, 0 = phase B decides
+  __shared__ __attribute__((aligned(8))) uint16_t s_cmin[kCminTab];  // per stored sentence length: minimal cover, 0xffff = rejected, 0 = phase B decides
   __shared__ uint32_t s_npref[kWave + 1];  // exclusive hit prefix of the non-empty start positions
   __shared__ uint32_t s_nlo[kWave];
   __shared__ uint32_t s_nit[kWave];
@@ -472,13 +492,9 @@ __global__ void __launch_bounds__(kWave, 8) k_expand_a(DevIndex ix, DevBatch b, 
         s_bucket[lane] = 0;
         __syncthreads();
         for (uint32_t j = lane; j < p; j += kWave) atomicAdd(&s_bucket[sig_bit(pat[j])], 1u);
-        for (uint32_t sl = lane; sl < kCminTab; sl += kWave) {
-          // the length filter first (one evaluation); the threshold search only for lengths that pass it
-          uint32_t c = 0xffffu;
-          if (sl == kSigLenClamp) c = ix.max_slen >= kSigLenClamp ? 0u : 0xffffu;  // clamped lengths: phase B decides
-          else if (sl <= ix.max_slen && !reject_len(p, sl, prm)) c = use_sig ? cover_threshold(p, sl, prm) : kNeedExact;
-          s_cmin[sl] = (uint16_t)c;
-        }
+        // this pattern length's row of the threshold table (k_cmin): 64 lanes x 8 bytes
+        reinterpret_cast<unsigned long long*>(s_cmin)[lane] =
+            reinterpret_cast<const unsigned long long*>(w.cmin_tab + (size_t)p * kCminTab)[lane];
         __syncthreads();
         unsigned long long planes[kMaxPlanes];
         uint32_t n_planes = 0;
@@ -500,7 +516,7 @@ __global__ void __launch_bounds__(kWave, 8) k_expand_a(DevIndex ix, DevBatch b, 
             n_planes = 0;
           }
         }
-        const uint32_t ub_or = sig_off ? 0x10000u : 0u;  // signature bound disabled: every threshold passes
+        const uint32_t ub_or = sig_off ? kNeedExact : 0u;  // signature bound disabled: every threshold passes, 0xffff still rejects
         QHit* qb = w.qb + seg0;
         const unsigned long long h_lo = (unsigned long long)chunk * kExpandChunk;
         const unsigned long long h_hi = h_lo + kExpandChunk < hits ? h_lo + kExpandChunk : hits;
@@ -550,7 +566,7 @@ __global__ void __launch_bounds__(kWave, 8) k_expand_a(DevIndex ix, DevBatch b, 
                   if (kk2 < n_planes) ub += (uint32_t)__popcll(sig & planes[kk2]) << kk2;
               }
             }
-            return valid & (cmin != 0xffffu) & (ub >= cmin);
+            return valid & (ub >= cmin);  // cmin == 0xffff (length filter) exceeds every bound
           };
           // survivors of two hits per lane go to the LDS ring with one uniform branch
           auto push2 = [&](bool k0, uint32_t i0, uint32_t n0, bool k1, uint32_t i1, uint32_t n1) {
@@ -580,6 +596,32 @@ __global__ void __launch_bounds__(kWave, 8) k_expand_a(DevIndex ix, DevBatch b, 
               k = k0;
               const uint32_t it_hi = s_nit[k0] << 16;
               const uint32_t i_base = s_nlo[k0] - s_npref[k0];
+              if (blk_end - hh == kWave * kUnroll && n_planes <= 2) {
+                // the common case inside a long range, stripped of every per-hit branch: full block, at most
+                // two bit planes (no pattern word bucket holds four or more positions)
+                const SigPair* src = reinterpret_cast<const SigPair*>(ix.suf_sig + (i_base + hh)) + lane;
+                SigPair v[kUnroll / 2];
+#pragma unroll
+                for (int u = 0; u < kUnroll / 2; u++) v[u] = src[u * kWave];
+                const uint32_t p0l = (uint32_t)planes[0], p0h = (uint32_t)(planes[0] >> 32);
+                const uint32_t p1l = (uint32_t)planes[1], p1h = (uint32_t)(planes[1] >> 32);
+                auto bound = [&](unsigned long long pk, uint32_t& cmin) -> bool {
+                  cmin = s_cmin[sig_slen(pk)];
+                  const uint32_t lo = (uint32_t)pk, hi = (uint32_t)(pk >> 32) & ((1u << (kSigBits - 32)) - 1u);
+                  const uint32_t c0 = (uint32_t)__popc(lo & p0l) + (uint32_t)__popc(hi & p0h);
+                  const uint32_t c1 = (uint32_t)__popc(lo & p1l) + (uint32_t)__popc(hi & p1h);
+                  return ((c0 + (c1 << 1)) | ub_or) >= cmin;
+                };
+#pragma unroll
+                for (int u = 0; u < kUnroll / 2; u++) {
+                  const uint32_t i0 = i_base + hh + u * 2 * kWave + 2 * lane;
+                  uint32_t c0, c1;
+                  const bool keep0 = bound(v[u].a, c0);
+                  const bool keep1 = bound(v[u].b, c1);
+                  push2(keep0, i0, it_hi | c0, keep1, i0 + 1, it_hi | c1);
+                }
+                continue;
+              }
               unsigned long long hpk[kUnroll];
 #pragma unroll
               for (int u = 0; u < kUnroll / 2; u++) {
