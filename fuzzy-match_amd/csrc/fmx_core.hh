@@ -551,15 +551,20 @@ struct CostHeap {
 
 // One turn of the candidate loop (src/fuzzy_match.cc:587-610) given the candidate's DP outcome.
 // Returns true when the candidate becomes a Match (score >= fuzzy); score_out is its score.
-FMX_HD bool replay_candidate(CostHeap& heap, const Params& prm, uint32_t p, uint32_t s_len, float final_cost,
-                             float M, float& score_out) {
+// `score` = score_from_cost(final_cost), computed by the caller (the kernels evaluate it for 64 candidates in
+// parallel before the sequential walk: the double-precision division is most of a turn's instructions).
+FMX_HD bool replay_candidate_scored(CostHeap& heap, const Params& prm, uint32_t p, uint32_t s_len, float final_cost,
+                                    float M, float score) {
   const float ub = heap.top();
   if ((prm.no_perfect && final_cost == 0.f && s_len == p) || M > ub) return false;
-  const float score = score_from_cost(final_cost);
   heap.push(final_cost);
   if (score < prm.fuzzy || (prm.cbuf > 0 && heap.n > (uint32_t)prm.cbuf)) heap.pop();
-  score_out = score;
   return score >= prm.fuzzy;
+}
+FMX_HD bool replay_candidate(CostHeap& heap, const Params& prm, uint32_t p, uint32_t s_len, float final_cost,
+                             float M, float& score_out) {
+  score_out = score_from_cost(final_cost);
+  return replay_candidate_scored(heap, prm, p, s_len, final_cost, M, score_out);
 }
 
 // order-preserving float -> uint32 (ascending)

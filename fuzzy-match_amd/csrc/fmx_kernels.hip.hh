@@ -1686,7 +1686,7 @@ struct DevScratch {
 };
 
 struct ReplayShared {
-  float    final_cost[kWave], M[kWave];
+  float    final_cost[kWave], M[kWave], score[kWave];
   uint32_t sid[kWave], L[kWave], slen[kWave];
   float    ub;
 };
@@ -1727,6 +1727,7 @@ __device__ __forceinline__ uint32_t replay_body(const Params& prm, uint32_t p, u
         sh.final_cost[lane] = cd.score; sh.M[lane] = cd.penalty; sh.sid[lane] = cd.sid;
         sh.L[lane] = cd.longest & 0xffffu; sh.slen[lane] = slen;
         maybe = !((prm.no_perfect && cd.score == 0.f && slen == p) || cd.penalty > sh.ub);
+        if (maybe) sh.score[lane] = score_from_cost(cd.score);
       }
       unsigned long long todo = __ballot(maybe);
       __syncthreads();
@@ -1734,8 +1735,8 @@ __device__ __forceinline__ uint32_t replay_body(const Params& prm, uint32_t p, u
         while (todo) {
           const uint32_t k = (uint32_t)__ffsll((long long)todo) - 1u;
           todo &= todo - 1ull;
-          float score;
-          if (replay_candidate(heap, prm, p, sh.slen[k], sh.final_cost[k], sh.M[k], score)) {
+          const float score = sh.score[k];
+          if (replay_candidate_scored(heap, prm, p, sh.slen[k], sh.final_cost[k], sh.M[k], score)) {
             Cand a;
             a.sid = sh.sid[k]; a.longest = sh.L[k]; a.score = score; a.penalty = 0.f;
             seg[acc++] = a;
@@ -1767,6 +1768,7 @@ __device__ __forceinline__ unsigned long long replay_small(const Params& prm, ui
     sh.final_cost[lane] = cd.score; sh.M[lane] = cd.penalty; sh.sid[lane] = cd.sid;
     sh.L[lane] = cd.longest & 0xffffu; sh.slen[lane] = slen;
     maybe = !(prm.no_perfect && cd.score == 0.f && slen == p);
+    sh.score[lane] = score_from_cost(cd.score);
   }
   unsigned long long todo = __ballot(maybe);
   wave_lds_sync();
@@ -1776,11 +1778,7 @@ __device__ __forceinline__ unsigned long long replay_small(const Params& prm, ui
     while (todo) {
       const uint32_t k = (uint32_t)__ffsll((long long)todo) - 1u;
       todo &= todo - 1ull;
-      float score;
-      if (replay_candidate(heap, prm, p, sh.slen[k], sh.final_cost[k], sh.M[k], score)) {
-        sh.final_cost[k] = score;
-        acc |= 1ull << k;
-      }
+      if (replay_candidate_scored(heap, prm, p, sh.slen[k], sh.final_cost[k], sh.M[k], sh.score[k])) acc |= 1ull << k;
     }
   }
   wave_lds_sync();
@@ -1932,12 +1930,12 @@ __global__ void __launch_bounds__(kWave) k_finish(DevIndex ix, DevBatch b, DevWo
       const uint32_t emit = want < cap ? want : cap;
       const bool mine = (acc >> lane) & 1ull;
       // ascending key = score desc, s_id asc (sentence ids are unique within a candidate set)
-      unsigned long long key = mine ? (((unsigned long long)(~float_key(sh.final_cost[lane])) << 32) | sh.sid[lane]) : ~0ull;
+      unsigned long long key = mine ? (((unsigned long long)(~float_key(sh.score[lane])) << 32) | sh.sid[lane]) : ~0ull;
       uint32_t idx = lane;
       wave_sort64_kv_upto(key, idx, n_cand);
       if (lane < emit) {
         Rec r;
-        r.score = sh.final_cost[idx]; r.penalty = 0.f; r.max_subseq = (int32_t)sh.L[idx]; r.s_id = sh.sid[idx];
+        r.score = sh.score[idx]; r.penalty = 0.f; r.max_subseq = (int32_t)sh.L[idx]; r.s_id = sh.sid[idx];
         out[lane] = r;
       }
       if (lane == 0) { w.q_acc[q] = n; out_count[gq] = emit; if (out_total) out_total[gq] = want; }
