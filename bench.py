@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--sentences", type=int, default=0)
     ap.add_argument("--queries", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive host-buffer measurement (profiling runs: keeps every launch full-size)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--verify", type=int, default=2000, help="queries of rank 0 checked against the oracle")
     args = ap.parse_args()
@@ -143,7 +144,7 @@ def main():
 
     # ---- PCIe-inclusive rate through the host-buffer entry point (never `value`) ----
     host_path = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_host_path:
         ix.match_batch(params, q_off, q_tok, cap=cap)  # warm the staging buffers
         t1 = time.perf_counter()
         _, _, _, hst = ix.match_batch(params, q_off, q_tok, cap=cap, want_stats=True)
