@@ -646,8 +646,11 @@ __global__ void __launch_bounds__(kWave, 8) k_expand_a(DevIndex ix, DevBatch b, 
             }
             uint32_t hi_[kUnroll], hit_[kUnroll];
             bool hv[kUnroll], adj[kUnroll / 2];
+            // a short block (the typical query: a dozen small ranges) only needs the first pair of hits per lane
+            const bool two = blk_end - hh > 2 * kWave;
 #pragma unroll
             for (int u = 0; u < kUnroll / 2; u++) {
+              if (u >= 1 && !two) { hv[2 * u] = hv[2 * u + 1] = false; hi_[2 * u] = hi_[2 * u + 1] = 0; hit_[2 * u] = hit_[2 * u + 1] = 0; adj[u] = false; continue; }
               uint32_t kk[2] = {0, 0};
 #pragma unroll
               for (int s2 = 0; s2 < 2; s2++) {
@@ -667,6 +670,7 @@ __global__ void __launch_bounds__(kWave, 8) k_expand_a(DevIndex ix, DevBatch b, 
             unsigned long long hpk[kUnroll];
 #pragma unroll
             for (int u = 0; u < kUnroll / 2; u++) {
+              if (u >= 1 && !two) { hpk[2 * u] = hpk[2 * u + 1] = 0; continue; }
               if (adj[u]) {
                 const SigPair v = *reinterpret_cast<const SigPair*>(ix.suf_sig + hi_[2 * u]);
                 hpk[2 * u] = v.a; hpk[2 * u + 1] = v.b;
@@ -677,6 +681,7 @@ __global__ void __launch_bounds__(kWave, 8) k_expand_a(DevIndex ix, DevBatch b, 
             }
 #pragma unroll
             for (int u = 0; u < kUnroll / 2; u++) {
+              if (u >= 1 && !two) continue;
               uint32_t c0, c1;
               const bool keep0 = test(hv[2 * u], hpk[2 * u], c0);
               const bool keep1 = test(hv[2 * u + 1], hpk[2 * u + 1], c1);
