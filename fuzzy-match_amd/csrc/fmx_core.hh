@@ -549,6 +549,62 @@ struct CostHeap {
   FMX_HD void pop() { if (n) n--; }
 };
 
+// ---------------------------------------------------------------------------------------------
+// Unit costs (insert = delete = replace = c >= 0, no idf / real-token / penalty-token terms): the float DP
+// of _edit_distance (src/edit_distance.cc:5-77) only ever adds the same increment inc = c * dw or 0, so a
+// cell whose integer edit distance is k holds exactly S_k = fl(fl(fl(inc + inc) + inc) ...), k additions
+// (induction over the recurrence: every predecessor holds S_a, S_a + inc = S_{a+1}, min(S_x, S_y) =
+// S_min(x,y) because S is non-decreasing).  The last cell therefore is S_k with k the plain Levenshtein
+// distance, and M = max(row minima, final) = final (row minima never decrease for non-negative costs).
+// k comes from Hyyro's bit-parallel recurrence for the global distance (pattern positions = bits; the
+// "<< 1 | 1" sets D[i][0] = i): ~20 word operations per sentence token plus the match mask, instead of
+// seven float operations per DP cell.  tests/emul checks S_k against the float DP on every candidate.
+// ---------------------------------------------------------------------------------------------
+struct LevState {
+  unsigned long long pv, mv;
+  uint32_t score;
+};
+FMX_HD void lev_init(LevState& st, uint32_t m) { st.pv = ~0ull; st.mv = 0ull; st.score = m; }
+// eq: bit j set iff pattern token j equals the sentence token of this row; m = pattern length (1..64)
+FMX_HD void lev_step(LevState& st, unsigned long long eq, uint32_t m) {
+  const unsigned long long xv = eq | st.mv;
+  const unsigned long long xh = (((eq & st.pv) + st.pv) ^ st.pv) | eq;
+  unsigned long long ph = st.mv | ~(xh | st.pv);
+  unsigned long long mh = st.pv & xh;
+  st.score += (uint32_t)((ph >> (m - 1)) & 1ull) - (uint32_t)((mh >> (m - 1)) & 1ull);
+  ph = (ph << 1) | 1ull;
+  mh = mh << 1;
+  st.pv = mh | ~(xv | ph);
+  st.mv = ph & xv;
+}
+FMX_HD void lev_step32(uint32_t& pv, uint32_t& mv, uint32_t& score, uint32_t eq, uint32_t m) {  // m <= 32
+  const uint32_t xv = eq | mv;
+  const uint32_t xh = (((eq & pv) + pv) ^ pv) | eq;
+  uint32_t ph = mv | ~(xh | pv);
+  uint32_t mh = pv & xh;
+  score += ((ph >> (m - 1)) & 1u) - ((mh >> (m - 1)) & 1u);
+  ph = (ph << 1) | 1u;
+  mh = mh << 1;
+  pv = mh | ~(xv | ph);
+  mv = ph & xv;
+}
+FMX_HD float unit_cost_sum(uint32_t k, float inc) {
+  float a = 0.f;
+  for (uint32_t i = 0; i < k; i++) a = a + inc;
+  return a;
+}
+// plain-loop version (host / emulation; the kernels keep the pattern in registers)
+FMX_HD uint32_t lev_distance(const uint32_t* __restrict__ sent, uint32_t n1, const uint32_t* __restrict__ pat, uint32_t n2) {
+  LevState st;
+  lev_init(st, n2);
+  for (uint32_t i = 0; i < n1; i++) {
+    unsigned long long eq = 0;
+    for (uint32_t j = 0; j < n2; j++) eq |= (unsigned long long)(sent[i] == pat[j]) << j;
+    lev_step(st, eq, n2);
+  }
+  return st.score;
+}
+
 // One turn of the candidate loop (src/fuzzy_match.cc:587-610) given the candidate's DP outcome.
 // Returns true when the candidate becomes a Match (score >= fuzzy); score_out is its score.
 // `score` = score_from_cost(final_cost), computed by the caller (the kernels evaluate it for 64 candidates in

@@ -152,7 +152,12 @@ void DeviceIndex::upload(const HostIndex& h, int device) {
   m.d.gram.mask3 = h.gram.empty() ? 0u : (uint32_t)(h.gram.size() - 1);
   m.d.gram.g5 = h.gram5.empty() ? nullptr : dev_upload(h.gram5);
   m.d.gram.mask5 = h.gram5.empty() ? 0u : (uint32_t)(h.gram5.size() - 1);
-  m.d.tok = dev_upload(h.buf);
+  {  // eight spare tokens: the DP kernels read the sentence four tokens at a time, possibly past its end
+    uint32_t* t = dev_alloc<uint32_t>(h.buf.size() + 8);
+    HIP_TRY(hipMemset(t, 0, (h.buf.size() + 8) * sizeof(uint32_t)));
+    if (!h.buf.empty()) HIP_TRY(hipMemcpy(t, h.buf.data(), h.buf.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    m.d.tok = t;
+  }
   m.d.sent_pos = dev_upload(h.sent_pos);
   m.d.qva = dev_upload(h.qva);
   m.d.idf = dev_upload(h.idf);
@@ -335,6 +340,11 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm_in, const D
           if (use_idf) {
             hipLaunchKernelGGL((k_dp_reg<32, true>), dim3(grid), dim3(kWave), 0, stream, m.d, b, w, prm);
             if (p_max > 32) hipLaunchKernelGGL((k_dp_reg<64, true>), dim3(grid), dim3(kWave), 0, stream, m.d, b, w, prm);
+          } else if (prm.ins == prm.del && prm.del == prm.rep && prm.rep >= 0.f) {
+            // unit costs: bit-parallel Levenshtein distance, then the float sum the DP would have produced
+            // few registers: eight waves per SIMD hide the dependent loads in front of every candidate
+            hipLaunchKernelGGL((k_dp_reg<32, false, true>), dim3(grid), dim3(kWave), 0, stream, m.d, b, w, prm);
+            if (p_max > 32) hipLaunchKernelGGL((k_dp_reg<64, false, true>), dim3(grid), dim3(kWave), 0, stream, m.d, b, w, prm);
           } else {
             hipLaunchKernelGGL((k_dp_reg<32, false>), dim3(grid), dim3(kWave), 0, stream, m.d, b, w, prm);
             if (p_max > 32) hipLaunchKernelGGL((k_dp_reg<64, false>), dim3(grid), dim3(kWave), 0, stream, m.d, b, w, prm);

@@ -1616,6 +1616,67 @@ __device__ __forceinline__ float edit_distance_reg(const uint32_t* __restrict__ 
   return final_v;
 }
 
+struct __attribute__((packed, aligned(4))) Tok4 {
+  uint32_t t[4];
+};
+
+// Unit costs: bit-parallel Levenshtein distance (fmx_core.hh) with the pattern in registers, then S_k.
+// P = register capacity; EXACT: every lane's pattern has exactly P tokens, otherwise columns beyond n2 hold
+// 0xffffffff (never equal, their bits stay 0 and never reach bit n2 - 1).
+template <int P, bool EXACT>
+__device__ __forceinline__ float edit_distance_unit(const uint32_t* __restrict__ sent, uint32_t n1,
+                                                    const uint32_t* __restrict__ pat, uint32_t n2, float inc, float& M_out) {
+  uint32_t pt[P];
+#pragma unroll
+  for (int j = 0; j < P; j++) pt[j] = (EXACT || (uint32_t)j < n2) ? pat[j] : 0xffffffffu;
+  uint32_t k;
+  // The recurrence is short, so the sentence's tokens are fetched four at a time (one 16-byte load, any
+  // 4-byte alignment; the token buffer has spare tokens behind it) one group ahead of their use.
+  const Tok4* sent4 = reinterpret_cast<const Tok4*>(sent);
+  Tok4 nxt = n1 ? sent4[0] : Tok4{{0u, 0u, 0u, 0u}};
+  uint32_t pv = ~0u, mv = 0u, score = n2;
+  LevState st;
+  lev_init(st, n2);
+  for (uint32_t i0 = 0; i0 < n1; i0 += 4) {
+    const Tok4 cur = nxt;
+    if (i0 + 4 < n1) nxt = sent4[(i0 >> 2) + 1];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (i0 + u >= n1) break;
+      const uint32_t wd = cur.t[u];
+      if (P <= 32) {
+        uint32_t eq = 0;
+#pragma unroll
+        for (int j = P - 1; j >= 0; j--) eq = (eq << 1) | (uint32_t)(wd == pt[j]);
+        lev_step32(pv, mv, score, eq, n2);
+      } else {
+        uint32_t eq_lo = 0, eq_hi = 0;
+#pragma unroll
+        for (int j = 31; j >= 0; j--) eq_lo = (eq_lo << 1) | (uint32_t)(wd == pt[j]);
+#pragma unroll
+        for (int j = P - 1; j >= 32; j--) eq_hi = (eq_hi << 1) | (uint32_t)(wd == pt[j]);
+        lev_step(st, ((unsigned long long)eq_hi << 32) | eq_lo, n2);
+      }
+    }
+  }
+  k = P <= 32 ? score : st.score;
+  const float f = unit_cost_sum(k, inc);
+  M_out = f;
+  return f;
+}
+
+template <int LO, int HI>
+__device__ __forceinline__ float edit_distance_unit_dispatch(uint32_t p_u, const uint32_t* __restrict__ sent, uint32_t n1,
+                                                             const uint32_t* __restrict__ pat, float inc, float& M) {
+  if constexpr (LO == HI) {
+    return edit_distance_unit<LO, true>(sent, n1, pat, (uint32_t)LO, inc, M);
+  } else {
+    constexpr int MID = (LO + HI) / 2;
+    if (p_u <= (uint32_t)MID) return edit_distance_unit_dispatch<LO, MID>(p_u, sent, n1, pat, inc, M);
+    return edit_distance_unit_dispatch<MID + 1, HI>(p_u, sent, n1, pat, inc, M);
+  }
+}
+
 // Dispatch on the wave's common pattern length: the variant compiled for exactly that length.
 template <int LO, int HI, bool IDF>
 __device__ __forceinline__ float edit_distance_exact_dispatch(uint32_t p_u, const uint32_t* __restrict__ sent, uint32_t n1,
@@ -1632,7 +1693,8 @@ __device__ __forceinline__ float edit_distance_exact_dispatch(uint32_t p_u, cons
   }
 }
 
-template <int P, bool IDF>
+// UNIT: insert = delete = replace >= 0 and no idf term (decided by the host): bit-parallel distance
+template <int P, bool IDF, bool UNIT = false>
 __global__ void __launch_bounds__(kWave) k_dp_reg(DevIndex ix, DevBatch b, DevWork w, Params prm) {
   const uint32_t lane = lane_id();
   unsigned long long j_lo, j_hi;
@@ -1655,7 +1717,12 @@ __global__ void __launch_bounds__(kWave) k_dp_reg(DevIndex ix, DevBatch b, DevWo
     float M, final_cost;
     // the list is in pattern-length order: all active lanes of a wave normally share one length
     const uint32_t p_u = __builtin_amdgcn_readfirstlane(p);
-    if (__ballot(p != p_u) == 0ull)
+    const bool same_p = __ballot(p != p_u) == 0ull;
+    if constexpr (UNIT) {
+      const float inc = prm.rep * dw;  // = ins * dw = del * dw
+      if (same_p) final_cost = edit_distance_unit_dispatch<(P == 32 ? 1 : 33), P>(p_u, sent, slen, pat, inc, M);
+      else final_cost = edit_distance_unit<P, false>(sent, slen, pat, p, inc, M);
+    } else if (same_p)
       final_cost = edit_distance_exact_dispatch<(P == 32 ? 1 : 33), P, IDF>(p_u, sent, slen, pat, prm.ins, prm.del, prm.rep,
                                                                           dw, M, p_idf, idf_weight);
     else

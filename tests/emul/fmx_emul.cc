@@ -147,9 +147,15 @@ extern "C" int emul_match_batch(const EmulIndex* ix, const Params* prm_in, uint6
             if (use_idf) { side.p_idf = idf.data(); side.idf_weight = (dw * prm.idf_penalty) / prm.idf_max; }
             final_cost = edit_distance<true>(sent, slen, pat, p, prm.ins, prm.del, prm.rep, dw, side, s_ub,
                                              VecRow{row.data()}, M);
-          } else
+          } else {
             final_cost = edit_distance<false>(sent, slen, pat, p, prm.ins, prm.del, prm.rep, dw, side, s_ub,
                                               VecRow{row.data()}, M);
+            // the kernels' unit-cost path: bit-parallel distance k, then k additions of the increment
+            if (!use_idf && p <= 64 && prm.ins == prm.del && prm.del == prm.rep && prm.rep >= 0.f) {
+              const float f = unit_cost_sum(lev_distance(sent, slen, pat, p), prm.rep * dw);
+              if (f != final_cost || f != M) return -6;
+            }
+          }
           if (stats) stats[3]++;
         }
         c_final[k] = final_cost; c_M[k] = M; c_pass[k] = pass; c_slen[k] = slen;
@@ -206,6 +212,7 @@ extern "C" int emul_match_batch(const EmulIndex* ix, const Params* prm_in, uint6
           float M;
           const float ed = edit_distance<false>(ix->tok + csp + 1, n1, ix->tok + msp + 1, n2, 1.f, 1.f, 1.f, dw, none,
                                                 FLT_MAX, VecRow{crow.data()}, M);
+          if (n2 <= 64 && unit_cost_sum(lev_distance(ix->tok + csp + 1, n1, ix->tok + msp + 1, n2), 1.f * dw) != ed) return -7;
           const float pen = score_from_cost(ed);
           pen_sum[k] = pen_sum[k] + pen;
           pen_max[k] = (picked == 1) ? pen : (pen_max[k] < pen ? pen : pen_max[k]);
