@@ -1912,8 +1912,8 @@ __device__ __forceinline__ void select_body(const DevIndex& ix, const Params& pr
         const uint32_t n1 = ix.tok[csp];
         const float dw = 100.f / normalizer(n1, n2, 1.f, 1.f, 1.f);
         float M, ed;
-        if (MODE == 0) ed = edit_distance_reg<32>(ix.tok + csp + 1, n1, s2, n2, 1.f, 1.f, 1.f, dw, M);
-        else if (MODE == 1) ed = edit_distance_reg<64>(ix.tok + csp + 1, n1, s2, n2, 1.f, 1.f, 1.f, dw, M);
+        if (MODE == 0) ed = edit_distance_unit<32, false>(ix.tok + csp + 1, n1, s2, n2, 1.f * dw, M);
+        else if (MODE == 1) ed = edit_distance_unit<64, false>(ix.tok + csp + 1, n1, s2, n2, 1.f * dw, M);
         else ed = edit_distance<false>(ix.tok + csp + 1, n1, s2, n2, 1.f, 1.f, 1.f, dw, side, FLT_MAX,
                                        LdsRow{s_rows + lane}, M);
         const float pen = score_from_cost(ed);
@@ -2205,7 +2205,7 @@ __global__ void __launch_bounds__(kWave) k_cdp(DevIndex ix, DevBatch b, DevWork 
     const uint32_t n1 = ix.tok[csp];
     const float dw = 100.f / normalizer(n1, n2, 1.f, 1.f, 1.f);
     float M;
-    const float ed = edit_distance_reg<P>(ix.tok + csp + 1, n1, ix.tok + msp + 1, n2, 1.f, 1.f, 1.f, dw, M);
+    const float ed = edit_distance_unit<P, false>(ix.tok + csp + 1, n1, ix.tok + msp + 1, n2, 1.f * dw, M);  // costs (1, 1, 1)
     const float pen = score_from_cost(ed);
     const float sum = sc.f0[seg0 + k] + pen;
     sc.f0[seg0 + k] = sum;
