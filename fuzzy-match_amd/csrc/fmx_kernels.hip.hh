@@ -1638,12 +1638,13 @@ __device__ __forceinline__ float edit_distance_unit(const uint32_t* __restrict__
   LevState st;
   lev_init(st, n2);
   for (uint32_t i0 = 0; i0 < n1; i0 += 4) {
-    const Tok4 cur = nxt;
+    uint32_t c0 = nxt.t[0], c1 = nxt.t[1], c2 = nxt.t[2], c3 = nxt.t[3];
     if (i0 + 4 < n1) nxt = sent4[(i0 >> 2) + 1];
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      if (i0 + u >= n1) break;
-      const uint32_t wd = cur.t[u];
+    const uint32_t nu = n1 - i0 < 4 ? n1 - i0 : 4;
+#pragma unroll 1
+    for (uint32_t u = 0; u < nu; u++) {  // not unrolled: one copy of the row per pattern length keeps the code small
+      const uint32_t wd = c0;
+      c0 = c1; c1 = c2; c2 = c3;
       if (P <= 32) {
         uint32_t eq = 0;
 #pragma unroll
