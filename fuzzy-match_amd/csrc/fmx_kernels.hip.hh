@@ -359,37 +359,6 @@ __device__ __forceinline__ void pat_hash_build(PatHash& ph, const uint32_t* s_pa
   wave_lds_sync();
 }
 
-// does the sentence cover at least `need` pattern positions?  (PatternCoverage::count_covered_words
-// compared with the threshold; stops as soon as the answer is yes)
-__device__ __forceinline__ bool cover_at_least(const PatHash& ph, const uint32_t* __restrict__ sent, uint32_t slen,
-                                               uint32_t need) {
-  unsigned long long seen = 0;
-  uint32_t cover = 0;
-  if (need == 0) return true;
-  // four tokens per step: their loads are issued together (the walk is bound by load latency)
-  for (uint32_t k0 = 0; k0 < slen; k0 += 4) {
-    uint32_t t[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) t[u] = k0 + u < slen ? sent[k0 + u] : kHashEmpty;
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      if (k0 + u >= slen) break;
-      uint32_t h = pat_hash_slot(t[u]);
-      uint32_t key = ph.key[h];
-      while (key != t[u] && key != kHashEmpty) { h = (h + 1) & (kHashSlots - 1); key = ph.key[h]; }
-      if (key == t[u]) {
-        const uint32_t d = ph.idx[h];
-        if (!((seen >> d) & 1ull)) {
-          seen |= 1ull << d;
-          cover += ph.cnt[d];
-          if (cover >= need) return true;
-        }
-      }
-    }
-  }
-  return false;
-}
-
 constexpr int kUnroll = FMX_UNROLL;  // hits per lane per phase-A iteration
 constexpr uint32_t kQueue = 256;  // LDS ring of hits that passed the cheap tests (power of two >= 64 + 2 * 64)
 constexpr uint32_t kPhaseBChunk = 1024;  // queued hits per k_expand_b work item
