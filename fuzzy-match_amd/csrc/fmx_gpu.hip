@@ -271,7 +271,7 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm_in, const D
         hipLaunchKernelGGL(k_prank, dim3((b.nq + per_block - 1) / per_block), dim3(kRankThreads), 0, stream, b, w);
       }
       tick(); tick();
-      if (b.nt) hipLaunchKernelGGL(k_probe, dim3((b.nt + 255) / 256), dim3(256), 0, stream, m.d, b, w);
+      if (b.nt) hipLaunchKernelGGL(k_probe, dim3((b.nt + 63) / 64), dim3(64), 0, stream, m.d, b, w);
       tick(); tick();
       {
         hipLaunchKernelGGL(k_caps, dim3((b.nq + 1 + 255) / 256), dim3(256), 0, stream, b, w, m.items, m.item_cap, m.s_max);

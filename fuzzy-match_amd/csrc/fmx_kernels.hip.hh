@@ -129,7 +129,7 @@ __global__ void k_tidf(DevIndex ix, DevBatch b, DevWork w) {
 // equal_range calls converge to for the seed n-gram (src/suffix_array.cc:105-212,
 // src/fuzzy_match.cc:495-551).  Each compare step is one 8-byte SufRec load + token loads.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_probe(DevIndex ix, DevBatch b, DevWork w) {
+__global__ void __launch_bounds__(64) k_probe(DevIndex ix, DevBatch b, DevWork w) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= b.nt) return;
   const uint32_t q = w.t_q[t];
