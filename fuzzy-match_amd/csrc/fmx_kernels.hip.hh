@@ -927,13 +927,18 @@ __global__ void __launch_bounds__(kWave, 8) k_expand_b(DevIndex ix, DevBatch b, 
         // match, ordered by (longest desc, sentence id asc)
         wave_lds_sync();
         unsigned long long key = lane < n_out ? s_out[lane] : ~0ull;
-        key = wave_sort64_upto(key, n_out);
+        if (n_out > 1) key = wave_sort64_upto(key, n_out);
         const uint32_t nlo = __shfl_down((uint32_t)key, 1, 64), nhi = __shfl_down((uint32_t)(key >> 32), 1, 64);
         const unsigned long long nxt = lane == 63 ? ~0ull : (((unsigned long long)nhi << 32) | nlo);
         const bool last = lane < n_out && (nxt >> 16) != (key >> 16);
         unsigned long long k2 = last ? (((unsigned long long)(0xffffu - (uint32_t)(key & 0xffffu)) << 32) | (key >> 16)) : ~0ull;
-        const uint32_t n_cand = __popcll(__ballot(last));
-        k2 = wave_sort64_upto(k2, n_out);
+        const unsigned long long lastm = __ballot(last);
+        const uint32_t n_cand = __popcll(lastm);
+        if (n_cand > 1) k2 = wave_sort64_upto(k2, n_out);
+        else if (n_cand == 1) {  // the single candidate moves to lane 0 without a sorting network
+          const int src = __ffsll((long long)lastm) - 1;
+          k2 = ((unsigned long long)__shfl((uint32_t)(k2 >> 32), src, 64) << 32) | __shfl((uint32_t)k2, src, 64);
+        }
         if (lane < n_cand) {
           Cand c;
           c.sid = (uint32_t)(k2 & 0xffffffffu);
@@ -1059,8 +1064,7 @@ __device__ __forceinline__ unsigned long long wave_sort64_n(unsigned long long k
       const uint32_t lo = __shfl_xor((uint32_t)key, j, 64), hi = __shfl_xor((uint32_t)(key >> 32), j, 64);
       const unsigned long long other = ((unsigned long long)hi << 32) | lo;
       const bool take_min = ((lane & k) == 0) == ((lane & j) == 0);
-      const unsigned long long mn = key < other ? key : other, mx = key < other ? other : key;
-      key = take_min ? mn : mx;
+      key = ((other < key) == take_min) ? other : key;  // one compare, one select (equal keys: either is fine)
     }
   }
   return key;
@@ -1108,8 +1112,7 @@ __device__ __forceinline__ unsigned long long wave_sort64(unsigned long long key
       const uint32_t lo = __shfl_xor((uint32_t)key, j, 64), hi = __shfl_xor((uint32_t)(key >> 32), j, 64);
       const unsigned long long other = ((unsigned long long)hi << 32) | lo;
       const bool take_min = ((lane & k) == 0) == ((lane & j) == 0);
-      const unsigned long long mn = key < other ? key : other, mx = key < other ? other : key;
-      key = take_min ? mn : mx;
+      key = ((other < key) == take_min) ? other : key;  // one compare, one select (equal keys: either is fine)
     }
   }
   return key;
