@@ -2100,58 +2100,45 @@ __global__ void __launch_bounds__(kWave) k_camap(DevBatch b, DevWork w, DevScrat
   }
 }
 
-__global__ void __launch_bounds__(kWave) k_cpick(DevBatch b, DevWork w, Params prm, DevScratch sc, uint32_t round,
-                                                 uint32_t cap, Rec* out_rec, uint32_t* out_count, uint32_t* out_total) {
-  const uint32_t q = blockIdx.x;
-  const uint32_t lane = lane_id();
+__global__ void __launch_bounds__(256) k_cpick(DevBatch b, DevWork w, Params prm, DevScratch sc, uint32_t round,
+                                               uint32_t cap, Rec* out_rec, uint32_t* out_count, uint32_t* out_total) {
+  // one thread per query: the accepted list of a query is a handful of entries (at most the contrast buffer),
+  // and a wave per query spent its time on the dependent loads in front of them
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= b.nq) return;
   if (w.q_cand[q] == 0) return;  // k_finish wrote the empty result
   const uint32_t acc = w.q_acc[q];
   if ((acc >> 30) >= 2) return;  // queued for k_contrast<2>
   const uint32_t n = acc & 0x3fffffffu;
   const uint32_t gq = b.q_begin + q;
   const uint32_t want = prm.nmatch < n ? prm.nmatch : n;
-  if (n == 0 && round == 0 && lane == 0) { out_count[gq] = 0; if (out_total) out_total[gq] = 0; }
+  if (n == 0 && round == 0) { out_count[gq] = 0; if (out_total) out_total[gq] = 0; }
   if (round >= want) return;
   const unsigned long long seg0 = w.q_seg[q];
   const Cand* seg = w.seg + seg0;
   unsigned long long* keys = sc.keys + 2ull * seg0;
   const float* pen_cur = sc.f1 + seg0;
   // std::max_element over the remaining list (score desc, s_id asc): first maximum of score - factor * penalty
-  float best_key = 0.f, best_score = 0.f;
-  uint32_t best_sid = 0;
+  float best_key = 0.f, best_score = 0.f, best_pen = 0.f;
+  uint32_t best_sid = 0, best_longest = 0;
   int best = -1;
-  auto better = [](float key, float score, uint32_t sid, float bkey, float bscore, uint32_t bsid) {
-    return bkey < key || (bkey == key && (bscore < score || (bscore == score && sid < bsid)));
-  };
-  for (uint32_t k = lane; k < n; k += kWave) {
+  for (uint32_t k = 0; k < n; k++) {
     if (keys[k] >> 63) continue;
     const Cand c = seg[k];
-    const float key = c.score - (prm.contrast * pen_cur[k]);
-    if (best < 0 || better(key, c.score, c.sid, best_key, best_score, best_sid)) {
-      best = (int)k; best_key = key; best_score = c.score; best_sid = c.sid;
+    const float pen = pen_cur[k];
+    const float key = c.score - (prm.contrast * pen);
+    if (best < 0 || best_key < key || (best_key == key && (best_score < c.score || (best_score == c.score && c.sid < best_sid)))) {
+      best = (int)k; best_key = key; best_score = c.score; best_sid = c.sid; best_pen = pen; best_longest = c.longest;
     }
   }
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) {
-    const float ok = __shfl_xor(best_key, d, 64);
-    const float os = __shfl_xor(best_score, d, 64);
-    const uint32_t oi = __shfl_xor(best_sid, d, 64);
-    const int   ob = __shfl_xor(best, d, 64);
-    if (ob >= 0 && (best < 0 || better(ok, os, oi, best_key, best_score, best_sid))) {
-      best = ob; best_key = ok; best_score = os; best_sid = oi;
-    }
+  if (round < cap) {
+    Rec r;
+    r.score = best_score; r.penalty = best_pen; r.max_subseq = (int32_t)best_longest; r.s_id = best_sid;
+    out_rec[(unsigned long long)gq * cap + round] = r;
   }
-  if (lane == 0) {
-    if (round < cap) {
-      const Cand c = seg[best];
-      Rec r;
-      r.score = c.score; r.penalty = pen_cur[best]; r.max_subseq = (int32_t)c.longest; r.s_id = c.sid;
-      out_rec[(unsigned long long)gq * cap + round] = r;
-    }
-    keys[best] |= 1ull << 63;
-    w.q_aux[q] = (uint32_t)best;
-    if (round + 1 == want) { out_count[gq] = want < cap ? want : cap; if (out_total) out_total[gq] = want; }
-  }
+  keys[best] |= 1ull << 63;
+  w.q_aux[q] = (uint32_t)best;
+  if (round + 1 == want) { out_count[gq] = want < cap ? want : cap; if (out_total) out_total[gq] = want; }
 }
 
 template <int P>
