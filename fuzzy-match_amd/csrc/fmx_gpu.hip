@@ -386,7 +386,7 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm_in, const D
                 if (m.d.max_slen > 32)
                   hipLaunchKernelGGL(k_cdp<64>, dim3(256 * 8), dim3(kWave), 0, stream, m.d, b, w, prm, m.sc, r);
               }
-              hipLaunchKernelGGL(k_cpick, dim3((b.nq + 255) / 256), dim3(256), 0, stream, b, w, prm, m.sc, r, cap, d_out, d_out_count,
+              hipLaunchKernelGGL(k_cpick, dim3((b.nq + 255) / 256), dim3(256), 0, stream, m.d, b, w, prm, m.sc, r, cap, d_out, d_out_count,
                                  d_out_total);
             }
           } else {

@@ -61,7 +61,7 @@ struct DevWork {
   uint32_t* q_cand;     // nq
   uint32_t* q_acc;      // nq
   uint32_t* q_pb;       // nq   hits queued by k_expand_a for k_expand_b
-  uint32_t* q_aux;      // nq   contrastive rerank: the match picked last
+  uint32_t* q_aux;      // nq   contrastive rerank: sentence-buffer position of the match picked last
   uint32_t* q_rank;     // nq   position of the query in pattern-length order (DP lists are built in that order)
   uint32_t* p_hist;     // 2 x kPBins: queries per pattern length, then the placement cursors
   const uint16_t* cmin_tab;  // (p_max + 1) x kCminTab: per (pattern length, stored sentence length) the phase-A threshold
@@ -2100,7 +2100,7 @@ __global__ void __launch_bounds__(kWave) k_camap(DevBatch b, DevWork w, DevScrat
   }
 }
 
-__global__ void __launch_bounds__(256) k_cpick(DevBatch b, DevWork w, Params prm, DevScratch sc, uint32_t round,
+__global__ void __launch_bounds__(256) k_cpick(DevIndex ix, DevBatch b, DevWork w, Params prm, DevScratch sc, uint32_t round,
                                                uint32_t cap, Rec* out_rec, uint32_t* out_count, uint32_t* out_total) {
   // one thread per query: the accepted list of a query is a handful of entries (at most the contrast buffer),
   // and a wave per query spent its time on the dependent loads in front of them
@@ -2137,7 +2137,7 @@ __global__ void __launch_bounds__(256) k_cpick(DevBatch b, DevWork w, Params prm
     out_rec[(unsigned long long)gq * cap + round] = r;
   }
   keys[best] |= 1ull << 63;
-  w.q_aux[q] = (uint32_t)best;
+  w.q_aux[q] = ix.sent_pos[best_sid];  // where the picked sentence starts: k_cdp needs nothing else of it
   if (round + 1 == want) { out_count[gq] = want < cap ? want : cap; if (out_total) out_total[gq] = want; }
 }
 
@@ -2159,7 +2159,7 @@ __global__ void __launch_bounds__(kWave) k_cdp(DevIndex ix, DevBatch b, DevWork 
     unsigned long long* keys = sc.keys + 2ull * seg0;
     if (keys[k] >> 63) continue;
     const Cand* seg = w.seg + seg0;
-    const uint32_t msp = ix.sent_pos[seg[w.q_aux[q]].sid];
+    const uint32_t msp = w.q_aux[q];
     const uint32_t n2 = ix.tok[msp];
     const uint32_t csp = ix.sent_pos[seg[k].sid];
     const uint32_t n1 = ix.tok[csp];
