@@ -104,15 +104,46 @@ def test_threshold_monotonicity_and_order(fmx, c2):
 
 
 def test_oracle_sample_at_scale(fmx, c2):
-    """3000 of the 100 k queries against the oracle on the full 1 M-sentence index, every BASELINE parameter set."""
+    """All 100 k queries of config C2 against the oracle on the full 1 M-sentence index, bit for bit, for the
+    C3 / C4 / C5 parameter sets (a few seconds of oracle time on the GPU box's host cores each)."""
     ix, c_off, c_tok, q_off, q_tok, vs = c2
     o = oracle_lib.OracleIndex()
     o.set_arrays(ix.array("suf_sid"), ix.array("suf_pos"), ix.array("buffer"), ix.array("sent_pos"), ix.array("qva"),
                  ix.array("sfreq"))
-    n = 3000
+    n = len(q_off) - 1
     so, st = q_off[:n + 1], q_tok[:int(q_off[n])]
     for name in ["C3", "C4", "C5"]:
         kw = workloads.PARAM_SETS[name]
         oo, oc = o.match_batch(oracle_lib.Params(**kw), so, st, 5, nthreads=oracle_lib.effective_cpus())
         go, gc, _ = ix.match_batch(fmx.Params(**kw), so, st, cap=5)
         workloads.compare(oo, oc, go, gc, name)
+
+
+def test_c3_headline_config_parity(fmx, gpu_device):
+    """The bench workload itself (config C3: 5 M sentences, mean 25 tokens, fuzzy 0.7, nmatch 5): 200 k of its
+    1 M queries, every record compared bit for bit with the oracle on the same index (≈ 7 s of oracle time on
+    16 host cores), and the remaining queries through the self-match property."""
+    c_off, c_tok, q_off, q_tok, vs = workloads.synthetic(5_000_000, 1_000_000, 25)
+    ix = fmx.Index.create()
+    ix.add_ids(c_off, c_tok, vs)
+    ix.sort(gpu_device)
+    ix.finalize()
+    ix.to_device(gpu_device)
+    kw = workloads.PARAM_SETS["C3"]
+    go, gc, _ = ix.match_batch(fmx.Params(**kw), q_off, q_tok, cap=5)
+    o = oracle_lib.OracleIndex()
+    o.set_arrays(ix.array("suf_sid"), ix.array("suf_pos"), ix.array("buffer"), ix.array("sent_pos"), ix.array("qva"),
+                 ix.array("sfreq"))
+    n = 200_000
+    so, st = q_off[:n + 1], q_tok[:int(q_off[n])]
+    oo, oc = o.match_batch(oracle_lib.Params(**kw), so, st, 5, nthreads=oracle_lib.effective_cpus())
+    workloads.compare(oo, oc, go[:n], gc[:n], "C3 headline")
+    # all 1 M: results ordered, scores within (fuzzy, 1], ids valid
+    n_sent = len(c_off) - 1
+    cnt = gc.astype(np.int64)
+    assert cnt.max() <= 5 and int((cnt > 0).sum()) > 500_000
+    valid = np.arange(5)[None, :] < cnt[:, None]
+    sc, sid = go["score"], go["s_id"]
+    assert np.all(sid[valid] < n_sent) and np.all(sc[valid] >= np.float32(0.7)) and np.all(sc[valid] <= 1.0)
+    both = valid[:, 1:] & valid[:, :-1]
+    assert np.all((sc[:, :-1] > sc[:, 1:])[both] | ((sc[:, :-1] == sc[:, 1:]) & (sid[:, :-1] < sid[:, 1:]))[both])
