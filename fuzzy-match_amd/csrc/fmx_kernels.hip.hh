@@ -1801,34 +1801,41 @@ __device__ __forceinline__ uint32_t replay_body(const Params& prm, uint32_t p, u
 // global memory: accepted candidates are flagged in a mask and their scores replace the costs in LDS.
 // Single-wave workgroup: LDS ordering by wave_lds_sync, no barriers.
 __device__ __forceinline__ unsigned long long replay_small(const Params& prm, uint32_t p, uint32_t n_cand, const Cand* seg,
-                                                           float* heap_store, ReplayShared& sh) {
+                                                           ReplayShared& sh) {
   const uint32_t lane = lane_id();
-  CostHeap heap;
-  heap.v = heap_store;
-  heap.n = 0;
   bool maybe = false;
+  float my_cost = 0.f, my_M = 0.f, my_score = 0.f;
   if (lane < n_cand) {
     const Cand cd = seg[lane];
     const uint32_t slen = cd.longest >> 16;
-    sh.final_cost[lane] = cd.score; sh.M[lane] = cd.penalty; sh.sid[lane] = cd.sid;
-    sh.L[lane] = cd.longest & 0xffffu; sh.slen[lane] = slen;
+    my_cost = cd.score; my_M = cd.penalty; my_score = score_from_cost(cd.score);
+    sh.sid[lane] = cd.sid; sh.L[lane] = cd.longest & 0xffffu; sh.score[lane] = my_score;  // for the ranking afterwards
     maybe = !(prm.no_perfect && cd.score == 0.f && slen == p);
-    sh.score[lane] = score_from_cost(cd.score);
   }
   unsigned long long todo = __ballot(maybe);
-  wave_lds_sync();
+  // lowest_costs as a sorted array spread over the lanes (lane i holds v[i], CostHeap's layout): a turn of the
+  // candidate loop is a handful of cross-lane operations on wave-uniform values, with no LDS round trips.
+  float hv = FLT_MAX;  // v[0] = FLT_MAX, the reference's initial bound
+  uint32_t n = 1;
   unsigned long long acc = 0;
-  if (lane == 0) {
-    heap.push(FLT_MAX);
-    while (todo) {
-      const uint32_t k = (uint32_t)__ffsll((long long)todo) - 1u;
-      todo &= todo - 1ull;
-      if (replay_candidate_scored(heap, prm, p, sh.slen[k], sh.final_cost[k], sh.M[k], sh.score[k])) acc |= 1ull << k;
-    }
+  while (todo) {
+    const int k = __builtin_ctzll(todo);
+    todo &= todo - 1ull;
+    const float fc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_cost), k));
+    const float Mk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_M), k));
+    const float sc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_score), k));
+    const float ub = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hv), (int)(n - 1)));
+    if (Mk > ub) continue;  // replay_candidate_scored; the no_perfect rule is already in `todo`
+    // push(fc): behind the elements <= fc, the larger ones move up one lane
+    const uint32_t pos = (uint32_t)__popcll(__ballot(lane < n && hv <= fc));
+    const float up = __shfl_up(hv, 1, 64);
+    hv = lane == pos ? fc : ((lane > pos && lane <= n) ? up : hv);
+    n++;
+    if (sc < prm.fuzzy || (prm.cbuf > 0 && n > (uint32_t)prm.cbuf)) n--;  // pop: the largest goes
+    if (sc >= prm.fuzzy) acc |= 1ull << k;
   }
   wave_lds_sync();
-  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)acc), hi = __builtin_amdgcn_readfirstlane((uint32_t)(acc >> 32));
-  return ((unsigned long long)hi << 32) | lo;
+  return acc;
 }
 
 template <int MODE>
@@ -1969,7 +1976,7 @@ __global__ void __launch_bounds__(kWave) k_finish(DevIndex ix, DevBatch b, DevWo
       // one wave holds the whole candidate set: replay, rank and emit from registers / LDS
       const unsigned long long seg0 = uni(w.q_seg[q]);
       const uint32_t p = uni(b.q_off[gq + 1]) - uni(b.q_off[gq]);
-      const unsigned long long acc = replay_small(prm, p, n_cand, w.seg + seg0, s_heap, sh);
+      const unsigned long long acc = replay_small(prm, p, n_cand, w.seg + seg0, sh);
       const uint32_t n = (uint32_t)__popcll(acc);
       const uint32_t want = prm.nmatch == 0 ? n : (prm.nmatch < n ? prm.nmatch : n);
       const uint32_t emit = want < cap ? want : cap;
