@@ -1738,7 +1738,7 @@ struct ReplayShared {
 
 __device__ __forceinline__ uint32_t replay_body(const Params& prm, uint32_t p, uint32_t n_cand, Cand* seg,
                                                 float* heap_store, ReplayShared& sh, uint32_t& max_slen_out) {
-  constexpr int kAhead = 4;  // chunks whose candidates are requested together (the loop is a latency chain)
+  constexpr int kAhead = 8;  // chunks whose candidates are requested together (the loop is a latency chain)
   uint32_t max_slen = 0;
   const uint32_t lane = lane_id();
   CostHeap heap;
