@@ -59,3 +59,35 @@ def test_random_parameters(fmx, corpora, case):
     oo, oc = o.match_batch(oracle_lib.Params(**kw), q_off, q_tok, cap, nthreads=oracle_lib.effective_cpus())
     go, gc, gt = ix.match_batch(fmx.Params(**kw), q_off, q_tok, cap=cap)
     workloads.compare(oo, oc, go, gc, str(kw))
+
+
+@pytest.fixture(scope="module")
+def dense(fmx, gpu_device):
+    """Tiny vocabularies: hundreds of candidates per query, many exact ties in score and match length, UNK /
+    empty / over-long / id-0 patterns (workloads.edge_queries)."""
+    out = []
+    for seed, vocab in enumerate([3, 5, 9]):
+        rng = np.random.default_rng(50 + seed)
+        c_off, c_tok = workloads.dense_corpus(rng, 1500, vocab, min_len=1, max_len=14)
+        q_off, q_tok = workloads.edge_queries(rng, c_off, c_tok, vocab, 300)
+        ix = fmx.Index.create(max_tokens=24)
+        ix.add_ids(c_off, c_tok, vocab + 2)
+        ix.sort(gpu_device)
+        ix.finalize()
+        ix.to_device(gpu_device)
+        o = oracle_lib.OracleIndex(max_tokens=24)
+        o.add_ids_bulk(c_off, c_tok, vocab + 2, sfreq=ix.array("sfreq"))
+        o.sort(2)
+        out.append((ix, o, q_off, q_tok))
+    return out
+
+
+@pytest.mark.parametrize("case", range(N_CASES))
+def test_random_parameters_dense(fmx, dense, case):
+    rng = np.random.default_rng(5000 + case)
+    ix, o, q_off, q_tok = dense[case % len(dense)]
+    kw = _draw(rng)
+    cap = kw["nmatch"] or 2048
+    oo, oc = o.match_batch(oracle_lib.Params(**kw), q_off, q_tok, cap, nthreads=oracle_lib.effective_cpus())
+    go, gc, gt = ix.match_batch(fmx.Params(**kw), q_off, q_tok, cap=cap)
+    workloads.compare(oo, oc, go, gc, str(kw))
