@@ -148,7 +148,20 @@ __global__ void __launch_bounds__(64) k_probe(DevIndex ix, DevBatch b, DevWork w
   }
   const uint32_t cnt = hi - lo;
   w.t_lo[t] = lo;
-  w.t_cnt[t] = cnt;  // summed per query by k_caps (an atomic per start position here costs more than the search)
+  w.t_cnt[t] = cnt;
+  // Per-query hit totals (q_hits, zeroed by the host): a query's start positions are consecutive lanes, so a
+  // segmented scan over the wave leaves one atomic per (wave, query) instead of one per start position.
+  const uint32_t lane = lane_id();
+  unsigned long long sum = cnt;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t oq = __shfl_up(q, d, 64);
+    const uint32_t olo = __shfl_up((uint32_t)sum, d, 64), ohi = __shfl_up((uint32_t)(sum >> 32), d, 64);
+    if (lane >= (uint32_t)d && oq == q) sum += ((unsigned long long)ohi << 32) | olo;
+  }
+  const uint32_t nq = __shfl_down(q, 1, 64);
+  const bool tail = lane == 63 || t + 1 >= b.nt || nq != q;
+  if (tail && sum != 0) atomicAdd(&w.q_hits[q], sum);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -240,27 +253,9 @@ struct WorkItem {
 
 __global__ void __launch_bounds__(256) k_caps(DevBatch b, DevWork w, WorkItem* items, uint32_t item_cap, uint32_t s_max) {
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-  // hits of the query = sum of its start positions' range sizes.  The block's queries own one contiguous
-  // token span: it is read coalesced by the whole block and summed per query through LDS.
-  __shared__ unsigned long long s_hits[256];
-  __shared__ uint32_t s_span[2];
-  s_hits[threadIdx.x] = 0;
-  if (threadIdx.x == 0) {
-    const uint32_t q0 = blockIdx.x * blockDim.x;
-    const uint32_t q1 = q0 + blockDim.x < b.nq ? q0 + blockDim.x : b.nq;
-    s_span[0] = b.q_off[b.q_begin + q0] - b.t_begin;
-    s_span[1] = b.q_off[b.q_begin + q1] - b.t_begin;
-  }
-  __syncthreads();
-  for (uint32_t t = s_span[0] + threadIdx.x; t < s_span[1]; t += blockDim.x) {
-    const uint32_t c = w.t_cnt[t];
-    if (c) atomicAdd(&s_hits[w.t_q[t] - blockIdx.x * blockDim.x], (unsigned long long)c);
-  }
-  __syncthreads();
   if (q > b.nq) return;
   if (q == b.nq) { w.q_cap[q] = 0; return; }
-  const unsigned long long hits = w.q_m[q] != kNoMatchLen ? s_hits[threadIdx.x] : 0ull;
-  w.q_hits[q] = hits;
+  const unsigned long long hits = w.q_hits[q];  // summed by k_probe
   w.q_cap[q] = hits < s_max ? hits : (unsigned long long)s_max;
   w.q_kept[q] = 0;
   if (hits > kExpandChunk) {
