@@ -195,6 +195,12 @@ def main():
                             "traffic": traffic,
                             "algorithmic_bytes_per_launch": round(probe_bytes_per_query * nq / max(launches_per_step, 1)), "algorithmic_bytes_per_query": round(probe_bytes_per_query, 1),
                             "kernel_ms_per_step": round(probe_ms, 4), "launches_per_step": launches_per_step,
+                            # the same launch priced on its measured HBM traffic (the north star's >= 0.40 target)
+                            "traffic_gbps": round(traffic * launches_per_step / (probe_ms * 1e-3) / 1e9, 2) if traffic else None,
+                            "traffic_frac": round(traffic * launches_per_step / (probe_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None,
+                            "note": "achieved/frac use the reference algorithm's logical bytes (SURVEY 8d: every compare step of "
+                                    "equal_range from the top of the first-word bucket); the n-gram tables skip most of those "
+                                    "steps, so frac can exceed 1. traffic_* is the PMC-measured HBM traffic of the same launch.",
                             "stage_ms_per_step": {k: round(v, 4) for k, v in per_stage.items()}}
         if not args.no_cpu_baseline and world == 1:
             cores = oracle_lib.effective_cpus()  # cgroup CPU quota, not the 256 hardware threads of the host
