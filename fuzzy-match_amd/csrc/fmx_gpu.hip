@@ -86,6 +86,8 @@ struct DeviceIndex::Impl {
   uint32_t   sub_queries = 1u << 20;  // queries per pipeline pass: large passes amortise the ~40 launches and their tails
   uint32_t   host_sub_queries = 1u << 18;  // pass size of the host-buffer entry point: result copies overlap the next pass
   hipStream_t copy_stream = nullptr;       // D2H of finished passes (non-blocking stream)
+  hipStream_t side_stream = nullptr;       // the few-queries / long-latency tail kernels run beside the bulk kernels
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   uint16_t*  cmin_tab = nullptr;           // threshold table of k_cmin, (cmin_rows) x 256
   uint32_t   cmin_rows = 0;
   std::function<void(uint32_t)> on_launched;  // match_host's hook: pass `sb` is enqueued, passes < sb are complete
@@ -117,6 +119,7 @@ DeviceIndex::~DeviceIndex() {
     hipFree(m.d_qoff); hipFree(m.d_qtok); hipFree(m.d_qreal); hipFree(m.d_qitok);
     hipFree(m.d_out); hipFree(m.d_out_count); hipFree(m.d_out_total); hipFree(m.items); hipFree(m.items_b);
     if (m.copy_stream) { hipStreamDestroy(m.copy_stream); m.copy_stream = nullptr; }
+    if (m.side_stream) { hipStreamDestroy(m.side_stream); m.side_stream = nullptr; hipEventDestroy(m.ev_fork); hipEventDestroy(m.ev_join); }
     hipFree(m.cmin_tab); m.cmin_tab = nullptr; m.cmin_rows = 0;
     if (m.ev_ok) for (auto& e : m.ev) hipEventDestroy(e);
   }
@@ -302,16 +305,28 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm_in, const D
                            (const WorkItem*)m.items_b, m.item_cap);
       }
       tick(); tick();
+      if (!m.side_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&m.side_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&m.ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&m.ev_join, hipEventDisableTiming));
+      }
+      // fork: `side` continues after everything enqueued on `stream` so far; join: `stream` waits for `side`
+      auto fork = [&]() { HIP_TRY(hipEventRecord(m.ev_fork, stream)); HIP_TRY(hipStreamWaitEvent(m.side_stream, m.ev_fork, 0)); };
+      auto join = [&]() { HIP_TRY(hipEventRecord(m.ev_join, m.side_stream)); HIP_TRY(hipStreamWaitEvent(stream, m.ev_join, 0)); };
       hipLaunchKernelGGL(k_cand, dim3((b.nq + 3) / 4), dim3(256), 0, stream, b, w, m.big_list, m.mid_list);
-      hipLaunchKernelGGL(k_cand_mid, dim3(1024), dim3(256), 0, stream, w, (const uint32_t*)m.mid_list);
-      tick(); tick();
       {
+        // The sorter of the few huge survivor sets is one workgroup per query and leaves the GPU almost idle:
+        // it runs on the side stream next to k_cand_mid (disjoint queries).
         // radix passes needed: sentence ids < n_sent, match lengths <= longest pattern
         uint32_t sid_bytes = 1, len_bytes = p_max < 255 ? 1u : 2u;
         while (sid_bytes < 4 && (m.d.n_sent >> (8 * sid_bytes)) != 0) sid_bytes++;
-        hipLaunchKernelGGL(k_cand_big, dim3(kBigGrid), dim3(kBigThreads), 0, stream, w, m.sc.keys,
+        fork();
+        hipLaunchKernelGGL(k_cand_big, dim3(kBigGrid), dim3(kBigThreads), 0, m.side_stream, w, m.sc.keys,
                            (const uint32_t*)m.big_list, sid_bytes, len_bytes);
       }
+      hipLaunchKernelGGL(k_cand_mid, dim3(1024), dim3(256), 0, stream, w, (const uint32_t*)m.mid_list);
+      tick(); tick();
+      join();  // stage "cand_big" = what is left of the big sorter after k_cand_mid
       tick(); tick();
       {
         // dense per-class candidate lists: three exclusive scans of the per-query candidate counts
@@ -324,7 +339,7 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm_in, const D
           hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanThreads), 0, stream, m.tile_sums, tiles, m.grand_total);
           hipLaunchKernelGGL(k_scan_add, dim3(tiles), dim3(kScanThreads), 0, stream, w.c_off + (size_t)c * n, m.tile_sums, n);
         }
-        hipLaunchKernelGGL(k_cmap, dim3((b.nq + 255) / 256), dim3(256), 0, stream, b, w, full ? 1 : 0);
+        hipLaunchKernelGGL(k_cmap, dim3((b.nq + 255) / 256), dim3(256), 0, stream, b, w, full ? 1 : 0, m.fin_list);
       }
       tick(); tick();
       {
@@ -362,10 +377,14 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm_in, const D
       }
       tick(); tick();
       {
+        // the queue of large candidate sets was filled by k_cmap: their (long, mostly sequential) replay runs on the
+        // side stream next to the bulk kernel; the two touch disjoint queries
+        fork();
+        hipLaunchKernelGGL((k_finish<kLdsSortMax, true>), dim3(2048), dim3(kWave), 0, m.side_stream, m.d, b, w, prm, m.sc, cap,
+                           d_out, d_out_count, d_out_total, m.contrast_list, m.fin_list);
         hipLaunchKernelGGL((k_finish<64, false>), dim3(b.nq), dim3(kWave), 0, stream, m.d, b, w, prm, m.sc, cap, d_out,
                            d_out_count, d_out_total, m.contrast_list, m.fin_list);
-        hipLaunchKernelGGL((k_finish<kLdsSortMax, true>), dim3(2048), dim3(kWave), 0, stream, m.d, b, w, prm, m.sc, cap,
-                           d_out, d_out_count, d_out_total, m.contrast_list, m.fin_list);
+        join();
         if (prm.contrast > 0.f) {
           const uint32_t* cl = m.contrast_list;
           if (prm.nmatch >= 1 && prm.nmatch <= kMaxFlatRounds) {

@@ -1419,13 +1419,14 @@ __global__ void k_classify(DevBatch b, DevWork w, int full) {
 
 // lane per query: small candidate sets are written by their own lane, large ones by the whole wave
 constexpr uint32_t kCmapSmall = 16;
-__global__ void __launch_bounds__(256) k_cmap(DevBatch b, DevWork w, int full) {
+__global__ void __launch_bounds__(256) k_cmap(DevBatch b, DevWork w, int full, uint32_t* fin_list) {
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t lane = lane_id();
   uint32_t n = 0;
   unsigned long long base = 0;
   if (q < b.nq) {
     n = w.q_cand[q];
+    if (n > kWave) fin_list[atomicAdd(&w.counters[14], 1ull)] = q;  // k_finish<.., true>: replay + large sorter
     if (n) {
       const size_t stride = (size_t)b.nq + 1;
       const uint32_t p = b.q_off[b.q_begin + q + 1] - b.q_off[b.q_begin + q];
@@ -1961,10 +1962,7 @@ __global__ void __launch_bounds__(kWave) k_finish(DevIndex ix, DevBatch b, DevWo
     const uint32_t q = LIST ? fin_list[item] : (uint32_t)item;
     const uint32_t gq = b.q_begin + q;
     const uint32_t n_cand = w.q_cand[q];
-    if (!LIST && n_cand > kWave) {  // needs the large sorter / multi-chunk replay
-      if (lane == 0) fin_list[atomicAdd(&w.counters[14], 1ull)] = q;
-      continue;
-    }
+    if (!LIST && n_cand > kWave) continue;  // queued by k_cmap for the list kernel (large sorter / multi-chunk replay)
     Rec* out = out_rec + (unsigned long long)gq * cap;
     uint32_t cnt = 0, tot = 0;
     if (!LIST && !contrast && n_cand != 0 && prm.cbuf > 0 && prm.cbuf <= (int)kHeapLdsMax) {
