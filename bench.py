@@ -161,7 +161,7 @@ def main():
         per_stage = {n: float(stage_ms[i] / max(args.steps, 1)) for i, n in enumerate(names)}
         log(f"[bench] kernel ms/step by stage: { {k: round(v, 3) for k, v in per_stage.items()} }")
         log(f"[bench] last step: hits {last.n_hits} kept {last.n_kept} candidates {last.n_candidates} dp {last.n_dp} "
-            f"retries {last.n_retries} big {last.n_big} phaseB {last.n_phase_b} max_kept {last.max_kept} "
+            f"retries {last.n_retries} big {last.n_big} phaseB {last.n_phase_b} max_kept {last.max_kept} heavy {last.n_heavy_hits} heavy_pass {last.n_heavy_pass} "
             f"wall {last.ms_total:.2f} ms")
         import oracle_lib
         t1 = time.time()

@@ -5,9 +5,15 @@
 
 #include <string.h>
 
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <exception>
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "fmx_gpu.hh"
@@ -15,11 +21,16 @@
 
 using namespace fmx;
 
+struct Coalescer;
+
 struct fmx_index {
-  HostIndex                    host;
-  std::unique_ptr<DeviceIndex> dev;
-  bool                         finalized = false;
-  std::mutex                   mu;  // serialises matching calls (one workspace per index) and interning
+  HostIndex                                 host;
+  std::vector<std::unique_ptr<DeviceIndex>> devs;  // replicas of the frozen index, one per device
+  bool                                      finalized = false;
+  std::mutex                                mu;    // interning of penalty strings, lazy construction of the coalescer
+  std::unique_ptr<Coalescer>                co;
+  int64_t                                   coalesce_us = 50;
+  ~fmx_index();
 };
 
 static thread_local std::string g_err;
@@ -32,8 +43,12 @@ static int fail(int code, const std::string& msg) {
 template <class F> static int guarded(F&& f) {
   try {
     return f();
+  } catch (const UnsupportedError& e) {
+    return fail(FMX_E_UNSUPPORTED, e.what());
   } catch (const GpuError& e) {
     return fail(FMX_E_NO_DEVICE, e.what());
+  } catch (const std::invalid_argument& e) {
+    return fail(FMX_E_INVALID, e.what());
   } catch (const std::bad_alloc&) {
     return fail(FMX_E_NOMEM, "out of host memory");
   } catch (const std::exception& e) {
@@ -48,6 +63,8 @@ const char* fmx_version(void) { return "fmx 0.1 (gfx950)"; }
 const char* fmx_stage_name(int stage) { return stage_name(stage); }
 
 int fmx_device_count(void) { return gpu_device_count(); }
+void* fmx_host_alloc(size_t bytes) { return gpu_host_alloc(bytes); }
+void  fmx_host_free(void* p) { gpu_host_free(p); }
 
 fmx_index* fmx_index_create(int32_t pt, uint64_t max_tokens_in_pattern) {
   try {
@@ -92,7 +109,7 @@ int64_t fmx_index_add_tm(fmx_index* ix, const char* id, const char* const* norm,
                          const char* const* itok_str) {
   if (!ix || (n_norm && !norm)) return fail(FMX_E_INVALID, "null argument");
   if (ix->finalized) return fail(FMX_E_STATE, "index is finalized");
-  int64_t r = -1;
+  int64_t r = FMX_TM_SKIPPED;
   int rc = guarded([&]() {
     std::vector<std::string> toks(norm, norm + n_norm);
     RealTok real;
@@ -104,6 +121,7 @@ int64_t fmx_index_add_tm(fmx_index* ix, const char* id, const char* const* norm,
     for (uint32_t k = 0; k < n_itoks; k++) real.itoks.emplace_back(itok_idx[k], std::string(itok_str[k]));
     if (!ix->host.ids.empty() || ix->host.sent_pos.empty()) {
       r = ix->host.add_tm(id ? id : "", real, toks);
+      if (r < 0) r = FMX_TM_SKIPPED;  // ignored like the reference ignores it: not an error
     } else
       throw std::runtime_error("cannot mix id-only and string-level sentences in one index");
     return FMX_OK;
@@ -135,17 +153,35 @@ int fmx_index_finalize(fmx_index* ix) {
   return guarded([&]() { ix->host.derive(); ix->finalized = true; return (int)FMX_OK; });
 }
 
-int fmx_index_to_device(fmx_index* ix, int device) {
-  if (!ix) return fail(FMX_E_INVALID, "null argument");
-  if (!ix->finalized) return fail(FMX_E_STATE, "index is not finalized");
-  if (ix->dev) return ix->dev->device() == device ? (int)FMX_OK : fail(FMX_E_STATE, "index already on another device");
+static int add_device(fmx_index* ix, int device) {
+  for (auto& d : ix->devs) if (d->device() == device) return FMX_OK;
   return guarded([&]() {
     std::unique_ptr<DeviceIndex> d(new DeviceIndex);
     d->upload(ix->host, device);
-    ix->dev = std::move(d);
+    ix->devs.push_back(std::move(d));
     return (int)FMX_OK;
   });
 }
+
+int fmx_index_to_device(fmx_index* ix, int device) {
+  if (!ix) return fail(FMX_E_INVALID, "null argument");
+  if (!ix->finalized) return fail(FMX_E_STATE, "index is not finalized");
+  if (!ix->devs.empty())
+    return ix->devs[0]->device() == device ? (int)FMX_OK : fail(FMX_E_STATE, "index already on another device (fmx_index_to_devices adds replicas)");
+  return add_device(ix, device);
+}
+
+int fmx_index_to_devices(fmx_index* ix, const int* devices, int n_devices) {
+  if (!ix || !devices || n_devices <= 0) return fail(FMX_E_INVALID, "null argument");
+  if (!ix->finalized) return fail(FMX_E_STATE, "index is not finalized");
+  for (int k = 0; k < n_devices; k++) {
+    const int rc = add_device(ix, devices[k]);
+    if (rc != FMX_OK) return rc;
+  }
+  return FMX_OK;
+}
+
+int fmx_set_devices(fmx_index* ix, const int* devices, int n_devices) { return fmx_index_to_devices(ix, devices, n_devices); }
 
 int fmx_vocab_lookup(const fmx_index* ix, const char* const* toks, uint64_t n, uint32_t* ids) {
   if (!ix || (n && (!toks || !ids))) return fail(FMX_E_INVALID, "null argument");
@@ -213,12 +249,12 @@ int fmx_index_get_info(const fmx_index* ix, fmx_index_info* info) {
   info->pt = h.pt;
   info->sorted = h.sorted;
   info->finalized = ix->finalized;
-  info->on_device = ix->dev != nullptr;
-  info->device = ix->dev ? ix->dev->device() : -1;
+  info->on_device = (int32_t)ix->devs.size();
+  info->device = !ix->devs.empty() ? ix->devs[0]->device() : -1;
   info->real_differs = h.real_differs;
   info->n_itok = (uint32_t)h.itok_strings.size();
   info->idf_max = h.idf_max;
-  info->device_bytes = ix->dev ? ix->dev->bytes() : 0;
+  info->device_bytes = !ix->devs.empty() ? ix->devs[0]->bytes() : 0;
   return FMX_OK;
 }
 
@@ -246,6 +282,58 @@ static void copy_stats(const Stats& s, fmx_stats* o) {
   for (int i = 0; i < 16; i++) { o->ms_kernel[i] = s.ms_kernel[i]; o->launches[i] = s.launches[i]; }
   o->n_hits = s.n_hits; o->n_kept = s.n_kept; o->n_candidates = s.n_candidates; o->n_dp = s.n_dp;
   o->n_retries = s.n_retries; o->n_big = s.n_big; o->n_phase_b = s.n_phase_b; o->max_kept = s.max_kept;
+  o->n_heavy_hits = s.n_heavy_hits; o->n_heavy_pass = s.n_heavy_pass; o->pinned = s.pinned;
+}
+
+// match(const Tokens&) builds `real` from the pattern itself (src/fuzzy_match.cc:428): the real token of position
+// j is the word form; unknown words never equal an indexed word id anyway.
+static void real_from_forms(const fmx_index* ix, const uint32_t* wids, uint64_t n, uint32_t* out) {
+  for (uint64_t t = 0; t < n; t++) {
+    const uint32_t w = wids[t];
+    out[t] = (w < ix->host.forms.size() && w != 1u) ? ix->host.lookup_real(ix->host.forms[w]) : 0x7ffffffeu;
+  }
+}
+
+// One batch over every replica of the index: contiguous query blocks, one per device, run concurrently; each
+// block's records land directly in the caller's buffers (index replicated, no data-path exchange).
+static void match_on_devices(fmx_index* ix, const Params& prm, const HostBatchView& v, fmx_match* out, uint32_t* out_count,
+                             uint32_t* out_total, uint32_t cap, Stats* st) {
+  const size_t nd = ix->devs.size();
+  if (nd == 1 || v.nq < 2 * nd) {
+    ix->devs[0]->match_host(ix->host, prm, v, (Rec*)out, out_count, out_total, cap, st);
+    return;
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  std::vector<Stats> sts(nd);
+  std::vector<std::exception_ptr> errs(nd);
+  auto run = [&](size_t d) {
+    try {
+      const uint64_t lo = v.nq * d / nd, hi = v.nq * (d + 1) / nd;
+      HostBatchView s = v;
+      s.nq = hi - lo;
+      s.q_off = v.q_off + lo;                            // absolute offsets: the block's tokens are q_tok[q_off[lo] .. q_off[hi])
+      if (v.q_itok) s.q_itok = v.q_itok + lo;            // slot of (query, j) = q_off[q] + q + j: the block's view starts lo slots in
+      ix->devs[d]->match_host(ix->host, prm, s, (Rec*)(out + lo * cap), out_count + lo, out_total ? out_total + lo : nullptr, cap, &sts[d]);
+    } catch (...) {
+      errs[d] = std::current_exception();
+    }
+  };
+  std::vector<std::thread> th;
+  for (size_t d = 1; d < nd; d++) th.emplace_back(run, d);
+  run(0);
+  for (auto& t : th) t.join();
+  for (auto& e : errs) if (e) std::rethrow_exception(e);
+  if (st) {
+    for (size_t d = 0; d < nd; d++) {
+      const Stats& s = sts[d];
+      for (int i = 0; i < 16; i++) { st->ms_kernel[i] = std::max(st->ms_kernel[i], s.ms_kernel[i]); st->launches[i] += s.launches[i]; }
+      st->ms_h2d = std::max(st->ms_h2d, s.ms_h2d); st->ms_d2h = std::max(st->ms_d2h, s.ms_d2h);
+      st->n_hits += s.n_hits; st->n_kept += s.n_kept; st->n_candidates += s.n_candidates; st->n_dp += s.n_dp;
+      st->n_retries += s.n_retries; st->n_big += s.n_big; st->n_phase_b += s.n_phase_b; st->max_kept = std::max(st->max_kept, s.max_kept);
+      st->n_heavy_hits += s.n_heavy_hits; st->n_heavy_pass += s.n_heavy_pass; st->pinned = s.pinned;
+    }
+    st->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  }
 }
 
 int fmx_match_batch(fmx_index* ix, const fmx_params* params, const fmx_batch* hb, fmx_match* out,
@@ -254,28 +342,173 @@ int fmx_match_batch(fmx_index* ix, const fmx_params* params, const fmx_batch* hb
   if (hb->nq && (!hb->q_off || (hb->q_off[hb->nq] && !hb->q_tok))) return fail(FMX_E_INVALID, "null batch arrays");
   if (cap == 0) return fail(FMX_E_INVALID, "cap must be > 0");
   if (!ix->finalized) return fail(FMX_E_STATE, "index is not finalized");
-  if (!ix->dev) return fail(FMX_E_NO_DEVICE, "index is not on a device (fmx_index_to_device); there is no CPU path");
+  if (ix->devs.empty()) return fail(FMX_E_NO_DEVICE, "index is not on a device (fmx_index_to_device); there is no CPU path");
+  // re-entrant: no index-wide lock; every call works in its own context (fmx_gpu.hip)
   return guarded([&]() {
-    std::lock_guard<std::mutex> lk(ix->mu);
     HostBatchView v;
     v.nq = hb->nq; v.q_off = hb->q_off; v.q_tok = hb->q_tok; v.q_real = hb->q_real; v.q_itok = hb->q_itok;
-    std::vector<uint32_t> real_from_forms;
+    std::vector<uint32_t> forms_real;
     if (ix->host.real_differs && !v.q_real && hb->nq) {
-      // match(const Tokens&) builds `real` from the pattern itself (src/fuzzy_match.cc:428): the real
-      // token of position j is the word form; unknown words never equal an indexed word id anyway.
       const uint64_t nt = hb->q_off[hb->nq];
-      real_from_forms.resize(nt);
-      for (uint64_t t = 0; t < nt; t++) {
-        const uint32_t w = hb->q_tok[t];
-        real_from_forms[t] = (w < ix->host.forms.size() && w != 1u) ? ix->host.lookup_real(ix->host.forms[w]) : 0x7ffffffeu;
-      }
-      v.q_real = real_from_forms.data();
+      forms_real.resize(nt);
+      real_from_forms(ix, hb->q_tok, nt, forms_real.data());
+      v.q_real = forms_real.data();
     }
     Stats st;
-    ix->dev->match_host(ix->host, make_params(ix, params), v, (Rec*)out, out_count, out_total, cap, &st);
+    match_on_devices(ix, make_params(ix, params), v, out, out_count, out_total, cap, &st);
     copy_stats(st, stats);
     return (int)FMX_OK;
   });
+}
+
+// ---------------------------------------------------------------------------------------------
+// Request coalescer behind fmx_match_one.  The reference's match() is called one pattern at a time from N
+// threads; a GPU pass costs ~45 launches whatever its size, so concurrent requests with equal parameters are
+// gathered into one micro-batch.  Dispatcher threads (one per context) take everything that is pending the moment
+// they become free; an idle dispatcher waits at most coalesce_us after the first arrival for company.
+// ---------------------------------------------------------------------------------------------
+struct Request {
+  fmx_params      prm;
+  const uint32_t* wids; uint32_t p;
+  const uint32_t* real; const uint32_t* itok;
+  fmx_match*      out; uint32_t cap;
+  uint32_t        count = 0, total = 0;
+  int             status = FMX_OK;
+  std::string     err;
+  bool            done = false;
+};
+
+struct Coalescer {
+  fmx_index*               ix;
+  std::mutex               mu;
+  std::condition_variable  cv_work, cv_done;
+  std::deque<Request*>     pending;
+  std::vector<std::thread> workers;
+  bool                     stop = false;
+  uint32_t                 last_batch = 1;
+
+  explicit Coalescer(fmx_index* ix_, int n_workers) : ix(ix_) {
+    for (int k = 0; k < n_workers; k++) workers.emplace_back([this]() { loop(); });
+  }
+  ~Coalescer() {
+    { std::lock_guard<std::mutex> lk(mu); stop = true; }
+    cv_work.notify_all();
+    for (auto& t : workers) t.join();
+  }
+  void submit_and_wait(Request& r) {
+    std::unique_lock<std::mutex> lk(mu);
+    pending.push_back(&r);
+    cv_work.notify_one();
+    cv_done.wait(lk, [&]() { return r.done; });
+  }
+  void loop() {
+    struct Pinned {
+      void* p = nullptr; size_t cap = 0;
+      void* get(size_t n) { if (n > cap) { gpu_host_free(p); p = gpu_host_alloc(n + n / 2); cap = p ? n + n / 2 : 0; } return p; }
+      ~Pinned() { gpu_host_free(p); }
+    } b_off, b_tok, b_real, b_itok, b_out, b_cnt, b_tot;
+    std::vector<Request*> batch;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_work.wait(lk, [&]() { return stop || !pending.empty(); });
+        if (stop && pending.empty()) return;
+        // idle start: give the other callers a moment to arrive (at most coalesce_us, less once as many as last
+        // time are waiting)
+        const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(ix->coalesce_us);
+        while (!stop && pending.size() < last_batch && std::chrono::steady_clock::now() < deadline)
+          cv_work.wait_until(lk, deadline);
+        batch.clear();
+        const fmx_params first = pending.front()->prm;
+        const uint32_t cap = pending.front()->cap;
+        for (auto it = pending.begin(); it != pending.end() && batch.size() < 65536;) {
+          if (memcmp(&(*it)->prm, &first, sizeof(fmx_params)) == 0 && (*it)->cap == cap) { batch.push_back(*it); it = pending.erase(it); }
+          else ++it;
+        }
+        last_batch = (uint32_t)batch.size();
+        if (!pending.empty()) cv_work.notify_one();  // other parameter sets: another dispatcher may take them
+      }
+      const uint64_t nq = batch.size();
+      uint64_t nt = 0;
+      bool any_real = ix->host.real_differs, any_itok = false;
+      for (auto* r : batch) { nt += r->p; any_itok = any_itok || r->itok; }
+      const uint32_t cap = batch[0]->cap;
+      uint32_t* q_off = (uint32_t*)b_off.get((nq + 1) * 4);
+      uint32_t* q_tok = (uint32_t*)b_tok.get((nt + 1) * 4);
+      uint32_t* q_real = any_real ? (uint32_t*)b_real.get((nt + 1) * 4) : nullptr;
+      uint32_t* q_itok = any_itok ? (uint32_t*)b_itok.get((nt + nq + 1) * 4) : nullptr;
+      fmx_match* out = (fmx_match*)b_out.get(nq * cap * sizeof(fmx_match));
+      uint32_t* cnt = (uint32_t*)b_cnt.get(nq * 4);
+      uint32_t* tot = (uint32_t*)b_tot.get(nq * 4);
+      int status = FMX_OK;
+      std::string err;
+      if (!q_off || !q_tok || (any_real && !q_real) || (any_itok && !q_itok) || !out || !cnt || !tot) {
+        status = FMX_E_NOMEM; err = "out of pinned host memory";
+      } else {
+        uint32_t o = 0;
+        for (uint64_t q = 0; q < nq; q++) {
+          const Request& r = *batch[q];
+          q_off[q] = o;
+          memcpy(q_tok + o, r.wids, (size_t)r.p * 4);
+          if (q_real) { if (r.real) memcpy(q_real + o, r.real, (size_t)r.p * 4); else real_from_forms(ix, r.wids, r.p, q_real + o); }
+          if (q_itok) { if (r.itok) memcpy(q_itok + o + q, r.itok, (size_t)(r.p + 1) * 4); else memset(q_itok + o + q, 0, (size_t)(r.p + 1) * 4); }
+          o += r.p;
+        }
+        q_off[nq] = o;
+        status = guarded([&]() {
+          HostBatchView v;
+          v.nq = nq; v.q_off = q_off; v.q_tok = q_tok; v.q_real = q_real; v.q_itok = q_itok;
+          match_on_devices(ix, make_params(ix, &batch[0]->prm), v, out, cnt, tot, cap, nullptr);
+          return (int)FMX_OK;
+        });
+        if (status != FMX_OK) err = g_err;
+      }
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        for (uint64_t q = 0; q < nq; q++) {
+          Request& r = *batch[q];
+          r.status = status;
+          if (status == FMX_OK) {
+            r.count = cnt[q]; r.total = tot[q];
+            memcpy(r.out, out + q * cap, (size_t)cnt[q] * sizeof(fmx_match));
+          } else r.err = err;
+          r.done = true;
+        }
+      }
+      cv_done.notify_all();
+    }
+  }
+};
+
+fmx_index::~fmx_index() { co.reset(); }
+
+int fmx_match_one(fmx_index* ix, const fmx_params* params, const uint32_t* wids, uint32_t p, const uint32_t* q_real,
+                  const uint32_t* q_itok, fmx_match* out, uint32_t cap, uint32_t* out_count, uint32_t* out_total) {
+  if (!ix || !params || !out || !out_count || (p && !wids)) return fail(FMX_E_INVALID, "null argument");
+  if (cap == 0) return fail(FMX_E_INVALID, "cap must be > 0");
+  if (!ix->finalized) return fail(FMX_E_STATE, "index is not finalized");
+  if (ix->devs.empty()) return fail(FMX_E_NO_DEVICE, "index is not on a device (fmx_index_to_device); there is no CPU path");
+  if (!ix->co) {
+    std::lock_guard<std::mutex> lk(ix->mu);
+    if (!ix->co) {
+      try { ix->co.reset(new Coalescer(ix, 2)); } catch (const std::exception& e) { return fail(FMX_E_NOMEM, e.what()); }
+    }
+  }
+  Request r;
+  r.prm = *params; r.wids = wids; r.p = p; r.real = q_real; r.itok = q_itok; r.out = out; r.cap = cap;
+  ix->co->submit_and_wait(r);
+  if (r.status != FMX_OK) return fail(r.status, r.err);
+  *out_count = r.count;
+  if (out_total) *out_total = r.total;
+  return FMX_OK;
+}
+
+int fmx_index_reopen(fmx_index* ix) {
+  if (!ix) return fail(FMX_E_INVALID, "null argument");
+  ix->co.reset();
+  ix->devs.clear();
+  ix->finalized = false;
+  return FMX_OK;
 }
 
 int fmx_match_batch_device(fmx_index* ix, const fmx_params* params, const fmx_batch* db, uint64_t total_tokens,
@@ -285,20 +518,20 @@ int fmx_match_batch_device(fmx_index* ix, const fmx_params* params, const fmx_ba
   if (!ix || !params || !db || !d_out || !d_out_count) return fail(FMX_E_INVALID, "null argument");
   if (cap == 0) return fail(FMX_E_INVALID, "cap must be > 0");
   if (!ix->finalized) return fail(FMX_E_STATE, "index is not finalized");
-  if (!ix->dev) return fail(FMX_E_NO_DEVICE, "index is not on a device (fmx_index_to_device); there is no CPU path");
+  if (ix->devs.empty()) return fail(FMX_E_NO_DEVICE, "index is not on a device (fmx_index_to_device); there is no CPU path");
   if (ix->host.real_differs && !db->q_real)
     return fail(FMX_E_INVALID, "this index has real tokens: device batches must carry q_real");
   if (db->nq == 0) return FMX_OK;
   return guarded([&]() {
-    std::lock_guard<std::mutex> lk(ix->mu);
+    DeviceIndex* dev = ix->devs[0].get();  // device buffers live on one device: the first replica's
     DeviceBatchView v;
     v.nq = db->nq; v.q_off = db->q_off; v.q_tok = db->q_tok; v.q_real = db->q_real; v.q_itok = db->q_itok;
     v.p_max = db->max_len;
     const auto t0 = std::chrono::steady_clock::now();
-    std::vector<uint32_t> bounds = ix->dev->sub_bounds_from_device(db->q_off, db->nq, &v.p_max, stream);
+    std::vector<uint32_t> bounds = dev->sub_bounds_from_device(db->q_off, db->nq, &v.p_max, stream);
     if (v.p_max == 0) v.p_max = 1;
     Stats st;
-    ix->dev->match_device(ix->host, make_params(ix, params), v, (Rec*)d_out, d_out_count, d_out_total, cap, stream,
+    dev->match_device(ix->host, make_params(ix, params), v, (Rec*)d_out, d_out_count, d_out_total, cap, stream,
                           bounds, &st);
     st.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     copy_stats(st, stats);
@@ -308,12 +541,17 @@ int fmx_match_batch_device(fmx_index* ix, const fmx_params* params, const fmx_ba
 
 int fmx_set_option(fmx_index* ix, const char* name, int64_t value) {
   if (!ix || !name) return fail(FMX_E_INVALID, "null argument");
-  if (!ix->dev) return fail(FMX_E_STATE, "index is not on a device");
   const std::string n(name);
-  if (n == "sub_queries") ix->dev->set_sub_queries((uint32_t)std::max<int64_t>(value, 1));
-  else if (n == "host_sub_queries") ix->dev->set_host_sub_queries((uint32_t)std::max<int64_t>(value, 1));
-  else if (n == "initial_segment") ix->dev->set_initial_segment((uint64_t)std::max<int64_t>(value, 1024));
-  else return fail(FMX_E_INVALID, "unknown option " + n);
+  if (n == "coalesce_us") { ix->coalesce_us = std::max<int64_t>(value, 0); return FMX_OK; }
+  if (ix->devs.empty()) return fail(FMX_E_STATE, "index is not on a device");
+  for (auto& d : ix->devs) {
+    if (n == "sub_queries") d->set_sub_queries((uint32_t)std::max<int64_t>(value, 1));
+    else if (n == "host_sub_queries") d->set_host_sub_queries((uint32_t)std::max<int64_t>(value, 1));
+    else if (n == "initial_segment") d->set_initial_segment((uint64_t)std::max<int64_t>(value, 1024));
+    else if (n == "heavy_min") d->set_heavy_min((uint32_t)std::max<int64_t>(value, 0));
+    else if (n == "contexts") d->set_contexts((uint32_t)std::max<int64_t>(value, 1));
+    else return fail(FMX_E_INVALID, "unknown option " + n);
+  }
   return FMX_OK;
 }
 

@@ -9,7 +9,10 @@
 
 namespace fmx {
 
-struct GpuError : std::runtime_error {
+struct GpuError : std::runtime_error {  // a HIP call failed / no usable device
+  using std::runtime_error::runtime_error;
+};
+struct UnsupportedError : std::runtime_error {  // a documented limit of this build (not a device failure)
   using std::runtime_error::runtime_error;
 };
 
@@ -21,6 +24,7 @@ struct Stats {
   double   ms_kernel[16] = {0};
   uint64_t launches[16] = {0};
   uint64_t n_hits = 0, n_kept = 0, n_candidates = 0, n_dp = 0, n_retries = 0, n_big = 0, n_phase_b = 0, max_kept = 0;
+  uint64_t n_heavy_hits = 0, n_heavy_pass = 0, pinned = 0;
 };
 
 struct Rec;  // == fmx_match, defined in fmx_kernels.hip.hh
@@ -44,6 +48,8 @@ struct DeviceBatchView {
 
 int  gpu_device_count();
 void gpu_suffix_sort(HostIndex& h, int device);
+void* gpu_host_alloc(size_t bytes);  // pinned host memory (hipHostMalloc), nullptr on failure
+void  gpu_host_free(void* p);
 
 class DeviceIndex {
  public:
@@ -59,6 +65,8 @@ class DeviceIndex {
   void     set_sub_queries(uint32_t n);
   void     set_host_sub_queries(uint32_t n);
   void     set_initial_segment(uint64_t n);
+  void     set_heavy_min(uint32_t n);   // ranges at least this long use the bit-plane kernel (0 = never)
+  void     set_contexts(uint32_t n);    // concurrent calls served at once (each owns a workspace)
 
   // every pointer in HBM of device(); sub_tok_bounds = q_off at each sub-batch boundary (+ q_off[nq])
   void match_device(const HostIndex& h, const Params& prm, const DeviceBatchView& b, Rec* d_out,

@@ -1,13 +1,11 @@
 // fmx_gpu.hip — device residency of the index and the batched match() pipeline.
 //
-// HBM layout (immutable, SoA, replicated per GPU — SURVEY §8e):
-//   suf      SufRec[n_suf]  8 B   {token offset, tokens left, sentence length}: one load per compare step
-//   suf_sid  u32[n_suf]           sentence id, only read for hits that survive the filters
-//   tok      u32[n_buf]           the reference's _sentence_buffer verbatim: [len, tok x len, 0]
-//   sent_pos u32[n_sent]          _sentence_pos
-//   qva      u32[vocab+1]         _quickVocabAccess
-//   idf      f32[vocab]           logf(N / sfreq[w]) computed on the host with glibc (bit-exact scores)
-//   real / itok / itok_dist       only for indexes whose real tokens differ from the normalised ones
+// HBM layout (immutable, SoA, replicated per GPU — SURVEY §8e): see DESIGN.md §3.
+//
+// Re-entrancy (the reference's match() is const and is called from N threads on one instance,
+// cli/src/FuzzyMatch-cli.cc:139-147): the index arrays are immutable after upload(); everything a call
+// mutates — workspace, staging buffers, streams, events — lives in a Ctx taken from a small pool, so
+// concurrent calls overlap on the GPU instead of serialising on a lock.
 #include "fmx_gpu.hh"
 
 #include <string.h>
@@ -18,6 +16,10 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <shared_mutex>
 #include <stdexcept>
 #include <string>
 
@@ -32,17 +34,36 @@ namespace fmx {
       throw GpuError(std::string(#expr) + ": " + hipGetErrorString(e_));                            \
   } while (0)
 
+static bool is_gfx950(int ordinal) {
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, ordinal) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return std::string(prop.gcnArchName).rfind("gfx950", 0) == 0;
+}
+
+// number of HIP ordinals; ordinals that are not gfx950 are rejected individually by check_device()
 int gpu_device_count() {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
   int usable = 0;
-  for (int d = 0; d < n; d++) {
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, d) != hipSuccess) continue;
-    if (std::string(prop.gcnArchName).rfind("gfx950", 0) == 0) usable++;
-  }
+  for (int d = 0; d < n; d++) usable += is_gfx950(d) ? 1 : 0;
   return usable;
 }
+
+// `device` is a HIP ordinal: it must exist and be a gfx950 part itself (a lower ordinal of another
+// architecture does not make a higher one usable, and vice versa)
+static void check_device(int device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); n = 0; }
+  if (device < 0 || device >= n || !is_gfx950(device))
+    throw GpuError("no usable gfx950 device at HIP ordinal " + std::to_string(device));
+}
+
+void* gpu_host_alloc(size_t bytes) {
+  void* p = nullptr;
+  if (hipHostMalloc(&p, std::max<size_t>(bytes, 1), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return p;
+}
+void gpu_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
 template <class T> static T* dev_alloc(size_t n) {
   void* p = nullptr;
@@ -56,72 +77,152 @@ template <class T> static T* dev_upload(const std::vector<T>& v) {
   return p;
 }
 
+// device buffer that only ever grows, by at least 1.5x (first-call and heavy-tail latency cliffs: one buffer
+// growing never frees the others)
+template <class T> struct Grow {
+  T*       p = nullptr;
+  uint64_t cap = 0;
+  bool ensure(uint64_t need) {  // true if reallocated
+    if (need <= cap && p) return false;
+    const uint64_t c = std::max<uint64_t>(need, cap + cap / 2);
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+    p = dev_alloc<T>(c);
+    cap = c;
+    return true;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+constexpr int kMaxPassesInFlight = 2;
+
+// Everything one call mutates.
+struct Ctx {
+  // ---- workspace ----
+  Grow<uint32_t> q_m, q_kept, q_cand, q_acc, q_pb, q_aux, q_rank, big_list, mid_list, fin_list, contrast_list;
+  Grow<unsigned long long> q_hits, q_hits_a, q_seg, q_cap, c_in, c_off;
+  Grow<uint32_t> t_q, t_lo, t_cnt;
+  Grow<float>    t_idf;
+  Grow<unsigned long long> c_qi, keys;
+  Grow<Cand>     seg;
+  Grow<QHit>     qb;
+  Grow<float>    heap, f0, f1;
+  Grow<uint32_t> vals;
+  Grow<uint32_t> p_hist;
+  Grow<unsigned long long> counters, tile_sums, grand_total;
+  Grow<WorkItem> items, items_b;
+  Grow<HeavyItem> items_h;
+  Grow<uint16_t> cmin_tab;
+  Grow<float>    g_rows;      // DP rows in HBM for patterns / sentences too long for the LDS rows
+  uint32_t s_max = 4096;      // survivors kept per query before a retry with a larger segment
+  uint64_t seg_cap = 0;
+  // ---- staging of the host-buffer entry point (each buffer tracks its own capacity) ----
+  Grow<uint32_t> d_qoff, d_qtok, d_qreal, d_qitok, d_cnt, d_tot;
+  Grow<Rec>      d_out;
+  // ---- streams / events ----
+  hipStream_t stream = nullptr, h2d = nullptr, d2h = nullptr, side = nullptr;
+  hipEvent_t  ev[2 * kNumStages]{};
+  hipEvent_t  ev_fork = nullptr, ev_join = nullptr, ev_in[kMaxPassesInFlight]{}, ev_done = nullptr;
+  unsigned long long* h_ctr = nullptr;  // pinned: the pass counters land here
+  bool ok = false;
+
+  void init() {
+    HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&h2d, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&d2h, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+    HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming));
+    for (auto& e : ev_in) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIP_TRY(hipHostMalloc((void**)&h_ctr, kNumCounters * sizeof(unsigned long long), hipHostMallocDefault));
+    counters.ensure(kNumCounters);
+    tile_sums.ensure(kScanTile);
+    grand_total.ensure(1);
+    p_hist.ensure(2 * kPBins);
+    ok = true;
+  }
+  void destroy() {
+    q_m.release(); q_kept.release(); q_cand.release(); q_acc.release(); q_pb.release(); q_aux.release(); q_rank.release();
+    big_list.release(); mid_list.release(); fin_list.release(); contrast_list.release();
+    q_hits.release(); q_hits_a.release(); q_seg.release(); q_cap.release(); c_in.release(); c_off.release();
+    t_q.release(); t_lo.release(); t_cnt.release(); t_idf.release(); c_qi.release(); keys.release(); seg.release(); qb.release();
+    heap.release(); f0.release(); f1.release(); vals.release(); p_hist.release(); counters.release(); tile_sums.release();
+    grand_total.release(); items.release(); items_b.release(); items_h.release(); cmin_tab.release(); g_rows.release();
+    d_qoff.release(); d_qtok.release(); d_qreal.release(); d_qitok.release(); d_cnt.release(); d_tot.release(); d_out.release();
+    if (stream) (void)hipStreamDestroy(stream);
+    if (h2d) (void)hipStreamDestroy(h2d);
+    if (d2h) (void)hipStreamDestroy(d2h);
+    if (side) (void)hipStreamDestroy(side);
+    for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : ev_in) if (e) (void)hipEventDestroy(e);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
+    if (ev_done) (void)hipEventDestroy(ev_done);
+    if (h_ctr) (void)hipHostFree(h_ctr);
+  }
+};
+
 struct DeviceIndex::Impl {
   int      device = -1;
   DevIndex d{};
   uint64_t bytes = 0;
   uint64_t itok_version = ~0ull;
-  // workspace (grown on demand, reused across calls; one call at a time per index)
-  uint64_t cap_q = 0, cap_t = 0, cap_seg = 0;
-  DevWork  w{};
-  DevScratch sc{};
-  unsigned long long* tile_sums = nullptr;
-  unsigned long long* grand_total = nullptr;
-  uint32_t* big_list = nullptr;
-  uint32_t* mid_list = nullptr;
-  uint32_t* fin_list = nullptr;
-  uint32_t* contrast_list = nullptr;  // 2 x cap_q
-  WorkItem* items = nullptr;
-  WorkItem* items_b = nullptr;
-  uint32_t  item_cap = 0;
-  uint32_t  s_max = 4096;   // survivors kept per query before a retry with a larger segment
-  // staging for the host-batch entry point
-  uint32_t *d_qoff = nullptr, *d_qtok = nullptr, *d_qreal = nullptr, *d_qitok = nullptr;
-  uint64_t  cap_hq = 0, cap_ht = 0;
-  Rec*      d_out = nullptr;
-  uint32_t *d_out_count = nullptr, *d_out_total = nullptr;
-  uint64_t  cap_out = 0, cap_outq = 0;
-  hipEvent_t ev[2 * kNumStages]{};
-  bool       ev_ok = false;
-  uint32_t   sub_queries = 1u << 20;  // queries per pipeline pass: large passes amortise the ~40 launches and their tails
-  uint32_t   host_sub_queries = 1u << 18;  // pass size of the host-buffer entry point: result copies overlap the next pass
-  hipStream_t copy_stream = nullptr;       // D2H of finished passes (non-blocking stream)
-  hipStream_t side_stream = nullptr;       // the few-queries / long-latency tail kernels run beside the bulk kernels
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  uint16_t*  cmin_tab = nullptr;           // threshold table of k_cmin, (cmin_rows) x 256
-  uint32_t   cmin_rows = 0;
-  std::function<void(uint32_t)> on_launched;  // match_host's hook: pass `sb` is enqueued, passes < sb are complete
-  uint64_t   init_seg = 1ull << 24;
+  std::shared_mutex itok_mu;  // matching calls hold it shared; a grown penalty-string table swaps under exclusive
+  // options
+  uint32_t sub_queries = 1u << 20;       // queries per pipeline pass: large passes amortise the ~40 launches and their tails
+  uint32_t host_sub_queries = 1u << 18;  // pass size of the host-buffer entry point: copies overlap the neighbouring passes
+  uint64_t init_seg = 1ull << 24;
+  uint32_t heavy_min = kHeavyMinDefault; // suffix ranges at least this long go through the bit-plane kernel (0 = never)
+  uint32_t max_ctx = 2;
+  // context pool
+  std::mutex              pool_mu;
+  std::condition_variable pool_cv;
+  std::vector<std::unique_ptr<Ctx>> all;
+  std::vector<Ctx*>       idle;
+
+  Ctx* acquire() {
+    std::unique_lock<std::mutex> lk(pool_mu);
+    for (;;) {
+      if (!idle.empty()) { Ctx* c = idle.back(); idle.pop_back(); return c; }
+      if (all.size() < max_ctx) {
+        all.emplace_back(new Ctx);
+        Ctx* c = all.back().get();
+        lk.unlock();
+        try { c->init(); } catch (...) { lk.lock(); idle.push_back(c); pool_cv.notify_one(); throw; }
+        return c;
+      }
+      pool_cv.wait(lk);
+    }
+  }
+  void release(Ctx* c) {
+    { std::lock_guard<std::mutex> lk(pool_mu); idle.push_back(c); }
+    pool_cv.notify_one();
+  }
+};
+
+struct CtxLease {
+  DeviceIndex::Impl& m;
+  Ctx* c;
+  explicit CtxLease(DeviceIndex::Impl& m_) : m(m_), c(m_.acquire()) {
+    if (!c->ok) { Ctx* bad = c; c = nullptr; m.release(bad); throw GpuError("context initialisation failed earlier"); }
+  }
+  ~CtxLease() { if (c) m.release(c); }
 };
 
 DeviceIndex::DeviceIndex() : impl_(new Impl) {}
-
-static void free_ws(DeviceIndex::Impl& m) {
-  hipFree(m.w.q_m); hipFree(m.w.t_q); hipFree(m.w.t_lo); hipFree(m.w.t_cnt); hipFree(m.w.q_hits);
-  hipFree(m.w.q_seg); hipFree(m.w.q_kept); hipFree(m.w.q_cand); hipFree(m.w.q_acc); hipFree(m.w.q_pb); hipFree(m.w.q_aux); hipFree(m.w.q_rank); hipFree(m.w.p_hist); hipFree(m.w.c_in); hipFree(m.w.c_off); hipFree(m.w.t_idf); hipFree(m.w.c_qi); hipFree(m.big_list); m.big_list = nullptr; hipFree(m.mid_list); m.mid_list = nullptr; hipFree(m.fin_list); m.fin_list = nullptr; hipFree(m.contrast_list); m.contrast_list = nullptr;
-  hipFree(m.w.seg); hipFree(m.w.qb); hipFree(m.w.heap); hipFree(m.w.counters);
-  hipFree(m.sc.keys); hipFree(m.sc.vals); hipFree(m.sc.f0); hipFree(m.sc.f1);
-  hipFree(m.tile_sums); hipFree(m.grand_total); hipFree(m.w.q_cap);
-  m.w = DevWork{}; m.sc = DevScratch{};
-  m.tile_sums = m.grand_total = nullptr;
-  m.cap_q = m.cap_t = m.cap_seg = 0;
-}
 
 DeviceIndex::~DeviceIndex() {
   if (!impl_) return;
   Impl& m = *impl_;
   if (m.device >= 0) {
     (void)hipSetDevice(m.device);
+    (void)hipDeviceSynchronize();
     hipFree((void*)m.d.suf); hipFree((void*)m.d.suf_sig); hipFree((void*)m.d.suf_key); hipFree((void*)m.d.gram.g3); hipFree((void*)m.d.gram.g5); hipFree((void*)m.d.suf_b); hipFree((void*)m.d.tok); hipFree((void*)m.d.sent_pos);
     hipFree((void*)m.d.qva); hipFree((void*)m.d.idf); hipFree((void*)m.d.real); hipFree((void*)m.d.itok);
-    hipFree((void*)m.d.itok_dist);
-    free_ws(m);
-    hipFree(m.d_qoff); hipFree(m.d_qtok); hipFree(m.d_qreal); hipFree(m.d_qitok);
-    hipFree(m.d_out); hipFree(m.d_out_count); hipFree(m.d_out_total); hipFree(m.items); hipFree(m.items_b);
-    if (m.copy_stream) { hipStreamDestroy(m.copy_stream); m.copy_stream = nullptr; }
-    if (m.side_stream) { hipStreamDestroy(m.side_stream); m.side_stream = nullptr; hipEventDestroy(m.ev_fork); hipEventDestroy(m.ev_join); }
-    hipFree(m.cmin_tab); m.cmin_tab = nullptr; m.cmin_rows = 0;
-    if (m.ev_ok) for (auto& e : m.ev) hipEventDestroy(e);
+    hipFree((void*)m.d.itok_dist); hipFree((void*)m.d.planes);
+    for (auto& c : m.all) c->destroy();
   }
   delete impl_;
 }
@@ -131,8 +232,16 @@ uint64_t DeviceIndex::bytes() const { return impl_->bytes; }
 void     DeviceIndex::set_sub_queries(uint32_t n) { impl_->sub_queries = std::max<uint32_t>(n, 1); }
 void     DeviceIndex::set_host_sub_queries(uint32_t n) { impl_->host_sub_queries = std::max<uint32_t>(n, 1); }
 void     DeviceIndex::set_initial_segment(uint64_t n) { impl_->init_seg = std::max<uint64_t>(n, 1024); }
+void     DeviceIndex::set_heavy_min(uint32_t n) { impl_->heavy_min = n; }
+void     DeviceIndex::set_contexts(uint32_t n) {
+  std::lock_guard<std::mutex> lk(impl_->pool_mu);
+  impl_->max_ctx = std::max<uint32_t>(std::max<uint32_t>(n, 1), (uint32_t)impl_->all.size());
+}
 
-static void upload_itok_table(DeviceIndex::Impl& m, const HostIndex& h) {
+// the penalty-string distance table grows when queries intern new strings: swap it in while no call runs
+static void refresh_itok_table(DeviceIndex::Impl& m, const HostIndex& h) {
+  if (m.itok_version == h.itok_version) return;
+  std::unique_lock<std::shared_mutex> lk(m.itok_mu);
   if (m.itok_version == h.itok_version) return;
   hipFree((void*)m.d.itok_dist);
   m.d.itok_dist = nullptr;
@@ -141,10 +250,12 @@ static void upload_itok_table(DeviceIndex::Impl& m, const HostIndex& h) {
   m.itok_version = h.itok_version;
 }
 
+constexpr size_t kDynLdsMax = 150 * 1024;  // dynamic LDS the row kernels may ask for (160 KB per CU on gfx950)
+
 void DeviceIndex::upload(const HostIndex& h, int device) {
   Impl& m = *impl_;
   if (m.device >= 0) throw GpuError("index is already on a device");
-  if (gpu_device_count() <= device || device < 0) throw GpuError("no usable gfx950 device " + std::to_string(device));
+  check_device(device);
   HIP_TRY(hipSetDevice(device));
   m.device = device;
   m.d.suf = dev_upload(h.suf_rec);
@@ -172,56 +283,55 @@ void DeviceIndex::upload(const HostIndex& h, int device) {
   m.d.max_slen = mx;
   m.bytes = h.suf_rec.size() * 8 + h.suf_sig.size() * 8 + h.suf_key.size() * sizeof(SufKey) + h.gram.size() * 16 + h.gram5.size() * 16 + h.suf_b.size() * 16 + h.buf.size() * 4 + h.sent_pos.size() * 4 +
             h.qva.size() * 4 + h.idf.size() * 4;
+  // bit planes of the signatures, built on the device from suf_sig: plane-major, one 64-bit word per
+  // (signature bucket, block of 64 consecutive suffixes)
+  m.d.n_blk = (m.d.n_suf + 63) / 64;
+  m.d.planes = nullptr;
+  if (m.d.n_suf) {
+    unsigned long long* pl = dev_alloc<unsigned long long>((size_t)kPlaneRows * m.d.n_blk);
+    hipLaunchKernelGGL(k_build_planes, dim3((unsigned)m.d.n_blk), dim3(kWave), 0, 0, m.d.suf_sig, m.d.n_suf, m.d.n_blk, pl);
+    HIP_TRY(hipGetLastError());
+    m.d.planes = pl;
+    m.bytes += (uint64_t)kPlaneRows * m.d.n_blk * 8;
+  }
   if (h.real_differs) {
     m.d.real = dev_upload(h.real_ids);
     m.d.itok = dev_upload(h.itok_ids);
     m.bytes += h.real_ids.size() * 4 + h.itok_ids.size() * 4;
   }
-  upload_itok_table(m, h);
-  for (auto& e : m.ev) HIP_TRY(hipEventCreate(&e));
-  m.ev_ok = true;
+  refresh_itok_table(m, h);
+  // the LDS-row kernels may ask for up to kDynLdsMax of dynamic LDS: raise the limit once (not per call: the
+  // attribute is process-wide and calls run concurrently)
+  HIP_TRY(hipFuncSetAttribute((const void*)k_dp<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDynLdsMax));
+  HIP_TRY(hipFuncSetAttribute((const void*)k_dp<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDynLdsMax));
+  HIP_TRY(hipFuncSetAttribute((const void*)k_contrast<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDynLdsMax));
   HIP_TRY(hipDeviceSynchronize());
 }
 
-static void ensure_ws(DeviceIndex::Impl& m, uint64_t nq, uint64_t nt, uint64_t seg) {
-  if (nq > m.cap_q || nt > m.cap_t || seg > m.cap_seg) {
-    const uint64_t cq = std::max(nq, m.cap_q), ct = std::max(nt, m.cap_t), cs = std::max(seg, m.cap_seg);
-    free_ws(m);
-    m.w.q_m = dev_alloc<uint32_t>(cq);
-    m.w.t_q = dev_alloc<uint32_t>(ct);
-    m.w.t_lo = dev_alloc<uint32_t>(ct);
-    m.w.t_cnt = dev_alloc<uint32_t>(ct);
-    m.w.q_hits = dev_alloc<unsigned long long>(cq + 1);
-    m.w.q_seg = dev_alloc<unsigned long long>(cq + 1);
-    m.w.q_cap = dev_alloc<unsigned long long>(cq + 1);
-    m.w.q_kept = dev_alloc<uint32_t>(cq);
-    m.w.q_cand = dev_alloc<uint32_t>(cq);
-    m.w.q_acc = dev_alloc<uint32_t>(cq);
-    m.w.q_pb = dev_alloc<uint32_t>(cq);
-    m.w.q_aux = dev_alloc<uint32_t>(cq);
-    m.w.q_rank = dev_alloc<uint32_t>(cq);
-    m.w.p_hist = dev_alloc<uint32_t>(2 * kPBins);
-    m.w.c_in = dev_alloc<unsigned long long>(3 * (cq + 1));
-    m.w.c_off = dev_alloc<unsigned long long>(3 * (cq + 1));
-    m.w.t_idf = dev_alloc<float>(ct);
-    m.w.c_qi = dev_alloc<unsigned long long>(cs);
-    m.big_list = dev_alloc<uint32_t>(cq);
-    m.mid_list = dev_alloc<uint32_t>(cq);
-    m.fin_list = dev_alloc<uint32_t>(cq);
-    m.contrast_list = dev_alloc<uint32_t>(2 * cq);
-    m.w.seg = dev_alloc<Cand>(cs);
-    m.w.qb = dev_alloc<QHit>(cs);
-    m.w.heap = dev_alloc<float>(cs + cq + 1);
-    m.w.counters = dev_alloc<unsigned long long>(16);
-    m.w.seg_cap = cs;
-    m.sc.keys = dev_alloc<unsigned long long>(2 * cs);
-    m.sc.vals = dev_alloc<uint32_t>(2 * cs);
-    m.sc.f0 = dev_alloc<float>(cs);
-    m.sc.f1 = dev_alloc<float>(cs);
-    m.tile_sums = dev_alloc<unsigned long long>(kScanTile);
-    m.grand_total = dev_alloc<unsigned long long>(1);
-    m.cap_q = cq; m.cap_t = ct; m.cap_seg = cs;
+static void ensure_ws(Ctx& c, uint64_t nq, uint64_t nt, uint64_t seg) {
+  c.q_m.ensure(nq); c.q_kept.ensure(nq); c.q_cand.ensure(nq); c.q_acc.ensure(nq); c.q_pb.ensure(nq); c.q_aux.ensure(nq);
+  c.q_rank.ensure(nq); c.big_list.ensure(nq); c.mid_list.ensure(nq); c.fin_list.ensure(nq); c.contrast_list.ensure(2 * nq);
+  c.q_hits.ensure(nq + 1); c.q_hits_a.ensure(nq + 1); c.q_seg.ensure(nq + 1); c.q_cap.ensure(nq + 1);
+  c.c_in.ensure(3 * (nq + 1)); c.c_off.ensure(3 * (nq + 1));
+  c.t_q.ensure(nt); c.t_lo.ensure(nt); c.t_cnt.ensure(nt); c.t_idf.ensure(nt);
+  if (seg > c.seg_cap) {
+    const uint64_t s = std::max<uint64_t>(seg, c.seg_cap + c.seg_cap / 2);
+    c.c_qi.ensure(s); c.seg.ensure(s); c.qb.ensure(s); c.f0.ensure(s); c.f1.ensure(s);
+    c.keys.ensure(2 * s); c.vals.ensure(2 * s);
+    c.seg_cap = s;
   }
+  c.heap.ensure(c.seg_cap + nq + 1);
+  if (!c.items.p) { c.items.ensure(1u << 22); c.items_b.ensure(1u << 22); c.items_h.ensure(1u << 20); }
+}
+
+static DevWork work_view(Ctx& c) {
+  DevWork w{};
+  w.q_m = c.q_m.p; w.t_q = c.t_q.p; w.t_lo = c.t_lo.p; w.t_cnt = c.t_cnt.p; w.q_hits = c.q_hits.p; w.q_hits_a = c.q_hits_a.p;
+  w.q_cap = c.q_cap.p; w.q_seg = c.q_seg.p; w.q_kept = c.q_kept.p; w.q_cand = c.q_cand.p; w.q_acc = c.q_acc.p; w.q_pb = c.q_pb.p;
+  w.q_aux = c.q_aux.p; w.q_rank = c.q_rank.p; w.p_hist = c.p_hist.p; w.cmin_tab = c.cmin_tab.p; w.c_in = c.c_in.p;
+  w.c_off = c.c_off.p; w.c_qi = c.c_qi.p; w.t_idf = c.t_idf.p; w.seg = c.seg.p; w.qb = c.qb.p; w.heap = c.heap.p;
+  w.seg_cap = c.seg_cap; w.counters = c.counters.p;
+  return w;
 }
 
 const char* stage_name(int s) {
@@ -229,17 +339,18 @@ const char* stage_name(int s) {
   return (s >= 0 && s < kNumStages) ? names[s] : "";
 }
 
-void DeviceIndex::match_device(const HostIndex& h, const Params& prm_in, const DeviceBatchView& bv, Rec* d_out,
-                               uint32_t* d_out_count, uint32_t* d_out_total, uint32_t cap, void* stream_v,
-                               const std::vector<uint32_t>& sub_tok_bounds, Stats* st) {
-  Impl& m = *impl_;
-  if (m.device < 0) throw GpuError("index is not on a device");
-  HIP_TRY(hipSetDevice(m.device));
-  hipStream_t stream = (hipStream_t)stream_v;
-  upload_itok_table(m, h);
+// hooks of the host-buffer path around each pass (sub-batch) of the pipeline
+struct PassHooks {
+  std::function<void(uint32_t)> before;  // inputs of pass sb must be on their way; make `stream` wait for them
+  std::function<void(uint32_t)> after;   // pass sb is complete and final
+};
+
+static void run_passes(DeviceIndex::Impl& m, Ctx& c, const Params& prm_in, const DeviceBatchView& bv, Rec* d_out,
+                       uint32_t* d_out_count, uint32_t* d_out_total, uint32_t cap, hipStream_t stream,
+                       const std::vector<uint32_t>& sub_tok_bounds, uint32_t sub_queries, Stats* st, const PassHooks* hooks) {
   Params prm = prm_in;
-  if (cap == 0) throw GpuError("cap must be > 0");
-  // cost model: real-token / penalty-token terms need the general kernel (rows in LDS); idf alone has a
+  if (cap == 0) throw std::invalid_argument("cap must be > 0");
+  // cost model: real-token / penalty-token terms need the general kernel (DP rows in LDS / HBM); idf alone has a
   // register kernel
   const bool side_terms = (m.d.real && bv.q_real) || (bv.q_itok != nullptr) || (m.d.itok != nullptr);
   const bool use_idf = prm.idf_penalty != 0.f;
@@ -248,22 +359,30 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm_in, const D
   for (uint32_t sb = 0; sb < n_sub; sb++) {
     DevBatch b;
     b.q_off = bv.q_off; b.q_tok = bv.q_tok; b.q_real = bv.q_real; b.q_itok = bv.q_itok;
-    b.q_begin = sb * m.sub_queries;
-    b.nq = (uint32_t)std::min<uint64_t>(m.sub_queries, bv.nq - b.q_begin);
+    b.q_begin = sb * sub_queries;
+    b.nq = (uint32_t)std::min<uint64_t>(sub_queries, bv.nq - b.q_begin);
     b.t_begin = sub_tok_bounds[sb];
     b.nt = sub_tok_bounds[sb + 1] - sub_tok_bounds[sb];
-    uint64_t want_seg = std::max<uint64_t>(m.cap_seg, m.init_seg);
+    uint64_t want_seg = std::max<uint64_t>(c.seg_cap, std::min<uint64_t>(m.init_seg, std::max<uint64_t>(4096, (uint64_t)b.nq * 64)));
     uint32_t p_max = (uint32_t)std::min<uint64_t>(prm.max_tokens, std::max<uint32_t>(b.nt, 1));
     p_max = std::max<uint32_t>(1, std::min<uint32_t>(p_max, bv.p_max ? bv.p_max : p_max));
+    if (hooks && hooks->before) hooks->before(sb);
     for (int attempt = 0;; attempt++) {
-      ensure_ws(m, b.nq, std::max<uint32_t>(b.nt, 1), want_seg);
-      if (!m.items) { m.item_cap = 1u << 22; m.items = dev_alloc<WorkItem>(m.item_cap); m.items_b = dev_alloc<WorkItem>(m.item_cap); }
-      DevWork w = m.w;
+      ensure_ws(c, b.nq, std::max<uint32_t>(b.nt, 1), want_seg);
+      c.cmin_tab.ensure((uint64_t)(p_max + 1) * 256);
+      DevWork w = work_view(c);
+      const uint32_t item_cap = (uint32_t)std::min<uint64_t>(c.items.cap, 0xffffffffull);
+      const uint32_t item_h_cap = (uint32_t)std::min<uint64_t>(c.items_h.cap, 0xffffffffull);
       HIP_TRY(hipMemsetAsync(w.q_hits, 0, (b.nq + 1) * sizeof(unsigned long long), stream));
-      HIP_TRY(hipMemsetAsync(w.counters, 0, 16 * sizeof(unsigned long long), stream));
+      HIP_TRY(hipMemsetAsync(w.q_hits_a, 0, (b.nq + 1) * sizeof(unsigned long long), stream));
+      HIP_TRY(hipMemsetAsync(w.counters, 0, kNumCounters * sizeof(unsigned long long), stream));
       HIP_TRY(hipMemsetAsync(w.q_pb, 0, b.nq * sizeof(uint32_t), stream));
       int e = 0;
-      auto tick = [&]() { HIP_TRY(hipEventRecord(m.ev[e++], stream)); };
+      auto tick = [&]() { HIP_TRY(hipEventRecord(c.ev[e++], stream)); };
+      // the signature bound needs theoretical_rejection_cover to be monotone in the cover: costs >= 0
+      const int use_sig = prm.ins >= 0.f && prm.del >= 0.f && prm.rep >= 0.f;
+      // suffix ranges of at least heavy_min hits are walked through the signature bit planes (k_expand_h)
+      const uint32_t heavy_min = (use_sig && m.d.planes && m.heavy_min) ? std::max<uint32_t>(m.heavy_min, 256u) : 0xffffffffu;
       tick();
       hipLaunchKernelGGL(k_setup, dim3((b.nq + 255) / 256), dim3(256), 0, stream, m.d, b, w, prm);
       if (prm.idf_penalty != 0.f) hipLaunchKernelGGL(k_tidf, dim3((b.nt + 255) / 256), dim3(256), 0, stream, m.d, b, w);
@@ -274,46 +393,42 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm_in, const D
         hipLaunchKernelGGL(k_prank, dim3((b.nq + per_block - 1) / per_block), dim3(kRankThreads), 0, stream, b, w);
       }
       tick(); tick();
-      if (b.nt) hipLaunchKernelGGL(k_probe, dim3((b.nt + 63) / 64), dim3(64), 0, stream, m.d, b, w);
+      if (b.nt)
+        hipLaunchKernelGGL(k_probe, dim3((b.nt + 63) / 64), dim3(64), 0, stream, m.d, b, w, heavy_min, c.items_h.p, item_h_cap);
       tick(); tick();
       {
-        hipLaunchKernelGGL(k_caps, dim3((b.nq + 1 + 255) / 256), dim3(256), 0, stream, b, w, m.items, m.item_cap, m.s_max);
+        hipLaunchKernelGGL(k_caps, dim3((b.nq + 1 + 255) / 256), dim3(256), 0, stream, b, w, c.items.p, item_cap, c.s_max);
         const uint32_t n = b.nq + 1;  // one extra so that q_seg[nq] = total
         const uint32_t tiles = (n + kScanTile - 1) / kScanTile;
-        if (tiles > (uint32_t)kScanTile) throw GpuError("sub-batch too large for the scan");
-        hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(kScanThreads), 0, stream, w.q_cap, w.q_seg, m.tile_sums, n);
-        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanThreads), 0, stream, m.tile_sums, tiles, m.grand_total);
-        hipLaunchKernelGGL(k_scan_add, dim3(tiles), dim3(kScanThreads), 0, stream, w.q_seg, m.tile_sums, n);
+        if (tiles > (uint32_t)kScanTile) throw std::invalid_argument("sub-batch too large for the scan");
+        hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(kScanThreads), 0, stream, w.q_cap, w.q_seg, c.tile_sums.p, n);
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanThreads), 0, stream, c.tile_sums.p, tiles, c.grand_total.p);
+        hipLaunchKernelGGL(k_scan_add, dim3(tiles), dim3(kScanThreads), 0, stream, w.q_seg, c.tile_sums.p, n);
       }
       tick(); tick();
-      {
-        // the signature bound needs theoretical_rejection_cover to be monotone in the cover: costs >= 0
-        const int use_sig = prm.ins >= 0.f && prm.del >= 0.f && prm.rep >= 0.f;
-        if (p_max + 1 > m.cmin_rows) {
-          hipFree(m.cmin_tab);
-          m.cmin_rows = p_max + 1;
-          m.cmin_tab = dev_alloc<uint16_t>((size_t)m.cmin_rows * 256);
-        }
-        w.cmin_tab = m.cmin_tab;
-        hipLaunchKernelGGL(k_cmin, dim3(p_max + 1), dim3(256), 0, stream, m.d.max_slen, prm, use_sig, m.cmin_tab);
-        hipLaunchKernelGGL(k_expand_a, dim3(b.nq + kExpandExtraGrid), dim3(kWave), 0, stream, m.d, b, w, prm,
-                           (const WorkItem*)m.items, m.item_cap, use_sig);
-        hipLaunchKernelGGL(k_caps_b, dim3((b.nq + 255) / 256), dim3(256), 0, stream, b, w, m.items_b, m.item_cap);
-        const size_t lds = (size_t)p_max * 4;
-        if (lds > 64 * 1024) throw GpuError("patterns too long for the expand kernel's LDS staging");
-        hipLaunchKernelGGL(k_expand_b, dim3(b.nq + kExpandExtraGrid), dim3(kWave), lds, stream, m.d, b, w, prm,
-                           (const WorkItem*)m.items_b, m.item_cap);
-      }
-      tick(); tick();
-      if (!m.side_stream) {
-        HIP_TRY(hipStreamCreateWithFlags(&m.side_stream, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&m.ev_fork, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&m.ev_join, hipEventDisableTiming));
-      }
       // fork: `side` continues after everything enqueued on `stream` so far; join: `stream` waits for `side`
-      auto fork = [&]() { HIP_TRY(hipEventRecord(m.ev_fork, stream)); HIP_TRY(hipStreamWaitEvent(m.side_stream, m.ev_fork, 0)); };
-      auto join = [&]() { HIP_TRY(hipEventRecord(m.ev_join, m.side_stream)); HIP_TRY(hipStreamWaitEvent(stream, m.ev_join, 0)); };
-      hipLaunchKernelGGL(k_cand, dim3((b.nq + 3) / 4), dim3(256), 0, stream, b, w, m.big_list, m.mid_list);
+      auto fork = [&]() { HIP_TRY(hipEventRecord(c.ev_fork, stream)); HIP_TRY(hipStreamWaitEvent(c.side, c.ev_fork, 0)); };
+      auto join = [&]() { HIP_TRY(hipEventRecord(c.ev_join, c.side)); HIP_TRY(hipStreamWaitEvent(stream, c.ev_join, 0)); };
+      {
+        hipLaunchKernelGGL(k_cmin, dim3(p_max + 1), dim3(256), 0, stream, m.d.max_slen, prm, use_sig, c.cmin_tab.p);
+        // the few long ranges stream through the bit planes on the side stream next to the per-hit walk of
+        // everything else: both append to the per-query queues of k_expand_b
+        if (heavy_min != 0xffffffffu) {
+          fork();
+          hipLaunchKernelGGL(k_expand_h, dim3(kHeavyGrid), dim3(kWave), 0, c.side, m.d, b, w, prm, (const HeavyItem*)c.items_h.p,
+                             item_h_cap);
+        }
+        hipLaunchKernelGGL(k_expand_a, dim3(b.nq + kExpandExtraGrid), dim3(kWave), 0, stream, m.d, b, w, prm,
+                           (const WorkItem*)c.items.p, item_cap, use_sig);
+        if (heavy_min != 0xffffffffu) join();
+        hipLaunchKernelGGL(k_caps_b, dim3((b.nq + 255) / 256), dim3(256), 0, stream, b, w, c.items_b.p, item_cap);
+        const size_t lds = (size_t)p_max * 4;
+        if (lds > 64 * 1024) throw UnsupportedError("patterns too long for the expand kernel's LDS staging");
+        hipLaunchKernelGGL(k_expand_b, dim3(b.nq + kExpandExtraGrid), dim3(kWave), lds, stream, m.d, b, w, prm,
+                           (const WorkItem*)c.items_b.p, item_cap);
+      }
+      tick(); tick();
+      hipLaunchKernelGGL(k_cand, dim3((b.nq + 3) / 4), dim3(256), 0, stream, b, w, c.big_list.p, c.mid_list.p);
       {
         // The sorter of the few huge survivor sets is one workgroup per query and leaves the GPU almost idle:
         // it runs on the side stream next to k_cand_mid (disjoint queries).
@@ -321,10 +436,10 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm_in, const D
         uint32_t sid_bytes = 1, len_bytes = p_max < 255 ? 1u : 2u;
         while (sid_bytes < 4 && (m.d.n_sent >> (8 * sid_bytes)) != 0) sid_bytes++;
         fork();
-        hipLaunchKernelGGL(k_cand_big, dim3(kBigGrid), dim3(kBigThreads), 0, m.side_stream, w, m.sc.keys,
-                           (const uint32_t*)m.big_list, sid_bytes, len_bytes);
+        hipLaunchKernelGGL(k_cand_big, dim3(kBigGrid), dim3(kBigThreads), 0, c.side, w, c.keys.p,
+                           (const uint32_t*)c.big_list.p, sid_bytes, len_bytes);
       }
-      hipLaunchKernelGGL(k_cand_mid, dim3(1024), dim3(256), 0, stream, w, (const uint32_t*)m.mid_list);
+      hipLaunchKernelGGL(k_cand_mid, dim3(1024), dim3(256), 0, stream, w, (const uint32_t*)c.mid_list.p);
       tick(); tick();
       join();  // stage "cand_big" = what is left of the big sorter after k_cand_mid
       tick(); tick();
@@ -333,23 +448,32 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm_in, const D
         const uint32_t n = b.nq + 1;
         const uint32_t tiles = (n + kScanTile - 1) / kScanTile;
         hipLaunchKernelGGL(k_classify, dim3((n + 255) / 256), dim3(256), 0, stream, b, w, full ? 1 : 0);
-        for (int c = 0; c < 3; c++) {
-          hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(kScanThreads), 0, stream, w.c_in + (size_t)c * n,
-                             w.c_off + (size_t)c * n, m.tile_sums, n);
-          hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanThreads), 0, stream, m.tile_sums, tiles, m.grand_total);
-          hipLaunchKernelGGL(k_scan_add, dim3(tiles), dim3(kScanThreads), 0, stream, w.c_off + (size_t)c * n, m.tile_sums, n);
+        for (int k = 0; k < 3; k++) {
+          hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(kScanThreads), 0, stream, w.c_in + (size_t)k * n,
+                             w.c_off + (size_t)k * n, c.tile_sums.p, n);
+          hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanThreads), 0, stream, c.tile_sums.p, tiles, c.grand_total.p);
+          hipLaunchKernelGGL(k_scan_add, dim3(tiles), dim3(kScanThreads), 0, stream, w.c_off + (size_t)k * n, c.tile_sums.p, n);
         }
-        hipLaunchKernelGGL(k_cmap, dim3((b.nq + 255) / 256), dim3(256), 0, stream, b, w, full ? 1 : 0, m.fin_list);
+        hipLaunchKernelGGL(k_cmap, dim3((b.nq + 255) / 256), dim3(256), 0, stream, b, w, full ? 1 : 0, c.fin_list.p);
       }
       tick(); tick();
       {
         const size_t lds = ((size_t)p_max + 1) * kWave * 4;
-        if (lds > 150 * 1024)
-          throw GpuError("patterns of " + std::to_string(p_max) + " tokens need more LDS than one CU has (limit ~590)");
+        const bool rows_in_hbm = lds > kDynLdsMax;  // patterns too long for LDS rows: same kernel over rows in HBM
         const unsigned grid = 256 * 16;  // grid-stride over the flat candidate list
+        const unsigned grid_g = 1024;
+        if (rows_in_hbm) c.g_rows.ensure((uint64_t)grid_g * kWave * (p_max + 1));
+        auto launch_rows = [&](bool with_side) {
+          if (with_side) {
+            if (rows_in_hbm) hipLaunchKernelGGL((k_dp<true, true>), dim3(grid_g), dim3(kWave), 0, stream, m.d, b, w, prm, c.g_rows.p, p_max + 1);
+            else hipLaunchKernelGGL((k_dp<true, false>), dim3(grid), dim3(kWave), lds, stream, m.d, b, w, prm, (float*)nullptr, 0u);
+          } else {
+            if (rows_in_hbm) hipLaunchKernelGGL((k_dp<false, true>), dim3(grid_g), dim3(kWave), 0, stream, m.d, b, w, prm, c.g_rows.p, p_max + 1);
+            else hipLaunchKernelGGL((k_dp<false, false>), dim3(grid), dim3(kWave), lds, stream, m.d, b, w, prm, (float*)nullptr, 0u);
+          }
+        };
         if (full) {
-          HIP_TRY(hipFuncSetAttribute((const void*)k_dp<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-          hipLaunchKernelGGL(k_dp<true>, dim3(grid), dim3(kWave), lds, stream, m.d, b, w, prm);
+          launch_rows(true);
         } else {
           // by pattern length: row + pattern in 32 or 64 registers, longer ones with the row in LDS
           if (use_idf) {
@@ -364,15 +488,7 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm_in, const D
             hipLaunchKernelGGL((k_dp_reg<32, false>), dim3(grid), dim3(kWave), 0, stream, m.d, b, w, prm);
             if (p_max > 32) hipLaunchKernelGGL((k_dp_reg<64, false>), dim3(grid), dim3(kWave), 0, stream, m.d, b, w, prm);
           }
-          if (p_max > 64) {
-            if (use_idf) {
-              HIP_TRY(hipFuncSetAttribute((const void*)k_dp<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-              hipLaunchKernelGGL(k_dp<true>, dim3(grid), dim3(kWave), lds, stream, m.d, b, w, prm);
-            } else {
-              HIP_TRY(hipFuncSetAttribute((const void*)k_dp<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-              hipLaunchKernelGGL(k_dp<false>, dim3(grid), dim3(kWave), lds, stream, m.d, b, w, prm);
-            }
-          }
+          if (p_max > 64) launch_rows(use_idf);
         }
       }
       tick(); tick();
@@ -380,80 +496,88 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm_in, const D
         // the queue of large candidate sets was filled by k_cmap: their (long, mostly sequential) replay runs on the
         // side stream next to the bulk kernel; the two touch disjoint queries
         fork();
-        hipLaunchKernelGGL((k_finish<kLdsSortMax, true>), dim3(2048), dim3(kWave), 0, m.side_stream, m.d, b, w, prm, m.sc, cap,
-                           d_out, d_out_count, d_out_total, m.contrast_list, m.fin_list);
-        hipLaunchKernelGGL((k_finish<64, false>), dim3(b.nq), dim3(kWave), 0, stream, m.d, b, w, prm, m.sc, cap, d_out,
-                           d_out_count, d_out_total, m.contrast_list, m.fin_list);
+        hipLaunchKernelGGL((k_finish<kLdsSortMax, true>), dim3(2048), dim3(kWave), 0, c.side, m.d, b, w, prm, DevScratch{c.keys.p, c.vals.p, c.f0.p, c.f1.p}, cap,
+                           d_out, d_out_count, d_out_total, c.contrast_list.p, c.fin_list.p);
+        hipLaunchKernelGGL((k_finish<64, false>), dim3(b.nq), dim3(kWave), 0, stream, m.d, b, w, prm, DevScratch{c.keys.p, c.vals.p, c.f0.p, c.f1.p}, cap, d_out,
+                           d_out_count, d_out_total, c.contrast_list.p, c.fin_list.p);
         join();
+        const DevScratch sc{c.keys.p, c.vals.p, c.f0.p, c.f1.p};
         if (prm.contrast > 0.f) {
-          const uint32_t* cl = m.contrast_list;
-          if (prm.nmatch >= 1 && prm.nmatch <= kMaxFlatRounds) {
+          const uint32_t* cl = c.contrast_list.p;
+          const bool flat = prm.nmatch >= 1 && prm.nmatch <= kMaxFlatRounds;
+          if (flat) {
             // flattened rounds: pick, then one edit distance per remaining accepted match of any query
             const uint32_t n = b.nq + 1;
             const uint32_t tiles = (n + kScanTile - 1) / kScanTile;
             hipLaunchKernelGGL(k_cacc, dim3((n + 255) / 256), dim3(256), 0, stream, b, w);
-            for (int c = 0; c < 2; c++) {
-              hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(kScanThreads), 0, stream, w.c_in + (size_t)c * n,
-                                 w.c_off + (size_t)c * n, m.tile_sums, n);
-              hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanThreads), 0, stream, m.tile_sums, tiles, m.grand_total);
-              hipLaunchKernelGGL(k_scan_add, dim3(tiles), dim3(kScanThreads), 0, stream, w.c_off + (size_t)c * n, m.tile_sums, n);
+            for (int k = 0; k < 2; k++) {
+              hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(kScanThreads), 0, stream, w.c_in + (size_t)k * n,
+                                 w.c_off + (size_t)k * n, c.tile_sums.p, n);
+              hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanThreads), 0, stream, c.tile_sums.p, tiles, c.grand_total.p);
+              hipLaunchKernelGGL(k_scan_add, dim3(tiles), dim3(kScanThreads), 0, stream, w.c_off + (size_t)k * n, c.tile_sums.p, n);
             }
-            hipLaunchKernelGGL(k_camap, dim3(b.nq), dim3(kWave), 0, stream, b, w, m.sc);
+            hipLaunchKernelGGL(k_camap, dim3(b.nq), dim3(kWave), 0, stream, b, w, sc);
             for (uint32_t r = 0; r < prm.nmatch; r++) {
               if (r) {
-                hipLaunchKernelGGL(k_cdp<32>, dim3(256 * 16), dim3(kWave), 0, stream, m.d, b, w, prm, m.sc, r);
+                hipLaunchKernelGGL(k_cdp<32>, dim3(256 * 16), dim3(kWave), 0, stream, m.d, b, w, prm, sc, r);
                 if (m.d.max_slen > 32)
-                  hipLaunchKernelGGL(k_cdp<64>, dim3(256 * 8), dim3(kWave), 0, stream, m.d, b, w, prm, m.sc, r);
+                  hipLaunchKernelGGL(k_cdp<64>, dim3(256 * 8), dim3(kWave), 0, stream, m.d, b, w, prm, sc, r);
               }
-              hipLaunchKernelGGL(k_cpick, dim3((b.nq + 255) / 256), dim3(256), 0, stream, m.d, b, w, prm, m.sc, r, cap, d_out, d_out_count,
+              hipLaunchKernelGGL(k_cpick, dim3((b.nq + 255) / 256), dim3(256), 0, stream, m.d, b, w, prm, sc, r, cap, d_out, d_out_count,
                                  d_out_total);
             }
           } else {
-            hipLaunchKernelGGL(k_contrast<0>, dim3(b.nq), dim3(kWave), 0, stream, m.d, b, w, prm, m.sc, cap, d_out,
-                               d_out_count, d_out_total, cl);
+            hipLaunchKernelGGL(k_contrast<0>, dim3(b.nq), dim3(kWave), 0, stream, m.d, b, w, prm, sc, cap, d_out,
+                               d_out_count, d_out_total, cl, (float*)nullptr, 0u);
           }
-          const bool flat = prm.nmatch >= 1 && prm.nmatch <= kMaxFlatRounds;
           if (m.d.max_slen > 32 && !flat)
-            hipLaunchKernelGGL(k_contrast<1>, dim3(2048), dim3(kWave), 0, stream, m.d, b, w, prm, m.sc, cap, d_out,
-                               d_out_count, d_out_total, cl);
+            hipLaunchKernelGGL(k_contrast<1>, dim3(2048), dim3(kWave), 0, stream, m.d, b, w, prm, sc, cap, d_out,
+                               d_out_count, d_out_total, cl, (float*)nullptr, 0u);
           if (m.d.max_slen > 64) {
             const size_t lds = ((size_t)m.d.max_slen + 1) * kWave * 4;
-            if (lds > 120 * 1024) throw GpuError("contrastive rerank: indexed sentences too long for the LDS DP rows");
-            HIP_TRY(hipFuncSetAttribute((const void*)k_contrast<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(k_contrast<2>, dim3(512), dim3(kWave), lds, stream, m.d, b, w, prm, m.sc, cap, d_out,
-                               d_out_count, d_out_total, cl);
+            if (lds > kDynLdsMax - 8 * 1024) {  // indexed sentences too long for LDS rows: rows in HBM
+              const unsigned grid_g = 512;
+              c.g_rows.ensure((uint64_t)grid_g * kWave * (m.d.max_slen + 1));
+              hipLaunchKernelGGL(k_contrast<3>, dim3(grid_g), dim3(kWave), 0, stream, m.d, b, w, prm, sc, cap, d_out,
+                                 d_out_count, d_out_total, cl, c.g_rows.p, m.d.max_slen + 1);
+            } else {
+              hipLaunchKernelGGL(k_contrast<2>, dim3(512), dim3(kWave), lds, stream, m.d, b, w, prm, sc, cap, d_out,
+                                 d_out_count, d_out_total, cl, (float*)nullptr, 0u);
+            }
           }
         }
       }
       tick();
       hipLaunchKernelGGL(k_stats, dim3((b.nq + 1023) / 1024), dim3(1024), 0, stream, w, b.nq);
       HIP_TRY(hipGetLastError());
-      if (m.on_launched) m.on_launched(sb);  // host-buffer path: copy out finished passes while this one runs
-      unsigned long long ctr[16];
-      HIP_TRY(hipMemcpyAsync(ctr, w.counters, sizeof(ctr), hipMemcpyDeviceToHost, stream));
+      HIP_TRY(hipMemcpyAsync(c.h_ctr, w.counters, kNumCounters * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
       HIP_TRY(hipStreamSynchronize(stream));
+      const unsigned long long* ctr = c.h_ctr;
       if (st) {
         for (int s = 0; s < kNumStages; s++) {
           float ms = 0.f;
-          HIP_TRY(hipEventElapsedTime(&ms, m.ev[2 * s], m.ev[2 * s + 1]));
+          HIP_TRY(hipEventElapsedTime(&ms, c.ev[2 * s], c.ev[2 * s + 1]));
           st->ms_kernel[s] += ms;
           st->launches[s] += 1;
         }
       }
       bool retry = false;
-      if (ctr[6] > m.w.seg_cap) { want_seg = ctr[6] + ctr[6] / 4; retry = true; }       // segments did not fit
-      if (ctr[4] > m.s_max) {                                                          // a query had more survivors
-        uint32_t s = m.s_max;
-        while (s < ctr[4]) s <<= 1;
-        m.s_max = s;
+      if (ctr[6] > c.seg_cap) { want_seg = ctr[6] + ctr[6] / 4; retry = true; }         // segments did not fit
+      if (ctr[4] > c.s_max) {                                                          // a query had more survivors
+        unsigned long long s = c.s_max;
+        while (s < ctr[4] && s < (1ull << 31)) s <<= 1;
+        c.s_max = (uint32_t)std::min<unsigned long long>(s, 0x80000000ull);
+        if (ctr[4] > c.s_max) throw UnsupportedError("a query kept more than 2^31 hits");
         retry = true;
       }
-      if (std::max(ctr[5], ctr[12]) > m.item_cap) {                                    // work-item list too short
-        hipFree(m.items); hipFree(m.items_b);
+      if (std::max(ctr[5], ctr[12]) > item_cap) {                                      // work-item list too short
         const unsigned long long need = std::max(ctr[5], ctr[12]);
-        m.item_cap = (uint32_t)std::min<unsigned long long>(need + need / 4, 0xffffffffull);
-        m.items = dev_alloc<WorkItem>(m.item_cap);
-        m.items_b = dev_alloc<WorkItem>(m.item_cap);
+        const uint64_t nc = std::min<unsigned long long>(need + need / 4, 0xffffffffull);
+        c.items.ensure(nc); c.items_b.ensure(nc);
+        retry = true;
+      }
+      if (ctr[15] > item_h_cap) {                                                      // heavy-range item list too short
+        c.items_h.ensure(std::min<unsigned long long>(ctr[15] + ctr[15] / 4, 0xffffffffull));
         retry = true;
       }
       if (retry) {
@@ -464,12 +588,45 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm_in, const D
       if (st) {
         st->n_hits += ctr[0]; st->n_kept += ctr[1]; st->n_candidates += ctr[2]; st->n_dp += ctr[3];
         st->n_big += ctr[7]; st->n_phase_b += ctr[8]; st->max_kept = std::max<uint64_t>(st->max_kept, ctr[9]);
+        st->n_heavy_hits += ctr[16]; st->n_heavy_pass += ctr[17];
       }
       break;
     }
+    if (hooks && hooks->after) hooks->after(sb);
   }
 }
 
+void DeviceIndex::match_device(const HostIndex& h, const Params& prm, const DeviceBatchView& bv, Rec* d_out,
+                               uint32_t* d_out_count, uint32_t* d_out_total, uint32_t cap, void* stream_v,
+                               const std::vector<uint32_t>& sub_tok_bounds, Stats* st) {
+  Impl& m = *impl_;
+  if (m.device < 0) throw GpuError("index is not on a device");
+  HIP_TRY(hipSetDevice(m.device));
+  refresh_itok_table(m, h);
+  std::shared_lock<std::shared_mutex> rl(m.itok_mu);
+  CtxLease lease(m);
+  // the caller's stream carries the work (NULL = the context's own stream)
+  hipStream_t stream = stream_v ? (hipStream_t)stream_v : lease.c->stream;
+  if (!stream_v) HIP_TRY(hipDeviceSynchronize());  // inputs may have been produced on other streams
+  run_passes(m, *lease.c, prm, bv, d_out, d_out_count, d_out_total, cap, stream, sub_tok_bounds, m.sub_queries, st, nullptr);
+}
+
+static bool is_pinned(const void* p) {
+  if (!p) return true;
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return a.type == hipMemoryTypeHost;
+}
+
+__global__ void k_rebase(uint32_t* off, uint32_t n, uint32_t base) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) off[i] -= base;
+}
+
+// Host buffers in, host buffers out.  The batch is cut into passes of host_sub_queries queries; the inputs of pass
+// i + 1 travel over PCIe (own stream) while pass i computes, and the records of pass i - 1 travel back (own stream)
+// at the same time.  With pinned buffers (fmx_host_alloc) the copies are truly asynchronous; pageable buffers
+// still work (the runtime stages them).
 void DeviceIndex::match_host(const HostIndex& h, const Params& prm, const HostBatchView& hb, Rec* out,
                              uint32_t* out_count, uint32_t* out_total, uint32_t cap, Stats* st) {
   Impl& m = *impl_;
@@ -478,78 +635,74 @@ void DeviceIndex::match_host(const HostIndex& h, const Params& prm, const HostBa
   const auto t0 = std::chrono::steady_clock::now();
   const uint64_t nq = hb.nq;
   if (nq == 0) return;
-  const uint64_t nt = hb.q_off[nq];
-  if (nq + 1 > m.cap_hq) {
-    hipFree(m.d_qoff);
-    m.d_qoff = dev_alloc<uint32_t>(nq + 1);
-    m.cap_hq = nq + 1;
-  }
-  if (nt + nq + 1 > m.cap_ht) {
-    hipFree(m.d_qtok); hipFree(m.d_qreal); hipFree(m.d_qitok);
-    m.d_qtok = dev_alloc<uint32_t>(nt + 1);
-    m.d_qreal = dev_alloc<uint32_t>(nt + 1);
-    m.d_qitok = dev_alloc<uint32_t>(nt + nq + 1);
-    m.cap_ht = nt + nq + 1;
-  }
-  if (nq * cap > m.cap_out || nq > m.cap_outq) {
-    hipFree(m.d_out); hipFree(m.d_out_count); hipFree(m.d_out_total);
-    m.d_out = dev_alloc<Rec>(nq * cap);
-    m.d_out_count = dev_alloc<uint32_t>(nq);
-    m.d_out_total = dev_alloc<uint32_t>(nq);
-    m.cap_out = nq * cap; m.cap_outq = nq;
-  }
-  const auto h0 = std::chrono::steady_clock::now();
-  HIP_TRY(hipMemcpy(m.d_qoff, hb.q_off, (nq + 1) * 4, hipMemcpyHostToDevice));
-  if (nt) HIP_TRY(hipMemcpy(m.d_qtok, hb.q_tok, nt * 4, hipMemcpyHostToDevice));
-  if (hb.q_real && nt) HIP_TRY(hipMemcpy(m.d_qreal, hb.q_real, nt * 4, hipMemcpyHostToDevice));
-  if (hb.q_itok) HIP_TRY(hipMemcpy(m.d_qitok, hb.q_itok, (nt + nq) * 4, hipMemcpyHostToDevice));
-  const auto h1 = std::chrono::steady_clock::now();
-  DeviceBatchView bv;
-  bv.nq = nq; bv.q_off = m.d_qoff; bv.q_tok = m.d_qtok;
-  bv.q_real = hb.q_real ? m.d_qreal : nullptr;
-  bv.q_itok = hb.q_itok ? m.d_qitok : nullptr;
+  const uint32_t base = hb.q_off[0];
+  const uint64_t nt = hb.q_off[nq] - base;
+  refresh_itok_table(m, h);
+  std::shared_lock<std::shared_mutex> rl(m.itok_mu);
+  CtxLease lease(m);
+  Ctx& c = *lease.c;
+  c.d_qoff.ensure(nq + 1);
+  c.d_qtok.ensure(nt + 1);
+  if (hb.q_real) c.d_qreal.ensure(nt + 1);
+  if (hb.q_itok) c.d_qitok.ensure(nt + nq + 1);
+  c.d_out.ensure(nq * cap);
+  c.d_cnt.ensure(nq);
+  c.d_tot.ensure(nq);
+  const uint32_t sub = std::max<uint32_t>(1, std::min(m.sub_queries, m.host_sub_queries));
+  const uint32_t n_sub = (uint32_t)((nq + sub - 1) / sub);
+  std::vector<uint32_t> bounds(n_sub + 1);
   uint32_t p_max = 0;
+  for (uint32_t s = 0; s < n_sub; s++) bounds[s] = hb.q_off[(uint64_t)s * sub] - base;
+  bounds[n_sub] = (uint32_t)nt;
   for (uint64_t q = 0; q < nq; q++) p_max = std::max(p_max, hb.q_off[q + 1] - hb.q_off[q]);
+  DeviceBatchView bv;
+  bv.nq = nq; bv.q_off = c.d_qoff.p; bv.q_tok = c.d_qtok.p;
+  bv.q_real = hb.q_real ? c.d_qreal.p : nullptr;
+  bv.q_itok = hb.q_itok ? c.d_qitok.p : nullptr;
   bv.p_max = std::max<uint32_t>(p_max, 1);
-  // Passes of host_sub_queries queries: the results of pass i travel to the host on their own stream while
-  // pass i + 1 computes, so only the last pass's copy is exposed.
-  const uint32_t saved_sub = m.sub_queries;
-  m.sub_queries = std::min(saved_sub, m.host_sub_queries);
-  std::vector<uint32_t> bounds;
-  for (uint64_t q = 0; q < nq; q += m.sub_queries) bounds.push_back(hb.q_off[q]);
-  bounds.push_back(hb.q_off[nq]);
-  if (!m.copy_stream) HIP_TRY(hipStreamCreateWithFlags(&m.copy_stream, hipStreamNonBlocking));
-  uint64_t copied_q = 0;
-  double ms_copy = 0.0;
-  auto copy_upto = [&](uint64_t q_end) {
-    if (q_end <= copied_q) return;
-    const auto c0 = std::chrono::steady_clock::now();
-    const uint64_t n = q_end - copied_q;
-    HIP_TRY(hipMemcpyAsync(out + copied_q * cap, m.d_out + copied_q * cap, n * cap * sizeof(Rec), hipMemcpyDeviceToHost, m.copy_stream));
-    HIP_TRY(hipMemcpyAsync(out_count + copied_q, m.d_out_count + copied_q, n * 4, hipMemcpyDeviceToHost, m.copy_stream));
-    if (out_total) HIP_TRY(hipMemcpyAsync(out_total + copied_q, m.d_out_total + copied_q, n * 4, hipMemcpyDeviceToHost, m.copy_stream));
-    HIP_TRY(hipStreamSynchronize(m.copy_stream));
-    copied_q = q_end;
-    ms_copy += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - c0).count();
+  const bool pinned = is_pinned(hb.q_off) && is_pinned(hb.q_tok) && is_pinned(out) && is_pinned(out_count);
+  double ms_h2d = 0.0, ms_d2h = 0.0;
+  // inputs of pass s: offsets [s*sub, end] (the last pass also sends q_off[nq]), tokens of those queries
+  auto send = [&](uint32_t s) {
+    const auto a = std::chrono::steady_clock::now();
+    const uint64_t q0 = (uint64_t)s * sub, q1 = std::min<uint64_t>(q0 + sub, nq);
+    // pass s reads offsets [q0, q1] inclusive; q0 itself already came with the previous pass
+    const uint64_t o_lo = s == 0 ? q0 : q0 + 1, n_off = q1 - o_lo + 1;
+    HIP_TRY(hipMemcpyAsync(c.d_qoff.p + o_lo, hb.q_off + o_lo, n_off * 4, hipMemcpyHostToDevice, c.h2d));
+    if (base) hipLaunchKernelGGL(k_rebase, dim3((unsigned)((n_off + 255) / 256)), dim3(256), 0, c.h2d, c.d_qoff.p + o_lo, (uint32_t)n_off, base);
+    const uint64_t t0_ = bounds[s], t1_ = bounds[s + 1];
+    if (t1_ > t0_) {
+      HIP_TRY(hipMemcpyAsync(c.d_qtok.p + t0_, hb.q_tok + base + t0_, (t1_ - t0_) * 4, hipMemcpyHostToDevice, c.h2d));
+      if (hb.q_real) HIP_TRY(hipMemcpyAsync(c.d_qreal.p + t0_, hb.q_real + base + t0_, (t1_ - t0_) * 4, hipMemcpyHostToDevice, c.h2d));
+    }
+    if (hb.q_itok)  // slot of (query q, position j) = q_off[q] + q + j: nt + nq entries, pass s owns [t0 + q0, t1 + q1)
+      HIP_TRY(hipMemcpyAsync(c.d_qitok.p + t0_ + q0, hb.q_itok + base + t0_ + q0, (t1_ - t0_ + q1 - q0) * 4, hipMemcpyHostToDevice, c.h2d));
+    HIP_TRY(hipEventRecord(c.ev_in[s % kMaxPassesInFlight], c.h2d));
+    ms_h2d += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
   };
-  const uint32_t sub = m.sub_queries;
-  m.on_launched = [&](uint32_t sb) { copy_upto(std::min<uint64_t>((uint64_t)sb * sub, nq)); };
-  try {
-    match_device(h, prm, bv, m.d_out, m.d_out_count, m.d_out_total, cap, nullptr, bounds, st);
-  } catch (...) {
-    m.on_launched = nullptr;
-    m.sub_queries = saved_sub;
-    throw;
-  }
-  m.on_launched = nullptr;
-  m.sub_queries = saved_sub;
-  copy_upto(nq);
-  const auto h3 = std::chrono::steady_clock::now();
+  PassHooks hooks;
+  hooks.before = [&](uint32_t s) {
+    if (s == 0) send(0);
+    HIP_TRY(hipStreamWaitEvent(c.stream, c.ev_in[s % kMaxPassesInFlight], 0));
+    if (s + 1 < n_sub) send(s + 1);  // travels while pass s computes
+  };
+  hooks.after = [&](uint32_t s) {  // pass s is complete (run_passes synchronised the stream): its records go home
+    const auto a = std::chrono::steady_clock::now();
+    const uint64_t q0 = (uint64_t)s * sub, q1 = std::min<uint64_t>(q0 + sub, nq), n = q1 - q0;
+    HIP_TRY(hipMemcpyAsync(out + q0 * cap, c.d_out.p + q0 * cap, n * cap * sizeof(Rec), hipMemcpyDeviceToHost, c.d2h));
+    HIP_TRY(hipMemcpyAsync(out_count + q0, c.d_cnt.p + q0, n * 4, hipMemcpyDeviceToHost, c.d2h));
+    if (out_total) HIP_TRY(hipMemcpyAsync(out_total + q0, c.d_tot.p + q0, n * 4, hipMemcpyDeviceToHost, c.d2h));
+    ms_d2h += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
+  };
+  run_passes(m, c, prm, bv, c.d_out.p, c.d_cnt.p, c.d_tot.p, cap, c.stream, bounds, sub, st, &hooks);
+  const auto a = std::chrono::steady_clock::now();
+  HIP_TRY(hipStreamSynchronize(c.d2h));
+  ms_d2h += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
   if (st) {
-    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-    st->ms_h2d += ms(h0, h1);
-    st->ms_d2h += ms_copy;  // mostly hidden behind the following pass
-    st->ms_total += ms(t0, h3);
+    st->ms_h2d += ms_h2d;   // host time spent enqueuing / staging; with pinned buffers the copies overlap the passes
+    st->ms_d2h += ms_d2h;
+    st->pinned = pinned ? 1 : 0;
+    st->ms_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   }
 }
 
@@ -573,14 +726,15 @@ std::vector<uint32_t> DeviceIndex::sub_bounds_from_device(const uint32_t* d_q_of
   for (uint64_t q = 0; q < nq; q += m.sub_queries, k++)
     HIP_TRY(hipMemcpyAsync(&bounds[k], d_q_off + q, 4, hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipMemcpyAsync(&bounds[k], d_q_off + nq, 4, hipMemcpyDeviceToHost, stream));
+  uint32_t* d_pm = nullptr;
   if (p_max && *p_max == 0 && nq) {
-    ensure_ws(m, 1, 1, 1024);
-    uint32_t* d_pm = (uint32_t*)m.grand_total;
+    d_pm = dev_alloc<uint32_t>(1);
     HIP_TRY(hipMemsetAsync(d_pm, 0, 4, stream));
     hipLaunchKernelGGL(k_pmax, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, stream, d_q_off, nq, d_pm);
     HIP_TRY(hipMemcpyAsync(p_max, d_pm, 4, hipMemcpyDeviceToHost, stream));
   }
   HIP_TRY(hipStreamSynchronize(stream));
+  if (d_pm) (void)hipFree(d_pm);
   return bounds;
 }
 
@@ -632,7 +786,7 @@ __global__ void k_extract_keys(const GpuSortKey* keys, unsigned long long* out, 
 }
 
 void gpu_suffix_sort(HostIndex& h, int device) {
-  if (gpu_device_count() <= device || device < 0) throw GpuError("no usable gfx950 device " + std::to_string(device));
+  check_device(device);
   HIP_TRY(hipSetDevice(device));
   const uint64_t n = h.suf_sid.size();
   if (n == 0) { h.adopt_sorted(nullptr, 0); return; }

@@ -34,6 +34,11 @@ struct DevIndex {
   uint32_t        n_sent;
   uint32_t        max_slen;
   uint64_t        n_suf;
+  // Signature bit planes (built on the device at upload): planes[k * n_blk + blk], bit i = bucket k of the signature
+  // of suffix 64 * blk + i; row kSigBits = "stored sentence length is clamped (>= 255)".  Plane-major, so a wave that
+  // walks 64 consecutive blocks reads 512 contiguous bytes per bucket and only the buckets its pattern uses.
+  const unsigned long long* planes;
+  uint64_t        n_blk;
 };
 
 struct DevBatch {
@@ -54,7 +59,8 @@ struct DevWork {
   uint32_t* t_q;        // nt   token -> local query
   uint32_t* t_lo;       // nt   range start per (query, start)
   uint32_t* t_cnt;      // nt   range size
-  unsigned long long* q_hits;  // nq   hits per query (sum of t_cnt)
+  unsigned long long* q_hits;  // nq   hits per query (every range of the query)
+  unsigned long long* q_hits_a;  // nq  hits of the ranges k_expand_a walks (sum of t_cnt: the long ranges go to k_expand_h)
   unsigned long long* q_cap;   // nq+1 segment capacity per query: min(hits, s_max)
   unsigned long long* q_seg;   // nq+1 exclusive scan of q_cap
   uint32_t* q_kept;     // nq
@@ -78,7 +84,10 @@ struct DevWork {
                                  // [7]=queries queued for k_cand_big [8]=phase-B hits [9]=max kept
                                  // [10],[11]=queries queued for k_contrast<1>, <2> [12]=extra k_expand_b items
                                  // [13]=queries queued for k_cand_mid [14]=queries queued for the large k_finish
+                                 // [15]=work items of k_expand_h [16]=hits walked through the bit planes
+                                 // [17]=of those, hits that passed the plane test (re-tested exactly)
 };
+constexpr int kNumCounters = 24;
 
 constexpr int kWave = 64;
 constexpr uint32_t kLdsSortMax = 1024;   // per-wave LDS sort capacity (keys)
@@ -129,7 +138,33 @@ __global__ void k_tidf(DevIndex ix, DevBatch b, DevWork w) {
 // equal_range calls converge to for the seed n-gram (src/suffix_array.cc:105-212,
 // src/fuzzy_match.cc:495-551).  Each compare step is one 8-byte SufRec load + token loads.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_probe(DevIndex ix, DevBatch b, DevWork w) {
+// A long suffix range handed to k_expand_h: `chunk` selects kHeavyChunkBlocks blocks of 64 suffixes of it.
+struct HeavyItem {
+  uint32_t t;      // token index of the (query, start position) inside the pass
+  uint32_t lo;     // the range [lo, lo + cnt)
+  uint32_t cnt;
+  uint32_t chunk;
+};
+constexpr uint32_t kPlaneRows = kSigBits + 1;   // 56 signature buckets + the "stored length is clamped" mask
+constexpr uint32_t kPlaneMaxP = 63;             // six-level bit-sliced counters: patterns of up to 63 tokens
+constexpr uint32_t kHeavyMinDefault = 1024;     // ranges at least this long stream through the bit planes
+constexpr uint32_t kHeavyChunkBlocks = 256;     // blocks of 64 suffixes per k_expand_h work item (16384 hits)
+constexpr uint32_t kHeavyGrid = 8192;
+
+// segmented inclusive scan of (value per lane) over runs of equal `q` in a wave
+__device__ __forceinline__ unsigned long long seg_scan_u64(unsigned long long v, uint32_t q) {
+  const uint32_t lane = threadIdx.x & 63;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t oq = __shfl_up(q, d, 64);
+    const uint32_t olo = __shfl_up((uint32_t)v, d, 64), ohi = __shfl_up((uint32_t)(v >> 32), d, 64);
+    if (lane >= (uint32_t)d && oq == q) v += ((unsigned long long)ohi << 32) | olo;
+  }
+  return v;
+}
+
+__global__ void __launch_bounds__(64) k_probe(DevIndex ix, DevBatch b, DevWork w, uint32_t heavy_min, HeavyItem* items_h,
+                                              uint32_t item_h_cap) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= b.nt) return;
   const uint32_t q = w.t_q[t];
@@ -147,21 +182,45 @@ __global__ void __launch_bounds__(64) k_probe(DevIndex ix, DevBatch b, DevWork w
       mgram_range_hashed(ix.gram, ix.suf_key, ix.suf, ix.tok, ix.qva, ix.n_qva, b.q_tok + b.t_begin + t, m, lo, hi);
   }
   const uint32_t cnt = hi - lo;
+  // Long ranges (a repeated phrase: 0.1 % of the ranges hold most of the hits) are not walked hit by hit: they become
+  // work items of k_expand_h, which tests 64 suffixes per lane through the signature bit planes.
+  const bool heavy = cnt >= heavy_min && p <= kPlaneMaxP;
   w.t_lo[t] = lo;
-  w.t_cnt[t] = cnt;
-  // Per-query hit totals (q_hits, zeroed by the host): a query's start positions are consecutive lanes, so a
+  w.t_cnt[t] = heavy ? 0u : cnt;
+  if (heavy) {
+    const uint32_t blk0 = lo >> 6, blk1 = (hi - 1) >> 6;
+    const uint32_t n_items = (blk1 - blk0) / kHeavyChunkBlocks + 1;
+    const unsigned long long base = atomicAdd(&w.counters[15], (unsigned long long)n_items);
+    for (uint32_t k = 0; k < n_items; k++)
+      if (base + k < item_h_cap) { HeavyItem h; h.t = t; h.lo = lo; h.cnt = cnt; h.chunk = k; items_h[base + k] = h; }
+  }
+  // Per-query hit totals (q_hits / q_hits_a, zeroed by the host): a query's start positions are consecutive lanes, so a
   // segmented scan over the wave leaves one atomic per (wave, query) instead of one per start position.
   const uint32_t lane = lane_id();
-  unsigned long long sum = cnt;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t oq = __shfl_up(q, d, 64);
-    const uint32_t olo = __shfl_up((uint32_t)sum, d, 64), ohi = __shfl_up((uint32_t)(sum >> 32), d, 64);
-    if (lane >= (uint32_t)d && oq == q) sum += ((unsigned long long)ohi << 32) | olo;
-  }
+  const unsigned long long sum = seg_scan_u64(cnt, q);
+  const unsigned long long sum_a = seg_scan_u64(heavy ? 0u : cnt, q);
   const uint32_t nq = __shfl_down(q, 1, 64);
   const bool tail = lane == 63 || t + 1 >= b.nt || nq != q;
   if (tail && sum != 0) atomicAdd(&w.q_hits[q], sum);
+  if (tail && sum_a != 0) atomicAdd(&w.q_hits_a[q], sum_a);
+}
+
+// Signature bit planes of the suffix array (index build, once per upload): one wave per block of 64 suffixes.
+__global__ void __launch_bounds__(kWave) k_build_planes(const unsigned long long* __restrict__ suf_sig, unsigned long long n_suf,
+                                                        unsigned long long n_blk, unsigned long long* __restrict__ planes) {
+  const unsigned long long blk = blockIdx.x;
+  const uint32_t lane = threadIdx.x & 63;
+  const unsigned long long i = blk * 64 + lane;
+  const unsigned long long pk = i < n_suf ? suf_sig[i] : 0ull;
+  unsigned long long mine = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < kSigBits; k++) {
+    const unsigned long long m = __ballot((pk >> k) & 1ull);
+    if (lane == k) mine = m;
+  }
+  const unsigned long long cl = __ballot(i < n_suf && sig_slen(pk) == kSigLenClamp);
+  if (lane == kSigBits) mine = cl;
+  if (lane < kPlaneRows) planes[(unsigned long long)lane * n_blk + blk] = mine;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -255,9 +314,10 @@ __global__ void __launch_bounds__(256) k_caps(DevBatch b, DevWork w, WorkItem* i
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q > b.nq) return;
   if (q == b.nq) { w.q_cap[q] = 0; return; }
-  const unsigned long long hits = w.q_hits[q];  // summed by k_probe
-  w.q_cap[q] = hits < s_max ? hits : (unsigned long long)s_max;
+  const unsigned long long all_hits = w.q_hits[q];  // summed by k_probe
+  w.q_cap[q] = all_hits < s_max ? all_hits : (unsigned long long)s_max;
   w.q_kept[q] = 0;
+  const unsigned long long hits = w.q_hits_a[q];  // what k_expand_a walks
   if (hits > kExpandChunk) {
     const uint32_t n_extra = (uint32_t)((hits + kExpandChunk - 1) / kExpandChunk) - 1;
     const unsigned long long base = atomicAdd(&w.counters[5], (unsigned long long)n_extra);
@@ -440,7 +500,7 @@ __global__ void __launch_bounds__(kWave, 8) k_expand_a(DevIndex ix, DevBatch b, 
       chunk = __builtin_amdgcn_readfirstlane(items[item_idx].chunk);
     }
     const uint32_t msl = uni(w.q_m[q]);
-    const unsigned long long hits = msl == kNoMatchLen ? 0ull : uni(w.q_hits[q]);
+    const unsigned long long hits = msl == kNoMatchLen ? 0ull : uni(w.q_hits_a[q]);
     if (hits != 0) {
       const unsigned long long seg0 = uni(w.q_seg[q]);
       const uint32_t cap = (uint32_t)(uni(w.q_seg[q + 1]) - seg0);
@@ -662,11 +722,225 @@ __global__ void __launch_bounds__(kWave, 8) k_expand_a(DevIndex ix, DevBatch b, 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_expand_h — phase A for the long suffix ranges.  84 % of all hits at C3 lie in the ~0.1 % of ranges with thousands
+// of suffixes (a repeated phrase), and k_expand_a is a pure 8-byte-per-hit HBM stream on them.  Here one LANE tests a
+// whole block of 64 consecutive suffixes: the signature bit planes (DevIndex::planes) give, per signature bucket,
+// one 64-bit word = that bucket's bit of the 64 suffixes, so the cover upper bound of all 64 is a bit-sliced sum
+// (carry-save adders on 64-bit words) of the planes of the pattern's buckets, weighted by positions per bucket.
+// Only the ~20 planes a pattern uses are read: ~3 bytes per hit instead of 8, 64 lanes x 8 bytes contiguous per load.
+// The bit-sliced sum is compared with the smallest threshold of any admissible sentence length (a superset of phase
+// A's survivors, ~1-3 % of the hits); those are re-tested exactly like k_expand_a does (same 8-byte word, same
+// table), so the hits queued for k_expand_b are identical.  One wave per work item (range, 256 blocks).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void csa64(unsigned long long& s, unsigned long long& c, unsigned long long x, unsigned long long y,
+                                      unsigned long long z) {
+  const unsigned long long u = x ^ y;
+  c = (x & y) | (u & z);
+  s = u ^ z;
+}
+
+// a[] = six-level bit-sliced counters (bit i of a[l] = bit l of suffix i's count); adds eight one-bit planes with
+// weight 2^J.  Carries beyond level 5 cannot occur (the total never exceeds the pattern length <= 63).
+template <int J>
+__device__ __forceinline__ void vadd8(unsigned long long (&a)[6], const unsigned long long (&x)[8]) {
+  unsigned long long s, c0, c1, c2, c3;
+  csa64(s, c0, a[J], x[0], x[1]);
+  csa64(s, c1, s, x[2], x[3]);
+  csa64(s, c2, s, x[4], x[5]);
+  csa64(s, c3, s, x[6], x[7]);
+  a[J] = s;
+  if constexpr (J + 1 < 6) {
+    unsigned long long d0, d1;
+    csa64(s, d0, a[J + 1], c0, c1);
+    csa64(s, d1, s, c2, c3);
+    a[J + 1] = s;
+    if constexpr (J + 2 < 6) {
+      unsigned long long e;
+      csa64(s, e, a[J + 2], d0, d1);
+      a[J + 2] = s;
+#pragma unroll
+      for (int l = J + 3; l < 6; l++) { const unsigned long long t = a[l] & e; a[l] ^= e; e = t; }
+    }
+  }
+}
+
+// adds, with weight 2^J, the planes of the buckets in the (wave-uniform) mask m; col = this lane's column of the planes
+template <int J>
+__device__ __forceinline__ void plane_level(unsigned long long (&a)[6], unsigned long long m, const unsigned long long* col,
+                                            unsigned long long n_blk, bool valid) {
+  while (m) {
+    unsigned long long x[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      x[u] = 0;
+      if (m) {
+        const uint32_t bk = (uint32_t)__builtin_ctzll(m);
+        m &= m - 1ull;
+        if (valid) x[u] = col[(unsigned long long)bk * n_blk];
+      }
+    }
+    vadd8<J>(a, x);
+  }
+}
+
+constexpr uint32_t kHeavyList = 2 * kWave;  // LDS list of plane-test survivors waiting for the exact test
+
+__global__ void __launch_bounds__(kWave, 8) k_expand_h(DevIndex ix, DevBatch b, DevWork w, Params prm, const HeavyItem* items,
+                                                       uint32_t item_cap) {
+  __shared__ __attribute__((aligned(8))) uint16_t s_cmin[kCminTab];
+  __shared__ uint32_t s_bucket[kWave];
+  __shared__ uint32_t s_list[kHeavyList];
+  __shared__ QHit s_q[kQueue];
+  const uint32_t lane = lane_id();
+  const unsigned long long below = (1ull << lane) - 1ull;
+  unsigned long long n_items = w.counters[15];
+  if (n_items > item_cap) n_items = item_cap;
+  for (unsigned long long item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const uint32_t t = uni(items[item].t), r_lo = uni(items[item].lo), r_cnt = uni(items[item].cnt), chunk = uni(items[item].chunk);
+    const uint32_t q = uni(w.t_q[t]);
+    const unsigned long long seg0 = uni(w.q_seg[q]);
+    const uint32_t cap = (uint32_t)(uni(w.q_seg[q + 1]) - seg0);
+    if (seg0 + cap > w.seg_cap) continue;  // workspace too small: reported by k_caps_b, the host re-runs the pass
+    const uint32_t o0 = uni(b.q_off[b.q_begin + q]);
+    const uint32_t p = uni(b.q_off[b.q_begin + q + 1]) - o0;
+    const uint32_t* pat = b.q_tok + o0;
+    const uint32_t it = t - (o0 - b.t_begin);
+    const uint32_t it_hi = it << 16;
+    wave_lds_sync();
+    s_bucket[lane] = 0;
+    wave_lds_sync();
+    for (uint32_t j = lane; j < p; j += kWave) atomicAdd(&s_bucket[sig_bit(pat[j])], 1u);
+    reinterpret_cast<unsigned long long*>(s_cmin)[lane] =
+        reinterpret_cast<const unsigned long long*>(w.cmin_tab + (size_t)p * kCminTab)[lane];
+    wave_lds_sync();
+    // positions per bucket as bit planes over the buckets (wave-uniform 64-bit masks, like k_expand_a)
+    unsigned long long pl[6];
+    {
+      const uint32_t mycnt = s_bucket[lane];
+#pragma unroll
+      for (uint32_t k = 0; k < 6; k++) pl[k] = __ballot((mycnt >> k) & 1u);
+    }
+    // smallest threshold of any admissible stored length below the clamp (0xffff: the length filter rejects all)
+    uint32_t t_min = 0xffffu;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+      const uint32_t sl = lane * 4 + k;
+      const uint32_t v = s_cmin[sl];
+      if (sl != kSigLenClamp && v < t_min) t_min = v;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(t_min, d, 64); t_min = o < t_min ? o : t_min; }
+    t_min = uni(t_min);
+    const bool clamp_possible = s_cmin[kSigLenClamp] != 0xffffu;  // uniform: the index holds sentences of >= 255 tokens
+    QHit* qb = w.qb + seg0;
+    uint32_t q_head = 0, q_tail = 0, n_list = 0;
+    auto flush = [&](uint32_t n_take) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(&w.q_pb[q], n_take);
+      base = __shfl(base, 0, 64);
+      if (lane < n_take && base + lane < cap) qb[base + lane] = s_q[(q_head + lane) & (kQueue - 1)];
+      q_head += n_take;
+      wave_lds_sync();
+    };
+    // exact phase-A test of one hit per lane (same word, same table, same bound as k_expand_a) and queueing
+    auto exact = [&](bool valid, uint32_t i) {
+      const unsigned long long pk = valid ? ix.suf_sig[i] : 0ull;
+      const uint32_t cmin = s_cmin[sig_slen(pk)];
+      const unsigned long long sig = sig_bits(pk);
+      uint32_t ub = 0;
+#pragma unroll
+      for (uint32_t k = 0; k < 6; k++) ub += (uint32_t)__popcll(sig & pl[k]) << k;
+      const bool keep = valid & (ub >= cmin);
+      const unsigned long long m = __ballot(keep);
+      if (m) {
+        if (keep) { QHit e; e.i = i; e.it_need = it_hi | cmin; s_q[(q_tail + __popcll(m & below)) & (kQueue - 1)] = e; }
+        q_tail += __popcll(m);
+        if (q_tail - q_head >= kWave) { wave_lds_sync(); do flush(kWave); while (q_tail - q_head >= kWave); }
+      }
+    };
+    const uint32_t r_hi = r_lo + r_cnt;  // exclusive
+    const uint32_t blk_first = (r_lo >> 6) + chunk * kHeavyChunkBlocks;
+    const uint32_t blk_last_r = (r_hi - 1) >> 6;
+    const uint32_t blk_end = blk_first + kHeavyChunkBlocks - 1 < blk_last_r ? blk_first + kHeavyChunkBlocks : blk_last_r + 1;
+    unsigned long long n_pass = 0;
+    for (uint32_t b0 = blk_first; b0 < blk_end; b0 += kWave) {
+      const uint32_t blk = b0 + lane;
+      const bool valid = blk < blk_end;
+      unsigned long long a[6] = {0, 0, 0, 0, 0, 0};
+      const unsigned long long* col = ix.planes + blk;
+      plane_level<0>(a, pl[0], col, ix.n_blk, valid);
+      plane_level<1>(a, pl[1], col, ix.n_blk, valid);
+      plane_level<2>(a, pl[2], col, ix.n_blk, valid);
+      plane_level<3>(a, pl[3], col, ix.n_blk, valid);
+      plane_level<4>(a, pl[4], col, ix.n_blk, valid);
+      plane_level<5>(a, pl[5], col, ix.n_blk, valid);
+      // count >= t_min, bit-sliced (t_min uniform; > 63 cannot be reached)
+      unsigned long long ge = 0;
+      if (t_min <= kPlaneMaxP) {
+        unsigned long long gt = 0, eq = ~0ull;
+#pragma unroll
+        for (int l = 5; l >= 0; l--) {
+          if ((t_min >> l) & 1u) eq &= a[l];
+          else gt |= eq & a[l];
+        }
+        ge = gt | eq;
+      }
+      if (clamp_possible && valid) ge |= col[(unsigned long long)kSigBits * ix.n_blk];  // clamped lengths: phase B decides
+      // the part of the block inside [r_lo, r_hi)
+      const uint32_t lo_bit = blk == (r_lo >> 6) ? (r_lo & 63u) : 0u;
+      const uint32_t hi_bit = blk == blk_last_r ? ((r_hi - 1) & 63u) + 1u : 64u;
+      unsigned long long mask = hi_bit == 64 ? ~0ull : ((1ull << hi_bit) - 1ull);
+      mask &= ~((1ull << lo_bit) - 1ull);
+      unsigned long long surv = valid ? (ge & mask) : 0ull;
+      n_pass += (unsigned long long)__popcll(surv);
+      // survivors -> LDS list, 64 at a time through the exact test
+      for (;;) {
+        const bool has = surv != 0;
+        const unsigned long long hm = __ballot(has);
+        if (!hm) break;
+        if (has) {
+          const uint32_t bit = (uint32_t)__builtin_ctzll(surv);
+          surv &= surv - 1ull;
+          s_list[n_list + __popcll(hm & below)] = blk * 64u + bit;
+        }
+        n_list += __popcll(hm);
+        if (n_list >= kWave) {
+          wave_lds_sync();
+          const uint32_t i = s_list[lane];
+          const uint32_t rest = n_list - kWave;
+          const uint32_t carry = lane < rest ? s_list[kWave + lane] : 0u;
+          wave_lds_sync();
+          if (lane < rest) s_list[lane] = carry;
+          n_list = rest;
+          exact(true, i);
+        }
+      }
+    }
+    if (n_list) {
+      wave_lds_sync();
+      const uint32_t i = lane < n_list ? s_list[lane] : 0u;
+      exact(lane < n_list, i);
+    }
+    if (q_tail != q_head) { wave_lds_sync(); flush(q_tail - q_head); }
+    // statistics: one atomic pair per work item
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) n_pass += __shfl_xor(n_pass, d, 64);
+    if (lane == 0) {
+      const uint32_t h0 = blk_first == (r_lo >> 6) ? r_lo : blk_first * 64u;
+      const uint32_t h1 = blk_end == blk_last_r + 1 ? r_hi : blk_end * 64u;
+      atomicAdd(&w.counters[16], (unsigned long long)(h1 - h0));
+      if (n_pass) atomicAdd(&w.counters[17], n_pass);
+    }
+  }
+}
+
 // work items of k_expand_b for queries with more than kPhaseBChunk queued hits
 __global__ void k_caps_b(DevBatch b, DevWork w, WorkItem* items, uint32_t item_cap) {
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= b.nq) return;
   const uint32_t cap = (uint32_t)(w.q_seg[q + 1] - w.q_seg[q]);
+  if (w.q_seg[q + 1] > w.seg_cap) { if (q + 1 == b.nq) atomicMax(&w.counters[6], w.q_seg[b.nq]); return; }  // host re-runs the pass with a larger workspace
   const uint32_t n = w.q_pb[q];
   if (n > cap) { atomicMax(&w.counters[4], (unsigned long long)n); return; }  // queue overflow: retry with a larger s_max
   if (n > kPhaseBChunk) {
@@ -1471,10 +1745,12 @@ struct LdsRow {
   __device__ __forceinline__ float& operator[](uint32_t j) const { return base[j * kWave]; }
 };
 
-template <bool FULL>
-__global__ void __launch_bounds__(kWave) k_dp(DevIndex ix, DevBatch b, DevWork w, Params prm) {
+// GROWS: the rows live in HBM (g_rows: row_len x 64 floats per workgroup) instead of dynamic LDS — patterns longer
+// than ~590 tokens (--max-tokens-in-pattern above the default, include/fuzzy/suffix_array_index.hh:15).
+template <bool FULL, bool GROWS>
+__global__ void __launch_bounds__(kWave) k_dp(DevIndex ix, DevBatch b, DevWork w, Params prm, float* g_rows, uint32_t row_len) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* s_rows = (float*)smem;
+  float* s_rows = GROWS ? g_rows + (size_t)blockIdx.x * row_len * kWave : (float*)smem;
   const uint32_t lane = lane_id();
   unsigned long long j_lo, j_hi;
   dp_class_range(b, w, 2, j_lo, j_hi);
@@ -2023,21 +2299,25 @@ __global__ void __launch_bounds__(kWave) k_finish(DevIndex ix, DevBatch b, DevWo
 // <= 32 tokens, 1: <= 64, 2: longer), so the common case keeps the picked sentence and the DP row in registers.
 constexpr uint32_t kContrastLds = 256;
 
+// MODE 3 = MODE 2 with the DP rows in HBM (g_rows: row_len x 64 floats per workgroup): indexed sentences too long for
+// the LDS rows.
 template <int MODE>
 __global__ void __launch_bounds__(kWave) k_contrast(DevIndex ix, DevBatch b, DevWork w, Params prm, DevScratch sc,
                                                     uint32_t cap, Rec* out_rec, uint32_t* out_count,
-                                                    uint32_t* out_total, const uint32_t* contrast_list) {
+                                                    uint32_t* out_total, const uint32_t* contrast_list, float* g_rows,
+                                                    uint32_t row_len) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* s_rows = (float*)smem;
+  float* s_rows = MODE == 3 ? g_rows + (size_t)blockIdx.x * row_len * kWave : (float*)smem;
+  constexpr int QMODE = MODE == 3 ? 2 : MODE;  // the queue k_finish filled
   // small LDS footprint (the accepted list is rarely longer than the contrast buffer): more waves per CU
   __shared__ unsigned long long s_keys[kContrastLds];
   __shared__ uint32_t s_vals[kContrastLds];
   __shared__ float    s_f0[kContrastLds], s_f1[kContrastLds];
   const uint32_t lane = lane_id();
   // MODE 0: one wave per query of the sub-batch; MODE 1 / 2: grid-stride over the queue k_finish filled
-  const unsigned long long n_items = MODE == 0 ? (unsigned long long)b.nq : w.counters[9 + MODE];
+  const unsigned long long n_items = MODE == 0 ? (unsigned long long)b.nq : w.counters[9 + QMODE];
   for (unsigned long long item = blockIdx.x; item < n_items; item += gridDim.x) {
-    const uint32_t q = MODE == 0 ? (uint32_t)item : contrast_list[(size_t)(MODE - 1) * b.nq + item];
+    const uint32_t q = MODE == 0 ? (uint32_t)item : contrast_list[(size_t)(QMODE - 1) * b.nq + item];
     const uint32_t gq = b.q_begin + q;
     if (w.q_cand[q] == 0) continue;  // k_finish already wrote an empty result
     const uint32_t acc = w.q_acc[q];

@@ -53,7 +53,8 @@ class Stats(C.Structure):
                 ("ms_kernel", C.c_double * 16), ("launches", C.c_uint64 * 16),
                 ("n_hits", C.c_uint64), ("n_kept", C.c_uint64), ("n_candidates", C.c_uint64),
                 ("n_dp", C.c_uint64), ("n_retries", C.c_uint64), ("n_big", C.c_uint64),
-                ("n_phase_b", C.c_uint64), ("max_kept", C.c_uint64)]
+                ("n_phase_b", C.c_uint64), ("max_kept", C.c_uint64), ("n_heavy_hits", C.c_uint64),
+                ("n_heavy_pass", C.c_uint64), ("pinned", C.c_uint64)]
 
 
 class Info(C.Structure):
@@ -70,7 +71,9 @@ EXPORTS = [
     "fmx_index_sort", "fmx_index_finalize", "fmx_index_to_device", "fmx_vocab_lookup",
     "fmx_index_lookup_real", "fmx_index_intern_itok", "fmx_index_sentence_id", "fmx_index_array",
     "fmx_index_get_info", "fmx_match_batch", "fmx_match_batch_device", "fmx_set_option",
+    "fmx_host_alloc", "fmx_host_free", "fmx_index_to_devices", "fmx_set_devices", "fmx_index_reopen", "fmx_match_one",
 ]
+TM_SKIPPED = -100
 
 _lib = None
 
@@ -121,6 +124,14 @@ def lib():
     L.fmx_match_batch_device.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Batch), C.c_uint64, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(Stats)]
     L.fmx_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+    L.fmx_host_alloc.restype = C.c_void_p
+    L.fmx_host_alloc.argtypes = [C.c_size_t]
+    L.fmx_host_free.argtypes = [C.c_void_p]
+    L.fmx_index_to_devices.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int]
+    L.fmx_set_devices.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int]
+    L.fmx_index_reopen.argtypes = [C.c_void_p]
+    L.fmx_match_one.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     _lib = L
     return L
 
@@ -140,6 +151,47 @@ def device_count():
 
 def _ptr(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class _PinnedBlock:
+    def __init__(self, nbytes):
+        self.ptr = lib().fmx_host_alloc(max(int(nbytes), 1))
+        if not self.ptr:
+            raise MemoryError("fmx_host_alloc failed")
+        self.buf = (C.c_char * max(int(nbytes), 1)).from_address(self.ptr)
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                lib().fmx_host_free(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+_pinned_blocks = {}
+
+
+def pinned_empty(shape, dtype):
+    """numpy array over pinned host memory (fmx_host_alloc): fmx_match_batch overlaps its PCIe copies with compute
+    when the batch and result buffers are pinned.  The memory lives until pinned_free(array) or interpreter exit."""
+    dt = np.dtype(dtype)
+    shape = (shape,) if np.isscalar(shape) else tuple(shape)
+    n = int(np.prod(shape)) if shape else 1
+    blk = _PinnedBlock(n * dt.itemsize)
+    arr = np.frombuffer(blk.buf, dtype=dt, count=n).reshape(shape)
+    _pinned_blocks[arr.ctypes.data] = blk
+    return arr
+
+
+def pinned_copy(a):
+    out = pinned_empty(a.shape, a.dtype)
+    out[...] = a
+    return out
+
+
+def pinned_free(arr):
+    _pinned_blocks.pop(arr.ctypes.data, None)
 
 
 class Index:
@@ -185,7 +237,9 @@ class Index:
         idx = (C.c_uint64 * max(n, 1))(*list(itoks.keys()))
         strs = (C.c_char_p * max(n, 1))(*[v.encode("utf-8") for v in itoks.values()])
         r = lib().fmx_index_add_tm(self.h, sid.encode("utf-8"), arr, len(norm), real_s, n, idx, strs)
-        if r < -1:
+        if r == TM_SKIPPED:
+            return -1  # ignored like the reference ignores it (empty / too long)
+        if r < 0:
             _check(int(r))
         return int(r)
 
@@ -202,6 +256,27 @@ class Index:
 
     def to_device(self, device=0):
         _check(lib().fmx_index_to_device(self.h, device))
+
+    def to_devices(self, devices):
+        arr = (C.c_int * len(devices))(*devices)
+        _check(lib().fmx_index_to_devices(self.h, arr, len(devices)))
+
+    def reopen(self):
+        _check(lib().fmx_index_reopen(self.h))
+
+    def match_one(self, params, wids, q_real=None, q_itok=None, cap=None):
+        """FuzzyMatch::match for one pattern through the request coalescer (thread-safe, blocking)."""
+        wids = np.ascontiguousarray(wids, dtype=np.uint32)
+        cap = cap or (params.nmatch if params.nmatch > 0 else 64)
+        out = np.zeros(cap, dtype=MATCH_DTYPE)
+        cnt, tot = C.c_uint32(0), C.c_uint32(0)
+        if q_real is not None:
+            q_real = np.ascontiguousarray(q_real, dtype=np.uint32)
+        if q_itok is not None:
+            q_itok = np.ascontiguousarray(q_itok, dtype=np.uint32)
+        _check(lib().fmx_match_one(self.h, C.byref(params), _ptr(wids), len(wids), _ptr(q_real), _ptr(q_itok), _ptr(out),
+                                   cap, C.byref(cnt), C.byref(tot)))
+        return out[:cnt.value], tot.value
 
     def info(self):
         i = Info()
@@ -238,17 +313,22 @@ class Index:
     def set_option(self, name, value):
         _check(lib().fmx_set_option(self.h, name.encode(), int(value)))
 
-    def match_batch(self, params, q_off, q_tok, q_real=None, q_itok=None, cap=None, want_stats=False):
+    def match_batch(self, params, q_off, q_tok, q_real=None, q_itok=None, cap=None, want_stats=False, out=None):
         """FuzzyMatch::match over a CSR batch of vocabulary-id patterns (host buffers).
-        Returns (records[nq, cap], counts[nq], totals[nq]) (+ Stats)."""
+        Returns (records[nq, cap], counts[nq], totals[nq]) (+ Stats).  `out` = (records, counts, totals) arrays to
+        fill (e.g. pinned_empty ones) instead of fresh pageable arrays."""
         q_off = np.ascontiguousarray(q_off, dtype=np.uint32)
         q_tok = np.ascontiguousarray(q_tok, dtype=np.uint32)
         nq = len(q_off) - 1
         if cap is None:
             cap = params.nmatch if params.nmatch > 0 else 64
-        out = np.zeros((max(nq, 1), cap), dtype=MATCH_DTYPE)
-        cnt = np.zeros(max(nq, 1), dtype=np.uint32)
-        tot = np.zeros(max(nq, 1), dtype=np.uint32)
+        if out is not None:
+            out, cnt, tot = out
+            assert out.shape[0] >= nq and out.shape[1] == cap and out.dtype == MATCH_DTYPE
+        else:
+            out = np.zeros((max(nq, 1), cap), dtype=MATCH_DTYPE)
+            cnt = np.zeros(max(nq, 1), dtype=np.uint32)
+            tot = np.zeros(max(nq, 1), dtype=np.uint32)
         if q_real is not None:
             q_real = np.ascontiguousarray(q_real, dtype=np.uint32)
         if q_itok is not None:

@@ -7,12 +7,14 @@
 // of SYSTRAN/fuzzy-match, so a caller of libFuzzyMatch.so re-links against libfmx.so and keeps its
 // source.  Header only; every call goes through the extern "C" entry points.
 //
-// Not provided (out of scope of the match() hot path): the std::string overloads
-// that run the OpenNMT tokenizer (add_tm(id, string), match(string, ...)) and subsequence().  They exist
-// so that callers compile, and throw std::logic_error.
+// add_tm(..., sort = true) does what the reference does — further add_tm calls stay legal: the suffix sort, the
+// derived arrays and the upload to HBM happen lazily at the first match()/export after a change, and an add_tm
+// after that thaws the index again (fmx_index_reopen).  match() is const and re-entrant like the reference's:
+// every call goes through fmx_match_one, which coalesces concurrent callers into GPU micro-batches.
 #pragma once
 #include <stdint.h>
 
+#include <atomic>
 #include <cstring>
 #include <mutex>
 #include <stdexcept>
@@ -97,7 +99,10 @@ class FuzzyMatch {
   bool add_tm(const std::string& id, const Tokens& norm, bool sort = true) {
     return add_tm(id, Sentence(norm), norm, sort);
   }
+  // SuffixArrayIndex::add_tm (src/suffix_array_index.cc:10-30): legal at any time, also after sort() / match()
   bool add_tm(const std::string& id, const Sentence& source, const Tokens& norm, bool sort = true) {
+    std::lock_guard<std::mutex> lk(_mu);
+    if (_ready) { check(fmx_index_reopen(_ix)); _ready = false; }
     std::vector<const char*> toks;
     for (const auto& t : norm) toks.push_back(t.c_str());
     std::vector<uint64_t> idx;
@@ -105,22 +110,14 @@ class FuzzyMatch {
     for (const auto& kv : source.itoks()) { idx.push_back(kv.first); strs.push_back(kv.second.c_str()); }
     const int64_t r = fmx_index_add_tm(_ix, id.c_str(), toks.data(), (uint32_t)toks.size(), source.tokstring().c_str(),
                                        (uint32_t)idx.size(), idx.data(), strs.data());
-    if (r < -1) throw std::runtime_error(fmx_last_error());
-    if (sort) this->sort();
+    if (r < 0 && r != FMX_TM_SKIPPED) throw std::runtime_error(fmx_last_error());
+    (void)sort;  // the sort is lazy: see ensure_ready()
     return true;
   }
-  bool add_tm(const std::string&, const std::string&, bool = true) {
-    throw std::logic_error("add_tm(id, text): the tokenizer front-end is outside the MI355X match() build");
-  }
+  bool add_tm(const std::string& id, const std::string& sentence, bool sort = true);  // fuzzy_text.hh (restricted tokenizer)
 
-  // SuffixArray::sort then upload: the index becomes immutable (the reference allows further add_tm
-  // calls after sort(); this build freezes the index at the first sort()).
-  void sort() {
-    if (_ready) return;
-    check(fmx_index_sort(_ix, _device, 0));
-    make_ready();
-  }
-
+  // SuffixArray::sort (src/suffix_array.cc:58-102): here a promise — the work happens in ensure_ready()
+  void sort() {}
   // match(const Tokens&, ...) — include/fuzzy/fuzzy_match.hh:59-69
   bool match(const Tokens& pattern, float fuzzy, unsigned number_of_matches, std::vector<Match>& matches,
              int min_subseq_length = 2, float min_subseq_ratio = 0, float vocab_idf_penalty = 0,
@@ -136,9 +133,15 @@ class FuzzyMatch {
              std::vector<Match>& matches, int min_subseq_length = 3, float min_subseq_ratio = 0.3,
              float vocab_idf_penalty = 0, const EditCosts& edit_costs = EditCosts(), float contrastive_factor = 0,
              ContrastReduce reduce = ContrastReduce::MEAN, int contrast_buffer = -1) const {
-    if (!_ready) throw std::logic_error("FuzzyMatch::match before sort()/import");
+    ensure_ready();
     const uint32_t p = (uint32_t)pattern.size();
     if (p == 0 || p > _max_tokens) return false;  // src/fuzzy_match.cc:455-461
+    // `matches` is appended to, never cleared, and entries already in it count towards number_of_matches
+    // (src/fuzzy_match.cc:633,670)
+    const size_t existing = matches.size();
+    if (number_of_matches != 0 && existing >= number_of_matches) return true;
+    if (existing != 0 && contrastive_factor > 0)
+      throw std::logic_error("match(): contrastive rerank against matches already in the vector is not built (SURVEY §8a row J)");
     std::vector<const char*> toks;
     for (const auto& t : pattern) toks.push_back(t.c_str());
     std::vector<uint32_t> wids(p), q_real, q_itok;
@@ -157,25 +160,23 @@ class FuzzyMatch {
         if (kv.first <= p) q_itok[kv.first] = fmx_index_intern_itok(_ix, kv.second.data(), kv.second.size());
     }
     fmx_params prm;
-    prm.fuzzy = fuzzy; prm.nmatch = number_of_matches; prm.no_perfect = no_perfect;
+    prm.fuzzy = fuzzy;
+    prm.nmatch = number_of_matches ? number_of_matches - (unsigned)existing : 0;
+    prm.no_perfect = no_perfect;
     prm.min_subseq_length = min_subseq_length; prm.min_subseq_ratio = min_subseq_ratio;
     prm.idf_penalty = vocab_idf_penalty;
     prm.insert_cost = edit_costs.insert_cost; prm.delete_cost = edit_costs.delete_cost;
     prm.replace_cost = edit_costs.replace_cost;
     prm.contrast = contrastive_factor; prm.reduce = reduce == ContrastReduce::MAX ? 1 : 0;
-    prm.contrast_buffer = contrast_buffer;
-    const uint32_t q_off[2] = {0, p};
-    fmx_batch b;
-    b.nq = 1; b.q_off = q_off; b.q_tok = wids.data();
-    b.q_real = q_real.empty() ? nullptr : q_real.data();
-    b.q_itok = q_itok.empty() ? nullptr : q_itok.data();
-    b.max_len = p;
-    uint32_t cap = number_of_matches ? number_of_matches : 64;
+    // "-1 => number_of_matches" is taken on the caller's number (src/fuzzy_match.cc:451-452)
+    prm.contrast_buffer = contrast_buffer == -1 ? (int)number_of_matches : contrast_buffer;
+    uint32_t cap = prm.nmatch ? prm.nmatch : 64;
     std::vector<fmx_match> out;
     uint32_t count = 0, total = 0;
     for (;;) {  // number_of_matches == 0 means "all": grow until everything fits
       out.resize(cap);
-      check(fmx_match_batch(_ix, &prm, &b, out.data(), &count, &total, cap, nullptr));
+      check(fmx_match_one(_ix, &prm, wids.data(), p, q_real.empty() ? nullptr : q_real.data(),
+                          q_itok.empty() ? nullptr : q_itok.data(), out.data(), cap, &count, &total));
       if (total <= cap) break;
       cap = total;
     }
@@ -188,13 +189,17 @@ class FuzzyMatch {
     return matches.size() > 0;
   }
 
-  bool match(const std::string&, float, unsigned, bool, std::vector<Match>&, int = 3, float = 0.3, float = 0,
-             const EditCosts& = EditCosts(), float = 0, ContrastReduce = ContrastReduce::MEAN, int = -1) const {
-    throw std::logic_error("match(text, ...): the tokenizer front-end is outside the MI355X match() build");
-  }
-  bool subsequence(const std::string&, unsigned, bool, std::vector<Match>&, int = 3, float = 0.3, bool = false) const {
-    throw std::logic_error("subsequence(): outside the MI355X match() build");
-  }
+  // match(const std::string&, ...) — include/fuzzy/fuzzy_match.hh:85-97, src/fuzzy_match.cc:393-412: tokenise +
+  // normalise, then the Sentence/Tokens overload.  Defined in fuzzy_text.hh (restricted tokenizer, see there).
+  bool match(const std::string& sentence, float fuzzy, unsigned number_of_matches, bool no_perfect,
+             std::vector<Match>& matches, int min_subseq_length = 3, float min_subseq_ratio = 0.3,
+             float vocab_idf_penalty = 0, const EditCosts& edit_costs = EditCosts(), float contrastive_factor = 0,
+             ContrastReduce reduce = ContrastReduce::MEAN, int contrast_buffer = -1) const;
+  // subsequence() — include/fuzzy/fuzzy_match.hh:99-105, src/fuzzy_match.cc:250-365 (fuzzy_text.hh)
+  bool subsequence(const std::string& sentence, unsigned number_of_matches, bool no_perfect, std::vector<Match>& matches,
+                   int min_subseq_length = 3, float min_subseq_ratio = 0.3, bool idf_weighting = false) const;
+  bool subsequence(const Tokens& pattern, unsigned number_of_matches, bool no_perfect, std::vector<Match>& matches,
+                   int min_subseq_length = 3, float min_subseq_ratio = 0.3, bool idf_weighting = false) const;
 
   size_t max_tokens_in_pattern() const { return _max_tokens; }
   fmx_index* handle() const { return _ix; }
@@ -203,6 +208,14 @@ class FuzzyMatch {
   friend void import_binarized_fuzzy_matcher(const std::string&, FuzzyMatch&);
   friend void export_binarized_fuzzy_matcher(const std::string&, const FuzzyMatch&);
   static void check(int rc) { if (rc != FMX_OK) throw std::runtime_error(fmx_last_error()); }
+  // sort + derive + upload, once after any change (match() is const in the reference: the state is mutable here)
+  void ensure_ready() const {
+    if (_ready.load(std::memory_order_acquire)) return;
+    std::lock_guard<std::mutex> lk(_mu);
+    if (_ready.load(std::memory_order_relaxed)) return;
+    check(fmx_index_sort(_ix, _device, 0));
+    const_cast<FuzzyMatch*>(this)->make_ready();
+  }
   void make_ready() {
     check(fmx_index_finalize(_ix));
     check(fmx_index_to_device(_ix, _device));
@@ -214,13 +227,15 @@ class FuzzyMatch {
     const void* p; uint64_t n;
     check(fmx_index_array(_ix, FMX_A_BUFFER, &p, &n)); _buffer = (const unsigned*)p;
     check(fmx_index_array(_ix, FMX_A_SENT_POS, &p, &n)); _sent_pos = (const unsigned*)p;
-    _ready = true;
+    _ready.store(true, std::memory_order_release);
   }
   int _pt;
   size_t _max_tokens;
   int _device;
   fmx_index* _ix;
-  bool _ready = false, _real_differs = false;
+  mutable std::mutex _mu;
+  std::atomic<bool> _ready{false};
+  bool _real_differs = false;
   const unsigned* _buffer = nullptr;
   const unsigned* _sent_pos = nullptr;
 };
@@ -233,11 +248,11 @@ inline void import_binarized_fuzzy_matcher(const std::string& path, FuzzyMatch& 
   fmx_index_free(fm._ix);
   fm._ix = ix;
   fm._ready = false;
-  if (fmx_index_sort(ix, fm._device, 0) != FMX_OK) throw std::runtime_error(fmx_last_error());  // no-op when sorted
-  fm.make_ready();
+  fm.ensure_ready();  // the reference's import leaves a usable matcher; errors surface here, like there
 }
 
 inline void export_binarized_fuzzy_matcher(const std::string& path, const FuzzyMatch& fm) {
+  fm.ensure_ready();  // the file holds the sorted suffix array
   if (fmx_index_save(fm._ix, path.c_str()) != FMX_OK) throw std::runtime_error(fmx_last_error());
 }
 

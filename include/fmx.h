@@ -30,8 +30,12 @@ typedef enum fmx_status {
   FMX_E_NO_DEVICE = -3,   /* no usable GPU, or HIP call failed */
   FMX_E_NOMEM = -4,
   FMX_E_STATE = -5,       /* index not sorted / not finalized / not on the device */
-  FMX_E_UNSUPPORTED = -6
+  FMX_E_UNSUPPORTED = -6  /* a documented limit of this build was hit (the message names it) */
 } fmx_status;
+
+/* fmx_index_add_tm: the sentence was ignored exactly like the reference ignores it (empty, or longer than
+ * max_tokens_in_pattern; src/suffix_array_index.cc:16).  Distinct from every fmx_status. */
+#define FMX_TM_SKIPPED (-100)
 
 typedef struct fmx_index fmx_index;
 
@@ -89,6 +93,9 @@ typedef struct fmx_stats {
   uint64_t n_big;           /* queries whose survivor set needed the 1024-thread sorter */
   uint64_t n_phase_b;       /* hits that passed the length + signature tests (tokens were read) */
   uint64_t max_kept;        /* largest survivor set of a single query */
+  uint64_t n_heavy_hits;    /* of n_hits: hits of long ranges, tested 64 per lane through the signature bit planes */
+  uint64_t n_heavy_pass;    /* of those: hits that passed the plane test and were re-tested exactly */
+  uint64_t pinned;          /* 1 if the host buffers of fmx_match_batch were pinned (copies overlapped compute) */
 } fmx_stats;
 
 const char* fmx_last_error(void);
@@ -97,6 +104,10 @@ const char* fmx_stage_name(int stage);
 
 /* ---- devices --------------------------------------------------------------------------- */
 int fmx_device_count(void);                 /* number of usable gfx950 devices, 0 if none */
+/* Pinned host memory for batch buffers (q_off / q_tok / out / out_count ...): with these fmx_match_batch
+ * overlaps the PCIe copies of one pass with the kernels of its neighbours.  Pageable buffers work too. */
+void* fmx_host_alloc(size_t bytes);
+void  fmx_host_free(void*);
 
 /* ---- index lifetime ---------------------------------------------------------------------
  * fuzzy::FuzzyMatch(int pt, size_t max_tokens_in_pattern) — include/fuzzy/fuzzy_match.hh:48-49 */
@@ -110,8 +121,8 @@ int        fmx_index_save(const fmx_index*, const char* fmi_path);
 
 /* FuzzyMatch::add_tm(id, Sentence real, Tokens norm, sort=false) — include/fuzzy/fuzzy_match.hh:52,
  * src/suffix_array_index.cc:10-30.  real_tokstring = real tokens joined by '\t' (NULL: same as norm,
- * the Tokens overload fuzzy_match.hh:51).  Returns the sentence id, or -1 when the reference would
- * have skipped the sentence, or another negative fmx_status. */
+ * the Tokens overload fuzzy_match.hh:51).  Returns the sentence id (>= 0), FMX_TM_SKIPPED when the reference
+ * would have ignored the sentence, or a negative fmx_status. */
 int64_t fmx_index_add_tm(fmx_index*, const char* id, const char* const* norm, uint32_t n_norm,
                          const char* real_tokstring, uint32_t n_itoks, const uint64_t* itok_idx,
                          const char* const* itok_str);
@@ -124,8 +135,18 @@ int fmx_index_add_ids(fmx_index*, const uint32_t* off, const uint32_t* toks, uin
 int fmx_index_sort(fmx_index*, int device, int nthreads);
 /* derive the SoA arrays (after sort or load) and freeze the index */
 int fmx_index_finalize(fmx_index*);
-/* copy the frozen index into the HBM of `device` (replicated per GPU) */
+/* copy the frozen index into the HBM of `device` (a HIP ordinal of a gfx950 part) */
 int fmx_index_to_device(fmx_index*, int device);
+/* Replicate the frozen index on several devices (index replicated, queries sharded).  fmx_match_batch
+ * and fmx_match_one then cut every batch into contiguous query blocks, one per device, run them concurrently and
+ * write each block's records straight into the caller's buffers (single process, host gather; the RCCL gather
+ * of the one-process-per-GPU deployment lives in fuzzy-match_amd/shard.py).  Devices already holding the index
+ * are kept.  fmx_set_devices is the name SURVEY §8b gives this entry point. */
+int fmx_index_to_devices(fmx_index*, const int* devices, int n_devices);
+int fmx_set_devices(fmx_index*, const int* devices, int n_devices);
+/* Thaw a finalized index (drops the device copies and the derived arrays) so that add_tm can be called again —
+ * the reference allows add_tm after sort() (include/fuzzy/fuzzy_match.hh:51-56). */
+int fmx_index_reopen(fmx_index*);
 
 /* ---- index queries (host) ---------------------------------------------------------------- */
 /* VocabIndexer::getIndex — src/vocab_indexer.cc:52-71 (unknown -> 1) */
@@ -182,7 +203,17 @@ int fmx_match_batch_device(fmx_index*, const fmx_params*, const fmx_batch* devic
                            uint64_t total_tokens, fmx_match* d_out, uint32_t* d_out_count,
                            uint32_t* d_out_total, uint32_t cap, void* stream, fmx_stats* stats);
 
+/* FuzzyMatch::match for ONE pattern, as the reference's callers issue it from N threads
+ * (cli/src/FuzzyMatch-cli.cc:139-147,254-257).  Thread-safe and blocking; concurrent callers are coalesced into
+ * micro-batches behind the scenes (flushed when the GPU is free, or after "coalesce_us" at the latest), so the
+ * launch overhead of a pass is shared.  q_real: p entries or NULL; q_itok: p + 1 entries or NULL. */
+int fmx_match_one(fmx_index*, const fmx_params*, const uint32_t* wids, uint32_t p, const uint32_t* q_real,
+                  const uint32_t* q_itok, fmx_match* out, uint32_t cap, uint32_t* out_count, uint32_t* out_total);
+
 /* tuning knobs (all have sane defaults):
+ *   "contexts"          concurrent calls served at once per device, each with its own workspace (default 2)
+ *   "heavy_min"         suffix ranges at least this long are tested through the bit planes (default 1024, 0 = never)
+ *   "coalesce_us"       longest time fmx_match_one waits for company (default 50)
  *   "sub_queries"       queries per pipeline pass (default 1 048 576)
  *   "host_sub_queries"  pass size of fmx_match_batch (host buffers, default 262 144): the results of a pass are
  *                       copied to the host while the next pass computes

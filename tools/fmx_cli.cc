@@ -162,7 +162,8 @@ int main(int argc, char** argv) {
       if (toks.empty()) { std::cerr << "WARNING: cannot index empty segment: (" << id << ")" << std::endl; continue; }
       std::vector<const char*> ptr;
       for (const auto& t : toks) ptr.push_back(t.c_str());
-      if (fmx_index_add_tm(ix, id.c_str(), ptr.data(), (uint32_t)ptr.size(), nullptr, 0, nullptr, nullptr) < -1) {
+      const int64_t sid = fmx_index_add_tm(ix, id.c_str(), ptr.data(), (uint32_t)ptr.size(), nullptr, 0, nullptr, nullptr);
+      if (sid < 0 && sid != FMX_TM_SKIPPED) {
         std::cerr << "ERROR: " << fmx_last_error() << std::endl;
         return 1;
       }
