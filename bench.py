@@ -1,19 +1,34 @@
 #!/usr/bin/env python3
 """bench.py — query patterns/sec of the match() hot path on MI355X (BASELINE.json metric).
 
-One "step" = one pass of the whole GPU pipeline (probe -> expand -> cand -> score -> select) over one
-batch of synthetic query patterns already resident in HBM, results left in HBM (N > 1: plus the RCCL
-gather of the top-N records to rank 0).  Workload = BASELINE config C3 (5 M-sentence synthetic corpus,
-mean 25 tokens, 1 M queries per GPU per step, fuzzy 0.7, nmatch 5) unless overridden; the index is
-replicated per GPU and queries are sharded by rank (weak scaling).
+One "step" = one call of the C-ABI batch entry point (`fmx_match_batch`, include/fmx.h) over one batch of synthetic
+query patterns: host buffers in, host buffers out.  That is the phase the reference CLI brackets with
+TICK("Matching") ... TICK("Done") (cli/src/FuzzyMatch-cli.cc:450-467): H2D of the queries, every kernel,
+D2H of the records.  The buffers are pinned (fmx_host_alloc) and the library cuts a batch into passes whose copies
+overlap the neighbouring passes' kernels; like the reference's `match()`, the entry point is re-entrant and is
+driven from two host threads so that one call's last copy overlaps the other call's first kernels.
+`value` = queries of all ranks x K / wall time of K steps (barrier + device sync on both sides, max over ranks).
+The same batch run from HBM-resident buffers (device entry point, no PCIe) is reported as `device_resident`, with the
+per-stage HIP-event times the roofline objects are priced with.
 
-Prints ONE JSON line on rank 0 with `roofline` (probe kernel, algorithmic bytes of the reference's
-equal_range steps / HIP-event kernel time) and `cpu_baseline` (the oracle timed on the host cores).
+Workload = BASELINE config C3 (5 M-sentence synthetic corpus, mean 25 tokens, 1 M queries per step, fuzzy 0.7,
+nmatch 5) unless overridden.  N > 1 (one process per GPU, torch.distributed / RCCL): the index is replicated, the
+queries are sharded by rank and the top-N records are gathered to rank 0 over xGMI (the path's only collective,
+SURVEY §8e).  `--scaling weak` (default): 1 M queries per rank per step; `--scaling strong`: BASELINE's shape, the
+same 1 M queries cut into N contiguous blocks.  Both are measured in one run when N > 1 (`scaling_other`).
+
+Prints ONE JSON line on rank 0.
 """
 import argparse
+import concurrent.futures as cf
+import csv
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -24,7 +39,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 
 CONFIGS = {
-    # name: (sentences, mean_len, queries_per_gpu, params)
+    # name: (sentences, mean_len, queries_per_step, params)
     "C1": (10_000, 25, 1_000, dict(fuzzy=0.8, nmatch=5)),
     "C2": (1_000_000, 20, 100_000, dict(fuzzy=0.7, nmatch=5)),
     "C3": (5_000_000, 25, 1_000_000, dict(fuzzy=0.7, nmatch=5)),
@@ -32,137 +47,328 @@ CONFIGS = {
     "C5": (5_000_000, 25, 1_000_000, dict(fuzzy=0.7, nmatch=5, contrast=0.3, contrast_buffer=32)),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+CALIBRATION = os.path.join(ROOT, "profiles", "r02_fetch_size_calibration.json")
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="C3", choices=list(CONFIGS))
     ap.add_argument("--sentences", type=int, default=0)
     ap.add_argument("--queries", type=int, default=0)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--threads", type=int, default=2, help="host threads driving fmx_match_batch concurrently")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive host-buffer measurement (profiling runs: keeps every launch full-size)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline.traffic = null)")
+    ap.add_argument("--child", action="store_true", help="profiling child: device-resident steps only, no output line")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--verify", type=int, default=2000, help="queries of rank 0 checked against the oracle")
-    args = ap.parse_args()
+    ap.add_argument("--model-queries", type=int, default=20000, help="queries the reference byte model is counted on")
+    return ap.parse_args()
 
+
+def pmc_pass(counter, argv_child, log):
+    """One `rocprofv3 --pmc <counter>` pass over a child run of this script (device-resident steps only).
+    Returns {kernel name: mean counter value per dispatch over the child's timed dispatches} or None."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    out = tempfile.mkdtemp(prefix=f"fmx_pmc_{counter}_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable,
+           os.path.join(ROOT, "bench.py"), "--child"] + argv_child
+    try:
+        r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=900)
+        files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+        if r.returncode != 0 or not files:
+            log(f"[bench] pmc pass {counter} failed (rc {r.returncode}): {r.stderr[-300:]}")
+            return None
+        by = {}
+        for row in csv.DictReader(open(files[0])):
+            if row["Counter_Name"] != counter:
+                continue
+            by.setdefault(row["Kernel_Name"].split("(")[0], []).append((int(row["Dispatch_Id"]), float(row["Counter_Value"])))
+        res = {}
+        for k, v in by.items():
+            v.sort()
+            res[k] = v
+        return res
+    except Exception as e:  # noqa: BLE001
+        log(f"[bench] pmc pass {counter} failed: {e}")
+        return None
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
+def main():
+    args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         args.gpus = world
 
-    import torch  # plumbing only: device tensors, streams, torch.distributed
+    import torch  # plumbing only: device tensors for the device entry point, torch.distributed
     import torch.distributed as dist
     import fmx_import
     fmx = fmx_import.load().fmx
+    shard = fmx_import.load().shard
     import synth
 
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
     torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    n_sent, mean_len, nq, pkw = CONFIGS[args.config]
+    n_sent, mean_len, nq_cfg, pkw = CONFIGS[args.config]
     n_sent = args.sentences or n_sent
-    nq = args.queries or nq
+    nq_cfg = args.queries or nq_cfg
     log = (lambda *a: print(*a, file=sys.stderr, flush=True)) if rank == 0 else (lambda *a: None)
 
+    # ---- synthetic corpus / queries (SURVEY §8d generator, same bytes on every box) ----
     t0 = time.time()
     L = synth.lib()
     hc = L.fms_corpus_new(n_sent, float(mean_len), synth.VOCAB_TYPES, synth.CORPUS_SEED)
-    hq = L.fms_queries_new(hc, nq, float(mean_len), synth.VOCAB_TYPES, synth.QUERY_SEED + rank)
     c_off, c_tok = synth._take(hc)
-    q_off, q_tok = synth._take(hq)
     vs = L.fms_vocab_size(hc)
-    L.fms_free(hc)
-    L.fms_free(hq)
-    log(f"[bench] generated {n_sent} sentences / {nq} queries in {time.time() - t0:.1f}s")
 
+    def queries(seed, n):
+        hq = L.fms_queries_new(hc, n, float(mean_len), synth.VOCAB_TYPES, seed)
+        off, tok = synth._take(hq)
+        L.fms_free(hq)
+        return off, tok
+
+    # weak: every rank draws its own nq_cfg queries; strong: all ranks draw the SAME nq_cfg queries and take a block
+    w_off, w_tok = queries(synth.QUERY_SEED + rank, nq_cfg)
+    s_off_all, s_tok_all = queries(synth.QUERY_SEED, nq_cfg) if world > 1 else (w_off, w_tok)
+    L.fms_free(hc)
+    s_off, s_tok, _, _ = shard.shard_batch(s_off_all, s_tok_all, rank, world)
+    log(f"[bench] generated {n_sent} sentences / {nq_cfg} queries in {time.time() - t0:.1f}s")
+
+    # ---- index: sorted on the GPU, derived, uploaded (not in the metric) ----
     t0 = time.time()
     ix = fmx.Index.create()
     ix.add_ids(c_off, c_tok, vs)
-    ix.sort(local_rank)  # suffix sort on the GPU
+    ix.sort(local_rank)
     ix.finalize()
     ix.to_device(local_rank)
-    if os.environ.get("FMX_SUB_QUERIES"):
-        ix.set_option("sub_queries", int(os.environ["FMX_SUB_QUERIES"]))
+    ix.set_option("contexts", max(2, args.threads))
+    for opt in ("FMX_SUB_QUERIES", "FMX_HOST_SUB_QUERIES", "FMX_HEAVY_MIN"):
+        if os.environ.get(opt):
+            ix.set_option(opt[4:].lower(), int(os.environ[opt]))
     info = ix.info()
     log(f"[bench] index built+uploaded in {time.time() - t0:.1f}s: {info.n_suffixes} suffixes, "
         f"{info.device_bytes / 1e9:.2f} GB in HBM")
 
     params = fmx.Params(**pkw)
     cap = params.nmatch or 16
-    dev = torch.device("cuda", local_rank)
-    d_off = torch.from_numpy(q_off.astype(np.int32)).to(dev)
-    d_tok = torch.from_numpy(q_tok.astype(np.int32)).to(dev)
-    shard = fmx_import.load().shard
-    # double-buffered result slots; for N > 1 the gather of step i to rank 0 (the path's only collective,
-    # SURVEY §8e) runs on RCCL's stream over xGMI while step i + 1 computes into the other slot
-    rg = shard.RecordGather(nq, cap, dev, dst=0)
-    step_no = [0]
-    max_len = int(np.diff(q_off).max()) if nq else 0
-    stream = torch.cuda.current_stream().cuda_stream
-    total_tokens = int(q_off[-1])
 
-    def step():
-        i = step_no[0]
-        step_no[0] += 1
-        d_out, d_cnt = rg.buffers(i)  # waits (in stream order) for the gather that last used this slot
-        st = ix.match_batch_device(params, nq, d_off.data_ptr(), d_tok.data_ptr(), total_tokens, d_out.data_ptr(),
-                                   d_cnt.data_ptr(), 0, cap, stream=stream, max_len=max_len)
-        rg.launch(i)
-        return st
+    class Workload:
+        """One batch in pinned host memory (+ a device copy for the device-resident measurement)."""
+
+        def __init__(self, q_off, q_tok):
+            self.nq = len(q_off) - 1
+            self.q_off = fmx.pinned_copy(q_off.astype(np.uint32))
+            self.q_tok = fmx.pinned_copy(q_tok.astype(np.uint32))
+            self.total_tokens = int(q_off[-1])
+            self.max_len = int(np.diff(q_off).max()) if self.nq else 0
+            # one result slot per host thread
+            self.out = [(fmx.pinned_empty((max(self.nq, 1), cap), fmx.MATCH_DTYPE), fmx.pinned_empty(max(self.nq, 1), np.uint32),
+                         fmx.pinned_empty(max(self.nq, 1), np.uint32)) for _ in range(max(args.threads, 1))]
+            self.d_off = self.d_tok = None
+
+        def to_device(self):
+            if self.d_off is None:
+                self.d_off = torch.from_numpy(self.q_off.astype(np.int32)).to(dev)
+                self.d_tok = torch.from_numpy(self.q_tok.astype(np.int32)).to(dev)
 
     def sync():
-        rg.wait_all()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    sync()
-    stage_ms = np.zeros(16)
-    launches = np.zeros(16)
-    last = None
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        last = step()
-        stage_ms += np.array(list(last.ms_kernel))
-        launches += np.array(list(last.launches))
-    sync()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def run_host_steps(wl, k_steps, gather=None):
+        """K calls of fmx_match_batch (pinned host buffers in and out) from args.threads host threads.  N > 1: each
+        step's records are also gathered to rank 0 over RCCL (device copies kept by the call)."""
+        stats = []
 
-    # ---- PCIe-inclusive rate through the host-buffer entry point (never `value`) ----
-    host_path = None
-    if rank == 0 and world == 1 and not args.no_host_path:
-        ix.match_batch(params, q_off, q_tok, cap=cap)  # warm the staging buffers
+        def one(i):
+            slot = i % len(wl.out)
+            return ix.match_batch(params, wl.q_off, wl.q_tok, cap=cap, want_stats=True, out=wl.out[slot])[3]
+
+        if gather is None:
+            if args.threads <= 1:
+                for i in range(k_steps):
+                    stats.append(one(i))
+            else:
+                # thread t runs steps t, t + T, ...: its result slot is never written by two calls at once
+                def lane(t):
+                    return [one(i) for i in range(t, k_steps, args.threads)]
+                with cf.ThreadPoolExecutor(args.threads) as pool:
+                    for part in pool.map(lane, range(args.threads)):
+                        stats.extend(part)
+        else:
+            for i in range(k_steps):
+                d_out, d_cnt = gather.buffers(i, host_sync=True)
+                # the records go home over PCIe AND stay in HBM (fmx_match_batch_keep) for the gather over xGMI
+                st = ix.match_batch(params, wl.q_off, wl.q_tok, cap=cap, want_stats=True, out=wl.out[0],
+                                    keep=(d_out.data_ptr(), d_cnt.data_ptr()))[3]
+                gather.launch(i)
+                stats.append(st)
+            gather.wait_all()
+        return stats
+
+    def timed(fn, k_steps):
+        sync()
         t1 = time.perf_counter()
-        _, _, _, hst = ix.match_batch(params, q_off, q_tok, cap=cap, want_stats=True)
-        dt = time.perf_counter() - t1
-        host_path = {"patterns_per_s": round(nq / dt, 1), "ms": round(dt * 1e3, 2), "ms_h2d": round(hst.ms_h2d, 2),
-                     "ms_d2h": round(hst.ms_d2h, 2), "note": "fmx_match_batch with pageable host buffers: H2D + pipeline + D2H"}
+        res = fn(k_steps)
+        sync()
+        el = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, res
 
-    # ---- parity spot check + algorithmic bytes + CPU baseline (rank 0) ----
-    roofline = None
-    cpu_baseline = None
-    parity = None
+    def run_device_steps(wl, k_steps):
+        """The same batch from HBM-resident buffers through the device entry point (no PCIe)."""
+        wl.to_device()
+        d_out = torch.zeros((max(wl.nq, 1), cap, 4), dtype=torch.int32, device=dev)
+        d_cnt = torch.zeros((max(wl.nq, 1),), dtype=torch.int32, device=dev)
+        sts = []
+        for _ in range(k_steps):
+            sts.append(ix.match_batch_device(params, wl.nq, wl.d_off.data_ptr(), wl.d_tok.data_ptr(), wl.total_tokens,
+                                             d_out.data_ptr(), d_cnt.data_ptr(), 0, cap, stream=0, max_len=wl.max_len))
+        return sts, d_out, d_cnt
+
+    weak = Workload(w_off, w_tok)
+    strong = Workload(s_off, s_tok) if world > 1 else weak
+    main_wl, other_wl = (weak, strong) if args.scaling == "weak" else (strong, weak)
+
+    if args.child:  # profiling child of a --pmc pass: device-resident steps, nothing else
+        run_device_steps(main_wl, args.warmup)
+        torch.cuda.synchronize()
+        run_device_steps(main_wl, args.steps)
+        torch.cuda.synchronize()
+        return
+
+    # ---- the metric: PCIe-inclusive steps through fmx_match_batch ----
+    def measure(wl):
+        gather = shard.RecordGather(wl.nq, cap, dev, dst=0) if world > 1 else None
+        run_host_steps(wl, args.warmup, gather)
+        el, sts = timed(lambda k: run_host_steps(wl, k, gather), args.steps)
+        return el, sts
+
+    elapsed, host_stats = measure(main_wl)
+    nq_step_all = main_wl.nq
+    if world > 1:
+        t = torch.tensor([main_wl.nq], dtype=torch.int64, device=dev)
+        dist.all_reduce(t)
+        nq_step_all = int(t.item())
+    value = nq_step_all * args.steps / elapsed
+    scaling_other = None
+    if world > 1:
+        el2, _ = measure(other_wl)
+        t = torch.tensor([other_wl.nq], dtype=torch.int64, device=dev)
+        dist.all_reduce(t)
+        scaling_other = {"scaling": "strong" if args.scaling == "weak" else "weak", "value": round(int(t.item()) * args.steps / el2, 1),
+                         "ms_per_step": round(el2 / args.steps * 1e3, 3), "queries_per_step_all_ranks": int(t.item())}
+
+    # ---- the same batch from HBM (device entry point): stage times for the rooflines ----
+    run_device_steps(main_wl, 1)
+    el_dev, (dev_stats, d_out, d_cnt) = timed(lambda k: run_device_steps(main_wl, k), args.steps)
+    names = fmx.stage_names()
+    stage_ms = np.zeros(16)
+    for st in dev_stats:
+        stage_ms += np.array(list(st.ms_kernel))
+    per_stage = {n: float(stage_ms[i] / max(args.steps, 1)) for i, n in enumerate(names)}
+    last = dev_stats[-1]
+    # per-rank probe GB/s of its own byte model needs the counting variant of the kernel: one untimed step
+    ix.set_option("probe_count", 1)
+    (cst,), _, _ = run_device_steps(main_wl, 1)
+    ix.set_option("probe_count", 0)
+    torch.cuda.synchronize()
+
+    probe_ms, exa_ms = per_stage.get("probe", 0.0), per_stage.get("expand_a", 0.0)
+    # byte models of THIS algorithm, per launch, from the kernels' own counters (DESIGN.md §5):
+    #   k_probe     bytes its loads request (n-gram, qva pair, 16 B table entries, 32 B keys per bisection level, ...)
+    #   expand_a    k_expand_a: 8 B per hit it walks; k_expand_h: 8 B per plane word + 8 B per hit re-tested exactly;
+    #               both: 8 B per hit queued for k_expand_b, 8 B per (query, start) range descriptor
+    b_probe = float(cst.probe_bytes)
+    light_hits = last.n_hits - last.n_heavy_hits
+    b_exa = 8.0 * light_hits + 8.0 * last.plane_words + 8.0 * last.n_heavy_pass + 8.0 * last.n_phase_b + 8.0 * main_wl.total_tokens
+    probe_gbs = b_probe / (probe_ms * 1e-3) / 1e9 if probe_ms > 0 else 0.0
+    exa_gbs = b_exa / (exa_ms * 1e-3) / 1e9 if exa_ms > 0 else 0.0
+    rank_rates = None
+    if world > 1:
+        t = torch.tensor([probe_gbs, exa_gbs, per_stage.get("probe", 0.0), el_dev / args.steps * 1e3], dtype=torch.float64, device=dev)
+        g = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(g, t)
+        rank_rates = [{"rank": r, "probe_model_gbps": round(float(x[0]), 1), "expand_a_model_gbps": round(float(x[1]), 1),
+                       "probe_ms": round(float(x[2]), 4), "device_ms_per_step": round(float(x[3]), 3)} for r, x in enumerate(g)]
+
+    line = None
     if rank == 0:
-        names = fmx.stage_names()
-        per_stage = {n: float(stage_ms[i] / max(args.steps, 1)) for i, n in enumerate(names)}
+        log(f"[bench] PCIe-inclusive: {value / 1e6:.2f} M patterns/s, {elapsed / args.steps * 1e3:.3f} ms/step "
+            f"(pinned={host_stats[-1].pinned}); device-resident: {main_wl.nq * args.steps / el_dev / 1e6:.2f} M patterns/s")
         log(f"[bench] kernel ms/step by stage: { {k: round(v, 3) for k, v in per_stage.items()} }")
-        log(f"[bench] last step: hits {last.n_hits} kept {last.n_kept} candidates {last.n_candidates} dp {last.n_dp} "
-            f"retries {last.n_retries} big {last.n_big} phaseB {last.n_phase_b} max_kept {last.max_kept} heavy {last.n_heavy_hits} heavy_pass {last.n_heavy_pass} "
-            f"wall {last.ms_total:.2f} ms")
+        log(f"[bench] last step: hits {last.n_hits} (bit planes {last.n_heavy_hits}, passed {last.n_heavy_pass}) phaseB {last.n_phase_b} "
+            f"kept {last.n_kept} candidates {last.n_candidates} retries {last.n_retries} big {last.n_big} max_kept {last.max_kept}")
+
+        # ---- HBM traffic of the two kernels, measured now: rocprofv3 --pmc child passes (separate passes) ----
+        traffic = {}
+        if world == 1 and not args.no_pmc:
+            child = ["--config", args.config, "--steps", "2", "--warmup", "1", "--scaling", args.scaling]
+            if args.sentences:
+                child += ["--sentences", str(args.sentences)]
+            if args.queries:
+                child += ["--queries", str(args.queries)]
+            cal = json.load(open(CALIBRATION)) if os.path.exists(CALIBRATION) else {}
+            t1 = time.time()
+            fetch = pmc_pass("FETCH_SIZE", child, log)
+            write = pmc_pass("WRITE_SIZE", child, log) if fetch else None
+            log(f"[bench] pmc child passes: {time.time() - t1:.0f}s")
+            if fetch and write:
+                for kern, pattern in (("fmx::k_probe", "random"), ("fmx::k_expand_a", "stream16"), ("fmx::k_expand_h", "stream8")):
+                    key = next((k for k in fetch if k.replace("void ", "").startswith(kern)), None)
+                    if key is None:
+                        continue
+                    f_kb = np.mean([v for _, v in fetch[key][-2:]])   # the child's two timed dispatches
+                    w_kb = np.mean([v for _, v in write.get(key, [(0, 0.0)])[-2:]])
+                    f_fac = float(cal.get("fetch_factor", {}).get(pattern, 2.0))
+                    w_fac = float(cal.get("write_factor", 1.0))
+                    traffic[kern.split("::")[1]] = {"bytes": int(f_kb * 1024 * f_fac + w_kb * 1024 * w_fac), "fetch_kb_raw": float(f_kb),
+                                                    "write_kb_raw": float(w_kb), "fetch_factor": f_fac, "write_factor": w_fac,
+                                                    "calibrated": bool(cal)}
+
+        def roof(kernel, model_bytes, ms, tr_keys, what):
+            ach = model_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            tr = sum(traffic[k]["bytes"] for k in tr_keys if k in traffic) if all(k in traffic for k in tr_keys) and tr_keys else None
+            return {"kernel": kernel, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": tr,
+                    "traffic_gbps": round(tr / (ms * 1e-3) / 1e9, 1) if tr and ms > 0 else None,
+                    "traffic_frac": round(tr / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if tr and ms > 0 else None,
+                    "algorithmic_bytes_per_launch": int(model_bytes), "kernel_ms": round(ms, 4), "launches_per_step": 1,
+                    "model": what}
+
+        r_probe = roof("k_probe", b_probe, probe_ms, ["k_probe"],
+                       "bytes requested by the kernel's own loads, counted by k_probe<COUNT> on the same batch: seed n-gram, "
+                       "_quickVocabAccess pair, 16 B trigram / 5-gram entries, two 32 B keys per bisection level")
+        r_exa = roof("k_expand_a+k_expand_h", b_exa, exa_ms, ["k_expand_a", "k_expand_h"],
+                     "phase A of the hit walk (two kernels side by side): 8 B per hit walked one by one, 8 B per bit-plane word, "
+                     "8 B per plane survivor re-tested, 8 B per hit queued, 8 B per range descriptor (kernel counters)")
+        r_probe["lines_bytes_per_launch"] = int(cst.probe_lines) * 128  # distinct 128 B lines x 128: what random reads cost the memory system
+        dominant = r_exa if exa_ms >= probe_ms else r_probe
+        other = r_probe if dominant is r_exa else r_exa
+
+        # ---- parity spot check, reference byte model, CPU baseline (the oracle: test infrastructure, outside the timed region) ----
         import oracle_lib
         t1 = time.time()
         o = oracle_lib.OracleIndex()
@@ -170,40 +376,34 @@ def main():
                      ix.array("qva"), ix.array("sfreq"))
         log(f"[bench] oracle index ready in {time.time() - t1:.1f}s")
         oprm = oracle_lib.Params(**pkw)
+        q_off, q_tok = main_wl.q_off, main_wl.q_tok
+        nq = main_wl.nq
+        parity = ref_model = cpu_baseline = None
         nv = min(args.verify, nq)
         if nv:
-            oo, oc, ctr = o.match_batch(oprm, q_off[:nv + 1], q_tok[:int(q_off[nv])], cap,
-                                        nthreads=oracle_lib.effective_cpus(), want_counters=True)
-            d_out, d_cnt = rg.buffers(step_no[0] - 1)  # this rank's records of the last step
+            oo, oc = o.match_batch(oprm, q_off[:nv + 1], q_tok[:int(q_off[nv])], cap, nthreads=oracle_lib.effective_cpus())
+            bad_h = bad_d = 0
+            ho, hc_, _ = main_wl.out[0]
             go = d_out[:nv].cpu().numpy().view(oracle_lib.MATCH_DTYPE).reshape(nv, cap)
             gc = d_cnt[:nv].cpu().numpy().astype(np.uint32)
-            bad = sum(1 for q in range(nv) if oc[q] != gc[q] or oo[q, :oc[q]].tobytes() != go[q, :gc[q]].tobytes())
-            parity = {"checked": int(nv), "mismatches": int(bad)}
+            for q in range(nv):
+                ref = oo[q, :oc[q]].tobytes()
+                bad_h += int(oc[q] != hc_[q] or ref != ho[q, :hc_[q]].tobytes())
+                bad_d += int(oc[q] != gc[q] or ref != go[q, :gc[q]].tobytes())
+            parity = {"checked": int(nv), "mismatches": int(bad_h + bad_d), "paths": "host-buffer and device entry points vs oracle"}
+        nm = min(args.model_queries, nq)
+        if nm:
+            _, _, ctr = o.match_batch(oprm, q_off[:nm + 1], q_tok[:int(q_off[nm])], cap, nthreads=oracle_lib.effective_cpus(),
+                                      want_counters=True)
             d = ctr.as_dict()
-            probe_bytes_per_query = d["probe_bytes"] / max(d["queries"], 1)
-            probe_ms = per_stage.get("probe", 0.0)
-            launches_per_step = launches[names.index("probe")] / max(args.steps, 1)
-            if probe_ms > 0:
-                achieved = probe_bytes_per_query * nq / (probe_ms * 1e-3) / 1e9
-                # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same workload
-                traffic = None
-                tpath = os.path.join(ROOT, "profiles", "r01_c3_probe_traffic.json")
-                if args.config == "C3" and not args.sentences and not args.queries and os.path.exists(tpath):
-                    traffic = json.load(open(tpath)).get("traffic_bytes_per_launch")
-                roofline = {"kernel": "k_probe", "bound": "hbm", "achieved": round(achieved, 2),
-                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                            "traffic": traffic,
-                            "algorithmic_bytes_per_launch": round(probe_bytes_per_query * nq / max(launches_per_step, 1)), "algorithmic_bytes_per_query": round(probe_bytes_per_query, 1),
-                            "kernel_ms_per_step": round(probe_ms, 4), "launches_per_step": launches_per_step,
-                            # the same launch priced on its measured HBM traffic (the north star's >= 0.40 target)
-                            "traffic_gbps": round(traffic * launches_per_step / (probe_ms * 1e-3) / 1e9, 2) if traffic else None,
-                            "traffic_frac": round(traffic * launches_per_step / (probe_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None,
-                            "note": "achieved/frac use the reference algorithm's logical bytes (SURVEY 8d: every compare step of "
-                                    "equal_range from the top of the first-word bucket); the n-gram tables skip most of those "
-                                    "steps, so frac can exceed 1. traffic_* is the PMC-measured HBM traffic of the same launch.",
-                            "stage_ms_per_step": {k: round(v, 4) for k, v in per_stage.items()}}
+            nqc = max(d["queries"], 1)
+            ref_model = {"queries_counted": int(nqc), "B_probe_per_query": round(d["probe_bytes"] / nqc, 1),
+                         "B_reg_per_query": round(d.get("reg_bytes", 0) / nqc, 1), "B_cand_per_query": round(d.get("cand_bytes", 0) / nqc, 1),
+                         "note": "SURVEY §8d's model of the REFERENCE algorithm's logical reads, counted by the oracle; the hash tables and "
+                                 "bit planes skip most of that work, so pricing this build on it gives fractions above 1 "
+                                 f"(probe: {d['probe_bytes'] / nqc * nq / max(probe_ms, 1e-9) / 1e6 / HBM_PEAK_GBS:.2f})"}
         if not args.no_cpu_baseline and world == 1:
-            cores = oracle_lib.effective_cpus()  # cgroup CPU quota, not the 256 hardware threads of the host
+            cores = oracle_lib.effective_cpus()  # cgroup CPU quota, not the hardware threads of the host
             ns = min(nq, max(2000, 64 * cores))
             t1 = time.perf_counter()
             o.match_batch(oprm, q_off[:ns + 1], q_tok[:int(q_off[ns])], cap, nthreads=cores)
@@ -218,19 +418,26 @@ def main():
                                       f"{os.cpu_count()} hardware threads), {dt:.1f}s"}
         o.close()
 
-    if rank == 0:
-        value = nq * world * args.steps / elapsed
         line = {
             "metric": "query patterns/sec @ fuzzy=0.7, 5M-sentence .fmi; 1/2/4/8 GPU + CPU ref",
             "value": round(value, 1), "unit": "patterns/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u32+f32", "data": "synthetic",
-            "config": {"workload": f"{args.config}: {n_sent}-sentence synthetic corpus (mean {mean_len} tok, "
-                                   f"near-duplicate families), {nq} queries per GPU per step, "
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "u32+f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {n_sent}-sentence synthetic corpus (mean {mean_len} tok, near-duplicate families), "
+                                   f"{nq_cfg} queries per {'GPU' if args.scaling == 'weak' else 'job'} per step, "
                                    + " ".join(f"{k}={v}" for k, v in pkw.items()),
-                       "queries_per_gpu": nq, "sentences": n_sent, "index_bytes_hbm": int(info.device_bytes),
+                       "queries_per_step_all_ranks": nq_step_all, "sentences": n_sent, "index_bytes_hbm": int(info.device_bytes),
+                       "timed_path": "fmx_match_batch: pinned host buffers in, pinned host buffers out (H2D + kernels + D2H), "
+                                     f"{args.threads} host threads" + (", + RCCL gather of the records to rank 0" if world > 1 else ""),
                        "parallelism": f"queries sharded over {world} GPU(s), index replicated"},
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity, "host_buffers": host_path,
+            "roofline": dominant, "roofline_other": [other], "reference_byte_model": ref_model,
+            "device_resident": {"value": round(nq_step_all * args.steps / el_dev, 1),
+                                "ms_per_step": round(el_dev / args.steps * 1e3, 3),
+                                "stage_ms_per_step": {k: round(v, 4) for k, v in per_stage.items()},
+                                "note": "same batch, buffers already in HBM (fmx_match_batch_device); stage times are HIP events on the "
+                                        "launch stream"},
+            "scaling_other": scaling_other, "per_rank": rank_rates,
+            "cpu_baseline": cpu_baseline, "parity": parity,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

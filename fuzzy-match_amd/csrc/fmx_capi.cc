@@ -283,6 +283,7 @@ static void copy_stats(const Stats& s, fmx_stats* o) {
   o->n_hits = s.n_hits; o->n_kept = s.n_kept; o->n_candidates = s.n_candidates; o->n_dp = s.n_dp;
   o->n_retries = s.n_retries; o->n_big = s.n_big; o->n_phase_b = s.n_phase_b; o->max_kept = s.max_kept;
   o->n_heavy_hits = s.n_heavy_hits; o->n_heavy_pass = s.n_heavy_pass; o->pinned = s.pinned;
+  o->plane_words = s.plane_words; o->probe_bytes = s.probe_bytes; o->probe_lines = s.probe_lines;
 }
 
 // match(const Tokens&) builds `real` from the pattern itself (src/fuzzy_match.cc:428): the real token of position
@@ -297,10 +298,11 @@ static void real_from_forms(const fmx_index* ix, const uint32_t* wids, uint64_t 
 // One batch over every replica of the index: contiguous query blocks, one per device, run concurrently; each
 // block's records land directly in the caller's buffers (index replicated, no data-path exchange).
 static void match_on_devices(fmx_index* ix, const Params& prm, const HostBatchView& v, fmx_match* out, uint32_t* out_count,
-                             uint32_t* out_total, uint32_t cap, Stats* st) {
+                             uint32_t* out_total, uint32_t cap, Stats* st, fmx_match* d_keep = nullptr,
+                             uint32_t* d_keep_count = nullptr) {
   const size_t nd = ix->devs.size();
-  if (nd == 1 || v.nq < 2 * nd) {
-    ix->devs[0]->match_host(ix->host, prm, v, (Rec*)out, out_count, out_total, cap, st);
+  if (nd == 1 || v.nq < 2 * nd || d_keep) {
+    ix->devs[0]->match_host(ix->host, prm, v, (Rec*)out, out_count, out_total, cap, st, (Rec*)d_keep, d_keep_count);
     return;
   }
   const auto t0 = std::chrono::steady_clock::now();
@@ -331,6 +333,7 @@ static void match_on_devices(fmx_index* ix, const Params& prm, const HostBatchVi
       st->n_hits += s.n_hits; st->n_kept += s.n_kept; st->n_candidates += s.n_candidates; st->n_dp += s.n_dp;
       st->n_retries += s.n_retries; st->n_big += s.n_big; st->n_phase_b += s.n_phase_b; st->max_kept = std::max(st->max_kept, s.max_kept);
       st->n_heavy_hits += s.n_heavy_hits; st->n_heavy_pass += s.n_heavy_pass; st->pinned = s.pinned;
+      st->plane_words += s.plane_words; st->probe_bytes += s.probe_bytes; st->probe_lines += s.probe_lines;
     }
     st->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   }
@@ -338,6 +341,12 @@ static void match_on_devices(fmx_index* ix, const Params& prm, const HostBatchVi
 
 int fmx_match_batch(fmx_index* ix, const fmx_params* params, const fmx_batch* hb, fmx_match* out,
                     uint32_t* out_count, uint32_t* out_total, uint32_t cap, fmx_stats* stats) {
+  return fmx_match_batch_keep(ix, params, hb, out, out_count, out_total, cap, nullptr, nullptr, stats);
+}
+
+int fmx_match_batch_keep(fmx_index* ix, const fmx_params* params, const fmx_batch* hb, fmx_match* out,
+                         uint32_t* out_count, uint32_t* out_total, uint32_t cap, fmx_match* d_keep,
+                         uint32_t* d_keep_count, fmx_stats* stats) {
   if (!ix || !params || !hb || !out || !out_count) return fail(FMX_E_INVALID, "null argument");
   if (hb->nq && (!hb->q_off || (hb->q_off[hb->nq] && !hb->q_tok))) return fail(FMX_E_INVALID, "null batch arrays");
   if (cap == 0) return fail(FMX_E_INVALID, "cap must be > 0");
@@ -355,7 +364,7 @@ int fmx_match_batch(fmx_index* ix, const fmx_params* params, const fmx_batch* hb
       v.q_real = forms_real.data();
     }
     Stats st;
-    match_on_devices(ix, make_params(ix, params), v, out, out_count, out_total, cap, &st);
+    match_on_devices(ix, make_params(ix, params), v, out, out_count, out_total, cap, &st, d_keep, d_keep_count);
     copy_stats(st, stats);
     return (int)FMX_OK;
   });
@@ -550,6 +559,7 @@ int fmx_set_option(fmx_index* ix, const char* name, int64_t value) {
     else if (n == "initial_segment") d->set_initial_segment((uint64_t)std::max<int64_t>(value, 1024));
     else if (n == "heavy_min") d->set_heavy_min((uint32_t)std::max<int64_t>(value, 0));
     else if (n == "contexts") d->set_contexts((uint32_t)std::max<int64_t>(value, 1));
+    else if (n == "probe_count") d->set_probe_count(value != 0);
     else return fail(FMX_E_INVALID, "unknown option " + n);
   }
   return FMX_OK;

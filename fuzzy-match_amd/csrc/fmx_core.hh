@@ -128,36 +128,48 @@ FMX_HD int start_by_from(const uint32_t* __restrict__ tok, SufRec r, const uint3
   return 0;
 }
 
+// Measurement only (option "probe_count"): bytes and 128-byte lines the probe's loads request, per lane.  It is the
+// byte model of THIS algorithm, next to SURVEY §8d's model of the reference's equal_range steps.
+struct ProbeTally {
+  uint32_t bytes;
+  uint32_t lines;
+};
+FMX_HD void tally_add(ProbeTally* t, uint32_t bytes, uint32_t lines = 1) {
+  if (t) { t->bytes += bytes; t->lines += lines; }
+}
+
 // Half-open range of suffixes starting with ngram[0..m) — the value SuffixArray::equal_range
 // (src/suffix_array.cc:105-212) converges to, computed as a plain lower bound followed by a
 // galloping upper bound (ranges of long n-grams are short).  m >= 1.
 FMX_HD void mgram_range(const SufRec* __restrict__ suf, const uint32_t* __restrict__ tok,
                         const uint32_t* __restrict__ qva, uint32_t n_qva,
-                        const uint32_t* __restrict__ ngram, uint32_t m, uint32_t& out_lo, uint32_t& out_hi) {
+                        const uint32_t* __restrict__ ngram, uint32_t m, uint32_t& out_lo, uint32_t& out_hi,
+                        ProbeTally* tally = nullptr) {
   out_lo = out_hi = 0;
   const uint32_t w0 = ngram[0];
   if (w0 + 1 >= n_qva) return;
   uint32_t lo = qva[w0], hi = qva[w0 + 1];
+  tally_add(tally, 8);
   if (m == 1 || lo >= hi) { out_lo = lo; out_hi = hi; return; }
   // lower bound: first i with start_by >= 0
   uint32_t a = lo, b = hi;
   while (a < b) {
     const uint32_t mid = a + ((b - a) >> 1);
-    if (start_by_from(tok, suf[mid], ngram, 1, m) < 0) a = mid + 1; else b = mid;
+    if ((tally_add(tally, 8 + 4 * (m - 1), 2), start_by_from(tok, suf[mid], ngram, 1, m)) < 0) a = mid + 1; else b = mid;
   }
   const uint32_t first = a;
-  if (first >= hi || start_by_from(tok, suf[first], ngram, 1, m) != 0) { out_lo = out_hi = first; return; }
+  if (first >= hi || (tally_add(tally, 8 + 4 * (m - 1), 2), start_by_from(tok, suf[first], ngram, 1, m)) != 0) { out_lo = out_hi = first; return; }
   // upper bound: gallop from first, then bisect; invariant start_by(a) == 0, start_by(b) > 0 or b == hi
   uint32_t step = 1;
   a = first;
   b = hi;
   while ((unsigned long long)a + step < hi) {
-    if (start_by_from(tok, suf[a + step], ngram, 1, m) == 0) { a += step; step <<= 1; }
+    if ((tally_add(tally, 8 + 4 * (m - 1), 2), start_by_from(tok, suf[a + step], ngram, 1, m)) == 0) { a += step; step <<= 1; }
     else { b = a + step; break; }
   }
   while (b - a > 1) {
     const uint32_t mid = a + ((b - a) >> 1);
-    if (start_by_from(tok, suf[mid], ngram, 1, m) == 0) a = mid; else b = mid;
+    if ((tally_add(tally, 8 + 4 * (m - 1), 2), start_by_from(tok, suf[mid], ngram, 1, m)) == 0) a = mid; else b = mid;
   }
   out_lo = first;
   out_hi = b;
@@ -194,31 +206,33 @@ FMX_HD int start_by_keyed(const SufKey* __restrict__ key, const SufRec* __restri
 // mgram_range over the keyed layout; same result.
 FMX_HD void mgram_range_keyed(const SufKey* __restrict__ key, const SufRec* __restrict__ suf,
                               const uint32_t* __restrict__ tok, const uint32_t* __restrict__ qva, uint32_t n_qva,
-                              const uint32_t* __restrict__ ngram, uint32_t m, uint32_t& out_lo, uint32_t& out_hi) {
+                              const uint32_t* __restrict__ ngram, uint32_t m, uint32_t& out_lo, uint32_t& out_hi,
+                              ProbeTally* tally = nullptr) {
   for (uint32_t k = 1; k < m && k <= kKeyTokens; k++)
-    if (ngram[k] == 0) { mgram_range(suf, tok, qva, n_qva, ngram, m, out_lo, out_hi); return; }
+    if (ngram[k] == 0) { mgram_range(suf, tok, qva, n_qva, ngram, m, out_lo, out_hi, tally); return; }
   out_lo = out_hi = 0;
   const uint32_t w0 = ngram[0];
   if (w0 + 1 >= n_qva) return;
   uint32_t lo = qva[w0], hi = qva[w0 + 1];
+  tally_add(tally, 8);
   if (m == 1 || lo >= hi) { out_lo = lo; out_hi = hi; return; }
   uint32_t a = lo, b = hi;
   while (a < b) {
     const uint32_t mid = a + ((b - a) >> 1);
-    if (start_by_keyed(key, suf, tok, mid, ngram, m) < 0) a = mid + 1; else b = mid;
+    if ((tally_add(tally, 32), start_by_keyed(key, suf, tok, mid, ngram, m)) < 0) a = mid + 1; else b = mid;
   }
   const uint32_t first = a;
-  if (first >= hi || start_by_keyed(key, suf, tok, first, ngram, m) != 0) { out_lo = out_hi = first; return; }
+  if (first >= hi || (tally_add(tally, 32), start_by_keyed(key, suf, tok, first, ngram, m)) != 0) { out_lo = out_hi = first; return; }
   uint32_t step = 1;
   a = first;
   b = hi;
   while ((unsigned long long)a + step < hi) {
-    if (start_by_keyed(key, suf, tok, a + step, ngram, m) == 0) { a += step; step <<= 1; }
+    if ((tally_add(tally, 32), start_by_keyed(key, suf, tok, a + step, ngram, m)) == 0) { a += step; step <<= 1; }
     else { b = a + step; break; }
   }
   while (b - a > 1) {
     const uint32_t mid = a + ((b - a) >> 1);
-    if (start_by_keyed(key, suf, tok, mid, ngram, m) == 0) a = mid; else b = mid;
+    if ((tally_add(tally, 32), start_by_keyed(key, suf, tok, mid, ngram, m)) == 0) a = mid; else b = mid;
   }
   out_lo = first;
   out_hi = b;
@@ -298,14 +312,15 @@ FMX_HD int key_cmp(const SufKey& kk, const uint32_t (&ng)[kKeyTokens + 1], uint3
 FMX_HD void mgram_range_hashed(const GramTables& gt, const SufKey* __restrict__ key,
                                const SufRec* __restrict__ suf, const uint32_t* __restrict__ tok,
                                const uint32_t* __restrict__ qva, uint32_t n_qva, const uint32_t* __restrict__ ngram,
-                               uint32_t m, uint32_t& out_lo, uint32_t& out_hi) {
+                               uint32_t m, uint32_t& out_lo, uint32_t& out_hi, ProbeTally* tally = nullptr) {
   uint32_t ng[kKeyTokens + 1];
+  tally_add(tally, 4 * (m < kKeyTokens + 1 ? m : kKeyTokens + 1));  // the seed n-gram itself
 #pragma unroll
   for (uint32_t k = 0; k <= kKeyTokens; k++) ng[k] = k < m ? ngram[k] : 0u;
   bool usable = gt.g3 != nullptr && m >= 3 && n_qva >= 2;
 #pragma unroll
   for (uint32_t k = 1; k <= kKeyTokens; k++) usable = usable && (k >= m || ng[k] != 0);
-  if (!usable) { mgram_range_keyed(key, suf, tok, qva, n_qva, ngram, m, out_lo, out_hi); return; }
+  if (!usable) { mgram_range_keyed(key, suf, tok, qva, n_qva, ngram, m, out_lo, out_hi, tally); return; }
   out_lo = out_hi = 0;
   const uint32_t w0 = ng[0];
   const bool w_ok = w0 + 1 < n_qva;
@@ -313,6 +328,7 @@ FMX_HD void mgram_range_hashed(const GramTables& gt, const SufKey* __restrict__ 
   uint32_t slot = gram_hash(w0, ng[1], ng[2]) & gt.mask3;
   GramEntry e = gt.g3[slot];  // requested together with the bucket bounds
   const uint32_t blo = qva[wi], bhi = qva[wi + 1];
+  tally_add(tally, 16); tally_add(tally, 8);
   if (!w_ok || blo >= bhi) return;
   uint32_t lo, hi;
   for (;;) {
@@ -320,6 +336,7 @@ FMX_HD void mgram_range_hashed(const GramTables& gt, const SufKey* __restrict__ 
     if (e.w1 == ng[1] && e.w2 == ng[2] && e.lo >= blo && e.lo < bhi) { lo = e.lo; hi = e.lo + e.cnt; break; }
     slot = (slot + 1) & gt.mask3;
     e = gt.g3[slot];
+    tally_add(tally, 16, 0);  // linear probing: the next slot is almost always in the same line
   }
   if (m == 3) { out_lo = lo; out_hi = hi; return; }
   uint32_t from = 3;
@@ -327,6 +344,7 @@ FMX_HD void mgram_range_hashed(const GramTables& gt, const SufKey* __restrict__ 
     slot = gram_hash(lo, ng[3], ng[4]) & gt.mask5;
     for (;;) {
       const GramEntry e5 = gt.g5[slot];
+      tally_add(tally, 16);
       if (e5.lo == kGramEmpty) return;  // no suffix of this trigram continues with (w3, w4)
       if (e5.w1 == ng[3] && e5.w2 == ng[4] && e5.lo >= lo && e5.lo < hi) { lo = e5.lo; hi = e5.lo + e5.cnt; break; }
       slot = (slot + 1) & gt.mask5;
@@ -345,14 +363,15 @@ FMX_HD void mgram_range_hashed(const GramTables& gt, const SufKey* __restrict__ 
     if (!act2) m2 = m1;
     const SufKey k1 = key[m1];
     const SufKey k2 = key[m2];
+    tally_add(tally, 32); if (m2 != m1) tally_add(tally, 32);
     SufRec r1, r2;
     r1.off = 0; r1.rem = 0; r1.slen = 0; r2 = r1;
-    if (deep) { r1 = suf[m1]; r2 = suf[m2]; }  // requested with the keys: a tie costs one more level, not two
+    if (deep) { r1 = suf[m1]; r2 = suf[m2]; tally_add(tally, 8); if (m2 != m1) tally_add(tally, 8); }  // requested with the keys: a tie costs one more level, not two
     int c1 = key_cmp(k1, ng, from, lim);
     int c2 = key_cmp(k2, ng, from, lim);
     if (deep) {
-      if (c1 == 0) c1 = start_by_from(tok, r1, ngram, kKeyTokens + 1, m);
-      if (c2 == 0) c2 = m2 == m1 ? c1 : start_by_from(tok, r2, ngram, kKeyTokens + 1, m);
+      if (c1 == 0) { c1 = start_by_from(tok, r1, ngram, kKeyTokens + 1, m); tally_add(tally, 4 * (m - kKeyTokens - 1)); }
+      if (c2 == 0) { if (m2 != m1) tally_add(tally, 4 * (m - kKeyTokens - 1)); c2 = m2 == m1 ? c1 : start_by_from(tok, r2, ngram, kKeyTokens + 1, m); }
     }
     if (act1) { if (c1 < 0) a1 = m1 + 1; else b1 = m1; }
     if (act2) { if (c2 <= 0) a2 = m2 + 1; else b2 = m2; }

@@ -16,7 +16,7 @@ struct UnsupportedError : std::runtime_error {  // a documented limit of this bu
   using std::runtime_error::runtime_error;
 };
 
-constexpr int kNumStages = 9;
+constexpr int kNumStages = 10;
 const char* stage_name(int s);
 
 struct Stats {
@@ -25,6 +25,7 @@ struct Stats {
   uint64_t launches[16] = {0};
   uint64_t n_hits = 0, n_kept = 0, n_candidates = 0, n_dp = 0, n_retries = 0, n_big = 0, n_phase_b = 0, max_kept = 0;
   uint64_t n_heavy_hits = 0, n_heavy_pass = 0, pinned = 0;
+  uint64_t plane_words = 0, probe_bytes = 0, probe_lines = 0;
 };
 
 struct Rec;  // == fmx_match, defined in fmx_kernels.hip.hh
@@ -66,6 +67,7 @@ class DeviceIndex {
   void     set_host_sub_queries(uint32_t n);
   void     set_initial_segment(uint64_t n);
   void     set_heavy_min(uint32_t n);   // ranges at least this long use the bit-plane kernel (0 = never)
+  void     set_probe_count(bool on);    // measurement: k_probe also counts the bytes / 128-byte lines it requests
   void     set_contexts(uint32_t n);    // concurrent calls served at once (each owns a workspace)
 
   // every pointer in HBM of device(); sub_tok_bounds = q_off at each sub-batch boundary (+ q_off[nq])
@@ -73,8 +75,9 @@ class DeviceIndex {
                     uint32_t* d_out_count, uint32_t* d_out_total, uint32_t cap, void* stream,
                     const std::vector<uint32_t>& sub_tok_bounds, Stats* st);
   // host buffers: H2D, match_device, D2H
+  // d_keep / d_keep_count (optional, in the HBM of device()): the records are also left there
   void match_host(const HostIndex& h, const Params& prm, const HostBatchView& b, Rec* out, uint32_t* out_count,
-                  uint32_t* out_total, uint32_t cap, Stats* st);
+                  uint32_t* out_total, uint32_t cap, Stats* st, Rec* d_keep = nullptr, uint32_t* d_keep_count = nullptr);
   // q_off values at the sub-batch boundaries of a device-resident batch, and its longest pattern
   std::vector<uint32_t> sub_bounds_from_device(const uint32_t* d_q_off, uint64_t nq, uint32_t* p_max, void* stream);
 

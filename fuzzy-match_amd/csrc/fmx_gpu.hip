@@ -176,6 +176,7 @@ struct DeviceIndex::Impl {
   uint64_t init_seg = 1ull << 24;
   uint32_t heavy_min = kHeavyMinDefault; // suffix ranges at least this long go through the bit-plane kernel (0 = never)
   uint32_t max_ctx = 2;
+  bool     probe_count = false;
   // context pool
   std::mutex              pool_mu;
   std::condition_variable pool_cv;
@@ -233,6 +234,7 @@ void     DeviceIndex::set_sub_queries(uint32_t n) { impl_->sub_queries = std::ma
 void     DeviceIndex::set_host_sub_queries(uint32_t n) { impl_->host_sub_queries = std::max<uint32_t>(n, 1); }
 void     DeviceIndex::set_initial_segment(uint64_t n) { impl_->init_seg = std::max<uint64_t>(n, 1024); }
 void     DeviceIndex::set_heavy_min(uint32_t n) { impl_->heavy_min = n; }
+void     DeviceIndex::set_probe_count(bool on) { impl_->probe_count = on; }
 void     DeviceIndex::set_contexts(uint32_t n) {
   std::lock_guard<std::mutex> lk(impl_->pool_mu);
   impl_->max_ctx = std::max<uint32_t>(std::max<uint32_t>(n, 1), (uint32_t)impl_->all.size());
@@ -335,7 +337,7 @@ static DevWork work_view(Ctx& c) {
 }
 
 const char* stage_name(int s) {
-  static const char* names[kNumStages] = {"setup", "probe", "scan", "expand", "cand", "cand_big", "cand_scan", "dp", "finish"};
+  static const char* names[kNumStages] = {"setup", "probe", "scan", "expand_a", "expand_b", "cand", "cand_big", "cand_scan", "dp", "finish"};
   return (s >= 0 && s < kNumStages) ? names[s] : "";
 }
 
@@ -369,7 +371,7 @@ static void run_passes(DeviceIndex::Impl& m, Ctx& c, const Params& prm_in, const
     if (hooks && hooks->before) hooks->before(sb);
     for (int attempt = 0;; attempt++) {
       ensure_ws(c, b.nq, std::max<uint32_t>(b.nt, 1), want_seg);
-      c.cmin_tab.ensure((uint64_t)(p_max + 1) * 256);
+      c.cmin_tab.ensure((uint64_t)(p_max + 1) * kCminRow);
       DevWork w = work_view(c);
       const uint32_t item_cap = (uint32_t)std::min<uint64_t>(c.items.cap, 0xffffffffull);
       const uint32_t item_h_cap = (uint32_t)std::min<uint64_t>(c.items_h.cap, 0xffffffffull);
@@ -393,8 +395,12 @@ static void run_passes(DeviceIndex::Impl& m, Ctx& c, const Params& prm_in, const
         hipLaunchKernelGGL(k_prank, dim3((b.nq + per_block - 1) / per_block), dim3(kRankThreads), 0, stream, b, w);
       }
       tick(); tick();
-      if (b.nt)
-        hipLaunchKernelGGL(k_probe, dim3((b.nt + 63) / 64), dim3(64), 0, stream, m.d, b, w, heavy_min, c.items_h.p, item_h_cap);
+      if (b.nt) {
+        if (m.probe_count)  // measurement runs only: the same kernel, also counting the bytes / lines it requests
+          hipLaunchKernelGGL(k_probe<true>, dim3((b.nt + 63) / 64), dim3(64), 0, stream, m.d, b, w, heavy_min, c.items_h.p, item_h_cap);
+        else
+          hipLaunchKernelGGL(k_probe<false>, dim3((b.nt + 63) / 64), dim3(64), 0, stream, m.d, b, w, heavy_min, c.items_h.p, item_h_cap);
+      }
       tick(); tick();
       {
         hipLaunchKernelGGL(k_caps, dim3((b.nq + 1 + 255) / 256), dim3(256), 0, stream, b, w, c.items.p, item_cap, c.s_max);
@@ -421,6 +427,7 @@ static void run_passes(DeviceIndex::Impl& m, Ctx& c, const Params& prm_in, const
         hipLaunchKernelGGL(k_expand_a, dim3(b.nq + kExpandExtraGrid), dim3(kWave), 0, stream, m.d, b, w, prm,
                            (const WorkItem*)c.items.p, item_cap, use_sig);
         if (heavy_min != 0xffffffffu) join();
+        tick(); tick();  // "expand_a" = k_cmin + k_expand_a with k_expand_h beside it; "expand_b" = the token work
         hipLaunchKernelGGL(k_caps_b, dim3((b.nq + 255) / 256), dim3(256), 0, stream, b, w, c.items_b.p, item_cap);
         const size_t lds = (size_t)p_max * 4;
         if (lds > 64 * 1024) throw UnsupportedError("patterns too long for the expand kernel's LDS staging");
@@ -588,7 +595,8 @@ static void run_passes(DeviceIndex::Impl& m, Ctx& c, const Params& prm_in, const
       if (st) {
         st->n_hits += ctr[0]; st->n_kept += ctr[1]; st->n_candidates += ctr[2]; st->n_dp += ctr[3];
         st->n_big += ctr[7]; st->n_phase_b += ctr[8]; st->max_kept = std::max<uint64_t>(st->max_kept, ctr[9]);
-        st->n_heavy_hits += ctr[16]; st->n_heavy_pass += ctr[17];
+        st->n_heavy_hits += ctr[16]; st->n_heavy_pass += ctr[17]; st->plane_words += ctr[18];
+        st->probe_bytes += ctr[19]; st->probe_lines += ctr[20];
       }
       break;
     }
@@ -628,7 +636,8 @@ __global__ void k_rebase(uint32_t* off, uint32_t n, uint32_t base) {
 // at the same time.  With pinned buffers (fmx_host_alloc) the copies are truly asynchronous; pageable buffers
 // still work (the runtime stages them).
 void DeviceIndex::match_host(const HostIndex& h, const Params& prm, const HostBatchView& hb, Rec* out,
-                             uint32_t* out_count, uint32_t* out_total, uint32_t cap, Stats* st) {
+                             uint32_t* out_count, uint32_t* out_total, uint32_t cap, Stats* st, Rec* d_keep,
+                             uint32_t* d_keep_count) {
   Impl& m = *impl_;
   if (m.device < 0) throw GpuError("index is not on a device");
   HIP_TRY(hipSetDevice(m.device));
@@ -692,6 +701,10 @@ void DeviceIndex::match_host(const HostIndex& h, const Params& prm, const HostBa
     HIP_TRY(hipMemcpyAsync(out + q0 * cap, c.d_out.p + q0 * cap, n * cap * sizeof(Rec), hipMemcpyDeviceToHost, c.d2h));
     HIP_TRY(hipMemcpyAsync(out_count + q0, c.d_cnt.p + q0, n * 4, hipMemcpyDeviceToHost, c.d2h));
     if (out_total) HIP_TRY(hipMemcpyAsync(out_total + q0, c.d_tot.p + q0, n * 4, hipMemcpyDeviceToHost, c.d2h));
+    if (d_keep) {  // a device-resident copy for a collective that follows (the multi-process RCCL gather)
+      HIP_TRY(hipMemcpyAsync(d_keep + q0 * cap, c.d_out.p + q0 * cap, n * cap * sizeof(Rec), hipMemcpyDeviceToDevice, c.d2h));
+      if (d_keep_count) HIP_TRY(hipMemcpyAsync(d_keep_count + q0, c.d_cnt.p + q0, n * 4, hipMemcpyDeviceToDevice, c.d2h));
+    }
     ms_d2h += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
   };
   run_passes(m, c, prm, bv, c.d_out.p, c.d_cnt.p, c.d_tot.p, cap, c.stream, bounds, sub, st, &hooks);

@@ -34,9 +34,10 @@ struct DevIndex {
   uint32_t        n_sent;
   uint32_t        max_slen;
   uint64_t        n_suf;
-  // Signature bit planes (built on the device at upload): planes[k * n_blk + blk], bit i = bucket k of the signature
-  // of suffix 64 * blk + i; row kSigBits = "stored sentence length is clamped (>= 255)".  Plane-major, so a wave that
-  // walks 64 consecutive blocks reads 512 contiguous bytes per bucket and only the buckets its pattern uses.
+  // Bit planes of suf_sig (built on the device at upload): planes[k * n_blk + blk], bit i = bit k of the packed word of
+  // suffix 64 * blk + i — rows 0..55 the signature buckets, rows 56..63 the stored (clamped) sentence length.
+  // Plane-major, so a wave that walks 64 consecutive blocks reads 512 contiguous bytes per row and only the rows its
+  // pattern uses.
   const unsigned long long* planes;
   uint64_t        n_blk;
 };
@@ -86,6 +87,7 @@ struct DevWork {
                                  // [13]=queries queued for k_cand_mid [14]=queries queued for the large k_finish
                                  // [15]=work items of k_expand_h [16]=hits walked through the bit planes
                                  // [17]=of those, hits that passed the plane test (re-tested exactly)
+                                 // [18]=8-byte plane words read by k_expand_h [19],[20]=bytes / lines requested by k_probe<true>
 };
 constexpr int kNumCounters = 24;
 
@@ -145,7 +147,7 @@ struct HeavyItem {
   uint32_t cnt;
   uint32_t chunk;
 };
-constexpr uint32_t kPlaneRows = kSigBits + 1;   // 56 signature buckets + the "stored length is clamped" mask
+constexpr uint32_t kPlaneRows = 64;             // bit planes of the packed word: 56 signature buckets + 8 bits of the stored length
 constexpr uint32_t kPlaneMaxP = 63;             // six-level bit-sliced counters: patterns of up to 63 tokens
 constexpr uint32_t kHeavyMinDefault = 1024;     // ranges at least this long stream through the bit planes
 constexpr uint32_t kHeavyChunkBlocks = 256;     // blocks of 64 suffixes per k_expand_h work item (16384 hits)
@@ -163,6 +165,8 @@ __device__ __forceinline__ unsigned long long seg_scan_u64(unsigned long long v,
   return v;
 }
 
+// COUNT (measurement runs): also tallies the bytes / lines the lane's loads request into counters[19], [20].
+template <bool COUNT>
 __global__ void __launch_bounds__(64) k_probe(DevIndex ix, DevBatch b, DevWork w, uint32_t heavy_min, HeavyItem* items_h,
                                               uint32_t item_h_cap) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -173,13 +177,23 @@ __global__ void __launch_bounds__(64) k_probe(DevIndex ix, DevBatch b, DevWork w
   const uint32_t p = b.q_off[b.q_begin + q + 1] - b.t_begin - o0;
   const uint32_t it = t - o0;
   uint32_t lo = 0, hi = 0;
+  ProbeTally tally;
+  tally.bytes = 16 + 12;  // t_q, q_m, two offsets; t_lo / t_cnt written, the hit totals
+  tally.lines = 0;
   if (msl != kNoMatchLen) {
     const uint32_t m = seed_len(p, msl);
     // register_suffix_range_match ignores match_length < _min_seq_len (src/ngram_matches.cc:65-66);
     // with p == 1 the only registered length is 1.
     const bool reachable = (p == 1) ? (msl <= 1) : true;
     if (reachable && it + m <= p)
-      mgram_range_hashed(ix.gram, ix.suf_key, ix.suf, ix.tok, ix.qva, ix.n_qva, b.q_tok + b.t_begin + t, m, lo, hi);
+      mgram_range_hashed(ix.gram, ix.suf_key, ix.suf, ix.tok, ix.qva, ix.n_qva, b.q_tok + b.t_begin + t, m, lo, hi,
+                         COUNT ? &tally : nullptr);
+  }
+  if (COUNT) {
+    unsigned long long tb = tally.bytes, tl = tally.lines;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { tb += __shfl_xor(tb, d, 64); tl += __shfl_xor(tl, d, 64); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&w.counters[19], tb); atomicAdd(&w.counters[20], tl); }
   }
   const uint32_t cnt = hi - lo;
   // Long ranges (a repeated phrase: 0.1 % of the ranges hold most of the hits) are not walked hit by hit: they become
@@ -212,15 +226,13 @@ __global__ void __launch_bounds__(kWave) k_build_planes(const unsigned long long
   const uint32_t lane = threadIdx.x & 63;
   const unsigned long long i = blk * 64 + lane;
   const unsigned long long pk = i < n_suf ? suf_sig[i] : 0ull;
-  unsigned long long mine = 0;
+  unsigned long long mine = 0;  // 64 x 64 bit transpose of the block: row k = bit k of the 64 packed words
 #pragma unroll
-  for (uint32_t k = 0; k < kSigBits; k++) {
+  for (uint32_t k = 0; k < 64; k++) {
     const unsigned long long m = __ballot((pk >> k) & 1ull);
     if (lane == k) mine = m;
   }
-  const unsigned long long cl = __ballot(i < n_suf && sig_slen(pk) == kSigLenClamp);
-  if (lane == kSigBits) mine = cl;
-  if (lane < kPlaneRows) planes[(unsigned long long)lane * n_blk + blk] = mine;
+  planes[(unsigned long long)lane * n_blk + blk] = mine;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -364,6 +376,8 @@ __device__ __forceinline__ uint32_t cover_lds(const uint32_t* __restrict__ sent,
 }
 
 constexpr uint32_t kCminTab = 256;    // one entry per stored sentence length (8 bits, the last = "255 or longer")
+constexpr uint32_t kLenClasses = 8;   // length classes of the bit-sliced test (k_expand_h)
+constexpr uint32_t kCminRow = kCminTab + 32;  // table row: 256 thresholds, then kLenClasses x {first, last, threshold} and the class count
 constexpr uint32_t kMaxPlanes = 8;    // bit planes of the per-bucket position counts (counts < 256)
 
 // Per-work-item hash set of the pattern's distinct words (p <= 64): slot -> distinct index, and the number
@@ -449,11 +463,30 @@ struct __attribute__((aligned(8))) SigPair {  // two consecutive suf_sig words: 
 // theoretical_rejection_cover.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_cmin(uint32_t max_slen, Params prm, int use_sig, uint16_t* tab) {
+  __shared__ uint16_t s_c[kCminTab];
   const uint32_t p = blockIdx.x, sl = threadIdx.x;
   uint32_t c = 0xffffu;
   if (sl == kSigLenClamp) c = max_slen >= kSigLenClamp ? 0u : 0xffffu;
   else if (sl <= max_slen && !reject_len(p, sl, prm)) c = use_sig ? cover_threshold(p, sl, prm) : kNeedExact;
-  tab[(size_t)p * 256 + sl] = (uint16_t)c;
+  uint16_t* row = tab + (size_t)p * kCminRow;
+  row[sl] = (uint16_t)c;
+  s_c[sl] = (uint16_t)c;
+  __syncthreads();
+  // Length classes for the bit-sliced test of k_expand_h: up to kLenClasses runs of stored lengths [first, last] with
+  // one threshold each (the smallest of the run); lengths the table rejects are in no class.  Runs of equal
+  // thresholds are exact; if there are more than kLenClasses of them the last class absorbs the rest.
+  if (threadIdx.x == 0) {
+    uint32_t n = 0;
+    uint16_t* cls = row + kCminTab;
+    for (uint32_t l = 0; l < kSigLenClamp; l++) {
+      const uint32_t v = s_c[l];
+      if (v > kPlaneMaxP) continue;  // rejected (0xffff), or no bound (kNeedExact): not handled through the planes
+      if (n && cls[3 * (n - 1) + 2] == v && cls[3 * (n - 1) + 1] + 1u == l) { cls[3 * (n - 1) + 1] = (uint16_t)l; continue; }
+      if (n < kLenClasses) { cls[3 * n] = (uint16_t)l; cls[3 * n + 1] = (uint16_t)l; cls[3 * n + 2] = (uint16_t)v; n++; }
+      else { cls[3 * (n - 1) + 1] = (uint16_t)l; if (v < cls[3 * (n - 1) + 2]) cls[3 * (n - 1) + 2] = (uint16_t)v; }
+    }
+    cls[3 * kLenClasses] = (uint16_t)n;
+  }
 }
 
 // a hit that passed the cheap tests of phase A, queued for phase B
@@ -518,7 +551,7 @@ __global__ void __launch_bounds__(kWave, 8) k_expand_a(DevIndex ix, DevBatch b, 
         for (uint32_t j = lane; j < p; j += kWave) atomicAdd(&s_bucket[sig_bit(pat[j])], 1u);
         // this pattern length's row of the threshold table (k_cmin): 64 lanes x 8 bytes
         reinterpret_cast<unsigned long long*>(s_cmin)[lane] =
-            reinterpret_cast<const unsigned long long*>(w.cmin_tab + (size_t)p * kCminTab)[lane];
+            reinterpret_cast<const unsigned long long*>(w.cmin_tab + (size_t)p * kCminRow)[lane];
         __syncthreads();
         unsigned long long planes[kMaxPlanes];
         uint32_t n_planes = 0;
@@ -786,7 +819,7 @@ __device__ __forceinline__ void plane_level(unsigned long long (&a)[6], unsigned
 
 constexpr uint32_t kHeavyList = 2 * kWave;  // LDS list of plane-test survivors waiting for the exact test
 
-__global__ void __launch_bounds__(kWave, 8) k_expand_h(DevIndex ix, DevBatch b, DevWork w, Params prm, const HeavyItem* items,
+__global__ void __launch_bounds__(kWave, 6) k_expand_h(DevIndex ix, DevBatch b, DevWork w, Params prm, const HeavyItem* items,
                                                        uint32_t item_cap) {
   __shared__ __attribute__((aligned(8))) uint16_t s_cmin[kCminTab];
   __shared__ uint32_t s_bucket[kWave];
@@ -812,7 +845,7 @@ __global__ void __launch_bounds__(kWave, 8) k_expand_h(DevIndex ix, DevBatch b, 
     wave_lds_sync();
     for (uint32_t j = lane; j < p; j += kWave) atomicAdd(&s_bucket[sig_bit(pat[j])], 1u);
     reinterpret_cast<unsigned long long*>(s_cmin)[lane] =
-        reinterpret_cast<const unsigned long long*>(w.cmin_tab + (size_t)p * kCminTab)[lane];
+        reinterpret_cast<const unsigned long long*>(w.cmin_tab + (size_t)p * kCminRow)[lane];
     wave_lds_sync();
     // positions per bucket as bit planes over the buckets (wave-uniform 64-bit masks, like k_expand_a)
     unsigned long long pl[6];
@@ -821,17 +854,14 @@ __global__ void __launch_bounds__(kWave, 8) k_expand_h(DevIndex ix, DevBatch b, 
 #pragma unroll
       for (uint32_t k = 0; k < 6; k++) pl[k] = __ballot((mycnt >> k) & 1u);
     }
-    // smallest threshold of any admissible stored length below the clamp (0xffff: the length filter rejects all)
-    uint32_t t_min = 0xffffu;
+    // length classes {first, last, threshold} of this pattern length (k_cmin), wave-uniform
+    const uint16_t* cls_row = w.cmin_tab + (size_t)p * kCminRow + kCminTab;
+    const uint32_t n_cls = uni((uint32_t)cls_row[3 * kLenClasses]);
+    uint32_t c_first[kLenClasses], c_last[kLenClasses], c_thr[kLenClasses];
 #pragma unroll
-    for (uint32_t k = 0; k < 4; k++) {
-      const uint32_t sl = lane * 4 + k;
-      const uint32_t v = s_cmin[sl];
-      if (sl != kSigLenClamp && v < t_min) t_min = v;
+    for (uint32_t k = 0; k < kLenClasses; k++) {
+      c_first[k] = uni((uint32_t)cls_row[3 * k]); c_last[k] = uni((uint32_t)cls_row[3 * k + 1]); c_thr[k] = uni((uint32_t)cls_row[3 * k + 2]);
     }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(t_min, d, 64); t_min = o < t_min ? o : t_min; }
-    t_min = uni(t_min);
     const bool clamp_possible = s_cmin[kSigLenClamp] != 0xffffu;  // uniform: the index holds sentences of >= 255 tokens
     QHit* qb = w.qb + seg0;
     uint32_t q_head = 0, q_tail = 0, n_list = 0;
@@ -875,18 +905,36 @@ __global__ void __launch_bounds__(kWave, 8) k_expand_h(DevIndex ix, DevBatch b, 
       plane_level<3>(a, pl[3], col, ix.n_blk, valid);
       plane_level<4>(a, pl[4], col, ix.n_blk, valid);
       plane_level<5>(a, pl[5], col, ix.n_blk, valid);
-      // count >= t_min, bit-sliced (t_min uniform; > 63 cannot be reached)
-      unsigned long long ge = 0;
-      if (t_min <= kPlaneMaxP) {
+      // stored length, bit-sliced (rows 56..63), requested after the counting so that its registers are free
+      unsigned long long L[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) L[k] = valid ? col[(unsigned long long)(kSigBits + k) * ix.n_blk] : 0ull;
+      // a suffix passes when its length lies in a class and its count reaches that class's threshold
+      auto len_ge = [&](uint32_t x) -> unsigned long long {  // stored length >= x, x uniform in [0, 255]
         unsigned long long gt = 0, eq = ~0ull;
 #pragma unroll
-        for (int l = 5; l >= 0; l--) {
-          if ((t_min >> l) & 1u) eq &= a[l];
-          else gt |= eq & a[l];
+        for (int l = 7; l >= 0; l--) {
+          if ((x >> l) & 1u) eq &= L[l];
+          else gt |= eq & L[l];
         }
-        ge = gt | eq;
+        return gt | eq;
+      };
+      unsigned long long ge = 0;
+#pragma unroll
+      for (uint32_t k = 0; k < kLenClasses; k++) {
+        if (k < n_cls) {
+          const unsigned long long in = len_ge(c_first[k]) & ~len_ge(c_last[k] + 1u);  // last <= 254
+          unsigned long long gt = 0, eq = ~0ull;
+          const uint32_t t = c_thr[k];
+#pragma unroll
+          for (int l = 5; l >= 0; l--) {
+            if ((t >> l) & 1u) eq &= a[l];
+            else gt |= eq & a[l];
+          }
+          ge |= in & (gt | eq);
+        }
       }
-      if (clamp_possible && valid) ge |= col[(unsigned long long)kSigBits * ix.n_blk];  // clamped lengths: phase B decides
+      if (clamp_possible) ge |= L[0] & L[1] & L[2] & L[3] & L[4] & L[5] & L[6] & L[7];  // clamped lengths: phase B decides
       // the part of the block inside [r_lo, r_hi)
       const uint32_t lo_bit = blk == (r_lo >> 6) ? (r_lo & 63u) : 0u;
       const uint32_t hi_bit = blk == blk_last_r ? ((r_hi - 1) & 63u) + 1u : 64u;
@@ -931,6 +979,10 @@ __global__ void __launch_bounds__(kWave, 8) k_expand_h(DevIndex ix, DevBatch b, 
       const uint32_t h1 = blk_end == blk_last_r + 1 ? r_hi : blk_end * 64u;
       atomicAdd(&w.counters[16], (unsigned long long)(h1 - h0));
       if (n_pass) atomicAdd(&w.counters[17], n_pass);
+      uint32_t rows = 8u;  // the length rows
+#pragma unroll
+      for (int k = 0; k < 6; k++) rows += (uint32_t)__popcll(pl[k]);
+      atomicAdd(&w.counters[18], (unsigned long long)rows * (blk_end - blk_first));
     }
   }
 }

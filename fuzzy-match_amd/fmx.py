@@ -54,7 +54,8 @@ class Stats(C.Structure):
                 ("n_hits", C.c_uint64), ("n_kept", C.c_uint64), ("n_candidates", C.c_uint64),
                 ("n_dp", C.c_uint64), ("n_retries", C.c_uint64), ("n_big", C.c_uint64),
                 ("n_phase_b", C.c_uint64), ("max_kept", C.c_uint64), ("n_heavy_hits", C.c_uint64),
-                ("n_heavy_pass", C.c_uint64), ("pinned", C.c_uint64)]
+                ("n_heavy_pass", C.c_uint64), ("pinned", C.c_uint64), ("plane_words", C.c_uint64),
+                ("probe_bytes", C.c_uint64), ("probe_lines", C.c_uint64)]
 
 
 class Info(C.Structure):
@@ -71,7 +72,7 @@ EXPORTS = [
     "fmx_index_sort", "fmx_index_finalize", "fmx_index_to_device", "fmx_vocab_lookup",
     "fmx_index_lookup_real", "fmx_index_intern_itok", "fmx_index_sentence_id", "fmx_index_array",
     "fmx_index_get_info", "fmx_match_batch", "fmx_match_batch_device", "fmx_set_option",
-    "fmx_host_alloc", "fmx_host_free", "fmx_index_to_devices", "fmx_set_devices", "fmx_index_reopen", "fmx_match_one",
+    "fmx_host_alloc", "fmx_host_free", "fmx_index_to_devices", "fmx_set_devices", "fmx_index_reopen", "fmx_match_one", "fmx_match_batch_keep",
 ]
 TM_SKIPPED = -100
 
@@ -121,6 +122,8 @@ def lib():
     L.fmx_index_get_info.argtypes = [C.c_void_p, C.POINTER(Info)]
     L.fmx_match_batch.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Batch), C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_uint32, C.POINTER(Stats)]
+    L.fmx_match_batch_keep.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Batch), C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(Stats)]
     L.fmx_match_batch_device.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Batch), C.c_uint64, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(Stats)]
     L.fmx_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
@@ -313,7 +316,7 @@ class Index:
     def set_option(self, name, value):
         _check(lib().fmx_set_option(self.h, name.encode(), int(value)))
 
-    def match_batch(self, params, q_off, q_tok, q_real=None, q_itok=None, cap=None, want_stats=False, out=None):
+    def match_batch(self, params, q_off, q_tok, q_real=None, q_itok=None, cap=None, want_stats=False, out=None, keep=None):
         """FuzzyMatch::match over a CSR batch of vocabulary-id patterns (host buffers).
         Returns (records[nq, cap], counts[nq], totals[nq]) (+ Stats).  `out` = (records, counts, totals) arrays to
         fill (e.g. pinned_empty ones) instead of fresh pageable arrays."""
@@ -335,8 +338,12 @@ class Index:
             q_itok = np.ascontiguousarray(q_itok, dtype=np.uint32)
         b = Batch(nq, _ptr(q_off), _ptr(q_tok), _ptr(q_real), _ptr(q_itok), 0)
         st = Stats()
-        _check(lib().fmx_match_batch(self.h, C.byref(params), C.byref(b), _ptr(out), _ptr(cnt), _ptr(tot), cap,
-                                     C.byref(st)))
+        if keep is not None:  # (device pointer of records, device pointer of counts): a copy stays in HBM
+            _check(lib().fmx_match_batch_keep(self.h, C.byref(params), C.byref(b), _ptr(out), _ptr(cnt), _ptr(tot), cap,
+                                              keep[0], keep[1], C.byref(st)))
+        else:
+            _check(lib().fmx_match_batch(self.h, C.byref(params), C.byref(b), _ptr(out), _ptr(cnt), _ptr(tot), cap,
+                                         C.byref(st)))
         res = (out[:nq], cnt[:nq], tot[:nq])
         return res + (st,) if want_stats else res
 

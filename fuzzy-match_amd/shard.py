@@ -78,15 +78,20 @@ class RecordGather:
                 slot["g_cnt"] = torch.zeros((self.world, self.mx), dtype=torch.int32, device=device)
             self.slots.append(slot)
 
-    def _wait(self, slot):
+    def _wait(self, slot, host_sync=False):
+        had = bool(slot["work"])
         for w in slot["work"]:
             w.wait()
         slot["work"] = []
+        # RCCL's wait() only orders torch's current stream behind the collective; a producer that writes the slot
+        # from its own streams (fmx_match_batch_keep) needs the host to know the gather is over
+        if had and host_sync and slot["out"].is_cuda:
+            self.torch.cuda.current_stream(slot["out"].device).synchronize()
 
-    def buffers(self, i):
+    def buffers(self, i, host_sync=False):
         """(records, counts) tensors of step i for this rank's queries; safe to overwrite when returned."""
         slot = self.slots[i % len(self.slots)]
-        self._wait(slot)
+        self._wait(slot, host_sync)
         return slot["out"][:self.nq], slot["cnt"][:self.nq]
 
     def launch(self, i):

@@ -96,6 +96,9 @@ typedef struct fmx_stats {
   uint64_t n_heavy_hits;    /* of n_hits: hits of long ranges, tested 64 per lane through the signature bit planes */
   uint64_t n_heavy_pass;    /* of those: hits that passed the plane test and were re-tested exactly */
   uint64_t pinned;          /* 1 if the host buffers of fmx_match_batch were pinned (copies overlapped compute) */
+  uint64_t plane_words;     /* 8-byte bit-plane words k_expand_h read (its byte model: 8 x this) */
+  uint64_t probe_bytes;     /* option "probe_count": bytes k_probe's loads requested (its byte model) */
+  uint64_t probe_lines;     /* option "probe_count": distinct 128-byte lines those loads touched, per lane */
 } fmx_stats;
 
 const char* fmx_last_error(void);
@@ -196,6 +199,11 @@ int fmx_index_get_info(const fmx_index*, fmx_index_info*);
 int fmx_match_batch(fmx_index*, const fmx_params*, const fmx_batch* host_batch,
                     fmx_match* out, uint32_t* out_count, uint32_t* out_total, uint32_t cap,
                     fmx_stats* stats);
+/* fmx_match_batch that also leaves the records (and counts) in device memory of the index's first device, for a
+ * collective that follows — the RCCL gather of the one-process-per-GPU deployment (fuzzy-match_amd/shard.py). */
+int fmx_match_batch_keep(fmx_index*, const fmx_params*, const fmx_batch* host_batch,
+                         fmx_match* out, uint32_t* out_count, uint32_t* out_total, uint32_t cap,
+                         fmx_match* d_keep, uint32_t* d_keep_count, fmx_stats* stats);
 /* Same with every buffer already in the HBM of the index's device; `stream` is a hipStream_t
  * (NULL = default stream).  total_tokens = q_off[nq] (saves a device read).  Work is enqueued on
  * `stream`; the call synchronises that stream before returning. */
@@ -214,6 +222,7 @@ int fmx_match_one(fmx_index*, const fmx_params*, const uint32_t* wids, uint32_t 
  *   "contexts"          concurrent calls served at once per device, each with its own workspace (default 2)
  *   "heavy_min"         suffix ranges at least this long are tested through the bit planes (default 1024, 0 = never)
  *   "coalesce_us"       longest time fmx_match_one waits for company (default 50)
+ *   "probe_count"       measurement: k_probe also counts the bytes and lines it requests (fmx_stats.probe_*)
  *   "sub_queries"       queries per pipeline pass (default 1 048 576)
  *   "host_sub_queries"  pass size of fmx_match_batch (host buffers, default 262 144): the results of a pass are
  *                       copied to the host while the next pass computes

@@ -45,7 +45,7 @@ int main(int argc, char** argv) {
                 h.gram5.empty() ? 0u : (uint32_t)(h.gram5.size() - 1)};
   // classes by range size: [1,8) [8,64) [64,512) [512,4096) [4096,32768) [32768,inf)
   auto cls = [](uint32_t n) { return n < 8 ? 0 : n < 64 ? 1 : n < 512 ? 2 : n < 4096 ? 3 : n < 32768 ? 4 : 5; };
-  struct Acc { uint64_t ranges = 0, hits = 0, dom = 0, passA = 0, passA_nd = 0, lenpass = 0; uint64_t blk[4] = {0, 0, 0, 0}, blk_rej[4] = {0, 0, 0, 0}; uint64_t whole_dom = 0, whole_dom_hits = 0; };
+  struct Acc { uint64_t pl_tmin = 0, pl_len = 0, pl_2cls = 0, pl_4cls = 0; uint64_t ranges = 0, hits = 0, dom = 0, passA = 0, passA_nd = 0, lenpass = 0; uint64_t blk[4] = {0, 0, 0, 0}, blk_rej[4] = {0, 0, 0, 0}; uint64_t whole_dom = 0, whole_dom_hits = 0; };
   Acc acc[6];
   std::vector<uint64_t> per_query;
   const int B[4] = {8, 16, 32, 64};
@@ -83,6 +83,32 @@ int main(int argc, char** argv) {
         a.passA += ok;
         a.passA_nd += ok && !d;
       }
+      {
+        // plane-test variants: uniform threshold(s) instead of the per-length table
+        uint32_t tmin = 0xffff, smin = 0xffff, smax = 0, t_lo = 0xffff, t_hi = 0xffff, t4[4] = {0xffff, 0xffff, 0xffff, 0xffff};
+        for (uint32_t sl = 1; sl < 255; sl++) {
+          if (reject_len(p, sl, prm)) continue;
+          const uint32_t cm = cover_threshold(p, sl, prm);
+          if (cm == 0xffff) continue;
+          tmin = std::min(tmin, cm); smin = std::min(smin, sl); smax = std::max(smax, sl);
+        }
+        for (uint32_t sl = smin; sl <= smax && smin != 0xffff; sl++) {
+          const uint32_t cm = cover_threshold(p, sl, prm);
+          if (sl <= p) t_lo = std::min(t_lo, cm); else t_hi = std::min(t_hi, cm);
+          const uint32_t c4 = sl <= p ? 0 : std::min<uint32_t>(3, 1 + (sl - p - 1) * 3 / std::max<uint32_t>(1, smax - p));
+          t4[c4] = std::min(t4[c4], cm);
+        }
+        for (uint32_t i = lo; i < hi; i++) {
+          const uint32_t sl = h.suf_b[i].slen;
+          const uint32_t ub = sig_cover_upper(sig_bits(h.suf_sig[i]), hbit.data(), p);
+          a.pl_tmin += ub >= tmin;
+          const bool in = sl >= smin && sl <= smax;
+          a.pl_len += in && ub >= tmin;
+          a.pl_2cls += in && ub >= (sl <= p ? t_lo : t_hi);
+          const uint32_t c4 = sl <= p ? 0 : std::min<uint32_t>(3, 1 + (sl - p - 1) * 3 / std::max<uint32_t>(1, smax - p));
+          a.pl_4cls += in && ub >= t4[c4];
+        }
+      }
       a.dom += dom;
       if (dom == n) { a.whole_dom++; a.whole_dom_hits += n; }
       for (int b = 0; b < 4; b++) {
@@ -115,6 +141,7 @@ int main(int argc, char** argv) {
     printf("%-10s %8lu %10lu  %5.3f  %6.3f   %6.3f   %6.4f  %6.4f   %6.3f   ", names[k], a.ranges, a.hits, (double)a.hits / th,
            (double)a.dom / a.hits, (double)a.lenpass / a.hits, (double)a.passA / a.hits, (double)a.passA_nd / a.hits, (double)a.whole_dom_hits / a.hits);
     for (int b = 0; b < 4; b++) printf("  %6.3f", (double)a.blk_rej[b] * B[b] / a.hits);
+    printf("  | plane pass: tmin %.4f +len %.4f 2cls %.4f 4cls %.4f", (double)a.pl_tmin / a.hits, (double)a.pl_len / a.hits, (double)a.pl_2cls / a.hits, (double)a.pl_4cls / a.hits);
     printf("\n");
   }
   std::sort(per_query.begin(), per_query.end());
