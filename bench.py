@@ -85,7 +85,7 @@ def pmc_pass(counter, argv_child, log):
         r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=900)
         files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
         if r.returncode != 0 or not files:
-            log(f"[bench] pmc pass {counter} failed (rc {r.returncode}): {r.stderr[-300:]}")
+            log(f"[bench] pmc pass {counter} failed (rc {r.returncode}): {r.stderr[-1500:]}")
             return None
         by = {}
         for row in csv.DictReader(open(files[0])):

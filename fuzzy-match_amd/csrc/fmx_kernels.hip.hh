@@ -829,6 +829,7 @@ __global__ void __launch_bounds__(kWave, 6) k_expand_h(DevIndex ix, DevBatch b, 
   const unsigned long long below = (1ull << lane) - 1ull;
   unsigned long long n_items = w.counters[15];
   if (n_items > item_cap) n_items = item_cap;
+  unsigned long long tot_hits = 0, tot_pass = 0, tot_words = 0;
   for (unsigned long long item = blockIdx.x; item < n_items; item += gridDim.x) {
     const uint32_t t = uni(items[item].t), r_lo = uni(items[item].lo), r_cnt = uni(items[item].cnt), chunk = uni(items[item].chunk);
     const uint32_t q = uni(w.t_q[t]);
@@ -971,19 +972,24 @@ __global__ void __launch_bounds__(kWave, 6) k_expand_h(DevIndex ix, DevBatch b, 
       exact(lane < n_list, i);
     }
     if (q_tail != q_head) { wave_lds_sync(); flush(q_tail - q_head); }
-    // statistics: one atomic pair per work item
+    // statistics, summed per workgroup (a shared atomic per work item would serialise the whole kernel on one address)
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) n_pass += __shfl_xor(n_pass, d, 64);
-    if (lane == 0) {
+    {
       const uint32_t h0 = blk_first == (r_lo >> 6) ? r_lo : blk_first * 64u;
       const uint32_t h1 = blk_end == blk_last_r + 1 ? r_hi : blk_end * 64u;
-      atomicAdd(&w.counters[16], (unsigned long long)(h1 - h0));
-      if (n_pass) atomicAdd(&w.counters[17], n_pass);
       uint32_t rows = 8u;  // the length rows
 #pragma unroll
       for (int k = 0; k < 6; k++) rows += (uint32_t)__popcll(pl[k]);
-      atomicAdd(&w.counters[18], (unsigned long long)rows * (blk_end - blk_first));
+      tot_hits += h1 - h0;
+      tot_pass += n_pass;
+      tot_words += (unsigned long long)rows * (blk_end - blk_first);
     }
+  }
+  if (lane == 0 && tot_hits) {
+    atomicAdd(&w.counters[16], tot_hits);
+    atomicAdd(&w.counters[17], tot_pass);
+    atomicAdd(&w.counters[18], tot_words);
   }
 }
 

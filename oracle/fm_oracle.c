@@ -1096,6 +1096,153 @@ int64_t fmo_match(const fmo_index* ix, const fmo_params* prm, const uint32_t* p_
   return r;
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* FuzzyMatch::subsequence — src/fuzzy_match.cc:250-365, after _tokenize_and_normalize            */
+/* ------------------------------------------------------------------------------------------ */
+
+typedef struct subseq { float weight; uint64_t position; uint64_t length; } subseq;
+
+/* Subseq::operator< — src/fuzzy_match.cc:240-243 */
+static inline int subseq_less(const subseq* a, const subseq* b) {
+  return a->weight < b->weight || (a->weight == b->weight && a->position > b->position);
+}
+
+/* std::priority_queue<Subseq> is std::push_heap / std::pop_heap over a vector.  Equal keys (same weight and
+ * position, different length: only possible when an idf weight is exactly 0) pop in an order that depends on the
+ * heap algorithm, so libstdc++'s published one is restated: __push_heap and __adjust_heap (bits/stl_heap.h). */
+static void sq_push_heap(subseq* first, int64_t hole, int64_t top, subseq value) {
+  int64_t parent = (hole - 1) / 2;
+  while (hole > top && subseq_less(&first[parent], &value)) {
+    first[hole] = first[parent];
+    hole = parent;
+    parent = (hole - 1) / 2;
+  }
+  first[hole] = value;
+}
+static void sq_adjust_heap(subseq* first, int64_t hole, int64_t len, subseq value) {
+  const int64_t top = hole;
+  int64_t second = hole;
+  while (second < (len - 1) / 2) {
+    second = 2 * (second + 1);
+    if (subseq_less(&first[second], &first[second - 1])) second--;
+    first[hole] = first[second];
+    hole = second;
+  }
+  if ((len & 1) == 0 && second == (len - 2) / 2) {
+    second = 2 * (second + 1);
+    first[hole] = first[second - 1];
+    hole = second - 1;
+  }
+  sq_push_heap(first, hole, top, value);
+}
+
+int fmo_subsequence(const fmo_index* ix, const uint32_t* pidx, uint32_t p, const char* p_real_tokstring,
+                    uint32_t n_itoks, const uint64_t* itok_idx, const char* const* itok_str,
+                    uint32_t number_of_matches, int no_perfect, int min_subseq_length, float min_subseq_ratio,
+                    int idf_weighting, fmo_rec* out, uint32_t* out_position) {
+  if (!ix || !ix->sorted || !out) return -1;
+  const uint64_t p_length = p;
+  /* :267-271 */
+  if ((int)(min_subseq_ratio * p_length) > min_subseq_length) min_subseq_length = (int)(min_subseq_ratio * p_length);
+  if ((int)p_length < min_subseq_length) return 0;
+  fmo_real real;
+  memset(&real, 0, sizeof(real));
+  const fmo_real* rp = NULL;
+  if (p_real_tokstring || n_itoks) { real_set(&real, p_real_tokstring, n_itoks, itok_idx, itok_str); rp = &real; }
+  /* compute_idf_penalty(pidx, -1) — :276-277,372-390 */
+  float* idf = (float*)xrealloc(NULL, (p_length + 1) * sizeof(float));
+  const unsigned num_sentences = (unsigned)ix->n_sent;
+  for (uint64_t j = 0; j < p_length; j++) {
+    const uint32_t wid = pidx[j];
+    if (wid != 1) {
+      const uint32_t f = (ix->sfreq && wid < ix->vocab_size) ? ix->sfreq[wid] : 0;
+      idf[j] = logf((float)num_sentences / (float)f);
+    } else
+      idf[j] = -1.f;
+  }
+  /* subsequences by weight — :279-290 */
+  subseq* q = NULL;
+  int64_t qn = 0, qcap = 0;
+  for (uint64_t it = 0; it < p_length; it++) {
+    float idf_weight = 0;
+    for (uint64_t jt = it; jt < p_length; jt++) {
+      const float weight = idf[jt];
+      if (weight == -1) break;
+      idf_weight += idf_weighting ? weight : 1;
+      if ((int)(jt - it + 1) >= min_subseq_length) {
+        if (qn + 1 > qcap) { qcap = qcap ? qcap * 2 : 256; q = (subseq*)xrealloc(q, (size_t)qcap * sizeof(subseq)); }
+        subseq v; v.weight = idf_weight; v.position = it; v.length = jt - it + 1;
+        q[qn] = v; qn++;
+        sq_push_heap(q, qn - 1, 0, v);
+      }
+    }
+  }
+  int max_distance = 10000;
+  fmo_rec best;
+  memset(&best, 0, sizeof(best));
+  uint32_t best_pos = 0;
+  /* std::set<unsigned> candidates, perfect — :295-296 */
+  uint32_t *cands = NULL, *perfect = NULL;
+  uint64_t n_cands = 0, n_perfect = 0, cap_c = 0, cap_p = 0;
+  /* pattern side of the DP — :298-301 */
+  const char** st = (const char**)xrealloc(NULL, (p_length + 1) * sizeof(char*));
+  int* sn = (int*)xrealloc(NULL, (p_length + 1) * sizeof(int));
+  for (uint64_t j = 0; j <= p_length; j++) { st[j] = NULL; sn[j] = 0; }
+  get_itoks(rp, st, sn, (int)p_length + 1);
+  const int compare_real = ix->has_real;
+  strview* real2 = NULL;
+  int cap_real2 = 0, n_real2 = 0;
+  if (compare_real && rp && rp->tokstring) n_real2 = split_tokstring(rp->tokstring, &real2, &cap_real2);
+  dp_scratch dp;
+  memset(&dp, 0, sizeof(dp));
+  while (qn > 0 && max_distance == 10000) {  /* :303-304 */
+    const subseq top = q[0];
+    uint64_t range[2];
+    fmo_equal_range(ix, pidx + top.position, top.length, 0, 0, range, NULL);
+    for (uint64_t si = range[0]; si < range[1] && n_cands < number_of_matches; si++) {  /* :311-312 */
+      const uint32_t s_id = ix->suf_sid[si];
+      int seen = 0;
+      for (uint64_t k = 0; k < n_cands && !seen; k++) seen = cands[k] == s_id;
+      for (uint64_t k = 0; k < n_perfect && !seen; k++) seen = perfect[k] == s_id;
+      if (seen) continue;
+      uint64_t s_length = 0;
+      const uint32_t* thes = get_sentence(ix, s_id, &s_length);
+      const float diff_word = 100.f / fmo_normalizer(p_length, s_length, 1.f, 1.f, 1.f);
+      const fmo_real* sentence_real = (ix->has_real && ix->real) ? &ix->real[s_id] : NULL;
+      const float cost = edit_distance_full(thes, sentence_real, (int)s_length, pidx, real2, n_real2, (int)p_length, st, sn,
+                                            idf, 0.f, 1.f, 1.f, 1.f, diff_word, (float)max_distance, compare_real, &dp, NULL);
+      if (cost == 0 && no_perfect) {  /* :329-332 */
+        if (n_perfect + 1 > cap_p) { cap_p = cap_p ? cap_p * 2 : 64; perfect = (uint32_t*)xrealloc(perfect, cap_p * 4); }
+        perfect[n_perfect++] = s_id;
+        continue;
+      }
+      if (cost < max_distance) {  /* :333-351; max_distance is an int: the assignment truncates */
+        best.score = fmo_score_from_cost(cost);
+        best.max_subseq = (int32_t)top.length;
+        best.s_id = s_id;
+        best_pos = (uint32_t)top.position;
+        max_distance = (int)cost;
+        if (cost == 0) break;
+      }
+      if (n_cands + 1 > cap_c) { cap_c = cap_c ? cap_c * 2 : 64; cands = (uint32_t*)xrealloc(cands, cap_c * 4); }
+      cands[n_cands++] = s_id;
+    }
+    /* subseq_queue.pop() — :356 */
+    const subseq last = q[qn - 1];
+    qn--;
+    if (qn > 0) sq_adjust_heap(q, 0, qn, last);
+  }
+  free(q); free(idf); free(cands); free(perfect); free((void*)st); free(sn); free(real2);
+  free(dp.arr); free(dp.tag); free((void*)dp.st1); free(dp.sn1); free(dp.real1);
+  real_clear(&real);
+  if (max_distance != 10000) {
+    *out = best;
+    if (out_position) *out_position = best_pos;
+    return 1;
+  }
+  return 0;
+}
+
 typedef struct batch_job {
   const fmo_index*  ix;
   const fmo_params* prm;

@@ -122,6 +122,14 @@ int fmo_match_batch(const fmo_index*, const fmo_params*,
                     int nthreads, fmo_rec* out, uint32_t* out_count, uint64_t cap,
                     fmo_counters* ctr);
 
+/* FuzzyMatch::subsequence (src/fuzzy_match.cc:250-365) after tokenisation, on vocabulary ids.  Returns 1 and fills
+ * *out (score, max_subseq = length of the sub-n-gram, s_id; penalty 0) and *out_position (start of the sub-n-gram in
+ * the pattern: the reference appends its detokenised text to Match::id) when a match was found, 0 when not. */
+int fmo_subsequence(const fmo_index*, const uint32_t* p_wids, uint32_t p, const char* p_real_tokstring,
+                    uint32_t n_itoks, const uint64_t* itok_idx, const char* const* itok_str,
+                    uint32_t number_of_matches, int no_perfect, int min_subseq_length, float min_subseq_ratio,
+                    int idf_weighting, fmo_rec* out, uint32_t* out_position);
+
 /* pieces exported for unit tests */
 float fmo_edit_distance_ids(const uint32_t* s1, int n1, const uint32_t* s2, int n2,
                             float ins, float del, float rep, float diff_word, float max_fuzzyness);

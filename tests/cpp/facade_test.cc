@@ -3,7 +3,9 @@
 // usage: facade_test <tm1.fmi> <cases.tsv>   (cases: id \t fuzzy \t no_perfect \t nmatch \t norm(space) \t real(space) \t itoks(idx=str,...))
 #include <fuzzy/fuzzy_match.hh>
 
+#include <atomic>
 #include <cstdio>
+#include <thread>
 #include <fstream>
 #include <iostream>
 #include <sstream>
@@ -62,5 +64,58 @@ int main(int argc, char** argv) {
   const size_t first = matches.size();
   fm.match(fuzzy::Tokens{"aa", "bb", "cc", "dd"}, 0.6f, 0, matches);
   std::printf("APPEND %zu %zu\n", first, matches.size());
+  // entries already in the vector count towards number_of_matches (src/fuzzy_match.cc:633,670)
+  {
+    std::vector<fuzzy::FuzzyMatch::Match> m2;
+    fm.match(fuzzy::Tokens{"aa", "bb", "cc", "dd"}, 0.6f, 2, m2);
+    const size_t a = m2.size();
+    const bool r = fm.match(fuzzy::Tokens{"aa", "bb", "cc"}, 0.6f, 2, m2);
+    std::printf("LIMIT %zu %zu %d\n", a, m2.size(), r ? 1 : 0);
+    std::vector<fuzzy::FuzzyMatch::Match> m3;
+    fm.match(fuzzy::Tokens{"aa", "bb", "cc", "dd"}, 0.6f, 1, m3);
+    fm.match(fuzzy::Tokens{"aa", "bb", "cc", "dd"}, 0.6f, 3, m3);
+    std::printf("LIMIT3 %zu %d %d\n", m3.size(), m3.size() > 1 ? (int)m3[0].s_id : -1, m3.size() > 1 ? (int)m3[1].s_id : -2);
+  }
+  // the reference's idiom: add_tm with the default sort = true, repeatedly, and again after a match()
+  {
+    fuzzy::FuzzyMatch fm2;
+    fm2.add_tm("s1", fuzzy::Tokens{"aa", "bb", "cc", "dd"});
+    fm2.add_tm("s2", fuzzy::Tokens{"aa", "bb", "cc", "ee"});
+    fm2.add_tm("skip", fuzzy::Tokens{});
+    std::vector<fuzzy::FuzzyMatch::Match> m;
+    fm2.match(fuzzy::Tokens{"aa", "bb", "cc", "ff"}, 0.5f, 0, m);
+    const size_t a = m.size();
+    fm2.add_tm("s3", fuzzy::Tokens{"aa", "bb", "cc", "ff"});
+    m.clear();
+    fm2.match(fuzzy::Tokens{"aa", "bb", "cc", "ff"}, 0.5f, 0, m);
+    std::printf("REOPEN %zu %zu %s %.9g\n", a, m.size(), m.empty() ? "-" : m[0].id.c_str(), m.empty() ? 0.f : m[0].score);
+  }
+  // match() is const and re-entrant: 16 threads, one pattern per call, the same answers as one thread
+  {
+    const std::vector<fuzzy::Tokens> pats = {{"aa", "bb", "cc", "dd"}, {"aa", "bb", "cc"}, {"aa", "bb", "aa", "cc", "dd"}, {"aa", "bb", "cc", "ff"}};
+    std::vector<std::string> ref;
+    for (const auto& p : pats) {
+      std::vector<fuzzy::FuzzyMatch::Match> m;
+      fm.match(p, 0.5f, 0, m);
+      std::string r;
+      for (const auto& x : m) r += x.id + ":" + std::to_string(x.score) + ";";
+      ref.push_back(r);
+    }
+    std::atomic<int> bad{0};
+    std::vector<std::thread> th;
+    for (int t = 0; t < 16; t++)
+      th.emplace_back([&, t]() {
+        for (int k = 0; k < 40; k++) {
+          const size_t i = (size_t)(t + k) % pats.size();
+          std::vector<fuzzy::FuzzyMatch::Match> m;
+          fm.match(pats[i], 0.5f, 0, m);
+          std::string r;
+          for (const auto& x : m) r += x.id + ":" + std::to_string(x.score) + ";";
+          if (r != ref[i]) bad++;
+        }
+      });
+    for (auto& x : th) x.join();
+    std::printf("THREADS %d\n", bad.load());
+  }
   return 0;
 }

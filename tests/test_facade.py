@@ -16,7 +16,7 @@ def _build(fmx):
     src = os.path.join(ROOT, "tests", "cpp", "facade_test.cc")
     if not os.path.exists(EXE) or os.path.getmtime(EXE) < max(os.path.getmtime(src), os.path.getmtime(fmx.LIB_PATH)):
         subprocess.check_call(["g++", "-std=c++17", "-O1", src, "-I", os.path.join(PKG, "include"), "-L", PKG, "-lfmx",
-                               "-Wl,-rpath," + PKG, "-Wl,-rpath,/opt/rocm/lib", "-o", EXE])
+                               "-Wl,-rpath," + PKG, "-Wl,-rpath,/opt/rocm/lib", "-pthread", "-o", EXE])
 
 
 def _cases_file(tmp_path):
@@ -63,3 +63,8 @@ def test_facade_tm1_fixture(fmx, gpu_device, tmp_path):
     assert "MAX_TOKENS 300" in r.stdout
     ap = [l for l in r.stdout.splitlines() if l.startswith("APPEND")][0].split()
     assert int(ap[2]) == 2 * int(ap[1]) and int(ap[1]) > 0
+    lines = {l.split()[0]: l.split()[1:] for l in r.stdout.splitlines() if l.split() and l.split()[0] in ("LIMIT", "LIMIT3", "REOPEN", "THREADS")}
+    assert lines["LIMIT"] == ["2", "2", "1"]          # a full vector takes no more matches and match() still says true
+    assert lines["LIMIT3"][0] == "3" and lines["LIMIT3"][1] == lines["LIMIT3"][2]  # 1 kept + the best 2 of the second call
+    assert lines["REOPEN"][:3] == ["2", "3", "s3"] and float(lines["REOPEN"][3]) == 1.0  # add_tm after match(): re-sorted lazily
+    assert lines["THREADS"] == ["0"]

@@ -147,3 +147,32 @@ def test_c3_headline_config_parity(fmx, gpu_device):
     assert np.all(sid[valid] < n_sent) and np.all(sc[valid] >= np.float32(0.7)) and np.all(sc[valid] <= 1.0)
     both = valid[:, 1:] & valid[:, :-1]
     assert np.all((sc[:, :-1] > sc[:, 1:])[both] | ((sc[:, :-1] == sc[:, 1:]) & (sid[:, :-1] < sid[:, 1:]))[both])
+    # BASELINE configs C4 (fuzzy 0.5, --mr 0.5, idf 1) and C5 (contrastive rerank, buffer 32) on the SAME 5 M index:
+    # their heavy-tail paths (big candidate sets, list replay, contrast on large accepted sets) see loads the
+    # 1 M-sentence corpus does not produce.  60 k queries each, every record against the oracle.
+    m = 60_000
+    so, st = q_off[:m + 1], q_tok[:int(q_off[m])]
+    for name in ["C4", "C5"]:
+        kw = workloads.PARAM_SETS[name]
+        oo, oc = o.match_batch(oracle_lib.Params(**kw), so, st, 5, nthreads=oracle_lib.effective_cpus())
+        g2, c2_, _, st2 = ix.match_batch(fmx.Params(**kw), so, st, cap=5, want_stats=True)
+        workloads.compare(oo, oc, g2, c2_, name + " on the 5 M index")
+        assert int(oc.sum()) > 10_000, name
+    # the long ranges of this corpus go through the bit planes: make sure that path was what ran
+    _, _, _, st3 = ix.match_batch(fmx.Params(**workloads.PARAM_SETS["C3"]), so, st, cap=5, want_stats=True)
+    assert st3.n_heavy_hits > st3.n_hits // 2 and st3.n_heavy_pass < st3.n_heavy_hits // 10, (st3.n_hits, st3.n_heavy_hits, st3.n_heavy_pass)
+    ix.set_option("heavy_min", 0)  # and the per-hit walk alone gives the same records
+    g3, c3_, _ = ix.match_batch(fmx.Params(**workloads.PARAM_SETS["C3"]), so, st, cap=5)
+    assert np.array_equal(c3_, gc[:m]) and g3.tobytes() == go[:m].tobytes()
+
+
+def test_gpu_sort_equals_independent_oracle_sort_at_1m(fmx, c2):
+    """SuffixArray::sort on the GPU against the oracle's own sort (its restatement of src/suffix_array.cc:58-102,235-251)
+    on the full 1 M-sentence corpus: every array equal, not a sample."""
+    ix, c_off, c_tok, _, _, vs = c2
+    o = oracle_lib.OracleIndex()
+    o.add_ids_bulk(c_off, c_tok, vs, sfreq=ix.array("sfreq"))
+    o.sort(oracle_lib.effective_cpus())
+    a = o.arrays()
+    for k in ["suf_sid", "suf_pos", "buffer", "sent_pos", "qva"]:
+        assert np.array_equal(a[k], ix.array(k)), k
