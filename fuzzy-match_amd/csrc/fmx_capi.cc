@@ -512,6 +512,29 @@ int fmx_match_one(fmx_index* ix, const fmx_params* params, const uint32_t* wids,
   return FMX_OK;
 }
 
+int fmx_subsequence_batch(fmx_index* ix, const fmx_batch* hb, uint32_t number_of_matches, int32_t no_perfect,
+                          int32_t min_subseq_length, float min_subseq_ratio, int32_t idf_weighting, fmx_match* out,
+                          uint32_t* out_found, uint32_t* out_position) {
+  if (!ix || !hb || !out || !out_found) return fail(FMX_E_INVALID, "null argument");
+  if (hb->nq && (!hb->q_off || (hb->q_off[hb->nq] && !hb->q_tok))) return fail(FMX_E_INVALID, "null batch arrays");
+  if (!ix->finalized) return fail(FMX_E_STATE, "index is not finalized");
+  if (ix->devs.empty()) return fail(FMX_E_NO_DEVICE, "index is not on a device (fmx_index_to_device); there is no CPU path");
+  return guarded([&]() {
+    HostBatchView v;
+    v.nq = hb->nq; v.q_off = hb->q_off; v.q_tok = hb->q_tok; v.q_real = hb->q_real; v.q_itok = hb->q_itok;
+    std::vector<uint32_t> forms_real;
+    if (ix->host.real_differs && !v.q_real && hb->nq) {
+      const uint64_t nt = hb->q_off[hb->nq];
+      forms_real.resize(nt);
+      real_from_forms(ix, hb->q_tok, nt, forms_real.data());
+      v.q_real = forms_real.data();
+    }
+    ix->devs[0]->subsequence_host(ix->host, v, number_of_matches, no_perfect != 0, min_subseq_length, min_subseq_ratio,
+                                  idf_weighting != 0, (Rec*)out, out_found, out_position);
+    return (int)FMX_OK;
+  });
+}
+
 int fmx_index_reopen(fmx_index* ix) {
   if (!ix) return fail(FMX_E_INVALID, "null argument");
   ix->co.reset();

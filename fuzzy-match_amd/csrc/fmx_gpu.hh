@@ -78,6 +78,9 @@ class DeviceIndex {
   // d_keep / d_keep_count (optional, in the HBM of device()): the records are also left there
   void match_host(const HostIndex& h, const Params& prm, const HostBatchView& b, Rec* out, uint32_t* out_count,
                   uint32_t* out_total, uint32_t cap, Stats* st, Rec* d_keep = nullptr, uint32_t* d_keep_count = nullptr);
+  // FuzzyMatch::subsequence (src/fuzzy_match.cc:250-365) for a batch of tokenised patterns; one record per query
+  void subsequence_host(const HostIndex& h, const HostBatchView& b, uint32_t number_of_matches, bool no_perfect, int min_subseq_length,
+                        float min_subseq_ratio, bool idf_weighting, Rec* out, uint32_t* out_found, uint32_t* out_pos);
   // q_off values at the sub-batch boundaries of a device-resident batch, and its longest pattern
   std::vector<uint32_t> sub_bounds_from_device(const uint32_t* d_q_off, uint64_t nq, uint32_t* p_max, void* stream);
 

@@ -24,6 +24,7 @@
 #include <string>
 
 #include "fmx_kernels.hip.hh"
+#include "fmx_subseq.hip.hh"
 
 namespace fmx {
 
@@ -716,6 +717,135 @@ void DeviceIndex::match_host(const HostIndex& h, const Params& prm, const HostBa
     st->ms_d2h += ms_d2h;
     st->pinned = pinned ? 1 : 0;
     st->ms_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// FuzzyMatch::subsequence (src/fuzzy_match.cc:250-365) for a batch of tokenised patterns.  The priority queue over the
+// sub-n-grams is host prep (std::priority_queue<Subseq> = std::push_heap / pop_heap; libstdc++'s algorithm is restated
+// so that equal keys pop in the reference's order); ranges, edit distances and the acceptance run on the device.
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct Subseq { float weight; uint32_t position, length; };
+inline bool subseq_less(const Subseq& a, const Subseq& b) {  // src/fuzzy_match.cc:240-243
+  return a.weight < b.weight || (a.weight == b.weight && a.position > b.position);
+}
+void sq_push_heap(Subseq* first, int64_t hole, int64_t top, Subseq value) {  // bits/stl_heap.h __push_heap
+  int64_t parent = (hole - 1) / 2;
+  while (hole > top && subseq_less(first[parent], value)) { first[hole] = first[parent]; hole = parent; parent = (hole - 1) / 2; }
+  first[hole] = value;
+}
+void sq_adjust_heap(Subseq* first, int64_t hole, int64_t len, Subseq value) {  // bits/stl_heap.h __adjust_heap
+  const int64_t top = hole;
+  int64_t second = hole;
+  while (second < (len - 1) / 2) {
+    second = 2 * (second + 1);
+    if (subseq_less(first[second], first[second - 1])) second--;
+    first[hole] = first[second];
+    hole = second;
+  }
+  if ((len & 1) == 0 && second == (len - 2) / 2) { second = 2 * (second + 1); first[hole] = first[second - 1]; hole = second - 1; }
+  sq_push_heap(first, hole, top, value);
+}
+}  // namespace
+
+void DeviceIndex::subsequence_host(const HostIndex& h, const HostBatchView& hb, uint32_t nm, bool no_perfect, int ml_in, float mr,
+                                   bool idf_weighting, Rec* out, uint32_t* out_found, uint32_t* out_pos) {
+  Impl& m = *impl_;
+  if (m.device < 0) throw GpuError("index is not on a device");
+  HIP_TRY(hipSetDevice(m.device));
+  const uint64_t nq_all = hb.nq;
+  for (uint64_t q = 0; q < nq_all; q++) { out_found[q] = 0; if (out_pos) out_pos[q] = 0; out[q] = Rec{0.f, 0.f, 0, 0}; }
+  if (nq_all == 0 || nm == 0) return;  // candidates.size() < 0 never holds: nothing is ever scored (:312)
+  refresh_itok_table(m, h);
+  std::shared_lock<std::shared_mutex> rl(m.itok_mu);
+  CtxLease lease(m);
+  Ctx& c = *lease.c;
+  hipStream_t stream = c.stream;
+  const uint32_t seen_cap = nm + 1024;  // candidates (<= nm) + perfect matches skipped under no_perfect
+  constexpr uint64_t kChunk = 16384;    // queries per round trip: bounds the host-side queues
+  for (uint64_t q0 = 0; q0 < nq_all; q0 += kChunk) {
+    const uint64_t nq = std::min<uint64_t>(kChunk, nq_all - q0);
+    const uint32_t base = hb.q_off[q0];
+    const uint64_t nt = hb.q_off[q0 + nq] - base;
+    std::vector<uint32_t> off(nq + 1);
+    uint32_t p_max = 1;
+    for (uint64_t q = 0; q <= nq; q++) off[q] = hb.q_off[q0 + q] - base;
+    for (uint64_t q = 0; q < nq; q++) p_max = std::max(p_max, off[q + 1] - off[q]);
+    const size_t lds = ((size_t)p_max + 1) * kWave * 4;
+    if (lds > kDynLdsMax) throw UnsupportedError("subsequence(): patterns of more than ~590 tokens");
+    HIP_TRY(hipFuncSetAttribute((const void*)k_sub_eval, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDynLdsMax));
+    c.d_qoff.ensure(nq + 1); c.d_qtok.ensure(nt + 1); c.t_q.ensure(nt + 1);
+    HIP_TRY(hipMemcpyAsync(c.d_qoff.p, off.data(), (nq + 1) * 4, hipMemcpyHostToDevice, stream));
+    if (nt) HIP_TRY(hipMemcpyAsync(c.d_qtok.p, hb.q_tok + base, nt * 4, hipMemcpyHostToDevice, stream));
+    const uint32_t* d_real = nullptr;
+    const uint32_t* d_itok = nullptr;
+    if (hb.q_real) { c.d_qreal.ensure(nt + 1); if (nt) HIP_TRY(hipMemcpyAsync(c.d_qreal.p, hb.q_real + base, nt * 4, hipMemcpyHostToDevice, stream)); d_real = c.d_qreal.p; }
+    if (hb.q_itok) { c.d_qitok.ensure(nt + nq + 1); HIP_TRY(hipMemcpyAsync(c.d_qitok.p, hb.q_itok + base + q0, (nt + nq) * 4, hipMemcpyHostToDevice, stream)); d_itok = c.d_qitok.p; }
+    Grow<uint16_t> d_len; Grow<SubItem> d_items; Grow<SubState> d_st; Grow<uint32_t> d_seen;
+    struct Free { Grow<uint16_t>& a; Grow<SubItem>& b; Grow<SubState>& c_; Grow<uint32_t>& d; ~Free() { a.release(); b.release(); c_.release(); d.release(); } } guard{d_len, d_items, d_st, d_seen};
+    d_len.ensure(nt + 1); d_items.ensure(nq); d_st.ensure(nq); d_seen.ensure(nq * (uint64_t)seen_cap);
+    std::vector<uint16_t> t_len(nt);
+    if (nt) {
+      hipLaunchKernelGGL(k_sub_tq, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, stream, c.d_qoff.p, (uint32_t)nq, c.t_q.p);
+      hipLaunchKernelGGL(k_sub_extent, dim3((unsigned)((nt + 63) / 64)), dim3(64), 0, stream, m.d, c.d_qoff.p, c.d_qtok.p, c.t_q.p, (uint32_t)nt, d_len.p);
+      HIP_TRY(hipMemcpyAsync(t_len.data(), d_len.p, nt * 2, hipMemcpyDeviceToHost, stream));
+    }
+    std::vector<SubState> st(nq);
+    for (auto& s : st) { s = SubState{}; s.md = 10000; }
+    HIP_TRY(hipMemcpyAsync(d_st.p, st.data(), nq * sizeof(SubState), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    // the queues (src/fuzzy_match.cc:279-290)
+    std::vector<std::vector<Subseq>> heaps(nq);
+    for (uint64_t q = 0; q < nq; q++) {
+      const uint32_t p = off[q + 1] - off[q];
+      int ml = ml_in;
+      if ((int)(mr * p) > ml) ml = (int)(mr * p);  // :267-268
+      if ((int)p < ml) continue;                    // :270-271
+      const uint32_t* w = hb.q_tok + base + off[q];
+      auto& hp = heaps[q];
+      for (uint32_t it = 0; it < p; it++) {
+        float idf_weight = 0;
+        for (uint32_t jt = it; jt < p; jt++) {
+          const uint32_t wid = w[jt];
+          if (wid == 1u || wid >= h.idf.size()) break;  // weight -1: ｟unk｠ (:283-284)
+          // compute_idf_penalty (:372-390): HostIndex::idf holds logf(N / sfreq) per word
+          idf_weight += idf_weighting ? h.idf[wid] : 1;
+          if ((int)(jt - it + 1) >= ml) {
+            const Subseq v{idf_weight, it, jt - it + 1};
+            hp.push_back(v);
+            sq_push_heap(hp.data(), (int64_t)hp.size() - 1, 0, v);
+          }
+        }
+      }
+    }
+    std::vector<SubItem> items;
+    for (;;) {
+      items.clear();
+      for (uint64_t q = 0; q < nq; q++) {
+        auto& hp = heaps[q];
+        if (st[q].md != 10000 || st[q].overflow) { hp.clear(); continue; }  // while (... && max_distance == 10000) (:303-304)
+        while (!hp.empty()) {
+          const Subseq top = hp[0];
+          const Subseq last = hp.back();
+          hp.pop_back();
+          if (!hp.empty()) sq_adjust_heap(hp.data(), 0, (int64_t)hp.size(), last);
+          // an empty range does nothing in the reference's loop; ranges are non-empty exactly up to the extent
+          if (top.length <= t_len[off[q] + top.position]) { items.push_back(SubItem{(uint32_t)q, top.position, top.length}); break; }
+        }
+      }
+      if (items.empty()) break;
+      HIP_TRY(hipMemcpyAsync(d_items.p, items.data(), items.size() * sizeof(SubItem), hipMemcpyHostToDevice, stream));
+      hipLaunchKernelGGL(k_sub_eval, dim3((unsigned)std::min<size_t>(items.size(), 65535)), dim3(kWave), lds, stream, m.d, c.d_qoff.p, c.d_qtok.p,
+                         d_real, d_itok, (const SubItem*)d_items.p, (uint32_t)items.size(), d_st.p, d_seen.p, seen_cap, nm, no_perfect ? 1 : 0);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipMemcpyAsync(st.data(), d_st.p, nq * sizeof(SubState), hipMemcpyDeviceToHost, stream));
+      HIP_TRY(hipStreamSynchronize(stream));
+    }
+    for (uint64_t q = 0; q < nq; q++) {
+      if (st[q].overflow) throw UnsupportedError("subsequence(): more than 1024 perfect matches skipped for one pattern");
+      if (st[q].md != 10000) { out[q0 + q] = st[q].best; out_found[q0 + q] = 1; if (out_pos) out_pos[q0 + q] = st[q].pos; }
+    }
   }
 }
 

@@ -73,6 +73,7 @@ EXPORTS = [
     "fmx_index_lookup_real", "fmx_index_intern_itok", "fmx_index_sentence_id", "fmx_index_array",
     "fmx_index_get_info", "fmx_match_batch", "fmx_match_batch_device", "fmx_set_option",
     "fmx_host_alloc", "fmx_host_free", "fmx_index_to_devices", "fmx_set_devices", "fmx_index_reopen", "fmx_match_one", "fmx_match_batch_keep",
+    "fmx_subsequence_batch",
 ]
 TM_SKIPPED = -100
 
@@ -135,6 +136,8 @@ def lib():
     L.fmx_index_reopen.argtypes = [C.c_void_p]
     L.fmx_match_one.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.fmx_subsequence_batch.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_uint32, C.c_int32, C.c_int32, C.c_float,
+                                        C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = L
     return L
 
@@ -346,6 +349,25 @@ class Index:
                                          C.byref(st)))
         res = (out[:nq], cnt[:nq], tot[:nq])
         return res + (st,) if want_stats else res
+
+    def subsequence_batch(self, q_off, q_tok, nmatch, no_perfect=False, min_subseq_length=3, min_subseq_ratio=0.3,
+                          idf_weighting=False, q_real=None, q_itok=None):
+        """FuzzyMatch::subsequence over a CSR batch of vocabulary-id patterns.
+        Returns (record[nq], found[nq], position[nq])."""
+        q_off = np.ascontiguousarray(q_off, dtype=np.uint32)
+        q_tok = np.ascontiguousarray(q_tok, dtype=np.uint32)
+        nq = len(q_off) - 1
+        out = np.zeros(max(nq, 1), dtype=MATCH_DTYPE)
+        found = np.zeros(max(nq, 1), dtype=np.uint32)
+        pos = np.zeros(max(nq, 1), dtype=np.uint32)
+        if q_real is not None:
+            q_real = np.ascontiguousarray(q_real, dtype=np.uint32)
+        if q_itok is not None:
+            q_itok = np.ascontiguousarray(q_itok, dtype=np.uint32)
+        b = Batch(nq, _ptr(q_off), _ptr(q_tok), _ptr(q_real), _ptr(q_itok), 0)
+        _check(lib().fmx_subsequence_batch(self.h, C.byref(b), nmatch, int(no_perfect), min_subseq_length,
+                                           min_subseq_ratio, int(idf_weighting), _ptr(out), _ptr(found), _ptr(pos)))
+        return out[:nq], found[:nq], pos[:nq]
 
     def match_batch_device(self, params, nq, d_q_off, d_q_tok, total_tokens, d_out, d_count, d_total, cap,
                            stream=0, d_q_real=0, d_q_itok=0, max_len=0):

@@ -218,6 +218,15 @@ int fmx_match_batch_device(fmx_index*, const fmx_params*, const fmx_batch* devic
 int fmx_match_one(fmx_index*, const fmx_params*, const uint32_t* wids, uint32_t p, const uint32_t* q_real,
                   const uint32_t* q_itok, fmx_match* out, uint32_t cap, uint32_t* out_count, uint32_t* out_total);
 
+/* FuzzyMatch::subsequence(...) — include/fuzzy/fuzzy_match.hh:99-105, src/fuzzy_match.cc:250-365, for a batch of
+ * tokenised patterns: the sub-n-gram of the pattern with the largest weight (its length, or its summed idf when
+ * idf_weighting) that occurs in an indexed sentence, and the best of up to number_of_matches sentences containing
+ * it.  Per query: out_found (0 / 1), one record (score, max_subseq = length of the sub-n-gram, s_id) and the start
+ * of the sub-n-gram in the pattern (the reference appends its text to Match::id). */
+int fmx_subsequence_batch(fmx_index*, const fmx_batch* host_batch, uint32_t number_of_matches, int32_t no_perfect,
+                          int32_t min_subseq_length, float min_subseq_ratio, int32_t idf_weighting,
+                          fmx_match* out, uint32_t* out_found, uint32_t* out_position);
+
 /* tuning knobs (all have sane defaults):
  *   "contexts"          concurrent calls served at once per device, each with its own workspace (default 2)
  *   "heavy_min"         suffix ranges at least this long are tested through the bit planes (default 1024, 0 = never)
