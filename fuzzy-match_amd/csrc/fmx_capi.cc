@@ -583,6 +583,7 @@ int fmx_set_option(fmx_index* ix, const char* name, int64_t value) {
     else if (n == "heavy_min") d->set_heavy_min((uint32_t)std::max<int64_t>(value, 0));
     else if (n == "contexts") d->set_contexts((uint32_t)std::max<int64_t>(value, 1));
     else if (n == "probe_count") d->set_probe_count(value != 0);
+    else if (n == "serial") d->set_serial(value != 0);
     else return fail(FMX_E_INVALID, "unknown option " + n);
   }
   return FMX_OK;

@@ -68,6 +68,7 @@ class DeviceIndex {
   void     set_initial_segment(uint64_t n);
   void     set_heavy_min(uint32_t n);   // ranges at least this long use the bit-plane kernel (0 = never)
   void     set_probe_count(bool on);    // measurement: k_probe also counts the bytes / 128-byte lines it requests
+  void     set_serial(bool on);         // measurement: no side stream, every kernel alone on the GPU
   void     set_contexts(uint32_t n);    // concurrent calls served at once (each owns a workspace)
 
   // every pointer in HBM of device(); sub_tok_bounds = q_off at each sub-batch boundary (+ q_off[nq])

@@ -178,6 +178,7 @@ struct DeviceIndex::Impl {
   uint32_t heavy_min = kHeavyMinDefault; // suffix ranges at least this long go through the bit-plane kernel (0 = never)
   uint32_t max_ctx = 2;
   bool     probe_count = false;
+  bool     serial = false;        // measurement runs: no side stream, every kernel alone on the GPU
   // context pool
   std::mutex              pool_mu;
   std::condition_variable pool_cv;
@@ -223,7 +224,7 @@ DeviceIndex::~DeviceIndex() {
     (void)hipDeviceSynchronize();
     hipFree((void*)m.d.suf); hipFree((void*)m.d.suf_sig); hipFree((void*)m.d.suf_key); hipFree((void*)m.d.gram.g3); hipFree((void*)m.d.gram.g5); hipFree((void*)m.d.suf_b); hipFree((void*)m.d.tok); hipFree((void*)m.d.sent_pos);
     hipFree((void*)m.d.qva); hipFree((void*)m.d.idf); hipFree((void*)m.d.real); hipFree((void*)m.d.itok);
-    hipFree((void*)m.d.itok_dist); hipFree((void*)m.d.planes);
+    hipFree((void*)m.d.itok_dist); hipFree((void*)m.d.planes); hipFree((void*)m.d.thermo);
     for (auto& c : m.all) c->destroy();
   }
   delete impl_;
@@ -236,6 +237,7 @@ void     DeviceIndex::set_host_sub_queries(uint32_t n) { impl_->host_sub_queries
 void     DeviceIndex::set_initial_segment(uint64_t n) { impl_->init_seg = std::max<uint64_t>(n, 1024); }
 void     DeviceIndex::set_heavy_min(uint32_t n) { impl_->heavy_min = n; }
 void     DeviceIndex::set_probe_count(bool on) { impl_->probe_count = on; }
+void     DeviceIndex::set_serial(bool on) { impl_->serial = on; }
 void     DeviceIndex::set_contexts(uint32_t n) {
   std::lock_guard<std::mutex> lk(impl_->pool_mu);
   impl_->max_ctx = std::max<uint32_t>(std::max<uint32_t>(n, 1), (uint32_t)impl_->all.size());
@@ -286,16 +288,20 @@ void DeviceIndex::upload(const HostIndex& h, int device) {
   m.d.max_slen = mx;
   m.bytes = h.suf_rec.size() * 8 + h.suf_sig.size() * 8 + h.suf_key.size() * sizeof(SufKey) + h.gram.size() * 16 + h.gram5.size() * 16 + h.suf_b.size() * 16 + h.buf.size() * 4 + h.sent_pos.size() * 4 +
             h.qva.size() * 4 + h.idf.size() * 4;
-  // bit planes of the signatures, built on the device from suf_sig: plane-major, one 64-bit word per
-  // (signature bucket, block of 64 consecutive suffixes)
+  // bit planes of the signatures and thermometer planes of the stored lengths, built on the device from suf_sig
+  // (DESIGN.md §3): plane-major, one 64-bit word per (row, block of 64 consecutive suffixes)
   m.d.n_blk = (m.d.n_suf + 63) / 64;
   m.d.planes = nullptr;
+  m.d.thermo = nullptr;
+  m.d.n_thermo = std::min<uint32_t>(mx, kSigLenClamp);
   if (m.d.n_suf) {
     unsigned long long* pl = dev_alloc<unsigned long long>((size_t)kPlaneRows * m.d.n_blk);
-    hipLaunchKernelGGL(k_build_planes, dim3((unsigned)m.d.n_blk), dim3(kWave), 0, 0, m.d.suf_sig, m.d.n_suf, m.d.n_blk, pl);
+    unsigned long long* th = dev_alloc<unsigned long long>((size_t)std::max<uint32_t>(m.d.n_thermo, 1) * m.d.n_blk);
+    hipLaunchKernelGGL(k_build_planes, dim3((unsigned)m.d.n_blk), dim3(kWave), 0, 0, m.d.suf_sig, m.d.n_suf, m.d.n_blk, pl, th, m.d.n_thermo);
     HIP_TRY(hipGetLastError());
     m.d.planes = pl;
-    m.bytes += (uint64_t)kPlaneRows * m.d.n_blk * 8;
+    m.d.thermo = th;
+    m.bytes += (uint64_t)(kPlaneRows + m.d.n_thermo) * m.d.n_blk * 8;
   }
   if (h.real_differs) {
     m.d.real = dev_upload(h.real_ids);
@@ -414,15 +420,16 @@ static void run_passes(DeviceIndex::Impl& m, Ctx& c, const Params& prm_in, const
       }
       tick(); tick();
       // fork: `side` continues after everything enqueued on `stream` so far; join: `stream` waits for `side`
-      auto fork = [&]() { HIP_TRY(hipEventRecord(c.ev_fork, stream)); HIP_TRY(hipStreamWaitEvent(c.side, c.ev_fork, 0)); };
-      auto join = [&]() { HIP_TRY(hipEventRecord(c.ev_join, c.side)); HIP_TRY(hipStreamWaitEvent(stream, c.ev_join, 0)); };
+      const hipStream_t side = m.serial ? stream : c.side;
+      auto fork = [&]() { if (!m.serial) { HIP_TRY(hipEventRecord(c.ev_fork, stream)); HIP_TRY(hipStreamWaitEvent(c.side, c.ev_fork, 0)); } };
+      auto join = [&]() { if (!m.serial) { HIP_TRY(hipEventRecord(c.ev_join, c.side)); HIP_TRY(hipStreamWaitEvent(stream, c.ev_join, 0)); } };
       {
         hipLaunchKernelGGL(k_cmin, dim3(p_max + 1), dim3(256), 0, stream, m.d.max_slen, prm, use_sig, c.cmin_tab.p);
         // the few long ranges stream through the bit planes on the side stream next to the per-hit walk of
         // everything else: both append to the per-query queues of k_expand_b
         if (heavy_min != 0xffffffffu) {
           fork();
-          hipLaunchKernelGGL(k_expand_h, dim3(kHeavyGrid), dim3(kWave), 0, c.side, m.d, b, w, prm, (const HeavyItem*)c.items_h.p,
+          hipLaunchKernelGGL(k_expand_h, dim3(kHeavyGrid), dim3(kWave), 0, side, m.d, b, w, prm, (const HeavyItem*)c.items_h.p,
                              item_h_cap);
         }
         hipLaunchKernelGGL(k_expand_a, dim3(b.nq + kExpandExtraGrid), dim3(kWave), 0, stream, m.d, b, w, prm,
@@ -444,7 +451,7 @@ static void run_passes(DeviceIndex::Impl& m, Ctx& c, const Params& prm_in, const
         uint32_t sid_bytes = 1, len_bytes = p_max < 255 ? 1u : 2u;
         while (sid_bytes < 4 && (m.d.n_sent >> (8 * sid_bytes)) != 0) sid_bytes++;
         fork();
-        hipLaunchKernelGGL(k_cand_big, dim3(kBigGrid), dim3(kBigThreads), 0, c.side, w, c.keys.p,
+        hipLaunchKernelGGL(k_cand_big, dim3(kBigGrid), dim3(kBigThreads), 0, side, w, c.keys.p,
                            (const uint32_t*)c.big_list.p, sid_bytes, len_bytes);
       }
       hipLaunchKernelGGL(k_cand_mid, dim3(1024), dim3(256), 0, stream, w, (const uint32_t*)c.mid_list.p);
@@ -504,7 +511,7 @@ static void run_passes(DeviceIndex::Impl& m, Ctx& c, const Params& prm_in, const
         // the queue of large candidate sets was filled by k_cmap: their (long, mostly sequential) replay runs on the
         // side stream next to the bulk kernel; the two touch disjoint queries
         fork();
-        hipLaunchKernelGGL((k_finish<kLdsSortMax, true>), dim3(2048), dim3(kWave), 0, c.side, m.d, b, w, prm, DevScratch{c.keys.p, c.vals.p, c.f0.p, c.f1.p}, cap,
+        hipLaunchKernelGGL((k_finish<kLdsSortMax, true>), dim3(2048), dim3(kWave), 0, side, m.d, b, w, prm, DevScratch{c.keys.p, c.vals.p, c.f0.p, c.f1.p}, cap,
                            d_out, d_out_count, d_out_total, c.contrast_list.p, c.fin_list.p);
         hipLaunchKernelGGL((k_finish<64, false>), dim3(b.nq), dim3(kWave), 0, stream, m.d, b, w, prm, DevScratch{c.keys.p, c.vals.p, c.f0.p, c.f1.p}, cap, d_out,
                            d_out_count, d_out_total, c.contrast_list.p, c.fin_list.p);

@@ -34,12 +34,16 @@ struct DevIndex {
   uint32_t        n_sent;
   uint32_t        max_slen;
   uint64_t        n_suf;
-  // Bit planes of suf_sig (built on the device at upload): planes[k * n_blk + blk], bit i = bit k of the packed word of
-  // suffix 64 * blk + i — rows 0..55 the signature buckets, rows 56..63 the stored (clamped) sentence length.
-  // Plane-major, so a wave that walks 64 consecutive blocks reads 512 contiguous bytes per row and only the rows its
-  // pattern uses.
+  // Bit planes of suf_sig (built on the device at upload): planes[k * n_blk + blk], bit i = bit k of the signature of
+  // suffix 64 * blk + i (rows 0..55 = the signature buckets).  Plane-major, so a wave that walks 64 consecutive blocks
+  // reads 512 contiguous bytes per row and only the rows its pattern uses.
   const unsigned long long* planes;
+  // Thermometer planes of the stored (clamped) sentence length: thermo[(s - 1) * n_blk + blk], bit i = "stored length
+  // of suffix 64 * blk + i >= s", for s = 1 .. n_thermo (= the longest stored length, at most 255).  A length interval
+  // [a, b] of 64 suffixes is T[a] & ~T[b + 1]: two loads instead of a bit-sliced compare.
+  const unsigned long long* thermo;
   uint64_t        n_blk;
+  uint32_t        n_thermo;
 };
 
 struct DevBatch {
@@ -147,7 +151,7 @@ struct HeavyItem {
   uint32_t cnt;
   uint32_t chunk;
 };
-constexpr uint32_t kPlaneRows = 64;             // bit planes of the packed word: 56 signature buckets + 8 bits of the stored length
+constexpr uint32_t kPlaneRows = 56;             // bit planes of the signature: one per bucket (== kSigBits)
 constexpr uint32_t kPlaneMaxP = 63;             // six-level bit-sliced counters: patterns of up to 63 tokens
 constexpr uint32_t kHeavyMinDefault = 1024;     // ranges at least this long stream through the bit planes
 constexpr uint32_t kHeavyChunkBlocks = 256;     // blocks of 64 suffixes per k_expand_h work item (16384 hits)
@@ -219,9 +223,11 @@ __global__ void __launch_bounds__(64) k_probe(DevIndex ix, DevBatch b, DevWork w
   if (tail && sum_a != 0) atomicAdd(&w.q_hits_a[q], sum_a);
 }
 
-// Signature bit planes of the suffix array (index build, once per upload): one wave per block of 64 suffixes.
+// Signature bit planes and length thermometer planes of the suffix array (index build, once per upload): one wave per
+// block of 64 suffixes.
 __global__ void __launch_bounds__(kWave) k_build_planes(const unsigned long long* __restrict__ suf_sig, unsigned long long n_suf,
-                                                        unsigned long long n_blk, unsigned long long* __restrict__ planes) {
+                                                        unsigned long long n_blk, unsigned long long* __restrict__ planes,
+                                                        unsigned long long* __restrict__ thermo, uint32_t n_thermo) {
   const unsigned long long blk = blockIdx.x;
   const uint32_t lane = threadIdx.x & 63;
   const unsigned long long i = blk * 64 + lane;
@@ -232,7 +238,16 @@ __global__ void __launch_bounds__(kWave) k_build_planes(const unsigned long long
     const unsigned long long m = __ballot((pk >> k) & 1ull);
     if (lane == k) mine = m;
   }
-  planes[(unsigned long long)lane * n_blk + blk] = mine;
+  if (lane < kPlaneRows) planes[(unsigned long long)lane * n_blk + blk] = mine;
+  const uint32_t len = i < n_suf ? sig_slen(pk) : 0u;
+  for (uint32_t s0 = 1; s0 <= n_thermo; s0 += 64) {
+    unsigned long long row = 0;
+    for (uint32_t k = 0; k < 64 && s0 + k <= n_thermo; k++) {
+      const unsigned long long m = __ballot(len >= s0 + k);
+      if (lane == k) row = m;
+    }
+    if (s0 + lane <= n_thermo) thermo[(unsigned long long)(s0 + lane - 1) * n_blk + blk] = row;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -376,8 +391,9 @@ __device__ __forceinline__ uint32_t cover_lds(const uint32_t* __restrict__ sent,
 }
 
 constexpr uint32_t kCminTab = 256;    // one entry per stored sentence length (8 bits, the last = "255 or longer")
-constexpr uint32_t kLenClasses = 8;   // length classes of the bit-sliced test (k_expand_h)
-constexpr uint32_t kCminRow = kCminTab + 32;  // table row: 256 thresholds, then kLenClasses x {first, last, threshold} and the class count
+constexpr uint32_t kGeLevels = 8;     // thresholds tmin .. tmin + 7 are told apart by the bit-sliced test (k_expand_h); higher ones count as tmin + 7
+constexpr uint32_t kCminExt = 40;     // after the 256 thresholds: tmin, a spare, then per level two length intervals {first, last}
+constexpr uint32_t kCminRow = kCminTab + kCminExt;
 constexpr uint32_t kMaxPlanes = 8;    // bit planes of the per-bucket position counts (counts < 256)
 
 // Per-work-item hash set of the pattern's distinct words (p <= 64): slot -> distinct index, and the number
@@ -472,20 +488,35 @@ __global__ void __launch_bounds__(256) k_cmin(uint32_t max_slen, Params prm, int
   row[sl] = (uint16_t)c;
   s_c[sl] = (uint16_t)c;
   __syncthreads();
-  // Length classes for the bit-sliced test of k_expand_h: up to kLenClasses runs of stored lengths [first, last] with
-  // one threshold each (the smallest of the run); lengths the table rejects are in no class.  Runs of equal
-  // thresholds are exact; if there are more than kLenClasses of them the last class absorbs the rest.
+  // Length intervals for the bit-sliced test of k_expand_h: tmin = the smallest threshold of any admissible stored
+  // length, and for each level j (threshold tmin + j; j = 7 also stands for everything above) up to two intervals
+  // [first, last] of stored lengths with that threshold.  Thresholds are constant below the pattern length and grow
+  // above it, so two intervals per level are exact in practice; a third run is merged into the second (the lengths in
+  // between are then tested against a threshold that is too low or should have been rejected by the length filter:
+  // a superset, and every plane survivor is re-tested exactly).  Lengths the table rejects lie in no interval.
   if (threadIdx.x == 0) {
-    uint32_t n = 0;
-    uint16_t* cls = row + kCminTab;
+    uint16_t* ext = row + kCminTab;
+    uint32_t tmin = 0xffffu;
     for (uint32_t l = 0; l < kSigLenClamp; l++) {
       const uint32_t v = s_c[l];
-      if (v > kPlaneMaxP) continue;  // rejected (0xffff), or no bound (kNeedExact): not handled through the planes
-      if (n && cls[3 * (n - 1) + 2] == v && cls[3 * (n - 1) + 1] + 1u == l) { cls[3 * (n - 1) + 1] = (uint16_t)l; continue; }
-      if (n < kLenClasses) { cls[3 * n] = (uint16_t)l; cls[3 * n + 1] = (uint16_t)l; cls[3 * n + 2] = (uint16_t)v; n++; }
-      else { cls[3 * (n - 1) + 1] = (uint16_t)l; if (v < cls[3 * (n - 1) + 2]) cls[3 * (n - 1) + 2] = (uint16_t)v; }
+      if (v <= kPlaneMaxP && v < tmin) tmin = v;  // rejected (0xffff) and "no bound" (kNeedExact) are above kPlaneMaxP
     }
-    cls[3 * kLenClasses] = (uint16_t)n;
+    ext[0] = (uint16_t)tmin;
+    ext[1] = 0;
+    uint32_t cnt[kGeLevels];
+    for (uint32_t j = 0; j < kGeLevels; j++) {
+      cnt[j] = 0;
+      for (uint32_t r = 0; r < 2; r++) { ext[2 + 4 * j + 2 * r] = 1; ext[3 + 4 * j + 2 * r] = 0; }  // empty: first > last
+    }
+    for (uint32_t l = 0; l < kSigLenClamp && tmin != 0xffffu; l++) {
+      const uint32_t v = s_c[l];
+      if (v > kPlaneMaxP) continue;
+      const uint32_t j = v - tmin < kGeLevels ? v - tmin : kGeLevels - 1;
+      uint16_t* iv = ext + 2 + 4 * j;
+      if (cnt[j] && iv[2 * (cnt[j] - 1) + 1] + 1u == l) iv[2 * (cnt[j] - 1) + 1] = (uint16_t)l;
+      else if (cnt[j] < 2) { iv[2 * cnt[j]] = (uint16_t)l; iv[2 * cnt[j] + 1] = (uint16_t)l; cnt[j]++; }
+      else iv[3] = (uint16_t)l;
+    }
   }
 }
 
@@ -756,15 +787,20 @@ __global__ void __launch_bounds__(kWave, 8) k_expand_a(DevIndex ix, DevBatch b, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_expand_h — phase A for the long suffix ranges.  84 % of all hits at C3 lie in the ~0.1 % of ranges with thousands
-// of suffixes (a repeated phrase), and k_expand_a is a pure 8-byte-per-hit HBM stream on them.  Here one LANE tests a
-// whole block of 64 consecutive suffixes: the signature bit planes (DevIndex::planes) give, per signature bucket,
-// one 64-bit word = that bucket's bit of the 64 suffixes, so the cover upper bound of all 64 is a bit-sliced sum
-// (carry-save adders on 64-bit words) of the planes of the pattern's buckets, weighted by positions per bucket.
-// Only the ~20 planes a pattern uses are read: ~3 bytes per hit instead of 8, 64 lanes x 8 bytes contiguous per load.
-// The bit-sliced sum is compared with the smallest threshold of any admissible sentence length (a superset of phase
-// A's survivors, ~1-3 % of the hits); those are re-tested exactly like k_expand_a does (same 8-byte word, same
-// table), so the hits queued for k_expand_b are identical.  One wave per work item (range, 256 blocks).
+// k_expand_h — phase A for the long suffix ranges.  98 % of all hits at C3 lie in the ~0.1 % of ranges with thousands
+// of suffixes (a repeated phrase under a short pattern), and walking them hit by hit is an 8-byte-per-hit stream with
+// ~20 VALU instructions per hit.  Here one LANE tests a whole block of 64 consecutive suffixes:
+//   count   the signature bit planes (DevIndex::planes) give, per signature bucket, one 64-bit word = that bucket's bit
+//           of the 64 suffixes, so the cover upper bound of all 64 is a bit-sliced sum (carry-save adders on 64-bit
+//           words) of the planes of the pattern's buckets, weighted by positions per bucket
+//   need    the threshold depends on the sentence length.  d = count - tmin is formed bit-sliced (tmin = the smallest
+//           threshold of any admissible length, wave-uniform), decoded into the eight masks "d >= j", and each mask is
+//           ANDed with the length intervals whose threshold is tmin + j — an interval [a, b] is T[a] & ~T[b + 1] on the
+//           length thermometer planes (DevIndex::thermo): two loads, no compare
+// Only the ~13-20 rows a pattern uses and ~10 thermometer rows are read: ~3 bytes per hit instead of 8, 64 lanes x 8 bytes
+// contiguous per load, and ~5 VALU instructions per hit.  The survivors (a superset of phase A's, ~1 % of the hits) are
+// re-tested exactly like k_expand_a does (same 8-byte word, same table), so the hits queued for k_expand_b are
+// identical.  One wave per work item (range, 256 blocks).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void csa64(unsigned long long& s, unsigned long long& c, unsigned long long x, unsigned long long y,
                                       unsigned long long z) {
@@ -855,13 +891,15 @@ __global__ void __launch_bounds__(kWave, 6) k_expand_h(DevIndex ix, DevBatch b, 
 #pragma unroll
       for (uint32_t k = 0; k < 6; k++) pl[k] = __ballot((mycnt >> k) & 1u);
     }
-    // length classes {first, last, threshold} of this pattern length (k_cmin), wave-uniform
-    const uint16_t* cls_row = w.cmin_tab + (size_t)p * kCminRow + kCminTab;
-    const uint32_t n_cls = uni((uint32_t)cls_row[3 * kLenClasses]);
-    uint32_t c_first[kLenClasses], c_last[kLenClasses], c_thr[kLenClasses];
+    // tmin and the length intervals {first | last << 16} per level of this pattern length (k_cmin), wave-uniform
+    const uint32_t* ext = reinterpret_cast<const uint32_t*>(w.cmin_tab + (size_t)p * kCminRow + kCminTab);
+    const uint32_t tmin = uni(ext[0]) & 0xffffu;
+    uint32_t iv[2 * kGeLevels];
+    uint32_t n_iv = 0;
 #pragma unroll
-    for (uint32_t k = 0; k < kLenClasses; k++) {
-      c_first[k] = uni((uint32_t)cls_row[3 * k]); c_last[k] = uni((uint32_t)cls_row[3 * k + 1]); c_thr[k] = uni((uint32_t)cls_row[3 * k + 2]);
+    for (uint32_t k = 0; k < 2 * kGeLevels; k++) {
+      iv[k] = uni(ext[1 + k]);
+      n_iv += (iv[k] & 0xffffu) <= (iv[k] >> 16) ? 1u : 0u;
     }
     const bool clamp_possible = s_cmin[kSigLenClamp] != 0xffffu;  // uniform: the index holds sentences of >= 255 tokens
     QHit* qb = w.qb + seg0;
@@ -898,6 +936,12 @@ __global__ void __launch_bounds__(kWave, 6) k_expand_h(DevIndex ix, DevBatch b, 
     for (uint32_t b0 = blk_first; b0 < blk_end; b0 += kWave) {
       const uint32_t blk = b0 + lane;
       const bool valid = blk < blk_end;
+      // stored length >= s for the 64 suffixes of this lane's block (s wave-uniform)
+      auto T = [&](uint32_t s_) -> unsigned long long {
+        if (s_ == 0) return ~0ull;
+        if (s_ > ix.n_thermo || !valid) return 0ull;
+        return ix.thermo[(unsigned long long)(s_ - 1) * ix.n_blk + blk];
+      };
       unsigned long long a[6] = {0, 0, 0, 0, 0, 0};
       const unsigned long long* col = ix.planes + blk;
       plane_level<0>(a, pl[0], col, ix.n_blk, valid);
@@ -906,42 +950,37 @@ __global__ void __launch_bounds__(kWave, 6) k_expand_h(DevIndex ix, DevBatch b, 
       plane_level<3>(a, pl[3], col, ix.n_blk, valid);
       plane_level<4>(a, pl[4], col, ix.n_blk, valid);
       plane_level<5>(a, pl[5], col, ix.n_blk, valid);
-      // stored length, bit-sliced (rows 56..63), requested after the counting so that its registers are free
-      unsigned long long L[8];
+      // d = count - tmin, bit-sliced (tmin wave-uniform: each level is two operations); bor = borrow = count < tmin
+      unsigned long long d[6], bor = 0;
 #pragma unroll
-      for (int k = 0; k < 8; k++) L[k] = valid ? col[(unsigned long long)(kSigBits + k) * ix.n_blk] : 0ull;
-      // a suffix passes when its length lies in a class and its count reaches that class's threshold
-      auto len_ge = [&](uint32_t x) -> unsigned long long {  // stored length >= x, x uniform in [0, 255]
-        unsigned long long gt = 0, eq = ~0ull;
-#pragma unroll
-        for (int l = 7; l >= 0; l--) {
-          if ((x >> l) & 1u) eq &= L[l];
-          else gt |= eq & L[l];
-        }
-        return gt | eq;
-      };
-      unsigned long long ge = 0;
-#pragma unroll
-      for (uint32_t k = 0; k < kLenClasses; k++) {
-        if (k < n_cls) {
-          const unsigned long long in = len_ge(c_first[k]) & ~len_ge(c_last[k] + 1u);  // last <= 254
-          unsigned long long gt = 0, eq = ~0ull;
-          const uint32_t t = c_thr[k];
-#pragma unroll
-          for (int l = 5; l >= 0; l--) {
-            if ((t >> l) & 1u) eq &= a[l];
-            else gt |= eq & a[l];
-          }
-          ge |= in & (gt | eq);
-        }
+      for (int l = 0; l < 6; l++) {
+        if ((tmin >> l) & 1u) { d[l] = ~(a[l] ^ bor); bor = ~a[l] | bor; }
+        else { d[l] = a[l] ^ bor; bor = ~a[l] & bor; }
       }
-      if (clamp_possible) ge |= L[0] & L[1] & L[2] & L[3] & L[4] & L[5] & L[6] & L[7];  // clamped lengths: phase B decides
+      const unsigned long long hi = d[3] | d[4] | d[5];
+      unsigned long long ge[kGeLevels];  // ge[j]: count >= tmin + j
+      ge[0] = ~0ull;
+      ge[1] = hi | d[0] | d[1] | d[2];
+      ge[2] = hi | d[1] | d[2];
+      ge[3] = hi | d[2] | (d[1] & d[0]);
+      ge[4] = hi | d[2];
+      ge[5] = hi | (d[2] & (d[1] | d[0]));
+      ge[6] = hi | (d[2] & d[1]);
+      ge[7] = hi | (d[2] & d[1] & d[0]);
+      unsigned long long pass = 0;
+#pragma unroll
+      for (uint32_t k = 0; k < 2 * kGeLevels; k++) {
+        const uint32_t first = iv[k] & 0xffffu, last = iv[k] >> 16;
+        if (first <= last) pass |= T(first) & ~T(last + 1u) & ge[k >> 1];  // last <= 254
+      }
+      pass &= ~bor;
+      if (clamp_possible) pass |= T(kSigLenClamp);  // clamped lengths: phase B decides
       // the part of the block inside [r_lo, r_hi)
       const uint32_t lo_bit = blk == (r_lo >> 6) ? (r_lo & 63u) : 0u;
       const uint32_t hi_bit = blk == blk_last_r ? ((r_hi - 1) & 63u) + 1u : 64u;
       unsigned long long mask = hi_bit == 64 ? ~0ull : ((1ull << hi_bit) - 1ull);
       mask &= ~((1ull << lo_bit) - 1ull);
-      unsigned long long surv = valid ? (ge & mask) : 0ull;
+      unsigned long long surv = valid ? (pass & mask) : 0ull;
       n_pass += (unsigned long long)__popcll(surv);
       // survivors -> LDS list, 64 at a time through the exact test
       for (;;) {
@@ -974,11 +1013,11 @@ __global__ void __launch_bounds__(kWave, 6) k_expand_h(DevIndex ix, DevBatch b, 
     if (q_tail != q_head) { wave_lds_sync(); flush(q_tail - q_head); }
     // statistics, summed per workgroup (a shared atomic per work item would serialise the whole kernel on one address)
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) n_pass += __shfl_xor(n_pass, d, 64);
+    for (int d2 = 32; d2 >= 1; d2 >>= 1) n_pass += __shfl_xor(n_pass, d2, 64);
     {
       const uint32_t h0 = blk_first == (r_lo >> 6) ? r_lo : blk_first * 64u;
       const uint32_t h1 = blk_end == blk_last_r + 1 ? r_hi : blk_end * 64u;
-      uint32_t rows = 8u;  // the length rows
+      uint32_t rows = 2u * n_iv + (clamp_possible ? 1u : 0u);  // thermometer rows
 #pragma unroll
       for (int k = 0; k < 6; k++) rows += (uint32_t)__popcll(pl[k]);
       tot_hits += h1 - h0;

@@ -98,6 +98,8 @@ def lib():
     L.fmo_match.argtypes = [vp, C.POINTER(Params), vp, u32, C.c_char_p, u32, C.POINTER(u64),
                             C.POINTER(C.c_char_p), vp, u64, C.POINTER(Counters)]
     L.fmo_match_batch.argtypes = [vp, C.POINTER(Params), vp, vp, u64, C.c_int, vp, vp, u64, C.POINTER(Counters)]
+    L.fmo_subsequence.argtypes = [vp, vp, u32, C.c_char_p, u32, C.POINTER(u64), C.POINTER(C.c_char_p), u32, C.c_int, C.c_int,
+                                  C.c_float, C.c_int, vp, C.POINTER(u32)]
     L.fmo_edit_distance_ids.restype = C.c_float
     L.fmo_edit_distance_ids.argtypes = [vp, C.c_int, vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]
     L.fmo_edit_distance_char.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int]
@@ -237,6 +239,20 @@ class OracleIndex:
     def match_tokens(self, params, tokens, real=None, itoks=None, cap=256):
         """match(const Tokens&, …) / match(Sentence, Tokens, …) with string tokens."""
         return self.match_ids(params, self.vocab.get_index(tokens), real=real, itoks=itoks, cap=cap)
+
+    def subsequence_ids(self, wids, nmatch, no_perfect=False, min_subseq_length=3, min_subseq_ratio=0.3,
+                        idf_weighting=False, real=None, itoks=None):
+        """FuzzyMatch::subsequence after tokenisation.  Returns (record | None, start of the sub-n-gram)."""
+        w = np.ascontiguousarray(wids, np.uint32)
+        n, idx, strs = _itok_args(itoks)
+        ts = None if (real is None and not itoks) else "\t".join(real if real is not None else []).encode("utf-8")
+        out = np.zeros(1, dtype=MATCH_DTYPE)
+        pos = C.c_uint32(0)
+        r = self.L.fmo_subsequence(self.h, _ptr(w), len(w), ts, n, idx, strs, nmatch, int(no_perfect), min_subseq_length,
+                                   min_subseq_ratio, int(idf_weighting), _ptr(out), C.byref(pos))
+        if r < 0:
+            raise RuntimeError("oracle subsequence failed")
+        return (out[0].copy(), int(pos.value)) if r else (None, 0)
 
     def match_batch(self, params, q_off, q_tok, cap, nthreads=1, want_counters=False):
         q_off = np.ascontiguousarray(q_off, np.uint32)
