@@ -18,6 +18,7 @@
 
 #include "fmx_gpu.hh"
 #include "fmx_host.hh"
+#include "fmx_text.hh"
 
 using namespace fmx;
 
@@ -533,6 +534,69 @@ int fmx_subsequence_batch(fmx_index* ix, const fmx_batch* hb, uint32_t number_of
                                   idf_weighting != 0, (Rec*)out, out_found, out_position);
     return (int)FMX_OK;
   });
+}
+
+struct fmx_text {
+  int         pt = 0;
+  TextTokens  t;
+  std::string scratch;
+};
+
+fmx_text* fmx_text_tokenize(int32_t pt, const char* sentence, size_t len) {
+  try {
+    std::unique_ptr<fmx_text> h(new fmx_text);
+    h->pt = pt;
+    tokenize_and_normalize(pt, sentence ? std::string(sentence, len) : std::string(), h->t);
+    return h.release();
+  } catch (...) {
+    g_err = "out of host memory";
+    return nullptr;
+  }
+}
+void        fmx_text_free(fmx_text* h) { delete h; }
+uint32_t    fmx_text_num_tokens(const fmx_text* h) { return h ? (uint32_t)h->t.norm.size() : 0u; }
+const char* fmx_text_norm(const fmx_text* h, uint32_t i) { return h && i < h->t.norm.size() ? h->t.norm[i].c_str() : ""; }
+const char* fmx_text_real(const fmx_text* h, uint32_t i) { return h && i < h->t.real.size() ? h->t.real[i].c_str() : ""; }
+uint32_t    fmx_text_num_itoks(const fmx_text* h) { return h ? (uint32_t)h->t.itoks.size() : 0u; }
+uint64_t    fmx_text_itok_index(const fmx_text* h, uint32_t k) { return h && k < h->t.itoks.size() ? h->t.itoks[k].first : 0u; }
+const char* fmx_text_itok(const fmx_text* h, uint32_t k) { return h && k < h->t.itoks.size() ? h->t.itoks[k].second.c_str() : ""; }
+uint32_t    fmx_text_num_raw(const fmx_text* h) { return h ? (uint32_t)h->t.raw.size() : 0u; }
+const char* fmx_text_raw(const fmx_text* h, uint32_t i) { return h && i < h->t.raw.size() ? h->t.raw[i].c_str() : ""; }
+uint32_t    fmx_text_map(const fmx_text* h, uint32_t k) { return h && k < h->t.map_tokens.size() ? h->t.map_tokens[k] : 0u; }
+const char* fmx_text_detokenize(fmx_text* h, uint32_t from, uint32_t to) {
+  if (!h) return "";
+  try {
+    const uint32_t n = (uint32_t)h->t.map_tokens.size();
+    const uint32_t a = from < n ? h->t.map_tokens[from] : (uint32_t)h->t.raw.size();
+    const uint32_t b = to < n ? h->t.map_tokens[to] : (uint32_t)h->t.raw.size();
+    std::vector<std::string> toks, feats;
+    for (uint32_t i = a; i < b && i < h->t.raw.size(); i++) { toks.push_back(h->t.raw[i]); feats.push_back(h->t.feat[i]); }
+    h->scratch = detokenize(h->pt, toks, feats);
+    return h->scratch.c_str();
+  } catch (...) {
+    return "";
+  }
+}
+
+int64_t fmx_index_add_text(fmx_index* ix, const char* id, const char* sentence, size_t len) {
+  if (!ix || !sentence) return fail(FMX_E_INVALID, "null argument");
+  if (ix->finalized) return fail(FMX_E_STATE, "index is finalized");
+  int64_t r = FMX_TM_SKIPPED;
+  int rc = guarded([&]() {
+    TextTokens t;
+    tokenize_and_normalize(ix->host.pt, std::string(sentence, len), t);
+    if (t.norm.empty()) return (int)FMX_OK;  // "WARNING: cannot index empty segment" (src/fuzzy_match.cc:218-221)
+    RealTok real;
+    for (size_t i = 0; i < t.real.size(); i++) { if (i) real.tokstring += '\t'; real.tokstring += t.real[i]; }
+    for (const auto& kv : t.itoks) real.itoks.emplace_back(kv.first, kv.second);
+    if (!ix->host.ids.empty() || ix->host.sent_pos.empty()) {
+      r = ix->host.add_tm(id ? id : "", real, t.norm);
+      if (r < 0) r = FMX_TM_SKIPPED;
+    } else
+      throw std::runtime_error("cannot mix id-only and string-level sentences in one index");
+    return (int)FMX_OK;
+  });
+  return rc == FMX_OK ? r : rc;
 }
 
 int fmx_index_reopen(fmx_index* ix) {

@@ -125,6 +125,8 @@ struct Ctx {
   hipEvent_t  ev[2 * kNumStages]{};
   hipEvent_t  ev_fork = nullptr, ev_join = nullptr, ev_in[kMaxPassesInFlight]{}, ev_done = nullptr;
   unsigned long long* h_ctr = nullptr;  // pinned: the pass counters land here
+  unsigned long long* h_ctr_group = nullptr;  // pinned: one slot per pass of an asynchronous group
+  std::vector<hipEvent_t> ev_pass;      // "pass done" events of an asynchronous group
   bool ok = false;
 
   void init() {
@@ -162,6 +164,8 @@ struct Ctx {
     if (ev_join) (void)hipEventDestroy(ev_join);
     if (ev_done) (void)hipEventDestroy(ev_done);
     if (h_ctr) (void)hipHostFree(h_ctr);
+    if (h_ctr_group) (void)hipHostFree(h_ctr_group);
+    for (auto& e : ev_pass) if (e) (void)hipEventDestroy(e);
   }
 };
 
@@ -350,224 +354,294 @@ const char* stage_name(int s) {
 
 // hooks of the host-buffer path around each pass (sub-batch) of the pipeline
 struct PassHooks {
-  std::function<void(uint32_t)> before;  // inputs of pass sb must be on their way; make `stream` wait for them
-  std::function<void(uint32_t)> after;   // pass sb is complete and final
+  std::function<void(uint32_t)> before;        // inputs of pass sb must be on their way; make `stream` wait for them
+  std::function<void(uint32_t, hipEvent_t)> after;  // the records of pass sb are final once the event (or, if null, the stream) is done
 };
 
+struct PassEnv {
+  DeviceIndex::Impl& m;
+  Ctx& c;
+  Params prm;
+  bool full, use_idf;
+  Rec* d_out; uint32_t* d_out_count; uint32_t* d_out_total;
+  uint32_t cap;
+  hipStream_t stream;
+};
+
+// every launch of one pass, in stream order; the pass counters land in h_ctr_slot (pinned).  No host synchronisation.
+static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool timing, unsigned long long* h_ctr_slot) {
+  DeviceIndex::Impl& m = E.m;
+  Ctx& c = E.c;
+  const Params& prm = E.prm;
+  const bool full = E.full, use_idf = E.use_idf;
+  Rec* d_out = E.d_out; uint32_t* d_out_count = E.d_out_count; uint32_t* d_out_total = E.d_out_total;
+  const uint32_t cap = E.cap;
+  hipStream_t stream = E.stream;
+    DevWork w = work_view(c);
+    const uint32_t item_cap = (uint32_t)std::min<uint64_t>(c.items.cap, 0xffffffffull);
+    const uint32_t item_h_cap = (uint32_t)std::min<uint64_t>(c.items_h.cap, 0xffffffffull);
+    HIP_TRY(hipMemsetAsync(w.q_hits, 0, (b.nq + 1) * sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(w.q_hits_a, 0, (b.nq + 1) * sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(w.counters, 0, kNumCounters * sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(w.q_pb, 0, b.nq * sizeof(uint32_t), stream));
+    int e = 0;
+    auto tick = [&]() { if (timing) HIP_TRY(hipEventRecord(c.ev[e], stream)); e++; };
+    // the signature bound needs theoretical_rejection_cover to be monotone in the cover: costs >= 0
+    const int use_sig = prm.ins >= 0.f && prm.del >= 0.f && prm.rep >= 0.f;
+    // suffix ranges of at least heavy_min hits are walked through the signature bit planes (k_expand_h)
+    const uint32_t heavy_min = (use_sig && m.d.planes && m.heavy_min) ? std::max<uint32_t>(m.heavy_min, 256u) : 0xffffffffu;
+    tick();
+    hipLaunchKernelGGL(k_setup, dim3((b.nq + 255) / 256), dim3(256), 0, stream, m.d, b, w, prm);
+    if (prm.idf_penalty != 0.f) hipLaunchKernelGGL(k_tidf, dim3((b.nt + 255) / 256), dim3(256), 0, stream, m.d, b, w);
+    HIP_TRY(hipMemsetAsync(w.p_hist, 0, 2 * kPBins * sizeof(uint32_t), stream));
+    {
+      const uint32_t per_block = kRankThreads * kRankPer;
+      hipLaunchKernelGGL(k_phist, dim3((b.nq + per_block - 1) / per_block), dim3(kRankThreads), 0, stream, b, w);
+      hipLaunchKernelGGL(k_prank, dim3((b.nq + per_block - 1) / per_block), dim3(kRankThreads), 0, stream, b, w);
+    }
+    tick(); tick();
+    if (b.nt) {
+      if (m.probe_count)  // measurement runs only: the same kernel, also counting the bytes / lines it requests
+        hipLaunchKernelGGL(k_probe<true>, dim3((b.nt + 63) / 64), dim3(64), 0, stream, m.d, b, w, heavy_min, c.items_h.p, item_h_cap);
+      else
+        hipLaunchKernelGGL(k_probe<false>, dim3((b.nt + 63) / 64), dim3(64), 0, stream, m.d, b, w, heavy_min, c.items_h.p, item_h_cap);
+    }
+    tick(); tick();
+    {
+      hipLaunchKernelGGL(k_caps, dim3((b.nq + 1 + 255) / 256), dim3(256), 0, stream, b, w, c.items.p, item_cap, c.s_max);
+      const uint32_t n = b.nq + 1;  // one extra so that q_seg[nq] = total
+      const uint32_t tiles = (n + kScanTile - 1) / kScanTile;
+      if (tiles > (uint32_t)kScanTile) throw std::invalid_argument("sub-batch too large for the scan");
+      hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(kScanThreads), 0, stream, w.q_cap, w.q_seg, c.tile_sums.p, n);
+      hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanThreads), 0, stream, c.tile_sums.p, tiles, c.grand_total.p);
+      hipLaunchKernelGGL(k_scan_add, dim3(tiles), dim3(kScanThreads), 0, stream, w.q_seg, c.tile_sums.p, n);
+    }
+    tick(); tick();
+    // fork: `side` continues after everything enqueued on `stream` so far; join: `stream` waits for `side`
+    const hipStream_t side = m.serial ? stream : c.side;
+    auto fork = [&]() { if (!m.serial) { HIP_TRY(hipEventRecord(c.ev_fork, stream)); HIP_TRY(hipStreamWaitEvent(c.side, c.ev_fork, 0)); } };
+    auto join = [&]() { if (!m.serial) { HIP_TRY(hipEventRecord(c.ev_join, c.side)); HIP_TRY(hipStreamWaitEvent(stream, c.ev_join, 0)); } };
+    {
+      hipLaunchKernelGGL(k_cmin, dim3(p_max + 1), dim3(256), 0, stream, m.d.max_slen, prm, use_sig, c.cmin_tab.p);
+      // the few long ranges stream through the bit planes on the side stream next to the per-hit walk of
+      // everything else: both append to the per-query queues of k_expand_b
+      if (heavy_min != 0xffffffffu) {
+        fork();
+        hipLaunchKernelGGL(k_expand_h, dim3(kHeavyGrid), dim3(kWave), 0, side, m.d, b, w, prm, (const HeavyItem*)c.items_h.p,
+                           item_h_cap);
+      }
+      hipLaunchKernelGGL(k_expand_a, dim3(b.nq + kExpandExtraGrid), dim3(kWave), 0, stream, m.d, b, w, prm,
+                         (const WorkItem*)c.items.p, item_cap, use_sig);
+      if (heavy_min != 0xffffffffu) join();
+      tick(); tick();  // "expand_a" = k_cmin + k_expand_a with k_expand_h beside it; "expand_b" = the token work
+      hipLaunchKernelGGL(k_caps_b, dim3((b.nq + 255) / 256), dim3(256), 0, stream, b, w, c.items_b.p, item_cap);
+      const size_t lds = (size_t)p_max * 4;
+      if (lds > 64 * 1024) throw UnsupportedError("patterns too long for the expand kernel's LDS staging");
+      hipLaunchKernelGGL(k_expand_b, dim3(b.nq + kExpandExtraGrid), dim3(kWave), lds, stream, m.d, b, w, prm,
+                         (const WorkItem*)c.items_b.p, item_cap);
+    }
+    tick(); tick();
+    hipLaunchKernelGGL(k_cand, dim3((b.nq + 3) / 4), dim3(256), 0, stream, b, w, c.big_list.p, c.mid_list.p);
+    {
+      // The sorter of the few huge survivor sets is one workgroup per query and leaves the GPU almost idle:
+      // it runs on the side stream next to k_cand_mid (disjoint queries).
+      // radix passes needed: sentence ids < n_sent, match lengths <= longest pattern
+      uint32_t sid_bytes = 1, len_bytes = p_max < 255 ? 1u : 2u;
+      while (sid_bytes < 4 && (m.d.n_sent >> (8 * sid_bytes)) != 0) sid_bytes++;
+      fork();
+      hipLaunchKernelGGL(k_cand_big, dim3(kBigGrid), dim3(kBigThreads), 0, side, w, c.keys.p,
+                         (const uint32_t*)c.big_list.p, sid_bytes, len_bytes);
+    }
+    hipLaunchKernelGGL(k_cand_mid, dim3(1024), dim3(256), 0, stream, w, (const uint32_t*)c.mid_list.p);
+    tick(); tick();
+    join();  // stage "cand_big" = what is left of the big sorter after k_cand_mid
+    tick(); tick();
+    {
+      // dense per-class candidate lists: three exclusive scans of the per-query candidate counts
+      const uint32_t n = b.nq + 1;
+      const uint32_t tiles = (n + kScanTile - 1) / kScanTile;
+      hipLaunchKernelGGL(k_classify, dim3((n + 255) / 256), dim3(256), 0, stream, b, w, full ? 1 : 0);
+      for (int k = 0; k < 3; k++) {
+        hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(kScanThreads), 0, stream, w.c_in + (size_t)k * n,
+                           w.c_off + (size_t)k * n, c.tile_sums.p, n);
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanThreads), 0, stream, c.tile_sums.p, tiles, c.grand_total.p);
+        hipLaunchKernelGGL(k_scan_add, dim3(tiles), dim3(kScanThreads), 0, stream, w.c_off + (size_t)k * n, c.tile_sums.p, n);
+      }
+      hipLaunchKernelGGL(k_cmap, dim3((b.nq + 255) / 256), dim3(256), 0, stream, b, w, full ? 1 : 0, c.fin_list.p);
+    }
+    tick(); tick();
+    {
+      const size_t lds = ((size_t)p_max + 1) * kWave * 4;
+      const bool rows_in_hbm = lds > kDynLdsMax;  // patterns too long for LDS rows: same kernel over rows in HBM
+      const unsigned grid = 256 * 16;  // grid-stride over the flat candidate list
+      const unsigned grid_g = 1024;
+      if (rows_in_hbm) c.g_rows.ensure((uint64_t)grid_g * kWave * (p_max + 1));
+      auto launch_rows = [&](bool with_side) {
+        if (with_side) {
+          if (rows_in_hbm) hipLaunchKernelGGL((k_dp<true, true>), dim3(grid_g), dim3(kWave), 0, stream, m.d, b, w, prm, c.g_rows.p, p_max + 1);
+          else hipLaunchKernelGGL((k_dp<true, false>), dim3(grid), dim3(kWave), lds, stream, m.d, b, w, prm, (float*)nullptr, 0u);
+        } else {
+          if (rows_in_hbm) hipLaunchKernelGGL((k_dp<false, true>), dim3(grid_g), dim3(kWave), 0, stream, m.d, b, w, prm, c.g_rows.p, p_max + 1);
+          else hipLaunchKernelGGL((k_dp<false, false>), dim3(grid), dim3(kWave), lds, stream, m.d, b, w, prm, (float*)nullptr, 0u);
+        }
+      };
+      if (full) {
+        launch_rows(true);
+      } else {
+        // by pattern length: row + pattern in 32 or 64 registers, longer ones with the row in LDS
+        if (use_idf) {
+          hipLaunchKernelGGL((k_dp_reg<32, true>), dim3(grid), dim3(kWave), 0, stream, m.d, b, w, prm);
+          if (p_max > 32) hipLaunchKernelGGL((k_dp_reg<64, true>), dim3(grid), dim3(kWave), 0, stream, m.d, b, w, prm);
+        } else if (prm.ins == prm.del && prm.del == prm.rep && prm.rep >= 0.f) {
+          // unit costs: bit-parallel Levenshtein distance, then the float sum the DP would have produced
+          // few registers: eight waves per SIMD hide the dependent loads in front of every candidate
+          hipLaunchKernelGGL((k_dp_reg<32, false, true>), dim3(grid), dim3(kWave), 0, stream, m.d, b, w, prm);
+          if (p_max > 32) hipLaunchKernelGGL((k_dp_reg<64, false, true>), dim3(grid), dim3(kWave), 0, stream, m.d, b, w, prm);
+        } else {
+          hipLaunchKernelGGL((k_dp_reg<32, false>), dim3(grid), dim3(kWave), 0, stream, m.d, b, w, prm);
+          if (p_max > 32) hipLaunchKernelGGL((k_dp_reg<64, false>), dim3(grid), dim3(kWave), 0, stream, m.d, b, w, prm);
+        }
+        if (p_max > 64) launch_rows(use_idf);
+      }
+    }
+    tick(); tick();
+    {
+      // the queue of large candidate sets was filled by k_cmap: their (long, mostly sequential) replay runs on the
+      // side stream next to the bulk kernel; the two touch disjoint queries
+      fork();
+      hipLaunchKernelGGL((k_finish<kLdsSortMax, true>), dim3(2048), dim3(kWave), 0, side, m.d, b, w, prm, DevScratch{c.keys.p, c.vals.p, c.f0.p, c.f1.p}, cap,
+                         d_out, d_out_count, d_out_total, c.contrast_list.p, c.fin_list.p);
+      hipLaunchKernelGGL((k_finish<64, false>), dim3(b.nq), dim3(kWave), 0, stream, m.d, b, w, prm, DevScratch{c.keys.p, c.vals.p, c.f0.p, c.f1.p}, cap, d_out,
+                         d_out_count, d_out_total, c.contrast_list.p, c.fin_list.p);
+      join();
+      const DevScratch sc{c.keys.p, c.vals.p, c.f0.p, c.f1.p};
+      if (prm.contrast > 0.f) {
+        const uint32_t* cl = c.contrast_list.p;
+        const bool flat = prm.nmatch >= 1 && prm.nmatch <= kMaxFlatRounds;
+        if (flat) {
+          // flattened rounds: pick, then one edit distance per remaining accepted match of any query
+          const uint32_t n = b.nq + 1;
+          const uint32_t tiles = (n + kScanTile - 1) / kScanTile;
+          hipLaunchKernelGGL(k_cacc, dim3((n + 255) / 256), dim3(256), 0, stream, b, w);
+          for (int k = 0; k < 2; k++) {
+            hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(kScanThreads), 0, stream, w.c_in + (size_t)k * n,
+                               w.c_off + (size_t)k * n, c.tile_sums.p, n);
+            hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanThreads), 0, stream, c.tile_sums.p, tiles, c.grand_total.p);
+            hipLaunchKernelGGL(k_scan_add, dim3(tiles), dim3(kScanThreads), 0, stream, w.c_off + (size_t)k * n, c.tile_sums.p, n);
+          }
+          hipLaunchKernelGGL(k_camap, dim3(b.nq), dim3(kWave), 0, stream, b, w, sc);
+          for (uint32_t r = 0; r < prm.nmatch; r++) {
+            if (r) {
+              hipLaunchKernelGGL(k_cdp<32>, dim3(256 * 16), dim3(kWave), 0, stream, m.d, b, w, prm, sc, r);
+              if (m.d.max_slen > 32)
+                hipLaunchKernelGGL(k_cdp<64>, dim3(256 * 8), dim3(kWave), 0, stream, m.d, b, w, prm, sc, r);
+            }
+            hipLaunchKernelGGL(k_cpick, dim3((b.nq + 255) / 256), dim3(256), 0, stream, m.d, b, w, prm, sc, r, cap, d_out, d_out_count,
+                               d_out_total);
+          }
+        } else {
+          hipLaunchKernelGGL(k_contrast<0>, dim3(b.nq), dim3(kWave), 0, stream, m.d, b, w, prm, sc, cap, d_out,
+                             d_out_count, d_out_total, cl, (float*)nullptr, 0u);
+        }
+        if (m.d.max_slen > 32 && !flat)
+          hipLaunchKernelGGL(k_contrast<1>, dim3(2048), dim3(kWave), 0, stream, m.d, b, w, prm, sc, cap, d_out,
+                             d_out_count, d_out_total, cl, (float*)nullptr, 0u);
+        if (m.d.max_slen > 64) {
+          const size_t lds = ((size_t)m.d.max_slen + 1) * kWave * 4;
+          if (lds > kDynLdsMax - 8 * 1024) {  // indexed sentences too long for LDS rows: rows in HBM
+            const unsigned grid_g = 512;
+            c.g_rows.ensure((uint64_t)grid_g * kWave * (m.d.max_slen + 1));
+            hipLaunchKernelGGL(k_contrast<3>, dim3(grid_g), dim3(kWave), 0, stream, m.d, b, w, prm, sc, cap, d_out,
+                               d_out_count, d_out_total, cl, c.g_rows.p, m.d.max_slen + 1);
+          } else {
+            hipLaunchKernelGGL(k_contrast<2>, dim3(512), dim3(kWave), lds, stream, m.d, b, w, prm, sc, cap, d_out,
+                               d_out_count, d_out_total, cl, (float*)nullptr, 0u);
+          }
+        }
+      }
+    }
+    tick();
+    hipLaunchKernelGGL(k_stats, dim3((b.nq + 1023) / 1024), dim3(1024), 0, stream, w, b.nq);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h_ctr_slot, w.counters, kNumCounters * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+}
+
+// what the counters of a finished pass ask for: true = re-run it (something was too small; it has been enlarged)
+static bool pass_needs_retry(Ctx& c, const unsigned long long* ctr, uint64_t& want_seg) {
+  const uint32_t item_cap = (uint32_t)std::min<uint64_t>(c.items.cap, 0xffffffffull);
+  const uint32_t item_h_cap = (uint32_t)std::min<uint64_t>(c.items_h.cap, 0xffffffffull);
+  bool retry = false;
+  if (ctr[6] > c.seg_cap) { want_seg = std::max<uint64_t>(want_seg, ctr[6] + ctr[6] / 4); retry = true; }   // segments did not fit
+  if (ctr[4] > c.s_max) {                                                          // a query had more survivors
+    unsigned long long s = c.s_max;
+    while (s < ctr[4] && s < (1ull << 31)) s <<= 1;
+    c.s_max = (uint32_t)std::min<unsigned long long>(s, 0x80000000ull);
+    if (ctr[4] > c.s_max) throw UnsupportedError("a query kept more than 2^31 hits");
+    retry = true;
+  }
+  if (std::max(ctr[5], ctr[12]) > item_cap) {                                      // work-item list too short
+    const unsigned long long need = std::max(ctr[5], ctr[12]);
+    const uint64_t nc = std::min<unsigned long long>(need + need / 4, 0xffffffffull);
+    c.items.ensure(nc); c.items_b.ensure(nc);
+    retry = true;
+  }
+  if (ctr[15] > item_h_cap) {                                                      // heavy-range item list too short
+    c.items_h.ensure(std::min<unsigned long long>(ctr[15] + ctr[15] / 4, 0xffffffffull));
+    retry = true;
+  }
+  return retry;
+}
+
+static void add_counters(Stats* st, const unsigned long long* ctr) {
+  if (!st) return;
+  st->n_hits += ctr[0]; st->n_kept += ctr[1]; st->n_candidates += ctr[2]; st->n_dp += ctr[3];
+  st->n_big += ctr[7]; st->n_phase_b += ctr[8]; st->max_kept = std::max<uint64_t>(st->max_kept, ctr[9]);
+  st->n_heavy_hits += ctr[16]; st->n_heavy_pass += ctr[17]; st->plane_words += ctr[18];
+  st->probe_bytes += ctr[19]; st->probe_lines += ctr[20];
+}
+
+constexpr uint32_t kAsyncGroup = 32;  // passes enqueued before the host looks at their counters
+
+// async_ok: the passes of a group are enqueued back to back (the host runs ahead of the GPU, no bubble between passes);
+// their counters are checked afterwards and a pass whose workspace was too small is re-run (first calls only).
+// Otherwise (device entry point with stage timing) each pass is synchronised and timed.
 static void run_passes(DeviceIndex::Impl& m, Ctx& c, const Params& prm_in, const DeviceBatchView& bv, Rec* d_out,
                        uint32_t* d_out_count, uint32_t* d_out_total, uint32_t cap, hipStream_t stream,
-                       const std::vector<uint32_t>& sub_tok_bounds, uint32_t sub_queries, Stats* st, const PassHooks* hooks) {
-  Params prm = prm_in;
+                       const std::vector<uint32_t>& sub_tok_bounds, uint32_t sub_queries, Stats* st, const PassHooks* hooks,
+                       bool async_ok) {
   if (cap == 0) throw std::invalid_argument("cap must be > 0");
   // cost model: real-token / penalty-token terms need the general kernel (DP rows in LDS / HBM); idf alone has a
   // register kernel
   const bool side_terms = (m.d.real && bv.q_real) || (bv.q_itok != nullptr) || (m.d.itok != nullptr);
-  const bool use_idf = prm.idf_penalty != 0.f;
-  const bool full = side_terms;
+  PassEnv E{m, c, prm_in, side_terms, prm_in.idf_penalty != 0.f, d_out, d_out_count, d_out_total, cap, stream};
   const uint32_t n_sub = (uint32_t)sub_tok_bounds.size() - 1;
-  for (uint32_t sb = 0; sb < n_sub; sb++) {
+  auto batch_of = [&](uint32_t sb) {
     DevBatch b;
     b.q_off = bv.q_off; b.q_tok = bv.q_tok; b.q_real = bv.q_real; b.q_itok = bv.q_itok;
     b.q_begin = sb * sub_queries;
     b.nq = (uint32_t)std::min<uint64_t>(sub_queries, bv.nq - b.q_begin);
     b.t_begin = sub_tok_bounds[sb];
     b.nt = sub_tok_bounds[sb + 1] - sub_tok_bounds[sb];
-    uint64_t want_seg = std::max<uint64_t>(c.seg_cap, std::min<uint64_t>(m.init_seg, std::max<uint64_t>(4096, (uint64_t)b.nq * 64)));
-    uint32_t p_max = (uint32_t)std::min<uint64_t>(prm.max_tokens, std::max<uint32_t>(b.nt, 1));
-    p_max = std::max<uint32_t>(1, std::min<uint32_t>(p_max, bv.p_max ? bv.p_max : p_max));
-    if (hooks && hooks->before) hooks->before(sb);
+    return b;
+  };
+  auto p_max_of = [&](const DevBatch& b) {
+    uint32_t p_max = (uint32_t)std::min<uint64_t>(E.prm.max_tokens, std::max<uint32_t>(b.nt, 1));
+    return std::max<uint32_t>(1, std::min<uint32_t>(p_max, bv.p_max ? bv.p_max : p_max));
+  };
+  auto seg_for = [&](const DevBatch& b) {
+    return std::max<uint64_t>(c.seg_cap, std::min<uint64_t>(m.init_seg, std::max<uint64_t>(4096, (uint64_t)b.nq * 64)));
+  };
+  // one pass, synchronised, re-run until its workspace fits
+  auto run_sync = [&](uint32_t sb, bool call_before, uint64_t want_seg) {
+    const DevBatch b = batch_of(sb);
+    const uint32_t p_max = p_max_of(b);
+    want_seg = std::max<uint64_t>(want_seg, seg_for(b));
+    if (call_before && hooks && hooks->before) hooks->before(sb);
     for (int attempt = 0;; attempt++) {
       ensure_ws(c, b.nq, std::max<uint32_t>(b.nt, 1), want_seg);
       c.cmin_tab.ensure((uint64_t)(p_max + 1) * kCminRow);
-      DevWork w = work_view(c);
-      const uint32_t item_cap = (uint32_t)std::min<uint64_t>(c.items.cap, 0xffffffffull);
-      const uint32_t item_h_cap = (uint32_t)std::min<uint64_t>(c.items_h.cap, 0xffffffffull);
-      HIP_TRY(hipMemsetAsync(w.q_hits, 0, (b.nq + 1) * sizeof(unsigned long long), stream));
-      HIP_TRY(hipMemsetAsync(w.q_hits_a, 0, (b.nq + 1) * sizeof(unsigned long long), stream));
-      HIP_TRY(hipMemsetAsync(w.counters, 0, kNumCounters * sizeof(unsigned long long), stream));
-      HIP_TRY(hipMemsetAsync(w.q_pb, 0, b.nq * sizeof(uint32_t), stream));
-      int e = 0;
-      auto tick = [&]() { HIP_TRY(hipEventRecord(c.ev[e++], stream)); };
-      // the signature bound needs theoretical_rejection_cover to be monotone in the cover: costs >= 0
-      const int use_sig = prm.ins >= 0.f && prm.del >= 0.f && prm.rep >= 0.f;
-      // suffix ranges of at least heavy_min hits are walked through the signature bit planes (k_expand_h)
-      const uint32_t heavy_min = (use_sig && m.d.planes && m.heavy_min) ? std::max<uint32_t>(m.heavy_min, 256u) : 0xffffffffu;
-      tick();
-      hipLaunchKernelGGL(k_setup, dim3((b.nq + 255) / 256), dim3(256), 0, stream, m.d, b, w, prm);
-      if (prm.idf_penalty != 0.f) hipLaunchKernelGGL(k_tidf, dim3((b.nt + 255) / 256), dim3(256), 0, stream, m.d, b, w);
-      HIP_TRY(hipMemsetAsync(w.p_hist, 0, 2 * kPBins * sizeof(uint32_t), stream));
-      {
-        const uint32_t per_block = kRankThreads * kRankPer;
-        hipLaunchKernelGGL(k_phist, dim3((b.nq + per_block - 1) / per_block), dim3(kRankThreads), 0, stream, b, w);
-        hipLaunchKernelGGL(k_prank, dim3((b.nq + per_block - 1) / per_block), dim3(kRankThreads), 0, stream, b, w);
-      }
-      tick(); tick();
-      if (b.nt) {
-        if (m.probe_count)  // measurement runs only: the same kernel, also counting the bytes / lines it requests
-          hipLaunchKernelGGL(k_probe<true>, dim3((b.nt + 63) / 64), dim3(64), 0, stream, m.d, b, w, heavy_min, c.items_h.p, item_h_cap);
-        else
-          hipLaunchKernelGGL(k_probe<false>, dim3((b.nt + 63) / 64), dim3(64), 0, stream, m.d, b, w, heavy_min, c.items_h.p, item_h_cap);
-      }
-      tick(); tick();
-      {
-        hipLaunchKernelGGL(k_caps, dim3((b.nq + 1 + 255) / 256), dim3(256), 0, stream, b, w, c.items.p, item_cap, c.s_max);
-        const uint32_t n = b.nq + 1;  // one extra so that q_seg[nq] = total
-        const uint32_t tiles = (n + kScanTile - 1) / kScanTile;
-        if (tiles > (uint32_t)kScanTile) throw std::invalid_argument("sub-batch too large for the scan");
-        hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(kScanThreads), 0, stream, w.q_cap, w.q_seg, c.tile_sums.p, n);
-        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanThreads), 0, stream, c.tile_sums.p, tiles, c.grand_total.p);
-        hipLaunchKernelGGL(k_scan_add, dim3(tiles), dim3(kScanThreads), 0, stream, w.q_seg, c.tile_sums.p, n);
-      }
-      tick(); tick();
-      // fork: `side` continues after everything enqueued on `stream` so far; join: `stream` waits for `side`
-      const hipStream_t side = m.serial ? stream : c.side;
-      auto fork = [&]() { if (!m.serial) { HIP_TRY(hipEventRecord(c.ev_fork, stream)); HIP_TRY(hipStreamWaitEvent(c.side, c.ev_fork, 0)); } };
-      auto join = [&]() { if (!m.serial) { HIP_TRY(hipEventRecord(c.ev_join, c.side)); HIP_TRY(hipStreamWaitEvent(stream, c.ev_join, 0)); } };
-      {
-        hipLaunchKernelGGL(k_cmin, dim3(p_max + 1), dim3(256), 0, stream, m.d.max_slen, prm, use_sig, c.cmin_tab.p);
-        // the few long ranges stream through the bit planes on the side stream next to the per-hit walk of
-        // everything else: both append to the per-query queues of k_expand_b
-        if (heavy_min != 0xffffffffu) {
-          fork();
-          hipLaunchKernelGGL(k_expand_h, dim3(kHeavyGrid), dim3(kWave), 0, side, m.d, b, w, prm, (const HeavyItem*)c.items_h.p,
-                             item_h_cap);
-        }
-        hipLaunchKernelGGL(k_expand_a, dim3(b.nq + kExpandExtraGrid), dim3(kWave), 0, stream, m.d, b, w, prm,
-                           (const WorkItem*)c.items.p, item_cap, use_sig);
-        if (heavy_min != 0xffffffffu) join();
-        tick(); tick();  // "expand_a" = k_cmin + k_expand_a with k_expand_h beside it; "expand_b" = the token work
-        hipLaunchKernelGGL(k_caps_b, dim3((b.nq + 255) / 256), dim3(256), 0, stream, b, w, c.items_b.p, item_cap);
-        const size_t lds = (size_t)p_max * 4;
-        if (lds > 64 * 1024) throw UnsupportedError("patterns too long for the expand kernel's LDS staging");
-        hipLaunchKernelGGL(k_expand_b, dim3(b.nq + kExpandExtraGrid), dim3(kWave), lds, stream, m.d, b, w, prm,
-                           (const WorkItem*)c.items_b.p, item_cap);
-      }
-      tick(); tick();
-      hipLaunchKernelGGL(k_cand, dim3((b.nq + 3) / 4), dim3(256), 0, stream, b, w, c.big_list.p, c.mid_list.p);
-      {
-        // The sorter of the few huge survivor sets is one workgroup per query and leaves the GPU almost idle:
-        // it runs on the side stream next to k_cand_mid (disjoint queries).
-        // radix passes needed: sentence ids < n_sent, match lengths <= longest pattern
-        uint32_t sid_bytes = 1, len_bytes = p_max < 255 ? 1u : 2u;
-        while (sid_bytes < 4 && (m.d.n_sent >> (8 * sid_bytes)) != 0) sid_bytes++;
-        fork();
-        hipLaunchKernelGGL(k_cand_big, dim3(kBigGrid), dim3(kBigThreads), 0, side, w, c.keys.p,
-                           (const uint32_t*)c.big_list.p, sid_bytes, len_bytes);
-      }
-      hipLaunchKernelGGL(k_cand_mid, dim3(1024), dim3(256), 0, stream, w, (const uint32_t*)c.mid_list.p);
-      tick(); tick();
-      join();  // stage "cand_big" = what is left of the big sorter after k_cand_mid
-      tick(); tick();
-      {
-        // dense per-class candidate lists: three exclusive scans of the per-query candidate counts
-        const uint32_t n = b.nq + 1;
-        const uint32_t tiles = (n + kScanTile - 1) / kScanTile;
-        hipLaunchKernelGGL(k_classify, dim3((n + 255) / 256), dim3(256), 0, stream, b, w, full ? 1 : 0);
-        for (int k = 0; k < 3; k++) {
-          hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(kScanThreads), 0, stream, w.c_in + (size_t)k * n,
-                             w.c_off + (size_t)k * n, c.tile_sums.p, n);
-          hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanThreads), 0, stream, c.tile_sums.p, tiles, c.grand_total.p);
-          hipLaunchKernelGGL(k_scan_add, dim3(tiles), dim3(kScanThreads), 0, stream, w.c_off + (size_t)k * n, c.tile_sums.p, n);
-        }
-        hipLaunchKernelGGL(k_cmap, dim3((b.nq + 255) / 256), dim3(256), 0, stream, b, w, full ? 1 : 0, c.fin_list.p);
-      }
-      tick(); tick();
-      {
-        const size_t lds = ((size_t)p_max + 1) * kWave * 4;
-        const bool rows_in_hbm = lds > kDynLdsMax;  // patterns too long for LDS rows: same kernel over rows in HBM
-        const unsigned grid = 256 * 16;  // grid-stride over the flat candidate list
-        const unsigned grid_g = 1024;
-        if (rows_in_hbm) c.g_rows.ensure((uint64_t)grid_g * kWave * (p_max + 1));
-        auto launch_rows = [&](bool with_side) {
-          if (with_side) {
-            if (rows_in_hbm) hipLaunchKernelGGL((k_dp<true, true>), dim3(grid_g), dim3(kWave), 0, stream, m.d, b, w, prm, c.g_rows.p, p_max + 1);
-            else hipLaunchKernelGGL((k_dp<true, false>), dim3(grid), dim3(kWave), lds, stream, m.d, b, w, prm, (float*)nullptr, 0u);
-          } else {
-            if (rows_in_hbm) hipLaunchKernelGGL((k_dp<false, true>), dim3(grid_g), dim3(kWave), 0, stream, m.d, b, w, prm, c.g_rows.p, p_max + 1);
-            else hipLaunchKernelGGL((k_dp<false, false>), dim3(grid), dim3(kWave), lds, stream, m.d, b, w, prm, (float*)nullptr, 0u);
-          }
-        };
-        if (full) {
-          launch_rows(true);
-        } else {
-          // by pattern length: row + pattern in 32 or 64 registers, longer ones with the row in LDS
-          if (use_idf) {
-            hipLaunchKernelGGL((k_dp_reg<32, true>), dim3(grid), dim3(kWave), 0, stream, m.d, b, w, prm);
-            if (p_max > 32) hipLaunchKernelGGL((k_dp_reg<64, true>), dim3(grid), dim3(kWave), 0, stream, m.d, b, w, prm);
-          } else if (prm.ins == prm.del && prm.del == prm.rep && prm.rep >= 0.f) {
-            // unit costs: bit-parallel Levenshtein distance, then the float sum the DP would have produced
-            // few registers: eight waves per SIMD hide the dependent loads in front of every candidate
-            hipLaunchKernelGGL((k_dp_reg<32, false, true>), dim3(grid), dim3(kWave), 0, stream, m.d, b, w, prm);
-            if (p_max > 32) hipLaunchKernelGGL((k_dp_reg<64, false, true>), dim3(grid), dim3(kWave), 0, stream, m.d, b, w, prm);
-          } else {
-            hipLaunchKernelGGL((k_dp_reg<32, false>), dim3(grid), dim3(kWave), 0, stream, m.d, b, w, prm);
-            if (p_max > 32) hipLaunchKernelGGL((k_dp_reg<64, false>), dim3(grid), dim3(kWave), 0, stream, m.d, b, w, prm);
-          }
-          if (p_max > 64) launch_rows(use_idf);
-        }
-      }
-      tick(); tick();
-      {
-        // the queue of large candidate sets was filled by k_cmap: their (long, mostly sequential) replay runs on the
-        // side stream next to the bulk kernel; the two touch disjoint queries
-        fork();
-        hipLaunchKernelGGL((k_finish<kLdsSortMax, true>), dim3(2048), dim3(kWave), 0, side, m.d, b, w, prm, DevScratch{c.keys.p, c.vals.p, c.f0.p, c.f1.p}, cap,
-                           d_out, d_out_count, d_out_total, c.contrast_list.p, c.fin_list.p);
-        hipLaunchKernelGGL((k_finish<64, false>), dim3(b.nq), dim3(kWave), 0, stream, m.d, b, w, prm, DevScratch{c.keys.p, c.vals.p, c.f0.p, c.f1.p}, cap, d_out,
-                           d_out_count, d_out_total, c.contrast_list.p, c.fin_list.p);
-        join();
-        const DevScratch sc{c.keys.p, c.vals.p, c.f0.p, c.f1.p};
-        if (prm.contrast > 0.f) {
-          const uint32_t* cl = c.contrast_list.p;
-          const bool flat = prm.nmatch >= 1 && prm.nmatch <= kMaxFlatRounds;
-          if (flat) {
-            // flattened rounds: pick, then one edit distance per remaining accepted match of any query
-            const uint32_t n = b.nq + 1;
-            const uint32_t tiles = (n + kScanTile - 1) / kScanTile;
-            hipLaunchKernelGGL(k_cacc, dim3((n + 255) / 256), dim3(256), 0, stream, b, w);
-            for (int k = 0; k < 2; k++) {
-              hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(kScanThreads), 0, stream, w.c_in + (size_t)k * n,
-                                 w.c_off + (size_t)k * n, c.tile_sums.p, n);
-              hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanThreads), 0, stream, c.tile_sums.p, tiles, c.grand_total.p);
-              hipLaunchKernelGGL(k_scan_add, dim3(tiles), dim3(kScanThreads), 0, stream, w.c_off + (size_t)k * n, c.tile_sums.p, n);
-            }
-            hipLaunchKernelGGL(k_camap, dim3(b.nq), dim3(kWave), 0, stream, b, w, sc);
-            for (uint32_t r = 0; r < prm.nmatch; r++) {
-              if (r) {
-                hipLaunchKernelGGL(k_cdp<32>, dim3(256 * 16), dim3(kWave), 0, stream, m.d, b, w, prm, sc, r);
-                if (m.d.max_slen > 32)
-                  hipLaunchKernelGGL(k_cdp<64>, dim3(256 * 8), dim3(kWave), 0, stream, m.d, b, w, prm, sc, r);
-              }
-              hipLaunchKernelGGL(k_cpick, dim3((b.nq + 255) / 256), dim3(256), 0, stream, m.d, b, w, prm, sc, r, cap, d_out, d_out_count,
-                                 d_out_total);
-            }
-          } else {
-            hipLaunchKernelGGL(k_contrast<0>, dim3(b.nq), dim3(kWave), 0, stream, m.d, b, w, prm, sc, cap, d_out,
-                               d_out_count, d_out_total, cl, (float*)nullptr, 0u);
-          }
-          if (m.d.max_slen > 32 && !flat)
-            hipLaunchKernelGGL(k_contrast<1>, dim3(2048), dim3(kWave), 0, stream, m.d, b, w, prm, sc, cap, d_out,
-                               d_out_count, d_out_total, cl, (float*)nullptr, 0u);
-          if (m.d.max_slen > 64) {
-            const size_t lds = ((size_t)m.d.max_slen + 1) * kWave * 4;
-            if (lds > kDynLdsMax - 8 * 1024) {  // indexed sentences too long for LDS rows: rows in HBM
-              const unsigned grid_g = 512;
-              c.g_rows.ensure((uint64_t)grid_g * kWave * (m.d.max_slen + 1));
-              hipLaunchKernelGGL(k_contrast<3>, dim3(grid_g), dim3(kWave), 0, stream, m.d, b, w, prm, sc, cap, d_out,
-                                 d_out_count, d_out_total, cl, c.g_rows.p, m.d.max_slen + 1);
-            } else {
-              hipLaunchKernelGGL(k_contrast<2>, dim3(512), dim3(kWave), lds, stream, m.d, b, w, prm, sc, cap, d_out,
-                                 d_out_count, d_out_total, cl, (float*)nullptr, 0u);
-            }
-          }
-        }
-      }
-      tick();
-      hipLaunchKernelGGL(k_stats, dim3((b.nq + 1023) / 1024), dim3(1024), 0, stream, w, b.nq);
-      HIP_TRY(hipGetLastError());
-      HIP_TRY(hipMemcpyAsync(c.h_ctr, w.counters, kNumCounters * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+      enqueue_pass(E, b, p_max, st != nullptr, c.h_ctr);
       HIP_TRY(hipStreamSynchronize(stream));
-      const unsigned long long* ctr = c.h_ctr;
       if (st) {
         for (int s = 0; s < kNumStages; s++) {
           float ms = 0.f;
@@ -576,39 +650,57 @@ static void run_passes(DeviceIndex::Impl& m, Ctx& c, const Params& prm_in, const
           st->launches[s] += 1;
         }
       }
-      bool retry = false;
-      if (ctr[6] > c.seg_cap) { want_seg = ctr[6] + ctr[6] / 4; retry = true; }         // segments did not fit
-      if (ctr[4] > c.s_max) {                                                          // a query had more survivors
-        unsigned long long s = c.s_max;
-        while (s < ctr[4] && s < (1ull << 31)) s <<= 1;
-        c.s_max = (uint32_t)std::min<unsigned long long>(s, 0x80000000ull);
-        if (ctr[4] > c.s_max) throw UnsupportedError("a query kept more than 2^31 hits");
-        retry = true;
-      }
-      if (std::max(ctr[5], ctr[12]) > item_cap) {                                      // work-item list too short
-        const unsigned long long need = std::max(ctr[5], ctr[12]);
-        const uint64_t nc = std::min<unsigned long long>(need + need / 4, 0xffffffffull);
-        c.items.ensure(nc); c.items_b.ensure(nc);
-        retry = true;
-      }
-      if (ctr[15] > item_h_cap) {                                                      // heavy-range item list too short
-        c.items_h.ensure(std::min<unsigned long long>(ctr[15] + ctr[15] / 4, 0xffffffffull));
-        retry = true;
-      }
-      if (retry) {
+      if (pass_needs_retry(c, c.h_ctr, want_seg)) {
         if (attempt >= 6) throw GpuError("workspace kept overflowing");
         if (st) st->n_retries++;
         continue;
       }
-      if (st) {
-        st->n_hits += ctr[0]; st->n_kept += ctr[1]; st->n_candidates += ctr[2]; st->n_dp += ctr[3];
-        st->n_big += ctr[7]; st->n_phase_b += ctr[8]; st->max_kept = std::max<uint64_t>(st->max_kept, ctr[9]);
-        st->n_heavy_hits += ctr[16]; st->n_heavy_pass += ctr[17]; st->plane_words += ctr[18];
-        st->probe_bytes += ctr[19]; st->probe_lines += ctr[20];
-      }
+      add_counters(st, c.h_ctr);
       break;
     }
-    if (hooks && hooks->after) hooks->after(sb);
+    if (hooks && hooks->after) hooks->after(sb, nullptr);
+  };
+  if (!async_ok) {
+    for (uint32_t sb = 0; sb < n_sub; sb++) run_sync(sb, true, 0);
+    return;
+  }
+  if (!c.h_ctr_group) HIP_TRY(hipHostMalloc((void**)&c.h_ctr_group, (size_t)kAsyncGroup * kNumCounters * sizeof(unsigned long long), hipHostMallocDefault));
+  while (c.ev_pass.size() < kAsyncGroup) {
+    hipEvent_t e;
+    HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    c.ev_pass.push_back(e);
+  }
+  for (uint32_t g0 = 0; g0 < n_sub; g0 += kAsyncGroup) {
+    const uint32_t g1 = std::min<uint32_t>(g0 + kAsyncGroup, n_sub);
+    // the workspace of the largest pass of the group, once (growing it later would wait for the passes in flight)
+    uint64_t nq_max = 1, nt_max = 1, seg_max = 0;
+    uint32_t pm_max = 1;
+    for (uint32_t sb = g0; sb < g1; sb++) {
+      const DevBatch b = batch_of(sb);
+      nq_max = std::max<uint64_t>(nq_max, b.nq); nt_max = std::max<uint64_t>(nt_max, b.nt);
+      seg_max = std::max<uint64_t>(seg_max, seg_for(b)); pm_max = std::max(pm_max, p_max_of(b));
+    }
+    ensure_ws(c, nq_max, nt_max, seg_max);
+    c.cmin_tab.ensure((uint64_t)(pm_max + 1) * kCminRow);
+    for (uint32_t sb = g0; sb < g1; sb++) {
+      const DevBatch b = batch_of(sb);
+      if (hooks && hooks->before) hooks->before(sb);
+      enqueue_pass(E, b, p_max_of(b), false, c.h_ctr_group + (size_t)(sb - g0) * kNumCounters);
+      HIP_TRY(hipEventRecord(c.ev_pass[sb - g0], stream));
+      if (hooks && hooks->after) hooks->after(sb, c.ev_pass[sb - g0]);
+    }
+    HIP_TRY(hipStreamSynchronize(stream));
+    uint64_t want_seg = 0;
+    std::vector<uint32_t> redo;
+    for (uint32_t sb = g0; sb < g1; sb++) {
+      const unsigned long long* ctr = c.h_ctr_group + (size_t)(sb - g0) * kNumCounters;
+      if (pass_needs_retry(c, ctr, want_seg)) redo.push_back(sb);
+      else add_counters(st, ctr);
+    }
+    for (uint32_t sb : redo) {
+      if (st) st->n_retries++;
+      run_sync(sb, false, want_seg);
+    }
   }
 }
 
@@ -624,7 +716,7 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm, const Devi
   // the caller's stream carries the work (NULL = the context's own stream)
   hipStream_t stream = stream_v ? (hipStream_t)stream_v : lease.c->stream;
   if (!stream_v) HIP_TRY(hipDeviceSynchronize());  // inputs may have been produced on other streams
-  run_passes(m, *lease.c, prm, bv, d_out, d_out_count, d_out_total, cap, stream, sub_tok_bounds, m.sub_queries, st, nullptr);
+  run_passes(m, *lease.c, prm, bv, d_out, d_out_count, d_out_total, cap, stream, sub_tok_bounds, m.sub_queries, st, nullptr, false);
 }
 
 static bool is_pinned(const void* p) {
@@ -703,9 +795,10 @@ void DeviceIndex::match_host(const HostIndex& h, const Params& prm, const HostBa
     HIP_TRY(hipStreamWaitEvent(c.stream, c.ev_in[s % kMaxPassesInFlight], 0));
     if (s + 1 < n_sub) send(s + 1);  // travels while pass s computes
   };
-  hooks.after = [&](uint32_t s) {  // pass s is complete (run_passes synchronised the stream): its records go home
+  hooks.after = [&](uint32_t s, hipEvent_t done) {  // the records of pass s go home once `done` (null: already complete)
     const auto a = std::chrono::steady_clock::now();
     const uint64_t q0 = (uint64_t)s * sub, q1 = std::min<uint64_t>(q0 + sub, nq), n = q1 - q0;
+    if (done) HIP_TRY(hipStreamWaitEvent(c.d2h, done, 0));
     HIP_TRY(hipMemcpyAsync(out + q0 * cap, c.d_out.p + q0 * cap, n * cap * sizeof(Rec), hipMemcpyDeviceToHost, c.d2h));
     HIP_TRY(hipMemcpyAsync(out_count + q0, c.d_cnt.p + q0, n * 4, hipMemcpyDeviceToHost, c.d2h));
     if (out_total) HIP_TRY(hipMemcpyAsync(out_total + q0, c.d_tot.p + q0, n * 4, hipMemcpyDeviceToHost, c.d2h));
@@ -715,7 +808,8 @@ void DeviceIndex::match_host(const HostIndex& h, const Params& prm, const HostBa
     }
     ms_d2h += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
   };
-  run_passes(m, c, prm, bv, c.d_out.p, c.d_cnt.p, c.d_tot.p, cap, c.stream, bounds, sub, st, &hooks);
+  // stage timing (st with events) is the device entry point's job: here the passes run back to back, unsynchronised
+  run_passes(m, c, prm, bv, c.d_out.p, c.d_cnt.p, c.d_tot.p, cap, c.stream, bounds, sub, st, &hooks, true);
   const auto a = std::chrono::steady_clock::now();
   HIP_TRY(hipStreamSynchronize(c.d2h));
   ms_d2h += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();

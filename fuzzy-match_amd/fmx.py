@@ -73,7 +73,9 @@ EXPORTS = [
     "fmx_index_lookup_real", "fmx_index_intern_itok", "fmx_index_sentence_id", "fmx_index_array",
     "fmx_index_get_info", "fmx_match_batch", "fmx_match_batch_device", "fmx_set_option",
     "fmx_host_alloc", "fmx_host_free", "fmx_index_to_devices", "fmx_set_devices", "fmx_index_reopen", "fmx_match_one", "fmx_match_batch_keep",
-    "fmx_subsequence_batch",
+    "fmx_subsequence_batch", "fmx_text_tokenize", "fmx_text_free", "fmx_text_num_tokens", "fmx_text_norm", "fmx_text_real",
+    "fmx_text_num_itoks", "fmx_text_itok_index", "fmx_text_itok", "fmx_text_num_raw", "fmx_text_raw", "fmx_text_map",
+    "fmx_text_detokenize", "fmx_index_add_text",
 ]
 TM_SKIPPED = -100
 
@@ -138,6 +140,25 @@ def lib():
                                 C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.fmx_subsequence_batch.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_uint32, C.c_int32, C.c_int32, C.c_float,
                                         C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.fmx_text_tokenize.restype = C.c_void_p
+    L.fmx_text_tokenize.argtypes = [C.c_int32, C.c_char_p, C.c_size_t]
+    L.fmx_text_free.argtypes = [C.c_void_p]
+    for name in ("num_tokens", "num_itoks", "num_raw"):
+        f = getattr(L, "fmx_text_" + name)
+        f.restype = C.c_uint32
+        f.argtypes = [C.c_void_p]
+    for name in ("norm", "real", "itok", "raw"):
+        f = getattr(L, "fmx_text_" + name)
+        f.restype = C.c_char_p
+        f.argtypes = [C.c_void_p, C.c_uint32]
+    L.fmx_text_itok_index.restype = C.c_uint64
+    L.fmx_text_itok_index.argtypes = [C.c_void_p, C.c_uint32]
+    L.fmx_text_map.restype = C.c_uint32
+    L.fmx_text_map.argtypes = [C.c_void_p, C.c_uint32]
+    L.fmx_text_detokenize.restype = C.c_char_p
+    L.fmx_text_detokenize.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+    L.fmx_index_add_text.restype = C.c_int64
+    L.fmx_index_add_text.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t]
     _lib = L
     return L
 
@@ -200,6 +221,37 @@ def pinned_free(arr):
     _pinned_blocks.pop(arr.ctypes.data, None)
 
 
+def tokenize(pt, sentence):
+    """FuzzyMatch::_tokenize_and_normalize through the restricted text front-end (fmx_text_tokenize).
+    Returns dict(norm, real, itoks {index: str}, raw, map)."""
+    L = lib()
+    b = sentence.encode("utf-8")
+    h = L.fmx_text_tokenize(pt, b, len(b))
+    if not h:
+        raise MemoryError("fmx_text_tokenize failed")
+    try:
+        n = L.fmx_text_num_tokens(h)
+        d = lambda x: x.decode("utf-8", "replace")  # noqa: E731
+        return {"norm": [d(L.fmx_text_norm(h, i)) for i in range(n)],
+                "real": [d(L.fmx_text_real(h, i)) for i in range(n)],
+                "itoks": {int(L.fmx_text_itok_index(h, k)): d(L.fmx_text_itok(h, k)) for k in range(L.fmx_text_num_itoks(h))},
+                "raw": [d(L.fmx_text_raw(h, i)) for i in range(L.fmx_text_num_raw(h))],
+                "map": [int(L.fmx_text_map(h, k)) for k in range(n + 1)]}
+    finally:
+        L.fmx_text_free(h)
+
+
+def detokenize_span(pt, sentence, start, end):
+    """Detokenised raw tokens behind the normalised tokens [start, end) of `sentence` (subsequence()'s Match::id suffix)."""
+    L = lib()
+    b = sentence.encode("utf-8")
+    h = L.fmx_text_tokenize(pt, b, len(b))
+    try:
+        return L.fmx_text_detokenize(h, start, end).decode("utf-8", "replace")
+    finally:
+        L.fmx_text_free(h)
+
+
 class Index:
     """Handle on an fmx_index (FuzzyMatch + SuffixArrayIndex of the reference)."""
 
@@ -245,6 +297,16 @@ class Index:
         r = lib().fmx_index_add_tm(self.h, sid.encode("utf-8"), arr, len(norm), real_s, n, idx, strs)
         if r == TM_SKIPPED:
             return -1  # ignored like the reference ignores it (empty / too long)
+        if r < 0:
+            _check(int(r))
+        return int(r)
+
+    def add_text(self, sid, sentence):
+        """add_tm(id, sentence): tokenised by the restricted text front-end; -1 = empty segment, not indexed."""
+        b = sentence.encode("utf-8")
+        r = lib().fmx_index_add_text(self.h, sid.encode("utf-8"), b, len(b))
+        if r == TM_SKIPPED:
+            return -1
         if r < 0:
             _check(int(r))
         return int(r)

@@ -227,6 +227,30 @@ int fmx_subsequence_batch(fmx_index*, const fmx_batch* host_batch, uint32_t numb
                           int32_t min_subseq_length, float min_subseq_ratio, int32_t idf_weighting,
                           fmx_match* out, uint32_t* out_found, uint32_t* out_position);
 
+/* ---- text front-end ------------------------------------------------------------------------
+ * FuzzyMatch::_tokenize_and_normalize — src/fuzzy_match.cc:108-193: tokenise a sentence and split it into the
+ * normalised tokens (`pattern`), the real tokens and the penalty strings (`real`) according to the penalty-token mask
+ * pt.  The tokenizer is a restricted restatement of the one the reference configures (src/fuzzy_match.cc:70-91,
+ * OpenNMT Tokenizer, aggressive mode) — see fuzzy-match_amd/csrc/fmx_text.hh for what it covers; ICU NFC
+ * normalisation is not applied.  The handle owns every string it returns. */
+typedef struct fmx_text fmx_text;
+fmx_text*   fmx_text_tokenize(int32_t pt, const char* sentence, size_t len);
+void        fmx_text_free(fmx_text*);
+uint32_t    fmx_text_num_tokens(const fmx_text*);               /* normalised tokens */
+const char* fmx_text_norm(const fmx_text*, uint32_t i);
+const char* fmx_text_real(const fmx_text*, uint32_t i);
+uint32_t    fmx_text_num_itoks(const fmx_text*);                /* penalty strings, ascending real-token index */
+uint64_t    fmx_text_itok_index(const fmx_text*, uint32_t k);
+const char* fmx_text_itok(const fmx_text*, uint32_t k);
+uint32_t    fmx_text_num_raw(const fmx_text*);                  /* tokenizer output (`tokens`, src/fuzzy_match.cc:113) */
+const char* fmx_text_raw(const fmx_text*, uint32_t i);
+uint32_t    fmx_text_map(const fmx_text*, uint32_t k);          /* map_tokens[k], k in [0, num_tokens] */
+/* detokenised raw tokens [map[from], map[to]) — what subsequence() appends to Match::id (src/fuzzy_match.cc:341-348) */
+const char* fmx_text_detokenize(fmx_text*, uint32_t from, uint32_t to);
+/* FuzzyMatch::add_tm(id, sentence) — src/fuzzy_match.cc:213-224: FMX_TM_SKIPPED for an empty segment (the reference
+ * warns on stderr and returns false) */
+int64_t fmx_index_add_text(fmx_index*, const char* id, const char* sentence, size_t len);
+
 /* tuning knobs (all have sane defaults):
  *   "contexts"          concurrent calls served at once per device, each with its own workspace (default 2)
  *   "heavy_min"         suffix ranges at least this long are tested through the bit planes (default 1024, 0 = never)

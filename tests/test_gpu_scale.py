@@ -163,7 +163,7 @@ def test_c3_headline_config_parity(fmx, gpu_device):
     assert st3.n_heavy_hits > st3.n_hits // 2 and st3.n_heavy_pass < st3.n_heavy_hits // 10, (st3.n_hits, st3.n_heavy_hits, st3.n_heavy_pass)
     ix.set_option("heavy_min", 0)  # and the per-hit walk alone gives the same records
     g3, c3_, _ = ix.match_batch(fmx.Params(**workloads.PARAM_SETS["C3"]), so, st, cap=5)
-    assert np.array_equal(c3_, gc[:m]) and g3.tobytes() == go[:m].tobytes()
+    workloads.compare(go[:m], gc[:m], g3, c3_, "per-hit walk vs bit planes")  # entries beyond the count are unspecified
 
 
 def test_gpu_sort_equals_independent_oracle_sort_at_1m(fmx, c2):
