@@ -101,7 +101,7 @@ constexpr int kMaxPassesInFlight = 2;
 struct Ctx {
   // ---- workspace ----
   Grow<uint32_t> q_m, q_kept, q_cand, q_acc, q_pb, q_aux, q_rank, big_list, mid_list, fin_list, contrast_list;
-  Grow<unsigned long long> q_hits, q_hits_a, q_seg, q_cap, c_in, c_off;
+  Grow<unsigned long long> q_hits, q_hits_a, q_seg, q_qseg, q_cap, c_in, c_off;
   Grow<uint32_t> t_q, t_lo, t_cnt;
   Grow<float>    t_idf;
   Grow<unsigned long long> c_qi, keys;
@@ -116,7 +116,9 @@ struct Ctx {
   Grow<uint16_t> cmin_tab;
   Grow<float>    g_rows;      // DP rows in HBM for patterns / sentences too long for the LDS rows
   uint32_t s_max = 4096;      // survivors kept per query before a retry with a larger segment
+  uint32_t heavy_div = 16;    // share of a query's long-range hits its queue reserves room for (1 / heavy_div)
   uint64_t seg_cap = 0;
+  uint64_t want_qb = 1ull << 24;  // queue entries (8 bytes each) wanted: grows when a pass reports more
   // ---- staging of the host-buffer entry point (each buffer tracks its own capacity) ----
   Grow<uint32_t> d_qoff, d_qtok, d_qreal, d_qitok, d_cnt, d_tot;
   Grow<Rec>      d_out;
@@ -149,7 +151,7 @@ struct Ctx {
   void destroy() {
     q_m.release(); q_kept.release(); q_cand.release(); q_acc.release(); q_pb.release(); q_aux.release(); q_rank.release();
     big_list.release(); mid_list.release(); fin_list.release(); contrast_list.release();
-    q_hits.release(); q_hits_a.release(); q_seg.release(); q_cap.release(); c_in.release(); c_off.release();
+    q_hits.release(); q_hits_a.release(); q_seg.release(); q_qseg.release(); q_cap.release(); c_in.release(); c_off.release();
     t_q.release(); t_lo.release(); t_cnt.release(); t_idf.release(); c_qi.release(); keys.release(); seg.release(); qb.release();
     heap.release(); f0.release(); f1.release(); vals.release(); p_hist.release(); counters.release(); tile_sums.release();
     grand_total.release(); items.release(); items_b.release(); items_h.release(); cmin_tab.release(); g_rows.release();
@@ -324,23 +326,24 @@ void DeviceIndex::upload(const HostIndex& h, int device) {
 static void ensure_ws(Ctx& c, uint64_t nq, uint64_t nt, uint64_t seg) {
   c.q_m.ensure(nq); c.q_kept.ensure(nq); c.q_cand.ensure(nq); c.q_acc.ensure(nq); c.q_pb.ensure(nq); c.q_aux.ensure(nq);
   c.q_rank.ensure(nq); c.big_list.ensure(nq); c.mid_list.ensure(nq); c.fin_list.ensure(nq); c.contrast_list.ensure(2 * nq);
-  c.q_hits.ensure(nq + 1); c.q_hits_a.ensure(nq + 1); c.q_seg.ensure(nq + 1); c.q_cap.ensure(nq + 1);
+  c.q_hits.ensure(nq + 1); c.q_hits_a.ensure(nq + 1); c.q_seg.ensure(nq + 1); c.q_qseg.ensure(nq + 1); c.q_cap.ensure(nq + 1);
   c.c_in.ensure(3 * (nq + 1)); c.c_off.ensure(3 * (nq + 1));
   c.t_q.ensure(nt); c.t_lo.ensure(nt); c.t_cnt.ensure(nt); c.t_idf.ensure(nt);
   if (seg > c.seg_cap) {
     const uint64_t s = std::max<uint64_t>(seg, c.seg_cap + c.seg_cap / 2);
-    c.c_qi.ensure(s); c.seg.ensure(s); c.qb.ensure(s); c.f0.ensure(s); c.f1.ensure(s);
+    c.c_qi.ensure(s); c.seg.ensure(s); c.f0.ensure(s); c.f1.ensure(s);
     c.keys.ensure(2 * s); c.vals.ensure(2 * s);
     c.seg_cap = s;
   }
   c.heap.ensure(c.seg_cap + nq + 1);
+  c.qb.ensure(c.want_qb);
   if (!c.items.p) { c.items.ensure(1u << 22); c.items_b.ensure(1u << 22); c.items_h.ensure(1u << 20); }
 }
 
 static DevWork work_view(Ctx& c) {
   DevWork w{};
   w.q_m = c.q_m.p; w.t_q = c.t_q.p; w.t_lo = c.t_lo.p; w.t_cnt = c.t_cnt.p; w.q_hits = c.q_hits.p; w.q_hits_a = c.q_hits_a.p;
-  w.q_cap = c.q_cap.p; w.q_seg = c.q_seg.p; w.q_kept = c.q_kept.p; w.q_cand = c.q_cand.p; w.q_acc = c.q_acc.p; w.q_pb = c.q_pb.p;
+  w.q_cap = c.q_cap.p; w.q_seg = c.q_seg.p; w.q_qseg = c.q_qseg.p; w.qb_cap = c.qb.cap; w.q_kept = c.q_kept.p; w.q_cand = c.q_cand.p; w.q_acc = c.q_acc.p; w.q_pb = c.q_pb.p;
   w.q_aux = c.q_aux.p; w.q_rank = c.q_rank.p; w.p_hist = c.p_hist.p; w.cmin_tab = c.cmin_tab.p; w.c_in = c.c_in.p;
   w.c_off = c.c_off.p; w.c_qi = c.c_qi.p; w.t_idf = c.t_idf.p; w.seg = c.seg.p; w.qb = c.qb.p; w.heap = c.heap.p;
   w.seg_cap = c.seg_cap; w.counters = c.counters.p;
@@ -408,13 +411,13 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
     }
     tick(); tick();
     {
-      hipLaunchKernelGGL(k_caps, dim3((b.nq + 1 + 255) / 256), dim3(256), 0, stream, b, w, c.items.p, item_cap, c.s_max);
+      hipLaunchKernelGGL(k_caps, dim3((b.nq + 1 + 255) / 256), dim3(256), 0, stream, b, w, c.items.p, item_cap, c.s_max, c.heavy_div);
       const uint32_t n = b.nq + 1;  // one extra so that q_seg[nq] = total
       const uint32_t tiles = (n + kScanTile - 1) / kScanTile;
       if (tiles > (uint32_t)kScanTile) throw std::invalid_argument("sub-batch too large for the scan");
-      hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(kScanThreads), 0, stream, w.q_cap, w.q_seg, c.tile_sums.p, n);
+      hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(kScanThreads), 0, stream, w.q_cap, w.q_qseg, c.tile_sums.p, n);
       hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanThreads), 0, stream, c.tile_sums.p, tiles, c.grand_total.p);
-      hipLaunchKernelGGL(k_scan_add, dim3(tiles), dim3(kScanThreads), 0, stream, w.q_seg, c.tile_sums.p, n);
+      hipLaunchKernelGGL(k_scan_add, dim3(tiles), dim3(kScanThreads), 0, stream, w.q_qseg, c.tile_sums.p, n);
     }
     tick(); tick();
     // fork: `side` continues after everything enqueued on `stream` so far; join: `stream` waits for `side`
@@ -434,7 +437,15 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
                          (const WorkItem*)c.items.p, item_cap, use_sig);
       if (heavy_min != 0xffffffffu) join();
       tick(); tick();  // "expand_a" = k_cmin + k_expand_a with k_expand_h beside it; "expand_b" = the token work
-      hipLaunchKernelGGL(k_caps_b, dim3((b.nq + 255) / 256), dim3(256), 0, stream, b, w, c.items_b.p, item_cap);
+      {
+        // the hits phase A really queued size the segments of everything downstream: second scan, q_cap -> q_seg
+        hipLaunchKernelGGL(k_caps_b, dim3((b.nq + 1 + 255) / 256), dim3(256), 0, stream, b, w, c.items_b.p, item_cap);
+        const uint32_t n = b.nq + 1;
+        const uint32_t tiles = (n + kScanTile - 1) / kScanTile;
+        hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(kScanThreads), 0, stream, w.q_cap, w.q_seg, c.tile_sums.p, n);
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanThreads), 0, stream, c.tile_sums.p, tiles, c.grand_total.p);
+        hipLaunchKernelGGL(k_scan_add, dim3(tiles), dim3(kScanThreads), 0, stream, w.q_seg, c.tile_sums.p, n);
+      }
       const size_t lds = (size_t)p_max * 4;
       if (lds > 64 * 1024) throw UnsupportedError("patterns too long for the expand kernel's LDS staging");
       hipLaunchKernelGGL(k_expand_b, dim3(b.nq + kExpandExtraGrid), dim3(kWave), lds, stream, m.d, b, w, prm,
@@ -572,11 +583,16 @@ static bool pass_needs_retry(Ctx& c, const unsigned long long* ctr, uint64_t& wa
   const uint32_t item_h_cap = (uint32_t)std::min<uint64_t>(c.items_h.cap, 0xffffffffull);
   bool retry = false;
   if (ctr[6] > c.seg_cap) { want_seg = std::max<uint64_t>(want_seg, ctr[6] + ctr[6] / 4); retry = true; }   // segments did not fit
+  if (ctr[21] > c.qb.cap) { c.want_qb = std::max<uint64_t>(c.want_qb, ctr[21] + ctr[21] / 4); retry = true; }  // queues did not fit
   if (ctr[4] > c.s_max) {                                                          // a query had more survivors
     unsigned long long s = c.s_max;
     while (s < ctr[4] && s < (1ull << 31)) s <<= 1;
     c.s_max = (uint32_t)std::min<unsigned long long>(s, 0x80000000ull);
     if (ctr[4] > c.s_max) throw UnsupportedError("a query kept more than 2^31 hits");
+    retry = true;
+  } else if (ctr[4] != 0) {                                                        // more of its long-range hits passed than reserved
+    if (c.heavy_div == 1) throw GpuError("a query queued more hits than it has");
+    c.heavy_div = c.heavy_div > 4 ? 4 : 1;
     retry = true;
   }
   if (std::max(ctr[5], ctr[12]) > item_cap) {                                      // work-item list too short
@@ -613,6 +629,7 @@ static void run_passes(DeviceIndex::Impl& m, Ctx& c, const Params& prm_in, const
   // cost model: real-token / penalty-token terms need the general kernel (DP rows in LDS / HBM); idf alone has a
   // register kernel
   const bool side_terms = (m.d.real && bv.q_real) || (bv.q_itok != nullptr) || (m.d.itok != nullptr);
+  if (!c.qb.p) c.want_qb = std::min<uint64_t>(c.want_qb, std::max<uint64_t>(m.init_seg, 4096));  // a small initial segment also starts the queues small
   PassEnv E{m, c, prm_in, side_terms, prm_in.idf_penalty != 0.f, d_out, d_out_count, d_out_total, cap, stream};
   const uint32_t n_sub = (uint32_t)sub_tok_bounds.size() - 1;
   auto batch_of = [&](uint32_t sb) {

@@ -66,8 +66,9 @@ struct DevWork {
   uint32_t* t_cnt;      // nt   range size
   unsigned long long* q_hits;  // nq   hits per query (every range of the query)
   unsigned long long* q_hits_a;  // nq  hits of the ranges k_expand_a walks (sum of t_cnt: the long ranges go to k_expand_h)
-  unsigned long long* q_cap;   // nq+1 segment capacity per query: min(hits, s_max)
-  unsigned long long* q_seg;   // nq+1 exclusive scan of q_cap
+  unsigned long long* q_cap;   // nq+1 scan input: first the queue capacity per query (k_caps), then its queued hits (k_caps_b)
+  unsigned long long* q_qseg;  // nq+1 queue offsets into qb: exclusive scan of the capacities (an upper bound of what phase A queues)
+  unsigned long long* q_seg;   // nq+1 segment offsets into seg / c_qi / keys ...: exclusive scan of the hits phase A really queued
   uint32_t* q_kept;     // nq
   uint32_t* q_cand;     // nq
   uint32_t* q_acc;      // nq
@@ -81,13 +82,15 @@ struct DevWork {
   unsigned long long* c_qi;    // seg_cap  (query << 32 | candidate index), dense per length class
   float*    t_idf;      // nt   idf_penalty per pattern position (src/fuzzy_match.cc:372-390)
   Cand*     seg;        // capacity seg_cap
-  QHit*     qb;      // capacity seg_cap: per-query queues between the two expand phases
+  QHit*     qb;      // capacity qb_cap: per-query queues between the two expand phases
   float*    heap;       // capacity seg_cap + nq (lowest_costs spill)
   unsigned long long  seg_cap;
+  unsigned long long  qb_cap;
   unsigned long long* counters;  // [0]=hits [1]=kept [2]=cands [3]=dp [4]=max survivors of a query whose
                                  // segment overflowed [5]=extra work items [6]=segment space needed
                                  // [7]=queries queued for k_cand_big [8]=phase-B hits [9]=max kept
                                  // [10],[11]=queries queued for k_contrast<1>, <2> [12]=extra k_expand_b items
+                                 // [21]=queue space needed (when qb is too small)
                                  // [13]=queries queued for k_cand_mid [14]=queries queued for the large k_finish
                                  // [15]=work items of k_expand_h [16]=hits walked through the bit planes
                                  // [17]=of those, hits that passed the plane test (re-tested exactly)
@@ -337,14 +340,19 @@ struct WorkItem {
   uint32_t chunk;
 };
 
-__global__ void __launch_bounds__(256) k_caps(DevBatch b, DevWork w, WorkItem* items, uint32_t item_cap, uint32_t s_max) {
+__global__ void __launch_bounds__(256) k_caps(DevBatch b, DevWork w, WorkItem* items, uint32_t item_cap, uint32_t s_max,
+                                              uint32_t heavy_div) {
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q > b.nq) return;
   if (q == b.nq) { w.q_cap[q] = 0; return; }
   const unsigned long long all_hits = w.q_hits[q];  // summed by k_probe
-  w.q_cap[q] = all_hits < s_max ? all_hits : (unsigned long long)s_max;
+  const unsigned long long hits = w.q_hits_a[q];    // what k_expand_a walks
+  // Queue / segment capacity of the query: every hit of the short ranges may survive phase A (near-duplicates: most
+  // do), of the long ranges only a few per cent do — a heavy_div-th of them is reserved, and a query that needs more
+  // is reported by k_caps_b (the host re-runs the pass with a smaller divisor, down to 1 = every hit).
+  const unsigned long long want = hits + (all_hits - hits + heavy_div - 1) / heavy_div;
+  w.q_cap[q] = want < s_max ? want : (unsigned long long)s_max;
   w.q_kept[q] = 0;
-  const unsigned long long hits = w.q_hits_a[q];  // what k_expand_a walks
   if (hits > kExpandChunk) {
     const uint32_t n_extra = (uint32_t)((hits + kExpandChunk - 1) / kExpandChunk) - 1;
     const unsigned long long base = atomicAdd(&w.counters[5], (unsigned long long)n_extra);
@@ -566,10 +574,10 @@ __global__ void __launch_bounds__(kWave, 8) k_expand_a(DevIndex ix, DevBatch b, 
     const uint32_t msl = uni(w.q_m[q]);
     const unsigned long long hits = msl == kNoMatchLen ? 0ull : uni(w.q_hits_a[q]);
     if (hits != 0) {
-      const unsigned long long seg0 = uni(w.q_seg[q]);
-      const uint32_t cap = (uint32_t)(uni(w.q_seg[q + 1]) - seg0);
-      if (seg0 + cap > w.seg_cap) {  // workspace too small: host re-runs the sub-batch with a larger one
-        if (lane == 0) atomicMax(&w.counters[6], w.q_seg[b.nq]);
+      const unsigned long long seg0 = uni(w.q_qseg[q]);
+      const uint32_t cap = (uint32_t)(uni(w.q_qseg[q + 1]) - seg0);
+      if (seg0 + cap > w.qb_cap) {  // queue space too small: host re-runs the sub-batch with a larger one
+        if (lane == 0) atomicMax(&w.counters[21], w.q_qseg[b.nq]);
       } else {
         const uint32_t o0 = uni(b.q_off[b.q_begin + q]);
         const uint32_t p = uni(b.q_off[b.q_begin + q + 1]) - o0;
@@ -869,9 +877,9 @@ __global__ void __launch_bounds__(kWave, 6) k_expand_h(DevIndex ix, DevBatch b, 
   for (unsigned long long item = blockIdx.x; item < n_items; item += gridDim.x) {
     const uint32_t t = uni(items[item].t), r_lo = uni(items[item].lo), r_cnt = uni(items[item].cnt), chunk = uni(items[item].chunk);
     const uint32_t q = uni(w.t_q[t]);
-    const unsigned long long seg0 = uni(w.q_seg[q]);
-    const uint32_t cap = (uint32_t)(uni(w.q_seg[q + 1]) - seg0);
-    if (seg0 + cap > w.seg_cap) continue;  // workspace too small: reported by k_caps_b, the host re-runs the pass
+    const unsigned long long seg0 = uni(w.q_qseg[q]);
+    const uint32_t cap = (uint32_t)(uni(w.q_qseg[q + 1]) - seg0);
+    if (seg0 + cap > w.qb_cap) continue;  // queue space too small: reported by k_caps_b, the host re-runs the pass
     const uint32_t o0 = uni(b.q_off[b.q_begin + q]);
     const uint32_t p = uni(b.q_off[b.q_begin + q + 1]) - o0;
     const uint32_t* pat = b.q_tok + o0;
@@ -1032,14 +1040,19 @@ __global__ void __launch_bounds__(kWave, 6) k_expand_h(DevIndex ix, DevBatch b, 
   }
 }
 
-// work items of k_expand_b for queries with more than kPhaseBChunk queued hits
+// After phase A: the hits each query really queued become its segment size (scan input; the segments of everything
+// downstream are sized by these, not by the loose bound the queues were sized by), and queries with more than
+// kPhaseBChunk queued hits get extra work items of k_expand_b.
 __global__ void k_caps_b(DevBatch b, DevWork w, WorkItem* items, uint32_t item_cap) {
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= b.nq) return;
-  const uint32_t cap = (uint32_t)(w.q_seg[q + 1] - w.q_seg[q]);
-  if (w.q_seg[q + 1] > w.seg_cap) { if (q + 1 == b.nq) atomicMax(&w.counters[6], w.q_seg[b.nq]); return; }  // host re-runs the pass with a larger workspace
+  if (q > b.nq) return;
+  if (q == b.nq) { w.q_cap[q] = 0; return; }
+  w.q_cap[q] = 0;
+  const uint32_t cap = (uint32_t)(w.q_qseg[q + 1] - w.q_qseg[q]);
+  if (w.q_qseg[q + 1] > w.qb_cap) { if (q + 1 == b.nq) atomicMax(&w.counters[21], w.q_qseg[b.nq]); return; }  // host re-runs the pass with a larger queue space
   const uint32_t n = w.q_pb[q];
-  if (n > cap) { atomicMax(&w.counters[4], (unsigned long long)n); return; }  // queue overflow: retry with a larger s_max
+  if (n > cap) { atomicMax(&w.counters[4], (unsigned long long)n); return; }  // queue overflow: retry with a larger capacity
+  w.q_cap[q] = n;
   if (n > kPhaseBChunk) {
     const uint32_t n_extra = (n + kPhaseBChunk - 1) / kPhaseBChunk - 1;
     const unsigned long long base = atomicAdd(&w.counters[12], (unsigned long long)n_extra);
@@ -1080,15 +1093,18 @@ __global__ void __launch_bounds__(kWave, 8) k_expand_b(DevIndex ix, DevBatch b, 
     // so everything that can be requested together is: level 1 = all per-query scalars.
     const unsigned long long seg0 = uni(w.q_seg[q]);
     const unsigned long long seg1 = uni(w.q_seg[q + 1]);
+    const unsigned long long qseg0 = uni(w.q_qseg[q]);
     const uint32_t n_q = uni(w.q_pb[q]);
     const uint32_t msl = uni(w.q_m[q]);
     const uint32_t o0 = uni(b.q_off[b.q_begin + q]);
     const uint32_t p = uni(b.q_off[b.q_begin + q + 1]) - o0;
     const uint32_t cap = (uint32_t)(seg1 - seg0);
-    if (n_q != 0 && n_q <= cap && seg0 + cap <= w.seg_cap) {
+    if (seg1 > w.seg_cap) {  // segments too small (cap == n_q unless the queue overflowed): host re-runs the pass
+      if (lane == 0 && n_q != 0) atomicMax(&w.counters[6], w.q_seg[b.nq]);
+    } else if (n_q != 0 && n_q <= cap) {
       const uint32_t m = seed_len(p, msl);
       const uint32_t* pat = b.q_tok + o0;
-      const QHit* qb = w.qb + seg0;
+      const QHit* qb = w.qb + qseg0;
       Cand* seg = w.seg + seg0;
       const uint32_t e_lo = chunk * kPhaseBChunk;
       const uint32_t e_hi = e_lo + kPhaseBChunk < n_q ? e_lo + kPhaseBChunk : n_q;

@@ -15,6 +15,7 @@
 #include <stdint.h>
 
 #include <atomic>
+#include <iostream>
 #include <cstring>
 #include <mutex>
 #include <stdexcept>
@@ -114,7 +115,20 @@ class FuzzyMatch {
     (void)sort;  // the sort is lazy: see ensure_ready()
     return true;
   }
-  bool add_tm(const std::string& id, const std::string& sentence, bool sort = true);  // fuzzy_text.hh (restricted tokenizer)
+  // add_tm(id, sentence) — src/fuzzy_match.cc:213-224: tokenised by the library's restricted text front-end
+  // (include/fmx.h, fmx_text_*); an empty segment is not indexed (warning on stderr, false)
+  bool add_tm(const std::string& id, const std::string& sentence, bool sort = true) {
+    std::lock_guard<std::mutex> lk(_mu);
+    if (_ready) { check(fmx_index_reopen(_ix)); _ready = false; }
+    const int64_t r = fmx_index_add_text(_ix, id.c_str(), sentence.data(), sentence.size());
+    if (r < 0 && r != FMX_TM_SKIPPED) throw std::runtime_error(fmx_last_error());
+    (void)sort;
+    if (r == FMX_TM_SKIPPED && text_is_empty(sentence)) {
+      std::cerr << "WARNING: cannot index empty segment: " << sentence << " (" << id << ")" << std::endl;
+      return false;
+    }
+    return true;
+  }
 
   // SuffixArray::sort (src/suffix_array.cc:58-102): here a promise — the work happens in ensure_ready()
   void sort() {}
@@ -146,19 +160,7 @@ class FuzzyMatch {
     for (const auto& t : pattern) toks.push_back(t.c_str());
     std::vector<uint32_t> wids(p), q_real, q_itok;
     check(fmx_vocab_lookup(_ix, toks.data(), p, wids.data()));
-    if (_real_differs) {
-      const Tokens rt = (Tokens)real;
-      q_real.resize(p);
-      for (uint32_t j = 0; j < p; j++) {
-        const std::string r = j < rt.size() ? rt[j] : std::string();
-        q_real[j] = fmx_index_lookup_real(_ix, r.data(), r.size());
-      }
-    }
-    if (!real.itoks().empty()) {
-      q_itok.assign(p + 1, 0);
-      for (const auto& kv : real.itoks())
-        if (kv.first <= p) q_itok[kv.first] = fmx_index_intern_itok(_ix, kv.second.data(), kv.second.size());
-    }
+    real_ids(real, p, q_real, q_itok);
     fmx_params prm;
     prm.fuzzy = fuzzy;
     prm.nmatch = number_of_matches ? number_of_matches - (unsigned)existing : 0;
@@ -190,16 +192,49 @@ class FuzzyMatch {
   }
 
   // match(const std::string&, ...) — include/fuzzy/fuzzy_match.hh:85-97, src/fuzzy_match.cc:393-412: tokenise +
-  // normalise, then the Sentence/Tokens overload.  Defined in fuzzy_text.hh (restricted tokenizer, see there).
+  // normalise (restricted text front-end of the library), then the Sentence/Tokens overload
   bool match(const std::string& sentence, float fuzzy, unsigned number_of_matches, bool no_perfect,
              std::vector<Match>& matches, int min_subseq_length = 3, float min_subseq_ratio = 0.3,
              float vocab_idf_penalty = 0, const EditCosts& edit_costs = EditCosts(), float contrastive_factor = 0,
-             ContrastReduce reduce = ContrastReduce::MEAN, int contrast_buffer = -1) const;
-  // subsequence() — include/fuzzy/fuzzy_match.hh:99-105, src/fuzzy_match.cc:250-365 (fuzzy_text.hh)
+             ContrastReduce reduce = ContrastReduce::MEAN, int contrast_buffer = -1) const {
+    TextHandle t(_pt, sentence);
+    Sentence real;
+    Tokens norm;
+    t.fill(real, norm);
+    return match(real, norm, fuzzy, number_of_matches, no_perfect, matches, min_subseq_length, min_subseq_ratio,
+                 vocab_idf_penalty, edit_costs, contrastive_factor, reduce, contrast_buffer);
+  }
+  // subsequence() — include/fuzzy/fuzzy_match.hh:99-105, src/fuzzy_match.cc:250-365: the sub-n-gram of the sentence
+  // with the largest weight that occurs in the memory, and the closest of up to number_of_matches sentences holding
+  // it; Match::id = the sentence's id + '\t' + the detokenised sub-n-gram
   bool subsequence(const std::string& sentence, unsigned number_of_matches, bool no_perfect, std::vector<Match>& matches,
-                   int min_subseq_length = 3, float min_subseq_ratio = 0.3, bool idf_weighting = false) const;
+                   int min_subseq_length = 3, float min_subseq_ratio = 0.3, bool idf_weighting = false) const {
+    TextHandle t(_pt, sentence);
+    Sentence real;
+    Tokens norm;
+    t.fill(real, norm);
+    uint32_t pos = 0;
+    Match m;
+    if (!subsequence_tokens(real, norm, number_of_matches, no_perfect, min_subseq_length, min_subseq_ratio, idf_weighting, m, pos))
+      return false;
+    m.id += "\t";
+    m.id += fmx_text_detokenize(t.h, pos, pos + (uint32_t)m.max_subseq);
+    matches.push_back(m);
+    return true;
+  }
+  // the same on a tokenised pattern (no text to detokenise: the sub-n-gram's tokens are joined by blanks)
   bool subsequence(const Tokens& pattern, unsigned number_of_matches, bool no_perfect, std::vector<Match>& matches,
-                   int min_subseq_length = 3, float min_subseq_ratio = 0.3, bool idf_weighting = false) const;
+                   int min_subseq_length = 3, float min_subseq_ratio = 0.3, bool idf_weighting = false) const {
+    uint32_t pos = 0;
+    Match m;
+    if (!subsequence_tokens(Sentence(pattern), pattern, number_of_matches, no_perfect, min_subseq_length, min_subseq_ratio,
+                            idf_weighting, m, pos))
+      return false;
+    m.id += "\t";
+    for (int k = 0; k < m.max_subseq; k++) { if (k) m.id += ' '; m.id += pattern[pos + k]; }
+    matches.push_back(m);
+    return true;
+  }
 
   size_t max_tokens_in_pattern() const { return _max_tokens; }
   fmx_index* handle() const { return _ix; }
@@ -208,6 +243,64 @@ class FuzzyMatch {
   friend void import_binarized_fuzzy_matcher(const std::string&, FuzzyMatch&);
   friend void export_binarized_fuzzy_matcher(const std::string&, const FuzzyMatch&);
   static void check(int rc) { if (rc != FMX_OK) throw std::runtime_error(fmx_last_error()); }
+  struct TextHandle {  // fmx_text of one sentence (RAII)
+    fmx_text* h;
+    TextHandle(int pt, const std::string& s) : h(fmx_text_tokenize(pt, s.data(), s.size())) { if (!h) throw std::bad_alloc(); }
+    ~TextHandle() { fmx_text_free(h); }
+    TextHandle(const TextHandle&) = delete;
+    TextHandle& operator=(const TextHandle&) = delete;
+    void fill(Sentence& real, Tokens& norm) const {
+      const uint32_t n = fmx_text_num_tokens(h);
+      for (uint32_t i = 0; i < n; i++) { norm.emplace_back(fmx_text_norm(h, i)); real.push_back(fmx_text_real(h, i)); }
+      for (uint32_t k = 0; k < fmx_text_num_itoks(h); k++) real.set_itok(fmx_text_itok_index(h, k), fmx_text_itok(h, k));
+    }
+  };
+  bool text_is_empty(const std::string& sentence) const {
+    TextHandle t(_pt, sentence);
+    return fmx_text_num_tokens(t.h) == 0;
+  }
+  // ids of the real tokens / penalty strings of `real` for a pattern of p tokens (the `real` argument of match())
+  void real_ids(const Sentence& real, uint32_t p, std::vector<uint32_t>& q_real, std::vector<uint32_t>& q_itok) const {
+    if (_real_differs) {
+      const Tokens rt = (Tokens)real;
+      q_real.resize(p);
+      for (uint32_t j = 0; j < p; j++) {
+        const std::string r = j < rt.size() ? rt[j] : std::string();
+        q_real[j] = fmx_index_lookup_real(_ix, r.data(), r.size());
+      }
+    }
+    if (!real.itoks().empty()) {
+      q_itok.assign(p + 1, 0);
+      for (const auto& kv : real.itoks())
+        if (kv.first <= p) q_itok[kv.first] = fmx_index_intern_itok(_ix, kv.second.data(), kv.second.size());
+    }
+  }
+  bool subsequence_tokens(const Sentence& real, const Tokens& pattern, unsigned number_of_matches, bool no_perfect,
+                          int min_subseq_length, float min_subseq_ratio, bool idf_weighting, Match& m, uint32_t& pos) const {
+    ensure_ready();
+    const uint32_t p = (uint32_t)pattern.size();
+    if (p == 0) return false;
+    std::vector<const char*> toks;
+    for (const auto& t : pattern) toks.push_back(t.c_str());
+    std::vector<uint32_t> wids(p), q_real, q_itok;
+    check(fmx_vocab_lookup(_ix, toks.data(), p, wids.data()));
+    real_ids(real, p, q_real, q_itok);
+    const uint32_t off[2] = {0, p};
+    fmx_batch b;
+    b.nq = 1; b.q_off = off; b.q_tok = wids.data();
+    b.q_real = q_real.empty() ? nullptr : q_real.data();
+    b.q_itok = q_itok.empty() ? nullptr : q_itok.data();
+    b.max_len = p;
+    fmx_match rec;
+    uint32_t found = 0;
+    check(fmx_subsequence_batch(_ix, &b, number_of_matches, no_perfect ? 1 : 0, min_subseq_length, min_subseq_ratio,
+                                idf_weighting ? 1 : 0, &rec, &found, &pos));
+    if (!found) return false;
+    m = Match(_buffer + _sent_pos[rec.s_id] + 1, (int)_buffer[_sent_pos[rec.s_id]]);
+    m.score = rec.score; m.penalty = 0; m.max_subseq = rec.max_subseq; m.s_id = rec.s_id;
+    m.id = fmx_index_sentence_id(_ix, rec.s_id);
+    return true;
+  }
   // sort + derive + upload, once after any change (match() is const in the reference: the state is mutable here)
   void ensure_ready() const {
     if (_ready.load(std::memory_order_acquire)) return;

@@ -117,5 +117,42 @@ int main(int argc, char** argv) {
     for (auto& x : th) x.join();
     std::printf("THREADS %d\n", bad.load());
   }
+  // text front-end: a memory built from raw sentences, queried with raw sentences (test/test.cc:102-120
+  // buildtm1_serialize), export / import round trip, subsequence()
+  if (argc >= 5) {
+    fuzzy::FuzzyMatch ft(fuzzy::FuzzyMatch::pt_tag | fuzzy::FuzzyMatch::pt_nbr | fuzzy::FuzzyMatch::pt_cas);
+    std::ifstream tm(argv[3]);
+    int count = 0;
+    while (std::getline(tm, line)) ft.add_tm(std::to_string(++count) + "=" + line, line);
+    std::printf("EMPTY %d\n", ft.add_tm("none", std::string("")) ? 1 : 0);
+    auto run = [&](fuzzy::FuzzyMatch& m, const char* tag) {
+      std::ifstream cs(argv[4]);
+      std::string l;
+      while (std::getline(cs, l)) {
+        if (l.empty() || l[0] == '#') continue;
+        const auto f = split(l, '\t');
+        std::vector<fuzzy::FuzzyMatch::Match> matches;
+        m.match(f[1], std::stof(f[2]), (unsigned)std::stoul(f[4]), f[3] == "true", matches, 2, 0);
+        std::printf("%s %s", tag, f[0].c_str());
+        for (const auto& x : matches) std::printf("\t%.9g\t%s", x.score, x.id.c_str());
+        std::printf("\n");
+      }
+    };
+    run(ft, "TEXT");
+    const std::string tmp = std::string(argv[2]) + ".text.fmi";
+    fuzzy::export_binarized_fuzzy_matcher(tmp, ft);
+    fuzzy::FuzzyMatch reload;
+    fuzzy::import_binarized_fuzzy_matcher(tmp, reload);
+    run(reload, "RELOAD");
+    std::vector<fuzzy::FuzzyMatch::Match> sm;
+    const bool ok = ft.subsequence(std::string("zz Aa bb cc yy"), 2, false, sm, 2, 0);
+    std::printf("SUBSEQ %d\t%.9g\t%d\t%s\n", ok ? 1 : 0, sm.empty() ? 0.f : sm[0].score, sm.empty() ? 0 : sm[0].max_subseq,
+                sm.empty() ? "-" : sm[0].id.c_str());
+    sm.clear();
+    const bool ok2 = ft.subsequence(fuzzy::Tokens{"zz", "aa", "bb", "cc", "yy"}, 2, false, sm, 2, 0);
+    std::printf("SUBSEQTOK %d\t%.9g\t%s\n", ok2 ? 1 : 0, sm.empty() ? 0.f : sm[0].score, sm.empty() ? "-" : sm[0].id.c_str());
+    sm.clear();
+    std::printf("SUBSEQNONE %d\n", ft.subsequence(std::string("zz yy"), 2, false, sm, 2, 0) ? 1 : 0);
+  }
   return 0;
 }

@@ -1,5 +1,6 @@
 """tools/fmx-cli: the reference CLI's flags, output format (`score<TAB>id` pairs, %.9g like
-boost::lexical_cast<float>) and stderr lines (STEP / NMATCH), on pre-tokenised input."""
+boost::lexical_cast<float>) and stderr lines (STEP / NMATCH): raw text like the reference (the library's restricted
+text front-end), or pre-tokenised input with --tokenised; actions index / match / subseq."""
 import os
 import subprocess
 
@@ -41,9 +42,9 @@ def test_cli_index_then_match(fmx, gpu_device, tmp_path):
     sents = [[words[int(x)] for x in rng.integers(0, 40, size=int(rng.integers(3, 12)))] for _ in range(300)]
     corpus = tmp_path / "corpus.tok"
     corpus.write_text("".join("id%d\t%s\n" % (i, " ".join(s)) for i, s in enumerate(sents)))
-    r = subprocess.run([CLI, "-c", str(corpus), "-a", "index"], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([CLI, "--tokenised", "-c", str(corpus), "-a", "index"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
-    assert os.path.exists(str(corpus) + ".fmi") and "STEP\tIndexing" in r.stderr
+    assert os.path.exists(str(corpus) + ".fmi") and "STEP\tImporting TM" in r.stderr and "STEP\tSorting Index" in r.stderr
     queries = []
     for i in range(60):
         s = list(sents[int(rng.integers(0, 300))])
@@ -53,7 +54,7 @@ def test_cli_index_then_match(fmx, gpu_device, tmp_path):
             s = []
         queries.append(s)
     inp = "".join(" ".join(q) + "\n" for q in queries)
-    r = subprocess.run([CLI, "-i", str(corpus) + ".fmi", "-a", "match", "-f", "0.5", "-n", "3", "--ml", "2", "--mr", "0",
+    r = subprocess.run([CLI, "--tokenised", "-i", str(corpus) + ".fmi", "-a", "match", "-f", "0.5", "-n", "3", "--ml", "2", "--mr", "0",
                         "--batch", "17"], input=inp, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     lines = r.stdout.split("\n")[:-1]
@@ -70,3 +71,36 @@ def test_cli_index_then_match(fmx, gpu_device, tmp_path):
         assert line == exp, (q, line, exp)
         n_nonempty += 1 if len(res) else 0
     assert "NMATCH\t%d\t/\t%d" % (n_nonempty, len(queries)) in r.stderr and "STEP\tMatching" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_raw_text_tm2_like_the_reference_ci(fmx, gpu_device, tmp_path):
+    """.github/workflows/cmake.yml:41 + test/test.cc:217-221: `-c tm2.en.gz,tm2.fr.gz --add-target` builds
+    tm2.en.gz.fmi from the gzipped bitext; `-i ... -a match` on the raw test-tm2 sentences prints what the reference's
+    test expects (ids '<line>=<target>', scores within its 0.009 tolerance)."""
+    import shutil
+    import test_text_frontend as tf
+    _build(fmx)
+    for f in ("tm2.en.gz", "tm2.fr.gz"):
+        shutil.copy(os.path.join(golden_util.GOLDEN, f), tmp_path / f)
+    r = subprocess.run([CLI, "-c", f"{tmp_path}/tm2.en.gz,{tmp_path}/tm2.fr.gz", "--add-target"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and os.path.exists(f"{tmp_path}/tm2.en.gz.fmi"), r.stderr
+    cases = tf.read_cases("test-tm2")
+    inp = "".join(c["text"] + "\n" for c in cases)
+    r = subprocess.run([CLI, "-i", f"{tmp_path}/tm2.en.gz.fmi", "-a", "match", "-f", "0.5", "-n", "2", "-P"], input=inp,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.split("\n")[:-1]
+    assert len(lines) == len(cases)
+    for c, line in zip(cases, lines):
+        f = line.split("\t") if line else []
+        tf.check_case(c, [float(f[i]) for i in range(0, len(f), 2)], [f[i + 1] for i in range(0, len(f), 2)])
+    assert "NMATCH\t12\t/\t100" in r.stderr
+    # -a subseq (cli/src/FuzzyMatch-cli.cc:234-248): score, length, id, and the text of the sub-n-gram
+    r = subprocess.run([CLI, "-i", f"{tmp_path}/tm2.en.gz.fmi", "-a", "subseq", "-n", "3"], input="I declare adjourned the session of the European Parliament .\nzzzz qqqq\n",
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    out = r.stdout.split("\n")
+    f = out[0].split("\t")
+    assert len(f) == 4 and int(f[1]) >= 6 and f[3] in "I declare adjourned the session of the European Parliament ." and out[1] == ""
+    assert "NMATCH\t1\t/\t2" in r.stderr

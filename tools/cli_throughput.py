@@ -31,11 +31,11 @@ dump(corpus, c_off, c_tok)
 dump(queries, q_off, q_tok)
 cli = os.path.join(ROOT, "tools", "fmx-cli")
 t = time.time()
-subprocess.check_call([cli, "-c", corpus, "-a", "index"], stderr=subprocess.DEVNULL)
+subprocess.check_call([cli, "--tokenised", "-c", corpus, "-a", "index"], stderr=subprocess.DEVNULL)
 print(f"index: {n_sent} sentences in {time.time() - t:.1f}s")
 for batch in (65536,):
     t = time.time()
-    r = subprocess.run([cli, "-i", corpus + ".fmi", "-a", "match", "-f", "0.7", "-n", "5", "--batch", str(batch)],
+    r = subprocess.run([cli, "--tokenised", "-i", corpus + ".fmi", "-a", "match", "-f", "0.7", "-n", "5", "--batch", str(batch)],
                        stdin=open(queries), stdout=open(os.path.join(out_dir, "cli_out.tsv"), "w"), stderr=subprocess.PIPE, text=True)
     dt = time.time() - t
     steps = {l.split("\t")[1]: float(l.split("\t")[5]) for l in r.stderr.splitlines() if l.startswith("STEP")}
