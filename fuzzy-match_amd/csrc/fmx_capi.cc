@@ -31,6 +31,7 @@ struct fmx_index {
   std::mutex                                mu;    // interning of penalty strings, lazy construction of the coalescer
   std::unique_ptr<Coalescer>                co;
   int64_t                                   coalesce_us = 50;
+  int64_t                                   host_lanes = 1;   // host threads (contexts) per device inside one fmx_match_batch call
   ~fmx_index();
 };
 
@@ -298,37 +299,45 @@ static void real_from_forms(const fmx_index* ix, const uint32_t* wids, uint64_t 
 
 // One batch over every replica of the index: contiguous query blocks, one per device, run concurrently; each
 // block's records land directly in the caller's buffers (index replicated, no data-path exchange).
+// A device's block is cut once more into `host_lanes` contiguous parts, each driven by its own host thread through
+// its own context (workspace + streams): while one part sits in a kernel's tail or waits for a copy, the other's
+// kernels fill the GPU, so a single call keeps the device as busy as several concurrent callers would.
 static void match_on_devices(fmx_index* ix, const Params& prm, const HostBatchView& v, fmx_match* out, uint32_t* out_count,
                              uint32_t* out_total, uint32_t cap, Stats* st, fmx_match* d_keep = nullptr,
                              uint32_t* d_keep_count = nullptr) {
-  const size_t nd = ix->devs.size();
-  if (nd == 1 || v.nq < 2 * nd || d_keep) {
+  const size_t nd = d_keep ? 1 : ix->devs.size();  // a device-resident copy lives on one device: no sharding over replicas
+  constexpr uint64_t kMinLaneQueries = 32768;
+  size_t lanes = (size_t)std::max<int64_t>(ix->host_lanes, 1);
+  while (lanes > 1 && v.nq / (nd * lanes) < kMinLaneQueries) lanes--;
+  const size_t nb = nd * lanes;
+  if (nb == 1 || v.nq < 2 * nb) {
     ix->devs[0]->match_host(ix->host, prm, v, (Rec*)out, out_count, out_total, cap, st, (Rec*)d_keep, d_keep_count);
     return;
   }
   const auto t0 = std::chrono::steady_clock::now();
-  std::vector<Stats> sts(nd);
-  std::vector<std::exception_ptr> errs(nd);
-  auto run = [&](size_t d) {
+  std::vector<Stats> sts(nb);
+  std::vector<std::exception_ptr> errs(nb);
+  auto run = [&](size_t k) {
     try {
-      const uint64_t lo = v.nq * d / nd, hi = v.nq * (d + 1) / nd;
+      const uint64_t lo = v.nq * k / nb, hi = v.nq * (k + 1) / nb;
       HostBatchView s = v;
       s.nq = hi - lo;
       s.q_off = v.q_off + lo;                            // absolute offsets: the block's tokens are q_tok[q_off[lo] .. q_off[hi])
       if (v.q_itok) s.q_itok = v.q_itok + lo;            // slot of (query, j) = q_off[q] + q + j: the block's view starts lo slots in
-      ix->devs[d]->match_host(ix->host, prm, s, (Rec*)(out + lo * cap), out_count + lo, out_total ? out_total + lo : nullptr, cap, &sts[d]);
+      ix->devs[k / lanes]->match_host(ix->host, prm, s, (Rec*)(out + lo * cap), out_count + lo, out_total ? out_total + lo : nullptr, cap, &sts[k],
+                                      d_keep ? (Rec*)(d_keep + lo * cap) : nullptr, d_keep_count ? d_keep_count + lo : nullptr);
     } catch (...) {
-      errs[d] = std::current_exception();
+      errs[k] = std::current_exception();
     }
   };
   std::vector<std::thread> th;
-  for (size_t d = 1; d < nd; d++) th.emplace_back(run, d);
+  for (size_t k = 1; k < nb; k++) th.emplace_back(run, k);
   run(0);
   for (auto& t : th) t.join();
   for (auto& e : errs) if (e) std::rethrow_exception(e);
   if (st) {
-    for (size_t d = 0; d < nd; d++) {
-      const Stats& s = sts[d];
+    for (size_t k = 0; k < nb; k++) {
+      const Stats& s = sts[k];
       for (int i = 0; i < 16; i++) { st->ms_kernel[i] = std::max(st->ms_kernel[i], s.ms_kernel[i]); st->launches[i] += s.launches[i]; }
       st->ms_h2d = std::max(st->ms_h2d, s.ms_h2d); st->ms_d2h = std::max(st->ms_d2h, s.ms_d2h);
       st->n_hits += s.n_hits; st->n_kept += s.n_kept; st->n_candidates += s.n_candidates; st->n_dp += s.n_dp;
@@ -639,6 +648,11 @@ int fmx_set_option(fmx_index* ix, const char* name, int64_t value) {
   if (!ix || !name) return fail(FMX_E_INVALID, "null argument");
   const std::string n(name);
   if (n == "coalesce_us") { ix->coalesce_us = std::max<int64_t>(value, 0); return FMX_OK; }
+  if (n == "host_lanes") {
+    ix->host_lanes = std::min<int64_t>(std::max<int64_t>(value, 1), 8);
+    for (auto& d : ix->devs) d->set_contexts((uint32_t)ix->host_lanes + 1);  // + one for a concurrent caller / the coalescer
+    return FMX_OK;
+  }
   if (ix->devs.empty()) return fail(FMX_E_STATE, "index is not on a device");
   for (auto& d : ix->devs) {
     if (n == "sub_queries") d->set_sub_queries((uint32_t)std::max<int64_t>(value, 1));

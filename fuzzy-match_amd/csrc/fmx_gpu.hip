@@ -96,6 +96,7 @@ template <class T> struct Grow {
 };
 
 constexpr int kMaxPassesInFlight = 2;
+constexpr int kScanSlots = 4;  // scans per pass: queue capacities, queued hits, candidate classes, contrast lists
 
 // Everything one call mutates.
 struct Ctx {
@@ -109,8 +110,13 @@ struct Ctx {
   Grow<QHit>     qb;
   Grow<float>    heap, f0, f1;
   Grow<uint32_t> vals;
-  Grow<uint32_t> p_hist;
-  Grow<unsigned long long> counters, tile_sums, grand_total;
+  // zeroed by one memset per pass: [counters | scan state + tickets | p_hist]
+  Grow<unsigned long long> zero_blk;
+  unsigned long long* counters_p() { return zero_blk.p; }
+  unsigned long long* scan_state(int slot) { return zero_blk.p + kNumCounters + (size_t)slot * kLbMaxArrays * kLbMaxTiles; }
+  uint32_t* scan_ticket(int slot) { return reinterpret_cast<uint32_t*>(zero_blk.p + kNumCounters + (size_t)kScanSlots * kLbMaxArrays * kLbMaxTiles) + slot; }
+  uint32_t* p_hist_p() { return scan_ticket(0) + 2 * kScanSlots; }
+  static constexpr size_t zero_words() { return kNumCounters + (size_t)kScanSlots * kLbMaxArrays * kLbMaxTiles + kScanSlots + kPBins + 2; }
   Grow<WorkItem> items, items_b;
   Grow<HeavyItem> items_h;
   Grow<uint16_t> cmin_tab;
@@ -125,7 +131,7 @@ struct Ctx {
   // ---- streams / events ----
   hipStream_t stream = nullptr, h2d = nullptr, d2h = nullptr, side = nullptr;
   hipEvent_t  ev[2 * kNumStages]{};
-  hipEvent_t  ev_fork = nullptr, ev_join = nullptr, ev_in[kMaxPassesInFlight]{}, ev_done = nullptr;
+  hipEvent_t  ev_fork = nullptr, ev_join = nullptr, ev_cmin = nullptr, ev_in[kMaxPassesInFlight]{}, ev_done = nullptr;
   unsigned long long* h_ctr = nullptr;  // pinned: the pass counters land here
   unsigned long long* h_ctr_group = nullptr;  // pinned: one slot per pass of an asynchronous group
   std::vector<hipEvent_t> ev_pass;      // "pass done" events of an asynchronous group
@@ -139,13 +145,11 @@ struct Ctx {
     for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
     HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&ev_cmin, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming));
     for (auto& e : ev_in) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIP_TRY(hipHostMalloc((void**)&h_ctr, kNumCounters * sizeof(unsigned long long), hipHostMallocDefault));
-    counters.ensure(kNumCounters);
-    tile_sums.ensure(kScanTile);
-    grand_total.ensure(1);
-    p_hist.ensure(2 * kPBins);
+    zero_blk.ensure(zero_words());
     ok = true;
   }
   void destroy() {
@@ -153,8 +157,8 @@ struct Ctx {
     big_list.release(); mid_list.release(); fin_list.release(); contrast_list.release();
     q_hits.release(); q_hits_a.release(); q_seg.release(); q_qseg.release(); q_cap.release(); c_in.release(); c_off.release();
     t_q.release(); t_lo.release(); t_cnt.release(); t_idf.release(); c_qi.release(); keys.release(); seg.release(); qb.release();
-    heap.release(); f0.release(); f1.release(); vals.release(); p_hist.release(); counters.release(); tile_sums.release();
-    grand_total.release(); items.release(); items_b.release(); items_h.release(); cmin_tab.release(); g_rows.release();
+    heap.release(); f0.release(); f1.release(); vals.release(); zero_blk.release();
+    items.release(); items_b.release(); items_h.release(); cmin_tab.release(); g_rows.release();
     d_qoff.release(); d_qtok.release(); d_qreal.release(); d_qitok.release(); d_cnt.release(); d_tot.release(); d_out.release();
     if (stream) (void)hipStreamDestroy(stream);
     if (h2d) (void)hipStreamDestroy(h2d);
@@ -164,6 +168,7 @@ struct Ctx {
     for (auto& e : ev_in) if (e) (void)hipEventDestroy(e);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
+    if (ev_cmin) (void)hipEventDestroy(ev_cmin);
     if (ev_done) (void)hipEventDestroy(ev_done);
     if (h_ctr) (void)hipHostFree(h_ctr);
     if (h_ctr_group) (void)hipHostFree(h_ctr_group);
@@ -179,10 +184,10 @@ struct DeviceIndex::Impl {
   std::shared_mutex itok_mu;  // matching calls hold it shared; a grown penalty-string table swaps under exclusive
   // options
   uint32_t sub_queries = 1u << 20;       // queries per pipeline pass: large passes amortise the ~40 launches and their tails
-  uint32_t host_sub_queries = 1u << 18;  // pass size of the host-buffer entry point: copies overlap the neighbouring passes
+  uint32_t host_sub_queries = 1u << 19;  // pass size of the host-buffer entry point: copies overlap the neighbouring passes
   uint64_t init_seg = 1ull << 24;
   uint32_t heavy_min = kHeavyMinDefault; // suffix ranges at least this long go through the bit-plane kernel (0 = never)
-  uint32_t max_ctx = 2;
+  uint32_t max_ctx = 3;
   bool     probe_count = false;
   bool     serial = false;        // measurement runs: no side stream, every kernel alone on the GPU
   // context pool
@@ -344,9 +349,9 @@ static DevWork work_view(Ctx& c) {
   DevWork w{};
   w.q_m = c.q_m.p; w.t_q = c.t_q.p; w.t_lo = c.t_lo.p; w.t_cnt = c.t_cnt.p; w.q_hits = c.q_hits.p; w.q_hits_a = c.q_hits_a.p;
   w.q_cap = c.q_cap.p; w.q_seg = c.q_seg.p; w.q_qseg = c.q_qseg.p; w.qb_cap = c.qb.cap; w.q_kept = c.q_kept.p; w.q_cand = c.q_cand.p; w.q_acc = c.q_acc.p; w.q_pb = c.q_pb.p;
-  w.q_aux = c.q_aux.p; w.q_rank = c.q_rank.p; w.p_hist = c.p_hist.p; w.cmin_tab = c.cmin_tab.p; w.c_in = c.c_in.p;
+  w.q_aux = c.q_aux.p; w.q_rank = c.q_rank.p; w.p_hist = c.p_hist_p(); w.cmin_tab = c.cmin_tab.p; w.c_in = c.c_in.p;
   w.c_off = c.c_off.p; w.c_qi = c.c_qi.p; w.t_idf = c.t_idf.p; w.seg = c.seg.p; w.qb = c.qb.p; w.heap = c.heap.p;
-  w.seg_cap = c.seg_cap; w.counters = c.counters.p;
+  w.seg_cap = c.seg_cap; w.counters = c.counters_p();
   return w;
 }
 
@@ -383,20 +388,30 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
     DevWork w = work_view(c);
     const uint32_t item_cap = (uint32_t)std::min<uint64_t>(c.items.cap, 0xffffffffull);
     const uint32_t item_h_cap = (uint32_t)std::min<uint64_t>(c.items_h.cap, 0xffffffffull);
-    HIP_TRY(hipMemsetAsync(w.q_hits, 0, (b.nq + 1) * sizeof(unsigned long long), stream));
-    HIP_TRY(hipMemsetAsync(w.q_hits_a, 0, (b.nq + 1) * sizeof(unsigned long long), stream));
-    HIP_TRY(hipMemsetAsync(w.counters, 0, kNumCounters * sizeof(unsigned long long), stream));
-    HIP_TRY(hipMemsetAsync(w.q_pb, 0, b.nq * sizeof(uint32_t), stream));
+    // one memset per pass: counters, scan states / tickets, pattern-length histogram (the per-query accumulators are
+    // zeroed by k_setup)
+    HIP_TRY(hipMemsetAsync(c.zero_blk.p, 0, Ctx::zero_words() * sizeof(unsigned long long), stream));
+    const uint32_t n_scan = b.nq + 1;  // one extra element so that out[nq] = total
+    const uint32_t scan_tiles = (n_scan + kScanTile - 1) / kScanTile;
+    if (scan_tiles > kLbMaxTiles) throw std::invalid_argument("sub-batch too large for the scan");
     int e = 0;
     auto tick = [&]() { if (timing) HIP_TRY(hipEventRecord(c.ev[e], stream)); e++; };
     // the signature bound needs theoretical_rejection_cover to be monotone in the cover: costs >= 0
     const int use_sig = prm.ins >= 0.f && prm.del >= 0.f && prm.rep >= 0.f;
     // suffix ranges of at least heavy_min hits are walked through the signature bit planes (k_expand_h)
     const uint32_t heavy_min = (use_sig && m.d.planes && m.heavy_min) ? std::max<uint32_t>(m.heavy_min, 256u) : 0xffffffffu;
+    // fork: `side` continues after everything enqueued on `stream` so far; join: `stream` waits for `side`
+    const hipStream_t side = m.serial ? stream : c.side;
+    auto fork = [&]() { if (!m.serial) { HIP_TRY(hipEventRecord(c.ev_fork, stream)); HIP_TRY(hipStreamWaitEvent(c.side, c.ev_fork, 0)); } };
+    auto join = [&]() { if (!m.serial) { HIP_TRY(hipEventRecord(c.ev_join, c.side)); HIP_TRY(hipStreamWaitEvent(stream, c.ev_join, 0)); } };
     tick();
-    hipLaunchKernelGGL(k_setup, dim3((b.nq + 255) / 256), dim3(256), 0, stream, m.d, b, w, prm);
+    // the phase-A threshold table depends on the parameters only: computed on the side stream while the probe runs
+    // (after the fork: the previous pass, which read the table, is complete)
+    fork();
+    hipLaunchKernelGGL(k_cmin, dim3(p_max + 1), dim3(256), 0, side, m.d.max_slen, prm, use_sig, c.cmin_tab.p);
+    if (!m.serial) HIP_TRY(hipEventRecord(c.ev_cmin, c.side));
+    hipLaunchKernelGGL(k_setup, dim3((b.nq + 1 + 255) / 256), dim3(256), 0, stream, m.d, b, w, prm);
     if (prm.idf_penalty != 0.f) hipLaunchKernelGGL(k_tidf, dim3((b.nt + 255) / 256), dim3(256), 0, stream, m.d, b, w);
-    HIP_TRY(hipMemsetAsync(w.p_hist, 0, 2 * kPBins * sizeof(uint32_t), stream));
     {
       const uint32_t per_block = kRankThreads * kRankPer;
       hipLaunchKernelGGL(k_phist, dim3((b.nq + per_block - 1) / per_block), dim3(kRankThreads), 0, stream, b, w);
@@ -412,20 +427,12 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
     tick(); tick();
     {
       hipLaunchKernelGGL(k_caps, dim3((b.nq + 1 + 255) / 256), dim3(256), 0, stream, b, w, c.items.p, item_cap, c.s_max, c.heavy_div);
-      const uint32_t n = b.nq + 1;  // one extra so that q_seg[nq] = total
-      const uint32_t tiles = (n + kScanTile - 1) / kScanTile;
-      if (tiles > (uint32_t)kScanTile) throw std::invalid_argument("sub-batch too large for the scan");
-      hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(kScanThreads), 0, stream, w.q_cap, w.q_qseg, c.tile_sums.p, n);
-      hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanThreads), 0, stream, c.tile_sums.p, tiles, c.grand_total.p);
-      hipLaunchKernelGGL(k_scan_add, dim3(tiles), dim3(kScanThreads), 0, stream, w.q_qseg, c.tile_sums.p, n);
+      hipLaunchKernelGGL(k_scan_lb<1>, dim3(scan_tiles), dim3(kScanThreads), 0, stream, w.q_cap, w.q_qseg, (size_t)0, n_scan,
+                         c.scan_state(0), c.scan_ticket(0));
     }
     tick(); tick();
-    // fork: `side` continues after everything enqueued on `stream` so far; join: `stream` waits for `side`
-    const hipStream_t side = m.serial ? stream : c.side;
-    auto fork = [&]() { if (!m.serial) { HIP_TRY(hipEventRecord(c.ev_fork, stream)); HIP_TRY(hipStreamWaitEvent(c.side, c.ev_fork, 0)); } };
-    auto join = [&]() { if (!m.serial) { HIP_TRY(hipEventRecord(c.ev_join, c.side)); HIP_TRY(hipStreamWaitEvent(stream, c.ev_join, 0)); } };
     {
-      hipLaunchKernelGGL(k_cmin, dim3(p_max + 1), dim3(256), 0, stream, m.d.max_slen, prm, use_sig, c.cmin_tab.p);
+      if (!m.serial) HIP_TRY(hipStreamWaitEvent(stream, c.ev_cmin, 0));
       // the few long ranges stream through the bit planes on the side stream next to the per-hit walk of
       // everything else: both append to the per-query queues of k_expand_b
       if (heavy_min != 0xffffffffu) {
@@ -440,11 +447,8 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
       {
         // the hits phase A really queued size the segments of everything downstream: second scan, q_cap -> q_seg
         hipLaunchKernelGGL(k_caps_b, dim3((b.nq + 1 + 255) / 256), dim3(256), 0, stream, b, w, c.items_b.p, item_cap);
-        const uint32_t n = b.nq + 1;
-        const uint32_t tiles = (n + kScanTile - 1) / kScanTile;
-        hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(kScanThreads), 0, stream, w.q_cap, w.q_seg, c.tile_sums.p, n);
-        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanThreads), 0, stream, c.tile_sums.p, tiles, c.grand_total.p);
-        hipLaunchKernelGGL(k_scan_add, dim3(tiles), dim3(kScanThreads), 0, stream, w.q_seg, c.tile_sums.p, n);
+        hipLaunchKernelGGL(k_scan_lb<1>, dim3(scan_tiles), dim3(kScanThreads), 0, stream, w.q_cap, w.q_seg, (size_t)0, n_scan,
+                           c.scan_state(1), c.scan_ticket(1));
       }
       const size_t lds = (size_t)p_max * 4;
       if (lds > 64 * 1024) throw UnsupportedError("patterns too long for the expand kernel's LDS staging");
@@ -469,15 +473,9 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
     tick(); tick();
     {
       // dense per-class candidate lists: three exclusive scans of the per-query candidate counts
-      const uint32_t n = b.nq + 1;
-      const uint32_t tiles = (n + kScanTile - 1) / kScanTile;
-      hipLaunchKernelGGL(k_classify, dim3((n + 255) / 256), dim3(256), 0, stream, b, w, full ? 1 : 0);
-      for (int k = 0; k < 3; k++) {
-        hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(kScanThreads), 0, stream, w.c_in + (size_t)k * n,
-                           w.c_off + (size_t)k * n, c.tile_sums.p, n);
-        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanThreads), 0, stream, c.tile_sums.p, tiles, c.grand_total.p);
-        hipLaunchKernelGGL(k_scan_add, dim3(tiles), dim3(kScanThreads), 0, stream, w.c_off + (size_t)k * n, c.tile_sums.p, n);
-      }
+      hipLaunchKernelGGL(k_classify, dim3((n_scan + 255) / 256), dim3(256), 0, stream, b, w, full ? 1 : 0);
+      hipLaunchKernelGGL(k_scan_lb<3>, dim3(scan_tiles), dim3(kScanThreads), 0, stream, w.c_in, w.c_off, (size_t)n_scan, n_scan,
+                         c.scan_state(2), c.scan_ticket(2));
       hipLaunchKernelGGL(k_cmap, dim3((b.nq + 255) / 256), dim3(256), 0, stream, b, w, full ? 1 : 0, c.fin_list.p);
     }
     tick(); tick();
@@ -531,15 +529,9 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
         const bool flat = prm.nmatch >= 1 && prm.nmatch <= kMaxFlatRounds;
         if (flat) {
           // flattened rounds: pick, then one edit distance per remaining accepted match of any query
-          const uint32_t n = b.nq + 1;
-          const uint32_t tiles = (n + kScanTile - 1) / kScanTile;
-          hipLaunchKernelGGL(k_cacc, dim3((n + 255) / 256), dim3(256), 0, stream, b, w);
-          for (int k = 0; k < 2; k++) {
-            hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(kScanThreads), 0, stream, w.c_in + (size_t)k * n,
-                               w.c_off + (size_t)k * n, c.tile_sums.p, n);
-            hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanThreads), 0, stream, c.tile_sums.p, tiles, c.grand_total.p);
-            hipLaunchKernelGGL(k_scan_add, dim3(tiles), dim3(kScanThreads), 0, stream, w.c_off + (size_t)k * n, c.tile_sums.p, n);
-          }
+          hipLaunchKernelGGL(k_cacc, dim3((n_scan + 255) / 256), dim3(256), 0, stream, b, w);
+          hipLaunchKernelGGL(k_scan_lb<2>, dim3(scan_tiles), dim3(kScanThreads), 0, stream, w.c_in, w.c_off, (size_t)n_scan, n_scan,
+                             c.scan_state(3), c.scan_ticket(3));
           hipLaunchKernelGGL(k_camap, dim3(b.nq), dim3(kWave), 0, stream, b, w, sc);
           for (uint32_t r = 0; r < prm.nmatch; r++) {
             if (r) {
@@ -577,31 +569,40 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
     HIP_TRY(hipMemcpyAsync(h_ctr_slot, w.counters, kNumCounters * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
 }
 
-// what the counters of a finished pass ask for: true = re-run it (something was too small; it has been enlarged)
-static bool pass_needs_retry(Ctx& c, const unsigned long long* ctr, uint64_t& want_seg) {
-  const uint32_t item_cap = (uint32_t)std::min<uint64_t>(c.items.cap, 0xffffffffull);
-  const uint32_t item_h_cap = (uint32_t)std::min<uint64_t>(c.items_h.cap, 0xffffffffull);
+// the limits a pass was enqueued with (several passes of an asynchronous group run before any of their counters is read)
+struct PassLimits {
+  uint32_t s_max, heavy_div;
+  uint64_t seg_cap, qb_cap, item_cap, item_h_cap;
+};
+static PassLimits limits_of(const Ctx& c) {
+  return PassLimits{c.s_max, c.heavy_div, c.seg_cap, c.qb.cap, std::min<uint64_t>(c.items.cap, 0xffffffffull),
+                    std::min<uint64_t>(c.items_h.cap, 0xffffffffull)};
+}
+
+// what the counters of a finished pass ask for: true = re-run it (something was too small for it under the limits `ran`
+// it was enqueued with; the context's limits are raised, never lowered)
+static bool pass_needs_retry(Ctx& c, const unsigned long long* ctr, const PassLimits& ran, uint64_t& want_seg) {
   bool retry = false;
-  if (ctr[6] > c.seg_cap) { want_seg = std::max<uint64_t>(want_seg, ctr[6] + ctr[6] / 4); retry = true; }   // segments did not fit
-  if (ctr[21] > c.qb.cap) { c.want_qb = std::max<uint64_t>(c.want_qb, ctr[21] + ctr[21] / 4); retry = true; }  // queues did not fit
-  if (ctr[4] > c.s_max) {                                                          // a query had more survivors
-    unsigned long long s = c.s_max;
+  if (ctr[6] > ran.seg_cap) { want_seg = std::max<uint64_t>(want_seg, ctr[6] + ctr[6] / 4); retry = true; }   // segments did not fit
+  if (ctr[21] > ran.qb_cap) { c.want_qb = std::max<uint64_t>(c.want_qb, ctr[21] + ctr[21] / 4); retry = true; }  // queues did not fit
+  if (ctr[4] > ran.s_max) {                                                        // a query had more survivors
+    unsigned long long s = std::max<uint32_t>(c.s_max, ran.s_max);
     while (s < ctr[4] && s < (1ull << 31)) s <<= 1;
-    c.s_max = (uint32_t)std::min<unsigned long long>(s, 0x80000000ull);
-    if (ctr[4] > c.s_max) throw UnsupportedError("a query kept more than 2^31 hits");
+    if (ctr[4] > s) throw UnsupportedError("a query kept more than 2^31 hits");
+    c.s_max = std::max<uint32_t>(c.s_max, (uint32_t)s);
     retry = true;
   } else if (ctr[4] != 0) {                                                        // more of its long-range hits passed than reserved
-    if (c.heavy_div == 1) throw GpuError("a query queued more hits than it has");
-    c.heavy_div = c.heavy_div > 4 ? 4 : 1;
+    if (ran.heavy_div == 1) throw GpuError("a query queued more hits than it has");
+    c.heavy_div = std::min<uint32_t>(c.heavy_div, ran.heavy_div > 4 ? 4u : 1u);
     retry = true;
   }
-  if (std::max(ctr[5], ctr[12]) > item_cap) {                                      // work-item list too short
+  if (std::max(ctr[5], ctr[12]) > ran.item_cap) {                                  // work-item list too short
     const unsigned long long need = std::max(ctr[5], ctr[12]);
     const uint64_t nc = std::min<unsigned long long>(need + need / 4, 0xffffffffull);
     c.items.ensure(nc); c.items_b.ensure(nc);
     retry = true;
   }
-  if (ctr[15] > item_h_cap) {                                                      // heavy-range item list too short
+  if (ctr[15] > ran.item_h_cap) {                                                  // heavy-range item list too short
     c.items_h.ensure(std::min<unsigned long long>(ctr[15] + ctr[15] / 4, 0xffffffffull));
     retry = true;
   }
@@ -623,8 +624,8 @@ constexpr uint32_t kAsyncGroup = 32;  // passes enqueued before the host looks a
 // Otherwise (device entry point with stage timing) each pass is synchronised and timed.
 static void run_passes(DeviceIndex::Impl& m, Ctx& c, const Params& prm_in, const DeviceBatchView& bv, Rec* d_out,
                        uint32_t* d_out_count, uint32_t* d_out_total, uint32_t cap, hipStream_t stream,
-                       const std::vector<uint32_t>& sub_tok_bounds, uint32_t sub_queries, Stats* st, const PassHooks* hooks,
-                       bool async_ok) {
+                       const std::vector<uint64_t>& sub_q_bounds, const std::vector<uint32_t>& sub_tok_bounds, Stats* st,
+                       const PassHooks* hooks, bool async_ok) {
   if (cap == 0) throw std::invalid_argument("cap must be > 0");
   // cost model: real-token / penalty-token terms need the general kernel (DP rows in LDS / HBM); idf alone has a
   // register kernel
@@ -635,8 +636,8 @@ static void run_passes(DeviceIndex::Impl& m, Ctx& c, const Params& prm_in, const
   auto batch_of = [&](uint32_t sb) {
     DevBatch b;
     b.q_off = bv.q_off; b.q_tok = bv.q_tok; b.q_real = bv.q_real; b.q_itok = bv.q_itok;
-    b.q_begin = sb * sub_queries;
-    b.nq = (uint32_t)std::min<uint64_t>(sub_queries, bv.nq - b.q_begin);
+    b.q_begin = (uint32_t)sub_q_bounds[sb];
+    b.nq = (uint32_t)(sub_q_bounds[sb + 1] - sub_q_bounds[sb]);
     b.t_begin = sub_tok_bounds[sb];
     b.nt = sub_tok_bounds[sb + 1] - sub_tok_bounds[sb];
     return b;
@@ -657,6 +658,7 @@ static void run_passes(DeviceIndex::Impl& m, Ctx& c, const Params& prm_in, const
     for (int attempt = 0;; attempt++) {
       ensure_ws(c, b.nq, std::max<uint32_t>(b.nt, 1), want_seg);
       c.cmin_tab.ensure((uint64_t)(p_max + 1) * kCminRow);
+      const PassLimits ran = limits_of(c);
       enqueue_pass(E, b, p_max, st != nullptr, c.h_ctr);
       HIP_TRY(hipStreamSynchronize(stream));
       if (st) {
@@ -667,7 +669,7 @@ static void run_passes(DeviceIndex::Impl& m, Ctx& c, const Params& prm_in, const
           st->launches[s] += 1;
         }
       }
-      if (pass_needs_retry(c, c.h_ctr, want_seg)) {
+      if (pass_needs_retry(c, c.h_ctr, ran, want_seg)) {
         if (attempt >= 6) throw GpuError("workspace kept overflowing");
         if (st) st->n_retries++;
         continue;
@@ -699,6 +701,7 @@ static void run_passes(DeviceIndex::Impl& m, Ctx& c, const Params& prm_in, const
     }
     ensure_ws(c, nq_max, nt_max, seg_max);
     c.cmin_tab.ensure((uint64_t)(pm_max + 1) * kCminRow);
+    const PassLimits ran = limits_of(c);  // every pass of the group runs under these
     for (uint32_t sb = g0; sb < g1; sb++) {
       const DevBatch b = batch_of(sb);
       if (hooks && hooks->before) hooks->before(sb);
@@ -711,7 +714,7 @@ static void run_passes(DeviceIndex::Impl& m, Ctx& c, const Params& prm_in, const
     std::vector<uint32_t> redo;
     for (uint32_t sb = g0; sb < g1; sb++) {
       const unsigned long long* ctr = c.h_ctr_group + (size_t)(sb - g0) * kNumCounters;
-      if (pass_needs_retry(c, ctr, want_seg)) redo.push_back(sb);
+      if (pass_needs_retry(c, ctr, ran, want_seg)) redo.push_back(sb);
       else add_counters(st, ctr);
     }
     for (uint32_t sb : redo) {
@@ -733,7 +736,11 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm, const Devi
   // the caller's stream carries the work (NULL = the context's own stream)
   hipStream_t stream = stream_v ? (hipStream_t)stream_v : lease.c->stream;
   if (!stream_v) HIP_TRY(hipDeviceSynchronize());  // inputs may have been produced on other streams
-  run_passes(m, *lease.c, prm, bv, d_out, d_out_count, d_out_total, cap, stream, sub_tok_bounds, m.sub_queries, st, nullptr, false);
+  std::vector<uint64_t> q_bounds;
+  for (uint64_t q = 0; q < bv.nq; q += m.sub_queries) q_bounds.push_back(q);
+  q_bounds.push_back(bv.nq);
+  if (q_bounds.size() != sub_tok_bounds.size()) throw std::invalid_argument("sub-batch bounds do not match the batch");
+  run_passes(m, *lease.c, prm, bv, d_out, d_out_count, d_out_total, cap, stream, q_bounds, sub_tok_bounds, st, nullptr, false);
 }
 
 static bool is_pinned(const void* p) {
@@ -741,6 +748,24 @@ static bool is_pinned(const void* p) {
   hipPointerAttribute_t a;
   if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
   return a.type == hipMemoryTypeHost;
+}
+
+// device-visible address of a pinned host buffer (nullptr if the buffer is pageable)
+template <class T> static T* pinned_device_ptr(T* p) {
+  if (!p) return nullptr;
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return a.type == hipMemoryTypeHost ? (T*)a.devicePointer : nullptr;
+}
+
+// Small result arrays (counts, totals: 4 bytes per query) written straight into the caller's pinned buffers over PCIe: a
+// 1 MB copy through the DMA engine costs ~150 us of set-up, two of them after the last pass are half of the call's tail.
+__global__ void k_export_counts(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ tot, uint32_t* __restrict__ h_cnt,
+                                uint32_t* __restrict__ h_tot, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  h_cnt[i] = cnt[i];
+  if (h_tot) h_tot[i] = tot[i];
 }
 
 __global__ void k_rebase(uint32_t* off, uint32_t n, uint32_t base) {
@@ -774,11 +799,19 @@ void DeviceIndex::match_host(const HostIndex& h, const Params& prm, const HostBa
   c.d_out.ensure(nq * cap);
   c.d_cnt.ensure(nq);
   c.d_tot.ensure(nq);
-  const uint32_t sub = std::max<uint32_t>(1, std::min(m.sub_queries, m.host_sub_queries));
-  const uint32_t n_sub = (uint32_t)((nq + sub - 1) / sub);
+  // Pass schedule: uniform passes of host_sub_queries queries.  A pass costs ~0.8 ms of launch gaps and kernel tails on
+  // top of its per-query time, the inputs of the first pass and the records of the last cross PCIe with no kernel to hide
+  // behind, and a pass's records (88 bytes per query) must be home before the next pass ends: measured on the C3
+  // workload, two passes per million queries are the best trade (tools/host_sweep.py; uneven schedules with small
+  // first / last passes were worse: the big middle pass's copies stick out).
+  const uint64_t per_pass = std::max<uint32_t>(1, std::min(m.sub_queries, m.host_sub_queries));
+  std::vector<uint64_t> qb;
+  for (uint64_t q = 0; q < nq; q += per_pass) qb.push_back(q);
+  qb.push_back(nq);
+  const uint32_t n_sub = (uint32_t)qb.size() - 1;
   std::vector<uint32_t> bounds(n_sub + 1);
   uint32_t p_max = 0;
-  for (uint32_t s = 0; s < n_sub; s++) bounds[s] = hb.q_off[(uint64_t)s * sub] - base;
+  for (uint32_t s = 0; s < n_sub; s++) bounds[s] = hb.q_off[qb[s]] - base;
   bounds[n_sub] = (uint32_t)nt;
   for (uint64_t q = 0; q < nq; q++) p_max = std::max(p_max, hb.q_off[q + 1] - hb.q_off[q]);
   DeviceBatchView bv;
@@ -787,11 +820,14 @@ void DeviceIndex::match_host(const HostIndex& h, const Params& prm, const HostBa
   bv.q_itok = hb.q_itok ? c.d_qitok.p : nullptr;
   bv.p_max = std::max<uint32_t>(p_max, 1);
   const bool pinned = is_pinned(hb.q_off) && is_pinned(hb.q_tok) && is_pinned(out) && is_pinned(out_count);
+  uint32_t* const hd_count = pinned_device_ptr(out_count);
+  uint32_t* const hd_total = out_total ? pinned_device_ptr(out_total) : nullptr;
+  const bool export_kernel = hd_count && (!out_total || hd_total);
   double ms_h2d = 0.0, ms_d2h = 0.0;
   // inputs of pass s: offsets [s*sub, end] (the last pass also sends q_off[nq]), tokens of those queries
   auto send = [&](uint32_t s) {
     const auto a = std::chrono::steady_clock::now();
-    const uint64_t q0 = (uint64_t)s * sub, q1 = std::min<uint64_t>(q0 + sub, nq);
+    const uint64_t q0 = qb[s], q1 = qb[s + 1];
     // pass s reads offsets [q0, q1] inclusive; q0 itself already came with the previous pass
     const uint64_t o_lo = s == 0 ? q0 : q0 + 1, n_off = q1 - o_lo + 1;
     HIP_TRY(hipMemcpyAsync(c.d_qoff.p + o_lo, hb.q_off + o_lo, n_off * 4, hipMemcpyHostToDevice, c.h2d));
@@ -814,11 +850,17 @@ void DeviceIndex::match_host(const HostIndex& h, const Params& prm, const HostBa
   };
   hooks.after = [&](uint32_t s, hipEvent_t done) {  // the records of pass s go home once `done` (null: already complete)
     const auto a = std::chrono::steady_clock::now();
-    const uint64_t q0 = (uint64_t)s * sub, q1 = std::min<uint64_t>(q0 + sub, nq), n = q1 - q0;
+    const uint64_t q0 = qb[s], q1 = qb[s + 1], n = q1 - q0;
     if (done) HIP_TRY(hipStreamWaitEvent(c.d2h, done, 0));
+    // (the records stay with the DMA engine: a copy kernel writing them over PCIe was 1 ms per million queries slower)
     HIP_TRY(hipMemcpyAsync(out + q0 * cap, c.d_out.p + q0 * cap, n * cap * sizeof(Rec), hipMemcpyDeviceToHost, c.d2h));
-    HIP_TRY(hipMemcpyAsync(out_count + q0, c.d_cnt.p + q0, n * 4, hipMemcpyDeviceToHost, c.d2h));
-    if (out_total) HIP_TRY(hipMemcpyAsync(out_total + q0, c.d_tot.p + q0, n * 4, hipMemcpyDeviceToHost, c.d2h));
+    if (export_kernel) {
+      hipLaunchKernelGGL(k_export_counts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.d2h, (const uint32_t*)c.d_cnt.p + q0,
+                         (const uint32_t*)c.d_tot.p + q0, hd_count + q0, hd_total ? hd_total + q0 : nullptr, (uint32_t)n);
+    } else {
+      HIP_TRY(hipMemcpyAsync(out_count + q0, c.d_cnt.p + q0, n * 4, hipMemcpyDeviceToHost, c.d2h));
+      if (out_total) HIP_TRY(hipMemcpyAsync(out_total + q0, c.d_tot.p + q0, n * 4, hipMemcpyDeviceToHost, c.d2h));
+    }
     if (d_keep) {  // a device-resident copy for a collective that follows (the multi-process RCCL gather)
       HIP_TRY(hipMemcpyAsync(d_keep + q0 * cap, c.d_out.p + q0 * cap, n * cap * sizeof(Rec), hipMemcpyDeviceToDevice, c.d2h));
       if (d_keep_count) HIP_TRY(hipMemcpyAsync(d_keep_count + q0, c.d_cnt.p + q0, n * 4, hipMemcpyDeviceToDevice, c.d2h));
@@ -826,7 +868,7 @@ void DeviceIndex::match_host(const HostIndex& h, const Params& prm, const HostBa
     ms_d2h += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
   };
   // stage timing (st with events) is the device entry point's job: here the passes run back to back, unsynchronised
-  run_passes(m, c, prm, bv, c.d_out.p, c.d_cnt.p, c.d_tot.p, cap, c.stream, bounds, sub, st, &hooks, true);
+  run_passes(m, c, prm, bv, c.d_out.p, c.d_cnt.p, c.d_tot.p, cap, c.stream, qb, bounds, st, &hooks, true);
   const auto a = std::chrono::steady_clock::now();
   HIP_TRY(hipStreamSynchronize(c.d2h));
   ms_d2h += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();

@@ -125,7 +125,10 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 // ---------------------------------------------------------------------------------------------
 __global__ void k_setup(DevIndex ix, DevBatch b, DevWork w, Params prm) {
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= b.nq) return;
+  if (q > b.nq) return;
+  w.q_hits[q] = 0; w.q_hits_a[q] = 0;  // k_probe's per-query accumulators (nq + 1 entries)
+  if (q == b.nq) return;
+  w.q_pb[q] = 0;
   const uint32_t o0 = b.q_off[b.q_begin + q], o1 = b.q_off[b.q_begin + q + 1];
   const uint32_t p = o1 - o0;
   const uint32_t msl = min_seq_len(p, prm);
@@ -254,7 +257,7 @@ __global__ void __launch_bounds__(kWave) k_build_planes(const unsigned long long
 }
 
 // ---------------------------------------------------------------------------------------------
-// exclusive scan of q_hits -> q_seg (three small kernels; nq <= 8192 * 8192)
+// exclusive scans of per-query counts -> segment offsets
 // ---------------------------------------------------------------------------------------------
 constexpr int kScanThreads = 1024;
 constexpr int kScanItems = 8;
@@ -287,39 +290,75 @@ __device__ __forceinline__ unsigned long long block_excl_scan(unsigned long long
   return base + x - v;
 }
 
-__global__ void __launch_bounds__(kScanThreads) k_scan_tiles(const unsigned long long* in, unsigned long long* out,
-                                                            unsigned long long* tile_sums, uint32_t n) {
-  const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
-  unsigned long long v[kScanItems], s = 0;
-#pragma unroll
-  for (int k = 0; k < kScanItems; k++) { v[k] = base + k < n ? in[base + k] : 0ull; s += v[k]; }
-  unsigned long long total;
-  unsigned long long ex = block_excl_scan(s, &total);
-#pragma unroll
-  for (int k = 0; k < kScanItems; k++) { if (base + k < n) out[base + k] = ex; ex += v[k]; }
-  if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
-}
+// Single-pass exclusive scan with decoupled look-back (Merrill & Garland 2016) of NARR arrays of n elements laid out
+// `stride` apart: out[i] = sum of in[0 .. i), so with a zero last element out[n - 1] is the total.  One launch instead
+// of the reduce / scan-of-sums / add triple (the pipeline runs five scans per pass; between the large kernels every
+// launch is ~10 us of empty GPU).  Tiles are numbered by a ticket, so every predecessor a tile waits for is already
+// running.  state[a * kLbMaxTiles + tile] = flag << 62 | value: 1 = the tile's own sum, 2 = the inclusive prefix up to
+// and including the tile; the host zeroes state and ticket once per pass (one memset with the counters).
+constexpr uint32_t kLbMaxTiles = 1024;  // tiles per scan: sub-batches of up to 8 M queries
+constexpr int kLbMaxArrays = 3;
+constexpr unsigned long long kLbValMask = (1ull << 62) - 1ull;
 
-__global__ void __launch_bounds__(kScanThreads) k_scan_sums(unsigned long long* tile_sums, uint32_t n_tiles,
-                                                           unsigned long long* grand_total) {
-  // single block; n_tiles <= kScanTile
-  const uint32_t base = threadIdx.x * kScanItems;
-  unsigned long long v[kScanItems], s = 0;
+template <int NARR>
+__global__ void __launch_bounds__(kScanThreads) k_scan_lb(const unsigned long long* in, unsigned long long* out, size_t stride,
+                                                         uint32_t n, unsigned long long* state, uint32_t* ticket) {
+  __shared__ uint32_t s_tile;
+  __shared__ unsigned long long s_total[NARR], s_prefix[NARR];
+  if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+  __syncthreads();
+  const uint32_t tile = s_tile;
+  const uint32_t base = tile * kScanTile + threadIdx.x * kScanItems;
+  unsigned long long v[NARR][kScanItems], ex[NARR];
 #pragma unroll
-  for (int k = 0; k < kScanItems; k++) { v[k] = base + k < n_tiles ? tile_sums[base + k] : 0ull; s += v[k]; }
-  unsigned long long total;
-  unsigned long long ex = block_excl_scan(s, &total);
+  for (int a = 0; a < NARR; a++) {
+    unsigned long long sum = 0;
 #pragma unroll
-  for (int k = 0; k < kScanItems; k++) { if (base + k < n_tiles) tile_sums[base + k] = ex; ex += v[k]; }
-  if (threadIdx.x == 0) *grand_total = total;
-}
-
-__global__ void __launch_bounds__(kScanThreads) k_scan_add(unsigned long long* out, const unsigned long long* tile_sums,
-                                                          uint32_t n) {
-  const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
-  const unsigned long long add = tile_sums[blockIdx.x];
+    for (int k = 0; k < kScanItems; k++) { v[a][k] = base + k < n ? in[a * stride + base + k] : 0ull; sum += v[a][k]; }
+    unsigned long long total;
+    ex[a] = block_excl_scan(sum, &total);
+    if (threadIdx.x == 0) s_total[a] = total;
+  }
+  __syncthreads();
+  if (threadIdx.x < kWave) {  // the first wave publishes the tile's sums and looks back, 64 predecessors at a time
+    const uint32_t lane = threadIdx.x;
 #pragma unroll
-  for (int k = 0; k < kScanItems; k++) if (base + k < n) out[base + k] += add;
+    for (int a = 0; a < NARR; a++) {
+      unsigned long long* st = state + (size_t)a * kLbMaxTiles;
+      const unsigned long long total = s_total[a];
+      unsigned long long run = 0;
+      if (tile != 0) {
+        if (lane == 0) __hip_atomic_store(&st[tile], (1ull << 62) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int hi = (int)tile - 1;  // nearest predecessor not yet accounted for
+        for (;;) {
+          const int t = hi - (int)lane;
+          unsigned long long sv = 0;
+          do {
+            sv = t >= 0 ? __hip_atomic_load(&st[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2ull << 62);
+          } while (__ballot((sv >> 62) == 0ull) != 0ull);
+          const unsigned long long pm = __ballot((sv >> 62) == 2ull);  // lanes that found an inclusive prefix (t < 0 counts as one of 0)
+          const int first_p = pm ? __ffsll((long long)pm) - 1 : kWave;
+          unsigned long long part = (int)lane <= first_p ? (sv & kLbValMask) : 0ull;
+#pragma unroll
+          for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+          run += part;
+          if (pm) break;
+          hi -= kWave;
+        }
+      }
+      if (lane == 0) {
+        __hip_atomic_store(&st[tile], (2ull << 62) | ((run + total) & kLbValMask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_prefix[a] = run;
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < NARR; a++) {
+    unsigned long long e = s_prefix[a] + ex[a];
+#pragma unroll
+    for (int k = 0; k < kScanItems; k++) { if (base + k < n) out[a * stride + base + k] = e; e += v[a][k]; }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------

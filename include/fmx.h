@@ -255,10 +255,13 @@ int64_t fmx_index_add_text(fmx_index*, const char* id, const char* sentence, siz
  *   "contexts"          concurrent calls served at once per device, each with its own workspace (default 2)
  *   "heavy_min"         suffix ranges at least this long are tested through the bit planes (default 1024, 0 = never)
  *   "coalesce_us"       longest time fmx_match_one waits for company (default 50)
+ *   "host_lanes"        host threads (each with its own workspace and streams) one fmx_match_batch call spreads a
+ *                       device's queries over (default 1: measured no better than one lane with the pass schedule
+ *                       below; concurrent callers overlap anyway, every call works in its own context)
  *   "probe_count"       measurement: k_probe also counts the bytes and lines it requests (fmx_stats.probe_*)
  *   "sub_queries"       queries per pipeline pass (default 1 048 576)
- *   "host_sub_queries"  pass size of fmx_match_batch (host buffers, default 262 144): the results of a pass are
- *                       copied to the host while the next pass computes
+ *   "host_sub_queries"  pass size of fmx_match_batch (host buffers, default 524 288): the inputs of the next pass and
+ *                       the records of the previous one cross PCIe while a pass computes
  *   "initial_segment"   initial capacity of the hit workspace (grows on demand) */
 int fmx_set_option(fmx_index*, const char* name, int64_t value);
 

@@ -161,6 +161,35 @@ def test_big_candidate_sets(fmx, gpu_device):
         assert st.n_big > 0 and st.max_kept > 1024, (name, st.n_big, st.max_kept)
 
 
+def test_many_passes_in_one_asynchronous_group_with_a_small_workspace(fmx, gpu_device):
+    """fmx_match_batch enqueues up to 32 passes before it reads any of their counters.  Several passes of one group
+    then report that the queues / segments / per-query capacity they ran with were too small: each report has to be
+    judged against the limits the pass was enqueued with, not against limits an earlier report has already raised
+    (a stale comparison used to end in 'a query queued more hits than it has')."""
+    rng = np.random.default_rng(17)
+    vocab = 8
+    c_off, c_tok = workloads.dense_corpus(rng, 30000, vocab, min_len=4, max_len=10)
+    q_off, q_tok = workloads.edge_queries(rng, c_off, c_tok, vocab, 48)
+    ix = fmx.Index.create(max_tokens=40)
+    ix.add_ids(c_off, c_tok, vocab + 2)
+    ix.sort(gpu_device)
+    ix.finalize()
+    ix.to_device(gpu_device)
+    ix.set_option("initial_segment", 1024)
+    ix.set_option("host_sub_queries", 2)   # 24 passes, one asynchronous group
+    o = oracle_lib.OracleIndex(max_tokens=40)
+    o.add_ids_bulk(c_off, c_tok, vocab + 2, sfreq=ix.array("sfreq"))
+    o.sort(oracle_lib.effective_cpus())
+    kw = dict(fuzzy=0.2, nmatch=0, min_subseq_length=2, min_subseq_ratio=0)
+    oo, oc = o.match_batch(oracle_lib.Params(**kw), q_off, q_tok, 128, nthreads=oracle_lib.effective_cpus())
+    go, gc, gt, st = ix.match_batch(fmx.Params(**kw), q_off, q_tok, cap=128, want_stats=True)
+    workloads.compare(oo, oc, go, gc, "small workspace, 24 passes")
+    assert st.n_retries > 1, st.n_retries
+    go, gc, gt, st = ix.match_batch(fmx.Params(**kw), q_off, q_tok, cap=128, want_stats=True)  # grown: no retry left
+    workloads.compare(oo, oc, go, gc, "second call")
+    assert st.n_retries == 0, st.n_retries
+
+
 def test_long_sentences_beyond_threshold_table(fmx, gpu_device):
     """Sentences longer than phase A's 1024-entry length table (decided by phase B instead) and patterns
     longer than 256 tokens (signature planes overflow; DP rows through LDS)."""
