@@ -214,9 +214,36 @@ const char* fmx_index_sentence_id(const fmx_index* ix, uint32_t s_id) {
   return ix->host.ids[s_id].c_str();
 }
 
+int fmx_index_device_array(const fmx_index* ix, int replica, int which, void* dst, uint64_t capacity_bytes, uint64_t* count) {
+  if (!ix || !count) return fail(FMX_E_INVALID, "null argument");
+  if (replica < 0 || (size_t)replica >= ix->devs.size()) return fail(FMX_E_NO_DEVICE, "no such replica");
+  int k;
+  switch (which) {
+    case FMX_A_SUF_REC: k = 0; break;
+    case FMX_A_SUF_SIG: k = 1; break;
+    case FMX_A_SUF_KEY: k = 2; break;
+    case FMX_A_GRAM: k = 3; break;
+    case FMX_A_GRAM5: k = 4; break;
+    case FMX_A_SUF_B: k = 5; break;
+    default: return fail(FMX_E_INVALID, "not a device-built array");
+  }
+  return guarded([&]() { *count = ix->devs[replica]->download(k, dst, capacity_bytes); return (int)FMX_OK; });
+}
+
 int fmx_index_array(const fmx_index* ix, int which, const void** data, uint64_t* count) {
   if (!ix || !data || !count) return fail(FMX_E_INVALID, "null argument");
   const HostIndex& h = ix->host;
+  switch (which) {  // the accelerator arrays live in HBM only; their host twins (test oracle, CPU emulation) are built on request
+    case FMX_A_SUF_REC: case FMX_A_SUF_SIG: case FMX_A_SUF_KEY: case FMX_A_GRAM: case FMX_A_GRAM5: case FMX_A_SUF_B: {
+      if (!ix->finalized) return fail(FMX_E_STATE, "index is not finalized");
+      fmx_index* mix = const_cast<fmx_index*>(ix);
+      std::lock_guard<std::mutex> lk(mix->mu);
+      const int rc = guarded([&]() { mix->host.derive_heavy(); return (int)FMX_OK; });
+      if (rc != FMX_OK) return rc;
+      break;
+    }
+    default: break;
+  }
   switch (which) {
     case FMX_A_SUF_SID: *data = h.suf_sid.data(); *count = h.suf_sid.size(); break;
     case FMX_A_SUF_POS: *data = h.suf_pos.data(); *count = h.suf_pos.size(); break;

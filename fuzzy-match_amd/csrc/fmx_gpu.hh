@@ -62,6 +62,8 @@ class DeviceIndex {
 
   void     upload(const HostIndex& h, int device);
   int      device() const;
+  // test / debug: one of the device-built arrays (0 suf, 1 suf_sig, 2 suf_key, 3 gram, 4 gram5, 5 suf_b); returns its element count
+  uint64_t download(int which, void* dst, uint64_t capacity_bytes) const;
   uint64_t bytes() const;
   void     set_sub_queries(uint32_t n);
   void     set_host_sub_queries(uint32_t n);

@@ -25,6 +25,7 @@
 
 #include "fmx_kernels.hip.hh"
 #include "fmx_subseq.hip.hh"
+#include "fmx_derive.hip.hh"
 
 namespace fmx {
 
@@ -268,25 +269,130 @@ static void refresh_itok_table(DeviceIndex::Impl& m, const HostIndex& h) {
 
 constexpr size_t kDynLdsMax = 150 * 1024;  // dynamic LDS the row kernels may ask for (160 KB per CU on gfx950)
 
+// The accelerator arrays from the reference's arrays, on the device: kernels in fmx_derive.hip.hh.
+// m.d.tok and m.d.sent_pos are already resident; the suffix array goes up (6 bytes per suffix) and is dropped afterwards.
+static void derive_on_device(DeviceIndex::Impl& m, const HostIndex& h) {
+  const uint64_t n = h.num_suffixes();
+  const uint32_t n_sent = h.num_sentences();
+  m.d.suf = nullptr; m.d.suf_b = nullptr; m.d.suf_sig = nullptr; m.d.suf_key = nullptr;
+  m.d.gram.g3 = nullptr; m.d.gram.g5 = nullptr; m.d.gram.mask3 = 0; m.d.gram.mask5 = 0;
+  SufRec* suf = dev_alloc<SufRec>(n);
+  SufRecB* suf_b = dev_alloc<SufRecB>(n);
+  unsigned long long* suf_sig = dev_alloc<unsigned long long>(n);
+  SufKey* suf_key = dev_alloc<SufKey>(n);
+  m.d.suf = suf; m.d.suf_b = suf_b; m.d.suf_sig = suf_sig; m.d.suf_key = suf_key;
+  m.bytes += n * (sizeof(SufRec) + sizeof(SufRecB) + 8 + sizeof(SufKey));
+  if (n == 0) return;
+  {
+    uint32_t* d_sid = dev_upload(h.suf_sid);
+    uint16_t* d_pos = dev_upload(h.suf_pos);
+    unsigned long long* d_ssig = dev_alloc<unsigned long long>(n_sent);
+    hipLaunchKernelGGL(k_dv_sent_sig, dim3((n_sent + 255) / 256), dim3(256), 0, 0, m.d.tok, m.d.sent_pos, n_sent, d_ssig);
+    hipLaunchKernelGGL(k_dv_suffix, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, m.d.tok, m.d.sent_pos, (const uint32_t*)d_sid,
+                       (const uint16_t*)d_pos, (const unsigned long long*)d_ssig, (unsigned long long)n, suf, suf_b, suf_sig, suf_key);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    hipFree(d_sid); hipFree(d_pos); hipFree(d_ssig);
+  }
+  // ---- n-gram tables ----
+  const uint32_t n32 = (uint32_t)n;
+  uint32_t* bnd3 = dev_alloc<uint32_t>(n);
+  uint32_t* bnd5 = nullptr;
+  uint32_t* lo3 = nullptr;
+  size_t* d_num = dev_alloc<size_t>(1);
+  unsigned long long* d_count = dev_alloc<unsigned long long>(1);
+  void* tmp = nullptr;
+  auto cleanup = [&]() { hipFree(bnd3); hipFree(bnd5); hipFree(lo3); hipFree(d_num); hipFree(d_count); hipFree(tmp); };
+  try {
+    const DvTriBoundary tri{suf, suf_key, m.d.tok};
+    auto select = [&](auto pred, uint32_t* out) -> uint32_t {
+      size_t bytes = 0;
+      HIP_TRY(rocprim::select(nullptr, bytes, rocprim::counting_iterator<uint32_t>(0), out, d_num, (size_t)n, pred, (hipStream_t)0, false));
+      hipFree(tmp); tmp = nullptr;
+      HIP_TRY(hipMalloc(&tmp, std::max<size_t>(bytes, 1)));
+      HIP_TRY(rocprim::select(tmp, bytes, rocprim::counting_iterator<uint32_t>(0), out, d_num, (size_t)n, pred, (hipStream_t)0, false));
+      size_t num = 0;
+      HIP_TRY(hipMemcpy(&num, d_num, sizeof(size_t), hipMemcpyDeviceToHost));
+      return (uint32_t)num;
+    };
+    auto read_count = [&]() { unsigned long long v = 0; HIP_TRY(hipMemcpy(&v, d_count, 8, hipMemcpyDeviceToHost)); return v; };
+    auto table_cap = [](unsigned long long groups) { unsigned long long cap = 16; while (cap < groups * 2) cap <<= 1; return cap; };
+    const uint32_t n_b3 = select(tri, bnd3);
+    HIP_TRY(hipMemset(d_count, 0, 8));
+    hipLaunchKernelGGL(k_dv_count_starts, dim3((n_b3 + 255) / 256), dim3(256), 0, 0, (const uint32_t*)bnd3, n_b3, (const SufRec*)suf, 3u, d_count);
+    const unsigned long long groups = read_count();
+    const unsigned long long cap3 = table_cap(groups);
+    if (groups != 0 && cap3 <= (1ull << 31)) {  // else: the keyed search is used instead (same rule as HostIndex::build_gram_table)
+      GramEntry* g3 = dev_alloc<GramEntry>(cap3);
+      m.d.gram.g3 = g3; m.d.gram.mask3 = (uint32_t)(cap3 - 1);
+      m.bytes += cap3 * sizeof(GramEntry);
+      hipLaunchKernelGGL(k_dv_fill_empty, dim3((unsigned)((cap3 + 255) / 256)), dim3(256), 0, 0, g3, cap3);
+      hipLaunchKernelGGL(k_dv_insert3, dim3((n_b3 + 255) / 256), dim3(256), 0, 0, (const uint32_t*)bnd3, n_b3, n32, (const SufRec*)suf,
+                         (const SufKey*)suf_key, m.d.tok, g3, (uint32_t)(cap3 - 1));
+      // second level: the distinct 5-grams of the trigram groups with more than kDeepGramMin suffixes
+      bnd5 = dev_alloc<uint32_t>(n);
+      const uint32_t n_b5 = select(DvFiveBoundary{tri}, bnd5);
+      lo3 = dev_alloc<uint32_t>(n_b5);
+      HIP_TRY(hipMemset(d_count, 0, 8));
+      hipLaunchKernelGGL(k_dv_mark5, dim3((n_b5 + 255) / 256), dim3(256), 0, 0, (const uint32_t*)bnd5, n_b5, (const uint32_t*)bnd3, n_b3, n32,
+                         (const SufRec*)suf, lo3, d_count);
+      const unsigned long long groups5 = read_count();
+      const unsigned long long cap5 = table_cap(groups5);
+      if (groups5 != 0 && cap5 <= (1ull << 31)) {
+        GramEntry* g5 = dev_alloc<GramEntry>(cap5);
+        m.d.gram.g5 = g5; m.d.gram.mask5 = (uint32_t)(cap5 - 1);
+        m.bytes += cap5 * sizeof(GramEntry);
+        hipLaunchKernelGGL(k_dv_fill_empty, dim3((unsigned)((cap5 + 255) / 256)), dim3(256), 0, 0, g5, cap5);
+        hipLaunchKernelGGL(k_dv_insert5, dim3((n_b5 + 255) / 256), dim3(256), 0, 0, (const uint32_t*)bnd5, n_b5, n32, (const uint32_t*)lo3,
+                           (const SufKey*)suf_key, g5, (uint32_t)(cap5 - 1));
+      }
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+  } catch (...) {
+    cleanup();
+    throw;
+  }
+  cleanup();
+}
+
+// test / debug: a derived array as it sits in HBM
+uint64_t DeviceIndex::download(int which, void* dst, uint64_t capacity_bytes) const {
+  const Impl& m = *impl_;
+  if (m.device < 0) throw GpuError("index is not on a device");
+  HIP_TRY(hipSetDevice(m.device));
+  const void* src = nullptr;
+  uint64_t count = 0, elem = 0;
+  switch (which) {
+    case 0: src = m.d.suf; count = m.d.n_suf; elem = sizeof(SufRec); break;
+    case 1: src = m.d.suf_sig; count = m.d.n_suf; elem = 8; break;
+    case 2: src = m.d.suf_key; count = m.d.n_suf; elem = sizeof(SufKey); break;
+    case 3: src = m.d.gram.g3; count = m.d.gram.g3 ? (uint64_t)m.d.gram.mask3 + 1 : 0; elem = sizeof(GramEntry); break;
+    case 4: src = m.d.gram.g5; count = m.d.gram.g5 ? (uint64_t)m.d.gram.mask5 + 1 : 0; elem = sizeof(GramEntry); break;
+    case 5: src = m.d.suf_b; count = m.d.n_suf; elem = sizeof(SufRecB); break;
+    default: throw std::invalid_argument("unknown device array");
+  }
+  if (dst && count) {
+    if (count * elem > capacity_bytes) throw std::invalid_argument("destination too small");
+    HIP_TRY(hipMemcpy(dst, src, count * elem, hipMemcpyDeviceToHost));
+  }
+  return count;
+}
+
 void DeviceIndex::upload(const HostIndex& h, int device) {
   Impl& m = *impl_;
   if (m.device >= 0) throw GpuError("index is already on a device");
   check_device(device);
   HIP_TRY(hipSetDevice(device));
   m.device = device;
-  m.d.suf = dev_upload(h.suf_rec);
-  m.d.suf_b = dev_upload(h.suf_b);
-  m.d.suf_sig = (const unsigned long long*)dev_upload(h.suf_sig);
-  m.d.suf_key = dev_upload(h.suf_key);
-  m.d.gram.g3 = h.gram.empty() ? nullptr : dev_upload(h.gram);
-  m.d.gram.mask3 = h.gram.empty() ? 0u : (uint32_t)(h.gram.size() - 1);
-  m.d.gram.g5 = h.gram5.empty() ? nullptr : dev_upload(h.gram5);
-  m.d.gram.mask5 = h.gram5.empty() ? 0u : (uint32_t)(h.gram5.size() - 1);
+  const uint64_t n_suf = h.num_suffixes();
+  if (n_suf >= 0xffffffffull) throw UnsupportedError("more than 2^32 - 1 suffixes");
+  uint32_t* d_tok = nullptr;
   {  // eight spare tokens: the DP kernels read the sentence four tokens at a time, possibly past its end
-    uint32_t* t = dev_alloc<uint32_t>(h.buf.size() + 8);
-    HIP_TRY(hipMemset(t, 0, (h.buf.size() + 8) * sizeof(uint32_t)));
-    if (!h.buf.empty()) HIP_TRY(hipMemcpy(t, h.buf.data(), h.buf.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    m.d.tok = t;
+    d_tok = dev_alloc<uint32_t>(h.buf.size() + 8);
+    HIP_TRY(hipMemset(d_tok, 0, (h.buf.size() + 8) * sizeof(uint32_t)));
+    if (!h.buf.empty()) HIP_TRY(hipMemcpy(d_tok, h.buf.data(), h.buf.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    m.d.tok = d_tok;
   }
   m.d.sent_pos = dev_upload(h.sent_pos);
   m.d.qva = dev_upload(h.qva);
@@ -297,8 +403,8 @@ void DeviceIndex::upload(const HostIndex& h, int device) {
   uint32_t mx = 0;
   for (uint32_t sp : h.sent_pos) mx = std::max(mx, h.buf[sp]);
   m.d.max_slen = mx;
-  m.bytes = h.suf_rec.size() * 8 + h.suf_sig.size() * 8 + h.suf_key.size() * sizeof(SufKey) + h.gram.size() * 16 + h.gram5.size() * 16 + h.suf_b.size() * 16 + h.buf.size() * 4 + h.sent_pos.size() * 4 +
-            h.qva.size() * 4 + h.idf.size() * 4;
+  m.bytes = h.buf.size() * 4 + h.sent_pos.size() * 4 + h.qva.size() * 4 + h.idf.size() * 4;
+  derive_on_device(m, h);
   // bit planes of the signatures and thermometer planes of the stored lengths, built on the device from suf_sig
   // (DESIGN.md §3): plane-major, one 64-bit word per (row, block of 64 consecutive suffixes)
   m.d.n_blk = (m.d.n_suf + 63) / 64;

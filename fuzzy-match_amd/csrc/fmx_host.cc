@@ -378,7 +378,11 @@ uint32_t HostIndex::lookup_real(const std::string& s) const {
   return it != real_intern.end() ? it->second : 0x7ffffffeu;
 }
 
-void HostIndex::derive() {
+// The per-suffix records, signatures, keys and the n-gram tables.  The product builds them on the device
+// (fmx_derive.hip.hh); this host version serves the CPU emulation of the kernels (tests/emul) and is the oracle the
+// device build is compared with (tests/test_gpu_derive.py).
+void HostIndex::derive_heavy() {
+  if (heavy_ready) return;
   if (!sorted) throw std::runtime_error("derive: index is not sorted");
   const uint64_t n = suf_sid.size();
   suf_rec.resize(n);
@@ -418,6 +422,14 @@ void HostIndex::derive() {
     unsigned hw = std::thread::hardware_concurrency();
     build_gram_table((int)std::min<unsigned>(hw ? hw : 1, 32));
   }
+  heavy_ready = true;
+}
+
+void HostIndex::derive() {
+  if (!sorted) throw std::runtime_error("derive: index is not sorted");
+  heavy_ready = false;
+  suf_rec.clear(); suf_rec.shrink_to_fit(); suf_sig.clear(); suf_sig.shrink_to_fit(); suf_key.clear(); suf_key.shrink_to_fit();
+  suf_b.clear(); suf_b.shrink_to_fit(); gram.clear(); gram.shrink_to_fit(); gram5.clear(); gram5.shrink_to_fit();
   // compute_idf_penalty / compute_max_idf_penalty — src/fuzzy_match.cc:367-390 (glibc logf / log)
   const unsigned N = num_sentences();
   idf.assign(vocab_size, 0.f);

@@ -44,7 +44,8 @@ class HostIndex {
   std::vector<std::string> ids;
   std::vector<RealTok>     real;
 
-  // ---- derived (derive()) ----
+  // ---- derived on demand by derive_heavy(): the product builds these on the device (fmx_derive.hip.hh) ----
+  bool                  heavy_ready = false;
   std::vector<SufRec>   suf_rec;   // one 8-byte record per suffix, suffix-array order
   std::vector<uint64_t> suf_sig;   // sentence length (8 bits, clamped) << 56 | 56-bit word signature of the suffix's sentence
   std::vector<SufKey>   suf_key;   // the eight tokens after each suffix's first token (0-padded)
@@ -52,6 +53,7 @@ class HostIndex {
   std::vector<GramEntry> gram;     // trigram -> suffix range hash table (power-of-two size, empty if tiny index)
   std::vector<GramEntry> gram5;    // (trigram range start, w3, w4) -> 5-gram range, for trigrams with > kDeepGramMin suffixes
   void build_gram_table(int nthreads);
+  // ---- derived by derive() ----
   std::vector<float>    idf;       // logf(N / sfreq[w]) per word id (src/fuzzy_match.cc:384)
   float                 idf_max = 0.01f;
   bool                  real_differs = false;  // some sentence has real tokens != its normalised tokens, or itoks
@@ -82,7 +84,8 @@ class HostIndex {
   // unsorted (sid<<16|pos) keys + first-token bucket offsets, for the GPU builder
   void bucket_keys(std::vector<uint64_t>& keys, std::vector<uint64_t>& bucket_off) const;
 
-  void derive();
+  void derive();        // idf table, interned real tokens / penalty tokens (what the host side of the product needs)
+  void derive_heavy();  // + the per-suffix accelerator arrays and n-gram tables on the host (tests, CPU emulation)
   uint32_t num_sentences() const { return (uint32_t)sent_pos.size(); }
   uint64_t num_suffixes() const { return suf_sid.size(); }
 

@@ -75,7 +75,7 @@ EXPORTS = [
     "fmx_host_alloc", "fmx_host_free", "fmx_index_to_devices", "fmx_set_devices", "fmx_index_reopen", "fmx_match_one", "fmx_match_batch_keep",
     "fmx_subsequence_batch", "fmx_text_tokenize", "fmx_text_free", "fmx_text_num_tokens", "fmx_text_norm", "fmx_text_real",
     "fmx_text_num_itoks", "fmx_text_itok_index", "fmx_text_itok", "fmx_text_num_raw", "fmx_text_raw", "fmx_text_map",
-    "fmx_text_detokenize", "fmx_index_add_text",
+    "fmx_text_detokenize", "fmx_index_add_text", "fmx_index_device_array",
 ]
 TM_SKIPPED = -100
 
@@ -122,6 +122,7 @@ def lib():
     L.fmx_index_sentence_id.restype = C.c_char_p
     L.fmx_index_sentence_id.argtypes = [C.c_void_p, C.c_uint32]
     L.fmx_index_array.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    L.fmx_index_device_array.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.fmx_index_get_info.argtypes = [C.c_void_p, C.POINTER(Info)]
     L.fmx_match_batch.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Batch), C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_uint32, C.POINTER(Stats)]
@@ -360,6 +361,16 @@ class Index:
             return np.zeros(0, dtype=dt)
         buf = (C.c_char * (n.value * np.dtype(dt).itemsize)).from_address(p.value)
         return np.frombuffer(buf, dtype=dt).copy()
+
+    def device_array(self, name, replica=0):
+        """A device-built accelerator array copied out of HBM (tests)."""
+        which, dt = ARRAYS[name]
+        n = C.c_uint64()
+        _check(lib().fmx_index_device_array(self.h, replica, which, None, 0, C.byref(n)))
+        out = np.zeros(n.value, dtype=dt)
+        if n.value:
+            _check(lib().fmx_index_device_array(self.h, replica, which, _ptr(out), out.nbytes, C.byref(n)))
+        return out
 
     def vocab_lookup(self, tokens):
         arr = (C.c_char_p * len(tokens))(*[t.encode("utf-8") for t in tokens])

@@ -179,6 +179,11 @@ typedef enum fmx_array {
 } fmx_array;
 /* borrowed pointer to a host array of the index, valid until the index changes or is freed */
 int fmx_index_array(const fmx_index*, int which, const void** data, uint64_t* count);
+/* The "(derived)" per-suffix arrays and n-gram tables (FMX_A_SUF_REC, _SUF_SIG, _SUF_KEY, _GRAM, _GRAM5, _SUF_B) are built
+ * on the device by fmx_index_to_device; fmx_index_array builds their host twins on request (tests, CPU emulation).
+ * fmx_index_device_array copies one of them out of the HBM of replica `replica` as it is used by the kernels:
+ * dst == NULL only reports the element count. */
+int fmx_index_device_array(const fmx_index*, int replica, int which, void* dst, uint64_t capacity_bytes, uint64_t* count);
 
 typedef struct fmx_index_info {
   uint64_t n_sentences, n_suffixes, buffer_size, vocab_size, max_tokens_in_pattern;

@@ -1,0 +1,76 @@
+"""The accelerator arrays of DESIGN.md §3 are built ON THE DEVICE at fmx_index_to_device (fmx_derive.hip.hh).  Here they
+are copied back out of HBM and compared with HostIndex::derive_heavy, the host loops the CPU emulation of the kernels runs
+on (tests/test_emul_vs_oracle.py pins those against the oracle): per-suffix arrays byte for byte, hash tables as sets
+(slot placement depends on the order concurrent inserts land in)."""
+import os
+
+import numpy as np
+import pytest
+
+import golden_util
+import workloads
+
+pytestmark = pytest.mark.gpu
+
+
+def _entries(tab):
+    live = tab[tab["lo"] != 0xffffffff]
+    return np.sort(live, order=["lo", "cnt", "w1", "w2"])
+
+
+def _compare(ix, label):
+    for name in ["suf_rec", "suf_sig", "suf_key", "suf_b"]:
+        host, dev = ix.array(name), ix.device_array(name)
+        assert host.shape == dev.shape and np.array_equal(host.view(np.uint8), dev.view(np.uint8)), (label, name)
+    for name in ["gram", "gram5"]:
+        host, dev = ix.array(name), ix.device_array(name)
+        assert len(host) == len(dev), (label, name, len(host), len(dev))   # same capacity rule
+        assert np.array_equal(_entries(host), _entries(dev)), (label, name)
+        if len(dev):
+            # open addressing stays searchable: every live entry is reachable from its home slot without crossing an empty one
+            assert (dev["lo"] != 0xffffffff).sum() * 2 <= len(dev), (label, name)
+    return len(ix.device_array("gram")), len(ix.device_array("gram5"))
+
+
+def test_device_built_arrays_equal_the_host_build_synthetic(fmx, gpu_device):
+    c_off, c_tok, _, _, vs = workloads.synthetic(30_000, 10, 25)
+    ix = fmx.Index.create()
+    ix.add_ids(c_off, c_tok, vs)
+    ix.sort(gpu_device)
+    ix.finalize()
+    ix.to_device(gpu_device)
+    n3, n5 = _compare(ix, "synthetic 30k")
+    assert n3 > 0
+
+
+@pytest.mark.parametrize("seed,vocab", [(1, 3), (2, 6), (3, 40)])
+def test_device_built_arrays_equal_the_host_build_dense(fmx, gpu_device, seed, vocab):
+    """Tiny vocabularies: trigram groups of thousands of suffixes, so the 5-gram level is populated; one- and two-token
+    sentences (suffixes that end a run); duplicates."""
+    rng = np.random.default_rng(seed)
+    c_off, c_tok = workloads.dense_corpus(rng, 6000, vocab, min_len=1, max_len=14)
+    ix = fmx.Index.create(max_tokens=20)
+    ix.add_ids(c_off, c_tok, vocab + 2)
+    ix.sort(gpu_device)
+    ix.finalize()
+    ix.to_device(gpu_device)
+    n3, n5 = _compare(ix, f"dense vocab {vocab}")
+    assert n3 > 0 and (vocab > 6 or n5 > 0), (n3, n5)
+
+
+@pytest.mark.parametrize("fmi", ["tm1.fmi", "tm1.old.fmi"])
+def test_device_built_arrays_of_the_reference_fixture(fmx, gpu_device, fmi):
+    ix = fmx.Index.load(os.path.join(golden_util.GOLDEN, fmi))
+    ix.finalize()
+    ix.to_device(gpu_device)
+    _compare(ix, fmi)
+
+
+def test_single_sentence_and_single_token(fmx, gpu_device):
+    for toks in ([5], [5, 5], [2, 3, 4], [7] * 9):
+        ix = fmx.Index.create()
+        ix.add_ids(np.asarray([0, len(toks)], np.uint32), np.asarray(toks, np.uint32), 10)
+        ix.sort(gpu_device)
+        ix.finalize()
+        ix.to_device(gpu_device)
+        _compare(ix, str(toks))

@@ -37,7 +37,7 @@ int main(int argc, char** argv) {
   HostIndex h;
   h.add_ids_bulk(fms_offsets(c), fms_tokens(c), fms_num_sentences(c), fms_vocab_size(c));
   h.sort(8);
-  h.derive();
+  h.derive(); h.derive_heavy();
   fprintf(stderr, "index: %zu suffixes\n", h.suf_rec.size());
   const uint32_t* q_off = fms_offsets(qs);
   const uint32_t* q_tok = fms_tokens(qs);
