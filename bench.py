@@ -59,7 +59,8 @@ def parse_args():
     ap.add_argument("--sentences", type=int, default=0)
     ap.add_argument("--queries", type=int, default=0)
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
-    ap.add_argument("--threads", type=int, default=2, help="host threads driving fmx_match_batch concurrently")
+    ap.add_argument("--threads", type=int, default=3, help="synchronous fmx_match_batch calls kept in flight (one host thread each)")
+    ap.add_argument("--force-gather", action="store_true", help="N = 1 test of the N > 1 step: records also kept in HBM for the (empty) gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline.traffic = null)")
     ap.add_argument("--child", action="store_true", help="profiling child: device-resident steps only, no output line")
@@ -195,33 +196,36 @@ def main():
         torch.cuda.synchronize()
 
     def run_host_steps(wl, k_steps, gather=None):
-        """K calls of fmx_match_batch (pinned host buffers in and out) from args.threads host threads.  N > 1: each
-        step's records are also gathered to rank 0 over RCCL (device copies kept by the call)."""
+        """K calls of fmx_match_batch (pinned host buffers in and out), args.threads of them in flight at a time: step
+        i + T is submitted when step i has returned, so the copies at both ends of one call overlap the kernels of the
+        other (the calls themselves are synchronous: a caller with a queue of batches would do exactly this).  N > 1:
+        each step's records also stay in HBM (fmx_match_batch_keep) and are gathered to rank 0 over RCCL; the gathers
+        are launched by this thread in step order, so every rank issues its collectives in the same order."""
+        T = max(args.threads, 1)
         stats = []
 
-        def one(i):
-            slot = i % len(wl.out)
-            return ix.match_batch(params, wl.q_off, wl.q_tok, cap=cap, want_stats=True, out=wl.out[slot])[3]
+        def one(i, keep):
+            return ix.match_batch(params, wl.q_off, wl.q_tok, cap=cap, want_stats=True, out=wl.out[i % T], keep=keep)[3]
 
-        if gather is None:
-            if args.threads <= 1:
-                for i in range(k_steps):
-                    stats.append(one(i))
-            else:
-                # thread t runs steps t, t + T, ...: its result slot is never written by two calls at once
-                def lane(t):
-                    return [one(i) for i in range(t, k_steps, args.threads)]
-                with cf.ThreadPoolExecutor(args.threads) as pool:
-                    for part in pool.map(lane, range(args.threads)):
-                        stats.extend(part)
-        else:
+        with cf.ThreadPoolExecutor(T) as pool:
+            futs = {}
+
+            def submit(i):
+                keep = None
+                if gather is not None:
+                    d_out, d_cnt = gather.buffers(i, host_sync=True)  # the slot's previous gather is over
+                    keep = (d_out.data_ptr(), d_cnt.data_ptr())
+                futs[i] = pool.submit(one, i, keep)
+
+            for i in range(min(T, k_steps)):
+                submit(i)
             for i in range(k_steps):
-                d_out, d_cnt = gather.buffers(i, host_sync=True)
-                # the records go home over PCIe AND stay in HBM (fmx_match_batch_keep) for the gather over xGMI
-                st = ix.match_batch(params, wl.q_off, wl.q_tok, cap=cap, want_stats=True, out=wl.out[0],
-                                    keep=(d_out.data_ptr(), d_cnt.data_ptr()))[3]
-                gather.launch(i)
-                stats.append(st)
+                stats.append(futs.pop(i).result())
+                if gather is not None:
+                    gather.launch(i)
+                if i + T < k_steps:
+                    submit(i + T)
+        if gather is not None:
             gather.wait_all()
         return stats
 
@@ -261,7 +265,7 @@ def main():
 
     # ---- the metric: PCIe-inclusive steps through fmx_match_batch ----
     def measure(wl):
-        gather = shard.RecordGather(wl.nq, cap, dev, dst=0) if world > 1 else None
+        gather = shard.RecordGather(wl.nq, cap, dev, dst=0, depth=max(args.threads, 1) + 1) if (world > 1 or args.force_gather) else None
         run_host_steps(wl, args.warmup, gather)
         el, sts = timed(lambda k: run_host_steps(wl, k, gather), args.steps)
         return el, sts
@@ -428,7 +432,7 @@ def main():
                                    + " ".join(f"{k}={v}" for k, v in pkw.items()),
                        "queries_per_step_all_ranks": nq_step_all, "sentences": n_sent, "index_bytes_hbm": int(info.device_bytes),
                        "timed_path": "fmx_match_batch: pinned host buffers in, pinned host buffers out (H2D + kernels + D2H), "
-                                     f"{args.threads} host threads" + (", + RCCL gather of the records to rank 0" if world > 1 else ""),
+                                     f"{args.threads} synchronous call(s) in flight" + (", + RCCL gather of the records to rank 0" if world > 1 else ""),
                        "parallelism": f"queries sharded over {world} GPU(s), index replicated"},
             "roofline": dominant, "roofline_other": [other], "reference_byte_model": ref_model,
             "device_resident": {"value": round(nq_step_all * args.steps / el_dev, 1),

@@ -168,22 +168,22 @@ def test_many_passes_in_one_asynchronous_group_with_a_small_workspace(fmx, gpu_d
     (a stale comparison used to end in 'a query queued more hits than it has')."""
     rng = np.random.default_rng(17)
     vocab = 8
-    c_off, c_tok = workloads.dense_corpus(rng, 30000, vocab, min_len=4, max_len=10)
-    q_off, q_tok = workloads.edge_queries(rng, c_off, c_tok, vocab, 16)
+    c_off, c_tok = workloads.dense_corpus(rng, 8000, vocab, min_len=4, max_len=10)
+    q_off, q_tok = workloads.edge_queries(rng, c_off, c_tok, vocab, 12)
     ix = fmx.Index.create(max_tokens=40)
     ix.add_ids(c_off, c_tok, vocab + 2)
     ix.sort(gpu_device)
     ix.finalize()
     ix.to_device(gpu_device)
     ix.set_option("initial_segment", 1024)
-    ix.set_option("host_sub_queries", 2)   # 8 passes, one asynchronous group
+    ix.set_option("host_sub_queries", 2)   # 6 passes, one asynchronous group
     o = oracle_lib.OracleIndex(max_tokens=40)
     o.add_ids_bulk(c_off, c_tok, vocab + 2, sfreq=ix.array("sfreq"))
     o.sort(oracle_lib.effective_cpus())
     kw = dict(fuzzy=0.2, nmatch=0, min_subseq_length=2, min_subseq_ratio=0)
     oo, oc = o.match_batch(oracle_lib.Params(**kw), q_off, q_tok, 128, nthreads=oracle_lib.effective_cpus())
     go, gc, gt, st = ix.match_batch(fmx.Params(**kw), q_off, q_tok, cap=128, want_stats=True)
-    workloads.compare(oo, oc, go, gc, "small workspace, 8 passes")
+    workloads.compare(oo, oc, go, gc, "small workspace, 6 passes")
     assert st.n_retries > 1, st.n_retries
     go, gc, gt, st = ix.match_batch(fmx.Params(**kw), q_off, q_tok, cap=128, want_stats=True)  # grown: no retry left
     workloads.compare(oo, oc, go, gc, "second call")
