@@ -562,15 +562,19 @@ void HostIndex::load_fmi(const std::string& path) {
   if (r.str() != "serialization::archive") throw std::runtime_error("FMI: not a Boost binary archive");
   const uint16_t lvt = r.get<uint16_t>();
   if (lvt < 10) throw std::runtime_error("FMI: unsupported Boost archive library version");
+  fmi = FmiMeta();
+  fmi.loaded = true;
+  fmi.lvt = lvt;
   uint8_t sizes[4];
   r.raw(sizes, 4);
   if (sizes[0] != 4 || sizes[1] != 8 || sizes[2] != 4 || sizes[3] != 8 || r.get<uint32_t>() != 1)
     throw std::runtime_error("FMI: archive written on an incompatible platform");
 
-  r.class_info();                      // FuzzyMatch
+  fmi.fm_version = r.class_info();     // FuzzyMatch
   pt = r.get<int32_t>();
   r.get<int16_t>();                    // class_id of SuffixArrayIndex (pointer)
   const uint32_t sai_version = r.class_info();
+  fmi.sai_version = sai_version;
   r.get<uint32_t>();                   // object_id
 
   // VocabIndexer: forms, sfreq, form2index — vocab_indexer.hh:45-52
@@ -588,13 +592,15 @@ void HostIndex::load_fmi(const std::string& path) {
   bool pair_su_seen = false;
   {
     const uint64_t n = r.get<uint64_t>();
-    r.get<uint64_t>();                 // bucket_count
+    fmi.map_buckets = r.get<uint64_t>();  // bucket_count
     r.get<uint32_t>();                 // item_version
     form2index.reserve(n);
+    fmi.map_order.reserve(n);
     for (uint64_t i = 0; i < n; i++) {
       if (!pair_su_seen) { r.class_info(); pair_su_seen = true; }
       std::string k = r.str();
       const uint32_t v = r.get<uint32_t>();
+      fmi.map_order.push_back(v);
       form2index.emplace(std::move(k), v);
     }
   }
@@ -650,7 +656,7 @@ void HostIndex::load_fmi(const std::string& path) {
       real[i].tokstring = r.str();
       if (!map_seen) { r.class_info(); map_seen = true; }  // std::unordered_map<size_t, std::string>
       const uint64_t m = r.get<uint64_t>();
-      r.get<uint64_t>();               // bucket_count
+      fmi.itok_buckets.push_back(r.get<uint64_t>());  // bucket_count
       r.get<uint32_t>();               // item_version
       for (uint64_t k = 0; k < m; k++) {
         if (!pair_seen) { r.class_info(); pair_seen = true; }
@@ -684,15 +690,19 @@ void HostIndex::save_fmi(const std::string& path) const {
   w.raw("FMI", 3);
   w.put<char>('1');                    // FuzzyMatch::version — src/fuzzy_match.cc:23
   w.str("serialization::archive");
-  w.put<uint16_t>(14);                 // same library version as the reference's fixtures
+  // a loaded file keeps its versions and map layout (FmiMeta) as long as nothing was added since
+  const bool keep = fmi.loaded && fmi.map_order.size() == forms.size() && forms.size() >= vocab_size &&
+                    fmi.itok_buckets.size() == sent_pos.size();
+  const uint32_t sai_version = keep ? fmi.sai_version : 1u;
+  w.put<uint16_t>(keep ? fmi.lvt : (uint16_t)14);  // 14 = the library version of the reference's fixtures
   const uint8_t sizes[4] = {4, 8, 4, 8};
   w.raw(sizes, 4);
   w.put<uint32_t>(1);
-  w.class_info(1);                     // FuzzyMatch v1
+  w.class_info(keep ? fmi.fm_version : 1u);  // FuzzyMatch class version
   w.put<int32_t>(pt);
   w.put<int16_t>(1);                   // class_id
   w.put<uint8_t>(1);                   // tracking
-  w.put<uint32_t>(1);                  // SuffixArrayIndex v1
+  w.put<uint32_t>(sai_version);        // SuffixArrayIndex class version
   w.put<uint32_t>(0);                  // object_id
   w.class_info(0);                     // VocabIndexer
   w.class_info(0);                     // vector<string>
@@ -709,12 +719,14 @@ void HostIndex::save_fmi(const std::string& path) const {
   write_pod_vector(w, sf);
   w.class_info(0);                     // unordered_map<string, unsigned>
   w.put<uint64_t>(f.size());
-  w.put<uint64_t>(f.size() * 2 + 1);
+  w.put<uint64_t>(keep ? fmi.map_buckets : f.size() * 2 + 1);
   w.put<uint32_t>(0);
   for (uint32_t k = 0; k < f.size(); k++) {
     if (k == 0) w.class_info(0);       // pair<const string, unsigned>
-    w.str(f[k]);
-    w.put<uint32_t>(k);
+    const uint32_t v = keep ? fmi.map_order[k] : k;  // any order loads: the reader rebuilds the map
+    if (v >= f.size()) throw std::runtime_error("FMI: vocabulary map out of range");
+    w.str(f[v]);
+    w.put<uint32_t>(v);
   }
   w.class_info(1);                     // SuffixArray v1
   w.put<uint8_t>(sorted ? 1 : 0);
@@ -750,7 +762,7 @@ void HostIndex::save_fmi(const std::string& path) const {
     if (i == 0) w.class_info(0);       // unordered_map<size_t, string>
     const uint64_t m = i < real.size() ? real[i].itoks.size() : 0;
     w.put<uint64_t>(m);
-    w.put<uint64_t>(m ? m * 2 + 1 : 1);
+    w.put<uint64_t>(keep ? fmi.itok_buckets[i] : (m ? m * 2 + 1 : 1));
     w.put<uint32_t>(0);
     for (uint64_t k = 0; k < m; k++) {
       if (!pair_seen) { w.class_info(0); pair_seen = true; }
@@ -758,7 +770,7 @@ void HostIndex::save_fmi(const std::string& path) const {
       w.str(real[i].itoks[k].second);
     }
   }
-  w.put<uint64_t>(max_tokens);
+  if (sai_version >= 1) w.put<uint64_t>(max_tokens);  // suffix_array_index.hxx:33-43
   std::ofstream ofs(path, std::ios::binary);
   if (!ofs) throw std::runtime_error("cannot open FMI file for writing: " + path);
   ofs.write(w.d_.data(), (std::streamsize)w.d_.size());

@@ -40,6 +40,19 @@ class HostIndex {
   std::vector<uint32_t> sent_pos;  // _sentence_pos
   std::vector<uint32_t> qva;       // _quickVocabAccess
 
+  // What a loaded .fmi does not determine from the arrays alone: archive / class versions and the iteration order and
+  // bucket counts of its unordered_maps (implementation-defined in the writer's C++ library).  Kept so that
+  // load -> save reproduces a reference-written file byte for byte; a freshly built index writes the current versions.
+  struct FmiMeta {
+    bool     loaded = false;
+    uint16_t lvt = 14;            // Boost archive library version
+    uint32_t fm_version = 1;      // FuzzyMatch class version
+    uint32_t sai_version = 1;     // SuffixArrayIndex class version (1 = _max_tokens_in_pattern trailer)
+    std::vector<uint32_t> map_order;     // form2index values in file order
+    uint64_t map_buckets = 0;
+    std::vector<uint64_t> itok_buckets;  // per sentence
+  } fmi;
+
   // SuffixArrayIndex::_ids / _real_tokens — empty for id-only corpora
   std::vector<std::string> ids;
   std::vector<RealTok>     real;

@@ -49,6 +49,7 @@ def read_fmi(path):
     out["forms"] = [r.s() for _ in range(n)]
     out["sfreq"] = r.vec("I")
     r.ci()
+    map_start = r.p
     n = r.u("Q")
     r.u("Q")
     r.u("I")
@@ -59,6 +60,7 @@ def read_fmi(path):
         k = r.s()
         f2i[k] = r.u("I")
     out["form2index"] = f2i
+    out["map_span"] = (map_start, r.p)  # the unordered_map's count, bucket count and items: order is the writer's C++ library's
     sa_version = r.ci()
     out["sa_version"] = sa_version
     out["sorted"] = r.u("B")
@@ -87,6 +89,7 @@ def read_fmi(path):
     r.u("I")
     real = []
     map_seen = pair_seen = False
+    bucket_fields = []  # offsets of the per-sentence unordered_map bucket counts (the writer's C++ library's choice)
     for i in range(n):
         if i == 0:
             r.ci()
@@ -95,6 +98,7 @@ def read_fmi(path):
             r.ci()
             map_seen = True
         m = r.u("Q")
+        bucket_fields.append(r.p)
         r.u("Q")
         r.u("I")
         itoks = {}
@@ -106,6 +110,7 @@ def read_fmi(path):
             itoks[idx] = r.s()
         real.append((ts, itoks))
     out["real"] = real
+    out["itok_bucket_fields"] = bucket_fields
     out["max_tokens"] = r.u("Q") if sai_version >= 1 else 300
     out["consumed"], out["size"] = r.p, len(r.d)
     return out

@@ -85,6 +85,68 @@ def test_fmi_writer_roundtrip(fmx, tmp_path):
     assert ix2.info().max_tokens_in_pattern == 7
 
 
+def test_fmi_writer_reproduces_the_reference_fixture_bytes(fmx, tmp_path):
+    """export_binarized_fuzzy_matcher (src/fuzzy_matcher_binarization.cc:16-30): a reference-written file, loaded and
+    saved again, comes back byte for byte — headers, class-info records, versions (this fixture is SuffixArrayIndex v0:
+    no _max_tokens_in_pattern trailer, include/fuzzy/suffix_array_index.hxx:33-43), every array, ids, real tokens, and the
+    unordered_maps in the order and with the bucket counts the file had."""
+    src = os.path.join(golden_util.GOLDEN, "tm1.fmi")
+    out = tmp_path / "again.fmi"
+    fmx.Index.load(src).save(str(out))
+    assert out.read_bytes() == open(src, "rb").read()
+
+
+def _without_bucket_counts(data, decoded):
+    data = bytearray(data)
+    for off in decoded["itok_bucket_fields"]:
+        data[off:off + 8] = bytes(8)
+    return bytes(data)
+
+
+def test_fmi_old_layout_is_rewritten_in_the_current_layout(fmx, tmp_path):
+    """tm1.old.fmi (SuffixArray v0: vector<pair<unsigned, unsigned short>> with struct padding) saved again is the
+    SuffixArray v1 layout of tm1.fmi: identical bytes everywhere except what belongs to the C++ library that wrote each
+    file — the iteration order of the vocabulary's unordered_map and the bucket counts of the maps; decoded, the two
+    are equal."""
+    ref = os.path.join(golden_util.GOLDEN, "tm1.fmi")
+    out = tmp_path / "upgraded.fmi"
+    fmx.Index.load(os.path.join(golden_util.GOLDEN, "tm1.old.fmi")).save(str(out))
+    a, b = out.read_bytes(), open(ref, "rb").read()
+    da, db = fmi_reader.read_fmi(str(out)), fmi_reader.read_fmi(ref)
+    assert da["map_span"] == db["map_span"] and len(a) == len(b)
+    lo, hi = db["map_span"]
+    assert a[:lo] == b[:lo] and _without_bucket_counts(a, da)[hi:] == _without_bucket_counts(b, db)[hi:]
+    for k in da:
+        assert da[k] == db[k], k
+
+
+def test_fmi_writer_on_a_rebuilt_tm1(fmx, tmp_path):
+    """tm1 rebuilt from its raw sentences (text front-end, same penalty-token flags as the fixture) and exported: the
+    current class versions (SuffixArrayIndex v1 = the fixture's bytes + the u64 _max_tokens_in_pattern trailer), and
+    outside the vocabulary map the bytes of the reference-built fixture."""
+    ref = os.path.join(golden_util.GOLDEN, "tm1.fmi")
+    lines = [ln for ln in open(os.path.join(golden_util.GOLDEN, "tm1"), encoding="utf-8").read().split("\n") if ln != ""]
+    ix = fmx.Index.create(pt=1 | 16 | 32)  # pt_tag | pt_nbr | pt_cas (test/test.cc:102-120)
+    for i, ln in enumerate(lines):
+        assert ix.add_text(f"{i + 1}={ln}", ln) == i
+    ix.sort(-1, 1)
+    out = tmp_path / "rebuilt.fmi"
+    ix.save(str(out))
+    a, b = out.read_bytes(), open(ref, "rb").read()
+    da, db = fmi_reader.read_fmi(str(out)), fmi_reader.read_fmi(ref)
+    assert da["consumed"] == da["size"] and da["max_tokens"] == 300
+    for k in da:
+        if k not in ("map_span", "size", "consumed"):
+            assert da[k] == db[k], k
+    lo, hi = db["map_span"]
+    assert da["map_span"] == (lo, hi)
+    # the SuffixArrayIndex class version (one byte of the header) and the trailer are the only differences
+    assert len(a) == len(b) + 8 and a[-8:] == (300).to_bytes(8, "little")
+    ver = [i for i in range(lo) if a[i] != b[i]]
+    assert len(ver) == 1 and a[ver[0]] == 1 and b[ver[0]] == 0, ver
+    assert _without_bucket_counts(a, da)[hi:len(b)] == _without_bucket_counts(b, db)[hi:]
+
+
 def test_match_without_device_fails_loudly(fmx):
     if fmx.device_count() > 0:
         pytest.skip("a GPU is present")
