@@ -12,21 +12,23 @@
 
 namespace fmx {
 
-// 56-bit word signature per sentence (fmx_core.hh: sig_bit)
+// word signature per sentence (fmx_core.hh: sig_bit, sig_half): sent_sig2[2 s + h] = half h of the 112-bucket signature;
+// the 56-bit signature of suf_sig is the OR of the two
 __global__ void __launch_bounds__(256) k_dv_sent_sig(const uint32_t* __restrict__ buf, const uint32_t* __restrict__ sent_pos,
-                                                     uint32_t n_sent, unsigned long long* __restrict__ sent_sig) {
+                                                     uint32_t n_sent, unsigned long long* __restrict__ sent_sig2) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n_sent) return;
   const uint32_t sp = sent_pos[s], len = buf[sp];
-  unsigned long long sg = 0;
-  for (uint32_t k = 0; k < len; k++) sg |= 1ull << sig_bit(buf[sp + 1 + k]);
-  sent_sig[s] = sg;
+  unsigned long long sg[2] = {0, 0};
+  for (uint32_t k = 0; k < len; k++) { const uint32_t w = buf[sp + 1 + k]; sg[sig_half(w)] |= 1ull << sig_bit(w); }
+  sent_sig2[2ull * s] = sg[0];
+  sent_sig2[2ull * s + 1] = sg[1];
 }
 
 // per suffix: SufRec, SufRecB, packed signature word, the eight key tokens
 __global__ void __launch_bounds__(256) k_dv_suffix(const uint32_t* __restrict__ buf, const uint32_t* __restrict__ sent_pos,
                                                    const uint32_t* __restrict__ suf_sid, const uint16_t* __restrict__ suf_pos,
-                                                   const unsigned long long* __restrict__ sent_sig, unsigned long long n,
+                                                   const unsigned long long* __restrict__ sent_sig2, unsigned long long n,
                                                    SufRec* __restrict__ suf, SufRecB* __restrict__ suf_b,
                                                    unsigned long long* __restrict__ suf_sig, SufKey* __restrict__ suf_key) {
   const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -43,7 +45,7 @@ __global__ void __launch_bounds__(256) k_dv_suffix(const uint32_t* __restrict__ 
   rb.prev = r.rem < r.slen ? buf[r.off - 1] : 0u;
   rb.sid = sid;
   suf_b[i] = rb;
-  suf_sig[i] = sig_pack(r.slen, sent_sig[sid]);
+  suf_sig[i] = sig_pack(r.slen, sent_sig2[2ull * sid] | sent_sig2[2ull * sid + 1]);
   SufKey k;
 #pragma unroll
   for (uint32_t t = 0; t < kKeyTokens; t++) k.t[t] = t + 1 < r.rem ? buf[r.off + 1 + t] : 0u;

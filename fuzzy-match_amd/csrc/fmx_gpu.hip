@@ -271,7 +271,9 @@ constexpr size_t kDynLdsMax = 150 * 1024;  // dynamic LDS the row kernels may as
 
 // The accelerator arrays from the reference's arrays, on the device: kernels in fmx_derive.hip.hh.
 // m.d.tok and m.d.sent_pos are already resident; the suffix array goes up (6 bytes per suffix) and is dropped afterwards.
-static void derive_on_device(DeviceIndex::Impl& m, const HostIndex& h) {
+// Returns the per-sentence 112-bucket signatures (two words per sentence, device memory): the caller builds the bit planes
+// from them and frees them.
+static unsigned long long* derive_on_device(DeviceIndex::Impl& m, const HostIndex& h) {
   const uint64_t n = h.num_suffixes();
   const uint32_t n_sent = h.num_sentences();
   m.d.suf = nullptr; m.d.suf_b = nullptr; m.d.suf_sig = nullptr; m.d.suf_key = nullptr;
@@ -282,17 +284,17 @@ static void derive_on_device(DeviceIndex::Impl& m, const HostIndex& h) {
   SufKey* suf_key = dev_alloc<SufKey>(n);
   m.d.suf = suf; m.d.suf_b = suf_b; m.d.suf_sig = suf_sig; m.d.suf_key = suf_key;
   m.bytes += n * (sizeof(SufRec) + sizeof(SufRecB) + 8 + sizeof(SufKey));
-  if (n == 0) return;
+  if (n == 0) return nullptr;
+  unsigned long long* d_ssig = dev_alloc<unsigned long long>(2ull * n_sent);
   {
     uint32_t* d_sid = dev_upload(h.suf_sid);
     uint16_t* d_pos = dev_upload(h.suf_pos);
-    unsigned long long* d_ssig = dev_alloc<unsigned long long>(n_sent);
     hipLaunchKernelGGL(k_dv_sent_sig, dim3((n_sent + 255) / 256), dim3(256), 0, 0, m.d.tok, m.d.sent_pos, n_sent, d_ssig);
     hipLaunchKernelGGL(k_dv_suffix, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, m.d.tok, m.d.sent_pos, (const uint32_t*)d_sid,
                        (const uint16_t*)d_pos, (const unsigned long long*)d_ssig, (unsigned long long)n, suf, suf_b, suf_sig, suf_key);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
-    hipFree(d_sid); hipFree(d_pos); hipFree(d_ssig);
+    hipFree(d_sid); hipFree(d_pos);
   }
   // ---- n-gram tables ----
   const uint32_t n32 = (uint32_t)n;
@@ -351,9 +353,11 @@ static void derive_on_device(DeviceIndex::Impl& m, const HostIndex& h) {
     HIP_TRY(hipDeviceSynchronize());
   } catch (...) {
     cleanup();
+    hipFree(d_ssig);
     throw;
   }
   cleanup();
+  return d_ssig;
 }
 
 // test / debug: a derived array as it sits in HBM
@@ -404,7 +408,7 @@ void DeviceIndex::upload(const HostIndex& h, int device) {
   for (uint32_t sp : h.sent_pos) mx = std::max(mx, h.buf[sp]);
   m.d.max_slen = mx;
   m.bytes = h.buf.size() * 4 + h.sent_pos.size() * 4 + h.qva.size() * 4 + h.idf.size() * 4;
-  derive_on_device(m, h);
+  unsigned long long* d_ssig = derive_on_device(m, h);
   // bit planes of the signatures and thermometer planes of the stored lengths, built on the device from suf_sig
   // (DESIGN.md §3): plane-major, one 64-bit word per (row, block of 64 consecutive suffixes)
   m.d.n_blk = (m.d.n_suf + 63) / 64;
@@ -414,12 +418,15 @@ void DeviceIndex::upload(const HostIndex& h, int device) {
   if (m.d.n_suf) {
     unsigned long long* pl = dev_alloc<unsigned long long>((size_t)kPlaneRows * m.d.n_blk);
     unsigned long long* th = dev_alloc<unsigned long long>((size_t)std::max<uint32_t>(m.d.n_thermo, 1) * m.d.n_blk);
-    hipLaunchKernelGGL(k_build_planes, dim3((unsigned)m.d.n_blk), dim3(kWave), 0, 0, m.d.suf_sig, m.d.n_suf, m.d.n_blk, pl, th, m.d.n_thermo);
+    hipLaunchKernelGGL(k_build_planes, dim3((unsigned)m.d.n_blk), dim3(kWave), 0, 0, m.d.suf_sig, m.d.suf_b, (const unsigned long long*)d_ssig, m.d.n_suf,
+                       m.d.n_blk, pl, th, m.d.n_thermo);
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
     m.d.planes = pl;
     m.d.thermo = th;
     m.bytes += (uint64_t)(kPlaneRows + m.d.n_thermo) * m.d.n_blk * 8;
   }
+  hipFree(d_ssig);
   if (h.real_differs) {
     m.d.real = dev_upload(h.real_ids);
     m.d.itok = dev_upload(h.itok_ids);

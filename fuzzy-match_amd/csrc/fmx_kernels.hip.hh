@@ -157,7 +157,7 @@ struct HeavyItem {
   uint32_t cnt;
   uint32_t chunk;
 };
-constexpr uint32_t kPlaneRows = 56;             // bit planes of the signature: one per bucket (== kSigBits)
+constexpr uint32_t kPlaneRows = kSigBits2;      // bit planes of the 112-bucket signature: rows 0..55 = first half, 56..111 = second half of each bucket
 constexpr uint32_t kPlaneMaxP = 63;             // six-level bit-sliced counters: patterns of up to 63 tokens
 constexpr uint32_t kHeavyMinDefault = 1024;     // ranges at least this long stream through the bit planes
 constexpr uint32_t kHeavyChunkBlocks = 256;     // blocks of 64 suffixes per k_expand_h work item (16384 hits)
@@ -230,21 +230,26 @@ __global__ void __launch_bounds__(64) k_probe(DevIndex ix, DevBatch b, DevWork w
 }
 
 // Signature bit planes and length thermometer planes of the suffix array (index build, once per upload): one wave per
-// block of 64 suffixes.
-__global__ void __launch_bounds__(kWave) k_build_planes(const unsigned long long* __restrict__ suf_sig, unsigned long long n_suf,
+// block of 64 suffixes.  sent_sig2 = the two halves of each sentence's 112-bucket signature (k_dv_sent_sig).
+__global__ void __launch_bounds__(kWave) k_build_planes(const unsigned long long* __restrict__ suf_sig, const SufRecB* __restrict__ suf_b,
+                                                        const unsigned long long* __restrict__ sent_sig2, unsigned long long n_suf,
                                                         unsigned long long n_blk, unsigned long long* __restrict__ planes,
                                                         unsigned long long* __restrict__ thermo, uint32_t n_thermo) {
   const unsigned long long blk = blockIdx.x;
   const uint32_t lane = threadIdx.x & 63;
   const unsigned long long i = blk * 64 + lane;
   const unsigned long long pk = i < n_suf ? suf_sig[i] : 0ull;
-  unsigned long long mine = 0;  // 64 x 64 bit transpose of the block: row k = bit k of the 64 packed words
 #pragma unroll
-  for (uint32_t k = 0; k < 64; k++) {
-    const unsigned long long m = __ballot((pk >> k) & 1ull);
-    if (lane == k) mine = m;
+  for (uint32_t half = 0; half < 2; half++) {
+    const unsigned long long sg = i < n_suf ? sent_sig2[2ull * suf_b[i].sid + half] : 0ull;
+    unsigned long long mine = 0;  // 64 x 64 bit transpose of the block: row k = bit k of the 64 words
+#pragma unroll
+    for (uint32_t k = 0; k < kSigBits; k++) {
+      const unsigned long long m = __ballot((sg >> k) & 1ull);
+      if (lane == k) mine = m;
+    }
+    if (lane < kSigBits) planes[(unsigned long long)(half * kSigBits + lane) * n_blk + blk] = mine;
   }
-  if (lane < kPlaneRows) planes[(unsigned long long)lane * n_blk + blk] = mine;
   const uint32_t len = i < n_suf ? sig_slen(pk) : 0u;
   for (uint32_t s0 = 1; s0 <= n_thermo; s0 += 64) {
     unsigned long long row = 0;
@@ -905,7 +910,7 @@ constexpr uint32_t kHeavyList = 2 * kWave;  // LDS list of plane-test survivors 
 __global__ void __launch_bounds__(kWave, 6) k_expand_h(DevIndex ix, DevBatch b, DevWork w, Params prm, const HeavyItem* items,
                                                        uint32_t item_cap) {
   __shared__ __attribute__((aligned(8))) uint16_t s_cmin[kCminTab];
-  __shared__ uint32_t s_bucket[kWave];
+  __shared__ uint32_t s_bucket[2 * kWave];  // pattern positions per bucket of the 112-bucket signature: [0, 56) first halves, [64, 120) second halves
   __shared__ uint32_t s_list[kHeavyList];
   __shared__ QHit s_q[kQueue];
   const uint32_t lane = lane_id();
@@ -925,18 +930,23 @@ __global__ void __launch_bounds__(kWave, 6) k_expand_h(DevIndex ix, DevBatch b, 
     const uint32_t it = t - (o0 - b.t_begin);
     const uint32_t it_hi = it << 16;
     wave_lds_sync();
-    s_bucket[lane] = 0;
+    s_bucket[lane] = 0; s_bucket[kWave + lane] = 0;
     wave_lds_sync();
-    for (uint32_t j = lane; j < p; j += kWave) atomicAdd(&s_bucket[sig_bit(pat[j])], 1u);
+    for (uint32_t j = lane; j < p; j += kWave) { const uint32_t wd = pat[j]; atomicAdd(&s_bucket[sig_bit(wd) + kWave * sig_half(wd)], 1u); }
     reinterpret_cast<unsigned long long*>(s_cmin)[lane] =
         reinterpret_cast<const unsigned long long*>(w.cmin_tab + (size_t)p * kCminRow)[lane];
     wave_lds_sync();
-    // positions per bucket as bit planes over the buckets (wave-uniform 64-bit masks, like k_expand_a)
-    unsigned long long pl[6];
+    // positions per bucket as bit planes over the buckets (wave-uniform 64-bit masks, like k_expand_a): pl = the 56
+    // buckets of suf_sig (exact re-test), plh[h] = the two halves of each bucket (plane test)
+    unsigned long long pl[6], plh[2][6];
     {
-      const uint32_t mycnt = s_bucket[lane];
+      const uint32_t c0 = s_bucket[lane], c1 = s_bucket[kWave + lane];
 #pragma unroll
-      for (uint32_t k = 0; k < 6; k++) pl[k] = __ballot((mycnt >> k) & 1u);
+      for (uint32_t k = 0; k < 6; k++) {
+        pl[k] = __ballot(((c0 + c1) >> k) & 1u);
+        plh[0][k] = __ballot((c0 >> k) & 1u);
+        plh[1][k] = __ballot((c1 >> k) & 1u);
+      }
     }
     // tmin and the length intervals {first | last << 16} per level of this pattern length (k_cmin), wave-uniform
     const uint32_t* ext = reinterpret_cast<const uint32_t*>(w.cmin_tab + (size_t)p * kCminRow + kCminTab);
@@ -991,12 +1001,16 @@ __global__ void __launch_bounds__(kWave, 6) k_expand_h(DevIndex ix, DevBatch b, 
       };
       unsigned long long a[6] = {0, 0, 0, 0, 0, 0};
       const unsigned long long* col = ix.planes + blk;
-      plane_level<0>(a, pl[0], col, ix.n_blk, valid);
-      plane_level<1>(a, pl[1], col, ix.n_blk, valid);
-      plane_level<2>(a, pl[2], col, ix.n_blk, valid);
-      plane_level<3>(a, pl[3], col, ix.n_blk, valid);
-      plane_level<4>(a, pl[4], col, ix.n_blk, valid);
-      plane_level<5>(a, pl[5], col, ix.n_blk, valid);
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const unsigned long long* ch = col + (unsigned long long)(h * kSigBits) * ix.n_blk;
+        plane_level<0>(a, plh[h][0], ch, ix.n_blk, valid);
+        plane_level<1>(a, plh[h][1], ch, ix.n_blk, valid);
+        plane_level<2>(a, plh[h][2], ch, ix.n_blk, valid);
+        plane_level<3>(a, plh[h][3], ch, ix.n_blk, valid);
+        plane_level<4>(a, plh[h][4], ch, ix.n_blk, valid);
+        plane_level<5>(a, plh[h][5], ch, ix.n_blk, valid);
+      }
       // d = count - tmin, bit-sliced (tmin wave-uniform: each level is two operations); bor = borrow = count < tmin
       unsigned long long d[6], bor = 0;
 #pragma unroll
@@ -1066,7 +1080,7 @@ __global__ void __launch_bounds__(kWave, 6) k_expand_h(DevIndex ix, DevBatch b, 
       const uint32_t h1 = blk_end == blk_last_r + 1 ? r_hi : blk_end * 64u;
       uint32_t rows = 2u * n_iv + (clamp_possible ? 1u : 0u);  // thermometer rows
 #pragma unroll
-      for (int k = 0; k < 6; k++) rows += (uint32_t)__popcll(pl[k]);
+      for (int k = 0; k < 6; k++) rows += (uint32_t)__popcll(plh[0][k]) + (uint32_t)__popcll(plh[1][k]);
       tot_hits += h1 - h0;
       tot_pass += n_pass;
       tot_words += (unsigned long long)rows * (blk_end - blk_first);
