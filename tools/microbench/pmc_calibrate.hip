@@ -6,6 +6,7 @@
 //   k_random32   one 32 B load per lane at a random 32 B-aligned address, every 128 B line touched at most once
 //                (k_probe's key loads): requested = 32 B, the memory system moves a line
 //   k_random16   same with 16 B loads (trigram entries)
+//   k_random16_pair  two 16 B loads per lane, one in each 64 B half of the lane's line: fill granularity of a random miss
 //   k_write8      8 B per lane streaming store (queue appends)
 // tools/pmc_calibrate.py runs this under `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` and writes the factors.
 //   hipcc --offload-arch=gfx950 -O3 -o pmc_calibrate pmc_calibrate.hip
@@ -41,6 +42,16 @@ __global__ void __launch_bounds__(256) k_random16(const V16* a, uint64_t n_lines
   const V16 v = a[line * 8 + (t & 7)];
   if ((v.t[0] ^ v.t[3]) == 0x12345678u) out[0] = v.t[1];
 }
+// Both halves of every line, by the same lane: tells a 128-byte fill (the second load hits the line just filled: the counter
+// stays where k_random16 leaves it) from 64-byte sector fills (the counter doubles).
+__global__ void __launch_bounds__(256) k_random16_pair(const V16* a, uint64_t n_lines, uint32_t* out) {
+  const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  if (t >= n_lines) return;
+  const uint64_t line = (t * 0x9E3779B97F4A7C15ull) & (n_lines - 1);
+  const V16 v = a[line * 8 + (t & 3)];
+  const V16 u = a[line * 8 + 4 + (t & 3)];
+  if ((v.t[0] ^ u.t[3]) == 0x12345678u) out[0] = v.t[1];
+}
 __global__ void __launch_bounds__(256) k_write8(unsigned long long* a, uint64_t n) {
   for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) a[i] = i * 0x9E3779B97F4A7C15ull;
 }
@@ -57,6 +68,7 @@ int main() {
     hipLaunchKernelGGL(k_stream8, dim3(65536), dim3(256), 0, 0, (const unsigned long long*)a, bytes / 8, out);
     hipLaunchKernelGGL(k_random32, dim3((unsigned)(n_lines / 256)), dim3(256), 0, 0, (const V32*)a, n_lines, out);
     hipLaunchKernelGGL(k_random16, dim3((unsigned)(n_lines / 256)), dim3(256), 0, 0, (const V16*)a, n_lines, out);
+    hipLaunchKernelGGL(k_random16_pair, dim3((unsigned)(n_lines / 256)), dim3(256), 0, 0, (const V16*)a, n_lines, out);
     hipLaunchKernelGGL(k_write8, dim3(65536), dim3(256), 0, 0, (unsigned long long*)a, bytes / 8);
     hipDeviceSynchronize();
   }

@@ -48,6 +48,9 @@ res = {
         "random16": lines * 128 / (fetch["k_random16"] * 1024),
     },
     "raw_bytes_per_load": {"random32": fetch["k_random32"] * 1024 / lines, "random16": fetch["k_random16"] * 1024 / lines},
+    # both halves of each line touched by one lane: ~ the same raw count as k_random16 = a miss fills the whole 128 B line
+    # (the x2 of the streaming kernels applies to random loads too); ~ twice = 64 B sector fills (x1)
+    "raw_bytes_per_line_both_halves": fetch["k_random16_pair"] * 1024 / lines,
     "write_factor": B / (write["k_write8"] * 1024),
 }
 path = os.path.join(ROOT, "profiles", f"{rnd}_fetch_size_calibration.json")
