@@ -308,6 +308,11 @@ def main():
     b_probe = float(cst.probe_bytes)
     light_hits = last.n_hits - last.n_heavy_hits
     b_exa = 8.0 * light_hits + 8.0 * last.plane_words + 8.0 * last.n_heavy_pass + 8.0 * last.n_phase_b + 8.0 * main_wl.total_tokens
+    #   expand_b    8 B queue entry + 16 B record per queued hit, the pattern once per query, and for every hit it keeps the
+    #               sentence's tokens (mean length of the corpus) and a 16 B segment entry; the tokens of hits that fail the
+    #               dominance / coverage tests are not counted (a lower bound of what the kernel has to read)
+    exb_ms = per_stage.get("expand_b", 0.0)
+    b_exb = 24.0 * last.n_phase_b + 4.0 * main_wl.total_tokens + last.n_kept * (4.0 * (mean_len + 1) + 16.0)
     probe_gbs = b_probe / (probe_ms * 1e-3) / 1e9 if probe_ms > 0 else 0.0
     exa_gbs = b_exa / (exa_ms * 1e-3) / 1e9 if exa_ms > 0 else 0.0
     rank_rates = None
@@ -340,7 +345,8 @@ def main():
             write = pmc_pass("WRITE_SIZE", child, log) if fetch else None
             log(f"[bench] pmc child passes: {time.time() - t1:.0f}s")
             if fetch and write:
-                for kern, pattern in (("fmx::k_probe", "random"), ("fmx::k_expand_a", "stream16"), ("fmx::k_expand_h", "stream8")):
+                for kern, pattern in (("fmx::k_probe", "random"), ("fmx::k_expand_a", "stream16"), ("fmx::k_expand_h", "stream8"),
+                                      ("fmx::k_expand_b", "random")):
                     key = next((k for k in fetch if k.replace("void ", "").startswith(kern)), None)
                     if key is None:
                         continue
@@ -369,8 +375,12 @@ def main():
                      "phase A of the hit walk (two kernels side by side): 8 B per hit walked one by one, 8 B per bit-plane word, "
                      "8 B per plane survivor re-tested, 8 B per hit queued, 8 B per range descriptor (kernel counters)")
         r_probe["lines_bytes_per_launch"] = int(cst.probe_lines) * 128  # distinct 128 B lines x 128: what random reads cost the memory system
-        dominant = r_exa if exa_ms >= probe_ms else r_probe
-        other = r_probe if dominant is r_exa else r_exa
+        r_exb = roof("k_expand_b", b_exb, exb_ms, ["k_expand_b"],
+                     "phase B: 8 B queue entry + 16 B record per queued hit, 4 B per pattern token, and per kept hit its sentence "
+                     "(4 B x (mean length + 1)) and a 16 B segment entry; reads for hits that fail the dominance / exact "
+                     "coverage tests are not counted (lower bound)")
+        roofs = sorted([r_probe, r_exa, r_exb], key=lambda r: -r["kernel_ms"])
+        dominant, others = roofs[0], roofs[1:]
 
         # ---- parity spot check, reference byte model, CPU baseline (the oracle: test infrastructure, outside the timed region) ----
         import oracle_lib
@@ -434,7 +444,7 @@ def main():
                        "timed_path": "fmx_match_batch: pinned host buffers in, pinned host buffers out (H2D + kernels + D2H), "
                                      f"{args.threads} synchronous call(s) in flight" + (", + RCCL gather of the records to rank 0" if world > 1 else ""),
                        "parallelism": f"queries sharded over {world} GPU(s), index replicated"},
-            "roofline": dominant, "roofline_other": [other], "reference_byte_model": ref_model,
+            "roofline": dominant, "roofline_other": others, "reference_byte_model": ref_model,
             "device_resident": {"value": round(nq_step_all * args.steps / el_dev, 1),
                                 "ms_per_step": round(el_dev / args.steps * 1e3, 3),
                                 "stage_ms_per_step": {k: round(v, 4) for k, v in per_stage.items()},
