@@ -75,12 +75,15 @@ struct DvFiveBoundary {
   }
 };
 
+// (grid-stride, one atomic per wave at the end: one atomic per 64 boundaries on a single address was 6 ms at C3)
 __global__ void __launch_bounds__(256) k_dv_count_starts(const uint32_t* __restrict__ bnd, uint32_t n_bnd, const SufRec* __restrict__ suf,
                                                          uint32_t min_rem, unsigned long long* __restrict__ count) {
-  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool is = k < n_bnd && suf[bnd[k]].rem >= min_rem;
-  const unsigned long long m = __ballot(is);
-  if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, (unsigned long long)__popcll(m));
+  unsigned long long mine = 0;
+  for (unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; k < n_bnd; k += (unsigned long long)gridDim.x * blockDim.x)
+    mine += suf[bnd[k]].rem >= min_rem ? 1ull : 0ull;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d, 64);
+  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(count, mine);
 }
 
 __device__ __forceinline__ void dv_insert(GramEntry* g, uint32_t mask, uint32_t h, uint32_t w1, uint32_t w2, uint32_t lo, uint32_t cnt) {

@@ -102,8 +102,8 @@ constexpr int kScanSlots = 4;  // scans per pass: queue capacities, queued hits,
 // Everything one call mutates.
 struct Ctx {
   // ---- workspace ----
-  Grow<uint32_t> q_m, q_kept, q_cand, q_acc, q_pb, q_aux, q_rank, big_list, mid_list, fin_list, contrast_list;
-  Grow<unsigned long long> q_hits, q_hits_a, q_seg, q_qseg, q_cap, c_in, c_off;
+  Grow<uint32_t> q_m, q_kept, q_cand, q_acc, q_pb, q_rank, big_list, mid_list, fin_list, contrast_list;
+  Grow<unsigned long long> q_hits, q_hits_a, q_seg, q_qseg, q_cap, c_in, c_off, q_best;
   Grow<uint32_t> t_q, t_lo, t_cnt;
   Grow<float>    t_idf;
   Grow<unsigned long long> c_qi, keys;
@@ -154,7 +154,7 @@ struct Ctx {
     ok = true;
   }
   void destroy() {
-    q_m.release(); q_kept.release(); q_cand.release(); q_acc.release(); q_pb.release(); q_aux.release(); q_rank.release();
+    q_m.release(); q_kept.release(); q_cand.release(); q_acc.release(); q_pb.release(); q_rank.release(); q_best.release();
     big_list.release(); mid_list.release(); fin_list.release(); contrast_list.release();
     q_hits.release(); q_hits_a.release(); q_seg.release(); q_qseg.release(); q_cap.release(); c_in.release(); c_off.release();
     t_q.release(); t_lo.release(); t_cnt.release(); t_idf.release(); c_qi.release(); keys.release(); seg.release(); qb.release();
@@ -321,7 +321,7 @@ static unsigned long long* derive_on_device(DeviceIndex::Impl& m, const HostInde
     auto table_cap = [](unsigned long long groups) { unsigned long long cap = 16; while (cap < groups * 2) cap <<= 1; return cap; };
     const uint32_t n_b3 = select(tri, bnd3);
     HIP_TRY(hipMemset(d_count, 0, 8));
-    hipLaunchKernelGGL(k_dv_count_starts, dim3((n_b3 + 255) / 256), dim3(256), 0, 0, (const uint32_t*)bnd3, n_b3, (const SufRec*)suf, 3u, d_count);
+    hipLaunchKernelGGL(k_dv_count_starts, dim3(std::min<uint32_t>((n_b3 + 255) / 256, 2048u)), dim3(256), 0, 0, (const uint32_t*)bnd3, n_b3, (const SufRec*)suf, 3u, d_count);
     const unsigned long long groups = read_count();
     const unsigned long long cap3 = table_cap(groups);
     if (groups != 0 && cap3 <= (1ull << 31)) {  // else: the keyed search is used instead (same rule as HostIndex::build_gram_table)
@@ -442,7 +442,7 @@ void DeviceIndex::upload(const HostIndex& h, int device) {
 }
 
 static void ensure_ws(Ctx& c, uint64_t nq, uint64_t nt, uint64_t seg) {
-  c.q_m.ensure(nq); c.q_kept.ensure(nq); c.q_cand.ensure(nq); c.q_acc.ensure(nq); c.q_pb.ensure(nq); c.q_aux.ensure(nq);
+  c.q_m.ensure(nq); c.q_kept.ensure(nq); c.q_cand.ensure(nq); c.q_acc.ensure(nq); c.q_pb.ensure(nq); c.q_best.ensure(3 * nq);
   c.q_rank.ensure(nq); c.big_list.ensure(nq); c.mid_list.ensure(nq); c.fin_list.ensure(nq); c.contrast_list.ensure(2 * nq);
   c.q_hits.ensure(nq + 1); c.q_hits_a.ensure(nq + 1); c.q_seg.ensure(nq + 1); c.q_qseg.ensure(nq + 1); c.q_cap.ensure(nq + 1);
   c.c_in.ensure(3 * (nq + 1)); c.c_off.ensure(3 * (nq + 1));
@@ -462,7 +462,7 @@ static DevWork work_view(Ctx& c) {
   DevWork w{};
   w.q_m = c.q_m.p; w.t_q = c.t_q.p; w.t_lo = c.t_lo.p; w.t_cnt = c.t_cnt.p; w.q_hits = c.q_hits.p; w.q_hits_a = c.q_hits_a.p;
   w.q_cap = c.q_cap.p; w.q_seg = c.q_seg.p; w.q_qseg = c.q_qseg.p; w.qb_cap = c.qb.cap; w.q_kept = c.q_kept.p; w.q_cand = c.q_cand.p; w.q_acc = c.q_acc.p; w.q_pb = c.q_pb.p;
-  w.q_aux = c.q_aux.p; w.q_rank = c.q_rank.p; w.p_hist = c.p_hist_p(); w.cmin_tab = c.cmin_tab.p; w.c_in = c.c_in.p;
+  w.q_best = c.q_best.p; w.q_rank = c.q_rank.p; w.p_hist = c.p_hist_p(); w.cmin_tab = c.cmin_tab.p; w.c_in = c.c_in.p;
   w.c_off = c.c_off.p; w.c_qi = c.c_qi.p; w.t_idf = c.t_idf.p; w.seg = c.seg.p; w.qb = c.qb.p; w.heap = c.heap.p;
   w.seg_cap = c.seg_cap; w.counters = c.counters_p();
   return w;
@@ -645,15 +645,12 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
           hipLaunchKernelGGL(k_cacc, dim3((n_scan + 255) / 256), dim3(256), 0, stream, b, w);
           hipLaunchKernelGGL(k_scan_lb<2>, dim3(scan_tiles), dim3(kScanThreads), 0, stream, w.c_in, w.c_off, (size_t)n_scan, n_scan,
                              c.scan_state(3), c.scan_ticket(3));
-          hipLaunchKernelGGL(k_camap, dim3(b.nq), dim3(kWave), 0, stream, b, w, sc);
-          for (uint32_t r = 0; r < prm.nmatch; r++) {
-            if (r) {
-              hipLaunchKernelGGL(k_cdp<32>, dim3(256 * 16), dim3(kWave), 0, stream, m.d, b, w, prm, sc, r);
-              if (m.d.max_slen > 32)
-                hipLaunchKernelGGL(k_cdp<64>, dim3(256 * 8), dim3(kWave), 0, stream, m.d, b, w, prm, sc, r);
-            }
-            hipLaunchKernelGGL(k_cpick, dim3((b.nq + 255) / 256), dim3(256), 0, stream, m.d, b, w, prm, sc, r, cap, d_out, d_out_count,
-                               d_out_total);
+          hipLaunchKernelGGL(k_camap, dim3(b.nq), dim3(kWave), 0, stream, m.d, b, w, sc, prm, d_out_count, d_out_total);
+          // round r: the match picked in round r - 1 emits itself, the others bid for round r's pick
+          for (uint32_t r = 1; r <= prm.nmatch; r++) {
+            hipLaunchKernelGGL(k_cround<32>, dim3(256 * 16), dim3(kWave), 0, stream, m.d, b, w, prm, sc, r, cap, d_out, d_out_count, d_out_total);
+            if (m.d.max_slen > 32)
+              hipLaunchKernelGGL(k_cround<64>, dim3(256 * 8), dim3(kWave), 0, stream, m.d, b, w, prm, sc, r, cap, d_out, d_out_count, d_out_total);
           }
         } else {
           hipLaunchKernelGGL(k_contrast<0>, dim3(b.nq), dim3(kWave), 0, stream, m.d, b, w, prm, sc, cap, d_out,
@@ -662,7 +659,7 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
         if (m.d.max_slen > 32 && !flat)
           hipLaunchKernelGGL(k_contrast<1>, dim3(2048), dim3(kWave), 0, stream, m.d, b, w, prm, sc, cap, d_out,
                              d_out_count, d_out_total, cl, (float*)nullptr, 0u);
-        if (m.d.max_slen > 64) {
+        {  // long sentences, and the queries with more accepted matches than the flattened rerank indexes (k_finish queues both)
           const size_t lds = ((size_t)m.d.max_slen + 1) * kWave * 4;
           if (lds > kDynLdsMax - 8 * 1024) {  // indexed sentences too long for LDS rows: rows in HBM
             const unsigned grid_g = 512;

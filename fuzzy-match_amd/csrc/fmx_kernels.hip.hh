@@ -73,7 +73,7 @@ struct DevWork {
   uint32_t* q_cand;     // nq
   uint32_t* q_acc;      // nq
   uint32_t* q_pb;       // nq   hits queued by k_expand_a for k_expand_b
-  uint32_t* q_aux;      // nq   contrastive rerank: sentence-buffer position of the match picked last
+  unsigned long long* q_best;  // 3 x nq  contrastive rerank: the bids of three consecutive rounds (k_cround)
   uint32_t* q_rank;     // nq   position of the query in pattern-length order (DP lists are built in that order)
   uint32_t* p_hist;     // 2 x kPBins: queries per pattern length, then the placement cursors
   const uint16_t* cmin_tab;  // (p_max + 1) x kCminTab: per (pattern length, stored sentence length) the phase-A threshold
@@ -2161,6 +2161,9 @@ struct Rec {  // == fmx_match
   uint32_t s_id;
 };
 
+constexpr uint32_t kMaxFlatRounds = 16;       // flattened contrastive rerank: rounds (= nmatch) it is launched for
+constexpr uint32_t kMaxFlatAccepted = 65535;  // ... and accepted matches per query it indexes (16 bits of the bid)
+
 struct DevScratch {
   unsigned long long* keys;   // 2 * seg_cap
   uint32_t*           vals;   // 2 * seg_cap
@@ -2440,8 +2443,8 @@ __global__ void __launch_bounds__(kWave) k_finish(DevIndex ix, DevBatch b, DevWo
         w.q_acc[q] = n;
         // contrastive rerank: queries whose accepted sentences are longer than 32 / 64 tokens are queued for the
         // wider kernels; everything else is done by k_contrast<0> in place
-        if (contrast && n != 0 && mx > 32) {
-          const uint32_t cls = mx <= 64 ? 1u : 2u;
+        if (contrast && n != 0 && (mx > 32 || n > kMaxFlatAccepted)) {
+          const uint32_t cls = (mx <= 64 && n <= kMaxFlatAccepted) ? 1u : 2u;  // the flattened rerank indexes a query's matches with 16 bits
           contrast_list[(size_t)(cls - 1) * b.nq + atomicAdd(&w.counters[9 + cls], 1ull)] = q;
           w.q_acc[q] = n | (cls << 30);  // length class of the accepted sentences (0: <= 32, 1: <= 64, 2: longer)
         }
@@ -2505,17 +2508,27 @@ __global__ void __launch_bounds__(kWave) k_contrast(DevIndex ix, DevBatch b, Dev
 }
 
 // ---------------------------------------------------------------------------------------------
-// Flattened contrastive rerank for the common case (every accepted sentence <= 32 tokens, 1 <= nmatch <=
-// kMaxFlatRounds): one k_cpick (a wave per query picks the first maximum of score - factor * penalty and
-// emits it) and one k_cdp (one lane per still-unpicked accepted match of ANY query computes its ids-only
-// edit distance to the match its query picked last) per round.  A per-query kernel would run the DP with a
-// handful of busy lanes; here every wave is full.  State per accepted match lives in the global scratch
-// (pen_sum = sc.f0, Match::penalty = sc.f1, taken flag | running max = sc.keys), indexed by segment slot.
+// Flattened contrastive rerank (1 <= nmatch <= kMaxFlatRounds; accepted sentences of at most 64 tokens and at most
+// 65535 accepted matches per query, everything else goes to k_contrast<2>): ONE kernel per round, one lane per
+// still-unpicked accepted match of ANY query (every wave is full).  In round r the lane learns from q_best which match
+// its query picked in round r - 1 (src/fuzzy_match.cc:633-668: std::max_element of score - factor * penalty over the
+// remaining list, i.e. first maximum in (score desc, s_id asc) order); the picked match emits itself; every other match
+// computes its ids-only edit distance to the picked sentence, updates its penalty and bids for round r's pick with one
+// 64-bit atomicMax: orderable(score - factor * penalty) << 32 | (0xffff - list rank) << 16 | index.  The bids of three
+// consecutive rounds live in three arrays (read r - 1, write r, clear r + 1), so there is no separate pick kernel and no
+// second pass over the accepted lists.  State per accepted match lives in the global scratch (pen_sum = sc.f0,
+// Match::penalty = sc.f1, sc.keys = taken << 63 | list rank << 32 | running max, sc.vals = where its sentence starts),
+// indexed by segment slot.
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t kMaxFlatRounds = 16;
 
-// flat_cls_max: highest length class handled by the flattened path (1 normally; 0 when class 1 is left to
-// k_contrast<1>)
+__device__ __forceinline__ uint32_t float_orderable(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return (u >> 31) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ unsigned long long contrast_bid(float key, uint32_t rank, uint32_t k) {
+  return ((unsigned long long)float_orderable(key) << 32) | ((unsigned long long)(0xffffu - rank) << 16) | k;
+}
+
 __global__ void k_cacc(DevBatch b, DevWork w) {
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q > b.nq) return;
@@ -2530,95 +2543,111 @@ __global__ void k_cacc(DevBatch b, DevWork w) {
   w.c_in[stride + q] = v[1];
 }
 
-__global__ void __launch_bounds__(kWave) k_camap(DevBatch b, DevWork w, DevScratch sc) {
+// wave per query: the flat list of (query, accepted match) pairs, each match's rank in list order and sentence position,
+// the bid of round 0 (penalties are zero: the best score, first in list order)
+__global__ void __launch_bounds__(kWave) k_camap(DevIndex ix, DevBatch b, DevWork w, DevScratch sc, Params prm, uint32_t* out_count,
+                                                 uint32_t* out_total) {
   const uint32_t q = blockIdx.x;
-  if (w.q_cand[q] == 0) return;
+  if (w.q_cand[q] == 0) return;  // k_finish wrote the empty result
   const uint32_t acc = w.q_acc[q];
   const uint32_t cls = acc >> 30, n = acc & 0x3fffffffu;
   if (cls >= 2) return;
+  const uint32_t lane = lane_id();
+  if (n == 0) {
+    if (lane == 0) { out_count[b.q_begin + q] = 0; if (out_total) out_total[b.q_begin + q] = 0; }
+    return;
+  }
   const size_t stride = (size_t)b.nq + 1;
   unsigned long long base = w.c_off[cls * stride + q];
   if (cls == 1) base += w.c_off[b.nq];
   const unsigned long long seg0 = w.q_seg[q];
-  for (uint32_t k = lane_id(); k < n; k += kWave) {
-    w.c_qi[base + k] = ((unsigned long long)q << 32) | k;
-    sc.f0[seg0 + k] = 0.f; sc.f1[seg0 + k] = 0.f; sc.keys[2ull * seg0 + k] = 0ull;
-  }
-}
-
-__global__ void __launch_bounds__(256) k_cpick(DevIndex ix, DevBatch b, DevWork w, Params prm, DevScratch sc, uint32_t round,
-                                               uint32_t cap, Rec* out_rec, uint32_t* out_count, uint32_t* out_total) {
-  // one thread per query: the accepted list of a query is a handful of entries (at most the contrast buffer),
-  // and a wave per query spent its time on the dependent loads in front of them
-  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= b.nq) return;
-  if (w.q_cand[q] == 0) return;  // k_finish wrote the empty result
-  const uint32_t acc = w.q_acc[q];
-  if ((acc >> 30) >= 2) return;  // queued for k_contrast<2>
-  const uint32_t n = acc & 0x3fffffffu;
-  const uint32_t gq = b.q_begin + q;
-  const uint32_t want = prm.nmatch < n ? prm.nmatch : n;
-  if (n == 0 && round == 0) { out_count[gq] = 0; if (out_total) out_total[gq] = 0; }
-  if (round >= want) return;
-  const unsigned long long seg0 = w.q_seg[q];
   const Cand* seg = w.seg + seg0;
-  unsigned long long* keys = sc.keys + 2ull * seg0;
-  const float* pen_cur = sc.f1 + seg0;
-  // std::max_element over the remaining list (score desc, s_id asc): first maximum of score - factor * penalty
-  float best_key = 0.f, best_score = 0.f, best_pen = 0.f;
-  uint32_t best_sid = 0, best_longest = 0;
-  int best = -1;
-  for (uint32_t k = 0; k < n; k++) {
-    if (keys[k] >> 63) continue;
-    const Cand c = seg[k];
-    const float pen = pen_cur[k];
-    const float key = c.score - (prm.contrast * pen);
-    if (best < 0 || best_key < key || (best_key == key && (best_score < c.score || (best_score == c.score && c.sid < best_sid)))) {
-      best = (int)k; best_key = key; best_score = c.score; best_sid = c.sid; best_pen = pen; best_longest = c.longest;
+  unsigned long long best = 0;
+  for (uint32_t k0 = 0; k0 < n; k0 += kWave) {
+    const uint32_t k = k0 + lane;
+    Cand c;
+    c.sid = 0; c.longest = 0; c.score = 0.f; c.penalty = 0.f;
+    if (k < n) c = seg[k];
+    uint32_t rank = 0;
+    if (n <= kWave) {  // the usual case: the whole list sits in the wave's registers
+      for (uint32_t j = 0; j < n; j++) {
+        const float os = __shfl(c.score, (int)j, 64);
+        const uint32_t oid = __shfl(c.sid, (int)j, 64);
+        rank += (os > c.score || (os == c.score && oid < c.sid)) ? 1u : 0u;
+      }
+    } else if (k < n) {
+      for (uint32_t j = 0; j < n; j++) {
+        const float os = seg[j].score;
+        const uint32_t oid = seg[j].sid;
+        rank += (os > c.score || (os == c.score && oid < c.sid)) ? 1u : 0u;
+      }
     }
+    if (k >= n) continue;
+    w.c_qi[base + k] = ((unsigned long long)q << 32) | k;
+    sc.f0[seg0 + k] = 0.f; sc.f1[seg0 + k] = 0.f;
+    sc.keys[2ull * seg0 + k] = (unsigned long long)rank << 32;
+    sc.vals[2ull * seg0 + k] = ix.sent_pos[c.sid];
+    const unsigned long long bid = contrast_bid(c.score - (prm.contrast * 0.f), rank, k);
+    best = bid > best ? bid : best;
   }
-  if (round < cap) {
-    Rec r;
-    r.score = best_score; r.penalty = best_pen; r.max_subseq = (int32_t)best_longest; r.s_id = best_sid;
-    out_rec[(unsigned long long)gq * cap + round] = r;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const unsigned long long o = ((unsigned long long)__shfl_xor((uint32_t)(best >> 32), d, 64) << 32) | __shfl_xor((uint32_t)best, d, 64);
+    best = o > best ? o : best;
   }
-  keys[best] |= 1ull << 63;
-  w.q_aux[q] = ix.sent_pos[best_sid];  // where the picked sentence starts: k_cdp needs nothing else of it
-  if (round + 1 == want) { out_count[gq] = want < cap ? want : cap; if (out_total) out_total[gq] = want; }
+  if (lane == 0) { w.q_best[q] = best; w.q_best[(size_t)b.nq + q] = 0; w.q_best[2 * (size_t)b.nq + q] = 0; }
 }
 
 template <int P>
-__global__ void __launch_bounds__(kWave) k_cdp(DevIndex ix, DevBatch b, DevWork w, Params prm, DevScratch sc,
-                                               uint32_t round) {
+__global__ void __launch_bounds__(kWave) k_cround(DevIndex ix, DevBatch b, DevWork w, Params prm, DevScratch sc, uint32_t round,
+                                                  uint32_t cap, Rec* out_rec, uint32_t* out_count, uint32_t* out_total) {
   const uint32_t lane = lane_id();
   const size_t stride = (size_t)b.nq + 1;
   const unsigned long long t0 = w.c_off[b.nq], t1 = w.c_off[stride + b.nq];
   const unsigned long long j_lo = P == 32 ? 0ull : t0, j_hi = P == 32 ? t0 : t0 + t1;
+  const unsigned long long* bid_prev = w.q_best + (size_t)((round + 2) % 3) * b.nq;  // round - 1
+  unsigned long long* bid_cur = w.q_best + (size_t)(round % 3) * b.nq;
+  unsigned long long* bid_next = w.q_best + (size_t)((round + 1) % 3) * b.nq;
   for (unsigned long long j = j_lo + (unsigned long long)blockIdx.x * kWave + lane; j < j_hi;
        j += (unsigned long long)gridDim.x * kWave) {
     const unsigned long long qi = w.c_qi[j];
     const uint32_t q = (uint32_t)(qi >> 32), k = (uint32_t)qi;
     const uint32_t n = w.q_acc[q] & 0x3fffffffu;
     const uint32_t want = prm.nmatch < n ? prm.nmatch : n;
-    if (round >= want) continue;  // this query has emitted everything it will emit
+    if (round > want) continue;  // this query has emitted everything it will emit
     const unsigned long long seg0 = w.q_seg[q];
     unsigned long long* keys = sc.keys + 2ull * seg0;
-    if (keys[k] >> 63) continue;
-    const Cand* seg = w.seg + seg0;
-    const uint32_t msp = w.q_aux[q];
-    const uint32_t n2 = ix.tok[msp];
-    const uint32_t csp = ix.sent_pos[seg[k].sid];
-    const uint32_t n1 = ix.tok[csp];
+    const unsigned long long kw = keys[k];
+    if (kw >> 63) continue;      // picked in an earlier round
+    const uint32_t kb = (uint32_t)bid_prev[q] & 0xffffu;  // the match picked in round - 1
+    const Cand c = w.seg[seg0 + k];
+    if (k == kb) {
+      const uint32_t gq = b.q_begin + q;
+      if (round - 1 < cap) {
+        Rec r;
+        r.score = c.score; r.penalty = sc.f1[seg0 + k]; r.max_subseq = (int32_t)c.longest; r.s_id = c.sid;
+        out_rec[(unsigned long long)gq * cap + (round - 1)] = r;
+      }
+      keys[k] = kw | (1ull << 63);
+      if (round == want) { out_count[gq] = want < cap ? want : cap; if (out_total) out_total[gq] = want; }
+      bid_next[q] = 0;
+      continue;
+    }
+    if (round >= want) continue;  // nothing more will be picked for this query
+    const uint32_t msp = sc.vals[2ull * seg0 + kb], csp = sc.vals[2ull * seg0 + k];
+    const uint32_t n2 = ix.tok[msp], n1 = ix.tok[csp];
     const float dw = 100.f / normalizer(n1, n2, 1.f, 1.f, 1.f);
     float M;
     const float ed = edit_distance_unit<P, false>(ix.tok + csp + 1, n1, ix.tok + msp + 1, n2, 1.f * dw, M);  // costs (1, 1, 1)
     const float pen = score_from_cost(ed);
     const float sum = sc.f0[seg0 + k] + pen;
     sc.f0[seg0 + k] = sum;
-    float mx = __uint_as_float((uint32_t)(keys[k] & 0xffffffffull));
+    float mx = __uint_as_float((uint32_t)(kw & 0xffffffffull));
     mx = (round == 1) ? pen : (mx < pen ? pen : mx);
-    keys[k] = (unsigned long long)__float_as_uint(mx);
-    sc.f1[seg0 + k] = prm.reduce == 1 ? mx : (sum / (float)round);
+    keys[k] = (kw & 0x0000ffff00000000ull) | (unsigned long long)__float_as_uint(mx);
+    const float pen_now = prm.reduce == 1 ? mx : (sum / (float)round);
+    sc.f1[seg0 + k] = pen_now;
+    atomicMax(&bid_cur[q], contrast_bid(c.score - (prm.contrast * pen_now), (uint32_t)(kw >> 32) & 0xffffu, k));
   }
 }
 
