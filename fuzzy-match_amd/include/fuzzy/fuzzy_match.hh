@@ -13,6 +13,7 @@
 // every call goes through fmx_match_one, which coalesces concurrent callers into GPU micro-batches.
 #pragma once
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <atomic>
 #include <iostream>
@@ -132,6 +133,9 @@ class FuzzyMatch {
 
   // SuffixArray::sort (src/suffix_array.cc:58-102): here a promise — the work happens in ensure_ready()
   void sort() {}
+  // (not in the reference) GPUs to replicate the index on; call before the first match().  Default: the constructor's
+  // device, or the FMX_DEVICES environment variable ("0,1,2,3").
+  void set_devices(const std::vector<int>& devices) { _devices = devices; }
   // match(const Tokens&, ...) — include/fuzzy/fuzzy_match.hh:59-69
   bool match(const Tokens& pattern, float fuzzy, unsigned number_of_matches, std::vector<Match>& matches,
              int min_subseq_length = 2, float min_subseq_ratio = 0, float vocab_idf_penalty = 0,
@@ -311,7 +315,22 @@ class FuzzyMatch {
   }
   void make_ready() {
     check(fmx_index_finalize(_ix));
-    check(fmx_index_to_device(_ix, _device));
+    // one GPU by default; FMX_DEVICES="0,1,2,3" (or set_devices() before the first match) replicates the index and
+    // lets libfmx.so cut every batch into one block per GPU (include/fmx.h: fmx_index_to_devices)
+    std::vector<int> devs = _devices;
+    if (devs.empty()) {
+      if (const char* e = getenv("FMX_DEVICES")) {
+        for (const char* p = e; *p;) {
+          char* end = nullptr;
+          const long v = strtol(p, &end, 10);
+          if (end == p) break;
+          devs.push_back((int)v);
+          p = *end == ',' ? end + 1 : end;
+        }
+      }
+    }
+    if (devs.size() > 1) check(fmx_index_to_devices(_ix, devs.data(), (int)devs.size()));
+    else check(fmx_index_to_device(_ix, devs.empty() ? _device : devs[0]));
     fmx_index_info info;
     check(fmx_index_get_info(_ix, &info));
     _max_tokens = info.max_tokens_in_pattern;
@@ -325,6 +344,7 @@ class FuzzyMatch {
   int _pt;
   size_t _max_tokens;
   int _device;
+  std::vector<int> _devices;
   fmx_index* _ix;
   mutable std::mutex _mu;
   std::atomic<bool> _ready{false};

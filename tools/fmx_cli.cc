@@ -127,7 +127,8 @@ static int usage(int rc) {
                "  -I [ --idf-penalty ] arg (=0)\n  --insert-cost arg (=1)  --delete-cost arg (=1)  --replace-cost arg (=1)\n"
                "  --max-tokens-in-pattern arg (=300)\n  --contrast arg (=0)  --contrast-reduce arg (=mean)  --contrast-buffer arg (=-1)\n"
                "  -N [ --nthreads ] arg          helper threads for parsing / formatting (matching runs on the GPU)\n"
-               "  --batch arg (=65536)           patterns per GPU batch\n  --device arg (=0)\n";
+               "  --batch arg (=65536)           patterns per GPU batch\n  --device arg (=0)\n"
+               "  --devices a,b,...              replicate the index on several GPUs: every batch is cut into one block per GPU\n";
   return rc;
 }
 
@@ -141,6 +142,7 @@ int main(int argc, char** argv) {
   size_t batch = 65536;
   unsigned nthreads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
   int device = 0;
+  std::vector<int> devices;
   bool tokenised = false, add_target = false, add_target_no_index = false, idf_weighting = false;
   for (int i = 1; i < argc; i++) {
     const std::string a = argv[i];
@@ -173,6 +175,16 @@ int main(int argc, char** argv) {
     else if (a == "--tokenised" || a == "--tokenized") tokenised = true;
     else if (a == "--batch") batch = (size_t)strtoull(val(), nullptr, 10);
     else if (a == "--device") device = atoi(val());
+    else if (a == "--devices") {
+      std::string v = val();
+      for (size_t i = 0; i <= v.size();) {
+        size_t j = v.find(',', i);
+        if (j == std::string::npos) j = v.size();
+        if (j > i) devices.push_back(atoi(v.substr(i, j - i).c_str()));
+        i = j + 1;
+      }
+      if (!devices.empty()) device = devices[0];
+    }
     else { std::cerr << "ERROR: unknown option " << a << std::endl; return usage(2); }
   }
   prm.reduce = reduce == "max" ? 1 : 0;
@@ -255,7 +267,8 @@ int main(int argc, char** argv) {
 
   if (action == "match" || action == "subseq") {
     const bool subseq = action == "subseq";
-    if (fmx_index_sort(ix, device, 0) != FMX_OK || fmx_index_finalize(ix) != FMX_OK || fmx_index_to_device(ix, device) != FMX_OK) {
+    if (fmx_index_sort(ix, device, 0) != FMX_OK || fmx_index_finalize(ix) != FMX_OK ||
+        (devices.size() > 1 ? fmx_index_to_devices(ix, devices.data(), (int)devices.size()) : fmx_index_to_device(ix, device)) != FMX_OK) {
       std::cerr << "ERROR: " << fmx_last_error() << std::endl;
       return 1;
     }
