@@ -160,7 +160,7 @@ def main():
     ix.finalize()
     ix.to_device(local_rank)
     ix.set_option("contexts", max(2, args.threads))
-    for opt in ("FMX_SUB_QUERIES", "FMX_HOST_SUB_QUERIES", "FMX_HEAVY_MIN", "FMX_SERIAL"):
+    for opt in ("FMX_SUB_QUERIES", "FMX_HOST_SUB_QUERIES", "FMX_HEAVY_MIN", "FMX_SERIAL", "FMX_LIGHT_MAX", "FMX_HEAVY_GRID"):
         if os.environ.get(opt):
             ix.set_option(opt[4:].lower(), int(os.environ[opt]))
     info = ix.info()
@@ -332,7 +332,7 @@ def main():
             f"(pinned={host_stats[-1].pinned}); device-resident: {main_wl.nq * args.steps / el_dev / 1e6:.2f} M patterns/s")
         log(f"[bench] kernel ms/step by stage: { {k: round(v, 3) for k, v in per_stage.items()} }")
         log(f"[bench] last step: hits {last.n_hits} (bit planes {last.n_heavy_hits}, passed {last.n_heavy_pass}) phaseB {last.n_phase_b} "
-            f"kept {last.n_kept} candidates {last.n_candidates} retries {last.n_retries} big {last.n_big} max_kept {last.max_kept}")
+            f"(light queries {last.n_light_hits}) kept {last.n_kept} candidates {last.n_candidates} retries {last.n_retries} big {last.n_big} max_kept {last.max_kept}")
 
         # ---- HBM traffic of the two kernels, measured now: rocprofv3 --pmc child passes (separate passes) ----
         traffic = {}

@@ -16,7 +16,8 @@ struct UnsupportedError : std::runtime_error {  // a documented limit of this bu
   using std::runtime_error::runtime_error;
 };
 
-constexpr int kNumStages = 10;
+constexpr int kNumStages = 13;  // eleven consecutive stages of the main stream + two of the side stream beside stages 3-5
+constexpr int kStageExpandH = 11, kStageExpandB = 12;
 const char* stage_name(int s);
 
 struct Stats {
@@ -25,7 +26,7 @@ struct Stats {
   uint64_t launches[16] = {0};
   uint64_t n_hits = 0, n_kept = 0, n_candidates = 0, n_dp = 0, n_retries = 0, n_big = 0, n_phase_b = 0, max_kept = 0;
   uint64_t n_heavy_hits = 0, n_heavy_pass = 0, pinned = 0;
-  uint64_t plane_words = 0, probe_bytes = 0, probe_lines = 0;
+  uint64_t plane_words = 0, probe_bytes = 0, probe_lines = 0, n_light_hits = 0;
 };
 
 struct Rec;  // == fmx_match, defined in fmx_kernels.hip.hh
@@ -71,6 +72,8 @@ class DeviceIndex {
   void     set_heavy_min(uint32_t n);   // ranges at least this long use the bit-plane kernel (0 = never)
   void     set_probe_count(bool on);    // measurement: k_probe also counts the bytes / 128-byte lines it requests
   void     set_serial(bool on);         // measurement: no side stream, every kernel alone on the GPU
+  void     set_heavy_grid(uint32_t n);  // workgroups of the bit-plane kernel
+  void     set_light_max(uint32_t n);   // queries with at most n hits, all in short ranges, skip phase A (0 = none do)
   void     set_contexts(uint32_t n);    // concurrent calls served at once (each owns a workspace)
 
   // every pointer in HBM of device(); sub_tok_bounds = q_off at each sub-batch boundary (+ q_off[nq])

@@ -102,7 +102,7 @@ constexpr int kScanSlots = 4;  // scans per pass: queue capacities, queued hits,
 // Everything one call mutates.
 struct Ctx {
   // ---- workspace ----
-  Grow<uint32_t> q_m, q_kept, q_cand, q_acc, q_pb, q_rank, big_list, mid_list, fin_list, contrast_list;
+  Grow<uint32_t> q_m, q_kept, q_cand, q_acc, q_pb, q_rank, q_scap, big_list, mid_list, fin_list, contrast_list;
   Grow<unsigned long long> q_hits, q_hits_a, q_seg, q_qseg, q_cap, c_in, c_off, q_best;
   Grow<uint32_t> t_q, t_lo, t_cnt;
   Grow<float>    t_idf;
@@ -131,8 +131,8 @@ struct Ctx {
   Grow<Rec>      d_out;
   // ---- streams / events ----
   hipStream_t stream = nullptr, h2d = nullptr, d2h = nullptr, side = nullptr;
-  hipEvent_t  ev[2 * kNumStages]{};
-  hipEvent_t  ev_fork = nullptr, ev_join = nullptr, ev_cmin = nullptr, ev_in[kMaxPassesInFlight]{}, ev_done = nullptr;
+  hipEvent_t  ev[2 * kNumStages]{};   // [2 s], [2 s + 1]: start / end of stage s (the last stage's pair lives on the side stream)
+  hipEvent_t  ev_fork = nullptr, ev_join = nullptr, ev_cmin = nullptr, ev_a = nullptr, ev_in[kMaxPassesInFlight]{}, ev_done = nullptr;
   unsigned long long* h_ctr = nullptr;  // pinned: the pass counters land here
   unsigned long long* h_ctr_group = nullptr;  // pinned: one slot per pass of an asynchronous group
   std::vector<hipEvent_t> ev_pass;      // "pass done" events of an asynchronous group
@@ -147,6 +147,7 @@ struct Ctx {
     HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&ev_cmin, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&ev_a, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming));
     for (auto& e : ev_in) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIP_TRY(hipHostMalloc((void**)&h_ctr, kNumCounters * sizeof(unsigned long long), hipHostMallocDefault));
@@ -154,7 +155,7 @@ struct Ctx {
     ok = true;
   }
   void destroy() {
-    q_m.release(); q_kept.release(); q_cand.release(); q_acc.release(); q_pb.release(); q_rank.release(); q_best.release();
+    q_m.release(); q_kept.release(); q_cand.release(); q_acc.release(); q_pb.release(); q_rank.release(); q_scap.release(); q_best.release();
     big_list.release(); mid_list.release(); fin_list.release(); contrast_list.release();
     q_hits.release(); q_hits_a.release(); q_seg.release(); q_qseg.release(); q_cap.release(); c_in.release(); c_off.release();
     t_q.release(); t_lo.release(); t_cnt.release(); t_idf.release(); c_qi.release(); keys.release(); seg.release(); qb.release();
@@ -170,6 +171,7 @@ struct Ctx {
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
     if (ev_cmin) (void)hipEventDestroy(ev_cmin);
+    if (ev_a) (void)hipEventDestroy(ev_a);
     if (ev_done) (void)hipEventDestroy(ev_done);
     if (h_ctr) (void)hipHostFree(h_ctr);
     if (h_ctr_group) (void)hipHostFree(h_ctr_group);
@@ -191,6 +193,8 @@ struct DeviceIndex::Impl {
   uint32_t max_ctx = 3;
   bool     probe_count = false;
   bool     serial = false;        // measurement runs: no side stream, every kernel alone on the GPU
+  uint32_t heavy_grid = kHeavyGrid;      // workgroups of k_expand_h (it runs beside the light queries' kernel: it must not fill every wave slot)
+  uint32_t light_max = kLightMaxDefault;  // queries with at most this many hits, all in short ranges, skip phase A (0 = off)
   // context pool
   std::mutex              pool_mu;
   std::condition_variable pool_cv;
@@ -250,6 +254,8 @@ void     DeviceIndex::set_initial_segment(uint64_t n) { impl_->init_seg = std::m
 void     DeviceIndex::set_heavy_min(uint32_t n) { impl_->heavy_min = n; }
 void     DeviceIndex::set_probe_count(bool on) { impl_->probe_count = on; }
 void     DeviceIndex::set_serial(bool on) { impl_->serial = on; }
+void     DeviceIndex::set_heavy_grid(uint32_t n) { impl_->heavy_grid = std::min<uint32_t>(std::max<uint32_t>(n, 64u), 65536u); }
+void     DeviceIndex::set_light_max(uint32_t n) { impl_->light_max = std::min<uint32_t>(n, kPhaseBChunk); }
 void     DeviceIndex::set_contexts(uint32_t n) {
   std::lock_guard<std::mutex> lk(impl_->pool_mu);
   impl_->max_ctx = std::max<uint32_t>(std::max<uint32_t>(n, 1), (uint32_t)impl_->all.size());
@@ -443,8 +449,8 @@ void DeviceIndex::upload(const HostIndex& h, int device) {
 
 static void ensure_ws(Ctx& c, uint64_t nq, uint64_t nt, uint64_t seg) {
   c.q_m.ensure(nq); c.q_kept.ensure(nq); c.q_cand.ensure(nq); c.q_acc.ensure(nq); c.q_pb.ensure(nq); c.q_best.ensure(3 * nq);
-  c.q_rank.ensure(nq); c.big_list.ensure(nq); c.mid_list.ensure(nq); c.fin_list.ensure(nq); c.contrast_list.ensure(2 * nq);
-  c.q_hits.ensure(nq + 1); c.q_hits_a.ensure(nq + 1); c.q_seg.ensure(nq + 1); c.q_qseg.ensure(nq + 1); c.q_cap.ensure(nq + 1);
+  c.q_rank.ensure(nq); c.q_scap.ensure(nq); c.big_list.ensure(nq); c.mid_list.ensure(nq); c.fin_list.ensure(nq); c.contrast_list.ensure(2 * nq);
+  c.q_hits.ensure(nq + 1); c.q_hits_a.ensure(nq + 1); c.q_seg.ensure(3 * (nq + 1)); c.q_qseg.ensure(2 * (nq + 1)); c.q_cap.ensure(3 * (nq + 1));
   c.c_in.ensure(3 * (nq + 1)); c.c_off.ensure(3 * (nq + 1));
   c.t_q.ensure(nt); c.t_lo.ensure(nt); c.t_cnt.ensure(nt); c.t_idf.ensure(nt);
   if (seg > c.seg_cap) {
@@ -461,7 +467,7 @@ static void ensure_ws(Ctx& c, uint64_t nq, uint64_t nt, uint64_t seg) {
 static DevWork work_view(Ctx& c) {
   DevWork w{};
   w.q_m = c.q_m.p; w.t_q = c.t_q.p; w.t_lo = c.t_lo.p; w.t_cnt = c.t_cnt.p; w.q_hits = c.q_hits.p; w.q_hits_a = c.q_hits_a.p;
-  w.q_cap = c.q_cap.p; w.q_seg = c.q_seg.p; w.q_qseg = c.q_qseg.p; w.qb_cap = c.qb.cap; w.q_kept = c.q_kept.p; w.q_cand = c.q_cand.p; w.q_acc = c.q_acc.p; w.q_pb = c.q_pb.p;
+  w.q_cap = c.q_cap.p; w.q_seg = c.q_seg.p; w.q_qseg = c.q_qseg.p; w.qb_cap = c.qb.cap; w.q_kept = c.q_kept.p; w.q_cand = c.q_cand.p; w.q_acc = c.q_acc.p; w.q_pb = c.q_pb.p; w.q_scap = c.q_scap.p;
   w.q_best = c.q_best.p; w.q_rank = c.q_rank.p; w.p_hist = c.p_hist_p(); w.cmin_tab = c.cmin_tab.p; w.c_in = c.c_in.p;
   w.c_off = c.c_off.p; w.c_qi = c.c_qi.p; w.t_idf = c.t_idf.p; w.seg = c.seg.p; w.qb = c.qb.p; w.heap = c.heap.p;
   w.seg_cap = c.seg_cap; w.counters = c.counters_p();
@@ -469,7 +475,12 @@ static DevWork work_view(Ctx& c) {
 }
 
 const char* stage_name(int s) {
-  static const char* names[kNumStages] = {"setup", "probe", "scan", "expand_a", "expand_b", "cand", "cand_big", "cand_scan", "dp", "finish"};
+  // 0..10 follow one another on the main stream (their sum is the pass): expand_a = k_expand_a (phase A of the queries that are
+  // not light), expand_l = k_expand_b<true> (the light queries: ranges walked and reduced by one kernel), expand_wait = what the
+  // side stream still has to do then.  On the side stream, beside them: expand_h = k_expand_h, expand_b = second scan +
+  // k_expand_b<false> (the queries that are not light).
+  static const char* names[kNumStages] = {"setup", "probe", "scan", "expand_a", "expand_l", "expand_wait", "cand", "cand_big", "cand_scan", "dp",
+                                          "finish", "expand_h", "expand_b"};
   return (s >= 0 && s < kNumStages) ? names[s] : "";
 }
 
@@ -505,6 +516,8 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
     // zeroed by k_setup)
     HIP_TRY(hipMemsetAsync(c.zero_blk.p, 0, Ctx::zero_words() * sizeof(unsigned long long), stream));
     const uint32_t n_scan = b.nq + 1;  // one extra element so that out[nq] = total
+    w.q_capl = w.q_cap + n_scan;   // second array of the first scan (input / output)
+    w.q_segl = w.q_qseg + n_scan;
     const uint32_t scan_tiles = (n_scan + kScanTile - 1) / kScanTile;
     if (scan_tiles > kLbMaxTiles) throw std::invalid_argument("sub-batch too large for the scan");
     int e = 0;
@@ -538,35 +551,55 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
         hipLaunchKernelGGL(k_probe<false>, dim3((b.nt + 63) / 64), dim3(64), 0, stream, m.d, b, w, heavy_min, c.items_h.p, item_h_cap);
     }
     tick(); tick();
+    // light queries (k_caps): at most light_max hits, all in short ranges, pattern of at most one wave
+    const uint32_t light_max = b.nq ? std::min<uint32_t>(m.light_max, kPhaseBChunk) : 0u;
     {
-      hipLaunchKernelGGL(k_caps, dim3((b.nq + 1 + 255) / 256), dim3(256), 0, stream, b, w, c.items.p, item_cap, c.s_max, c.heavy_div);
-      hipLaunchKernelGGL(k_scan_lb<1>, dim3(scan_tiles), dim3(kScanThreads), 0, stream, w.q_cap, w.q_qseg, (size_t)0, n_scan,
+      hipLaunchKernelGGL(k_caps, dim3((b.nq + 1 + 1023) / 1024), dim3(1024), 0, stream, b, w, c.items.p, item_cap, c.s_max, c.heavy_div, light_max);
+      // one scan, two arrays: queue offsets of the queries phase A walks, segment offsets of the light queries
+      hipLaunchKernelGGL(k_scan_lb<2>, dim3(scan_tiles), dim3(kScanThreads), 0, stream, w.q_cap, w.q_qseg, (size_t)n_scan, n_scan,
                          c.scan_state(0), c.scan_ticket(0));
     }
     tick(); tick();
     {
-      if (!m.serial) HIP_TRY(hipStreamWaitEvent(stream, c.ev_cmin, 0));
-      // the few long ranges stream through the bit planes on the side stream next to the per-hit walk of
-      // everything else: both append to the per-query queues of k_expand_b
-      if (heavy_min != 0xffffffffu) {
-        fork();
-        hipLaunchKernelGGL(k_expand_h, dim3(kHeavyGrid), dim3(kWave), 0, side, m.d, b, w, prm, (const HeavyItem*)c.items_h.p,
-                           item_h_cap);
-      }
-      hipLaunchKernelGGL(k_expand_a, dim3(b.nq + kExpandExtraGrid), dim3(kWave), 0, stream, m.d, b, w, prm,
-                         (const WorkItem*)c.items.p, item_cap, use_sig);
-      if (heavy_min != 0xffffffffu) join();
-      tick(); tick();  // "expand_a" = k_cmin + k_expand_a with k_expand_h beside it; "expand_b" = the token work
-      {
-        // the hits phase A really queued size the segments of everything downstream: second scan, q_cap -> q_seg
-        hipLaunchKernelGGL(k_caps_b, dim3((b.nq + 1 + 255) / 256), dim3(256), 0, stream, b, w, c.items_b.p, item_cap);
-        hipLaunchKernelGGL(k_scan_lb<1>, dim3(scan_tiles), dim3(kScanThreads), 0, stream, w.q_cap, w.q_seg, (size_t)0, n_scan,
-                           c.scan_state(1), c.scan_ticket(1));
-      }
+      // Two lanes from here to the candidate stage:
+      //   main   k_expand_a (phase A of the queries that are not light, next to k_expand_h), then k_expand_b<true>: the light
+      //          queries — ranges walked, filtered and reduced to candidates by one kernel; their segments are known already
+      //   side   k_expand_h (the long ranges, through the bit planes), then — once k_expand_a is done too — the second scan
+      //          (segments of the other queries, sized by the hits phase A really queued) and k_expand_b<false> for them
+      // The light kernel is a per-query instruction stream, k_expand_h an HBM stream: they share the GPU well.
       const size_t lds = (size_t)p_max * 4;
       if (lds > 64 * 1024) throw UnsupportedError("patterns too long for the expand kernel's LDS staging");
-      hipLaunchKernelGGL(k_expand_b, dim3(b.nq + kExpandExtraGrid), dim3(kWave), lds, stream, m.d, b, w, prm,
-                         (const WorkItem*)c.items_b.p, item_cap);
+      if (!m.serial) HIP_TRY(hipStreamWaitEvent(stream, c.ev_cmin, 0));
+      auto side_tick = [&](int stage, int end) { if (timing) HIP_TRY(hipEventRecord(c.ev[2 * stage + end], side)); };
+      fork();
+      side_tick(kStageExpandH, 0);
+      if (heavy_min != 0xffffffffu)
+        hipLaunchKernelGGL(k_expand_h, dim3(m.heavy_grid), dim3(kWave), 0, side, m.d, b, w, prm, (const HeavyItem*)c.items_h.p, item_h_cap);
+      side_tick(kStageExpandH, 1);
+      // phase A of the queries that are not light: block q = query q (light_max == 0) or a work-item list
+      hipLaunchKernelGGL(k_expand_a, dim3((light_max ? 0u : b.nq) + kExpandExtraGrid), dim3(kWave), 0, stream, m.d, b, w, prm,
+                         (const WorkItem*)c.items.p, item_cap, use_sig, light_max ? 0u : b.nq);
+      if (!m.serial) { HIP_TRY(hipEventRecord(c.ev_a, stream)); HIP_TRY(hipStreamWaitEvent(c.side, c.ev_a, 0)); }
+      tick(); tick();
+      side_tick(kStageExpandB, 0);
+      {
+        // the hits phase A really queued size the segments of everything downstream: second scan, q_cap -> q_seg,
+        // placed behind the light queries' segments (k_segbase)
+        // (small workgroups: these kernels start next to the bulk kernel of the main stream, where a 1024-thread workgroup
+        // would wait for sixteen wave slots of one CU to be free at once; the work-item list of k_expand_b<false> is laid
+        // out by the same scan — second array, two strides on — instead of by atomics)
+        hipLaunchKernelGGL(k_caps_b, dim3((b.nq + 1 + 255) / 256), dim3(256), 0, side, b, w, light_max ? 1u : 0u);
+        hipLaunchKernelGGL(k_scan_lb<2>, dim3(scan_tiles), dim3(kScanThreads), 0, side, w.q_cap, w.q_seg, (size_t)2 * n_scan, n_scan,
+                           c.scan_state(1), c.scan_ticket(1));
+        hipLaunchKernelGGL(k_segbase, dim3((b.nq + 1 + 255) / 256), dim3(256), 0, side, b, w, c.items_b.p, item_cap, light_max ? 0u : 1u);
+        hipLaunchKernelGGL(k_expand_b<false>, dim3((light_max ? 0u : b.nq) + kExpandExtraGrid), dim3(kWave), lds, side, m.d, b, w, prm,
+                           (const WorkItem*)c.items_b.p, item_cap, light_max ? 0u : b.nq);
+      }
+      side_tick(kStageExpandB, 1);
+      if (light_max)
+        hipLaunchKernelGGL(k_expand_b<true>, dim3(b.nq), dim3(kWave), lds, stream, m.d, b, w, prm, (const WorkItem*)nullptr, 0u, b.nq);
+      tick(); tick();
+      join();  // stage "expand_wait": what the side lane still has to do when the light kernel is through
     }
     tick(); tick();
     hipLaunchKernelGGL(k_cand, dim3((b.nq + 3) / 4), dim3(256), 0, stream, b, w, c.big_list.p, c.mid_list.p);
@@ -724,7 +757,7 @@ static void add_counters(Stats* st, const unsigned long long* ctr) {
   st->n_hits += ctr[0]; st->n_kept += ctr[1]; st->n_candidates += ctr[2]; st->n_dp += ctr[3];
   st->n_big += ctr[7]; st->n_phase_b += ctr[8]; st->max_kept = std::max<uint64_t>(st->max_kept, ctr[9]);
   st->n_heavy_hits += ctr[16]; st->n_heavy_pass += ctr[17]; st->plane_words += ctr[18];
-  st->probe_bytes += ctr[19]; st->probe_lines += ctr[20];
+  st->probe_bytes += ctr[19]; st->probe_lines += ctr[20]; st->n_light_hits += ctr[22];
 }
 
 constexpr uint32_t kAsyncGroup = 32;  // passes enqueued before the host looks at their counters

@@ -68,7 +68,11 @@ struct DevWork {
   unsigned long long* q_hits_a;  // nq  hits of the ranges k_expand_a walks (sum of t_cnt: the long ranges go to k_expand_h)
   unsigned long long* q_cap;   // nq+1 scan input: first the queue capacity per query (k_caps), then its queued hits (k_caps_b)
   unsigned long long* q_qseg;  // nq+1 queue offsets into qb: exclusive scan of the capacities (an upper bound of what phase A queues)
-  unsigned long long* q_seg;   // nq+1 segment offsets into seg / c_qi / keys ...: exclusive scan of the hits phase A really queued
+  unsigned long long* q_seg;   // nq+1 segment offsets into seg / c_qi / keys ...: light queries first (q_segl), then the exclusive scan of the
+                               //      hits phase A really queued for the others (k_segbase merges the two)
+  unsigned long long* q_capl;  // nq+1 scan input beside q_cap: segment size of a "light" query (its hits; 0 = not light)
+  unsigned long long* q_segl;  // nq+1 its exclusive scan: segment offsets of the light queries (known before phase A runs)
+  uint32_t* q_scap;     // nq   segment capacity per query (k_segbase)
   uint32_t* q_kept;     // nq
   uint32_t* q_cand;     // nq
   uint32_t* q_acc;      // nq
@@ -95,6 +99,7 @@ struct DevWork {
                                  // [15]=work items of k_expand_h [16]=hits walked through the bit planes
                                  // [17]=of those, hits that passed the plane test (re-tested exactly)
                                  // [18]=8-byte plane words read by k_expand_h [19],[20]=bytes / lines requested by k_probe<true>
+                                 // [22]=hits of the light queries (walked by k_expand_b<true>)
 };
 constexpr int kNumCounters = 24;
 
@@ -160,6 +165,7 @@ struct HeavyItem {
 constexpr uint32_t kPlaneRows = kSigBits2;      // bit planes of the 112-bucket signature: rows 0..55 = first half, 56..111 = second half of each bucket
 constexpr uint32_t kPlaneMaxP = 63;             // six-level bit-sliced counters: patterns of up to 63 tokens
 constexpr uint32_t kHeavyMinDefault = 1024;     // ranges at least this long stream through the bit planes
+constexpr uint32_t kLightMaxDefault = 256;      // queries with at most this many hits (all in short ranges) skip phase A: k_expand_b<true>
 constexpr uint32_t kHeavyChunkBlocks = 256;     // blocks of 64 suffixes per k_expand_h work item (16384 hits)
 constexpr uint32_t kHeavyGrid = 8192;
 
@@ -384,25 +390,57 @@ struct WorkItem {
   uint32_t chunk;
 };
 
-__global__ void __launch_bounds__(256) k_caps(DevBatch b, DevWork w, WorkItem* items, uint32_t item_cap, uint32_t s_max,
-                                              uint32_t heavy_div) {
-  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q > b.nq) return;
-  if (q == b.nq) { w.q_cap[q] = 0; return; }
-  const unsigned long long all_hits = w.q_hits[q];  // summed by k_probe
-  const unsigned long long hits = w.q_hits_a[q];    // what k_expand_a walks
-  // Queue / segment capacity of the query: every hit of the short ranges may survive phase A (near-duplicates: most
-  // do), of the long ranges only a few per cent do — a heavy_div-th of them is reserved, and a query that needs more
-  // is reported by k_caps_b (the host re-runs the pass with a smaller divisor, down to 1 = every hit).
-  const unsigned long long want = hits + (all_hits - hits + heavy_div - 1) / heavy_div;
-  w.q_cap[q] = want < s_max ? want : (unsigned long long)s_max;
-  w.q_kept[q] = 0;
-  if (hits > kExpandChunk) {
-    const uint32_t n_extra = (uint32_t)((hits + kExpandChunk - 1) / kExpandChunk) - 1;
-    const unsigned long long base = atomicAdd(&w.counters[5], (unsigned long long)n_extra);
-    for (uint32_t k = 0; k < n_extra; k++)
-      if (base + k < item_cap) { WorkItem it; it.q = q; it.chunk = k + 1; items[base + k] = it; }
+// Appends n_items work items (q, first_chunk .. first_chunk + n_items - 1) of every thread of the block to a list with ONE
+// global atomic per block (same-address atomics retire one at a time: a million per-query atomics on one counter, or even
+// one per wave, would dominate the kernel).  Call with the whole block, blockDim.x a multiple of 64 and at most 1024.
+__device__ __forceinline__ void append_items(unsigned long long* counter, WorkItem* items, uint32_t item_cap, uint32_t q,
+                                             uint32_t first_chunk, uint32_t n_items) {
+  __shared__ uint32_t s_wave[16];
+  __shared__ unsigned long long s_base;
+  const uint32_t lane = lane_id(), wv = threadIdx.x >> 6, n_wv = blockDim.x >> 6;
+  const uint32_t incl = wave_incl_scan(n_items);
+  if (lane == 63) s_wave[wv] = incl;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t tot = 0;
+    for (uint32_t k = 0; k < n_wv; k++) { const uint32_t c = s_wave[k]; s_wave[k] = tot; tot += c; }
+    s_base = tot ? atomicAdd(counter, (unsigned long long)tot) : 0ull;
   }
+  __syncthreads();
+  const unsigned long long base = s_base + s_wave[wv] + (incl - n_items);
+  for (uint32_t k = 0; k < n_items; k++)
+    if (base + k < item_cap) { WorkItem it; it.q = q; it.chunk = first_chunk + k; items[base + k] = it; }
+}
+
+// light_max != 0: queries whose hits all lie in short ranges, at most light_max of them, and whose pattern fits one wave
+// are "light" — k_expand_b<true> walks their ranges itself (no phase A, no queue: two thirds of the hits of a short
+// range pass the signature test anyway, so phase A was a per-query instruction stream for nothing) and their segments
+// (q_capl -> q_segl) are sized by their hits.  Everything else goes through k_expand_a / k_expand_h as a work-item list
+// (chunk 0 included).  light_max == 0: every query is walked by block q of k_expand_a, the list holds chunks >= 1.
+__global__ void __launch_bounds__(1024) k_caps(DevBatch b, DevWork w, WorkItem* items, uint32_t item_cap, uint32_t s_max,
+                                              uint32_t heavy_div, uint32_t light_max) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t n_items = 0;
+  if (q == b.nq) { w.q_cap[q] = 0; w.q_capl[q] = 0; }
+  if (q < b.nq) {
+    const unsigned long long all_hits = w.q_hits[q];  // summed by k_probe
+    const unsigned long long hits = w.q_hits_a[q];    // the hits of the short ranges
+    bool light = false;
+    if (light_max != 0 && hits != 0 && hits == all_hits && hits <= light_max)
+      light = b.q_off[b.q_begin + q + 1] - b.q_off[b.q_begin + q] <= (uint32_t)kWave;
+    // Queue capacity of the query: every hit of the short ranges may survive phase A (near-duplicates: most
+    // do), of the long ranges only a few per cent do — a heavy_div-th of them is reserved, and a query that needs more
+    // is reported by k_caps_b (the host re-runs the pass with a smaller divisor, down to 1 = every hit).
+    const unsigned long long want = light ? 0ull : hits + (all_hits - hits + heavy_div - 1) / heavy_div;
+    w.q_cap[q] = want < s_max ? want : (unsigned long long)s_max;
+    w.q_capl[q] = light ? hits : 0ull;
+    w.q_kept[q] = 0;
+    if (!light && hits != 0) {
+      const uint32_t n_chunks = (uint32_t)((hits + kExpandChunk - 1) / kExpandChunk);
+      n_items = light_max != 0 ? n_chunks : n_chunks - 1;
+    }
+  }
+  append_items(&w.counters[5], items, item_cap, q, light_max != 0 ? 0u : 1u, n_items);
 }
 
 // PatternCoverage::count_covered_words (src/pattern_coverage.cc:15-28) with the pattern broadcast
@@ -593,7 +631,8 @@ struct QHit {
 // it is bound by HBM latency, so what matters is how many waves are resident.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kWave, 8) k_expand_a(DevIndex ix, DevBatch b, DevWork w, Params prm,
-                                                    const WorkItem* items, uint32_t item_cap, int use_sig) {
+                                                    const WorkItem* items, uint32_t item_cap, int use_sig,
+                                                    uint32_t first_q_blocks) {
   __shared__ __attribute__((aligned(8))) uint16_t s_cmin[kCminTab];  // per stored sentence length: minimal cover, 0xffff = rejected, 0 = phase B decides
   __shared__ uint32_t s_npref[kWave + 1];  // exclusive hit prefix of the non-empty start positions
   __shared__ uint32_t s_nlo[kWave];
@@ -603,9 +642,10 @@ __global__ void __launch_bounds__(kWave, 8) k_expand_a(DevIndex ix, DevBatch b, 
   const uint32_t lane = lane_id();
   uint32_t q, chunk;
   uint32_t item_idx = 0;
-  const bool extra = blockIdx.x >= b.nq;
+  // blocks [0, first_q_blocks) walk chunk 0 of query blockIdx.x; the others loop over the work-item list
+  const bool extra = blockIdx.x >= first_q_blocks;
   if (!extra) { q = blockIdx.x; chunk = 0; }
-  else item_idx = blockIdx.x - b.nq;
+  else item_idx = blockIdx.x - first_q_blocks;
   for (;;) {
     if (extra) {
       unsigned long long n_items = w.counters[5];
@@ -834,7 +874,7 @@ __global__ void __launch_bounds__(kWave, 8) k_expand_a(DevIndex ix, DevBatch b, 
       }
     }
     if (!extra) return;
-    item_idx += kExpandExtraGrid;
+    item_idx += gridDim.x - first_q_blocks;
   }
 }
 
@@ -1096,22 +1136,49 @@ __global__ void __launch_bounds__(kWave, 6) k_expand_h(DevIndex ix, DevBatch b, 
 // After phase A: the hits each query really queued become its segment size (scan input; the segments of everything
 // downstream are sized by these, not by the loose bound the queues were sized by), and queries with more than
 // kPhaseBChunk queued hits get extra work items of k_expand_b.
-__global__ void k_caps_b(DevBatch b, DevWork w, WorkItem* items, uint32_t item_cap) {
+__global__ void __launch_bounds__(256) k_caps_b(DevBatch b, DevWork w, uint32_t list0) {
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q > b.nq) return;
-  if (q == b.nq) { w.q_cap[q] = 0; return; }
-  w.q_cap[q] = 0;
-  const uint32_t cap = (uint32_t)(w.q_qseg[q + 1] - w.q_qseg[q]);
-  if (w.q_qseg[q + 1] > w.qb_cap) { if (q + 1 == b.nq) atomicMax(&w.counters[21], w.q_qseg[b.nq]); return; }  // host re-runs the pass with a larger queue space
-  const uint32_t n = w.q_pb[q];
-  if (n > cap) { atomicMax(&w.counters[4], (unsigned long long)n); return; }  // queue overflow: retry with a larger capacity
-  w.q_cap[q] = n;
-  if (n > kPhaseBChunk) {
-    const uint32_t n_extra = (n + kPhaseBChunk - 1) / kPhaseBChunk - 1;
-    const unsigned long long base = atomicAdd(&w.counters[12], (unsigned long long)n_extra);
-    for (uint32_t k = 0; k < n_extra; k++)
-      if (base + k < item_cap) { WorkItem it; it.q = q; it.chunk = k + 1; items[base + k] = it; }
+  unsigned long long* n_items = w.q_cap + 2 * (size_t)(b.nq + 1);  // scanned with q_cap: work items of k_expand_b<false> per query
+  unsigned long long segsz = 0, ni = 0;
+  if (q < b.nq) {
+    if (w.q_capl[q] != 0) {
+      // light query: its segment lies in the light area (q_segl), k_expand_b<true> walks it
+    } else if (w.q_qseg[q + 1] > w.qb_cap) {
+      if (q + 1 == b.nq) atomicMax(&w.counters[21], w.q_qseg[b.nq]);  // host re-runs the pass with a larger queue space
+    } else {
+      const uint32_t cap = (uint32_t)(w.q_qseg[q + 1] - w.q_qseg[q]);
+      const uint32_t n = w.q_pb[q];
+      if (n > cap) atomicMax(&w.counters[4], (unsigned long long)n);  // queue overflow: retry with a larger capacity
+      else {
+        segsz = n;
+        if (n != 0) {
+          const uint32_t n_chunks = (n + kPhaseBChunk - 1) / kPhaseBChunk;
+          ni = list0 ? n_chunks : n_chunks - 1;
+        }
+      }
+    }
   }
+  w.q_cap[q] = segsz;
+  n_items[q] = ni;
+}
+
+// Segment base and capacity per query once both scans are known: the light queries' segments come first (q_segl, sized
+// by their hits before phase A ran), the others follow in the order of the second scan (sized by the hits phase A
+// really queued).  In place on q_seg (each thread owns its element); q_seg[nq] = the segment space the pass needs.
+// Also lays out the work-item list of k_expand_b<false> (offsets from the same scan: no atomics, deterministic order).
+__global__ void __launch_bounds__(256) k_segbase(DevBatch b, DevWork w, WorkItem* items, uint32_t item_cap, uint32_t first_chunk) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q > b.nq) return;
+  const unsigned long long totl = w.q_segl[b.nq];
+  const unsigned long long* item_off = w.q_seg + 2 * (size_t)(b.nq + 1);
+  if (q == b.nq) { w.q_seg[q] += totl; w.counters[12] = item_off[q]; return; }
+  const unsigned long long l0 = w.q_segl[q], l1 = w.q_segl[q + 1];
+  const bool light = l1 > l0;
+  w.q_scap[q] = light ? (uint32_t)(l1 - l0) : (uint32_t)w.q_cap[q];
+  w.q_seg[q] = light ? l0 : totl + w.q_seg[q];
+  const unsigned long long i0 = item_off[q], i1 = item_off[q + 1];
+  for (unsigned long long k = i0; k < i1 && k < item_cap; k++) { WorkItem it; it.q = q; it.chunk = first_chunk + (uint32_t)(k - i0); items[k] = it; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1120,19 +1187,30 @@ __global__ void k_caps_b(DevBatch b, DevWork w, WorkItem* items, uint32_t item_c
 // length, exact coverage test through a per-item hash set of the pattern's words, then ballot/prefix
 // append of the survivors to the query's segment.  Dynamic LDS: pat[p_max].
 // ---------------------------------------------------------------------------------------------
+// LIGHT: the query's hits are not read from a queue but generated from its (short) suffix ranges — block q walks light
+// query q (k_caps); the length filter of phase A (the tabulated threshold of the sentence length) is applied here, the
+// signature bound is skipped (the exact coverage test decides).  !LIGHT: blocks [0, first_q_blocks) take chunk 0 of
+// query blockIdx.x, the others loop over the work-item list.
+template <bool LIGHT>
 __global__ void __launch_bounds__(kWave, 8) k_expand_b(DevIndex ix, DevBatch b, DevWork w, Params prm,
-                                                       const WorkItem* items, uint32_t item_cap) {
+                                                       const WorkItem* items, uint32_t item_cap, uint32_t first_q_blocks) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t* s_pat = (uint32_t*)smem;
   __shared__ PatHash ph;
   __shared__ SurvB s_surv[kWave * (kBUnroll + 1)];
   __shared__ unsigned long long s_out[kWave];  // survivors (sentence id << 16 | match length) while they fit one wave
+  // LIGHT: the non-empty start positions (exclusive hit prefix, range start, start position) and this pattern length's row
+  // of the phase-A threshold table
+  __shared__ uint32_t s_npref[LIGHT ? kWave : 1];
+  __shared__ uint32_t s_nlo[LIGHT ? kWave : 1];
+  __shared__ uint32_t s_nit[LIGHT ? kWave : 1];
+  __shared__ __attribute__((aligned(8))) uint16_t s_cmin[LIGHT ? kCminTab : 4];
   const uint32_t lane = lane_id();
   uint32_t q, chunk;
   uint32_t item_idx = 0;
-  const bool extra = blockIdx.x >= b.nq;
+  const bool extra = !LIGHT && blockIdx.x >= first_q_blocks;
   if (!extra) { q = blockIdx.x; chunk = 0; }
-  else item_idx = blockIdx.x - b.nq;
+  else item_idx = blockIdx.x - first_q_blocks;
   for (;;) {
     if (extra) {
       unsigned long long n_items = w.counters[12];
@@ -1144,16 +1222,15 @@ __global__ void __launch_bounds__(kWave, 8) k_expand_b(DevIndex ix, DevBatch b, 
     }
     // The kernel is a chain of dependent memory latencies per query (most queries queue a few dozen hits),
     // so everything that can be requested together is: level 1 = all per-query scalars.
-    const unsigned long long seg0 = uni(w.q_seg[q]);
-    const unsigned long long seg1 = uni(w.q_seg[q + 1]);
-    const unsigned long long qseg0 = uni(w.q_qseg[q]);
-    const uint32_t n_q = uni(w.q_pb[q]);
+    const unsigned long long seg0 = uni(LIGHT ? w.q_segl[q] : w.q_seg[q]);
+    const unsigned long long qseg0 = LIGHT ? 0ull : uni(w.q_qseg[q]);
+    const uint32_t cap = LIGHT ? (uint32_t)(uni(w.q_segl[q + 1]) - seg0) : uni(w.q_scap[q]);
+    const uint32_t n_q = LIGHT ? cap : uni(w.q_pb[q]);  // LIGHT: every hit of the query's ranges
     const uint32_t msl = uni(w.q_m[q]);
     const uint32_t o0 = uni(b.q_off[b.q_begin + q]);
     const uint32_t p = uni(b.q_off[b.q_begin + q + 1]) - o0;
-    const uint32_t cap = (uint32_t)(seg1 - seg0);
-    if (seg1 > w.seg_cap) {  // segments too small (cap == n_q unless the queue overflowed): host re-runs the pass
-      if (lane == 0 && n_q != 0) atomicMax(&w.counters[6], w.q_seg[b.nq]);
+    if (n_q != 0 && seg0 + cap > w.seg_cap) {  // segments too small: host re-runs the pass
+      if (lane == 0) atomicMax(&w.counters[6], LIGHT ? w.q_segl[b.nq] : w.q_seg[b.nq]);
     } else if (n_q != 0 && n_q <= cap) {
       const uint32_t m = seed_len(p, msl);
       const uint32_t* pat = b.q_tok + o0;
@@ -1167,13 +1244,42 @@ __global__ void __launch_bounds__(kWave, 8) k_expand_b(DevIndex ix, DevBatch b, 
       QHit hq[kBUnroll];
       SufRecB rb[kBUnroll];
       bool v[kBUnroll];
+      if constexpr (LIGHT) {
+        // the query's non-empty start positions, compacted: hit e belongs to the last one whose prefix is <= e
+        const uint32_t t0 = o0 - b.t_begin;
+        const uint32_t mycnt = lane < p ? w.t_cnt[t0 + lane] : 0u;  // p <= 64
+        const uint32_t mylo = lane < p ? w.t_lo[t0 + lane] : 0u;
+        reinterpret_cast<unsigned long long*>(s_cmin)[lane] =
+            reinterpret_cast<const unsigned long long*>(w.cmin_tab + (size_t)p * kCminRow)[lane];
+        const uint32_t incl = wave_incl_scan(mycnt);
+        const unsigned long long nz = __ballot(mycnt != 0);
+        if (mycnt != 0) {
+          const uint32_t k = __popcll(nz & ((1ull << lane) - 1ull));
+          s_npref[k] = incl - mycnt;
+          s_nlo[k] = mylo;
+          s_nit[k] = lane;
+        }
+        if (lane >= (uint32_t)__popcll(nz)) s_npref[lane] = 0xffffffffu;  // sentinels: the search below needs no bound test
+        wave_lds_sync();
+      }
       auto load_hits = [&](uint32_t e0) {
 #pragma unroll
         for (int u = 0; u < kBUnroll; u++) {
           const uint32_t e = e0 + u * kWave + lane;
           v[u] = e < e_hi;
           hq[u].i = 0; hq[u].it_need = 0;
-          if (v[u]) hq[u] = qb[e];
+          if constexpr (LIGHT) {
+            if (v[u]) {
+              uint32_t k = 0;
+#pragma unroll
+              for (uint32_t step = kWave / 2; step >= 1; step >>= 1)
+                if (s_npref[k + step] <= e) k += step;  // k + step <= 63; entries past the last start hold the sentinel
+              hq[u].i = s_nlo[k] + (e - s_npref[k]);
+              hq[u].it_need = s_nit[k] << 16;
+            }
+          } else {
+            if (v[u]) hq[u] = qb[e];
+          }
         }
       };
       auto load_recs = [&]() {
@@ -1325,12 +1431,19 @@ __global__ void __launch_bounds__(kWave, 8) k_expand_b(DevIndex ix, DevBatch b, 
         for (int u = 0; u < kBUnroll; u++) {
           const uint32_t it = hq[u].it_need >> 16;
           const bool dominated = it > 0 && rb[u].rem < rb[u].slen && rb[u].prev == s_pat[it ? it - 1 : 0];
-          const bool keep = v[u] && !dominated;
+          bool keep = v[u] && !dominated;
+          uint32_t it_need = hq[u].it_need;
+          if constexpr (LIGHT) {
+            // phase A's length filter: the tabulated threshold of the (clamped) sentence length, 0xffff = rejected
+            const uint32_t cmin = s_cmin[rb[u].slen < kSigLenClamp ? rb[u].slen : kSigLenClamp];
+            keep = keep && cmin != 0xffffu;
+            it_need |= cmin;
+          }
           const unsigned long long mask = __ballot(keep);
           if (keep) {
             SurvB sv;
             sv.off = rb[u].off; sv.rem_slen = (uint32_t)rb[u].rem | ((uint32_t)rb[u].slen << 16);
-            sv.sid = rb[u].sid; sv.it_need = hq[u].it_need;
+            sv.sid = rb[u].sid; sv.it_need = it_need;
             s_surv[n_s + __popcll(mask & ((1ull << lane) - 1ull))] = sv;
           }
           n_s += __popcll(mask);
@@ -1385,9 +1498,10 @@ __global__ void __launch_bounds__(kWave, 8) k_expand_b(DevIndex ix, DevBatch b, 
       } else if (sole && lane == 0) {
         w.q_kept[q] = n_out;
       }
+      if (LIGHT && lane == 0) w.q_pb[q] = n_q;  // statistics: the hits this kernel took over from phase A
     }
     if (!extra) return;
-    item_idx += kExpandExtraGrid;
+    item_idx += gridDim.x - first_q_blocks;
   }
 }
 
@@ -1566,7 +1680,7 @@ __global__ void __launch_bounds__(256) k_cand(DevBatch b, DevWork w, uint32_t* b
     if (lane == 0) w.q_cand[q] = 0;
     return;
   }
-  if ((unsigned long long)n > w.q_seg[q + 1] - w.q_seg[q]) {  // more survivors than the segment holds
+  if (n > w.q_scap[q]) {  // more survivors than the segment holds
     if (lane == 0) { w.q_cand[q] = 0; atomicMax(&w.counters[4], (unsigned long long)n); }
     return;
   }
@@ -2654,22 +2768,23 @@ __global__ void __launch_bounds__(kWave) k_cround(DevIndex ix, DevBatch b, DevWo
 // per-call statistics from the per-query arrays (kept out of the hot kernels: one shared atomic
 // per query costs more than the kernels' real work)
 __global__ void __launch_bounds__(1024) k_stats(DevWork w, uint32_t nq) {
-  __shared__ unsigned long long s_v[6];
-  if (threadIdx.x < 6) s_v[threadIdx.x] = 0;
+  __shared__ unsigned long long s_v[7];  // [0..4], [6] sums; [5] maximum
+  if (threadIdx.x < 7) s_v[threadIdx.x] = 0;
   __syncthreads();
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-  unsigned long long v[5] = {0, 0, 0, 0, 0};
+  unsigned long long v[6] = {0, 0, 0, 0, 0, 0};
   unsigned long long mx = 0;
   if (q < nq) {
     v[0] = w.q_m[q] == kNoMatchLen ? 0ull : w.q_hits[q];
     v[1] = w.q_kept[q] & ~kKeptReduced; v[2] = w.q_cand[q]; v[3] = w.q_cand[q]; v[4] = w.q_pb[q];
+    v[5] = w.q_capl[q];  // hits of the light queries (walked by k_expand_b<true>, not by phase A)
     mx = w.q_kept[q] & ~kKeptReduced;
   }
 #pragma unroll
-  for (int k = 0; k < 5; k++) {
+  for (int k = 0; k < 6; k++) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v[k] += __shfl_xor(v[k], d, 64);
-    if ((threadIdx.x & 63) == 0 && v[k]) atomicAdd(&s_v[k], v[k]);
+    if ((threadIdx.x & 63) == 0 && v[k]) atomicAdd(&s_v[k < 5 ? k : 6], v[k]);
   }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) { const unsigned long long o = __shfl_xor(mx, d, 64); mx = o > mx ? o : mx; }
@@ -2678,6 +2793,7 @@ __global__ void __launch_bounds__(1024) k_stats(DevWork w, uint32_t nq) {
   const int slot[5] = {0, 1, 2, 3, 8};
   if (threadIdx.x < 5 && s_v[threadIdx.x]) atomicAdd(&w.counters[slot[threadIdx.x]], s_v[threadIdx.x]);
   if (threadIdx.x == 5 && s_v[5]) atomicMax(&w.counters[9], s_v[5]);
+  if (threadIdx.x == 6 && s_v[6]) atomicAdd(&w.counters[22], s_v[6]);
 }
 
 }  // namespace fmx
