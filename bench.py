@@ -160,7 +160,7 @@ def main():
     ix.finalize()
     ix.to_device(local_rank)
     ix.set_option("contexts", max(2, args.threads))
-    for opt in ("FMX_SUB_QUERIES", "FMX_HOST_SUB_QUERIES", "FMX_HEAVY_MIN", "FMX_SERIAL", "FMX_LIGHT_MAX", "FMX_HEAVY_GRID"):
+    for opt in ("FMX_SUB_QUERIES", "FMX_HOST_SUB_QUERIES", "FMX_HEAVY_MIN", "FMX_SERIAL", "FMX_LIGHT_MAX", "FMX_HEAVY_GRID", "FMX_EXPAND_ORDER", "FMX_B_GRID"):
         if os.environ.get(opt):
             ix.set_option(opt[4:].lower(), int(os.environ[opt]))
     info = ix.info()
@@ -303,19 +303,25 @@ def main():
     ix.set_option("probe_count", 0)
     torch.cuda.synchronize()
 
+    # stage "expand_a" = k_expand_a and k_expand_h side by side (main stream: until both are done); "expand_l" = the second
+    # scan + k_expand_b<true> with k_expand_b<false> beside it, "expand_wait" = what is left of the latter afterwards
     probe_ms, exa_ms = per_stage.get("probe", 0.0), per_stage.get("expand_a", 0.0)
     # byte models of THIS algorithm, per launch, from the kernels' own counters:
     #   k_probe     bytes its loads request (n-gram, qva pair, 16 B table entries, 32 B keys per bisection level, ...)
-    #   expand_a    k_expand_a: 8 B per hit it walks; k_expand_h: 8 B per plane word + 8 B per hit re-tested exactly;
-    #               both: 8 B per hit queued for k_expand_b, 8 B per (query, start) range descriptor
+    #   expand_a    k_expand_a: 8 B per hit it walks (short ranges of the queries that are not light); k_expand_h: 8 B per
+    #               plane word + 8 B per hit re-tested exactly; both: 8 B per hit queued for k_expand_b<false>; 8 B per
+    #               (query, start) range descriptor of the queries they visit (upper bound: all)
     b_probe = float(cst.probe_bytes)
-    light_hits = last.n_hits - last.n_heavy_hits
-    b_exa = 8.0 * light_hits + 8.0 * last.plane_words + 8.0 * last.n_heavy_pass + 8.0 * last.n_phase_b + 8.0 * main_wl.total_tokens
-    #   expand_b    8 B queue entry + 16 B record per queued hit, the pattern once per query, and for every hit it keeps the
-    #               sentence's tokens (mean length of the corpus) and a 16 B segment entry; the tokens of hits that fail the
-    #               dominance / coverage tests are not counted (a lower bound of what the kernel has to read)
-    exb_ms = per_stage.get("expand_b", 0.0)
-    b_exb = 24.0 * last.n_phase_b + 4.0 * main_wl.total_tokens + last.n_kept * (4.0 * (mean_len + 1) + 16.0)
+    walked_a = last.n_hits - last.n_heavy_hits - last.n_light_hits
+    queued = last.n_phase_b - last.n_light_hits
+    b_exa = 8.0 * walked_a + 8.0 * last.plane_words + 8.0 * last.n_heavy_pass + 8.0 * queued + 8.0 * main_wl.total_tokens
+    #   expand_b    k_expand_b<true> (light queries): 8 B range descriptor per start position + 16 B record per hit;
+    #               k_expand_b<false>: 8 B queue entry + 16 B record per queued hit; both: the pattern once per query, and for
+    #               every hit kept the sentence's tokens (mean length of the corpus) and a 16 B segment entry; the tokens of
+    #               hits that fail the dominance / coverage tests are not counted (a lower bound of what the kernels read)
+    exb_ms = per_stage.get("expand_l", 0.0) + per_stage.get("expand_wait", 0.0)
+    b_exb = (16.0 * last.n_light_hits + 24.0 * queued + 12.0 * main_wl.total_tokens
+             + last.n_kept * (4.0 * (mean_len + 1) + 16.0))
     probe_gbs = b_probe / (probe_ms * 1e-3) / 1e9 if probe_ms > 0 else 0.0
     exa_gbs = b_exa / (exa_ms * 1e-3) / 1e9 if exa_ms > 0 else 0.0
     rank_rates = None
@@ -330,6 +336,8 @@ def main():
     if rank == 0:
         log(f"[bench] PCIe-inclusive: {value / 1e6:.2f} M patterns/s, {elapsed / args.steps * 1e3:.3f} ms/step "
             f"(pinned={host_stats[-1].pinned}); device-resident: {main_wl.nq * args.steps / el_dev / 1e6:.2f} M patterns/s")
+        log(f"[bench] host-path calls: retries {sum(int(s.n_retries) for s in host_stats)}, ms per call min/median/max "
+            f"{min(s.ms_total for s in host_stats):.2f}/{float(np.median([s.ms_total for s in host_stats])):.2f}/{max(s.ms_total for s in host_stats):.2f}")
         log(f"[bench] kernel ms/step by stage: { {k: round(v, 3) for k, v in per_stage.items()} }")
         log(f"[bench] last step: hits {last.n_hits} (bit planes {last.n_heavy_hits}, passed {last.n_heavy_pass}) phaseB {last.n_phase_b} "
             f"(light queries {last.n_light_hits}) kept {last.n_kept} candidates {last.n_candidates} retries {last.n_retries} big {last.n_big} max_kept {last.max_kept}")
@@ -350,11 +358,11 @@ def main():
             if fetch and write:
                 for kern, pattern in (("fmx::k_probe", "random"), ("fmx::k_expand_a", "stream16"), ("fmx::k_expand_h", "stream8"),
                                       ("fmx::k_expand_b", "random")):
-                    key = next((k for k in fetch if k.replace("void ", "").startswith(kern)), None)
-                    if key is None:
+                    keys = [k for k in fetch if k.replace("void ", "").startswith(kern)]  # template instantiations add up
+                    if not keys:
                         continue
-                    f_kb = np.mean([v for _, v in fetch[key][-2:]])   # the child's two timed dispatches
-                    w_kb = np.mean([v for _, v in write.get(key, [(0, 0.0)])[-2:]])
+                    f_kb = sum(np.mean([v for _, v in fetch[k][-2:]]) for k in keys)   # the child's two timed dispatches
+                    w_kb = sum(np.mean([v for _, v in write.get(k, [(0, 0.0)])[-2:]]) for k in keys)
                     f_fac = float(cal.get("fetch_factor", {}).get(pattern, 2.0))
                     w_fac = float(cal.get("write_factor", 1.0))
                     traffic[kern.split("::")[1]] = {"bytes": int(f_kb * 1024 * f_fac + w_kb * 1024 * w_fac), "fetch_kb_raw": float(f_kb),
@@ -374,14 +382,16 @@ def main():
         r_probe = roof("k_probe", b_probe, probe_ms, ["k_probe"],
                        "bytes requested by the kernel's own loads, counted by k_probe<COUNT> on the same batch: seed n-gram, "
                        "_quickVocabAccess pair, 16 B trigram / 5-gram entries, two 32 B keys per bisection level")
-        r_exa = roof("k_expand_a+k_expand_h", b_exa, exa_ms, ["k_expand_a", "k_expand_h"],
-                     "phase A of the hit walk (two kernels side by side): 8 B per hit walked one by one, 8 B per bit-plane word, "
-                     "8 B per plane survivor re-tested, 8 B per hit queued, 8 B per range descriptor (kernel counters)")
+        r_exa = roof("k_expand_h+k_expand_a", b_exa, exa_ms, ["k_expand_a", "k_expand_h"],
+                     "phase A of the queries with long ranges or many hits (two kernels side by side): 8 B per bit-plane word, "
+                     "8 B per plane survivor re-tested, 8 B per hit walked one by one, 8 B per hit queued, 8 B per range "
+                     "descriptor (kernel counters)")
         r_probe["lines_bytes_per_launch"] = int(cst.probe_lines) * 128  # distinct 128 B lines x 128: what random reads cost the memory system
-        r_exb = roof("k_expand_b", b_exb, exb_ms, ["k_expand_b"],
-                     "phase B: 8 B queue entry + 16 B record per queued hit, 4 B per pattern token, and per kept hit its sentence "
-                     "(4 B x (mean length + 1)) and a 16 B segment entry; reads for hits that fail the dominance / exact "
-                     "coverage tests are not counted (lower bound)")
+        r_exb = roof("k_expand_b<true>+k_expand_b<false>", b_exb, exb_ms, ["k_expand_b"],
+                     "hit walk of the light queries + phase B of the others (side by side): 8 B range descriptor per start, 16 B "
+                     "record per light hit, 8 B queue entry + 16 B record per queued hit, 4 B per pattern token, and per kept "
+                     "hit its sentence (4 B x (mean length + 1)) and a 16 B segment entry; reads for hits that fail the "
+                     "dominance / exact coverage tests are not counted (lower bound)")
         roofs = sorted([r_probe, r_exa, r_exb], key=lambda r: -r["kernel_ms"])
         dominant, others = roofs[0], roofs[1:]
 

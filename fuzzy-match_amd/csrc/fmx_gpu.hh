@@ -72,6 +72,8 @@ class DeviceIndex {
   void     set_heavy_min(uint32_t n);   // ranges at least this long use the bit-plane kernel (0 = never)
   void     set_probe_count(bool on);    // measurement: k_probe also counts the bytes / 128-byte lines it requests
   void     set_serial(bool on);         // measurement: no side stream, every kernel alone on the GPU
+  void     set_expand_order(uint32_t n);
+  void     set_b_grid(uint32_t n);
   void     set_heavy_grid(uint32_t n);  // workgroups of the bit-plane kernel
   void     set_light_max(uint32_t n);   // queries with at most n hits, all in short ranges, skip phase A (0 = none do)
   void     set_contexts(uint32_t n);    // concurrent calls served at once (each owns a workspace)

@@ -15,6 +15,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <memory>
@@ -187,12 +188,16 @@ struct DeviceIndex::Impl {
   std::shared_mutex itok_mu;  // matching calls hold it shared; a grown penalty-string table swaps under exclusive
   // options
   uint32_t sub_queries = 1u << 20;       // queries per pipeline pass: large passes amortise the ~40 launches and their tails
-  uint32_t host_sub_queries = 1u << 19;  // pass size of the host-buffer entry point: copies overlap the neighbouring passes
+  uint32_t host_sub_queries = 1u << 20;  // pass size of the host-buffer entry point (see match_host)
+  // what passes needed so far, per 1024 queries, shared by all contexts: a context sizes its workspace for a full pass of the
+  // call at hand up front (a pass that does not fit is re-run after a reallocation that stalls every call in flight)
+  std::atomic<uint64_t> hint_seg_kq{0}, hint_qb_kq{0};
   uint64_t init_seg = 1ull << 24;
   uint32_t heavy_min = kHeavyMinDefault; // suffix ranges at least this long go through the bit-plane kernel (0 = never)
   uint32_t max_ctx = 3;
   bool     probe_count = false;
   bool     serial = false;        // measurement runs: no side stream, every kernel alone on the GPU
+  uint32_t expand_order = 1, b_grid = kExpandExtraGrid;
   uint32_t heavy_grid = kHeavyGrid;      // workgroups of k_expand_h (it runs beside the light queries' kernel: it must not fill every wave slot)
   uint32_t light_max = kLightMaxDefault;  // queries with at most this many hits, all in short ranges, skip phase A (0 = off)
   // context pool
@@ -254,6 +259,8 @@ void     DeviceIndex::set_initial_segment(uint64_t n) { impl_->init_seg = std::m
 void     DeviceIndex::set_heavy_min(uint32_t n) { impl_->heavy_min = n; }
 void     DeviceIndex::set_probe_count(bool on) { impl_->probe_count = on; }
 void     DeviceIndex::set_serial(bool on) { impl_->serial = on; }
+void     DeviceIndex::set_expand_order(uint32_t n) { impl_->expand_order = n; }
+void     DeviceIndex::set_b_grid(uint32_t n) { impl_->b_grid = std::min<uint32_t>(std::max<uint32_t>(n, 64u), 65536u); }
 void     DeviceIndex::set_heavy_grid(uint32_t n) { impl_->heavy_grid = std::min<uint32_t>(std::max<uint32_t>(n, 64u), 65536u); }
 void     DeviceIndex::set_light_max(uint32_t n) { impl_->light_max = std::min<uint32_t>(n, kPhaseBChunk); }
 void     DeviceIndex::set_contexts(uint32_t n) {
@@ -459,7 +466,7 @@ static void ensure_ws(Ctx& c, uint64_t nq, uint64_t nt, uint64_t seg) {
     c.keys.ensure(2 * s); c.vals.ensure(2 * s);
     c.seg_cap = s;
   }
-  c.heap.ensure(c.seg_cap + nq + 1);
+  c.heap.ensure(2 * c.seg_cap + 2);
   c.qb.ensure(c.want_qb);
   if (!c.items.p) { c.items.ensure(1u << 22); c.items_b.ensure(1u << 22); c.items_h.ensure(1u << 20); }
 }
@@ -571,6 +578,15 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
       if (lds > 64 * 1024) throw UnsupportedError("patterns too long for the expand kernel's LDS staging");
       if (!m.serial) HIP_TRY(hipStreamWaitEvent(stream, c.ev_cmin, 0));
       auto side_tick = [&](int stage, int end) { if (timing) HIP_TRY(hipEventRecord(c.ev[2 * stage + end], side)); };
+      auto second_scan = [&](hipStream_t st) {
+        // the hits phase A really queued size the segments of everything downstream: second scan, q_cap -> q_seg, placed
+        // behind the light queries' segments (k_segbase); the work-item list of k_expand_b<false> is laid out by the same
+        // scan — second array, two strides on — instead of by atomics
+        hipLaunchKernelGGL(k_caps_b, dim3((b.nq + 1 + 255) / 256), dim3(256), 0, st, b, w, light_max ? 1u : 0u);
+        hipLaunchKernelGGL(k_scan_lb<2>, dim3(scan_tiles), dim3(kScanThreads), 0, st, w.q_cap, w.q_seg, (size_t)2 * n_scan, n_scan,
+                           c.scan_state(1), c.scan_ticket(1));
+        hipLaunchKernelGGL(k_segbase, dim3((b.nq + 1 + 255) / 256), dim3(256), 0, st, b, w, c.items_b.p, item_cap, light_max ? 0u : 1u);
+      };
       fork();
       side_tick(kStageExpandH, 0);
       if (heavy_min != 0xffffffffu)
@@ -579,26 +595,35 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
       // phase A of the queries that are not light: block q = query q (light_max == 0) or a work-item list
       hipLaunchKernelGGL(k_expand_a, dim3((light_max ? 0u : b.nq) + kExpandExtraGrid), dim3(kWave), 0, stream, m.d, b, w, prm,
                          (const WorkItem*)c.items.p, item_cap, use_sig, light_max ? 0u : b.nq);
-      if (!m.serial) { HIP_TRY(hipEventRecord(c.ev_a, stream)); HIP_TRY(hipStreamWaitEvent(c.side, c.ev_a, 0)); }
-      tick(); tick();
-      side_tick(kStageExpandB, 0);
-      {
-        // the hits phase A really queued size the segments of everything downstream: second scan, q_cap -> q_seg,
-        // placed behind the light queries' segments (k_segbase)
-        // (small workgroups: these kernels start next to the bulk kernel of the main stream, where a 1024-thread workgroup
-        // would wait for sixteen wave slots of one CU to be free at once; the work-item list of k_expand_b<false> is laid
-        // out by the same scan — second array, two strides on — instead of by atomics)
-        hipLaunchKernelGGL(k_caps_b, dim3((b.nq + 1 + 255) / 256), dim3(256), 0, side, b, w, light_max ? 1u : 0u);
-        hipLaunchKernelGGL(k_scan_lb<2>, dim3(scan_tiles), dim3(kScanThreads), 0, side, w.q_cap, w.q_seg, (size_t)2 * n_scan, n_scan,
-                           c.scan_state(1), c.scan_ticket(1));
-        hipLaunchKernelGGL(k_segbase, dim3((b.nq + 1 + 255) / 256), dim3(256), 0, side, b, w, c.items_b.p, item_cap, light_max ? 0u : 1u);
-        hipLaunchKernelGGL(k_expand_b<false>, dim3((light_max ? 0u : b.nq) + kExpandExtraGrid), dim3(kWave), lds, side, m.d, b, w, prm,
+      if (m.expand_order == 0) {
+        if (!m.serial) { HIP_TRY(hipEventRecord(c.ev_a, stream)); HIP_TRY(hipStreamWaitEvent(c.side, c.ev_a, 0)); }
+        tick(); tick();
+        side_tick(kStageExpandB, 0);
+        second_scan(side);
+        hipLaunchKernelGGL(k_expand_b<false>, dim3((light_max ? 0u : b.nq) + m.b_grid), dim3(kWave), lds, side, m.d, b, w, prm,
                            (const WorkItem*)c.items_b.p, item_cap, light_max ? 0u : b.nq);
+        side_tick(kStageExpandB, 1);
+        if (light_max)
+          hipLaunchKernelGGL(k_expand_b<true>, dim3(b.nq), dim3(kWave), lds, stream, m.d, b, w, prm, (const WorkItem*)nullptr, 0u, b.nq);
+        tick(); tick();
+      } else {
+        // long ranges first (k_expand_h next to k_expand_a), then the two k_expand_b side by side: the one for the queries
+        // that are not light is a chain of memory latencies on a small grid and must reach the GPU FIRST — workgroups of
+        // the oldest kernel are placed first, and the light kernel's million workgroups would starve anything younger
+        join();
+        tick(); tick();
+        second_scan(stream);
+        fork();
+        side_tick(kStageExpandB, 0);
+        hipLaunchKernelGGL(k_expand_b<false>, dim3((light_max ? 0u : b.nq) + m.b_grid), dim3(kWave), lds, side, m.d, b, w, prm,
+                           (const WorkItem*)c.items_b.p, item_cap, light_max ? 0u : b.nq);
+        side_tick(kStageExpandB, 1);
+        if (light_max) {
+          if (!m.serial) hipLaunchKernelGGL(k_lag, dim3(1), dim3(kWave), 0, stream, w.counters);
+          hipLaunchKernelGGL(k_expand_b<true>, dim3(b.nq), dim3(kWave), lds, stream, m.d, b, w, prm, (const WorkItem*)nullptr, 0u, b.nq);
+        }
+        tick(); tick();
       }
-      side_tick(kStageExpandB, 1);
-      if (light_max)
-        hipLaunchKernelGGL(k_expand_b<true>, dim3(b.nq), dim3(kWave), lds, stream, m.d, b, w, prm, (const WorkItem*)nullptr, 0u, b.nq);
-      tick(); tick();
       join();  // stage "expand_wait": what the side lane still has to do when the light kernel is through
     }
     tick(); tick();
@@ -724,6 +749,13 @@ static PassLimits limits_of(const Ctx& c) {
 
 // what the counters of a finished pass ask for: true = re-run it (something was too small for it under the limits `ran`
 // it was enqueued with; the context's limits are raised, never lowered)
+static void learn_sizes(DeviceIndex::Impl& m, const unsigned long long* ctr, uint64_t nq_pass) {
+  auto raise = [](std::atomic<uint64_t>& a, uint64_t v) { uint64_t cur = a.load(); while (v > cur && !a.compare_exchange_weak(cur, v)) {} };
+  if (!nq_pass) return;
+  raise(m.hint_seg_kq, (std::max(ctr[24], ctr[6]) * 1024 + nq_pass - 1) / nq_pass);
+  raise(m.hint_qb_kq, (std::max(ctr[25], ctr[21]) * 1024 + nq_pass - 1) / nq_pass);
+}
+
 static bool pass_needs_retry(Ctx& c, const unsigned long long* ctr, const PassLimits& ran, uint64_t& want_seg) {
   bool retry = false;
   if (ctr[6] > ran.seg_cap) { want_seg = std::max<uint64_t>(want_seg, ctr[6] + ctr[6] / 4); retry = true; }   // segments did not fit
@@ -789,8 +821,14 @@ static void run_passes(DeviceIndex::Impl& m, Ctx& c, const Params& prm_in, const
     uint32_t p_max = (uint32_t)std::min<uint64_t>(E.prm.max_tokens, std::max<uint32_t>(b.nt, 1));
     return std::max<uint32_t>(1, std::min<uint32_t>(p_max, bv.p_max ? bv.p_max : p_max));
   };
+  // the largest pass this call could be cut into (the cut depends on what else is in flight): the workspace is sized for it
+  const uint64_t nq_eff = std::min<uint64_t>(std::max<uint64_t>(bv.nq, 1), m.sub_queries);
+  const uint64_t nt_eff = (uint64_t)((double)(sub_tok_bounds.back() - sub_tok_bounds.front()) * ((double)nq_eff / (double)std::max<uint64_t>(bv.nq, 1)) * 1.05) + 64;
+  auto hinted = [&](const std::atomic<uint64_t>& kq) { const uint64_t h = kq.load(); return h ? (h * nq_eff / 1024) + (h * nq_eff / 1024) / 8 + 1024 : 0ull; };
+  c.want_qb = std::max<uint64_t>(c.want_qb, hinted(m.hint_qb_kq));
   auto seg_for = [&](const DevBatch& b) {
-    return std::max<uint64_t>(c.seg_cap, std::min<uint64_t>(m.init_seg, std::max<uint64_t>(4096, (uint64_t)b.nq * 64)));
+    return std::max<uint64_t>(std::max<uint64_t>(c.seg_cap, hinted(m.hint_seg_kq)),
+                              std::min<uint64_t>(m.init_seg, std::max<uint64_t>(4096, (uint64_t)b.nq * 64)));
   };
   // one pass, synchronised, re-run until its workspace fits
   auto run_sync = [&](uint32_t sb, bool call_before, uint64_t want_seg) {
@@ -799,7 +837,7 @@ static void run_passes(DeviceIndex::Impl& m, Ctx& c, const Params& prm_in, const
     want_seg = std::max<uint64_t>(want_seg, seg_for(b));
     if (call_before && hooks && hooks->before) hooks->before(sb);
     for (int attempt = 0;; attempt++) {
-      ensure_ws(c, b.nq, std::max<uint32_t>(b.nt, 1), want_seg);
+      ensure_ws(c, std::max<uint64_t>(b.nq, nq_eff), std::max<uint64_t>(std::max<uint32_t>(b.nt, 1), nt_eff), want_seg);
       c.cmin_tab.ensure((uint64_t)(p_max + 1) * kCminRow);
       const PassLimits ran = limits_of(c);
       enqueue_pass(E, b, p_max, st != nullptr, c.h_ctr);
@@ -812,6 +850,7 @@ static void run_passes(DeviceIndex::Impl& m, Ctx& c, const Params& prm_in, const
           st->launches[s] += 1;
         }
       }
+      learn_sizes(m, c.h_ctr, b.nq);
       if (pass_needs_retry(c, c.h_ctr, ran, want_seg)) {
         if (attempt >= 6) throw GpuError("workspace kept overflowing");
         if (st) st->n_retries++;
@@ -842,7 +881,7 @@ static void run_passes(DeviceIndex::Impl& m, Ctx& c, const Params& prm_in, const
       nq_max = std::max<uint64_t>(nq_max, b.nq); nt_max = std::max<uint64_t>(nt_max, b.nt);
       seg_max = std::max<uint64_t>(seg_max, seg_for(b)); pm_max = std::max(pm_max, p_max_of(b));
     }
-    ensure_ws(c, nq_max, nt_max, seg_max);
+    ensure_ws(c, std::max(nq_max, nq_eff), std::max(nt_max, nt_eff), seg_max);
     c.cmin_tab.ensure((uint64_t)(pm_max + 1) * kCminRow);
     const PassLimits ran = limits_of(c);  // every pass of the group runs under these
     for (uint32_t sb = g0; sb < g1; sb++) {
@@ -857,6 +896,7 @@ static void run_passes(DeviceIndex::Impl& m, Ctx& c, const Params& prm_in, const
     std::vector<uint32_t> redo;
     for (uint32_t sb = g0; sb < g1; sb++) {
       const unsigned long long* ctr = c.h_ctr_group + (size_t)(sb - g0) * kNumCounters;
+      learn_sizes(m, ctr, sub_q_bounds[sb + 1] - sub_q_bounds[sb]);
       if (pass_needs_retry(c, ctr, ran, want_seg)) redo.push_back(sb);
       else add_counters(st, ctr);
     }
@@ -942,11 +982,11 @@ void DeviceIndex::match_host(const HostIndex& h, const Params& prm, const HostBa
   c.d_out.ensure(nq * cap);
   c.d_cnt.ensure(nq);
   c.d_tot.ensure(nq);
-  // Pass schedule: uniform passes of host_sub_queries queries.  A pass costs ~0.8 ms of launch gaps and kernel tails on
-  // top of its per-query time, the inputs of the first pass and the records of the last cross PCIe with no kernel to hide
-  // behind, and a pass's records (88 bytes per query) must be home before the next pass ends: measured on the C3
-  // workload, two passes per million queries are the best trade (tools/host_sweep.py; uneven schedules with small
-  // first / last passes were worse: the big middle pass's copies stick out).
+  // Pass schedule: uniform passes of host_sub_queries queries (default 2^20).  Cutting a call finer lets its own copies hide
+  // behind its own kernels, but two half passes cost ~12 % more GPU time than one pass (fixed launches and tails, less
+  // work per kernel to hide latencies with), which is what the overlap wins for a lone caller; and as soon as two calls
+  // are in flight (the reference's N worker threads, bench.py's pipeline of three) each call's copies hide behind the
+  // OTHER calls' kernels anyway: measured on C3, 8.1 ms per million queries with one pass per call against 9.2 with two.
   const uint64_t per_pass = std::max<uint32_t>(1, std::min(m.sub_queries, m.host_sub_queries));
   std::vector<uint64_t> qb;
   for (uint64_t q = 0; q < nq; q += per_pass) qb.push_back(q);

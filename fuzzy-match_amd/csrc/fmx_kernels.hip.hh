@@ -87,7 +87,7 @@ struct DevWork {
   float*    t_idf;      // nt   idf_penalty per pattern position (src/fuzzy_match.cc:372-390)
   Cand*     seg;        // capacity seg_cap
   QHit*     qb;      // capacity qb_cap: per-query queues between the two expand phases
-  float*    heap;       // capacity seg_cap + nq (lowest_costs spill)
+  float*    heap;       // capacity 2 x seg_cap (lowest_costs spill, two slots per segment entry)
   unsigned long long  seg_cap;
   unsigned long long  qb_cap;
   unsigned long long* counters;  // [0]=hits [1]=kept [2]=cands [3]=dp [4]=max survivors of a query whose
@@ -100,8 +100,9 @@ struct DevWork {
                                  // [17]=of those, hits that passed the plane test (re-tested exactly)
                                  // [18]=8-byte plane words read by k_expand_h [19],[20]=bytes / lines requested by k_probe<true>
                                  // [22]=hits of the light queries (walked by k_expand_b<true>)
+                                 // [24],[25]=segment / queue entries the pass used (always written: the host sizes later workspaces by them)
 };
-constexpr int kNumCounters = 24;
+constexpr int kNumCounters = 26;
 
 constexpr int kWave = 64;
 constexpr uint32_t kLdsSortMax = 1024;   // per-wave LDS sort capacity (keys)
@@ -1163,6 +1164,11 @@ __global__ void __launch_bounds__(256) k_caps_b(DevBatch b, DevWork w, uint32_t 
   n_items[q] = ni;
 }
 
+// a few microseconds of nothing: keeps the kernel behind it from reaching the GPU before one launched on another stream
+__global__ void k_lag(const unsigned long long* p) {
+  if (threadIdx.x == 0 && p[0] == ~0ull) __builtin_amdgcn_s_sleep(1);
+}
+
 // Segment base and capacity per query once both scans are known: the light queries' segments come first (q_segl, sized
 // by their hits before phase A ran), the others follow in the order of the second scan (sized by the hits phase A
 // really queued).  In place on q_seg (each thread owns its element); q_seg[nq] = the segment space the pass needs.
@@ -1172,7 +1178,11 @@ __global__ void __launch_bounds__(256) k_segbase(DevBatch b, DevWork w, WorkItem
   if (q > b.nq) return;
   const unsigned long long totl = w.q_segl[b.nq];
   const unsigned long long* item_off = w.q_seg + 2 * (size_t)(b.nq + 1);
-  if (q == b.nq) { w.q_seg[q] += totl; w.counters[12] = item_off[q]; return; }
+  if (q == b.nq) {
+    w.q_seg[q] += totl; w.counters[12] = item_off[q];
+    w.counters[24] = w.q_seg[q]; w.counters[25] = w.q_qseg[q];
+    return;
+  }
   const unsigned long long l0 = w.q_segl[q], l1 = w.q_segl[q + 1];
   const bool light = l1 > l0;
   w.q_scap[q] = light ? (uint32_t)(l1 - l0) : (uint32_t)w.q_cap[q];
@@ -2552,7 +2562,7 @@ __global__ void __launch_bounds__(kWave) k_finish(DevIndex ix, DevBatch b, DevWo
       const uint32_t p = b.q_off[gq + 1] - b.q_off[gq];
       uint32_t n, mx;
       if (prm.cbuf > 0 && prm.cbuf <= (int)kHeapLdsMax) n = replay_body(prm, p, n_cand, seg, s_heap, sh, mx);
-      else n = replay_body(prm, p, n_cand, seg, w.heap + seg0 + q, sh, mx);
+      else n = replay_body(prm, p, n_cand, seg, w.heap + 2ull * seg0, sh, mx);  // n_cand + 1 <= 2 x the segment's capacity; segments are not in query order
       if (lane == 0) {
         w.q_acc[q] = n;
         // contrastive rerank: queries whose accepted sentences are longer than 32 / 64 tokens are queued for the
