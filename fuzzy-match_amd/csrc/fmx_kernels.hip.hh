@@ -2154,6 +2154,13 @@ struct __attribute__((packed, aligned(4))) Tok4 {
   uint32_t t[4];
 };
 
+// eq = 2 * eq + (a == b): a compare into VCC and an add-with-carry — two VALU instructions per pattern token.  (The compiler's
+// version of `eq = (eq << 1) | (a == b)` is compare, wait state, select of a constant, and half a shift-or: the match mask
+// was two thirds of the bit-parallel kernel's instructions.)
+__device__ __forceinline__ void eq_push(uint32_t& eq, uint32_t a, uint32_t b) {
+  asm("v_cmp_eq_u32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(eq) : "v"(a), "v"(b) : "vcc");
+}
+
 // Unit costs: bit-parallel Levenshtein distance (fmx_core.hh) with the pattern in registers, then S_k.
 // P = register capacity; EXACT: every lane's pattern has exactly P tokens, otherwise columns beyond n2 hold
 // 0xffffffff (never equal, their bits stay 0 and never reach bit n2 - 1).
@@ -2180,16 +2187,22 @@ __device__ __forceinline__ float edit_distance_unit(const uint32_t* __restrict__
       const uint32_t wd = c0;
       c0 = c1; c1 = c2; c2 = c3;
       if (P <= 32) {
-        uint32_t eq = 0;
+        // two independent chains (upper / lower half of the pattern), joined by one shift-or
+        constexpr int H = P / 2;
+        uint32_t eq_a = 0, eq_b = 0;
 #pragma unroll
-        for (int j = P - 1; j >= 0; j--) eq = (eq << 1) | (uint32_t)(wd == pt[j]);
-        lev_step32(pv, mv, score, eq, n2);
+        for (int t = 0; t < P - H; t++) {  // interleaved: neither chain waits for its own previous add
+          eq_push(eq_a, wd, pt[P - 1 - t]);
+          if (H - 1 - t >= 0) eq_push(eq_b, wd, pt[H - 1 - t >= 0 ? H - 1 - t : 0]);
+        }
+        lev_step32(pv, mv, score, H ? ((eq_a << H) | eq_b) : eq_a, n2);
       } else {
         uint32_t eq_lo = 0, eq_hi = 0;
 #pragma unroll
-        for (int j = 31; j >= 0; j--) eq_lo = (eq_lo << 1) | (uint32_t)(wd == pt[j]);
-#pragma unroll
-        for (int j = P - 1; j >= 32; j--) eq_hi = (eq_hi << 1) | (uint32_t)(wd == pt[j]);
+        for (int t = 0; t < 32; t++) {
+          eq_push(eq_lo, wd, pt[31 - t]);
+          if (P - 1 - t >= 32) eq_push(eq_hi, wd, pt[P - 1 - t >= 32 ? P - 1 - t : 32]);
+        }
         lev_step(st, ((unsigned long long)eq_hi << 32) | eq_lo, n2);
       }
     }
