@@ -257,7 +257,10 @@ FMX_HD uint32_t gram_hash(uint32_t w0, uint32_t w1, uint32_t w2) {
 // Second level: the distinct 5-grams of every trigram whose range holds more than kDeepGramMin suffixes,
 // keyed by (start of the trigram range, w3, w4).  It caps the length of the dependent-read chain of a
 // probe: without it one lane that has to bisect a 100 000-suffix trigram range keeps its whole wave waiting.
-constexpr uint32_t kDeepGramMin = 64;
+#ifndef FMX_DEEP_MIN
+#define FMX_DEEP_MIN 8
+#endif
+constexpr uint32_t kDeepGramMin = FMX_DEEP_MIN;
 
 struct GramTables {
   const GramEntry* g3;

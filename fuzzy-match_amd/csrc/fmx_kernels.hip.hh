@@ -1070,10 +1070,18 @@ __global__ void __launch_bounds__(kWave, 6) k_expand_h(DevIndex ix, DevBatch b, 
       ge[6] = hi | (d[2] & d[1]);
       ge[7] = hi | (d[2] & d[1] & d[0]);
       unsigned long long pass = 0;
+      // consecutive intervals usually touch (thresholds grow with the sentence length): the row that closed one opens the next
+      uint32_t prev_end = 0xffffffffu;
+      unsigned long long prev_t = 0;
 #pragma unroll
       for (uint32_t k = 0; k < 2 * kGeLevels; k++) {
         const uint32_t first = iv[k] & 0xffffu, last = iv[k] >> 16;
-        if (first <= last) pass |= T(first) & ~T(last + 1u) & ge[k >> 1];  // last <= 254
+        if (first <= last) {  // last <= 254
+          const unsigned long long tf = first == prev_end ? prev_t : T(first);
+          const unsigned long long tl = T(last + 1u);
+          pass |= tf & ~tl & ge[k >> 1];
+          prev_end = last + 1u; prev_t = tl;
+        }
       }
       pass &= ~bor;
       if (clamp_possible) pass |= T(kSigLenClamp);  // clamped lengths: phase B decides
@@ -1119,7 +1127,15 @@ __global__ void __launch_bounds__(kWave, 6) k_expand_h(DevIndex ix, DevBatch b, 
     {
       const uint32_t h0 = blk_first == (r_lo >> 6) ? r_lo : blk_first * 64u;
       const uint32_t h1 = blk_end == blk_last_r + 1 ? r_hi : blk_end * 64u;
-      uint32_t rows = 2u * n_iv + (clamp_possible ? 1u : 0u);  // thermometer rows
+      uint32_t rows = clamp_possible ? 1u : 0u;  // thermometer rows: two per interval, one where it continues the previous
+      {
+        uint32_t pe = 0xffffffffu;
+#pragma unroll
+        for (uint32_t k = 0; k < 2 * kGeLevels; k++) {
+          const uint32_t first = iv[k] & 0xffffu, last = iv[k] >> 16;
+          if (first <= last) { rows += first == pe ? 1u : 2u; pe = last + 1u; }
+        }
+      }
 #pragma unroll
       for (int k = 0; k < 6; k++) rows += (uint32_t)__popcll(plh[0][k]) + (uint32_t)__popcll(plh[1][k]);
       tot_hits += h1 - h0;
@@ -1385,12 +1401,32 @@ __global__ void __launch_bounds__(kWave, 8) k_expand_b(DevIndex ix, DevBatch b, 
         if (act) sv = s_surv[j0 + sub];
         const uint32_t it = sv.it_need >> 16, need = sv.it_need & 0xffffu;
         const uint32_t rem = sv.rem_slen & 0xffffu, sl = sv.rem_slen >> 16;
-        // match length: kSubLanes tokens per step, a position at or beyond the limit counts as a mismatch
+        // Everything the group needs from the sentence is requested at once — the first kLcpAhead steps of the match-length
+        // walk (kSubLanes tokens per step) and the first kCovAhead x kSubLanes tokens of the coverage scan — so that a
+        // typical survivor costs one memory latency here instead of one per step.
+        constexpr int kLcpAhead = 4, kCovAhead = 8;
         const uint32_t lim = act ? (rem < p - it ? rem : p - it) : 0u;
+        const uint32_t* sent = ix.tok + (sv.off - (sl - rem));
+        uint32_t lt[kLcpAhead], ct[kCovAhead];
+#pragma unroll
+        for (int u = 0; u < kLcpAhead; u++) { const uint32_t k = m + u * kSubLanes + part; lt[u] = k < lim ? ix.tok[sv.off + k] : 0u; }
+#pragma unroll
+        for (int u = 0; u < kCovAhead; u++) { const uint32_t k = part + u * kSubLanes; ct[u] = (act && k < sl) ? sent[k] : kHashEmpty; }
+        // match length: kSubLanes tokens per step, a position at or beyond the limit counts as a mismatch
         uint32_t L = m < lim ? m : lim;
         bool done = !act || m >= lim;
         uint32_t k0 = m;
-        while (__ballot(!done)) {
+#pragma unroll
+        for (int u = 0; u < kLcpAhead; u++) {
+          const uint32_t k = k0 + part;
+          const bool mism = !done && (k >= lim || lt[u] != s_pat[it + k]);
+          const uint32_t g = (uint32_t)(__ballot(mism) >> (sub * kSubLanes)) & ((1u << kSubLanes) - 1u);
+          if (!done) {
+            if (g) { L = k0 + (uint32_t)__ffs((int)g) - 1u; done = true; }
+            else k0 += kSubLanes;
+          }
+        }
+        while (__ballot(!done)) {  // longer matches: step by step
           const uint32_t k = k0 + part;
           const bool mism = !done && (k >= lim || ix.tok[sv.off + k] != s_pat[it + k]);
           const uint32_t g = (uint32_t)(__ballot(mism) >> (sub * kSubLanes)) & ((1u << kSubLanes) - 1u);
@@ -1402,18 +1438,23 @@ __global__ void __launch_bounds__(kWave, 8) k_expand_b(DevIndex ix, DevBatch b, 
         // coverage: distinct pattern words present in the sentence
         unsigned long long seen = 0;
         if (act && L < p) {
-          const uint32_t* sent = ix.tok + (sv.off - (sl - rem));
-          for (uint32_t kb = part; kb < sl; kb += 4 * kSubLanes) {
+          auto probe = [&](uint32_t t) {
+            uint32_t h = pat_hash_slot(t);
+            uint32_t key = ph.key[h];
+            while (key != t && key != kHashEmpty) { h = (h + 1) & (kHashSlots - 1); key = ph.key[h]; }
+            if (key == t) seen |= 1ull << ph.idx[h];
+          };
+#pragma unroll
+          for (int u = 0; u < kCovAhead; u++)
+            if (part + u * kSubLanes < sl) probe(ct[u]);
+          for (uint32_t kb = part + kCovAhead * kSubLanes; kb < sl; kb += 4 * kSubLanes) {  // sentences of more than 32 tokens
             uint32_t t[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) t[u] = kb + u * kSubLanes < sl ? sent[kb + u * kSubLanes] : kHashEmpty;
 #pragma unroll
             for (int u = 0; u < 4; u++) {
               if (kb + u * kSubLanes >= sl) break;
-              uint32_t h = pat_hash_slot(t[u]);
-              uint32_t key = ph.key[h];
-              while (key != t[u] && key != kHashEmpty) { h = (h + 1) & (kHashSlots - 1); key = ph.key[h]; }
-              if (key == t[u]) seen |= 1ull << ph.idx[h];
+              probe(t[u]);
             }
           }
         }
