@@ -255,7 +255,7 @@ int fmx_index_array(const fmx_index* ix, int which, const void** data, uint64_t*
     case FMX_A_IDF: *data = h.idf.data(); *count = h.idf.size(); break;
     case FMX_A_REAL_IDS: *data = h.real_ids.data(); *count = h.real_ids.size(); break;
     case FMX_A_ITOK_IDS: *data = h.itok_ids.data(); *count = h.itok_ids.size(); break;
-    case FMX_A_ITOK_DIST: *data = h.itok_dist.data(); *count = h.itok_dist.size(); break;
+    case FMX_A_ITOK_DIST: h.sync_itok_dist(); *data = h.itok_dist.data(); *count = h.itok_dist.size(); break;
     case FMX_A_SUF_SIG: *data = h.suf_sig.data(); *count = h.suf_sig.size(); break;
     case FMX_A_SUF_KEY: *data = h.suf_key.data(); *count = h.suf_key.size(); break;
     case FMX_A_GRAM: *data = h.gram.data(); *count = h.gram.size(); break;

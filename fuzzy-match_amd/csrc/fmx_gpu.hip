@@ -286,6 +286,7 @@ static void refresh_itok_table(DeviceIndex::Impl& m, const HostIndex& h) {
   if (m.itok_version == h.itok_version) return;
   hipFree((void*)m.d.itok_dist);
   m.d.itok_dist = nullptr;
+  h.sync_itok_dist();
   m.d.n_itok = (uint32_t)h.itok_strings.size();
   if (!h.itok_dist.empty()) m.d.itok_dist = dev_upload(h.itok_dist);
   m.itok_version = h.itok_version;

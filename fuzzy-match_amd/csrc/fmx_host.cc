@@ -345,32 +345,45 @@ void HostIndex::build_gram_table(int nthreads) {
   });
 }
 
+constexpr uint32_t kMaxItokStrings = 32768;  // the table is quadratic: 2 GB at the limit
+
 uint32_t HostIndex::intern_itok(const std::string& s) {
   if (itok_strings.empty()) {
     itok_strings.emplace_back();
     itok_intern.emplace(std::string(), 0u);
-    itok_dist.assign(1, 0);
+    itok_cap = 16;
+    itok_tab.assign((size_t)itok_cap * itok_cap, 0);
   }
   auto it = itok_intern.find(s);
   if (it != itok_intern.end()) return it->second;
   const uint32_t id = (uint32_t)itok_strings.size();
-  if (id >= 4096) throw std::runtime_error("too many distinct penalty-token strings (limit 4096)");
+  if (id >= kMaxItokStrings) throw std::runtime_error("too many distinct penalty-token strings (limit 32768)");
   itok_strings.push_back(s);
   itok_intern.emplace(s, id);
-  const uint32_t n = id + 1;
-  std::vector<uint16_t> d((size_t)n * n);
-  for (uint32_t a = 0; a < n; a++)
-    for (uint32_t b = 0; b < n; b++) {
-      if (a < n - 1 && b < n - 1) d[(size_t)a * n + b] = itok_dist[(size_t)a * (n - 1) + b];
-      else {
-        const int v = edit_distance_char(itok_strings[a].data(), (int)itok_strings[a].size(),
-                                         itok_strings[b].data(), (int)itok_strings[b].size());
-        d[(size_t)a * n + b] = (uint16_t)std::min(v, 65535);
-      }
-    }
-  itok_dist.swap(d);
+  if (id >= itok_cap) {  // stride doubles: re-lay the rows out
+    const uint32_t cap2 = itok_cap * 2;
+    std::vector<uint16_t> t((size_t)cap2 * cap2, 0);
+    for (uint32_t a = 0; a < id; a++) memcpy(&t[(size_t)a * cap2], &itok_tab[(size_t)a * itok_cap], (size_t)id * sizeof(uint16_t));
+    itok_tab.swap(t);
+    itok_cap = cap2;
+  }
+  for (uint32_t a = 0; a <= id; a++) {  // the new row and column
+    const int v = edit_distance_char(itok_strings[a].data(), (int)itok_strings[a].size(), itok_strings[id].data(), (int)itok_strings[id].size());
+    const int w = a == id ? v : edit_distance_char(itok_strings[id].data(), (int)itok_strings[id].size(), itok_strings[a].data(), (int)itok_strings[a].size());
+    itok_tab[(size_t)a * itok_cap + id] = (uint16_t)std::min(v, 65535);
+    itok_tab[(size_t)id * itok_cap + a] = (uint16_t)std::min(w, 65535);
+  }
   itok_version++;
   return id;
+}
+
+void HostIndex::sync_itok_dist() const {
+  std::lock_guard<std::mutex> lk(itok_sync_mu);
+  if (itok_dist_version == itok_version) return;
+  const uint32_t n = (uint32_t)itok_strings.size();
+  itok_dist.assign((size_t)n * n, 0);
+  for (uint32_t a = 0; a < n; a++) memcpy(&itok_dist[(size_t)a * n], &itok_tab[(size_t)a * itok_cap], (size_t)n * sizeof(uint16_t));
+  itok_dist_version = itok_version;
 }
 
 uint32_t HostIndex::lookup_real(const std::string& s) const {

@@ -3,6 +3,7 @@
 // are uploaded to HBM.  Pure C++17, no HIP.
 #pragma once
 #include <stdint.h>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <utility>
@@ -75,7 +76,15 @@ class HostIndex {
   std::unordered_map<std::string, uint32_t> real_intern;
   std::vector<std::string>                  itok_strings;  // id 0 = ""
   std::unordered_map<std::string, uint32_t> itok_intern;
-  std::vector<uint16_t>                     itok_dist;     // n x n byte-Levenshtein, n = itok_strings.size()
+  // byte-Levenshtein distance of every pair of penalty strings.  itok_tab is the working copy with a row stride of itok_cap
+  // (a power of two: a new string costs one row and one column, the table is re-laid out only when the stride doubles);
+  // itok_dist is the compact n x n copy the kernels index (n = itok_strings.size()), rebuilt by sync_itok_dist() when stale.
+  std::vector<uint16_t>                     itok_tab;
+  uint32_t                                  itok_cap = 0;
+  mutable std::vector<uint16_t>             itok_dist;
+  mutable uint64_t                          itok_dist_version = ~0ull;
+  mutable std::mutex                        itok_sync_mu;
+  void sync_itok_dist() const;
   uint64_t                                  itok_version = 0;
 
   HostIndex();

@@ -266,9 +266,14 @@ int64_t fmx_index_add_text(fmx_index*, const char* id, const char* sentence, siz
  *                       below; concurrent callers overlap anyway, every call works in its own context)
  *   "probe_count"       measurement: k_probe also counts the bytes and lines it requests (fmx_stats.probe_*)
  *   "sub_queries"       queries per pipeline pass (default 1 048 576)
- *   "host_sub_queries"  pass size of fmx_match_batch (host buffers, default 524 288): the inputs of the next pass and
+ *   "host_sub_queries"  pass size of fmx_match_batch (host buffers, default 1 048 576): the inputs of the next pass and
  *                       the records of the previous one cross PCIe while a pass computes
- *   "initial_segment"   initial capacity of the hit workspace (grows on demand) */
+ *   "turns"             host-buffer calls (of 32 768 queries or more) that may own the GPU's kernels at once while the
+ *                       copies of the other calls in flight run beside them (default 1; 0 = calls simply overlap)
+ *   "light_max"         queries with at most this many suffix-array hits, none of them in a long range, are walked by
+ *                       one kernel without the phase-A filter (default 256, at most 1024; 0 = none)
+ *   "expand_order", "b_grid", "heavy_grid", "serial"   measurement / design-time switches of the expand stage
+ *   "initial_segment"   initial capacity of the hit workspace (grows on demand; sizes are learned per index) */
 int fmx_set_option(fmx_index*, const char* name, int64_t value);
 
 #ifdef __cplusplus

@@ -164,3 +164,28 @@ def test_match_without_device_fails_loudly(fmx):
     ix3.add_tm("a", ["x"])
     with pytest.raises(fmx.FmxError):
         ix3.sort(0)
+
+
+def test_many_penalty_strings(fmx):
+    """The penalty-string distance table grows by one row and one column per new string (no limit of 4096 any more;
+    the reference interns nothing and recomputes the byte distance per cell, include/fuzzy/edit_distance.hxx:7-35)."""
+    def lev(a, b):
+        prev = list(range(len(b) + 1))
+        for i, ca in enumerate(a, 1):
+            cur = [i]
+            for j, cb in enumerate(b, 1):
+                cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (ca != cb)))
+            prev = cur
+        return prev[-1]
+    ix = fmx.Index.create()
+    strings = [""] + [f"{k:x}" + "~" * (k % 5) for k in range(1, 5000)]
+    ids = [ix.intern_itok(s) for s in strings[1:]]
+    assert ids == list(range(1, 5000))
+    assert ix.intern_itok(strings[4321]) == 4321  # already known
+    n = ix.info().n_itok
+    assert n == 5000
+    d = ix.array("itok_dist").reshape(n, n)
+    rng = np.random.default_rng(3)
+    for a, b in rng.integers(0, n, size=(300, 2)):
+        assert d[a, b] == lev(strings[a].encode(), strings[b].encode()), (a, b)
+    assert (d.diagonal() == 0).all() and d[0, 7] == len(strings[7])
