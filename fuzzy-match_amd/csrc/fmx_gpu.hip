@@ -198,7 +198,10 @@ struct DeviceIndex::Impl {
   std::mutex              turn_mu;
   std::condition_variable turn_cv;
   int                     turn_busy = 0;
-  uint32_t                turns = 1;     // calls that may own the kernels at once (option "turns"; 0 = no turns)
+  uint32_t                turns = 1;     // 0 = no turns; 1 = chained on the GPU (each call's first kernel waits for the event that ends
+                                         // the previous call's kernels: no hand-over through the host); 3 = turns taken on the host
+  std::mutex              chain_mu;
+  hipEvent_t              chain_last = nullptr;  // ends the kernels of the call enqueued last (owned by its context)
   // what passes needed so far, per 1024 queries, shared by all contexts: a context sizes its workspace for a full pass of the
   // call at hand up front (a pass that does not fit is re-run after a reallocation that stalls every call in flight)
   std::atomic<uint64_t> hint_seg_kq{0}, hint_qb_kq{0};
@@ -508,6 +511,7 @@ struct PassHooks {
   std::function<void(uint32_t)> before;        // inputs of pass sb must be on their way; make `stream` wait for them
   std::function<void(uint32_t, hipEvent_t)> after;  // the records of pass sb are final once the event (or, if null, the stream) is done
   std::function<void()> computed;              // the kernels of every pass of a group are through (their records may still be travelling)
+  std::function<void(hipEvent_t)> enqueued;    // every pass of the first group is enqueued; the event = its last kernel
 };
 
 struct PassEnv {
@@ -903,6 +907,7 @@ static void run_passes(DeviceIndex::Impl& m, Ctx& c, const Params& prm_in, const
       enqueue_pass(E, b, p_max_of(b), false, c.h_ctr_group + (size_t)(sb - g0) * kNumCounters);
       HIP_TRY(hipEventRecord(c.ev_pass[sb - g0], stream));
     }
+    if (g0 == 0 && hooks && hooks->enqueued) hooks->enqueued(c.ev_pass[g1 - 1 - g0]);
     // The records of a pass are sent home by the host once the pass is through, not queued behind an event: a copy that
     // waits in a DMA queue for its kernels holds up every copy queued after it — the inputs of the other calls in flight.
     for (uint32_t sb = g0; sb < g1; sb++) {
@@ -1076,7 +1081,7 @@ void DeviceIndex::match_host(const HostIndex& h, const Params& prm, const HostBa
     void acquire() {
       if (!m.turns) return;
       std::unique_lock<std::mutex> lk(m.turn_mu);
-      m.turn_cv.wait(lk, [&] { return m.turn_busy < (int)m.turns; });
+      m.turn_cv.wait(lk, [&] { return m.turn_busy < 1; });
       m.turn_busy++; held = true;
     }
     void release() {
@@ -1090,15 +1095,28 @@ void DeviceIndex::match_host(const HostIndex& h, const Params& prm, const HostBa
   bool first_sent = false;
   // (small calls — the coalescer's micro-batches, interactive callers — do not fill the GPU and simply overlap)
   constexpr uint64_t kTurnMinQueries = 32768;
-  if (m.turns && nq >= kTurnMinQueries) { send(0); first_sent = true; turn.acquire(); }
+  const uint32_t turns = nq >= kTurnMinQueries ? m.turns : 0u;
+  std::unique_lock<std::mutex> chain_lk(m.chain_mu, std::defer_lock);
+  if (turns == 1) {
+    // chained on the GPU: calls enqueue in the order they take the lock, each behind the end of its predecessor's kernels
+    send(0); first_sent = true;
+    chain_lk.lock();
+    if (m.chain_last) HIP_TRY(hipStreamWaitEvent(c.stream, m.chain_last, 0));
+  } else if (turns >= 3) {
+    send(0); first_sent = true; turn.acquire();
+  }
   hooks.before = [&](uint32_t s) {
     if (s == 0 && !first_sent) send(0);
     HIP_TRY(hipStreamWaitEvent(c.stream, c.ev_in[s % kMaxPassesInFlight], 0));
     if (s + 1 < n_sub) send(s + 1);  // travels while pass s computes
   };
+  hooks.enqueued = [&](hipEvent_t last) {
+    if (chain_lk.owns_lock()) { m.chain_last = last; chain_lk.unlock(); }
+  };
   hooks.computed = [&]() { turn.release(); };
   // stage timing (st with events) is the device entry point's job: here the passes run back to back, unsynchronised
   run_passes(m, c, prm, bv, c.d_out.p, c.d_cnt.p, c.d_tot.p, cap, c.stream, qb, bounds, st, &hooks, true);
+  if (chain_lk.owns_lock()) chain_lk.unlock();
   turn.release();
   const auto a = std::chrono::steady_clock::now();
   HIP_TRY(hipStreamSynchronize(c.d2h));
