@@ -122,6 +122,12 @@ struct Ctx {
   Grow<WorkItem> items, items_b;
   Grow<HeavyItem> items_h;
   Grow<uint16_t> cmin_tab;
+  // what the table in cmin_tab was computed for (k_cmin is skipped while a pass asks for the same: the coalescer's
+  // micro-batches repeat their parameters, and the kernel is 25 us of a ~250 us pass)
+  float    cmin_key[4] = {0, 0, 0, 0};
+  uint32_t cmin_pmax = 0, cmin_maxslen = 0;
+  int      cmin_sig = -1;
+  const uint16_t* cmin_ptr = nullptr;
   Grow<float>    g_rows;      // DP rows in HBM for patterns / sentences too long for the LDS rows
   uint32_t s_max = 4096;      // survivors kept per query before a retry with a larger segment
   uint32_t heavy_div = 16;    // share of a query's long-range hits its queue reserves room for (1 / heavy_div)
@@ -557,9 +563,16 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
     tick();
     // the phase-A threshold table depends on the parameters only: computed on the side stream while the probe runs
     // (after the fork: the previous pass, which read the table, is complete)
-    fork();
-    hipLaunchKernelGGL(k_cmin, dim3(p_max + 1), dim3(256), 0, side, m.d.max_slen, prm, use_sig, c.cmin_tab.p);
-    if (!m.serial) HIP_TRY(hipEventRecord(c.ev_cmin, c.side));
+    const float cmin_key[4] = {prm.fuzzy, prm.ins, prm.del, prm.rep};
+    const bool cmin_cached = c.cmin_ptr == c.cmin_tab.p && c.cmin_sig == use_sig && c.cmin_maxslen == m.d.max_slen && c.cmin_pmax >= p_max &&
+                             memcmp(c.cmin_key, cmin_key, sizeof cmin_key) == 0;
+    if (!cmin_cached) {
+      fork();
+      hipLaunchKernelGGL(k_cmin, dim3(p_max + 1), dim3(256), 0, side, m.d.max_slen, prm, use_sig, c.cmin_tab.p);
+      if (!m.serial) HIP_TRY(hipEventRecord(c.ev_cmin, c.side));
+      memcpy(c.cmin_key, cmin_key, sizeof cmin_key);
+      c.cmin_ptr = c.cmin_tab.p; c.cmin_sig = use_sig; c.cmin_maxslen = m.d.max_slen; c.cmin_pmax = p_max;
+    }
     hipLaunchKernelGGL(k_setup, dim3((b.nq + 1 + 255) / 256), dim3(256), 0, stream, m.d, b, w, prm);
     if (prm.idf_penalty != 0.f) hipLaunchKernelGGL(k_tidf, dim3((b.nt + 255) / 256), dim3(256), 0, stream, m.d, b, w);
     {
@@ -593,7 +606,11 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
       // The light kernel is a per-query instruction stream, k_expand_h an HBM stream: they share the GPU well.
       const size_t lds = (size_t)p_max * 4;
       if (lds > 64 * 1024) throw UnsupportedError("patterns too long for the expand kernel's LDS staging");
-      if (!m.serial) HIP_TRY(hipStreamWaitEvent(stream, c.ev_cmin, 0));
+      if (!m.serial && !cmin_cached) HIP_TRY(hipStreamWaitEvent(stream, c.ev_cmin, 0));
+      // persistent grids shrink with the pass (a micro-batch of the coalescer pays ~25 us for 8192 workgroups that find nothing to do)
+      const uint32_t grid_h = std::min<uint32_t>(m.heavy_grid, std::max<uint32_t>(256u, 4u * b.nq));
+      const uint32_t grid_l = std::min<uint32_t>(kExpandExtraGrid, std::max<uint32_t>(256u, b.nq));
+      const uint32_t grid_b = std::min<uint32_t>(m.b_grid, std::max<uint32_t>(256u, b.nq));
       auto side_tick = [&](int stage, int end) { if (timing) HIP_TRY(hipEventRecord(c.ev[2 * stage + end], side)); };
       auto second_scan = [&](hipStream_t st) {
         // the hits phase A really queued size the segments of everything downstream: second scan, q_cap -> q_seg, placed
@@ -607,17 +624,17 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
       fork();
       side_tick(kStageExpandH, 0);
       if (heavy_min != 0xffffffffu)
-        hipLaunchKernelGGL(k_expand_h, dim3(m.heavy_grid), dim3(kWave), 0, side, m.d, b, w, prm, (const HeavyItem*)c.items_h.p, item_h_cap);
+        hipLaunchKernelGGL(k_expand_h, dim3(grid_h), dim3(kWave), 0, side, m.d, b, w, prm, (const HeavyItem*)c.items_h.p, item_h_cap);
       side_tick(kStageExpandH, 1);
       // phase A of the queries that are not light: block q = query q (light_max == 0) or a work-item list
-      hipLaunchKernelGGL(k_expand_a, dim3((light_max ? 0u : b.nq) + kExpandExtraGrid), dim3(kWave), 0, stream, m.d, b, w, prm,
+      hipLaunchKernelGGL(k_expand_a, dim3((light_max ? 0u : b.nq) + grid_l), dim3(kWave), 0, stream, m.d, b, w, prm,
                          (const WorkItem*)c.items.p, item_cap, use_sig, light_max ? 0u : b.nq);
       if (m.expand_order == 0) {
         if (!m.serial) { HIP_TRY(hipEventRecord(c.ev_a, stream)); HIP_TRY(hipStreamWaitEvent(c.side, c.ev_a, 0)); }
         tick(); tick();
         side_tick(kStageExpandB, 0);
         second_scan(side);
-        hipLaunchKernelGGL(k_expand_b<false>, dim3((light_max ? 0u : b.nq) + m.b_grid), dim3(kWave), lds, side, m.d, b, w, prm,
+        hipLaunchKernelGGL(k_expand_b<false>, dim3((light_max ? 0u : b.nq) + grid_b), dim3(kWave), lds, side, m.d, b, w, prm,
                            (const WorkItem*)c.items_b.p, item_cap, light_max ? 0u : b.nq);
         side_tick(kStageExpandB, 1);
         if (light_max)
@@ -632,7 +649,7 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
         second_scan(stream);
         fork();
         side_tick(kStageExpandB, 0);
-        hipLaunchKernelGGL(k_expand_b<false>, dim3((light_max ? 0u : b.nq) + m.b_grid), dim3(kWave), lds, side, m.d, b, w, prm,
+        hipLaunchKernelGGL(k_expand_b<false>, dim3((light_max ? 0u : b.nq) + grid_b), dim3(kWave), lds, side, m.d, b, w, prm,
                            (const WorkItem*)c.items_b.p, item_cap, light_max ? 0u : b.nq);
         side_tick(kStageExpandB, 1);
         if (light_max) {
