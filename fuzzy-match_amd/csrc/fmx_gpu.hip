@@ -661,7 +661,9 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
       join();  // stage "expand_wait": what the side lane still has to do when the light kernel is through
     }
     tick(); tick();
-    hipLaunchKernelGGL(k_cand, dim3((b.nq + 3) / 4), dim3(256), 0, stream, b, w, c.big_list.p, c.mid_list.p);
+    // fin_list is free until k_cmap fills it: it carries k_cand's few queries
+    hipLaunchKernelGGL(k_cand_route, dim3((b.nq + 255) / 256), dim3(256), 0, stream, b, w, c.big_list.p, c.mid_list.p, c.fin_list.p);
+    hipLaunchKernelGGL(k_cand, dim3(std::min<uint32_t>(2048u, std::max<uint32_t>(64u, b.nq))), dim3(kWave), 0, stream, w, (const uint32_t*)c.fin_list.p);
     {
       // The sorter of the few huge survivor sets is one workgroup per query and leaves the GPU almost idle:
       // it runs on the side stream next to k_cand_mid (disjoint queries).

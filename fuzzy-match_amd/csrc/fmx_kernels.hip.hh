@@ -99,7 +99,7 @@ struct DevWork {
                                  // [15]=work items of k_expand_h [16]=hits walked through the bit planes
                                  // [17]=of those, hits that passed the plane test (re-tested exactly)
                                  // [18]=8-byte plane words read by k_expand_h [19],[20]=bytes / lines requested by k_probe<true>
-                                 // [22]=hits of the light queries (walked by k_expand_b<true>)
+                                 // [22]=hits of the light queries (walked by k_expand_b<true>) [23]=queries queued for k_cand
                                  // [24],[25]=segment / queue entries the pass used (always written: the host sizes later workspaces by them)
 };
 constexpr int kNumCounters = 26;
@@ -1218,7 +1218,7 @@ __global__ void __launch_bounds__(256) k_segbase(DevBatch b, DevWork w, WorkItem
 // signature bound is skipped (the exact coverage test decides).  !LIGHT: blocks [0, first_q_blocks) take chunk 0 of
 // query blockIdx.x, the others loop over the work-item list.
 template <bool LIGHT>
-__global__ void __launch_bounds__(kWave, 8) k_expand_b(DevIndex ix, DevBatch b, DevWork w, Params prm,
+__global__ void __launch_bounds__(kWave, 6) k_expand_b(DevIndex ix, DevBatch b, DevWork w, Params prm,
                                                        const WorkItem* items, uint32_t item_cap, uint32_t first_q_blocks) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t* s_pat = (uint32_t*)smem;
@@ -1718,50 +1718,49 @@ __device__ __forceinline__ unsigned long long wave_sort64(unsigned long long key
   return key;
 }
 
-// k_cand — four queries per 256-thread workgroup, one wave each.  Up to 64 survivors (the common case: the
-// coverage bound has already run) are de-duplicated and ordered entirely in registers; 65..1024 are queued
-// for k_cand_mid (LDS bitonic), more for k_cand_big (block radix sort).
-__global__ void __launch_bounds__(256) k_cand(DevBatch b, DevWork w, uint32_t* big_list, uint32_t* mid_list) {
-  const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
+// k_cand_route — one thread per query: nearly every query's survivors were already reduced to candidates by k_expand_b (in
+// LDS), so only the rest is handed to a kernel: up to 64 survivors -> small_list (k_cand: registers), 65..1024 -> mid_list
+// (k_cand_mid: LDS bitonic), more -> big_list (k_cand_big: block radix sort).
+__global__ void __launch_bounds__(256) k_cand_route(DevBatch b, DevWork w, uint32_t* big_list, uint32_t* mid_list, uint32_t* small_list) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= b.nq) return;
-  const uint32_t lane = lane_id();
   const uint32_t n = w.q_kept[q];
   if (n & kKeptReduced) return;  // k_expand_b already wrote the candidates and q_cand
-  if (n == 0) {
-    if (lane == 0) w.q_cand[q] = 0;
-    return;
-  }
-  if (n > w.q_scap[q]) {  // more survivors than the segment holds
-    if (lane == 0) { w.q_cand[q] = 0; atomicMax(&w.counters[4], (unsigned long long)n); }
-    return;
-  }
-  if (n > kWave) {
-    if (lane == 0) {
-      w.q_cand[q] = 0;
-      if (n > kLdsSortMax) big_list[atomicAdd(&w.counters[7], 1ull)] = q;
-      else mid_list[atomicAdd(&w.counters[13], 1ull)] = q;
+  w.q_cand[q] = 0;
+  if (n == 0) return;
+  if (n > w.q_scap[q]) { atomicMax(&w.counters[4], (unsigned long long)n); return; }  // more survivors than the segment holds
+  if (n > kLdsSortMax) big_list[atomicAdd(&w.counters[7], 1ull)] = q;
+  else if (n > kWave) mid_list[atomicAdd(&w.counters[13], 1ull)] = q;
+  else small_list[atomicAdd(&w.counters[23], 1ull)] = q;
+}
+
+// k_cand — one wave per query of small_list: up to 64 survivors are de-duplicated and ordered entirely in registers.
+__global__ void __launch_bounds__(kWave) k_cand(DevWork w, const uint32_t* small_list) {
+  const unsigned long long n_small = w.counters[23];
+  const uint32_t lane = lane_id();
+  for (unsigned long long idx = blockIdx.x; idx < n_small; idx += gridDim.x) {
+    const uint32_t q = small_list[idx];
+    const uint32_t n = w.q_kept[q];
+    Cand* seg = w.seg + w.q_seg[q];
+    unsigned long long key = ~0ull;
+    if (lane < n) key = ((unsigned long long)seg[lane].sid << 16) | (seg[lane].longest & 0xffffu);
+    key = wave_sort64(key);
+    // keep the last entry of each sentence group (its largest L); rewrite as (0xffff - L, sid)
+    const uint32_t nlo = __shfl_down((uint32_t)key, 1, 64), nhi = __shfl_down((uint32_t)(key >> 32), 1, 64);
+    const unsigned long long nxt = lane == 63 ? ~0ull : (((unsigned long long)nhi << 32) | nlo);
+    const bool keep = lane < n && (nxt >> 16) != (key >> 16);
+    unsigned long long k2 = keep ? (((unsigned long long)(0xffffu - (uint32_t)(key & 0xffffu)) << 32) | (key >> 16)) : ~0ull;
+    const uint32_t kept = __popcll(__ballot(keep));
+    k2 = wave_sort64(k2);
+    if (lane < kept) {
+      Cand c;
+      c.sid = (uint32_t)(k2 & 0xffffffffu);
+      c.longest = 0xffffu - (uint32_t)(k2 >> 32);
+      c.score = 0.f; c.penalty = 0.f;
+      seg[lane] = c;
     }
-    return;
+    if (lane == 0) w.q_cand[q] = kept;
   }
-  Cand* seg = w.seg + w.q_seg[q];
-  unsigned long long key = ~0ull;
-  if (lane < n) key = ((unsigned long long)seg[lane].sid << 16) | (seg[lane].longest & 0xffffu);
-  key = wave_sort64(key);
-  // keep the last entry of each sentence group (its largest L); rewrite as (0xffff - L, sid)
-  const uint32_t nlo = __shfl_down((uint32_t)key, 1, 64), nhi = __shfl_down((uint32_t)(key >> 32), 1, 64);
-  const unsigned long long nxt = lane == 63 ? ~0ull : (((unsigned long long)nhi << 32) | nlo);
-  const bool keep = lane < n && (nxt >> 16) != (key >> 16);
-  unsigned long long k2 = keep ? (((unsigned long long)(0xffffu - (uint32_t)(key & 0xffffu)) << 32) | (key >> 16)) : ~0ull;
-  const uint32_t kept = __popcll(__ballot(keep));
-  k2 = wave_sort64(k2);
-  if (lane < kept) {
-    Cand c;
-    c.sid = (uint32_t)(k2 & 0xffffffffu);
-    c.longest = 0xffffu - (uint32_t)(k2 >> 32);
-    c.score = 0.f; c.penalty = 0.f;
-    seg[lane] = c;
-  }
-  if (lane == 0) w.q_cand[q] = kept;
 }
 
 __global__ void __launch_bounds__(256) k_cand_mid(DevWork w, const uint32_t* mid_list) {
@@ -2284,7 +2283,7 @@ __device__ __forceinline__ float edit_distance_exact_dispatch(uint32_t p_u, cons
 
 // UNIT: insert = delete = replace >= 0 and no idf term (decided by the host): bit-parallel distance
 template <int P, bool IDF, bool UNIT = false>
-__global__ void __launch_bounds__(kWave) k_dp_reg(DevIndex ix, DevBatch b, DevWork w, Params prm) {
+__global__ void __launch_bounds__(kWave, (UNIT && P == 32) ? 8 : 1) k_dp_reg(DevIndex ix, DevBatch b, DevWork w, Params prm) {
   const uint32_t lane = lane_id();
   unsigned long long j_lo, j_hi;
   dp_class_range(b, w, P == 32 ? 0u : 1u, j_lo, j_hi);
