@@ -691,6 +691,7 @@ int fmx_set_option(fmx_index* ix, const char* name, int64_t value) {
     else if (n == "contexts") d->set_contexts((uint32_t)std::max<int64_t>(value, 1));
     else if (n == "probe_count") d->set_probe_count(value != 0);
     else if (n == "serial") d->set_serial(value != 0);
+    else if (n == "small_path") d->set_small_path(value != 0);
     else if (n == "turns") d->set_turns((uint32_t)std::max<int64_t>(value, 0));
     else if (n == "expand_order") d->set_expand_order((uint32_t)std::max<int64_t>(value, 0));
     else if (n == "b_grid") d->set_b_grid((uint32_t)std::max<int64_t>(value, 1));

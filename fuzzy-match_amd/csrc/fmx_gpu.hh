@@ -87,6 +87,7 @@ class DeviceIndex {
   // d_keep / d_keep_count (optional, in the HBM of device()): the records are also left there
   void match_host(const HostIndex& h, const Params& prm, const HostBatchView& b, Rec* out, uint32_t* out_count,
                   uint32_t* out_total, uint32_t cap, Stats* st, Rec* d_keep = nullptr, uint32_t* d_keep_count = nullptr);
+  void     set_small_path(bool on);      // micro-batches (<= 512 queries) in one kernel launch (fmx_small.hip.hh)
   // FuzzyMatch::subsequence (src/fuzzy_match.cc:250-365) for a batch of tokenised patterns; one record per query
   void subsequence_host(const HostIndex& h, const HostBatchView& b, uint32_t number_of_matches, bool no_perfect, int min_subseq_length,
                         float min_subseq_ratio, bool idf_weighting, Rec* out, uint32_t* out_found, uint32_t* out_pos);
@@ -94,6 +95,11 @@ class DeviceIndex {
   std::vector<uint32_t> sub_bounds_from_device(const uint32_t* d_q_off, uint64_t nq, uint32_t* p_max, void* stream);
 
  private:
+  // the pipeline for a host batch (match_host tries the one-launch path for micro-batches first)
+  void match_host_full(const HostIndex& h, const Params& prm, const HostBatchView& b, Rec* out, uint32_t* out_count,
+                       uint32_t* out_total, uint32_t cap, Stats* st, Rec* d_keep, uint32_t* d_keep_count);
+  bool match_host_small(const HostIndex& h, const Params& prm, const HostBatchView& b, Rec* out, uint32_t* out_count,
+                        uint32_t* out_total, uint32_t cap, Stats* st);
   Impl* impl_;
 };
 

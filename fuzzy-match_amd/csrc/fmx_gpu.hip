@@ -26,6 +26,7 @@
 
 #include "fmx_kernels.hip.hh"
 #include "fmx_subseq.hip.hh"
+#include "fmx_small.hip.hh"
 #include "fmx_derive.hip.hh"
 
 namespace fmx {
@@ -141,6 +142,7 @@ struct Ctx {
   hipEvent_t  ev[2 * kNumStages]{};   // [2 s], [2 s + 1]: start / end of stage s (the last stage's pair lives on the side stream)
   hipEvent_t  ev_fork = nullptr, ev_join = nullptr, ev_cmin = nullptr, ev_a = nullptr, ev_in[kMaxPassesInFlight]{}, ev_done = nullptr;
   unsigned long long* h_ctr = nullptr;  // pinned: the pass counters land here
+  char* h_small = nullptr; char* d_small = nullptr; size_t h_small_bytes = 0;  // pinned block of the one-launch path (host / device view)
   unsigned long long* h_ctr_group = nullptr;  // pinned: one slot per pass of an asynchronous group
   std::vector<hipEvent_t> ev_pass;      // "pass done" events of an asynchronous group
   bool ok = false;
@@ -181,6 +183,7 @@ struct Ctx {
     if (ev_a) (void)hipEventDestroy(ev_a);
     if (ev_done) (void)hipEventDestroy(ev_done);
     if (h_ctr) (void)hipHostFree(h_ctr);
+    if (h_small) (void)hipHostFree(h_small);
     if (h_ctr_group) (void)hipHostFree(h_ctr_group);
     for (auto& e : ev_pass) if (e) (void)hipEventDestroy(e);
   }
@@ -217,6 +220,9 @@ struct DeviceIndex::Impl {
   bool     probe_count = false;
   bool     serial = false;        // measurement runs: no side stream, every kernel alone on the GPU
   uint32_t expand_order = 1, b_grid = kExpandExtraGrid;
+  // micro-batches in one kernel launch (fmx_small.hip.hh); FMX_SMALL_PATH=0 in the environment starts with it off (the test
+  // suite does, so that its many small batches keep exercising the pipeline; tests/test_gpu_small.py turns it on)
+  bool     small_path = [] { const char* e = getenv("FMX_SMALL_PATH"); return e ? atoi(e) != 0 : true; }();
   uint32_t heavy_grid = kHeavyGrid;      // workgroups of k_expand_h (it runs beside the light queries' kernel: it must not fill every wave slot)
   uint32_t light_max = kLightMaxDefault;  // queries with at most this many hits, all in short ranges, skip phase A (0 = off)
   // context pool
@@ -251,6 +257,7 @@ struct CtxLease {
   explicit CtxLease(DeviceIndex::Impl& m_) : m(m_), c(m_.acquire()) {
     if (!c->ok) { Ctx* bad = c; c = nullptr; m.release(bad); throw GpuError("context initialisation failed earlier"); }
   }
+  void release_now() { if (c) { m.release(c); c = nullptr; } }
   ~CtxLease() { if (c) m.release(c); }
 };
 
@@ -279,6 +286,7 @@ void     DeviceIndex::set_heavy_min(uint32_t n) { impl_->heavy_min = n; }
 void     DeviceIndex::set_probe_count(bool on) { impl_->probe_count = on; }
 void     DeviceIndex::set_serial(bool on) { impl_->serial = on; }
 void     DeviceIndex::set_turns(uint32_t n) { impl_->turns = n; }
+void     DeviceIndex::set_small_path(bool on) { impl_->small_path = on; }
 void     DeviceIndex::set_expand_order(uint32_t n) { impl_->expand_order = n; }
 void     DeviceIndex::set_b_grid(uint32_t n) { impl_->b_grid = std::min<uint32_t>(std::max<uint32_t>(n, 64u), 65536u); }
 void     DeviceIndex::set_heavy_grid(uint32_t n) { impl_->heavy_grid = std::min<uint32_t>(std::max<uint32_t>(n, 64u), 65536u); }
@@ -1006,6 +1014,89 @@ __global__ void k_rebase(uint32_t* off, uint32_t n, uint32_t base) {
 void DeviceIndex::match_host(const HostIndex& h, const Params& prm, const HostBatchView& hb, Rec* out,
                              uint32_t* out_count, uint32_t* out_total, uint32_t cap, Stats* st, Rec* d_keep,
                              uint32_t* d_keep_count) {
+  if (!d_keep && match_host_small(h, prm, hb, out, out_count, out_total, cap, st)) return;
+  match_host_full(h, prm, hb, out, out_count, out_total, cap, st, d_keep, d_keep_count);
+}
+
+// A micro-batch in one kernel launch (fmx_small.hip.hh): inputs and results live in a pinned block of the context that the
+// kernel reads and writes directly (no copy commands: one launch, one synchronisation).  Queries the kernel does not take
+// (long patterns, many hits, long ranges, many survivors) go through the pipeline as a sub-batch afterwards.
+// Returns false when the batch or the parameters are not eligible.
+bool DeviceIndex::match_host_small(const HostIndex& h, const Params& prm, const HostBatchView& hb, Rec* out, uint32_t* out_count,
+                                   uint32_t* out_total, uint32_t cap, Stats* st) {
+  Impl& m = *impl_;
+  const uint64_t nq = hb.nq;
+  if (!m.small_path || nq == 0 || nq > kSmallMaxQueries || hb.q_real || hb.q_itok || m.d.itok || cap == 0 || cap > 4096 ||
+      !small_path_params_ok(prm) || m.device < 0)
+    return false;
+  const uint32_t base = hb.q_off[0];
+  const uint64_t nt = hb.q_off[nq] - base;
+  if (nt > (uint64_t)nq * 256) return false;
+  const auto t0 = std::chrono::steady_clock::now();
+  HIP_TRY(hipSetDevice(m.device));
+  CtxLease lease(m);
+  Ctx& c = *lease.c;
+  // layout of the pinned block: offsets | tokens | counts | totals | deferred | records
+  const size_t n_words = (nq + 1) + nt + 3 * nq;
+  const size_t bytes = ((n_words * 4 + 15) & ~(size_t)15) + nq * cap * sizeof(Rec);
+  if (bytes > c.h_small_bytes) {
+    if (c.h_small) (void)hipHostFree(c.h_small);
+    c.h_small = nullptr; c.h_small_bytes = 0;
+    const size_t want = std::max<size_t>(bytes + bytes / 2, 1u << 20);
+    HIP_TRY(hipHostMalloc((void**)&c.h_small, want, hipHostMallocDefault));
+    HIP_TRY(hipHostGetDevicePointer((void**)&c.d_small, c.h_small, 0));
+    c.h_small_bytes = want;
+  }
+  uint32_t* hw = (uint32_t*)c.h_small;
+  uint32_t* h_off = hw; uint32_t* h_tok = h_off + nq + 1; uint32_t* h_cnt = h_tok + nt; uint32_t* h_tot = h_cnt + nq; uint32_t* h_def = h_tot + nq;
+  Rec* h_rec = (Rec*)(c.h_small + ((n_words * 4 + 15) & ~(size_t)15));
+  for (uint64_t q = 0; q <= nq; q++) h_off[q] = hb.q_off[q] - base;
+  memcpy(h_tok, hb.q_tok + base, nt * 4);
+  const size_t dshift = c.d_small - c.h_small;  // device view of the same block
+  auto dv = [&](void* p) { return (void*)((char*)p + dshift); };
+  SmallArgs a;
+  a.q_off = (const uint32_t*)dv(h_off); a.q_tok = (const uint32_t*)dv(h_tok); a.nq = (uint32_t)nq; a.cap = cap;
+  const int use_sig = prm.ins >= 0.f && prm.del >= 0.f && prm.rep >= 0.f;
+  a.heavy_min = (use_sig && m.d.planes && m.heavy_min) ? std::max<uint32_t>(m.heavy_min, 256u) : 0xffffffffu;
+  a.out = (Rec*)dv(h_rec); a.out_count = (uint32_t*)dv(h_cnt); a.out_total = (uint32_t*)dv(h_tot); a.deferred = (uint32_t*)dv(h_def);
+  hipLaunchKernelGGL(k_match_small, dim3((unsigned)nq), dim3(kWave), 0, c.stream, m.d, a, prm);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(c.stream));
+  std::vector<uint32_t> rest;
+  for (uint64_t q = 0; q < nq; q++) {
+    if (h_def[q]) { rest.push_back((uint32_t)q); continue; }
+    out_count[q] = h_cnt[q];
+    if (out_total) out_total[q] = h_tot[q];
+    memcpy(out + q * cap, h_rec + q * cap, (size_t)h_cnt[q] * sizeof(Rec));
+  }
+  if (!rest.empty()) {  // the pipeline for what is left, as a batch of its own
+    std::vector<uint32_t> r_off(rest.size() + 1, 0), r_tok;
+    for (size_t k = 0; k < rest.size(); k++) {
+      const uint32_t q = rest[k];
+      r_tok.insert(r_tok.end(), hb.q_tok + hb.q_off[q], hb.q_tok + hb.q_off[q + 1]);
+      r_off[k + 1] = (uint32_t)r_tok.size();
+    }
+    if (r_tok.empty()) r_tok.push_back(0);
+    std::vector<Rec> r_out(rest.size() * cap);
+    std::vector<uint32_t> r_cnt(rest.size()), r_tot(rest.size());
+    HostBatchView sub;
+    sub.nq = rest.size(); sub.q_off = r_off.data(); sub.q_tok = r_tok.data();
+    lease.release_now();  // the pipeline leases its own context
+    match_host_full(h, prm, sub, r_out.data(), r_cnt.data(), r_tot.data(), cap, nullptr, nullptr, nullptr);
+    for (size_t k = 0; k < rest.size(); k++) {
+      const uint32_t q = rest[k];
+      out_count[q] = r_cnt[k];
+      if (out_total) out_total[q] = r_tot[k];
+      memcpy(out + (size_t)q * cap, r_out.data() + k * cap, (size_t)r_cnt[k] * sizeof(Rec));
+    }
+  }
+  if (st) st->ms_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return true;
+}
+
+void DeviceIndex::match_host_full(const HostIndex& h, const Params& prm, const HostBatchView& hb, Rec* out,
+                                  uint32_t* out_count, uint32_t* out_total, uint32_t cap, Stats* st, Rec* d_keep,
+                                  uint32_t* d_keep_count) {
   Impl& m = *impl_;
   if (m.device < 0) throw GpuError("index is not on a device");
   HIP_TRY(hipSetDevice(m.device));
