@@ -1090,7 +1090,10 @@ bool DeviceIndex::match_host_small(const HostIndex& h, const Params& prm, const 
       memcpy(out + (size_t)q * cap, r_out.data() + k * cap, (size_t)r_cnt[k] * sizeof(Rec));
     }
   }
-  if (st) st->ms_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (st) {
+    st->ms_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    st->n_small += nq - rest.size();
+  }
   return true;
 }
 

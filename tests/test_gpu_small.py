@@ -24,12 +24,16 @@ def _index(fmx, gpu_device, c_off, c_tok, vs, **kw):
 
 
 def _check_in_slices(fmx, ix, o, q_off, q_tok, kw, cap, step, label):
+    """Returns (queries answered by the one-launch kernel, queries in all)."""
     oo, oc = o.match_batch(oracle_lib.Params(**kw), q_off, q_tok, cap, nthreads=oracle_lib.effective_cpus())
     nq = len(q_off) - 1
+    n_small = 0
     for lo in range(0, nq, step):
         hi = min(nq, lo + step)
-        go, gc, gt = ix.match_batch(fmx.Params(**kw), q_off[lo:hi + 1], q_tok, cap=cap)  # absolute offsets into q_tok
+        go, gc, gt, st = ix.match_batch(fmx.Params(**kw), q_off[lo:hi + 1], q_tok, cap=cap, want_stats=True)  # absolute offsets into q_tok
         workloads.compare(oo[lo:hi], oc[lo:hi], go, gc, f"{label} [{lo}:{hi}]")
+        n_small += int(st.n_small)
+    return n_small, nq
 
 
 def test_small_path_synthetic(fmx, gpu_device):
@@ -38,7 +42,11 @@ def test_small_path_synthetic(fmx, gpu_device):
     o = workloads.build_oracle(c_off, c_tok, vs, sfreq=ix.array("sfreq"))
     for name in ["C1", "C3", "no_perfect", "fuzzy_zero", "ml_negative", "wide_all", "C4", "C5", "costs_101"]:  # the last four: partly / not eligible
         kw = workloads.PARAM_SETS[name]
-        _check_in_slices(fmx, ix, o, q_off, q_tok, kw, kw["nmatch"] or 64, 200, name)
+        n_small, nq = _check_in_slices(fmx, ix, o, q_off, q_tok, kw, kw["nmatch"] or 64, 200, name)
+        if name in ("C1", "C3", "no_perfect", "fuzzy_zero", "ml_negative"):
+            assert n_small > 0.8 * nq, (name, n_small, nq)   # nearly every query is answered by the one kernel
+        elif name != "wide_all":
+            assert n_small == 0, (name, n_small)             # idf / contrast / non-unit costs: the pipeline
     # one query per call, and an nmatch below / above what is found
     kw = dict(fuzzy=0.5, nmatch=2)
     _check_in_slices(fmx, ix, o, q_off[:41], q_tok, kw, 2, 1, "singles")
@@ -59,7 +67,8 @@ def test_small_path_dense_and_edges(fmx, gpu_device):
     for kw in [dict(fuzzy=0.6, nmatch=5), dict(fuzzy=0.0, nmatch=10, min_subseq_length=4, min_subseq_ratio=0.2),
                dict(fuzzy=0.4, nmatch=3, min_subseq_length=1, min_subseq_ratio=0), dict(fuzzy=0.8, nmatch=1, no_perfect=True),
                dict(fuzzy=0.5, nmatch=60, contrast_buffer=60, min_subseq_length=2, min_subseq_ratio=0)]:
-        _check_in_slices(fmx, ix, o, q_off, q_tok, kw, kw["nmatch"], 125, str(kw))
+        n_small, nq = _check_in_slices(fmx, ix, o, q_off, q_tok, kw, kw["nmatch"], 125, str(kw))
+        assert 0 < n_small < nq, (kw, n_small, nq)  # some queries answered here, some handed back to the pipeline
 
 
 def test_small_path_long_sentences_and_patterns(fmx, gpu_device):
