@@ -423,61 +423,53 @@ struct Request {
   uint32_t        count = 0, total = 0;
   int             status = FMX_OK;
   std::string     err;
-  std::atomic<bool> done{false};
+  // the caller sleeps on its own condition variable (one shared by all callers made every wake-up queue for one mutex)
+  std::mutex              m;
+  std::condition_variable cv;
+  bool                    done = false, lead = false;  // under m
 };
 
+// Flat combining: there are no dispatcher threads.  A caller that finds fewer than kLeaders batches in flight becomes a
+// leader: it waits a moment for company (at most coalesce_us, less once as many requests as last time are waiting), takes
+// every pending request with its own parameters, runs the batch on its own thread and wakes the others.  A request thus
+// costs one sleep / wake-up for its followers (each on its own condition variable) and none for its leader — with dispatcher threads every batch paid two
+// hand-overs (caller -> dispatcher -> caller), which, once a micro-batch is answered in ~60 us, was most of a call.
 struct Coalescer {
+  static constexpr int kLeaders = 2;  // batches in flight at once (their kernels overlap on the GPU)
   fmx_index*               ix;
   std::mutex               mu;
-  std::condition_variable  cv_work, cv_done;
+  std::condition_variable  cv_more;   // a gathering leader: another request arrived
   std::deque<Request*>     pending;
-  std::vector<std::thread> workers;
-  bool                     stop = false;
+  int                      leaders = 0, gathering = 0;  // a leader that is still waiting for company takes every arrival
   uint32_t                 last_batch = 1;
-  uint32_t                 n_blocked = 0;   // callers asleep on cv_done (under mu)
-  std::atomic<uint32_t>    n_pending{0};    // == pending.size(), readable without the lock
 
-  explicit Coalescer(fmx_index* ix_, int n_workers) : ix(ix_) {
-    for (int k = 0; k < n_workers; k++) workers.emplace_back([this]() { loop(); });
-  }
-  ~Coalescer() {
-    { std::lock_guard<std::mutex> lk(mu); stop = true; }
-    cv_work.notify_all();
-    for (auto& t : workers) t.join();
-  }
-  // (Spinning on the request instead of sleeping was tried when the one-launch path brought the answer down to ~60 us: it
-  // gains nothing at 16 callers and halves the rate at 64 — callers outnumber the cores and starve the dispatchers.)
+  explicit Coalescer(fmx_index* ix_, int) : ix(ix_) {}
+
   void submit_and_wait(Request& r) {
     std::unique_lock<std::mutex> lk(mu);
     pending.push_back(&r);
-    n_pending.store((uint32_t)pending.size(), std::memory_order_release);
-    cv_work.notify_one();
-    n_blocked++;
-    cv_done.wait(lk, [&]() { return r.done.load(std::memory_order_acquire); });
-    n_blocked--;
-  }
-  void loop() {
-    struct Pinned {
-      void* p = nullptr; size_t cap = 0;
-      void* get(size_t n) { if (n > cap) { gpu_host_free(p); p = gpu_host_alloc(n + n / 2); cap = p ? n + n / 2 : 0; } return p; }
-      ~Pinned() { gpu_host_free(p); }
-    } b_off, b_tok, b_real, b_itok, b_out, b_cnt, b_tot;
+    cv_more.notify_one();
     std::vector<Request*> batch;
     for (;;) {
-      {
-        // under load the next requests arrive within microseconds of the last answers: look for them before going to sleep
-        for (const auto t0 = std::chrono::steady_clock::now(); n_pending.load(std::memory_order_acquire) == 0 && !stop &&
-                                                                std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(200);)
-          __builtin_ia32_pause();
-        std::unique_lock<std::mutex> lk(mu);
-        cv_work.wait(lk, [&]() { return stop || !pending.empty(); });
-        if (stop && pending.empty()) return;
-        // idle start: give the other callers a moment to arrive (at most coalesce_us, less once as many as last
-        // time are waiting)
-        const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(ix->coalesce_us);
-        while (!stop && pending.size() < last_batch && std::chrono::steady_clock::now() < deadline)
-          cv_work.wait_until(lk, deadline);
-        batch.clear();
+      if (leaders >= kLeaders || gathering != 0 || pending.empty()) {
+        // sleep until a leader has answered this request, or hands this caller a free seat
+        lk.unlock();
+        {
+          std::unique_lock<std::mutex> rl(r.m);
+          r.cv.wait(rl, [&]() { return r.done || r.lead; });
+          r.lead = false;
+          if (r.done) return;
+        }
+        lk.lock();
+        continue;
+      }
+      // ---- this caller leads a batch ----
+      leaders++; gathering++;
+      const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(ix->coalesce_us);
+      while (pending.size() < last_batch && std::chrono::steady_clock::now() < deadline) cv_more.wait_until(lk, deadline);
+      gathering--;
+      batch.clear();
+      if (!pending.empty()) {
         const fmx_params first = pending.front()->prm;
         const uint32_t cap = pending.front()->cap;
         for (auto it = pending.begin(); it != pending.end() && batch.size() < 65536;) {
@@ -485,61 +477,80 @@ struct Coalescer {
           else ++it;
         }
         last_batch = (uint32_t)batch.size();
-        n_pending.store((uint32_t)pending.size(), std::memory_order_release);
-        if (!pending.empty()) cv_work.notify_one();  // other parameter sets: another dispatcher may take them
+        if (!pending.empty() && leaders < kLeaders) offer_seat();  // other parameter sets: someone else may lead them
       }
-      const uint64_t nq = batch.size();
-      uint64_t nt = 0;
-      bool any_real = ix->host.real_differs, any_itok = false;
-      for (auto* r : batch) { nt += r->p; any_itok = any_itok || r->itok; }
-      const uint32_t cap = batch[0]->cap;
-      uint32_t* q_off = (uint32_t*)b_off.get((nq + 1) * 4);
-      uint32_t* q_tok = (uint32_t*)b_tok.get((nt + 1) * 4);
-      uint32_t* q_real = any_real ? (uint32_t*)b_real.get((nt + 1) * 4) : nullptr;
-      uint32_t* q_itok = any_itok ? (uint32_t*)b_itok.get((nt + nq + 1) * 4) : nullptr;
-      fmx_match* out = (fmx_match*)b_out.get(nq * cap * sizeof(fmx_match));
-      uint32_t* cnt = (uint32_t*)b_cnt.get(nq * 4);
-      uint32_t* tot = (uint32_t*)b_tot.get(nq * 4);
-      int status = FMX_OK;
-      std::string err;
-      if (!q_off || !q_tok || (any_real && !q_real) || (any_itok && !q_itok) || !out || !cnt || !tot) {
-        status = FMX_E_NOMEM; err = "out of pinned host memory";
-      } else {
-        uint32_t o = 0;
-        for (uint64_t q = 0; q < nq; q++) {
-          const Request& r = *batch[q];
-          q_off[q] = o;
-          memcpy(q_tok + o, r.wids, (size_t)r.p * 4);
-          if (q_real) { if (r.real) memcpy(q_real + o, r.real, (size_t)r.p * 4); else real_from_forms(ix, r.wids, r.p, q_real + o); }
-          if (q_itok) { if (r.itok) memcpy(q_itok + o + q, r.itok, (size_t)(r.p + 1) * 4); else memset(q_itok + o + q, 0, (size_t)(r.p + 1) * 4); }
-          o += r.p;
+      bool mine = false;
+      if (!batch.empty()) {
+        lk.unlock();
+        int status = FMX_OK;
+        std::string err;
+        run(batch, status, err);
+        for (Request* q : batch) {
+          if (q == &r) { mine = true; r.status = status; if (status != FMX_OK) r.err = err; continue; }
+          std::lock_guard<std::mutex> ql(q->m);  // notified under its mutex: the request lives on its caller's stack
+          q->status = status;
+          if (status != FMX_OK) q->err = err;
+          q->done = true;
+          q->cv.notify_one();
         }
-        q_off[nq] = o;
-        status = guarded([&]() {
-          HostBatchView v;
-          v.nq = nq; v.q_off = q_off; v.q_tok = q_tok; v.q_real = q_real; v.q_itok = q_itok;
-          match_on_devices(ix, make_params(ix, &batch[0]->prm), v, out, cnt, tot, cap, nullptr);
-          return (int)FMX_OK;
-        });
-        if (status != FMX_OK) err = g_err;
+        lk.lock();
       }
-      bool wake = false;
-      {
-        std::lock_guard<std::mutex> lk(mu);
-        for (uint64_t q = 0; q < nq; q++) {
-          Request& r = *batch[q];
-          r.status = status;
-          if (status == FMX_OK) {
-            r.count = cnt[q]; r.total = tot[q];
-            memcpy(r.out, out + q * cap, (size_t)cnt[q] * sizeof(fmx_match));
-          } else r.err = err;
-          r.done.store(true, std::memory_order_release);  // the request (on its caller's stack) must not be touched after this
-        }
-        wake = n_blocked != 0;
-      }
-      if (wake) cv_done.notify_all();
+      leaders--;
+      if (!pending.empty()) offer_seat();
+      if (mine) return;
     }
   }
+
+  // under mu: wakes the owner of the oldest pending request so that it leads the next batch
+  void offer_seat() {
+    Request* q = pending.front();
+    std::lock_guard<std::mutex> ql(q->m);
+    q->lead = true;
+    q->cv.notify_one();
+  }
+
+  // staging buffers of the calling thread (the one-launch path copies them into its pinned block; larger batches are rare)
+  struct Staging { std::vector<uint32_t> off, tok, real, itok, cnt, tot; std::vector<fmx_match> out; };
+
+  void run(const std::vector<Request*>& batch, int& status, std::string& err) {
+    static thread_local Staging st;
+    const uint64_t nq = batch.size();
+    uint64_t nt = 0;
+    const bool any_real = ix->host.real_differs;
+    bool any_itok = false;
+    for (auto* r : batch) { nt += r->p; any_itok = any_itok || r->itok; }
+    const uint32_t cap = batch[0]->cap;
+    try {
+      st.off.resize(nq + 1); st.tok.resize(nt + 1); st.cnt.resize(nq); st.tot.resize(nq); st.out.resize(nq * cap);
+      if (any_real) st.real.resize(nt + 1);
+      if (any_itok) st.itok.resize(nt + nq + 1);
+    } catch (const std::exception&) { status = FMX_E_NOMEM; err = "out of host memory"; return; }
+    uint32_t* q_real = any_real ? st.real.data() : nullptr;
+    uint32_t* q_itok = any_itok ? st.itok.data() : nullptr;
+    uint32_t o = 0;
+    for (uint64_t q = 0; q < nq; q++) {
+      const Request& r = *batch[q];
+      st.off[q] = o;
+      memcpy(st.tok.data() + o, r.wids, (size_t)r.p * 4);
+      if (q_real) { if (r.real) memcpy(q_real + o, r.real, (size_t)r.p * 4); else real_from_forms(ix, r.wids, r.p, q_real + o); }
+      if (q_itok) { if (r.itok) memcpy(q_itok + o + q, r.itok, (size_t)(r.p + 1) * 4); else memset(q_itok + o + q, 0, (size_t)(r.p + 1) * 4); }
+      o += r.p;
+    }
+    st.off[nq] = o;
+    status = guarded([&]() {
+      HostBatchView v;
+      v.nq = nq; v.q_off = st.off.data(); v.q_tok = st.tok.data(); v.q_real = q_real; v.q_itok = q_itok;
+      match_on_devices(ix, make_params(ix, &batch[0]->prm), v, st.out.data(), st.cnt.data(), st.tot.data(), cap, nullptr);
+      return (int)FMX_OK;
+    });
+    if (status != FMX_OK) { err = g_err; return; }
+    for (uint64_t q = 0; q < nq; q++) {  // results into the callers' buffers (they sleep until `done`)
+      Request& r = *batch[q];
+      r.count = st.cnt[q]; r.total = st.tot[q];
+      memcpy(r.out, st.out.data() + q * cap, (size_t)st.cnt[q] * sizeof(fmx_match));
+    }
+  }
+
 };
 
 fmx_index::~fmx_index() { co.reset(); }
