@@ -157,7 +157,7 @@ struct Ctx {
     HIP_TRY(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&ev_cmin, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&ev_a, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming | hipEventBlockingSync));  // the host sleeps on it (see ev_pass)
     for (auto& e : ev_in) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIP_TRY(hipHostMalloc((void**)&h_ctr, kNumCounters * sizeof(unsigned long long), hipHostMallocDefault));
     zero_blk.ensure(zero_words());
@@ -912,7 +912,9 @@ static void run_passes(DeviceIndex::Impl& m, Ctx& c, const Params& prm_in, const
   if (!c.h_ctr_group) HIP_TRY(hipHostMalloc((void**)&c.h_ctr_group, (size_t)kAsyncGroup * kNumCounters * sizeof(unsigned long long), hipHostMallocDefault));
   while (c.ev_pass.size() < kAsyncGroup) {
     hipEvent_t e;
-    HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    // the host waits milliseconds on these: it sleeps instead of spinning (one process per GPU with three calls in flight
+    // each would otherwise keep 24 cores of an 8-GPU node busy doing nothing)
+    HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventBlockingSync));
     c.ev_pass.push_back(e);
   }
   for (uint32_t g0 = 0; g0 < n_sub; g0 += kAsyncGroup) {
@@ -1232,7 +1234,8 @@ void DeviceIndex::match_host_full(const HostIndex& h, const Params& prm, const H
   if (chain_lk.owns_lock()) chain_lk.unlock();
   turn.release();
   const auto a = std::chrono::steady_clock::now();
-  HIP_TRY(hipStreamSynchronize(c.d2h));
+  HIP_TRY(hipEventRecord(c.ev_done, c.d2h));
+  HIP_TRY(hipEventSynchronize(c.ev_done));
   ms_d2h += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
   if (st) {
     st->ms_h2d += ms_h2d;   // host time spent enqueuing / staging; with pinned buffers the copies overlap the passes
