@@ -160,7 +160,7 @@ def main():
     ix.finalize()
     ix.to_device(local_rank)
     ix.set_option("contexts", max(2, args.threads))
-    for opt in ("FMX_SUB_QUERIES", "FMX_HOST_SUB_QUERIES", "FMX_HEAVY_MIN", "FMX_SERIAL", "FMX_LIGHT_MAX", "FMX_HEAVY_GRID", "FMX_EXPAND_ORDER", "FMX_B_GRID", "FMX_TURNS"):
+    for opt in ("FMX_SUB_QUERIES", "FMX_HOST_SUB_QUERIES", "FMX_HEAVY_MIN", "FMX_SERIAL", "FMX_LIGHT_MAX", "FMX_HEAVY_GRID", "FMX_EXPAND_ORDER", "FMX_B_GRID", "FMX_TURNS", "FMX_PAIR_FINISH"):
         if os.environ.get(opt):
             ix.set_option(opt[4:].lower(), int(os.environ[opt]))
     info = ix.info()

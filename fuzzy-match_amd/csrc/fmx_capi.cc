@@ -716,6 +716,7 @@ int fmx_set_option(fmx_index* ix, const char* name, int64_t value) {
     else if (n == "contexts") d->set_contexts((uint32_t)std::max<int64_t>(value, 1));
     else if (n == "probe_count") d->set_probe_count(value != 0);
     else if (n == "serial") d->set_serial(value != 0);
+    else if (n == "pair_finish") d->set_pair_finish(value != 0);
     else if (n == "small_path") d->set_small_path(value != 0);
     else if (n == "turns") d->set_turns((uint32_t)std::max<int64_t>(value, 0));
     else if (n == "expand_order") d->set_expand_order((uint32_t)std::max<int64_t>(value, 0));

@@ -222,6 +222,7 @@ struct DeviceIndex::Impl {
   uint32_t expand_order = 1, b_grid = kExpandExtraGrid;
   // micro-batches in one kernel launch (fmx_small.hip.hh); FMX_SMALL_PATH=0 in the environment starts with it off (the test
   // suite does, so that its many small batches keep exercising the pipeline; tests/test_gpu_small.py turns it on)
+  bool     pair_finish = [] { const char* e = getenv("FMX_PAIR_FINISH"); return e ? atoi(e) != 0 : true; }();  // design-time switch
   bool     small_path = [] { const char* e = getenv("FMX_SMALL_PATH"); return e ? atoi(e) != 0 : true; }();
   uint32_t heavy_grid = kHeavyGrid;      // workgroups of k_expand_h (it runs beside the light queries' kernel: it must not fill every wave slot)
   uint32_t light_max = kLightMaxDefault;  // queries with at most this many hits, all in short ranges, skip phase A (0 = off)
@@ -287,6 +288,7 @@ void     DeviceIndex::set_probe_count(bool on) { impl_->probe_count = on; }
 void     DeviceIndex::set_serial(bool on) { impl_->serial = on; }
 void     DeviceIndex::set_turns(uint32_t n) { impl_->turns = n; }
 void     DeviceIndex::set_small_path(bool on) { impl_->small_path = on; }
+void     DeviceIndex::set_pair_finish(bool on) { impl_->pair_finish = on; }
 void     DeviceIndex::set_expand_order(uint32_t n) { impl_->expand_order = n; }
 void     DeviceIndex::set_b_grid(uint32_t n) { impl_->b_grid = std::min<uint32_t>(std::max<uint32_t>(n, 64u), 65536u); }
 void     DeviceIndex::set_heavy_grid(uint32_t n) { impl_->heavy_grid = std::min<uint32_t>(std::max<uint32_t>(n, 64u), 65536u); }
@@ -598,6 +600,8 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
     tick(); tick();
     // light queries (k_caps): at most light_max hits, all in short ranges, pattern of at most one wave
     const uint32_t light_max = b.nq ? std::min<uint32_t>(m.light_max, kPhaseBChunk) : 0u;
+    // two queries per wave in the last kernel (k_finish_pair): no contrastive rerank, lowest_costs fits half a wave
+    const bool pair_finish = m.pair_finish && !(prm.contrast > 0.f) && prm.cbuf > 0 && prm.cbuf <= (int)kPairMax - 2;
     {
       hipLaunchKernelGGL(k_caps, dim3((b.nq + 1 + 1023) / 1024), dim3(1024), 0, stream, b, w, c.items.p, item_cap, c.s_max, c.heavy_div, light_max);
       // one scan, two arrays: queue offsets of the queries phase A walks, segment offsets of the light queries
@@ -691,7 +695,7 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
       hipLaunchKernelGGL(k_classify, dim3((n_scan + 255) / 256), dim3(256), 0, stream, b, w, full ? 1 : 0);
       hipLaunchKernelGGL(k_scan_lb<3>, dim3(scan_tiles), dim3(kScanThreads), 0, stream, w.c_in, w.c_off, (size_t)n_scan, n_scan,
                          c.scan_state(2), c.scan_ticket(2));
-      hipLaunchKernelGGL(k_cmap, dim3((b.nq + 255) / 256), dim3(256), 0, stream, b, w, full ? 1 : 0, c.fin_list.p);
+      hipLaunchKernelGGL(k_cmap, dim3((b.nq + 1023) / 1024), dim3(1024), 0, stream, b, w, full ? 1 : 0, c.fin_list.p, pair_finish ? kPairMax : (uint32_t)kWave);
     }
     tick(); tick();
     {
@@ -735,7 +739,10 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
       fork();
       hipLaunchKernelGGL((k_finish<kLdsSortMax, true>), dim3(2048), dim3(kWave), 0, side, m.d, b, w, prm, DevScratch{c.keys.p, c.vals.p, c.f0.p, c.f1.p}, cap,
                          d_out, d_out_count, d_out_total, c.contrast_list.p, c.fin_list.p);
-      hipLaunchKernelGGL((k_finish<64, false>), dim3(b.nq), dim3(kWave), 0, stream, m.d, b, w, prm, DevScratch{c.keys.p, c.vals.p, c.f0.p, c.f1.p}, cap, d_out,
+      if (pair_finish)
+        hipLaunchKernelGGL(k_finish_pair, dim3((b.nq + 1) / 2), dim3(kWave), 0, stream, b, w, prm, cap, d_out, d_out_count, d_out_total);
+      else
+        hipLaunchKernelGGL((k_finish<64, false>), dim3(b.nq), dim3(kWave), 0, stream, m.d, b, w, prm, DevScratch{c.keys.p, c.vals.p, c.f0.p, c.f1.p}, cap, d_out,
                          d_out_count, d_out_total, c.contrast_list.p, c.fin_list.p);
       join();
       const DevScratch sc{c.keys.p, c.vals.p, c.f0.p, c.f1.p};

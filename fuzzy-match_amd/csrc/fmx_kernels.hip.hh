@@ -2023,14 +2023,31 @@ __global__ void k_classify(DevBatch b, DevWork w, int full) {
 
 // lane per query: small candidate sets are written by their own lane, large ones by the whole wave
 constexpr uint32_t kCmapSmall = 16;
-__global__ void __launch_bounds__(256) k_cmap(DevBatch b, DevWork w, int full, uint32_t* fin_list) {
+__global__ void __launch_bounds__(1024) k_cmap(DevBatch b, DevWork w, int full, uint32_t* fin_list, uint32_t list_above) {
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t lane = lane_id();
   uint32_t n = 0;
   unsigned long long base = 0;
+  if (q < b.nq) n = w.q_cand[q];
+  {
+    // queries for k_finish<.., true> (replay + large sorter): ONE atomic per workgroup (same-address atomics retire one at a
+    // time: with the pair kernel a third of the waves list something)
+    __shared__ uint32_t s_wave[16];
+    __shared__ unsigned long long s_base;
+    const bool listed = n > list_above;
+    const unsigned long long lm = __ballot(listed);
+    const uint32_t wv = threadIdx.x >> 6, n_wv = blockDim.x >> 6;
+    if (lane == 0) s_wave[wv] = (uint32_t)__popcll(lm);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t tot = 0;
+      for (uint32_t k = 0; k < n_wv; k++) { const uint32_t c = s_wave[k]; s_wave[k] = tot; tot += c; }
+      s_base = tot ? atomicAdd(&w.counters[14], (unsigned long long)tot) : 0ull;
+    }
+    __syncthreads();
+    if (listed) fin_list[s_base + s_wave[wv] + __popcll(lm & ((1ull << lane) - 1ull))] = q;
+  }
   if (q < b.nq) {
-    n = w.q_cand[q];
-    if (n > kWave) fin_list[atomicAdd(&w.counters[14], 1ull)] = q;  // k_finish<.., true>: replay + large sorter
     if (n) {
       const size_t stride = (size_t)b.nq + 1;
       const uint32_t p = b.q_off[b.q_begin + q + 1] - b.q_off[b.q_begin + q];
@@ -2647,6 +2664,101 @@ constexpr uint32_t kContrastLds = 256;
 
 // MODE 3 = MODE 2 with the DP rows in HBM (g_rows: row_len x 64 floats per workgroup): indexed sentences too long for
 // the LDS rows.
+// k_finish_pair — two queries per wave (lanes 0..31 and 32..63) for the common case: at most kPairMax candidates each, no
+// contrastive rerank, lowest_costs of at most kPairMax - 2 entries.  The replay of the candidate loop is an instruction
+// stream per query whatever the number of candidates (the kernel is bound by VALU issue): sharing each instruction between
+// two queries halves it.  Same steps as k_finish's one-wave path: lowest_costs as a sorted array spread over the half's
+// lanes, cross-lane reads by ds_bpermute instead of v_readlane (the two halves walk different candidates).
+constexpr uint32_t kPairMax = 32;
+// wave_sort64_kv_n for the two halves of a wave at once: every half sorts ascending (the direction of the last merge stage
+// comes from the lane number inside the half; wave_sort64_kv_n<32> would sort lanes 32..63 descending)
+template <int N>
+__device__ __forceinline__ void half_sort64_kv_n(unsigned long long& key, uint32_t& val) {
+  const uint32_t hl = lane_id() & 31u;
+#pragma unroll
+  for (int k = 2; k <= N; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const uint32_t lo = __shfl_xor((uint32_t)key, j, 64), hi = __shfl_xor((uint32_t)(key >> 32), j, 64);
+      const uint32_t ov = __shfl_xor(val, j, 64);
+      const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+      const bool take_min = ((hl & k) == 0) == ((hl & j) == 0);
+      const bool other_less = other < key;  // keys are distinct (or both ~0): no tie handling needed
+      const bool take_other = take_min ? other_less : !other_less && other != key;
+      key = take_other ? other : key;
+      val = take_other ? ov : val;
+    }
+  }
+}
+__global__ void __launch_bounds__(kWave) k_finish_pair(DevBatch b, DevWork w, Params prm, uint32_t cap, Rec* out_rec,
+                                                       uint32_t* out_count, uint32_t* out_total) {
+  __shared__ float s_score[kWave];
+  __shared__ uint32_t s_sid[kWave], s_L[kWave];
+  const uint32_t lane = lane_id(), hl = lane & 31u, base = lane & 32u;
+  const uint32_t q = blockIdx.x * 2u + (lane >> 5);
+  const bool have = q < b.nq;
+  const uint32_t gq = b.q_begin + (have ? q : 0u);
+  const uint32_t n_cand = have ? w.q_cand[q] : 0u;
+  const bool act_q = have && n_cand != 0 && n_cand <= kPairMax;  // larger sets were queued by k_cmap for the list kernel
+  uint32_t p = 0;
+  bool maybe = false;
+  float my_cost = 0.f, my_M = 0.f, my_score = 0.f;
+  if (act_q) p = b.q_off[gq + 1] - b.q_off[gq];
+  if (act_q && hl < n_cand) {
+    const Cand cd = w.seg[w.q_seg[q] + hl];
+    const uint32_t slen = cd.longest >> 16;
+    my_cost = cd.score; my_M = cd.penalty; my_score = score_from_cost(cd.score);
+    s_sid[lane] = cd.sid; s_L[lane] = cd.longest & 0xffffu; s_score[lane] = my_score;
+    maybe = !(prm.no_perfect && cd.score == 0.f && slen == p);
+  }
+  uint32_t todo = (uint32_t)(__ballot(maybe) >> base);
+  float hv = FLT_MAX;  // v[0] = FLT_MAX, the reference's initial bound; lane hl of the half holds v[hl]
+  uint32_t n = 1, acc = 0;
+  while (__ballot(todo != 0)) {
+    const bool on = todo != 0;
+    const uint32_t k = on ? (uint32_t)__builtin_ctz(todo) : 0u;
+    todo &= todo - 1u;  // 0 stays 0
+    const float fc = __shfl(my_cost, (int)(base + k), 64);
+    const float Mk = __shfl(my_M, (int)(base + k), 64);
+    const float sc = __shfl(my_score, (int)(base + k), 64);
+    const float ub = __shfl(hv, (int)(base + n - 1u), 64);
+    const bool go = on && !(Mk > ub);  // replay_candidate_scored; the no_perfect rule is already in `todo`
+    // push(fc): behind the elements <= fc, the larger ones move up one lane
+    const uint32_t pos = (uint32_t)__popc((uint32_t)(__ballot(go && hl < n && hv <= fc) >> base));
+    const float up = __shfl_up(hv, 1, 64);
+    if (go) {
+      hv = hl == pos ? fc : ((hl > pos && hl <= n) ? up : hv);
+      n++;
+      if (sc < prm.fuzzy || (prm.cbuf > 0 && n > (uint32_t)prm.cbuf)) n--;  // pop: the largest goes
+      if (sc >= prm.fuzzy) acc |= 1u << k;
+    }
+  }
+  const uint32_t n_acc = (uint32_t)__popc(acc);
+  const uint32_t want = prm.nmatch == 0 ? n_acc : (prm.nmatch < n_acc ? prm.nmatch : n_acc);
+  const uint32_t emit = want < cap ? want : cap;
+  const bool mine = act_q && ((acc >> hl) & 1u);
+  // ascending key = score desc, s_id asc (sentence ids are unique within a candidate set); each half is sorted on its own
+  unsigned long long key = mine ? (((unsigned long long)(~float_key(my_score)) << 32) | s_sid[lane]) : ~0ull;
+  uint32_t idx = hl;
+  uint32_t n_max = n_cand <= kPairMax ? n_cand : 0u;
+  { const uint32_t o = __shfl_xor(n_max, 32, 64); n_max = o > n_max ? o : n_max; }
+  n_max = __builtin_amdgcn_readfirstlane(n_max);
+  if (n_max > 16) half_sort64_kv_n<32>(key, idx);
+  else if (n_max > 8) half_sort64_kv_n<16>(key, idx);
+  else if (n_max > 1) half_sort64_kv_n<8>(key, idx);
+  wave_lds_sync();
+  if (act_q && hl < emit) {
+    Rec r;
+    r.score = s_score[base + idx]; r.penalty = 0.f; r.max_subseq = (int32_t)s_L[base + idx]; r.s_id = s_sid[base + idx];
+    out_rec[(unsigned long long)gq * cap + hl] = r;
+  }
+  if (have && hl == 0 && n_cand <= kPairMax) {
+    w.q_acc[q] = act_q ? n_acc : 0u;
+    out_count[gq] = act_q ? emit : 0u;
+    if (out_total) out_total[gq] = act_q ? want : 0u;
+  }
+}
+
 template <int MODE>
 __global__ void __launch_bounds__(kWave) k_contrast(DevIndex ix, DevBatch b, DevWork w, Params prm, DevScratch sc,
                                                     uint32_t cap, Rec* out_rec, uint32_t* out_count,
