@@ -148,10 +148,25 @@ struct Ctx {
   bool ok = false;
 
   void init() {
+    // HIP maps streams onto a few hardware queues (four per priority class by default) and everything on one hardware queue
+    // runs in order: when `stream` and `side` land on the same queue the kernels meant to run side by side take turns (−9 %,
+    // seen in about one process out of four), and a copy of another call waiting on a compute stream's queue stalls its
+    // kernels.  The priority classes have separate queue pools, so the three roles get three classes: kernels of the main
+    // lane normal, of the side lane high, copies low.  (The class itself does not change which workgroups are placed
+    // first: measured.)
+    int prio_low = 0, prio_high = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+    const bool classes = [] { const char* e = getenv("FMX_STREAM_CLASSES"); return e ? atoi(e) != 0 : true; }();
     HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&h2d, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&d2h, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    if (classes) {
+      HIP_TRY(hipStreamCreateWithPriority(&h2d, hipStreamNonBlocking, prio_low));
+      HIP_TRY(hipStreamCreateWithPriority(&d2h, hipStreamNonBlocking, prio_low));
+      HIP_TRY(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, prio_high));
+    } else {
+      HIP_TRY(hipStreamCreateWithFlags(&h2d, hipStreamNonBlocking));
+      HIP_TRY(hipStreamCreateWithFlags(&d2h, hipStreamNonBlocking));
+      HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    }
     for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
     HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
