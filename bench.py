@@ -121,11 +121,20 @@ def main():
     import synth
 
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
+    # FMX_BENCH_BACKEND=gloo: dry run of the N > 1 control flow on a box with ONE GPU (every rank on device 0, the collectives
+    # over gloo through host memory) — for the builder's tests only; the driver's runs use RCCL, one GPU per rank
+    backend = os.environ.get("FMX_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = torch.device("cpu") if backend == "gloo" else dev   # where the small collectives' tensors live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "gloo":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     n_sent, mean_len, nq_cfg, pkw = CONFIGS[args.config]
     n_sent = args.sentences or n_sent
@@ -236,7 +245,7 @@ def main():
         sync()
         el = time.perf_counter() - t1
         if world > 1:
-            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            t = torch.tensor([el], dtype=torch.float64, device=cdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         return el, res
@@ -265,7 +274,7 @@ def main():
 
     # ---- the metric: PCIe-inclusive steps through fmx_match_batch ----
     def measure(wl):
-        gather = shard.RecordGather(wl.nq, cap, dev, dst=0, depth=max(args.threads, 1) + 1) if (world > 1 or args.force_gather) else None
+        gather = shard.RecordGather(wl.nq, cap, dev, dst=0, depth=max(args.threads, 1) + 1, coll_device=cdev) if (world > 1 or args.force_gather) else None
         # set-up, not warm-up: every call in flight works in its own context, and a context sizes its workspace on its
         # first batches (allocation + re-runs); two rounds of T concurrent calls leave all T contexts grown
         run_host_steps(wl, 2 * max(args.threads, 1), gather)
@@ -276,14 +285,14 @@ def main():
     elapsed, host_stats = measure(main_wl)
     nq_step_all = main_wl.nq
     if world > 1:
-        t = torch.tensor([main_wl.nq], dtype=torch.int64, device=dev)
+        t = torch.tensor([main_wl.nq], dtype=torch.int64, device=cdev)
         dist.all_reduce(t)
         nq_step_all = int(t.item())
     value = nq_step_all * args.steps / elapsed
     scaling_other = None
     if world > 1:
         el2, _ = measure(other_wl)
-        t = torch.tensor([other_wl.nq], dtype=torch.int64, device=dev)
+        t = torch.tensor([other_wl.nq], dtype=torch.int64, device=cdev)
         dist.all_reduce(t)
         scaling_other = {"scaling": "strong" if args.scaling == "weak" else "weak", "value": round(int(t.item()) * args.steps / el2, 1),
                          "ms_per_step": round(el2 / args.steps * 1e3, 3), "queries_per_step_all_ranks": int(t.item())}
@@ -326,7 +335,7 @@ def main():
     exa_gbs = b_exa / (exa_ms * 1e-3) / 1e9 if exa_ms > 0 else 0.0
     rank_rates = None
     if world > 1:
-        t = torch.tensor([probe_gbs, exa_gbs, per_stage.get("probe", 0.0), el_dev / args.steps * 1e3], dtype=torch.float64, device=dev)
+        t = torch.tensor([probe_gbs, exa_gbs, per_stage.get("probe", 0.0), el_dev / args.steps * 1e3], dtype=torch.float64, device=cdev)
         g = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(g, t)
         rank_rates = [{"rank": r, "probe_model_gbps": round(float(x[0]), 1), "expand_a_model_gbps": round(float(x[1]), 1),

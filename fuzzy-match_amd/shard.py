@@ -54,15 +54,17 @@ class RecordGather:
     compute of step i + 1, which uses the other slot.  A slot is only handed out again after its previous
     gather has completed (stream-ordered wait, no host sync).  Sizes are exchanged once, not per step."""
 
-    def __init__(self, nq_local, cap, device, dst=0, depth=2):
+    def __init__(self, nq_local, cap, device, dst=0, depth=2, coll_device=None):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.dst, self.nq, self.cap = dst, nq_local, cap
+        # coll_device: where the collectives' tensors live when that is not `device` (gloo dry runs: host memory, synchronous)
+        self.staged = coll_device is not None and coll_device != device
         if self.world > 1:
-            n = torch.tensor([nq_local], dtype=torch.int64, device=device)
+            n = torch.tensor([nq_local], dtype=torch.int64, device=coll_device if self.staged else device)
             sizes = [torch.zeros_like(n) for _ in range(self.world)]
             dist.all_gather(sizes, n)
             self.sizes = [int(x.item()) for x in sizes]
@@ -100,6 +102,14 @@ class RecordGather:
             return
         slot = self.slots[i % len(self.slots)]
         on_dst = self.rank == self.dst
+        if self.staged:  # through host memory, synchronously (dry runs only)
+            for name, gname in (("out", "g_out"), ("cnt", "g_cnt")):
+                src = slot[name].cpu()
+                parts = [self.torch.empty_like(src) for _ in range(self.world)] if on_dst else None
+                self.dist.gather(src, parts, dst=self.dst)
+                if on_dst:
+                    slot[gname].copy_(self.torch.stack(parts))
+            return
         slot["work"] = [
             self.dist.gather(slot["out"], list(slot["g_out"].unbind(0)) if on_dst else None, dst=self.dst, async_op=True),
             self.dist.gather(slot["cnt"], list(slot["g_cnt"].unbind(0)) if on_dst else None, dst=self.dst, async_op=True)]
