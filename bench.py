@@ -53,7 +53,7 @@ CALIBRATION = os.path.join(ROOT, "profiles", "r02_fetch_size_calibration.json")
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="C3", choices=list(CONFIGS))
     ap.add_argument("--sentences", type=int, default=0)
