@@ -1,5 +1,5 @@
 """The expand stage's layouts and the host-buffer path's scheduling must not change a single record: light queries on /
-off / at the largest setting, both kernel orders, a serialised pass, and large concurrent host-buffer calls that take
+off / at the largest setting, both kernel orders, a serialised pass, one or two queries per wave in the last kernel, and large concurrent host-buffer calls that take
 turns on the GPU (src/fuzzy_match.cc:484-612 is order-free up to the candidate list; the reference's match() is const
 and re-entrant, cli/src/FuzzyMatch-cli.cc:139-147)."""
 import threading
@@ -39,14 +39,15 @@ def test_expand_layouts_agree_with_the_oracle(fmx, gpu_device, corpus):
         o.sort(2)
         sets = ["wide_all", "fuzzy_zero", "costs_101", "ml_negative"]
     layouts = [dict(light_max=256, expand_order=1), dict(light_max=0, expand_order=1), dict(light_max=1024, expand_order=0),
-               dict(light_max=17, expand_order=0), dict(light_max=256, expand_order=1, serial=1), dict(light_max=256, expand_order=0, heavy_min=0)]
+               dict(light_max=17, expand_order=0), dict(light_max=256, expand_order=1, serial=1), dict(light_max=256, expand_order=0, heavy_min=0),
+               dict(light_max=256, expand_order=1, pair_finish=0)]  # the others run k_finish_pair where the parameters allow it
     light_seen = 0
     for name in sets:
         kw = workloads.PARAM_SETS[name]
         cap = kw["nmatch"] or 256
         oo, oc = o.match_batch(oracle_lib.Params(**kw), q_off, q_tok, cap, nthreads=oracle_lib.effective_cpus())
         for lay in layouts:
-            for k, v in {"serial": 0, "heavy_min": 1024, **lay}.items():
+            for k, v in {"serial": 0, "heavy_min": 1024, "pair_finish": 1, **lay}.items():
                 ix.set_option(k, v)
             go, gc, gt, st = ix.match_batch(fmx.Params(**kw), q_off, q_tok, cap=cap, want_stats=True)
             workloads.compare(oo, oc, go, gc, f"{corpus} {name} {lay}")
