@@ -2631,7 +2631,24 @@ __global__ void __launch_bounds__(kWave) k_finish(DevIndex ix, DevBatch b, DevWo
       Cand* seg = w.seg + seg0;
       const uint32_t p = b.q_off[gq + 1] - b.q_off[gq];
       uint32_t n, mx;
-      if (prm.cbuf > 0 && prm.cbuf <= (int)kHeapLdsMax) n = replay_body(prm, p, n_cand, seg, s_heap, sh, mx);
+      if (!LIST && n_cand <= kWave && prm.cbuf > 0 && prm.cbuf <= (int)kHeapLdsMax) {
+        // (contrastive rerank with a candidate set of one wave) the replay spread over the lanes, like the plain path; the
+        // accepted matches are then compacted to the head of the segment in candidate order, as replay_body leaves them
+        const uint32_t my_slen = lane < n_cand ? (seg[lane].longest >> 16) : 0u;
+        const unsigned long long acc = replay_small(prm, p, n_cand, seg, sh);
+        const bool mine = (acc >> lane) & 1ull;
+        n = (uint32_t)__popcll(acc);
+        uint32_t m2 = mine ? my_slen : 0u;
+#pragma unroll
+        for (int d2 = 32; d2 >= 1; d2 >>= 1) { const uint32_t o = __shfl_xor(m2, d2, 64); m2 = o > m2 ? o : m2; }
+        mx = m2;
+        if (mine) {
+          Cand a;
+          a.sid = sh.sid[lane]; a.longest = sh.L[lane]; a.score = sh.score[lane]; a.penalty = 0.f;
+          seg[__popcll(acc & ((1ull << lane) - 1ull))] = a;  // every lane read its own candidate before (replay_small)
+        }
+        __syncthreads();
+      } else if (prm.cbuf > 0 && prm.cbuf <= (int)kHeapLdsMax) n = replay_body(prm, p, n_cand, seg, s_heap, sh, mx);
       else n = replay_body(prm, p, n_cand, seg, w.heap + 2ull * seg0, sh, mx);  // n_cand + 1 <= 2 x the segment's capacity; segments are not in query order
       if (lane == 0) {
         w.q_acc[q] = n;
