@@ -30,7 +30,7 @@ struct fmx_index {
   bool                                      finalized = false;
   std::mutex                                mu;    // interning of penalty strings, lazy construction of the coalescer
   std::unique_ptr<Coalescer>                co;
-  int64_t                                   coalesce_us = 50;
+  int64_t                                   coalesce_us = 100;
   int64_t                                   host_lanes = 1;   // host threads (contexts) per device inside one fmx_match_batch call
   ~fmx_index();
 };

@@ -261,7 +261,7 @@ int64_t fmx_index_add_text(fmx_index*, const char* id, const char* sentence, siz
 /* tuning knobs (all have sane defaults):
  *   "contexts"          concurrent calls served at once per device, each with its own workspace (default 2)
  *   "heavy_min"         suffix ranges at least this long are tested through the bit planes (default 1024, 0 = never)
- *   "coalesce_us"       longest time fmx_match_one waits for company (default 50)
+ *   "coalesce_us"       longest time fmx_match_one waits for company (default 100; a lone caller never waits)
  *   "host_lanes"        host threads (each with its own workspace and streams) one fmx_match_batch call spreads a
  *                       device's queries over (default 1: measured no better than one lane with the pass schedule
  *                       below; concurrent callers overlap anyway, every call works in its own context)
