@@ -771,11 +771,15 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
                              c.scan_state(3), c.scan_ticket(3));
           hipLaunchKernelGGL(k_camap, dim3(b.nq), dim3(kWave), 0, stream, m.d, b, w, sc, prm, d_out_count, d_out_total);
           // round r: the match picked in round r - 1 emits itself, the others bid for round r's pick
-          for (uint32_t r = 1; r <= prm.nmatch; r++) {
-            hipLaunchKernelGGL(k_cround<32>, dim3(256 * 16), dim3(kWave), 0, stream, m.d, b, w, prm, sc, r, cap, d_out, d_out_count, d_out_total);
-            if (m.d.max_slen > 32)
-              hipLaunchKernelGGL(k_cround<64>, dim3(256 * 8), dim3(kWave), 0, stream, m.d, b, w, prm, sc, r, cap, d_out, d_out_count, d_out_total);
+          // (the two length classes hold different queries: their rounds are two independent chains, one per stream)
+          if (m.d.max_slen > 32) {
+            fork();
+            for (uint32_t r = 1; r <= prm.nmatch; r++)
+              hipLaunchKernelGGL(k_cround<64>, dim3(256 * 8), dim3(kWave), 0, side, m.d, b, w, prm, sc, r, cap, d_out, d_out_count, d_out_total);
           }
+          for (uint32_t r = 1; r <= prm.nmatch; r++)
+            hipLaunchKernelGGL(k_cround<32>, dim3(256 * 16), dim3(kWave), 0, stream, m.d, b, w, prm, sc, r, cap, d_out, d_out_count, d_out_total);
+          if (m.d.max_slen > 32) join();
         } else {
           hipLaunchKernelGGL(k_contrast<0>, dim3(b.nq), dim3(kWave), 0, stream, m.d, b, w, prm, sc, cap, d_out,
                              d_out_count, d_out_total, cl, (float*)nullptr, 0u);
