@@ -164,6 +164,16 @@ def test_c3_headline_config_parity(fmx, gpu_device):
     ix.set_option("heavy_min", 0)  # and the per-hit walk alone gives the same records
     g3, c3_, _ = ix.match_batch(fmx.Params(**workloads.PARAM_SETS["C3"]), so, st, cap=5)
     workloads.compare(go[:m], gc[:m], g3, c3_, "per-hit walk vs bit planes")  # entries beyond the count are unspecified
+    ix.set_option("heavy_min", 1024)
+    # the one-launch path for micro-batches (fmx_small.hip.hh) on the 5 M index: 20 000 of the queries in calls of 500,
+    # against the records of the pipeline (== the oracle's, above); queries with long ranges are handed back to the pipeline
+    ix.set_option("small_path", 1)
+    n_small = 0
+    for lo in range(0, 20_000, 500):
+        g4, c4_, _, st4 = ix.match_batch(fmx.Params(**workloads.PARAM_SETS["C3"]), q_off[lo:lo + 501], q_tok, cap=5, want_stats=True)
+        workloads.compare(go[lo:lo + 500], gc[lo:lo + 500], g4, c4_, f"one-launch path [{lo}:{lo + 500}]")
+        n_small += int(st4.n_small)
+    assert 15_000 < n_small <= 20_000, n_small
 
 
 def test_gpu_sort_equals_independent_oracle_sort_at_1m(fmx, c2):
