@@ -102,7 +102,10 @@ struct DevWork {
                                  // [22]=hits of the light queries (walked by k_expand_b<true>) [23]=queries queued for k_cand
                                  // [24],[25]=segment / queue entries the pass used (always written: the host sizes later workspaces by them)
 };
-constexpr int kNumCounters = 26;
+constexpr int kStatSlots = 64;     // k_expand_h's three statistics are summed into 64 slots each (kStatBase + 3 x 64): 8192 workgroups
+                                   // adding to three single words at the end of the kernel queued for ~0.1 ms; k_stats folds them into [16..18]
+constexpr int kStatBase = 32;
+constexpr int kNumCounters = kStatBase + 3 * kStatSlots;
 
 constexpr int kWave = 64;
 constexpr uint32_t kLdsSortMax = 1024;   // per-wave LDS sort capacity (keys)
@@ -1144,9 +1147,10 @@ __global__ void __launch_bounds__(kWave, 6) k_expand_h(DevIndex ix, DevBatch b, 
     }
   }
   if (lane == 0 && tot_hits) {
-    atomicAdd(&w.counters[16], tot_hits);
-    atomicAdd(&w.counters[17], tot_pass);
-    atomicAdd(&w.counters[18], tot_words);
+    const uint32_t slot = blockIdx.x & (kStatSlots - 1);
+    atomicAdd(&w.counters[kStatBase + slot], tot_hits);
+    atomicAdd(&w.counters[kStatBase + kStatSlots + slot], tot_pass);
+    atomicAdd(&w.counters[kStatBase + 2 * kStatSlots + slot], tot_words);
   }
 }
 
@@ -2986,6 +2990,10 @@ __global__ void __launch_bounds__(1024) k_stats(DevWork w, uint32_t nq) {
   if (threadIdx.x < 5 && s_v[threadIdx.x]) atomicAdd(&w.counters[slot[threadIdx.x]], s_v[threadIdx.x]);
   if (threadIdx.x == 5 && s_v[5]) atomicMax(&w.counters[9], s_v[5]);
   if (threadIdx.x == 6 && s_v[6]) atomicAdd(&w.counters[22], s_v[6]);
+  if (blockIdx.x == 0 && threadIdx.x < 3 * kStatSlots) {  // k_expand_h's slots -> [16], [17], [18]
+    const unsigned long long v2 = w.counters[kStatBase + threadIdx.x];
+    if (v2) atomicAdd(&w.counters[16 + threadIdx.x / kStatSlots], v2);
+  }
 }
 
 }  // namespace fmx
