@@ -2660,7 +2660,10 @@ __global__ void __launch_bounds__(kWave) k_finish(DevIndex ix, DevBatch b, DevWo
         // wider kernels; everything else is done by k_contrast<0> in place
         if (contrast && n != 0 && (mx > 32 || n > kMaxFlatAccepted)) {
           const uint32_t cls = (mx <= 64 && n <= kMaxFlatAccepted) ? 1u : 2u;  // the flattened rerank indexes a query's matches with 16 bits
-          contrast_list[(size_t)(cls - 1) * b.nq + atomicAdd(&w.counters[9 + cls], 1ull)] = q;
+          // (the flattened rerank finds the queries of class 1 through their class bits: only the per-query kernels read the
+          // list, and a same-address atomic per query is what this kernel would then spend its time on)
+          const bool flat = prm.nmatch >= 1 && prm.nmatch <= kMaxFlatRounds;
+          if (cls == 2 || !flat) contrast_list[(size_t)(cls - 1) * b.nq + atomicAdd(&w.counters[9 + cls], 1ull)] = q;
           w.q_acc[q] = n | (cls << 30);  // length class of the accepted sentences (0: <= 32, 1: <= 64, 2: longer)
         }
       }
