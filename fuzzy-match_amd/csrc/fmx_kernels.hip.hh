@@ -540,7 +540,10 @@ __device__ __forceinline__ void pat_hash_build(PatHash& ph, const uint32_t* s_pa
 
 constexpr int kUnroll = FMX_UNROLL;  // hits per lane per phase-A iteration
 constexpr uint32_t kQueue = 256;  // LDS ring of hits that passed the cheap tests (power of two >= 64 + 2 * 64)
-constexpr uint32_t kPhaseBChunk = 1024;  // queued hits per k_expand_b work item
+#ifndef FMX_PHASE_B_CHUNK
+#define FMX_PHASE_B_CHUNK 1024
+#endif
+constexpr uint32_t kPhaseBChunk = FMX_PHASE_B_CHUNK;  // queued hits per k_expand_b work item
 // "no tabulated threshold": phase B evaluates the bound itself.  Table values are ordered so that phase A
 // needs one compare per hit: thresholds (< 0x8000) <= kNeedExact <= the bound with the signature disabled
 // (0x8000 | count) < 0xffff = rejected by the length filter.
