@@ -59,7 +59,7 @@ def parse_args():
     ap.add_argument("--sentences", type=int, default=0)
     ap.add_argument("--queries", type=int, default=0)
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
-    ap.add_argument("--threads", type=int, default=3, help="synchronous fmx_match_batch calls kept in flight (one host thread each)")
+    ap.add_argument("--threads", type=int, default=int(os.environ.get("FMX_BENCH_THREADS", "3")), help="synchronous fmx_match_batch calls kept in flight (one host thread each)")
     ap.add_argument("--force-gather", action="store_true", help="N = 1 test of the N > 1 step: records also kept in HBM for the (empty) gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline.traffic = null)")

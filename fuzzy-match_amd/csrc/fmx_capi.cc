@@ -30,8 +30,12 @@ struct fmx_index {
   bool                                      finalized = false;
   std::mutex                                mu;    // interning of penalty strings, lazy construction of the coalescer
   std::unique_ptr<Coalescer>                co;
+  std::once_flag                            co_once;   // first fmx_match_one from any thread constructs the coalescer
   int64_t                                   coalesce_us = 100;
   int64_t                                   host_lanes = 1;   // host threads (contexts) per device inside one fmx_match_batch call
+  int64_t                                   min_block_queries = 32768;  // a replica / host lane gets a block only if it is at least this large
+  bool                                      dup_devices = false;  // tests: the same ordinal may carry several replicas (option "duplicate_devices")
+  std::atomic<uint32_t>                     rr{0};            // round-robin replica for batches too small to shard
   ~fmx_index();
 };
 
@@ -88,6 +92,26 @@ fmx_index* fmx_index_load(const char* fmi_path, char* err, size_t errlen) {
     if (!fmi_path) throw std::runtime_error("null path");
     ix.reset(new fmx_index);
     ix->host.load_fmi(fmi_path);
+    return ix.release();
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    if (err && errlen) { strncpy(err, e.what(), errlen - 1); err[errlen - 1] = '\0'; }
+    return nullptr;
+  }
+}
+
+fmx_index* fmx_index_from_arrays(int32_t pt, uint64_t max_tokens_in_pattern, const uint32_t* suf_sid, const uint16_t* suf_pos,
+                                 uint64_t n_suffixes, const uint32_t* sentence_buffer, uint64_t buffer_size,
+                                 const uint32_t* sentence_pos, uint64_t n_sentences, const uint32_t* quick_vocab_access,
+                                 uint64_t n_qva, const uint32_t* sfreq, uint32_t vocab_size, char* err, size_t errlen) {
+  try {
+    if ((n_suffixes && (!suf_sid || !suf_pos)) || (buffer_size && !sentence_buffer) || (n_sentences && !sentence_pos))
+      throw std::runtime_error("null array");
+    std::unique_ptr<fmx_index> ix(new fmx_index);
+    ix->host.pt = pt;
+    ix->host.max_tokens = max_tokens_in_pattern;
+    ix->host.adopt_arrays(suf_sid, suf_pos, n_suffixes, sentence_buffer, buffer_size, sentence_pos, n_sentences,
+                          quick_vocab_access, n_qva, sfreq, vocab_size);
     return ix.release();
   } catch (const std::exception& e) {
     g_err = e.what();
@@ -156,10 +180,12 @@ int fmx_index_finalize(fmx_index* ix) {
 }
 
 static int add_device(fmx_index* ix, int device) {
-  for (auto& d : ix->devs) if (d->device() == device) return FMX_OK;
+  if (!ix->dup_devices)
+    for (auto& d : ix->devs) if (d->device() == device) return FMX_OK;
   return guarded([&]() {
     std::unique_ptr<DeviceIndex> d(new DeviceIndex);
     d->upload(ix->host, device);
+    d->set_contexts((uint32_t)std::max<int64_t>(ix->host_lanes + 1, 3));  // host_lanes may have been set before the upload
     ix->devs.push_back(std::move(d));
     return (int)FMX_OK;
   });
@@ -333,13 +359,17 @@ static void real_from_forms(const fmx_index* ix, const uint32_t* wids, uint64_t 
 static void match_on_devices(fmx_index* ix, const Params& prm, const HostBatchView& v, fmx_match* out, uint32_t* out_count,
                              uint32_t* out_total, uint32_t cap, Stats* st, fmx_match* d_keep = nullptr,
                              uint32_t* d_keep_count = nullptr) {
-  const size_t nd = d_keep ? 1 : ix->devs.size();  // a device-resident copy lives on one device: no sharding over replicas
-  constexpr uint64_t kMinLaneQueries = 32768;
+  size_t nd = d_keep ? 1 : ix->devs.size();  // a device-resident copy lives on one device: no sharding over replicas
+  const uint64_t min_block = (uint64_t)std::max<int64_t>(ix->min_block_queries, 1);
+  // a block must be worth a pass of its own (and a host thread): small batches — the coalescer's micro-batches above all — run
+  // whole on ONE replica, chosen round-robin, instead of paying nd launches and synchronisations for a few queries each
+  while (nd > 1 && v.nq / nd < min_block) nd--;
   size_t lanes = (size_t)std::max<int64_t>(ix->host_lanes, 1);
-  while (lanes > 1 && v.nq / (nd * lanes) < kMinLaneQueries) lanes--;
+  while (lanes > 1 && v.nq / (nd * lanes) < min_block) lanes--;
   const size_t nb = nd * lanes;
   if (nb == 1 || v.nq < 2 * nb) {
-    ix->devs[0]->match_host(ix->host, prm, v, (Rec*)out, out_count, out_total, cap, st, (Rec*)d_keep, d_keep_count);
+    const size_t k = (d_keep || ix->devs.size() == 1) ? 0 : ix->rr.fetch_add(1) % ix->devs.size();
+    ix->devs[k]->match_host(ix->host, prm, v, (Rec*)out, out_count, out_total, cap, st, (Rec*)d_keep, d_keep_count);
     return;
   }
   const auto t0 = std::chrono::steady_clock::now();
@@ -427,6 +457,7 @@ struct Request {
   std::mutex              m;
   std::condition_variable cv;
   bool                    done = false, lead = false;  // under m
+  bool                    taken = false;               // under Coalescer::mu: a leader moved it from `pending` into its batch
 };
 
 // Flat combining: there are no dispatcher threads.  A caller that finds fewer than kLeaders batches in flight becomes a
@@ -451,12 +482,16 @@ struct Coalescer {
     cv_more.notify_one();
     std::vector<Request*> batch;
     for (;;) {
-      if (leaders >= kLeaders || gathering != 0 || pending.empty()) {
+      // A caller only leads while its own request is still pending.  Once another leader has taken it (possible while this
+      // thread led a batch of other parameters, or between an offered seat and re-locking mu) it just waits for the answer:
+      // leading on would keep it busy with other callers' batches long after its own result is complete.
+      if (r.taken || leaders >= kLeaders || gathering != 0 || pending.empty()) {
         // sleep until a leader has answered this request, or hands this caller a free seat
+        const bool taken = r.taken;
         lk.unlock();
         {
           std::unique_lock<std::mutex> rl(r.m);
-          r.cv.wait(rl, [&]() { return r.done || r.lead; });
+          r.cv.wait(rl, [&]() { return r.done || (!taken && r.lead); });
           r.lead = false;
           if (r.done) return;
         }
@@ -473,7 +508,7 @@ struct Coalescer {
         const fmx_params first = pending.front()->prm;
         const uint32_t cap = pending.front()->cap;
         for (auto it = pending.begin(); it != pending.end() && batch.size() < 65536;) {
-          if (memcmp(&(*it)->prm, &first, sizeof(fmx_params)) == 0 && (*it)->cap == cap) { batch.push_back(*it); it = pending.erase(it); }
+          if (memcmp(&(*it)->prm, &first, sizeof(fmx_params)) == 0 && (*it)->cap == cap) { (*it)->taken = true; batch.push_back(*it); it = pending.erase(it); }
           else ++it;
         }
         last_batch = (uint32_t)batch.size();
@@ -561,12 +596,9 @@ int fmx_match_one(fmx_index* ix, const fmx_params* params, const uint32_t* wids,
   if (cap == 0) return fail(FMX_E_INVALID, "cap must be > 0");
   if (!ix->finalized) return fail(FMX_E_STATE, "index is not finalized");
   if (ix->devs.empty()) return fail(FMX_E_NO_DEVICE, "index is not on a device (fmx_index_to_device); there is no CPU path");
-  if (!ix->co) {
-    std::lock_guard<std::mutex> lk(ix->mu);
-    if (!ix->co) {
-      try { ix->co.reset(new Coalescer(ix, 2)); } catch (const std::exception& e) { return fail(FMX_E_NOMEM, e.what()); }
-    }
-  }
+  try {
+    std::call_once(ix->co_once, [&]() { ix->co.reset(new Coalescer(ix, 2)); });
+  } catch (const std::exception& e) { return fail(FMX_E_NOMEM, e.what()); }
   Request r;
   r.prm = *params; r.wids = wids; r.p = p; r.real = q_real; r.itok = q_itok; r.out = out; r.cap = cap;
   ix->co->submit_and_wait(r);
@@ -574,6 +606,41 @@ int fmx_match_one(fmx_index* ix, const fmx_params* params, const uint32_t* wids,
   *out_count = r.count;
   if (out_total) *out_total = r.total;
   return FMX_OK;
+}
+
+// match() with entries already in the caller's vector and a contrastive factor (src/fuzzy_match.cc:622-650): not coalesced
+// (every caller brings its own prior matches); one query through the pipeline with the priors as a side input.
+int fmx_match_one_prior(fmx_index* ix, const fmx_params* params, const uint32_t* wids, uint32_t p, const uint32_t* q_real,
+                        const uint32_t* q_itok, const uint32_t* prior_off, const uint32_t* prior_tok, uint32_t n_prior,
+                        fmx_match* out, uint32_t cap, uint32_t* out_count, uint32_t* out_total) {
+  if (!ix || !params || !out || !out_count || (p && !wids)) return fail(FMX_E_INVALID, "null argument");
+  if (n_prior && (!prior_off || (prior_off[n_prior] && !prior_tok))) return fail(FMX_E_INVALID, "null prior arrays");
+  if (cap == 0) return fail(FMX_E_INVALID, "cap must be > 0");
+  if (!ix->finalized) return fail(FMX_E_STATE, "index is not finalized");
+  if (ix->devs.empty()) return fail(FMX_E_NO_DEVICE, "index is not on a device (fmx_index_to_device); there is no CPU path");
+  return guarded([&]() {
+    const uint32_t off[2] = {0, p};
+    const uint32_t dummy = 0;
+    HostBatchView v;
+    v.nq = 1; v.q_off = off; v.q_tok = p ? wids : &dummy; v.q_real = q_real; v.q_itok = q_itok;
+    std::vector<uint32_t> forms_real;
+    if (ix->host.real_differs && !v.q_real && p) {
+      forms_real.resize(p);
+      real_from_forms(ix, wids, p, forms_real.data());
+      v.q_real = forms_real.data();
+    }
+    std::vector<uint32_t> p_off(prior_off, prior_off + (n_prior ? n_prior + 1 : 0));
+    if (n_prior) {  // rebase to 0: the staging copy starts at the first prior's tokens
+      const uint32_t base = p_off[0];
+      for (auto& o : p_off) o -= base;
+      v.n_prior = n_prior; v.prior_off = p_off.data(); v.prior_tok = prior_tok + base;
+    }
+    uint32_t total = 0;
+    const size_t k = ix->devs.size() == 1 ? 0 : ix->rr.fetch_add(1) % ix->devs.size();
+    ix->devs[k]->match_host(ix->host, make_params(ix, params), v, (Rec*)out, out_count, &total, cap, nullptr);
+    if (out_total) *out_total = total;
+    return (int)FMX_OK;
+  });
 }
 
 int fmx_subsequence_batch(fmx_index* ix, const fmx_batch* hb, uint32_t number_of_matches, int32_t no_perfect,
@@ -625,6 +692,7 @@ uint64_t    fmx_text_itok_index(const fmx_text* h, uint32_t k) { return h && k <
 const char* fmx_text_itok(const fmx_text* h, uint32_t k) { return h && k < h->t.itoks.size() ? h->t.itoks[k].second.c_str() : ""; }
 uint32_t    fmx_text_num_raw(const fmx_text* h) { return h ? (uint32_t)h->t.raw.size() : 0u; }
 const char* fmx_text_raw(const fmx_text* h, uint32_t i) { return h && i < h->t.raw.size() ? h->t.raw[i].c_str() : ""; }
+const char* fmx_text_feature(const fmx_text* h, uint32_t i) { return h && i < h->t.feat.size() ? h->t.feat[i].c_str() : ""; }
 uint32_t    fmx_text_map(const fmx_text* h, uint32_t k) { return h && k < h->t.map_tokens.size() ? h->t.map_tokens[k] : 0u; }
 const char* fmx_text_detokenize(fmx_text* h, uint32_t from, uint32_t to) {
   if (!h) return "";
@@ -702,6 +770,8 @@ int fmx_set_option(fmx_index* ix, const char* name, int64_t value) {
   if (!ix || !name) return fail(FMX_E_INVALID, "null argument");
   const std::string n(name);
   if (n == "coalesce_us") { ix->coalesce_us = std::max<int64_t>(value, 0); return FMX_OK; }
+  if (n == "duplicate_devices") { ix->dup_devices = value != 0; return FMX_OK; }   // tests on a one-GPU box: several replicas on one ordinal
+  if (n == "min_block_queries") { ix->min_block_queries = std::max<int64_t>(value, 1); return FMX_OK; }
   if (n == "host_lanes") {
     ix->host_lanes = std::min<int64_t>(std::max<int64_t>(value, 1), 8);
     for (auto& d : ix->devs) d->set_contexts((uint32_t)ix->host_lanes + 1);  // + one for a concurrent caller / the coalescer

@@ -37,6 +37,11 @@ struct HostBatchView {
   const uint32_t* q_tok = nullptr;
   const uint32_t* q_real = nullptr;
   const uint32_t* q_itok = nullptr;
+  // matches already in the caller's vector (contrastive rerank penalises against them, src/fuzzy_match.cc:622-650): CSR
+  // token sequences, shared by every query of the batch
+  uint32_t        n_prior = 0;
+  const uint32_t* prior_off = nullptr;
+  const uint32_t* prior_tok = nullptr;
 };
 
 struct DeviceBatchView {
@@ -46,6 +51,10 @@ struct DeviceBatchView {
   const uint32_t* q_real = nullptr;
   const uint32_t* q_itok = nullptr;
   uint32_t        p_max = 0;  // longest pattern of the batch (0 = unknown)
+  uint32_t        n_prior = 0;        // prior matches (device CSR), see HostBatchView
+  const uint32_t* prior_off = nullptr;
+  const uint32_t* prior_tok = nullptr;
+  uint32_t        prior_max_len = 0;  // longest prior match
 };
 
 int  gpu_device_count();

@@ -135,7 +135,7 @@ struct Ctx {
   uint64_t seg_cap = 0;
   uint64_t want_qb = 1ull << 24;  // queue entries (8 bytes each) wanted: grows when a pass reports more
   // ---- staging of the host-buffer entry point (each buffer tracks its own capacity) ----
-  Grow<uint32_t> d_qoff, d_qtok, d_qreal, d_qitok, d_cnt, d_tot;
+  Grow<uint32_t> d_qoff, d_qtok, d_qreal, d_qitok, d_cnt, d_tot, d_prior;
   Grow<Rec>      d_out;
   // ---- streams / events ----
   hipStream_t stream = nullptr, h2d = nullptr, d2h = nullptr, side = nullptr;
@@ -146,6 +146,24 @@ struct Ctx {
   unsigned long long* h_ctr_group = nullptr;  // pinned: one slot per pass of an asynchronous group
   std::vector<hipEvent_t> ev_pass;      // "pass done" events of an asynchronous group
   bool ok = false;
+  int  cu_group = -1;  // >= 0: the kernels of this context run on one half of the GPU's compute units (option "cu_split")
+
+  // A stream whose kernels only run on half of the compute units: hipExtStreamCreateWithCUMask (bit i of the mask = compute
+  // unit i in the enumeration the runtime spreads round-robin over the XCDs).  mode 1: the lower / upper half of the bits —
+  // half of the CUs of EVERY XCD; mode 2: bits by XCD parity — four whole XCDs (each with its own L2) per group.
+  static void create_masked(hipStream_t* st, int group, int mode) {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    const uint32_t n_cu = (uint32_t)prop.multiProcessorCount;
+    std::vector<uint32_t> mask((n_cu + 31) / 32, 0u);
+    for (uint32_t i = 0; i < n_cu; i++) {
+      const bool mine = mode == 2 ? ((i % 8) / 4 == (uint32_t)group) : ((i < n_cu / 2) == (group == 0));
+      if (mine) mask[i / 32] |= 1u << (i % 32);
+    }
+    HIP_TRY(hipExtStreamCreateWithCUMask(st, (uint32_t)mask.size(), mask.data()));
+  }
 
   void init() {
     // HIP maps streams onto a few hardware queues (four per priority class by default) and everything on one hardware queue
@@ -157,6 +175,13 @@ struct Ctx {
     int prio_low = 0, prio_high = 0;
     HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
     const bool classes = [] { const char* e = getenv("FMX_STREAM_CLASSES"); return e ? atoi(e) != 0 : true; }();
+    const int cu_mode = [] { const char* e = getenv("FMX_CU_SPLIT"); return e ? atoi(e) : 0; }();
+    if (cu_mode && cu_group >= 0) {
+      create_masked(&stream, cu_group, cu_mode);
+      create_masked(&side, cu_group, cu_mode);
+      HIP_TRY(hipStreamCreateWithPriority(&h2d, hipStreamNonBlocking, prio_low));
+      HIP_TRY(hipStreamCreateWithPriority(&d2h, hipStreamNonBlocking, prio_low));
+    } else {
     HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     if (classes) {
       HIP_TRY(hipStreamCreateWithPriority(&h2d, hipStreamNonBlocking, prio_low));
@@ -166,6 +191,7 @@ struct Ctx {
       HIP_TRY(hipStreamCreateWithFlags(&h2d, hipStreamNonBlocking));
       HIP_TRY(hipStreamCreateWithFlags(&d2h, hipStreamNonBlocking));
       HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    }
     }
     for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
     HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
@@ -185,7 +211,7 @@ struct Ctx {
     t_q.release(); t_lo.release(); t_cnt.release(); t_idf.release(); c_qi.release(); keys.release(); seg.release(); qb.release();
     heap.release(); f0.release(); f1.release(); vals.release(); zero_blk.release();
     items.release(); items_b.release(); items_h.release(); cmin_tab.release(); g_rows.release();
-    d_qoff.release(); d_qtok.release(); d_qreal.release(); d_qitok.release(); d_cnt.release(); d_tot.release(); d_out.release();
+    d_qoff.release(); d_qtok.release(); d_qreal.release(); d_qitok.release(); d_cnt.release(); d_tot.release(); d_out.release(); d_prior.release();
     if (stream) (void)hipStreamDestroy(stream);
     if (h2d) (void)hipStreamDestroy(h2d);
     if (d2h) (void)hipStreamDestroy(d2h);
@@ -208,7 +234,7 @@ struct DeviceIndex::Impl {
   int      device = -1;
   DevIndex d{};
   uint64_t bytes = 0;
-  uint64_t itok_version = ~0ull;
+  std::atomic<uint64_t> itok_version{~0ull};
   std::shared_mutex itok_mu;  // matching calls hold it shared; a grown penalty-string table swaps under exclusive
   // options
   uint32_t sub_queries = 1u << 20;       // queries per pipeline pass: large passes amortise the ~40 launches and their tails
@@ -254,6 +280,7 @@ struct DeviceIndex::Impl {
       if (all.size() < max_ctx) {
         all.emplace_back(new Ctx);
         Ctx* c = all.back().get();
+        c->cu_group = (int)((all.size() - 1) % 2);
         lk.unlock();
         try { c->init(); } catch (...) { lk.lock(); idle.push_back(c); pool_cv.notify_one(); throw; }
         return c;
@@ -315,15 +342,19 @@ void     DeviceIndex::set_contexts(uint32_t n) {
 
 // the penalty-string distance table grows when queries intern new strings: swap it in while no call runs
 static void refresh_itok_table(DeviceIndex::Impl& m, const HostIndex& h) {
-  if (m.itok_version == h.itok_version) return;
+  if (m.itok_version.load() == h.itok_version.load()) return;
   std::unique_lock<std::shared_mutex> lk(m.itok_mu);
-  if (m.itok_version == h.itok_version) return;
+  if (m.itok_version.load() == h.itok_version.load()) return;
+  // a consistent (table, string count, version) triple: another thread may be interning a string right now
+  std::vector<uint16_t> dist;
+  uint32_t n = 0;
+  uint64_t version = 0;
+  h.snapshot_itok_dist(dist, n, version);
   hipFree((void*)m.d.itok_dist);
   m.d.itok_dist = nullptr;
-  h.sync_itok_dist();
-  m.d.n_itok = (uint32_t)h.itok_strings.size();
-  if (!h.itok_dist.empty()) m.d.itok_dist = dev_upload(h.itok_dist);
-  m.itok_version = h.itok_version;
+  m.d.n_itok = n;
+  if (!dist.empty()) m.d.itok_dist = dev_upload(dist);
+  m.itok_version.store(version);
 }
 
 constexpr size_t kDynLdsMax = 150 * 1024;  // dynamic LDS the row kernels may ask for (160 KB per CU on gfx950)
@@ -553,6 +584,7 @@ struct PassEnv {
   Rec* d_out; uint32_t* d_out_count; uint32_t* d_out_total;
   uint32_t cap;
   hipStream_t stream;
+  uint32_t prior_max_len;  // longest prior match of the batch (rows of the general contrast kernel must hold it)
 };
 
 // every launch of one pass, in stream order; the pass counters land in h_ctr_slot (pinned).  No host synchronisation.
@@ -764,6 +796,7 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
       if (prm.contrast > 0.f) {
         const uint32_t* cl = c.contrast_list.p;
         const bool flat = prm.nmatch >= 1 && prm.nmatch <= kMaxFlatRounds;
+        const uint32_t row_tokens = std::max<uint32_t>(m.d.max_slen, E.prior_max_len);  // longest "pattern" side of the rerank's DP
         if (flat) {
           // flattened rounds: pick, then one edit distance per remaining accepted match of any query
           hipLaunchKernelGGL(k_cacc, dim3((n_scan + 255) / 256), dim3(256), 0, stream, b, w);
@@ -788,12 +821,12 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
           hipLaunchKernelGGL(k_contrast<1>, dim3(2048), dim3(kWave), 0, stream, m.d, b, w, prm, sc, cap, d_out,
                              d_out_count, d_out_total, cl, (float*)nullptr, 0u);
         {  // long sentences, and the queries with more accepted matches than the flattened rerank indexes (k_finish queues both)
-          const size_t lds = ((size_t)m.d.max_slen + 1) * kWave * 4;
+          const size_t lds = ((size_t)row_tokens + 1) * kWave * 4;
           if (lds > kDynLdsMax - 8 * 1024) {  // indexed sentences too long for LDS rows: rows in HBM
             const unsigned grid_g = 512;
-            c.g_rows.ensure((uint64_t)grid_g * kWave * (m.d.max_slen + 1));
+            c.g_rows.ensure((uint64_t)grid_g * kWave * (row_tokens + 1));
             hipLaunchKernelGGL(k_contrast<3>, dim3(grid_g), dim3(kWave), 0, stream, m.d, b, w, prm, sc, cap, d_out,
-                               d_out_count, d_out_total, cl, c.g_rows.p, m.d.max_slen + 1);
+                               d_out_count, d_out_total, cl, c.g_rows.p, row_tokens + 1);
           } else {
             hipLaunchKernelGGL(k_contrast<2>, dim3(512), dim3(kWave), lds, stream, m.d, b, w, prm, sc, cap, d_out,
                                d_out_count, d_out_total, cl, (float*)nullptr, 0u);
@@ -876,11 +909,12 @@ static void run_passes(DeviceIndex::Impl& m, Ctx& c, const Params& prm_in, const
   // register kernel
   const bool side_terms = (m.d.real && bv.q_real) || (bv.q_itok != nullptr) || (m.d.itok != nullptr);
   if (!c.qb.p) c.want_qb = std::min<uint64_t>(c.want_qb, std::max<uint64_t>(m.init_seg, 4096));  // a small initial segment also starts the queues small
-  PassEnv E{m, c, prm_in, side_terms, prm_in.idf_penalty != 0.f, d_out, d_out_count, d_out_total, cap, stream};
+  PassEnv E{m, c, prm_in, side_terms, prm_in.idf_penalty != 0.f, d_out, d_out_count, d_out_total, cap, stream, bv.prior_max_len};
   const uint32_t n_sub = (uint32_t)sub_tok_bounds.size() - 1;
   auto batch_of = [&](uint32_t sb) {
     DevBatch b;
     b.q_off = bv.q_off; b.q_tok = bv.q_tok; b.q_real = bv.q_real; b.q_itok = bv.q_itok;
+    b.prior_off = bv.prior_off; b.prior_tok = bv.prior_tok; b.n_prior = bv.n_prior;
     b.q_begin = (uint32_t)sub_q_bounds[sb];
     b.nq = (uint32_t)(sub_q_bounds[sb + 1] - sub_q_bounds[sb]);
     b.t_begin = sub_tok_bounds[sb];
@@ -1054,7 +1088,7 @@ bool DeviceIndex::match_host_small(const HostIndex& h, const Params& prm, const 
                                    uint32_t* out_total, uint32_t cap, Stats* st) {
   Impl& m = *impl_;
   const uint64_t nq = hb.nq;
-  if (!m.small_path || nq == 0 || nq > kSmallMaxQueries || hb.q_real || hb.q_itok || m.d.itok || cap == 0 || cap > 4096 ||
+  if (!m.small_path || nq == 0 || nq > kSmallMaxQueries || hb.q_real || hb.q_itok || hb.n_prior || m.d.itok || cap == 0 || cap > 4096 ||
       !small_path_params_ok(prm) || m.device < 0)
     return false;
   const uint32_t base = hb.q_off[0];
@@ -1167,6 +1201,14 @@ void DeviceIndex::match_host_full(const HostIndex& h, const Params& prm, const H
   bv.q_real = hb.q_real ? c.d_qreal.p : nullptr;
   bv.q_itok = hb.q_itok ? c.d_qitok.p : nullptr;
   bv.p_max = std::max<uint32_t>(p_max, 1);
+  if (hb.n_prior) {  // the caller's prior matches: offsets then tokens in one staging buffer, ahead of the first pass
+    const uint32_t n_tok = hb.prior_off[hb.n_prior];
+    c.d_prior.ensure((uint64_t)hb.n_prior + 1 + n_tok + 1);
+    HIP_TRY(hipMemcpyAsync(c.d_prior.p, hb.prior_off, ((size_t)hb.n_prior + 1) * 4, hipMemcpyHostToDevice, c.stream));
+    if (n_tok) HIP_TRY(hipMemcpyAsync(c.d_prior.p + hb.n_prior + 1, hb.prior_tok, (size_t)n_tok * 4, hipMemcpyHostToDevice, c.stream));
+    bv.n_prior = hb.n_prior; bv.prior_off = c.d_prior.p; bv.prior_tok = c.d_prior.p + hb.n_prior + 1;
+    for (uint32_t r = 0; r < hb.n_prior; r++) bv.prior_max_len = std::max(bv.prior_max_len, hb.prior_off[r + 1] - hb.prior_off[r]);
+  }
   const bool pinned = is_pinned(hb.q_off) && is_pinned(hb.q_tok) && is_pinned(out) && is_pinned(out_count);
   uint32_t* const hd_count = pinned_device_ptr(out_count);
   uint32_t* const hd_total = out_total ? pinned_device_ptr(out_total) : nullptr;

@@ -220,6 +220,80 @@ void HostIndex::adopt_sorted(const uint64_t* keys, uint64_t n) {
   sorted = true;
 }
 
+// true when suffix a sorts before suffix b under SuffixArray::comp (src/suffix_array.cc:235-251)
+static bool suffix_before(const std::vector<uint32_t>& buf, const std::vector<uint32_t>& sent_pos, uint32_t sa, uint32_t pa,
+                          uint32_t sb, uint32_t pb) {
+  const uint32_t* ba = buf.data() + sent_pos[sa];
+  const uint32_t* bb = buf.data() + sent_pos[sb];
+  const uint32_t la = ba[0] - (pa - 1), lb = bb[0] - (pb - 1);
+  const uint32_t mn = la < lb ? la : lb;
+  for (uint32_t i = 0; i < mn; i++) {
+    const uint32_t x = ba[pa + i], y = bb[pb + i];
+    if (x != y) return x < y;
+  }
+  if (la != lb) return la < lb;
+  return sa < sb;
+}
+
+void HostIndex::adopt_arrays(const uint32_t* sid, const uint16_t* pos, uint64_t n_suf, const uint32_t* buffer, uint64_t n_buf,
+                             const uint32_t* spos, uint64_t n_sent, const uint32_t* qva_in, uint64_t n_qva,
+                             const uint32_t* sfreq_in, uint32_t vocab_size_) {
+  if (!sent_pos.empty() || !buf.empty()) throw std::runtime_error("adopt_arrays: index is not empty");
+  if (n_sent > 0xffffffffull || n_buf > 0xffffffffull) throw std::runtime_error("adopt_arrays: more than 2^32 - 1 sentences / buffer words");
+  // the sentence buffer: [len, tok x len, 0] per sentence, sentence_pos = offsets of the len words, in order
+  uint64_t expect = 0, tokens = 0;
+  uint32_t vs = vocab_size_;
+  for (uint64_t s = 0; s < n_sent; s++) {
+    if (spos[s] != expect || expect >= n_buf) throw std::runtime_error("adopt_arrays: sentence_pos does not walk the sentence buffer");
+    const uint64_t len = buffer[expect];
+    if (len == 0 || len > 65535 || expect + len + 1 >= n_buf || buffer[expect + len + 1] != 0)
+      throw std::runtime_error("adopt_arrays: malformed sentence in the buffer");
+    for (uint64_t k = 1; k <= len; k++) { const uint32_t w = buffer[expect + k]; if (w >= vs) vs = w + 1; }
+    tokens += len;
+    expect += len + 2;
+  }
+  if (expect != n_buf) throw std::runtime_error("adopt_arrays: trailing words in the sentence buffer");
+  if (n_suf != tokens) throw std::runtime_error("adopt_arrays: the suffix array must hold one suffix per token");
+  buf.assign(buffer, buffer + n_buf);
+  sent_pos.assign(spos, spos + n_sent);
+  suf_sid.assign(sid, sid + n_suf);
+  suf_pos.assign(pos, pos + n_suf);
+  for (uint64_t i = 0; i < n_suf; i++)
+    if (suf_sid[i] >= n_sent || suf_pos[i] == 0 || suf_pos[i] > buf[sent_pos[suf_sid[i]]])
+      throw std::runtime_error("adopt_arrays: suffix outside its sentence");
+  // order: every adjacent pair up to a million suffixes, an evenly spread sample of a million pairs beyond
+  const uint64_t step = n_suf > (1ull << 20) ? n_suf >> 20 : 1;
+  for (uint64_t i = 0; i + 1 < n_suf; i += step)
+    if (!suffix_before(buf, sent_pos, suf_sid[i], suf_pos[i], suf_sid[i + 1], suf_pos[i + 1]))
+      throw std::runtime_error("adopt_arrays: the suffix array is not in SuffixArray::comp order");
+  vocab_size = vs;
+  // _quickVocabAccess — src/suffix_array.cc:76-98 (recomputed; a caller-supplied copy must agree)
+  qva.assign((size_t)vocab_size + 1, 0);
+  for (uint64_t i = 0; i < n_suf; i++) qva[buf[sent_pos[suf_sid[i]] + suf_pos[i]] + 1]++;
+  for (uint32_t w = 0; w < vocab_size; w++) qva[w + 1] += qva[w];
+  if (qva_in) {
+    // the reference's vector has one entry per word id it has seen plus the total; compare the common prefix
+    const uint64_t n_cmp = std::min<uint64_t>(n_qva, qva.size());
+    for (uint64_t w = 0; w < n_cmp; w++)
+      if (qva_in[w] != qva[w]) throw std::runtime_error("adopt_arrays: _quickVocabAccess does not match the suffix array");
+  }
+  // VocabIndexer::sfreq — sentences containing the word (src/vocab_indexer.cc:37-50)
+  sfreq.assign(vocab_size, 0);
+  if (sfreq_in) {
+    for (uint32_t w = 0; w < vocab_size_ && w < vocab_size; w++) sfreq[w] = sfreq_in[w];
+  } else {
+    std::vector<uint32_t> distinct;
+    for (uint64_t s = 0; s < n_sent; s++) {
+      const uint32_t* t = buf.data() + sent_pos[s] + 1;
+      distinct.assign(t, t + buf[sent_pos[s]]);
+      std::sort(distinct.begin(), distinct.end());
+      distinct.erase(std::unique(distinct.begin(), distinct.end()), distinct.end());
+      for (uint32_t w : distinct) sfreq[w]++;
+    }
+  }
+  sorted = true;
+}
+
 void HostIndex::bucket_keys(std::vector<uint64_t>& keys, std::vector<uint64_t>& bucket_off) const {
   const uint64_t n = suf_sid.size();
   keys.resize(n);
@@ -348,6 +422,7 @@ void HostIndex::build_gram_table(int nthreads) {
 constexpr uint32_t kMaxItokStrings = 32768;  // the table is quadratic: 2 GB at the limit
 
 uint32_t HostIndex::intern_itok(const std::string& s) {
+  std::lock_guard<std::mutex> lk(itok_sync_mu);
   if (itok_strings.empty()) {
     itok_strings.emplace_back();
     itok_intern.emplace(std::string(), 0u);
@@ -377,13 +452,24 @@ uint32_t HostIndex::intern_itok(const std::string& s) {
   return id;
 }
 
+static void compact_itok(const std::vector<uint16_t>& tab, uint32_t cap, uint32_t n, std::vector<uint16_t>& out) {
+  out.assign((size_t)n * n, 0);
+  for (uint32_t a = 0; a < n; a++) memcpy(&out[(size_t)a * n], &tab[(size_t)a * cap], (size_t)n * sizeof(uint16_t));
+}
+
 void HostIndex::sync_itok_dist() const {
   std::lock_guard<std::mutex> lk(itok_sync_mu);
-  if (itok_dist_version == itok_version) return;
-  const uint32_t n = (uint32_t)itok_strings.size();
-  itok_dist.assign((size_t)n * n, 0);
-  for (uint32_t a = 0; a < n; a++) memcpy(&itok_dist[(size_t)a * n], &itok_tab[(size_t)a * itok_cap], (size_t)n * sizeof(uint16_t));
-  itok_dist_version = itok_version;
+  const uint64_t v = itok_version.load();
+  if (itok_dist_version == v) return;
+  compact_itok(itok_tab, itok_cap, (uint32_t)itok_strings.size(), itok_dist);
+  itok_dist_version = v;
+}
+
+void HostIndex::snapshot_itok_dist(std::vector<uint16_t>& out, uint32_t& n, uint64_t& version) const {
+  std::lock_guard<std::mutex> lk(itok_sync_mu);
+  version = itok_version.load();
+  n = (uint32_t)itok_strings.size();
+  compact_itok(itok_tab, itok_cap, n, out);
 }
 
 uint32_t HostIndex::lookup_real(const std::string& s) const {

@@ -3,6 +3,7 @@
 // are uploaded to HBM.  Pure C++17, no HIP.
 #pragma once
 #include <stdint.h>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -83,9 +84,13 @@ class HostIndex {
   uint32_t                                  itok_cap = 0;
   mutable std::vector<uint16_t>             itok_dist;
   mutable uint64_t                          itok_dist_version = ~0ull;
+  // itok_sync_mu guards itok_strings / itok_intern / itok_tab / itok_cap / itok_dist: intern_itok() takes it for its whole
+  // body, so a match() that interns a new string cannot re-lay out the table under another thread's snapshot
   mutable std::mutex                        itok_sync_mu;
   void sync_itok_dist() const;
-  uint64_t                                  itok_version = 0;
+  // a consistent copy of the compact table with the version and string count it belongs to (what a device replica uploads)
+  void snapshot_itok_dist(std::vector<uint16_t>& out, uint32_t& n, uint64_t& version) const;
+  std::atomic<uint64_t>                     itok_version{0};
 
   HostIndex();
 
@@ -96,6 +101,12 @@ class HostIndex {
   // SuffixArrayIndex::add_tm (src/suffix_array_index.cc:10-30): returns the new sentence id or -1
   // when skipped (empty real tokens, or more than max_tokens normalised tokens).
   int64_t add_tm(const std::string& id, const RealTok& real_tokens, const std::vector<std::string>& norm);
+  // Adopt the reference's SuffixArray members as they are (include/fuzzy/suffix_array.hh:50-61): an already sorted suffix
+  // array, the sentence buffer, sentence positions and (optionally) _quickVocabAccess / VocabIndexer::sfreq.  Validates
+  // the structure (not the sort order of every pair: adjacent suffixes of a sample are compared).  Id-only index.
+  void adopt_arrays(const uint32_t* sid, const uint16_t* pos, uint64_t n_suf, const uint32_t* buffer, uint64_t n_buf,
+                    const uint32_t* spos, uint64_t n_sent, const uint32_t* qva_in, uint64_t n_qva, const uint32_t* sfreq_in,
+                    uint32_t vocab_size_);
   // id-level bulk add (synthetic corpora): CSR token stream with ids >= 2 already assigned.
   void add_ids_bulk(const uint32_t* off, const uint32_t* toks, uint64_t n_sent, uint32_t vocab_size_);
 
@@ -111,7 +122,7 @@ class HostIndex {
   uint32_t num_sentences() const { return (uint32_t)sent_pos.size(); }
   uint64_t num_suffixes() const { return suf_sid.size(); }
 
-  // penalty-string interning for query batches; grows itok_dist (not thread safe; callers lock)
+  // penalty-string interning for query batches; grows the distance table (thread safe: serialised on itok_sync_mu)
   uint32_t intern_itok(const std::string& s);
   uint32_t lookup_real(const std::string& s) const;  // 0x7ffffffe when absent
 

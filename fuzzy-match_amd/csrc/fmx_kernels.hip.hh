@@ -55,6 +55,11 @@ struct DevBatch {
   uint32_t        nq;       // queries in this sub-batch
   uint32_t        t_begin;  // q_off[q_begin]
   uint32_t        nt;       // tokens in this sub-batch
+  // contrastive rerank against matches the caller's vector already holds (src/fuzzy_match.cc:622-650): their token
+  // sequences (Match::s, Match::length) as CSR, shared by every query of the batch; n_prior == 0: none
+  const uint32_t* prior_off;
+  const uint32_t* prior_tok;
+  uint32_t        n_prior;
 };
 
 struct QHit;
@@ -2484,7 +2489,8 @@ template <int MODE>
 __device__ __forceinline__ void select_body(const DevIndex& ix, const Params& prm, const Cand* seg, uint32_t n,
                                             uint32_t np2, unsigned long long* keys, uint32_t* vals, float* pen_sum,
                                             float* pen_cur, float* s_rows, uint32_t cap, Rec* out,
-                                            uint32_t& out_count, uint32_t& out_total) {
+                                            uint32_t& out_count, uint32_t& out_total, const uint32_t* prior_off = nullptr,
+                                            const uint32_t* prior_tok = nullptr, uint32_t n_prior = 0) {
   const uint32_t lane = lane_id();
   const uint32_t want = prm.nmatch == 0 ? n : (prm.nmatch < n ? prm.nmatch : n);
   const uint32_t emit = want < cap ? want : cap;
@@ -2521,12 +2527,40 @@ __device__ __forceinline__ void select_body(const DevIndex& ix, const Params& pr
   side.itok_dist = nullptr; side.n_itok = 0; side.p_idf = nullptr; side.idf_weight = 0.f;
   uint32_t picked = 0;
   int last = -1;
+  // Entries already in the caller's `matches` (src/fuzzy_match.cc:622-650: "for (Match &match_memory : matches)" runs over
+  // them first, in order, in every round): their penalties are folded in before the first pick, the running sum / maximum
+  // continue over the picks.  Only the general kernels (MODE >= 2: float DP, rows in LDS / HBM) take priors; k_finish queues
+  // every query for them when the batch has any.
+  uint32_t n_mem = 0;  // penalties per candidate so far (priors + picks)
+  if (MODE >= 2) {
+    for (uint32_t r = 0; r < n_prior; r++) {
+      const uint32_t* s2 = prior_tok + prior_off[r];
+      const uint32_t n2 = prior_off[r + 1] - prior_off[r];
+      n_mem++;
+      for (uint32_t k = lane; k < n; k += kWave) {
+        const uint32_t csp = ix.sent_pos[seg[k].sid];
+        const uint32_t n1 = ix.tok[csp];
+        const float dw = 100.f / normalizer(n1, n2, 1.f, 1.f, 1.f);
+        float M;
+        const float ed = edit_distance<false>(ix.tok + csp + 1, n1, s2, n2, 1.f, 1.f, 1.f, dw, side, FLT_MAX, LdsRow{s_rows + lane}, M);
+        const float pen = score_from_cost(ed);
+        const float sum = pen_sum[k] + pen;
+        pen_sum[k] = sum;
+        float mx = __uint_as_float((uint32_t)(keys[k] & 0xffffffffull));
+        mx = (n_mem == 1) ? pen : (mx < pen ? pen : mx);
+        keys[k] = (unsigned long long)__float_as_uint(mx);
+        pen_cur[k] = prm.reduce == 1 ? mx : (sum / (float)n_mem);
+      }
+      __syncthreads();
+    }
+  }
   while (picked < n && (prm.nmatch == 0 || picked < prm.nmatch)) {
     if (last >= 0) {
       const uint32_t msid = seg[last].sid;
       const uint32_t msp = ix.sent_pos[msid];
       const uint32_t n2 = ix.tok[msp];
       const uint32_t* s2 = ix.tok + msp + 1;
+      n_mem++;
       for (uint32_t k = lane; k < n; k += kWave) {
         if (keys[k] >> 63) continue;
         const uint32_t csid = seg[k].sid;
@@ -2542,9 +2576,9 @@ __device__ __forceinline__ void select_body(const DevIndex& ix, const Params& pr
         const float sum = pen_sum[k] + pen;
         pen_sum[k] = sum;
         float mx = __uint_as_float((uint32_t)(keys[k] & 0xffffffffull));
-        mx = (picked == 1) ? pen : (mx < pen ? pen : mx);
+        mx = (n_mem == 1) ? pen : (mx < pen ? pen : mx);
         keys[k] = (unsigned long long)__float_as_uint(mx);
-        pen_cur[k] = prm.reduce == 1 ? mx : (sum / (float)picked);
+        pen_cur[k] = prm.reduce == 1 ? mx : (sum / (float)n_mem);
       }
       __syncthreads();
     }
@@ -2661,8 +2695,9 @@ __global__ void __launch_bounds__(kWave) k_finish(DevIndex ix, DevBatch b, DevWo
         w.q_acc[q] = n;
         // contrastive rerank: queries whose accepted sentences are longer than 32 / 64 tokens are queued for the
         // wider kernels; everything else is done by k_contrast<0> in place
-        if (contrast && n != 0 && (mx > 32 || n > kMaxFlatAccepted)) {
-          const uint32_t cls = (mx <= 64 && n <= kMaxFlatAccepted) ? 1u : 2u;  // the flattened rerank indexes a query's matches with 16 bits
+        if (contrast && n != 0 && (mx > 32 || n > kMaxFlatAccepted || b.n_prior != 0)) {
+          // (prior matches of the caller's vector, any length: only the general kernel folds them in)
+          const uint32_t cls = (mx <= 64 && n <= kMaxFlatAccepted && b.n_prior == 0) ? 1u : 2u;  // the flattened rerank indexes a query's matches with 16 bits
           // (the flattened rerank finds the queries of class 1 through their class bits: only the per-query kernels read the
           // list, and a same-address atomic per query is what this kernel would then spend its time on)
           const bool flat = prm.nmatch >= 1 && prm.nmatch <= kMaxFlatRounds;
@@ -2814,9 +2849,9 @@ __global__ void __launch_bounds__(kWave) k_contrast(DevIndex ix, DevBatch b, Dev
     uint32_t cnt = 0, tot = 0;
     if (n != 0) {
       const uint32_t np2 = next_pow2(n);
-      if (np2 <= kContrastLds) select_body<MODE>(ix, prm, seg, n, np2, s_keys, s_vals, s_f0, s_f1, s_rows, cap, out, cnt, tot);
+      if (np2 <= kContrastLds) select_body<MODE>(ix, prm, seg, n, np2, s_keys, s_vals, s_f0, s_f1, s_rows, cap, out, cnt, tot, b.prior_off, b.prior_tok, b.n_prior);
       else select_body<MODE>(ix, prm, seg, n, np2, sc.keys + 2ull * seg0, sc.vals + 2ull * seg0, sc.f0 + seg0, sc.f1 + seg0,
-                             s_rows, cap, out, cnt, tot);
+                             s_rows, cap, out, cnt, tot, b.prior_off, b.prior_tok, b.n_prior);
     }
     if (lane == 0) { out_count[gq] = cnt; if (out_total) out_total[gq] = tot; }
     __syncthreads();

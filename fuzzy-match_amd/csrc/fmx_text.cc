@@ -1,10 +1,97 @@
 // fmx_text.cc — restricted text front-end (see fmx_text.hh for scope and pinning).
 #include "fmx_text.hh"
 
+#include <dlfcn.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+
+#include <mutex>
 
 namespace fmx {
 namespace {
+
+// ---------------------------------------------------------------------------------------------
+// normalize() — src/fuzzy_match.cc:43-58: icu::Normalizer2::getNFCInstance()->normalize(UnicodeString::fromUTF8(text)),
+// back to UTF-8; on an ICU error the text is returned unchanged.  ICU is a system library, not part of this build: its
+// C API (unorm2_*, u_strFromUTF8WithSub, u_strToUTF8WithSub — what the C++ calls above are made of) is bound at run time
+// from the libicuuc the box has.  Symbols carry the library's major version as a suffix ("unorm2_normalize_70").
+// ---------------------------------------------------------------------------------------------
+typedef uint16_t UCh;
+struct Icu {
+  const void* (*get_nfc)(int* err) = nullptr;
+  int32_t (*normalize)(const void* n2, const UCh* src, int32_t len, UCh* dst, int32_t cap, int* err) = nullptr;
+  UCh* (*from_utf8)(UCh* dst, int32_t cap, int32_t* out_len, const char* src, int32_t len, int32_t sub, int32_t* n_sub, int* err) = nullptr;
+  char* (*to_utf8)(char* dst, int32_t cap, int32_t* out_len, const UCh* src, int32_t len, int32_t sub, int32_t* n_sub, int* err) = nullptr;
+  const void* nfc = nullptr;
+  bool ok = false;
+};
+
+const Icu& icu() {
+  static Icu g;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    void* h = nullptr;
+    int ver = 0;
+    if (const char* path = getenv("FMX_ICU_LIB")) {  // e.g. /usr/lib/x86_64-linux-gnu/libicuuc.so.70 ("none" disables)
+      if (strcmp(path, "none") != 0) h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+      if (h) { const char* dot = strrchr(path, '.'); if (dot) ver = atoi(dot + 1); }
+    } else {
+      for (int v = 80; v >= 50 && !h; v--) {
+        char name[64];
+        snprintf(name, sizeof name, "libicuuc.so.%d", v);
+        h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (h) ver = v;
+      }
+    }
+    auto sym = [&](const char* base) -> void* {
+      char name[96];
+      snprintf(name, sizeof name, "%s_%d", base, ver);
+      void* p = h ? dlsym(h, name) : nullptr;
+      if (!p && h) p = dlsym(h, base);  // builds without symbol renaming
+      return p;
+    };
+    if (h) {
+      g.get_nfc = (decltype(g.get_nfc))sym("unorm2_getNFCInstance");
+      g.normalize = (decltype(g.normalize))sym("unorm2_normalize");
+      g.from_utf8 = (decltype(g.from_utf8))sym("u_strFromUTF8WithSub");
+      g.to_utf8 = (decltype(g.to_utf8))sym("u_strToUTF8WithSub");
+      if (g.get_nfc && g.normalize && g.from_utf8 && g.to_utf8) {
+        int err = 0;
+        g.nfc = g.get_nfc(&err);
+        g.ok = err <= 0 && g.nfc != nullptr;  // U_FAILURE(code) = code > U_ZERO_ERROR
+      }
+    }
+    if (!g.ok)
+      fprintf(stderr, "fmx: WARNING: no usable ICU (libicuuc) found: sentences are NOT NFC-normalised, input is taken as NFC "
+                      "(the reference normalises, src/fuzzy_match.cc:43-58)\n");
+  });
+  return g;
+}
+
+std::string nfc_normalize(const std::string& text) {
+  bool ascii = true;
+  for (unsigned char c : text) if (c >= 0x80) { ascii = false; break; }
+  if (ascii) return text;  // ASCII is NFC
+  const Icu& u = icu();
+  if (!u.ok) return text;
+  int err = 0;
+  int32_t n16 = 0, n_sub = 0;
+  std::basic_string<UCh> src(text.size() + 1, 0);  // UTF-16 is never longer (in units) than UTF-8 (in bytes)
+  u.from_utf8(&src[0], (int32_t)src.size(), &n16, text.data(), (int32_t)text.size(), 0xFFFD, &n_sub, &err);  // fromUTF8: ill-formed -> U+FFFD
+  if (err > 0) return text;
+  std::basic_string<UCh> dst((size_t)n16 * 3 + 16, 0);  // NFC grows a string at most threefold
+  err = 0;
+  const int32_t m16 = u.normalize(u.nfc, src.data(), n16, &dst[0], (int32_t)dst.size(), &err);
+  if (err > 0) return text;  // "if (U_FAILURE(error_code)) return text_utf8"
+  std::string out((size_t)m16 * 3 + 4, '\0');
+  int32_t n8 = 0;
+  err = 0;
+  u.to_utf8(&out[0], (int32_t)out.size(), &n8, dst.data(), m16, 0xFFFD, &n_sub, &err);
+  if (err > 0) return text;
+  out.resize((size_t)n8);
+  return out;
+}
 
 typedef uint32_t cp_t;
 
@@ -388,7 +475,7 @@ void tokenize_aggressive(int pt, const std::string& text, std::vector<std::strin
 // src/fuzzy_match.cc:108-193
 void tokenize_and_normalize(int pt, const std::string& sentence, TextTokens& out) {
   out = TextTokens();
-  tokenize_aggressive(pt, sentence, out.raw, out.feat);
+  tokenize_aggressive(pt, nfc_normalize(sentence), out.raw, out.feat);  // src/fuzzy_match.cc:115-116
   out.map_tokens.push_back(0);
   auto set_itok = [&](uint64_t idx, const std::string& s) {  // Sentence::set_itok appends (include/fuzzy/sentence.hxx)
     if (!out.itoks.empty() && out.itoks.back().first == idx) out.itoks.back().second += s;

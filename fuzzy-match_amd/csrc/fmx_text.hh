@@ -2,10 +2,12 @@
 // RESTRICTED restatement of the tokenizer the reference configures in _update_tokenizer (src/fuzzy_match.cc:70-91):
 // OpenNMT Tokenizer v1.20, Mode::Aggressive, flags SegmentAlphabetChange | NoSubstitution | SupportPriorJoiners
 // (+ CaseFeature under pt_cas, + JoinerNew | JoinerAnnotate under pt_jnr, + SpacerNew | SpacerAnnotate under pt_sep),
-// segmenting Han / Kanbun / Katakana / Hiragana / Thai / Myanmar.  That library and ICU are third-party code absent
+// segmenting Han / Kanbun / Katakana / Hiragana / Thai / Myanmar.  That library is third-party code absent
 // from this image, so its published behaviour is restated for the character classes listed in fmx_text.cc
 // (Latin, Greek, Cyrillic, Armenian, Hebrew, Arabic, Indic, Thai, Myanmar, Georgian, Hangul, kana, Han, digits,
-// ASCII / Latin-1 / general punctuation); ICU NFC normalisation is NOT applied (input is taken as NFC).  It is pinned
+// ASCII / Latin-1 / general punctuation).  ICU's NFC normalisation (src/fuzzy_match.cc:43-58) IS applied, through the
+// system's libicuuc bound at run time (fmx_text.cc: icu(); without one a warning is printed once and the input is taken
+// as NFC).  It is pinned
 // by the reference's own text fixtures (test/data/tm1, test-tm1, test-tm1-{pct,sep,jnr,nonbr-nocas}, tm2.en.gz +
 // test-tm2: tests/test_text_frontend.py); text outside those classes is parity-unpinned.
 #pragma once

@@ -75,7 +75,8 @@ EXPORTS = [
     "fmx_host_alloc", "fmx_host_free", "fmx_index_to_devices", "fmx_set_devices", "fmx_index_reopen", "fmx_match_one", "fmx_match_batch_keep",
     "fmx_subsequence_batch", "fmx_text_tokenize", "fmx_text_free", "fmx_text_num_tokens", "fmx_text_norm", "fmx_text_real",
     "fmx_text_num_itoks", "fmx_text_itok_index", "fmx_text_itok", "fmx_text_num_raw", "fmx_text_raw", "fmx_text_map",
-    "fmx_text_detokenize", "fmx_index_add_text", "fmx_index_device_array",
+    "fmx_text_detokenize", "fmx_index_add_text", "fmx_index_device_array", "fmx_index_from_arrays", "fmx_text_feature",
+    "fmx_match_one_prior",
 ]
 TM_SKIPPED = -100
 
@@ -137,6 +138,11 @@ def lib():
     L.fmx_index_to_devices.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int]
     L.fmx_set_devices.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int]
     L.fmx_index_reopen.argtypes = [C.c_void_p]
+    L.fmx_index_from_arrays.restype = C.c_void_p
+    L.fmx_index_from_arrays.argtypes = [C.c_int32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p,
+                                        C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_char_p, C.c_size_t]
+    L.fmx_match_one_prior.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.fmx_match_one.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.fmx_subsequence_batch.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_uint32, C.c_int32, C.c_int32, C.c_float,
@@ -273,6 +279,23 @@ class Index:
             raise FmxError(err.value.decode("utf-8", "replace"))
         return cls(h)
 
+    @classmethod
+    def from_arrays(cls, suf_sid, suf_pos, buffer, sent_pos, qva=None, sfreq=None, vocab_size=0, pt=0, max_tokens=300):
+        """fmx_index_from_arrays: adopt an already sorted suffix array + sentence buffer (the reference's SuffixArray members)."""
+        suf_sid = np.ascontiguousarray(suf_sid, dtype=np.uint32)
+        suf_pos = np.ascontiguousarray(suf_pos, dtype=np.uint16)
+        buffer = np.ascontiguousarray(buffer, dtype=np.uint32)
+        sent_pos = np.ascontiguousarray(sent_pos, dtype=np.uint32)
+        qva = None if qva is None else np.ascontiguousarray(qva, dtype=np.uint32)
+        sfreq = None if sfreq is None else np.ascontiguousarray(sfreq, dtype=np.uint32)
+        err = C.create_string_buffer(512)
+        h = lib().fmx_index_from_arrays(pt, max_tokens, _ptr(suf_sid), _ptr(suf_pos), len(suf_sid), _ptr(buffer), len(buffer),
+                                        _ptr(sent_pos), len(sent_pos), _ptr(qva), 0 if qva is None else len(qva), _ptr(sfreq),
+                                        vocab_size or (0 if sfreq is None else len(sfreq)), err, 512)
+        if not h:
+            raise FmxError(err.value.decode("utf-8", "replace"))
+        return cls(h)
+
     def close(self):
         if self.h:
             lib().fmx_index_free(self.h)
@@ -345,6 +368,24 @@ class Index:
             q_itok = np.ascontiguousarray(q_itok, dtype=np.uint32)
         _check(lib().fmx_match_one(self.h, C.byref(params), _ptr(wids), len(wids), _ptr(q_real), _ptr(q_itok), _ptr(out),
                                    cap, C.byref(cnt), C.byref(tot)))
+        return out[:cnt.value], tot.value
+
+    def match_one_prior(self, params, wids, prior, q_real=None, q_itok=None, cap=None):
+        """match() for one pattern when the caller's vector already holds `prior` matches (lists of token ids) and the
+        contrastive factor is > 0; params.nmatch = NEW matches wanted."""
+        wids = np.ascontiguousarray(wids, dtype=np.uint32)
+        cap = cap or (params.nmatch if params.nmatch > 0 else 64)
+        out = np.zeros(cap, dtype=MATCH_DTYPE)
+        cnt, tot = C.c_uint32(0), C.c_uint32(0)
+        p_off = np.zeros(len(prior) + 1, np.uint32)
+        p_off[1:] = np.cumsum([len(x) for x in prior])
+        p_tok = np.ascontiguousarray(np.concatenate([np.asarray(x, np.uint32) for x in prior]) if len(prior) else np.zeros(1, np.uint32), dtype=np.uint32)
+        if q_real is not None:
+            q_real = np.ascontiguousarray(q_real, dtype=np.uint32)
+        if q_itok is not None:
+            q_itok = np.ascontiguousarray(q_itok, dtype=np.uint32)
+        _check(lib().fmx_match_one_prior(self.h, C.byref(params), _ptr(wids), len(wids), _ptr(q_real), _ptr(q_itok), _ptr(p_off),
+                                         _ptr(p_tok), len(prior), _ptr(out), cap, C.byref(cnt), C.byref(tot)))
         return out[:cnt.value], tot.value
 
     def info(self):

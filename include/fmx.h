@@ -121,6 +121,17 @@ void       fmx_index_free(fmx_index*);
 /* import_binarized_fuzzy_matcher — include/fuzzy/fuzzy_matcher_binarization.hh:9,
  * src/fuzzy_matcher_binarization.cc:32-51 (the reference throws; here NULL + error text) */
 fmx_index* fmx_index_load(const char* fmi_path, char* err, size_t errlen);
+/* Adopt the members of the reference's SuffixArray as they are — an index built and SORTED elsewhere (include/fuzzy/
+ * suffix_array.hh:50-61: _suffixes as parallel sentence-id / 1-based position arrays, _sentence_buffer = [len, tok x len, 0]
+ * per sentence, _sentence_pos, _quickVocabAccess) plus VocabIndexer::sfreq (include/fuzzy/vocab_indexer.hh:40).
+ * quick_vocab_access and sfreq may be NULL (recomputed).  The arrays are copied and validated (structure, and the
+ * SuffixArray::comp order of adjacent suffixes, src/suffix_array.cc:235-251); the result is a sorted id-only index:
+ * fmx_index_finalize + fmx_index_to_device make it searchable, fmx_index_save writes it as .fmi.  NULL + error text on
+ * failure (SURVEY §8b lists this entry point next to fmx_index_load). */
+fmx_index* fmx_index_from_arrays(int32_t pt, uint64_t max_tokens_in_pattern, const uint32_t* suf_sid, const uint16_t* suf_pos,
+                                 uint64_t n_suffixes, const uint32_t* sentence_buffer, uint64_t buffer_size,
+                                 const uint32_t* sentence_pos, uint64_t n_sentences, const uint32_t* quick_vocab_access,
+                                 uint64_t n_qva, const uint32_t* sfreq, uint32_t vocab_size, char* err, size_t errlen);
 /* export_binarized_fuzzy_matcher — fuzzy_matcher_binarization.hh:8 */
 int        fmx_index_save(const fmx_index*, const char* fmi_path);
 
@@ -225,6 +236,15 @@ int fmx_match_batch_device(fmx_index*, const fmx_params*, const fmx_batch* devic
 int fmx_match_one(fmx_index*, const fmx_params*, const uint32_t* wids, uint32_t p, const uint32_t* q_real,
                   const uint32_t* q_itok, fmx_match* out, uint32_t cap, uint32_t* out_count, uint32_t* out_total);
 
+/* fmx_match_one when the caller's `matches` vector already holds entries and contrastive_factor > 0: the reference's
+ * rerank loop penalises every new candidate against ALL of `matches` — the entries that were there before the call
+ * first, in their order, then its own picks (src/fuzzy_match.cc:622-650, "for (Match &match_memory : matches)").
+ * prior_off / prior_tok: the token sequences (Match::s, Match::length) of the n_prior entries as CSR.  params->nmatch is
+ * the number of NEW matches wanted (the facade passes number_of_matches - matches.size()).  Not coalesced. */
+int fmx_match_one_prior(fmx_index*, const fmx_params*, const uint32_t* wids, uint32_t p, const uint32_t* q_real,
+                        const uint32_t* q_itok, const uint32_t* prior_off, const uint32_t* prior_tok, uint32_t n_prior,
+                        fmx_match* out, uint32_t cap, uint32_t* out_count, uint32_t* out_total);
+
 /* FuzzyMatch::subsequence(...) — include/fuzzy/fuzzy_match.hh:99-105, src/fuzzy_match.cc:250-365, for a batch of
  * tokenised patterns: the sub-n-gram of the pattern with the largest weight (its length, or its summed idf when
  * idf_weighting) that occurs in an indexed sentence, and the best of up to number_of_matches sentences containing
@@ -238,8 +258,9 @@ int fmx_subsequence_batch(fmx_index*, const fmx_batch* host_batch, uint32_t numb
  * FuzzyMatch::_tokenize_and_normalize — src/fuzzy_match.cc:108-193: tokenise a sentence and split it into the
  * normalised tokens (`pattern`), the real tokens and the penalty strings (`real`) according to the penalty-token mask
  * pt.  The tokenizer is a restricted restatement of the one the reference configures (src/fuzzy_match.cc:70-91,
- * OpenNMT Tokenizer, aggressive mode) — see fuzzy-match_amd/csrc/fmx_text.hh for what it covers; ICU NFC
- * normalisation is not applied.  The handle owns every string it returns. */
+ * OpenNMT Tokenizer, aggressive mode) — see fuzzy-match_amd/csrc/fmx_text.hh for what it covers.  The sentence is first
+ * NFC-normalised by ICU like the reference does (src/fuzzy_match.cc:43-58), through the libicuuc of the system found at
+ * run time (without one: a warning on stderr once, and the input is taken as NFC).  The handle owns every string it returns. */
 typedef struct fmx_text fmx_text;
 fmx_text*   fmx_text_tokenize(int32_t pt, const char* sentence, size_t len);
 void        fmx_text_free(fmx_text*);
@@ -251,6 +272,7 @@ uint64_t    fmx_text_itok_index(const fmx_text*, uint32_t k);
 const char* fmx_text_itok(const fmx_text*, uint32_t k);
 uint32_t    fmx_text_num_raw(const fmx_text*);                  /* tokenizer output (`tokens`, src/fuzzy_match.cc:113) */
 const char* fmx_text_raw(const fmx_text*, uint32_t i);
+const char* fmx_text_feature(const fmx_text*, uint32_t i);      /* case feature of raw token i (`features[0][i]`; "N" without pt_cas) */
 uint32_t    fmx_text_map(const fmx_text*, uint32_t k);          /* map_tokens[k], k in [0, num_tokens] */
 /* detokenised raw tokens [map[from], map[to]) — what subsequence() appends to Match::id (src/fuzzy_match.cc:341-348) */
 const char* fmx_text_detokenize(fmx_text*, uint32_t from, uint32_t to);

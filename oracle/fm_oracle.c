@@ -686,6 +686,10 @@ typedef struct fmo_scratch {
   float*     pen_sum;
   float*     pen_max;
   uint32_t*  pen_cnt;
+  /* entries the caller's `matches` vector holds on entry (fmo_match_prior): token sequences as CSR */
+  uint32_t        n_prior;
+  const uint32_t* prior_off;
+  const uint32_t* prior_tok;
 } fmo_scratch;
 
 static void scratch_free(fmo_scratch* s) {
@@ -1016,11 +1020,27 @@ static int64_t match_impl(const fmo_index* ix, const fmo_params* prm, const uint
       sc->pen_cnt = (uint32_t*)xrealloc(sc->pen_cnt, sc->cap_memo * sizeof(uint32_t));
     }
     /* the list `candidates` keeps (score desc, s_id asc) order; erased entries are flagged.
-     * `matches` is taken to be empty on entry.  Every (candidate, picked) pair is evaluated
-     * exactly once per round in pick order, so the memo (fuzzy_match.cc:627) never changes a
-     * value and running sums equal std::accumulate over the penalties vector. */
+     * Every (candidate, memory) pair is evaluated exactly once in `matches` order (the entries the vector held on
+     * entry first — sc->n_prior of them, src/fuzzy_match.cc:634 "for (Match &match_memory : matches)" — then the
+     * picks), so the memo (fuzzy_match.cc:627) never changes a value and running sums equal std::accumulate over the
+     * penalties vector.  number_of_matches here counts NEW matches: the caller passes the reference's
+     * number_of_matches minus the entries already in its vector (loop condition fuzzy_match.cc:629). */
     uint8_t* taken = (uint8_t*)calloc(n ? n : 1, 1);
     for (uint64_t i = 0; i < n; i++) { sc->pen_sum[i] = 0.f; sc->pen_max[i] = 0.f; sc->pen_cnt[i] = 0; }
+    for (uint32_t r = 0; r < sc->n_prior; r++) {
+      const uint32_t* ms = sc->prior_tok + sc->prior_off[r];
+      const int mlen = (int)(sc->prior_off[r + 1] - sc->prior_off[r]);
+      for (uint64_t i = 0; i < n; i++) {
+        acc_match* m = &sc->result[i];
+        const float dw = 100.f / fmo_normalizer((uint64_t)m->length, (uint64_t)mlen, 1.f, 1.f, 1.f);
+        float pen = fmo_edit_distance_ids(m->s, m->length, ms, mlen, 1.f, 1.f, 1.f, dw, FLT_MAX);
+        pen = fmo_score_from_cost(pen);
+        sc->pen_sum[i] = sc->pen_sum[i] + pen;
+        sc->pen_max[i] = sc->pen_cnt[i] ? (sc->pen_max[i] < pen ? pen : sc->pen_max[i]) : pen;
+        sc->pen_cnt[i]++;
+        m->penalty = prm->reduce == 1 ? sc->pen_max[i] : sc->pen_sum[i] / (float)sc->pen_cnt[i];
+      }
+    }
     uint64_t remaining = n;
     int64_t  last_pick = -1;
     while (remaining && (number_of_matches == 0 || n_out < number_of_matches)) {
@@ -1092,6 +1112,19 @@ int64_t fmo_match(const fmo_index* ix, const fmo_params* prm, const uint32_t* p_
   }
   int64_t r = match_impl(ix, prm, p_wids, p, rp, out, cap, ctr, &sc);
   real_clear(&real);
+  scratch_free(&sc);
+  return r;
+}
+
+/* match() when `matches` already holds n_prior entries (their token sequences as CSR): only the contrastive rerank
+ * looks at them (src/fuzzy_match.cc:622-650).  prm->nmatch = NEW matches wanted. */
+int64_t fmo_match_prior(const fmo_index* ix, const fmo_params* prm, const uint32_t* p_wids, uint32_t p,
+                        const uint32_t* prior_off, const uint32_t* prior_tok, uint32_t n_prior, fmo_rec* out, uint64_t cap) {
+  if (!ix || !prm || !ix->sorted) return -1;
+  fmo_scratch sc;
+  memset(&sc, 0, sizeof(sc));
+  sc.n_prior = n_prior; sc.prior_off = prior_off; sc.prior_tok = prior_tok;
+  int64_t r = match_impl(ix, prm, p_wids, p, NULL, out, cap, NULL, &sc);
   scratch_free(&sc);
   return r;
 }

@@ -114,6 +114,11 @@ int64_t fmo_match(const fmo_index*, const fmo_params*,
                   uint32_t n_itoks, const uint64_t* itok_idx, const char* const* itok_str,
                   fmo_rec* out, uint64_t cap, fmo_counters* ctr);
 
+/* fmo_match for id-only patterns when the caller's `matches` vector already holds n_prior entries (token sequences as
+ * CSR): the contrastive rerank penalises against them first (src/fuzzy_match.cc:622-650).  prm->nmatch = NEW matches. */
+int64_t fmo_match_prior(const fmo_index*, const fmo_params*, const uint32_t* p_wids, uint32_t p,
+                        const uint32_t* prior_off, const uint32_t* prior_tok, uint32_t n_prior, fmo_rec* out, uint64_t cap);
+
 /* batch of id-only patterns over `nthreads` workers sharing one const index, results in
  * input order (the CLI's -N pool, cli/src/FuzzyMatch-cli.cc:112-193).  out is nq*cap
  * records, out_count nq entries (clamped to cap).  ctr (optional) receives the summed counters. */

@@ -236,6 +236,22 @@ class OracleIndex:
             raise RuntimeError("oracle match failed")
         return out[:min(int(r), cap)], int(r)
 
+    def match_ids_prior(self, params, wids, prior, cap=256):
+        """match() on ids when the caller's vector already holds `prior` matches (lists of token ids); params.nmatch = NEW
+        matches wanted (src/fuzzy_match.cc:622-650)."""
+        w = np.ascontiguousarray(wids, np.uint32)
+        p_off = np.zeros(len(prior) + 1, np.uint32)
+        p_off[1:] = np.cumsum([len(x) for x in prior])
+        p_tok = np.ascontiguousarray(np.concatenate([np.asarray(x, np.uint32) for x in prior]) if len(prior) else np.zeros(1, np.uint32), np.uint32)
+        out = np.zeros(cap, dtype=MATCH_DTYPE)
+        self.L.fmo_match_prior.restype = C.c_int64
+        self.L.fmo_match_prior.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32,
+                                           C.c_void_p, C.c_uint64]
+        r = self.L.fmo_match_prior(self.h, C.byref(params), _ptr(w), len(w), _ptr(p_off), _ptr(p_tok), len(prior), _ptr(out), cap)
+        if r < 0:
+            raise RuntimeError("oracle match failed")
+        return out[:min(int(r), cap)], int(r)
+
     def match_tokens(self, params, tokens, real=None, itoks=None, cap=256):
         """match(const Tokens&, …) / match(Sentence, Tokens, …) with string tokens."""
         return self.match_ids(params, self.vocab.get_index(tokens), real=real, itoks=itoks, cap=cap)

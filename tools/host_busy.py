@@ -48,9 +48,11 @@ if sys.argv[1] == "analyse":
 import synth, fmx_import
 fmx = fmx_import.load().fmx
 T = int(sys.argv[1]); steps = int(sys.argv[2])
-c_off, c_tok, q_off, q_tok, vs = synth.corpus_and_queries(5_000_000, 1_000_000, 25)
+c_off, c_tok, q_off, q_tok, vs = synth.corpus_and_queries(5_000_000, int(os.environ.get('NQ', 1_000_000)), 25)
 ix = fmx.Index.create(); ix.add_ids(c_off, c_tok, vs); ix.sort(0); ix.finalize(); ix.to_device(0)
 ix.set_option("contexts", max(2, T))
+for opt in ("FMX_TURNS", "FMX_HOST_SUB_QUERIES"):
+    if os.environ.get(opt): ix.set_option(opt[4:].lower(), int(os.environ[opt]))
 params = fmx.Params(fuzzy=0.7, nmatch=5)
 po, pt = fmx.pinned_copy(q_off.astype(np.uint32)), fmx.pinned_copy(q_tok.astype(np.uint32))
 nq = len(q_off) - 1
