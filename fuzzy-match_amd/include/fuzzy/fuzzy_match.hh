@@ -158,8 +158,6 @@ class FuzzyMatch {
     // (src/fuzzy_match.cc:633,670)
     const size_t existing = matches.size();
     if (number_of_matches != 0 && existing >= number_of_matches) return true;
-    if (existing != 0 && contrastive_factor > 0)
-      throw std::logic_error("match(): contrastive rerank against matches already in the vector is not built (SURVEY §8a row J)");
     std::vector<const char*> toks;
     for (const auto& t : pattern) toks.push_back(t.c_str());
     std::vector<uint32_t> wids(p), q_real, q_itok;
@@ -179,10 +177,27 @@ class FuzzyMatch {
     uint32_t cap = prm.nmatch ? prm.nmatch : 64;
     std::vector<fmx_match> out;
     uint32_t count = 0, total = 0;
+    // entries already in `matches` take part in the contrastive rerank: every round penalises the candidates against
+    // ALL of `matches`, the prior entries first (src/fuzzy_match.cc:622-650); their token sequences go along
+    std::vector<uint32_t> prior_off, prior_tok;
+    const bool with_prior = existing != 0 && contrastive_factor > 0;
+    if (with_prior) {
+      prior_off.push_back(0);
+      for (const Match& m : matches) {
+        for (int k = 0; k < m.length; k++) prior_tok.push_back(m.s[k]);
+        prior_off.push_back((uint32_t)prior_tok.size());
+      }
+      if (prior_tok.empty()) prior_tok.push_back(0);
+    }
     for (;;) {  // number_of_matches == 0 means "all": grow until everything fits
       out.resize(cap);
-      check(fmx_match_one(_ix, &prm, wids.data(), p, q_real.empty() ? nullptr : q_real.data(),
-                          q_itok.empty() ? nullptr : q_itok.data(), out.data(), cap, &count, &total));
+      if (with_prior)
+        check(fmx_match_one_prior(_ix, &prm, wids.data(), p, q_real.empty() ? nullptr : q_real.data(),
+                                  q_itok.empty() ? nullptr : q_itok.data(), prior_off.data(), prior_tok.data(), (uint32_t)existing,
+                                  out.data(), cap, &count, &total));
+      else
+        check(fmx_match_one(_ix, &prm, wids.data(), p, q_real.empty() ? nullptr : q_real.data(),
+                            q_itok.empty() ? nullptr : q_itok.data(), out.data(), cap, &count, &total));
       if (total <= cap) break;
       cap = total;
     }
@@ -238,6 +253,31 @@ class FuzzyMatch {
     for (int k = 0; k < m.max_subseq; k++) { if (k) m.id += ' '; m.id += pattern[pos + k]; }
     matches.push_back(m);
     return true;
+  }
+
+  // _tokenize_and_normalize — include/fuzzy/fuzzy_match.hh:106-118, src/fuzzy_match.cc:93-193 (both public in the
+  // reference): NFC normalisation, the aggressive tokenizer configured from the penalty-token mask, then the split into
+  // normalised tokens (`pattern`), real tokens and penalty strings (`real`)
+  void _tokenize_and_normalize(const std::string& sentence, Sentence& real, Tokens& pattern) const {
+    std::vector<unsigned> map_tokens;
+    std::vector<std::string> tokens;
+    std::vector<std::vector<std::string>> features;
+    _tokenize_and_normalize(sentence, real, pattern, map_tokens, tokens, features);
+  }
+  // ... also the tokenizer's own tokens and features and, per normalised token, the raw-token index behind it
+  // (map_tokens[0] = 0).  `features` holds one stream (the case feature) under pt_cas and none otherwise, like the
+  // tokenizer's output for the flags the reference sets (src/fuzzy_match.cc:70-80).
+  void _tokenize_and_normalize(const std::string& sentence, Sentence& real, Tokens& pattern, std::vector<unsigned>& map_tokens,
+                               std::vector<std::string>& tokens, std::vector<std::vector<std::string>>& features) const {
+    TextHandle t(_pt, sentence);
+    t.fill(real, pattern);
+    const uint32_t n_raw = fmx_text_num_raw(t.h), n = fmx_text_num_tokens(t.h);
+    for (uint32_t i = 0; i < n_raw; i++) tokens.emplace_back(fmx_text_raw(t.h, i));
+    if (_pt & pt_cas) {
+      features.emplace_back();
+      for (uint32_t i = 0; i < n_raw; i++) features.back().emplace_back(fmx_text_feature(t.h, i));
+    }
+    for (uint32_t k = 0; k <= n; k++) map_tokens.push_back(fmx_text_map(t.h, k));
   }
 
   size_t max_tokens_in_pattern() const { return _max_tokens; }

@@ -29,6 +29,29 @@ int main(int argc, char** argv) {
   } catch (const std::exception&) {
     std::puts("MISSING_FILE_THROWS");  // test/test.cc:22-26
   }
+  {
+    // the public _tokenize_and_normalize overloads (include/fuzzy/fuzzy_match.hh:106-118): host work, no device needed
+    fuzzy::FuzzyMatch tk(fuzzy::FuzzyMatch::pt_tag | fuzzy::FuzzyMatch::pt_nbr | fuzzy::FuzzyMatch::pt_cas);
+    fuzzy::Sentence real;
+    fuzzy::Tokens pattern;
+    tk._tokenize_and_normalize("Hello World 42 \xE2\x84\xA6", real, pattern);  // U+2126 OHM SIGN -> U+03A9 under NFC
+    std::printf("TOKNORM %zu", pattern.size());
+    for (const auto& t : pattern) std::printf("\t%s", t.c_str());
+    std::printf("\t|");
+    for (const auto& t : (fuzzy::Tokens)real) std::printf("\t%s", t.c_str());
+    std::printf("\n");
+    fuzzy::Sentence real2;
+    fuzzy::Tokens pattern2;
+    std::vector<unsigned> map_tokens;
+    std::vector<std::string> tokens;
+    std::vector<std::vector<std::string>> features;
+    tk._tokenize_and_normalize("Hello World 42 \xE2\x84\xA6", real2, pattern2, map_tokens, tokens, features);
+    std::printf("TOKNORM2 %zu %zu %zu %zu", pattern2.size(), map_tokens.size(), tokens.size(), features.size());
+    for (const auto& f : features) for (const auto& x : f) std::printf("\t%s", x.c_str());
+    std::printf("\t|");
+    for (unsigned m : map_tokens) std::printf("\t%u", m);
+    std::printf("\n");
+  }
   try {
     fuzzy::import_binarized_fuzzy_matcher(argv[1], fm);
   } catch (const std::exception& e) {
@@ -153,6 +176,34 @@ int main(int argc, char** argv) {
     std::printf("SUBSEQTOK %d\t%.9g\t%s\n", ok2 ? 1 : 0, sm.empty() ? 0.f : sm[0].score, sm.empty() ? "-" : sm[0].id.c_str());
     sm.clear();
     std::printf("SUBSEQNONE %d\n", ft.subsequence(std::string("zz yy"), 2, false, sm, 2, 0) ? 1 : 0);
+  }
+  // nfc_normalization — test/test.cc:305-335: the ohm sign is normalised into omega under NFC, on both sides
+  {
+    const std::string ohm = "\xE2\x84\xA6", omega = "\xCE\xA9";
+    fuzzy::FuzzyMatch fn;
+    fn.add_tm("", ohm);
+    fn.sort();
+    std::vector<fuzzy::FuzzyMatch::Match> m1, m2;
+    fn.match(ohm, 1, 1, false, m1, 1);
+    fn.match(omega, 1, 1, false, m2, 1);
+    std::printf("NFC %zu %zu\n", m1.size(), m2.size());
+  }
+  // contrastive rerank against matches already in the vector (src/fuzzy_match.cc:622-650); the hand-derived case of
+  // tests/test_prior_matches.py: empty vector -> A B C, vector holding B -> A C B (penalties .75 .75 .8333)
+  {
+    fuzzy::FuzzyMatch fp;
+    fp.add_tm("A", fuzzy::Tokens{"a", "b", "c", "d"});
+    fp.add_tm("B", fuzzy::Tokens{"a", "b", "c", "e"});
+    fp.add_tm("C", fuzzy::Tokens{"a", "b", "c", "f"});
+    std::vector<fuzzy::FuzzyMatch::Match> plain, held;
+    fp.match(fuzzy::Tokens{"a", "b", "c", "d"}, 0.5f, 3, plain, 2, 0, 0, fuzzy::EditCosts(), 1.0f);
+    fp.match(fuzzy::Tokens{"a", "b", "c", "e"}, 1.0f, 1, held, 2, 0);            // the vector now holds B
+    fp.match(fuzzy::Tokens{"a", "b", "c", "d"}, 0.5f, 4, held, 2, 0, 0, fuzzy::EditCosts(), 1.0f);
+    std::printf("PRIOR");
+    for (const auto& m : plain) std::printf("\t%s", m.id.c_str());
+    std::printf("\t|");
+    for (const auto& m : held) std::printf("\t%s:%.9g", m.id.c_str(), m.penalty);
+    std::printf("\n");
   }
   return 0;
 }

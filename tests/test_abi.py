@@ -189,3 +189,37 @@ def test_many_penalty_strings(fmx):
     for a, b in rng.integers(0, n, size=(300, 2)):
         assert d[a, b] == lev(strings[a].encode(), strings[b].encode()), (a, b)
     assert (d.diagonal() == 0).all() and d[0, 7] == len(strings[7])
+
+
+def test_index_from_arrays_adopts_the_reference_arrays(fmx, tmp_path):
+    """fmx_index_from_arrays: the SuffixArray members of a reference-built index (tm1.fmi) adopted as they
+    are -> the same arrays, the same derived tables; malformed input is refused with a message."""
+    src = fmx.Index.load(os.path.join(golden_util.GOLDEN, "tm1.fmi"))
+    arr = {k: np.array(src.array(k)) for k in ("suf_sid", "suf_pos", "buffer", "sent_pos", "qva", "sfreq")}
+    ix = fmx.Index.from_arrays(arr["suf_sid"], arr["suf_pos"], arr["buffer"], arr["sent_pos"], qva=arr["qva"], sfreq=arr["sfreq"], pt=49)
+    info = ix.info()
+    assert (info.n_sentences, info.n_suffixes, info.sorted, info.pt) == (8, 33, 1, 49)
+    for k in arr:
+        assert np.array_equal(np.array(ix.array(k)), arr[k]), k
+    ix.finalize()
+    src.finalize()
+    assert np.array_equal(np.array(ix.array("idf")), np.array(src.array("idf")))
+    # qva and sfreq recomputed when absent
+    ix2 = fmx.Index.from_arrays(arr["suf_sid"], arr["suf_pos"], arr["buffer"], arr["sent_pos"])
+    assert np.array_equal(np.array(ix2.array("qva")), arr["qva"]) and np.array_equal(np.array(ix2.array("sfreq"))[2:], arr["sfreq"][2:])
+    # refused: two suffixes swapped (order), a suffix outside its sentence, a wrong _quickVocabAccess, a broken buffer
+    bad = arr["suf_sid"].copy(), arr["suf_pos"].copy()
+    bad[0][[3, 4]] = bad[0][[4, 3]]
+    bad[1][[3, 4]] = bad[1][[4, 3]]
+    with pytest.raises(fmx.FmxError, match="order"):
+        fmx.Index.from_arrays(bad[0], bad[1], arr["buffer"], arr["sent_pos"])
+    pos = arr["suf_pos"].copy()
+    pos[0] = 60
+    with pytest.raises(fmx.FmxError, match="outside"):
+        fmx.Index.from_arrays(arr["suf_sid"], pos, arr["buffer"], arr["sent_pos"])
+    q = arr["qva"].copy()
+    q[3] += 1
+    with pytest.raises(fmx.FmxError, match="_quickVocabAccess"):
+        fmx.Index.from_arrays(arr["suf_sid"], arr["suf_pos"], arr["buffer"], arr["sent_pos"], qva=q)
+    with pytest.raises(fmx.FmxError):
+        fmx.Index.from_arrays(arr["suf_sid"], arr["suf_pos"], arr["buffer"][:-1], arr["sent_pos"])

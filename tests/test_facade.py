@@ -34,6 +34,12 @@ def test_facade_compiles_and_fails_loudly_without_gpu(fmx, tmp_path):
     r = subprocess.run([EXE, os.path.join(golden_util.GOLDEN, "tm1.fmi"), _cases_file(tmp_path)],
                        capture_output=True, text=True, timeout=120)
     assert "MISSING_FILE_THROWS" in r.stdout
+    # the public _tokenize_and_normalize overloads (pt_tag | pt_nbr | pt_cas): case features as real tokens, the number
+    # behind its placeholder, the ohm sign U+2126 NFC-normalised to capital omega U+03A9, then lowercased with feature C
+    tok = [l for l in r.stdout.splitlines() if l.startswith("TOKNORM ")][0].split("\t")
+    assert tok == ["TOKNORM 4", "hello", "world", "｟num｠", "\u03c9", "|", "C", "C", "42", "C"], tok
+    tok2 = [l for l in r.stdout.splitlines() if l.startswith("TOKNORM2 ")][0].split("\t")
+    assert tok2[0] == "TOKNORM2 4 5 4 1" and tok2[tok2.index("|") + 1:] == ["0", "1", "2", "3", "4"], tok2
     if fmx.device_count() == 0:
         assert r.returncode == 3 and "IMPORT_FAILED" in r.stdout  # no CPU fallback behind the facade
 
@@ -91,3 +97,7 @@ def test_facade_tm1_fixture(fmx, gpu_device, tmp_path):
     subt = [l for l in r.stdout.splitlines() if l.startswith("SUBSEQTOK ")][0].split("\t")
     assert subt[0] == "SUBSEQTOK 1" and subt[2:] == ["1=aa bb cc dd", "aa bb cc"]
     assert "SUBSEQNONE 0" in r.stdout
+    assert "NFC 1 1" in r.stdout                       # test/test.cc:305-335 (nfc_normalization)
+    prior = [l for l in r.stdout.splitlines() if l.startswith("PRIOR")][0].split("\t")
+    assert prior[1:4] == ["A", "B", "C"] and [x.split(":")[0] for x in prior[5:]] == ["B", "A", "C", "B"], prior
+    assert [float(x.split(":")[1]) for x in prior[6:]] == pytest.approx([0.75, 0.75, 0.8333333], abs=1e-6)

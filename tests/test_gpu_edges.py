@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 
 import oracle_lib
+import workloads
 
 pytestmark = pytest.mark.gpu
 
@@ -59,3 +60,24 @@ def test_duplicate_sentences_and_one_token_patterns(fmx, gpu_device):
                                 fuzzy=0.0, nmatch=0, min_subseq_length=1, min_subseq_ratio=0)
     assert gc.tolist() == oc.tolist() == [50, 3, 50]
     assert all(go[i, :gc[i]].tobytes() == oo[i, :oc[i]].tobytes() for i in range(3))
+
+
+def test_index_adopted_from_arrays_answers_like_the_index_it_came_from(fmx, gpu_device):
+    """fmx_index_from_arrays -> finalize -> device: the same records as the index whose arrays were adopted, and as the
+    oracle on those arrays."""
+    c_off, c_tok, q_off, q_tok, vs = workloads.synthetic(20000, 500, 20)
+    a = fmx.Index.create()
+    a.add_ids(c_off, c_tok, vs)
+    a.sort(gpu_device)
+    a.finalize()
+    b = fmx.Index.from_arrays(a.array("suf_sid"), a.array("suf_pos"), a.array("buffer"), a.array("sent_pos"), qva=a.array("qva"),
+                              sfreq=a.array("sfreq"))
+    b.finalize()
+    b.to_device(gpu_device)
+    o = oracle_lib.OracleIndex()
+    o.set_arrays(b.array("suf_sid"), b.array("suf_pos"), b.array("buffer"), b.array("sent_pos"), b.array("qva"), b.array("sfreq"))
+    kw = dict(fuzzy=0.6, nmatch=5)
+    oo, oc = o.match_batch(oracle_lib.Params(**kw), q_off, q_tok, 5, nthreads=oracle_lib.effective_cpus())
+    go, gc, _ = b.match_batch(fmx.Params(**kw), q_off, q_tok, cap=5)
+    workloads.compare(oo, oc, go, gc, "from_arrays")
+    assert int((gc > 0).sum()) > 100
