@@ -732,7 +732,7 @@ int64_t fmx_index_add_text(fmx_index* ix, const char* id, const char* sentence, 
 
 int fmx_index_reopen(fmx_index* ix) {
   if (!ix) return fail(FMX_E_INVALID, "null argument");
-  ix->co.reset();
+  // (the coalescer stays: it holds no device state, and it is constructed once per index — std::call_once)
   ix->devs.clear();
   ix->finalized = false;
   return FMX_OK;
@@ -741,7 +741,6 @@ int fmx_index_reopen(fmx_index* ix) {
 int fmx_match_batch_device(fmx_index* ix, const fmx_params* params, const fmx_batch* db, uint64_t total_tokens,
                            fmx_match* d_out, uint32_t* d_out_count, uint32_t* d_out_total, uint32_t cap,
                            void* stream, fmx_stats* stats) {
-  (void)total_tokens;
   if (!ix || !params || !db || !d_out || !d_out_count) return fail(FMX_E_INVALID, "null argument");
   if (cap == 0) return fail(FMX_E_INVALID, "cap must be > 0");
   if (!ix->finalized) return fail(FMX_E_STATE, "index is not finalized");
@@ -755,15 +754,65 @@ int fmx_match_batch_device(fmx_index* ix, const fmx_params* params, const fmx_ba
     v.nq = db->nq; v.q_off = db->q_off; v.q_tok = db->q_tok; v.q_real = db->q_real; v.q_itok = db->q_itok;
     v.p_max = db->max_len;
     const auto t0 = std::chrono::steady_clock::now();
-    std::vector<uint32_t> bounds = dev->sub_bounds_from_device(db->q_off, db->nq, &v.p_max, stream);
+    std::vector<uint32_t> bounds;
+    if (total_tokens != 0 && total_tokens <= 0xffffffffull && db->max_len != 0 && db->nq <= dev->sub_queries())
+      bounds = {0u, (uint32_t)total_tokens};  // one pass, everything known: no device read, no synchronisation up front
+    else
+      bounds = dev->sub_bounds_from_device(db->q_off, db->nq, &v.p_max, stream);
     if (v.p_max == 0) v.p_max = 1;
     Stats st;
+    // stats == NULL: the passes run back to back without per-stage events, and large calls issued from several host threads
+    // (each on its own stream) are chained on the GPU like fmx_match_batch chains them
     dev->match_device(ix->host, make_params(ix, params), v, (Rec*)d_out, d_out_count, d_out_total, cap, stream,
-                          bounds, &st);
+                          bounds, stats ? &st : nullptr);
     st.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     copy_stats(st, stats);
     return (int)FMX_OK;
   });
+}
+
+struct fmx_pending {
+  DeviceIndex*          dev = nullptr;
+  DeviceIndex::Pending* p = nullptr;
+};
+
+int fmx_match_batch_device_begin(fmx_index* ix, const fmx_params* params, const fmx_batch* db, uint64_t total_tokens,
+                                 fmx_match* d_out, uint32_t* d_out_count, uint32_t* d_out_total, uint32_t cap, void* stream,
+                                 fmx_pending** pending) {
+  if (!ix || !params || !db || !d_out || !d_out_count || !pending) return fail(FMX_E_INVALID, "null argument");
+  *pending = nullptr;
+  if (cap == 0) return fail(FMX_E_INVALID, "cap must be > 0");
+  if (!ix->finalized) return fail(FMX_E_STATE, "index is not finalized");
+  if (ix->devs.empty()) return fail(FMX_E_NO_DEVICE, "index is not on a device (fmx_index_to_device); there is no CPU path");
+  if (ix->host.real_differs && !db->q_real)
+    return fail(FMX_E_INVALID, "this index has real tokens: device batches must carry q_real");
+  return guarded([&]() {
+    std::unique_ptr<fmx_pending> h(new fmx_pending);
+    if (db->nq == 0) { *pending = h.release(); return (int)FMX_OK; }
+    DeviceIndex* dev = ix->devs[0].get();
+    DeviceBatchView v;
+    v.nq = db->nq; v.q_off = db->q_off; v.q_tok = db->q_tok; v.q_real = db->q_real; v.q_itok = db->q_itok;
+    v.p_max = db->max_len;
+    std::vector<uint32_t> bounds;
+    if (total_tokens != 0 && total_tokens <= 0xffffffffull && db->max_len != 0 && db->nq <= dev->sub_queries())
+      bounds = {0u, (uint32_t)total_tokens};
+    else
+      bounds = dev->sub_bounds_from_device(db->q_off, db->nq, &v.p_max, stream);
+    if (v.p_max == 0) v.p_max = 1;
+    h->dev = dev;
+    h->p = dev->match_device_begin(ix->host, make_params(ix, params), v, (Rec*)d_out, d_out_count, d_out_total, cap, stream, bounds);
+    *pending = h.release();
+    return (int)FMX_OK;
+  });
+}
+
+int fmx_match_batch_device_end(fmx_index* ix, fmx_pending* pending) {
+  if (!ix || !pending) return fail(FMX_E_INVALID, "null argument");
+  std::unique_ptr<fmx_pending> h(pending);
+  if (!h->p) return FMX_OK;
+  DeviceIndex::Pending* p = h->p;
+  h->p = nullptr;
+  return guarded([&]() { h->dev->match_device_end(p); return (int)FMX_OK; });
 }
 
 int fmx_set_option(fmx_index* ix, const char* name, int64_t value) {

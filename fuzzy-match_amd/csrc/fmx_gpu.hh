@@ -75,6 +75,7 @@ class DeviceIndex {
   // test / debug: one of the device-built arrays (0 suf, 1 suf_sig, 2 suf_key, 3 gram, 4 gram5, 5 suf_b); returns its element count
   uint64_t download(int which, void* dst, uint64_t capacity_bytes) const;
   uint64_t bytes() const;
+  uint32_t sub_queries() const;
   void     set_sub_queries(uint32_t n);
   void     set_host_sub_queries(uint32_t n);
   void     set_initial_segment(uint64_t n);
@@ -92,6 +93,13 @@ class DeviceIndex {
   void match_device(const HostIndex& h, const Params& prm, const DeviceBatchView& b, Rec* d_out,
                     uint32_t* d_out_count, uint32_t* d_out_total, uint32_t cap, void* stream,
                     const std::vector<uint32_t>& sub_tok_bounds, Stats* st);
+  // the two halves of match_device without statistics: begin enqueues every pass and returns, end waits (and re-runs a pass whose
+  // workspace overflowed).  Several calls may be pending at once, each in its own context; end on the thread that began.
+  struct Pending;
+  Pending* match_device_begin(const HostIndex& h, const Params& prm, const DeviceBatchView& b, Rec* d_out, uint32_t* d_out_count,
+                              uint32_t* d_out_total, uint32_t cap, void* stream, const std::vector<uint32_t>& sub_tok_bounds);
+  void match_device_end(Pending*);
+  void match_device_abandon(Pending*);
   // host buffers: H2D, match_device, D2H
   // d_keep / d_keep_count (optional, in the HBM of device()): the records are also left there
   void match_host(const HostIndex& h, const Params& prm, const HostBatchView& b, Rec* out, uint32_t* out_count,

@@ -99,6 +99,9 @@ template <class T> struct Grow {
 };
 
 constexpr int kMaxPassesInFlight = 2;
+constexpr uint64_t kTurnMinQueries = 262144;  // device-resident calls at least this large are chained on the GPU (Impl::turns), smaller ones overlap freely
+constexpr uint64_t kTurnMinQueriesHost = 32768;  // host-buffer calls: chained from here on (their copies interleave badly when the kernels of
+                                                 // 100 k-query calls overlap freely: 46 M patterns/s against 86 M chained at C2)
 constexpr int kScanSlots = 4;  // scans per pass: queue capacities, queued hits, candidate classes, contrast lists
 
 // Everything one call mutates.
@@ -141,6 +144,9 @@ struct Ctx {
   hipStream_t stream = nullptr, h2d = nullptr, d2h = nullptr, side = nullptr;
   hipEvent_t  ev[2 * kNumStages]{};   // [2 s], [2 s + 1]: start / end of stage s (the last stage's pair lives on the side stream)
   hipEvent_t  ev_fork = nullptr, ev_join = nullptr, ev_cmin = nullptr, ev_a = nullptr, ev_in[kMaxPassesInFlight]{}, ev_done = nullptr;
+  hipEvent_t  ev_chain = nullptr;  // the last kernel of a call's first group (what the next call waits for on the GPU: a plain event —
+                                   // the ev_pass events are made for a sleeping host and are slow to wait for from another stream)
+  hipEvent_t  ev_mid = nullptr;  // the memory-bound half of a pass (probe, long ranges) is through: the next call's probe may start (turns = 2)
   unsigned long long* h_ctr = nullptr;  // pinned: the pass counters land here
   char* h_small = nullptr; char* d_small = nullptr; size_t h_small_bytes = 0;  // pinned block of the one-launch path (host / device view)
   unsigned long long* h_ctr_group = nullptr;  // pinned: one slot per pass of an asynchronous group
@@ -198,6 +204,8 @@ struct Ctx {
     HIP_TRY(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&ev_cmin, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&ev_a, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&ev_mid, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&ev_chain, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming | hipEventBlockingSync));  // the host sleeps on it (see ev_pass)
     for (auto& e : ev_in) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIP_TRY(hipHostMalloc((void**)&h_ctr, kNumCounters * sizeof(unsigned long long), hipHostMallocDefault));
@@ -222,6 +230,8 @@ struct Ctx {
     if (ev_join) (void)hipEventDestroy(ev_join);
     if (ev_cmin) (void)hipEventDestroy(ev_cmin);
     if (ev_a) (void)hipEventDestroy(ev_a);
+    if (ev_mid) (void)hipEventDestroy(ev_mid);
+    if (ev_chain) (void)hipEventDestroy(ev_chain);
     if (ev_done) (void)hipEventDestroy(ev_done);
     if (h_ctr) (void)hipHostFree(h_ctr);
     if (h_small) (void)hipHostFree(h_small);
@@ -248,8 +258,11 @@ struct DeviceIndex::Impl {
   std::mutex              turn_mu;
   std::condition_variable turn_cv;
   int                     turn_busy = 0;
-  uint32_t                turns = 1;     // 0 = no turns; 1 = chained on the GPU (each call's first kernel waits for the event that ends
-                                         // the previous call's kernels: no hand-over through the host); 3 = turns taken on the host
+  uint32_t                turns = 2;     // 0 = no turns; 1 = chained on the GPU (each call's first kernel waits for the event that ends
+                                         // the previous call's kernels: no hand-over through the host); 2 = chained behind the
+                                         // predecessor's memory-bound half (its probe and long-range kernels): the probe of a call,
+                                         // bound by HBM, runs beside the hit walk / edit distances / replay of the call before it,
+                                         // bound by instruction issue and latency; 3 = turns taken on the host
   std::mutex              chain_mu;
   hipEvent_t              chain_last = nullptr;  // ends the kernels of the call enqueued last (owned by its context)
   // what passes needed so far, per 1024 queries, shared by all contexts: a context sizes its workspace for a full pass of the
@@ -292,6 +305,11 @@ struct DeviceIndex::Impl {
     { std::lock_guard<std::mutex> lk(pool_mu); idle.push_back(c); }
     pool_cv.notify_one();
   }
+  // true when acquire() would not have to wait for another call to finish
+  bool context_available() {
+    std::lock_guard<std::mutex> lk(pool_mu);
+    return !idle.empty() || all.size() < max_ctx;
+  }
 };
 
 struct CtxLease {
@@ -322,6 +340,7 @@ DeviceIndex::~DeviceIndex() {
 
 int      DeviceIndex::device() const { return impl_->device; }
 uint64_t DeviceIndex::bytes() const { return impl_->bytes; }
+uint32_t DeviceIndex::sub_queries() const { return impl_->sub_queries; }
 void     DeviceIndex::set_sub_queries(uint32_t n) { impl_->sub_queries = std::max<uint32_t>(n, 1); }
 void     DeviceIndex::set_host_sub_queries(uint32_t n) { impl_->host_sub_queries = std::max<uint32_t>(n, 1); }
 void     DeviceIndex::set_initial_segment(uint64_t n) { impl_->init_seg = std::max<uint64_t>(n, 1024); }
@@ -538,7 +557,9 @@ static void ensure_ws(Ctx& c, uint64_t nq, uint64_t nt, uint64_t seg) {
   c.c_in.ensure(3 * (nq + 1)); c.c_off.ensure(3 * (nq + 1));
   c.t_q.ensure(nt); c.t_lo.ensure(nt); c.t_cnt.ensure(nt); c.t_idf.ensure(nt);
   if (seg > c.seg_cap) {
-    const uint64_t s = std::max<uint64_t>(seg, c.seg_cap + c.seg_cap / 2);
+    // (the candidate lists name segment slots with 32 bits; a pass is at most a few million queries)
+    if (seg > 0xffffffffull) throw UnsupportedError("a pass needs more than 2^32 - 1 segment entries: lower \"sub_queries\"");
+    const uint64_t s = std::min<uint64_t>(std::max<uint64_t>(seg, c.seg_cap + c.seg_cap / 2), 0xffffffffull);
     c.c_qi.ensure(s); c.seg.ensure(s); c.f0.ensure(s); c.f1.ensure(s);
     c.keys.ensure(2 * s); c.vals.ensure(2 * s);
     c.seg_cap = s;
@@ -704,6 +725,7 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
         // that are not light is a chain of memory latencies on a small grid and must reach the GPU FIRST — workgroups of
         // the oldest kernel are placed first, and the light kernel's million workgroups would starve anything younger
         join();
+        HIP_TRY(hipEventRecord(c.ev_mid, stream));  // probe + long ranges done: what follows is bound by instruction issue and latency
         tick(); tick();
         second_scan(stream);
         fork();
@@ -897,21 +919,44 @@ static void add_counters(Stats* st, const unsigned long long* ctr) {
 
 constexpr uint32_t kAsyncGroup = 32;  // passes enqueued before the host looks at their counters
 
-// async_ok: the passes of a group are enqueued back to back (the host runs ahead of the GPU, no bubble between passes);
-// their counters are checked afterwards and a pass whose workspace was too small is re-run (first calls only).
-// Otherwise (device entry point with stage timing) each pass is synchronised and timed.
-static void run_passes(DeviceIndex::Impl& m, Ctx& c, const Params& prm_in, const DeviceBatchView& bv, Rec* d_out,
-                       uint32_t* d_out_count, uint32_t* d_out_total, uint32_t cap, hipStream_t stream,
-                       const std::vector<uint64_t>& sub_q_bounds, const std::vector<uint32_t>& sub_tok_bounds, Stats* st,
-                       const PassHooks* hooks, bool async_ok) {
-  if (cap == 0) throw std::invalid_argument("cap must be > 0");
-  // cost model: real-token / penalty-token terms need the general kernel (DP rows in LDS / HBM); idf alone has a
-  // register kernel
-  const bool side_terms = (m.d.real && bv.q_real) || (bv.q_itok != nullptr) || (m.d.itok != nullptr);
-  if (!c.qb.p) c.want_qb = std::min<uint64_t>(c.want_qb, std::max<uint64_t>(m.init_seg, 4096));  // a small initial segment also starts the queues small
-  PassEnv E{m, c, prm_in, side_terms, prm_in.idf_penalty != 0.f, d_out, d_out_count, d_out_total, cap, stream, bv.prior_max_len};
-  const uint32_t n_sub = (uint32_t)sub_tok_bounds.size() - 1;
-  auto batch_of = [&](uint32_t sb) {
+// One call's passes over a context.  async: the passes of a group are enqueued back to back (the host runs ahead of the GPU,
+// no bubble between passes); their counters are checked afterwards and a pass whose workspace was too small is re-run
+// (first calls only).  Otherwise (device entry point with stage timing) each pass is synchronised and timed.
+// begin_group / end_group are the two halves of a group, so that a caller may return to its own caller in between
+// (fmx_match_batch_device_begin / _end: several calls enqueued by ONE host thread).
+struct PassRun {
+  DeviceIndex::Impl& m;
+  Ctx& c;
+  DeviceBatchView bv;
+  std::vector<uint64_t> sub_q_bounds;
+  std::vector<uint32_t> sub_tok_bounds;
+  Stats* st;
+  PassHooks hooks;  // members may be empty
+  PassEnv E;
+  uint32_t n_sub;
+  uint64_t nq_eff, nt_eff;
+  PassLimits ran{};
+  hipStream_t stream;
+
+  PassRun(DeviceIndex::Impl& m_, Ctx& c_, const Params& prm_in, const DeviceBatchView& bv_, Rec* d_out, uint32_t* d_out_count,
+          uint32_t* d_out_total, uint32_t cap, hipStream_t stream_, std::vector<uint64_t> q_bounds, std::vector<uint32_t> tok_bounds,
+          Stats* st_, const PassHooks* hooks_)
+      : m(m_), c(c_), bv(bv_), sub_q_bounds(std::move(q_bounds)), sub_tok_bounds(std::move(tok_bounds)), st(st_),
+        hooks(hooks_ ? *hooks_ : PassHooks{}),
+        // cost model: real-token / penalty-token terms need the general kernel (DP rows in LDS / HBM); idf alone has a register kernel
+        E{m_, c_, prm_in, (m_.d.real && bv_.q_real) || (bv_.q_itok != nullptr) || (m_.d.itok != nullptr), prm_in.idf_penalty != 0.f, d_out,
+          d_out_count, d_out_total, cap, stream_, bv_.prior_max_len},
+        stream(stream_) {
+    if (cap == 0) throw std::invalid_argument("cap must be > 0");
+    if (!c.qb.p) c.want_qb = std::min<uint64_t>(c.want_qb, std::max<uint64_t>(m.init_seg, 4096));  // a small initial segment also starts the queues small
+    n_sub = (uint32_t)sub_tok_bounds.size() - 1;
+    // the largest pass this call could be cut into (the cut depends on what else is in flight): the workspace is sized for it
+    nq_eff = std::min<uint64_t>(std::max<uint64_t>(bv.nq, 1), m.sub_queries);
+    nt_eff = (uint64_t)((double)(sub_tok_bounds.back() - sub_tok_bounds.front()) * ((double)nq_eff / (double)std::max<uint64_t>(bv.nq, 1)) * 1.05) + 64;
+    c.want_qb = std::max<uint64_t>(c.want_qb, hinted(m.hint_qb_kq));
+  }
+  uint64_t hinted(const std::atomic<uint64_t>& kq) const { const uint64_t h = kq.load(); return h ? (h * nq_eff / 1024) + (h * nq_eff / 1024) / 8 + 1024 : 0ull; }
+  DevBatch batch_of(uint32_t sb) const {
     DevBatch b;
     b.q_off = bv.q_off; b.q_tok = bv.q_tok; b.q_real = bv.q_real; b.q_itok = bv.q_itok;
     b.prior_off = bv.prior_off; b.prior_tok = bv.prior_tok; b.n_prior = bv.n_prior;
@@ -920,30 +965,25 @@ static void run_passes(DeviceIndex::Impl& m, Ctx& c, const Params& prm_in, const
     b.t_begin = sub_tok_bounds[sb];
     b.nt = sub_tok_bounds[sb + 1] - sub_tok_bounds[sb];
     return b;
-  };
-  auto p_max_of = [&](const DevBatch& b) {
+  }
+  uint32_t p_max_of(const DevBatch& b) const {
     uint32_t p_max = (uint32_t)std::min<uint64_t>(E.prm.max_tokens, std::max<uint32_t>(b.nt, 1));
     return std::max<uint32_t>(1, std::min<uint32_t>(p_max, bv.p_max ? bv.p_max : p_max));
-  };
-  // the largest pass this call could be cut into (the cut depends on what else is in flight): the workspace is sized for it
-  const uint64_t nq_eff = std::min<uint64_t>(std::max<uint64_t>(bv.nq, 1), m.sub_queries);
-  const uint64_t nt_eff = (uint64_t)((double)(sub_tok_bounds.back() - sub_tok_bounds.front()) * ((double)nq_eff / (double)std::max<uint64_t>(bv.nq, 1)) * 1.05) + 64;
-  auto hinted = [&](const std::atomic<uint64_t>& kq) { const uint64_t h = kq.load(); return h ? (h * nq_eff / 1024) + (h * nq_eff / 1024) / 8 + 1024 : 0ull; };
-  c.want_qb = std::max<uint64_t>(c.want_qb, hinted(m.hint_qb_kq));
-  auto seg_for = [&](const DevBatch& b) {
+  }
+  uint64_t seg_for(const DevBatch& b) const {
     return std::max<uint64_t>(std::max<uint64_t>(c.seg_cap, hinted(m.hint_seg_kq)),
                               std::min<uint64_t>(m.init_seg, std::max<uint64_t>(4096, (uint64_t)b.nq * 64)));
-  };
+  }
   // one pass, synchronised, re-run until its workspace fits
-  auto run_sync = [&](uint32_t sb, bool call_before, uint64_t want_seg) {
+  void run_sync(uint32_t sb, bool call_before, uint64_t want_seg) {
     const DevBatch b = batch_of(sb);
     const uint32_t p_max = p_max_of(b);
     want_seg = std::max<uint64_t>(want_seg, seg_for(b));
-    if (call_before && hooks && hooks->before) hooks->before(sb);
+    if (call_before && hooks.before) hooks.before(sb);
     for (int attempt = 0;; attempt++) {
       ensure_ws(c, std::max<uint64_t>(b.nq, nq_eff), std::max<uint64_t>(std::max<uint32_t>(b.nt, 1), nt_eff), want_seg);
       c.cmin_tab.ensure((uint64_t)(p_max + 1) * kCminRow);
-      const PassLimits ran = limits_of(c);
+      const PassLimits lim = limits_of(c);
       enqueue_pass(E, b, p_max, st != nullptr, c.h_ctr);
       HIP_TRY(hipStreamSynchronize(stream));
       if (st) {
@@ -955,7 +995,7 @@ static void run_passes(DeviceIndex::Impl& m, Ctx& c, const Params& prm_in, const
         }
       }
       learn_sizes(m, c.h_ctr, b.nq);
-      if (pass_needs_retry(c, c.h_ctr, ran, want_seg)) {
+      if (pass_needs_retry(c, c.h_ctr, lim, want_seg)) {
         if (attempt >= 6) throw GpuError("workspace kept overflowing");
         if (st) st->n_retries++;
         continue;
@@ -963,22 +1003,21 @@ static void run_passes(DeviceIndex::Impl& m, Ctx& c, const Params& prm_in, const
       add_counters(st, c.h_ctr);
       break;
     }
-    if (hooks && hooks->after) hooks->after(sb, nullptr);
-  };
-  if (!async_ok) {
-    for (uint32_t sb = 0; sb < n_sub; sb++) run_sync(sb, true, 0);
-    return;
+    if (hooks.after) hooks.after(sb, nullptr);
   }
-  if (!c.h_ctr_group) HIP_TRY(hipHostMalloc((void**)&c.h_ctr_group, (size_t)kAsyncGroup * kNumCounters * sizeof(unsigned long long), hipHostMallocDefault));
-  while (c.ev_pass.size() < kAsyncGroup) {
-    hipEvent_t e;
-    // the host waits milliseconds on these: it sleeps instead of spinning (one process per GPU with three calls in flight
-    // each would otherwise keep 24 cores of an 8-GPU node busy doing nothing)
-    HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventBlockingSync));
-    c.ev_pass.push_back(e);
+  void run_all_sync() { for (uint32_t sb = 0; sb < n_sub; sb++) run_sync(sb, true, 0); }
+  void prepare_async() {
+    if (!c.h_ctr_group) HIP_TRY(hipHostMalloc((void**)&c.h_ctr_group, (size_t)kAsyncGroup * kNumCounters * sizeof(unsigned long long), hipHostMallocDefault));
+    while (c.ev_pass.size() < kAsyncGroup) {
+      hipEvent_t e;
+      // the host waits milliseconds on these: it sleeps instead of spinning (one process per GPU with three calls in flight
+      // each would otherwise keep 24 cores of an 8-GPU node busy doing nothing)
+      HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventBlockingSync));
+      c.ev_pass.push_back(e);
+    }
   }
-  for (uint32_t g0 = 0; g0 < n_sub; g0 += kAsyncGroup) {
-    const uint32_t g1 = std::min<uint32_t>(g0 + kAsyncGroup, n_sub);
+  // every launch of passes [g0, g1), nothing waited for
+  void begin_group(uint32_t g0, uint32_t g1) {
     // the workspace of the largest pass of the group, once (growing it later would wait for the passes in flight)
     uint64_t nq_max = 1, nt_max = 1, seg_max = 0;
     uint32_t pm_max = 1;
@@ -989,20 +1028,26 @@ static void run_passes(DeviceIndex::Impl& m, Ctx& c, const Params& prm_in, const
     }
     ensure_ws(c, std::max(nq_max, nq_eff), std::max(nt_max, nt_eff), seg_max);
     c.cmin_tab.ensure((uint64_t)(pm_max + 1) * kCminRow);
-    const PassLimits ran = limits_of(c);  // every pass of the group runs under these
+    ran = limits_of(c);  // every pass of the group runs under these
     for (uint32_t sb = g0; sb < g1; sb++) {
       const DevBatch b = batch_of(sb);
-      if (hooks && hooks->before) hooks->before(sb);
+      if (hooks.before) hooks.before(sb);
       enqueue_pass(E, b, p_max_of(b), false, c.h_ctr_group + (size_t)(sb - g0) * kNumCounters);
       HIP_TRY(hipEventRecord(c.ev_pass[sb - g0], stream));
     }
-    if (g0 == 0 && hooks && hooks->enqueued) hooks->enqueued(c.ev_pass[g1 - 1 - g0]);
+    if (g0 == 0 && hooks.enqueued) {
+      HIP_TRY(hipEventRecord(c.ev_chain, stream));
+      hooks.enqueued(c.ev_chain);
+    }
+  }
+  // waits for the group, hands the records on, re-runs what did not fit
+  void end_group(uint32_t g0, uint32_t g1) {
     // The records of a pass are sent home by the host once the pass is through, not queued behind an event: a copy that
     // waits in a DMA queue for its kernels holds up every copy queued after it — the inputs of the other calls in flight.
     for (uint32_t sb = g0; sb < g1; sb++) {
       HIP_TRY(hipEventSynchronize(c.ev_pass[sb - g0]));
-      if (sb + 1 == g1 && hooks && hooks->computed) hooks->computed();
-      if (hooks && hooks->after) hooks->after(sb, nullptr);
+      if (sb + 1 == g1 && hooks.computed) hooks.computed();
+      if (hooks.after) hooks.after(sb, nullptr);
     }
     HIP_TRY(hipStreamSynchronize(stream));
     uint64_t want_seg = 0;
@@ -1018,6 +1063,93 @@ static void run_passes(DeviceIndex::Impl& m, Ctx& c, const Params& prm_in, const
       run_sync(sb, false, want_seg);
     }
   }
+  void run_all_async() {
+    prepare_async();
+    for (uint32_t g0 = 0; g0 < n_sub; g0 += kAsyncGroup) {
+      const uint32_t g1 = std::min<uint32_t>(g0 + kAsyncGroup, n_sub);
+      begin_group(g0, g1);
+      end_group(g0, g1);
+    }
+  }
+};
+
+static void run_passes(DeviceIndex::Impl& m, Ctx& c, const Params& prm_in, const DeviceBatchView& bv, Rec* d_out,
+                       uint32_t* d_out_count, uint32_t* d_out_total, uint32_t cap, hipStream_t stream,
+                       const std::vector<uint64_t>& sub_q_bounds, const std::vector<uint32_t>& sub_tok_bounds, Stats* st,
+                       const PassHooks* hooks, bool async_ok) {
+  PassRun r(m, c, prm_in, bv, d_out, d_out_count, d_out_total, cap, stream, sub_q_bounds, sub_tok_bounds, st, hooks);
+  if (async_ok) r.run_all_async();
+  else r.run_all_sync();
+}
+
+// fmx_match_batch_device_begin / _end: the two halves of the stats-less device call, so that ONE host thread can keep several
+// calls in flight (each in its own context; chained on the GPU like concurrent callers are).
+struct DeviceIndex::Pending {
+  std::shared_lock<std::shared_mutex> rl;
+  std::unique_ptr<CtxLease> lease;
+  std::unique_ptr<PassRun> run;
+  bool done = false;
+};
+
+DeviceIndex::Pending* DeviceIndex::match_device_begin(const HostIndex& h, const Params& prm, const DeviceBatchView& bv, Rec* d_out,
+                                                      uint32_t* d_out_count, uint32_t* d_out_total, uint32_t cap, void* stream_v,
+                                                      const std::vector<uint32_t>& sub_tok_bounds) {
+  Impl& m = *impl_;
+  if (m.device < 0) throw GpuError("index is not on a device");
+  HIP_TRY(hipSetDevice(m.device));
+  if (!m.context_available())
+    throw std::invalid_argument("every context of the index is busy: end a pending call first, or raise the option \"contexts\"");
+  refresh_itok_table(m, h);
+  std::unique_ptr<Pending> p(new Pending);
+  p->rl = std::shared_lock<std::shared_mutex>(m.itok_mu);
+  p->lease.reset(new CtxLease(m));
+  Ctx& c = *p->lease->c;
+  hipStream_t stream = stream_v ? (hipStream_t)stream_v : c.stream;  // NULL: the context's stream, the caller's inputs are complete
+  std::vector<uint64_t> q_bounds;
+  for (uint64_t q = 0; q < bv.nq; q += m.sub_queries) q_bounds.push_back(q);
+  q_bounds.push_back(bv.nq);
+  if (q_bounds.size() != sub_tok_bounds.size()) throw std::invalid_argument("sub-batch bounds do not match the batch");
+  const uint32_t turns = bv.nq >= kTurnMinQueries ? m.turns : 0u;
+  std::unique_lock<std::mutex> chain_lk(m.chain_mu, std::defer_lock);
+  if (turns == 1 || turns == 2) {
+    chain_lk.lock();
+    if (m.chain_last) HIP_TRY(hipStreamWaitEvent(stream, m.chain_last, 0));
+  }
+  PassHooks hooks;
+  Ctx* cp = &c;
+  Impl* mp = &m;
+  bool chained = false;
+  hooks.enqueued = [mp, cp, turns, &chained](hipEvent_t last) {
+    mp->chain_last = (turns == 2 && mp->expand_order != 0 && !mp->serial) ? cp->ev_mid : last;
+    chained = true;
+  };
+  p->run.reset(new PassRun(m, c, prm, bv, d_out, d_out_count, d_out_total, cap, stream, q_bounds, sub_tok_bounds, nullptr, &hooks));
+  p->run->hooks.enqueued = nullptr;  // (re-armed below: the hook captures locals of this frame)
+  p->run->prepare_async();
+  if (p->run->n_sub <= kAsyncGroup) {
+    p->run->hooks.enqueued = hooks.enqueued;
+    p->run->begin_group(0, p->run->n_sub);
+    p->run->hooks.enqueued = nullptr;
+  } else {  // more passes than one group holds: the call runs to its end here
+    p->run->hooks.enqueued = hooks.enqueued;
+    p->run->run_all_async();
+    p->run->hooks.enqueued = nullptr;
+    p->done = true;
+  }
+  (void)chained;
+  return p.release();
+}
+
+void DeviceIndex::match_device_end(Pending* pending) {
+  std::unique_ptr<Pending> p(pending);
+  if (!p) return;
+  HIP_TRY(hipSetDevice(impl_->device));
+  if (!p->done) p->run->end_group(0, p->run->n_sub);
+}
+
+void DeviceIndex::match_device_abandon(Pending* pending) {
+  std::unique_ptr<Pending> p(pending);
+  if (p && p->run) (void)hipStreamSynchronize(p->run->stream);
 }
 
 void DeviceIndex::match_device(const HostIndex& h, const Params& prm, const DeviceBatchView& bv, Rec* d_out,
@@ -1029,14 +1161,32 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm, const Devi
   refresh_itok_table(m, h);
   std::shared_lock<std::shared_mutex> rl(m.itok_mu);
   CtxLease lease(m);
+  Ctx& c = *lease.c;
   // the caller's stream carries the work (NULL = the context's own stream)
-  hipStream_t stream = stream_v ? (hipStream_t)stream_v : lease.c->stream;
+  hipStream_t stream = stream_v ? (hipStream_t)stream_v : c.stream;
   if (!stream_v) HIP_TRY(hipDeviceSynchronize());  // inputs may have been produced on other streams
   std::vector<uint64_t> q_bounds;
   for (uint64_t q = 0; q < bv.nq; q += m.sub_queries) q_bounds.push_back(q);
   q_bounds.push_back(bv.nq);
   if (q_bounds.size() != sub_tok_bounds.size()) throw std::invalid_argument("sub-batch bounds do not match the batch");
-  run_passes(m, *lease.c, prm, bv, d_out, d_out_count, d_out_total, cap, stream, q_bounds, sub_tok_bounds, st, nullptr, false);
+  if (st) {  // per-stage HIP-event times wanted: every pass synchronised and timed
+    run_passes(m, c, prm, bv, d_out, d_out_count, d_out_total, cap, stream, q_bounds, sub_tok_bounds, st, nullptr, false);
+    return;
+  }
+  // No statistics: the passes are enqueued back to back and large calls from several host threads are chained on the GPU like
+  // the host-buffer path chains them (Impl::turns): each call's first kernel waits for the predecessor's chain event.
+  const uint32_t turns = bv.nq >= kTurnMinQueries ? m.turns : 0u;
+  std::unique_lock<std::mutex> chain_lk(m.chain_mu, std::defer_lock);
+  if (turns == 1 || turns == 2) {
+    chain_lk.lock();
+    if (m.chain_last) HIP_TRY(hipStreamWaitEvent(stream, m.chain_last, 0));
+  }
+  PassHooks hooks;
+  hooks.enqueued = [&](hipEvent_t last) {
+    if (chain_lk.owns_lock()) { m.chain_last = (turns == 2 && m.expand_order != 0 && !m.serial) ? c.ev_mid : last; chain_lk.unlock(); }
+  };
+  run_passes(m, c, prm, bv, d_out, d_out_count, d_out_total, cap, stream, q_bounds, sub_tok_bounds, nullptr, &hooks, true);
+  if (chain_lk.owns_lock()) chain_lk.unlock();
 }
 
 static bool is_pinned(const void* p) {
@@ -1276,12 +1426,14 @@ void DeviceIndex::match_host_full(const HostIndex& h, const Params& prm, const H
     ~Turn() { release(); }
   } turn(m);
   bool first_sent = false;
-  // (small calls — the coalescer's micro-batches, interactive callers — do not fill the GPU and simply overlap)
-  constexpr uint64_t kTurnMinQueries = 32768;
-  const uint32_t turns = nq >= kTurnMinQueries ? m.turns : 0u;
+  // (small calls — the coalescer's micro-batches, interactive callers, shards of a strongly scaled batch — do not fill the GPU
+  // for long and simply overlap: measured at 100 k and 125 k queries per call, 103 M patterns/s against 95 M chained)
+  const uint32_t turns = nq >= kTurnMinQueriesHost ? m.turns : 0u;
   std::unique_lock<std::mutex> chain_lk(m.chain_mu, std::defer_lock);
-  if (turns == 1) {
+  if (turns == 1 || turns == 2) {
     // chained on the GPU: calls enqueue in the order they take the lock, each behind the end of its predecessor's kernels
+    // (turns = 2: behind the predecessor's memory-bound half — its probe and long-range kernels — so that this call's probe,
+    // bound by HBM, runs beside the predecessor's hit walk / edit distances / replay, bound by instruction issue)
     send(0); first_sent = true;
     chain_lk.lock();
     if (m.chain_last) HIP_TRY(hipStreamWaitEvent(c.stream, m.chain_last, 0));
@@ -1294,7 +1446,7 @@ void DeviceIndex::match_host_full(const HostIndex& h, const Params& prm, const H
     if (s + 1 < n_sub) send(s + 1);  // travels while pass s computes
   };
   hooks.enqueued = [&](hipEvent_t last) {
-    if (chain_lk.owns_lock()) { m.chain_last = last; chain_lk.unlock(); }
+    if (chain_lk.owns_lock()) { m.chain_last = (turns == 2 && m.expand_order != 0 && !m.serial) ? c.ev_mid : last; chain_lk.unlock(); }
   };
   hooks.computed = [&]() { turn.release(); };
   // stage timing (st with events) is the device entry point's job: here the passes run back to back, unsynchronised

@@ -559,6 +559,9 @@ constexpr uint32_t kKeptReduced = 0x80000000u;
 __device__ __forceinline__ unsigned long long wave_sort64_upto(unsigned long long key, uint32_t n);
 
 constexpr int kBUnroll = 2;  // queued hits per lane per phase-B block (their records are loaded together)
+#ifndef FMX_LIGHT_WAVES
+#define FMX_LIGHT_WAVES 7
+#endif
 
 // a queued hit that passed phase B's dominance test, waiting in LDS for the token work
 struct __attribute__((aligned(16))) SurvB {
@@ -1230,13 +1233,18 @@ __global__ void __launch_bounds__(256) k_segbase(DevBatch b, DevWork w, WorkItem
 // signature bound is skipped (the exact coverage test decides).  !LIGHT: blocks [0, first_q_blocks) take chunk 0 of
 // query blockIdx.x, the others loop over the work-item list.
 template <bool LIGHT>
-__global__ void __launch_bounds__(kWave, 6) k_expand_b(DevIndex ix, DevBatch b, DevWork w, Params prm,
+__global__ void __launch_bounds__(kWave, LIGHT ? FMX_LIGHT_WAVES : 6) k_expand_b(DevIndex ix, DevBatch b, DevWork w, Params prm,
                                                        const WorkItem* items, uint32_t item_cap, uint32_t first_q_blocks) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t* s_pat = (uint32_t*)smem;
   __shared__ PatHash ph;
-  __shared__ SurvB s_surv[kWave * (kBUnroll + 1)];
+  // LIGHT: one block of 64 hits at a time (most light queries have no more), which keeps the kernel within 64 VGPRs and
+  // 5 KB of LDS: eight waves per SIMD hide the two dependent loads in front of the token work
+  constexpr int kBU = LIGHT ? 1 : kBUnroll;
+  __shared__ SurvB s_surv[LIGHT ? kWave + 16 : kWave * (kBU + 1)];  // a carried rest of fewer than 16 + one block
   __shared__ unsigned long long s_out[kWave];  // survivors (sentence id << 16 | match length) while they fit one wave
+  __shared__ uint32_t s_tb[kWave];             // ... where their sentence's tokens start (index into tok) and
+  __shared__ uint16_t s_sl[kWave];             // ... its length: handed to the edit-distance kernels with the candidate
   // LIGHT: the non-empty start positions (exclusive hit prefix, range start, start position) and this pattern length's row
   // of the phase-A threshold table
   __shared__ uint32_t s_npref[LIGHT ? kWave : 1];
@@ -1279,9 +1287,9 @@ __global__ void __launch_bounds__(kWave, 6) k_expand_b(DevIndex ix, DevBatch b, 
       const bool sole = n_q <= kPhaseBChunk;  // this wave is the query's only phase-B worker: no atomics needed
       bool in_lds = sole;                     // ... and up to 64 survivors stay in LDS and are reduced right here
       uint32_t n_out = 0;
-      QHit hq[kBUnroll];
-      SufRecB rb[kBUnroll];
-      bool v[kBUnroll];
+      QHit hq[kBU];
+      SufRecB rb[kBU];
+      bool v[kBU];
       if constexpr (LIGHT) {
         // the query's non-empty start positions, compacted: hit e belongs to the last one whose prefix is <= e
         const uint32_t t0 = o0 - b.t_begin;
@@ -1302,7 +1310,7 @@ __global__ void __launch_bounds__(kWave, 6) k_expand_b(DevIndex ix, DevBatch b, 
       }
       auto load_hits = [&](uint32_t e0) {
 #pragma unroll
-        for (int u = 0; u < kBUnroll; u++) {
+        for (int u = 0; u < kBU; u++) {
           const uint32_t e = e0 + u * kWave + lane;
           v[u] = e < e_hi;
           hq[u].i = 0; hq[u].it_need = 0;
@@ -1322,7 +1330,7 @@ __global__ void __launch_bounds__(kWave, 6) k_expand_b(DevIndex ix, DevBatch b, 
       };
       auto load_recs = [&]() {
 #pragma unroll
-        for (int u = 0; u < kBUnroll; u++) {
+        for (int u = 0; u < kBU; u++) {
           rb[u].off = 0; rb[u].rem = 0; rb[u].slen = 0; rb[u].prev = 0; rb[u].sid = 0;
           if (v[u]) rb[u] = ix.suf_b[hq[u].i];
         }
@@ -1335,12 +1343,12 @@ __global__ void __launch_bounds__(kWave, 6) k_expand_b(DevIndex ix, DevBatch b, 
       load_recs();
       wave_lds_sync();
       if (p <= kWave) pat_hash_build(ph, s_pat, p);
-      // Two stages per block of kWave * kBUnroll queued hits.  Stage 1: the dominance test (about two thirds
+      // Two stages per block of kWave * kBU queued hits.  Stage 1: the dominance test (about two thirds
       // of the queued hits fail it) compacts the survivors into LDS.  Stage 2: full waves of survivors do
       // the token work (match length + exact coverage), not diluted by dominated hits.
       uint32_t n_s = 0;
       // survivors of the token work go to the LDS set (while they fit one wave) or to the query's segment
-      auto append = [&](bool keep, uint32_t sid, uint32_t L) {
+      auto append = [&](bool keep, uint32_t sid, uint32_t L, uint32_t tb, uint32_t sl) {
         const unsigned long long mask = __ballot(keep);
         if (mask) {
           const uint32_t cnt = __popcll(mask);
@@ -1354,7 +1362,7 @@ __global__ void __launch_bounds__(kWave, 6) k_expand_b(DevIndex ix, DevBatch b, 
             in_lds = false;
           }
           if (in_lds) {
-            if (keep) s_out[n_out + rank] = ((unsigned long long)sid << 16) | (L & 0xffffu);
+            if (keep) { s_out[n_out + rank] = ((unsigned long long)sid << 16) | (L & 0xffffu); s_tb[n_out + rank] = tb; s_sl[n_out + rank] = (uint16_t)sl; }
           } else {
             uint32_t base = n_out;
             if (!sole) {
@@ -1388,7 +1396,8 @@ __global__ void __launch_bounds__(kWave, 6) k_expand_b(DevIndex ix, DevBatch b, 
           else keep = !reject_len(p, sl, prm) && !reject_cover(p, sl, cover, prm);
           sid = sv.sid;
         }
-        append(keep, sid, L);
+        const uint32_t sl_ = keep ? (s_surv[j0 + lane].rem_slen >> 16) : 0u;
+        append(keep, sid, L, keep ? s_surv[j0 + lane].off - (sl_ - (s_surv[j0 + lane].rem_slen & 0xffffu)) : 0u, sl_);
       };
       // patterns of up to 64 tokens (hash set built): kSubLanes lanes per survivor share the token work, so
       // a typical query's dozen survivors fill the wave instead of a fifth of it.  The lanes of a group
@@ -1486,12 +1495,12 @@ __global__ void __launch_bounds__(kWave, 6) k_expand_b(DevIndex ix, DevBatch b, 
           // need == 0: sentence length outside phase A's table, the length filter is still to be applied
           else keep = !reject_len(p, sl, prm) && !reject_cover(p, sl, cover, prm);
         }
-        append(keep, sv.sid, L);
+        append(keep, sv.sid, L, sv.off - (sl - rem), sl);
       };
       const uint32_t pass = p <= kWave ? kSubSurv : kWave;  // survivors per pass of the token work
       for (uint32_t e0 = e_lo; e0 < e_hi;) {
 #pragma unroll
-        for (int u = 0; u < kBUnroll; u++) {
+        for (int u = 0; u < kBU; u++) {
           const uint32_t it = hq[u].it_need >> 16;
           const bool dominated = it > 0 && rb[u].rem < rb[u].slen && rb[u].prev == s_pat[it ? it - 1 : 0];
           bool keep = v[u] && !dominated;
@@ -1511,7 +1520,7 @@ __global__ void __launch_bounds__(kWave, 6) k_expand_b(DevIndex ix, DevBatch b, 
           }
           n_s += __popcll(mask);
         }
-        e0 += kWave * kBUnroll;
+        e0 += kWave * kBU;
         const bool more = e0 < e_hi;
         if (more) { load_hits(e0); load_recs(); }  // next block's loads overlap this block's token work
         wave_lds_sync();
@@ -1537,12 +1546,15 @@ __global__ void __launch_bounds__(kWave, 6) k_expand_b(DevIndex ix, DevBatch b, 
         // what k_cand does for sets of up to 64 survivors: one candidate per sentence with its longest
         // match, ordered by (longest desc, sentence id asc)
         wave_lds_sync();
-        unsigned long long key = lane < n_out ? s_out[lane] : ~0ull;
+        // keys carry the survivor's slot in their low six bits (sentence id 32 | match length 16 | slot 6): after the two
+        // sorts every candidate still knows where its sentence's token base and length sit in LDS
+        unsigned long long key = lane < n_out ? ((s_out[lane] << 6) | lane) : ~0ull;
         if (n_out > 1) key = wave_sort64_upto(key, n_out);
         const uint32_t nlo = __shfl_down((uint32_t)key, 1, 64), nhi = __shfl_down((uint32_t)(key >> 32), 1, 64);
         const unsigned long long nxt = lane == 63 ? ~0ull : (((unsigned long long)nhi << 32) | nlo);
-        const bool last = lane < n_out && (nxt >> 16) != (key >> 16);
-        unsigned long long k2 = last ? (((unsigned long long)(0xffffu - (uint32_t)(key & 0xffffu)) << 32) | (key >> 16)) : ~0ull;
+        const bool last = lane < n_out && (nxt >> 22) != (key >> 22);
+        // (0xffff - L) 16 | sentence id 32 | slot 6
+        unsigned long long k2 = last ? (((unsigned long long)(0xffffu - (uint32_t)((key >> 6) & 0xffffu)) << 38) | ((key >> 22) << 6) | (key & 63ull)) : ~0ull;
         const unsigned long long lastm = __ballot(last);
         const uint32_t n_cand = __popcll(lastm);
         if (n_cand > 1) k2 = wave_sort64_upto(k2, n_out);
@@ -1551,10 +1563,13 @@ __global__ void __launch_bounds__(kWave, 6) k_expand_b(DevIndex ix, DevBatch b, 
           k2 = ((unsigned long long)__shfl((uint32_t)(k2 >> 32), src, 64) << 32) | __shfl((uint32_t)k2, src, 64);
         }
         if (lane < n_cand) {
+          const uint32_t slot = (uint32_t)(k2 & 63ull);
           Cand c;
-          c.sid = (uint32_t)(k2 & 0xffffffffu);
-          c.longest = 0xffffu - (uint32_t)(k2 >> 32);
-          c.score = 0.f; c.penalty = 0.f;
+          c.sid = (uint32_t)((k2 >> 6) & 0xffffffffull);
+          // the edit-distance kernels find the sentence without going through sent_pos: token base in `score` (0 = unknown:
+          // candidates rebuilt by k_cand*), sentence length beside the match length
+          c.longest = (0xffffu - (uint32_t)(k2 >> 38)) | ((uint32_t)s_sl[slot] << 16);
+          c.score = __uint_as_float(s_tb[slot]); c.penalty = 0.f;
           seg[lane] = c;
         }
         if (lane == 0) { w.q_cand[q] = n_cand; w.q_kept[q] = n_out | kKeptReduced; }
@@ -2069,15 +2084,18 @@ __global__ void __launch_bounds__(1024) k_cmap(DevBatch b, DevWork w, int full, 
       if (cls >= 2) base += w.c_off[stride + b.nq];
     }
   }
+  // list entry = query << 32 | absolute slot of the candidate in seg (the host keeps seg_cap below 2^32): the edit-distance
+  // kernels request the candidate record together with the query's offsets, not after q_seg[q]
+  const uint32_t s0 = n ? (uint32_t)w.q_seg[q] : 0u;
   if (n <= kCmapSmall)
-    for (uint32_t i = 0; i < n; i++) w.c_qi[base + i] = ((unsigned long long)q << 32) | i;
+    for (uint32_t i = 0; i < n; i++) w.c_qi[base + i] = ((unsigned long long)q << 32) | (s0 + i);
   unsigned long long big = __ballot(n > kCmapSmall);
   while (big) {
     const int l = __ffsll((long long)big) - 1;
     big &= big - 1ull;
-    const uint32_t qb = __shfl(q, l, 64), nb = __shfl(n, l, 64);
+    const uint32_t qb = __shfl(q, l, 64), nb = __shfl(n, l, 64), sb = __shfl(s0, l, 64);
     const unsigned long long bb = ((unsigned long long)__shfl((uint32_t)(base >> 32), l, 64) << 32) | __shfl((uint32_t)base, l, 64);
-    for (uint32_t i = lane; i < nb; i += kWave) w.c_qi[bb + i] = ((unsigned long long)qb << 32) | i;
+    for (uint32_t i = lane; i < nb; i += kWave) w.c_qi[bb + i] = ((unsigned long long)qb << 32) | (sb + i);
   }
 }
 
@@ -2118,14 +2136,15 @@ __global__ void __launch_bounds__(kWave) k_dp(DevIndex ix, DevBatch b, DevWork w
        j += (unsigned long long)gridDim.x * kWave) {
     const unsigned long long qi = w.c_qi[j];
     const uint32_t q = (uint32_t)(qi >> 32);
-    Cand* cd = w.seg + w.q_seg[q] + (uint32_t)qi;
-    const uint32_t sid = cd->sid;
+    Cand* cd = w.seg + (uint32_t)qi;
+    const Cand c0 = *cd;
     const uint32_t o0 = b.q_off[b.q_begin + q];
     const uint32_t p = b.q_off[b.q_begin + q + 1] - o0;
     const uint32_t* pat = b.q_tok + o0;
-    const uint32_t sp = ix.sent_pos[sid];
-    const uint32_t slen = ix.tok[sp];
-    const uint32_t* sent = ix.tok + sp + 1;
+    uint32_t tb = __float_as_uint(c0.score), slen = c0.longest >> 16;  // token base handed over by k_expand_b, 0 = unknown
+    if (tb == 0) { const uint32_t sp0 = ix.sent_pos[c0.sid]; slen = ix.tok[sp0]; tb = sp0 + 1; }
+    const uint32_t sp = tb - 1;
+    const uint32_t* sent = ix.tok + tb;
     const float dw = 100.f / normalizer(p, slen, prm.ins, prm.del, prm.rep);
     DpSide side;
     side.s_real = nullptr; side.p_real = nullptr; side.s_itok = nullptr; side.p_itok = nullptr;
@@ -2148,7 +2167,7 @@ __global__ void __launch_bounds__(kWave) k_dp(DevIndex ix, DevBatch b, DevWork w
                                                  LdsRow{s_rows + lane}, M);
     cd->score = final_cost;
     cd->penalty = M;
-    cd->longest = (cd->longest & 0xffffu) | (slen << 16);
+    cd->longest = (c0.longest & 0xffffu) | (slen << 16);
   }
 }
 
@@ -2318,16 +2337,18 @@ __global__ void __launch_bounds__(kWave, (UNIT && P == 32) ? 8 : 1) k_dp_reg(Dev
   dp_class_range(b, w, P == 32 ? 0u : 1u, j_lo, j_hi);
   for (unsigned long long j = j_lo + (unsigned long long)blockIdx.x * kWave + lane; j < j_hi;
        j += (unsigned long long)gridDim.x * kWave) {
+    // two dependency levels in front of the tokens: the list entry, then the query's offsets and the candidate record
+    // together (the record names the sentence's token base and length: no detour through sent_pos and the length word)
     const unsigned long long qi = w.c_qi[j];
     const uint32_t q = (uint32_t)(qi >> 32);
+    Cand* cd = w.seg + (uint32_t)qi;
+    const Cand c0 = *cd;
     const uint32_t o0 = b.q_off[b.q_begin + q];
     const uint32_t p = b.q_off[b.q_begin + q + 1] - o0;
-    Cand* cd = w.seg + w.q_seg[q] + (uint32_t)qi;
-    const uint32_t sid = cd->sid;
     const uint32_t* pat = b.q_tok + o0;
-    const uint32_t sp = ix.sent_pos[sid];
-    const uint32_t slen = ix.tok[sp];
-    const uint32_t* sent = ix.tok + sp + 1;
+    uint32_t tb = __float_as_uint(c0.score), slen = c0.longest >> 16;  // 0 = unknown (candidates rebuilt by k_cand*)
+    if (tb == 0) { const uint32_t sp0 = ix.sent_pos[c0.sid]; slen = ix.tok[sp0]; tb = sp0 + 1; }
+    const uint32_t* sent = ix.tok + tb;
     const float dw = 100.f / normalizer(p, slen, prm.ins, prm.del, prm.rep);
     const float* p_idf = w.t_idf + (o0 - b.t_begin);
     const float idf_weight = (dw * prm.idf_penalty) / prm.idf_max;  // src/fuzzy_match.cc:591
@@ -2346,7 +2367,7 @@ __global__ void __launch_bounds__(kWave, (UNIT && P == 32) ? 8 : 1) k_dp_reg(Dev
       final_cost = edit_distance_reg<P, IDF>(sent, slen, pat, p, prm.ins, prm.del, prm.rep, dw, M, p_idf, idf_weight);
     cd->score = final_cost;
     cd->penalty = M;
-    cd->longest = (cd->longest & 0xffffu) | (slen << 16);
+    cd->longest = (c0.longest & 0xffffu) | (slen << 16);
   }
 }
 

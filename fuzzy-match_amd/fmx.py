@@ -76,7 +76,7 @@ EXPORTS = [
     "fmx_subsequence_batch", "fmx_text_tokenize", "fmx_text_free", "fmx_text_num_tokens", "fmx_text_norm", "fmx_text_real",
     "fmx_text_num_itoks", "fmx_text_itok_index", "fmx_text_itok", "fmx_text_num_raw", "fmx_text_raw", "fmx_text_map",
     "fmx_text_detokenize", "fmx_index_add_text", "fmx_index_device_array", "fmx_index_from_arrays", "fmx_text_feature",
-    "fmx_match_one_prior",
+    "fmx_match_one_prior", "fmx_match_batch_device_begin", "fmx_match_batch_device_end",
 ]
 TM_SKIPPED = -100
 
@@ -132,6 +132,9 @@ def lib():
     L.fmx_match_batch_device.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Batch), C.c_uint64, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(Stats)]
     L.fmx_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+    L.fmx_match_batch_device_begin.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Batch), C.c_uint64, C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_void_p)]
+    L.fmx_match_batch_device_end.argtypes = [C.c_void_p, C.c_void_p]
     L.fmx_host_alloc.restype = C.c_void_p
     L.fmx_host_alloc.argtypes = [C.c_size_t]
     L.fmx_host_free.argtypes = [C.c_void_p]
@@ -484,13 +487,32 @@ class Index:
         return out[:nq], found[:nq], pos[:nq]
 
     def match_batch_device(self, params, nq, d_q_off, d_q_tok, total_tokens, d_out, d_count, d_total, cap,
-                           stream=0, d_q_real=0, d_q_itok=0, max_len=0):
-        """Same with raw device pointers (ints) — buffers owned by the caller (e.g. torch tensors)."""
+                           stream=0, d_q_real=0, d_q_itok=0, max_len=0, want_stats=True):
+        """Same with raw device pointers (ints) — buffers owned by the caller (e.g. torch tensors).  want_stats=False: no
+        per-stage timing, passes back to back, concurrent calls (own stream each) chained on the GPU."""
         b = Batch(nq, d_q_off, d_q_tok, d_q_real or None, d_q_itok or None, max_len)
-        st = Stats()
+        st = Stats() if want_stats else None
         _check(lib().fmx_match_batch_device(self.h, C.byref(params), C.byref(b), total_tokens, d_out, d_count,
-                                            d_total or None, cap, stream or None, C.byref(st)))
+                                            d_total or None, cap, stream or None, C.byref(st) if want_stats else None))
         return st
+
+
+def _device_begin(self, params, nq, d_q_off, d_q_tok, total_tokens, d_out, d_count, d_total, cap, stream=0, d_q_real=0,
+                  d_q_itok=0, max_len=0):
+    """fmx_match_batch_device_begin: enqueue the call, return a handle for device_end (same thread)."""
+    b = Batch(nq, d_q_off, d_q_tok, d_q_real or None, d_q_itok or None, max_len)
+    h = C.c_void_p()
+    _check(lib().fmx_match_batch_device_begin(self.h, C.byref(params), C.byref(b), total_tokens, d_out, d_count, d_total or None, cap,
+                                              stream or None, C.byref(h)))
+    return h
+
+
+def _device_end(self, handle):
+    _check(lib().fmx_match_batch_device_end(self.h, handle))
+
+
+Index.device_begin = _device_begin
+Index.device_end = _device_end
 
 
 def stage_names():

@@ -20,6 +20,7 @@ static std::vector<std::string> split(const std::string& s, char sep) {
 
 int main(int argc, char** argv) {
   if (argc < 3) return 2;
+  setvbuf(stdout, nullptr, _IOLBF, 0);  // a crash must not swallow the lines printed before it
   fuzzy::FuzzyMatch fm;
   try {
     fuzzy::FuzzyMatch missing;

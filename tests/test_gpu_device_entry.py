@@ -1,0 +1,160 @@
+"""fmx_match_batch_device: every buffer already in HBM.  With statistics every
+pass is synchronised and timed; without, the passes run back to back and concurrent callers — one host thread and stream
+each — are chained on the GPU.  Both against the oracle, bit for bit."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+import oracle_lib
+import workloads
+
+pytestmark = pytest.mark.gpu
+
+
+class Hip:
+    """Device buffers and streams straight from the HIP runtime libfmx.so is linked against (no torch: a second HIP runtime
+    initialised after the first one finds no device)."""
+
+    def __init__(self):
+        self.L = C.CDLL("/opt/rocm/lib/libamdhip64.so")
+
+    def check(self, rc):
+        assert rc == 0, f"HIP error {rc}"
+
+    def upload(self, a):
+        a = np.ascontiguousarray(a)
+        p = C.c_void_p()
+        self.check(self.L.hipMalloc(C.byref(p), C.c_size_t(max(a.nbytes, 4))))
+        self.check(self.L.hipMemcpy(p, a.ctypes.data_as(C.c_void_p), C.c_size_t(a.nbytes), 1))
+        return p.value
+
+    def zeros(self, nbytes):
+        p = C.c_void_p()
+        self.check(self.L.hipMalloc(C.byref(p), C.c_size_t(max(nbytes, 4))))
+        self.check(self.L.hipMemset(p, 0, C.c_size_t(nbytes)))
+        return p.value
+
+    def download(self, ptr, dtype, count):
+        out = np.zeros(count, dtype=dtype)
+        self.check(self.L.hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), C.c_size_t(out.nbytes), 2))
+        return out
+
+    def stream(self):
+        s = C.c_void_p()
+        self.check(self.L.hipStreamCreateWithFlags(C.byref(s), 1))  # hipStreamNonBlocking
+        return s.value
+
+    def sync(self):
+        self.check(self.L.hipDeviceSynchronize())
+
+
+@pytest.fixture(scope="module")
+def setup(fmx, gpu_device):
+    hip = Hip()
+    c_off, c_tok, q_off, q_tok, vs = workloads.synthetic(200_000, 60_000, 20)
+    ix = fmx.Index.create()
+    ix.add_ids(c_off, c_tok, vs)
+    ix.sort(gpu_device)
+    ix.finalize()
+    ix.to_device(gpu_device)
+    ix.set_option("contexts", 4)
+    o = oracle_lib.OracleIndex()
+    o.set_arrays(ix.array("suf_sid"), ix.array("suf_pos"), ix.array("buffer"), ix.array("sent_pos"), ix.array("qva"), ix.array("sfreq"))
+    kw = dict(fuzzy=0.7, nmatch=5)
+    oo, oc = o.match_batch(oracle_lib.Params(**kw), q_off, q_tok, 5, nthreads=oracle_lib.effective_cpus())
+    o.close()
+    d_off = hip.upload(q_off.astype(np.uint32))
+    d_tok = hip.upload(q_tok.astype(np.uint32))
+    return hip, ix, kw, q_off, q_tok, d_off, d_tok, oo, oc
+
+
+def _records(hip, d_out, d_cnt, nq, cap):
+    return hip.download(d_out, oracle_lib.MATCH_DTYPE, nq * cap).reshape(nq, cap), hip.download(d_cnt, np.uint32, nq)
+
+
+@pytest.mark.parametrize("want_stats", [True, False])
+@pytest.mark.parametrize("sub_queries", [0, 7001])
+def test_device_entry_point_matches_the_oracle(fmx, setup, want_stats, sub_queries):
+    hip, ix, kw, q_off, q_tok, d_off, d_tok, oo, oc = setup
+    nq, cap = len(q_off) - 1, 5
+    if sub_queries:
+        ix.set_option("sub_queries", sub_queries)   # several passes per call, bounds read from the device
+    try:
+        d_out, d_cnt, st = hip.zeros(nq * cap * 16), hip.zeros(nq * 4), hip.stream()
+        hip.sync()
+        ix.match_batch_device(fmx.Params(**kw), nq, d_off, d_tok, int(q_off[-1]), d_out, d_cnt, 0,
+                              cap, stream=st, max_len=int(np.diff(q_off).max()), want_stats=want_stats)
+        go, gc = _records(hip, d_out, d_cnt, nq, cap)
+        workloads.compare(oo, oc, go, gc, f"device entry point stats={want_stats} sub={sub_queries}")
+    finally:
+        ix.set_option("sub_queries", 1 << 20)
+
+
+@pytest.mark.parametrize("turns", [0, 1, 2])
+def test_concurrent_device_calls_are_chained(fmx, setup, turns):
+    """Four host threads, each on its own stream, three calls each: whatever the chaining mode (none, behind the predecessor's
+    last kernel, behind its memory-bound half) every call leaves the oracle's records."""
+    hip, ix, kw, q_off, q_tok, d_off, d_tok, oo, oc = setup
+    nq, cap = len(q_off) - 1, 5
+    ix.set_option("turns", turns)
+    errs = []
+
+    def worker(k):
+        try:
+            st = hip.stream()
+            for _ in range(3):
+                d_out, d_cnt = hip.zeros(nq * cap * 16), hip.zeros(nq * 4)
+                ix.match_batch_device(fmx.Params(**kw), nq, d_off, d_tok, int(q_off[-1]), d_out, d_cnt, 0, cap, stream=st,
+                                      max_len=int(np.diff(q_off).max()), want_stats=False)
+                go, gc = _records(hip, d_out, d_cnt, nq, cap)
+                workloads.compare(oo, oc, go, gc, f"thread {k} turns={turns}")
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e)[:500])
+
+    try:
+        th = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+    finally:
+        ix.set_option("turns", 1)
+    assert not errs, errs[:2]
+
+
+@pytest.mark.parametrize("turns", [1, 2])
+def test_begin_end_keeps_several_calls_in_flight_from_one_thread(fmx, setup, turns):
+    """fmx_match_batch_device_begin / _end: three calls pending at once, enqueued by this thread, ended in order; a fourth
+    begin without a free context is refused instead of dead-locking."""
+    hip, ix, kw, q_off, q_tok, d_off, d_tok, oo, oc = setup
+    nq, cap = len(q_off) - 1, 5
+    ix.set_option("turns", turns)
+    ix.set_option("contexts", 3)
+    try:
+        bufs = [(hip.zeros(nq * cap * 16), hip.zeros(nq * 4)) for _ in range(3)]
+        hip.sync()
+        ml = int(np.diff(q_off).max())
+        # the pool is finite: some begin is refused (an earlier test may have left more than three contexts behind)
+        pend, refused = [], False
+        for k in range(8):
+            try:
+                pend.append(ix.device_begin(fmx.Params(**kw), nq, d_off, d_tok, int(q_off[-1]), bufs[k % 3][0], bufs[k % 3][1], 0, cap, stream=0, max_len=ml))
+            except fmx.FmxError as e:
+                assert "context" in str(e)
+                refused = True
+                break
+        for h in pend:
+            ix.device_end(h)
+        assert refused and len(pend) >= 3
+        for rnd in range(2):
+            pend = [ix.device_begin(fmx.Params(**kw), nq, d_off, d_tok, int(q_off[-1]), o, c, 0, cap, stream=0, max_len=ml) for o, c in bufs]
+            for h in pend:
+                ix.device_end(h)
+            for o, c in bufs:
+                go, gc = _records(hip, o, c, nq, cap)
+                workloads.compare(oo, oc, go, gc, f"begin/end turns={turns} round {rnd}")
+    finally:
+        ix.set_option("turns", 1)
+        ix.set_option("contexts", 4)
