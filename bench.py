@@ -62,6 +62,7 @@ def parse_args():
     ap.add_argument("--threads", type=int, default=int(os.environ.get("FMX_BENCH_THREADS", "3")), help="synchronous fmx_match_batch calls kept in flight (one host thread each)")
     ap.add_argument("--force-gather", action="store_true", help="N = 1 test of the N > 1 step: records also kept in HBM for the (empty) gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-text-leg", action="store_true", help="skip the leg that starts from token strings")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline.traffic = null)")
     ap.add_argument("--child", action="store_true", help="profiling child: device-resident steps only, no output line")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -333,12 +334,68 @@ def main():
         dist.all_reduce(t)
         return int(t.item())
 
+    def measure_from_strings(wl):
+        """SURVEY §8(d)'s bracket includes the per-query host prep — VocabIndexer::getIndex per pattern token (src/fuzzy_match.cc:
+        468-470).  This leg starts from token STRINGS: every step looks its tokens up (fmx_vocab_lookup_mt, host threads) into the
+        pinned id buffer and then runs the host-buffer call.  The spellings are the generator's (tools/fm_synth.c: fms_word)."""
+        import ctypes
+        buf = ctypes.create_string_buffer(32)
+        words = [b"", b""]
+        for k in range(vs - 2):
+            n = L.fms_word(k, buf, 32)
+            words.append(buf.raw[:n])
+        offs = np.full(len(words), 0xffffffffffffffff, np.uint64)
+        pos = 0
+        for k in range(2, len(words)):
+            offs[k] = pos
+            pos += len(words[k]) + 1
+        arena = np.frombuffer(b"".join(w + b"\0" for w in words[2:]), dtype=np.uint8).copy()
+        word_ptrs = ix.set_forms_packed(arena, offs)
+        tok_ptrs = np.ascontiguousarray(word_ptrs[wl.q_tok])          # one char pointer per pattern token of the batch
+        T = max(args.threads, 1)
+        cores = max(1, (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count() or 1))
+        try:
+            import oracle_lib as _ol
+            cores = _ol.effective_cpus()
+        except Exception:  # noqa: BLE001
+            pass
+        per_call = max(1, cores // T)
+        ids = [fmx.pinned_empty(len(wl.q_tok), np.uint32) for _ in range(T)]
+        t_lookup = [0.0]
+
+        def one(i):
+            a = time.perf_counter()
+            ix.vocab_lookup_ptrs(tok_ptrs, ids[i % T], per_call)
+            t_lookup[0] += time.perf_counter() - a
+            return ix.match_batch(params, wl.q_off, ids[i % T], cap=cap, want_stats=True, out=wl.out[i % T])[3]
+
+        def run(k_steps):
+            futs = {i: pool.submit(one, i) for i in range(min(T, k_steps))}
+            for i in range(k_steps):
+                futs.pop(i).result()
+                if i + T < k_steps:
+                    futs[i + T] = pool.submit(one, i + T)
+
+        run(T)
+        assert np.array_equal(ids[0], wl.q_tok), "vocabulary lookup does not reproduce the ids"
+        t_lookup[0] = 0.0
+        k = max(6, args.steps // 2)
+        el, _ = timed(run, k)
+        return {"value": round(wl.nq * k / el, 1), "ms_per_step": round(el / k * 1e3, 3), "steps": k,
+                "lookup_ms_per_step": round(t_lookup[0] / k * 1e3, 3), "lookup_threads_per_call": per_call, "calls_in_flight": T,
+                "tokens_per_step": int(len(wl.q_tok)),
+                "note": "fmx_vocab_lookup_mt (token strings -> ids, in the timed region) + fmx_match_batch (pinned host buffers)"}
+
+    host_first = os.environ.get("FMX_BENCH_ORDER", "host_first") == "host_first"  # the host-buffer steps first: measured after the device-resident ones they lose a third at C2 (cause not found)
+    if host_first:
+        elapsed_host, host_stats = measure(main_wl)
     # ---- THE METRIC: inputs resident in HBM when the timed region starts ----
     elapsed = measure_device(main_wl)
     nq_step_all = all_ranks(main_wl.nq)
     value = nq_step_all * args.steps / elapsed
     # ---- the same steps from pinned host buffers (H2D + kernels + D2H; + the RCCL gather of the records when N > 1) ----
-    elapsed_host, host_stats = measure(main_wl)
+    if not host_first:
+        elapsed_host, host_stats = measure(main_wl)
     value_host = nq_step_all * args.steps / elapsed_host
     scaling_other = None
     if world > 1:
@@ -348,6 +405,8 @@ def main():
         scaling_other = {"scaling": "strong" if args.scaling == "weak" else "weak", "value": round(n2 * args.steps / el2, 1),
                          "ms_per_step": round(el2 / args.steps * 1e3, 3), "queries_per_step_all_ranks": n2,
                          "pcie_inclusive_value": round(n2 * args.steps / el2h, 1)}
+
+    from_strings = measure_from_strings(main_wl) if (world == 1 and not args.no_text_leg) else None
 
     # ---- the same batch from HBM (device entry point): stage times for the rooflines ----
     run_device_steps(main_wl, 1)
@@ -419,7 +478,7 @@ def main():
             log(f"[bench] pmc child passes: {time.time() - t1:.0f}s")
             if fetch and write:
                 for kern, pattern in (("fmx::k_probe", "random"), ("fmx::k_expand_a", "stream16"), ("fmx::k_expand_h", "stream8"),
-                                      ("fmx::k_expand_b", "random")):
+                                      ("fmx::k_expand_b", "random"), ("fmx::k_dp_reg", "random")):
                     keys = [k for k in fetch if k.replace("void ", "").startswith(kern)]  # template instantiations add up
                     if not keys:
                         continue
@@ -454,7 +513,14 @@ def main():
                      "record per light hit, 8 B queue entry + 16 B record per queued hit, 4 B per pattern token, and per kept "
                      "hit its sentence (4 B x (mean length + 1)) and a 16 B segment entry; reads for hits that fail the "
                      "dominance / exact coverage tests are not counted (lower bound)")
-        roofs = sorted([r_probe, r_exa, r_exb], key=lambda r: -r["kernel_ms"])
+        # edit distances: per candidate its sentence (length word + tokens), the 16 B candidate record read and written back, the
+        # 8 B list entry; the pattern is shared by the candidates of a query (4 B per pattern token per query)
+        dp_ms = per_stage.get("dp", 0.0)
+        b_dp = last.n_candidates * (4.0 * (mean_len + 1) + 16.0 + 16.0 + 8.0) + 4.0 * main_wl.total_tokens
+        r_dp = roof("k_dp_reg<32|64>", b_dp, dp_ms, ["k_dp_reg"],
+                    "one lane per (query, candidate): 4 B x (sentence length + 1) of the sentence, 16 B candidate record in and out, 8 B "
+                    "list entry, 4 B per pattern token per query (kernel counters; mean sentence length of the corpus)")
+        roofs = sorted([r_probe, r_exa, r_exb], key=lambda r: -r["kernel_ms"]) + [r_dp]
         dominant, others = roofs[0], roofs[1:]
 
         # ---- parity spot check, reference byte model, CPU baseline (the oracle: test infrastructure, outside the timed region) ----
@@ -528,6 +594,7 @@ def main():
             "pcie_inclusive": {"value": round(value_host, 1), "ms_per_step": round(elapsed_host / args.steps * 1e3, 3),
                                "note": "the same steps through fmx_match_batch: pinned host buffers in and out (H2D + kernels + D2H"
                                        + (" + the RCCL gather of the records to rank 0" if world > 1 else "") + f"), {args.threads} call(s) in flight"},
+            "from_token_strings": from_strings,
             "staged": {"value": round(nq_step_all * args.steps / el_dev, 1),
                        "ms_per_step": round(el_dev / args.steps * 1e3, 3),
                        "stage_ms_per_step": {k: round(v, 4) for k, v in per_stage.items()},

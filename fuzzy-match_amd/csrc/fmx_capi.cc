@@ -219,6 +219,16 @@ int fmx_vocab_lookup(const fmx_index* ix, const char* const* toks, uint64_t n, u
   });
 }
 
+int fmx_vocab_lookup_mt(const fmx_index* ix, const char* const* toks, uint64_t n, uint32_t* ids, int nthreads) {
+  if (!ix || (n && (!toks || !ids))) return fail(FMX_E_INVALID, "null argument");
+  return guarded([&]() { ix->host.get_indices(toks, n, ids, nthreads < 1 ? 1 : nthreads); return (int)FMX_OK; });
+}
+
+int fmx_index_set_forms(fmx_index* ix, const char* const* spellings, uint64_t n) {
+  if (!ix || (n && !spellings)) return fail(FMX_E_INVALID, "null argument");
+  return guarded([&]() { ix->host.set_forms(spellings, n); return (int)FMX_OK; });
+}
+
 uint32_t fmx_index_lookup_real(const fmx_index* ix, const char* s, size_t len) {
   if (!ix || !s) return 0x7ffffffeu;
   return ix->host.lookup_real(std::string(s, len));

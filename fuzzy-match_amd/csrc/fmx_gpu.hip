@@ -644,20 +644,22 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
     const float cmin_key[4] = {prm.fuzzy, prm.ins, prm.del, prm.rep};
     const bool cmin_cached = c.cmin_ptr == c.cmin_tab.p && c.cmin_sig == use_sig && c.cmin_maxslen == m.d.max_slen && c.cmin_pmax >= p_max &&
                              memcmp(c.cmin_key, cmin_key, sizeof cmin_key) == 0;
+    // beside the probe, on the side stream: the threshold table (unless the pass before asked for the same) and the pattern-length
+    // ranks (only k_classify, after the expand stage's join, reads them)
+    fork();
     if (!cmin_cached) {
-      fork();
       hipLaunchKernelGGL(k_cmin, dim3(p_max + 1), dim3(256), 0, side, m.d.max_slen, prm, use_sig, c.cmin_tab.p);
       if (!m.serial) HIP_TRY(hipEventRecord(c.ev_cmin, c.side));
       memcpy(c.cmin_key, cmin_key, sizeof cmin_key);
       c.cmin_ptr = c.cmin_tab.p; c.cmin_sig = use_sig; c.cmin_maxslen = m.d.max_slen; c.cmin_pmax = p_max;
     }
-    hipLaunchKernelGGL(k_setup, dim3((b.nq + 1 + 255) / 256), dim3(256), 0, stream, m.d, b, w, prm);
-    if (prm.idf_penalty != 0.f) hipLaunchKernelGGL(k_tidf, dim3((b.nt + 255) / 256), dim3(256), 0, stream, m.d, b, w);
     {
       const uint32_t per_block = kRankThreads * kRankPer;
-      hipLaunchKernelGGL(k_phist, dim3((b.nq + per_block - 1) / per_block), dim3(kRankThreads), 0, stream, b, w);
-      hipLaunchKernelGGL(k_prank, dim3((b.nq + per_block - 1) / per_block), dim3(kRankThreads), 0, stream, b, w);
+      hipLaunchKernelGGL(k_phist, dim3((b.nq + per_block - 1) / per_block), dim3(kRankThreads), 0, side, b, w);
+      hipLaunchKernelGGL(k_prank, dim3((b.nq + per_block - 1) / per_block), dim3(kRankThreads), 0, side, b, w);
     }
+    hipLaunchKernelGGL(k_setup, dim3((b.nq + 1 + 255) / 256), dim3(256), 0, stream, m.d, b, w, prm);
+    if (prm.idf_penalty != 0.f) hipLaunchKernelGGL(k_tidf, dim3((b.nt + 255) / 256), dim3(256), 0, stream, m.d, b, w);
     tick(); tick();
     if (b.nt) {
       if (m.probe_count)  // measurement runs only: the same kernel, also counting the bytes / lines it requests

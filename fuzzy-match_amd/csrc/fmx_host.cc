@@ -51,6 +51,75 @@ uint32_t HostIndex::get_index(const std::string& w) const {
   return it != form2index.end() ? it->second : 1u;  // VOCAB_UNK
 }
 
+static inline uint64_t spell_hash(const char* s, size_t& len) {  // FNV-1a, 64 bit
+  uint64_t h = 1469598103934665603ull;
+  size_t n = 0;
+  for (; s[n]; n++) { h ^= (unsigned char)s[n]; h *= 1099511628211ull; }
+  len = n;
+  return h ^ (h >> 29);
+}
+
+const HostIndex::FastVocab& HostIndex::fast_vocab() const {
+  std::lock_guard<std::mutex> lk(fast_mu_);
+  if (fast_.built_for == forms.size() && !fast_.slot.empty()) return fast_;
+  FastVocab& f = fast_;
+  uint64_t cap = 64;
+  while (cap < forms.size() * 2) cap <<= 1;
+  f.slot.assign(cap, ~0ull);
+  f.mask = cap - 1;
+  f.arena.clear();
+  for (size_t id = 0; id < forms.size(); id++) {
+    if (id >= 2 && forms[id].empty()) continue;  // ids without a spelling (partially attached vocabularies)
+    if (form2index.find(forms[id]) == form2index.end() || form2index.at(forms[id]) != id) continue;  // not the id getIndex returns
+    const uint64_t off = f.arena.size();
+    f.arena.insert(f.arena.end(), forms[id].begin(), forms[id].end());
+    f.arena.push_back('\0');
+    size_t len;
+    uint64_t h = spell_hash(f.arena.data() + off, len) & f.mask;
+    while (f.slot[h] != ~0ull) h = (h + 1) & f.mask;
+    f.slot[h] = (off << 32) | (uint64_t)id;
+  }
+  f.built_for = forms.size();
+  return f;
+}
+
+void HostIndex::get_indices(const char* const* toks, uint64_t n, uint32_t* ids, int nthreads) const {
+  const FastVocab& f = fast_vocab();
+  auto work = [&](uint64_t lo, uint64_t hi) {
+    for (uint64_t i = lo; i < hi; i++) {
+      const char* t = toks[i];
+      size_t len;
+      uint64_t h = spell_hash(t, len) & f.mask;
+      uint32_t id = 1u;  // VOCAB_UNK
+      for (;;) {
+        const uint64_t e = f.slot[h];
+        if (e == ~0ull) break;
+        const char* w = f.arena.data() + (e >> 32);
+        if (memcmp(w, t, len + 1) == 0) { id = (uint32_t)e; break; }
+        h = (h + 1) & f.mask;
+      }
+      ids[i] = id;
+    }
+  };
+  const uint64_t nt = (uint64_t)std::max(1, std::min<int>(nthreads, (int)std::min<uint64_t>(n / 4096 + 1, 256)));
+  if (nt == 1) { work(0, n); return; }
+  std::vector<std::thread> th;
+  for (uint64_t k = 1; k < nt; k++) th.emplace_back(work, n * k / nt, n * (k + 1) / nt);
+  work(0, n / nt);
+  for (auto& t : th) t.join();
+}
+
+void HostIndex::set_forms(const char* const* spellings, uint64_t n) {
+  if (!ids.empty()) throw std::runtime_error("set_forms: the index already holds string-level sentences");
+  if (n > forms.size()) { forms.resize(n); if (sfreq.size() < n) sfreq.resize(n, 0); }
+  for (uint64_t id = 2; id < n; id++) {
+    if (!spellings[id]) continue;
+    forms[id] = spellings[id];
+    form2index.emplace(forms[id], (uint32_t)id);  // the first id of a spelling wins, like addWord
+  }
+  if (forms.size() > vocab_size) vocab_size = (uint32_t)forms.size();
+}
+
 static void push_sentence(HostIndex& ix, const uint32_t* toks, uint32_t n) {
   // SuffixArray::add_sentence — src/suffix_array.cc:9-27
   const uint32_t sidx = (uint32_t)ix.sent_pos.size();

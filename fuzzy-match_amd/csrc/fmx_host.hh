@@ -94,9 +94,28 @@ class HostIndex {
 
   HostIndex();
 
+ private:
+  struct FastVocab {
+    std::vector<char>     arena;   // NUL-terminated spellings
+    std::vector<uint64_t> slot;    // offset into arena << 32 | id, ~0 = empty
+    uint64_t              mask = 0;
+    uint64_t              built_for = 0;  // forms.size() it was built from
+  };
+  mutable FastVocab  fast_;
+  mutable std::mutex fast_mu_;
+  const FastVocab& fast_vocab() const;
+
+ public:
+
   // VocabIndexer::addWord / getIndex (src/vocab_indexer.cc:37-60)
   uint32_t add_word(const std::string& w);
   uint32_t get_index(const std::string& w) const;
+  // getIndex for a stream of tokens (the per-query host prep of match(), src/fuzzy_match.cc:468-470) without a std::string
+  // per token: an open-addressing table over the packed spellings (built on first use, rebuilt when words were added),
+  // spread over `nthreads` host threads
+  void get_indices(const char* const* toks, uint64_t n, uint32_t* ids, int nthreads) const;
+  // attach spellings to an id-only index (ids 2 .. n - 1; bulk-built corpora): vocabulary lookups then work on it
+  void set_forms(const char* const* spellings, uint64_t n);
 
   // SuffixArrayIndex::add_tm (src/suffix_array_index.cc:10-30): returns the new sentence id or -1
   // when skipped (empty real tokens, or more than max_tokens normalised tokens).

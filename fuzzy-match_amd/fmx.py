@@ -76,7 +76,7 @@ EXPORTS = [
     "fmx_subsequence_batch", "fmx_text_tokenize", "fmx_text_free", "fmx_text_num_tokens", "fmx_text_norm", "fmx_text_real",
     "fmx_text_num_itoks", "fmx_text_itok_index", "fmx_text_itok", "fmx_text_num_raw", "fmx_text_raw", "fmx_text_map",
     "fmx_text_detokenize", "fmx_index_add_text", "fmx_index_device_array", "fmx_index_from_arrays", "fmx_text_feature",
-    "fmx_match_one_prior", "fmx_match_batch_device_begin", "fmx_match_batch_device_end",
+    "fmx_match_one_prior", "fmx_match_batch_device_begin", "fmx_match_batch_device_end", "fmx_vocab_lookup_mt", "fmx_index_set_forms",
 ]
 TM_SKIPPED = -100
 
@@ -135,6 +135,8 @@ def lib():
     L.fmx_match_batch_device_begin.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Batch), C.c_uint64, C.c_void_p, C.c_void_p,
                                                C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_void_p)]
     L.fmx_match_batch_device_end.argtypes = [C.c_void_p, C.c_void_p]
+    L.fmx_vocab_lookup_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
+    L.fmx_index_set_forms.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     L.fmx_host_alloc.restype = C.c_void_p
     L.fmx_host_alloc.argtypes = [C.c_size_t]
     L.fmx_host_free.argtypes = [C.c_void_p]
@@ -511,6 +513,22 @@ def _device_end(self, handle):
     _check(lib().fmx_match_batch_device_end(self.h, handle))
 
 
+def _set_forms_packed(self, arena, offsets):
+    """fmx_index_set_forms from a packed buffer: arena = NUL-terminated spellings (numpy uint8), offsets[k] = where id k's starts
+    (uint64; ~0 = none).  Returns the pointer array (keep it alive with the arena while lookups by pointer are made)."""
+    base = arena.ctypes.data
+    ptrs = np.where(offsets == np.uint64(0xffffffffffffffff), np.uint64(0), offsets + np.uint64(base)).astype(np.uint64)
+    _check(lib().fmx_index_set_forms(self.h, _ptr(ptrs), len(ptrs)))
+    return ptrs
+
+
+def _vocab_lookup_ptrs(self, ptrs, out, nthreads):
+    """fmx_vocab_lookup_mt over an array of char pointers (numpy uint64) into `out` (numpy uint32, e.g. pinned)."""
+    _check(lib().fmx_vocab_lookup_mt(self.h, _ptr(ptrs), len(ptrs), _ptr(out), nthreads))
+
+
+Index.set_forms_packed = _set_forms_packed
+Index.vocab_lookup_ptrs = _vocab_lookup_ptrs
 Index.device_begin = _device_begin
 Index.device_end = _device_end
 

@@ -167,6 +167,11 @@ int fmx_index_reopen(fmx_index*);
 /* ---- index queries (host) ---------------------------------------------------------------- */
 /* VocabIndexer::getIndex — src/vocab_indexer.cc:52-71 (unknown -> 1) */
 int fmx_vocab_lookup(const fmx_index*, const char* const* toks, uint64_t n, uint32_t* ids);
+/* the same for the token stream of a whole batch, spread over `nthreads` host threads (no std::string per token: the per-query
+ * host prep of match(), src/fuzzy_match.cc:468-470, at batch scale) */
+int fmx_vocab_lookup_mt(const fmx_index*, const char* const* toks, uint64_t n, uint32_t* ids, int nthreads);
+/* attach spellings to an index built from ids (fmx_index_add_ids): spellings[k] = the word of id k for k in [2, n), NULL = none */
+int fmx_index_set_forms(fmx_index*, const char* const* spellings, uint64_t n);
 uint32_t fmx_index_lookup_real(const fmx_index*, const char* s, size_t len);
 uint32_t fmx_index_intern_itok(fmx_index*, const char* s, size_t len);
 /* SuffixArrayIndex::id — src/suffix_array_index.cc:66-70; "" for id-only corpora */

@@ -223,3 +223,31 @@ def test_index_from_arrays_adopts_the_reference_arrays(fmx, tmp_path):
         fmx.Index.from_arrays(arr["suf_sid"], arr["suf_pos"], arr["buffer"], arr["sent_pos"], qva=q)
     with pytest.raises(fmx.FmxError):
         fmx.Index.from_arrays(arr["suf_sid"], arr["suf_pos"], arr["buffer"][:-1], arr["sent_pos"])
+
+
+def test_vocab_lookup_mt_and_attached_spellings(fmx):
+    """fmx_vocab_lookup_mt == fmx_vocab_lookup token by token (several threads, unknown words -> 1, the empty word -> 0), on a
+    string-built index and on an id-built one with spellings attached afterwards (fmx_index_set_forms)."""
+    import ctypes as C
+    ix = fmx.Index.load(os.path.join(golden_util.GOLDEN, "tm1.fmi"))
+    words = ["aa", "bb", "zz", "｟num｠", ".", "", "cc", "nope"] * 3000
+    ref = np.asarray(ix.vocab_lookup(words), np.uint32)
+    enc = [w.encode("utf-8") for w in words]
+    arr = (C.c_char_p * len(enc))(*enc)
+    out = np.zeros(len(enc), np.uint32)
+    for nt in (1, 5):
+        out[:] = 7
+        assert fmx.lib().fmx_vocab_lookup_mt(ix.h, arr, len(enc), out.ctypes.data_as(C.c_void_p), nt) == 0
+        assert np.array_equal(out, ref)
+    # an index built from ids gets its spellings afterwards
+    b = fmx.Index.create()
+    b.add_ids(np.asarray([0, 3, 5], np.uint32), np.asarray([2, 3, 4, 3, 5], np.uint32), 6)
+    sp = [None, None, b"two", b"three", b"four", b"five"]
+    sarr = (C.c_char_p * len(sp))(*sp)
+    assert fmx.lib().fmx_index_set_forms(b.h, sarr, len(sp)) == 0
+    assert list(b.vocab_lookup(["three", "five", "six", "two"])) == [3, 5, 1, 2]
+    q = [b"four", b"two", b"seven"]
+    qa = (C.c_char_p * 3)(*q)
+    o3 = np.zeros(3, np.uint32)
+    assert fmx.lib().fmx_vocab_lookup_mt(b.h, qa, 3, o3.ctypes.data_as(C.c_void_p), 2) == 0
+    assert list(o3) == [4, 2, 1]

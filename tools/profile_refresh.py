@@ -10,7 +10,7 @@ import subprocess
 import sys
 
 cfg = sys.argv[1]
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r03"
 src = f"gpurun_out/prof_{cfg}"
 low = cfg.lower()
 
@@ -32,6 +32,11 @@ open(f"profiles/{rnd}_{low}_bench_1gpu.json", "w").write(line + "\n")
 kt = sorted(glob.glob(f"{src}/kt/**/*kernel_trace.csv", recursive=True))[-1]
 open(f"profiles/{rnd}_{low}_kernel_trace_summary.csv", "w").write(
     subprocess.run([sys.executable, "tools/kernel_trace_summary.py", kt], capture_output=True, text=True).stdout)
+
+import os
+import shutil
+if os.path.exists(f"{src}/pipeline_busy.txt"):
+    shutil.copy(f"{src}/pipeline_busy.txt", f"profiles/{rnd}_{low}_pipeline_busy.txt")
 
 names = ["SQ_BUSY_CYCLES", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VALU", "SQ_INSTS_SALU",
          "SQ_INSTS_LDS"]
