@@ -257,7 +257,7 @@ def main():
 
     dev_slots = {}
 
-    def run_device_pipeline(wl, k_steps):
+    def run_device_pipeline(wl, k_steps, gather=None):
         """THE METRIC: K calls of the device entry point — query offsets / tokens already in HBM when the timed region starts,
         records written to HBM — with args.threads calls in flight: ONE host thread enqueues them (fmx_match_batch_device_begin
         returns once a call's launches are queued, _end waits for it), every call works in its own context and the library
@@ -272,15 +272,22 @@ def main():
         slots = dev_slots[wl]
 
         def begin(i):
-            _, d_out, d_cnt = slots[i % T]
+            if gather is not None:   # N > 1: the records are written where the RCCL gather of this step picks them up
+                d_out, d_cnt = gather.buffers(i, host_sync=True)  # the slot's previous gather is over
+            else:
+                _, d_out, d_cnt = slots[i % T]
             return ix.device_begin(params, wl.nq, wl.d_off.data_ptr(), wl.d_tok.data_ptr(), wl.total_tokens, d_out.data_ptr(),
                                    d_cnt.data_ptr(), 0, cap, stream=0, max_len=wl.max_len)
 
         pending = {i: begin(i) for i in range(min(T, k_steps))}
         for i in range(k_steps):
             ix.device_end(pending.pop(i))
+            if gather is not None:
+                gather.launch(i)     # the path's one collective: top-N records to rank 0 over xGMI, under the steps in flight
             if i + T < k_steps:
                 pending[i + T] = begin(i + T)
+        if gather is not None:
+            gather.wait_all()
         return slots
 
     def run_device_steps(wl, k_steps):
@@ -322,9 +329,12 @@ def main():
         return el, sts
 
     def measure_device(wl):
-        run_device_pipeline(wl, 2 * max(args.threads, 1))   # set-up: every context in flight sizes its workspace once
-        run_device_pipeline(wl, args.warmup)
-        el, _ = timed(lambda k: run_device_pipeline(wl, k), args.steps)
+        gather = shard.RecordGather(wl.nq, cap, dev, dst=0, depth=max(args.threads, 1) + 1, coll_device=cdev) if (world > 1 or args.force_gather) else None
+        run_device_pipeline(wl, 2 * max(args.threads, 1), gather)   # set-up: every context in flight sizes its workspace once
+        run_device_pipeline(wl, args.warmup, gather)
+        el, _ = timed(lambda k: run_device_pipeline(wl, k, gather), args.steps)
+        if gather is not None:  # the parity check below reads slot 0 of the plain buffers
+            run_device_pipeline(wl, 1)
         return el
 
     def all_ranks(n):
@@ -588,7 +598,8 @@ def main():
                                    + " ".join(f"{k}={v}" for k, v in pkw.items()),
                        "queries_per_step_all_ranks": nq_step_all, "sentences": n_sent, "index_bytes_hbm": int(info.device_bytes),
                        "timed_path": "fmx_match_batch_device_begin / _end: query offsets / tokens resident in HBM when the timed region starts, "
-                                     f"records written to HBM, {args.threads} call(s) in flight enqueued by one host thread (each in its own context)",
+                                     f"records written to HBM, {args.threads} call(s) in flight enqueued by one host thread (each in its own context)"
+                                     + (", + RCCL gather of every step's records to rank 0 (asynchronous, under the steps in flight)" if world > 1 else ""),
                        "parallelism": f"queries sharded over {world} GPU(s), index replicated"},
             "roofline": dominant, "roofline_other": others, "reference_byte_model": ref_model,
             "pcie_inclusive": {"value": round(value_host, 1), "ms_per_step": round(elapsed_host / args.steps * 1e3, 3),

@@ -1,15 +1,21 @@
 // fmx_kernels.hip.hh — the HIP kernels of the match() hot path for gfx950 (wave64).
 //
-// Stage map:
-//   k_setup   A   guards, min_subseq_length, token -> query map
-//   k_probe   C,D one lane per (query, start): range of the seed n-gram in the suffix array
-//   k_expand  D,E,G one wave per (query, 2048-hit chunk): walk the ranges, length filter, LCP, coverage
-//                 bound, ballot/prefix compaction of the survivors
-//   k_cand    E,F one wave per query: max per sentence, order (longest desc, s_id asc)
-//   k_score   H,I one wave per query: float edit distance (one candidate per lane, DP rows in
-//                 LDS), sequential replay of the lowest_costs bound
-//   k_select  H,J top-N by (score desc, s_id asc) or contrastive rerank
-// All integer/compare/float-scalar work: no MFMA anywhere (HBM-latency bound probe, LDS-bound DP).
+// Stage map (DESIGN.md §4 has the table with what bounds each kernel):
+//   k_setup, k_tidf, k_cmin, k_phist / k_prank   A   guards, min_subseq_length, token -> query map, idf per position, the
+//                 threshold table of the length / coverage filters, pattern-length ranks
+//   k_probe       C,D one lane per (query, start): range of the seed n-gram in the suffix array (n-gram hash tables + keys)
+//   k_caps, k_scan_lb, k_caps_b, k_segbase   work-item lists and segment offsets (single-pass look-back scans)
+//   k_expand_b<true>   D,E,F,G light queries (<= 256 hits, short ranges): ranges walked, dominance + length filter, match
+//                 length, exact coverage, max per sentence and candidate order, one wave per query
+//   k_expand_h / k_expand_a + k_expand_b<false>   the other queries: 64 hits per lane through the signature bit planes /
+//                 hit by hit with the signature bound, then the same token work on the queued hits
+//   k_cand_route, k_cand, k_cand_mid, k_cand_big   E,F survivor sets of more than 64: max per sentence, (longest desc, s_id asc)
+//   k_classify, k_cmap   dense candidate lists by pattern-length class
+//   k_dp_reg<P, IDF, UNIT>, k_dp<FULL, ROWS_IN_HBM>   I   one lane per (query, candidate): bit-parallel / register / LDS-row DP
+//   k_finish_pair, k_finish<SORT_CAP, LIST>   H   replay of the lowest_costs bound in reference order, top-N
+//   k_cacc, k_camap, k_cround<P>, k_contrast<MODE>   J   contrastive rerank (flattened rounds; per-query kernel for the tail
+//                 and for calls that bring prior matches)
+// All integer/compare/float-scalar work: no MFMA anywhere.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "fmx_core.hh"
