@@ -968,7 +968,17 @@ __device__ __forceinline__ void plane_level(unsigned long long (&a)[6], unsigned
 
 constexpr uint32_t kHeavyList = 2 * kWave;  // LDS list of plane-test survivors waiting for the exact test
 
-__global__ void __launch_bounds__(kWave, 6) k_expand_h(DevIndex ix, DevBatch b, DevWork w, Params prm, const HeavyItem* items,
+// Five waves per SIMD for the two kernels below (round 2: six): at six, k_expand_h kept 7 and k_expand_b<false> 8 VGPRs in
+// scratch; at five neither does, and neither is slower (k_expand_h 1.30 -> 1.28 ms at C3; four waves cost the overlapped
+// pipeline 8 %).  Their SGPR spills (~270 / ~130 wave-uniform values parked in VGPR lanes: bit planes of the pattern's
+// buckets, length intervals, range and segment descriptors) are what the algorithm keeps per wave, not compiler waste.
+#ifndef FMX_HEAVY_WAVES
+#define FMX_HEAVY_WAVES 5
+#endif
+#ifndef FMX_PHASEB_WAVES
+#define FMX_PHASEB_WAVES 5
+#endif
+__global__ void __launch_bounds__(kWave, FMX_HEAVY_WAVES) k_expand_h(DevIndex ix, DevBatch b, DevWork w, Params prm, const HeavyItem* items,
                                                        uint32_t item_cap) {
   __shared__ __attribute__((aligned(8))) uint16_t s_cmin[kCminTab];
   __shared__ uint32_t s_bucket[2 * kWave];  // pattern positions per bucket of the 112-bucket signature: [0, 56) first halves, [64, 120) second halves
@@ -1239,7 +1249,7 @@ __global__ void __launch_bounds__(256) k_segbase(DevBatch b, DevWork w, WorkItem
 // signature bound is skipped (the exact coverage test decides).  !LIGHT: blocks [0, first_q_blocks) take chunk 0 of
 // query blockIdx.x, the others loop over the work-item list.
 template <bool LIGHT>
-__global__ void __launch_bounds__(kWave, LIGHT ? FMX_LIGHT_WAVES : 6) k_expand_b(DevIndex ix, DevBatch b, DevWork w, Params prm,
+__global__ void __launch_bounds__(kWave, LIGHT ? FMX_LIGHT_WAVES : FMX_PHASEB_WAVES) k_expand_b(DevIndex ix, DevBatch b, DevWork w, Params prm,
                                                        const WorkItem* items, uint32_t item_cap, uint32_t first_q_blocks) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t* s_pat = (uint32_t*)smem;

@@ -119,16 +119,49 @@ def test_oracle_sample_at_scale(fmx, c2):
         workloads.compare(oo, oc, go, gc, name)
 
 
-def test_c3_headline_config_parity(fmx, gpu_device):
-    """The bench workload itself (config C3: 5 M sentences, mean 25 tokens, fuzzy 0.7, nmatch 5): 200 k of its
-    1 M queries, every record compared bit for bit with the oracle on the same index (≈ 7 s of oracle time on
-    16 host cores), and the remaining queries through the self-match property."""
+@pytest.fixture(scope="module")
+def c3(fmx, gpu_device):
     c_off, c_tok, q_off, q_tok, vs = workloads.synthetic(5_000_000, 1_000_000, 25)
     ix = fmx.Index.create()
     ix.add_ids(c_off, c_tok, vs)
     ix.sort(gpu_device)
     ix.finalize()
     ix.to_device(gpu_device)
+    return ix, c_off, c_tok, q_off, q_tok, vs
+
+
+def test_c3_index_equals_an_independent_oracle_build_at_5m(fmx, c3):
+    """The 5 M-sentence index of the headline config, built by the product (suffix sort on the GPU, VocabIndexer::sfreq on the
+    host), against the oracle's OWN build from the raw corpus — its restatement of SuffixArray::sort (src/suffix_array.cc:58-102,
+    235-251) and of the sentence frequencies (src/vocab_indexer.cc:37-50): every array equal.  The parity tests below feed the
+    oracle these arrays; this test is what makes them independent of the product."""
+    ix, c_off, c_tok, _, _, vs = c3
+    o = oracle_lib.OracleIndex()
+    o.add_ids_bulk(c_off, c_tok, vs)           # no sfreq handed over: the oracle counts its own
+    o.sort(oracle_lib.effective_cpus())
+    a = o.arrays()
+    for k in ["suf_sid", "suf_pos", "buffer", "sent_pos", "qva"]:
+        assert np.array_equal(a[k], ix.array(k)), k
+    mine = np.asarray(ix.array("sfreq"))
+    theirs = np.zeros(len(mine), np.int64)     # counted here, independently: sentences containing each word
+    n_sent = len(c_off) - 1
+    for s0 in range(0, n_sent, 1 << 20):
+        s1 = min(n_sent, s0 + (1 << 20))
+        lens = np.diff(c_off[s0:s1 + 1]).astype(np.int64)
+        sid = np.repeat(np.arange(s1 - s0, dtype=np.uint64), lens)
+        tok = c_tok[int(c_off[s0]):int(c_off[s1])].astype(np.uint64)
+        pairs = np.unique(sid << np.uint64(32) | tok)
+        theirs += np.bincount((pairs & np.uint64(0xffffffff)).astype(np.int64), minlength=len(theirs))[:len(theirs)]
+    n = min(len(mine), len(theirs))
+    assert np.array_equal(mine[2:n], theirs[2:n])
+    o.close()
+
+
+def test_c3_headline_config_parity(fmx, gpu_device, c3):
+    """The bench workload itself (config C3: 5 M sentences, mean 25 tokens, fuzzy 0.7, nmatch 5): 200 k of its
+    1 M queries, every record compared bit for bit with the oracle on the same index (≈ 7 s of oracle time on
+    16 host cores), and the remaining queries through the self-match property."""
+    ix, c_off, c_tok, q_off, q_tok, vs = c3
     kw = workloads.PARAM_SETS["C3"]
     go, gc, _ = ix.match_batch(fmx.Params(**kw), q_off, q_tok, cap=5)
     o = oracle_lib.OracleIndex()
