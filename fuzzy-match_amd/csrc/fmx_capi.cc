@@ -31,6 +31,7 @@ struct fmx_index {
   std::mutex                                mu;    // interning of penalty strings, lazy construction of the coalescer
   std::unique_ptr<Coalescer>                co;
   std::once_flag                            co_once;   // first fmx_match_one from any thread constructs the coalescer
+  std::unique_ptr<SortResident, void (*)(SortResident*)> sort_resident{nullptr, gpu_sort_resident_free};  // what the GPU sort left in HBM
   int64_t                                   coalesce_us = 100;
   int64_t                                   host_lanes = 1;   // host threads (contexts) per device inside one fmx_match_batch call
   int64_t                                   min_block_queries = 32768;  // a replica / host lane gets a block only if it is at least this large
@@ -166,7 +167,7 @@ int fmx_index_sort(fmx_index* ix, int device, int nthreads) {
   if (ix->finalized) return fail(FMX_E_STATE, "index is finalized");
   return guarded([&]() {
     if (ix->host.sorted) return (int)FMX_OK;
-    if (device >= 0) gpu_suffix_sort(ix->host, device);
+    if (device >= 0) ix->sort_resident.reset(gpu_suffix_sort(ix->host, device));
     else ix->host.sort(nthreads < 1 ? 1 : nthreads);
     return (int)FMX_OK;
   });
@@ -184,7 +185,9 @@ static int add_device(fmx_index* ix, int device) {
     for (auto& d : ix->devs) if (d->device() == device) return FMX_OK;
   return guarded([&]() {
     std::unique_ptr<DeviceIndex> d(new DeviceIndex);
-    d->upload(ix->host, device);
+    // the first replica on the device the suffix sort ran on adopts what the sort left in HBM
+    std::unique_ptr<SortResident, void (*)(SortResident*)> res(ix->sort_resident.release(), gpu_sort_resident_free);
+    d->upload(ix->host, device, res.get());
     d->set_contexts((uint32_t)std::max<int64_t>(ix->host_lanes + 1, 3));  // host_lanes may have been set before the upload
     ix->devs.push_back(std::move(d));
     return (int)FMX_OK;
@@ -743,6 +746,7 @@ int64_t fmx_index_add_text(fmx_index* ix, const char* id, const char* sentence, 
 int fmx_index_reopen(fmx_index* ix) {
   if (!ix) return fail(FMX_E_INVALID, "null argument");
   // (the coalescer stays: it holds no device state, and it is constructed once per index — std::call_once)
+  ix->sort_resident.reset();
   ix->devs.clear();
   ix->finalized = false;
   return FMX_OK;

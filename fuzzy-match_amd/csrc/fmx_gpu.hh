@@ -58,7 +58,19 @@ struct DeviceBatchView {
 };
 
 int  gpu_device_count();
-void gpu_suffix_sort(HostIndex& h, int device);
+// What the GPU suffix sort leaves in HBM for the upload that follows: the token buffer, the sentence positions and the sorted
+// suffix array, so that fmx_index_sort -> fmx_index_finalize -> fmx_index_to_device moves nothing across PCIe twice.
+struct SortResident {
+  int       device = -1;
+  uint32_t* d_buf = nullptr;       // h.buf + 8 spare zero words (what DeviceIndex keeps as `tok`)
+  uint32_t* d_sent_pos = nullptr;
+  uint32_t* d_sid = nullptr;       // sorted suffix array, parallel arrays
+  uint16_t* d_pos = nullptr;
+  uint64_t  n_buf = 0, n_sent = 0, n_suf = 0;
+};
+void gpu_sort_resident_free(SortResident*);
+// sorts h's suffix array on `device`; returns what stayed in HBM (nullptr for an empty index); the caller owns it
+SortResident* gpu_suffix_sort(HostIndex& h, int device);
 void* gpu_host_alloc(size_t bytes);  // pinned host memory (hipHostMalloc), nullptr on failure
 void  gpu_host_free(void* p);
 
@@ -70,7 +82,8 @@ class DeviceIndex {
   DeviceIndex(const DeviceIndex&) = delete;
   DeviceIndex& operator=(const DeviceIndex&) = delete;
 
-  void     upload(const HostIndex& h, int device);
+  // resident (optional, consumed): arrays the suffix sort left on the same device; they are adopted instead of uploaded again
+  void     upload(const HostIndex& h, int device, SortResident* resident = nullptr);
   int      device() const;
   // test / debug: one of the device-built arrays (0 suf, 1 suf_sig, 2 suf_key, 3 gram, 4 gram5, 5 suf_b); returns its element count
   uint64_t download(int which, void* dst, uint64_t capacity_bytes) const;

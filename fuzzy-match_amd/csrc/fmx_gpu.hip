@@ -382,7 +382,7 @@ constexpr size_t kDynLdsMax = 150 * 1024;  // dynamic LDS the row kernels may as
 // m.d.tok and m.d.sent_pos are already resident; the suffix array goes up (6 bytes per suffix) and is dropped afterwards.
 // Returns the per-sentence 112-bucket signatures (two words per sentence, device memory): the caller builds the bit planes
 // from them and frees them.
-static unsigned long long* derive_on_device(DeviceIndex::Impl& m, const HostIndex& h) {
+static unsigned long long* derive_on_device(DeviceIndex::Impl& m, const HostIndex& h, SortResident* res) {
   const uint64_t n = h.num_suffixes();
   const uint32_t n_sent = h.num_sentences();
   m.d.suf = nullptr; m.d.suf_b = nullptr; m.d.suf_sig = nullptr; m.d.suf_key = nullptr;
@@ -396,8 +396,10 @@ static unsigned long long* derive_on_device(DeviceIndex::Impl& m, const HostInde
   if (n == 0) return nullptr;
   unsigned long long* d_ssig = dev_alloc<unsigned long long>(2ull * n_sent);
   {
-    uint32_t* d_sid = dev_upload(h.suf_sid);
-    uint16_t* d_pos = dev_upload(h.suf_pos);
+    // the suffix array: still in HBM when the sort ran on this device just before, else uploaded (6 bytes per suffix)
+    uint32_t* d_sid = res ? res->d_sid : dev_upload(h.suf_sid);
+    uint16_t* d_pos = res ? res->d_pos : dev_upload(h.suf_pos);
+    if (res) { res->d_sid = nullptr; res->d_pos = nullptr; }
     hipLaunchKernelGGL(k_dv_sent_sig, dim3((n_sent + 255) / 256), dim3(256), 0, 0, m.d.tok, m.d.sent_pos, n_sent, d_ssig);
     hipLaunchKernelGGL(k_dv_suffix, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, m.d.tok, m.d.sent_pos, (const uint32_t*)d_sid,
                        (const uint16_t*)d_pos, (const unsigned long long*)d_ssig, (unsigned long long)n, suf, suf_b, suf_sig, suf_key);
@@ -492,7 +494,7 @@ uint64_t DeviceIndex::download(int which, void* dst, uint64_t capacity_bytes) co
   return count;
 }
 
-void DeviceIndex::upload(const HostIndex& h, int device) {
+void DeviceIndex::upload(const HostIndex& h, int device, SortResident* res) {
   Impl& m = *impl_;
   if (m.device >= 0) throw GpuError("index is already on a device");
   check_device(device);
@@ -500,14 +502,20 @@ void DeviceIndex::upload(const HostIndex& h, int device) {
   m.device = device;
   const uint64_t n_suf = h.num_suffixes();
   if (n_suf >= 0xffffffffull) throw UnsupportedError("more than 2^32 - 1 suffixes");
+  if (res && (res->device != device || res->n_buf != h.buf.size() || res->n_sent != h.sent_pos.size() || res->n_suf != n_suf || !res->d_buf ||
+              !res->d_sent_pos || !res->d_sid || !res->d_pos))
+    res = nullptr;  // not what this index looks like now: ignore it
   uint32_t* d_tok = nullptr;
-  {  // eight spare tokens: the DP kernels read the sentence four tokens at a time, possibly past its end
+  if (res) {  // left in HBM by the suffix sort (with the eight spare words)
+    m.d.tok = res->d_buf; res->d_buf = nullptr;
+    m.d.sent_pos = res->d_sent_pos; res->d_sent_pos = nullptr;
+  } else {  // eight spare tokens: the DP kernels read the sentence four tokens at a time, possibly past its end
     d_tok = dev_alloc<uint32_t>(h.buf.size() + 8);
     HIP_TRY(hipMemset(d_tok, 0, (h.buf.size() + 8) * sizeof(uint32_t)));
     if (!h.buf.empty()) HIP_TRY(hipMemcpy(d_tok, h.buf.data(), h.buf.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     m.d.tok = d_tok;
+    m.d.sent_pos = dev_upload(h.sent_pos);
   }
-  m.d.sent_pos = dev_upload(h.sent_pos);
   m.d.qva = dev_upload(h.qva);
   m.d.idf = dev_upload(h.idf);
   m.d.n_qva = (uint32_t)h.qva.size();
@@ -517,7 +525,7 @@ void DeviceIndex::upload(const HostIndex& h, int device) {
   for (uint32_t sp : h.sent_pos) mx = std::max(mx, h.buf[sp]);
   m.d.max_slen = mx;
   m.bytes = h.buf.size() * 4 + h.sent_pos.size() * 4 + h.qva.size() * 4 + h.idf.size() * 4;
-  unsigned long long* d_ssig = derive_on_device(m, h);
+  unsigned long long* d_ssig = derive_on_device(m, h, res);
   // bit planes of the signatures and thermometer planes of the stored lengths, built on the device from suf_sig
   // (DESIGN.md §3): plane-major, one 64-bit word per (row, block of 64 consecutive suffixes)
   m.d.n_blk = (m.d.n_suf + 63) / 64;
@@ -1657,48 +1665,117 @@ struct GpuSuffixLess {
   }
 };
 
-__global__ void k_make_sort_keys(const uint32_t* buf, const uint32_t* sent_pos, const uint32_t* suf_sid,
-                                 const uint16_t* suf_pos, GpuSortKey* keys, unsigned long long n) {
-  const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t sid = suf_sid[i], pos = suf_pos[i];
-  const uint32_t* b = buf + sent_pos[sid];
-  const uint32_t rem = b[0] - (pos - 1);
+// (sid, pos) of every suffix from the sentence buffer alone: one thread per buffer word; a token's sentence is found by bisecting
+// sent_pos (the suffixes are enumerated in buffer order, like SuffixArray::add_sentence does, src/suffix_array.cc:9-27)
+__global__ void k_enumerate_suffixes(const uint32_t* __restrict__ buf, const uint32_t* __restrict__ sent_pos, uint32_t n_sent,
+                                     unsigned long long n_buf, GpuSortKey* __restrict__ keys) {
+  const unsigned long long w = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_buf) return;
+  uint32_t lo = 0, hi = n_sent;  // last sentence whose position is <= w
+  while (hi - lo > 1) { const uint32_t mid = lo + ((hi - lo) >> 1); if (sent_pos[mid] <= w) lo = mid; else hi = mid; }
+  const uint32_t sp = sent_pos[lo], len = buf[sp];
+  const uint32_t pos = (uint32_t)(w - sp);  // 0 = the length word, len + 1 = the terminator
+  if (pos == 0 || pos > len) return;
+  const unsigned long long i = w - 2ull * lo - 1ull;  // suffix number: buffer words minus the two framing words of every sentence before
   GpuSortKey k;
-  k.prefix = ((unsigned long long)b[pos] << 32) | (rem > 1 ? b[pos + 1] : 0u);
-  k.key = ((unsigned long long)sid << 16) | pos;
+  k.prefix = ((unsigned long long)buf[w] << 32) | (pos < len ? buf[w + 1] : 0u);
+  k.key = ((unsigned long long)lo << 16) | pos;
   keys[i] = k;
 }
 
-__global__ void k_extract_keys(const GpuSortKey* keys, unsigned long long* out, unsigned long long n) {
+// sorted keys -> parallel arrays + the histogram of first tokens (-> _quickVocabAccess, src/suffix_array.cc:76-98)
+__global__ void k_split_sorted(const GpuSortKey* __restrict__ keys, unsigned long long n, uint32_t* __restrict__ sid, uint16_t* __restrict__ pos,
+                               uint32_t* __restrict__ first_hist, uint32_t n_hist) {
   const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = keys[i].key;
+  if (i >= n) return;
+  const GpuSortKey k = keys[i];
+  sid[i] = (uint32_t)(k.key >> 16);
+  pos[i] = (uint16_t)(k.key & 0xffffu);
+  const uint32_t w0 = (uint32_t)(k.prefix >> 32);
+  // sorted by first token: runs of equal w0 — one atomic per run boundary inside the wave
+  const uint32_t prev = __shfl_up(w0, 1, 64);
+  const bool head = (threadIdx.x & 63) == 0 || prev != w0 || i == 0;
+  const unsigned long long heads = __ballot(head);
+  if (head && w0 < n_hist) {
+    const uint32_t lane = threadIdx.x & 63;
+    const unsigned long long above = lane == 63 ? 0ull : (heads >> (lane + 1));
+    const uint32_t run = above ? (uint32_t)__builtin_ctzll(above) + 1u : 64u - lane;
+    const unsigned long long left = n - i;
+    atomicAdd(&first_hist[w0], (uint32_t)(run < left ? run : left));
+  }
 }
 
-void gpu_suffix_sort(HostIndex& h, int device) {
+void gpu_sort_resident_free(SortResident* r) {
+  if (!r) return;
+  if (r->device >= 0) (void)hipSetDevice(r->device);
+  hipFree(r->d_buf); hipFree(r->d_sent_pos); hipFree(r->d_sid); hipFree(r->d_pos);
+  delete r;
+}
+
+// Index build: the suffix array is enumerated, sorted and split on the device from the sentence buffer alone; the sorted arrays
+// come home once (the .fmi writer and the host-side views need them) and ALSO stay in HBM for the upload that follows.
+SortResident* gpu_suffix_sort(HostIndex& h, int device) {
   check_device(device);
   HIP_TRY(hipSetDevice(device));
   const uint64_t n = h.suf_sid.size();
-  if (n == 0) { h.adopt_sorted(nullptr, 0); return; }
-  uint32_t* d_buf = dev_upload(h.buf);
-  uint32_t* d_sp = dev_upload(h.sent_pos);
-  uint32_t* d_sid = dev_upload(h.suf_sid);
-  uint16_t* d_pos = dev_upload(h.suf_pos);
+  if (n == 0) { h.adopt_sorted(nullptr, 0); return nullptr; }
+  std::unique_ptr<SortResident, void (*)(SortResident*)> res(new SortResident, gpu_sort_resident_free);
+  res->device = device; res->n_buf = h.buf.size(); res->n_sent = h.sent_pos.size(); res->n_suf = n;
+  res->d_buf = dev_alloc<uint32_t>(h.buf.size() + 8);
+  HIP_TRY(hipMemset(res->d_buf + h.buf.size(), 0, 8 * sizeof(uint32_t)));
+  HIP_TRY(hipMemcpy(res->d_buf, h.buf.data(), h.buf.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  res->d_sent_pos = dev_upload(h.sent_pos);
   GpuSortKey* d_in = dev_alloc<GpuSortKey>(n);
-  GpuSortKey* d_out = dev_alloc<GpuSortKey>(n);
-  hipLaunchKernelGGL(k_make_sort_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_buf, d_sp, d_sid, d_pos, d_in, n);
-  size_t tmp_bytes = 0;
-  GpuSuffixLess less{d_buf, d_sp};
-  HIP_TRY(rocprim::merge_sort(nullptr, tmp_bytes, d_in, d_out, (size_t)n, less, (hipStream_t)0, false));
+  GpuSortKey* d_out = nullptr;
   void* tmp = nullptr;
-  HIP_TRY(hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 1)));
-  HIP_TRY(rocprim::merge_sort(tmp, tmp_bytes, d_in, d_out, (size_t)n, less, (hipStream_t)0, false));
-  unsigned long long* d_flat = (unsigned long long*)d_in;  // reuse
-  hipLaunchKernelGGL(k_extract_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_out, d_flat, n);
-  std::vector<uint64_t> flat(n);
-  HIP_TRY(hipMemcpy(flat.data(), d_flat, n * 8, hipMemcpyDeviceToHost));
-  hipFree(tmp); hipFree(d_in); hipFree(d_out); hipFree(d_buf); hipFree(d_sp); hipFree(d_sid); hipFree(d_pos);
-  h.adopt_sorted(flat.data(), n);
+  uint32_t* d_hist = nullptr;
+  auto cleanup = [&]() { hipFree(d_in); hipFree(d_out); hipFree(tmp); hipFree(d_hist); };
+  try {
+    d_out = dev_alloc<GpuSortKey>(n);
+    hipLaunchKernelGGL(k_enumerate_suffixes, dim3((unsigned)((h.buf.size() + 255) / 256)), dim3(256), 0, 0, res->d_buf, res->d_sent_pos,
+                       (uint32_t)h.sent_pos.size(), (unsigned long long)h.buf.size(), d_in);
+    size_t tmp_bytes = 0;
+    GpuSuffixLess less{res->d_buf, res->d_sent_pos};
+    HIP_TRY(rocprim::merge_sort(nullptr, tmp_bytes, d_in, d_out, (size_t)n, less, (hipStream_t)0, false));
+    HIP_TRY(hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 1)));
+    HIP_TRY(rocprim::merge_sort(tmp, tmp_bytes, d_in, d_out, (size_t)n, less, (hipStream_t)0, false));
+    hipFree(tmp); tmp = nullptr;
+    hipFree(d_in); d_in = nullptr;
+    res->d_sid = dev_alloc<uint32_t>(n);
+    res->d_pos = dev_alloc<uint16_t>(n);
+    // _quickVocabAccess: one entry per word id the index knows, plus the total
+    uint32_t vs = h.vocab_size;
+    const uint32_t n_hist = std::max<uint32_t>(vs, 2) + 1;
+    d_hist = dev_alloc<uint32_t>(n_hist);
+    HIP_TRY(hipMemset(d_hist, 0, (size_t)n_hist * 4));
+    hipLaunchKernelGGL(k_split_sorted, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (const GpuSortKey*)d_out, (unsigned long long)n, res->d_sid,
+                       res->d_pos, d_hist, n_hist - 1);
+    HIP_TRY(hipGetLastError());
+    std::vector<uint32_t> sid(n), hist(n_hist);
+    std::vector<uint16_t> pos(n);
+    HIP_TRY(hipMemcpy(sid.data(), res->d_sid, n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(pos.data(), res->d_pos, n * 2, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(hist.data(), d_hist, (size_t)n_hist * 4, hipMemcpyDeviceToHost));
+    // word ids above the declared vocabulary (bulk corpora may carry them): the host's rule grows the vocabulary to fit
+    uint64_t counted = 0;
+    for (uint32_t w = 0; w + 1 < n_hist; w++) counted += hist[w];
+    if (counted != n) {  // some first token >= vocab_size: let the host loop (which also grows vocab_size) do it
+      std::vector<uint64_t> flat(n);
+      for (uint64_t i = 0; i < n; i++) flat[i] = ((uint64_t)sid[i] << 16) | pos[i];
+      h.adopt_sorted(flat.data(), n);
+    } else {
+      std::vector<uint32_t> qva((size_t)n_hist, 0);  // exclusive prefix: first suffix per first-token id, [vocab] = total
+      uint32_t run = 0;
+      for (uint32_t w = 0; w + 1 < n_hist; w++) { qva[w] = run; run += hist[w]; }
+      qva[n_hist - 1] = run;
+      h.adopt_sorted_arrays(std::move(sid), std::move(pos), std::move(qva));
+    }
+  } catch (...) {
+    cleanup();
+    throw;
+  }
+  cleanup();
+  return res.release();
 }
 
 }  // namespace fmx

@@ -363,6 +363,18 @@ void HostIndex::adopt_arrays(const uint32_t* sid, const uint16_t* pos, uint64_t 
   sorted = true;
 }
 
+void HostIndex::adopt_sorted_arrays(std::vector<uint32_t>&& sid, std::vector<uint16_t>&& pos, std::vector<uint32_t>&& qva_in) {
+  if (sid.size() != suf_sid.size() || pos.size() != suf_pos.size()) throw std::runtime_error("adopt_sorted_arrays: size mismatch");
+  if (qva_in.size() < 2) throw std::runtime_error("adopt_sorted_arrays: empty _quickVocabAccess");
+  const uint32_t vs = (uint32_t)qva_in.size() - 1;
+  if (vs > vocab_size) { vocab_size = vs; sfreq.resize(vocab_size, 0); }
+  if (vs < vocab_size) qva_in.resize((size_t)vocab_size + 1, qva_in.back());  // words beyond the largest first token: empty buckets at the end
+  suf_sid = std::move(sid);
+  suf_pos = std::move(pos);
+  qva = std::move(qva_in);
+  sorted = true;
+}
+
 void HostIndex::bucket_keys(std::vector<uint64_t>& keys, std::vector<uint64_t>& bucket_off) const {
   const uint64_t n = suf_sid.size();
   keys.resize(n);

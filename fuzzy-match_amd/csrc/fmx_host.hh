@@ -133,6 +133,8 @@ class HostIndex {
   void sort(int nthreads);
   // adopt a suffix order computed elsewhere (the GPU builder) — keys = sid << 16 | pos, sorted.
   void adopt_sorted(const uint64_t* keys, uint64_t n);
+  // the same when the builder hands over the parallel arrays and _quickVocabAccess it computed itself (sizes must match)
+  void adopt_sorted_arrays(std::vector<uint32_t>&& sid, std::vector<uint16_t>&& pos, std::vector<uint32_t>&& qva_in);
   // unsorted (sid<<16|pos) keys + first-token bucket offsets, for the GPU builder
   void bucket_keys(std::vector<uint64_t>& keys, std::vector<uint64_t>& bucket_off) const;
 
