@@ -1517,9 +1517,16 @@ void DeviceIndex::subsequence_host(const HostIndex& h, const HostBatchView& hb, 
   CtxLease lease(m);
   Ctx& c = *lease.c;
   hipStream_t stream = c.stream;
-  const uint32_t seen_cap = nm + 1024;  // candidates (<= nm) + perfect matches skipped under no_perfect
-  constexpr uint64_t kChunk = 16384;    // queries per round trip: bounds the host-side queues
-  for (uint64_t q0 = 0; q0 < nq_all; q0 += kChunk) {
+  // per query: the sentences already seen = candidates (<= nm) + perfect matches skipped under no_perfect.  The list starts
+  // small; a chunk of queries in which one overflows is run again with a list eight times as long (the reference has no limit;
+  // at most every sentence of the index can be skipped)
+  uint32_t seen_cap = nm + 1024;
+  const uint64_t seen_max = (uint64_t)nm + h.num_sentences() + 1;
+  constexpr uint64_t kChunkMax = 16384;    // queries per round trip: bounds the host-side queues
+  uint64_t kChunk = kChunkMax;
+  for (uint64_t q0 = 0; q0 < nq_all;) {
+    // (a long seen list shrinks the chunk: the lists are nq x seen_cap words of HBM)
+    while (kChunk > 1 && kChunk * (uint64_t)seen_cap > (1ull << 28)) kChunk /= 2;
     const uint64_t nq = std::min<uint64_t>(kChunk, nq_all - q0);
     const uint32_t base = hb.q_off[q0];
     const uint64_t nt = hb.q_off[q0 + nq] - base;
@@ -1597,10 +1604,16 @@ void DeviceIndex::subsequence_host(const HostIndex& h, const HostBatchView& hb, 
       HIP_TRY(hipMemcpyAsync(st.data(), d_st.p, nq * sizeof(SubState), hipMemcpyDeviceToHost, stream));
       HIP_TRY(hipStreamSynchronize(stream));
     }
-    for (uint64_t q = 0; q < nq; q++) {
-      if (st[q].overflow) throw UnsupportedError("subsequence(): more than 1024 perfect matches skipped for one pattern");
-      if (st[q].md != 10000) { out[q0 + q] = st[q].best; out_found[q0 + q] = 1; if (out_pos) out_pos[q0 + q] = st[q].pos; }
+    bool overflow = false;
+    for (uint64_t q = 0; q < nq; q++) overflow = overflow || st[q].overflow;
+    if (overflow) {  // run this chunk again with longer lists
+      if (seen_cap >= seen_max) throw GpuError("subsequence(): the seen list overflowed at its largest size");
+      seen_cap = (uint32_t)std::min<uint64_t>((uint64_t)seen_cap * 8, std::min<uint64_t>(seen_max, 0xffffffffull));
+      continue;
     }
+    for (uint64_t q = 0; q < nq; q++)
+      if (st[q].md != 10000) { out[q0 + q] = st[q].best; out_found[q0 + q] = 1; if (out_pos) out_pos[q0 + q] = st[q].pos; }
+    q0 += nq;
   }
 }
 

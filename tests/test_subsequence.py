@@ -172,3 +172,32 @@ def test_gpu_subsequence_real_tokens_and_itoks(fmx, gpu_device):
         total += _check_batch(ix, o, q_off, q_tok, kw, real=[q[1] for q in queries], itoks=[q[2] for q in queries],
                               q_real=q_real, q_itok=q_itok, tag="real")
     assert total > 300
+
+
+@pytest.mark.gpu
+def test_gpu_subsequence_skips_thousands_of_perfect_matches(fmx, gpu_device):
+    """no_perfect with 3000 indexed copies of the sub-n-gram's sentence: every copy goes to `perfect`
+    (src/fuzzy_match.cc:329-332) before the first real candidate is scored — more than the 1024 entries the seen list starts
+    with; the chunk is re-run with a longer list (the reference has no limit)."""
+    rng = np.random.default_rng(9)
+    base = [2, 3, 4, 5, 6]
+    sents = [base] * 3000 + [[2, 3, 4, 5, 7], [2, 3, 4, 9, 6, 8], [3, 4, 5, 6]] + [list(rng.integers(2, 30, size=6)) for _ in range(200)]
+    c_off = np.zeros(len(sents) + 1, np.uint32)
+    c_off[1:] = np.cumsum([len(x) for x in sents])
+    c_tok = np.asarray([t for x in sents for t in x], np.uint32)
+    ix = fmx.Index.create()
+    ix.add_ids(c_off, c_tok, 32)
+    ix.sort(gpu_device)
+    ix.finalize()
+    ix.to_device(gpu_device)
+    o = workloads.build_oracle(c_off, c_tok, 32, sfreq=ix.array("sfreq"))
+    qs = [base, [2, 3, 4, 5], [9, 2, 3, 4, 5, 6, 9], [3, 4, 5, 6]]
+    q_off = np.zeros(len(qs) + 1, np.uint32)
+    q_off[1:] = np.cumsum([len(x) for x in qs])
+    q_tok = np.asarray([t for x in qs for t in x], np.uint32)
+    n = 0
+    for kw in [dict(nmatch=3, no_perfect=True, min_subseq_length=3, min_subseq_ratio=0), dict(nmatch=1, no_perfect=True, min_subseq_length=2, min_subseq_ratio=0),
+               dict(nmatch=5, no_perfect=False, min_subseq_length=3, min_subseq_ratio=0)]:
+        n += _check_batch(ix, o, q_off, q_tok, kw, tag="perfect")
+    assert n >= 6
+    o.close()
