@@ -60,8 +60,9 @@ static inline uint64_t spell_hash(const char* s, size_t& len) {  // FNV-1a, 64 b
 }
 
 const HostIndex::FastVocab& HostIndex::fast_vocab() const {
+  if (fast_.built_for.load(std::memory_order_acquire) == forms.size() && forms.size() != 0) return fast_;  // the common case: no lock
   std::lock_guard<std::mutex> lk(fast_mu_);
-  if (fast_.built_for == forms.size() && !fast_.slot.empty()) return fast_;
+  if (fast_.built_for.load(std::memory_order_relaxed) == forms.size() && !fast_.slot.empty()) return fast_;
   FastVocab& f = fast_;
   uint64_t cap = 64;
   while (cap < forms.size() * 2) cap <<= 1;
@@ -79,7 +80,7 @@ const HostIndex::FastVocab& HostIndex::fast_vocab() const {
     while (f.slot[h] != ~0ull) h = (h + 1) & f.mask;
     f.slot[h] = (off << 32) | (uint64_t)id;
   }
-  f.built_for = forms.size();
+  f.built_for.store(forms.size(), std::memory_order_release);
   return f;
 }
 

@@ -99,7 +99,7 @@ class HostIndex {
     std::vector<char>     arena;   // NUL-terminated spellings
     std::vector<uint64_t> slot;    // offset into arena << 32 | id, ~0 = empty
     uint64_t              mask = 0;
-    uint64_t              built_for = 0;  // forms.size() it was built from
+    std::atomic<uint64_t> built_for{0};   // forms.size() it was built from (0 = not built)
   };
   mutable FastVocab  fast_;
   mutable std::mutex fast_mu_;

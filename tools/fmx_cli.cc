@@ -331,7 +331,8 @@ int main(int argc, char** argv) {
             }
             const size_t base = ids[t].size();
             ids[t].resize(base + ptr.size());
-            if (!ptr.empty() && fmx_vocab_lookup(ix, ptr.data(), ptr.size(), ids[t].data() + base) != FMX_OK) fail(fmx_last_error());
+            // (the batch lookup: an open-addressing table over the packed spellings, no std::string per token)
+            if (!ptr.empty() && fmx_vocab_lookup_mt(ix, ptr.data(), ptr.size(), ids[t].data() + base, 1) != FMX_OK) fail(fmx_last_error());
             counts[t].push_back((uint32_t)ptr.size());
             if (th) {
               if (info.real_differs)
