@@ -915,42 +915,46 @@ __global__ void __launch_bounds__(kWave, 8) k_expand_a(DevIndex ix, DevBatch b, 
 // re-tested exactly like k_expand_a does (same 8-byte word, same table), so the hits queued for k_expand_b are
 // identical.  One wave per work item (range, 256 blocks).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void csa64(unsigned long long& s, unsigned long long& c, unsigned long long x, unsigned long long y,
-                                      unsigned long long z) {
-  const unsigned long long u = x ^ y;
-  c = (x & y) | (u & z);
+// carry-save adder on 32-bit words: s = x ^ y ^ z, c = majority(x, y, z).  The majority is a bit select — where x and y
+// agree the carry is x, elsewhere it is z — i.e. one v_bfi_b32: three operations instead of five.  (The compiler rewrites
+// the C expression of the select back into and / and / or, hence the asm; 32-bit halves because two asm results glued
+// into an aligned 64-bit register pair cost copies and registers.)
+__device__ __forceinline__ void csa32(uint32_t& s, uint32_t& c, uint32_t x, uint32_t y, uint32_t z) {
+  const uint32_t u = x ^ y;
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(c) : "v"(u), "v"(z), "v"(x));
   s = u ^ z;
 }
 
-// a[] = six-level bit-sliced counters (bit i of a[l] = bit l of suffix i's count); adds eight one-bit planes with
-// weight 2^J.  Carries beyond level 5 cannot occur (the total never exceeds the pattern length <= 63).
+// a[] = one 32-bit half of the six-level bit-sliced counters (bit i of a[l] = bit l of suffix i's count); adds eight
+// one-bit planes with weight 2^J.  Carries beyond level 5 cannot occur (the total never exceeds the pattern length <= 63).
 template <int J>
-__device__ __forceinline__ void vadd8(unsigned long long (&a)[6], const unsigned long long (&x)[8]) {
-  unsigned long long s, c0, c1, c2, c3;
-  csa64(s, c0, a[J], x[0], x[1]);
-  csa64(s, c1, s, x[2], x[3]);
-  csa64(s, c2, s, x[4], x[5]);
-  csa64(s, c3, s, x[6], x[7]);
+__device__ __forceinline__ void vadd8(uint32_t (&a)[6], const uint32_t (&x)[8]) {
+  uint32_t s, c0, c1, c2, c3;
+  csa32(s, c0, a[J], x[0], x[1]);
+  csa32(s, c1, s, x[2], x[3]);
+  csa32(s, c2, s, x[4], x[5]);
+  csa32(s, c3, s, x[6], x[7]);
   a[J] = s;
   if constexpr (J + 1 < 6) {
-    unsigned long long d0, d1;
-    csa64(s, d0, a[J + 1], c0, c1);
-    csa64(s, d1, s, c2, c3);
+    uint32_t d0, d1;
+    csa32(s, d0, a[J + 1], c0, c1);
+    csa32(s, d1, s, c2, c3);
     a[J + 1] = s;
     if constexpr (J + 2 < 6) {
-      unsigned long long e;
-      csa64(s, e, a[J + 2], d0, d1);
+      uint32_t e;
+      csa32(s, e, a[J + 2], d0, d1);
       a[J + 2] = s;
 #pragma unroll
-      for (int l = J + 3; l < 6; l++) { const unsigned long long t = a[l] & e; a[l] ^= e; e = t; }
+      for (int l = J + 3; l < 6; l++) { const uint32_t t = a[l] & e; a[l] ^= e; e = t; }
     }
   }
 }
 
 // adds, with weight 2^J, the planes of the buckets in the (wave-uniform) mask m; col = this lane's column of the planes
+// (lanes beyond the chunk point at its last block: no branch around the loads, the caller drops their result)
 template <int J>
-__device__ __forceinline__ void plane_level(unsigned long long (&a)[6], unsigned long long m, const unsigned long long* col,
-                                            unsigned long long n_blk, bool valid) {
+__device__ __forceinline__ void plane_level(uint32_t (&al)[6], uint32_t (&ah)[6], unsigned long long m, const unsigned long long* col,
+                                            unsigned long long n_blk) {
   while (m) {
     unsigned long long x[8];
 #pragma unroll
@@ -959,10 +963,15 @@ __device__ __forceinline__ void plane_level(unsigned long long (&a)[6], unsigned
       if (m) {
         const uint32_t bk = (uint32_t)__builtin_ctzll(m);
         m &= m - 1ull;
-        if (valid) x[u] = col[(unsigned long long)bk * n_blk];
+        x[u] = col[(unsigned long long)bk * n_blk];
       }
     }
-    vadd8<J>(a, x);
+    // all eight loads are in flight before the first half is looked at
+    uint32_t xl[8], xh[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) { xl[u] = (uint32_t)x[u]; xh[u] = (uint32_t)(x[u] >> 32); }
+    vadd8<J>(al, xl);
+    vadd8<J>(ah, xh);
   }
 }
 
@@ -1064,24 +1073,29 @@ __global__ void __launch_bounds__(kWave, FMX_HEAVY_WAVES) k_expand_h(DevIndex ix
     for (uint32_t b0 = blk_first; b0 < blk_end; b0 += kWave) {
       const uint32_t blk = b0 + lane;
       const bool valid = blk < blk_end;
+      // lanes beyond the chunk load the chunk's last block instead of branching around every load; `surv` drops them
+      const uint32_t blk_ld = valid ? blk : blk_end - 1u;
       // stored length >= s for the 64 suffixes of this lane's block (s wave-uniform)
       auto T = [&](uint32_t s_) -> unsigned long long {
         if (s_ == 0) return ~0ull;
         if (s_ > ix.n_thermo || !valid) return 0ull;
         return ix.thermo[(unsigned long long)(s_ - 1) * ix.n_blk + blk];
       };
-      unsigned long long a[6] = {0, 0, 0, 0, 0, 0};
-      const unsigned long long* col = ix.planes + blk;
+      uint32_t al[6] = {0, 0, 0, 0, 0, 0}, ah[6] = {0, 0, 0, 0, 0, 0};
+      const unsigned long long* col = ix.planes + blk_ld;
 #pragma unroll
       for (int h = 0; h < 2; h++) {
         const unsigned long long* ch = col + (unsigned long long)(h * kSigBits) * ix.n_blk;
-        plane_level<0>(a, plh[h][0], ch, ix.n_blk, valid);
-        plane_level<1>(a, plh[h][1], ch, ix.n_blk, valid);
-        plane_level<2>(a, plh[h][2], ch, ix.n_blk, valid);
-        plane_level<3>(a, plh[h][3], ch, ix.n_blk, valid);
-        plane_level<4>(a, plh[h][4], ch, ix.n_blk, valid);
-        plane_level<5>(a, plh[h][5], ch, ix.n_blk, valid);
+        plane_level<0>(al, ah, plh[h][0], ch, ix.n_blk);
+        plane_level<1>(al, ah, plh[h][1], ch, ix.n_blk);
+        plane_level<2>(al, ah, plh[h][2], ch, ix.n_blk);
+        plane_level<3>(al, ah, plh[h][3], ch, ix.n_blk);
+        plane_level<4>(al, ah, plh[h][4], ch, ix.n_blk);
+        plane_level<5>(al, ah, plh[h][5], ch, ix.n_blk);
       }
+      unsigned long long a[6];
+#pragma unroll
+      for (int l = 0; l < 6; l++) a[l] = ((unsigned long long)ah[l] << 32) | al[l];
       // d = count - tmin, bit-sliced (tmin wave-uniform: each level is two operations); bor = borrow = count < tmin
       unsigned long long d[6], bor = 0;
 #pragma unroll
