@@ -3,6 +3,7 @@
 // (src/fuzzy_match.cc:450-477).
 #include "../../include/fmx.h"
 
+#include <cstdlib>
 #include <string.h>
 
 #include <atomic>
@@ -62,6 +63,14 @@ template <class F> static int guarded(F&& f) {
     return fail(FMX_E_INVALID, e.what());
   }
 }
+
+// The HIP runtime spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues per device (four by default), and
+// streams that share a queue run in order.  Several matching calls in flight bring two compute streams each: with eight
+// queues six calls overlap (a 125 k-query pass 1.15 -> 0.97 ms, 100 k queries on the 1 M-sentence index 106 -> 129 M
+// patterns/s; more queues than that lost again).  Only a default: a value in the environment wins, and it only takes
+// effect when this library is loaded before the process's first HIP call (bench.py and the Python module set it before
+// importing torch for the same reason).
+__attribute__((constructor)) static void fmx_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 
 extern "C" {
 
@@ -852,6 +861,7 @@ int fmx_set_option(fmx_index* ix, const char* name, int64_t value) {
     else if (n == "pair_finish") d->set_pair_finish(value != 0);
     else if (n == "small_path") d->set_small_path(value != 0);
     else if (n == "turns") d->set_turns((uint32_t)std::max<int64_t>(value, 0));
+    else if (n == "device_turns") d->set_device_turns((uint32_t)std::max<int64_t>(value, 0));
     else if (n == "expand_order") d->set_expand_order((uint32_t)std::max<int64_t>(value, 0));
     else if (n == "b_grid") d->set_b_grid((uint32_t)std::max<int64_t>(value, 1));
     else if (n == "heavy_grid") d->set_heavy_grid((uint32_t)std::max<int64_t>(value, 1));

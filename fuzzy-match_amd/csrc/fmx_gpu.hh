@@ -96,6 +96,7 @@ class DeviceIndex {
   void     set_probe_count(bool on);    // measurement: k_probe also counts the bytes / 128-byte lines it requests
   void     set_serial(bool on);         // measurement: no side stream, every kernel alone on the GPU
   void     set_turns(uint32_t n);        // host-buffer calls that may own the GPU's kernels at once (0 = no turns)
+  void     set_device_turns(uint32_t n);  // chaining of the device-resident entry points only (default 0)
   void     set_expand_order(uint32_t n);
   void     set_b_grid(uint32_t n);
   void     set_heavy_grid(uint32_t n);  // workgroups of the bit-plane kernel

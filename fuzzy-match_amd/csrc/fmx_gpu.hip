@@ -263,6 +263,10 @@ struct DeviceIndex::Impl {
                                          // predecessor's memory-bound half (its probe and long-range kernels): the probe of a call,
                                          // bound by HBM, runs beside the hit walk / edit distances / replay of the call before it,
                                          // bound by instruction issue and latency; 3 = turns taken on the host
+  uint32_t                device_turns = 0;  // the same for the device-resident entry points.  0 by default: with eight hardware
+                                         // queues (GPU_MAX_HW_QUEUES, set at load) six unchained calls overlap better than any chaining
+                                         // (C3 5.59 against 5.82 ms per step, C4 3.74 against 4.08), and with the runtime's default of four
+                                         // queues and three calls in flight chaining made no difference (5.89 / 5.86)
   std::mutex              chain_mu;
   hipEvent_t              chain_last = nullptr;  // ends the kernels of the call enqueued last (owned by its context)
   // what passes needed so far, per 1024 queries, shared by all contexts: a context sizes its workspace for a full pass of the
@@ -347,7 +351,8 @@ void     DeviceIndex::set_initial_segment(uint64_t n) { impl_->init_seg = std::m
 void     DeviceIndex::set_heavy_min(uint32_t n) { impl_->heavy_min = n; }
 void     DeviceIndex::set_probe_count(bool on) { impl_->probe_count = on; }
 void     DeviceIndex::set_serial(bool on) { impl_->serial = on; }
-void     DeviceIndex::set_turns(uint32_t n) { impl_->turns = n; }
+void     DeviceIndex::set_turns(uint32_t n) { impl_->turns = n; impl_->device_turns = n; }
+void     DeviceIndex::set_device_turns(uint32_t n) { impl_->device_turns = n; }
 void     DeviceIndex::set_small_path(bool on) { impl_->small_path = on; }
 void     DeviceIndex::set_pair_finish(bool on) { impl_->pair_finish = on; }
 void     DeviceIndex::set_expand_order(uint32_t n) { impl_->expand_order = n; }
@@ -681,9 +686,9 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
     // two queries per wave in the last kernel (k_finish_pair): no contrastive rerank, lowest_costs fits half a wave
     const bool pair_finish = m.pair_finish && !(prm.contrast > 0.f) && prm.cbuf > 0 && prm.cbuf <= (int)kPairMax - 2;
     {
-      hipLaunchKernelGGL(k_caps, dim3((b.nq + 1 + 1023) / 1024), dim3(1024), 0, stream, b, w, c.items.p, item_cap, c.s_max, c.heavy_div, light_max);
-      // one scan, two arrays: queue offsets of the queries phase A walks, segment offsets of the light queries
-      hipLaunchKernelGGL(k_scan_lb<2>, dim3(scan_tiles), dim3(kScanThreads), 0, stream, w.q_cap, w.q_qseg, (size_t)n_scan, n_scan,
+      // capacities, one scan over two arrays (queue offsets of the queries phase A walks, segment offsets of the light queries)
+      // and the work-item list of phase A in one launch
+      hipLaunchKernelGGL(k_caps_scan, dim3(scan_tiles), dim3(kScanThreads), 0, stream, b, w, c.items.p, item_cap, c.s_max, c.heavy_div, light_max,
                          c.scan_state(0), c.scan_ticket(0));
     }
     tick(); tick();
@@ -706,10 +711,8 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
         // the hits phase A really queued size the segments of everything downstream: second scan, q_cap -> q_seg, placed
         // behind the light queries' segments (k_segbase); the work-item list of k_expand_b<false> is laid out by the same
         // scan — second array, two strides on — instead of by atomics
-        hipLaunchKernelGGL(k_caps_b, dim3((b.nq + 1 + 255) / 256), dim3(256), 0, st, b, w, light_max ? 1u : 0u);
-        hipLaunchKernelGGL(k_scan_lb<2>, dim3(scan_tiles), dim3(kScanThreads), 0, st, w.q_cap, w.q_seg, (size_t)2 * n_scan, n_scan,
+        hipLaunchKernelGGL(k_seg_scan, dim3(scan_tiles), dim3(kScanThreads), 0, st, b, w, c.items_b.p, item_cap, light_max ? 1u : 0u, light_max ? 0u : 1u,
                            c.scan_state(1), c.scan_ticket(1));
-        hipLaunchKernelGGL(k_segbase, dim3((b.nq + 1 + 255) / 256), dim3(256), 0, st, b, w, c.items_b.p, item_cap, light_max ? 0u : 1u);
       };
       fork();
       side_tick(kStageExpandH, 0);
@@ -796,19 +799,24 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
         launch_rows(true);
       } else {
         // by pattern length: row + pattern in 32 or 64 registers, longer ones with the row in LDS
+        // the length classes are disjoint lists: the kernel of the (few) patterns of 33..64 tokens runs on the side stream
+        // beside the bulk one instead of behind it (a small pass waited ~0.15 ms for a grid that fills a tenth of the GPU)
+        const bool two = p_max > 32;
+        if (two) fork();
         if (use_idf) {
+          if (two) hipLaunchKernelGGL((k_dp_reg<64, true>), dim3(grid), dim3(kWave), 0, side, m.d, b, w, prm);
           hipLaunchKernelGGL((k_dp_reg<32, true>), dim3(grid), dim3(kWave), 0, stream, m.d, b, w, prm);
-          if (p_max > 32) hipLaunchKernelGGL((k_dp_reg<64, true>), dim3(grid), dim3(kWave), 0, stream, m.d, b, w, prm);
         } else if (prm.ins == prm.del && prm.del == prm.rep && prm.rep >= 0.f) {
           // unit costs: bit-parallel Levenshtein distance, then the float sum the DP would have produced
           // few registers: eight waves per SIMD hide the dependent loads in front of every candidate
+          if (two) hipLaunchKernelGGL((k_dp_reg<64, false, true>), dim3(grid), dim3(kWave), 0, side, m.d, b, w, prm);
           hipLaunchKernelGGL((k_dp_reg<32, false, true>), dim3(grid), dim3(kWave), 0, stream, m.d, b, w, prm);
-          if (p_max > 32) hipLaunchKernelGGL((k_dp_reg<64, false, true>), dim3(grid), dim3(kWave), 0, stream, m.d, b, w, prm);
         } else {
+          if (two) hipLaunchKernelGGL((k_dp_reg<64, false>), dim3(grid), dim3(kWave), 0, side, m.d, b, w, prm);
           hipLaunchKernelGGL((k_dp_reg<32, false>), dim3(grid), dim3(kWave), 0, stream, m.d, b, w, prm);
-          if (p_max > 32) hipLaunchKernelGGL((k_dp_reg<64, false>), dim3(grid), dim3(kWave), 0, stream, m.d, b, w, prm);
         }
         if (p_max > 64) launch_rows(use_idf);
+        if (two) join();
       }
     }
     tick(); tick();
@@ -1119,7 +1127,7 @@ DeviceIndex::Pending* DeviceIndex::match_device_begin(const HostIndex& h, const 
   for (uint64_t q = 0; q < bv.nq; q += m.sub_queries) q_bounds.push_back(q);
   q_bounds.push_back(bv.nq);
   if (q_bounds.size() != sub_tok_bounds.size()) throw std::invalid_argument("sub-batch bounds do not match the batch");
-  const uint32_t turns = bv.nq >= kTurnMinQueries ? m.turns : 0u;
+  const uint32_t turns = bv.nq >= kTurnMinQueries ? m.device_turns : 0u;
   std::unique_lock<std::mutex> chain_lk(m.chain_mu, std::defer_lock);
   if (turns == 1 || turns == 2) {
     chain_lk.lock();
@@ -1185,7 +1193,7 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm, const Devi
   }
   // No statistics: the passes are enqueued back to back and large calls from several host threads are chained on the GPU like
   // the host-buffer path chains them (Impl::turns): each call's first kernel waits for the predecessor's chain event.
-  const uint32_t turns = bv.nq >= kTurnMinQueries ? m.turns : 0u;
+  const uint32_t turns = bv.nq >= kTurnMinQueries ? m.device_turns : 0u;
   std::unique_lock<std::mutex> chain_lk(m.chain_mu, std::defer_lock);
   if (turns == 1 || turns == 2) {
     chain_lk.lock();

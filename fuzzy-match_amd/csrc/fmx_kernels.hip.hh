@@ -326,23 +326,16 @@ constexpr uint32_t kLbMaxTiles = 1024;  // tiles per scan: sub-batches of up to 
 constexpr int kLbMaxArrays = 3;
 constexpr unsigned long long kLbValMask = (1ull << 62) - 1ull;
 
+// The tile's part of the look-back scan: given every thread's sums of its kScanItems consecutive elements (NARR arrays),
+// returns in ex[] the exclusive prefix of the WHOLE array in front of the thread's first element.  Whole block, once per kernel.
 template <int NARR>
-__global__ void __launch_bounds__(kScanThreads) k_scan_lb(const unsigned long long* in, unsigned long long* out, size_t stride,
-                                                         uint32_t n, unsigned long long* state, uint32_t* ticket) {
-  __shared__ uint32_t s_tile;
+__device__ __forceinline__ void scan_tile_lb(uint32_t tile, const unsigned long long (&sum)[NARR], unsigned long long (&ex)[NARR],
+                                             unsigned long long* state) {
   __shared__ unsigned long long s_total[NARR], s_prefix[NARR];
-  if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
-  __syncthreads();
-  const uint32_t tile = s_tile;
-  const uint32_t base = tile * kScanTile + threadIdx.x * kScanItems;
-  unsigned long long v[NARR][kScanItems], ex[NARR];
 #pragma unroll
   for (int a = 0; a < NARR; a++) {
-    unsigned long long sum = 0;
-#pragma unroll
-    for (int k = 0; k < kScanItems; k++) { v[a][k] = base + k < n ? in[a * stride + base + k] : 0ull; sum += v[a][k]; }
     unsigned long long total;
-    ex[a] = block_excl_scan(sum, &total);
+    ex[a] = block_excl_scan(sum[a], &total);
     if (threadIdx.x == 0) s_total[a] = total;
   }
   __syncthreads();
@@ -380,8 +373,32 @@ __global__ void __launch_bounds__(kScanThreads) k_scan_lb(const unsigned long lo
   }
   __syncthreads();
 #pragma unroll
+  for (int a = 0; a < NARR; a++) ex[a] += s_prefix[a];
+}
+
+__device__ __forceinline__ uint32_t scan_ticket_take(uint32_t* ticket) {
+  __shared__ uint32_t s_tile;
+  if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+  __syncthreads();
+  return s_tile;
+}
+
+template <int NARR>
+__global__ void __launch_bounds__(kScanThreads) k_scan_lb(const unsigned long long* in, unsigned long long* out, size_t stride,
+                                                         uint32_t n, unsigned long long* state, uint32_t* ticket) {
+  const uint32_t tile = scan_ticket_take(ticket);
+  const uint32_t base = tile * kScanTile + threadIdx.x * kScanItems;
+  unsigned long long v[NARR][kScanItems], sum[NARR], ex[NARR];
+#pragma unroll
   for (int a = 0; a < NARR; a++) {
-    unsigned long long e = s_prefix[a] + ex[a];
+    sum[a] = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; k++) { v[a][k] = base + k < n ? in[a * stride + base + k] : 0ull; sum[a] += v[a][k]; }
+  }
+  scan_tile_lb<NARR>(tile, sum, ex, state);
+#pragma unroll
+  for (int a = 0; a < NARR; a++) {
+    unsigned long long e = ex[a];
 #pragma unroll
     for (int k = 0; k < kScanItems; k++) { if (base + k < n) out[a * stride + base + k] = e; e += v[a][k]; }
   }
@@ -456,6 +473,76 @@ __global__ void __launch_bounds__(1024) k_caps(DevBatch b, DevWork w, WorkItem* 
     }
   }
   append_items(&w.counters[5], items, item_cap, q, light_max != 0 ? 0u : 1u, n_items);
+}
+
+// append_items for a thread that holds kScanItems consecutive queries (q0 .. q0 + kScanItems - 1) with ni[k] work items each
+__device__ __forceinline__ void append_items_multi(unsigned long long* counter, WorkItem* items, uint32_t item_cap, uint32_t q0,
+                                                   const uint32_t (&ni)[kScanItems], uint32_t first_chunk) {
+  __shared__ uint32_t s_wave[16];
+  __shared__ unsigned long long s_base;
+  const uint32_t lane = lane_id(), wv = threadIdx.x >> 6, n_wv = blockDim.x >> 6;
+  uint32_t mine = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; k++) mine += ni[k];
+  const uint32_t incl = wave_incl_scan(mine);
+  if (lane == 63) s_wave[wv] = incl;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t tot = 0;
+    for (uint32_t k = 0; k < n_wv; k++) { const uint32_t c = s_wave[k]; s_wave[k] = tot; tot += c; }
+    s_base = tot ? atomicAdd(counter, (unsigned long long)tot) : 0ull;
+  }
+  __syncthreads();
+  unsigned long long at = s_base + s_wave[wv] + (incl - mine);
+#pragma unroll
+  for (int k = 0; k < kScanItems; k++)
+    for (uint32_t j = 0; j < ni[k]; j++, at++)
+      if (at < item_cap) { WorkItem it; it.q = q0 + (uint32_t)k; it.chunk = first_chunk + j; items[at] = it; }
+}
+
+// k_caps and the scan behind it in ONE launch (a pass is a chain of dependent launches, and beside another call's large
+// kernels every one of them waits for wave slots): a thread computes the capacities of its kScanItems queries, the tile
+// scans them (q_cap -> q_qseg, q_capl -> q_segl, look-back over the tiles) and appends the work items.
+__global__ void __launch_bounds__(kScanThreads) k_caps_scan(DevBatch b, DevWork w, WorkItem* items, uint32_t item_cap, uint32_t s_max,
+                                                           uint32_t heavy_div, uint32_t light_max, unsigned long long* state,
+                                                           uint32_t* ticket) {
+  const uint32_t tile = scan_ticket_take(ticket);
+  const uint32_t base = tile * kScanTile + threadIdx.x * kScanItems;
+  unsigned long long v[2][kScanItems], sum[2] = {0ull, 0ull}, ex[2];
+  uint32_t ni[kScanItems];
+#pragma unroll
+  for (int k = 0; k < kScanItems; k++) {
+    const uint32_t q = base + k;
+    v[0][k] = 0; v[1][k] = 0; ni[k] = 0;
+    if (q == b.nq) w.q_capl[q] = 0;
+    if (q < b.nq) {
+      const unsigned long long all_hits = w.q_hits[q];  // summed by k_probe
+      const unsigned long long hits = w.q_hits_a[q];    // the hits of the short ranges
+      bool light = false;
+      if (light_max != 0 && hits != 0 && hits == all_hits && hits <= light_max)
+        light = b.q_off[b.q_begin + q + 1] - b.q_off[b.q_begin + q] <= (uint32_t)kWave;
+      // queue capacity: see k_caps
+      const unsigned long long want = light ? 0ull : hits + (all_hits - hits + heavy_div - 1) / heavy_div;
+      v[0][k] = want < s_max ? want : (unsigned long long)s_max;
+      v[1][k] = light ? hits : 0ull;
+      w.q_capl[q] = v[1][k];
+      w.q_kept[q] = 0;
+      if (!light && hits != 0) {
+        const uint32_t n_chunks = (uint32_t)((hits + kExpandChunk - 1) / kExpandChunk);
+        ni[k] = light_max != 0 ? n_chunks : n_chunks - 1;
+      }
+    }
+    sum[0] += v[0][k]; sum[1] += v[1][k];
+  }
+  scan_tile_lb<2>(tile, sum, ex, state);
+  unsigned long long e0 = ex[0], e1 = ex[1];
+#pragma unroll
+  for (int k = 0; k < kScanItems; k++) {
+    const uint32_t q = base + k;
+    if (q <= b.nq) { w.q_qseg[q] = e0; w.q_segl[q] = e1; }
+    e0 += v[0][k]; e1 += v[1][k];
+  }
+  append_items_multi(&w.counters[5], items, item_cap, base, ni, light_max != 0 ? 0u : 1u);
 }
 
 // PatternCoverage::count_covered_words (src/pattern_coverage.cc:15-28) with the pattern broadcast
@@ -1250,6 +1337,57 @@ __global__ void __launch_bounds__(256) k_segbase(DevBatch b, DevWork w, WorkItem
   w.q_seg[q] = light ? l0 : totl + w.q_seg[q];
   const unsigned long long i0 = item_off[q], i1 = item_off[q + 1];
   for (unsigned long long k = i0; k < i1 && k < item_cap; k++) { WorkItem it; it.q = q; it.chunk = first_chunk + (uint32_t)(k - i0); items[k] = it; }
+}
+
+// k_caps_b, the second scan and k_segbase in ONE launch (see k_caps_scan): the hits phase A queued -> segment sizes and the
+// work items of k_expand_b<false> per query, scanned over the tiles, then segment base / capacity and the work-item list.
+__global__ void __launch_bounds__(kScanThreads) k_seg_scan(DevBatch b, DevWork w, WorkItem* items, uint32_t item_cap, uint32_t list0,
+                                                          uint32_t first_chunk, unsigned long long* state, uint32_t* ticket) {
+  const uint32_t tile = scan_ticket_take(ticket);
+  const uint32_t base = tile * kScanTile + threadIdx.x * kScanItems;
+  unsigned long long v[2][kScanItems], capl[kScanItems], sum[2] = {0ull, 0ull}, ex[2];
+#pragma unroll
+  for (int k = 0; k < kScanItems; k++) {
+    const uint32_t q = base + k;
+    v[0][k] = 0; v[1][k] = 0; capl[k] = 0;
+    if (q < b.nq) {
+      capl[k] = w.q_capl[q];
+      if (capl[k] != 0) {
+        // light query: its segment lies in the light area (q_segl), k_expand_b<true> walks it
+      } else if (w.q_qseg[q + 1] > w.qb_cap) {
+        if (q + 1 == b.nq) atomicMax(&w.counters[21], w.q_qseg[b.nq]);  // host re-runs the pass with a larger queue space
+      } else {
+        const uint32_t cap = (uint32_t)(w.q_qseg[q + 1] - w.q_qseg[q]);
+        const uint32_t n = w.q_pb[q];
+        if (n > cap) atomicMax(&w.counters[4], (unsigned long long)n);  // queue overflow: retry with a larger capacity
+        else {
+          v[0][k] = n;
+          if (n != 0) {
+            const uint32_t n_chunks = (n + kPhaseBChunk - 1) / kPhaseBChunk;
+            v[1][k] = list0 ? n_chunks : n_chunks - 1;
+          }
+        }
+      }
+    }
+    sum[0] += v[0][k]; sum[1] += v[1][k];
+  }
+  scan_tile_lb<2>(tile, sum, ex, state);
+  const unsigned long long totl = w.q_segl[b.nq];  // the light queries' segments come first
+  unsigned long long e0 = ex[0], e1 = ex[1];
+#pragma unroll
+  for (int k = 0; k < kScanItems; k++) {
+    const uint32_t q = base + k;
+    if (q == b.nq) {
+      w.q_seg[q] = e0 + totl; w.counters[12] = e1;
+      w.counters[24] = e0 + totl; w.counters[25] = w.q_qseg[q];
+    } else if (q < b.nq) {
+      const bool light = capl[k] != 0;
+      w.q_scap[q] = light ? (uint32_t)capl[k] : (uint32_t)v[0][k];
+      w.q_seg[q] = light ? w.q_segl[q] : totl + e0;
+      for (unsigned long long i = e1; i < e1 + v[1][k] && i < item_cap; i++) { WorkItem it; it.q = q; it.chunk = first_chunk + (uint32_t)(i - e1); items[i] = it; }
+    }
+    e0 += v[0][k]; e1 += v[1][k];
+  }
 }
 
 // ---------------------------------------------------------------------------------------------

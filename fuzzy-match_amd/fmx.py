@@ -6,6 +6,8 @@ or no gfx950 device is present, the calls raise.
 """
 import ctypes as C
 import os
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before the process's first HIP call (see fmx_capi.cc, fmx_runtime_defaults)
 import subprocess
 
 import numpy as np
