@@ -273,6 +273,8 @@ int fmx_index_device_array(const fmx_index* ix, int replica, int which, void* ds
     case FMX_A_GRAM: k = 3; break;
     case FMX_A_GRAM5: k = 4; break;
     case FMX_A_SUF_B: k = 5; break;
+    case FMX_A_SENT_POS: k = 6; break;  // the device layout of the sentence buffer (DeviceIndex::upload): positions ...
+    case FMX_A_BUFFER: k = 7; break;    // ... and words
     default: return fail(FMX_E_INVALID, "not a device-built array");
   }
   return guarded([&]() { *count = ix->devs[replica]->download(k, dst, capacity_bytes); return (int)FMX_OK; });

@@ -14,6 +14,18 @@ namespace fmx {
 
 // word signature per sentence (fmx_core.hh: sig_bit, sig_half): sent_sig2[2 s + h] = half h of the 112-bucket signature;
 // the 56-bit signature of suf_sig is the OR of the two
+// The device copy of the sentence buffer keeps every sentence [len, tokens, 0] inside one 128-byte line when it fits in one
+// (DeviceIndex::upload lays out the positions): a candidate's sentence then costs one line of HBM traffic instead of ~1.8.
+// One thread per sentence copies its words of `src` (the token buffer, or a per-slot twin: real-token / penalty-token ids).
+__global__ void __launch_bounds__(256) k_relayout(const uint32_t* __restrict__ len_buf, const uint32_t* __restrict__ len_pos,
+                                                  const uint32_t* __restrict__ src, const uint32_t* __restrict__ old_pos,
+                                                  const uint32_t* __restrict__ new_pos, uint32_t n_sent, uint32_t* __restrict__ dst) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_sent) return;
+  const uint32_t n = len_buf[len_pos[s]] + 2u, a = old_pos[s], b = new_pos[s];
+  for (uint32_t k = 0; k < n; k++) dst[b + k] = src[a + k];
+}
+
 __global__ void __launch_bounds__(256) k_dv_sent_sig(const uint32_t* __restrict__ buf, const uint32_t* __restrict__ sent_pos,
                                                      uint32_t n_sent, unsigned long long* __restrict__ sent_sig2) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;

@@ -242,6 +242,7 @@ struct Ctx {
 
 struct DeviceIndex::Impl {
   int      device = -1;
+  uint64_t n_tok_words = 0;  // words of m.d.tok (device layout of the sentence buffer, without the eight spare words)
   DevIndex d{};
   uint64_t bytes = 0;
   std::atomic<uint64_t> itok_version{~0ull};
@@ -490,6 +491,8 @@ uint64_t DeviceIndex::download(int which, void* dst, uint64_t capacity_bytes) co
     case 3: src = m.d.gram.g3; count = m.d.gram.g3 ? (uint64_t)m.d.gram.mask3 + 1 : 0; elem = sizeof(GramEntry); break;
     case 4: src = m.d.gram.g5; count = m.d.gram.g5 ? (uint64_t)m.d.gram.mask5 + 1 : 0; elem = sizeof(GramEntry); break;
     case 5: src = m.d.suf_b; count = m.d.n_suf; elem = sizeof(SufRecB); break;
+    case 6: src = m.d.sent_pos; count = m.d.n_sent; elem = 4; break;   // positions in the device layout of the sentence buffer
+    case 7: src = m.d.tok; count = m.n_tok_words; elem = 4; break;
     default: throw std::invalid_argument("unknown device array");
   }
   if (dst && count) {
@@ -521,6 +524,37 @@ void DeviceIndex::upload(const HostIndex& h, int device, SortResident* res) {
     m.d.tok = d_tok;
     m.d.sent_pos = dev_upload(h.sent_pos);
   }
+  m.n_tok_words = h.buf.size();
+  // Device layout of the sentence buffer: a sentence [len, tokens, 0] that fits one 128-byte line does not straddle two (the
+  // expand and edit-distance kernels read a candidate's sentence at random: one line instead of ~1.8).  Every derived array
+  // holds offsets into THIS layout (they are all built on the device from m.d.tok / m.d.sent_pos); the host arrays and the
+  // .fmi keep the reference's packed _sentence_buffer.  d_old_pos = the packed positions (for the per-slot twins below).
+  uint32_t* d_old_pos = nullptr;
+  static const bool pad_tok = [] { const char* e = getenv("FMX_PAD_TOK"); return e ? atoi(e) != 0 : true; }();
+  if (pad_tok && !h.sent_pos.empty()) {
+    std::vector<uint32_t> pos(h.sent_pos.size());
+    uint64_t at = 0;
+    for (size_t s2 = 0; s2 < h.sent_pos.size(); s2++) {
+      const uint64_t size = (uint64_t)h.buf[h.sent_pos[s2]] + 2;
+      if ((at & 31) != 0 && (at & 31) + size > 32) at = (at + 31) & ~31ull;
+      pos[s2] = (uint32_t)at;
+      at += size;
+      if (at >= 0xfffffff0ull) break;
+    }
+    if (at < 0xfffffff0ull) {
+      uint32_t* d_new_pos = dev_upload(pos);
+      uint32_t* d_new = dev_alloc<uint32_t>(at + 8);
+      HIP_TRY(hipMemset(d_new, 0, (at + 8) * sizeof(uint32_t)));
+      const uint32_t ns = (uint32_t)h.sent_pos.size();
+      hipLaunchKernelGGL(k_relayout, dim3((ns + 255) / 256), dim3(256), 0, 0, m.d.tok, m.d.sent_pos, m.d.tok, m.d.sent_pos, (const uint32_t*)d_new_pos, ns, d_new);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipDeviceSynchronize());
+      hipFree((void*)m.d.tok);
+      d_old_pos = const_cast<uint32_t*>(m.d.sent_pos);
+      m.d.tok = d_new; m.d.sent_pos = d_new_pos;
+      m.n_tok_words = at;
+    }
+  }
   m.d.qva = dev_upload(h.qva);
   m.d.idf = dev_upload(h.idf);
   m.d.n_qva = (uint32_t)h.qva.size();
@@ -529,7 +563,7 @@ void DeviceIndex::upload(const HostIndex& h, int device, SortResident* res) {
   uint32_t mx = 0;
   for (uint32_t sp : h.sent_pos) mx = std::max(mx, h.buf[sp]);
   m.d.max_slen = mx;
-  m.bytes = h.buf.size() * 4 + h.sent_pos.size() * 4 + h.qva.size() * 4 + h.idf.size() * 4;
+  m.bytes = m.n_tok_words * 4 + h.sent_pos.size() * 4 + h.qva.size() * 4 + h.idf.size() * 4;
   unsigned long long* d_ssig = derive_on_device(m, h, res);
   // bit planes of the signatures and thermometer planes of the stored lengths, built on the device from suf_sig
   // (DESIGN.md §3): plane-major, one 64-bit word per (row, block of 64 consecutive suffixes)
@@ -552,8 +586,21 @@ void DeviceIndex::upload(const HostIndex& h, int device, SortResident* res) {
   if (h.real_differs) {
     m.d.real = dev_upload(h.real_ids);
     m.d.itok = dev_upload(h.itok_ids);
-    m.bytes += h.real_ids.size() * 4 + h.itok_ids.size() * 4;
+    if (d_old_pos) {  // the per-slot twins of the token buffer follow it into the device layout
+      const uint32_t ns = (uint32_t)h.sent_pos.size();
+      for (const uint32_t** twin : {&m.d.real, &m.d.itok}) {
+        uint32_t* d_new = dev_alloc<uint32_t>(m.n_tok_words + 8);
+        HIP_TRY(hipMemset(d_new, 0, (m.n_tok_words + 8) * sizeof(uint32_t)));
+        hipLaunchKernelGGL(k_relayout, dim3((ns + 255) / 256), dim3(256), 0, 0, m.d.tok, m.d.sent_pos, *twin, (const uint32_t*)d_old_pos, m.d.sent_pos, ns, d_new);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
+        hipFree((void*)*twin);
+        *twin = d_new;
+      }
+    }
+    m.bytes += 2 * m.n_tok_words * 4;
   }
+  if (d_old_pos) hipFree(d_old_pos);
   refresh_itok_table(m, h);
   // the LDS-row kernels may ask for up to kDynLdsMax of dynamic LDS: raise the limit once (not per call: the
   // attribute is process-wide and calls run concurrently)

@@ -18,9 +18,38 @@ def _entries(tab):
     return np.sort(live, order=["lo", "cnt", "w1", "w2"])
 
 
+def _to_device_layout(ix, off):
+    """Token offsets of the host's packed _sentence_buffer -> the device layout (DeviceIndex::upload keeps a sentence that fits
+    one 128-byte line inside one line): same sentence, same position in it."""
+    host_pos, dev_pos = ix.array("sent_pos").astype(np.int64), ix.device_array("sent_pos").astype(np.int64)
+    sid = np.searchsorted(host_pos, off.astype(np.int64), side="right") - 1
+    return (dev_pos[sid] + (off.astype(np.int64) - host_pos[sid])).astype(np.uint32)
+
+
+def _check_device_layout(ix, label):
+    """The device copy of the sentence buffer: every sentence's words unchanged, positions ascending, and no sentence of at
+    most 32 words crossing a 128-byte line."""
+    hb, hp = ix.array("buffer"), ix.array("sent_pos").astype(np.int64)
+    db, dp = ix.device_array("buffer"), ix.device_array("sent_pos").astype(np.int64)
+    assert len(hp) == len(dp), label
+    size = hb[hp].astype(np.int64) + 2
+    assert np.all(dp[1:] >= dp[:-1] + size[:-1]) and dp[-1] + size[-1] <= len(db), label
+    fits = size <= 32
+    assert np.all((dp[fits] // 32) == ((dp[fits] + size[fits] - 1) // 32)), label
+    idx_h = np.repeat(hp, size) + (np.arange(size.sum()) - np.repeat(np.cumsum(size) - size, size))
+    idx_d = np.repeat(dp, size) + (np.arange(size.sum()) - np.repeat(np.cumsum(size) - size, size))
+    assert np.array_equal(hb[idx_h], db[idx_d]), label
+
+
 def _compare(ix, label):
+    _check_device_layout(ix, label)
     for name in ["suf_rec", "suf_sig", "suf_key", "suf_b"]:
-        host, dev = ix.array(name), ix.device_array(name)
+        host, dev = ix.array(name).copy(), ix.device_array(name)
+        # the host twins hold offsets into the packed buffer, the device arrays into the device layout
+        if name == "suf_rec":
+            host = (host & np.uint64(0xffffffff00000000)) | _to_device_layout(ix, (host & np.uint64(0xffffffff)).astype(np.uint32)).astype(np.uint64)
+        if name == "suf_b":
+            host["off"] = _to_device_layout(ix, host["off"])
         assert host.shape == dev.shape and np.array_equal(host.view(np.uint8), dev.view(np.uint8)), (label, name)
     for name in ["gram", "gram5"]:
         host, dev = ix.array(name), ix.device_array(name)
