@@ -728,7 +728,7 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
         hipLaunchKernelGGL(k_probe<false>, dim3((b.nt + 63) / 64), dim3(64), 0, stream, m.d, b, w, heavy_min, c.items_h.p, item_h_cap);
     }
     tick(); tick();
-    // light queries (k_caps): at most light_max hits, all in short ranges, pattern of at most one wave
+    // light queries (k_caps_scan): at most light_max hits, all in short ranges, pattern of at most one wave
     const uint32_t light_max = b.nq ? std::min<uint32_t>(m.light_max, kPhaseBChunk) : 0u;
     // two queries per wave in the last kernel (k_finish_pair): no contrastive rerank, lowest_costs fits half a wave
     const bool pair_finish = m.pair_finish && !(prm.contrast > 0.f) && prm.cbuf > 0 && prm.cbuf <= (int)kPairMax - 2;
@@ -756,7 +756,7 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
       auto side_tick = [&](int stage, int end) { if (timing) HIP_TRY(hipEventRecord(c.ev[2 * stage + end], side)); };
       auto second_scan = [&](hipStream_t st) {
         // the hits phase A really queued size the segments of everything downstream: second scan, q_cap -> q_seg, placed
-        // behind the light queries' segments (k_segbase); the work-item list of k_expand_b<false> is laid out by the same
+        // behind the light queries' segments; the work-item list of k_expand_b<false> is laid out by the same
         // scan — second array, two strides on — instead of by atomics
         hipLaunchKernelGGL(k_seg_scan, dim3(scan_tiles), dim3(kScanThreads), 0, st, b, w, c.items_b.p, item_cap, light_max ? 1u : 0u, light_max ? 0u : 1u,
                            c.scan_state(1), c.scan_ticket(1));

@@ -4,7 +4,7 @@
 //   k_setup, k_tidf, k_cmin, k_phist / k_prank   A   guards, min_subseq_length, token -> query map, idf per position, the
 //                 threshold table of the length / coverage filters, pattern-length ranks
 //   k_probe       C,D one lane per (query, start): range of the seed n-gram in the suffix array (n-gram hash tables + keys)
-//   k_caps, k_scan_lb, k_caps_b, k_segbase   work-item lists and segment offsets (single-pass look-back scans)
+//   k_caps_scan, k_seg_scan, k_scan_lb   work-item lists and segment offsets (single-pass look-back scans, capacities fused in)
 //   k_expand_b<true>   D,E,F,G light queries (<= 256 hits, short ranges): ranges walked, dominance + length filter, match
 //                 length, exact coverage, max per sentence and candidate order, one wave per query
 //   k_expand_h / k_expand_a + k_expand_b<false>   the other queries: 64 hits per lane through the signature bit planes /
@@ -77,13 +77,13 @@ struct DevWork {
   uint32_t* t_cnt;      // nt   range size
   unsigned long long* q_hits;  // nq   hits per query (every range of the query)
   unsigned long long* q_hits_a;  // nq  hits of the ranges k_expand_a walks (sum of t_cnt: the long ranges go to k_expand_h)
-  unsigned long long* q_cap;   // nq+1 scan input: first the queue capacity per query (k_caps), then its queued hits (k_caps_b)
+  unsigned long long* q_cap;   // nq+1 spare scan arrays; q_cap + nq + 1 = q_capl
   unsigned long long* q_qseg;  // nq+1 queue offsets into qb: exclusive scan of the capacities (an upper bound of what phase A queues)
   unsigned long long* q_seg;   // nq+1 segment offsets into seg / c_qi / keys ...: light queries first (q_segl), then the exclusive scan of the
-                               //      hits phase A really queued for the others (k_segbase merges the two)
+                               //      hits phase A really queued for the others (k_seg_scan merges the two)
   unsigned long long* q_capl;  // nq+1 scan input beside q_cap: segment size of a "light" query (its hits; 0 = not light)
   unsigned long long* q_segl;  // nq+1 its exclusive scan: segment offsets of the light queries (known before phase A runs)
-  uint32_t* q_scap;     // nq   segment capacity per query (k_segbase)
+  uint32_t* q_scap;     // nq   segment capacity per query (k_seg_scan)
   uint32_t* q_kept;     // nq
   uint32_t* q_cand;     // nq
   uint32_t* q_acc;      // nq
@@ -405,8 +405,8 @@ __global__ void __launch_bounds__(kScanThreads) k_scan_lb(const unsigned long lo
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_caps — per query: segment capacity min(hits, s_max) (input of the scan) and, for queries with
-// more than kExpandChunk hits, extra work items so that several waves share the walk.
+// Work items of the expand stage: queries with more than kExpandChunk hits get several, so that several waves share
+// the walk (k_caps_scan below lays them out).
 // ---------------------------------------------------------------------------------------------
 #ifndef FMX_EXPAND_CHUNK
 #define FMX_EXPAND_CHUNK 16384
@@ -422,60 +422,9 @@ struct WorkItem {
   uint32_t chunk;
 };
 
-// Appends n_items work items (q, first_chunk .. first_chunk + n_items - 1) of every thread of the block to a list with ONE
-// global atomic per block (same-address atomics retire one at a time: a million per-query atomics on one counter, or even
-// one per wave, would dominate the kernel).  Call with the whole block, blockDim.x a multiple of 64 and at most 1024.
-__device__ __forceinline__ void append_items(unsigned long long* counter, WorkItem* items, uint32_t item_cap, uint32_t q,
-                                             uint32_t first_chunk, uint32_t n_items) {
-  __shared__ uint32_t s_wave[16];
-  __shared__ unsigned long long s_base;
-  const uint32_t lane = lane_id(), wv = threadIdx.x >> 6, n_wv = blockDim.x >> 6;
-  const uint32_t incl = wave_incl_scan(n_items);
-  if (lane == 63) s_wave[wv] = incl;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t tot = 0;
-    for (uint32_t k = 0; k < n_wv; k++) { const uint32_t c = s_wave[k]; s_wave[k] = tot; tot += c; }
-    s_base = tot ? atomicAdd(counter, (unsigned long long)tot) : 0ull;
-  }
-  __syncthreads();
-  const unsigned long long base = s_base + s_wave[wv] + (incl - n_items);
-  for (uint32_t k = 0; k < n_items; k++)
-    if (base + k < item_cap) { WorkItem it; it.q = q; it.chunk = first_chunk + k; items[base + k] = it; }
-}
-
-// light_max != 0: queries whose hits all lie in short ranges, at most light_max of them, and whose pattern fits one wave
-// are "light" — k_expand_b<true> walks their ranges itself (no phase A, no queue: two thirds of the hits of a short
-// range pass the signature test anyway, so phase A was a per-query instruction stream for nothing) and their segments
-// (q_capl -> q_segl) are sized by their hits.  Everything else goes through k_expand_a / k_expand_h as a work-item list
-// (chunk 0 included).  light_max == 0: every query is walked by block q of k_expand_a, the list holds chunks >= 1.
-__global__ void __launch_bounds__(1024) k_caps(DevBatch b, DevWork w, WorkItem* items, uint32_t item_cap, uint32_t s_max,
-                                              uint32_t heavy_div, uint32_t light_max) {
-  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t n_items = 0;
-  if (q == b.nq) { w.q_cap[q] = 0; w.q_capl[q] = 0; }
-  if (q < b.nq) {
-    const unsigned long long all_hits = w.q_hits[q];  // summed by k_probe
-    const unsigned long long hits = w.q_hits_a[q];    // the hits of the short ranges
-    bool light = false;
-    if (light_max != 0 && hits != 0 && hits == all_hits && hits <= light_max)
-      light = b.q_off[b.q_begin + q + 1] - b.q_off[b.q_begin + q] <= (uint32_t)kWave;
-    // Queue capacity of the query: every hit of the short ranges may survive phase A (near-duplicates: most
-    // do), of the long ranges only a few per cent do — a heavy_div-th of them is reserved, and a query that needs more
-    // is reported by k_caps_b (the host re-runs the pass with a smaller divisor, down to 1 = every hit).
-    const unsigned long long want = light ? 0ull : hits + (all_hits - hits + heavy_div - 1) / heavy_div;
-    w.q_cap[q] = want < s_max ? want : (unsigned long long)s_max;
-    w.q_capl[q] = light ? hits : 0ull;
-    w.q_kept[q] = 0;
-    if (!light && hits != 0) {
-      const uint32_t n_chunks = (uint32_t)((hits + kExpandChunk - 1) / kExpandChunk);
-      n_items = light_max != 0 ? n_chunks : n_chunks - 1;
-    }
-  }
-  append_items(&w.counters[5], items, item_cap, q, light_max != 0 ? 0u : 1u, n_items);
-}
-
-// append_items for a thread that holds kScanItems consecutive queries (q0 .. q0 + kScanItems - 1) with ni[k] work items each
+// Appends work items to a list with ONE global atomic per block (same-address atomics retire one at a time: a million
+// per-query atomics on one counter, or even one per wave, would dominate the kernel).  Whole block, blockDim.x a multiple of
+// 64 and at most 1024; a thread holds kScanItems consecutive queries (q0 .. q0 + kScanItems - 1) with ni[k] work items each.
 __device__ __forceinline__ void append_items_multi(unsigned long long* counter, WorkItem* items, uint32_t item_cap, uint32_t q0,
                                                    const uint32_t (&ni)[kScanItems], uint32_t first_chunk) {
   __shared__ uint32_t s_wave[16];
@@ -500,9 +449,15 @@ __device__ __forceinline__ void append_items_multi(unsigned long long* counter, 
       if (at < item_cap) { WorkItem it; it.q = q0 + (uint32_t)k; it.chunk = first_chunk + j; items[at] = it; }
 }
 
-// k_caps and the scan behind it in ONE launch (a pass is a chain of dependent launches, and beside another call's large
-// kernels every one of them waits for wave slots): a thread computes the capacities of its kScanItems queries, the tile
-// scans them (q_cap -> q_qseg, q_capl -> q_segl, look-back over the tiles) and appends the work items.
+// k_caps_scan — per query: queue capacity (input of the scan), "light" or not, and the work items of phase A; the scan behind
+// it in the SAME launch (a pass is a chain of dependent launches, and beside another call's large kernels every one of them
+// waits for wave slots): a thread computes the capacities of its kScanItems queries, the tile scans them (capacity -> q_qseg,
+// light segment size -> q_segl, look-back over the tiles) and appends the work items.
+// light_max != 0: queries whose hits all lie in short ranges, at most light_max of them, and whose pattern fits one wave
+// are "light" — k_expand_b<true> walks their ranges itself (no phase A, no queue: two thirds of the hits of a short
+// range pass the signature test anyway, so phase A was a per-query instruction stream for nothing) and their segments
+// (q_capl -> q_segl) are sized by their hits.  Everything else goes through k_expand_a / k_expand_h as a work-item list
+// (chunk 0 included).  light_max == 0: every query is walked by block q of k_expand_a, the list holds chunks >= 1.
 __global__ void __launch_bounds__(kScanThreads) k_caps_scan(DevBatch b, DevWork w, WorkItem* items, uint32_t item_cap, uint32_t s_max,
                                                            uint32_t heavy_div, uint32_t light_max, unsigned long long* state,
                                                            uint32_t* ticket) {
@@ -521,7 +476,9 @@ __global__ void __launch_bounds__(kScanThreads) k_caps_scan(DevBatch b, DevWork 
       bool light = false;
       if (light_max != 0 && hits != 0 && hits == all_hits && hits <= light_max)
         light = b.q_off[b.q_begin + q + 1] - b.q_off[b.q_begin + q] <= (uint32_t)kWave;
-      // queue capacity: see k_caps
+      // Queue capacity of the query: every hit of the short ranges may survive phase A (near-duplicates: most
+      // do), of the long ranges only a few per cent do — a heavy_div-th of them is reserved, and a query that needs more
+      // is reported by k_seg_scan (the host re-runs the pass with a smaller divisor, down to 1 = every hit).
       const unsigned long long want = light ? 0ull : hits + (all_hits - hits + heavy_div - 1) / heavy_div;
       v[0][k] = want < s_max ? want : (unsigned long long)s_max;
       v[1][k] = light ? hits : 0ull;
@@ -1090,7 +1047,7 @@ __global__ void __launch_bounds__(kWave, FMX_HEAVY_WAVES) k_expand_h(DevIndex ix
     const uint32_t q = uni(w.t_q[t]);
     const unsigned long long seg0 = uni(w.q_qseg[q]);
     const uint32_t cap = (uint32_t)(uni(w.q_qseg[q + 1]) - seg0);
-    if (seg0 + cap > w.qb_cap) continue;  // queue space too small: reported by k_caps_b, the host re-runs the pass
+    if (seg0 + cap > w.qb_cap) continue;  // queue space too small: reported by k_seg_scan, the host re-runs the pass
     const uint32_t o0 = uni(b.q_off[b.q_begin + q]);
     const uint32_t p = uni(b.q_off[b.q_begin + q + 1]) - o0;
     const uint32_t* pat = b.q_tok + o0;
@@ -1282,65 +1239,17 @@ __global__ void __launch_bounds__(kWave, FMX_HEAVY_WAVES) k_expand_h(DevIndex ix
   }
 }
 
-// After phase A: the hits each query really queued become its segment size (scan input; the segments of everything
-// downstream are sized by these, not by the loose bound the queues were sized by), and queries with more than
-// kPhaseBChunk queued hits get extra work items of k_expand_b.
-__global__ void __launch_bounds__(256) k_caps_b(DevBatch b, DevWork w, uint32_t list0) {
-  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q > b.nq) return;
-  unsigned long long* n_items = w.q_cap + 2 * (size_t)(b.nq + 1);  // scanned with q_cap: work items of k_expand_b<false> per query
-  unsigned long long segsz = 0, ni = 0;
-  if (q < b.nq) {
-    if (w.q_capl[q] != 0) {
-      // light query: its segment lies in the light area (q_segl), k_expand_b<true> walks it
-    } else if (w.q_qseg[q + 1] > w.qb_cap) {
-      if (q + 1 == b.nq) atomicMax(&w.counters[21], w.q_qseg[b.nq]);  // host re-runs the pass with a larger queue space
-    } else {
-      const uint32_t cap = (uint32_t)(w.q_qseg[q + 1] - w.q_qseg[q]);
-      const uint32_t n = w.q_pb[q];
-      if (n > cap) atomicMax(&w.counters[4], (unsigned long long)n);  // queue overflow: retry with a larger capacity
-      else {
-        segsz = n;
-        if (n != 0) {
-          const uint32_t n_chunks = (n + kPhaseBChunk - 1) / kPhaseBChunk;
-          ni = list0 ? n_chunks : n_chunks - 1;
-        }
-      }
-    }
-  }
-  w.q_cap[q] = segsz;
-  n_items[q] = ni;
-}
-
 // a few microseconds of nothing: keeps the kernel behind it from reaching the GPU before one launched on another stream
 __global__ void k_lag(const unsigned long long* p) {
   if (threadIdx.x == 0 && p[0] == ~0ull) __builtin_amdgcn_s_sleep(1);
 }
 
-// Segment base and capacity per query once both scans are known: the light queries' segments come first (q_segl, sized
-// by their hits before phase A ran), the others follow in the order of the second scan (sized by the hits phase A
-// really queued).  In place on q_seg (each thread owns its element); q_seg[nq] = the segment space the pass needs.
-// Also lays out the work-item list of k_expand_b<false> (offsets from the same scan: no atomics, deterministic order).
-__global__ void __launch_bounds__(256) k_segbase(DevBatch b, DevWork w, WorkItem* items, uint32_t item_cap, uint32_t first_chunk) {
-  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q > b.nq) return;
-  const unsigned long long totl = w.q_segl[b.nq];
-  const unsigned long long* item_off = w.q_seg + 2 * (size_t)(b.nq + 1);
-  if (q == b.nq) {
-    w.q_seg[q] += totl; w.counters[12] = item_off[q];
-    w.counters[24] = w.q_seg[q]; w.counters[25] = w.q_qseg[q];
-    return;
-  }
-  const unsigned long long l0 = w.q_segl[q], l1 = w.q_segl[q + 1];
-  const bool light = l1 > l0;
-  w.q_scap[q] = light ? (uint32_t)(l1 - l0) : (uint32_t)w.q_cap[q];
-  w.q_seg[q] = light ? l0 : totl + w.q_seg[q];
-  const unsigned long long i0 = item_off[q], i1 = item_off[q + 1];
-  for (unsigned long long k = i0; k < i1 && k < item_cap; k++) { WorkItem it; it.q = q; it.chunk = first_chunk + (uint32_t)(k - i0); items[k] = it; }
-}
-
-// k_caps_b, the second scan and k_segbase in ONE launch (see k_caps_scan): the hits phase A queued -> segment sizes and the
-// work items of k_expand_b<false> per query, scanned over the tiles, then segment base / capacity and the work-item list.
+// k_seg_scan — after phase A, in ONE launch (see k_caps_scan): the hits each query really queued become its segment size (the
+// segments of everything downstream are sized by these, not by the loose bound the queues were sized by) and the work items
+// of k_expand_b<false> per query (queries with more than kPhaseBChunk queued hits get several); both are scanned over the
+// tiles; then segment base and capacity per query — the light queries' segments come first (q_segl, sized by their hits
+// before phase A ran), the others follow in the order of this scan — and the work-item list, laid out by the same scan (no
+// atomics, deterministic order).  q_seg[nq] = the segment space the pass needs.
 __global__ void __launch_bounds__(kScanThreads) k_seg_scan(DevBatch b, DevWork w, WorkItem* items, uint32_t item_cap, uint32_t list0,
                                                           uint32_t first_chunk, unsigned long long* state, uint32_t* ticket) {
   const uint32_t tile = scan_ticket_take(ticket);
@@ -1397,7 +1306,7 @@ __global__ void __launch_bounds__(kScanThreads) k_seg_scan(DevBatch b, DevWork w
 // append of the survivors to the query's segment.  Dynamic LDS: pat[p_max].
 // ---------------------------------------------------------------------------------------------
 // LIGHT: the query's hits are not read from a queue but generated from its (short) suffix ranges — block q walks light
-// query q (k_caps); the length filter of phase A (the tabulated threshold of the sentence length) is applied here, the
+// query q (k_caps_scan); the length filter of phase A (the tabulated threshold of the sentence length) is applied here, the
 // signature bound is skipped (the exact coverage test decides).  !LIGHT: blocks [0, first_q_blocks) take chunk 0 of
 // query blockIdx.x, the others loop over the work-item list.
 template <bool LIGHT>
