@@ -1429,22 +1429,29 @@ void DeviceIndex::match_host_full(const HostIndex& h, const Params& prm, const H
   uint32_t* const hd_total = out_total ? pinned_device_ptr(out_total) : nullptr;
   const bool export_kernel = hd_count && (!out_total || hd_total);
   double ms_h2d = 0.0, ms_d2h = 0.0;
+  // Small single-pass calls put their copies on the compute stream: in order, no event between streams.  (With eight hardware
+  // queues every stream has a queue of its own and a dependency between two of them is a signal round trip; a 100 k-query call
+  // has four of them around ~1 ms of kernels, and its copies are too short to be worth overlapping with its own kernels —
+  // other calls in flight fill the gaps.)
+  static const uint64_t inline_max = [] { const char* e = getenv("FMX_HOST_INLINE_COPY"); return e ? (uint64_t)atoll(e) : (uint64_t)262144; }();
+  const bool inline_copies = n_sub == 1 && nq <= inline_max && !m.serial;
+  const hipStream_t h2d = inline_copies ? c.stream : c.h2d, d2h = inline_copies ? c.stream : c.d2h;
   // inputs of pass s: offsets [s*sub, end] (the last pass also sends q_off[nq]), tokens of those queries
   auto send = [&](uint32_t s) {
     const auto a = std::chrono::steady_clock::now();
     const uint64_t q0 = qb[s], q1 = qb[s + 1];
     // pass s reads offsets [q0, q1] inclusive; q0 itself already came with the previous pass
     const uint64_t o_lo = s == 0 ? q0 : q0 + 1, n_off = q1 - o_lo + 1;
-    HIP_TRY(hipMemcpyAsync(c.d_qoff.p + o_lo, hb.q_off + o_lo, n_off * 4, hipMemcpyHostToDevice, c.h2d));
-    if (base) hipLaunchKernelGGL(k_rebase, dim3((unsigned)((n_off + 255) / 256)), dim3(256), 0, c.h2d, c.d_qoff.p + o_lo, (uint32_t)n_off, base);
+    HIP_TRY(hipMemcpyAsync(c.d_qoff.p + o_lo, hb.q_off + o_lo, n_off * 4, hipMemcpyHostToDevice, h2d));
+    if (base) hipLaunchKernelGGL(k_rebase, dim3((unsigned)((n_off + 255) / 256)), dim3(256), 0, h2d, c.d_qoff.p + o_lo, (uint32_t)n_off, base);
     const uint64_t t0_ = bounds[s], t1_ = bounds[s + 1];
     if (t1_ > t0_) {
-      HIP_TRY(hipMemcpyAsync(c.d_qtok.p + t0_, hb.q_tok + base + t0_, (t1_ - t0_) * 4, hipMemcpyHostToDevice, c.h2d));
-      if (hb.q_real) HIP_TRY(hipMemcpyAsync(c.d_qreal.p + t0_, hb.q_real + base + t0_, (t1_ - t0_) * 4, hipMemcpyHostToDevice, c.h2d));
+      HIP_TRY(hipMemcpyAsync(c.d_qtok.p + t0_, hb.q_tok + base + t0_, (t1_ - t0_) * 4, hipMemcpyHostToDevice, h2d));
+      if (hb.q_real) HIP_TRY(hipMemcpyAsync(c.d_qreal.p + t0_, hb.q_real + base + t0_, (t1_ - t0_) * 4, hipMemcpyHostToDevice, h2d));
     }
     if (hb.q_itok)  // slot of (query q, position j) = q_off[q] + q + j: nt + nq entries, pass s owns [t0 + q0, t1 + q1)
-      HIP_TRY(hipMemcpyAsync(c.d_qitok.p + t0_ + q0, hb.q_itok + base + t0_ + q0, (t1_ - t0_ + q1 - q0) * 4, hipMemcpyHostToDevice, c.h2d));
-    HIP_TRY(hipEventRecord(c.ev_in[s % kMaxPassesInFlight], c.h2d));
+      HIP_TRY(hipMemcpyAsync(c.d_qitok.p + t0_ + q0, hb.q_itok + base + t0_ + q0, (t1_ - t0_ + q1 - q0) * 4, hipMemcpyHostToDevice, h2d));
+    HIP_TRY(hipEventRecord(c.ev_in[s % kMaxPassesInFlight], h2d));
     ms_h2d += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
   };
   PassHooks hooks;
@@ -1456,19 +1463,19 @@ void DeviceIndex::match_host_full(const HostIndex& h, const Params& prm, const H
   hooks.after = [&](uint32_t s, hipEvent_t done) {  // the records of pass s go home once `done` (null: already complete)
     const auto a = std::chrono::steady_clock::now();
     const uint64_t q0 = qb[s], q1 = qb[s + 1], n = q1 - q0;
-    if (done) HIP_TRY(hipStreamWaitEvent(c.d2h, done, 0));
+    if (done) HIP_TRY(hipStreamWaitEvent(d2h, done, 0));
     // (the records stay with the DMA engine: a copy kernel writing them over PCIe was 1 ms per million queries slower)
-    HIP_TRY(hipMemcpyAsync(out + q0 * cap, c.d_out.p + q0 * cap, n * cap * sizeof(Rec), hipMemcpyDeviceToHost, c.d2h));
+    HIP_TRY(hipMemcpyAsync(out + q0 * cap, c.d_out.p + q0 * cap, n * cap * sizeof(Rec), hipMemcpyDeviceToHost, d2h));
     if (export_kernel) {
-      hipLaunchKernelGGL(k_export_counts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.d2h, (const uint32_t*)c.d_cnt.p + q0,
+      hipLaunchKernelGGL(k_export_counts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d2h, (const uint32_t*)c.d_cnt.p + q0,
                          (const uint32_t*)c.d_tot.p + q0, hd_count + q0, hd_total ? hd_total + q0 : nullptr, (uint32_t)n);
     } else {
-      HIP_TRY(hipMemcpyAsync(out_count + q0, c.d_cnt.p + q0, n * 4, hipMemcpyDeviceToHost, c.d2h));
-      if (out_total) HIP_TRY(hipMemcpyAsync(out_total + q0, c.d_tot.p + q0, n * 4, hipMemcpyDeviceToHost, c.d2h));
+      HIP_TRY(hipMemcpyAsync(out_count + q0, c.d_cnt.p + q0, n * 4, hipMemcpyDeviceToHost, d2h));
+      if (out_total) HIP_TRY(hipMemcpyAsync(out_total + q0, c.d_tot.p + q0, n * 4, hipMemcpyDeviceToHost, d2h));
     }
     if (d_keep) {  // a device-resident copy for a collective that follows (the multi-process RCCL gather)
-      HIP_TRY(hipMemcpyAsync(d_keep + q0 * cap, c.d_out.p + q0 * cap, n * cap * sizeof(Rec), hipMemcpyDeviceToDevice, c.d2h));
-      if (d_keep_count) HIP_TRY(hipMemcpyAsync(d_keep_count + q0, c.d_cnt.p + q0, n * 4, hipMemcpyDeviceToDevice, c.d2h));
+      HIP_TRY(hipMemcpyAsync(d_keep + q0 * cap, c.d_out.p + q0 * cap, n * cap * sizeof(Rec), hipMemcpyDeviceToDevice, d2h));
+      if (d_keep_count) HIP_TRY(hipMemcpyAsync(d_keep_count + q0, c.d_cnt.p + q0, n * 4, hipMemcpyDeviceToDevice, d2h));
     }
     ms_d2h += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
   };
@@ -1519,7 +1526,7 @@ void DeviceIndex::match_host_full(const HostIndex& h, const Params& prm, const H
   if (chain_lk.owns_lock()) chain_lk.unlock();
   turn.release();
   const auto a = std::chrono::steady_clock::now();
-  HIP_TRY(hipEventRecord(c.ev_done, c.d2h));
+  HIP_TRY(hipEventRecord(c.ev_done, d2h));
   HIP_TRY(hipEventSynchronize(c.ev_done));
   ms_d2h += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
   if (st) {
