@@ -231,8 +231,8 @@ int fmx_match_batch_keep(fmx_index*, const fmx_params*, const fmx_batch* host_ba
  * (NULL = a stream of the library after a device-wide synchronisation).  total_tokens = q_off[nq] when q_off[0] == 0, else
  * 0 (with it and max_len set, a batch of one pass needs no device read up front).  Work is enqueued on `stream`; the call
  * synchronises that stream before returning.  stats != NULL: every pass is synchronised and timed per stage (HIP events);
- * stats == NULL: the passes run back to back, and calls of 262 144 queries or more issued concurrently from several host
- * threads (each on its own stream) are chained on the GPU like concurrent fmx_match_batch calls ("turns"). */
+ * stats == NULL: the passes run back to back; concurrent calls overlap on the GPU (with the option "device_turns" set, calls
+ * of 262 144 queries or more are chained like concurrent fmx_match_batch calls, see "turns"). */
 int fmx_match_batch_device(fmx_index*, const fmx_params*, const fmx_batch* device_batch,
                            uint64_t total_tokens, fmx_match* d_out, uint32_t* d_out_count,
                            uint32_t* d_out_total, uint32_t cap, void* stream, fmx_stats* stats);
@@ -240,8 +240,9 @@ int fmx_match_batch_device(fmx_index*, const fmx_params*, const fmx_batch* devic
 /* The two halves of fmx_match_batch_device(stats = NULL): _begin enqueues every launch of the call and returns, _end waits
  * for it (and re-runs a pass whose workspace overflowed: first calls on an index only).  ONE host thread can thus keep
  * several batches in flight — each in its own context ("contexts" option: at most that many pending) — and the library
- * overlaps them on the GPU: with "turns" = 2 the probe of a call (bound by HBM) runs beside the hit walk / edit distances /
- * replay of its predecessor (bound by instruction issue).  stream = NULL: a stream of the call's context; the caller's inputs
+ * overlaps them on the GPU: the kernels of one call that are bound by HBM run beside those of the others that are bound by
+ * instruction issue (six calls in flight over eight hardware queues measured best; the library asks for the queues with
+ * GPU_MAX_HW_QUEUES=8 when it is loaded, which only works before the process's first HIP call).  stream = NULL: a stream of the call's context; the caller's inputs
  * must be complete.  The output buffers are final after _end.  Call _end on the thread that called _begin, once per handle. */
 typedef struct fmx_pending fmx_pending;
 int fmx_match_batch_device_begin(fmx_index*, const fmx_params*, const fmx_batch* device_batch, uint64_t total_tokens,
@@ -311,7 +312,8 @@ int64_t fmx_index_add_text(fmx_index*, const char* id, const char* sentence, siz
  *   "sub_queries"       queries per pipeline pass (default 1 048 576)
  *   "host_sub_queries"  pass size of fmx_match_batch (host buffers, default 1 048 576): the inputs of the next pass and
  *                       the records of the previous one cross PCIe while a pass computes
- *   "turns"             how concurrent calls of 262 144 queries or more share the GPU (smaller calls simply overlap): 2 (default)
+ *   "device_turns"      the same for the device-resident entry points only (default 0: they simply overlap; "turns" sets both)
+ *   "turns"             how concurrent host-buffer calls of 32 768 queries or more share the GPU (smaller calls simply overlap): 2 (default)
  *                       = a call's first kernel waits until its predecessor's probe and long-range kernels are through, so its
  *                       HBM-bound probe runs beside the predecessor's issue-bound second half; 1 = it waits for the predecessor's
  *                       last kernel; 0 = calls simply overlap; 3 = turns are taken on the host
