@@ -64,7 +64,7 @@ def parse_args():
     ap.add_argument("--queries", type=int, default=0)
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--threads", type=int, default=int(os.environ.get("FMX_BENCH_THREADS", "6")), help="synchronous fmx_match_batch calls kept in flight (one host thread each)")
-    ap.add_argument("--host-threads", type=int, default=int(os.environ.get("FMX_BENCH_HOST_THREADS", "3")),
+    ap.add_argument("--host-threads", type=int, default=int(os.environ.get("FMX_BENCH_HOST_THREADS", "4")),
                     help="calls in flight of the host-buffer legs (PCIe-inclusive, from token strings): each adds two copy streams to its two "
                          "compute streams, and beyond ~24 busy hardware queues the GPU's scheduler starts time-slicing them")
     ap.add_argument("--force-gather", action="store_true", help="N = 1 test of the N > 1 step: records also kept in HBM for the (empty) gather")
