@@ -497,13 +497,16 @@ def main():
             write = pmc_pass("WRITE_SIZE", child, log) if fetch else None
             log(f"[bench] pmc child passes: {time.time() - t1:.0f}s")
             if fetch and write:
-                for kern, pattern in (("fmx::k_probe", "random"), ("fmx::k_expand_a", "stream16"), ("fmx::k_expand_h", "stream8"),
-                                      ("fmx::k_expand_b", "random"), ("fmx::k_dp_reg", "random")):
+                rounds = int(pkw.get("nmatch", 1)) if pkw.get("contrast", 0.0) > 0.0 else 1
+                for kern, pattern, per_step in (("fmx::k_probe", "random", 1), ("fmx::k_expand_a", "stream16", 1), ("fmx::k_expand_h", "stream8", 1),
+                                                ("fmx::k_expand_b", "random", 1), ("fmx::k_dp_reg", "random", 1), ("fmx::k_finish", "random", 1),
+                                                ("fmx::k_camap", "random", 1), ("fmx::k_cround", "random", rounds)):
                     keys = [k for k in fetch if k.replace("void ", "").startswith(kern)]  # template instantiations add up
                     if not keys:
                         continue
-                    f_kb = sum(np.mean([v for _, v in fetch[k][-2:]]) for k in keys)   # the child's two timed dispatches
-                    w_kb = sum(np.mean([v for _, v in write.get(k, [(0, 0.0)])[-2:]]) for k in keys)
+                    # the child's two timed steps (per_step dispatches each): bytes per step
+                    f_kb = sum(np.sum([v for _, v in fetch[k][-2 * per_step:]]) / 2.0 for k in keys)
+                    w_kb = sum(np.sum([v for _, v in write.get(k, [(0, 0.0)])[-2 * per_step:]]) / 2.0 for k in keys)
                     f_fac = float(cal.get("fetch_factor", {}).get(pattern, 2.0))
                     w_fac = float(cal.get("write_factor", 1.0))
                     traffic[kern.split("::")[1]] = {"bytes": int(f_kb * 1024 * f_fac + w_kb * 1024 * w_fac), "fetch_kb_raw": float(f_kb),
@@ -541,6 +544,16 @@ def main():
                     "one lane per (query, candidate): 4 B x (sentence length + 1) of the sentence, 16 B candidate record in and out, 8 B "
                     "list entry, 4 B per pattern token per query (kernel counters; mean sentence length of the corpus)")
         roofs = sorted([r_probe, r_exa, r_exb], key=lambda r: -r["kernel_ms"]) + [r_dp]
+        if pkw.get("contrast", 0.0) > 0.0:
+            # the contrastive rerank: per sentence-pair distance both sentences and the per-match state (list entry 8, record 16,
+            # keys 8 + 8, penalty sum 4 + 4, penalty 4, two sentence positions 8); per candidate the 16 B record the replay reads
+            fin_ms = per_stage.get("finish", 0.0)
+            b_fin = last.n_rerank * (8.0 * (mean_len + 1) + 64.0) + 16.0 * last.n_candidates
+            roofs.append(roof("finish stage: k_finish<64> + k_camap + nmatch x k_cround<32|64>", b_fin, fin_ms, ["k_finish", "k_camap", "k_cround"],
+                              f"replay + contrastive rerank; {int(last.n_rerank)} sentence-pair edit distances per step (kernel counter) x (two sentences "
+                              "of 4 B x (mean length + 1) + 64 B of per-match state) + 16 B per candidate; the rounds are bound by VALU issue "
+                              "(~1800 instructions per distance, VALU busy 0.75: profiles/r03_c5_pmc_sq.csv), not by HBM — priced here because the "
+                              "line's schema has no issue roofline"))
         dominant, others = roofs[0], roofs[1:]
 
         # ---- parity spot check, reference byte model, CPU baseline (the oracle: test infrastructure, outside the timed region) ----

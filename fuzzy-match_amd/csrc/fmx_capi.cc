@@ -363,7 +363,7 @@ static void copy_stats(const Stats& s, fmx_stats* o) {
   o->n_retries = s.n_retries; o->n_big = s.n_big; o->n_phase_b = s.n_phase_b; o->max_kept = s.max_kept;
   o->n_heavy_hits = s.n_heavy_hits; o->n_heavy_pass = s.n_heavy_pass; o->pinned = s.pinned;
   o->plane_words = s.plane_words; o->probe_bytes = s.probe_bytes; o->probe_lines = s.probe_lines;
-  o->n_light_hits = s.n_light_hits; o->n_small = s.n_small;
+  o->n_light_hits = s.n_light_hits; o->n_small = s.n_small; o->n_rerank = s.n_rerank;
 }
 
 // match(const Tokens&) builds `real` from the pattern itself (src/fuzzy_match.cc:428): the real token of position
@@ -426,7 +426,7 @@ static void match_on_devices(fmx_index* ix, const Params& prm, const HostBatchVi
       st->n_retries += s.n_retries; st->n_big += s.n_big; st->n_phase_b += s.n_phase_b; st->max_kept = std::max(st->max_kept, s.max_kept);
       st->n_heavy_hits += s.n_heavy_hits; st->n_heavy_pass += s.n_heavy_pass; st->pinned = s.pinned;
       st->plane_words += s.plane_words; st->probe_bytes += s.probe_bytes; st->probe_lines += s.probe_lines;
-      st->n_light_hits += s.n_light_hits; st->n_small += s.n_small;
+      st->n_light_hits += s.n_light_hits; st->n_small += s.n_small; st->n_rerank += s.n_rerank;
     }
     st->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   }

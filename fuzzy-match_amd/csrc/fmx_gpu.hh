@@ -26,7 +26,7 @@ struct Stats {
   uint64_t launches[16] = {0};
   uint64_t n_hits = 0, n_kept = 0, n_candidates = 0, n_dp = 0, n_retries = 0, n_big = 0, n_phase_b = 0, max_kept = 0;
   uint64_t n_heavy_hits = 0, n_heavy_pass = 0, pinned = 0;
-  uint64_t plane_words = 0, probe_bytes = 0, probe_lines = 0, n_light_hits = 0, n_small = 0;
+  uint64_t plane_words = 0, probe_bytes = 0, probe_lines = 0, n_light_hits = 0, n_small = 0, n_rerank = 0;
 };
 
 struct Rec;  // == fmx_match, defined in fmx_kernels.hip.hh

@@ -979,7 +979,7 @@ static void add_counters(Stats* st, const unsigned long long* ctr) {
   st->n_hits += ctr[0]; st->n_kept += ctr[1]; st->n_candidates += ctr[2]; st->n_dp += ctr[3];
   st->n_big += ctr[7]; st->n_phase_b += ctr[8]; st->max_kept = std::max<uint64_t>(st->max_kept, ctr[9]);
   st->n_heavy_hits += ctr[16]; st->n_heavy_pass += ctr[17]; st->plane_words += ctr[18];
-  st->probe_bytes += ctr[19]; st->probe_lines += ctr[20]; st->n_light_hits += ctr[22];
+  st->probe_bytes += ctr[19]; st->probe_lines += ctr[20]; st->n_light_hits += ctr[22]; st->n_rerank += ctr[27];
 }
 
 constexpr uint32_t kAsyncGroup = 32;  // passes enqueued before the host looks at their counters

@@ -112,6 +112,7 @@ struct DevWork {
                                  // [18]=8-byte plane words read by k_expand_h [19],[20]=bytes / lines requested by k_probe<true>
                                  // [22]=hits of the light queries (walked by k_expand_b<true>) [23]=queries queued for k_cand
                                  // [24],[25]=segment / queue entries the pass used (always written: the host sizes later workspaces by them)
+                                 // [27]=sentence-pair edit distances of the flattened contrastive rerank (k_cround)
 };
 constexpr int kStatSlots = 64;     // k_expand_h's three statistics are summed into 64 slots each (kStatBase + 3 x 64): 8192 workgroups
                                    // adding to three single words at the end of the kernel queued for ~0.1 ms; k_stats folds them into [16..18]
@@ -3057,6 +3058,7 @@ __global__ void __launch_bounds__(kWave) k_cround(DevIndex ix, DevBatch b, DevWo
   const unsigned long long* bid_prev = w.q_best + (size_t)((round + 2) % 3) * b.nq;  // round - 1
   unsigned long long* bid_cur = w.q_best + (size_t)(round % 3) * b.nq;
   unsigned long long* bid_next = w.q_best + (size_t)((round + 1) % 3) * b.nq;
+  uint32_t n_dist = 0;  // statistics: sentence-pair distances of this lane
   for (unsigned long long j = j_lo + (unsigned long long)blockIdx.x * kWave + lane; j < j_hi;
        j += (unsigned long long)gridDim.x * kWave) {
     const unsigned long long qi = w.c_qi[j];
@@ -3097,7 +3099,10 @@ __global__ void __launch_bounds__(kWave) k_cround(DevIndex ix, DevBatch b, DevWo
     const float pen_now = prm.reduce == 1 ? mx : (sum / (float)round);
     sc.f1[seg0 + k] = pen_now;
     atomicMax(&bid_cur[q], contrast_bid(c.score - (prm.contrast * pen_now), (uint32_t)(kw >> 32) & 0xffffu, k));
+    n_dist++;
   }
+  n_dist = wave_sum(n_dist);  // (every lane is back here: the loop's exits are per lane)
+  if (lane == 0 && n_dist) atomicAdd(&w.counters[27], (unsigned long long)n_dist);
 }
 
 // per-call statistics from the per-query arrays (kept out of the hot kernels: one shared atomic

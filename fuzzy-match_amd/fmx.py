@@ -57,7 +57,7 @@ class Stats(C.Structure):
                 ("n_dp", C.c_uint64), ("n_retries", C.c_uint64), ("n_big", C.c_uint64),
                 ("n_phase_b", C.c_uint64), ("max_kept", C.c_uint64), ("n_heavy_hits", C.c_uint64),
                 ("n_heavy_pass", C.c_uint64), ("pinned", C.c_uint64), ("plane_words", C.c_uint64),
-                ("probe_bytes", C.c_uint64), ("probe_lines", C.c_uint64), ("n_light_hits", C.c_uint64), ("n_small", C.c_uint64)]
+                ("probe_bytes", C.c_uint64), ("probe_lines", C.c_uint64), ("n_light_hits", C.c_uint64), ("n_small", C.c_uint64), ("n_rerank", C.c_uint64)]
 
 
 class Info(C.Structure):

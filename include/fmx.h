@@ -101,6 +101,7 @@ typedef struct fmx_stats {
   uint64_t probe_lines;     /* option "probe_count": distinct 128-byte lines those loads touched, per lane */
   uint64_t n_light_hits;    /* of n_hits: hits of "light" queries, walked by k_expand_b itself (no phase A, no queue) */
   uint64_t n_small;         /* queries answered by the one-launch path for micro-batches (k_match_small) */
+  uint64_t n_rerank;        /* sentence-pair edit distances of the flattened contrastive rerank (k_cround) */
 } fmx_stats;
 
 const char* fmx_last_error(void);
