@@ -158,3 +158,47 @@ def test_begin_end_keeps_several_calls_in_flight_from_one_thread(fmx, setup, tur
     finally:
         ix.set_option("turns", 1)
         ix.set_option("contexts", 4)
+
+
+def test_device_turns_is_a_separate_option(fmx, setup):
+    """`device_turns` chains the device-resident entry points only (default 0: they overlap freely); `turns` keeps setting
+    both.  Four concurrent callers under either setting leave the oracle's records."""
+    hip, ix, kw, q_off, q_tok, d_off, d_tok, oo, oc = setup
+    nq, cap = len(q_off) - 1, 5
+    errs = []
+
+    def worker(k):
+        try:
+            st = hip.stream()
+            d_out, d_cnt = hip.zeros(nq * cap * 16), hip.zeros(nq * 4)
+            ix.match_batch_device(fmx.Params(**kw), nq, d_off, d_tok, int(q_off[-1]), d_out, d_cnt, 0, cap, stream=st,
+                                  max_len=int(np.diff(q_off).max()), want_stats=False)
+            go, gc = _records(hip, d_out, d_cnt, nq, cap)
+            workloads.compare(oo, oc, go, gc, f"thread {k}")
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e)[:500])
+
+    try:
+        for dt in (2, 0):
+            ix.set_option("device_turns", dt)
+            th = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+    finally:
+        ix.set_option("turns", 1)
+    assert not errs, errs[:2]
+    with pytest.raises(Exception):
+        ix.set_option("no_such_option", 1)
+
+
+def test_rerank_distances_are_counted(fmx, setup):
+    """fmx_stats.n_rerank: sentence-pair distances of the flattened contrastive rerank — none without a contrastive factor."""
+    hip, ix, kw, q_off, q_tok, d_off, d_tok, oo, oc = setup
+    n = 5000
+    qo, qt = q_off[:n + 1], q_tok[:int(q_off[n])]
+    plain = ix.match_batch(fmx.Params(**kw), qo, qt, cap=5, want_stats=True)[3]
+    assert plain.n_rerank == 0
+    st = ix.match_batch(fmx.Params(contrast=0.3, contrast_buffer=32, **kw), qo, qt, cap=5, want_stats=True)[3]
+    assert st.n_rerank > 0
