@@ -745,9 +745,9 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
     tick(); tick();
     if (b.nt) {
       if (m.probe_count)  // measurement runs only: the same kernel, also counting the bytes / lines it requests
-        hipLaunchKernelGGL(k_probe<true>, dim3((b.nt + 63) / 64), dim3(64), 0, stream, m.d, b, w, heavy_min, c.items_h.p, item_h_cap);
+        hipLaunchKernelGGL(k_probe<true>, dim3((b.nt + kProbeBlock - 1) / kProbeBlock), dim3(kProbeBlock), 0, stream, m.d, b, w, heavy_min, c.items_h.p, item_h_cap);
       else
-        hipLaunchKernelGGL(k_probe<false>, dim3((b.nt + 63) / 64), dim3(64), 0, stream, m.d, b, w, heavy_min, c.items_h.p, item_h_cap);
+        hipLaunchKernelGGL(k_probe<false>, dim3((b.nt + kProbeBlock - 1) / kProbeBlock), dim3(kProbeBlock), 0, stream, m.d, b, w, heavy_min, c.items_h.p, item_h_cap);
     }
     tick(); tick();
     // light queries (k_caps_scan): at most light_max hits, all in short ranges, pattern of at most one wave

@@ -198,8 +198,12 @@ __device__ __forceinline__ unsigned long long seg_scan_u64(unsigned long long v,
 }
 
 // COUNT (measurement runs): also tallies the bytes / lines the lane's loads request into counters[19], [20].
+#ifndef FMX_PROBE_BLOCK
+#define FMX_PROBE_BLOCK 64
+#endif
+constexpr uint32_t kProbeBlock = FMX_PROBE_BLOCK;  // threads per workgroup of k_probe (waves are independent: no LDS, no barrier)
 template <bool COUNT>
-__global__ void __launch_bounds__(64) k_probe(DevIndex ix, DevBatch b, DevWork w, uint32_t heavy_min, HeavyItem* items_h,
+__global__ void __launch_bounds__(kProbeBlock) k_probe(DevIndex ix, DevBatch b, DevWork w, uint32_t heavy_min, HeavyItem* items_h,
                                               uint32_t item_h_cap) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= b.nt) return;
