@@ -51,11 +51,15 @@ uint32_t HostIndex::get_index(const std::string& w) const {
   return it != form2index.end() ? it->second : 1u;  // VOCAB_UNK
 }
 
-static inline uint64_t spell_hash(const char* s, size_t& len) {  // FNV-1a, 64 bit
-  uint64_t h = 1469598103934665603ull;
+static inline uint64_t spell_hash(const char* s, size_t& len, uint64_t& head) {  // FNV-1a, 64 bit; head = the first eight bytes
+  uint64_t h = 1469598103934665603ull, hd = 0;
   size_t n = 0;
-  for (; s[n]; n++) { h ^= (unsigned char)s[n]; h *= 1099511628211ull; }
+  for (; s[n]; n++) {
+    h ^= (unsigned char)s[n]; h *= 1099511628211ull;
+    if (n < 8) hd |= (uint64_t)(unsigned char)s[n] << (8 * n);
+  }
   len = n;
+  head = hd;
   return h ^ (h >> 29);
 }
 
@@ -67,6 +71,7 @@ const HostIndex::FastVocab& HostIndex::fast_vocab() const {
   uint64_t cap = 64;
   while (cap < forms.size() * 2) cap <<= 1;
   f.slot.assign(cap, ~0ull);
+  f.head.assign(cap, 0ull);
   f.mask = cap - 1;
   f.arena.clear();
   for (size_t id = 0; id < forms.size(); id++) {
@@ -76,9 +81,11 @@ const HostIndex::FastVocab& HostIndex::fast_vocab() const {
     f.arena.insert(f.arena.end(), forms[id].begin(), forms[id].end());
     f.arena.push_back('\0');
     size_t len;
-    uint64_t h = spell_hash(f.arena.data() + off, len) & f.mask;
+    uint64_t hd;
+    uint64_t h = spell_hash(f.arena.data() + off, len, hd) & f.mask;
     while (f.slot[h] != ~0ull) h = (h + 1) & f.mask;
     f.slot[h] = (off << 32) | (uint64_t)id;
+    f.head[h] = hd;
   }
   f.built_for.store(forms.size(), std::memory_order_release);
   return f;
@@ -90,13 +97,17 @@ void HostIndex::get_indices(const char* const* toks, uint64_t n, uint32_t* ids, 
     for (uint64_t i = lo; i < hi; i++) {
       const char* t = toks[i];
       size_t len;
-      uint64_t h = spell_hash(t, len) & f.mask;
+      uint64_t hd;
+      uint64_t h = spell_hash(t, len, hd) & f.mask;
       uint32_t id = 1u;  // VOCAB_UNK
       for (;;) {
         const uint64_t e = f.slot[h];
         if (e == ~0ull) break;
-        const char* w = f.arena.data() + (e >> 32);
-        if (memcmp(w, t, len + 1) == 0) { id = (uint32_t)e; break; }
+        if (f.head[h] == hd) {
+          // up to seven bytes: equal heads are equal spellings (the zero padding carries the length); longer ones: the rest
+          // (and the terminator) from the arena
+          if (len < 8 || memcmp(f.arena.data() + (e >> 32) + 8, t + 8, len - 8 + 1) == 0) { id = (uint32_t)e; break; }
+        }
         h = (h + 1) & f.mask;
       }
       ids[i] = id;

@@ -98,6 +98,8 @@ class HostIndex {
   struct FastVocab {
     std::vector<char>     arena;   // NUL-terminated spellings
     std::vector<uint64_t> slot;    // offset into arena << 32 | id, ~0 = empty
+    std::vector<uint64_t> head;    // beside every slot: the spelling's first eight bytes (zero-padded) — spellings of up to eight
+                                   // bytes are decided without touching the arena (one cache miss fewer per look-up)
     uint64_t              mask = 0;
     std::atomic<uint64_t> built_for{0};   // forms.size() it was built from (0 = not built)
   };
