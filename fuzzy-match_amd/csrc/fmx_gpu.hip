@@ -1619,8 +1619,10 @@ void DeviceIndex::subsequence_host(const HostIndex& h, const HostBatchView& hb, 
     for (uint64_t q = 0; q <= nq; q++) off[q] = hb.q_off[q0 + q] - base;
     for (uint64_t q = 0; q < nq; q++) p_max = std::max(p_max, off[q + 1] - off[q]);
     const size_t lds = ((size_t)p_max + 1) * kWave * 4;
-    if (lds > kDynLdsMax) throw UnsupportedError("subsequence(): patterns of more than ~590 tokens");
-    HIP_TRY(hipFuncSetAttribute((const void*)k_sub_eval, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDynLdsMax));
+    const bool rows_in_hbm = lds > kDynLdsMax;  // patterns of more than ~590 tokens: the same kernel over rows in HBM
+    const unsigned sub_grid_g = 1024;
+    if (rows_in_hbm) c.g_rows.ensure((uint64_t)sub_grid_g * kWave * (p_max + 1));
+    else HIP_TRY(hipFuncSetAttribute((const void*)k_sub_eval<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDynLdsMax));
     c.d_qoff.ensure(nq + 1); c.d_qtok.ensure(nt + 1); c.t_q.ensure(nt + 1);
     HIP_TRY(hipMemcpyAsync(c.d_qoff.p, off.data(), (nq + 1) * 4, hipMemcpyHostToDevice, stream));
     if (nt) HIP_TRY(hipMemcpyAsync(c.d_qtok.p, hb.q_tok + base, nt * 4, hipMemcpyHostToDevice, stream));
@@ -1682,8 +1684,14 @@ void DeviceIndex::subsequence_host(const HostIndex& h, const HostBatchView& hb, 
       }
       if (items.empty()) break;
       HIP_TRY(hipMemcpyAsync(d_items.p, items.data(), items.size() * sizeof(SubItem), hipMemcpyHostToDevice, stream));
-      hipLaunchKernelGGL(k_sub_eval, dim3((unsigned)std::min<size_t>(items.size(), 65535)), dim3(kWave), lds, stream, m.d, c.d_qoff.p, c.d_qtok.p,
-                         d_real, d_itok, (const SubItem*)d_items.p, (uint32_t)items.size(), d_st.p, d_seen.p, seen_cap, nm, no_perfect ? 1 : 0);
+      if (rows_in_hbm)
+        hipLaunchKernelGGL(k_sub_eval<true>, dim3((unsigned)std::min<size_t>(items.size(), sub_grid_g)), dim3(kWave), 0, stream, m.d, c.d_qoff.p, c.d_qtok.p,
+                           d_real, d_itok, (const SubItem*)d_items.p, (uint32_t)items.size(), d_st.p, d_seen.p, seen_cap, nm, no_perfect ? 1 : 0,
+                           c.g_rows.p, p_max + 1);
+      else
+        hipLaunchKernelGGL(k_sub_eval<false>, dim3((unsigned)std::min<size_t>(items.size(), 65535)), dim3(kWave), lds, stream, m.d, c.d_qoff.p, c.d_qtok.p,
+                           d_real, d_itok, (const SubItem*)d_items.p, (uint32_t)items.size(), d_st.p, d_seen.p, seen_cap, nm, no_perfect ? 1 : 0,
+                           (float*)nullptr, 0u);
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipMemcpyAsync(st.data(), d_st.p, nq * sizeof(SubState), hipMemcpyDeviceToHost, stream));
       HIP_TRY(hipStreamSynchronize(stream));

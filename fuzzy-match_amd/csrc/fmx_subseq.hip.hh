@@ -57,11 +57,15 @@ __global__ void __launch_bounds__(64) k_sub_extent(DevIndex ix, const uint32_t* 
 }
 
 // dynamic LDS: (p_max + 1) x 64 floats (DP rows)
+// GROWS: the DP rows live in HBM (g_rows: row_len x 64 floats per workgroup) instead of dynamic LDS — patterns of more than
+// ~590 tokens (--max-tokens-in-pattern above the default, include/fuzzy/suffix_array_index.hh:15), like k_dp<FULL, true>.
+template <bool GROWS>
 __global__ void __launch_bounds__(kWave) k_sub_eval(DevIndex ix, const uint32_t* q_off, const uint32_t* q_tok, const uint32_t* q_real,
                                                     const uint32_t* q_itok, const SubItem* items, uint32_t n_items, SubState* states,
-                                                    uint32_t* seen, uint32_t seen_cap, uint32_t nm, int no_perfect) {
+                                                    uint32_t* seen, uint32_t seen_cap, uint32_t nm, int no_perfect, float* g_rows,
+                                                    uint32_t row_len) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* s_rows = (float*)smem;
+  float* s_rows = GROWS ? g_rows + (size_t)blockIdx.x * row_len * kWave : (float*)smem;
   __shared__ float s_final[kWave], s_M[kWave];
   __shared__ uint32_t s_sid[kWave];
   __shared__ SubState s_st;

@@ -201,3 +201,40 @@ def test_gpu_subsequence_skips_thousands_of_perfect_matches(fmx, gpu_device):
         n += _check_batch(ix, o, q_off, q_tok, kw, tag="perfect")
     assert n >= 6
     o.close()
+
+
+@pytest.mark.gpu
+def test_gpu_subsequence_patterns_beyond_the_lds_rows(fmx, gpu_device):
+    """Patterns of 650-900 tokens (--max-tokens-in-pattern above the default): the DP rows of k_sub_eval no longer fit the LDS
+    and live in HBM (k_sub_eval<true>) — same records as the oracle, next to short patterns in the same batch."""
+    rng = np.random.default_rng(5)
+    vocab = 40
+    lens = np.concatenate([rng.integers(600, 1000, 60), rng.integers(3, 30, 400)])
+    rng.shuffle(lens)
+    c_off = np.zeros(len(lens) + 1, np.uint32)
+    c_off[1:] = np.cumsum(lens)
+    c_tok = rng.integers(2, vocab + 2, int(c_off[-1])).astype(np.uint32)
+    long_ids = np.flatnonzero(lens >= 650)
+    qs = []
+    for s in long_ids[:12]:
+        t = c_tok[c_off[s]:c_off[s + 1]].copy()
+        for _ in range(int(rng.integers(0, 12))):  # a few substitutions; one pattern stays a perfect match
+            t[int(rng.integers(0, len(t)))] = int(rng.integers(2, vocab + 2))
+        qs.append(t[:900])
+    qs += [rng.integers(2, vocab + 2, int(rng.integers(2, 20))).astype(np.uint32) for _ in range(20)]
+    q_off = np.zeros(len(qs) + 1, np.uint32)
+    q_off[1:] = np.cumsum([len(t) for t in qs])
+    q_tok = np.concatenate(qs).astype(np.uint32)
+    assert int(np.diff(q_off).max()) > 650
+    ix = fmx.Index.create(max_tokens=1000)
+    ix.add_ids(c_off, c_tok, vocab + 2)
+    ix.sort(gpu_device)
+    ix.finalize()
+    ix.to_device(gpu_device)
+    o = oracle_lib.OracleIndex(max_tokens=1000)
+    o.add_ids_bulk(c_off, c_tok, vocab + 2, sfreq=ix.array("sfreq"))
+    o.sort(2)
+    total = 0
+    for kw in (dict(nmatch=1), dict(nmatch=3, no_perfect=True), dict(nmatch=2, idf_weighting=True)):
+        total += _check_batch(ix, o, q_off, q_tok, kw, tag="long patterns")
+    assert total > 30
