@@ -428,6 +428,65 @@ def main():
 
     from_strings = measure_from_strings(main_wl) if (world == 1 and not args.no_text_leg) else None
 
+    def measure_from_packed_text(wl):
+        """The same bracket with the id lookup ON THE DEVICE (fmx_match_batch_text): a step hands over its patterns as packed token
+        spellings — NUL-terminated, back to back, what a tokenizer writes — in pinned host memory; the spellings cross PCIe instead
+        of the ids, k_vocab_lookup turns them into ids in HBM, the pipeline follows.  Records come back to pinned host buffers."""
+        import ctypes
+        buf = ctypes.create_string_buffer(32)
+        wlen = np.zeros(vs, np.int64)
+        parts = []
+        woff = np.zeros(vs, np.int64)
+        pos = 0
+        for k in range(vs - 2):
+            n = L.fms_word(k, buf, 32)
+            parts.append(buf.raw[:n] + b"\0")
+            wlen[k + 2] = n + 1
+            woff[k + 2] = pos
+            pos += n + 1
+        arena = np.frombuffer(b"".join(parts), dtype=np.uint8)
+        tl = wlen[wl.q_tok]
+        total = int(tl.sum())
+        text = fmx.pinned_empty(total, np.uint8)
+        at = 0
+        for lo in range(0, len(wl.q_tok), 1 << 21):  # in slices: the gather index of the whole batch would be gigabytes
+            t = wl.q_tok[lo:lo + (1 << 21)]
+            ln = wlen[t]
+            n = int(ln.sum())
+            start = np.cumsum(ln) - ln
+            idx = np.repeat(woff[t] - start, ln) + np.arange(n)
+            text[at:at + n] = arena[idx]
+            at += n
+        T = max(min(args.host_threads, args.threads), 1)
+
+        def one(i):
+            return ix.match_batch_text(params, wl.q_off, text, cap=cap, want_stats=True, out=wl.out[i % T])[3]
+
+        def run(k_steps):
+            futs = {i: pool.submit(one, i) for i in range(min(T, k_steps))}
+            for i in range(k_steps):
+                futs.pop(i).result()
+                if i + T < k_steps:
+                    futs[i + T] = pool.submit(one, i + T)
+
+        run(2 * T)
+        ref = ix.match_batch(params, wl.q_off, wl.q_tok, cap=cap)
+        got = ix.match_batch_text(params, wl.q_off, text, cap=cap)
+        assert np.array_equal(ref[1], got[1]) and ref[0][:2000].tobytes() == got[0][:2000].tobytes(), "text batch differs from the id batch"
+        k = max(6, args.steps // 2)
+        el, _ = timed(run, k)
+        return {"value": round(wl.nq * k / el, 1), "ms_per_step": round(el / k * 1e3, 3), "steps": k, "calls_in_flight": T,
+                "text_bytes_per_step": total, "tokens_per_step": int(len(wl.q_tok)),
+                "note": "fmx_match_batch_text: packed token spellings in pinned host memory -> H2D -> k_vocab_lookup (ids in HBM) -> pipeline -> "
+                        "records to pinned host buffers; checked against the id batch"}
+
+    from_text = None
+    if world == 1 and not args.no_text_leg:
+        try:
+            from_text = measure_from_packed_text(main_wl)
+        except Exception as e:  # noqa: BLE001  (a side leg: the line is still worth printing)
+            log(f"[bench] from_packed_text leg failed: {e!r}")
+
     # ---- the same batch from HBM (device entry point): stage times for the rooflines ----
     run_device_steps(main_wl, 1)
     el_dev, (dev_stats, d_out, d_cnt) = timed(lambda k: run_device_steps(main_wl, k), args.steps)
@@ -628,7 +687,7 @@ def main():
             "pcie_inclusive": {"value": round(value_host, 1), "ms_per_step": round(elapsed_host / args.steps * 1e3, 3),
                                "note": "the same steps through fmx_match_batch: pinned host buffers in and out (H2D + kernels + D2H"
                                        + (" + the RCCL gather of the records to rank 0" if world > 1 else "") + f"), {max(min(args.host_threads, args.threads), 1)} call(s) in flight"},
-            "from_token_strings": from_strings,
+            "from_token_strings": from_strings, "from_packed_text": from_text,
             "staged": {"value": round(nq_step_all * args.steps / el_dev, 1),
                        "ms_per_step": round(el_dev / args.steps * 1e3, 3),
                        "stage_ms_per_step": {k: round(v, 4) for k, v in per_stage.items()},

@@ -463,6 +463,26 @@ int fmx_match_batch_keep(fmx_index* ix, const fmx_params* params, const fmx_batc
   });
 }
 
+int fmx_match_batch_text(fmx_index* ix, const fmx_params* params, const fmx_text_batch* tb, fmx_match* out,
+                         uint32_t* out_count, uint32_t* out_total, uint32_t cap, fmx_stats* stats) {
+  if (!ix || !params || !tb || !out || !out_count) return fail(FMX_E_INVALID, "null argument");
+  if (tb->nq && (!tb->q_off || (tb->q_off[tb->nq] && !tb->text))) return fail(FMX_E_INVALID, "null batch arrays");
+  if (cap == 0) return fail(FMX_E_INVALID, "cap must be > 0");
+  if (!ix->finalized) return fail(FMX_E_STATE, "index is not finalized");
+  if (ix->devs.empty()) return fail(FMX_E_NO_DEVICE, "index is not on a device (fmx_index_to_device); there is no CPU path");
+  if (ix->host.real_differs) return fail(FMX_E_UNSUPPORTED, "text batches carry no real tokens: this index distinguishes them (look the ids up with fmx_vocab_lookup_mt)");
+  return guarded([&]() {
+    HostBatchView v;
+    v.nq = tb->nq; v.q_off = tb->q_off; v.text = tb->text; v.n_text = tb->n_bytes;
+    Stats st;
+    // (one replica per call, round-robin: a block of a text batch would need the byte offset of its first spelling)
+    const size_t k = ix->devs.size() == 1 ? 0 : ix->rr.fetch_add(1) % ix->devs.size();
+    ix->devs[k]->match_host(ix->host, make_params(ix, params), v, (Rec*)out, out_count, out_total, cap, &st, nullptr, nullptr);
+    copy_stats(st, stats);
+    return (int)FMX_OK;
+  });
+}
+
 // ---------------------------------------------------------------------------------------------
 // Request coalescer behind fmx_match_one.  The reference's match() is called one pattern at a time from N
 // threads; a GPU pass costs ~45 launches whatever its size, so concurrent requests with equal parameters are

@@ -42,6 +42,10 @@ struct HostBatchView {
   uint32_t        n_prior = 0;
   const uint32_t* prior_off = nullptr;
   const uint32_t* prior_tok = nullptr;
+  // the patterns as token SPELLINGS instead of ids (q_tok == nullptr): q_off[nq] NUL-terminated spellings back to back; the
+  // vocabulary ids are looked up on the device (fmx_vocab.hip.hh)
+  const char*     text = nullptr;
+  uint64_t        n_text = 0;
 };
 
 struct DeviceBatchView {

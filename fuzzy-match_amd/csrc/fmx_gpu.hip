@@ -28,6 +28,7 @@
 #include "fmx_subseq.hip.hh"
 #include "fmx_small.hip.hh"
 #include "fmx_derive.hip.hh"
+#include "fmx_vocab.hip.hh"
 
 namespace fmx {
 
@@ -139,6 +140,9 @@ struct Ctx {
   uint64_t want_qb = 1ull << 24;  // queue entries (8 bytes each) wanted: grows when a pass reports more
   // ---- staging of the host-buffer entry point (each buffer tracks its own capacity) ----
   Grow<uint32_t> d_qoff, d_qtok, d_qreal, d_qitok, d_cnt, d_tot, d_prior;
+  Grow<unsigned char> d_text;              // token spellings of a text batch
+  Grow<unsigned long long> d_vstate;       // look-back state of k_vocab_lookup (one word per tile + ticket + total)
+  unsigned long long* h_vtotal = nullptr;  // pinned: tokens k_vocab_lookup found
   Grow<Rec>      d_out;
   // ---- streams / events ----
   hipStream_t stream = nullptr, h2d = nullptr, d2h = nullptr, side = nullptr;
@@ -223,7 +227,7 @@ struct Ctx {
     t_q.release(); t_lo.release(); t_cnt.release(); t_idf.release(); c_qi.release(); keys.release(); seg.release(); qb.release();
     heap.release(); f0.release(); f1.release(); vals.release(); zero_blk.release();
     items.release(); items_b.release(); items_h.release(); cmin_tab.release(); g_rows.release();
-    d_qoff.release(); d_qtok.release(); d_qreal.release(); d_qitok.release(); d_cnt.release(); d_tot.release(); d_out.release(); d_prior.release();
+    d_qoff.release(); d_qtok.release(); d_qreal.release(); d_qitok.release(); d_text.release(); d_vstate.release(); d_cnt.release(); d_tot.release(); d_out.release(); d_prior.release();
     if (stream) (void)hipStreamDestroy(stream);
     if (h2d && !shared_copy) (void)hipStreamDestroy(h2d);
     if (d2h && !shared_copy) (void)hipStreamDestroy(d2h);
@@ -238,6 +242,7 @@ struct Ctx {
     if (ev_chain) (void)hipEventDestroy(ev_chain);
     if (ev_done) (void)hipEventDestroy(ev_done);
     if (h_ctr) (void)hipHostFree(h_ctr);
+    if (h_vtotal) (void)hipHostFree(h_vtotal);
     if (h_small) (void)hipHostFree(h_small);
     if (h_ctr_group) (void)hipHostFree(h_ctr_group);
     for (auto& e : ev_pass) if (e) (void)hipEventDestroy(e);
@@ -296,6 +301,11 @@ struct DeviceIndex::Impl {
   // stream — gain too (C3 5.42 -> 5.35 ms, C2's 100 k-query calls 0.78 -> 0.67 ms): queues cost even when they idle.
   // (FMX_SHARED_COPY=0: a pair per context, as before.)
   hipStream_t             copy_h2d = nullptr, copy_d2h = nullptr;
+  // device copy of the host's spelling table (text batches: fmx_vocab.hip.hh); replaced under itok_mu (exclusive) when the
+  // vocabulary grew, read under the shared lock every matching call holds
+  DevVocab                vocab{};
+  uint64_t                vocab_built_for = 0;
+  std::mutex              vocab_mu;
   std::mutex              pool_mu;
   std::condition_variable pool_cv;
   std::vector<std::unique_ptr<Ctx>> all;
@@ -358,6 +368,7 @@ DeviceIndex::~DeviceIndex() {
     hipFree((void*)m.d.qva); hipFree((void*)m.d.idf); hipFree((void*)m.d.real); hipFree((void*)m.d.itok);
     hipFree((void*)m.d.itok_dist); hipFree((void*)m.d.planes); hipFree((void*)m.d.thermo);
     for (auto& c : m.all) c->destroy();
+    hipFree((void*)m.vocab.slot); hipFree((void*)m.vocab.head); hipFree((void*)m.vocab.arena);
     if (m.copy_h2d) (void)hipStreamDestroy(m.copy_h2d);
     if (m.copy_d2h) (void)hipStreamDestroy(m.copy_d2h);
     m.copy_h2d = m.copy_d2h = nullptr;
@@ -402,6 +413,30 @@ static void refresh_itok_table(DeviceIndex::Impl& m, const HostIndex& h) {
   m.d.n_itok = n;
   if (!dist.empty()) m.d.itok_dist = dev_upload(dist);
   m.itok_version.store(version);
+}
+
+// the device copy of the host's spelling table (text batches): uploaded on first use, replaced when words were added
+static void refresh_vocab_table(DeviceIndex::Impl& m, const HostIndex& h) {
+  const HostIndex::VocabTable t = h.vocab_table();
+  {
+    std::lock_guard<std::mutex> g(m.vocab_mu);
+    if (m.vocab.slot && m.vocab_built_for == t.built_for) return;
+  }
+  std::unique_lock<std::shared_mutex> lk(m.itok_mu);  // no matching call in flight
+  std::lock_guard<std::mutex> g(m.vocab_mu);
+  if (m.vocab.slot && m.vocab_built_for == t.built_for) return;
+  if (t.n_slots == 0) throw std::invalid_argument("text batch on an index without spellings (fmx_index_set_forms)");
+  hipFree((void*)m.vocab.slot); hipFree((void*)m.vocab.head); hipFree((void*)m.vocab.arena);
+  m.vocab = DevVocab{};
+  unsigned long long* ds = dev_alloc<unsigned long long>(t.n_slots);
+  unsigned long long* dh = dev_alloc<unsigned long long>(t.n_slots);
+  unsigned char* da = dev_alloc<unsigned char>(t.arena_bytes + 16);
+  HIP_TRY(hipMemcpy(ds, t.slot, t.n_slots * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dh, t.head, t.n_slots * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(da, 0, t.arena_bytes + 16));
+  if (t.arena_bytes) HIP_TRY(hipMemcpy(da, t.arena, t.arena_bytes, hipMemcpyHostToDevice));
+  m.vocab.slot = ds; m.vocab.head = dh; m.vocab.arena = da; m.vocab.mask = t.n_slots - 1;
+  m.vocab_built_for = t.built_for;
 }
 
 constexpr size_t kDynLdsMax = 150 * 1024;  // dynamic LDS the row kernels may ask for (160 KB per CU on gfx950)
@@ -1313,7 +1348,7 @@ __global__ void k_rebase(uint32_t* off, uint32_t n, uint32_t base) {
 void DeviceIndex::match_host(const HostIndex& h, const Params& prm, const HostBatchView& hb, Rec* out,
                              uint32_t* out_count, uint32_t* out_total, uint32_t cap, Stats* st, Rec* d_keep,
                              uint32_t* d_keep_count) {
-  if (!d_keep && match_host_small(h, prm, hb, out, out_count, out_total, cap, st)) return;
+  if (!d_keep && !hb.text && match_host_small(h, prm, hb, out, out_count, out_total, cap, st)) return;
   match_host_full(h, prm, hb, out, out_count, out_total, cap, st, d_keep, d_keep_count);
 }
 
@@ -1407,12 +1442,22 @@ void DeviceIndex::match_host_full(const HostIndex& h, const Params& prm, const H
   if (nq == 0) return;
   const uint32_t base = hb.q_off[0];
   const uint64_t nt = hb.q_off[nq] - base;
+  if (hb.text && base != 0) throw std::invalid_argument("text batch: offsets must start at 0");
   refresh_itok_table(m, h);
+  if (hb.text) refresh_vocab_table(m, h);
   std::shared_lock<std::shared_mutex> rl(m.itok_mu);
   CtxLease lease(m);
   Ctx& c = *lease.c;
   c.d_qoff.ensure(nq + 1);
   c.d_qtok.ensure(nt + 1);
+  const uint64_t text_tiles = hb.text ? (hb.n_text + (uint64_t)kScanThreads * kVocabChunk - 1) / ((uint64_t)kScanThreads * kVocabChunk) : 0;
+  if (hb.text) {
+    if (hb.q_real || hb.q_itok || m.d.real) throw UnsupportedError("text batches carry no real tokens / penalty tokens: look the ids up on the host");
+    c.d_text.ensure(hb.n_text + 2 * kVocabChunk + 16);
+    c.d_vstate.ensure(text_tiles + 4);
+    if (!c.h_vtotal) HIP_TRY(hipHostMalloc((void**)&c.h_vtotal, sizeof(unsigned long long), hipHostMallocDefault));
+    *c.h_vtotal = ~0ull;
+  }
   if (hb.q_real) c.d_qreal.ensure(nt + 1);
   if (hb.q_itok) c.d_qitok.ensure(nt + nq + 1);
   c.d_out.ensure(nq * cap);
@@ -1467,7 +1512,12 @@ void DeviceIndex::match_host_full(const HostIndex& h, const Params& prm, const H
     HIP_TRY(hipMemcpyAsync(c.d_qoff.p + o_lo, hb.q_off + o_lo, n_off * 4, hipMemcpyHostToDevice, h2d));
     if (base) hipLaunchKernelGGL(k_rebase, dim3((unsigned)((n_off + 255) / 256)), dim3(256), 0, h2d, c.d_qoff.p + o_lo, (uint32_t)n_off, base);
     const uint64_t t0_ = bounds[s], t1_ = bounds[s + 1];
-    if (t1_ > t0_) {
+    if (hb.text) {
+      if (s == 0 && hb.n_text) {  // the whole text with the first pass; the ids are looked up on the compute stream (hooks.before)
+        HIP_TRY(hipMemsetAsync(c.d_text.p + hb.n_text, 0, 2 * kVocabChunk + 16, h2d));
+        HIP_TRY(hipMemcpyAsync(c.d_text.p, hb.text, hb.n_text, hipMemcpyHostToDevice, h2d));
+      }
+    } else if (t1_ > t0_) {
       HIP_TRY(hipMemcpyAsync(c.d_qtok.p + t0_, hb.q_tok + base + t0_, (t1_ - t0_) * 4, hipMemcpyHostToDevice, h2d));
       if (hb.q_real) HIP_TRY(hipMemcpyAsync(c.d_qreal.p + t0_, hb.q_real + base + t0_, (t1_ - t0_) * 4, hipMemcpyHostToDevice, h2d));
     }
@@ -1537,6 +1587,14 @@ void DeviceIndex::match_host_full(const HostIndex& h, const Params& prm, const H
   hooks.before = [&](uint32_t s) {
     if (s == 0 && !first_sent) send(0);
     HIP_TRY(hipStreamWaitEvent(c.stream, c.ev_in[s % kMaxPassesInFlight], 0));
+    if (s == 0 && hb.text && hb.n_text) {  // spellings -> ids, for every pass of the call
+      HIP_TRY(hipMemsetAsync(c.d_vstate.p, 0, (text_tiles + 4) * sizeof(unsigned long long), c.stream));
+      unsigned long long* d_total = nullptr;
+      HIP_TRY(hipHostGetDevicePointer((void**)&d_total, c.h_vtotal, 0));
+      hipLaunchKernelGGL(k_vocab_lookup, dim3((unsigned)text_tiles), dim3(kScanThreads), 0, c.stream, (const unsigned char*)c.d_text.p,
+                         (unsigned long long)hb.n_text, (unsigned long long)nt, m.vocab, c.d_qtok.p, c.d_vstate.p,
+                         reinterpret_cast<uint32_t*>(c.d_vstate.p + text_tiles + 1), d_total);
+    }
     if (s + 1 < n_sub) send(s + 1);  // travels while pass s computes
   };
   hooks.enqueued = [&](hipEvent_t last) {
@@ -1550,6 +1608,8 @@ void DeviceIndex::match_host_full(const HostIndex& h, const Params& prm, const H
   const auto a = std::chrono::steady_clock::now();
   HIP_TRY(hipEventRecord(c.ev_done, d2h));
   HIP_TRY(hipEventSynchronize(c.ev_done));
+  if (hb.text && hb.n_text && *c.h_vtotal != nt)
+    throw std::invalid_argument("text batch: the text holds " + std::to_string(*c.h_vtotal) + " spellings, the offsets count " + std::to_string(nt));
   ms_d2h += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
   if (st) {
     st->ms_h2d += ms_h2d;   // host time spent enqueuing / staging; with pinned buffers the copies overlap the passes

@@ -91,6 +91,11 @@ const HostIndex::FastVocab& HostIndex::fast_vocab() const {
   return f;
 }
 
+HostIndex::VocabTable HostIndex::vocab_table() const {
+  const FastVocab& f = fast_vocab();
+  return VocabTable{f.slot.data(), f.head.data(), f.arena.data(), (uint64_t)f.slot.size(), (uint64_t)f.arena.size(), f.built_for.load()};
+}
+
 void HostIndex::get_indices(const char* const* toks, uint64_t n, uint32_t* ids, int nthreads) const {
   const FastVocab& f = fast_vocab();
   auto work = [&](uint64_t lo, uint64_t hi) {

@@ -116,6 +116,9 @@ class HostIndex {
   // per token: an open-addressing table over the packed spellings (built on first use, rebuilt when words were added),
   // spread over `nthreads` host threads
   void get_indices(const char* const* toks, uint64_t n, uint32_t* ids, int nthreads) const;
+  // the spelling table behind get_indices, for its device copy (fmx_vocab.hip.hh); built_for = forms.size() it was built from
+  struct VocabTable { const uint64_t* slot; const uint64_t* head; const char* arena; uint64_t n_slots, arena_bytes, built_for; };
+  VocabTable vocab_table() const;
   // attach spellings to an id-only index (ids 2 .. n - 1; bulk-built corpora): vocabulary lookups then work on it
   void set_forms(const char* const* spellings, uint64_t n);
 

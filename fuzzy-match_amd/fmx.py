@@ -50,6 +50,11 @@ class Batch(C.Structure):
                 ("q_real", C.c_void_p), ("q_itok", C.c_void_p), ("max_len", C.c_uint32)]
 
 
+class TextBatch(C.Structure):
+    """fmx_text_batch: patterns as NUL-terminated token spellings back to back."""
+    _fields_ = [("nq", C.c_uint64), ("q_off", C.c_void_p), ("text", C.c_void_p), ("n_bytes", C.c_uint64)]
+
+
 class Stats(C.Structure):
     _fields_ = [("ms_total", C.c_double), ("ms_h2d", C.c_double), ("ms_d2h", C.c_double),
                 ("ms_kernel", C.c_double * 16), ("launches", C.c_uint64 * 16),
@@ -73,7 +78,7 @@ EXPORTS = [
     "fmx_index_free", "fmx_index_load", "fmx_index_save", "fmx_index_add_tm", "fmx_index_add_ids",
     "fmx_index_sort", "fmx_index_finalize", "fmx_index_to_device", "fmx_vocab_lookup",
     "fmx_index_lookup_real", "fmx_index_intern_itok", "fmx_index_sentence_id", "fmx_index_array",
-    "fmx_index_get_info", "fmx_match_batch", "fmx_match_batch_device", "fmx_set_option",
+    "fmx_index_get_info", "fmx_match_batch", "fmx_match_batch_text", "fmx_match_batch_device", "fmx_set_option",
     "fmx_host_alloc", "fmx_host_free", "fmx_index_to_devices", "fmx_set_devices", "fmx_index_reopen", "fmx_match_one", "fmx_match_batch_keep",
     "fmx_subsequence_batch", "fmx_text_tokenize", "fmx_text_free", "fmx_text_num_tokens", "fmx_text_norm", "fmx_text_real",
     "fmx_text_num_itoks", "fmx_text_itok_index", "fmx_text_itok", "fmx_text_num_raw", "fmx_text_raw", "fmx_text_map",
@@ -127,6 +132,8 @@ def lib():
     L.fmx_index_array.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     L.fmx_index_device_array.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.fmx_index_get_info.argtypes = [C.c_void_p, C.POINTER(Info)]
+    L.fmx_match_batch_text.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(TextBatch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                       C.POINTER(Stats)]
     L.fmx_match_batch.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Batch), C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_uint32, C.POINTER(Stats)]
     L.fmx_match_batch_keep.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Batch), C.c_void_p, C.c_void_p,
@@ -468,6 +475,27 @@ class Index:
         else:
             _check(lib().fmx_match_batch(self.h, C.byref(params), C.byref(b), _ptr(out), _ptr(cnt), _ptr(tot), cap,
                                          C.byref(st)))
+        res = (out[:nq], cnt[:nq], tot[:nq])
+        return res + (st,) if want_stats else res
+
+    def match_batch_text(self, params, q_off, text, cap=None, want_stats=False, out=None):
+        """fmx_match_batch_text: the patterns as token spellings (uint8 array: NUL-terminated spellings back to back, q_off in
+        tokens); the vocabulary ids are looked up on the device."""
+        q_off = np.ascontiguousarray(q_off, dtype=np.uint32)
+        text = np.ascontiguousarray(text, dtype=np.uint8)
+        nq = len(q_off) - 1
+        if cap is None:
+            cap = params.nmatch if params.nmatch > 0 else 64
+        if out is not None:
+            out, cnt, tot = out
+            assert out.shape[0] >= nq and out.shape[1] == cap and out.dtype == MATCH_DTYPE
+        else:
+            out = np.zeros((max(nq, 1), cap), dtype=MATCH_DTYPE)
+            cnt = np.zeros(max(nq, 1), dtype=np.uint32)
+            tot = np.zeros(max(nq, 1), dtype=np.uint32)
+        b = TextBatch(nq, _ptr(q_off), _ptr(text), len(text))
+        st = Stats()
+        _check(lib().fmx_match_batch_text(self.h, C.byref(params), C.byref(b), _ptr(out), _ptr(cnt), _ptr(tot), cap, C.byref(st)))
         res = (out[:nq], cnt[:nq], tot[:nq])
         return res + (st,) if want_stats else res
 

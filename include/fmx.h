@@ -228,6 +228,21 @@ int fmx_match_batch(fmx_index*, const fmx_params*, const fmx_batch* host_batch,
 int fmx_match_batch_keep(fmx_index*, const fmx_params*, const fmx_batch* host_batch,
                          fmx_match* out, uint32_t* out_count, uint32_t* out_total, uint32_t cap,
                          fmx_match* d_keep, uint32_t* d_keep_count, fmx_stats* stats);
+/* fmx_match_batch with the patterns as token SPELLINGS instead of vocabulary ids: q_off[nq] NUL-terminated, non-empty
+ * spellings back to back in `text` (n_bytes bytes; pinned memory for asynchronous copies), q_off[0] == 0.  The per-pattern
+ * host prep of match() — VocabIndexer::getIndex per token, src/fuzzy_match.cc:468-470, src/vocab_indexer.cc:52-60 — runs on
+ * the device (k_vocab_lookup: token starts by a scan over the bytes, one look-up per start in the device copy of the spelling
+ * table; unknown spellings are VOCAB_UNK).  For indexes whose real tokens equal their normalised tokens (no penalty tokens,
+ * no case / joiner features): otherwise FMX_E_UNSUPPORTED — use fmx_vocab_lookup_mt + fmx_match_batch.  FMX_E_INVALID when
+ * the text does not hold exactly q_off[nq] spellings. */
+typedef struct fmx_text_batch {
+  uint64_t        nq;
+  const uint32_t* q_off;    /* nq + 1 offsets in tokens */
+  const char*     text;
+  uint64_t        n_bytes;
+} fmx_text_batch;
+int fmx_match_batch_text(fmx_index*, const fmx_params*, const fmx_text_batch*, fmx_match* out, uint32_t* out_count,
+                         uint32_t* out_total, uint32_t cap, fmx_stats* stats);
 /* Same with every buffer already in the HBM of the index's device; `stream` is a hipStream_t
  * (NULL = a stream of the library after a device-wide synchronisation).  total_tokens = q_off[nq] when q_off[0] == 0, else
  * 0 (with it and max_len set, a batch of one pass needs no device read up front).  Work is enqueued on `stream`; the call

@@ -1,0 +1,94 @@
+"""fmx_match_batch_text: the patterns arrive as token spellings and the vocabulary ids are looked up ON THE DEVICE
+(k_vocab_lookup).  Same records as fmx_match_batch on the ids the host's getIndex gives (VocabIndexer::getIndex,
+src/vocab_indexer.cc:52-60: unknown spellings are VOCAB_UNK), which the rest of the suite checks against the oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _spelling(k):
+    """deterministic spellings of every length class: one to seven bytes, exactly eight, longer, shared eight-byte prefixes"""
+    base = "w%d" % k
+    if k % 7 == 3:
+        return ("prefix__" + base).encode()       # longer than eight bytes, the first eight shared by many
+    if k % 7 == 5:
+        return ("%08d" % k).encode()              # exactly eight bytes
+    if k % 11 == 0:
+        return ("été%d" % k).encode()   # multi-byte UTF-8
+    return base.encode()
+
+
+def _pack(words):
+    return np.frombuffer(b"".join(w + b"\0" for w in words), dtype=np.uint8).copy()
+
+
+@pytest.fixture(scope="module")
+def text_index(fmx, gpu_device):
+    rng = np.random.default_rng(3)
+    vocab = 3000
+    lens = rng.integers(3, 30, 20000)
+    c_off = np.zeros(len(lens) + 1, np.uint32)
+    c_off[1:] = np.cumsum(lens)
+    # Zipf-ish ids so that n-grams repeat
+    c_tok = (2 + np.minimum((rng.pareto(1.2, int(c_off[-1])) * 3).astype(np.int64), vocab - 1)).astype(np.uint32)
+    ix = fmx.Index.create()
+    ix.add_ids(c_off, c_tok, vocab + 2)
+    ix.sort(gpu_device)
+    ix.finalize()
+    words = [b"", b""] + [_spelling(k) for k in range(vocab)]
+    offs = np.full(len(words), 0xffffffffffffffff, np.uint64)
+    pos = 0
+    for k in range(2, len(words)):
+        offs[k] = pos
+        pos += len(words[k]) + 1
+    arena = _pack(words[2:])
+    ix.set_forms_packed(arena, offs)
+    ix.to_device(gpu_device)
+    return ix, words, c_off, c_tok, vocab, arena
+
+
+def _queries(rng, words, c_off, c_tok, vocab, n):
+    toks, lens = [], []
+    for _ in range(n):
+        s = int(rng.integers(0, len(c_off) - 1))
+        t = [words[i] for i in c_tok[c_off[s]:c_off[s + 1]]]
+        for _ in range(int(rng.integers(0, 3))):
+            j = int(rng.integers(0, len(t)))
+            r = rng.random()
+            if r < 0.4:
+                t[j] = b"never-seen-%d" % int(rng.integers(0, 1000))   # unknown: VOCAB_UNK
+            elif r < 0.6:
+                t[j] = words[2 + int(rng.integers(0, vocab))][:-1] or b"x"  # a proper prefix of a spelling: unknown too (mostly)
+            else:
+                t[j] = words[2 + int(rng.integers(0, vocab))]
+        toks += t
+        lens.append(len(t))
+    q_off = np.zeros(n + 1, np.uint32)
+    q_off[1:] = np.cumsum(lens)
+    return q_off, toks
+
+
+@pytest.mark.parametrize("n,seed", [(1, 0), (37, 1), (5000, 2), (60000, 3)])
+def test_text_batches_equal_id_batches(fmx, text_index, n, seed):
+    ix, words, c_off, c_tok, vocab, _ = text_index
+    rng = np.random.default_rng(seed)
+    q_off, toks = _queries(rng, words, c_off, c_tok, vocab, n)
+    ids = ix.vocab_lookup([t.decode("utf-8") for t in toks])
+    assert (ids == 1).any() or n < 10
+    for kw in (dict(fuzzy=0.6, nmatch=5), dict(fuzzy=0.8, nmatch=2, no_perfect=True)):
+        want = ix.match_batch(fmx.Params(**kw), q_off, ids)
+        got = ix.match_batch_text(fmx.Params(**kw), q_off, _pack(toks))
+        assert np.array_equal(want[1], got[1]) and np.array_equal(want[2], got[2]), (n, kw)
+        for q in range(n):
+            assert want[0][q, :want[1][q]].tobytes() == got[0][q, :got[1][q]].tobytes(), (n, kw, q)
+    assert int((want[1] > 0).sum()) > 0
+
+
+def test_text_batch_with_the_wrong_number_of_spellings_is_refused(fmx, text_index):
+    ix, words, c_off, c_tok, vocab, _ = text_index
+    q_off = np.asarray([0, 3, 5], np.uint32)
+    with pytest.raises(Exception):
+        ix.match_batch_text(fmx.Params(fuzzy=0.6), q_off, _pack([b"w1", b"w2", b"w4", b"w8"]))  # four spellings, five tokens
+    got = ix.match_batch_text(fmx.Params(fuzzy=0.6), q_off, _pack([b"w1", b"w2", b"w4", b"w8", b"w9"]))
+    assert len(got[1]) == 2
