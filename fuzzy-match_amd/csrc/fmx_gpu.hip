@@ -368,7 +368,7 @@ DeviceIndex::~DeviceIndex() {
     hipFree((void*)m.d.qva); hipFree((void*)m.d.idf); hipFree((void*)m.d.real); hipFree((void*)m.d.itok);
     hipFree((void*)m.d.itok_dist); hipFree((void*)m.d.planes); hipFree((void*)m.d.thermo);
     for (auto& c : m.all) c->destroy();
-    hipFree((void*)m.vocab.slot); hipFree((void*)m.vocab.head); hipFree((void*)m.vocab.arena);
+    hipFree((void*)m.vocab.entry); hipFree((void*)m.vocab.arena);
     if (m.copy_h2d) (void)hipStreamDestroy(m.copy_h2d);
     if (m.copy_d2h) (void)hipStreamDestroy(m.copy_d2h);
     m.copy_h2d = m.copy_d2h = nullptr;
@@ -420,22 +420,22 @@ static void refresh_vocab_table(DeviceIndex::Impl& m, const HostIndex& h) {
   const HostIndex::VocabTable t = h.vocab_table();
   {
     std::lock_guard<std::mutex> g(m.vocab_mu);
-    if (m.vocab.slot && m.vocab_built_for == t.built_for) return;
+    if (m.vocab.entry && m.vocab_built_for == t.built_for) return;
   }
   std::unique_lock<std::shared_mutex> lk(m.itok_mu);  // no matching call in flight
   std::lock_guard<std::mutex> g(m.vocab_mu);
-  if (m.vocab.slot && m.vocab_built_for == t.built_for) return;
+  if (m.vocab.entry && m.vocab_built_for == t.built_for) return;
   if (t.n_slots == 0) throw std::invalid_argument("text batch on an index without spellings (fmx_index_set_forms)");
-  hipFree((void*)m.vocab.slot); hipFree((void*)m.vocab.head); hipFree((void*)m.vocab.arena);
+  hipFree((void*)m.vocab.entry); hipFree((void*)m.vocab.arena);
   m.vocab = DevVocab{};
-  unsigned long long* ds = dev_alloc<unsigned long long>(t.n_slots);
-  unsigned long long* dh = dev_alloc<unsigned long long>(t.n_slots);
+  std::vector<ulonglong2> ent(t.n_slots);  // slot and head side by side: one 16-byte load per probe
+  for (uint64_t k = 0; k < t.n_slots; k++) { ent[k].x = t.slot[k]; ent[k].y = t.head[k]; }
+  ulonglong2* de = dev_alloc<ulonglong2>(t.n_slots);
   unsigned char* da = dev_alloc<unsigned char>(t.arena_bytes + 16);
-  HIP_TRY(hipMemcpy(ds, t.slot, t.n_slots * 8, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(dh, t.head, t.n_slots * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(de, ent.data(), t.n_slots * sizeof(ulonglong2), hipMemcpyHostToDevice));
   HIP_TRY(hipMemset(da, 0, t.arena_bytes + 16));
   if (t.arena_bytes) HIP_TRY(hipMemcpy(da, t.arena, t.arena_bytes, hipMemcpyHostToDevice));
-  m.vocab.slot = ds; m.vocab.head = dh; m.vocab.arena = da; m.vocab.mask = t.n_slots - 1;
+  m.vocab.entry = de; m.vocab.arena = da; m.vocab.mask = t.n_slots - 1;
   m.vocab_built_for = t.built_for;
 }
 
