@@ -92,3 +92,21 @@ def test_text_batch_with_the_wrong_number_of_spellings_is_refused(fmx, text_inde
         ix.match_batch_text(fmx.Params(fuzzy=0.6), q_off, _pack([b"w1", b"w2", b"w4", b"w8"]))  # four spellings, five tokens
     got = ix.match_batch_text(fmx.Params(fuzzy=0.6), q_off, _pack([b"w1", b"w2", b"w4", b"w8", b"w9"]))
     assert len(got[1]) == 2
+
+
+def test_text_batch_over_several_passes(fmx, text_index):
+    """A text batch cut into several pipeline passes: the ids of every pass come from the one look-up ahead of the first."""
+    ix, words, c_off, c_tok, vocab, _ = text_index
+    rng = np.random.default_rng(9)
+    q_off, toks = _queries(rng, words, c_off, c_tok, vocab, 7000)
+    ids = ix.vocab_lookup([t.decode("utf-8") for t in toks])
+    kw = dict(fuzzy=0.6, nmatch=5)
+    want = ix.match_batch(fmx.Params(**kw), q_off, ids)
+    try:
+        ix.set_option("host_sub_queries", 1500)
+        got = ix.match_batch_text(fmx.Params(**kw), q_off, _pack(toks))
+    finally:
+        ix.set_option("host_sub_queries", 1 << 20)
+    assert np.array_equal(want[1], got[1])
+    for q in range(len(q_off) - 1):
+        assert want[0][q, :want[1][q]].tobytes() == got[0][q, :got[1][q]].tobytes(), q
