@@ -788,7 +788,9 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
     // light queries (k_caps_scan): at most light_max hits, all in short ranges, pattern of at most one wave
     const uint32_t light_max = b.nq ? std::min<uint32_t>(m.light_max, kPhaseBChunk) : 0u;
     // two queries per wave in the last kernel (k_finish_pair): no contrastive rerank, lowest_costs fits half a wave
-    const bool pair_finish = m.pair_finish && !(prm.contrast > 0.f) && prm.cbuf > 0 && prm.cbuf <= (int)kPairMax - 2;
+    // (with or without a contrastive factor; any contrast_buffer: beyond 30 entries the pair kernel takes 31 candidates per query)
+    const bool pair_finish = m.pair_finish && prm.cbuf > 0;
+    const uint32_t pair_max = prm.cbuf <= (int)kPairMax - 2 ? kPairMax : kPairMax - 1;
     {
       // capacities, one scan over two arrays (queue offsets of the queries phase A walks, segment offsets of the light queries)
       // and the work-item list of phase A in one launch
@@ -881,7 +883,7 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
       hipLaunchKernelGGL(k_classify, dim3((n_scan + 255) / 256), dim3(256), 0, stream, b, w, full ? 1 : 0);
       hipLaunchKernelGGL(k_scan_lb<3>, dim3(scan_tiles), dim3(kScanThreads), 0, stream, w.c_in, w.c_off, (size_t)n_scan, n_scan,
                          c.scan_state(2), c.scan_ticket(2));
-      hipLaunchKernelGGL(k_cmap, dim3((b.nq + 1023) / 1024), dim3(1024), 0, stream, b, w, full ? 1 : 0, c.fin_list.p, pair_finish ? kPairMax : (uint32_t)kWave);
+      hipLaunchKernelGGL(k_cmap, dim3((b.nq + 1023) / 1024), dim3(1024), 0, stream, b, w, full ? 1 : 0, c.fin_list.p, pair_finish ? pair_max : (uint32_t)kWave);
     }
     tick(); tick();
     {
@@ -931,7 +933,8 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
       hipLaunchKernelGGL((k_finish<kLdsSortMax, true>), dim3(2048), dim3(kWave), 0, side, m.d, b, w, prm, DevScratch{c.keys.p, c.vals.p, c.f0.p, c.f1.p}, cap,
                          d_out, d_out_count, d_out_total, c.contrast_list.p, c.fin_list.p);
       if (pair_finish)
-        hipLaunchKernelGGL(k_finish_pair, dim3((b.nq + 1) / 2), dim3(kWave), 0, stream, b, w, prm, cap, d_out, d_out_count, d_out_total);
+        hipLaunchKernelGGL(k_finish_pair, dim3((b.nq + 1) / 2), dim3(kWave), 0, stream, b, w, prm, cap, d_out, d_out_count, d_out_total, pair_max,
+                           c.contrast_list.p);
       else
         hipLaunchKernelGGL((k_finish<64, false>), dim3(b.nq), dim3(kWave), 0, stream, m.d, b, w, prm, DevScratch{c.keys.p, c.vals.p, c.f0.p, c.f1.p}, cap, d_out,
                          d_out_count, d_out_total, c.contrast_list.p, c.fin_list.p);

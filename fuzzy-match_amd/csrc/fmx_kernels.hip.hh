@@ -2855,8 +2855,12 @@ __device__ __forceinline__ void half_sort64_kv_n(unsigned long long& key, uint32
     }
   }
 }
+// pair_max: 32 candidates per query while lowest_costs is capped below 32 entries (contrast_buffer <= 30), else 31 — the bound
+// list then never holds more than the candidates + 1 = 32 entries, one per lane of the half.  With a contrastive factor the
+// accepted matches are not ranked and emitted but compacted to the head of the segment for the rerank kernels, like k_finish does.
 __global__ void __launch_bounds__(kWave) k_finish_pair(DevBatch b, DevWork w, Params prm, uint32_t cap, Rec* out_rec,
-                                                       uint32_t* out_count, uint32_t* out_total) {
+                                                       uint32_t* out_count, uint32_t* out_total, uint32_t pair_max,
+                                                       uint32_t* contrast_list) {
   __shared__ float s_score[kWave];
   __shared__ uint32_t s_sid[kWave], s_L[kWave];
   const uint32_t lane = lane_id(), hl = lane & 31u, base = lane & 32u;
@@ -2864,14 +2868,16 @@ __global__ void __launch_bounds__(kWave) k_finish_pair(DevBatch b, DevWork w, Pa
   const bool have = q < b.nq;
   const uint32_t gq = b.q_begin + (have ? q : 0u);
   const uint32_t n_cand = have ? w.q_cand[q] : 0u;
-  const bool act_q = have && n_cand != 0 && n_cand <= kPairMax;  // larger sets were queued by k_cmap for the list kernel
-  uint32_t p = 0;
+  const bool act_q = have && n_cand != 0 && n_cand <= pair_max;  // larger sets were queued by k_cmap for the list kernel
+  const bool contrast = prm.contrast > 0.f;
+  uint32_t p = 0, my_slen = 0;
   bool maybe = false;
   float my_cost = 0.f, my_M = 0.f, my_score = 0.f;
   if (act_q) p = b.q_off[gq + 1] - b.q_off[gq];
   if (act_q && hl < n_cand) {
     const Cand cd = w.seg[w.q_seg[q] + hl];
     const uint32_t slen = cd.longest >> 16;
+    my_slen = slen;
     my_cost = cd.score; my_M = cd.penalty; my_score = score_from_cost(cd.score);
     s_sid[lane] = cd.sid; s_L[lane] = cd.longest & 0xffffu; s_score[lane] = my_score;
     maybe = !(prm.no_perfect && cd.score == 0.f && slen == p);
@@ -2899,13 +2905,37 @@ __global__ void __launch_bounds__(kWave) k_finish_pair(DevBatch b, DevWork w, Pa
     }
   }
   const uint32_t n_acc = (uint32_t)__popc(acc);
+  if (contrast) {  // wave-uniform: the accepted matches to the head of the segment in candidate order, the class of the rerank
+    const bool mine_c = act_q && ((acc >> hl) & 1u);
+    uint32_t mx = mine_c ? my_slen : 0u;
+#pragma unroll
+    for (int d2 = 16; d2 >= 1; d2 >>= 1) { const uint32_t o = __shfl_xor(mx, d2, 64); mx = o > mx ? o : mx; }  // within the half
+    wave_lds_sync();
+    if (mine_c) {
+      Cand a;
+      a.sid = s_sid[lane]; a.longest = s_L[lane]; a.score = my_score; a.penalty = 0.f;
+      w.seg[w.q_seg[q] + (uint32_t)__popc(acc & ((1u << hl) - 1u))] = a;  // every lane read its own candidate at the top
+    }
+    if (have && hl == 0 && n_cand <= pair_max) {
+      uint32_t qa = act_q ? n_acc : 0u;
+      if (act_q && n_acc != 0 && (mx > 32 || n_acc > kMaxFlatAccepted || b.n_prior != 0)) {
+        const uint32_t cls = (mx <= 64 && n_acc <= kMaxFlatAccepted && b.n_prior == 0) ? 1u : 2u;
+        const bool flat = prm.nmatch >= 1 && prm.nmatch <= kMaxFlatRounds;
+        if (cls == 2 || !flat) contrast_list[(size_t)(cls - 1) * b.nq + atomicAdd(&w.counters[9 + cls], 1ull)] = q;
+        qa |= cls << 30;
+      }
+      w.q_acc[q] = qa;
+      if (!act_q) { out_count[gq] = 0u; if (out_total) out_total[gq] = 0u; }  // no candidates: nothing for the rerank to write
+    }
+    return;
+  }
   const uint32_t want = prm.nmatch == 0 ? n_acc : (prm.nmatch < n_acc ? prm.nmatch : n_acc);
   const uint32_t emit = want < cap ? want : cap;
   const bool mine = act_q && ((acc >> hl) & 1u);
   // ascending key = score desc, s_id asc (sentence ids are unique within a candidate set); each half is sorted on its own
   unsigned long long key = mine ? (((unsigned long long)(~float_key(my_score)) << 32) | s_sid[lane]) : ~0ull;
   uint32_t idx = hl;
-  uint32_t n_max = n_cand <= kPairMax ? n_cand : 0u;
+  uint32_t n_max = n_cand <= pair_max ? n_cand : 0u;
   { const uint32_t o = __shfl_xor(n_max, 32, 64); n_max = o > n_max ? o : n_max; }
   n_max = __builtin_amdgcn_readfirstlane(n_max);
   if (n_max > 16) half_sort64_kv_n<32>(key, idx);
@@ -2917,7 +2947,7 @@ __global__ void __launch_bounds__(kWave) k_finish_pair(DevBatch b, DevWork w, Pa
     r.score = s_score[base + idx]; r.penalty = 0.f; r.max_subseq = (int32_t)s_L[base + idx]; r.s_id = s_sid[base + idx];
     out_rec[(unsigned long long)gq * cap + hl] = r;
   }
-  if (have && hl == 0 && n_cand <= kPairMax) {
+  if (have && hl == 0 && n_cand <= pair_max) {
     w.q_acc[q] = act_q ? n_acc : 0u;
     out_count[gq] = act_q ? emit : 0u;
     if (out_total) out_total[gq] = act_q ? want : 0u;
