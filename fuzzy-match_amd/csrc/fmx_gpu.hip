@@ -949,7 +949,7 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
           hipLaunchKernelGGL(k_cacc, dim3((n_scan + 255) / 256), dim3(256), 0, stream, b, w);
           hipLaunchKernelGGL(k_scan_lb<2>, dim3(scan_tiles), dim3(kScanThreads), 0, stream, w.c_in, w.c_off, (size_t)n_scan, n_scan,
                              c.scan_state(3), c.scan_ticket(3));
-          hipLaunchKernelGGL(k_camap, dim3(b.nq), dim3(kWave), 0, stream, m.d, b, w, sc, prm, d_out_count, d_out_total);
+          hipLaunchKernelGGL(k_camap, dim3((b.nq + kWave / kCamapGroup - 1) / (kWave / kCamapGroup)), dim3(kWave), 0, stream, m.d, b, w, sc, prm, d_out_count, d_out_total);
           // round r: the match picked in round r - 1 emits itself, the others bid for round r's pick
           // (the two length classes hold different queries: their rounds are two independent chains, one per stream)
           if (m.d.max_slen > 32) {

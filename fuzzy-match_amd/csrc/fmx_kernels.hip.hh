@@ -3029,9 +3029,8 @@ __global__ void k_cacc(DevBatch b, DevWork w) {
 
 // wave per query: the flat list of (query, accepted match) pairs, each match's rank in list order and sentence position,
 // the bid of round 0 (penalties are zero: the best score, first in list order)
-__global__ void __launch_bounds__(kWave) k_camap(DevIndex ix, DevBatch b, DevWork w, DevScratch sc, Params prm, uint32_t* out_count,
-                                                 uint32_t* out_total) {
-  const uint32_t q = blockIdx.x;
+__device__ __forceinline__ void camap_query(const DevIndex& ix, const DevBatch& b, const DevWork& w, const DevScratch& sc, const Params& prm,
+                                            uint32_t* out_count, uint32_t* out_total, uint32_t q) {
   if (w.q_cand[q] == 0) return;  // k_finish wrote the empty result
   const uint32_t acc = w.q_acc[q];
   const uint32_t cls = acc >> 30, n = acc & 0x3fffffffu;
@@ -3080,6 +3079,65 @@ __global__ void __launch_bounds__(kWave) k_camap(DevIndex ix, DevBatch b, DevWor
     best = o > best ? o : best;
   }
   if (lane == 0) { w.q_best[q] = best; w.q_best[(size_t)b.nq + q] = 0; w.q_best[2 * (size_t)b.nq + q] = 0; }
+}
+
+// k_camap: FOUR queries per wave, sixteen lanes each (a query of the rerank has ~7 accepted matches: one wave per query ran a
+// tenth full); a wave whose four queries do not all fit (more than 16 accepted matches) takes them one after the other with
+// the whole wave.
+constexpr uint32_t kCamapGroup = 16;
+__global__ void __launch_bounds__(kWave) k_camap(DevIndex ix, DevBatch b, DevWork w, DevScratch sc, Params prm, uint32_t* out_count,
+                                                 uint32_t* out_total) {
+  const uint32_t lane = lane_id(), gl = lane & (kCamapGroup - 1), gb = lane & ~(kCamapGroup - 1);
+  const uint32_t q0 = blockIdx.x * (kWave / kCamapGroup);
+  const uint32_t q = q0 + lane / kCamapGroup;
+  bool work = false;      // this lane's query takes part in the flattened rerank
+  uint32_t n = 0, cls = 0;
+  if (q < b.nq && w.q_cand[q] != 0) {
+    const uint32_t acc = w.q_acc[q];
+    cls = acc >> 30; n = acc & 0x3fffffffu;
+    work = cls < 2;
+  }
+  if (__ballot(work && n > kCamapGroup)) {  // (wave-uniform)
+    for (uint32_t k = 0; k < kWave / kCamapGroup; k++)
+      if (q0 + k < b.nq) camap_query(ix, b, w, sc, prm, out_count, out_total, q0 + k);
+    return;
+  }
+  if (work && n == 0 && gl == 0) { out_count[b.q_begin + q] = 0; if (out_total) out_total[b.q_begin + q] = 0; }
+  uint32_t n_max = work ? n : 0u;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(n_max, d, 64); n_max = o > n_max ? o : n_max; }
+  if (n_max == 0) return;
+  const bool mine = work && gl < n;
+  const size_t stride = (size_t)b.nq + 1;
+  unsigned long long base = 0, seg0 = 0;
+  Cand c;
+  c.sid = 0; c.longest = 0; c.score = 0.f; c.penalty = 0.f;
+  if (mine) {
+    base = w.c_off[cls * stride + q];
+    if (cls == 1) base += w.c_off[b.nq];
+    seg0 = w.q_seg[q];
+    c = w.seg[seg0 + gl];
+  }
+  uint32_t rank = 0;
+  for (uint32_t j = 0; j < n_max; j++) {
+    const float os = __shfl(c.score, (int)(gb + j), 64);
+    const uint32_t oid = __shfl(c.sid, (int)(gb + j), 64);
+    rank += (j < n && (os > c.score || (os == c.score && oid < c.sid))) ? 1u : 0u;
+  }
+  unsigned long long best = 0;
+  if (mine) {
+    w.c_qi[base + gl] = ((unsigned long long)q << 32) | gl;
+    sc.f0[seg0 + gl] = 0.f; sc.f1[seg0 + gl] = 0.f;
+    sc.keys[2ull * seg0 + gl] = (unsigned long long)rank << 32;
+    sc.vals[2ull * seg0 + gl] = ix.sent_pos[c.sid];
+    best = contrast_bid(c.score - (prm.contrast * 0.f), rank, gl);
+  }
+#pragma unroll
+  for (int d = kCamapGroup / 2; d >= 1; d >>= 1) {
+    const unsigned long long o = ((unsigned long long)__shfl_xor((uint32_t)(best >> 32), d, 64) << 32) | __shfl_xor((uint32_t)best, d, 64);
+    best = o > best ? o : best;
+  }
+  if (work && n != 0 && gl == 0) { w.q_best[q] = best; w.q_best[(size_t)b.nq + q] = 0; w.q_best[2 * (size_t)b.nq + q] = 0; }
 }
 
 template <int P>
