@@ -725,6 +725,12 @@ struct PassEnv {
   uint32_t prior_max_len;  // longest prior match of the batch (rows of the general contrast kernel must hold it)
 };
 
+// grid of the flattened rerank rounds (grid-stride over the flat list): design-time switch FMX_CROUND_GRID = workgroups per CU
+static unsigned cround_grid(int p) {
+  static const int per_cu = [] { const char* e = getenv("FMX_CROUND_GRID"); return e ? atoi(e) : 0; }();
+  if (per_cu > 0) return 256u * (unsigned)per_cu;
+  return p == 32 ? 256u * 64u : 256u * 32u;  // (16 / 8 per CU until round 3: at 64 the stage is 0.3 ms shorter — six waves per SIMD instead of four)
+}
 // every launch of one pass, in stream order; the pass counters land in h_ctr_slot (pinned).  No host synchronisation.
 static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool timing, unsigned long long* h_ctr_slot) {
   DeviceIndex::Impl& m = E.m;
@@ -955,10 +961,10 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
           if (m.d.max_slen > 32) {
             fork();
             for (uint32_t r = 1; r <= prm.nmatch; r++)
-              hipLaunchKernelGGL(k_cround<64>, dim3(256 * 8), dim3(kWave), 0, side, m.d, b, w, prm, sc, r, cap, d_out, d_out_count, d_out_total);
+              hipLaunchKernelGGL(k_cround<64>, dim3(cround_grid(64)), dim3(kWave), 0, side, m.d, b, w, prm, sc, r, cap, d_out, d_out_count, d_out_total);
           }
           for (uint32_t r = 1; r <= prm.nmatch; r++)
-            hipLaunchKernelGGL(k_cround<32>, dim3(256 * 16), dim3(kWave), 0, stream, m.d, b, w, prm, sc, r, cap, d_out, d_out_count, d_out_total);
+            hipLaunchKernelGGL(k_cround<32>, dim3(cround_grid(32)), dim3(kWave), 0, stream, m.d, b, w, prm, sc, r, cap, d_out, d_out_count, d_out_total);
           if (m.d.max_slen > 32) join();
         } else {
           hipLaunchKernelGGL(k_contrast<0>, dim3(b.nq), dim3(kWave), 0, stream, m.d, b, w, prm, sc, cap, d_out,
