@@ -895,7 +895,8 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
     {
       const size_t lds = ((size_t)p_max + 1) * kWave * 4;
       const bool rows_in_hbm = lds > kDynLdsMax;  // patterns too long for LDS rows: same kernel over rows in HBM
-      const unsigned grid = 256 * 16;  // grid-stride over the flat candidate list
+      static const unsigned dp_per_cu = [] { const char* e = getenv("FMX_DP_GRID"); return e ? (unsigned)atoi(e) : 16u; }();  // design-time switch
+      const unsigned grid = 256 * dp_per_cu;  // grid-stride over the flat candidate list
       const unsigned grid_g = 1024;
       if (rows_in_hbm) c.g_rows.ensure((uint64_t)grid_g * kWave * (p_max + 1));
       auto launch_rows = [&](bool with_side) {
