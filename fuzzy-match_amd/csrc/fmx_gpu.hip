@@ -1598,12 +1598,14 @@ void DeviceIndex::match_host_full(const HostIndex& h, const Params& prm, const H
     if (s == 0 && !first_sent) send(0);
     HIP_TRY(hipStreamWaitEvent(c.stream, c.ev_in[s % kMaxPassesInFlight], 0));
     if (s == 0 && hb.text && hb.n_text) {  // spellings -> ids, for every pass of the call
-      HIP_TRY(hipMemsetAsync(c.d_vstate.p, 0, (text_tiles + 4) * sizeof(unsigned long long), c.stream));
       unsigned long long* d_total = nullptr;
       HIP_TRY(hipHostGetDevicePointer((void**)&d_total, c.h_vtotal, 0));
+      uint32_t* tile_count = reinterpret_cast<uint32_t*>(c.d_vstate.p);
+      hipLaunchKernelGGL(k_vocab_count, dim3((unsigned)text_tiles), dim3(kScanThreads), 0, c.stream, (const unsigned char*)c.d_text.p,
+                         (unsigned long long)hb.n_text, tile_count);
+      hipLaunchKernelGGL(k_vocab_scan, dim3(1), dim3(kScanThreads), 0, c.stream, tile_count, (uint32_t)text_tiles, d_total);
       hipLaunchKernelGGL(k_vocab_lookup, dim3((unsigned)text_tiles), dim3(kScanThreads), 0, c.stream, (const unsigned char*)c.d_text.p,
-                         (unsigned long long)hb.n_text, (unsigned long long)nt, m.vocab, c.d_qtok.p, c.d_vstate.p,
-                         reinterpret_cast<uint32_t*>(c.d_vstate.p + text_tiles + 1), d_total);
+                         (unsigned long long)hb.n_text, (unsigned long long)nt, m.vocab, c.d_qtok.p, (const uint32_t*)tile_count);
     }
     if (s + 1 < n_sub) send(s + 1);  // travels while pass s computes
   };

@@ -1,8 +1,8 @@
 // fmx_vocab.hip.hh — VocabIndexer::getIndex (src/vocab_indexer.cc:52-60; the per-pattern host prep of match(),
 // src/fuzzy_match.cc:468-470) for a whole batch ON THE DEVICE: the batch arrives as token SPELLINGS — NUL-terminated, back to
-// back, what a tokenizer writes — and leaves as vocabulary ids in HBM, in token order.  One kernel: every thread takes
-// kVocabChunk bytes of the text, marks the token starts in them, the tile scans the counts (look-back over the tiles: the
-// rank of a token is the number of starts in front of it) and every start is looked up in the device copy of the host's
+// back, what a tokenizer writes — and leaves as vocabulary ids in HBM, in token order.  Every thread takes
+// kVocabChunk bytes of the text and marks the token starts in them; the rank of a token is the number of starts in front of
+// it (counts per tile, a scan of the tile counts, a scan inside the tile); every start is looked up in the device copy of the host's
 // spelling table (HostIndex::FastVocab: open addressing, the first eight bytes beside every slot, the spellings in an arena;
 // same hash).  Unknown spellings get VOCAB_UNK (1), like getIndex.
 #pragma once
@@ -18,14 +18,9 @@ struct DevVocab {
   unsigned long long   mask;
 };
 
-// text: n_bytes bytes followed by at least kVocabChunk + 16 zero bytes, 16-byte aligned.  ids: n_tok words.  total: the
-// number of tokens found (the host compares it with the offsets it was given).
-__global__ void __launch_bounds__(kScanThreads) k_vocab_lookup(const unsigned char* __restrict__ text, unsigned long long n_bytes,
-                                                              unsigned long long n_tok, DevVocab v, uint32_t* __restrict__ ids,
-                                                              unsigned long long* state, uint32_t* ticket, unsigned long long* total) {
-  const uint32_t tile = scan_ticket_take(ticket);
-  const unsigned long long b0 = ((unsigned long long)tile * kScanThreads + threadIdx.x) * kVocabChunk;
-  unsigned long long starts = 0;
+// Token starts of the kVocabChunk bytes at b0 (bit i = a spelling starts at byte b0 + i)
+__device__ __forceinline__ uint32_t vocab_starts(const unsigned char* __restrict__ text, unsigned long long b0, unsigned long long n_bytes) {
+  uint32_t starts = 0;
   if (b0 < n_bytes) {
     unsigned char prev = b0 ? text[b0 - 1] : (unsigned char)0;
 #pragma unroll
@@ -35,15 +30,67 @@ __global__ void __launch_bounds__(kScanThreads) k_vocab_lookup(const unsigned ch
 #pragma unroll
       for (uint32_t k = 0; k < 16; k++) {
         const unsigned char c = (unsigned char)(xs[k >> 2] >> (8 * (k & 3)));
-        if (c != 0 && prev == 0 && b0 + 16 * w + k < n_bytes) starts |= 1ull << (16 * w + k);
+        if (c != 0 && prev == 0 && b0 + 16 * w + k < n_bytes) starts |= 1u << (16 * w + k);
         prev = c;
       }
     }
   }
-  unsigned long long sum[1] = {(unsigned long long)__popcll(starts)}, ex[1];
-  scan_tile_lb<1>(tile, sum, ex, state);
-  unsigned long long rank = ex[0];
-  if (b0 < n_bytes && b0 + kVocabChunk >= n_bytes) *total = rank + sum[0];  // the thread that holds the last byte
+  return starts;
+}
+
+// Pass 1: spellings per tile of kScanThreads x kVocabChunk bytes.  (A single-pass look-back scan over the ~5000 tiles of a
+// million queries was a chain of ~0.1 us per tile — 0.41 ms; three short kernels without a chain take a third of that.)
+__global__ void __launch_bounds__(kScanThreads) k_vocab_count(const unsigned char* __restrict__ text, unsigned long long n_bytes,
+                                                             uint32_t* __restrict__ tile_count) {
+  __shared__ uint32_t s_w[kScanThreads / kWave];
+  const unsigned long long b0 = ((unsigned long long)blockIdx.x * kScanThreads + threadIdx.x) * kVocabChunk;
+  uint32_t n = wave_sum((uint32_t)__popc(vocab_starts(text, b0, n_bytes)));
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = n;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t t = 0;
+    for (uint32_t k = 0; k < kScanThreads / kWave; k++) t += s_w[k];
+    tile_count[blockIdx.x] = t;
+  }
+}
+
+// Pass 2: exclusive scan of the tile counts by ONE workgroup (in place); total[0] = the number of spellings.
+__global__ void __launch_bounds__(kScanThreads) k_vocab_scan(uint32_t* tile_count, uint32_t n_tiles, unsigned long long* total) {
+  __shared__ uint32_t s_w[kScanThreads / kWave];
+  __shared__ uint32_t s_run;
+  if (threadIdx.x == 0) s_run = 0;
+  __syncthreads();
+  for (uint32_t t0 = 0; t0 < n_tiles; t0 += kScanThreads) {
+    const uint32_t t = t0 + threadIdx.x;
+    const uint32_t v = t < n_tiles ? tile_count[t] : 0u;
+    const uint32_t incl = wave_incl_scan(v);
+    if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (uint32_t k = 0; k < (threadIdx.x >> 6); k++) wbase += s_w[k];
+    const uint32_t run = s_run;
+    if (t < n_tiles) tile_count[t] = run + wbase + incl - v;
+    __syncthreads();
+    if (threadIdx.x == kScanThreads - 1) s_run = run + wbase + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total = s_run;
+}
+
+// Pass 3: text: n_bytes bytes followed by at least kVocabChunk + 16 zero bytes, 16-byte aligned.  ids: n_tok words.
+__global__ void __launch_bounds__(kScanThreads) k_vocab_lookup(const unsigned char* __restrict__ text, unsigned long long n_bytes,
+                                                              unsigned long long n_tok, DevVocab v, uint32_t* __restrict__ ids,
+                                                              const uint32_t* __restrict__ tile_base) {
+  __shared__ uint32_t s_w[kScanThreads / kWave];
+  const unsigned long long b0 = ((unsigned long long)blockIdx.x * kScanThreads + threadIdx.x) * kVocabChunk;
+  unsigned long long starts = vocab_starts(text, b0, n_bytes);
+  const uint32_t cnt = (uint32_t)__popcll(starts);
+  const uint32_t incl = wave_incl_scan(cnt);
+  if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = incl;
+  __syncthreads();
+  uint32_t wbase = 0;
+  for (uint32_t k = 0; k < (threadIdx.x >> 6); k++) wbase += s_w[k];
+  unsigned long long rank = (unsigned long long)tile_base[blockIdx.x] + wbase + incl - cnt;
   while (starts) {
     const uint32_t i = (uint32_t)__builtin_ctzll(starts);
     starts &= starts - 1ull;
@@ -72,6 +119,7 @@ __global__ void __launch_bounds__(kScanThreads) k_vocab_lookup(const unsigned ch
     bool ended = false;
 #pragma unroll
     for (uint32_t k = 0; k < 16; k++) {
+      if ((k & 3) == 0 && k != 0 && __ballot(!ended) == 0ull) break;  // every spelling of the wave is through (most are short)
       const unsigned char c = (unsigned char)(tw[k >> 2] >> (8 * (k & 3)));
       ended = ended || c == 0;
       if (!ended) {
