@@ -467,6 +467,9 @@ int fmx_match_batch_text(fmx_index* ix, const fmx_params* params, const fmx_text
                          uint32_t* out_count, uint32_t* out_total, uint32_t cap, fmx_stats* stats) {
   if (!ix || !params || !tb || !out || !out_count) return fail(FMX_E_INVALID, "null argument");
   if (tb->nq && (!tb->q_off || (tb->q_off[tb->nq] && !tb->text))) return fail(FMX_E_INVALID, "null batch arrays");
+  if (tb->nq && tb->q_off[0] != 0) return fail(FMX_E_INVALID, "text batch: offsets must start at 0");
+  // the text must hold exactly q_off[nq] spellings; every spelling takes at least its terminator
+  if (tb->nq && tb->q_off[tb->nq] > tb->n_bytes) return fail(FMX_E_INVALID, "text batch: fewer bytes than spellings counted by the offsets");
   if (cap == 0) return fail(FMX_E_INVALID, "cap must be > 0");
   if (!ix->finalized) return fail(FMX_E_STATE, "index is not finalized");
   if (ix->devs.empty()) return fail(FMX_E_NO_DEVICE, "index is not on a device (fmx_index_to_device); there is no CPU path");

@@ -99,6 +99,13 @@ template <class T> struct Grow {
   void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+// device allocations owned by whoever holds the last reference (see Impl::tab_mu)
+struct DevBlob {
+  void* a = nullptr;
+  void* b = nullptr;
+  ~DevBlob() { if (a) (void)hipFree(a); if (b) (void)hipFree(b); }
+};
+
 constexpr int kMaxPassesInFlight = 2;
 constexpr uint64_t kTurnMinQueries = 262144;  // device-resident calls at least this large are chained on the GPU (Impl::turns), smaller ones overlap freely
 constexpr uint64_t kTurnMinQueriesHost = 32768;  // host-buffer calls: chained from here on (their copies interleave badly when the kernels of
@@ -255,7 +262,14 @@ struct DeviceIndex::Impl {
   DevIndex d{};
   uint64_t bytes = 0;
   std::atomic<uint64_t> itok_version{~0ull};
-  std::shared_mutex itok_mu;  // matching calls hold it shared; a grown penalty-string table swaps under exclusive
+  // The two tables that may be replaced while calls are in flight — the penalty-string distance table (a query interned a new
+  // string) and the device copy of the spelling table (words were added) — are reference-counted: a call pins the pair it was
+  // enqueued with (pin_tables), a refresh swaps the pointers under tab_mu and the old memory is freed when its last call is
+  // through.  No lock is held across a call: a thread with calls pending (fmx_match_batch_device_begin) may intern a string,
+  // issue its first text batch or refresh a table without deadlocking against itself, and never starves another thread's refresh.
+  std::mutex              tab_mu;
+  std::mutex              refresh_mu;   // one refresh at a time (the upload happens outside tab_mu)
+  std::shared_ptr<DevBlob> itok_hold, vocab_hold;
   // options
   uint32_t sub_queries = 1u << 20;       // queries per pipeline pass: large passes amortise the ~40 launches and their tails
   uint32_t host_sub_queries = 1u << 20;  // pass size of the host-buffer entry point (see match_host)
@@ -301,17 +315,17 @@ struct DeviceIndex::Impl {
   // stream — gain too (C3 5.42 -> 5.35 ms, C2's 100 k-query calls 0.78 -> 0.67 ms): queues cost even when they idle.
   // (FMX_SHARED_COPY=0: a pair per context, as before.)
   hipStream_t             copy_h2d = nullptr, copy_d2h = nullptr;
-  // device copy of the host's spelling table (text batches: fmx_vocab.hip.hh); replaced under itok_mu (exclusive) when the
-  // vocabulary grew, read under the shared lock every matching call holds
+  // device copy of the host's spelling table (text batches: fmx_vocab.hip.hh); replaced (under tab_mu) when the vocabulary
+  // changed; a call reads the copy it pinned
   DevVocab                vocab{};
-  uint64_t                vocab_built_for = 0;
-  std::mutex              vocab_mu;
+  uint64_t                vocab_built_for = ~0ull;
   std::mutex              pool_mu;
   std::condition_variable pool_cv;
   std::vector<std::unique_ptr<Ctx>> all;
   std::vector<Ctx*>       idle;
 
-  Ctx* acquire() {
+  // wait = false: nullptr instead of waiting when every context is busy (check and take are one critical section)
+  Ctx* acquire(bool wait = true) {
     std::unique_lock<std::mutex> lk(pool_mu);
     for (;;) {
       if (!idle.empty()) { Ctx* c = idle.back(); idle.pop_back(); return c; }
@@ -332,6 +346,7 @@ struct DeviceIndex::Impl {
         try { c->init(sh, sd); } catch (...) { lk.lock(); idle.push_back(c); pool_cv.notify_one(); throw; }
         return c;
       }
+      if (!wait) return nullptr;
       pool_cv.wait(lk);
     }
   }
@@ -339,17 +354,13 @@ struct DeviceIndex::Impl {
     { std::lock_guard<std::mutex> lk(pool_mu); idle.push_back(c); }
     pool_cv.notify_one();
   }
-  // true when acquire() would not have to wait for another call to finish
-  bool context_available() {
-    std::lock_guard<std::mutex> lk(pool_mu);
-    return !idle.empty() || all.size() < max_ctx;
-  }
 };
 
 struct CtxLease {
   DeviceIndex::Impl& m;
   Ctx* c;
-  explicit CtxLease(DeviceIndex::Impl& m_) : m(m_), c(m_.acquire()) {
+  explicit CtxLease(DeviceIndex::Impl& m_, bool no_wait = false) : m(m_), c(m_.acquire(!no_wait)) {
+    if (!c) throw std::invalid_argument("every context of the index is busy: end a pending call first, or raise the option \"contexts\"");
     if (!c->ok) { Ctx* bad = c; c = nullptr; m.release(bad); throw GpuError("context initialisation failed earlier"); }
   }
   void release_now() { if (c) { m.release(c); c = nullptr; } }
@@ -366,9 +377,9 @@ DeviceIndex::~DeviceIndex() {
     (void)hipDeviceSynchronize();
     hipFree((void*)m.d.suf); hipFree((void*)m.d.suf_sig); hipFree((void*)m.d.suf_key); hipFree((void*)m.d.gram.g3); hipFree((void*)m.d.gram.g5); hipFree((void*)m.d.suf_b); hipFree((void*)m.d.tok); hipFree((void*)m.d.sent_pos);
     hipFree((void*)m.d.qva); hipFree((void*)m.d.idf); hipFree((void*)m.d.real); hipFree((void*)m.d.itok);
-    hipFree((void*)m.d.itok_dist); hipFree((void*)m.d.planes); hipFree((void*)m.d.thermo);
+    hipFree((void*)m.d.planes); hipFree((void*)m.d.thermo);
     for (auto& c : m.all) c->destroy();
-    hipFree((void*)m.vocab.entry); hipFree((void*)m.vocab.arena);
+    m.itok_hold.reset(); m.vocab_hold.reset();
     if (m.copy_h2d) (void)hipStreamDestroy(m.copy_h2d);
     if (m.copy_d2h) (void)hipStreamDestroy(m.copy_d2h);
     m.copy_h2d = m.copy_d2h = nullptr;
@@ -398,20 +409,46 @@ void     DeviceIndex::set_contexts(uint32_t n) {
   impl_->max_ctx = std::max<uint32_t>(std::max<uint32_t>(n, 1), (uint32_t)impl_->all.size());
 }
 
-// the penalty-string distance table grows when queries intern new strings: swap it in while no call runs
+// what a call pins for its lifetime: the penalty-string table and the spelling table it was enqueued with
+struct TableSnap {
+  std::shared_ptr<DevBlob> itok_hold, vocab_hold;
+  const uint16_t* itok_dist = nullptr;
+  uint32_t        n_itok = 0;
+  DevVocab        vocab{};
+};
+static TableSnap pin_tables(DeviceIndex::Impl& m) {
+  std::lock_guard<std::mutex> g(m.tab_mu);
+  TableSnap s;
+  s.itok_hold = m.itok_hold; s.vocab_hold = m.vocab_hold;
+  s.itok_dist = m.d.itok_dist; s.n_itok = m.d.n_itok; s.vocab = m.vocab;
+  return s;
+}
+// the index's device view as a call sees it: the immutable arrays + the pinned tables
+static DevIndex dev_view(const DeviceIndex::Impl& m, const TableSnap& s) {
+  DevIndex d = m.d;
+  d.itok_dist = s.itok_dist; d.n_itok = s.n_itok;
+  return d;
+}
+
+// the penalty-string distance table grows when queries intern new strings: the new table is uploaded beside the old one and
+// swapped in; calls in flight keep the table they pinned
 static void refresh_itok_table(DeviceIndex::Impl& m, const HostIndex& h) {
   if (m.itok_version.load() == h.itok_version.load()) return;
-  std::unique_lock<std::shared_mutex> lk(m.itok_mu);
+  std::lock_guard<std::mutex> one(m.refresh_mu);
   if (m.itok_version.load() == h.itok_version.load()) return;
   // a consistent (table, string count, version) triple: another thread may be interning a string right now
   std::vector<uint16_t> dist;
   uint32_t n = 0;
   uint64_t version = 0;
   h.snapshot_itok_dist(dist, n, version);
-  hipFree((void*)m.d.itok_dist);
-  m.d.itok_dist = nullptr;
-  m.d.n_itok = n;
-  if (!dist.empty()) m.d.itok_dist = dev_upload(dist);
+  std::shared_ptr<DevBlob> blob(new DevBlob);
+  if (!dist.empty()) blob->a = dev_upload(dist);
+  {
+    std::lock_guard<std::mutex> g(m.tab_mu);
+    m.itok_hold = blob;
+    m.d.itok_dist = (const uint16_t*)blob->a;
+    m.d.n_itok = n;
+  }
   m.itok_version.store(version);
 }
 
@@ -419,22 +456,28 @@ static void refresh_itok_table(DeviceIndex::Impl& m, const HostIndex& h) {
 static void refresh_vocab_table(DeviceIndex::Impl& m, const HostIndex& h) {
   const HostIndex::VocabTable t = h.vocab_table();
   {
-    std::lock_guard<std::mutex> g(m.vocab_mu);
+    std::lock_guard<std::mutex> g(m.tab_mu);
     if (m.vocab.entry && m.vocab_built_for == t.built_for) return;
   }
-  std::unique_lock<std::shared_mutex> lk(m.itok_mu);  // no matching call in flight
-  std::lock_guard<std::mutex> g(m.vocab_mu);
-  if (m.vocab.entry && m.vocab_built_for == t.built_for) return;
+  std::lock_guard<std::mutex> one(m.refresh_mu);
+  {
+    std::lock_guard<std::mutex> g(m.tab_mu);
+    if (m.vocab.entry && m.vocab_built_for == t.built_for) return;
+  }
   if (t.n_slots == 0) throw std::invalid_argument("text batch on an index without spellings (fmx_index_set_forms)");
-  hipFree((void*)m.vocab.entry); hipFree((void*)m.vocab.arena);
-  m.vocab = DevVocab{};
   std::vector<ulonglong2> ent(t.n_slots);  // slot and head side by side: one 16-byte load per probe
   for (uint64_t k = 0; k < t.n_slots; k++) { ent[k].x = t.slot[k]; ent[k].y = t.head[k]; }
+  std::shared_ptr<DevBlob> blob(new DevBlob);
   ulonglong2* de = dev_alloc<ulonglong2>(t.n_slots);
+  blob->a = de;
   unsigned char* da = dev_alloc<unsigned char>(t.arena_bytes + 16);
+  blob->b = da;
   HIP_TRY(hipMemcpy(de, ent.data(), t.n_slots * sizeof(ulonglong2), hipMemcpyHostToDevice));
   HIP_TRY(hipMemset(da, 0, t.arena_bytes + 16));
   if (t.arena_bytes) HIP_TRY(hipMemcpy(da, t.arena, t.arena_bytes, hipMemcpyHostToDevice));
+  std::lock_guard<std::mutex> g(m.tab_mu);
+  m.vocab_hold = blob;
+  m.vocab = DevVocab{};
   m.vocab.entry = de; m.vocab.arena = da; m.vocab.mask = t.n_slots - 1;
   m.vocab_built_for = t.built_for;
 }
@@ -717,6 +760,8 @@ struct PassHooks {
 struct PassEnv {
   DeviceIndex::Impl& m;
   Ctx& c;
+  TableSnap snap;  // the replaceable tables this call pinned
+  DevIndex d;      // the index as this call's kernels see it
   Params prm;
   bool full, use_idf;
   Rec* d_out; uint32_t* d_out_count; uint32_t* d_out_total;
@@ -756,7 +801,7 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
     // the signature bound needs theoretical_rejection_cover to be monotone in the cover: costs >= 0
     const int use_sig = prm.ins >= 0.f && prm.del >= 0.f && prm.rep >= 0.f;
     // suffix ranges of at least heavy_min hits are walked through the signature bit planes (k_expand_h)
-    const uint32_t heavy_min = (use_sig && m.d.planes && m.heavy_min) ? std::max<uint32_t>(m.heavy_min, 256u) : 0xffffffffu;
+    const uint32_t heavy_min = (use_sig && E.d.planes && m.heavy_min) ? std::max<uint32_t>(m.heavy_min, 256u) : 0xffffffffu;
     // fork: `side` continues after everything enqueued on `stream` so far; join: `stream` waits for `side`
     const hipStream_t side = m.serial ? stream : c.side;
     auto fork = [&]() { if (!m.serial) { HIP_TRY(hipEventRecord(c.ev_fork, stream)); HIP_TRY(hipStreamWaitEvent(c.side, c.ev_fork, 0)); } };
@@ -765,30 +810,30 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
     // the phase-A threshold table depends on the parameters only: computed on the side stream while the probe runs
     // (after the fork: the previous pass, which read the table, is complete)
     const float cmin_key[4] = {prm.fuzzy, prm.ins, prm.del, prm.rep};
-    const bool cmin_cached = c.cmin_ptr == c.cmin_tab.p && c.cmin_sig == use_sig && c.cmin_maxslen == m.d.max_slen && c.cmin_pmax >= p_max &&
+    const bool cmin_cached = c.cmin_ptr == c.cmin_tab.p && c.cmin_sig == use_sig && c.cmin_maxslen == E.d.max_slen && c.cmin_pmax >= p_max &&
                              memcmp(c.cmin_key, cmin_key, sizeof cmin_key) == 0;
     // beside the probe, on the side stream: the threshold table (unless the pass before asked for the same) and the pattern-length
     // ranks (only k_classify, after the expand stage's join, reads them)
     fork();
     if (!cmin_cached) {
-      hipLaunchKernelGGL(k_cmin, dim3(p_max + 1), dim3(256), 0, side, m.d.max_slen, prm, use_sig, c.cmin_tab.p);
+      hipLaunchKernelGGL(k_cmin, dim3(p_max + 1), dim3(256), 0, side, E.d.max_slen, prm, use_sig, c.cmin_tab.p);
       if (!m.serial) HIP_TRY(hipEventRecord(c.ev_cmin, c.side));
       memcpy(c.cmin_key, cmin_key, sizeof cmin_key);
-      c.cmin_ptr = c.cmin_tab.p; c.cmin_sig = use_sig; c.cmin_maxslen = m.d.max_slen; c.cmin_pmax = p_max;
+      c.cmin_ptr = c.cmin_tab.p; c.cmin_sig = use_sig; c.cmin_maxslen = E.d.max_slen; c.cmin_pmax = p_max;
     }
     {
       const uint32_t per_block = kRankThreads * kRankPer;
       hipLaunchKernelGGL(k_phist, dim3((b.nq + per_block - 1) / per_block), dim3(kRankThreads), 0, side, b, w);
       hipLaunchKernelGGL(k_prank, dim3((b.nq + per_block - 1) / per_block), dim3(kRankThreads), 0, side, b, w);
     }
-    hipLaunchKernelGGL(k_setup, dim3((b.nq + 1 + 255) / 256), dim3(256), 0, stream, m.d, b, w, prm);
-    if (prm.idf_penalty != 0.f) hipLaunchKernelGGL(k_tidf, dim3((b.nt + 255) / 256), dim3(256), 0, stream, m.d, b, w);
+    hipLaunchKernelGGL(k_setup, dim3((b.nq + 1 + 255) / 256), dim3(256), 0, stream, E.d, b, w, prm);
+    if (prm.idf_penalty != 0.f) hipLaunchKernelGGL(k_tidf, dim3((b.nt + 255) / 256), dim3(256), 0, stream, E.d, b, w);
     tick(); tick();
     if (b.nt) {
       if (m.probe_count)  // measurement runs only: the same kernel, also counting the bytes / lines it requests
-        hipLaunchKernelGGL(k_probe<true>, dim3((b.nt + kProbeBlock - 1) / kProbeBlock), dim3(kProbeBlock), 0, stream, m.d, b, w, heavy_min, c.items_h.p, item_h_cap);
+        hipLaunchKernelGGL(k_probe<true>, dim3((b.nt + kProbeBlock - 1) / kProbeBlock), dim3(kProbeBlock), 0, stream, E.d, b, w, heavy_min, c.items_h.p, item_h_cap);
       else
-        hipLaunchKernelGGL(k_probe<false>, dim3((b.nt + kProbeBlock - 1) / kProbeBlock), dim3(kProbeBlock), 0, stream, m.d, b, w, heavy_min, c.items_h.p, item_h_cap);
+        hipLaunchKernelGGL(k_probe<false>, dim3((b.nt + kProbeBlock - 1) / kProbeBlock), dim3(kProbeBlock), 0, stream, E.d, b, w, heavy_min, c.items_h.p, item_h_cap);
     }
     tick(); tick();
     // light queries (k_caps_scan): at most light_max hits, all in short ranges, pattern of at most one wave
@@ -829,21 +874,21 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
       fork();
       side_tick(kStageExpandH, 0);
       if (heavy_min != 0xffffffffu)
-        hipLaunchKernelGGL(k_expand_h, dim3(grid_h), dim3(kWave), 0, side, m.d, b, w, prm, (const HeavyItem*)c.items_h.p, item_h_cap);
+        hipLaunchKernelGGL(k_expand_h, dim3(grid_h), dim3(kWave), 0, side, E.d, b, w, prm, (const HeavyItem*)c.items_h.p, item_h_cap);
       side_tick(kStageExpandH, 1);
       // phase A of the queries that are not light: block q = query q (light_max == 0) or a work-item list
-      hipLaunchKernelGGL(k_expand_a, dim3((light_max ? 0u : b.nq) + grid_l), dim3(kWave), 0, stream, m.d, b, w, prm,
+      hipLaunchKernelGGL(k_expand_a, dim3((light_max ? 0u : b.nq) + grid_l), dim3(kWave), 0, stream, E.d, b, w, prm,
                          (const WorkItem*)c.items.p, item_cap, use_sig, light_max ? 0u : b.nq);
       if (m.expand_order == 0) {
         if (!m.serial) { HIP_TRY(hipEventRecord(c.ev_a, stream)); HIP_TRY(hipStreamWaitEvent(c.side, c.ev_a, 0)); }
         tick(); tick();
         side_tick(kStageExpandB, 0);
         second_scan(side);
-        hipLaunchKernelGGL(k_expand_b<false>, dim3((light_max ? 0u : b.nq) + grid_b), dim3(kWave), lds, side, m.d, b, w, prm,
+        hipLaunchKernelGGL(k_expand_b<false>, dim3((light_max ? 0u : b.nq) + grid_b), dim3(kWave), lds, side, E.d, b, w, prm,
                            (const WorkItem*)c.items_b.p, item_cap, light_max ? 0u : b.nq);
         side_tick(kStageExpandB, 1);
         if (light_max)
-          hipLaunchKernelGGL(k_expand_b<true>, dim3(b.nq), dim3(kWave), lds, stream, m.d, b, w, prm, (const WorkItem*)nullptr, 0u, b.nq);
+          hipLaunchKernelGGL(k_expand_b<true>, dim3(b.nq), dim3(kWave), lds, stream, E.d, b, w, prm, (const WorkItem*)nullptr, 0u, b.nq);
         tick(); tick();
       } else {
         // long ranges first (k_expand_h next to k_expand_a), then the two k_expand_b side by side: the one for the queries
@@ -855,12 +900,12 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
         second_scan(stream);
         fork();
         side_tick(kStageExpandB, 0);
-        hipLaunchKernelGGL(k_expand_b<false>, dim3((light_max ? 0u : b.nq) + grid_b), dim3(kWave), lds, side, m.d, b, w, prm,
+        hipLaunchKernelGGL(k_expand_b<false>, dim3((light_max ? 0u : b.nq) + grid_b), dim3(kWave), lds, side, E.d, b, w, prm,
                            (const WorkItem*)c.items_b.p, item_cap, light_max ? 0u : b.nq);
         side_tick(kStageExpandB, 1);
         if (light_max) {
           if (!m.serial) hipLaunchKernelGGL(k_lag, dim3(1), dim3(kWave), 0, stream, w.counters);
-          hipLaunchKernelGGL(k_expand_b<true>, dim3(b.nq), dim3(kWave), lds, stream, m.d, b, w, prm, (const WorkItem*)nullptr, 0u, b.nq);
+          hipLaunchKernelGGL(k_expand_b<true>, dim3(b.nq), dim3(kWave), lds, stream, E.d, b, w, prm, (const WorkItem*)nullptr, 0u, b.nq);
         }
         tick(); tick();
       }
@@ -875,7 +920,7 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
       // it runs on the side stream next to k_cand_mid (disjoint queries).
       // radix passes needed: sentence ids < n_sent, match lengths <= longest pattern
       uint32_t sid_bytes = 1, len_bytes = p_max < 255 ? 1u : 2u;
-      while (sid_bytes < 4 && (m.d.n_sent >> (8 * sid_bytes)) != 0) sid_bytes++;
+      while (sid_bytes < 4 && (E.d.n_sent >> (8 * sid_bytes)) != 0) sid_bytes++;
       fork();
       hipLaunchKernelGGL(k_cand_big, dim3(kBigGrid), dim3(kBigThreads), 0, side, w, c.keys.p,
                          (const uint32_t*)c.big_list.p, sid_bytes, len_bytes);
@@ -901,11 +946,11 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
       if (rows_in_hbm) c.g_rows.ensure((uint64_t)grid_g * kWave * (p_max + 1));
       auto launch_rows = [&](bool with_side) {
         if (with_side) {
-          if (rows_in_hbm) hipLaunchKernelGGL((k_dp<true, true>), dim3(grid_g), dim3(kWave), 0, stream, m.d, b, w, prm, c.g_rows.p, p_max + 1);
-          else hipLaunchKernelGGL((k_dp<true, false>), dim3(grid), dim3(kWave), lds, stream, m.d, b, w, prm, (float*)nullptr, 0u);
+          if (rows_in_hbm) hipLaunchKernelGGL((k_dp<true, true>), dim3(grid_g), dim3(kWave), 0, stream, E.d, b, w, prm, c.g_rows.p, p_max + 1);
+          else hipLaunchKernelGGL((k_dp<true, false>), dim3(grid), dim3(kWave), lds, stream, E.d, b, w, prm, (float*)nullptr, 0u);
         } else {
-          if (rows_in_hbm) hipLaunchKernelGGL((k_dp<false, true>), dim3(grid_g), dim3(kWave), 0, stream, m.d, b, w, prm, c.g_rows.p, p_max + 1);
-          else hipLaunchKernelGGL((k_dp<false, false>), dim3(grid), dim3(kWave), lds, stream, m.d, b, w, prm, (float*)nullptr, 0u);
+          if (rows_in_hbm) hipLaunchKernelGGL((k_dp<false, true>), dim3(grid_g), dim3(kWave), 0, stream, E.d, b, w, prm, c.g_rows.p, p_max + 1);
+          else hipLaunchKernelGGL((k_dp<false, false>), dim3(grid), dim3(kWave), lds, stream, E.d, b, w, prm, (float*)nullptr, 0u);
         }
       };
       if (full) {
@@ -917,16 +962,16 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
         const bool two = p_max > 32;
         if (two) fork();
         if (use_idf) {
-          if (two) hipLaunchKernelGGL((k_dp_reg<64, true>), dim3(grid), dim3(kWave), 0, side, m.d, b, w, prm);
-          hipLaunchKernelGGL((k_dp_reg<32, true>), dim3(grid), dim3(kWave), 0, stream, m.d, b, w, prm);
+          if (two) hipLaunchKernelGGL((k_dp_reg<64, true>), dim3(grid), dim3(kWave), 0, side, E.d, b, w, prm);
+          hipLaunchKernelGGL((k_dp_reg<32, true>), dim3(grid), dim3(kWave), 0, stream, E.d, b, w, prm);
         } else if (prm.ins == prm.del && prm.del == prm.rep && prm.rep >= 0.f) {
           // unit costs: bit-parallel Levenshtein distance, then the float sum the DP would have produced
           // few registers: eight waves per SIMD hide the dependent loads in front of every candidate
-          if (two) hipLaunchKernelGGL((k_dp_reg<64, false, true>), dim3(grid), dim3(kWave), 0, side, m.d, b, w, prm);
-          hipLaunchKernelGGL((k_dp_reg<32, false, true>), dim3(grid), dim3(kWave), 0, stream, m.d, b, w, prm);
+          if (two) hipLaunchKernelGGL((k_dp_reg<64, false, true>), dim3(grid), dim3(kWave), 0, side, E.d, b, w, prm);
+          hipLaunchKernelGGL((k_dp_reg<32, false, true>), dim3(grid), dim3(kWave), 0, stream, E.d, b, w, prm);
         } else {
-          if (two) hipLaunchKernelGGL((k_dp_reg<64, false>), dim3(grid), dim3(kWave), 0, side, m.d, b, w, prm);
-          hipLaunchKernelGGL((k_dp_reg<32, false>), dim3(grid), dim3(kWave), 0, stream, m.d, b, w, prm);
+          if (two) hipLaunchKernelGGL((k_dp_reg<64, false>), dim3(grid), dim3(kWave), 0, side, E.d, b, w, prm);
+          hipLaunchKernelGGL((k_dp_reg<32, false>), dim3(grid), dim3(kWave), 0, stream, E.d, b, w, prm);
         }
         if (p_max > 64) launch_rows(use_idf);
         if (two) join();
@@ -937,52 +982,52 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
       // the queue of large candidate sets was filled by k_cmap: their (long, mostly sequential) replay runs on the
       // side stream next to the bulk kernel; the two touch disjoint queries
       fork();
-      hipLaunchKernelGGL((k_finish<kLdsSortMax, true>), dim3(2048), dim3(kWave), 0, side, m.d, b, w, prm, DevScratch{c.keys.p, c.vals.p, c.f0.p, c.f1.p}, cap,
+      hipLaunchKernelGGL((k_finish<kLdsSortMax, true>), dim3(2048), dim3(kWave), 0, side, E.d, b, w, prm, DevScratch{c.keys.p, c.vals.p, c.f0.p, c.f1.p}, cap,
                          d_out, d_out_count, d_out_total, c.contrast_list.p, c.fin_list.p);
       if (pair_finish)
         hipLaunchKernelGGL(k_finish_pair, dim3((b.nq + 1) / 2), dim3(kWave), 0, stream, b, w, prm, cap, d_out, d_out_count, d_out_total, pair_max,
                            c.contrast_list.p);
       else
-        hipLaunchKernelGGL((k_finish<64, false>), dim3(b.nq), dim3(kWave), 0, stream, m.d, b, w, prm, DevScratch{c.keys.p, c.vals.p, c.f0.p, c.f1.p}, cap, d_out,
+        hipLaunchKernelGGL((k_finish<64, false>), dim3(b.nq), dim3(kWave), 0, stream, E.d, b, w, prm, DevScratch{c.keys.p, c.vals.p, c.f0.p, c.f1.p}, cap, d_out,
                          d_out_count, d_out_total, c.contrast_list.p, c.fin_list.p);
       join();
       const DevScratch sc{c.keys.p, c.vals.p, c.f0.p, c.f1.p};
       if (prm.contrast > 0.f) {
         const uint32_t* cl = c.contrast_list.p;
         const bool flat = prm.nmatch >= 1 && prm.nmatch <= kMaxFlatRounds;
-        const uint32_t row_tokens = std::max<uint32_t>(m.d.max_slen, E.prior_max_len);  // longest "pattern" side of the rerank's DP
+        const uint32_t row_tokens = std::max<uint32_t>(E.d.max_slen, E.prior_max_len);  // longest "pattern" side of the rerank's DP
         if (flat) {
           // flattened rounds: pick, then one edit distance per remaining accepted match of any query
           hipLaunchKernelGGL(k_cacc, dim3((n_scan + 255) / 256), dim3(256), 0, stream, b, w);
           hipLaunchKernelGGL(k_scan_lb<2>, dim3(scan_tiles), dim3(kScanThreads), 0, stream, w.c_in, w.c_off, (size_t)n_scan, n_scan,
                              c.scan_state(3), c.scan_ticket(3));
-          hipLaunchKernelGGL(k_camap, dim3((b.nq + kWave / kCamapGroup - 1) / (kWave / kCamapGroup)), dim3(kWave), 0, stream, m.d, b, w, sc, prm, d_out_count, d_out_total);
+          hipLaunchKernelGGL(k_camap, dim3((b.nq + kWave / kCamapGroup - 1) / (kWave / kCamapGroup)), dim3(kWave), 0, stream, E.d, b, w, sc, prm, d_out_count, d_out_total);
           // round r: the match picked in round r - 1 emits itself, the others bid for round r's pick
           // (the two length classes hold different queries: their rounds are two independent chains, one per stream)
-          if (m.d.max_slen > 32) {
+          if (E.d.max_slen > 32) {
             fork();
             for (uint32_t r = 1; r <= prm.nmatch; r++)
-              hipLaunchKernelGGL(k_cround<64>, dim3(cround_grid(64)), dim3(kWave), 0, side, m.d, b, w, prm, sc, r, cap, d_out, d_out_count, d_out_total);
+              hipLaunchKernelGGL(k_cround<64>, dim3(cround_grid(64)), dim3(kWave), 0, side, E.d, b, w, prm, sc, r, cap, d_out, d_out_count, d_out_total);
           }
           for (uint32_t r = 1; r <= prm.nmatch; r++)
-            hipLaunchKernelGGL(k_cround<32>, dim3(cround_grid(32)), dim3(kWave), 0, stream, m.d, b, w, prm, sc, r, cap, d_out, d_out_count, d_out_total);
-          if (m.d.max_slen > 32) join();
+            hipLaunchKernelGGL(k_cround<32>, dim3(cround_grid(32)), dim3(kWave), 0, stream, E.d, b, w, prm, sc, r, cap, d_out, d_out_count, d_out_total);
+          if (E.d.max_slen > 32) join();
         } else {
-          hipLaunchKernelGGL(k_contrast<0>, dim3(b.nq), dim3(kWave), 0, stream, m.d, b, w, prm, sc, cap, d_out,
+          hipLaunchKernelGGL(k_contrast<0>, dim3(b.nq), dim3(kWave), 0, stream, E.d, b, w, prm, sc, cap, d_out,
                              d_out_count, d_out_total, cl, (float*)nullptr, 0u);
         }
-        if (m.d.max_slen > 32 && !flat)
-          hipLaunchKernelGGL(k_contrast<1>, dim3(2048), dim3(kWave), 0, stream, m.d, b, w, prm, sc, cap, d_out,
+        if (E.d.max_slen > 32 && !flat)
+          hipLaunchKernelGGL(k_contrast<1>, dim3(2048), dim3(kWave), 0, stream, E.d, b, w, prm, sc, cap, d_out,
                              d_out_count, d_out_total, cl, (float*)nullptr, 0u);
         {  // long sentences, and the queries with more accepted matches than the flattened rerank indexes (k_finish queues both)
           const size_t lds = ((size_t)row_tokens + 1) * kWave * 4;
           if (lds > kDynLdsMax - 8 * 1024) {  // indexed sentences too long for LDS rows: rows in HBM
             const unsigned grid_g = 512;
             c.g_rows.ensure((uint64_t)grid_g * kWave * (row_tokens + 1));
-            hipLaunchKernelGGL(k_contrast<3>, dim3(grid_g), dim3(kWave), 0, stream, m.d, b, w, prm, sc, cap, d_out,
+            hipLaunchKernelGGL(k_contrast<3>, dim3(grid_g), dim3(kWave), 0, stream, E.d, b, w, prm, sc, cap, d_out,
                                d_out_count, d_out_total, cl, c.g_rows.p, row_tokens + 1);
           } else {
-            hipLaunchKernelGGL(k_contrast<2>, dim3(512), dim3(kWave), lds, stream, m.d, b, w, prm, sc, cap, d_out,
+            hipLaunchKernelGGL(k_contrast<2>, dim3(512), dim3(kWave), lds, stream, E.d, b, w, prm, sc, cap, d_out,
                                d_out_count, d_out_total, cl, (float*)nullptr, 0u);
           }
         }
@@ -1028,6 +1073,8 @@ static bool pass_needs_retry(Ctx& c, const unsigned long long* ctr, const PassLi
     c.heavy_div = std::min<uint32_t>(c.heavy_div, ran.heavy_div > 4 ? 4u : 1u);
     retry = true;
   }
+  if (ctr[26] != 0)  // k_setup: q_off[first query] / q_off[last query + 1] are not what the pass was enqueued with
+    throw std::invalid_argument("device batch: total_tokens / offsets disagree with q_off on the device (q_off[0] must be 0 and q_off[nq] == total_tokens)");
   if (std::max(ctr[5], ctr[12]) > ran.item_cap) {                                  // work-item list too short
     const unsigned long long need = std::max(ctr[5], ctr[12]);
     const uint64_t nc = std::min<unsigned long long>(need + need / 4, 0xffffffffull);
@@ -1076,9 +1123,11 @@ struct PassRun {
       : m(m_), c(c_), bv(bv_), sub_q_bounds(std::move(q_bounds)), sub_tok_bounds(std::move(tok_bounds)), st(st_),
         hooks(hooks_ ? *hooks_ : PassHooks{}),
         // cost model: real-token / penalty-token terms need the general kernel (DP rows in LDS / HBM); idf alone has a register kernel
-        E{m_, c_, prm_in, (m_.d.real && bv_.q_real) || (bv_.q_itok != nullptr) || (m_.d.itok != nullptr), prm_in.idf_penalty != 0.f, d_out,
+        E{m_, c_, TableSnap{}, DevIndex{}, prm_in, (m_.d.real && bv_.q_real) || (bv_.q_itok != nullptr) || (m_.d.itok != nullptr), prm_in.idf_penalty != 0.f, d_out,
           d_out_count, d_out_total, cap, stream_, bv_.prior_max_len},
         stream(stream_) {
+    E.snap = pin_tables(m);
+    E.d = dev_view(m, E.snap);
     if (cap == 0) throw std::invalid_argument("cap must be > 0");
     if (!c.qb.p) c.want_qb = std::min<uint64_t>(c.want_qb, std::max<uint64_t>(m.init_seg, 4096));  // a small initial segment also starts the queues small
     n_sub = (uint32_t)sub_tok_bounds.size() - 1;
@@ -1217,7 +1266,6 @@ static void run_passes(DeviceIndex::Impl& m, Ctx& c, const Params& prm_in, const
 // fmx_match_batch_device_begin / _end: the two halves of the stats-less device call, so that ONE host thread can keep several
 // calls in flight (each in its own context; chained on the GPU like concurrent callers are).
 struct DeviceIndex::Pending {
-  std::shared_lock<std::shared_mutex> rl;
   std::unique_ptr<CtxLease> lease;
   std::unique_ptr<PassRun> run;
   bool done = false;
@@ -1229,12 +1277,9 @@ DeviceIndex::Pending* DeviceIndex::match_device_begin(const HostIndex& h, const 
   Impl& m = *impl_;
   if (m.device < 0) throw GpuError("index is not on a device");
   HIP_TRY(hipSetDevice(m.device));
-  if (!m.context_available())
-    throw std::invalid_argument("every context of the index is busy: end a pending call first, or raise the option \"contexts\"");
   refresh_itok_table(m, h);
   std::unique_ptr<Pending> p(new Pending);
-  p->rl = std::shared_lock<std::shared_mutex>(m.itok_mu);
-  p->lease.reset(new CtxLease(m));
+  p->lease.reset(new CtxLease(m, /*no_wait=*/true));  // throws instead of waiting: the busy contexts may all be pendings of this thread
   Ctx& c = *p->lease->c;
   hipStream_t stream = stream_v ? (hipStream_t)stream_v : c.stream;  // NULL: the context's stream, the caller's inputs are complete
   std::vector<uint64_t> q_bounds;
@@ -1250,10 +1295,10 @@ DeviceIndex::Pending* DeviceIndex::match_device_begin(const HostIndex& h, const 
   PassHooks hooks;
   Ctx* cp = &c;
   Impl* mp = &m;
-  bool chained = false;
-  hooks.enqueued = [mp, cp, turns, &chained](hipEvent_t last) {
-    mp->chain_last = (turns == 2 && mp->expand_order != 0 && !mp->serial) ? cp->ev_mid : last;
-    chained = true;
+  // (chain_last belongs to chain_mu: written only by a chained call, which holds the lock until its launches are queued)
+  const bool chain_held = chain_lk.owns_lock();
+  hooks.enqueued = [mp, cp, turns, chain_held](hipEvent_t last) {
+    if (chain_held) mp->chain_last = (turns == 2 && mp->expand_order != 0 && !mp->serial) ? cp->ev_mid : last;
   };
   p->run.reset(new PassRun(m, c, prm, bv, d_out, d_out_count, d_out_total, cap, stream, q_bounds, sub_tok_bounds, nullptr, &hooks));
   p->run->hooks.enqueued = nullptr;  // (re-armed below: the hook captures locals of this frame)
@@ -1268,7 +1313,6 @@ DeviceIndex::Pending* DeviceIndex::match_device_begin(const HostIndex& h, const 
     p->run->hooks.enqueued = nullptr;
     p->done = true;
   }
-  (void)chained;
   return p.release();
 }
 
@@ -1291,7 +1335,6 @@ void DeviceIndex::match_device(const HostIndex& h, const Params& prm, const Devi
   if (m.device < 0) throw GpuError("index is not on a device");
   HIP_TRY(hipSetDevice(m.device));
   refresh_itok_table(m, h);
-  std::shared_lock<std::shared_mutex> rl(m.itok_mu);
   CtxLease lease(m);
   Ctx& c = *lease.c;
   // the caller's stream carries the work (NULL = the context's own stream)
@@ -1455,7 +1498,7 @@ void DeviceIndex::match_host_full(const HostIndex& h, const Params& prm, const H
   if (hb.text && base != 0) throw std::invalid_argument("text batch: offsets must start at 0");
   refresh_itok_table(m, h);
   if (hb.text) refresh_vocab_table(m, h);
-  std::shared_lock<std::shared_mutex> rl(m.itok_mu);
+  const TableSnap text_snap = pin_tables(m);  // (the pass run pins its own pair; this one keeps the spelling table of the lookup alive)
   CtxLease lease(m);
   Ctx& c = *lease.c;
   c.d_qoff.ensure(nq + 1);
@@ -1601,11 +1644,14 @@ void DeviceIndex::match_host_full(const HostIndex& h, const Params& prm, const H
       unsigned long long* d_total = nullptr;
       HIP_TRY(hipHostGetDevicePointer((void**)&d_total, c.h_vtotal, 0));
       uint32_t* tile_count = reinterpret_cast<uint32_t*>(c.d_vstate.p);
+      // a text with fewer spellings than the offsets count leaves the tail of the ids untouched: VOCAB_UNK there, not whatever the
+      // buffer held (the call still fails after the synchronisation, but no kernel runs on garbage)
+      if (nt) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)c.d_qtok.p, 1, nt, c.stream));
       hipLaunchKernelGGL(k_vocab_count, dim3((unsigned)text_tiles), dim3(kScanThreads), 0, c.stream, (const unsigned char*)c.d_text.p,
                          (unsigned long long)hb.n_text, tile_count);
       hipLaunchKernelGGL(k_vocab_scan, dim3(1), dim3(kScanThreads), 0, c.stream, tile_count, (uint32_t)text_tiles, d_total);
       hipLaunchKernelGGL(k_vocab_lookup, dim3((unsigned)text_tiles), dim3(kScanThreads), 0, c.stream, (const unsigned char*)c.d_text.p,
-                         (unsigned long long)hb.n_text, (unsigned long long)nt, m.vocab, c.d_qtok.p, (const uint32_t*)tile_count);
+                         (unsigned long long)hb.n_text, (unsigned long long)nt, text_snap.vocab, c.d_qtok.p, (const uint32_t*)tile_count);
     }
     if (s + 1 < n_sub) send(s + 1);  // travels while pass s computes
   };
@@ -1620,7 +1666,7 @@ void DeviceIndex::match_host_full(const HostIndex& h, const Params& prm, const H
   const auto a = std::chrono::steady_clock::now();
   HIP_TRY(hipEventRecord(c.ev_done, d2h));
   HIP_TRY(hipEventSynchronize(c.ev_done));
-  if (hb.text && hb.n_text && *c.h_vtotal != nt)
+  if (hb.text && (hb.n_text ? *c.h_vtotal : 0ull) != nt)
     throw std::invalid_argument("text batch: the text holds " + std::to_string(*c.h_vtotal) + " spellings, the offsets count " + std::to_string(nt));
   ms_d2h += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
   if (st) {
@@ -1669,7 +1715,8 @@ void DeviceIndex::subsequence_host(const HostIndex& h, const HostBatchView& hb, 
   for (uint64_t q = 0; q < nq_all; q++) { out_found[q] = 0; if (out_pos) out_pos[q] = 0; out[q] = Rec{0.f, 0.f, 0, 0}; }
   if (nq_all == 0 || nm == 0) return;  // candidates.size() < 0 never holds: nothing is ever scored (:312)
   refresh_itok_table(m, h);
-  std::shared_lock<std::shared_mutex> rl(m.itok_mu);
+  const TableSnap snap = pin_tables(m);
+  const DevIndex D = dev_view(m, snap);
   CtxLease lease(m);
   Ctx& c = *lease.c;
   hipStream_t stream = c.stream;
@@ -1708,7 +1755,7 @@ void DeviceIndex::subsequence_host(const HostIndex& h, const HostBatchView& hb, 
     std::vector<uint16_t> t_len(nt);
     if (nt) {
       hipLaunchKernelGGL(k_sub_tq, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, stream, c.d_qoff.p, (uint32_t)nq, c.t_q.p);
-      hipLaunchKernelGGL(k_sub_extent, dim3((unsigned)((nt + 63) / 64)), dim3(64), 0, stream, m.d, c.d_qoff.p, c.d_qtok.p, c.t_q.p, (uint32_t)nt, d_len.p);
+      hipLaunchKernelGGL(k_sub_extent, dim3((unsigned)((nt + 63) / 64)), dim3(64), 0, stream, D, c.d_qoff.p, c.d_qtok.p, c.t_q.p, (uint32_t)nt, d_len.p);
       HIP_TRY(hipMemcpyAsync(t_len.data(), d_len.p, nt * 2, hipMemcpyDeviceToHost, stream));
     }
     std::vector<SubState> st(nq);
@@ -1757,11 +1804,11 @@ void DeviceIndex::subsequence_host(const HostIndex& h, const HostBatchView& hb, 
       if (items.empty()) break;
       HIP_TRY(hipMemcpyAsync(d_items.p, items.data(), items.size() * sizeof(SubItem), hipMemcpyHostToDevice, stream));
       if (rows_in_hbm)
-        hipLaunchKernelGGL(k_sub_eval<true>, dim3((unsigned)std::min<size_t>(items.size(), sub_grid_g)), dim3(kWave), 0, stream, m.d, c.d_qoff.p, c.d_qtok.p,
+        hipLaunchKernelGGL(k_sub_eval<true>, dim3((unsigned)std::min<size_t>(items.size(), sub_grid_g)), dim3(kWave), 0, stream, D, c.d_qoff.p, c.d_qtok.p,
                            d_real, d_itok, (const SubItem*)d_items.p, (uint32_t)items.size(), d_st.p, d_seen.p, seen_cap, nm, no_perfect ? 1 : 0,
                            c.g_rows.p, p_max + 1);
       else
-        hipLaunchKernelGGL(k_sub_eval<false>, dim3((unsigned)std::min<size_t>(items.size(), 65535)), dim3(kWave), lds, stream, m.d, c.d_qoff.p, c.d_qtok.p,
+        hipLaunchKernelGGL(k_sub_eval<false>, dim3((unsigned)std::min<size_t>(items.size(), 65535)), dim3(kWave), lds, stream, D, c.d_qoff.p, c.d_qtok.p,
                            d_real, d_itok, (const SubItem*)d_items.p, (uint32_t)items.size(), d_st.p, d_seen.p, seen_cap, nm, no_perfect ? 1 : 0,
                            (float*)nullptr, 0u);
       HIP_TRY(hipGetLastError());

@@ -43,6 +43,7 @@ uint32_t HostIndex::add_word(const std::string& w) {
   forms.push_back(w);
   sfreq.push_back(0);
   vocab_size = (uint32_t)forms.size();
+  vocab_gen_.fetch_add(1, std::memory_order_release);
   return id;
 }
 
@@ -64,9 +65,10 @@ static inline uint64_t spell_hash(const char* s, size_t& len, uint64_t& head) { 
 }
 
 const HostIndex::FastVocab& HostIndex::fast_vocab() const {
-  if (fast_.built_for.load(std::memory_order_acquire) == forms.size() && forms.size() != 0) return fast_;  // the common case: no lock
+  const uint64_t gen = vocab_gen_.load(std::memory_order_acquire);
+  if (fast_.built_for.load(std::memory_order_acquire) == gen) return fast_;  // the common case: no lock
   std::lock_guard<std::mutex> lk(fast_mu_);
-  if (fast_.built_for.load(std::memory_order_relaxed) == forms.size() && !fast_.slot.empty()) return fast_;
+  if (fast_.built_for.load(std::memory_order_relaxed) == gen && !fast_.slot.empty()) return fast_;
   FastVocab& f = fast_;
   uint64_t cap = 64;
   while (cap < forms.size() * 2) cap <<= 1;
@@ -87,7 +89,7 @@ const HostIndex::FastVocab& HostIndex::fast_vocab() const {
     f.slot[h] = (off << 32) | (uint64_t)id;
     f.head[h] = hd;
   }
-  f.built_for.store(forms.size(), std::memory_order_release);
+  f.built_for.store(gen, std::memory_order_release);
   return f;
 }
 
@@ -131,10 +133,16 @@ void HostIndex::set_forms(const char* const* spellings, uint64_t n) {
   if (n > forms.size()) { forms.resize(n); if (sfreq.size() < n) sfreq.resize(n, 0); }
   for (uint64_t id = 2; id < n; id++) {
     if (!spellings[id]) continue;
+    if (forms[id] == spellings[id]) continue;
+    if (!forms[id].empty()) {  // a spelling is being replaced: the old one no longer names this id
+      auto old = form2index.find(forms[id]);
+      if (old != form2index.end() && old->second == (uint32_t)id) form2index.erase(old);
+    }
     forms[id] = spellings[id];
     form2index.emplace(forms[id], (uint32_t)id);  // the first id of a spelling wins, like addWord
   }
   if (forms.size() > vocab_size) vocab_size = (uint32_t)forms.size();
+  vocab_gen_.fetch_add(1, std::memory_order_release);
 }
 
 static void push_sentence(HostIndex& ix, const uint32_t* toks, uint32_t n) {
@@ -778,6 +786,7 @@ void HostIndex::load_fmi(const std::string& path) {
   r.class_info();                      // VocabIndexer
   r.class_info();                      // std::vector<std::string>
   forms.clear(); sfreq.clear(); form2index.clear();
+  vocab_gen_.fetch_add(1, std::memory_order_release);
   {
     const uint64_t n = r.get<uint64_t>();
     r.get<uint32_t>();                 // item_version
@@ -803,6 +812,7 @@ void HostIndex::load_fmi(const std::string& path) {
   }
   vocab_size = (uint32_t)forms.size();
   sfreq.resize(vocab_size, 0);
+  vocab_gen_.fetch_add(1, std::memory_order_release);
 
   // SuffixArray — suffix_array.hxx:55-91
   const uint32_t sa_version = r.class_info();

@@ -101,8 +101,11 @@ class HostIndex {
     std::vector<uint64_t> head;    // beside every slot: the spelling's first eight bytes (zero-padded) — spellings of up to eight
                                    // bytes are decided without touching the arena (one cache miss fewer per look-up)
     uint64_t              mask = 0;
-    std::atomic<uint64_t> built_for{0};   // forms.size() it was built from (0 = not built)
+    std::atomic<uint64_t> built_for{0};   // vocabulary generation it was built from (0 = not built)
   };
+  // bumped by everything that changes a spelling or an id (add_word, set_forms, load_fmi): the spelling table here and its
+  // device copy are keyed on it, not on forms.size() (set_forms can change spellings without changing the size)
+  std::atomic<uint64_t> vocab_gen_{1};
   mutable FastVocab  fast_;
   mutable std::mutex fast_mu_;
   const FastVocab& fast_vocab() const;
@@ -116,7 +119,7 @@ class HostIndex {
   // per token: an open-addressing table over the packed spellings (built on first use, rebuilt when words were added),
   // spread over `nthreads` host threads
   void get_indices(const char* const* toks, uint64_t n, uint32_t* ids, int nthreads) const;
-  // the spelling table behind get_indices, for its device copy (fmx_vocab.hip.hh); built_for = forms.size() it was built from
+  // the spelling table behind get_indices, for its device copy (fmx_vocab.hip.hh); built_for = the vocabulary generation it was built from
   struct VocabTable { const uint64_t* slot; const uint64_t* head; const char* arena; uint64_t n_slots, arena_bytes, built_for; };
   VocabTable vocab_table() const;
   // attach spellings to an id-only index (ids 2 .. n - 1; bulk-built corpora): vocabulary lookups then work on it

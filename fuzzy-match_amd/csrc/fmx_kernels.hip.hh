@@ -112,6 +112,7 @@ struct DevWork {
                                  // [18]=8-byte plane words read by k_expand_h [19],[20]=bytes / lines requested by k_probe<true>
                                  // [22]=hits of the light queries (walked by k_expand_b<true>) [23]=queries queued for k_cand
                                  // [24],[25]=segment / queue entries the pass used (always written: the host sizes later workspaces by them)
+                                 // [26]=passes whose token bounds disagree with q_off (k_setup; the call fails)
                                  // [27]=sentence-pair edit distances of the flattened contrastive rerank (k_cround)
 };
 constexpr int kStatSlots = 64;     // k_expand_h's three statistics are summed into 64 slots each (kStatBase + 3 x 64): 8192 workgroups
@@ -148,13 +149,20 @@ __global__ void k_setup(DevIndex ix, DevBatch b, DevWork w, Params prm) {
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q > b.nq) return;
   w.q_hits[q] = 0; w.q_hits_a[q] = 0;  // k_probe's per-query accumulators (nq + 1 entries)
-  if (q == b.nq) return;
+  if (q == b.nq) {
+    // the token bounds the host enqueued this pass with (the caller's total_tokens, when it gave one) against q_off itself
+    if (b.q_off[b.q_begin] != b.t_begin || b.q_off[b.q_begin + b.nq] != b.t_begin + b.nt) atomicAdd(&w.counters[26], 1ull);
+    return;
+  }
   w.q_pb[q] = 0;
   const uint32_t o0 = b.q_off[b.q_begin + q], o1 = b.q_off[b.q_begin + q + 1];
   const uint32_t p = o1 - o0;
-  const uint32_t msl = min_seq_len(p, prm);
+  // (a query whose tokens lie outside the bounds the pass was enqueued with — a wrong total_tokens — is skipped: nothing is
+  // indexed out of range; the q == nq thread above makes the call fail)
+  const bool inside = o0 >= b.t_begin && o1 >= o0 && o1 - b.t_begin <= b.nt;
+  const uint32_t msl = inside ? min_seq_len(p, prm) : kNoMatchLen;
   w.q_m[q] = msl == kNoMatchLen ? kNoMatchLen : msl;
-  for (uint32_t k = 0; k < p; k++) w.t_q[o0 - b.t_begin + k] = q;
+  if (inside) for (uint32_t k = 0; k < p; k++) w.t_q[o0 - b.t_begin + k] = q;
 }
 
 // compute_idf_penalty — src/fuzzy_match.cc:381-387 (UNK and out-of-vocabulary ids -> 0), one thread per

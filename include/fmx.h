@@ -245,7 +245,9 @@ int fmx_match_batch_text(fmx_index*, const fmx_params*, const fmx_text_batch*, f
                          uint32_t* out_total, uint32_t cap, fmx_stats* stats);
 /* Same with every buffer already in the HBM of the index's device; `stream` is a hipStream_t
  * (NULL = a stream of the library after a device-wide synchronisation).  total_tokens = q_off[nq] when q_off[0] == 0, else
- * 0 (with it and max_len set, a batch of one pass needs no device read up front).  Work is enqueued on `stream`; the call
+ * 0 (with it and max_len set, a batch of one pass needs no device read up front; the value is CHECKED on the device against
+ * q_off[0] == 0 and q_off[nq]: a call whose total_tokens disagrees skips the queries outside the stated bounds and returns
+ * FMX_E_INVALID — from _end for the two-halves form).  Work is enqueued on `stream`; the call
  * synchronises that stream before returning.  stats != NULL: every pass is synchronised and timed per stage (HIP events);
  * stats == NULL: the passes run back to back; concurrent calls overlap on the GPU (with the option "device_turns" set, calls
  * of 262 144 queries or more are chained like concurrent fmx_match_batch calls, see "turns"). */

@@ -251,3 +251,45 @@ def test_vocab_lookup_mt_and_attached_spellings(fmx):
     o3 = np.zeros(3, np.uint32)
     assert fmx.lib().fmx_vocab_lookup_mt(b.h, qa, 3, o3.ctypes.data_as(C.c_void_p), 2) == 0
     assert list(o3) == [4, 2, 1]
+
+
+def test_respelled_ids_reach_every_lookup(fmx):
+    """fmx_index_set_forms a second time with the same count but other spellings (round-3 advice: the spelling table was keyed
+    on the vocabulary's size): fmx_vocab_lookup and fmx_vocab_lookup_mt both see the new words and forget the old ones."""
+    import ctypes as C
+    b = fmx.Index.create()
+    b.add_ids(np.asarray([0, 3, 5], np.uint32), np.asarray([2, 3, 4, 3, 5], np.uint32), 6)
+
+    def both(words):
+        enc = [w.encode() for w in words]
+        arr = (C.c_char_p * len(enc))(*enc)
+        out = np.zeros(len(enc), np.uint32)
+        assert fmx.lib().fmx_vocab_lookup_mt(b.h, arr, len(enc), out.ctypes.data_as(C.c_void_p), 2) == 0
+        one = list(b.vocab_lookup(words))
+        assert one == list(out)
+        return one
+
+    for sp, probe, want in (([None, None, b"two", b"three", b"four", b"five"], ["two", "four", "vier", "five"], [2, 4, 1, 5]),
+                            ([None, None, b"two", b"three", b"vier", b"fuenf"], ["two", "four", "vier", "five", "fuenf"], [2, 1, 4, 1, 5]),
+                            ([None, None, b"two", b"three", b"vier", b"five"], ["five", "fuenf", "vier"], [5, 1, 4])):
+        sarr = (C.c_char_p * len(sp))(*sp)
+        assert fmx.lib().fmx_index_set_forms(b.h, sarr, len(sp)) == 0
+        assert both(probe) == want
+
+
+def test_text_batch_arguments_are_checked_up_front(fmx):
+    """fmx_match_batch_text: offsets that count spellings the text cannot hold (n_bytes == 0 with q_off[nq] > 0, fewer bytes than
+    spellings) or that do not start at 0 are FMX_E_INVALID before anything runs (include/fmx.h)."""
+    import ctypes as C
+    b = fmx.Index.create()
+    b.add_ids(np.asarray([0, 3], np.uint32), np.asarray([2, 3, 4], np.uint32), 5)
+    b.sort()
+    b.finalize()
+    out = np.zeros((2, 1), fmx.MATCH_DTYPE)
+    cnt = np.zeros(2, np.uint32)
+    prm = fmx.Params()
+    text = np.frombuffer(b"a\0b\0c\0", np.uint8).copy()
+    for q_off, n_bytes in ((np.asarray([0, 2, 3], np.uint32), 0), (np.asarray([0, 2, 9], np.uint32), 6), (np.asarray([1, 2, 3], np.uint32), 6)):
+        tb = fmx.TextBatch(2, q_off.ctypes.data, text.ctypes.data, n_bytes)
+        rc = fmx.lib().fmx_match_batch_text(b.h, C.byref(prm), C.byref(tb), out.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p), None, 1, None)
+        assert rc == -1, (rc, fmx.lib().fmx_last_error())   # FMX_E_INVALID

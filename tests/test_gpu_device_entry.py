@@ -202,3 +202,71 @@ def test_rerank_distances_are_counted(fmx, setup):
     assert plain.n_rerank == 0
     st = ix.match_batch(fmx.Params(contrast=0.3, contrast_buffer=32, **kw), qo, qt, cap=5, want_stats=True)[3]
     assert st.n_rerank > 0
+
+
+def test_a_wrong_total_tokens_is_refused(fmx, setup):
+    """total_tokens is checked on the device against q_off (k_setup): a stale or approximate value fails the call instead of
+    running the passes with wrong token bounds."""
+    hip, ix, kw, q_off, q_tok, d_off, d_tok, oo, oc = setup
+    nq, cap = 20_000, 5
+    d_out, d_cnt = hip.zeros(nq * cap * 16), hip.zeros(nq * 4)
+    hip.sync()
+    ml = int(np.diff(q_off).max())
+    for wrong in (int(q_off[nq]) - 7, int(q_off[nq]) + 5):
+        with pytest.raises(fmx.FmxError):
+            ix.match_batch_device(fmx.Params(**kw), nq, d_off, d_tok, wrong, d_out, d_cnt, 0, cap, stream=0, max_len=ml, want_stats=False)
+        h = ix.device_begin(fmx.Params(**kw), nq, d_off, d_tok, wrong, d_out, d_cnt, 0, cap, stream=0, max_len=ml)
+        with pytest.raises(fmx.FmxError):
+            ix.device_end(h)
+    # and the right value still works afterwards, in the same contexts
+    ix.match_batch_device(fmx.Params(**kw), nq, d_off, d_tok, int(q_off[nq]), d_out, d_cnt, 0, cap, stream=0, max_len=ml, want_stats=False)
+    go, gc = _records(hip, d_out, d_cnt, nq, cap)
+    workloads.compare(oo[:nq], oc[:nq], go, gc, "after refused calls")
+
+
+def test_tables_are_refreshed_while_this_thread_has_calls_pending(fmx, gpu_device):
+    """The penalty-string table and the spelling table are pinned per call, not locked across it: a thread that holds pending
+    calls can intern a new penalty string, make its first text batch and start further calls without dead-locking against
+    itself (round-3 advice)."""
+    import faulthandler
+    hip = Hip()
+    faulthandler.dump_traceback_later(120, exit=True)   # a dead-lock ends the test run instead of hanging the box
+    try:
+        c_off, c_tok, q_off, q_tok, vs = workloads.synthetic(20_000, 4_000, 12)
+        ix = fmx.Index.create()
+        ix.add_ids(c_off, c_tok, vs)
+        ix.sort(gpu_device)
+        ix.finalize()
+        ix.to_device(gpu_device)
+        ix.set_option("contexts", 4)
+        words = [b"", b""] + [b"w%d" % k for k in range(2, vs)]
+        arena = np.frombuffer(b"".join(w + b"\0" for w in words[2:]), dtype=np.uint8).copy()
+        offs = np.full(len(words), 0xffffffffffffffff, np.uint64)
+        pos = 0
+        for k in range(2, len(words)):
+            offs[k] = pos
+            pos += len(words[k]) + 1
+        ix.set_forms_packed(arena, offs)
+        kw = dict(fuzzy=0.6, nmatch=3)
+        nq, cap = len(q_off) - 1, 3
+        d_off, d_tok = hip.upload(q_off.astype(np.uint32)), hip.upload(q_tok.astype(np.uint32))
+        bufs = [(hip.zeros(nq * cap * 16), hip.zeros(nq * 4)) for _ in range(2)]
+        hip.sync()
+        ml = int(np.diff(q_off).max())
+        ref = ix.match_batch(fmx.Params(**kw), q_off, q_tok, cap=cap)
+        pend = [ix.device_begin(fmx.Params(**kw), nq, d_off, d_tok, int(q_off[-1]), o, c, 0, cap, stream=0, max_len=ml) for o, c in bufs]
+        # with two calls pending: a new penalty string (the distance table grows), then a call that refreshes the device table
+        # and the first text batch of the index (uploads the spelling table)
+        assert ix.intern_itok("｟new_tag｠") > 0
+        again = ix.match_batch(fmx.Params(**kw), q_off, q_tok, cap=cap)
+        text = np.frombuffer(b"".join(words[t] + b"\0" for t in q_tok), dtype=np.uint8).copy()
+        got = ix.match_batch_text(fmx.Params(**kw), q_off, text, cap=cap)
+        for h in pend:
+            ix.device_end(h)
+        for o, c in bufs:
+            go, gc = _records(hip, o, c, nq, cap)
+            workloads.compare(ref[0], ref[1], go, gc, "pending call")
+        workloads.compare(ref[0], ref[1], again[0], again[1], "call issued while others were pending")
+        workloads.compare(ref[0], ref[1], got[0], got[1], "text batch issued while others were pending")
+    finally:
+        faulthandler.cancel_dump_traceback_later()
