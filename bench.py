@@ -1,21 +1,28 @@
 #!/usr/bin/env python3
 """bench.py — query patterns/sec of the match() hot path on MI355X (BASELINE.json metric).
 
-One "step" = one call of the C-ABI batch entry point (`fmx_match_batch`, include/fmx.h) over one batch of synthetic
-query patterns: host buffers in, host buffers out.  That is the phase the reference CLI brackets with
-TICK("Matching") ... TICK("Done") (cli/src/FuzzyMatch-cli.cc:450-467): H2D of the queries, every kernel,
-D2H of the records.  The buffers are pinned (fmx_host_alloc) and the library cuts a batch into passes whose copies
-overlap the neighbouring passes' kernels; like the reference's `match()`, the entry point is re-entrant and is
-driven from two host threads so that one call's last copy overlaps the other call's first kernels.
-`value` = queries of all ranks x K / wall time of K steps (barrier + device sync on both sides, max over ranks).
-The same batch run from HBM-resident buffers (device entry point, no PCIe) is reported as `device_resident`, with the
-per-stage HIP-event times the roofline objects are priced with.
+One "step" = one batch of synthetic query patterns through the C-ABI (include/fmx.h).  `value` is measured on the bracket
+SURVEY §8(d) gives the metric — the phase the reference CLI times between TICK("Matching") and TICK("Done")
+(cli/src/FuzzyMatch-cli.cc:450-467): per-query host prep (vocabulary id lookup), H2D of the queries, every kernel, D2H of
+the records.  A step of that leg is one `fmx_match_batch_text` call: the patterns are handed over as what a tokenizer holds —
+packed token SPELLINGS in pinned host memory — the ids are looked up on the device (k_vocab_lookup), the pipeline runs, the
+top-N records come back to pinned host buffers.  Several synchronous calls are kept in flight from host threads, like the
+reference's N worker threads call match().
 
-Workload = BASELINE config C3 (5 M-sentence synthetic corpus, mean 25 tokens, 1 M queries per step, fuzzy 0.7,
-nmatch 5) unless overridden.  N > 1 (one process per GPU, torch.distributed / RCCL): the index is replicated, the
-queries are sharded by rank and the top-N records are gathered to rank 0 over xGMI (the path's only collective,
-SURVEY §8e).  `--scaling weak` (default): 1 M queries per rank per step; `--scaling strong`: BASELINE's shape, the
-same 1 M queries cut into N contiguous blocks.  Both are measured in one run when N > 1 (`scaling_other`).
+Every leg rotates DISTINCT query batches (seeds QUERY_SEED + k, one more batch than calls in flight) through its calls, so that
+calls overlapping on the GPU never walk the same index lines a fraction of a millisecond apart.
+
+Side legs in the same JSON line (never `value`):
+  device_resident     the same steps through fmx_match_batch_device_begin/_end: offsets / ids already in HBM, records left in HBM
+  pcie_inclusive_ids  fmx_match_batch: vocabulary ids in pinned host memory in, records out (no lookup: the caller already holds ids)
+  from_token_strings  fmx_vocab_lookup_mt on host threads inside the timed region, then fmx_match_batch
+  staged              one device-resident call at a time with per-stage HIP events: the kernel times the rooflines are priced with
+
+Workload = BASELINE config C3 (5 M-sentence synthetic corpus, mean 25 tokens, 1 M queries per step, fuzzy 0.7, nmatch 5) unless
+overridden.  N > 1 (one process per GPU, torch.distributed / RCCL): the index is replicated, the queries are sharded by rank and
+the top-N records are gathered to rank 0 over xGMI (the path's only collective).  `--scaling strong` (the default when
+WORLD_SIZE > 1: BASELINE's shape, one 1 M-query batch cut into N contiguous blocks) or `weak` (1 M queries per rank per step); the
+other one is measured too and reported as `scaling_other`.
 
 Prints ONE JSON line on rank 0.
 """
@@ -62,25 +69,29 @@ def parse_args():
     ap.add_argument("--config", default="C3", choices=list(CONFIGS))
     ap.add_argument("--sentences", type=int, default=0)
     ap.add_argument("--queries", type=int, default=0)
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
-    ap.add_argument("--threads", type=int, default=int(os.environ.get("FMX_BENCH_THREADS", "6")), help="synchronous fmx_match_batch calls kept in flight (one host thread each)")
+    ap.add_argument("--scaling", default="auto", choices=["auto", "weak", "strong"],
+                    help="auto = strong when WORLD_SIZE > 1 (BASELINE's C3 is ONE 1 M-query batch cut over 1/2/4/8 GPUs), weak at N = 1 (the same thing there)")
+    ap.add_argument("--threads", type=int, default=int(os.environ.get("FMX_BENCH_THREADS", "6")), help="device-resident calls kept in flight (one host thread enqueues them)")
     ap.add_argument("--host-threads", type=int, default=int(os.environ.get("FMX_BENCH_HOST_THREADS", "4")),
-                    help="calls in flight of the host-buffer legs (PCIe-inclusive, from token strings): each adds two copy streams to its two "
-                         "compute streams, and beyond ~24 busy hardware queues the GPU's scheduler starts time-slicing them")
+                    help="synchronous host-buffer calls in flight (one host thread each) — the `value` leg and the other PCIe-inclusive legs: each adds "
+                         "two copy streams to its two compute streams, and beyond ~24 busy hardware queues the GPU's scheduler starts time-slicing them")
+    ap.add_argument("--batches", type=int, default=0, help="distinct query batches rotated through the steps (0 = calls in flight + 1)")
     ap.add_argument("--force-gather", action="store_true", help="N = 1 test of the N > 1 step: records also kept in HBM for the (empty) gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-text-leg", action="store_true", help="skip the leg that starts from token strings")
+    ap.add_argument("--no-text-leg", action="store_true", help="skip the side leg that looks the ids up on host threads")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline.traffic = null)")
     ap.add_argument("--child", action="store_true", help="profiling child: device-resident steps only, no output line")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--verify", type=int, default=2000, help="queries of rank 0 checked against the oracle")
+    ap.add_argument("--verify", type=int, default=20000, help="queries of rank 0 checked against the oracle in every leg, spread evenly over a batch")
     ap.add_argument("--model-queries", type=int, default=20000, help="queries the reference byte model is counted on")
+    ap.add_argument("--via-fmi", action="store_true", help="the index goes through the reference's on-disk format first: fmx_index_save -> fmx_index_load "
+                                                           "(arrays compared, times and file size reported); the steps then run on the LOADED index")
     return ap.parse_args()
 
 
 def pmc_pass(counter, argv_child, log):
     """One `rocprofv3 --pmc <counter>` pass over a child run of this script (device-resident steps only).
-    Returns {kernel name: mean counter value per dispatch over the child's timed dispatches} or None."""
+    Returns {kernel name: [(dispatch id, counter value)] over the child's dispatches} or None."""
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None
@@ -113,6 +124,17 @@ def pmc_pass(counter, argv_child, log):
         shutil.rmtree(out, ignore_errors=True)
 
 
+def take_queries(q_off, q_tok, idx):
+    """CSR of the queries idx (ascending) of a batch."""
+    lens = (q_off[idx + 1] - q_off[idx]).astype(np.int64)
+    off = np.zeros(len(idx) + 1, np.uint32)
+    off[1:] = np.cumsum(lens)
+    total = int(off[-1])
+    start = q_off[idx].astype(np.int64)
+    pos = np.repeat(start - off[:-1].astype(np.int64), lens) + np.arange(total, dtype=np.int64)
+    return off, q_tok[pos]
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -120,6 +142,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         args.gpus = world
+    if args.scaling == "auto":
+        args.scaling = "strong" if world > 1 else "weak"
 
     import torch  # plumbing only: device tensors for the device entry point, torch.distributed
     import torch.distributed as dist
@@ -148,6 +172,10 @@ def main():
     n_sent = args.sentences or n_sent
     nq_cfg = args.queries or nq_cfg
     log = (lambda *a: print(*a, file=sys.stderr, flush=True)) if rank == 0 else (lambda *a: None)
+    T_dev = max(args.threads, 1)
+    T_host = max(min(args.host_threads, args.threads), 1)
+    NB = args.batches or (T_dev + 1)          # distinct batches of the device-resident legs
+    NB_host = min(NB, T_host + 1) if not args.batches else NB   # ... of the host-buffer legs (fewer calls in flight)
 
     # ---- synthetic corpus / queries (SURVEY §8d generator, same bytes on every box) ----
     t0 = time.time()
@@ -162,12 +190,20 @@ def main():
         L.fms_free(hq)
         return off, tok
 
-    # weak: every rank draws its own nq_cfg queries; strong: all ranks draw the SAME nq_cfg queries and take a block
-    w_off, w_tok = queries(synth.QUERY_SEED + rank, nq_cfg)
-    s_off_all, s_tok_all = queries(synth.QUERY_SEED, nq_cfg) if world > 1 else (w_off, w_tok)
+    # batch k: weak = every rank draws its own nq_cfg queries (seed QUERY_SEED + k + 101 x rank); strong = all ranks draw the SAME
+    # nq_cfg queries (seed QUERY_SEED + k) and take their contiguous block
+    def draw(k, scaling):
+        if scaling == "weak" or world == 1:
+            return queries(synth.QUERY_SEED + k + 101 * rank, nq_cfg)
+        off_all, tok_all = queries(synth.QUERY_SEED + k, nq_cfg)
+        off, tok, _, _ = shard.shard_batch(off_all, tok_all, rank, world)
+        return off, tok
+
+    raw_main = [draw(k, args.scaling) for k in range(NB)]
+    other_scaling = "strong" if args.scaling == "weak" else "weak"
+    raw_other = [draw(k, other_scaling) for k in range(NB_host)] if world > 1 else []
     L.fms_free(hc)
-    s_off, s_tok, _, _ = shard.shard_batch(s_off_all, s_tok_all, rank, world)
-    log(f"[bench] generated {n_sent} sentences / {nq_cfg} queries in {time.time() - t0:.1f}s")
+    log(f"[bench] generated {n_sent} sentences, {NB} batches of {nq_cfg} queries in {time.time() - t0:.1f}s")
 
     # ---- index: sorted on the GPU, derived, uploaded (not in the metric) ----
     t0 = time.time()
@@ -175,8 +211,29 @@ def main():
     ix.add_ids(c_off, c_tok, vs)
     ix.sort(local_rank)
     ix.finalize()
-    ix.to_device(local_rank)
-    ix.set_option("contexts", max(2, args.threads))
+    # the spellings of the generator's vocabulary (tools/fm_synth.c: fms_word): text batches are looked up against them, and a saved
+    # .fmi carries real words
+    import ctypes
+    wbuf = ctypes.create_string_buffer(32)
+    words = [b"", b""]
+    for k in range(vs - 2):
+        n = L.fms_word(k, wbuf, 32)
+        words.append(wbuf.raw[:n])
+    w_offs = np.full(len(words), 0xffffffffffffffff, np.uint64)
+    pos = 0
+    for k in range(2, len(words)):
+        w_offs[k] = pos
+        pos += len(words[k]) + 1
+    w_arena = np.frombuffer(b"".join(w + b"\0" for w in words[2:]), dtype=np.uint8).copy()
+    word_ptrs = ix.set_forms_packed(w_arena, w_offs)
+    via_fmi = None
+    if args.via_fmi:
+        via_fmi = through_fmi(fmx, ix, local_rank, rank, log)
+        ix = via_fmi.pop("index")
+        word_ptrs = ix.set_forms_packed(w_arena, w_offs)   # (same spellings: pointers for the host-lookup leg)
+    else:
+        ix.to_device(local_rank)
+    ix.set_option("contexts", max(2, T_dev))
     for opt in ("FMX_SUB_QUERIES", "FMX_HOST_SUB_QUERIES", "FMX_HEAVY_MIN", "FMX_SERIAL", "FMX_LIGHT_MAX", "FMX_HEAVY_GRID", "FMX_EXPAND_ORDER", "FMX_B_GRID", "FMX_TURNS", "FMX_DEVICE_TURNS", "FMX_PAIR_FINISH"):
         if os.environ.get(opt):
             ix.set_option(opt[4:].lower(), int(os.environ[opt]))
@@ -188,23 +245,36 @@ def main():
     cap = params.nmatch or 16
 
     class Workload:
-        """One batch in pinned host memory (+ a device copy for the device-resident measurement)."""
+        """One batch: ids and packed spellings in pinned host memory (+ a device copy of the ids for the device-resident legs)."""
 
-        def __init__(self, q_off, q_tok):
+        def __init__(self, q_off, q_tok, want_text):
             self.nq = len(q_off) - 1
             self.q_off = fmx.pinned_copy(q_off.astype(np.uint32))
             self.q_tok = fmx.pinned_copy(q_tok.astype(np.uint32))
             self.total_tokens = int(q_off[-1])
             self.max_len = int(np.diff(q_off).max()) if self.nq else 0
-            # one result slot per host thread
-            self.out = [(fmx.pinned_empty((max(self.nq, 1), cap), fmx.MATCH_DTYPE), fmx.pinned_empty(max(self.nq, 1), np.uint32),
-                         fmx.pinned_empty(max(self.nq, 1), np.uint32)) for _ in range(max(args.threads, 1))]
             self.d_off = self.d_tok = None
+            self.text = None
+            if want_text:
+                need = int(L.fms_pack_text(self.q_tok.ctypes.data, len(self.q_tok), None, 0))
+                self.text = synth.pack_text(self.q_tok, out=fmx.pinned_empty(max(need, 1), np.uint8))
+            self.tok_ptrs = None
 
         def to_device(self):
             if self.d_off is None:
                 self.d_off = torch.from_numpy(self.q_off.astype(np.int32)).to(dev)
                 self.d_tok = torch.from_numpy(self.q_tok.astype(np.int32)).to(dev)
+
+    t0 = time.time()
+    main_set = [Workload(o, t, k < NB_host) for k, (o, t) in enumerate(raw_main)]
+    other_set = [Workload(o, t, True) for (o, t) in raw_other]
+    del raw_main, raw_other
+    nq_max = max([w.nq for w in main_set + other_set] + [1])
+    # one result slot per call in flight, shared by the batches (step i writes slot i % T)
+    out_slots = [(fmx.pinned_empty((nq_max, cap), fmx.MATCH_DTYPE), fmx.pinned_empty(nq_max, np.uint32), fmx.pinned_empty(nq_max, np.uint32))
+                 for _ in range(T_host)]
+    log(f"[bench] batches pinned + packed as text in {time.time() - t0:.1f}s ({main_set[0].text.nbytes / 1e6:.0f} MB of spellings, "
+        f"{main_set[0].q_tok.nbytes / 1e6:.0f} MB of ids per batch)")
 
     def sync():
         torch.cuda.synchronize()
@@ -214,38 +284,47 @@ def main():
 
     # the host threads that keep calls in flight live for the whole run: a new thread pays for its HIP thread state on its
     # first call (milliseconds), which must not land inside the timed region
-    pool = cf.ThreadPoolExecutor(max(args.threads, 1))
+    pool = cf.ThreadPoolExecutor(max(T_dev, 1))
 
-    def run_host_steps(wl, k_steps, gather=None):
-        """K calls of fmx_match_batch (pinned host buffers in and out), args.threads of them in flight at a time: step
-        i + T is submitted when step i has returned, so the copies at both ends of one call overlap the kernels of the
-        other (the calls themselves are synchronous: a caller with a queue of batches would do exactly this).  N > 1:
-        each step's records also stay in HBM (fmx_match_batch_keep) and are gathered to rank 0 over RCCL; the gathers
-        are launched by this thread in step order, so every rank issues its collectives in the same order."""
-        T = max(min(args.host_threads, args.threads), 1)
+    def run_host_steps(wls, k_steps, kind, gather=None):
+        """K synchronous host-buffer calls, T_host of them in flight: step i (batch i % len(wls)) is submitted when step i - T has
+        returned, so the copies at both ends of one call overlap the kernels of the others.  kind: "text" = fmx_match_batch_text
+        (packed spellings in, ids looked up on the device: THE METRIC), "ids" = fmx_match_batch, "strings" = fmx_vocab_lookup_mt on
+        host threads, then fmx_match_batch.  N > 1: each step's records also stay in HBM (the _keep entry points) and are gathered
+        to rank 0 over RCCL; the gathers are launched by this thread in step order, so every rank issues its collectives in the
+        same order."""
+        T = T_host
         stats = []
+        nb = len(wls)
 
         def one(i, keep):
-            return ix.match_batch(params, wl.q_off, wl.q_tok, cap=cap, want_stats=True, out=wl.out[i % T], keep=keep)[3]
+            wl = wls[i % nb]
+            if kind == "text":
+                return ix.match_batch_text(params, wl.q_off, wl.text, cap=cap, want_stats=True, out=out_slots[i % T], keep=keep)[3]
+            if kind == "strings":
+                a = time.perf_counter()
+                ix.vocab_lookup_ptrs(wl.tok_ptrs, str_ids[i % T], str_threads)
+                t_lookup[0] += time.perf_counter() - a
+                return ix.match_batch(params, wl.q_off, str_ids[i % T][:len(wl.q_tok)], cap=cap, want_stats=True, out=out_slots[i % T], keep=keep)[3]
+            return ix.match_batch(params, wl.q_off, wl.q_tok, cap=cap, want_stats=True, out=out_slots[i % T], keep=keep)[3]
 
-        if True:
-            futs = {}
+        futs = {}
 
-            def submit(i):
-                keep = None
-                if gather is not None:
-                    d_out, d_cnt = gather.buffers(i, host_sync=True)  # the slot's previous gather is over
-                    keep = (d_out.data_ptr(), d_cnt.data_ptr())
-                futs[i] = pool.submit(one, i, keep)
+        def submit(i):
+            keep = None
+            if gather is not None:
+                d_out, d_cnt = gather.buffers(i, host_sync=True)  # the slot's previous gather is over
+                keep = (d_out.data_ptr(), d_cnt.data_ptr())
+            futs[i] = pool.submit(one, i, keep)
 
-            for i in range(min(T, k_steps)):
-                submit(i)
-            for i in range(k_steps):
-                stats.append(futs.pop(i).result())
-                if gather is not None:
-                    gather.launch(i)
-                if i + T < k_steps:
-                    submit(i + T)
+        for i in range(min(T, k_steps)):
+            submit(i)
+        for i in range(k_steps):
+            stats.append(futs.pop(i).result())
+            if gather is not None:
+                gather.launch(i)
+            if i + T < k_steps:
+                submit(i + T)
         if gather is not None:
             gather.wait_all()
         return stats
@@ -262,27 +341,26 @@ def main():
             el = float(t.item())
         return el, res
 
-    dev_slots = {}
+    dev_slots = [(torch.zeros((nq_max, cap, 4), dtype=torch.int32, device=dev), torch.zeros((nq_max,), dtype=torch.int32, device=dev))
+                 for _ in range(T_dev)]
+    torch.cuda.synchronize()
 
-    def run_device_pipeline(wl, k_steps, gather=None):
-        """THE METRIC: K calls of the device entry point — query offsets / tokens already in HBM when the timed region starts,
-        records written to HBM — with args.threads calls in flight: ONE host thread enqueues them (fmx_match_batch_device_begin
-        returns once a call's launches are queued, _end waits for it), every call works in its own context and the library
-        chains them on the GPU so that a call's HBM-bound probe runs beside its predecessor's issue-bound second half.
-        No per-stage events, no statistics.  Step i + T is enqueued when step i has been waited for."""
-        wl.to_device()
-        T = max(args.threads, 1)
-        if wl not in dev_slots:
-            dev_slots[wl] = [(None, torch.zeros((max(wl.nq, 1), cap, 4), dtype=torch.int32, device=dev),
-                              torch.zeros((max(wl.nq, 1),), dtype=torch.int32, device=dev)) for _ in range(T)]
-            torch.cuda.synchronize()
-        slots = dev_slots[wl]
+    def run_device_pipeline(wls, k_steps, gather=None):
+        """Side leg `device_resident`: K calls of the device entry point — query offsets / ids already in HBM when the timed region
+        starts, records written to HBM — with T_dev calls in flight: ONE host thread enqueues them (fmx_match_batch_device_begin
+        returns once a call's launches are queued, _end waits for it), every call works in its own context.  No per-stage events,
+        no statistics.  Step i (batch i % len(wls)) is enqueued when step i - T has been waited for."""
+        for wl in wls:
+            wl.to_device()
+        T = T_dev
+        nb = len(wls)
 
         def begin(i):
+            wl = wls[i % nb]
             if gather is not None:   # N > 1: the records are written where the RCCL gather of this step picks them up
                 d_out, d_cnt = gather.buffers(i, host_sync=True)  # the slot's previous gather is over
             else:
-                _, d_out, d_cnt = slots[i % T]
+                d_out, d_cnt = dev_slots[i % T]
             return ix.device_begin(params, wl.nq, wl.d_off.data_ptr(), wl.d_tok.data_ptr(), wl.total_tokens, d_out.data_ptr(),
                                    d_cnt.data_ptr(), 0, cap, stream=0, max_len=wl.max_len)
 
@@ -295,53 +373,86 @@ def main():
                 pending[i + T] = begin(i + T)
         if gather is not None:
             gather.wait_all()
-        return slots
 
-    def run_device_steps(wl, k_steps):
-        """The same batch, one call at a time with per-stage HIP events (stage times for the rooflines)."""
-        wl.to_device()
-        d_out = torch.zeros((max(wl.nq, 1), cap, 4), dtype=torch.int32, device=dev)
-        d_cnt = torch.zeros((max(wl.nq, 1),), dtype=torch.int32, device=dev)
+    st_out = torch.zeros((nq_max, cap, 4), dtype=torch.int32, device=dev)
+    st_cnt = torch.zeros((nq_max,), dtype=torch.int32, device=dev)
+
+    def run_device_steps(wls, k_steps, first=0):
+        """One call at a time with per-stage HIP events (stage times for the rooflines); step i runs batch (first + i) % len(wls)."""
+        for wl in wls:
+            wl.to_device()
         sts = []
-        for _ in range(k_steps):
+        for i in range(k_steps):
+            wl = wls[(first + i) % len(wls)]
             sts.append(ix.match_batch_device(params, wl.nq, wl.d_off.data_ptr(), wl.d_tok.data_ptr(), wl.total_tokens,
-                                             d_out.data_ptr(), d_cnt.data_ptr(), 0, cap, stream=0, max_len=wl.max_len))
-        return sts, d_out, d_cnt
+                                             st_out.data_ptr(), st_cnt.data_ptr(), 0, cap, stream=0, max_len=wl.max_len))
+        return sts
 
-    weak = Workload(w_off, w_tok)
-    strong = Workload(s_off, s_tok) if world > 1 else weak
-    main_wl, other_wl = (weak, strong) if args.scaling == "weak" else (strong, weak)
-
-    if args.child and os.environ.get("FMX_CHILD_MODE") == "pipeline":  # design-time: trace of the timed region itself
-        run_device_pipeline(main_wl, 2 * max(args.threads, 1) + args.warmup)
+    if args.child and os.environ.get("FMX_CHILD_MODE") == "pipeline":  # design-time: trace of the overlapped device-resident calls
+        run_device_pipeline(main_set, 2 * T_dev + args.warmup)
         torch.cuda.synchronize()
-        run_device_pipeline(main_wl, args.steps)
+        run_device_pipeline(main_set, args.steps)
         torch.cuda.synchronize()
         return
-    if args.child:  # profiling child of a --pmc pass: device-resident steps, nothing else
-        run_device_steps(main_wl, args.warmup)
+    if args.child and os.environ.get("FMX_CHILD_MODE") == "text":      # design-time: trace of the timed region of `value`
+        run_host_steps(main_set[:NB_host], 2 * T_host + args.warmup, "text")
         torch.cuda.synchronize()
-        run_device_steps(main_wl, args.steps)
+        run_host_steps(main_set[:NB_host], args.steps, "text")
+        torch.cuda.synchronize()
+        return
+    if args.child:  # profiling child of a --pmc pass: device-resident steps one at a time, nothing else
+        run_device_steps(main_set, args.warmup)
+        torch.cuda.synchronize()
+        run_device_steps(main_set, args.steps)
         torch.cuda.synchronize()
         return
 
-    # ---- PCIe-inclusive steps through fmx_match_batch (reported beside the metric, never as `value`) ----
-    def measure(wl):
-        gather = shard.RecordGather(wl.nq, cap, dev, dst=0, depth=max(args.threads, 1) + 1, coll_device=cdev) if (world > 1 or args.force_gather) else None
+    def make_gather(wls):
+        if not (world > 1 or args.force_gather):
+            return None
+        return shard.RecordGather(wls[0].nq, cap, dev, dst=0, depth=T_dev + 1, coll_device=cdev)
+
+    # what a leg's last timed step left behind, sampled for the parity check: {leg: (batch index, query indices, records, counts)}
+    samples = {}
+
+    def sample_idx(nq):
+        nv = min(args.verify, nq)
+        return (np.arange(nv, dtype=np.int64) * nq // max(nv, 1)) if nv else np.zeros(0, np.int64)
+
+    def keep_host_sample(leg, k_steps, wls):
+        if rank != 0 or not args.verify:
+            return
+        i = k_steps - 1
+        b = i % len(wls)
+        idx = sample_idx(wls[b].nq)
+        o, c, _ = out_slots[i % T_host]
+        samples[leg] = (b, idx, o[idx].copy(), c[idx].copy())
+
+    def measure_host(wls, kind, k_steps, leg):
+        gather = make_gather(wls)
         # set-up, not warm-up: every call in flight works in its own context, and a context sizes its workspace on its
         # first batches (allocation + re-runs); two rounds of T concurrent calls leave all T contexts grown
-        run_host_steps(wl, 2 * max(args.threads, 1), gather)
-        run_host_steps(wl, args.warmup, gather)
-        el, sts = timed(lambda k: run_host_steps(wl, k, gather), args.steps)
+        run_host_steps(wls, 2 * T_host, kind, gather)
+        run_host_steps(wls, args.warmup, kind, gather)
+        el, sts = timed(lambda k: run_host_steps(wls, k, kind, gather), k_steps)
+        if leg:
+            keep_host_sample(leg, k_steps, wls)
         return el, sts
 
-    def measure_device(wl):
-        gather = shard.RecordGather(wl.nq, cap, dev, dst=0, depth=max(args.threads, 1) + 1, coll_device=cdev) if (world > 1 or args.force_gather) else None
-        run_device_pipeline(wl, 2 * max(args.threads, 1), gather)   # set-up: every context in flight sizes its workspace once
-        run_device_pipeline(wl, args.warmup, gather)
-        el, _ = timed(lambda k: run_device_pipeline(wl, k, gather), args.steps)
-        if gather is not None:  # the parity check below reads slot 0 of the plain buffers
-            run_device_pipeline(wl, 1)
+    def measure_device(wls, leg):
+        gather = make_gather(wls)
+        run_device_pipeline(wls, 2 * T_dev, gather)   # set-up: every context in flight sizes its workspace once
+        run_device_pipeline(wls, args.warmup, gather)
+        el, _ = timed(lambda k: run_device_pipeline(wls, k, gather), args.steps)
+        if gather is not None:  # the parity check reads the plain slots
+            run_device_pipeline(wls, args.steps)
+        if leg and rank == 0 and args.verify:
+            i = args.steps - 1
+            b = i % len(wls)
+            idx = sample_idx(wls[b].nq)
+            d_out, d_cnt = dev_slots[i % T_dev]
+            tidx = torch.from_numpy(idx).to(dev)
+            samples[leg] = (b, idx, d_out[tidx].cpu().numpy().view(fmx.MATCH_DTYPE).reshape(len(idx), cap), d_cnt[tidx].cpu().numpy().astype(np.uint32))
         return el
 
     def all_ranks(n):
@@ -351,176 +462,98 @@ def main():
         dist.all_reduce(t)
         return int(t.item())
 
-    def measure_from_strings(wl):
-        """SURVEY §8(d)'s bracket includes the per-query host prep — VocabIndexer::getIndex per pattern token (src/fuzzy_match.cc:
-        468-470).  This leg starts from token STRINGS: every step looks its tokens up (fmx_vocab_lookup_mt, host threads) into the
-        pinned id buffer and then runs the host-buffer call.  The spellings are the generator's (tools/fm_synth.c: fms_word)."""
-        import ctypes
-        buf = ctypes.create_string_buffer(32)
-        words = [b"", b""]
-        for k in range(vs - 2):
-            n = L.fms_word(k, buf, 32)
-            words.append(buf.raw[:n])
-        offs = np.full(len(words), 0xffffffffffffffff, np.uint64)
-        pos = 0
-        for k in range(2, len(words)):
-            offs[k] = pos
-            pos += len(words[k]) + 1
-        arena = np.frombuffer(b"".join(w + b"\0" for w in words[2:]), dtype=np.uint8).copy()
-        word_ptrs = ix.set_forms_packed(arena, offs)
-        tok_ptrs = np.ascontiguousarray(word_ptrs[wl.q_tok])          # one char pointer per pattern token of the batch
-        T = max(min(args.host_threads, args.threads), 1)
-        cores = max(1, (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count() or 1))
-        try:
-            import oracle_lib as _ol
-            cores = _ol.effective_cpus()
-        except Exception:  # noqa: BLE001
-            pass
-        per_call = max(1, cores // T)
-        ids = [fmx.pinned_empty(len(wl.q_tok), np.uint32) for _ in range(T)]
-        t_lookup = [0.0]
-
-        def one(i):
-            a = time.perf_counter()
-            ix.vocab_lookup_ptrs(tok_ptrs, ids[i % T], per_call)
-            t_lookup[0] += time.perf_counter() - a
-            return ix.match_batch(params, wl.q_off, ids[i % T], cap=cap, want_stats=True, out=wl.out[i % T])[3]
-
-        def run(k_steps):
-            futs = {i: pool.submit(one, i) for i in range(min(T, k_steps))}
-            for i in range(k_steps):
-                futs.pop(i).result()
-                if i + T < k_steps:
-                    futs[i + T] = pool.submit(one, i + T)
-
-        run(T)
-        assert np.array_equal(ids[0], wl.q_tok), "vocabulary lookup does not reproduce the ids"
-        t_lookup[0] = 0.0
-        k = max(6, args.steps // 2)
-        el, _ = timed(run, k)
-        return {"value": round(wl.nq * k / el, 1), "ms_per_step": round(el / k * 1e3, 3), "steps": k,
-                "lookup_ms_per_step": round(t_lookup[0] / k * 1e3, 3), "lookup_threads_per_call": per_call, "calls_in_flight": T,
-                "tokens_per_step": int(len(wl.q_tok)),
-                "note": "fmx_vocab_lookup_mt (token strings -> ids, in the timed region) + fmx_match_batch (pinned host buffers)"}
-
-    # The metric first.  (Round 3, first half: the host-buffer steps ran first because at C2 they lost a third when measured after
-    # the device-resident ones; with eight hardware queues the order no longer matters to them — 1.41-1.53 ms either way — while
-    # a host-buffer leg with too many busy queues can leave the process's queues time-sliced and cost the metric 5 %.)
-    host_first = os.environ.get("FMX_BENCH_ORDER", "dev_first") == "host_first"
-    if host_first:
-        elapsed_host, host_stats = measure(main_wl)
-    # ---- THE METRIC: inputs resident in HBM when the timed region starts ----
-    elapsed = measure_device(main_wl)
-    nq_step_all = all_ranks(main_wl.nq)
+    host_set = main_set[:NB_host]
+    # ---- THE METRIC: SURVEY §8(d)'s bracket.  Packed spellings in pinned host memory -> H2D -> k_vocab_lookup -> pipeline -> D2H ----
+    elapsed, text_stats = measure_host(host_set, "text", args.steps, "value")
+    nq_step_all = all_ranks(host_set[0].nq)
     value = nq_step_all * args.steps / elapsed
-    # ---- the same steps from pinned host buffers (H2D + kernels + D2H; + the RCCL gather of the records when N > 1) ----
-    if not host_first:
-        elapsed_host, host_stats = measure(main_wl)
-    value_host = nq_step_all * args.steps / elapsed_host
+    # ---- side legs ----
+    elapsed_dev = measure_device(main_set, "device_resident")
+    value_dev = nq_step_all * args.steps / elapsed_dev
+    elapsed_ids, ids_stats = measure_host(host_set, "ids", args.steps, "pcie_inclusive_ids")
+    value_ids = nq_step_all * args.steps / elapsed_ids
     scaling_other = None
     if world > 1:
-        el2 = measure_device(other_wl)
-        el2h, _ = measure(other_wl)
-        n2 = all_ranks(other_wl.nq)
-        scaling_other = {"scaling": "strong" if args.scaling == "weak" else "weak", "value": round(n2 * args.steps / el2, 1),
+        el2, _ = measure_host(other_set, "text", args.steps, None)
+        el2d = measure_device(other_set, None)
+        n2 = all_ranks(other_set[0].nq)
+        scaling_other = {"scaling": other_scaling, "value": round(n2 * args.steps / el2, 1),
                          "ms_per_step": round(el2 / args.steps * 1e3, 3), "queries_per_step_all_ranks": n2,
-                         "pcie_inclusive_value": round(n2 * args.steps / el2h, 1)}
+                         "device_resident_value": round(n2 * args.steps / el2d, 1)}
 
-    from_strings = measure_from_strings(main_wl) if (world == 1 and not args.no_text_leg) else None
-
-    def measure_from_packed_text(wl):
-        """The same bracket with the id lookup ON THE DEVICE (fmx_match_batch_text): a step hands over its patterns as packed token
-        spellings — NUL-terminated, back to back, what a tokenizer writes — in pinned host memory; the spellings cross PCIe instead
-        of the ids, k_vocab_lookup turns them into ids in HBM, the pipeline follows.  Records come back to pinned host buffers."""
-        import ctypes
-        buf = ctypes.create_string_buffer(32)
-        wlen = np.zeros(vs, np.int64)
-        parts = []
-        woff = np.zeros(vs, np.int64)
-        pos = 0
-        for k in range(vs - 2):
-            n = L.fms_word(k, buf, 32)
-            parts.append(buf.raw[:n] + b"\0")
-            wlen[k + 2] = n + 1
-            woff[k + 2] = pos
-            pos += n + 1
-        arena = np.frombuffer(b"".join(parts), dtype=np.uint8)
-        tl = wlen[wl.q_tok]
-        total = int(tl.sum())
-        text = fmx.pinned_empty(total, np.uint8)
-        at = 0
-        for lo in range(0, len(wl.q_tok), 1 << 21):  # in slices: the gather index of the whole batch would be gigabytes
-            t = wl.q_tok[lo:lo + (1 << 21)]
-            ln = wlen[t]
-            n = int(ln.sum())
-            start = np.cumsum(ln) - ln
-            idx = np.repeat(woff[t] - start, ln) + np.arange(n)
-            text[at:at + n] = arena[idx]
-            at += n
-        T = max(min(args.host_threads, args.threads), 1)
-
-        def one(i):
-            return ix.match_batch_text(params, wl.q_off, text, cap=cap, want_stats=True, out=wl.out[i % T])[3]
-
-        def run(k_steps):
-            futs = {i: pool.submit(one, i) for i in range(min(T, k_steps))}
-            for i in range(k_steps):
-                futs.pop(i).result()
-                if i + T < k_steps:
-                    futs[i + T] = pool.submit(one, i + T)
-
-        run(2 * T)
-        ref = ix.match_batch(params, wl.q_off, wl.q_tok, cap=cap)
-        got = ix.match_batch_text(params, wl.q_off, text, cap=cap)
-        assert np.array_equal(ref[1], got[1]) and ref[0][:2000].tobytes() == got[0][:2000].tobytes(), "text batch differs from the id batch"
-        k = max(6, args.steps // 2)
-        el, _ = timed(run, k)
-        return {"value": round(wl.nq * k / el, 1), "ms_per_step": round(el / k * 1e3, 3), "steps": k, "calls_in_flight": T,
-                "text_bytes_per_step": total, "tokens_per_step": int(len(wl.q_tok)),
-                "note": "fmx_match_batch_text: packed token spellings in pinned host memory -> H2D -> k_vocab_lookup (ids in HBM) -> pipeline -> "
-                        "records to pinned host buffers; checked against the id batch"}
-
-    from_text = None
+    from_strings = None
+    str_ids, str_threads, t_lookup = [], 1, [0.0]
     if world == 1 and not args.no_text_leg:
-        try:
-            from_text = measure_from_packed_text(main_wl)
-        except Exception as e:  # noqa: BLE001  (a side leg: the line is still worth printing)
-            log(f"[bench] from_packed_text leg failed: {e!r}")
+        # SURVEY §8(d)'s bracket with the id lookup on HOST threads — VocabIndexer::getIndex per pattern token (src/fuzzy_match.cc:
+        # 468-470) as fmx_vocab_lookup_mt over one char pointer per token — then the host-buffer call.  Two batches rotate (a batch
+        # of pointers is 200 MB).
+        import oracle_lib as _ol
+        cores = _ol.effective_cpus()
+        str_threads = max(1, cores // T_host)
+        str_set = host_set[:2]
+        for wl in str_set:
+            wl.tok_ptrs = np.ascontiguousarray(word_ptrs[wl.q_tok])          # one char pointer per pattern token of the batch
+        str_ids = [fmx.pinned_empty(max(len(w.q_tok) for w in str_set), np.uint32) for _ in range(T_host)]
+        run_host_steps(str_set, T_host, "strings")
+        assert np.array_equal(str_ids[(T_host - 1) % T_host][:len(str_set[(T_host - 1) % 2].q_tok)], str_set[(T_host - 1) % 2].q_tok), "vocabulary lookup does not reproduce the ids"
+        t_lookup[0] = 0.0
+        k = max(6, args.steps // 2)
+        el, _ = timed(lambda kk: run_host_steps(str_set, kk, "strings"), k)
+        from_strings = {"value": round(str_set[0].nq * k / el, 1), "ms_per_step": round(el / k * 1e3, 3), "steps": k,
+                        "lookup_ms_per_step": round(t_lookup[0] / k * 1e3, 3), "lookup_threads_per_call": str_threads, "calls_in_flight": T_host,
+                        "tokens_per_step": int(len(str_set[0].q_tok)),
+                        "note": "fmx_vocab_lookup_mt (token strings -> ids on host threads, in the timed region) + fmx_match_batch (pinned host buffers)"}
+        for wl in str_set:
+            wl.tok_ptrs = None
 
-    # ---- the same batch from HBM (device entry point): stage times for the rooflines ----
-    run_device_steps(main_wl, 1)
-    el_dev, (dev_stats, d_out, d_cnt) = timed(lambda k: run_device_steps(main_wl, k), args.steps)
+    # ---- one call at a time from HBM (device entry point with statistics): stage times for the rooflines ----
+    run_device_steps(main_set, 1)
+    el_dev, dev_stats = timed(lambda k: run_device_steps(main_set, k), args.steps)
+    if rank == 0 and args.verify:
+        b = (args.steps - 1) % len(main_set)
+        idx = sample_idx(main_set[b].nq)
+        tidx = torch.from_numpy(idx).to(dev)
+        samples["staged"] = (b, idx, st_out[tidx].cpu().numpy().view(fmx.MATCH_DTYPE).reshape(len(idx), cap), st_cnt[tidx].cpu().numpy().astype(np.uint32))
     names = fmx.stage_names()
     stage_ms = np.zeros(16)
     for st in dev_stats:
         stage_ms += np.array(list(st.ms_kernel))
     per_stage = {n: float(stage_ms[i] / max(args.steps, 1)) for i, n in enumerate(names)}
-    last = dev_stats[-1]
-    # per-rank probe GB/s of its own byte model needs the counting variant of the kernel: one untimed step
+    K = max(len(dev_stats), 1)
+
+    def mean_ctr(name):   # kernel counters, averaged over the staged steps (the batches rotate)
+        return sum(float(getattr(s, name)) for s in dev_stats) / K
+
+    max_kept = max(int(s.max_kept) for s in dev_stats)
+    # bytes / lines the probe's own loads request: the counting variant of the kernel, one untimed step per distinct batch
     ix.set_option("probe_count", 1)
-    (cst,), _, _ = run_device_steps(main_wl, 1)
+    csts = run_device_steps(main_set, len(main_set))
     ix.set_option("probe_count", 0)
     torch.cuda.synchronize()
+    probe_bytes = sum(float(s.probe_bytes) for s in csts) / len(csts)
+    probe_lines = sum(float(s.probe_lines) for s in csts) / len(csts)
+    tot_tokens = sum(w.total_tokens for w in main_set) / len(main_set)
 
     # stage "expand_a" = k_expand_a and k_expand_h side by side (main stream: until both are done); "expand_l" = the second
     # scan + k_expand_b<true> with k_expand_b<false> beside it, "expand_wait" = what is left of the latter afterwards
     probe_ms, exa_ms = per_stage.get("probe", 0.0), per_stage.get("expand_a", 0.0)
     # byte models of THIS algorithm, per launch, from the kernels' own counters (DESIGN.md §5):
-    #   k_probe     bytes its loads request (n-gram, qva pair, 16 B table entries, 32 B keys per bisection level, ...)
+    #   k_probe     bytes its loads request (n-gram, qva pair, table buckets, key tails, ...)
     #   expand_a    k_expand_a: 8 B per hit it walks (short ranges of the queries that are not light); k_expand_h: 8 B per
     #               plane word + 8 B per hit re-tested exactly; both: 8 B per hit queued for k_expand_b<false>; 8 B per
     #               (query, start) range descriptor of the queries they visit (upper bound: all)
-    b_probe = float(cst.probe_bytes)
-    walked_a = last.n_hits - last.n_heavy_hits - last.n_light_hits
-    queued = last.n_phase_b - last.n_light_hits
-    b_exa = 8.0 * walked_a + 8.0 * last.plane_words + 8.0 * last.n_heavy_pass + 8.0 * queued + 8.0 * main_wl.total_tokens
+    b_probe = probe_bytes
+    n_hits, n_heavy_hits, n_light_hits = mean_ctr("n_hits"), mean_ctr("n_heavy_hits"), mean_ctr("n_light_hits")
+    n_phase_b, n_kept, n_cand, n_rerank = mean_ctr("n_phase_b"), mean_ctr("n_kept"), mean_ctr("n_candidates"), mean_ctr("n_rerank")
+    walked_a = n_hits - n_heavy_hits - n_light_hits
+    queued = n_phase_b - n_light_hits
+    b_exa = 8.0 * walked_a + 8.0 * mean_ctr("plane_words") + 8.0 * mean_ctr("n_heavy_pass") + 8.0 * queued + 8.0 * tot_tokens
     #   expand_b    k_expand_b<true> (light queries): 8 B range descriptor per start position + 16 B record per hit;
     #               k_expand_b<false>: 8 B queue entry + 16 B record per queued hit; both: the pattern once per query, and for
     #               every hit kept the sentence's tokens (mean length of the corpus) and a 16 B segment entry; the tokens of
     #               hits that fail the dominance / coverage tests are not counted (a lower bound of what the kernels read)
     exb_ms = per_stage.get("expand_l", 0.0) + per_stage.get("expand_wait", 0.0)
-    b_exb = (16.0 * last.n_light_hits + 24.0 * queued + 12.0 * main_wl.total_tokens
-             + last.n_kept * (4.0 * (mean_len + 1) + 16.0))
+    b_exb = (16.0 * n_light_hits + 24.0 * queued + 12.0 * tot_tokens + n_kept * (4.0 * (mean_len + 1) + 16.0))
     probe_gbs = b_probe / (probe_ms * 1e-3) / 1e9 if probe_ms > 0 else 0.0
     exa_gbs = b_exa / (exa_ms * 1e-3) / 1e9 if exa_ms > 0 else 0.0
     rank_rates = None
@@ -533,19 +566,22 @@ def main():
 
     line = None
     if rank == 0:
-        log(f"[bench] value (inputs in HBM, {args.threads} calls in flight): {value / 1e6:.2f} M patterns/s, {elapsed / args.steps * 1e3:.3f} ms/step; "
-            f"PCIe-inclusive: {value_host / 1e6:.2f} M patterns/s, {elapsed_host / args.steps * 1e3:.3f} ms/step "
-            f"(pinned={host_stats[-1].pinned}); one call at a time with stage events: {main_wl.nq * args.steps / el_dev / 1e6:.2f} M patterns/s")
-        log(f"[bench] host-path calls: retries {sum(int(s.n_retries) for s in host_stats)}, ms per call min/median/max "
-            f"{min(s.ms_total for s in host_stats):.2f}/{float(np.median([s.ms_total for s in host_stats])):.2f}/{max(s.ms_total for s in host_stats):.2f}")
+        log(f"[bench] value (packed spellings in pinned host memory -> records in pinned host memory, {T_host} calls in flight): {value / 1e6:.2f} M patterns/s, "
+            f"{elapsed / args.steps * 1e3:.3f} ms/step; device-resident ({T_dev} in flight): {value_dev / 1e6:.2f} M, {elapsed_dev / args.steps * 1e3:.3f} ms/step; "
+            f"from ids in pinned host memory: {value_ids / 1e6:.2f} M, {elapsed_ids / args.steps * 1e3:.3f} ms/step (pinned={ids_stats[-1].pinned}); "
+            f"one call at a time with stage events: {main_set[0].nq * args.steps / el_dev / 1e6:.2f} M patterns/s")
+        log(f"[bench] value-leg calls: retries {sum(int(s.n_retries) for s in text_stats)}, ms per call min/median/max "
+            f"{min(s.ms_total for s in text_stats):.2f}/{float(np.median([s.ms_total for s in text_stats])):.2f}/{max(s.ms_total for s in text_stats):.2f}")
         log(f"[bench] kernel ms/step by stage: { {k: round(v, 3) for k, v in per_stage.items()} }")
-        log(f"[bench] last step: hits {last.n_hits} (bit planes {last.n_heavy_hits}, passed {last.n_heavy_pass}) phaseB {last.n_phase_b} "
-            f"(light queries {last.n_light_hits}) kept {last.n_kept} candidates {last.n_candidates} retries {last.n_retries} big {last.n_big} max_kept {last.max_kept}")
+        log(f"[bench] mean step: hits {n_hits:.0f} (bit planes {n_heavy_hits:.0f}, passed {mean_ctr('n_heavy_pass'):.0f}) phaseB {n_phase_b:.0f} "
+            f"(light queries {n_light_hits:.0f}) kept {n_kept:.0f} candidates {n_cand:.0f} retries {sum(int(s.n_retries) for s in dev_stats)} "
+            f"big {mean_ctr('n_big'):.1f} max_kept {max_kept}")
 
-        # ---- HBM traffic of the two kernels, measured now: rocprofv3 --pmc child passes (separate passes) ----
+        # ---- HBM traffic of the kernels, measured now: rocprofv3 --pmc child passes (separate passes) ----
         traffic = {}
         if world == 1 and not args.no_pmc:
-            child = ["--config", args.config, "--steps", "2", "--warmup", "1", "--scaling", args.scaling]
+            child = ["--config", args.config, "--steps", "2", "--warmup", "1", "--scaling", args.scaling, "--threads", str(args.threads),
+                     "--host-threads", str(args.host_threads)]
             if args.sentences:
                 child += ["--sentences", str(args.sentences)]
             if args.queries:
@@ -583,39 +619,40 @@ def main():
                     "model": what}
 
         r_probe = roof("k_probe", b_probe, probe_ms, ["k_probe"],
-                       "bytes requested by the kernel's own loads, counted by k_probe<COUNT> on the same batch: seed n-gram, "
-                       "_quickVocabAccess pair, 16 B trigram / 5-gram entries, two 32 B keys per bisection level")
+                       "bytes requested by the kernel's own loads, counted by k_probe<COUNT> on the same batches: seed n-gram, "
+                       "_quickVocabAccess pair, n-gram table buckets, key tails / 32 B keys of the bisection")
         r_exa = roof("k_expand_h+k_expand_a", b_exa, exa_ms, ["k_expand_a", "k_expand_h"],
                      "phase A of the queries with long ranges or many hits (two kernels side by side): 8 B per bit-plane word, "
                      "8 B per plane survivor re-tested, 8 B per hit walked one by one, 8 B per hit queued, 8 B per range "
                      "descriptor (kernel counters)")
-        r_probe["lines_bytes_per_launch"] = int(cst.probe_lines) * 128  # distinct 128 B lines x 128: what random reads cost the memory system
+        r_probe["lines_bytes_per_launch"] = int(probe_lines) * 128  # 128 B lines its loads touch x 128: what random reads cost the memory system
         r_exb = roof("k_expand_b<true>+k_expand_b<false>", b_exb, exb_ms, ["k_expand_b"],
                      "hit walk of the light queries + phase B of the others (side by side): 8 B range descriptor per start, 16 B "
                      "record per light hit, 8 B queue entry + 16 B record per queued hit, 4 B per pattern token, and per kept "
                      "hit its sentence (4 B x (mean length + 1)) and a 16 B segment entry; reads for hits that fail the "
-                     "dominance / exact coverage tests are not counted (lower bound)")
+                     "dominance / length tests are not counted (lower bound)")
         # edit distances: per candidate its sentence (length word + tokens), the 16 B candidate record read and written back, the
         # 8 B list entry; the pattern is shared by the candidates of a query (4 B per pattern token per query)
         dp_ms = per_stage.get("dp", 0.0)
-        b_dp = last.n_candidates * (4.0 * (mean_len + 1) + 16.0 + 16.0 + 8.0) + 4.0 * main_wl.total_tokens
+        b_dp = n_cand * (4.0 * (mean_len + 1) + 16.0 + 16.0 + 8.0) + 4.0 * tot_tokens
         r_dp = roof("k_dp_reg<32|64>", b_dp, dp_ms, ["k_dp_reg"],
                     "one lane per (query, candidate): 4 B x (sentence length + 1) of the sentence, 16 B candidate record in and out, 8 B "
                     "list entry, 4 B per pattern token per query (kernel counters; mean sentence length of the corpus)")
-        roofs = sorted([r_probe, r_exa, r_exb], key=lambda r: -r["kernel_ms"]) + [r_dp]
+        roofs = [r_probe, r_exa, r_exb, r_dp]
         if pkw.get("contrast", 0.0) > 0.0:
             # the contrastive rerank: per sentence-pair distance both sentences and the per-match state (list entry 8, record 16,
             # keys 8 + 8, penalty sum 4 + 4, penalty 4, two sentence positions 8); per candidate the 16 B record the replay reads
             fin_ms = per_stage.get("finish", 0.0)
-            b_fin = last.n_rerank * (8.0 * (mean_len + 1) + 64.0) + 16.0 * last.n_candidates
-            roofs.append(roof("finish stage: k_finish<64> + k_camap + nmatch x k_cround<32|64>", b_fin, fin_ms, ["k_finish", "k_camap", "k_cround"],
-                              f"replay + contrastive rerank; {int(last.n_rerank)} sentence-pair edit distances per step (kernel counter) x (two sentences "
+            b_fin = n_rerank * (8.0 * (mean_len + 1) + 64.0) + 16.0 * n_cand
+            roofs.append(roof("finish stage: replay + k_camap + nmatch x k_cround<32|64>", b_fin, fin_ms, ["k_finish", "k_camap", "k_cround"],
+                              f"replay + contrastive rerank; {int(n_rerank)} sentence-pair edit distances per step (kernel counter) x (two sentences "
                               "of 4 B x (mean length + 1) + 64 B of per-match state) + 16 B per candidate; the rounds are bound by VALU issue "
-                              "(~1800 instructions per distance, VALU busy 0.75: profiles/r03_c5_pmc_sq.csv), not by HBM — priced here because the "
-                              "line's schema has no issue roofline"))
+                              "(~1800 instructions per distance), not by HBM — priced here because the line's schema has no issue roofline"))
+        # the dominant kernel group = the longest stage, whatever it is (C5: the finish stage)
+        roofs.sort(key=lambda r: -r["kernel_ms"])
         dominant, others = roofs[0], roofs[1:]
 
-        # ---- parity spot check, reference byte model, CPU baseline (the oracle: test infrastructure, outside the timed region) ----
+        # ---- parity check, reference byte model, CPU baseline (the oracle: test infrastructure, outside the timed region) ----
         import oracle_lib
         t1 = time.time()
         o = oracle_lib.OracleIndex()
@@ -623,26 +660,22 @@ def main():
                      ix.array("qva"), ix.array("sfreq"))
         log(f"[bench] oracle index ready in {time.time() - t1:.1f}s")
         oprm = oracle_lib.Params(**pkw)
-        q_off, q_tok = main_wl.q_off, main_wl.q_tok
-        nq = main_wl.nq
         parity = ref_model = cpu_baseline = None
-        nv = min(args.verify, nq)
-        if nv:
-            oo, oc = o.match_batch(oprm, q_off[:nv + 1], q_tok[:int(q_off[nv])], cap, nthreads=oracle_lib.effective_cpus())
-            bad_h = bad_d = bad_p = 0
-            ho, hc_, _ = main_wl.out[0]
-            go = d_out[:nv].cpu().numpy().view(oracle_lib.MATCH_DTYPE).reshape(nv, cap)
-            gc = d_cnt[:nv].cpu().numpy().astype(np.uint32)
-            _, p_out, p_cnt = dev_slots[main_wl][0]          # what the timed (pipelined, stats-less) device calls left in HBM
-            po = p_out[:nv].cpu().numpy().view(oracle_lib.MATCH_DTYPE).reshape(nv, cap)
-            pc = p_cnt[:nv].cpu().numpy().astype(np.uint32)
-            for q in range(nv):
-                ref = oo[q, :oc[q]].tobytes()
-                bad_h += int(oc[q] != hc_[q] or ref != ho[q, :hc_[q]].tobytes())
-                bad_d += int(oc[q] != gc[q] or ref != go[q, :gc[q]].tobytes())
-                bad_p += int(oc[q] != pc[q] or ref != po[q, :pc[q]].tobytes())
-            parity = {"checked": int(nv), "mismatches": int(bad_h + bad_d + bad_p),
-                      "paths": "the timed device calls, the host-buffer entry point and the staged device calls vs oracle"}
+        if samples:
+            bad = {}
+            want = {}
+            for leg, (b, idx, recs, cnts) in samples.items():
+                wl = (host_set if leg in ("value", "pcie_inclusive_ids") else main_set)[b]
+                key = (id(wl), len(idx))
+                if key not in want:
+                    s_off, s_tok = take_queries(wl.q_off, wl.q_tok, idx)
+                    want[key] = o.match_batch(oprm, s_off, s_tok, cap, nthreads=oracle_lib.effective_cpus())
+                oo, oc = want[key]
+                bad[leg] = sum(int(oc[q] != cnts[q] or oo[q, :oc[q]].tobytes() != recs[q, :cnts[q]].tobytes()) for q in range(len(idx)))
+            parity = {"checked": int(min(args.verify, host_set[0].nq)), "mismatches": int(sum(bad.values())), "per_leg": bad,
+                      "paths": "what the LAST timed step of each leg left behind (the value leg, the device-resident pipeline, the id batches, the "
+                               "staged calls), every (nq / checked)-th query of that step's batch, vs the oracle"}
+        q_off, q_tok, nq = main_set[0].q_off, main_set[0].q_tok, main_set[0].nq
         nm = min(args.model_queries, nq)
         if nm:
             _, _, ctr = o.match_batch(oprm, q_off[:nm + 1], q_tok[:int(q_off[nm])], cap, nthreads=oracle_lib.effective_cpus(),
@@ -665,11 +698,12 @@ def main():
             o.match_batch(oprm, q_off[:ns2 + 1], q_tok[:int(q_off[ns2])], cap, nthreads=cores)
             dt = time.perf_counter() - t1
             cpu_baseline = {"value": round(ns2 / dt, 1), "unit": "patterns/s", "cores": cores, "kind": "port",
-                            "sample": f"first {ns2} queries of the same {args.config} workload, oracle/fm_oracle.c "
+                            "sample": f"first {ns2} queries of batch 0 of the same {args.config} workload, oracle/fm_oracle.c "
                                       f"fmo_match_batch with {cores} threads (= usable CPUs: min(affinity, cgroup cpu.max) of "
-                                      f"{os.cpu_count()} hardware threads), {dt:.1f}s"}
+                                      f"{os.cpu_count()} hardware threads), ids in (no lookup), {dt:.1f}s"}
         o.close()
 
+        text_bytes = int(host_set[0].text.nbytes)
         line = {
             "metric": "query patterns/sec @ fuzzy=0.7, 5M-sentence .fmi; 1/2/4/8 GPU + CPU ref",
             "value": round(value, 1), "unit": "patterns/s", "n_gpus": world, "steps": args.steps,
@@ -679,20 +713,27 @@ def main():
                                    f"{nq_cfg} queries per {'GPU' if args.scaling == 'weak' else 'job'} per step, "
                                    + " ".join(f"{k}={v}" for k, v in pkw.items()),
                        "queries_per_step_all_ranks": nq_step_all, "sentences": n_sent, "index_bytes_hbm": int(info.device_bytes),
-                       "timed_path": "fmx_match_batch_device_begin / _end: query offsets / tokens resident in HBM when the timed region starts, "
-                                     f"records written to HBM, {args.threads} call(s) in flight enqueued by one host thread (each in its own context)"
+                       "timed_path": "SURVEY §8(d)'s bracket (cli/src/FuzzyMatch-cli.cc:450-467), PCIe inside: fmx_match_batch_text per step — packed token "
+                                     f"spellings in pinned host memory ({text_bytes} B per step) -> H2D -> vocabulary id lookup on the device (k_vocab_lookup) -> "
+                                     f"every kernel of the pipeline -> D2H of the top-N records into pinned host memory; {T_host} synchronous call(s) in flight "
+                                     f"(one host thread each, each in its own context); {len(host_set)} distinct query batches rotate through the steps"
                                      + (", + RCCL gather of every step's records to rank 0 (asynchronous, under the steps in flight)" if world > 1 else ""),
+                       "distinct_batches": {"value_leg": len(host_set), "device_resident": len(main_set), "seeds": f"QUERY_SEED + k{' + 101 x rank' if args.scaling == 'weak' else ''}"},
+                       "index_via_fmi": via_fmi,
                        "parallelism": f"queries sharded over {world} GPU(s), index replicated"},
             "roofline": dominant, "roofline_other": others, "reference_byte_model": ref_model,
-            "pcie_inclusive": {"value": round(value_host, 1), "ms_per_step": round(elapsed_host / args.steps * 1e3, 3),
-                               "note": "the same steps through fmx_match_batch: pinned host buffers in and out (H2D + kernels + D2H"
-                                       + (" + the RCCL gather of the records to rank 0" if world > 1 else "") + f"), {max(min(args.host_threads, args.threads), 1)} call(s) in flight"},
-            "from_token_strings": from_strings, "from_packed_text": from_text,
+            "device_resident": {"value": round(value_dev, 1), "ms_per_step": round(elapsed_dev / args.steps * 1e3, 3), "calls_in_flight": T_dev,
+                                "note": "NOT the metric's bracket: fmx_match_batch_device_begin / _end, query offsets / ids resident in HBM when the timed "
+                                        "region starts, records left in HBM (no lookup, no PCIe); one host thread enqueues, each call in its own context"},
+            "pcie_inclusive_ids": {"value": round(value_ids, 1), "ms_per_step": round(elapsed_ids / args.steps * 1e3, 3), "calls_in_flight": T_host,
+                                   "note": "fmx_match_batch: vocabulary ids in pinned host memory in, records out (H2D + kernels + D2H"
+                                           + (" + the RCCL gather" if world > 1 else "") + "): a caller that already holds ids"},
+            "from_token_strings": from_strings,
             "staged": {"value": round(nq_step_all * args.steps / el_dev, 1),
                        "ms_per_step": round(el_dev / args.steps * 1e3, 3),
                        "stage_ms_per_step": {k: round(v, 4) for k, v in per_stage.items()},
-                       "note": "same batch from HBM, ONE call at a time, every pass synchronised and timed per stage with HIP events on "
-                               "the launch stream (the kernel times the rooflines are priced with)"},
+                       "note": "device-resident, ONE call at a time, every pass synchronised and timed per stage with HIP events on "
+                               "the launch stream (the kernel times the rooflines are priced with); batches rotate here too"},
             "scaling_other": scaling_other, "per_rank": rank_rates,
             "cpu_baseline": cpu_baseline, "parity": parity,
         }
@@ -700,6 +741,38 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def through_fmi(fmx, ix, device, rank, log):
+    """--via-fmi: the index as the metric names it — a .fmi file.  fmx_index_save writes the reference's on-disk format
+    (src/fuzzy_matcher_binarization.cc:16-30), fmx_index_load reads it back (:32-51); every array of the loaded index is compared with
+    the one that was saved.  Returns the loaded index (on the device) and the figures."""
+    path = os.path.join(tempfile.gettempdir(), f"fmx_bench_{os.getpid()}_{rank}.fmi")
+    try:
+        t0 = time.time()
+        ix.save(path)
+        t_save = time.time() - t0
+        size = os.path.getsize(path)
+        t0 = time.time()
+        ld = fmx.Index.load(path)
+        t_load = time.time() - t0
+        same = True
+        for name in ("suf_sid", "suf_pos", "buffer", "sent_pos", "qva", "sfreq"):
+            same = same and np.array_equal(ix.array(name), ld.array(name))
+        assert same, "the index loaded from the .fmi differs from the one that was saved"
+        a, b = ix.info(), ld.info()
+        assert (a.n_sentences, a.n_suffixes, a.vocab_size, a.max_tokens_in_pattern, a.pt) == (b.n_sentences, b.n_suffixes, b.vocab_size, b.max_tokens_in_pattern, b.pt)
+        ix.close()
+        t0 = time.time()
+        ld.finalize()
+        ld.to_device(device)
+        t_up = time.time() - t0
+        log(f"[bench] .fmi: {size / 1e9:.2f} GB, saved in {t_save:.1f}s, loaded in {t_load:.1f}s, finalized + uploaded in {t_up:.1f}s; arrays equal")
+        return {"index": ld, "file_bytes": int(size), "save_s": round(t_save, 2), "load_s": round(t_load, 2), "finalize_upload_s": round(t_up, 2),
+                "arrays_equal": True}
+    finally:
+        if os.path.exists(path):
+            os.unlink(path)
 
 
 if __name__ == "__main__":

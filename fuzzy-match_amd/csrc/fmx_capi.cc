@@ -465,6 +465,12 @@ int fmx_match_batch_keep(fmx_index* ix, const fmx_params* params, const fmx_batc
 
 int fmx_match_batch_text(fmx_index* ix, const fmx_params* params, const fmx_text_batch* tb, fmx_match* out,
                          uint32_t* out_count, uint32_t* out_total, uint32_t cap, fmx_stats* stats) {
+  return fmx_match_batch_text_keep(ix, params, tb, out, out_count, out_total, cap, nullptr, nullptr, stats);
+}
+
+int fmx_match_batch_text_keep(fmx_index* ix, const fmx_params* params, const fmx_text_batch* tb, fmx_match* out,
+                              uint32_t* out_count, uint32_t* out_total, uint32_t cap, fmx_match* d_keep, uint32_t* d_keep_count,
+                              fmx_stats* stats) {
   if (!ix || !params || !tb || !out || !out_count) return fail(FMX_E_INVALID, "null argument");
   if (tb->nq && (!tb->q_off || (tb->q_off[tb->nq] && !tb->text))) return fail(FMX_E_INVALID, "null batch arrays");
   if (tb->nq && tb->q_off[0] != 0) return fail(FMX_E_INVALID, "text batch: offsets must start at 0");
@@ -479,8 +485,9 @@ int fmx_match_batch_text(fmx_index* ix, const fmx_params* params, const fmx_text
     v.nq = tb->nq; v.q_off = tb->q_off; v.text = tb->text; v.n_text = tb->n_bytes;
     Stats st;
     // (one replica per call, round-robin: a block of a text batch would need the byte offset of its first spelling)
-    const size_t k = ix->devs.size() == 1 ? 0 : ix->rr.fetch_add(1) % ix->devs.size();
-    ix->devs[k]->match_host(ix->host, make_params(ix, params), v, (Rec*)out, out_count, out_total, cap, &st, nullptr, nullptr);
+    // (a kept copy lives on the first replica's device, like fmx_match_batch_keep's)
+    const size_t k = (ix->devs.size() == 1 || d_keep) ? 0 : ix->rr.fetch_add(1) % ix->devs.size();
+    ix->devs[k]->match_host(ix->host, make_params(ix, params), v, (Rec*)out, out_count, out_total, cap, &st, (Rec*)d_keep, d_keep_count);
     copy_stats(st, stats);
     return (int)FMX_OK;
   });

@@ -707,6 +707,7 @@ class Reader {
     return v;
   }
   void raw(void* dst, size_t n) { need(n); memcpy(dst, d_.data() + pos_, n); pos_ += n; }
+  const char* span(uint64_t n) { need(n); const char* p = d_.data() + pos_; pos_ += n; return p; }  // n bytes, consumed
   std::string str() {
     const uint64_t n = get<uint64_t>();
     need(n);
@@ -715,6 +716,12 @@ class Reader {
     return s;
   }
   uint32_t class_info() { get<uint8_t>(); return get<uint32_t>(); }  // tracking, version
+  // a collection size: every element takes at least `min_bytes` of what is left of the file (a corrupt count must not size a vector)
+  uint64_t count(uint64_t min_bytes) {
+    const uint64_t n = get<uint64_t>();
+    if (n > (d_.size() - pos_) / (min_bytes ? min_bytes : 1)) throw std::runtime_error("FMI file truncated or corrupt (collection size)");
+    return n;
+  }
   size_t pos() const { return pos_; }
   size_t size() const { return d_.size(); }
  private:
@@ -731,12 +738,12 @@ class Writer {
   void raw(const void* p, size_t n) { d_.insert(d_.end(), (const char*)p, (const char*)p + n); }
   void str(const std::string& s) { put<uint64_t>(s.size()); raw(s.data(), s.size()); }
   void class_info(uint32_t version) { put<uint8_t>(0); put<uint32_t>(version); }
+  char* grow(size_t n) { const size_t at = d_.size(); d_.resize(at + n); return d_.data() + at; }  // n more bytes, to be filled by the caller
   std::vector<char> d_;
 };
 
 template <class T> void read_pod_vector(Reader& r, std::vector<T>& v) {
-  const uint64_t n = r.get<uint64_t>();
-  if (n > r.size() / sizeof(T) + 1) throw std::runtime_error("FMI file corrupt (vector size)");
+  const uint64_t n = r.count(sizeof(T));
   v.resize(n);
   if (n) r.raw(v.data(), n * sizeof(T));
 }
@@ -788,7 +795,7 @@ void HostIndex::load_fmi(const std::string& path) {
   forms.clear(); sfreq.clear(); form2index.clear();
   vocab_gen_.fetch_add(1, std::memory_order_release);
   {
-    const uint64_t n = r.get<uint64_t>();
+    const uint64_t n = r.count(8);     // (a string is at least its length word)
     r.get<uint32_t>();                 // item_version
     forms.reserve(n);
     for (uint64_t i = 0; i < n; i++) forms.push_back(r.str());
@@ -797,7 +804,7 @@ void HostIndex::load_fmi(const std::string& path) {
   r.class_info();                      // std::unordered_map<std::string, unsigned>
   bool pair_su_seen = false;
   {
-    const uint64_t n = r.get<uint64_t>();
+    const uint64_t n = r.count(12);
     fmi.map_buckets = r.get<uint64_t>();  // bucket_count
     r.get<uint32_t>();                 // item_version
     form2index.reserve(n);
@@ -806,6 +813,7 @@ void HostIndex::load_fmi(const std::string& path) {
       if (!pair_su_seen) { r.class_info(); pair_su_seen = true; }
       std::string k = r.str();
       const uint32_t v = r.get<uint32_t>();
+      if (v >= forms.size()) throw std::runtime_error("FMI file corrupt (vocabulary map names an id beyond the vocabulary)");
       fmi.map_order.push_back(v);
       form2index.emplace(std::move(k), v);
     }
@@ -820,16 +828,17 @@ void HostIndex::load_fmi(const std::string& path) {
   suf_sid.clear(); suf_pos.clear();
   if (sa_version == 1) {
     r.class_info();                    // std::vector<SuffixView>
-    const uint64_t n = r.get<uint64_t>();
+    const uint64_t n = r.count(6);
     r.get<uint32_t>();                 // item_version
-    if (n > r.size()) throw std::runtime_error("FMI file corrupt (suffix count)");
     suf_sid.resize(n); suf_pos.resize(n);
     if (n) r.class_info();             // SuffixView
-    for (uint64_t i = 0; i < n; i++) { suf_sid[i] = r.get<uint32_t>(); suf_pos[i] = r.get<uint16_t>(); }
+    if (n) {                           // packed {u32 sid; u16 pos} records: one bounds check, then a plain loop over the bytes
+      const char* p = r.span(n * 6);
+      for (uint64_t i = 0; i < n; i++, p += 6) { memcpy(&suf_sid[i], p, 4); memcpy(&suf_pos[i], p + 4, 2); }
+    }
   } else if (sa_version == 0) {
     r.class_info();                    // std::vector<std::pair<unsigned, unsigned short>>
-    const uint64_t n = r.get<uint64_t>();
-    if (n > r.size()) throw std::runtime_error("FMI file corrupt (suffix count)");
+    const uint64_t n = r.count(8);
     suf_sid.resize(n); suf_pos.resize(n);
     for (uint64_t i = 0; i < n; i++) {
       suf_sid[i] = r.get<uint32_t>();
@@ -845,7 +854,7 @@ void HostIndex::load_fmi(const std::string& path) {
   // _ids — std::vector<std::string> (class info already emitted)
   ids.clear();
   {
-    const uint64_t n = r.get<uint64_t>();
+    const uint64_t n = r.count(8);
     r.get<uint32_t>();
     ids.reserve(n);
     for (uint64_t i = 0; i < n; i++) ids.push_back(r.str());
@@ -854,15 +863,16 @@ void HostIndex::load_fmi(const std::string& path) {
   real.clear();
   {
     r.class_info();                    // std::vector<Sentence>
-    const uint64_t n = r.get<uint64_t>();
+    const uint64_t n = r.count(8 + 8 + 8 + 4);  // tokstring length + map count + bucket count + item version
     r.get<uint32_t>();
     real.resize(n);
+    fmi.itok_buckets.reserve(n);
     bool map_seen = false, pair_seen = false;
     for (uint64_t i = 0; i < n; i++) {
       if (i == 0) r.class_info();      // Sentence
       real[i].tokstring = r.str();
       if (!map_seen) { r.class_info(); map_seen = true; }  // std::unordered_map<size_t, std::string>
-      const uint64_t m = r.get<uint64_t>();
+      const uint64_t m = r.count(16);
       fmi.itok_buckets.push_back(r.get<uint64_t>());  // bucket_count
       r.get<uint32_t>();               // item_version
       for (uint64_t k = 0; k < m; k++) {
@@ -888,12 +898,17 @@ void HostIndex::load_fmi(const std::string& path) {
   }
   if (!qva.empty() && qva.back() != suf_sid.size() && !suf_sid.empty() && sorted)
     throw std::runtime_error("FMI file corrupt (quick vocab access)");
+  // _quickVocabAccess names suffix ranges (src/suffix_array.cc:76-98): the probe indexes the suffix array with it
+  for (size_t w = 0; w < qva.size(); w++)
+    if (qva[w] > suf_sid.size() || (w && qva[w] < qva[w - 1])) throw std::runtime_error("FMI file corrupt (quick vocab access)");
   if (ids.size() != sent_pos.size() || real.size() != sent_pos.size())
     throw std::runtime_error("FMI file corrupt (ids / real tokens count)");
 }
 
 void HostIndex::save_fmi(const std::string& path) const {
   Writer w;
+  // (one allocation for the bulk of a large index: suffixes, buffers, ~ (8 + 6 bytes per token) per Sentence record)
+  w.d_.reserve(4096 + suf_sid.size() * 6 + (buf.size() + sent_pos.size() + qva.size()) * 4 + sent_pos.size() * 64 + buf.size() * 8);
   w.raw("FMI", 3);
   w.put<char>('1');                    // FuzzyMatch::version — src/fuzzy_match.cc:23
   w.str("serialization::archive");
@@ -940,10 +955,10 @@ void HostIndex::save_fmi(const std::string& path) const {
   w.class_info(0);                     // vector<SuffixView>
   w.put<uint64_t>(suf_sid.size());
   w.put<uint32_t>(0);
-  for (uint64_t i = 0; i < suf_sid.size(); i++) {
-    if (i == 0) w.class_info(0);       // SuffixView
-    w.put<uint32_t>(suf_sid[i]);
-    w.put<uint16_t>(suf_pos[i]);
+  if (!suf_sid.empty()) {
+    w.class_info(0);                   // SuffixView
+    char* p = w.grow(suf_sid.size() * 6);  // packed {u32 sid; u16 pos} records (suffix_array.hxx:55-91)
+    for (uint64_t i = 0; i < suf_sid.size(); i++, p += 6) { memcpy(p, &suf_sid[i], 4); memcpy(p + 4, &suf_pos[i], 2); }
   }
   write_pod_vector(w, buf);
   write_pod_vector(w, sent_pos);
@@ -960,11 +975,18 @@ void HostIndex::save_fmi(const std::string& path) const {
     if (i == 0) w.class_info(0);       // Sentence
     if (i < real.size()) w.str(real[i].tokstring);
     else {
-      // real tokens = normalised forms (Sentence(const Tokens&), src/sentence.cc:24)
-      std::string ts;
+      // real tokens = normalised forms (Sentence(const Tokens&), src/sentence.cc:24): '\t'-joined, written in place
       const uint32_t sp = sent_pos[i], len = buf[sp];
-      for (uint32_t k = 0; k < len; k++) { if (k) ts += '\t'; ts += f[buf[sp + 1 + k]]; }
-      w.str(ts);
+      uint64_t bytes = len ? len - 1 : 0;
+      for (uint32_t k = 0; k < len; k++) bytes += f[buf[sp + 1 + k]].size();
+      w.put<uint64_t>(bytes);
+      char* p = w.grow(bytes);
+      for (uint32_t k = 0; k < len; k++) {
+        if (k) *p++ = '\t';
+        const std::string& t = f[buf[sp + 1 + k]];
+        memcpy(p, t.data(), t.size());
+        p += t.size();
+      }
     }
     if (i == 0) w.class_info(0);       // unordered_map<size_t, string>
     const uint64_t m = i < real.size() ? real[i].itoks.size() : 0;

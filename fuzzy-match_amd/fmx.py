@@ -78,7 +78,7 @@ EXPORTS = [
     "fmx_index_free", "fmx_index_load", "fmx_index_save", "fmx_index_add_tm", "fmx_index_add_ids",
     "fmx_index_sort", "fmx_index_finalize", "fmx_index_to_device", "fmx_vocab_lookup",
     "fmx_index_lookup_real", "fmx_index_intern_itok", "fmx_index_sentence_id", "fmx_index_array",
-    "fmx_index_get_info", "fmx_match_batch", "fmx_match_batch_text", "fmx_match_batch_device", "fmx_set_option",
+    "fmx_index_get_info", "fmx_match_batch", "fmx_match_batch_text", "fmx_match_batch_text_keep", "fmx_match_batch_device", "fmx_set_option",
     "fmx_host_alloc", "fmx_host_free", "fmx_index_to_devices", "fmx_set_devices", "fmx_index_reopen", "fmx_match_one", "fmx_match_batch_keep",
     "fmx_subsequence_batch", "fmx_text_tokenize", "fmx_text_free", "fmx_text_num_tokens", "fmx_text_norm", "fmx_text_real",
     "fmx_text_num_itoks", "fmx_text_itok_index", "fmx_text_itok", "fmx_text_num_raw", "fmx_text_raw", "fmx_text_map",
@@ -134,6 +134,8 @@ def lib():
     L.fmx_index_get_info.argtypes = [C.c_void_p, C.POINTER(Info)]
     L.fmx_match_batch_text.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(TextBatch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
                                        C.POINTER(Stats)]
+    L.fmx_match_batch_text_keep.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(TextBatch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                            C.c_void_p, C.c_void_p, C.POINTER(Stats)]
     L.fmx_match_batch.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Batch), C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_uint32, C.POINTER(Stats)]
     L.fmx_match_batch_keep.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Batch), C.c_void_p, C.c_void_p,
@@ -478,7 +480,7 @@ class Index:
         res = (out[:nq], cnt[:nq], tot[:nq])
         return res + (st,) if want_stats else res
 
-    def match_batch_text(self, params, q_off, text, cap=None, want_stats=False, out=None):
+    def match_batch_text(self, params, q_off, text, cap=None, want_stats=False, out=None, keep=None):
         """fmx_match_batch_text: the patterns as token spellings (uint8 array: NUL-terminated spellings back to back, q_off in
         tokens); the vocabulary ids are looked up on the device."""
         q_off = np.ascontiguousarray(q_off, dtype=np.uint32)
@@ -495,7 +497,11 @@ class Index:
             tot = np.zeros(max(nq, 1), dtype=np.uint32)
         b = TextBatch(nq, _ptr(q_off), _ptr(text), len(text))
         st = Stats()
-        _check(lib().fmx_match_batch_text(self.h, C.byref(params), C.byref(b), _ptr(out), _ptr(cnt), _ptr(tot), cap, C.byref(st)))
+        if keep is not None:  # (device pointers: records, counts) also left in HBM for a collective that follows
+            _check(lib().fmx_match_batch_text_keep(self.h, C.byref(params), C.byref(b), _ptr(out), _ptr(cnt), _ptr(tot), cap,
+                                                   C.c_void_p(keep[0]), C.c_void_p(keep[1]), C.byref(st)))
+        else:
+            _check(lib().fmx_match_batch_text(self.h, C.byref(params), C.byref(b), _ptr(out), _ptr(cnt), _ptr(tot), cap, C.byref(st)))
         res = (out[:nq], cnt[:nq], tot[:nq])
         return res + (st,) if want_stats else res
 

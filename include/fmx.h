@@ -243,6 +243,9 @@ typedef struct fmx_text_batch {
 } fmx_text_batch;
 int fmx_match_batch_text(fmx_index*, const fmx_params*, const fmx_text_batch*, fmx_match* out, uint32_t* out_count,
                          uint32_t* out_total, uint32_t cap, fmx_stats* stats);
+/* fmx_match_batch_text that also leaves the records (and counts) in device memory, like fmx_match_batch_keep */
+int fmx_match_batch_text_keep(fmx_index*, const fmx_params*, const fmx_text_batch*, fmx_match* out, uint32_t* out_count,
+                              uint32_t* out_total, uint32_t cap, fmx_match* d_keep, uint32_t* d_keep_count, fmx_stats* stats);
 /* Same with every buffer already in the HBM of the index's device; `stream` is a hipStream_t
  * (NULL = a stream of the library after a device-wide synchronisation).  total_tokens = q_off[nq] when q_off[0] == 0, else
  * 0 (with it and max_len set, a batch of one pass needs no device read up front; the value is CHECKED on the device against

@@ -1,4 +1,4 @@
-"""bench.py's N > 1 control flow (rank sharding, keep + gather slots, weak and strong measurements, per-rank rates, the
+"""bench.py's N > 1 control flow (rank sharding, text batches with keep + gather slots, strong and weak measurements, per-rank rates, the
 one JSON line on rank 0) run end to end on a box with ONE GPU: two ranks on device 0, the collectives over gloo through
 host memory (FMX_BENCH_BACKEND=gloo).  The driver's multi-GPU runs use RCCL with one GPU per rank; this only makes sure
 that nothing on that path is broken."""
@@ -24,6 +24,9 @@ def test_two_ranks_on_one_gpu(gpu_device):
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["queries_per_step_all_ranks"] == 80000
-    assert d["scaling_other"]["scaling"] == "strong" and d["scaling_other"]["queries_per_step_all_ranks"] == 40000
-    assert len(d["per_rank"]) == 2 and d["parity"]["mismatches"] == 0 and d["value"] > 0
+    # N > 1 defaults to BASELINE's shape: ONE batch of --queries cut over the ranks (strong); the weak shape is measured beside it
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["queries_per_step_all_ranks"] == 40000
+    assert d["scaling_other"]["scaling"] == "weak" and d["scaling_other"]["queries_per_step_all_ranks"] == 80000
+    assert len(d["per_rank"]) == 2 and d["parity"]["mismatches"] == 0 and d["parity"]["checked"] > 0 and d["value"] > 0
+    assert "fmx_match_batch_text" in d["config"]["timed_path"] and d["device_resident"]["value"] > 0
+    assert d["scaling_other"]["value"] > 0 and d["scaling_other"]["device_resident_value"] > 0

@@ -256,3 +256,21 @@ int fms_word(uint32_t k, char* buf, int buflen) {
   buf[n] = '\0';
   return n;
 }
+
+/* A batch of patterns as a tokenizer would hand it over: the spellings of ids[0..n) back to back, each NUL-terminated (ids 0 and 1
+ * — the empty word and the unknown word — are written as an empty spelling and as "?" — a word no vocabulary of this generator
+ * holds).  Returns the bytes written, or the bytes needed when out == NULL / cap is too small (nothing is written past cap). */
+uint64_t fms_pack_text(const uint32_t* ids, uint64_t n, char* out, uint64_t cap) {
+  uint64_t at = 0;
+  char w[16];
+  for (uint64_t i = 0; i < n; i++) {
+    int len;
+    if (ids[i] == 0) { len = 0; w[0] = '\0'; }
+    else if (ids[i] == 1) { len = 1; w[0] = '?'; w[1] = '\0'; }
+    else len = fms_word(ids[i] - 2, w, (int)sizeof w);
+    if (len < 0) len = 0;
+    if (out && at + (uint64_t)len + 1 <= cap) memcpy(out + at, w, (size_t)len + 1);
+    at += (uint64_t)len + 1;
+  }
+  return at;
+}

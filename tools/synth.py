@@ -39,6 +39,8 @@ def lib():
             getattr(L, n).restype = C.c_void_p
             getattr(L, n).argtypes = [C.c_void_p]
         L.fms_word.argtypes = [C.c_uint32, C.c_char_p, C.c_int]
+        L.fms_pack_text.restype = C.c_uint64
+        L.fms_pack_text.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
         _lib = L
     return _lib
 
@@ -72,3 +74,16 @@ def word(k):
     buf = C.create_string_buffer(16)
     lib().fms_word(k, buf, 16)
     return buf.value.decode()
+
+
+def pack_text(ids, out=None):
+    """The patterns as packed token spellings (NUL-terminated, back to back): what a tokenizer writes.  `out`: a uint8 array to
+    fill (e.g. pinned memory); None = a new numpy array.  Returns the filled array (a view of `out`)."""
+    ids = np.ascontiguousarray(ids, dtype=np.uint32)
+    L = lib()
+    need = L.fms_pack_text(ids.ctypes.data, len(ids), None, 0)
+    if out is None:
+        out = np.empty(need, np.uint8)
+    assert out.nbytes >= need
+    L.fms_pack_text(ids.ctypes.data, len(ids), out.ctypes.data, out.nbytes)
+    return out[:need]
