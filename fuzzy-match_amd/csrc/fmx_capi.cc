@@ -272,6 +272,7 @@ int fmx_index_device_array(const fmx_index* ix, int replica, int which, void* ds
     case FMX_A_SUF_KEY: k = 2; break;
     case FMX_A_GRAM: k = 3; break;
     case FMX_A_GRAM5: k = 4; break;
+    case FMX_A_GRAM7: k = 8; break;
     case FMX_A_SUF_B: k = 5; break;
     case FMX_A_SENT_POS: k = 6; break;  // the device layout of the sentence buffer (DeviceIndex::upload): positions ...
     case FMX_A_BUFFER: k = 7; break;    // ... and words
@@ -284,7 +285,7 @@ int fmx_index_array(const fmx_index* ix, int which, const void** data, uint64_t*
   if (!ix || !data || !count) return fail(FMX_E_INVALID, "null argument");
   const HostIndex& h = ix->host;
   switch (which) {  // the accelerator arrays live in HBM only; their host twins (test oracle, CPU emulation) are built on request
-    case FMX_A_SUF_REC: case FMX_A_SUF_SIG: case FMX_A_SUF_KEY: case FMX_A_GRAM: case FMX_A_GRAM5: case FMX_A_SUF_B: {
+    case FMX_A_SUF_REC: case FMX_A_SUF_SIG: case FMX_A_SUF_KEY: case FMX_A_GRAM: case FMX_A_GRAM5: case FMX_A_GRAM7: case FMX_A_SUF_B: {
       if (!ix->finalized) return fail(FMX_E_STATE, "index is not finalized");
       fmx_index* mix = const_cast<fmx_index*>(ix);
       std::lock_guard<std::mutex> lk(mix->mu);
@@ -310,6 +311,7 @@ int fmx_index_array(const fmx_index* ix, int which, const void** data, uint64_t*
     case FMX_A_SUF_KEY: *data = h.suf_key.data(); *count = h.suf_key.size(); break;
     case FMX_A_GRAM: *data = h.gram.data(); *count = h.gram.size(); break;
     case FMX_A_GRAM5: *data = h.gram5.data(); *count = h.gram5.size(); break;
+    case FMX_A_GRAM7: *data = h.gram7.data(); *count = h.gram7.size(); break;
     case FMX_A_SUF_B: *data = h.suf_b.data(); *count = h.suf_b.size(); break;
     default: return fail(FMX_E_INVALID, "unknown array id");
   }

@@ -254,18 +254,55 @@ FMX_HD uint32_t gram_hash(uint32_t w0, uint32_t w1, uint32_t w2) {
   return h ^ (h >> 16);
 }
 
-// Second level: the distinct 5-grams of every trigram whose range holds more than kDeepGramMin suffixes,
-// keyed by (start of the trigram range, w3, w4).  It caps the length of the dependent-read chain of a
-// probe: without it one lane that has to bisect a 100 000-suffix trigram range keeps its whole wave waiting.
+// 5-gram buckets (round 4): EVERY distinct 5-gram of the index, one 128-byte line per probe.  A seed n-gram of five tokens
+// or more (patterns of 17 tokens and more at the default min_subseq_ratio: 97 % of the probed starts at C3) goes straight
+// to the bucket of its first five tokens instead of trigram entry -> 5-gram entry -> keys, and the bucket is the unit of
+// traffic: an entry carries what the next step needs —
+//   * the five tokens (w0 implied by the _quickVocabAccess bucket `lo` lies in), the group's suffix range,
+//   * the four tokens that follow the 5-gram in the group's FIRST suffix, and how many of them the WHOLE group shares
+//     (`lcp`, 0..4: first and last suffix of a sorted group agree on exactly the tokens all of them agree on).
+// A seed of up to 5 + lcp tokens is decided inside the bucket (the whole group, or nothing); a longer one is decided when it
+// differs from the shared tokens (nothing), and only otherwise continues into the group's keys.  A bucket holds three
+// entries; the table has about one bucket per distinct 5-gram (kG5FillPer16), so a bucket overflows into its successors
+// rarely (flag `over`) and an absent 5-gram — most probed starts: the pattern was edited there — costs one line.
+struct G5Entry {
+  uint32_t w1, w2, w3, w4;  // tokens 1..4 of the 5-gram
+  uint32_t lo, cnt;         // its suffix range [lo, lo + cnt)
+  uint32_t t[4];            // tokens 5..8 of suffix lo (0 past the end of its sentence)
+};
+struct __attribute__((aligned(128))) G5Bucket {
+  G5Entry  e[3];
+  uint32_t used;   // bits 0..15: entries in use (may read > 3 while a build is in flight: clamp); bits 16 + 4 k ..: lcp of entry k
+  uint32_t over;   // != 0: an entry whose home is this bucket (or one that passed through) lives in a later bucket
+};
+constexpr uint32_t kG5PerBucket = 3;
+constexpr uint32_t kG5FillPer16 = 16;  // distinct 5-grams per 16 buckets (16 = one per bucket: 1.9 % of the buckets overflow)
+FMX_HD uint32_t g5_lcp_of(uint32_t used, uint32_t k) { return (used >> (16 + 4 * k)) & 15u; }
+FMX_HD uint32_t gram5_hash(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t w4) {
+  uint32_t h = w0 * 0x9E3779B1u;
+  h = (h ^ (h >> 15)) + w1 * 0x85EBCA6Bu;
+  h = (h ^ (h >> 13)) + w2 * 0xC2B2AE35u;
+  h = (h ^ (h >> 16)) + w3 * 0x27D4EB2Fu;
+  h = (h ^ (h >> 15)) + w4 * 0x165667B1u;
+  h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15;
+  return h;
+}
+FMX_HD uint32_t g5_bucket_of(uint32_t h, uint32_t n_buckets) { return (uint32_t)(((unsigned long long)h * n_buckets) >> 32); }
+
+// Second level under the 5-gram buckets: the distinct 7-grams of every 5-gram whose range holds more than kDeepGramMin
+// suffixes (a repeated phrase), keyed by (start of the 5-gram range, w5, w6), 16-byte entries, open addressing.  It caps the
+// length of the dependent-read chain of a probe: without it one lane that has to bisect a 100 000-suffix range keeps its
+// whole wave waiting.
 #ifndef FMX_DEEP_MIN
 #define FMX_DEEP_MIN 8
 #endif
 constexpr uint32_t kDeepGramMin = FMX_DEEP_MIN;
 
 struct GramTables {
-  const GramEntry* g3;
-  const GramEntry* g5;
-  uint32_t         mask3, mask5;
+  const GramEntry* g3;   // trigrams (seeds of three and four tokens)
+  const G5Bucket*  g5;   // 5-gram buckets (seeds of five tokens and more)
+  const GramEntry* g7;   // 7-grams of the heavy 5-grams
+  uint32_t         mask3, n_b5, mask7;
 };
 
 // [lo, hi) -> the sub-range whose suffixes compare equal under cmp (cmp(i) < 0: before, 0: inside, > 0: after)
@@ -308,10 +345,11 @@ FMX_HD int key_cmp(const SufKey& kk, const uint32_t (&ng)[kKeyTokens + 1], uint3
 
 // mgram_range through the n-gram tables; same result as mgram_range / mgram_range_keyed.
 //
-// The probe is a chain of dependent random reads, and each level costs a full memory latency for the whole
-// wave, so the chain is kept short: the first-word bucket and the trigram entry are requested together, the
-// n-gram lives in registers, and the lower and the upper end of the equal range are bisected in lockstep
-// (two independent key loads per level) instead of one after the other.
+// The probe is a chain of dependent random reads, and each costs the memory system a 128-byte line whatever it requests, so
+// the chain is kept short and every line is made to count: the first-word bucket bounds and the table line are requested
+// together, the n-gram lives in registers, seeds of five tokens and more are answered by ONE line of the 5-gram buckets
+// whenever the group's shared tokens decide them (see G5Bucket), and what is left is bisected over the group's keys with the
+// lower and the upper end of the equal range in lockstep (two independent key loads per level).
 FMX_HD void mgram_range_hashed(const GramTables& gt, const SufKey* __restrict__ key,
                                const SufRec* __restrict__ suf, const uint32_t* __restrict__ tok,
                                const uint32_t* __restrict__ qva, uint32_t n_qva, const uint32_t* __restrict__ ngram,
@@ -328,32 +366,70 @@ FMX_HD void mgram_range_hashed(const GramTables& gt, const SufKey* __restrict__ 
   const uint32_t w0 = ng[0];
   const bool w_ok = w0 + 1 < n_qva;
   const uint32_t wi = w_ok ? w0 : 0u;
-  uint32_t slot = gram_hash(w0, ng[1], ng[2]) & gt.mask3;
-  GramEntry e = gt.g3[slot];  // requested together with the bucket bounds
-  const uint32_t blo = qva[wi], bhi = qva[wi + 1];
-  tally_add(tally, 16); tally_add(tally, 8);
-  if (!w_ok || blo >= bhi) return;
-  uint32_t lo, hi;
-  for (;;) {
-    if (e.lo == kGramEmpty) return;  // no suffix starts with this trigram
-    if (e.w1 == ng[1] && e.w2 == ng[2] && e.lo >= blo && e.lo < bhi) { lo = e.lo; hi = e.lo + e.cnt; break; }
-    slot = (slot + 1) & gt.mask3;
-    e = gt.g3[slot];
-    tally_add(tally, 16, 0);  // linear probing: the next slot is almost always in the same line
-  }
-  if (m == 3) { out_lo = lo; out_hi = hi; return; }
-  uint32_t from = 3;
-  if (m >= 5 && gt.g5 != nullptr && hi - lo > kDeepGramMin) {
-    slot = gram_hash(lo, ng[3], ng[4]) & gt.mask5;
-    for (;;) {
-      const GramEntry e5 = gt.g5[slot];
-      tally_add(tally, 16);
-      if (e5.lo == kGramEmpty) return;  // no suffix of this trigram continues with (w3, w4)
-      if (e5.w1 == ng[3] && e5.w2 == ng[4] && e5.lo >= lo && e5.lo < hi) { lo = e5.lo; hi = e5.lo + e5.cnt; break; }
-      slot = (slot + 1) & gt.mask5;
+  uint32_t lo, hi, from;
+  if (m >= 5 && gt.g5 != nullptr) {
+    // ---- seeds of five tokens and more: the bucket of the first five ----
+    uint32_t b = g5_bucket_of(gram5_hash(w0, ng[1], ng[2], ng[3], ng[4]), gt.n_b5);
+    const uint32_t blo = qva[wi], bhi = qva[wi + 1];  // (requested together with the bucket)
+    tally_add(tally, 8);
+    uint32_t lcp = 0, t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    bool found = false;
+    for (uint32_t hops = 0;; hops++) {
+      const G5Bucket bk = gt.g5[b];
+      tally_add(tally, 128);
+      const uint32_t used = bk.used & 0xffffu;
+#pragma unroll
+      for (uint32_t k = 0; k < kG5PerBucket; k++) {
+        const G5Entry& e = bk.e[k];
+        if (k < used && e.w1 == ng[1] && e.w2 == ng[2] && e.w3 == ng[3] && e.w4 == ng[4] && e.lo >= blo && e.lo < bhi) {
+          found = true; lo = e.lo; hi = e.lo + e.cnt; lcp = g5_lcp_of(bk.used, k);
+          t0 = e.t[0]; t1 = e.t[1]; t2 = e.t[2]; t3 = e.t[3];
+        }
+      }
+      if (found || bk.over == 0u || hops >= gt.n_b5) break;
+      b = b + 1 == gt.n_b5 ? 0u : b + 1;
     }
+    if (!found || !w_ok || blo >= bhi) return;  // no suffix starts with these five tokens
     if (m == 5) { out_lo = lo; out_hi = hi; return; }
-    from = 5;
+    // the tokens the whole group shares after the 5-gram (tokens 5 .. 5 + lcp - 1 = those of its first suffix)
+    const uint32_t need = m - 5, sh = need < lcp ? need : lcp;
+    bool differ = false;
+    differ = differ || (sh > 0 && t0 != ng[5]);
+    differ = differ || (sh > 1 && t1 != ng[6]);
+    differ = differ || (sh > 2 && t2 != ng[7]);
+    differ = differ || (sh > 3 && t3 != ng[8]);
+    if (differ) return;                                    // every suffix of the group continues otherwise
+    if (need <= lcp) { out_lo = lo; out_hi = hi; return; }  // every suffix of the group continues like the seed
+    from = 5 + lcp;
+    // heavy groups: the 7-gram entry (unless the shared tokens already cover w5, w6: the entry would name the whole group)
+    if (m >= 7 && lcp < 2 && gt.g7 != nullptr && hi - lo > kDeepGramMin) {
+      uint32_t slot = gram_hash(lo, ng[5], ng[6]) & gt.mask7;
+      for (;;) {
+        const GramEntry e7 = gt.g7[slot];
+        tally_add(tally, 16);
+        if (e7.lo == kGramEmpty) return;  // no suffix of this 5-gram continues with (w5, w6)
+        if (e7.w1 == ng[5] && e7.w2 == ng[6] && e7.lo >= lo && e7.lo < hi) { lo = e7.lo; hi = e7.lo + e7.cnt; break; }
+        slot = (slot + 1) & gt.mask7;
+      }
+      if (m == 7) { out_lo = lo; out_hi = hi; return; }
+      from = 7;
+    }
+  } else {
+    // ---- seeds of three and four tokens: the trigram table ----
+    uint32_t slot = gram_hash(w0, ng[1], ng[2]) & gt.mask3;
+    GramEntry e = gt.g3[slot];  // requested together with the bucket bounds
+    const uint32_t blo = qva[wi], bhi = qva[wi + 1];
+    tally_add(tally, 16); tally_add(tally, 8);
+    if (!w_ok || blo >= bhi) return;
+    for (;;) {
+      if (e.lo == kGramEmpty) return;  // no suffix starts with this trigram
+      if (e.w1 == ng[1] && e.w2 == ng[2] && e.lo >= blo && e.lo < bhi) { lo = e.lo; hi = e.lo + e.cnt; break; }
+      slot = (slot + 1) & gt.mask3;
+      e = gt.g3[slot];
+      tally_add(tally, 16, 0);  // linear probing: the next slot is almost always in the same line
+    }
+    if (m == 3) { out_lo = lo; out_hi = hi; return; }
+    from = 3;
   }
   // equal range of the remaining tokens inside [lo, hi): a1 -> first suffix >= n-gram, a2 -> first suffix > n-gram
   const uint32_t lim = m - 1 < kKeyTokens ? m - 1 : kKeyTokens;

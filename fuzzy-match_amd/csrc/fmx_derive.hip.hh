@@ -87,6 +87,16 @@ struct DvFiveBoundary {
   }
 };
 
+// 7-gram groups inside the 5-gram groups: additionally cut at suffixes of fewer than seven tokens and where (w5, w6) change
+struct DvSevenBoundary {
+  DvFiveBoundary five;
+  __device__ bool operator()(uint32_t i) const {
+    if (five(i)) return true;
+    if (five.tri.suf[i].rem < 7 || five.tri.suf[i - 1].rem < 7) return true;
+    return five.tri.key[i].t[4] != five.tri.key[i - 1].t[4] || five.tri.key[i].t[5] != five.tri.key[i - 1].t[5];
+  }
+};
+
 // (grid-stride, one atomic per wave at the end: one atomic per 64 boundaries on a single address was 6 ms at C3)
 __global__ void __launch_bounds__(256) k_dv_count_starts(const uint32_t* __restrict__ bnd, uint32_t n_bnd, const SufRec* __restrict__ suf,
                                                          uint32_t min_rem, unsigned long long* __restrict__ count) {
@@ -125,40 +135,75 @@ __global__ void __launch_bounds__(256) k_dv_insert3(const uint32_t* __restrict__
   dv_insert(g, mask, gram_hash(w0, w1, w2), w1, w2, i, e - i);
 }
 
-// one thread per 5-gram boundary: lo3[k] = start of the enclosing trigram group if that group is deep (more than
-// kDeepGramMin suffixes) and the boundary starts a 5-gram group, else kGramEmpty
-__global__ void __launch_bounds__(256) k_dv_mark5(const uint32_t* __restrict__ bnd5, uint32_t n_bnd5, const uint32_t* __restrict__ bnd3,
-                                                  uint32_t n_bnd3, uint32_t n_suf, const SufRec* __restrict__ suf,
-                                                  uint32_t* __restrict__ lo3, unsigned long long* __restrict__ count) {
+// one thread per 5-gram boundary: a boundary whose suffix has >= 5 tokens starts a 5-gram group that ends at the next boundary.
+// Its entry goes into the first bucket with a free slot from its home bucket on (fmx_core.hh: G5Bucket): tokens 1..4, the range,
+// tokens 5..8 of the first suffix and how many of them the last suffix shares (= what the whole sorted group shares).
+__global__ void __launch_bounds__(256) k_dv_insert5x(const uint32_t* __restrict__ bnd5, uint32_t n_bnd5, uint32_t n_suf,
+                                                     const SufRec* __restrict__ suf, const SufKey* __restrict__ key,
+                                                     const uint32_t* __restrict__ tok, G5Bucket* g, uint32_t n_buckets) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_bnd5) return;
+  const uint32_t i = bnd5[k];
+  const SufRec r = suf[i];
+  if (r.rem < 5) return;
+  const uint32_t e = k + 1 < n_bnd5 ? bnd5[k + 1] : n_suf;
+  const SufKey first = key[i], last = key[e - 1];
+  uint32_t lcp = 0;
+  while (lcp < 4 && first.t[4 + lcp] == last.t[4 + lcp]) lcp++;
+  uint32_t b = g5_bucket_of(gram5_hash(tok[r.off], first.t[0], first.t[1], first.t[2], first.t[3]), n_buckets);
+  for (;;) {
+    const uint32_t slot = atomicAdd(&g[b].used, 1u) & 0xffffu;
+    if (slot < kG5PerBucket) {
+      G5Entry en;
+      en.w1 = first.t[0]; en.w2 = first.t[1]; en.w3 = first.t[2]; en.w4 = first.t[3];
+      en.lo = i; en.cnt = e - i;
+      en.t[0] = first.t[4]; en.t[1] = first.t[5]; en.t[2] = first.t[6]; en.t[3] = first.t[7];
+      g[b].e[slot] = en;
+      if (lcp) atomicOr(&g[b].used, lcp << (16 + 4 * slot));
+      return;
+    }
+    atomicSub(&g[b].used, 1u);
+    atomicOr(&g[b].over, 1u);
+    b = b + 1 == n_buckets ? 0u : b + 1;
+  }
+}
+
+// Second level.  One thread per child boundary (7-gram boundaries under the 5-gram groups): lo_parent[k] = start of the
+// enclosing parent group if that group is deep (more than kDeepGramMin suffixes; its suffixes have at least `parent_rem`
+// tokens) and the boundary starts a child group (at least `child_rem` tokens), else kGramEmpty
+__global__ void __launch_bounds__(256) k_dv_mark_deep(const uint32_t* __restrict__ bnd_c, uint32_t n_bnd_c, const uint32_t* __restrict__ bnd_p,
+                                                      uint32_t n_bnd_p, uint32_t n_suf, const SufRec* __restrict__ suf, uint32_t parent_rem,
+                                                      uint32_t child_rem, uint32_t* __restrict__ lo_parent, unsigned long long* __restrict__ count) {
   const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
   bool is = false;
-  if (k < n_bnd5) {
-    const uint32_t j = bnd5[k];
+  if (k < n_bnd_c) {
+    const uint32_t j = bnd_c[k];
     uint32_t v = kGramEmpty;
-    if (suf[j].rem >= 5) {
-      // the enclosing trigram group: the last trigram boundary at or before j
-      uint32_t a = 0, b = n_bnd3;  // bnd3[a] <= j < bnd3[b]
-      while (b - a > 1) { const uint32_t mid = a + ((b - a) >> 1); if (bnd3[mid] <= j) a = mid; else b = mid; }
-      const uint32_t g_lo = bnd3[a], g_hi = a + 1 < n_bnd3 ? bnd3[a + 1] : n_suf;
-      if (g_hi - g_lo > kDeepGramMin) { v = g_lo; is = true; }
+    if (suf[j].rem >= child_rem) {
+      // the enclosing parent group: the last parent boundary at or before j
+      uint32_t a = 0, b = n_bnd_p;  // bnd_p[a] <= j < bnd_p[b]
+      while (b - a > 1) { const uint32_t mid = a + ((b - a) >> 1); if (bnd_p[mid] <= j) a = mid; else b = mid; }
+      const uint32_t g_lo = bnd_p[a], g_hi = a + 1 < n_bnd_p ? bnd_p[a + 1] : n_suf;
+      if (suf[g_lo].rem >= parent_rem && g_hi - g_lo > kDeepGramMin) { v = g_lo; is = true; }
     }
-    lo3[k] = v;
+    lo_parent[k] = v;
   }
   const unsigned long long m = __ballot(is);
   if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, (unsigned long long)__popcll(m));
 }
 
-__global__ void __launch_bounds__(256) k_dv_insert5(const uint32_t* __restrict__ bnd5, uint32_t n_bnd5, uint32_t n_suf,
-                                                    const uint32_t* __restrict__ lo3, const SufKey* __restrict__ key, GramEntry* g,
-                                                    uint32_t mask) {
+// key_at = index into the suffix key of the child's two distinguishing tokens (7-grams under 5-grams: tokens 5 and 6 = t[4], t[5])
+__global__ void __launch_bounds__(256) k_dv_insert_deep(const uint32_t* __restrict__ bnd_c, uint32_t n_bnd_c, uint32_t n_suf,
+                                                        const uint32_t* __restrict__ lo_parent, const SufKey* __restrict__ key, uint32_t key_at,
+                                                        GramEntry* g, uint32_t mask) {
   const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= n_bnd5) return;
-  const uint32_t g3 = lo3[k];
-  if (g3 == kGramEmpty) return;
-  const uint32_t j = bnd5[k];
-  const uint32_t e = k + 1 < n_bnd5 ? bnd5[k + 1] : n_suf;
-  const uint32_t w3 = key[j].t[2], w4 = key[j].t[3];
-  dv_insert(g, mask, gram_hash(g3, w3, w4), w3, w4, j, e - j);
+  if (k >= n_bnd_c) return;
+  const uint32_t gp = lo_parent[k];
+  if (gp == kGramEmpty) return;
+  const uint32_t j = bnd_c[k];
+  const uint32_t e = k + 1 < n_bnd_c ? bnd_c[k + 1] : n_suf;
+  const uint32_t wa = key[j].t[key_at], wb = key[j].t[key_at + 1];
+  dv_insert(g, mask, gram_hash(gp, wa, wb), wa, wb, j, e - j);
 }
 
 }  // namespace fmx

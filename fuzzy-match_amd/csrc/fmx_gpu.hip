@@ -296,6 +296,9 @@ struct DeviceIndex::Impl {
   // what passes needed so far, per 1024 queries, shared by all contexts: a context sizes its workspace for a full pass of the
   // call at hand up front (a pass that does not fit is re-run after a reallocation that stalls every call in flight)
   std::atomic<uint64_t> hint_seg_kq{0}, hint_qb_kq{0};
+  // ... and the per-query limits a context learned the hard way (a re-run): the other contexts adopt them at their next call
+  // instead of each re-running a pass of its own when the batch with the heaviest query reaches it
+  std::atomic<uint32_t> hint_s_max{0}, hint_heavy_div{0};
   uint64_t init_seg = 1ull << 24;
   uint32_t heavy_min = kHeavyMinDefault; // suffix ranges at least this long go through the bit-plane kernel (0 = never)
   uint32_t max_ctx = 3;
@@ -375,7 +378,7 @@ DeviceIndex::~DeviceIndex() {
   if (m.device >= 0) {
     (void)hipSetDevice(m.device);
     (void)hipDeviceSynchronize();
-    hipFree((void*)m.d.suf); hipFree((void*)m.d.suf_sig); hipFree((void*)m.d.suf_key); hipFree((void*)m.d.gram.g3); hipFree((void*)m.d.gram.g5); hipFree((void*)m.d.suf_b); hipFree((void*)m.d.tok); hipFree((void*)m.d.sent_pos);
+    hipFree((void*)m.d.suf); hipFree((void*)m.d.suf_sig); hipFree((void*)m.d.suf_key); hipFree((void*)m.d.gram.g3); hipFree((void*)m.d.gram.g5); hipFree((void*)m.d.gram.g7); hipFree((void*)m.d.suf_b); hipFree((void*)m.d.tok); hipFree((void*)m.d.sent_pos);
     hipFree((void*)m.d.qva); hipFree((void*)m.d.idf); hipFree((void*)m.d.real); hipFree((void*)m.d.itok);
     hipFree((void*)m.d.planes); hipFree((void*)m.d.thermo);
     for (auto& c : m.all) c->destroy();
@@ -492,7 +495,7 @@ static unsigned long long* derive_on_device(DeviceIndex::Impl& m, const HostInde
   const uint64_t n = h.num_suffixes();
   const uint32_t n_sent = h.num_sentences();
   m.d.suf = nullptr; m.d.suf_b = nullptr; m.d.suf_sig = nullptr; m.d.suf_key = nullptr;
-  m.d.gram.g3 = nullptr; m.d.gram.g5 = nullptr; m.d.gram.mask3 = 0; m.d.gram.mask5 = 0;
+  m.d.gram.g3 = nullptr; m.d.gram.g5 = nullptr; m.d.gram.g7 = nullptr; m.d.gram.mask3 = 0; m.d.gram.n_b5 = 0; m.d.gram.mask7 = 0;
   SufRec* suf = dev_alloc<SufRec>(n);
   SufRecB* suf_b = dev_alloc<SufRecB>(n);
   unsigned long long* suf_sig = dev_alloc<unsigned long long>(n);
@@ -517,11 +520,12 @@ static unsigned long long* derive_on_device(DeviceIndex::Impl& m, const HostInde
   const uint32_t n32 = (uint32_t)n;
   uint32_t* bnd3 = dev_alloc<uint32_t>(n);
   uint32_t* bnd5 = nullptr;
+  uint32_t* bnd7 = nullptr;
   uint32_t* lo3 = nullptr;
   size_t* d_num = dev_alloc<size_t>(1);
   unsigned long long* d_count = dev_alloc<unsigned long long>(1);
   void* tmp = nullptr;
-  auto cleanup = [&]() { hipFree(bnd3); hipFree(bnd5); hipFree(lo3); hipFree(d_num); hipFree(d_count); hipFree(tmp); };
+  auto cleanup = [&]() { hipFree(bnd3); hipFree(bnd5); hipFree(bnd7); hipFree(lo3); hipFree(d_num); hipFree(d_count); hipFree(tmp); };
   try {
     const DvTriBoundary tri{suf, suf_key, m.d.tok};
     auto select = [&](auto pred, uint32_t* out) -> uint32_t {
@@ -548,22 +552,38 @@ static unsigned long long* derive_on_device(DeviceIndex::Impl& m, const HostInde
       hipLaunchKernelGGL(k_dv_fill_empty, dim3((unsigned)((cap3 + 255) / 256)), dim3(256), 0, 0, g3, cap3);
       hipLaunchKernelGGL(k_dv_insert3, dim3((n_b3 + 255) / 256), dim3(256), 0, 0, (const uint32_t*)bnd3, n_b3, n32, (const SufRec*)suf,
                          (const SufKey*)suf_key, m.d.tok, g3, (uint32_t)(cap3 - 1));
-      // second level: the distinct 5-grams of the trigram groups with more than kDeepGramMin suffixes
+      // the 5-gram buckets: every distinct 5-gram (fmx_core.hh: G5Bucket)
       bnd5 = dev_alloc<uint32_t>(n);
-      const uint32_t n_b5 = select(DvFiveBoundary{tri}, bnd5);
-      lo3 = dev_alloc<uint32_t>(n_b5);
+      const DvFiveBoundary five{tri};
+      const uint32_t n_b5 = select(five, bnd5);
       HIP_TRY(hipMemset(d_count, 0, 8));
-      hipLaunchKernelGGL(k_dv_mark5, dim3((n_b5 + 255) / 256), dim3(256), 0, 0, (const uint32_t*)bnd5, n_b5, (const uint32_t*)bnd3, n_b3, n32,
-                         (const SufRec*)suf, lo3, d_count);
+      hipLaunchKernelGGL(k_dv_count_starts, dim3(std::min<uint32_t>((n_b5 + 255) / 256, 2048u)), dim3(256), 0, 0, (const uint32_t*)bnd5, n_b5, (const SufRec*)suf, 5u, d_count);
       const unsigned long long groups5 = read_count();
-      const unsigned long long cap5 = table_cap(groups5);
-      if (groups5 != 0 && cap5 <= (1ull << 31)) {
-        GramEntry* g5 = dev_alloc<GramEntry>(cap5);
-        m.d.gram.g5 = g5; m.d.gram.mask5 = (uint32_t)(cap5 - 1);
-        m.bytes += cap5 * sizeof(GramEntry);
-        hipLaunchKernelGGL(k_dv_fill_empty, dim3((unsigned)((cap5 + 255) / 256)), dim3(256), 0, 0, g5, cap5);
-        hipLaunchKernelGGL(k_dv_insert5, dim3((n_b5 + 255) / 256), dim3(256), 0, 0, (const uint32_t*)bnd5, n_b5, n32, (const uint32_t*)lo3,
-                           (const SufKey*)suf_key, g5, (uint32_t)(cap5 - 1));
+      const unsigned long long nb5 = std::max<unsigned long long>(16, (groups5 * 16 + kG5FillPer16 - 1) / kG5FillPer16);
+      if (groups5 != 0 && nb5 <= 0xffffffffull) {
+        G5Bucket* g5 = dev_alloc<G5Bucket>(nb5);
+        m.d.gram.g5 = g5; m.d.gram.n_b5 = (uint32_t)nb5;
+        m.bytes += nb5 * sizeof(G5Bucket);
+        HIP_TRY(hipMemset(g5, 0, nb5 * sizeof(G5Bucket)));
+        hipLaunchKernelGGL(k_dv_insert5x, dim3((n_b5 + 255) / 256), dim3(256), 0, 0, (const uint32_t*)bnd5, n_b5, n32, (const SufRec*)suf,
+                           (const SufKey*)suf_key, m.d.tok, g5, (uint32_t)nb5);
+        // second level: the distinct 7-grams of the 5-gram groups with more than kDeepGramMin suffixes
+        bnd7 = dev_alloc<uint32_t>(n);
+        const uint32_t n_b7 = select(DvSevenBoundary{five}, bnd7);
+        lo3 = dev_alloc<uint32_t>(n_b7);
+        HIP_TRY(hipMemset(d_count, 0, 8));
+        hipLaunchKernelGGL(k_dv_mark_deep, dim3((n_b7 + 255) / 256), dim3(256), 0, 0, (const uint32_t*)bnd7, n_b7, (const uint32_t*)bnd5, n_b5, n32,
+                           (const SufRec*)suf, 5u, 7u, lo3, d_count);
+        const unsigned long long groups7 = read_count();
+        const unsigned long long cap7 = table_cap(groups7);
+        if (groups7 != 0 && cap7 <= (1ull << 31)) {
+          GramEntry* g7 = dev_alloc<GramEntry>(cap7);
+          m.d.gram.g7 = g7; m.d.gram.mask7 = (uint32_t)(cap7 - 1);
+          m.bytes += cap7 * sizeof(GramEntry);
+          hipLaunchKernelGGL(k_dv_fill_empty, dim3((unsigned)((cap7 + 255) / 256)), dim3(256), 0, 0, g7, cap7);
+          hipLaunchKernelGGL(k_dv_insert_deep, dim3((n_b7 + 255) / 256), dim3(256), 0, 0, (const uint32_t*)bnd7, n_b7, n32, (const uint32_t*)lo3,
+                             (const SufKey*)suf_key, 4u, g7, (uint32_t)(cap7 - 1));
+        }
       }
     }
     HIP_TRY(hipGetLastError());
@@ -589,7 +609,8 @@ uint64_t DeviceIndex::download(int which, void* dst, uint64_t capacity_bytes) co
     case 1: src = m.d.suf_sig; count = m.d.n_suf; elem = 8; break;
     case 2: src = m.d.suf_key; count = m.d.n_suf; elem = sizeof(SufKey); break;
     case 3: src = m.d.gram.g3; count = m.d.gram.g3 ? (uint64_t)m.d.gram.mask3 + 1 : 0; elem = sizeof(GramEntry); break;
-    case 4: src = m.d.gram.g5; count = m.d.gram.g5 ? (uint64_t)m.d.gram.mask5 + 1 : 0; elem = sizeof(GramEntry); break;
+    case 4: src = m.d.gram.g5; count = m.d.gram.g5 ? (uint64_t)m.d.gram.n_b5 : 0; elem = sizeof(G5Bucket); break;
+    case 8: src = m.d.gram.g7; count = m.d.gram.g7 ? (uint64_t)m.d.gram.mask7 + 1 : 0; elem = sizeof(GramEntry); break;
     case 5: src = m.d.suf_b; count = m.d.n_suf; elem = sizeof(SufRecB); break;
     case 6: src = m.d.sent_pos; count = m.d.n_sent; elem = 4; break;   // positions in the device layout of the sentence buffer
     case 7: src = m.d.tok; count = m.n_tok_words; elem = 4; break;
@@ -1058,7 +1079,7 @@ static void learn_sizes(DeviceIndex::Impl& m, const unsigned long long* ctr, uin
   raise(m.hint_qb_kq, (std::max(ctr[25], ctr[21]) * 1024 + nq_pass - 1) / nq_pass);
 }
 
-static bool pass_needs_retry(Ctx& c, const unsigned long long* ctr, const PassLimits& ran, uint64_t& want_seg) {
+static bool pass_needs_retry(DeviceIndex::Impl& m, Ctx& c, const unsigned long long* ctr, const PassLimits& ran, uint64_t& want_seg) {
   bool retry = false;
   if (ctr[6] > ran.seg_cap) { want_seg = std::max<uint64_t>(want_seg, ctr[6] + ctr[6] / 4); retry = true; }   // segments did not fit
   if (ctr[21] > ran.qb_cap) { c.want_qb = std::max<uint64_t>(c.want_qb, ctr[21] + ctr[21] / 4); retry = true; }  // queues did not fit
@@ -1067,10 +1088,12 @@ static bool pass_needs_retry(Ctx& c, const unsigned long long* ctr, const PassLi
     while (s < ctr[4] && s < (1ull << 31)) s <<= 1;
     if (ctr[4] > s) throw UnsupportedError("a query kept more than 2^31 hits");
     c.s_max = std::max<uint32_t>(c.s_max, (uint32_t)s);
+    { uint32_t cur = m.hint_s_max.load(); while (c.s_max > cur && !m.hint_s_max.compare_exchange_weak(cur, c.s_max)) {} }
     retry = true;
   } else if (ctr[4] != 0) {                                                        // more of its long-range hits passed than reserved
     if (ran.heavy_div == 1) throw GpuError("a query queued more hits than it has");
     c.heavy_div = std::min<uint32_t>(c.heavy_div, ran.heavy_div > 4 ? 4u : 1u);
+    { uint32_t cur = m.hint_heavy_div.load(); while ((cur == 0 || c.heavy_div < cur) && !m.hint_heavy_div.compare_exchange_weak(cur, c.heavy_div)) {} }
     retry = true;
   }
   if (ctr[26] != 0)  // k_setup: q_off[first query] / q_off[last query + 1] are not what the pass was enqueued with
@@ -1135,6 +1158,8 @@ struct PassRun {
     nq_eff = std::min<uint64_t>(std::max<uint64_t>(bv.nq, 1), m.sub_queries);
     nt_eff = (uint64_t)((double)(sub_tok_bounds.back() - sub_tok_bounds.front()) * ((double)nq_eff / (double)std::max<uint64_t>(bv.nq, 1)) * 1.05) + 64;
     c.want_qb = std::max<uint64_t>(c.want_qb, hinted(m.hint_qb_kq));
+    c.s_max = std::max<uint32_t>(c.s_max, m.hint_s_max.load());
+    if (const uint32_t hd = m.hint_heavy_div.load()) c.heavy_div = std::min<uint32_t>(c.heavy_div, hd);
   }
   uint64_t hinted(const std::atomic<uint64_t>& kq) const { const uint64_t h = kq.load(); return h ? (h * nq_eff / 1024) + (h * nq_eff / 1024) / 8 + 1024 : 0ull; }
   DevBatch batch_of(uint32_t sb) const {
@@ -1176,7 +1201,7 @@ struct PassRun {
         }
       }
       learn_sizes(m, c.h_ctr, b.nq);
-      if (pass_needs_retry(c, c.h_ctr, lim, want_seg)) {
+      if (pass_needs_retry(m, c, c.h_ctr, lim, want_seg)) {
         if (attempt >= 6) throw GpuError("workspace kept overflowing");
         if (st) st->n_retries++;
         continue;
@@ -1236,7 +1261,7 @@ struct PassRun {
     for (uint32_t sb = g0; sb < g1; sb++) {
       const unsigned long long* ctr = c.h_ctr_group + (size_t)(sb - g0) * kNumCounters;
       learn_sizes(m, ctr, sub_q_bounds[sb + 1] - sub_q_bounds[sb]);
-      if (pass_needs_retry(c, ctr, ran, want_seg)) redo.push_back(sb);
+      if (pass_needs_retry(m, c, ctr, ran, want_seg)) redo.push_back(sb);
       else add_counters(st, ctr);
     }
     for (uint32_t sb : redo) {

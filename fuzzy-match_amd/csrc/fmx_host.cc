@@ -481,45 +481,96 @@ void HostIndex::build_gram_table(int nthreads) {
     }
   });
 
-  // second level: distinct 5-grams of the trigrams with more than kDeepGramMin suffixes
+  // ---- 5-gram buckets: every distinct 5-gram (fmx_core.hh: G5Bucket); 7-gram entries under the heavy ones ----
   gram5.clear();
-  auto for_deep_groups = [&](int t, auto fn) {
+  gram7.clear();
+  // a 5-gram group: a maximal run of suffixes with at least five tokens and the same first five
+  auto same5 = [&](uint64_t a, uint64_t b2) {
+    return w0_of(a) == w0_of(b2) && suf_key[a].t[0] == suf_key[b2].t[0] && suf_key[a].t[1] == suf_key[b2].t[1] &&
+           suf_key[a].t[2] == suf_key[b2].t[2] && suf_key[a].t[3] == suf_key[b2].t[3];
+  };
+  auto is_start5 = [&](uint64_t i) {
+    if (suf_rec[i].rem < 5) return false;
+    if (i == 0 || suf_rec[i - 1].rem < 5) return true;
+    return !same5(i, i - 1);
+  };
+  auto for_groups5 = [&](int t, auto fn) {  // fn(lo, cnt)
     const uint64_t a = n * (uint64_t)t / (uint64_t)nthreads, b = n * (uint64_t)(t + 1) / (uint64_t)nthreads;
     for (uint64_t i = a; i < b; i++) {
-      if (!is_start(i)) continue;
-      uint64_t e = i + 1;
-      const uint32_t w0 = w0_of(i), w1 = suf_key[i].t[0], w2 = suf_key[i].t[1];
-      while (e < n && suf_rec[e].rem >= 3 && w0_of(e) == w0 && suf_key[e].t[0] == w1 && suf_key[e].t[1] == w2) e++;
-      if (e - i <= kDeepGramMin) continue;
-      for (uint64_t j = i; j < e;) {  // 5-gram groups inside [i, e)
-        if (suf_rec[j].rem < 5) { j++; continue; }
-        uint64_t g = j + 1;
-        while (g < e && suf_rec[g].rem >= 5 && suf_key[g].t[2] == suf_key[j].t[2] && suf_key[g].t[3] == suf_key[j].t[3]) g++;
-        fn((uint32_t)i, suf_key[j].t[2], suf_key[j].t[3], (uint32_t)j, (uint32_t)(g - j));
-        j = g;
-      }
+      if (!is_start5(i)) continue;
+      uint64_t e = i + 1;  // the group may extend into the next thread's slice
+      while (e < n && suf_rec[e].rem >= 5 && same5(e, i)) e++;
+      fn(i, e - i);
     }
   };
   std::fill(part_count.begin(), part_count.end(), 0);
-  run([&](int t) { uint64_t c = 0; for_deep_groups(t, [&](uint32_t, uint32_t, uint32_t, uint32_t, uint32_t) { c++; }); part_count[t] = c; });
+  run([&](int t) { uint64_t c = 0; for_groups5(t, [&](uint64_t, uint64_t) { c++; }); part_count[t] = c; });
   uint64_t groups5 = 0;
   for (auto c : part_count) groups5 += c;
   if (groups5 == 0) return;
-  uint64_t cap5 = 16;
-  while (cap5 < groups5 * 2) cap5 <<= 1;
-  if (cap5 > (1ull << 31)) return;
-  gram5.assign(cap5, empty);
-  const uint32_t mask5 = (uint32_t)(cap5 - 1);
+  const uint64_t nb5 = std::max<uint64_t>(16, (groups5 * 16 + kG5FillPer16 - 1) / kG5FillPer16);
+  if (nb5 > 0xffffffffull) return;  // (the trigram table + keys are used instead)
+  {
+    G5Bucket zero;
+    memset(&zero, 0, sizeof zero);
+    gram5.assign(nb5, zero);
+  }
   run([&](int t) {
-    for_deep_groups(t, [&](uint32_t lo3, uint32_t w3, uint32_t w4, uint32_t lo5, uint32_t cnt5) {
-      uint32_t slot = gram_hash(lo3, w3, w4) & mask5;
+    for_groups5(t, [&](uint64_t lo, uint64_t cnt) {
+      const SufKey& first = suf_key[lo];
+      const SufKey& last = suf_key[lo + cnt - 1];
+      uint32_t lcp = 0;
+      while (lcp < 4 && first.t[4 + lcp] == last.t[4 + lcp]) lcp++;
+      uint32_t b = g5_bucket_of(gram5_hash(w0_of(lo), first.t[0], first.t[1], first.t[2], first.t[3]), (uint32_t)nb5);
       for (;;) {
-        uint32_t expect = kGramEmpty;
-        if (__atomic_compare_exchange_n(&gram5[slot].lo, &expect, lo5, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE)) {
-          gram5[slot].w1 = w3; gram5[slot].w2 = w4; gram5[slot].cnt = cnt5;
+        const uint32_t slot = __atomic_fetch_add(&gram5[b].used, 1u, __ATOMIC_ACQ_REL) & 0xffffu;
+        if (slot < kG5PerBucket) {
+          G5Entry& e = gram5[b].e[slot];
+          e.w1 = first.t[0]; e.w2 = first.t[1]; e.w3 = first.t[2]; e.w4 = first.t[3];
+          e.lo = (uint32_t)lo; e.cnt = (uint32_t)cnt;
+          for (int k = 0; k < 4; k++) e.t[k] = first.t[4 + k];
+          __atomic_fetch_or(&gram5[b].used, lcp << (16 + 4 * slot), __ATOMIC_ACQ_REL);
           break;
         }
-        slot = (slot + 1) & mask5;
+        __atomic_fetch_sub(&gram5[b].used, 1u, __ATOMIC_ACQ_REL);
+        __atomic_store_n(&gram5[b].over, 1u, __ATOMIC_RELEASE);
+        b = b + 1 == nb5 ? 0u : b + 1;
+      }
+    });
+  });
+  // second level: the distinct 7-grams of the 5-grams with more than kDeepGramMin suffixes
+  auto for_deep7 = [&](int t, auto fn) {  // fn(lo5, w5, w6, lo7, cnt7)
+    for_groups5(t, [&](uint64_t lo, uint64_t cnt) {
+      if (cnt <= kDeepGramMin) return;
+      for (uint64_t j = lo; j < lo + cnt;) {
+        if (suf_rec[j].rem < 7) { j++; continue; }
+        uint64_t g = j + 1;
+        while (g < lo + cnt && suf_rec[g].rem >= 7 && suf_key[g].t[4] == suf_key[j].t[4] && suf_key[g].t[5] == suf_key[j].t[5]) g++;
+        fn((uint32_t)lo, suf_key[j].t[4], suf_key[j].t[5], (uint32_t)j, (uint32_t)(g - j));
+        j = g;
+      }
+    });
+  };
+  std::fill(part_count.begin(), part_count.end(), 0);
+  run([&](int t) { uint64_t c = 0; for_deep7(t, [&](uint32_t, uint32_t, uint32_t, uint32_t, uint32_t) { c++; }); part_count[t] = c; });
+  uint64_t groups7 = 0;
+  for (auto c : part_count) groups7 += c;
+  if (groups7 == 0) return;
+  uint64_t cap7 = 16;
+  while (cap7 < groups7 * 2) cap7 <<= 1;
+  if (cap7 > (1ull << 31)) return;
+  gram7.assign(cap7, empty);
+  const uint32_t mask7 = (uint32_t)(cap7 - 1);
+  run([&](int t) {
+    for_deep7(t, [&](uint32_t lo5, uint32_t w5, uint32_t w6, uint32_t lo7, uint32_t cnt7) {
+      uint32_t slot = gram_hash(lo5, w5, w6) & mask7;
+      for (;;) {
+        uint32_t expect = kGramEmpty;
+        if (__atomic_compare_exchange_n(&gram7[slot].lo, &expect, lo7, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE)) {
+          gram7[slot].w1 = w5; gram7[slot].w2 = w6; gram7[slot].cnt = cnt7;
+          break;
+        }
+        slot = (slot + 1) & mask7;
       }
     });
   });
@@ -634,7 +685,7 @@ void HostIndex::derive() {
   if (!sorted) throw std::runtime_error("derive: index is not sorted");
   heavy_ready = false;
   suf_rec.clear(); suf_rec.shrink_to_fit(); suf_sig.clear(); suf_sig.shrink_to_fit(); suf_key.clear(); suf_key.shrink_to_fit();
-  suf_b.clear(); suf_b.shrink_to_fit(); gram.clear(); gram.shrink_to_fit(); gram5.clear(); gram5.shrink_to_fit();
+  suf_b.clear(); suf_b.shrink_to_fit(); gram.clear(); gram.shrink_to_fit(); gram5.clear(); gram5.shrink_to_fit(); gram7.clear(); gram7.shrink_to_fit();
   // compute_idf_penalty / compute_max_idf_penalty — src/fuzzy_match.cc:367-390 (glibc logf / log)
   const unsigned N = num_sentences();
   idf.assign(vocab_size, 0.f);

@@ -66,7 +66,8 @@ class HostIndex {
   std::vector<SufKey>   suf_key;   // the eight tokens after each suffix's first token (0-padded)
   std::vector<SufRecB>  suf_b;     // phase-B record: SufRec + previous token + sentence id
   std::vector<GramEntry> gram;     // trigram -> suffix range hash table (power-of-two size, empty if tiny index)
-  std::vector<GramEntry> gram5;    // (trigram range start, w3, w4) -> 5-gram range, for trigrams with > kDeepGramMin suffixes
+  std::vector<G5Bucket>  gram5;    // every distinct 5-gram -> suffix range + the tokens its group shares (128-byte buckets, fmx_core.hh)
+  std::vector<GramEntry> gram7;    // (5-gram range start, w5, w6) -> 7-gram range, for 5-grams with > kDeepGramMin suffixes
   void build_gram_table(int nthreads);
   // ---- derived by derive() ----
   std::vector<float>    idf;       // logf(N / sfreq[w]) per word id (src/fuzzy_match.cc:384)

@@ -23,7 +23,10 @@ ARRAYS = {
     "itok_ids": (9, np.uint32), "itok_dist": (10, np.uint16), "suf_sig": (11, np.uint64), "suf_key": (12, np.dtype([("t", np.uint32, 8)])),
     "gram": (13, np.dtype([("w1", np.uint32), ("w2", np.uint32), ("lo", np.uint32), ("cnt", np.uint32)])),
     "suf_b": (15, np.dtype([("off", np.uint32), ("rem", np.uint16), ("slen", np.uint16), ("prev", np.uint32), ("sid", np.uint32)])),
-    "gram5": (14, np.dtype([("w1", np.uint32), ("w2", np.uint32), ("lo", np.uint32), ("cnt", np.uint32)])),
+    # 128-byte buckets of the 5-gram table (fmx_core.hh: G5Bucket): three 40-byte entries + {entries in use | lcp bits, overflow flag}
+    "gram5": (14, np.dtype([("e", np.dtype([("w", np.uint32, 4), ("lo", np.uint32), ("cnt", np.uint32), ("t", np.uint32, 4)]), 3),
+                            ("used", np.uint32), ("over", np.uint32)])),
+    "gram7": (16, np.dtype([("w1", np.uint32), ("w2", np.uint32), ("lo", np.uint32), ("cnt", np.uint32)])),
 }
 
 MATCH_DTYPE = np.dtype([("score", np.float32), ("penalty", np.float32),

@@ -193,12 +193,13 @@ typedef enum fmx_array {
   FMX_A_SUF_SIG = 11,  /* 8 B x n_suffixes    min(sentence length, 255) << 56 | 56-bit word signature of the sentence (derived) */
   FMX_A_SUF_KEY = 12,  /* 32 B x n_suffixes   the eight tokens after the suffix's first token (derived) */
   FMX_A_GRAM = 13,     /* 16 B x 2^k          trigram -> suffix range hash table {w1, w2, lo, cnt} (derived) */
-  FMX_A_GRAM5 = 14,    /* 16 B x 2^k          5-gram table of the heavy trigrams {w3, w4, lo, cnt} (derived) */
-  FMX_A_SUF_B = 15     /* 16 B x n_suffixes   {u32 off; u16 rem; u16 slen; u32 previous token; u32 sentence id} (derived) */
+  FMX_A_GRAM5 = 14,    /* 128 B x n_buckets   5-gram buckets: three entries {w1..w4, lo, cnt, tokens 5..8 of suffix lo} + {used | lcp bits, overflow flag} (derived) */
+  FMX_A_SUF_B = 15,    /* 16 B x n_suffixes   {u32 off; u16 rem; u16 slen; u32 previous token; u32 sentence id} (derived) */
+  FMX_A_GRAM7 = 16     /* 16 B x 2^k          7-gram table of the heavy 5-grams {w5, w6, lo, cnt} (derived) */
 } fmx_array;
 /* borrowed pointer to a host array of the index, valid until the index changes or is freed */
 int fmx_index_array(const fmx_index*, int which, const void** data, uint64_t* count);
-/* The "(derived)" per-suffix arrays and n-gram tables (FMX_A_SUF_REC, _SUF_SIG, _SUF_KEY, _GRAM, _GRAM5, _SUF_B) are built
+/* The "(derived)" per-suffix arrays and n-gram tables (FMX_A_SUF_REC, _SUF_SIG, _SUF_KEY, _GRAM, _GRAM5, _GRAM7, _SUF_B) are built
  * on the device by fmx_index_to_device; fmx_index_array builds their host twins on request (tests, CPU emulation).
  * fmx_index_device_array copies one of them out of the HBM of replica `replica` as it is used by the kernels:
  * dst == NULL only reports the element count. */

@@ -16,15 +16,27 @@ using namespace fmx;
 struct Rec { float score; float penalty; int32_t max_subseq; uint32_t s_id; };
 
 struct EmulIndex {
-  const SufRec* suf; const uint64_t* suf_sig; const SufKey* suf_key; const GramEntry* gram; const GramEntry* gram5; const SufRecB* suf_b; const uint32_t* tok; const uint32_t* sent_pos; const uint32_t* qva;
+  const SufRec* suf; const uint64_t* suf_sig; const SufKey* suf_key; const GramEntry* gram; const G5Bucket* gram5; const GramEntry* gram7; const SufRecB* suf_b; const uint32_t* tok; const uint32_t* sent_pos; const uint32_t* qva;
   const float* idf; const uint32_t* real; const uint32_t* itok; const uint16_t* itok_dist;
-  uint32_t n_itok, n_qva, gram_mask, gram5_mask;
+  uint32_t n_itok, n_qva, gram_mask, gram5_buckets, gram7_mask;
 };
 
 struct VecRow {
   float* base;
   float& operator[](uint32_t j) const { return base[j]; }
 };
+
+// the probe's range function alone (fmx_core.hh: mgram_range_hashed — n-gram tables, 5-gram buckets, keys), for n-grams of any length:
+// ngrams = n x stride tokens, lens[k] = length of n-gram k; out = n x {lo, hi}
+extern "C" void emul_ngram_ranges(const EmulIndex* ix, const uint32_t* ngrams, const uint32_t* lens, uint64_t n, uint32_t stride,
+                                  uint32_t* out) {
+  const GramTables gt{ix->gram, ix->gram5, ix->gram7, ix->gram_mask, ix->gram5_buckets, ix->gram7_mask};
+  for (uint64_t k = 0; k < n; k++) {
+    uint32_t lo = 0, hi = 0;
+    mgram_range_hashed(gt, ix->suf_key, ix->suf, ix->tok, ix->qva, ix->n_qva, ngrams + k * stride, lens[k], lo, hi);
+    out[2 * k] = lo; out[2 * k + 1] = hi;
+  }
+}
 
 extern "C" int emul_match_batch(const EmulIndex* ix, const Params* prm_in, uint64_t nq, const uint32_t* q_off,
                                 const uint32_t* q_tok, const uint32_t* q_real, const uint32_t* q_itok, Rec* out,
@@ -49,7 +61,7 @@ extern "C" int emul_match_batch(const EmulIndex* ix, const Params* prm_in, uint6
     const bool use_sig = prm.ins >= 0.f && prm.del >= 0.f && prm.rep >= 0.f;
     for (uint32_t it = 0; it < p; it++) {
       uint32_t lo = 0, hi = 0;
-      if (reachable && it + m <= p) mgram_range_hashed(GramTables{ix->gram, ix->gram5, ix->gram_mask, ix->gram5_mask}, ix->suf_key, ix->suf, ix->tok, ix->qva, ix->n_qva, pat + it, m, lo, hi);
+      if (reachable && it + m <= p) mgram_range_hashed(GramTables{ix->gram, ix->gram5, ix->gram7, ix->gram_mask, ix->gram5_buckets, ix->gram7_mask}, ix->suf_key, ix->suf, ix->tok, ix->qva, ix->n_qva, pat + it, m, lo, hi);
       if (stats) stats[0] += hi - lo;
       for (uint32_t i = lo; i < hi; i++) {
         const SufRec r = ix->suf[i];

@@ -21,9 +21,9 @@ class CoreParams(C.Structure):
 
 
 class EmulIndex(C.Structure):
-    _fields_ = [("suf", C.c_void_p), ("suf_sig", C.c_void_p), ("suf_key", C.c_void_p), ("gram", C.c_void_p), ("gram5", C.c_void_p), ("suf_b", C.c_void_p), ("tok", C.c_void_p), ("sent_pos", C.c_void_p),
+    _fields_ = [("suf", C.c_void_p), ("suf_sig", C.c_void_p), ("suf_key", C.c_void_p), ("gram", C.c_void_p), ("gram5", C.c_void_p), ("gram7", C.c_void_p), ("suf_b", C.c_void_p), ("tok", C.c_void_p), ("sent_pos", C.c_void_p),
                 ("qva", C.c_void_p), ("idf", C.c_void_p), ("real", C.c_void_p), ("itok", C.c_void_p),
-                ("itok_dist", C.c_void_p), ("n_itok", C.c_uint32), ("n_qva", C.c_uint32), ("gram_mask", C.c_uint32), ("gram5_mask", C.c_uint32)]
+                ("itok_dist", C.c_void_p), ("n_itok", C.c_uint32), ("n_qva", C.c_uint32), ("gram_mask", C.c_uint32), ("gram5_buckets", C.c_uint32), ("gram7_mask", C.c_uint32)]
 
 
 _lib = None
@@ -50,20 +50,38 @@ class Emul:
         self.ix = fmx_index
         info = fmx_index.info()
         self.info = info
-        self.a = {n: fmx_index.array(n) for n in ["suf_rec", "suf_sig", "suf_key", "gram", "gram5", "suf_b", "buffer", "sent_pos", "qva", "idf"]}
+        self.a = {n: fmx_index.array(n) for n in ["suf_rec", "suf_sig", "suf_key", "gram", "gram5", "gram7", "suf_b", "buffer", "sent_pos", "qva", "idf"]}
         self.a["real_ids"] = fmx_index.array("real_ids") if info.real_differs else None
         self.a["itok_ids"] = fmx_index.array("itok_ids") if info.real_differs else None
+
+    def _index(self):
+        info = self.ix.info()
+        return EmulIndex(_p(self.a["suf_rec"]), _p(self.a["suf_sig"]), _p(self.a["suf_key"]), _p(self.a["gram"]), _p(self.a["gram5"]), _p(self.a["gram7"]), _p(self.a["suf_b"]), _p(self.a["buffer"]), _p(self.a["sent_pos"]),
+                         _p(self.a["qva"]), _p(self.a["idf"]), None, None, None, info.n_itok, len(self.a["qva"]),
+                         max(len(self.a["gram"]), 1) - 1, len(self.a["gram5"]), max(len(self.a["gram7"]), 1) - 1)
+
+    def ngram_ranges(self, ngrams, lens):
+        """mgram_range_hashed for every row of `ngrams` (n x stride uint32; lens[k] tokens of row k count): n x 2 (lo, hi)."""
+        ngrams = np.ascontiguousarray(ngrams, np.uint32)
+        lens = np.ascontiguousarray(lens, np.uint32)
+        out = np.zeros((len(lens), 2), np.uint32)
+        e = self._index()
+        L = lib()
+        L.emul_ngram_ranges.argtypes = [C.POINTER(EmulIndex), C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]
+        L.emul_ngram_ranges.restype = None
+        L.emul_ngram_ranges(C.byref(e), _p(ngrams), _p(lens), len(lens), ngrams.shape[1], out.ctypes.data_as(C.c_void_p))
+        return out
 
     def match_batch(self, p, q_off, q_tok, q_real=None, q_itok=None, cap=None):
         """p: the fmx Params (fmx_params layout)."""
         info = self.ix.info()
         dist = self.ix.array("itok_dist") if info.n_itok else None
-        e = EmulIndex(_p(self.a["suf_rec"]), _p(self.a["suf_sig"]), _p(self.a["suf_key"]), _p(self.a["gram"]), _p(self.a["gram5"]), _p(self.a["suf_b"]), _p(self.a["buffer"]), _p(self.a["sent_pos"]),
+        e = EmulIndex(_p(self.a["suf_rec"]), _p(self.a["suf_sig"]), _p(self.a["suf_key"]), _p(self.a["gram"]), _p(self.a["gram5"]), _p(self.a["gram7"]), _p(self.a["suf_b"]), _p(self.a["buffer"]), _p(self.a["sent_pos"]),
                       _p(self.a["qva"]), _p(self.a["idf"]),
                       _p(self.a["real_ids"]) if self.a["real_ids"] is not None else None,
                       _p(self.a["itok_ids"]) if self.a["itok_ids"] is not None else None,
                       _p(dist) if dist is not None else None, info.n_itok, len(self.a["qva"]),
-                      max(len(self.a["gram"]), 1) - 1, max(len(self.a["gram5"]), 1) - 1)
+                      max(len(self.a["gram"]), 1) - 1, len(self.a["gram5"]), max(len(self.a["gram7"]), 1) - 1)
         cp = CoreParams(p.fuzzy, p.nmatch, p.no_perfect, p.min_subseq_length, p.min_subseq_ratio, p.idf_penalty,
                         p.insert_cost, p.delete_cost, p.replace_cost, p.contrast, p.reduce,
                         p.nmatch if p.contrast_buffer == -1 else p.contrast_buffer,

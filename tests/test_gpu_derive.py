@@ -18,6 +18,57 @@ def _entries(tab):
     return np.sort(live, order=["lo", "cnt", "w1", "w2"])
 
 
+def _bucket_entries(tab):
+    """Live entries of the 5-gram buckets as sorted rows (w1..w4, lo, cnt, t5..t8, lcp)."""
+    if len(tab) == 0:
+        return np.zeros((0, 11), np.uint32)
+    used = np.minimum(tab["used"] & 0xffff, 3)
+    rows = []
+    for k in range(3):
+        sel = used > k
+        e = tab["e"][sel, k]
+        lcp = (tab["used"][sel] >> (16 + 4 * k)) & 15
+        rows.append(np.column_stack([e["w"], e["lo"], e["cnt"], e["t"], lcp]).astype(np.uint32))
+    rows = np.concatenate(rows) if rows else np.zeros((0, 11), np.uint32)
+    return rows[np.lexsort(rows.T[::-1])]
+
+
+def _check_buckets_searchable(ix, tab, label):
+    """Every entry sits in its home bucket or in a later one with every bucket from home up to it flagged `over` (what a lookup
+    follows); lcp = tokens 5..8 shared by the group's first and last suffix."""
+    nb = len(tab)
+    key, rec, buf = ix.array("suf_key")["t"], ix.array("suf_rec"), ix.array("buffer")
+    off = (rec & np.uint64(0xffffffff)).astype(np.int64)
+    used = np.minimum(tab["used"] & 0xffff, 3)
+    M32 = np.uint64(0xffffffff)
+
+    def h5(w0, w):
+        def mul(a, c): return (a * np.uint64(c)) & M32
+        h = mul(w0.astype(np.uint64), 0x9E3779B1)
+        for (sh, c, col) in ((15, 0x85EBCA6B, 0), (13, 0xC2B2AE35, 1), (16, 0x27D4EB2F, 2), (15, 0x165667B1, 3)):
+            h = ((h ^ (h >> np.uint64(sh))) + mul(w[:, col].astype(np.uint64), c)) & M32
+        h ^= h >> np.uint64(16); h = mul(h, 0x7FEB352D); h ^= h >> np.uint64(15)
+        return h
+
+    for k in range(3):
+        at = np.nonzero(used > k)[0]
+        if not len(at):
+            continue
+        e = tab["e"][at, k]
+        lo, cnt = e["lo"].astype(np.int64), e["cnt"].astype(np.int64)
+        assert np.array_equal(key[lo][:, :4], e["w"]) and np.array_equal(key[lo][:, 4:], e["t"]), label
+        first, last = key[lo][:, 4:], key[lo + cnt - 1][:, 4:]
+        eq = first == last
+        lcp = np.where(eq.all(axis=1), 4, np.argmin(eq, axis=1))
+        assert np.array_equal(lcp, (tab["used"][at] >> (16 + 4 * k)) & 15), label
+        home = ((h5(buf[off[lo]], e["w"]) * np.uint64(nb)) >> np.uint64(32)).astype(np.int64)
+        dist = (at - home) % nb
+        assert dist.max() < 64, (label, int(dist.max()))
+        for d in range(1, int(dist.max()) + 1):       # displaced entries: every bucket they passed is flagged
+            far = dist >= d
+            assert np.all(tab["over"][(home[far] + d - 1) % nb] != 0), label
+
+
 def _to_device_layout(ix, off):
     """Token offsets of the host's packed _sentence_buffer -> the device layout (DeviceIndex::upload keeps a sentence that fits
     one 128-byte line inside one line): same sentence, same position in it."""
@@ -51,14 +102,21 @@ def _compare(ix, label):
         if name == "suf_b":
             host["off"] = _to_device_layout(ix, host["off"])
         assert host.shape == dev.shape and np.array_equal(host.view(np.uint8), dev.view(np.uint8)), (label, name)
-    for name in ["gram", "gram5"]:
+    for name in ["gram", "gram7"]:
         host, dev = ix.array(name), ix.device_array(name)
         assert len(host) == len(dev), (label, name, len(host), len(dev))   # same capacity rule
         assert np.array_equal(_entries(host), _entries(dev)), (label, name)
         if len(dev):
             # open addressing stays searchable: every live entry is reachable from its home slot without crossing an empty one
             assert (dev["lo"] != 0xffffffff).sum() * 2 <= len(dev), (label, name)
-    return len(ix.device_array("gram")), len(ix.device_array("gram5"))
+    # the 5-gram buckets: same number of buckets, the same entries (with their lcp) wherever concurrent inserts put them
+    host, dev = ix.array("gram5"), ix.device_array("gram5")
+    assert len(host) == len(dev), (label, "gram5", len(host), len(dev))
+    he, de = _bucket_entries(host), _bucket_entries(dev)
+    assert he.shape == de.shape and np.array_equal(he, de), (label, "gram5")
+    if len(dev):
+        _check_buckets_searchable(ix, dev, label)
+    return len(ix.device_array("gram")), len(de)
 
 
 def test_device_built_arrays_equal_the_host_build_synthetic(fmx, gpu_device):
@@ -74,8 +132,8 @@ def test_device_built_arrays_equal_the_host_build_synthetic(fmx, gpu_device):
 
 @pytest.mark.parametrize("seed,vocab", [(1, 3), (2, 6), (3, 40)])
 def test_device_built_arrays_equal_the_host_build_dense(fmx, gpu_device, seed, vocab):
-    """Tiny vocabularies: trigram groups of thousands of suffixes, so the 5-gram level is populated; one- and two-token
-    sentences (suffixes that end a run); duplicates."""
+    """Tiny vocabularies: 5-gram groups of hundreds of suffixes, so the 7-gram level is populated and buckets overflow; one- and
+    two-token sentences (suffixes that end a run); duplicates."""
     rng = np.random.default_rng(seed)
     c_off, c_tok = workloads.dense_corpus(rng, 6000, vocab, min_len=1, max_len=14)
     ix = fmx.Index.create(max_tokens=20)
