@@ -481,10 +481,15 @@ int fmx_match_batch_text_keep(fmx_index* ix, const fmx_params* params, const fmx
   if (cap == 0) return fail(FMX_E_INVALID, "cap must be > 0");
   if (!ix->finalized) return fail(FMX_E_STATE, "index is not finalized");
   if (ix->devs.empty()) return fail(FMX_E_NO_DEVICE, "index is not on a device (fmx_index_to_device); there is no CPU path");
-  if (ix->host.real_differs) return fail(FMX_E_UNSUPPORTED, "text batches carry no real tokens: this index distinguishes them (look the ids up with fmx_vocab_lookup_mt)");
+  if (tb->nq && tb->real_text && tb->q_off[tb->nq] > tb->n_real_bytes) return fail(FMX_E_INVALID, "text batch: fewer real-token bytes than spellings counted by the offsets");
+  if (tb->n_itoks && (!tb->itok_slot || !tb->itok_id)) return fail(FMX_E_INVALID, "text batch: null penalty-token arrays");
   return guarded([&]() {
     HostBatchView v;
     v.nq = tb->nq; v.q_off = tb->q_off; v.text = tb->text; v.n_text = tb->n_bytes;
+    if (ix->host.real_differs) {  // (an index whose real tokens are its normalised tokens has no use for them)
+      v.real_text = tb->real_text; v.n_real_text = tb->real_text ? tb->n_real_bytes : 0;
+      v.n_itoks = tb->n_itoks; v.itok_slot = tb->itok_slot; v.itok_id = tb->itok_id;
+    }
     Stats st;
     // (one replica per call, round-robin: a block of a text batch would need the byte offset of its first spelling)
     // (a kept copy lives on the first replica's device, like fmx_match_batch_keep's)

@@ -263,8 +263,13 @@ FMX_HD uint32_t gram_hash(uint32_t w0, uint32_t w1, uint32_t w2) {
 //     (`lcp`, 0..4: first and last suffix of a sorted group agree on exactly the tokens all of them agree on).
 // A seed of up to 5 + lcp tokens is decided inside the bucket (the whole group, or nothing); a longer one is decided when it
 // differs from the shared tokens (nothing), and only otherwise continues into the group's keys.  A bucket holds three
-// entries; the table has about one bucket per distinct 5-gram (kG5FillPer16), so a bucket overflows into its successors
-// rarely (flag `over`) and an absent 5-gram — most probed starts: the pattern was edited there — costs one line.
+// entries and an eight-byte directory — a 16-bit tag per entry (a second hash of the 5-gram) and the bucket's state —, and
+// a lane reads the DIRECTORY first: most probed starts name a 5-gram the index does not hold (the pattern was edited
+// there) and are through after that one 8-byte load; a tag that matches is followed by the 40 bytes of its entry, out of
+// the line the directory just brought in.  (Loading the whole 128 bytes per lane — eight 16-byte loads, each touching 64
+// different lines per wave — halved the HBM traffic of the probe and made it SLOWER, 1.78 -> 2.04 ms at C3: the kernel had
+// become bound by load instructions, not by lines.)  The table has about one bucket per distinct 5-gram (kG5FillPer16), so a
+// bucket overflows into its successors rarely (flag `over`) and an absent 5-gram costs one line.
 struct G5Entry {
   uint32_t w1, w2, w3, w4;  // tokens 1..4 of the 5-gram
   uint32_t lo, cnt;         // its suffix range [lo, lo + cnt)
@@ -272,12 +277,16 @@ struct G5Entry {
 };
 struct __attribute__((aligned(128))) G5Bucket {
   G5Entry  e[3];
-  uint32_t used;   // bits 0..15: entries in use (may read > 3 while a build is in flight: clamp); bits 16 + 4 k ..: lcp of entry k
-  uint32_t over;   // != 0: an entry whose home is this bucket (or one that passed through) lives in a later bucket
+  uint32_t dir_a;  // tag of entry 0 | tag of entry 1 << 16
+  uint32_t dir_b;  // tag of entry 2 | state << 16: bits 0-1 entries in use, bit 2 `over` (an entry whose home is this bucket, or one
+                   // that passed through, lives in a later bucket), bits 4 + 3 k .. 6 + 3 k the lcp of entry k
 };
 constexpr uint32_t kG5PerBucket = 3;
 constexpr uint32_t kG5FillPer16 = 16;  // distinct 5-grams per 16 buckets (16 = one per bucket: 1.9 % of the buckets overflow)
-FMX_HD uint32_t g5_lcp_of(uint32_t used, uint32_t k) { return (used >> (16 + 4 * k)) & 15u; }
+FMX_HD uint32_t g5_used(uint32_t dir_b) { return (dir_b >> 16) & 3u; }
+FMX_HD uint32_t g5_over(uint32_t dir_b) { return (dir_b >> 18) & 1u; }
+FMX_HD uint32_t g5_lcp_of(uint32_t dir_b, uint32_t k) { return (dir_b >> (20 + 3 * k)) & 7u; }
+FMX_HD uint32_t g5_tag_of(uint32_t dir_a, uint32_t dir_b, uint32_t k) { return k == 0 ? (dir_a & 0xffffu) : (k == 1 ? (dir_a >> 16) : (dir_b & 0xffffu)); }
 FMX_HD uint32_t gram5_hash(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t w4) {
   uint32_t h = w0 * 0x9E3779B1u;
   h = (h ^ (h >> 15)) + w1 * 0x85EBCA6Bu;
@@ -286,6 +295,16 @@ FMX_HD uint32_t gram5_hash(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, u
   h = (h ^ (h >> 15)) + w4 * 0x165667B1u;
   h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15;
   return h;
+}
+// the entry's tag: 16 bits of a SECOND hash of the five tokens (entries of one bucket share most bits of the first)
+FMX_HD uint32_t gram5_tag(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t w4) {
+  uint32_t h = w4 * 0x9E3779B1u;
+  h = (h ^ (h >> 13)) + w3 * 0xC2B2AE35u;
+  h = (h ^ (h >> 15)) + w2 * 0x27D4EB2Fu;
+  h = (h ^ (h >> 16)) + w1 * 0x165667B1u;
+  h = (h ^ (h >> 13)) + w0 * 0x85EBCA6Bu;
+  h ^= h >> 15; h *= 0x846CA68Bu;
+  return h >> 16;
 }
 FMX_HD uint32_t g5_bucket_of(uint32_t h, uint32_t n_buckets) { return (uint32_t)(((unsigned long long)h * n_buckets) >> 32); }
 
@@ -370,23 +389,28 @@ FMX_HD void mgram_range_hashed(const GramTables& gt, const SufKey* __restrict__ 
   if (m >= 5 && gt.g5 != nullptr) {
     // ---- seeds of five tokens and more: the bucket of the first five ----
     uint32_t b = g5_bucket_of(gram5_hash(w0, ng[1], ng[2], ng[3], ng[4]), gt.n_b5);
-    const uint32_t blo = qva[wi], bhi = qva[wi + 1];  // (requested together with the bucket)
+    const uint32_t tag = gram5_tag(w0, ng[1], ng[2], ng[3], ng[4]);
+    const uint32_t blo = qva[wi], bhi = qva[wi + 1];  // (requested together with the bucket's directory)
     tally_add(tally, 8);
     uint32_t lcp = 0, t0 = 0, t1 = 0, t2 = 0, t3 = 0;
     bool found = false;
     for (uint32_t hops = 0;; hops++) {
-      const G5Bucket bk = gt.g5[b];
-      tally_add(tally, 128);
-      const uint32_t used = bk.used & 0xffffu;
+      const G5Bucket* bk = gt.g5 + b;
+      const uint32_t dir_a = bk->dir_a, dir_b = bk->dir_b;  // one 8-byte load: most starts end here
+      tally_add(tally, 8);
+      const uint32_t used = g5_used(dir_b);
 #pragma unroll
       for (uint32_t k = 0; k < kG5PerBucket; k++) {
-        const G5Entry& e = bk.e[k];
-        if (k < used && e.w1 == ng[1] && e.w2 == ng[2] && e.w3 == ng[3] && e.w4 == ng[4] && e.lo >= blo && e.lo < bhi) {
-          found = true; lo = e.lo; hi = e.lo + e.cnt; lcp = g5_lcp_of(bk.used, k);
-          t0 = e.t[0]; t1 = e.t[1]; t2 = e.t[2]; t3 = e.t[3];
+        if (!found && k < used && g5_tag_of(dir_a, dir_b, k) == tag) {
+          const G5Entry e = bk->e[k];  // same line as the directory
+          tally_add(tally, 40, 0);
+          if (e.w1 == ng[1] && e.w2 == ng[2] && e.w3 == ng[3] && e.w4 == ng[4] && e.lo >= blo && e.lo < bhi) {
+            found = true; lo = e.lo; hi = e.lo + e.cnt; lcp = g5_lcp_of(dir_b, k);
+            t0 = e.t[0]; t1 = e.t[1]; t2 = e.t[2]; t3 = e.t[3];
+          }
         }
       }
-      if (found || bk.over == 0u || hops >= gt.n_b5) break;
+      if (found || g5_over(dir_b) == 0u || hops >= gt.n_b5) break;
       b = b + 1 == gt.n_b5 ? 0u : b + 1;
     }
     if (!found || !w_ok || blo >= bhi) return;  // no suffix starts with these five tokens

@@ -150,20 +150,28 @@ __global__ void __launch_bounds__(256) k_dv_insert5x(const uint32_t* __restrict_
   const SufKey first = key[i], last = key[e - 1];
   uint32_t lcp = 0;
   while (lcp < 4 && first.t[4 + lcp] == last.t[4 + lcp]) lcp++;
-  uint32_t b = g5_bucket_of(gram5_hash(tok[r.off], first.t[0], first.t[1], first.t[2], first.t[3]), n_buckets);
+  const uint32_t w0 = tok[r.off];
+  uint32_t b = g5_bucket_of(gram5_hash(w0, first.t[0], first.t[1], first.t[2], first.t[3]), n_buckets);
+  const uint32_t tag = gram5_tag(w0, first.t[0], first.t[1], first.t[2], first.t[3]);
   for (;;) {
-    const uint32_t slot = atomicAdd(&g[b].used, 1u) & 0xffffu;
+    // claim a slot: entries in use = bits 16..17 of dir_b (compare-and-swap: the count never passes three)
+    uint32_t old = __hip_atomic_load(&g[b].dir_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), slot = kG5PerBucket;
+    while (g5_used(old) < kG5PerBucket) {
+      const uint32_t seen = atomicCAS(&g[b].dir_b, old, old + (1u << 16));
+      if (seen == old) { slot = g5_used(old); break; }
+      old = seen;
+    }
     if (slot < kG5PerBucket) {
       G5Entry en;
       en.w1 = first.t[0]; en.w2 = first.t[1]; en.w3 = first.t[2]; en.w4 = first.t[3];
       en.lo = i; en.cnt = e - i;
       en.t[0] = first.t[4]; en.t[1] = first.t[5]; en.t[2] = first.t[6]; en.t[3] = first.t[7];
       g[b].e[slot] = en;
-      if (lcp) atomicOr(&g[b].used, lcp << (16 + 4 * slot));
+      if (slot < 2) atomicOr(&g[b].dir_a, tag << (16 * slot));
+      atomicOr(&g[b].dir_b, (slot == 2 ? tag : 0u) | (lcp << (20 + 3 * slot)));
       return;
     }
-    atomicSub(&g[b].used, 1u);
-    atomicOr(&g[b].over, 1u);
+    atomicOr(&g[b].dir_b, 1u << 18);
     b = b + 1 == n_buckets ? 0u : b + 1;
   }
 }

@@ -46,6 +46,13 @@ struct HostBatchView {
   // vocabulary ids are looked up on the device (fmx_vocab.hip.hh)
   const char*     text = nullptr;
   uint64_t        n_text = 0;
+  // ... with the real tokens as a second stream of q_off[nq] spellings (nullptr: the pattern tokens' own spellings) and the
+  // penalty tokens as (slot, interned id) pairs, slot = q_off[q] + q + j like q_itok — indexes with real tokens only
+  const char*     real_text = nullptr;
+  uint64_t        n_real_text = 0;
+  uint64_t        n_itoks = 0;
+  const uint64_t* itok_slot = nullptr;
+  const uint32_t* itok_id = nullptr;
 };
 
 struct DeviceBatchView {

@@ -147,8 +147,10 @@ struct Ctx {
   uint64_t want_qb = 1ull << 24;  // queue entries (8 bytes each) wanted: grows when a pass reports more
   // ---- staging of the host-buffer entry point (each buffer tracks its own capacity) ----
   Grow<uint32_t> d_qoff, d_qtok, d_qreal, d_qitok, d_cnt, d_tot, d_prior;
-  Grow<unsigned char> d_text;              // token spellings of a text batch
-  Grow<unsigned long long> d_vstate;       // look-back state of k_vocab_lookup (one word per tile + ticket + total)
+  Grow<unsigned char> d_text, d_text_r;    // token spellings of a text batch (normalised tokens; real tokens)
+  Grow<unsigned long long> d_vstate, d_vstate_r;  // spellings per tile of k_vocab_count, scanned in place
+  Grow<unsigned long long> d_islot;        // penalty tokens of a text batch: slot ...
+  Grow<uint32_t> d_iid;                    // ... and interned id
   unsigned long long* h_vtotal = nullptr;  // pinned: tokens k_vocab_lookup found
   Grow<Rec>      d_out;
   // ---- streams / events ----
@@ -234,7 +236,7 @@ struct Ctx {
     t_q.release(); t_lo.release(); t_cnt.release(); t_idf.release(); c_qi.release(); keys.release(); seg.release(); qb.release();
     heap.release(); f0.release(); f1.release(); vals.release(); zero_blk.release();
     items.release(); items_b.release(); items_h.release(); cmin_tab.release(); g_rows.release();
-    d_qoff.release(); d_qtok.release(); d_qreal.release(); d_qitok.release(); d_text.release(); d_vstate.release(); d_cnt.release(); d_tot.release(); d_out.release(); d_prior.release();
+    d_qoff.release(); d_qtok.release(); d_qreal.release(); d_qitok.release(); d_text.release(); d_vstate.release(); d_text_r.release(); d_vstate_r.release(); d_islot.release(); d_iid.release(); d_cnt.release(); d_tot.release(); d_out.release(); d_prior.release();
     if (stream) (void)hipStreamDestroy(stream);
     if (h2d && !shared_copy) (void)hipStreamDestroy(h2d);
     if (d2h && !shared_copy) (void)hipStreamDestroy(d2h);
@@ -322,6 +324,10 @@ struct DeviceIndex::Impl {
   // changed; a call reads the copy it pinned
   DevVocab                vocab{};
   uint64_t                vocab_built_for = ~0ull;
+  // the index's interned real tokens as the same kind of table (HostIndex::real_table): fixed at upload (real tokens are
+  // interned by derive()); only indexes whose real tokens differ from the normalised ones have one
+  DevVocab                real_vocab{};
+  DevBlob                 real_hold;
   std::mutex              pool_mu;
   std::condition_variable pool_cv;
   std::vector<std::unique_ptr<Ctx>> all;
@@ -455,6 +461,21 @@ static void refresh_itok_table(DeviceIndex::Impl& m, const HostIndex& h) {
   m.itok_version.store(version);
 }
 
+static DevVocab upload_vocab_table(const HostIndex::VocabTable& t, DevBlob& blob) {
+  std::vector<ulonglong2> ent(t.n_slots);  // slot and head side by side: one 16-byte load per probe
+  for (uint64_t k = 0; k < t.n_slots; k++) { ent[k].x = t.slot[k]; ent[k].y = t.head[k]; }
+  ulonglong2* de = dev_alloc<ulonglong2>(t.n_slots);
+  blob.a = de;
+  unsigned char* da = dev_alloc<unsigned char>(t.arena_bytes + 16);
+  blob.b = da;
+  HIP_TRY(hipMemcpy(de, ent.data(), t.n_slots * sizeof(ulonglong2), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(da, 0, t.arena_bytes + 16));
+  if (t.arena_bytes) HIP_TRY(hipMemcpy(da, t.arena, t.arena_bytes, hipMemcpyHostToDevice));
+  DevVocab v{};
+  v.entry = de; v.arena = da; v.mask = t.n_slots - 1;
+  return v;
+}
+
 // the device copy of the host's spelling table (text batches): uploaded on first use, replaced when words were added
 static void refresh_vocab_table(DeviceIndex::Impl& m, const HostIndex& h) {
   const HostIndex::VocabTable t = h.vocab_table();
@@ -468,20 +489,11 @@ static void refresh_vocab_table(DeviceIndex::Impl& m, const HostIndex& h) {
     if (m.vocab.entry && m.vocab_built_for == t.built_for) return;
   }
   if (t.n_slots == 0) throw std::invalid_argument("text batch on an index without spellings (fmx_index_set_forms)");
-  std::vector<ulonglong2> ent(t.n_slots);  // slot and head side by side: one 16-byte load per probe
-  for (uint64_t k = 0; k < t.n_slots; k++) { ent[k].x = t.slot[k]; ent[k].y = t.head[k]; }
   std::shared_ptr<DevBlob> blob(new DevBlob);
-  ulonglong2* de = dev_alloc<ulonglong2>(t.n_slots);
-  blob->a = de;
-  unsigned char* da = dev_alloc<unsigned char>(t.arena_bytes + 16);
-  blob->b = da;
-  HIP_TRY(hipMemcpy(de, ent.data(), t.n_slots * sizeof(ulonglong2), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemset(da, 0, t.arena_bytes + 16));
-  if (t.arena_bytes) HIP_TRY(hipMemcpy(da, t.arena, t.arena_bytes, hipMemcpyHostToDevice));
+  const DevVocab v = upload_vocab_table(t, *blob);
   std::lock_guard<std::mutex> g(m.tab_mu);
   m.vocab_hold = blob;
-  m.vocab = DevVocab{};
-  m.vocab.entry = de; m.vocab.arena = da; m.vocab.mask = t.n_slots - 1;
+  m.vocab = v;
   m.vocab_built_for = t.built_for;
 }
 
@@ -720,6 +732,7 @@ void DeviceIndex::upload(const HostIndex& h, int device, SortResident* res) {
       }
     }
     m.bytes += 2 * m.n_tok_words * 4;
+    m.real_vocab = upload_vocab_table(h.real_table(), m.real_hold);
   }
   if (d_old_pos) hipFree(d_old_pos);
   refresh_itok_table(m, h);
@@ -862,6 +875,9 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
     // two queries per wave in the last kernel (k_finish_pair): no contrastive rerank, lowest_costs fits half a wave
     // (with or without a contrastive factor; any contrast_buffer: beyond 30 entries the pair kernel takes 31 candidates per query)
     const bool pair_finish = m.pair_finish && prm.cbuf > 0;
+    // the exact coverage test moves into the edit-distance kernel when that is the bit-parallel one (k_expand_b: defer_cover)
+    static const bool defer_on = [] { const char* e = getenv("FMX_DEFER_COVER"); return e ? atoi(e) != 0 : true; }();  // design-time switch
+    const uint32_t defer_cover = (defer_on && !full && !use_idf && prm.ins == prm.del && prm.del == prm.rep && prm.rep >= 0.f) ? 1u : 0u;
     const uint32_t pair_max = prm.cbuf <= (int)kPairMax - 2 ? kPairMax : kPairMax - 1;
     {
       // capacities, one scan over two arrays (queue offsets of the queries phase A walks, segment offsets of the light queries)
@@ -906,10 +922,10 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
         side_tick(kStageExpandB, 0);
         second_scan(side);
         hipLaunchKernelGGL(k_expand_b<false>, dim3((light_max ? 0u : b.nq) + grid_b), dim3(kWave), lds, side, E.d, b, w, prm,
-                           (const WorkItem*)c.items_b.p, item_cap, light_max ? 0u : b.nq);
+                           (const WorkItem*)c.items_b.p, item_cap, light_max ? 0u : b.nq, defer_cover);
         side_tick(kStageExpandB, 1);
         if (light_max)
-          hipLaunchKernelGGL(k_expand_b<true>, dim3(b.nq), dim3(kWave), lds, stream, E.d, b, w, prm, (const WorkItem*)nullptr, 0u, b.nq);
+          hipLaunchKernelGGL(k_expand_b<true>, dim3(b.nq), dim3(kWave), lds, stream, E.d, b, w, prm, (const WorkItem*)nullptr, 0u, b.nq, defer_cover);
         tick(); tick();
       } else {
         // long ranges first (k_expand_h next to k_expand_a), then the two k_expand_b side by side: the one for the queries
@@ -922,11 +938,11 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
         fork();
         side_tick(kStageExpandB, 0);
         hipLaunchKernelGGL(k_expand_b<false>, dim3((light_max ? 0u : b.nq) + grid_b), dim3(kWave), lds, side, E.d, b, w, prm,
-                           (const WorkItem*)c.items_b.p, item_cap, light_max ? 0u : b.nq);
+                           (const WorkItem*)c.items_b.p, item_cap, light_max ? 0u : b.nq, defer_cover);
         side_tick(kStageExpandB, 1);
         if (light_max) {
           if (!m.serial) hipLaunchKernelGGL(k_lag, dim3(1), dim3(kWave), 0, stream, w.counters);
-          hipLaunchKernelGGL(k_expand_b<true>, dim3(b.nq), dim3(kWave), lds, stream, E.d, b, w, prm, (const WorkItem*)nullptr, 0u, b.nq);
+          hipLaunchKernelGGL(k_expand_b<true>, dim3(b.nq), dim3(kWave), lds, stream, E.d, b, w, prm, (const WorkItem*)nullptr, 0u, b.nq, defer_cover);
         }
         tick(); tick();
       }
@@ -1414,6 +1430,13 @@ __global__ void k_export_counts(const uint32_t* __restrict__ cnt, const uint32_t
   if (h_tot) h_tot[i] = tot[i];
 }
 
+// penalty tokens of a text batch: slot[k] (= q_off[q] + q + j, see fmx_batch::q_itok) gets the interned id id[k]
+__global__ void k_scatter_itoks(const unsigned long long* __restrict__ slot, const uint32_t* __restrict__ id, unsigned long long n,
+                                unsigned long long n_slots, uint32_t* __restrict__ q_itok) {
+  const unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n && slot[k] < n_slots) q_itok[slot[k]] = id[k];
+}
+
 __global__ void k_rebase(uint32_t* off, uint32_t n, uint32_t base) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) off[i] -= base;
@@ -1529,15 +1552,23 @@ void DeviceIndex::match_host_full(const HostIndex& h, const Params& prm, const H
   c.d_qoff.ensure(nq + 1);
   c.d_qtok.ensure(nt + 1);
   const uint64_t text_tiles = hb.text ? (hb.n_text + (uint64_t)kScanThreads * kVocabChunk - 1) / ((uint64_t)kScanThreads * kVocabChunk) : 0;
+  // a text batch on an index with real tokens: they are interned on the device too — from the batch's second stream of
+  // spellings (what _tokenize_and_normalize made of the sentence), or, without one, from the pattern tokens' own spellings
+  // (match(const Tokens&, ...): the real sentence IS the pattern, src/fuzzy_match.cc:402-416)
+  const bool text_real = hb.text && m.d.real != nullptr;
+  const uint64_t text_tiles_r = (text_real && hb.real_text) ? (hb.n_real_text + (uint64_t)kScanThreads * kVocabChunk - 1) / ((uint64_t)kScanThreads * kVocabChunk) : 0;
   if (hb.text) {
-    if (hb.q_real || hb.q_itok || m.d.real) throw UnsupportedError("text batches carry no real tokens / penalty tokens: look the ids up on the host");
+    if (hb.q_real || hb.q_itok) throw std::invalid_argument("text batch: real tokens / penalty tokens come as spellings and (slot, id) pairs, not as id arrays");
+    if (text_real && hb.real_text) { c.d_text_r.ensure(hb.n_real_text + 2 * kVocabChunk + 16); c.d_vstate_r.ensure(text_tiles_r + 4); }
     c.d_text.ensure(hb.n_text + 2 * kVocabChunk + 16);
     c.d_vstate.ensure(text_tiles + 4);
-    if (!c.h_vtotal) HIP_TRY(hipHostMalloc((void**)&c.h_vtotal, sizeof(unsigned long long), hipHostMallocDefault));
-    *c.h_vtotal = ~0ull;
+    if (!c.h_vtotal) HIP_TRY(hipHostMalloc((void**)&c.h_vtotal, 2 * sizeof(unsigned long long), hipHostMallocDefault));
+    c.h_vtotal[0] = ~0ull;
+    c.h_vtotal[1] = ~0ull;
   }
-  if (hb.q_real) c.d_qreal.ensure(nt + 1);
-  if (hb.q_itok) c.d_qitok.ensure(nt + nq + 1);
+  if (hb.q_real || text_real) c.d_qreal.ensure(nt + 1);
+  if (hb.q_itok || (hb.text && hb.n_itoks)) c.d_qitok.ensure(nt + nq + 1);
+  if (hb.text && hb.n_itoks) { c.d_islot.ensure(hb.n_itoks); c.d_iid.ensure(hb.n_itoks); }
   c.d_out.ensure(nq * cap);
   c.d_cnt.ensure(nq);
   c.d_tot.ensure(nq);
@@ -1558,8 +1589,8 @@ void DeviceIndex::match_host_full(const HostIndex& h, const Params& prm, const H
   for (uint64_t q = 0; q < nq; q++) p_max = std::max(p_max, hb.q_off[q + 1] - hb.q_off[q]);
   DeviceBatchView bv;
   bv.nq = nq; bv.q_off = c.d_qoff.p; bv.q_tok = c.d_qtok.p;
-  bv.q_real = hb.q_real ? c.d_qreal.p : nullptr;
-  bv.q_itok = hb.q_itok ? c.d_qitok.p : nullptr;
+  bv.q_real = (hb.q_real || text_real) ? c.d_qreal.p : nullptr;
+  bv.q_itok = (hb.q_itok || (hb.text && hb.n_itoks)) ? c.d_qitok.p : nullptr;
   bv.p_max = std::max<uint32_t>(p_max, 1);
   if (hb.n_prior) {  // the caller's prior matches: offsets then tokens in one staging buffer, ahead of the first pass
     const uint32_t n_tok = hb.prior_off[hb.n_prior];
@@ -1594,6 +1625,17 @@ void DeviceIndex::match_host_full(const HostIndex& h, const Params& prm, const H
       if (s == 0 && hb.n_text) {  // the whole text with the first pass; the ids are looked up on the compute stream (hooks.before)
         HIP_TRY(hipMemsetAsync(c.d_text.p + hb.n_text, 0, 2 * kVocabChunk + 16, h2d));
         HIP_TRY(hipMemcpyAsync(c.d_text.p, hb.text, hb.n_text, hipMemcpyHostToDevice, h2d));
+        if (text_real && hb.real_text && hb.n_real_text) {
+          HIP_TRY(hipMemsetAsync(c.d_text_r.p + hb.n_real_text, 0, 2 * kVocabChunk + 16, h2d));
+          HIP_TRY(hipMemcpyAsync(c.d_text_r.p, hb.real_text, hb.n_real_text, hipMemcpyHostToDevice, h2d));
+        }
+        if (hb.n_itoks) {  // the (few) penalty tokens of the batch: (slot, interned id) pairs, scattered into the zeroed slot array
+          HIP_TRY(hipMemsetAsync(c.d_qitok.p, 0, (nt + nq + 1) * 4, h2d));
+          HIP_TRY(hipMemcpyAsync(c.d_islot.p, hb.itok_slot, hb.n_itoks * 8, hipMemcpyHostToDevice, h2d));
+          HIP_TRY(hipMemcpyAsync(c.d_iid.p, hb.itok_id, hb.n_itoks * 4, hipMemcpyHostToDevice, h2d));
+          hipLaunchKernelGGL(k_scatter_itoks, dim3((unsigned)((hb.n_itoks + 255) / 256)), dim3(256), 0, h2d, (const unsigned long long*)c.d_islot.p,
+                             (const uint32_t*)c.d_iid.p, hb.n_itoks, (unsigned long long)(nt + nq), c.d_qitok.p);
+        }
       }
     } else if (t1_ > t0_) {
       HIP_TRY(hipMemcpyAsync(c.d_qtok.p + t0_, hb.q_tok + base + t0_, (t1_ - t0_) * 4, hipMemcpyHostToDevice, h2d));
@@ -1676,7 +1718,22 @@ void DeviceIndex::match_host_full(const HostIndex& h, const Params& prm, const H
                          (unsigned long long)hb.n_text, tile_count);
       hipLaunchKernelGGL(k_vocab_scan, dim3(1), dim3(kScanThreads), 0, c.stream, tile_count, (uint32_t)text_tiles, d_total);
       hipLaunchKernelGGL(k_vocab_lookup, dim3((unsigned)text_tiles), dim3(kScanThreads), 0, c.stream, (const unsigned char*)c.d_text.p,
-                         (unsigned long long)hb.n_text, (unsigned long long)nt, text_snap.vocab, c.d_qtok.p, (const uint32_t*)tile_count);
+                         (unsigned long long)hb.n_text, (unsigned long long)nt, text_snap.vocab, c.d_qtok.p, (const uint32_t*)tile_count, 1u);
+      if (text_real) {
+        constexpr uint32_t kNoReal = 0x7ffffffeu;  // HostIndex::lookup_real's "not a real token of this index"
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)c.d_qreal.p, (int)kNoReal, nt, c.stream));
+        if (hb.real_text) {  // a second stream of spellings, one per pattern token: counted (the call fails on a mismatch) and looked up
+          uint32_t* tile_count_r = reinterpret_cast<uint32_t*>(c.d_vstate_r.p);
+          hipLaunchKernelGGL(k_vocab_count, dim3((unsigned)text_tiles_r), dim3(kScanThreads), 0, c.stream, (const unsigned char*)c.d_text_r.p,
+                             (unsigned long long)hb.n_real_text, tile_count_r);
+          hipLaunchKernelGGL(k_vocab_scan, dim3(1), dim3(kScanThreads), 0, c.stream, tile_count_r, (uint32_t)text_tiles_r, d_total + 1);
+          hipLaunchKernelGGL(k_vocab_lookup, dim3((unsigned)text_tiles_r), dim3(kScanThreads), 0, c.stream, (const unsigned char*)c.d_text_r.p,
+                             (unsigned long long)hb.n_real_text, (unsigned long long)nt, m.real_vocab, c.d_qreal.p, (const uint32_t*)tile_count_r, kNoReal);
+        } else {             // the pattern tokens' own spellings, against the real-token table (same token starts, same ranks)
+          hipLaunchKernelGGL(k_vocab_lookup, dim3((unsigned)text_tiles), dim3(kScanThreads), 0, c.stream, (const unsigned char*)c.d_text.p,
+                             (unsigned long long)hb.n_text, (unsigned long long)nt, m.real_vocab, c.d_qreal.p, (const uint32_t*)tile_count, kNoReal);
+        }
+      }
     }
     if (s + 1 < n_sub) send(s + 1);  // travels while pass s computes
   };
@@ -1693,6 +1750,8 @@ void DeviceIndex::match_host_full(const HostIndex& h, const Params& prm, const H
   HIP_TRY(hipEventSynchronize(c.ev_done));
   if (hb.text && (hb.n_text ? *c.h_vtotal : 0ull) != nt)
     throw std::invalid_argument("text batch: the text holds " + std::to_string(*c.h_vtotal) + " spellings, the offsets count " + std::to_string(nt));
+  if (text_real && hb.real_text && nt && c.h_vtotal[1] != nt)
+    throw std::invalid_argument("text batch: the real-token text holds " + std::to_string(c.h_vtotal[1]) + " spellings, the offsets count " + std::to_string(nt));
   ms_d2h += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
   if (st) {
     st->ms_h2d += ms_h2d;   // host time spent enqueuing / staging; with pinned buffers the copies overlap the passes

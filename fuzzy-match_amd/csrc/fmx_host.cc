@@ -98,6 +98,36 @@ HostIndex::VocabTable HostIndex::vocab_table() const {
   return VocabTable{f.slot.data(), f.head.data(), f.arena.data(), (uint64_t)f.slot.size(), (uint64_t)f.arena.size(), f.built_for.load()};
 }
 
+// The interned real tokens of the index (derive(): real_intern) as the same kind of table: spelling -> interned id, for the
+// device-side lookup of a text batch's real tokens.  Built once per derive(); the empty spelling has no entry (a packed text
+// cannot hold it).
+HostIndex::VocabTable HostIndex::real_table() const {
+  std::lock_guard<std::mutex> lk(fast_mu_);
+  FastVocab& f = real_fast_;
+  if (f.built_for.load() != real_gen_ || f.slot.empty()) {
+    uint64_t cap = 64;
+    while (cap < real_intern.size() * 2) cap <<= 1;
+    f.slot.assign(cap, ~0ull);
+    f.head.assign(cap, 0ull);
+    f.mask = cap - 1;
+    f.arena.clear();
+    for (const auto& kv : real_intern) {
+      if (kv.first.empty()) continue;
+      const uint64_t off = f.arena.size();
+      f.arena.insert(f.arena.end(), kv.first.begin(), kv.first.end());
+      f.arena.push_back('\0');
+      size_t len;
+      uint64_t hd;
+      uint64_t h = spell_hash(f.arena.data() + off, len, hd) & f.mask;
+      while (f.slot[h] != ~0ull) h = (h + 1) & f.mask;
+      f.slot[h] = (off << 32) | (uint64_t)kv.second;
+      f.head[h] = hd;
+    }
+    f.built_for.store(real_gen_);
+  }
+  return VocabTable{f.slot.data(), f.head.data(), f.arena.data(), (uint64_t)f.slot.size(), (uint64_t)f.arena.size(), f.built_for.load()};
+}
+
 void HostIndex::get_indices(const char* const* toks, uint64_t n, uint32_t* ids, int nthreads) const {
   const FastVocab& f = fast_vocab();
   auto work = [&](uint64_t lo, uint64_t hi) {
@@ -522,18 +552,23 @@ void HostIndex::build_gram_table(int nthreads) {
       uint32_t lcp = 0;
       while (lcp < 4 && first.t[4 + lcp] == last.t[4 + lcp]) lcp++;
       uint32_t b = g5_bucket_of(gram5_hash(w0_of(lo), first.t[0], first.t[1], first.t[2], first.t[3]), (uint32_t)nb5);
+      const uint32_t tag = gram5_tag(w0_of(lo), first.t[0], first.t[1], first.t[2], first.t[3]);
       for (;;) {
-        const uint32_t slot = __atomic_fetch_add(&gram5[b].used, 1u, __ATOMIC_ACQ_REL) & 0xffffu;
+        // claim a slot: entries in use = bits 16..17 of dir_b (compare-and-swap: the count never passes three)
+        uint32_t old = __atomic_load_n(&gram5[b].dir_b, __ATOMIC_ACQUIRE), slot = kG5PerBucket;
+        while (g5_used(old) < kG5PerBucket) {
+          if (__atomic_compare_exchange_n(&gram5[b].dir_b, &old, old + (1u << 16), false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE)) { slot = g5_used(old); break; }
+        }
         if (slot < kG5PerBucket) {
           G5Entry& e = gram5[b].e[slot];
           e.w1 = first.t[0]; e.w2 = first.t[1]; e.w3 = first.t[2]; e.w4 = first.t[3];
           e.lo = (uint32_t)lo; e.cnt = (uint32_t)cnt;
           for (int k = 0; k < 4; k++) e.t[k] = first.t[4 + k];
-          __atomic_fetch_or(&gram5[b].used, lcp << (16 + 4 * slot), __ATOMIC_ACQ_REL);
+          if (slot < 2) __atomic_fetch_or(&gram5[b].dir_a, tag << (16 * slot), __ATOMIC_ACQ_REL);
+          __atomic_fetch_or(&gram5[b].dir_b, (slot == 2 ? tag : 0u) | (lcp << (20 + 3 * slot)), __ATOMIC_ACQ_REL);
           break;
         }
-        __atomic_fetch_sub(&gram5[b].used, 1u, __ATOMIC_ACQ_REL);
-        __atomic_store_n(&gram5[b].over, 1u, __ATOMIC_RELEASE);
+        __atomic_fetch_or(&gram5[b].dir_b, 1u << 18, __ATOMIC_ACQ_REL);
         b = b + 1 == nb5 ? 0u : b + 1;
       }
     });
@@ -701,6 +736,7 @@ void HostIndex::derive() {
   real_ids.clear();
   itok_ids.clear();
   real_intern.clear();
+  real_gen_++;
   if (!real.empty()) {
     for (uint32_t s = 0; s < real.size() && !real_differs; s++) {
       if (!real[s].itoks.empty()) { real_differs = true; break; }

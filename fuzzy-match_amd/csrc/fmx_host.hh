@@ -108,6 +108,8 @@ class HostIndex {
   // device copy are keyed on it, not on forms.size() (set_forms can change spellings without changing the size)
   std::atomic<uint64_t> vocab_gen_{1};
   mutable FastVocab  fast_;
+  mutable FastVocab  real_fast_;     // the same kind of table over the interned real tokens (real_table())
+  uint64_t           real_gen_ = 1;  // bumped by derive() (real_intern is rebuilt there)
   mutable std::mutex fast_mu_;
   const FastVocab& fast_vocab() const;
 
@@ -123,6 +125,7 @@ class HostIndex {
   // the spelling table behind get_indices, for its device copy (fmx_vocab.hip.hh); built_for = the vocabulary generation it was built from
   struct VocabTable { const uint64_t* slot; const uint64_t* head; const char* arena; uint64_t n_slots, arena_bytes, built_for; };
   VocabTable vocab_table() const;
+  VocabTable real_table() const;   // interned real-token spellings -> ids (indexes whose real tokens differ from the normalised ones)
   // attach spellings to an id-only index (ids 2 .. n - 1; bulk-built corpora): vocabulary lookups then work on it
   void set_forms(const char* const* spellings, uint64_t n);
 

@@ -4,7 +4,8 @@
 // kVocabChunk bytes of the text and marks the token starts in them; the rank of a token is the number of starts in front of
 // it (counts per tile, a scan of the tile counts, a scan inside the tile); every start is looked up in the device copy of the host's
 // spelling table (HostIndex::FastVocab: open addressing, the first eight bytes beside every slot, the spellings in an arena;
-// same hash).  Unknown spellings get VOCAB_UNK (1), like getIndex.
+// same hash).  Unknown spellings get VOCAB_UNK (1), like getIndex.  The same kernel interns a batch's REAL tokens against the
+// index's real-token table (HostIndex::real_table) for indexes whose real tokens differ from the normalised ones.
 #pragma once
 #include "fmx_kernels.hip.hh"
 
@@ -80,7 +81,7 @@ __global__ void __launch_bounds__(kScanThreads) k_vocab_scan(uint32_t* tile_coun
 // Pass 3: text: n_bytes bytes followed by at least kVocabChunk + 16 zero bytes, 16-byte aligned.  ids: n_tok words.
 __global__ void __launch_bounds__(kScanThreads) k_vocab_lookup(const unsigned char* __restrict__ text, unsigned long long n_bytes,
                                                               unsigned long long n_tok, DevVocab v, uint32_t* __restrict__ ids,
-                                                              const uint32_t* __restrict__ tile_base) {
+                                                              const uint32_t* __restrict__ tile_base, uint32_t unknown_id) {
   __shared__ uint32_t s_w[kScanThreads / kWave];
   const unsigned long long b0 = ((unsigned long long)blockIdx.x * kScanThreads + threadIdx.x) * kVocabChunk;
   unsigned long long starts = vocab_starts(text, b0, n_bytes);
@@ -131,7 +132,7 @@ __global__ void __launch_bounds__(kScanThreads) k_vocab_lookup(const unsigned ch
     if (!ended)
       for (unsigned char c = t[len]; c != 0; c = t[++len]) { h ^= c; h *= 1099511628211ull; }
     h = (h ^ (h >> 29)) & v.mask;
-    uint32_t id = 1u;  // VOCAB_UNK
+    uint32_t id = unknown_id;  // VOCAB_UNK (1) for the vocabulary; "no such real token" for the real-token table
     for (;;) {
       const ulonglong2 e = v.entry[h];
       if (e.x == ~0ull) break;

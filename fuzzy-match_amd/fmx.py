@@ -23,9 +23,9 @@ ARRAYS = {
     "itok_ids": (9, np.uint32), "itok_dist": (10, np.uint16), "suf_sig": (11, np.uint64), "suf_key": (12, np.dtype([("t", np.uint32, 8)])),
     "gram": (13, np.dtype([("w1", np.uint32), ("w2", np.uint32), ("lo", np.uint32), ("cnt", np.uint32)])),
     "suf_b": (15, np.dtype([("off", np.uint32), ("rem", np.uint16), ("slen", np.uint16), ("prev", np.uint32), ("sid", np.uint32)])),
-    # 128-byte buckets of the 5-gram table (fmx_core.hh: G5Bucket): three 40-byte entries + {entries in use | lcp bits, overflow flag}
+    # 128-byte buckets of the 5-gram table (fmx_core.hh: G5Bucket): three 40-byte entries + the directory {tags 0, 1 | tag 2, state}
     "gram5": (14, np.dtype([("e", np.dtype([("w", np.uint32, 4), ("lo", np.uint32), ("cnt", np.uint32), ("t", np.uint32, 4)]), 3),
-                            ("used", np.uint32), ("over", np.uint32)])),
+                            ("dir_a", np.uint32), ("dir_b", np.uint32)])),
     "gram7": (16, np.dtype([("w1", np.uint32), ("w2", np.uint32), ("lo", np.uint32), ("cnt", np.uint32)])),
 }
 
@@ -55,7 +55,8 @@ class Batch(C.Structure):
 
 class TextBatch(C.Structure):
     """fmx_text_batch: patterns as NUL-terminated token spellings back to back."""
-    _fields_ = [("nq", C.c_uint64), ("q_off", C.c_void_p), ("text", C.c_void_p), ("n_bytes", C.c_uint64)]
+    _fields_ = [("nq", C.c_uint64), ("q_off", C.c_void_p), ("text", C.c_void_p), ("n_bytes", C.c_uint64),
+                ("real_text", C.c_void_p), ("n_real_bytes", C.c_uint64), ("n_itoks", C.c_uint64), ("itok_slot", C.c_void_p), ("itok_id", C.c_void_p)]
 
 
 class Stats(C.Structure):
@@ -483,7 +484,7 @@ class Index:
         res = (out[:nq], cnt[:nq], tot[:nq])
         return res + (st,) if want_stats else res
 
-    def match_batch_text(self, params, q_off, text, cap=None, want_stats=False, out=None, keep=None):
+    def match_batch_text(self, params, q_off, text, cap=None, want_stats=False, out=None, keep=None, real_text=None, itoks=None):
         """fmx_match_batch_text: the patterns as token spellings (uint8 array: NUL-terminated spellings back to back, q_off in
         tokens); the vocabulary ids are looked up on the device."""
         q_off = np.ascontiguousarray(q_off, dtype=np.uint32)
@@ -498,7 +499,14 @@ class Index:
             out = np.zeros((max(nq, 1), cap), dtype=MATCH_DTYPE)
             cnt = np.zeros(max(nq, 1), dtype=np.uint32)
             tot = np.zeros(max(nq, 1), dtype=np.uint32)
-        b = TextBatch(nq, _ptr(q_off), _ptr(text), len(text))
+        b = TextBatch(nq, _ptr(q_off), _ptr(text), len(text), None, 0, 0, None, None)
+        if real_text is not None:   # the real tokens as a second stream of spellings
+            real_text = np.ascontiguousarray(real_text, dtype=np.uint8)
+            b.real_text, b.n_real_bytes = _ptr(real_text), len(real_text)
+        if itoks is not None:       # (slots, interned ids) of the batch's penalty tokens
+            i_slot = np.ascontiguousarray(itoks[0], dtype=np.uint64)
+            i_id = np.ascontiguousarray(itoks[1], dtype=np.uint32)
+            b.n_itoks, b.itok_slot, b.itok_id = len(i_slot), _ptr(i_slot), _ptr(i_id)
         st = Stats()
         if keep is not None:  # (device pointers: records, counts) also left in HBM for a collective that follows
             _check(lib().fmx_match_batch_text_keep(self.h, C.byref(params), C.byref(b), _ptr(out), _ptr(cnt), _ptr(tot), cap,

@@ -193,7 +193,7 @@ typedef enum fmx_array {
   FMX_A_SUF_SIG = 11,  /* 8 B x n_suffixes    min(sentence length, 255) << 56 | 56-bit word signature of the sentence (derived) */
   FMX_A_SUF_KEY = 12,  /* 32 B x n_suffixes   the eight tokens after the suffix's first token (derived) */
   FMX_A_GRAM = 13,     /* 16 B x 2^k          trigram -> suffix range hash table {w1, w2, lo, cnt} (derived) */
-  FMX_A_GRAM5 = 14,    /* 128 B x n_buckets   5-gram buckets: three entries {w1..w4, lo, cnt, tokens 5..8 of suffix lo} + {used | lcp bits, overflow flag} (derived) */
+  FMX_A_GRAM5 = 14,    /* 128 B x n_buckets   5-gram buckets: three entries {w1..w4, lo, cnt, tokens 5..8 of suffix lo} + directory {16-bit tags, entries in use, overflow flag, lcp per entry} (derived) */
   FMX_A_SUF_B = 15,    /* 16 B x n_suffixes   {u32 off; u16 rem; u16 slen; u32 previous token; u32 sentence id} (derived) */
   FMX_A_GRAM7 = 16     /* 16 B x 2^k          7-gram table of the heavy 5-grams {w5, w6, lo, cnt} (derived) */
 } fmx_array;
@@ -233,14 +233,29 @@ int fmx_match_batch_keep(fmx_index*, const fmx_params*, const fmx_batch* host_ba
  * spellings back to back in `text` (n_bytes bytes; pinned memory for asynchronous copies), q_off[0] == 0.  The per-pattern
  * host prep of match() — VocabIndexer::getIndex per token, src/fuzzy_match.cc:468-470, src/vocab_indexer.cc:52-60 — runs on
  * the device (k_vocab_lookup: token starts by a scan over the bytes, one look-up per start in the device copy of the spelling
- * table; unknown spellings are VOCAB_UNK).  For indexes whose real tokens equal their normalised tokens (no penalty tokens,
- * no case / joiner features): otherwise FMX_E_UNSUPPORTED — use fmx_vocab_lookup_mt + fmx_match_batch.  FMX_E_INVALID when
- * the text does not hold exactly q_off[nq] spellings. */
+ * table; unknown spellings are VOCAB_UNK).  FMX_E_INVALID when a text does not hold exactly q_off[nq] spellings.
+ * Indexes whose real tokens differ from their normalised tokens (the reference CLI's default -p nbr,tag,cas: a word's real
+ * token is its case feature, a number's its digits, src/fuzzy_match.cc:123-192) get the `real` Sentence of
+ * match(const Sentence&, const Tokens&, ...) the same way:
+ *   real_text   q_off[nq] spellings, the real token of every pattern token (what _tokenize_and_normalize put into `real`);
+ *               interned on the device against the index's real-token table (a spelling the index never saw differs from
+ *               every indexed one, like on the host).  NULL: the pattern tokens' own spellings — match(const Tokens&, ...),
+ *               whose real sentence is the pattern itself (src/fuzzy_match.cc:402-416).  An empty real token cannot be
+ *               written as a spelling: such patterns go through fmx_match_batch.
+ *   itok_slot / itok_id   the batch's penalty tokens (Sentence::set_itok) as n_itoks pairs: slot = q_off[q] + q + j for the
+ *               string in front of real token j of pattern q (the layout of fmx_batch::q_itok), id = fmx_index_intern_itok of
+ *               the string (interning stays on the host: a new string grows the distance table there).
+ * All three are ignored by an index without real tokens. */
 typedef struct fmx_text_batch {
   uint64_t        nq;
   const uint32_t* q_off;    /* nq + 1 offsets in tokens */
   const char*     text;
   uint64_t        n_bytes;
+  const char*     real_text;      /* optional, see above */
+  uint64_t        n_real_bytes;
+  uint64_t        n_itoks;        /* optional */
+  const uint64_t* itok_slot;
+  const uint32_t* itok_id;
 } fmx_text_batch;
 int fmx_match_batch_text(fmx_index*, const fmx_params*, const fmx_text_batch*, fmx_match* out, uint32_t* out_count,
                          uint32_t* out_total, uint32_t cap, fmx_stats* stats);

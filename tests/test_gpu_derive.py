@@ -18,39 +18,57 @@ def _entries(tab):
     return np.sort(live, order=["lo", "cnt", "w1", "w2"])
 
 
+def _bucket_fields(tab):
+    used = (tab["dir_b"] >> 16) & 3
+    over = (tab["dir_b"] >> 18) & 1
+    tags = np.stack([tab["dir_a"] & 0xffff, tab["dir_a"] >> 16, tab["dir_b"] & 0xffff], axis=1)
+    lcp = np.stack([(tab["dir_b"] >> (20 + 3 * k)) & 7 for k in range(3)], axis=1)
+    return used, over, tags, lcp
+
+
 def _bucket_entries(tab):
-    """Live entries of the 5-gram buckets as sorted rows (w1..w4, lo, cnt, t5..t8, lcp)."""
+    """Live entries of the 5-gram buckets as sorted rows (w1..w4, lo, cnt, t5..t8, lcp, tag)."""
     if len(tab) == 0:
-        return np.zeros((0, 11), np.uint32)
-    used = np.minimum(tab["used"] & 0xffff, 3)
+        return np.zeros((0, 12), np.uint32)
+    used, _, tags, lcp = _bucket_fields(tab)
     rows = []
     for k in range(3):
         sel = used > k
         e = tab["e"][sel, k]
-        lcp = (tab["used"][sel] >> (16 + 4 * k)) & 15
-        rows.append(np.column_stack([e["w"], e["lo"], e["cnt"], e["t"], lcp]).astype(np.uint32))
-    rows = np.concatenate(rows) if rows else np.zeros((0, 11), np.uint32)
+        rows.append(np.column_stack([e["w"], e["lo"], e["cnt"], e["t"], lcp[sel, k], tags[sel, k]]).astype(np.uint32))
+    rows = np.concatenate(rows) if rows else np.zeros((0, 12), np.uint32)
     return rows[np.lexsort(rows.T[::-1])]
 
 
 def _check_buckets_searchable(ix, tab, label):
     """Every entry sits in its home bucket or in a later one with every bucket from home up to it flagged `over` (what a lookup
-    follows); lcp = tokens 5..8 shared by the group's first and last suffix."""
+    follows); lcp = tokens 5..8 shared by the group's first and last suffix; unused tag slots are zero."""
     nb = len(tab)
     key, rec, buf = ix.array("suf_key")["t"], ix.array("suf_rec"), ix.array("buffer")
     off = (rec & np.uint64(0xffffffff)).astype(np.int64)
-    used = np.minimum(tab["used"] & 0xffff, 3)
+    used, over, tags, lcps = _bucket_fields(tab)
     M32 = np.uint64(0xffffffff)
 
+    def mul(a, c):
+        return (a * np.uint64(c)) & M32
+
     def h5(w0, w):
-        def mul(a, c): return (a * np.uint64(c)) & M32
         h = mul(w0.astype(np.uint64), 0x9E3779B1)
         for (sh, c, col) in ((15, 0x85EBCA6B, 0), (13, 0xC2B2AE35, 1), (16, 0x27D4EB2F, 2), (15, 0x165667B1, 3)):
             h = ((h ^ (h >> np.uint64(sh))) + mul(w[:, col].astype(np.uint64), c)) & M32
         h ^= h >> np.uint64(16); h = mul(h, 0x7FEB352D); h ^= h >> np.uint64(15)
         return h
 
+    def tag5(w0, w):
+        h = mul(w[:, 3].astype(np.uint64), 0x9E3779B1)
+        for (sh, c, col) in ((13, 0xC2B2AE35, 2), (15, 0x27D4EB2F, 1), (16, 0x165667B1, 0)):
+            h = ((h ^ (h >> np.uint64(sh))) + mul(w[:, col].astype(np.uint64), c)) & M32
+        h = ((h ^ (h >> np.uint64(13))) + mul(w0.astype(np.uint64), 0x85EBCA6B)) & M32
+        h ^= h >> np.uint64(15); h = mul(h, 0x846CA68B)
+        return h >> np.uint64(16)
+
     for k in range(3):
+        assert np.all(tags[used <= k, k] == 0) and np.all(lcps[used <= k, k] == 0), label
         at = np.nonzero(used > k)[0]
         if not len(at):
             continue
@@ -60,13 +78,15 @@ def _check_buckets_searchable(ix, tab, label):
         first, last = key[lo][:, 4:], key[lo + cnt - 1][:, 4:]
         eq = first == last
         lcp = np.where(eq.all(axis=1), 4, np.argmin(eq, axis=1))
-        assert np.array_equal(lcp, (tab["used"][at] >> (16 + 4 * k)) & 15), label
-        home = ((h5(buf[off[lo]], e["w"]) * np.uint64(nb)) >> np.uint64(32)).astype(np.int64)
+        assert np.array_equal(lcp, lcps[at, k]), label
+        w0 = buf[off[lo]]
+        assert np.array_equal(tag5(w0, e["w"]), tags[at, k].astype(np.uint64)), label
+        home = ((h5(w0, e["w"]) * np.uint64(nb)) >> np.uint64(32)).astype(np.int64)
         dist = (at - home) % nb
         assert dist.max() < 64, (label, int(dist.max()))
         for d in range(1, int(dist.max()) + 1):       # displaced entries: every bucket they passed is flagged
             far = dist >= d
-            assert np.all(tab["over"][(home[far] + d - 1) % nb] != 0), label
+            assert np.all(over[(home[far] + d - 1) % nb] != 0), label
 
 
 def _to_device_layout(ix, off):

@@ -227,3 +227,82 @@ def test_tm2_gpu_against_reference_outputs_and_oracle(fmx, gpu_device):
             assert ref.tobytes() == go[qi, :gc[qi]].tobytes(), (kw, qi, sample[qi], ref, go[qi, :gc[qi]])
             n_rec += len(ref)
         assert n_rec > 250, (kw, n_rec)
+
+
+def _text_batch_args(toks, q_off, ix):
+    """A batch as the tokenizer front-end holds it: packed normalised spellings, packed real spellings, (slot, id) penalty tokens."""
+    pack = lambda words: np.frombuffer(b"".join(w.encode("utf-8") + b"\0" for w in words), dtype=np.uint8).copy()
+    norm = pack([w for t in toks for w in t["norm"]])
+    real = pack([w for t in toks for w in t["real"]])
+    slots, ids = [], []
+    for qi, t in enumerate(toks):
+        for k, v in t["itoks"].items():
+            slots.append(int(q_off[qi]) + qi + k)
+            ids.append(ix.intern_itok(v))
+    return norm, real, (np.asarray(slots, np.uint64), np.asarray(ids, np.uint32))
+
+
+@pytest.mark.gpu
+def test_text_batches_on_an_index_with_real_tokens(fmx, gpu_device):
+    """fmx_match_batch_text on the reference CLI's default configuration (-p nbr,tag,cas: a word's real token is its case feature,
+    a number's its digits): the real tokens arrive as a second stream of spellings and are interned ON THE DEVICE against the
+    index's real-token table, penalty tokens as (slot, id) pairs.  tm2 (20 000 Europarl sentences): the reference's 100 queries
+    and 2 000 of the memory's own sentences through the text batch == the id batch (which the test above pins to the oracle and
+    to the reference's printed scores); then the same without the real stream == the id batch with the pattern's own spellings
+    as real tokens (match(const Tokens&, ...)); tm1 under pct / jnr for penalty tokens in quantity."""
+    en, fr = tm2_lines()
+    pt = PT["tag"] | PT["nbr"] | PT["cas"]
+    ix, ids = _gpu_index(fmx, gpu_device, pt, en, [f"{i + 1}={fr[i]}" for i in range(len(en))])
+    assert ix.info().real_differs
+    cases = read_cases("test-tm2") + [{"text": en[i]} for i in range(0, 20000, 10)] + [{"text": "Résumé 2024 ｟it＃1｠ of the Commission 12 May"}]
+    toks, q_off, q_tok, q_real, q_itok = _gpu_batch(fmx, ix, pt, cases)
+    keep = [qi for qi, t in enumerate(toks) if t["norm"] and all(r != "" for r in t["real"])]
+    assert len(keep) > 2000
+    toks = [toks[qi] for qi in keep]
+    q_off = np.zeros(len(toks) + 1, np.uint32)
+    q_off[1:] = np.cumsum([len(t["norm"]) for t in toks])
+    q_tok = np.concatenate([ix.vocab_lookup(t["norm"]) for t in toks]).astype(np.uint32)
+    q_real = np.asarray([ix.lookup_real(r) for t in toks for r in t["real"]], np.uint32)
+    q_itok = np.zeros(int(q_off[-1]) + len(toks), np.uint32)
+    for qi, t in enumerate(toks):
+        for k, v in t["itoks"].items():
+            q_itok[int(q_off[qi]) + qi + k] = ix.intern_itok(v)
+    norm, real, itoks = _text_batch_args(toks, q_off, ix)
+    assert len(itoks[0]) >= 1
+    n_rec = 0
+    for kw in [dict(fuzzy=0.5, nmatch=2, no_perfect=True), dict(fuzzy=0.6, nmatch=5), dict(fuzzy=0.5, nmatch=3, idf_penalty=0.5)]:
+        want = ix.match_batch(fmx.Params(**kw), q_off, q_tok, q_real=q_real, q_itok=q_itok, cap=5)
+        got = ix.match_batch_text(fmx.Params(**kw), q_off, norm, cap=5, real_text=real, itoks=itoks)
+        assert np.array_equal(want[1], got[1]), kw
+        for q in range(len(toks)):
+            assert want[0][q, :want[1][q]].tobytes() == got[0][q, :got[1][q]].tobytes(), (kw, q, toks[q])
+        n_rec += int(want[1].sum())
+        # without the real stream: the pattern's own spellings are its real tokens (Tokens API)
+        own = np.asarray([ix.lookup_real(w) for t in toks for w in t["norm"]], np.uint32)
+        want = ix.match_batch(fmx.Params(**kw), q_off, q_tok, q_real=own, cap=5)
+        got = ix.match_batch_text(fmx.Params(**kw), q_off, norm, cap=5)
+        assert np.array_equal(want[1], got[1]), kw
+        for q in range(len(toks)):
+            assert want[0][q, :want[1][q]].tobytes() == got[0][q, :got[1][q]].tobytes(), ("own spellings", kw, q)
+    assert n_rec > 3000
+    # a real stream with the wrong number of spellings is refused
+    with pytest.raises(Exception):
+        ix.match_batch_text(fmx.Params(fuzzy=0.5), q_off, norm, cap=5, real_text=real[:-3])
+    # penalty tokens in quantity: tm1 under pct (punctuation) and jnr (joiners)
+    lines = tm1_lines()
+    for pt2, fixture in ((PT["pct"] | PT["nbr"] | PT["cas"], "test-tm1-pct"), (PT["tag"] | PT["jnr"] | PT["cas"] | PT["nbr"], "test-tm1-jnr")):
+        ix2, _ = _gpu_index(fmx, gpu_device, pt2, lines, [f"{i + 1}={ln}" for i, ln in enumerate(lines)])
+        cs = [c for c in read_cases(fixture)]
+        tk, off2, tok2, real2, itok2 = _gpu_batch(fmx, ix2, pt2, cs)
+        if any(r == "" for t in tk for r in t["real"]) or any(not t["norm"] for t in tk):
+            sel = [qi for qi, t in enumerate(tk) if t["norm"] and all(r != "" for r in t["real"])]
+            cs = [cs[qi] for qi in sel]
+            tk, off2, tok2, real2, itok2 = _gpu_batch(fmx, ix2, pt2, cs)
+        n2, r2, it2 = _text_batch_args(tk, off2, ix2)
+        assert len(it2[0]) > 0
+        prm = fmx.Params(fuzzy=0.4, nmatch=8, min_subseq_length=2, min_subseq_ratio=0)
+        want = ix2.match_batch(prm, off2, tok2, q_real=real2, q_itok=itok2, cap=8)
+        got = ix2.match_batch_text(prm, off2, n2, cap=8, real_text=r2, itoks=it2)
+        assert np.array_equal(want[1], got[1]) and int(want[1].sum()) > 0, fixture
+        for q in range(len(tk)):
+            assert want[0][q, :want[1][q]].tobytes() == got[0][q, :got[1][q]].tobytes(), (fixture, q)
