@@ -500,6 +500,23 @@ int fmx_match_batch_text_keep(fmx_index* ix, const fmx_params* params, const fmx
   });
 }
 
+int fmx_match_batch_lines(fmx_index* ix, const fmx_params* params, const char* text, uint64_t n_bytes, uint64_t n_lines,
+                          fmx_match* out, uint32_t* out_count, uint32_t* out_total, uint32_t cap, fmx_stats* stats) {
+  if (!ix || !params || !out || !out_count || (n_bytes && !text)) return fail(FMX_E_INVALID, "null argument");
+  if (cap == 0) return fail(FMX_E_INVALID, "cap must be > 0");
+  if (n_lines > n_bytes) return fail(FMX_E_INVALID, "line batch: more lines than bytes (every line ends with a line feed)");
+  if (n_bytes && text[n_bytes - 1] != '\n') return fail(FMX_E_INVALID, "line batch: the text must end with a line feed");
+  if (!ix->finalized) return fail(FMX_E_STATE, "index is not finalized");
+  if (ix->devs.empty()) return fail(FMX_E_NO_DEVICE, "index is not on a device (fmx_index_to_device); there is no CPU path");
+  return guarded([&]() {
+    Stats st;
+    const size_t k = ix->devs.size() == 1 ? 0 : ix->rr.fetch_add(1) % ix->devs.size();
+    ix->devs[k]->match_lines(ix->host, make_params(ix, params), text, n_bytes, n_lines, (Rec*)out, out_count, out_total, cap, &st);
+    copy_stats(st, stats);
+    return (int)FMX_OK;
+  });
+}
+
 // ---------------------------------------------------------------------------------------------
 // Request coalescer behind fmx_match_one.  The reference's match() is called one pattern at a time from N
 // threads; a GPU pass costs ~45 launches whatever its size, so concurrent requests with equal parameters are

@@ -129,6 +129,10 @@ class DeviceIndex {
   // d_keep / d_keep_count (optional, in the HBM of device()): the records are also left there
   void match_host(const HostIndex& h, const Params& prm, const HostBatchView& b, Rec* out, uint32_t* out_count,
                   uint32_t* out_total, uint32_t cap, Stats* st, Rec* d_keep = nullptr, uint32_t* d_keep_count = nullptr);
+  // pre-tokenised lines as they sit in a file (blank-separated tokens, one pattern per '\n'-terminated line): cut, looked up and
+  // matched on the device
+  void match_lines(const HostIndex& h, const Params& prm, const char* text, uint64_t n_bytes, uint64_t n_lines, Rec* out,
+                   uint32_t* out_count, uint32_t* out_total, uint32_t cap, Stats* st);
   void     set_pair_finish(bool on);     // two queries per wave in the replay / top-N kernel
   void     set_small_path(bool on);      // micro-batches (<= 512 queries) in one kernel launch (fmx_small.hip.hh)
   // FuzzyMatch::subsequence (src/fuzzy_match.cc:250-365) for a batch of tokenised patterns; one record per query

@@ -1762,6 +1762,87 @@ void DeviceIndex::match_host_full(const HostIndex& h, const Params& prm, const H
 }
 
 // ---------------------------------------------------------------------------------------------
+// Pre-tokenised lines (fmx_match_batch_lines): the bytes of a file go to the device as they are; it cuts them into patterns
+// and tokens (fmx_vocab.hip.hh: k_lines_count / k_lines_emit), looks the ids up (k_vocab_lookup) and runs the pipeline on the
+// device-resident CSR.  The host reads back two numbers (tokens found, longest pattern) before the passes are enqueued.
+// ---------------------------------------------------------------------------------------------
+void DeviceIndex::match_lines(const HostIndex& h, const Params& prm, const char* text, uint64_t n_bytes, uint64_t n_lines, Rec* out,
+                              uint32_t* out_count, uint32_t* out_total, uint32_t cap, Stats* st) {
+  Impl& m = *impl_;
+  if (m.device < 0) throw GpuError("index is not on a device");
+  HIP_TRY(hipSetDevice(m.device));
+  const auto t0 = std::chrono::steady_clock::now();
+  if (n_lines == 0) return;
+  if (n_bytes >= 0xfffffff0ull) throw std::invalid_argument("line batch: more than 4 GB of text in one call");
+  refresh_itok_table(m, h);
+  refresh_vocab_table(m, h);
+  const TableSnap text_snap = pin_tables(m);
+  CtxLease lease(m);
+  Ctx& c = *lease.c;
+  const uint64_t tiles = (n_bytes + (uint64_t)kScanThreads * kVocabChunk - 1) / ((uint64_t)kScanThreads * kVocabChunk);
+  const uint64_t tok_cap = n_bytes / 2 + 2;  // a token is at least one byte and its separator
+  c.d_text.ensure(n_bytes + 2 * kVocabChunk + 16);
+  c.d_vstate.ensure(tiles + 4);
+  c.d_vstate_r.ensure(tiles + 4);
+  c.d_qoff.ensure(n_lines + 1);
+  c.d_qtok.ensure(tok_cap);
+  const bool real = m.d.real != nullptr;
+  if (real) c.d_qreal.ensure(tok_cap);
+  c.d_out.ensure(n_lines * cap);
+  c.d_cnt.ensure(n_lines);
+  c.d_tot.ensure(n_lines);
+  if (!c.h_vtotal) HIP_TRY(hipHostMalloc((void**)&c.h_vtotal, 2 * sizeof(unsigned long long), hipHostMallocDefault));
+  c.h_vtotal[0] = c.h_vtotal[1] = ~0ull;
+  unsigned long long* d_total = nullptr;
+  HIP_TRY(hipHostGetDevicePointer((void**)&d_total, c.h_vtotal, 0));
+  hipStream_t s = c.stream;
+  HIP_TRY(hipMemsetAsync(c.d_text.p + n_bytes, 0, 2 * kVocabChunk + 16, s));
+  HIP_TRY(hipMemcpyAsync(c.d_text.p, text, n_bytes, hipMemcpyHostToDevice, s));
+  uint32_t* tile_tok = reinterpret_cast<uint32_t*>(c.d_vstate.p);
+  uint32_t* tile_nl = reinterpret_cast<uint32_t*>(c.d_vstate_r.p);
+  hipLaunchKernelGGL(k_lines_count, dim3((unsigned)tiles), dim3(kScanThreads), 0, s, (const unsigned char*)c.d_text.p, (unsigned long long)n_bytes, tile_tok, tile_nl);
+  hipLaunchKernelGGL(k_vocab_scan, dim3(1), dim3(kScanThreads), 0, s, tile_tok, (uint32_t)tiles, d_total);
+  hipLaunchKernelGGL(k_vocab_scan, dim3(1), dim3(kScanThreads), 0, s, tile_nl, (uint32_t)tiles, d_total + 1);
+  hipLaunchKernelGGL(k_lines_emit, dim3((unsigned)tiles), dim3(kScanThreads), 0, s, c.d_text.p, (unsigned long long)n_bytes, (const uint32_t*)tile_tok,
+                     (const uint32_t*)tile_nl, c.d_qoff.p, (unsigned long long)n_lines);
+  hipLaunchKernelGGL(k_vocab_lookup, dim3((unsigned)tiles), dim3(kScanThreads), 0, s, (const unsigned char*)c.d_text.p, (unsigned long long)n_bytes,
+                     (unsigned long long)tok_cap, text_snap.vocab, c.d_qtok.p, (const uint32_t*)tile_tok, 1u);
+  if (real)  // match(const Tokens&, ...): the pattern's own spellings are its real tokens (src/fuzzy_match.cc:402-416)
+    hipLaunchKernelGGL(k_vocab_lookup, dim3((unsigned)tiles), dim3(kScanThreads), 0, s, (const unsigned char*)c.d_text.p, (unsigned long long)n_bytes,
+                       (unsigned long long)tok_cap, m.real_vocab, c.d_qreal.p, (const uint32_t*)tile_tok, 0x7ffffffeu);
+  HIP_TRY(hipGetLastError());
+  // the passes need the token bounds and the longest pattern: one read-back (every pass boundary + the maximum) and one wait
+  DeviceBatchView bv;
+  bv.nq = n_lines; bv.q_off = c.d_qoff.p; bv.q_tok = c.d_qtok.p; bv.q_real = real ? c.d_qreal.p : nullptr;
+  uint32_t p_max = 0;
+  const std::vector<uint32_t> bounds = sub_bounds_from_device(c.d_qoff.p, n_lines, &p_max, s);
+  if (c.h_vtotal[1] != n_lines)
+    throw std::invalid_argument("line batch: the text holds " + std::to_string(c.h_vtotal[1]) + " line ends, the call names " + std::to_string(n_lines) + " lines");
+  bv.p_max = std::max<uint32_t>(p_max, 1);
+  std::vector<uint64_t> qb;
+  for (uint64_t q = 0; q < n_lines; q += m.sub_queries) qb.push_back(q);
+  qb.push_back(n_lines);
+  uint32_t* const hd_count = pinned_device_ptr(out_count);
+  uint32_t* const hd_total = out_total ? pinned_device_ptr(out_total) : nullptr;
+  const bool export_kernel = hd_count && (!out_total || hd_total);
+  PassHooks hooks;
+  hooks.after = [&](uint32_t sb, hipEvent_t) {  // the records of a finished pass go home (same stream: in order behind its kernels)
+    const uint64_t q0 = qb[sb], q1 = qb[sb + 1], n = q1 - q0;
+    HIP_TRY(hipMemcpyAsync(out + q0 * cap, c.d_out.p + q0 * cap, n * cap * sizeof(Rec), hipMemcpyDeviceToHost, s));
+    if (export_kernel) {
+      hipLaunchKernelGGL(k_export_counts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint32_t*)c.d_cnt.p + q0,
+                         (const uint32_t*)c.d_tot.p + q0, hd_count + q0, hd_total ? hd_total + q0 : nullptr, (uint32_t)n);
+    } else {
+      HIP_TRY(hipMemcpyAsync(out_count + q0, c.d_cnt.p + q0, n * 4, hipMemcpyDeviceToHost, s));
+      if (out_total) HIP_TRY(hipMemcpyAsync(out_total + q0, c.d_tot.p + q0, n * 4, hipMemcpyDeviceToHost, s));
+    }
+  };
+  run_passes(m, c, prm, bv, c.d_out.p, c.d_cnt.p, c.d_tot.p, cap, s, qb, bounds, st, &hooks, true);
+  HIP_TRY(hipStreamSynchronize(s));
+  if (st) st->ms_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// ---------------------------------------------------------------------------------------------
 // FuzzyMatch::subsequence (src/fuzzy_match.cc:250-365) for a batch of tokenised patterns.  The priority queue over the
 // sub-n-grams is host prep (std::priority_queue<Subseq> = std::push_heap / pop_heap; libstdc++'s algorithm is restated
 // so that equal keys pop in the reference's order); ranges, edit distances and the acceptance run on the device.

@@ -151,4 +151,81 @@ __global__ void __launch_bounds__(kScanThreads) k_vocab_lookup(const unsigned ch
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Pre-tokenised LINES as they sit in a file (fmx_match_batch_lines): tokens separated by blanks, one pattern per
+// '\n'-terminated line.  The device cuts them: token starts and line ends per 16 bytes, two scans of the tile counts, then
+// every line end writes the pattern's end offset (q_off[line + 1] = token starts in front of it) and the blanks become
+// terminators in place — what is left is the packed text k_vocab_lookup takes.  The host never looks at a token.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool text_blank(unsigned char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\n' || c == 0; }
+
+// starts: bit i = a token starts at byte b0 + i; nls: bit i = byte b0 + i is '\n'; conv = the 16 bytes with blanks zeroed
+__device__ __forceinline__ void line_masks(const unsigned char* __restrict__ text, unsigned long long b0, unsigned long long n_bytes,
+                                           uint32_t& starts, uint32_t& nls, uint4& conv) {
+  starts = 0; nls = 0; conv = make_uint4(0u, 0u, 0u, 0u);
+  if (b0 >= n_bytes) return;
+  bool prev_blank = b0 ? text_blank(text[b0 - 1]) : true;  // (a neighbour may have zeroed it already: still a blank)
+  const uint4 x = *reinterpret_cast<const uint4*>(text + b0);
+  uint32_t xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+  for (uint32_t k = 0; k < 16; k++) {
+    const unsigned char c = (unsigned char)(xs[k >> 2] >> (8 * (k & 3)));
+    const bool in = b0 + k < n_bytes;
+    const bool bl = text_blank(c) || !in;
+    if (!bl && prev_blank) starts |= 1u << k;
+    if (in && c == '\n') nls |= 1u << k;
+    if (bl) xs[k >> 2] &= ~(0xffu << (8 * (k & 3)));
+    prev_blank = bl;
+  }
+  conv = make_uint4(xs[0], xs[1], xs[2], xs[3]);
+}
+
+static_assert(kVocabChunk == 16, "line_masks handles one 16-byte word per thread");
+
+__global__ void __launch_bounds__(kScanThreads) k_lines_count(const unsigned char* __restrict__ text, unsigned long long n_bytes,
+                                                             uint32_t* __restrict__ tile_tok, uint32_t* __restrict__ tile_nl) {
+  __shared__ uint32_t s_t[kScanThreads / kWave], s_n[kScanThreads / kWave];
+  const unsigned long long b0 = ((unsigned long long)blockIdx.x * kScanThreads + threadIdx.x) * kVocabChunk;
+  uint32_t st, nl;
+  uint4 conv;
+  line_masks(text, b0, n_bytes, st, nl, conv);
+  const uint32_t a = wave_sum((uint32_t)__popc(st)), b = wave_sum((uint32_t)__popc(nl));
+  if ((threadIdx.x & 63) == 0) { s_t[threadIdx.x >> 6] = a; s_n[threadIdx.x >> 6] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t t = 0, n = 0;
+    for (uint32_t k = 0; k < kScanThreads / kWave; k++) { t += s_t[k]; n += s_n[k]; }
+    tile_tok[blockIdx.x] = t;
+    tile_nl[blockIdx.x] = n;
+  }
+}
+
+// tile_tok / tile_nl: exclusive scans of the tile counts.  q_off: n_lines + 1 entries.
+__global__ void __launch_bounds__(kScanThreads) k_lines_emit(unsigned char* __restrict__ text, unsigned long long n_bytes,
+                                                            const uint32_t* __restrict__ tile_tok, const uint32_t* __restrict__ tile_nl,
+                                                            uint32_t* __restrict__ q_off, unsigned long long n_lines) {
+  __shared__ uint32_t s_t[kScanThreads / kWave], s_n[kScanThreads / kWave];
+  const unsigned long long b0 = ((unsigned long long)blockIdx.x * kScanThreads + threadIdx.x) * kVocabChunk;
+  uint32_t st, nl;
+  uint4 conv;
+  line_masks(text, b0, n_bytes, st, nl, conv);
+  const uint32_t ct = (uint32_t)__popc(st), cn = (uint32_t)__popc(nl);
+  const uint32_t it = wave_incl_scan(ct), in = wave_incl_scan(cn);
+  if ((threadIdx.x & 63) == 63) { s_t[threadIdx.x >> 6] = it; s_n[threadIdx.x >> 6] = in; }
+  __syncthreads();
+  uint32_t bt = 0, bn = 0;
+  for (uint32_t k = 0; k < (threadIdx.x >> 6); k++) { bt += s_t[k]; bn += s_n[k]; }
+  const unsigned long long tok0 = (unsigned long long)tile_tok[blockIdx.x] + bt + it - ct;  // token starts in front of this thread's bytes
+  unsigned long long line = (unsigned long long)tile_nl[blockIdx.x] + bn + in - cn;         // line ends in front of them
+  if (blockIdx.x == 0 && threadIdx.x == 0) q_off[0] = 0u;
+  uint32_t m = nl;
+  while (m) {
+    const uint32_t i = (uint32_t)__builtin_ctz(m);
+    m &= m - 1u;
+    if (line < n_lines) q_off[line + 1] = (uint32_t)(tok0 + __popc(st & ((1u << i) - 1u)));
+    line++;
+  }
+  if (b0 < n_bytes) *reinterpret_cast<uint4*>(text + b0) = conv;  // blanks -> terminators (bytes beyond n_bytes are zero already)
+}
+
 }  // namespace fmx

@@ -82,7 +82,7 @@ EXPORTS = [
     "fmx_index_free", "fmx_index_load", "fmx_index_save", "fmx_index_add_tm", "fmx_index_add_ids",
     "fmx_index_sort", "fmx_index_finalize", "fmx_index_to_device", "fmx_vocab_lookup",
     "fmx_index_lookup_real", "fmx_index_intern_itok", "fmx_index_sentence_id", "fmx_index_array",
-    "fmx_index_get_info", "fmx_match_batch", "fmx_match_batch_text", "fmx_match_batch_text_keep", "fmx_match_batch_device", "fmx_set_option",
+    "fmx_index_get_info", "fmx_match_batch", "fmx_match_batch_text", "fmx_match_batch_text_keep", "fmx_match_batch_lines", "fmx_match_batch_device", "fmx_set_option",
     "fmx_host_alloc", "fmx_host_free", "fmx_index_to_devices", "fmx_set_devices", "fmx_index_reopen", "fmx_match_one", "fmx_match_batch_keep",
     "fmx_subsequence_batch", "fmx_text_tokenize", "fmx_text_free", "fmx_text_num_tokens", "fmx_text_norm", "fmx_text_real",
     "fmx_text_num_itoks", "fmx_text_itok_index", "fmx_text_itok", "fmx_text_num_raw", "fmx_text_raw", "fmx_text_map",
@@ -514,6 +514,21 @@ class Index:
         else:
             _check(lib().fmx_match_batch_text(self.h, C.byref(params), C.byref(b), _ptr(out), _ptr(cnt), _ptr(tot), cap, C.byref(st)))
         res = (out[:nq], cnt[:nq], tot[:nq])
+        return res + (st,) if want_stats else res
+
+    def match_batch_lines(self, params, text, n_lines, cap=None, want_stats=False):
+        """fmx_match_batch_lines: pre-tokenised lines (bytes / uint8 array: blank-separated tokens, every line ended by a line feed)."""
+        text = np.frombuffer(text, dtype=np.uint8) if isinstance(text, (bytes, bytearray)) else np.ascontiguousarray(text, dtype=np.uint8)
+        if cap is None:
+            cap = params.nmatch if params.nmatch > 0 else 64
+        out = np.zeros((max(n_lines, 1), cap), dtype=MATCH_DTYPE)
+        cnt = np.zeros(max(n_lines, 1), dtype=np.uint32)
+        tot = np.zeros(max(n_lines, 1), dtype=np.uint32)
+        st = Stats()
+        lib().fmx_match_batch_lines.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p,
+                                                C.c_void_p, C.c_uint32, C.POINTER(Stats)]
+        _check(lib().fmx_match_batch_lines(self.h, C.byref(params), _ptr(text), len(text), n_lines, _ptr(out), _ptr(cnt), _ptr(tot), cap, C.byref(st)))
+        res = (out[:n_lines], cnt[:n_lines], tot[:n_lines])
         return res + (st,) if want_stats else res
 
     def subsequence_batch(self, q_off, q_tok, nmatch, no_perfect=False, min_subseq_length=3, min_subseq_ratio=0.3,

@@ -262,6 +262,16 @@ int fmx_match_batch_text(fmx_index*, const fmx_params*, const fmx_text_batch*, f
 /* fmx_match_batch_text that also leaves the records (and counts) in device memory, like fmx_match_batch_keep */
 int fmx_match_batch_text_keep(fmx_index*, const fmx_params*, const fmx_text_batch*, fmx_match* out, uint32_t* out_count,
                               uint32_t* out_total, uint32_t cap, fmx_match* d_keep, uint32_t* d_keep_count, fmx_stats* stats);
+/* fmx_match_batch for PRE-TOKENISED LINES as they sit in a file: `text` = n_bytes bytes, tokens separated by blanks (' ', '\t',
+ * '\r'), one pattern per line, EVERY line ended by '\n' (n_lines of them; an empty line is an empty pattern: no match).  The host
+ * does not look at a token: the bytes cross PCIe as they are (pinned memory for asynchronous copies), the device cuts them into
+ * patterns and tokens, looks the vocabulary ids up (k_lines_count / k_lines_emit / k_vocab_lookup) and matches — the reference
+ * CLI's read -> tokens -> getIndex -> match() per line (cli/src/FuzzyMatch-cli.cc:112-193, src/fuzzy_match.cc:468-470) for input
+ * that is tokenised already.  On an index with real tokens the pattern's own spellings are its real tokens
+ * (match(const Tokens&, ...)).  Records: like fmx_match_batch, one row of `cap` per line.  FMX_E_INVALID when the text does not
+ * hold exactly n_lines line feeds. */
+int fmx_match_batch_lines(fmx_index*, const fmx_params*, const char* text, uint64_t n_bytes, uint64_t n_lines,
+                          fmx_match* out, uint32_t* out_count, uint32_t* out_total, uint32_t cap, fmx_stats* stats);
 /* Same with every buffer already in the HBM of the index's device; `stream` is a hipStream_t
  * (NULL = a stream of the library after a device-wide synchronisation).  total_tokens = q_off[nq] when q_off[0] == 0, else
  * 0 (with it and max_len set, a batch of one pass needs no device read up front; the value is CHECKED on the device against
