@@ -506,6 +506,14 @@ def main():
         for wl in str_set:
             wl.tok_ptrs = None
 
+    # ---- the drop-in CLI end to end on the same workload: stdin -> stdout through tools/fmx-cli --tokenised ----
+    cli_leg = None
+    if world == 1 and not args.no_text_leg:
+        try:
+            cli_leg = cli_end_to_end(ix, host_set[0], pkw, log)
+        except Exception as e:  # noqa: BLE001  (a side leg: the line is still worth printing)
+            log(f"[bench] cli_end_to_end leg failed: {e!r}")
+
     # ---- one call at a time from HBM (device entry point with statistics): stage times for the rooflines ----
     run_device_steps(main_set, 1)
     el_dev, dev_stats = timed(lambda k: run_device_steps(main_set, k), args.steps)
@@ -728,7 +736,7 @@ def main():
             "pcie_inclusive_ids": {"value": round(value_ids, 1), "ms_per_step": round(elapsed_ids / args.steps * 1e3, 3), "calls_in_flight": T_host,
                                    "note": "fmx_match_batch: vocabulary ids in pinned host memory in, records out (H2D + kernels + D2H"
                                            + (" + the RCCL gather" if world > 1 else "") + "): a caller that already holds ids"},
-            "from_token_strings": from_strings,
+            "from_token_strings": from_strings, "cli_end_to_end": cli_leg,
             "staged": {"value": round(nq_step_all * args.steps / el_dev, 1),
                        "ms_per_step": round(el_dev / args.steps * 1e3, 3),
                        "stage_ms_per_step": {k: round(v, 4) for k, v in per_stage.items()},
@@ -741,6 +749,51 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def cli_end_to_end(ix, wl, pkw, log):
+    """The drop-in CLI (tools/fmx-cli: the reference CLI's flags, output and stderr lines, cli/src/FuzzyMatch-cli.cc) on this run's
+    own index and first query batch, the way the reference's CI runs it: `-i index.fmi -a match < queries > matches`.  The index goes
+    through a .fmi file, the queries are a text file of blank-separated tokens.  Reported: patterns / second of the phase the
+    reference brackets with TICK("Matching") .. TICK("Done") (cli:450-467: read, match, format, print), from the CLI's own STEP
+    lines; the index load is outside, as it is there."""
+    cli = os.path.join(ROOT, "tools", "fmx-cli")
+    if not os.path.exists(cli):
+        return None
+    tmp = tempfile.mkdtemp(prefix="fmx_cli_", dir=os.environ.get("TMPDIR", "/tmp"))
+    try:
+        fmi, qf, of = os.path.join(tmp, "index.fmi"), os.path.join(tmp, "queries.tok"), os.path.join(tmp, "matches.tsv")
+        ix.save(fmi)
+        lines = np.array(wl.text, dtype=np.uint8, copy=True)        # packed spellings -> one line of blank-separated tokens per pattern
+        nul = np.flatnonzero(lines == 0)
+        lines[nul] = 32
+        lines[nul[wl.q_off[1:].astype(np.int64) - 1]] = 10
+        lines.tofile(qf)
+        argv = [cli, "--tokenised", "-i", fmi, "-a", "match", "-f", str(pkw.get("fuzzy", 0.8)), "-n", str(pkw.get("nmatch", 5)),
+                "--mr", str(pkw.get("min_subseq_ratio", 0.3)), "-I", str(pkw.get("idf_penalty", 0.0)), "--contrast", str(pkw.get("contrast", 0.0)),
+                "--contrast-buffer", str(pkw.get("contrast_buffer", -1))]
+        t0 = time.time()
+        r = subprocess.run(argv, stdin=open(qf, "rb"), stdout=open(of, "wb"), stderr=subprocess.PIPE, text=True, timeout=600)
+        wall = time.time() - t0
+        if r.returncode != 0:
+            raise RuntimeError(r.stderr[-500:])
+        steps = {}
+        for ln in r.stderr.splitlines():
+            f = ln.split("\t")
+            if len(f) >= 6 and f[0] == "STEP":
+                steps[f[1]] = float(f[5])
+        nmatch = [ln for ln in r.stderr.splitlines() if ln.startswith("NMATCH")]
+        phase = steps["Done"] - steps["Matching"]
+        out_bytes = os.path.getsize(of)
+        log(f"[bench] fmx-cli --tokenised: {wl.nq} patterns in {phase * 1e3:.0f} ms of matching phase = {wl.nq / phase / 1e6:.2f} M patterns/s "
+            f"(process wall {wall:.1f}s with the index load); {nmatch[-1] if nmatch else ''}")
+        return {"value": round(wl.nq / phase, 1), "unit": "patterns/s", "patterns": int(wl.nq), "matching_phase_s": round(phase, 4),
+                "process_wall_s": round(wall, 2), "input_bytes": int(lines.nbytes), "output_bytes": int(out_bytes), "nmatch_line": nmatch[-1] if nmatch else None,
+                "note": "tools/fmx-cli --tokenised -i index.fmi -a match < queries > matches: stdin -> fmx_match_batch_lines (the device cuts the lines "
+                        "into patterns and tokens and looks the ids up) -> formatted records on stdout, in input order; time between the CLI's own "
+                        "'Matching' and 'Done' STEP lines"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def through_fmi(fmx, ix, device, rank, log):

@@ -875,9 +875,6 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
     // two queries per wave in the last kernel (k_finish_pair): no contrastive rerank, lowest_costs fits half a wave
     // (with or without a contrastive factor; any contrast_buffer: beyond 30 entries the pair kernel takes 31 candidates per query)
     const bool pair_finish = m.pair_finish && prm.cbuf > 0;
-    // the exact coverage test moves into the edit-distance kernel when that is the bit-parallel one (k_expand_b: defer_cover)
-    static const bool defer_on = [] { const char* e = getenv("FMX_DEFER_COVER"); return e ? atoi(e) != 0 : true; }();  // design-time switch
-    const uint32_t defer_cover = (defer_on && !full && !use_idf && prm.ins == prm.del && prm.del == prm.rep && prm.rep >= 0.f) ? 1u : 0u;
     const uint32_t pair_max = prm.cbuf <= (int)kPairMax - 2 ? kPairMax : kPairMax - 1;
     {
       // capacities, one scan over two arrays (queue offsets of the queries phase A walks, segment offsets of the light queries)
@@ -922,10 +919,10 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
         side_tick(kStageExpandB, 0);
         second_scan(side);
         hipLaunchKernelGGL(k_expand_b<false>, dim3((light_max ? 0u : b.nq) + grid_b), dim3(kWave), lds, side, E.d, b, w, prm,
-                           (const WorkItem*)c.items_b.p, item_cap, light_max ? 0u : b.nq, defer_cover);
+                           (const WorkItem*)c.items_b.p, item_cap, light_max ? 0u : b.nq);
         side_tick(kStageExpandB, 1);
         if (light_max)
-          hipLaunchKernelGGL(k_expand_b<true>, dim3(b.nq), dim3(kWave), lds, stream, E.d, b, w, prm, (const WorkItem*)nullptr, 0u, b.nq, defer_cover);
+          hipLaunchKernelGGL(k_expand_b<true>, dim3(b.nq), dim3(kWave), lds, stream, E.d, b, w, prm, (const WorkItem*)nullptr, 0u, b.nq);
         tick(); tick();
       } else {
         // long ranges first (k_expand_h next to k_expand_a), then the two k_expand_b side by side: the one for the queries
@@ -938,11 +935,11 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
         fork();
         side_tick(kStageExpandB, 0);
         hipLaunchKernelGGL(k_expand_b<false>, dim3((light_max ? 0u : b.nq) + grid_b), dim3(kWave), lds, side, E.d, b, w, prm,
-                           (const WorkItem*)c.items_b.p, item_cap, light_max ? 0u : b.nq, defer_cover);
+                           (const WorkItem*)c.items_b.p, item_cap, light_max ? 0u : b.nq);
         side_tick(kStageExpandB, 1);
         if (light_max) {
           if (!m.serial) hipLaunchKernelGGL(k_lag, dim3(1), dim3(kWave), 0, stream, w.counters);
-          hipLaunchKernelGGL(k_expand_b<true>, dim3(b.nq), dim3(kWave), lds, stream, E.d, b, w, prm, (const WorkItem*)nullptr, 0u, b.nq, defer_cover);
+          hipLaunchKernelGGL(k_expand_b<true>, dim3(b.nq), dim3(kWave), lds, stream, E.d, b, w, prm, (const WorkItem*)nullptr, 0u, b.nq);
         }
         tick(); tick();
       }

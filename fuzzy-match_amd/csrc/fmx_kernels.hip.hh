@@ -1322,16 +1322,16 @@ __global__ void __launch_bounds__(kScanThreads) k_seg_scan(DevBatch b, DevWork w
 // query q (k_caps_scan); the length filter of phase A (the tabulated threshold of the sentence length) is applied here, the
 // signature bound is skipped (the exact coverage test decides).  !LIGHT: blocks [0, first_q_blocks) take chunk 0 of
 // query blockIdx.x, the others loop over the work-item list.
-// defer_cover (round 4): the exact coverage test of patterns of up to 64 tokens is left to the edit-distance kernel, where it is
-// a by-product — count_covered_words (src/pattern_coverage.cc:15-28) = the pattern positions whose word occurs in the sentence =
-// popcount of the OR over the sentence's rows of the match mask k_dp_reg<*, false, true> forms anyway.  The host sets it when
-// that kernel is what will run (unit costs, no idf / real-token / penalty-token terms): survivors are then kept on dominance,
-// the tabulated length filter and their match length alone, and the candidate the reference would have dropped before its
-// edit distance (src/fuzzy_match.cc:576-583) is marked there so that the replay skips it.
+// (Round 4 measured the alternative the round-3 review proposed — leave the exact coverage test of patterns of up to 64 tokens to
+// the bit-parallel edit-distance kernel, where count_covered_words is the popcount of the OR of the rows' match masks, and mark the
+// candidates it rejects so that the replay skips them: bit-identical, the light kernel 1.41 -> 1.08 ms and k_expand_b<false>
+// 0.82 -> 0.57 at C3, but the exact test removes a THIRD of the survivors (kept 8.3 M -> 11.9 M, candidates 6.7 M -> 10.1 M,
+// queries with more than 64 survivors 41 -> 339 per step), and what follows pays more than was saved: candidate kernels
+// 0.15 -> 0.48 ms, edit distances 0.58 -> 0.87, replay 0.46 -> 0.60 — one call at a time 179 -> 163 M patterns/s, six in flight
+// 203 -> 196 M.  Removed; profiles/r04_c3_defer_cover_*.json keep the two lines.)
 template <bool LIGHT>
 __global__ void __launch_bounds__(kWave, LIGHT ? FMX_LIGHT_WAVES : FMX_PHASEB_WAVES) k_expand_b(DevIndex ix, DevBatch b, DevWork w, Params prm,
-                                                       const WorkItem* items, uint32_t item_cap, uint32_t first_q_blocks,
-                                                       uint32_t defer_cover) {
+                                                       const WorkItem* items, uint32_t item_cap, uint32_t first_q_blocks) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t* s_pat = (uint32_t*)smem;
   __shared__ PatHash ph;
@@ -1439,8 +1439,7 @@ __global__ void __launch_bounds__(kWave, LIGHT ? FMX_LIGHT_WAVES : FMX_PHASEB_WA
       for (uint32_t j = lane; j < p; j += kWave) s_pat[j] = pat[j];
       load_recs();
       wave_lds_sync();
-      const bool defer = defer_cover != 0u && p <= kWave;  // (wave-uniform)
-      if (p <= kWave && !defer) pat_hash_build(ph, s_pat, p);
+      if (p <= kWave) pat_hash_build(ph, s_pat, p);
       // Two stages per block of kWave * kBU queued hits.  Stage 1: the dominance test (about two thirds
       // of the queued hits fail it) compacts the survivors into LDS.  Stage 2: full waves of survivors do
       // the token work (match length + exact coverage), not diluted by dominated hits.
@@ -1504,7 +1503,7 @@ __global__ void __launch_bounds__(kWave, LIGHT ? FMX_LIGHT_WAVES : FMX_PHASEB_WA
       constexpr uint32_t kSubLanes = 4, kSubSurv = kWave / kSubLanes;
       unsigned long long cplanes[7];
       uint32_t n_cpl = 0;
-      if (p <= kWave && !defer) {
+      if (p <= kWave) {
         const uint32_t mycnt = ph.cnt[lane];  // positions per distinct pattern word (0 beyond the distinct count)
 #pragma unroll
         for (uint32_t k = 0; k < 7; k++) {
@@ -1530,7 +1529,7 @@ __global__ void __launch_bounds__(kWave, LIGHT ? FMX_LIGHT_WAVES : FMX_PHASEB_WA
 #pragma unroll
         for (int u = 0; u < kLcpAhead; u++) { const uint32_t k = m + u * kSubLanes + part; lt[u] = k < lim ? ix.tok[sv.off + k] : 0u; }
 #pragma unroll
-        for (int u = 0; u < kCovAhead; u++) { const uint32_t k = part + u * kSubLanes; ct[u] = (!defer && act && k < sl) ? sent[k] : kHashEmpty; }
+        for (int u = 0; u < kCovAhead; u++) { const uint32_t k = part + u * kSubLanes; ct[u] = (act && k < sl) ? sent[k] : kHashEmpty; }
         // match length: kSubLanes tokens per step, a position at or beyond the limit counts as a mismatch
         uint32_t L = m < lim ? m : lim;
         bool done = !act || m >= lim;
@@ -1556,7 +1555,7 @@ __global__ void __launch_bounds__(kWave, LIGHT ? FMX_LIGHT_WAVES : FMX_PHASEB_WA
         }
         // coverage: distinct pattern words present in the sentence
         unsigned long long seen = 0;
-        if (!defer && act && L < p) {
+        if (act && L < p) {
           auto probe = [&](uint32_t t) {
             uint32_t h = pat_hash_slot(t);
             uint32_t key = ph.key[h];
@@ -1589,8 +1588,7 @@ __global__ void __launch_bounds__(kWave, LIGHT ? FMX_LIGHT_WAVES : FMX_PHASEB_WA
         if (L >= p) cover = p;
         bool keep = act && part == 0;
         if (keep) {
-          if (defer) { if (need == 0) keep = !reject_len(p, sl, prm); }  // the coverage test follows in the edit-distance kernel
-          else if (need != kNeedExact && need != 0) keep = cover >= need;
+          if (need != kNeedExact && need != 0) keep = cover >= need;
           // need == 0: sentence length outside phase A's table, the length filter is still to be applied
           else keep = !reject_len(p, sl, prm) && !reject_cover(p, sl, cover, prm);
         }
@@ -2351,11 +2349,9 @@ __device__ __forceinline__ void eq_push(uint32_t& eq, uint32_t a, uint32_t b) {
 // Unit costs: bit-parallel Levenshtein distance (fmx_core.hh) with the pattern in registers, then S_k.
 // P = register capacity; EXACT: every lane's pattern has exactly P tokens, otherwise columns beyond n2 hold
 // 0xffffffff (never equal, their bits stay 0 and never reach bit n2 - 1).
-// seen_out: OR of the rows' match masks = the pattern positions whose word occurs in the sentence (count_covered_words).
 template <int P, bool EXACT>
 __device__ __forceinline__ float edit_distance_unit(const uint32_t* __restrict__ sent, uint32_t n1,
-                                                    const uint32_t* __restrict__ pat, uint32_t n2, float inc, float& M_out,
-                                                    unsigned long long& seen_out) {
+                                                    const uint32_t* __restrict__ pat, uint32_t n2, float inc, float& M_out) {
   uint32_t pt[P];
 #pragma unroll
   for (int j = 0; j < P; j++) pt[j] = (EXACT || (uint32_t)j < n2) ? pat[j] : 0xffffffffu;
@@ -2365,7 +2361,6 @@ __device__ __forceinline__ float edit_distance_unit(const uint32_t* __restrict__
   const Tok4* sent4 = reinterpret_cast<const Tok4*>(sent);
   Tok4 nxt = n1 ? sent4[0] : Tok4{{0u, 0u, 0u, 0u}};
   uint32_t pv = ~0u, mv = 0u, score = n2;
-  uint32_t seen_lo = 0, seen_hi = 0;
   LevState st;
   lev_init(st, n2);
   for (uint32_t i0 = 0; i0 < n1; i0 += 4) {
@@ -2385,9 +2380,7 @@ __device__ __forceinline__ float edit_distance_unit(const uint32_t* __restrict__
           eq_push(eq_a, wd, pt[P - 1 - t]);
           if (H - 1 - t >= 0) eq_push(eq_b, wd, pt[H - 1 - t >= 0 ? H - 1 - t : 0]);
         }
-        const uint32_t eq = H ? ((eq_a << H) | eq_b) : eq_a;
-        seen_lo |= eq;
-        lev_step32(pv, mv, score, eq, n2);
+        lev_step32(pv, mv, score, H ? ((eq_a << H) | eq_b) : eq_a, n2);
       } else {
         uint32_t eq_lo = 0, eq_hi = 0;
 #pragma unroll
@@ -2395,7 +2388,6 @@ __device__ __forceinline__ float edit_distance_unit(const uint32_t* __restrict__
           eq_push(eq_lo, wd, pt[31 - t]);
           if (P - 1 - t >= 32) eq_push(eq_hi, wd, pt[P - 1 - t >= 32 ? P - 1 - t : 32]);
         }
-        seen_lo |= eq_lo; seen_hi |= eq_hi;
         lev_step(st, ((unsigned long long)eq_hi << 32) | eq_lo, n2);
       }
     }
@@ -2403,27 +2395,18 @@ __device__ __forceinline__ float edit_distance_unit(const uint32_t* __restrict__
   k = P <= 32 ? score : st.score;
   const float f = unit_cost_sum(k, inc);
   M_out = f;
-  seen_out = ((unsigned long long)seen_hi << 32) | seen_lo;
   return f;
-}
-
-template <int P, bool EXACT>
-__device__ __forceinline__ float edit_distance_unit(const uint32_t* __restrict__ sent, uint32_t n1,
-                                                    const uint32_t* __restrict__ pat, uint32_t n2, float inc, float& M_out) {
-  unsigned long long seen;  // (unused: the ORs fall away)
-  return edit_distance_unit<P, EXACT>(sent, n1, pat, n2, inc, M_out, seen);
 }
 
 template <int LO, int HI>
 __device__ __forceinline__ float edit_distance_unit_dispatch(uint32_t p_u, const uint32_t* __restrict__ sent, uint32_t n1,
-                                                             const uint32_t* __restrict__ pat, float inc, float& M,
-                                                             unsigned long long& seen) {
+                                                             const uint32_t* __restrict__ pat, float inc, float& M) {
   if constexpr (LO == HI) {
-    return edit_distance_unit<LO, true>(sent, n1, pat, (uint32_t)LO, inc, M, seen);
+    return edit_distance_unit<LO, true>(sent, n1, pat, (uint32_t)LO, inc, M);
   } else {
     constexpr int MID = (LO + HI) / 2;
-    if (p_u <= (uint32_t)MID) return edit_distance_unit_dispatch<LO, MID>(p_u, sent, n1, pat, inc, M, seen);
-    return edit_distance_unit_dispatch<MID + 1, HI>(p_u, sent, n1, pat, inc, M, seen);
+    if (p_u <= (uint32_t)MID) return edit_distance_unit_dispatch<LO, MID>(p_u, sent, n1, pat, inc, M);
+    return edit_distance_unit_dispatch<MID + 1, HI>(p_u, sent, n1, pat, inc, M);
   }
 }
 
@@ -2472,16 +2455,8 @@ __global__ void __launch_bounds__(kWave, (UNIT && P == 32) ? 8 : 1) k_dp_reg(Dev
     const bool same_p = __ballot(p != p_u) == 0ull;
     if constexpr (UNIT) {
       const float inc = prm.rep * dw;  // = ins * dw = del * dw
-      unsigned long long seen = 0;
-      if (same_p) final_cost = edit_distance_unit_dispatch<(P == 32 ? 1 : 33), P>(p_u, sent, slen, pat, inc, M, seen);
-      else final_cost = edit_distance_unit<P, false>(sent, slen, pat, p, inc, M, seen);
-      // The coverage test the candidate loop runs BEFORE the edit distance (src/fuzzy_match.cc:576-583; k_expand_b left it to
-      // this kernel, see defer_cover): cover = p when the longest match spans the pattern, else the covered positions.  A
-      // candidate it rejects never reaches lowest_costs: M = +inf makes every replay skip it ("M > bound", whatever the bound)
-      // without touching the heap, exactly like the reference's `continue`.
-      const uint32_t longest = c0.longest & 0xffffu;
-      const uint32_t cover = longest < p ? (uint32_t)__popcll(seen) : p;
-      if (reject_cover(p, slen, cover, prm)) M = __builtin_inff();
+      if (same_p) final_cost = edit_distance_unit_dispatch<(P == 32 ? 1 : 33), P>(p_u, sent, slen, pat, inc, M);
+      else final_cost = edit_distance_unit<P, false>(sent, slen, pat, p, inc, M);
     } else if (same_p)
       final_cost = edit_distance_exact_dispatch<(P == 32 ? 1 : 33), P, IDF>(p_u, sent, slen, pat, prm.ins, prm.del, prm.rep,
                                                                           dw, M, p_idf, idf_weight);

@@ -34,6 +34,10 @@ class Hip:
         p = C.c_void_p()
         self.check(self.L.hipMalloc(C.byref(p), C.c_size_t(max(nbytes, 4))))
         self.check(self.L.hipMemset(p, 0, C.c_size_t(nbytes)))
+        # hipMemset returns before the fill has run, and the non-blocking streams the calls use are not ordered behind the null
+        # stream: with every hardware queue busy the fill could land AFTER a call's kernels had written their records (seen once
+        # in 144 calls: a whole call's counts zero).  Wait for the null stream.
+        self.check(self.L.hipStreamSynchronize(None))
         return p.value
 
     def download(self, ptr, dtype, count):

@@ -110,3 +110,63 @@ def test_text_batch_over_several_passes(fmx, text_index):
     assert np.array_equal(want[1], got[1])
     for q in range(len(q_off) - 1):
         assert want[0][q, :want[1][q]].tobytes() == got[0][q, :got[1][q]].tobytes(), q
+
+
+@pytest.mark.parametrize("n,seed", [(1, 0), (37, 1), (5000, 2), (60000, 3)])
+def test_line_batches_equal_id_batches(fmx, text_index, n, seed):
+    """fmx_match_batch_lines: the bytes of a pre-tokenised file — blank-separated tokens, one pattern per line — are cut into
+    patterns and tokens ON THE DEVICE.  Every kind of blank (runs of spaces, tabs, carriage returns, leading and trailing ones),
+    empty lines (empty patterns: no match) and long lines; the records equal those of the id batch."""
+    ix, words, c_off, c_tok, vocab, _ = text_index
+    rng = np.random.default_rng(100 + seed)
+    q_off, toks = _queries(rng, words, c_off, c_tok, vocab, n)
+    # an empty pattern every so often
+    lens = np.diff(q_off).astype(np.int64)
+    lines, new_lens, at = [], [], 0
+    seps = [b" ", b"  ", b"\t", b" \t ", b" "]
+    for q in range(n):
+        t = toks[at:at + lens[q]]
+        at += lens[q]
+        if n > 20 and q % 53 == 7:
+            lines.append([b"", b"   ", b"\t\r"][q % 3])       # an empty line (possibly of blanks): an empty pattern
+            new_lens.append(0)
+        body = b""
+        for k, w in enumerate(t):
+            body += (seps[(q + k) % len(seps)] if k else [b"", b" ", b"\t"][q % 3]) + w
+        lines.append(body + [b"", b" ", b"\r", b" \t"][q % 4])
+        new_lens.append(len(t))
+    text = b"".join(ln + b"\n" for ln in lines)
+    off2 = np.zeros(len(lines) + 1, np.uint32)
+    off2[1:] = np.cumsum(new_lens)
+    ids = ix.vocab_lookup([t.decode("utf-8") for t in toks])
+    for kw in (dict(fuzzy=0.6, nmatch=5), dict(fuzzy=0.8, nmatch=2, no_perfect=True)):
+        want = ix.match_batch(fmx.Params(**kw), off2, ids)
+        got = ix.match_batch_lines(fmx.Params(**kw), text, len(lines))
+        assert np.array_equal(want[1], got[1]) and np.array_equal(want[2], got[2]), (n, kw)
+        for q in range(len(lines)):
+            assert want[0][q, :want[1][q]].tobytes() == got[0][q, :got[1][q]].tobytes(), (n, kw, q)
+    assert int((want[1] > 0).sum()) > 0
+
+
+def test_line_batch_arguments_and_several_passes(fmx, text_index):
+    ix, words, c_off, c_tok, vocab, _ = text_index
+    with pytest.raises(Exception):
+        ix.match_batch_lines(fmx.Params(fuzzy=0.6), b"w1 w2 w4\nw8 w9", 2)      # the last line is not terminated
+    with pytest.raises(Exception):
+        ix.match_batch_lines(fmx.Params(fuzzy=0.6), b"w1 w2 w4\nw8 w9\n", 3)    # two line feeds, three lines named
+    got = ix.match_batch_lines(fmx.Params(fuzzy=0.6), b"w1 w2 w4\nw8 w9\n", 2)
+    assert len(got[1]) == 2
+    rng = np.random.default_rng(77)
+    q_off, toks = _queries(rng, words, c_off, c_tok, vocab, 7000)
+    ids = ix.vocab_lookup([t.decode("utf-8") for t in toks])
+    text = b"".join(b" ".join(toks[q_off[q]:q_off[q + 1]]) + b"\n" for q in range(7000))
+    kw = dict(fuzzy=0.6, nmatch=5)
+    want = ix.match_batch(fmx.Params(**kw), q_off, ids)
+    try:
+        ix.set_option("sub_queries", 1500)        # several pipeline passes over one cut
+        got = ix.match_batch_lines(fmx.Params(**kw), text, 7000)
+    finally:
+        ix.set_option("sub_queries", 1 << 20)
+    assert np.array_equal(want[1], got[1])
+    for q in range(7000):
+        assert want[0][q, :want[1][q]].tobytes() == got[0][q, :got[1][q]].tobytes(), q

@@ -10,6 +10,7 @@
 //   fmx-cli -i tm.en.gz.fmi -a match -f 0.7 -n 5 < patterns.txt > matches.tsv
 //   fmx-cli -i tm.en.gz.fmi -a subseq -w < patterns.txt # score, length and text of the best sub-n-gram (cli:234-248)
 //   fmx-cli --tokenised -c corpus.tok -a index          # ids = line numbers, or "id<TAB>tokens"
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -276,21 +277,49 @@ int main(int argc, char** argv) {
     if (fmx_index_get_info(ix, &info) != FMX_OK) { std::cerr << "ERROR: " << fmx_last_error() << std::endl; return 1; }
     const int ix_pt = info.pt;  // penalty tokens are a property of the index (src/fuzzy_matcher_binarization.cc:32-51)
     tick(subseq ? "Subsequencing" : "Matching");
-    // Streaming pipeline (the reference keeps 1000 futures in flight over a worker pool, cli:112-193): batches
-    // of lines flow reader -> parser (tokens + vocabulary ids, `nthreads` helpers) -> GPU -> formatter/writer
-    // through bounded queues, so reading and parsing batch i + 1 and printing batch i - 1 overlap the GPU work
-    // of batch i.  Output order = input order.
+    // Streaming pipeline (the reference keeps 1000 futures in flight over a worker pool, cli:112-193): the reader cuts stdin into
+    // blocks of whole lines (no per-line strings), `nthreads` workers take a block each — at most kGpuCalls of them inside the
+    // library at once —, format its records and hand it to the writer, which prints the blocks in input order.
+    //   * --tokenised -a match: the block goes to the GPU AS IT IS (fmx_match_batch_lines): the device cuts it into patterns and
+    //     tokens and looks the ids up; the host never touches a token.
+    //   * raw text: the library's text front-end tokenises each line (host), the tokens travel as spellings
+    //     (fmx_match_batch_text: normalised + real tokens interned on the device, penalty tokens as pairs).
+    //   * -a subseq: vocabulary ids on the host (fmx_subsequence_batch takes ids).
     struct Job {
-      std::vector<std::string> lines;
-      std::vector<uint32_t> q_off, wids, q_real, q_itok, cnt, tot, pos;
-      std::vector<fmx_text*> text;  // subseq on raw text: kept for the detokenised sub-n-gram
-      std::vector<fmx_match> out;
-      uint32_t cap = 0;
-      bool has_real = false, has_itok = false;
-      ~Job() { for (fmx_text* t : text) fmx_text_free(t); }
+      uint64_t seq = 0;
+      char*    text = nullptr;      // pinned: the block, every line ended by '\n'
+      size_t   text_cap = 0, n_bytes = 0, n_lines = 0;
+      fmx_match* out = nullptr;     // pinned: n_lines x cap records
+      uint32_t *cnt = nullptr, *tot = nullptr;
+      size_t   out_cap = 0, cnt_cap = 0;
+      std::string printed;
+      size_t   nonempty = 0;
+      void need_text(size_t n) {
+        if (n <= text_cap) return;
+        char* p = (char*)fmx_host_alloc(n + n / 2);
+        if (!p) { fprintf(stderr, "ERROR: out of pinned memory\n"); exit(1); }
+        if (n_bytes) memcpy(p, text, n_bytes);
+        if (text) fmx_host_free(text);
+        text = p; text_cap = n + n / 2;
+      }
+      void need_out(size_t lines, uint32_t cap) {
+        if (lines * cap > out_cap) { if (out) fmx_host_free(out); out_cap = lines * cap + lines * cap / 4; out = (fmx_match*)fmx_host_alloc(out_cap * sizeof(fmx_match)); }
+        if (lines > cnt_cap) {
+          if (cnt) fmx_host_free(cnt);
+          if (tot) fmx_host_free(tot);
+          cnt_cap = lines + lines / 4;
+          cnt = (uint32_t*)fmx_host_alloc(cnt_cap * 4); tot = (uint32_t*)fmx_host_alloc(cnt_cap * 4);
+        }
+        if (!out || !cnt || !tot) { fprintf(stderr, "ERROR: out of pinned memory\n"); exit(1); }
+      }
+      ~Job() { if (text) fmx_host_free(text); if (out) fmx_host_free(out); if (cnt) fmx_host_free(cnt); if (tot) fmx_host_free(tot); }
     };
-    using JobPtr = std::unique_ptr<Job>;
-    Channel<JobPtr> to_parse(2), to_gpu(2), to_write(2);
+    const unsigned workers = std::max(1u, nthreads);
+    constexpr int kGpuCalls = 4;     // synchronous library calls in flight (each in its own context; their kernels and copies overlap)
+    const size_t n_jobs = workers + 3;
+    std::vector<std::unique_ptr<Job>> pool(n_jobs);
+    Channel<Job*> free_jobs(n_jobs + 1), to_work(n_jobs + 1), to_write(n_jobs + 1);
+    for (auto& j : pool) { j.reset(new Job); free_jobs.push(j.get()); }
     std::atomic<bool> failed{false};
     std::string fail_msg;
     std::mutex fail_mu;
@@ -298,187 +327,255 @@ int main(int argc, char** argv) {
       std::lock_guard<std::mutex> lk(fail_mu);
       if (!failed.exchange(true)) fail_msg = msg;
     };
-    const unsigned helpers = std::max(1u, nthreads);
+    std::mutex gpu_mu;
+    std::condition_variable gpu_cv;
+    int gpu_busy = 0;
+    struct GpuSlot {
+      std::mutex& mu; std::condition_variable& cv; int& busy;
+      GpuSlot(std::mutex& m, std::condition_variable& c, int& b) : mu(m), cv(c), busy(b) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return busy < kGpuCalls; }); busy++; }
+      ~GpuSlot() { { std::lock_guard<std::mutex> lk(mu); busy--; } cv.notify_one(); }
+    };
+    // boost::lexical_cast<std::string>(float) of a score (cli:230) = "%.9g"; scores are k / 10000 (src/fuzzy_match.cc:598): tabulated
+    std::vector<float> score_f(10001);
+    std::vector<std::array<char, 16>> score_s(10001);
+    std::vector<uint8_t> score_n(10001);
+    for (int k = 0; k <= 10000; k++) {
+      score_f[k] = (float)((double)k / 10000.0);
+      score_n[k] = (uint8_t)snprintf(score_s[k].data(), 16, "%.9g", score_f[k]);
+    }
+    auto put_score = [&](std::string& buf, float v) {
+      const int k = (int)(v * 10000.f + 0.5f);
+      if (k >= 0 && k <= 10000 && score_f[k] == v) { buf.append(score_s[k].data(), score_n[k]); return; }
+      char num[64];
+      buf.append(num, (size_t)snprintf(num, sizeof(num), "%.9g", v));
+    };
+    uint32_t cap0 = subseq ? 1u : (prm.nmatch ? prm.nmatch : 64);
+    std::atomic<uint32_t> cap_now{cap0};
+    const bool lines_path = tokenised && !subseq;
 
-    std::thread parser([&] {
-      JobPtr job;
-      while (to_parse.pop(job)) {
-        const size_t n = job->lines.size();
-        // per helper: ids, real-token ids, (slot, penalty-string id) pairs, token counts
-        std::vector<std::vector<uint32_t>> ids(helpers), reals(helpers), counts(helpers);
-        std::vector<std::vector<std::pair<uint64_t, uint32_t>>> itoks(helpers);  // (line << 32 | position, id)
-        if (!tokenised && subseq) job->text.assign(n, nullptr);
-        parallel_for(helpers, n, [&](unsigned t, size_t lo, size_t hi) {
-          std::vector<const char*> ptr;
-          for (size_t i = lo; i < hi; i++) {
-            std::string& l = job->lines[i];
-            ptr.clear();
-            fmx_text* th = nullptr;
-            if (tokenised) {
-              // tokens in place: blanks become terminators
-              size_t k = 0, len = l.size();
-              while (k < len) {
-                while (k < len && (l[k] == ' ' || l[k] == '\t' || l[k] == '\r')) l[k++] = '\0';
-                if (k >= len) break;
-                ptr.push_back(l.data() + k);
-                while (k < len && l[k] != ' ' && l[k] != '\t' && l[k] != '\r') k++;
-              }
-            } else {
-              th = fmx_text_tokenize(ix_pt, l.data(), l.size());
-              if (!th) { fail("out of memory"); counts[t].push_back(0); continue; }
-              const uint32_t nt = fmx_text_num_tokens(th);
-              for (uint32_t j = 0; j < nt; j++) ptr.push_back(fmx_text_norm(th, j));
+    auto work = [&](Job* job) {
+      const size_t n = job->n_lines;
+      uint32_t cap = cap_now.load();
+      std::vector<const char*> line_at;           // generic path: start of every line (lines are terminated in place)
+      std::vector<uint32_t> q_off, wids, pos;
+      std::vector<fmx_text*> texts;
+      struct FreeTexts { std::vector<fmx_text*>& v; ~FreeTexts() { for (fmx_text* t : v) fmx_text_free(t); } } free_texts{texts};
+      if (lines_path) {
+        for (;;) {  // nmatch == 0 (no limit): grow the per-query capacity until nothing is truncated
+          job->need_out(n, cap);
+          int rc;
+          { GpuSlot slot(gpu_mu, gpu_cv, gpu_busy); rc = fmx_match_batch_lines(ix, &prm, job->text, job->n_bytes, n, job->out, job->cnt, job->tot, cap, nullptr); }
+          if (rc != FMX_OK) { fail(fmx_last_error()); return; }
+          uint32_t mx = 0;
+          for (size_t q = 0; q < n; q++) mx = job->tot[q] > mx ? job->tot[q] : mx;
+          if (mx <= cap) break;
+          cap = mx;
+        }
+      } else {
+        // lines -> tokens on the host
+        line_at.reserve(n);
+        char* p = job->text;
+        char* const end = job->text + job->n_bytes;
+        while (p < end) { line_at.push_back(p); char* nl = (char*)memchr(p, '\n', (size_t)(end - p)); *nl = '\0'; p = nl + 1; }
+        q_off.assign(1, 0);
+        std::string norm_text, real_text;
+        std::vector<uint64_t> itok_slot;
+        std::vector<uint32_t> itok_id;
+        std::vector<const char*> ptr;
+        if (!tokenised && subseq) texts.assign(n, nullptr);
+        for (size_t i = 0; i < n; i++) {
+          char* l = const_cast<char*>(line_at[i]);
+          const size_t len = strlen(l);
+          ptr.clear();
+          fmx_text* th = nullptr;
+          if (tokenised) {  // tokens in place: blanks become terminators
+            size_t k = 0;
+            while (k < len) {
+              while (k < len && (l[k] == ' ' || l[k] == '\t' || l[k] == '\r')) l[k++] = '\0';
+              if (k >= len) break;
+              ptr.push_back(l + k);
+              while (k < len && l[k] != ' ' && l[k] != '\t' && l[k] != '\r') k++;
             }
-            const size_t base = ids[t].size();
-            ids[t].resize(base + ptr.size());
-            // (the batch lookup: an open-addressing table over the packed spellings, no std::string per token)
-            if (!ptr.empty() && fmx_vocab_lookup_mt(ix, ptr.data(), ptr.size(), ids[t].data() + base, 1) != FMX_OK) fail(fmx_last_error());
-            counts[t].push_back((uint32_t)ptr.size());
-            if (th) {
-              if (info.real_differs)
-                for (uint32_t j = 0; j < ptr.size(); j++) {
-                  const char* r = fmx_text_real(th, j);
-                  reals[t].push_back(fmx_index_lookup_real(ix, r, strlen(r)));
-                }
+          } else {
+            th = fmx_text_tokenize(ix_pt, l, len);
+            if (!th) { fail("out of memory"); return; }
+            const uint32_t nt = fmx_text_num_tokens(th);
+            for (uint32_t j = 0; j < nt; j++) ptr.push_back(fmx_text_norm(th, j));
+          }
+          if (subseq) {  // fmx_subsequence_batch takes vocabulary ids
+            const size_t base = wids.size();
+            wids.resize(base + ptr.size());
+            if (!ptr.empty() && fmx_vocab_lookup_mt(ix, ptr.data(), ptr.size(), wids.data() + base, 1) != FMX_OK) { fail(fmx_last_error()); return; }
+          } else {       // the tokens as spellings: ids (and real tokens) are interned on the device
+            bool empty_real = false;
+            for (uint32_t j = 0; j < ptr.size(); j++) {
+              norm_text.append(ptr[j]); norm_text.push_back('\0');
+              if (th && info.real_differs) { const char* r = fmx_text_real(th, j); empty_real = empty_real || !*r; real_text.append(r); real_text.push_back('\0'); }
+            }
+            if (empty_real) { fail("a pattern with an empty real token cannot travel as a text batch"); return; }
+            if (th)
               for (uint32_t k = 0; k < fmx_text_num_itoks(th); k++) {
                 const char* is = fmx_text_itok(th, k);
                 const uint64_t at = fmx_text_itok_index(th, k);
-                if (at <= ptr.size()) itoks[t].emplace_back(((uint64_t)i << 32) | at, fmx_index_intern_itok(ix, is, strlen(is)));
+                if (at <= ptr.size()) { itok_slot.push_back((uint64_t)q_off.back() + i + at); itok_id.push_back(fmx_index_intern_itok(ix, is, strlen(is))); }
               }
-              if (subseq) job->text[i] = th; else fmx_text_free(th);
-            }
           }
-        });
-        job->q_off.assign(1, 0);
-        job->q_off.reserve(n + 1);
-        size_t total = 0, n_itok = 0;
-        for (unsigned t = 0; t < helpers; t++) { total += ids[t].size(); n_itok += itoks[t].size(); }
-        job->wids.reserve(total);
-        job->has_real = !tokenised && info.real_differs;
-        job->has_itok = n_itok != 0;
-        for (unsigned t = 0; t < helpers; t++) {
-          for (uint32_t c : counts[t]) job->q_off.push_back(job->q_off.back() + c);
-          job->wids.insert(job->wids.end(), ids[t].begin(), ids[t].end());
-          if (job->has_real) job->q_real.insert(job->q_real.end(), reals[t].begin(), reals[t].end());
+          q_off.push_back(q_off.back() + (uint32_t)ptr.size());
+          if (th) { if (subseq) texts[i] = th; else fmx_text_free(th); }
         }
-        if (job->has_itok) {  // slot of (line q, position j) = q_off[q] + q + j
-          job->q_itok.assign(total + n, 0);
-          for (unsigned t = 0; t < helpers; t++)
-            for (const auto& kv : itoks[t]) {
-              const uint64_t q = kv.first >> 32, j = kv.first & 0xffffffffu;
-              job->q_itok[job->q_off[q] + q + j] = kv.second;
-            }
-        }
-        if (!to_gpu.push(std::move(job))) break;
-      }
-      to_gpu.close();
-      to_parse.close();  // unblocks the reader if this stage stopped early
-    });
-
-    std::thread gpu([&] {
-      JobPtr job;
-      uint32_t cap = subseq ? 1u : (prm.nmatch ? prm.nmatch : 64);
-      while (to_gpu.pop(job)) {
-        const size_t n = job->lines.size();
-        fmx_batch b = {n, job->q_off.data(), job->wids.data(), job->has_real ? job->q_real.data() : nullptr,
-                       job->has_itok ? job->q_itok.data() : nullptr, 0};
-        job->cnt.resize(n);
-        job->tot.resize(n);
         if (subseq) {
-          job->out.resize(n);
-          job->pos.resize(n);
-          if (fmx_subsequence_batch(ix, &b, prm.nmatch, prm.no_perfect, prm.min_subseq_length, prm.min_subseq_ratio,
-                                    idf_weighting ? 1 : 0, job->out.data(), job->cnt.data(), job->pos.data()) != FMX_OK)
-            fail(fmx_last_error());
+          job->need_out(n, 1);
+          pos.resize(n);
+          fmx_batch b = {n, q_off.data(), wids.data(), nullptr, nullptr, 0};
+          GpuSlot slot(gpu_mu, gpu_cv, gpu_busy);
+          if (fmx_subsequence_batch(ix, &b, prm.nmatch, prm.no_perfect, prm.min_subseq_length, prm.min_subseq_ratio, idf_weighting ? 1 : 0, job->out,
+                                    job->cnt, pos.data()) != FMX_OK) { fail(fmx_last_error()); return; }
+          cap = 1;
         } else {
-          for (;;) {  // nmatch == 0 (no limit): grow the per-query capacity until nothing is truncated
-            job->out.resize(n * (size_t)cap);
-            if (fmx_match_batch(ix, &prm, &b, job->out.data(), job->cnt.data(), job->tot.data(), cap, nullptr) != FMX_OK) {
-              fail(fmx_last_error());
-              break;
-            }
+          fmx_text_batch tb = {n, q_off.data(), norm_text.data(), norm_text.size(), nullptr, 0, 0, nullptr, nullptr};
+          if (!tokenised && info.real_differs) {
+            tb.real_text = real_text.data(); tb.n_real_bytes = real_text.size();
+            tb.n_itoks = itok_slot.size(); tb.itok_slot = itok_slot.data(); tb.itok_id = itok_id.data();
+          }
+          for (;;) {
+            job->need_out(n, cap);
+            int rc;
+            { GpuSlot slot(gpu_mu, gpu_cv, gpu_busy); rc = fmx_match_batch_text(ix, &prm, &tb, job->out, job->cnt, job->tot, cap, nullptr); }
+            if (rc != FMX_OK) { fail(fmx_last_error()); return; }
             uint32_t mx = 0;
-            for (uint32_t t : job->tot) mx = t > mx ? t : mx;
+            for (size_t q = 0; q < n; q++) mx = job->tot[q] > mx ? job->tot[q] : mx;
             if (mx <= cap) break;
             cap = mx;
           }
         }
-        job->cap = cap;
-        if (failed || !to_write.push(std::move(job))) break;
       }
-      to_write.close();
-      to_gpu.close();  // unblocks the parser if the GPU stage stopped early
-    });
-
-    size_t n_total = 0, n_nonempty = 0;
-    std::thread writer([&] {
-      JobPtr job;
-      while (to_write.pop(job)) {
-        const size_t n = job->lines.size();
-        std::vector<std::string> text(helpers);
-        std::vector<size_t> nonempty(helpers, 0);
-        parallel_for(helpers, n, [&](unsigned t, size_t lo, size_t hi) {
-          std::string& buf = text[t];
-          char num[64];
-          for (size_t q = lo; q < hi; q++) {
-            for (uint32_t k = 0; k < job->cnt[q]; k++) {
-              const fmx_match& m = job->out[q * job->cap + k];
-              snprintf(num, sizeof(num), "%.9g", m.score);  // boost::lexical_cast<std::string>(float), cli:230
-              if (k) buf += '\t';
-              buf += num;
-              buf += '\t';
-              if (subseq) {  // score, max_subseq, id, and the sub-n-gram itself appended to the id (cli:241-247, src/fuzzy_match.cc:348)
-                buf += std::to_string(m.max_subseq);
-                buf += '\t';
-              }
-              buf += fmx_index_sentence_id(ix, m.s_id);
-              if (subseq) {
-                buf += '\t';
-                if (!job->text.empty() && job->text[q]) buf += fmx_text_detokenize(job->text[q], job->pos[q], job->pos[q] + (uint32_t)m.max_subseq);
-                else {  // tokenised input: the tokens of the sub-n-gram (terminated in place by the parser)
-                  const char* w = job->lines[q].data();
-                  const char* end = w + job->lines[q].size();
-                  uint32_t idx = 0;
-                  bool first = true;
-                  while (w < end) {
-                    if (*w == '\0') { w++; continue; }
-                    const size_t len = strlen(w);
-                    if (idx >= job->pos[q] && idx < job->pos[q] + (uint32_t)m.max_subseq) { if (!first) buf += ' '; buf.append(w, len); first = false; }
-                    idx++;
-                    w += len;
-                  }
-                }
+      if (cap > cap_now.load()) cap_now.store(cap);
+      // records -> text (cli:219-248): score <TAB> id pairs joined by tabs, an empty line when nothing matched
+      std::string& buf = job->printed;
+      buf.clear();
+      buf.reserve(n * 48);
+      job->nonempty = 0;
+      for (size_t q = 0; q < n; q++) {
+        for (uint32_t k = 0; k < job->cnt[q]; k++) {
+          const fmx_match& mt = job->out[q * cap + k];
+          if (k) buf += '\t';
+          put_score(buf, mt.score);
+          buf += '\t';
+          if (subseq) {  // score, max_subseq, id, and the sub-n-gram itself appended to the id (cli:241-247, src/fuzzy_match.cc:348)
+            buf += std::to_string(mt.max_subseq);
+            buf += '\t';
+          }
+          buf += fmx_index_sentence_id(ix, mt.s_id);
+          if (subseq) {
+            buf += '\t';
+            if (!texts.empty() && texts[q]) buf += fmx_text_detokenize(texts[q], pos[q], pos[q] + (uint32_t)mt.max_subseq);
+            else {  // tokenised input: the tokens of the sub-n-gram (terminated in place above)
+              const char* w = line_at[q];
+              const char* end = q + 1 < n ? line_at[q + 1] - 1 : job->text + job->n_bytes - 1;
+              uint32_t idx = 0;
+              bool first = true;
+              while (w < end) {
+                if (*w == '\0') { w++; continue; }
+                const size_t len = strlen(w);
+                if (idx >= pos[q] && idx < pos[q] + (uint32_t)mt.max_subseq) { if (!first) buf += ' '; buf.append(w, len); first = false; }
+                idx++;
+                w += len;
               }
             }
-            buf += '\n';
-            if (job->cnt[q]) nonempty[t]++;
           }
-        });
-        for (unsigned t = 0; t < helpers; t++) {
-          fwrite(text[t].data(), 1, text[t].size(), stdout);
-          n_nonempty += nonempty[t];
         }
-        n_total += n;
+        buf += '\n';
+        if (job->cnt[q]) job->nonempty++;
+      }
+    };
+
+    std::vector<std::thread> work_threads;
+    for (unsigned t = 0; t < workers; t++)
+      work_threads.emplace_back([&] {
+        Job* job;
+        while (to_work.pop(job)) {
+          if (!failed) work(job);
+          if (!to_write.push(job)) break;
+        }
+      });
+
+    size_t n_total = 0, n_nonempty = 0;
+    std::atomic<uint64_t> jobs_made{~0ull};   // set by the reader at end of input
+    std::thread writer([&] {
+      std::vector<Job*> waiting;
+      uint64_t next = 0;
+      Job* job;
+      for (;;) {
+        if (next == jobs_made.load()) break;
+        if (!to_write.pop(job)) break;
+        waiting.push_back(job);
+        for (bool again = true; again;) {
+          again = false;
+          for (size_t k = 0; k < waiting.size(); k++)
+            if (waiting[k]->seq == next) {
+              Job* j = waiting[k];
+              waiting.erase(waiting.begin() + (long)k);
+              if (!failed) fwrite(j->printed.data(), 1, j->printed.size(), stdout);
+              n_total += j->n_lines; n_nonempty += j->nonempty;
+              j->n_bytes = j->n_lines = 0;
+              free_jobs.push(j);
+              next++;
+              again = true;
+              break;
+            }
+        }
       }
       fflush(stdout);
     });
 
-    {  // reader: this thread
-      std::string line;
+    {  // reader: this thread.  Blocks of whole lines, at most `batch` lines each; the rest of a read moves on to the next block.
+      const size_t chunk = 4u << 20;
+      std::vector<char> carry;
       bool eof = false;
-      while (!eof && !failed) {
-        JobPtr job(new Job);
-        job->lines.reserve(batch);
-        while (job->lines.size() < batch && std::getline(std::cin, line)) job->lines.push_back(line);
-        eof = job->lines.size() < batch;
-        if (job->lines.empty()) break;
-        if (!to_parse.push(std::move(job))) break;
+      uint64_t seq = 0;
+      while (!failed) {
+        Job* job;
+        if (!free_jobs.pop(job)) break;
+        job->n_bytes = 0;
+        job->need_text(carry.size() + chunk);
+        if (!carry.empty()) { memcpy(job->text, carry.data(), carry.size()); job->n_bytes = carry.size(); carry.clear(); }
+        size_t lines = 0, scanned = 0, cut = 0;  // cut = end of the last whole line among the first `batch`
+        for (;;) {
+          while (scanned < job->n_bytes && lines < batch) {
+            const char* nl = (const char*)memchr(job->text + scanned, '\n', job->n_bytes - scanned);
+            if (!nl) { scanned = job->n_bytes; break; }
+            scanned = (size_t)(nl - job->text) + 1;
+            cut = scanned;
+            lines++;
+          }
+          if (lines >= batch || eof) break;
+          if (job->n_bytes >= 64u << 20 && lines > 0) break;   // (a block is at most ~64 MB)
+          job->need_text(job->n_bytes + chunk);
+          const size_t got = fread(job->text + job->n_bytes, 1, chunk, stdin);
+          if (got == 0) { eof = true; }
+          job->n_bytes += got;
+        }
+        if (eof && cut < job->n_bytes) {  // a last line without a line feed
+          job->need_text(job->n_bytes + 1);
+          job->text[job->n_bytes++] = '\n';
+          cut = job->n_bytes;
+          lines++;
+        }
+        if (cut < job->n_bytes) carry.assign(job->text + cut, job->text + job->n_bytes);
+        job->n_bytes = cut;
+        job->n_lines = lines;
+        if (lines == 0) { free_jobs.push(job); if (eof) break; else continue; }
+        job->seq = seq++;
+        if (!to_work.push(job)) break;
+        if (eof && carry.empty()) break;
       }
-      to_parse.close();
+      jobs_made.store(seq);
+      to_work.close();
     }
-    parser.join();
-    gpu.join();
+    for (auto& t : work_threads) t.join();
+    to_write.close();   // (the writer leaves once it has printed `jobs_made` blocks, or here)
     writer.join();
+    free_jobs.close();
     if (failed) {
       std::cerr << "ERROR: " << fail_msg << std::endl;
       return 1;
