@@ -282,7 +282,10 @@ struct __attribute__((aligned(128))) G5Bucket {
                    // that passed through, lives in a later bucket), bits 4 + 3 k .. 6 + 3 k the lcp of entry k
 };
 constexpr uint32_t kG5PerBucket = 3;
-constexpr uint32_t kG5FillPer16 = 16;  // distinct 5-grams per 16 buckets (16 = one per bucket: 1.9 % of the buckets overflow)
+#ifndef FMX_G5_FILL
+#define FMX_G5_FILL 16
+#endif
+constexpr uint32_t kG5FillPer16 = FMX_G5_FILL;  // distinct 5-grams per 16 buckets (16 = one per bucket: 1.9 % of the buckets overflow)
 FMX_HD uint32_t g5_used(uint32_t dir_b) { return (dir_b >> 16) & 3u; }
 FMX_HD uint32_t g5_over(uint32_t dir_b) { return (dir_b >> 18) & 1u; }
 FMX_HD uint32_t g5_lcp_of(uint32_t dir_b, uint32_t k) { return (dir_b >> (20 + 3 * k)) & 7u; }

@@ -2427,19 +2427,25 @@ __device__ __forceinline__ float edit_distance_exact_dispatch(uint32_t p_u, cons
 }
 
 // UNIT: insert = delete = replace >= 0 and no idf term (decided by the host): bit-parallel distance
+#ifndef FMX_DPREG_WAVES
+#define FMX_DPREG_WAVES 8
+#endif
 template <int P, bool IDF, bool UNIT = false>
-__global__ void __launch_bounds__(kWave, (UNIT && P == 32) ? 8 : 1) k_dp_reg(DevIndex ix, DevBatch b, DevWork w, Params prm) {
+__global__ void __launch_bounds__(kWave, (UNIT && P == 32) ? FMX_DPREG_WAVES : 1) k_dp_reg(DevIndex ix, DevBatch b, DevWork w, Params prm) {
   const uint32_t lane = lane_id();
   unsigned long long j_lo, j_hi;
   dp_class_range(b, w, P == 32 ? 0u : 1u, j_lo, j_hi);
-  for (unsigned long long j = j_lo + (unsigned long long)blockIdx.x * kWave + lane; j < j_hi;
-       j += (unsigned long long)gridDim.x * kWave) {
+  // (32-bit loop state: the list holds fewer than 2^32 entries — the host keeps seg_cap below that —, and the candidate is
+  // remembered by its slot, not by a pointer: the unit-cost variant for 32 tokens sits at the 64 registers of eight waves per SIMD)
+  const uint32_t n_list = (uint32_t)(j_hi - j_lo);
+  const unsigned long long* __restrict__ list = w.c_qi + j_lo;
+  for (uint32_t j = blockIdx.x * kWave + lane; j < n_list; j += gridDim.x * kWave) {
     // two dependency levels in front of the tokens: the list entry, then the query's offsets and the candidate record
     // together (the record names the sentence's token base and length: no detour through sent_pos and the length word)
-    const unsigned long long qi = w.c_qi[j];
+    const unsigned long long qi = list[j];
     const uint32_t q = (uint32_t)(qi >> 32);
-    Cand* cd = w.seg + (uint32_t)qi;
-    const Cand c0 = *cd;
+    const uint32_t slot = (uint32_t)qi;
+    const Cand c0 = w.seg[slot];
     const uint32_t o0 = b.q_off[b.q_begin + q];
     const uint32_t p = b.q_off[b.q_begin + q + 1] - o0;
     const uint32_t* pat = b.q_tok + o0;
@@ -2462,6 +2468,7 @@ __global__ void __launch_bounds__(kWave, (UNIT && P == 32) ? 8 : 1) k_dp_reg(Dev
                                                                           dw, M, p_idf, idf_weight);
     else
       final_cost = edit_distance_reg<P, IDF>(sent, slen, pat, p, prm.ins, prm.del, prm.rep, dw, M, p_idf, idf_weight);
+    Cand* cd = w.seg + slot;
     cd->score = final_cost;
     cd->penalty = M;
     cd->longest = (c0.longest & 0xffffu) | (slen << 16);

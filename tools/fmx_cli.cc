@@ -276,7 +276,25 @@ int main(int argc, char** argv) {
     fmx_index_info info;
     if (fmx_index_get_info(ix, &info) != FMX_OK) { std::cerr << "ERROR: " << fmx_last_error() << std::endl; return 1; }
     const int ix_pt = info.pt;  // penalty tokens are a property of the index (src/fuzzy_matcher_binarization.cc:32-51)
-    tick(subseq ? "Subsequencing" : "Matching");
+    // Before the clock of the matching phase starts (like the index load): the blocks' pinned buffers and the library's call
+    // contexts (streams, events) — one tiny call per slot.
+    const unsigned workers = std::max(1u, nthreads);
+    constexpr int kGpuCalls = 4;     // synchronous library calls in flight (each in its own context; their kernels and copies overlap)
+    const bool lines_path = tokenised && !subseq;
+    const uint32_t cap0 = subseq ? 1u : (prm.nmatch ? prm.nmatch : 64);
+
+    const size_t n_jobs = std::min<size_t>(workers, 12) + 3;
+    {
+      std::vector<std::thread> warm;
+      for (int k = 0; k < kGpuCalls; k++)
+        warm.emplace_back([&] {
+          fmx_match out[64]; uint32_t c1 = 0, t1 = 0;
+          const uint32_t off[2] = {0, 1}, w1[1] = {1};
+          fmx_batch b1 = {1, off, w1, nullptr, nullptr, 1};
+          (void)fmx_match_batch(ix, &prm, &b1, out, &c1, &t1, std::min<uint32_t>(cap0, 64), nullptr);
+        });
+      for (auto& t : warm) t.join();
+    }
     // Streaming pipeline (the reference keeps 1000 futures in flight over a worker pool, cli:112-193): the reader cuts stdin into
     // blocks of whole lines (no per-line strings), `nthreads` workers take a block each — at most kGpuCalls of them inside the
     // library at once —, format its records and hand it to the writer, which prints the blocks in input order.
@@ -314,12 +332,18 @@ int main(int argc, char** argv) {
       }
       ~Job() { if (text) fmx_host_free(text); if (out) fmx_host_free(out); if (cnt) fmx_host_free(cnt); if (tot) fmx_host_free(tot); }
     };
-    const unsigned workers = std::max(1u, nthreads);
-    constexpr int kGpuCalls = 4;     // synchronous library calls in flight (each in its own context; their kernels and copies overlap)
-    const size_t n_jobs = workers + 3;
     std::vector<std::unique_ptr<Job>> pool(n_jobs);
     Channel<Job*> free_jobs(n_jobs + 1), to_work(n_jobs + 1), to_write(n_jobs + 1);
-    for (auto& j : pool) { j.reset(new Job); free_jobs.push(j.get()); }
+    for (auto& j : pool) {
+      j.reset(new Job);
+      j->need_text(std::min<size_t>(batch * 160, 48u << 20));   // (grown on demand: a block is `batch` lines, whatever their length)
+      j->need_out(batch, cap0);
+      free_jobs.push(j.get());
+    }
+    tick(subseq ? "Subsequencing" : "Matching");
+    const bool timing = getenv("FMX_CLI_TIMING") != nullptr;
+    std::atomic<uint64_t> us_gpu{0}, us_fmt{0}, us_read{0}, us_write{0}, us_wait_job{0};
+    auto now_us = [] { return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     std::atomic<bool> failed{false};
     std::string fail_msg;
     std::mutex fail_mu;
@@ -349,9 +373,7 @@ int main(int argc, char** argv) {
       char num[64];
       buf.append(num, (size_t)snprintf(num, sizeof(num), "%.9g", v));
     };
-    uint32_t cap0 = subseq ? 1u : (prm.nmatch ? prm.nmatch : 64);
     std::atomic<uint32_t> cap_now{cap0};
-    const bool lines_path = tokenised && !subseq;
 
     auto work = [&](Job* job) {
       const size_t n = job->n_lines;
@@ -364,7 +386,7 @@ int main(int argc, char** argv) {
         for (;;) {  // nmatch == 0 (no limit): grow the per-query capacity until nothing is truncated
           job->need_out(n, cap);
           int rc;
-          { GpuSlot slot(gpu_mu, gpu_cv, gpu_busy); rc = fmx_match_batch_lines(ix, &prm, job->text, job->n_bytes, n, job->out, job->cnt, job->tot, cap, nullptr); }
+          { GpuSlot slot(gpu_mu, gpu_cv, gpu_busy); const uint64_t a = now_us(); rc = fmx_match_batch_lines(ix, &prm, job->text, job->n_bytes, n, job->out, job->cnt, job->tot, cap, nullptr); us_gpu += now_us() - a; }
           if (rc != FMX_OK) { fail(fmx_last_error()); return; }
           uint32_t mx = 0;
           for (size_t q = 0; q < n; q++) mx = job->tot[q] > mx ? job->tot[q] : mx;
@@ -451,6 +473,7 @@ int main(int argc, char** argv) {
       }
       if (cap > cap_now.load()) cap_now.store(cap);
       // records -> text (cli:219-248): score <TAB> id pairs joined by tabs, an empty line when nothing matched
+      const uint64_t t_fmt = now_us();
       std::string& buf = job->printed;
       buf.clear();
       buf.reserve(n * 48);
@@ -487,6 +510,7 @@ int main(int argc, char** argv) {
         buf += '\n';
         if (job->cnt[q]) job->nonempty++;
       }
+      us_fmt += now_us() - t_fmt;
     };
 
     std::vector<std::thread> work_threads;
@@ -515,7 +539,9 @@ int main(int argc, char** argv) {
             if (waiting[k]->seq == next) {
               Job* j = waiting[k];
               waiting.erase(waiting.begin() + (long)k);
+              const uint64_t a = now_us();
               if (!failed) fwrite(j->printed.data(), 1, j->printed.size(), stdout);
+              us_write += now_us() - a;
               n_total += j->n_lines; n_nonempty += j->nonempty;
               j->n_bytes = j->n_lines = 0;
               free_jobs.push(j);
@@ -535,7 +561,10 @@ int main(int argc, char** argv) {
       uint64_t seq = 0;
       while (!failed) {
         Job* job;
+        const uint64_t t_w = now_us();
         if (!free_jobs.pop(job)) break;
+        const uint64_t t_r = now_us();
+        us_wait_job += t_r - t_w;
         job->n_bytes = 0;
         job->need_text(carry.size() + chunk);
         if (!carry.empty()) { memcpy(job->text, carry.data(), carry.size()); job->n_bytes = carry.size(); carry.clear(); }
@@ -566,6 +595,7 @@ int main(int argc, char** argv) {
         job->n_lines = lines;
         if (lines == 0) { free_jobs.push(job); if (eof) break; else continue; }
         job->seq = seq++;
+        us_read += now_us() - t_r;
         if (!to_work.push(job)) break;
         if (eof && carry.empty()) break;
       }
@@ -576,6 +606,9 @@ int main(int argc, char** argv) {
     to_write.close();   // (the writer leaves once it has printed `jobs_made` blocks, or here)
     writer.join();
     free_jobs.close();
+    if (timing)
+      std::cerr << "TIMING\tread_ms\t" << us_read / 1e3 << "\twait_free_block_ms\t" << us_wait_job / 1e3 << "\tgpu_calls_ms(sum)\t" << us_gpu / 1e3
+                << "\tformat_ms(sum)\t" << us_fmt / 1e3 << "\twrite_ms\t" << us_write / 1e3 << "\tworkers\t" << workers << "\tblocks\t" << n_jobs << std::endl;
     if (failed) {
       std::cerr << "ERROR: " << fail_msg << std::endl;
       return 1;
