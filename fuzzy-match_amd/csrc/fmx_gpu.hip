@@ -1031,7 +1031,18 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
         const bool flat = prm.nmatch >= 1 && prm.nmatch <= kMaxFlatRounds;
         const uint32_t row_tokens = std::max<uint32_t>(E.d.max_slen, E.prior_max_len);  // longest "pattern" side of the rerank's DP
         if (flat) {
-          // flattened rounds: pick, then one edit distance per remaining accepted match of any query
+          // accepted sets of up to 32 matches (sentences of up to 32 tokens): every round inside one launch, a group of 8 / 16 / 32
+          // lanes per query with the picked sentence's match masks in a small LDS table (k_crerank_g); the big / cand lists of the
+          // candidate stage are free by now and carry the three query lists
+          static const bool groups_on = [] { const char* e = getenv("FMX_RERANK_GROUPS"); return e ? atoi(e) != 0 : true; }();  // design-time switch
+          if (groups_on) {
+            hipLaunchKernelGGL(k_cgrp_route, dim3((b.nq + 1023) / 1024), dim3(1024), 0, stream, b, w, c.big_list.p, c.mid_list.p, c.fin_list.p);
+            const unsigned gg = std::min<unsigned>(256u * 32u, std::max<unsigned>(64u, b.nq / 4u));
+            hipLaunchKernelGGL(k_crerank_g<8>, dim3(gg), dim3(kWave), 0, stream, E.d, b, w, prm, (const uint32_t*)c.big_list.p, 0u, cap, d_out, d_out_count, d_out_total);
+            hipLaunchKernelGGL(k_crerank_g<16>, dim3(gg), dim3(kWave), 0, stream, E.d, b, w, prm, (const uint32_t*)c.mid_list.p, 1u, cap, d_out, d_out_count, d_out_total);
+            hipLaunchKernelGGL(k_crerank_g<32>, dim3(gg / 2), dim3(kWave), 0, stream, E.d, b, w, prm, (const uint32_t*)c.fin_list.p, 2u, cap, d_out, d_out_count, d_out_total);
+          }
+          // flattened rounds (the rest): pick, then one edit distance per remaining accepted match of any query
           hipLaunchKernelGGL(k_cacc, dim3((n_scan + 255) / 256), dim3(256), 0, stream, b, w);
           hipLaunchKernelGGL(k_scan_lb<2>, dim3(scan_tiles), dim3(kScanThreads), 0, stream, w.c_in, w.c_off, (size_t)n_scan, n_scan,
                              c.scan_state(3), c.scan_ticket(3));

@@ -3219,6 +3219,150 @@ __global__ void __launch_bounds__(kWave) k_cround(DevIndex ix, DevBatch b, DevWo
   if (lane == 0 && n_dist) atomicAdd(&w.counters[27], (unsigned long long)n_dist);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Contrastive rerank of the SMALL accepted sets inside one launch (round 4; src/fuzzy_match.cc:614-669).  The flattened rounds
+// above pay ~1900 instructions per sentence-pair distance, two thirds of them the match mask (the row's token against all 32
+// register-held tokens of the picked sentence), and a launch per round.  Here a GROUP of G lanes owns one query with at most G
+// accepted matches (k_cgrp_route sorts the queries into lists by size: G = 8, 16, 32; sentences of up to 32 tokens, no prior
+// matches), one match per lane, and runs every round itself: the pick is a maximum over the group's lanes; the picked
+// sentence's tokens go into a small LDS hash table of the group (token -> bit mask of its positions: 64 slots, 512 bytes), and
+// every other lane walks ITS sentence, one table look-up per token instead of 32 compares, through the same bit-parallel
+// recurrence (lev_step32) and the same float sum — penalties, keys and tie-breaks exactly as k_camap / k_cround compute them.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t kGrpSlots = 64;  // hash slots per group (a sentence of <= 32 tokens: load <= 0.5)
+
+// one thread per query: queries the group kernels take are listed by size and marked (class 3: the flattened path skips them)
+__global__ void __launch_bounds__(1024) k_cgrp_route(DevBatch b, DevWork w, uint32_t* list8, uint32_t* list16, uint32_t* list32) {
+  __shared__ uint32_t s_n[3], s_base[3];
+  if (threadIdx.x < 3) s_n[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  int g = -1;
+  uint32_t at = 0;
+  if (q < b.nq && w.q_cand[q] != 0) {
+    const uint32_t acc = w.q_acc[q];
+    const uint32_t n = acc & 0x3fffffffu;
+    if ((acc >> 30) == 0 && n >= 1 && n <= 32) g = n <= 8 ? 0 : (n <= 16 ? 1 : 2);
+  }
+  if (g >= 0) at = atomicAdd(&s_n[g], 1u);
+  __syncthreads();
+  if (threadIdx.x < 3) s_base[threadIdx.x] = s_n[threadIdx.x] ? (uint32_t)atomicAdd(&w.counters[28 + threadIdx.x], (unsigned long long)s_n[threadIdx.x]) : 0u;
+  __syncthreads();
+  if (g >= 0) {
+    (g == 0 ? list8 : (g == 1 ? list16 : list32))[s_base[g] + at] = q;
+    w.q_acc[q] |= 3u << 30;
+  }
+}
+
+template <int G>
+__global__ void __launch_bounds__(kWave) k_crerank_g(DevIndex ix, DevBatch b, DevWork w, Params prm, const uint32_t* list,
+                                                     uint32_t which, uint32_t cap, Rec* out_rec, uint32_t* out_count, uint32_t* out_total) {
+  constexpr uint32_t kGroups = kWave / G;
+  __shared__ uint32_t s_key[kGroups][kGrpSlots];
+  __shared__ uint32_t s_mask[kGroups][kGrpSlots];
+  const uint32_t lane = lane_id(), gl = lane % G, gi = lane / G, gb = lane - gl;
+  const unsigned long long n_list = w.counters[28 + which];
+  uint32_t n_dist = 0;
+  for (unsigned long long item0 = (unsigned long long)blockIdx.x * kGroups; item0 < n_list; item0 += (unsigned long long)gridDim.x * kGroups) {
+    const unsigned long long item = item0 + gi;
+    const bool have = item < n_list;
+    const uint32_t q = have ? list[item] : 0u;
+    const uint32_t n = have ? (w.q_acc[q] & 0x3fffffffu) : 0u;
+    const uint32_t gq = b.q_begin + q;
+    const bool mine = gl < n;
+    Cand c;
+    c.sid = 0; c.longest = 0; c.score = 0.f; c.penalty = 0.f;
+    if (mine) c = w.seg[w.q_seg[q] + gl];
+    const uint32_t csp = mine ? ix.sent_pos[c.sid] : 0u;
+    const uint32_t n1 = mine ? ix.tok[csp] : 0u;
+    // rank in list order (score desc, s_id asc), like k_camap
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < (uint32_t)G; j++) {
+      const float os = __shfl(c.score, (int)(gb + j), 64);
+      const uint32_t oid = __shfl(c.sid, (int)(gb + j), 64);
+      rank += (j < n && (os > c.score || (os == c.score && oid < c.sid))) ? 1u : 0u;
+    }
+    const uint32_t want = prm.nmatch == 0 ? n : (prm.nmatch < n ? prm.nmatch : n);
+    uint32_t want_max = want;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(want_max, d, 64); want_max = o > want_max ? o : want_max; }
+    bool picked = !mine;
+    float sum = 0.f, mx = 0.f, pen_now = 0.f;
+    for (uint32_t r = 0; r < want_max; r++) {       // round r + 1 of k_cround
+      const bool on = r < want;                       // this group's query still picks
+      unsigned long long bid = (on && !picked) ? contrast_bid(c.score - (prm.contrast * pen_now), rank, gl) : 0ull;
+#pragma unroll
+      for (int d = G / 2; d >= 1; d >>= 1) {
+        const unsigned long long o = ((unsigned long long)__shfl_xor((uint32_t)(bid >> 32), d, 64) << 32) | __shfl_xor((uint32_t)bid, d, 64);
+        bid = o > bid ? o : bid;
+      }
+      const uint32_t kb = (uint32_t)bid & 0xffffu;   // the group's pick of this round
+      if (on && mine && gl == kb) {
+        if (r < cap) {
+          Rec rec;
+          rec.score = c.score; rec.penalty = pen_now; rec.max_subseq = (int32_t)c.longest; rec.s_id = c.sid;
+          out_rec[(unsigned long long)gq * cap + r] = rec;
+        }
+        picked = true;
+      }
+      const bool more = on && r + 1 < want;           // another pick follows: the others need their distance to this one
+      if (__ballot(more) == 0ull) { if (r + 1 >= want_max) break; else continue; }
+      // the picked sentence's tokens -> the group's table (token -> mask of its positions)
+      const uint32_t msp = __shfl(csp, (int)(gb + kb), 64), n2 = __shfl(n1, (int)(gb + kb), 64);
+      wave_lds_sync();
+      for (uint32_t k = gl; k < kGrpSlots; k += G) { s_key[gi][k] = kHashEmpty; s_mask[gi][k] = 0u; }
+      wave_lds_sync();
+      if (more)
+        for (uint32_t j = gl; j < n2; j += G) {
+          const uint32_t t = ix.tok[msp + 1 + j];
+          uint32_t h = pat_hash_slot(t) & (kGrpSlots - 1);
+          for (;;) {
+            const uint32_t old = atomicCAS(&s_key[gi][h], kHashEmpty, t);
+            if (old == kHashEmpty || old == t) { atomicOr(&s_mask[gi][h], 1u << j); break; }
+            h = (h + 1) & (kGrpSlots - 1);
+          }
+        }
+      wave_lds_sync();
+      // every unpicked match of the group: bit-parallel distance of its sentence (rows) to the picked one (bits)
+      const bool act = more && mine && !picked;
+      const uint32_t rows = act ? n1 : 0u;
+      uint32_t rows_max = rows;
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(rows_max, d, 64); rows_max = o > rows_max ? o : rows_max; }
+      uint32_t pv = ~0u, mv = 0u, score = n2;
+      const uint32_t m_bits = n2 ? n2 : 1u;
+      for (uint32_t i0 = 0; i0 < rows_max; i0 += 4) {
+        uint32_t t4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) t4[u] = i0 + u < rows ? ix.tok[csp + 1 + i0 + u] : kHashEmpty;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          if (i0 + u < rows) {
+            const uint32_t t = t4[u];
+            uint32_t h = pat_hash_slot(t) & (kGrpSlots - 1);
+            uint32_t key = s_key[gi][h];
+            while (key != t && key != kHashEmpty) { h = (h + 1) & (kGrpSlots - 1); key = s_key[gi][h]; }
+            const uint32_t eq = key == t ? s_mask[gi][h] : 0u;
+            lev_step32(pv, mv, score, eq, m_bits);
+          }
+        }
+      }
+      if (act) {
+        const float dw = 100.f / normalizer(n1, n2, 1.f, 1.f, 1.f);
+        const float ed = n2 ? unit_cost_sum(score, 1.f * dw) : unit_cost_sum(n1, 1.f * dw);
+        const float pen = score_from_cost(ed);
+        sum = sum + pen;
+        mx = (r == 0) ? pen : (mx < pen ? pen : mx);
+        pen_now = prm.reduce == 1 ? mx : (sum / (float)(r + 1));
+        n_dist++;
+      }
+    }
+    if (have && gl == 0) { out_count[gq] = want < cap ? want : cap; if (out_total) out_total[gq] = want; }
+  }
+  n_dist = wave_sum(n_dist);
+  if (lane == 0 && n_dist) atomicAdd(&w.counters[27], (unsigned long long)n_dist);
+}
+
 // per-call statistics from the per-query arrays (kept out of the hot kernels: one shared atomic
 // per query costs more than the kernels' real work)
 __global__ void __launch_bounds__(1024) k_stats(DevWork w, uint32_t nq) {

@@ -33,7 +33,7 @@ cli = os.path.join(ROOT, "tools", "fmx-cli")
 t = time.time()
 subprocess.check_call([cli, "--tokenised", "-c", corpus, "-a", "index"], stderr=subprocess.DEVNULL)
 print(f"index: {n_sent} sentences in {time.time() - t:.1f}s")
-for batch in (65536, 131072, 262144):
+for batch in (32768, 65536, 131072):
     t = time.time()
     r = subprocess.run([cli, "--tokenised", "-i", corpus + ".fmi", "-a", "match", "-f", "0.7", "-n", "5", "--batch", str(batch)],
                        stdin=open(queries), stdout=open(os.path.join(out_dir, "cli_out.tsv"), "w"), stderr=subprocess.PIPE, text=True,

@@ -283,15 +283,21 @@ int main(int argc, char** argv) {
     const bool lines_path = tokenised && !subseq;
     const uint32_t cap0 = subseq ? 1u : (prm.nmatch ? prm.nmatch : 64);
 
-    const size_t n_jobs = std::min<size_t>(workers, 12) + 3;
+    const size_t n_jobs = std::min<size_t>(workers, 16) + 8;
     {
+      // one call per slot, at once, with a block's worth of patterns of unknown words: every context of the library creates its
+      // streams and sizes its workspace for `batch` patterns here instead of inside the first real calls (a context's first
+      // call allocates ~0.5 GB of HBM in a few dozen buffers: ~10 ms each)
+      const size_t nw = std::min<size_t>(batch, 1u << 20), len = 24;
+      std::vector<uint32_t> off(nw + 1), w1(nw * len, 1u);
+      for (size_t q = 0; q <= nw; q++) off[q] = (uint32_t)(q * len);
       std::vector<std::thread> warm;
       for (int k = 0; k < kGpuCalls; k++)
         warm.emplace_back([&] {
-          fmx_match out[64]; uint32_t c1 = 0, t1 = 0;
-          const uint32_t off[2] = {0, 1}, w1[1] = {1};
-          fmx_batch b1 = {1, off, w1, nullptr, nullptr, 1};
-          (void)fmx_match_batch(ix, &prm, &b1, out, &c1, &t1, std::min<uint32_t>(cap0, 64), nullptr);
+          std::vector<fmx_match> out(nw * cap0);
+          std::vector<uint32_t> c1(nw), t1(nw);
+          fmx_batch b1 = {nw, off.data(), w1.data(), nullptr, nullptr, (uint32_t)len};
+          (void)fmx_match_batch(ix, &prm, &b1, out.data(), c1.data(), t1.data(), cap0, nullptr);
         });
       for (auto& t : warm) t.join();
     }
