@@ -151,6 +151,7 @@ struct Ctx {
   Grow<unsigned long long> d_vstate, d_vstate_r;  // spellings per tile of k_vocab_count, scanned in place
   Grow<unsigned long long> d_islot;        // penalty tokens of a text batch: slot ...
   Grow<uint32_t> d_iid;                    // ... and interned id
+  Grow<uint32_t> d_scratch;                // a few scratch words (longest pattern of a line batch)
   unsigned long long* h_vtotal = nullptr;  // pinned: tokens k_vocab_lookup found
   Grow<Rec>      d_out;
   // ---- streams / events ----
@@ -236,7 +237,7 @@ struct Ctx {
     t_q.release(); t_lo.release(); t_cnt.release(); t_idf.release(); c_qi.release(); keys.release(); seg.release(); qb.release();
     heap.release(); f0.release(); f1.release(); vals.release(); zero_blk.release();
     items.release(); items_b.release(); items_h.release(); cmin_tab.release(); g_rows.release();
-    d_qoff.release(); d_qtok.release(); d_qreal.release(); d_qitok.release(); d_text.release(); d_vstate.release(); d_text_r.release(); d_vstate_r.release(); d_islot.release(); d_iid.release(); d_cnt.release(); d_tot.release(); d_out.release(); d_prior.release();
+    d_qoff.release(); d_qtok.release(); d_qreal.release(); d_qitok.release(); d_text.release(); d_vstate.release(); d_text_r.release(); d_vstate_r.release(); d_islot.release(); d_iid.release(); d_scratch.release(); d_cnt.release(); d_tot.release(); d_out.release(); d_prior.release();
     if (stream) (void)hipStreamDestroy(stream);
     if (h2d && !shared_copy) (void)hipStreamDestroy(h2d);
     if (d2h && !shared_copy) (void)hipStreamDestroy(d2h);
@@ -1570,7 +1571,7 @@ void DeviceIndex::match_host_full(const HostIndex& h, const Params& prm, const H
     if (text_real && hb.real_text) { c.d_text_r.ensure(hb.n_real_text + 2 * kVocabChunk + 16); c.d_vstate_r.ensure(text_tiles_r + 4); }
     c.d_text.ensure(hb.n_text + 2 * kVocabChunk + 16);
     c.d_vstate.ensure(text_tiles + 4);
-    if (!c.h_vtotal) HIP_TRY(hipHostMalloc((void**)&c.h_vtotal, 2 * sizeof(unsigned long long), hipHostMallocDefault));
+    if (!c.h_vtotal) HIP_TRY(hipHostMalloc((void**)&c.h_vtotal, 4 * sizeof(unsigned long long), hipHostMallocDefault));
     c.h_vtotal[0] = ~0ull;
     c.h_vtotal[1] = ~0ull;
   }
@@ -1769,6 +1770,14 @@ void DeviceIndex::match_host_full(const HostIndex& h, const Params& prm, const H
   }
 }
 
+__global__ void k_pmax(const uint32_t* q_off, unsigned long long nq, uint32_t* out) {
+  const unsigned long long q = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t p = q < nq ? q_off[q + 1] - q_off[q] : 0u;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) p = max(p, (uint32_t)__shfl_xor(p, d, 64));
+  if ((threadIdx.x & 63) == 0 && p) atomicMax(out, p);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Pre-tokenised lines (fmx_match_batch_lines): the bytes of a file go to the device as they are; it cuts them into patterns
 // and tokens (fmx_vocab.hip.hh: k_lines_count / k_lines_emit), looks the ids up (k_vocab_lookup) and runs the pipeline on the
@@ -1799,8 +1808,10 @@ void DeviceIndex::match_lines(const HostIndex& h, const Params& prm, const char*
   c.d_out.ensure(n_lines * cap);
   c.d_cnt.ensure(n_lines);
   c.d_tot.ensure(n_lines);
-  if (!c.h_vtotal) HIP_TRY(hipHostMalloc((void**)&c.h_vtotal, 2 * sizeof(unsigned long long), hipHostMallocDefault));
+  if (!c.h_vtotal) HIP_TRY(hipHostMalloc((void**)&c.h_vtotal, 4 * sizeof(unsigned long long), hipHostMallocDefault));
   c.h_vtotal[0] = c.h_vtotal[1] = ~0ull;
+  c.h_vtotal[2] = 0ull;
+  c.d_scratch.ensure(16);  // (a context-owned scratch word: no allocation, and no hipFree — a device-wide wait — inside a call)
   unsigned long long* d_total = nullptr;
   HIP_TRY(hipHostGetDevicePointer((void**)&d_total, c.h_vtotal, 0));
   hipStream_t s = c.stream;
@@ -1819,11 +1830,23 @@ void DeviceIndex::match_lines(const HostIndex& h, const Params& prm, const char*
     hipLaunchKernelGGL(k_vocab_lookup, dim3((unsigned)tiles), dim3(kScanThreads), 0, s, (const unsigned char*)c.d_text.p, (unsigned long long)n_bytes,
                        (unsigned long long)tok_cap, m.real_vocab, c.d_qreal.p, (const uint32_t*)tile_tok, 0x7ffffffeu);
   HIP_TRY(hipGetLastError());
-  // the passes need the token bounds and the longest pattern: one read-back (every pass boundary + the maximum) and one wait
+  // the passes need the token bounds and the longest pattern: read back with ONE wait (the token total is the end of the only
+  // pass; a call of more lines than a pass holds reads the boundaries of its passes too)
   DeviceBatchView bv;
   bv.nq = n_lines; bv.q_off = c.d_qoff.p; bv.q_tok = c.d_qtok.p; bv.q_real = real ? c.d_qreal.p : nullptr;
   uint32_t p_max = 0;
-  const std::vector<uint32_t> bounds = sub_bounds_from_device(c.d_qoff.p, n_lines, &p_max, s);
+  std::vector<uint32_t> bounds;
+  if (n_lines <= m.sub_queries) {
+    HIP_TRY(hipMemsetAsync(c.d_scratch.p, 0, 4, s));
+    hipLaunchKernelGGL(k_pmax, dim3((unsigned)((n_lines + 255) / 256)), dim3(256), 0, s, (const uint32_t*)c.d_qoff.p, (unsigned long long)n_lines, c.d_scratch.p);
+    HIP_TRY(hipMemcpyAsync(&c.h_vtotal[2], c.d_scratch.p, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    p_max = (uint32_t)c.h_vtotal[2];
+    if (c.h_vtotal[0] > 0xffffffffull) throw std::invalid_argument("line batch: more than 2^32 - 1 tokens");
+    bounds = {0u, (uint32_t)c.h_vtotal[0]};
+  } else {
+    bounds = sub_bounds_from_device(c.d_qoff.p, n_lines, &p_max, s);
+  }
   if (c.h_vtotal[1] != n_lines)
     throw std::invalid_argument("line batch: the text holds " + std::to_string(c.h_vtotal[1]) + " line ends, the call names " + std::to_string(n_lines) + " lines");
   bv.p_max = std::max<uint32_t>(p_max, 1);
@@ -1999,14 +2022,6 @@ void DeviceIndex::subsequence_host(const HostIndex& h, const HostBatchView& hb, 
       if (st[q].md != 10000) { out[q0 + q] = st[q].best; out_found[q0 + q] = 1; if (out_pos) out_pos[q0 + q] = st[q].pos; }
     q0 += nq;
   }
-}
-
-__global__ void k_pmax(const uint32_t* q_off, unsigned long long nq, uint32_t* out) {
-  const unsigned long long q = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t p = q < nq ? q_off[q + 1] - q_off[q] : 0u;
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) p = max(p, (uint32_t)__shfl_xor(p, d, 64));
-  if ((threadIdx.x & 63) == 0 && p) atomicMax(out, p);
 }
 
 std::vector<uint32_t> DeviceIndex::sub_bounds_from_device(const uint32_t* d_q_off, uint64_t nq, uint32_t* p_max,
