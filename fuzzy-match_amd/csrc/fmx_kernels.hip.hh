@@ -3228,6 +3228,9 @@ __global__ void __launch_bounds__(kWave) k_cround(DevIndex ix, DevBatch b, DevWo
 // sentence's tokens go into a small LDS hash table of the group (token -> bit mask of its positions: 64 slots, 512 bytes), and
 // every other lane walks ITS sentence, one table look-up per token instead of 32 compares, through the same bit-parallel
 // recurrence (lev_step32) and the same float sum — penalties, keys and tie-breaks exactly as k_camap / k_cround compute them.
+// A lane keeps its sentence in REGISTERS for all rounds (eight 16-byte loads, once) and the picked lane hands its tokens to the
+// group through LDS: the first version re-read the tokens from memory four at a time in every round — a chain of ~30 dependent
+// loads per query, 80 us per group and no faster than the flattened rounds (0.5 ms per launch whatever the list held).
 // ---------------------------------------------------------------------------------------------
 constexpr uint32_t kGrpSlots = 64;  // hash slots per group (a sentence of <= 32 tokens: load <= 0.5)
 
@@ -3260,6 +3263,7 @@ __global__ void __launch_bounds__(kWave) k_crerank_g(DevIndex ix, DevBatch b, De
   constexpr uint32_t kGroups = kWave / G;
   __shared__ uint32_t s_key[kGroups][kGrpSlots];
   __shared__ uint32_t s_mask[kGroups][kGrpSlots];
+  __shared__ uint32_t s_pick[kGroups][32];   // the picked sentence's tokens
   const uint32_t lane = lane_id(), gl = lane % G, gi = lane / G, gb = lane - gl;
   const unsigned long long n_list = w.counters[28 + which];
   uint32_t n_dist = 0;
@@ -3275,6 +3279,16 @@ __global__ void __launch_bounds__(kWave) k_crerank_g(DevIndex ix, DevBatch b, De
     if (mine) c = w.seg[w.q_seg[q] + gl];
     const uint32_t csp = mine ? ix.sent_pos[c.sid] : 0u;
     const uint32_t n1 = mine ? ix.tok[csp] : 0u;
+    uint32_t tk[32];  // this lane's sentence (<= 32 tokens; the token buffer has spare words behind it)
+    {
+      const Tok4* s4 = reinterpret_cast<const Tok4*>(ix.tok + csp + 1);
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        Tok4 v = Tok4{{0u, 0u, 0u, 0u}};
+        if (mine && (uint32_t)(4 * u) < n1) v = s4[u];
+        tk[4 * u] = v.t[0]; tk[4 * u + 1] = v.t[1]; tk[4 * u + 2] = v.t[2]; tk[4 * u + 3] = v.t[3];
+      }
+    }
     // rank in list order (score desc, s_id asc), like k_camap
     uint32_t rank = 0;
     for (uint32_t j = 0; j < (uint32_t)G; j++) {
@@ -3308,13 +3322,17 @@ __global__ void __launch_bounds__(kWave) k_crerank_g(DevIndex ix, DevBatch b, De
       const bool more = on && r + 1 < want;           // another pick follows: the others need their distance to this one
       if (__ballot(more) == 0ull) { if (r + 1 >= want_max) break; else continue; }
       // the picked sentence's tokens -> the group's table (token -> mask of its positions)
-      const uint32_t msp = __shfl(csp, (int)(gb + kb), 64), n2 = __shfl(n1, (int)(gb + kb), 64);
+      const uint32_t n2 = __shfl(n1, (int)(gb + kb), 64);
       wave_lds_sync();
+      if (more && mine && gl == kb) {
+#pragma unroll
+        for (int j = 0; j < 32; j++) if ((uint32_t)j < n1) s_pick[gi][j] = tk[j];
+      }
       for (uint32_t k = gl; k < kGrpSlots; k += G) { s_key[gi][k] = kHashEmpty; s_mask[gi][k] = 0u; }
       wave_lds_sync();
       if (more)
         for (uint32_t j = gl; j < n2; j += G) {
-          const uint32_t t = ix.tok[msp + 1 + j];
+          const uint32_t t = s_pick[gi][j];
           uint32_t h = pat_hash_slot(t) & (kGrpSlots - 1);
           for (;;) {
             const uint32_t old = atomicCAS(&s_key[gi][h], kHashEmpty, t);
@@ -3331,20 +3349,16 @@ __global__ void __launch_bounds__(kWave) k_crerank_g(DevIndex ix, DevBatch b, De
       for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(rows_max, d, 64); rows_max = o > rows_max ? o : rows_max; }
       uint32_t pv = ~0u, mv = 0u, score = n2;
       const uint32_t m_bits = n2 ? n2 : 1u;
-      for (uint32_t i0 = 0; i0 < rows_max; i0 += 4) {
-        uint32_t t4[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) t4[u] = i0 + u < rows ? ix.tok[csp + 1 + i0 + u] : kHashEmpty;
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          if (i0 + u < rows) {
-            const uint32_t t = t4[u];
-            uint32_t h = pat_hash_slot(t) & (kGrpSlots - 1);
-            uint32_t key = s_key[gi][h];
-            while (key != t && key != kHashEmpty) { h = (h + 1) & (kGrpSlots - 1); key = s_key[gi][h]; }
-            const uint32_t eq = key == t ? s_mask[gi][h] : 0u;
-            lev_step32(pv, mv, score, eq, m_bits);
-          }
+      for (int i = 0; i < 32; i++) {
+        if ((uint32_t)i >= rows_max) break;   // (wave-uniform)
+        if ((uint32_t)i < rows) {
+          const uint32_t t = tk[i];
+          uint32_t h = pat_hash_slot(t) & (kGrpSlots - 1);
+          uint32_t key = s_key[gi][h];
+          while (key != t && key != kHashEmpty) { h = (h + 1) & (kGrpSlots - 1); key = s_key[gi][h]; }
+          const uint32_t eq = key == t ? s_mask[gi][h] : 0u;
+          lev_step32(pv, mv, score, eq, m_bits);
         }
       }
       if (act) {

@@ -285,18 +285,32 @@ int main(int argc, char** argv) {
 
     const size_t n_jobs = std::min<size_t>(workers, 16) + 8;
     {
-      // one call per slot, at once, with a block's worth of patterns of unknown words: every context of the library creates its
-      // streams and sizes its workspace for `batch` patterns here instead of inside the first real calls (a context's first
-      // call allocates ~0.5 GB of HBM in a few dozen buffers: ~10 ms each)
-      const size_t nw = std::min<size_t>(batch, 1u << 20), len = 24;
-      std::vector<uint32_t> off(nw + 1), w1(nw * len, 1u);
-      for (size_t q = 0; q <= nw; q++) off[q] = (uint32_t)(q * len);
+      // one call per slot, at once, with a block's worth of the memory's OWN sentences as patterns: every context of the library
+      // creates its streams and sizes its workspace (segments, queues, work lists: learned from what a pass needed) on realistic
+      // hit and candidate counts here, instead of re-running and re-allocating inside the first real calls of a short run
+      const void* buf_v = nullptr; const void* pos_v = nullptr;
+      uint64_t n_buf = 0, n_pos = 0;
+      (void)fmx_index_array(ix, FMX_A_BUFFER, &buf_v, &n_buf);
+      (void)fmx_index_array(ix, FMX_A_SENT_POS, &pos_v, &n_pos);
+      const uint32_t* sbuf = (const uint32_t*)buf_v;
+      const uint32_t* spos = (const uint32_t*)pos_v;
+      const size_t nw = std::min<size_t>(batch, 1u << 20);
+      std::vector<uint32_t> off(nw + 1, 0), w1;
+      if (n_pos) {
+        w1.reserve(nw * 24);
+        for (size_t q = 0; q < nw; q++) {
+          const uint32_t sp = spos[(q * 7919u) % n_pos], len = sbuf[sp];   // spread over the memory
+          w1.insert(w1.end(), sbuf + sp + 1, sbuf + sp + 1 + len);
+          off[q + 1] = (uint32_t)w1.size();
+        }
+      }
+      if (w1.empty()) w1.push_back(1u);
       std::vector<std::thread> warm;
       for (int k = 0; k < kGpuCalls; k++)
         warm.emplace_back([&] {
           std::vector<fmx_match> out(nw * cap0);
           std::vector<uint32_t> c1(nw), t1(nw);
-          fmx_batch b1 = {nw, off.data(), w1.data(), nullptr, nullptr, (uint32_t)len};
+          fmx_batch b1 = {nw, off.data(), w1.data(), nullptr, nullptr, 0};
           (void)fmx_match_batch(ix, &prm, &b1, out.data(), c1.data(), t1.data(), cap0, nullptr);
         });
       for (auto& t : warm) t.join();
@@ -348,7 +362,7 @@ int main(int argc, char** argv) {
     }
     tick(subseq ? "Subsequencing" : "Matching");
     const bool timing = getenv("FMX_CLI_TIMING") != nullptr;
-    std::atomic<uint64_t> us_gpu{0}, us_fmt{0}, us_read{0}, us_write{0}, us_wait_job{0};
+    std::atomic<uint64_t> us_gpu{0}, us_fmt{0}, us_read{0}, us_write{0}, us_wait_job{0}, n_retries{0}, us_gpu_max{0};
     auto now_us = [] { return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     std::atomic<bool> failed{false};
     std::string fail_msg;
@@ -392,7 +406,7 @@ int main(int argc, char** argv) {
         for (;;) {  // nmatch == 0 (no limit): grow the per-query capacity until nothing is truncated
           job->need_out(n, cap);
           int rc;
-          { GpuSlot slot(gpu_mu, gpu_cv, gpu_busy); const uint64_t a = now_us(); rc = fmx_match_batch_lines(ix, &prm, job->text, job->n_bytes, n, job->out, job->cnt, job->tot, cap, nullptr); us_gpu += now_us() - a; }
+          { GpuSlot slot(gpu_mu, gpu_cv, gpu_busy); const uint64_t a = now_us(); fmx_stats fs; memset(&fs, 0, sizeof fs); rc = fmx_match_batch_lines(ix, &prm, job->text, job->n_bytes, n, job->out, job->cnt, job->tot, cap, timing ? &fs : nullptr); const uint64_t d = now_us() - a; us_gpu += d; n_retries += fs.n_retries; uint64_t mx = us_gpu_max.load(); while (d > mx && !us_gpu_max.compare_exchange_weak(mx, d)) {} }
           if (rc != FMX_OK) { fail(fmx_last_error()); return; }
           uint32_t mx = 0;
           for (size_t q = 0; q < n; q++) mx = job->tot[q] > mx ? job->tot[q] : mx;
@@ -614,7 +628,7 @@ int main(int argc, char** argv) {
     free_jobs.close();
     if (timing)
       std::cerr << "TIMING\tread_ms\t" << us_read / 1e3 << "\twait_free_block_ms\t" << us_wait_job / 1e3 << "\tgpu_calls_ms(sum)\t" << us_gpu / 1e3
-                << "\tformat_ms(sum)\t" << us_fmt / 1e3 << "\twrite_ms\t" << us_write / 1e3 << "\tworkers\t" << workers << "\tblocks\t" << n_jobs << std::endl;
+                << "\tformat_ms(sum)\t" << us_fmt / 1e3 << "\twrite_ms\t" << us_write / 1e3 << "\tgpu_call_max_ms\t" << us_gpu_max / 1e3 << "\tretries\t" << n_retries << "\tworkers\t" << workers << "\tblocks\t" << n_jobs << std::endl;
     if (failed) {
       std::cerr << "ERROR: " << fail_msg << std::endl;
       return 1;
