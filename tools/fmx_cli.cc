@@ -312,6 +312,12 @@ int main(int argc, char** argv) {
           std::vector<uint32_t> c1(nw), t1(nw);
           fmx_batch b1 = {nw, off.data(), w1.data(), nullptr, nullptr, 0};
           (void)fmx_match_batch(ix, &prm, &b1, out.data(), c1.data(), t1.data(), cap0, nullptr);
+          if (lines_path) {  // ... and the line path's own buffers and kernels: a block of the same shape, of words no memory holds
+            std::string dummy;
+            dummy.reserve(nw * 120);
+            for (size_t q = 0; q < nw; q++) { for (int k = 0; k < 24; k++) dummy += "?w?w "; dummy.back() = '\n'; }
+            (void)fmx_match_batch_lines(ix, &prm, dummy.data(), dummy.size(), nw, out.data(), c1.data(), t1.data(), cap0, nullptr);
+          }
         });
       for (auto& t : warm) t.join();
     }
@@ -363,7 +369,9 @@ int main(int argc, char** argv) {
     tick(subseq ? "Subsequencing" : "Matching");
     const bool timing = getenv("FMX_CLI_TIMING") != nullptr;
     std::atomic<uint64_t> us_gpu{0}, us_fmt{0}, us_read{0}, us_write{0}, us_wait_job{0}, n_retries{0}, us_gpu_max{0};
+    std::atomic<uint64_t> t_gpu_first_end{0}, t_gpu_last_end{0}, t_read_end{0}, t_fmt_last_end{0};
     auto now_us = [] { return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const uint64_t t_tick = now_us();
     std::atomic<bool> failed{false};
     std::string fail_msg;
     std::mutex fail_mu;
@@ -406,7 +414,7 @@ int main(int argc, char** argv) {
         for (;;) {  // nmatch == 0 (no limit): grow the per-query capacity until nothing is truncated
           job->need_out(n, cap);
           int rc;
-          { GpuSlot slot(gpu_mu, gpu_cv, gpu_busy); const uint64_t a = now_us(); fmx_stats fs; memset(&fs, 0, sizeof fs); rc = fmx_match_batch_lines(ix, &prm, job->text, job->n_bytes, n, job->out, job->cnt, job->tot, cap, timing ? &fs : nullptr); const uint64_t d = now_us() - a; us_gpu += d; n_retries += fs.n_retries; uint64_t mx = us_gpu_max.load(); while (d > mx && !us_gpu_max.compare_exchange_weak(mx, d)) {} }
+          { GpuSlot slot(gpu_mu, gpu_cv, gpu_busy); const uint64_t a = now_us(); fmx_stats fs; memset(&fs, 0, sizeof fs); rc = fmx_match_batch_lines(ix, &prm, job->text, job->n_bytes, n, job->out, job->cnt, job->tot, cap, timing ? &fs : nullptr); const uint64_t d = now_us() - a; us_gpu += d; n_retries += fs.n_retries; { uint64_t z = 0; t_gpu_first_end.compare_exchange_strong(z, a + d - t_tick); t_gpu_last_end.store(a + d - t_tick); } uint64_t mx = us_gpu_max.load(); while (d > mx && !us_gpu_max.compare_exchange_weak(mx, d)) {} }
           if (rc != FMX_OK) { fail(fmx_last_error()); return; }
           uint32_t mx = 0;
           for (size_t q = 0; q < n; q++) mx = job->tot[q] > mx ? job->tot[q] : mx;
@@ -531,6 +539,7 @@ int main(int argc, char** argv) {
         if (job->cnt[q]) job->nonempty++;
       }
       us_fmt += now_us() - t_fmt;
+      t_fmt_last_end.store(now_us() - t_tick);
     };
 
     std::vector<std::thread> work_threads;
@@ -620,6 +629,7 @@ int main(int argc, char** argv) {
         if (eof && carry.empty()) break;
       }
       jobs_made.store(seq);
+      t_read_end.store(now_us() - t_tick);
       to_work.close();
     }
     for (auto& t : work_threads) t.join();
@@ -628,7 +638,8 @@ int main(int argc, char** argv) {
     free_jobs.close();
     if (timing)
       std::cerr << "TIMING\tread_ms\t" << us_read / 1e3 << "\twait_free_block_ms\t" << us_wait_job / 1e3 << "\tgpu_calls_ms(sum)\t" << us_gpu / 1e3
-                << "\tformat_ms(sum)\t" << us_fmt / 1e3 << "\twrite_ms\t" << us_write / 1e3 << "\tgpu_call_max_ms\t" << us_gpu_max / 1e3 << "\tretries\t" << n_retries << "\tworkers\t" << workers << "\tblocks\t" << n_jobs << std::endl;
+                << "\tformat_ms(sum)\t" << us_fmt / 1e3 << "\twrite_ms\t" << us_write / 1e3 << "\tat_ms:first_gpu_done/read_done/last_gpu_done/last_format_done/end\t" << t_gpu_first_end / 1e3 << "/" << t_read_end / 1e3 << "/" << t_gpu_last_end / 1e3 << "/"
+                << t_fmt_last_end / 1e3 << "/" << (now_us() - t_tick) / 1e3 << "\tgpu_call_max_ms\t" << us_gpu_max / 1e3 << "\tretries\t" << n_retries << "\tworkers\t" << workers << "\tblocks\t" << n_jobs << std::endl;
     if (failed) {
       std::cerr << "ERROR: " << fail_msg << std::endl;
       return 1;
