@@ -266,13 +266,13 @@ def main():
                 self.d_tok = torch.from_numpy(self.q_tok.astype(np.int32)).to(dev)
 
     t0 = time.time()
-    main_set = [Workload(o, t, k < NB_host) for k, (o, t) in enumerate(raw_main)]
+    main_set = [Workload(o, t, True) for k, (o, t) in enumerate(raw_main)]
     other_set = [Workload(o, t, True) for (o, t) in raw_other]
     del raw_main, raw_other
     nq_max = max([w.nq for w in main_set + other_set] + [1])
     # one result slot per call in flight, shared by the batches (step i writes slot i % T)
     out_slots = [(fmx.pinned_empty((nq_max, cap), fmx.MATCH_DTYPE), fmx.pinned_empty(nq_max, np.uint32), fmx.pinned_empty(nq_max, np.uint32))
-                 for _ in range(T_host)]
+                 for _ in range(max(T_host, T_dev))]
     log(f"[bench] batches pinned + packed as text in {time.time() - t0:.1f}s ({main_set[0].text.nbytes / 1e6:.0f} MB of spellings, "
         f"{main_set[0].q_tok.nbytes / 1e6:.0f} MB of ids per batch)")
 
@@ -374,6 +374,31 @@ def main():
         if gather is not None:
             gather.wait_all()
 
+    def run_text_pipeline(wls, k_steps, gather=None):
+        """The text batches of the value leg driven by ONE host thread: fmx_match_batch_text_begin enqueues a step's copies in, its id
+        lookup and its passes and returns, _end waits and brings the records home; T_dev steps in flight, each in its own context
+        (step i, batch i % len(wls), begins when step i - T has ended)."""
+        T = T_dev
+        nb = len(wls)
+
+        def begin(i):
+            wl = wls[i % nb]
+            keep = None
+            if gather is not None:
+                d_out, d_cnt = gather.buffers(i, host_sync=True)
+                keep = (d_out.data_ptr(), d_cnt.data_ptr())
+            return ix.text_begin(params, wl.q_off, wl.text, out_slots[i % T], cap, keep=keep)
+
+        pending = {i: begin(i) for i in range(min(T, k_steps))}
+        for i in range(k_steps):
+            ix.text_end(pending.pop(i))
+            if gather is not None:
+                gather.launch(i)
+            if i + T < k_steps:
+                pending[i + T] = begin(i + T)
+        if gather is not None:
+            gather.wait_all()
+
     st_out = torch.zeros((nq_max, cap, 4), dtype=torch.int32, device=dev)
     st_cnt = torch.zeros((nq_max,), dtype=torch.int32, device=dev)
 
@@ -467,6 +492,21 @@ def main():
     elapsed, text_stats = measure_host(host_set, "text", args.steps, "value")
     nq_step_all = all_ranks(host_set[0].nq)
     value = nq_step_all * args.steps / elapsed
+    # the same bracket with ONE host thread keeping T_dev text batches in flight (fmx_match_batch_text_begin / _end)
+    text_async = None
+    if os.environ.get("FMX_BENCH_TEXT_ASYNC", "1") != "0":
+        g2 = make_gather(main_set)
+        run_text_pipeline(main_set, 2 * T_dev, g2)
+        run_text_pipeline(main_set, args.warmup, g2)
+        el_a, _ = timed(lambda k: run_text_pipeline(main_set, k, g2), args.steps)
+        if rank == 0 and args.verify:
+            i = args.steps - 1
+            b_ = i % len(main_set)
+            idx = sample_idx(main_set[b_].nq)
+            o_, c_, _t = out_slots[i % T_dev]
+            samples["text_one_thread"] = (b_, idx, o_[idx].copy(), c_[idx].copy())
+        text_async = {"value": round(nq_step_all * args.steps / el_a, 1), "ms_per_step": round(el_a / args.steps * 1e3, 3), "calls_in_flight": T_dev,
+                      "note": "the value leg's bracket with ONE host thread: fmx_match_batch_text_begin / _end, every step in its own context"}
     # ---- side legs ----
     elapsed_dev = measure_device(main_set, "device_resident")
     value_dev = nq_step_all * args.steps / elapsed_dev
@@ -578,6 +618,8 @@ def main():
             f"{elapsed / args.steps * 1e3:.3f} ms/step; device-resident ({T_dev} in flight): {value_dev / 1e6:.2f} M, {elapsed_dev / args.steps * 1e3:.3f} ms/step; "
             f"from ids in pinned host memory: {value_ids / 1e6:.2f} M, {elapsed_ids / args.steps * 1e3:.3f} ms/step (pinned={ids_stats[-1].pinned}); "
             f"one call at a time with stage events: {main_set[0].nq * args.steps / el_dev / 1e6:.2f} M patterns/s")
+        if text_async:
+            log(f"[bench] text batches from one host thread (begin / end, {T_dev} in flight): {text_async['value'] / 1e6:.2f} M patterns/s, {text_async['ms_per_step']:.3f} ms/step")
         log(f"[bench] value-leg calls: retries {sum(int(s.n_retries) for s in text_stats)}, ms per call min/median/max "
             f"{min(s.ms_total for s in text_stats):.2f}/{float(np.median([s.ms_total for s in text_stats])):.2f}/{max(s.ms_total for s in text_stats):.2f}")
         log(f"[bench] kernel ms/step by stage: { {k: round(v, 3) for k, v in per_stage.items()} }")
@@ -673,7 +715,7 @@ def main():
             bad = {}
             want = {}
             for leg, (b, idx, recs, cnts) in samples.items():
-                wl = (host_set if leg in ("value", "pcie_inclusive_ids") else main_set)[b]
+                wl = (host_set if leg in ("value", "pcie_inclusive_ids") else main_set)[b]   # (host_set is a prefix of main_set)
                 key = (id(wl), len(idx))
                 if key not in want:
                     s_off, s_tok = take_queries(wl.q_off, wl.q_tok, idx)
@@ -736,7 +778,7 @@ def main():
             "pcie_inclusive_ids": {"value": round(value_ids, 1), "ms_per_step": round(elapsed_ids / args.steps * 1e3, 3), "calls_in_flight": T_host,
                                    "note": "fmx_match_batch: vocabulary ids in pinned host memory in, records out (H2D + kernels + D2H"
                                            + (" + the RCCL gather" if world > 1 else "") + "): a caller that already holds ids"},
-            "from_token_strings": from_strings, "cli_end_to_end": cli_leg,
+            "text_one_thread": text_async, "from_token_strings": from_strings, "cli_end_to_end": cli_leg,
             "staged": {"value": round(nq_step_all * args.steps / el_dev, 1),
                        "ms_per_step": round(el_dev / args.steps * 1e3, 3),
                        "stage_ms_per_step": {k: round(v, 4) for k, v in per_stage.items()},

