@@ -202,7 +202,8 @@ def test_text_begin_end_keeps_several_batches_in_flight_from_one_thread(fmx, tex
             out[1][:] = 0
     # a text with the wrong number of spellings fails at _end
     q, t, out, _ = batches[0]
-    h = ix.text_begin(fmx.Params(**kw), q, fmx.pinned_copy(np.asarray(t[:-3])), out, 5)
+    nuls = np.flatnonzero(np.asarray(t) == 0)
+    h = ix.text_begin(fmx.Params(**kw), q, fmx.pinned_copy(np.asarray(t[:nuls[-2] + 1])), out, 5)   # the last spelling is missing
     with pytest.raises(fmx.FmxError):
         ix.text_end(h)
     ix.set_option("contexts", 4)
