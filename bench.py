@@ -4,18 +4,20 @@
 One "step" = one batch of synthetic query patterns through the C-ABI (include/fmx.h).  `value` is measured on the bracket
 SURVEY §8(d) gives the metric — the phase the reference CLI times between TICK("Matching") and TICK("Done")
 (cli/src/FuzzyMatch-cli.cc:450-467): per-query host prep (vocabulary id lookup), H2D of the queries, every kernel, D2H of
-the records.  A step of that leg is one `fmx_match_batch_text` call: the patterns are handed over as what a tokenizer holds —
-packed token SPELLINGS in pinned host memory — the ids are looked up on the device (k_vocab_lookup), the pipeline runs, the
-top-N records come back to pinned host buffers.  Several synchronous calls are kept in flight from host threads, like the
-reference's N worker threads call match().
+the records.  A step of that leg is one text batch: the patterns are handed over as what a tokenizer holds — packed token
+SPELLINGS in pinned host memory —, the ids are looked up on the device (k_vocab_lookup), the pipeline runs, the top-N records come
+back to pinned host buffers.  One host thread keeps five steps in flight (fmx_match_batch_text_begin / _end, each step in its own
+context), like the reference's N worker threads keep N patterns in flight.
 
 Every leg rotates DISTINCT query batches (seeds QUERY_SEED + k, one more batch than calls in flight) through its calls, so that
 calls overlapping on the GPU never walk the same index lines a fraction of a millisecond apart.
 
 Side legs in the same JSON line (never `value`):
+  text_sync_callers   the value leg's bracket from four synchronous callers (fmx_match_batch_text on as many host threads)
   device_resident     the same steps through fmx_match_batch_device_begin/_end: offsets / ids already in HBM, records left in HBM
   pcie_inclusive_ids  fmx_match_batch: vocabulary ids in pinned host memory in, records out (no lookup: the caller already holds ids)
   from_token_strings  fmx_vocab_lookup_mt on host threads inside the timed region, then fmx_match_batch
+  cli_end_to_end      tools/fmx-cli --tokenised on the run's own index (through a .fmi file) and first batch: stdin -> stdout
   staged              one device-resident call at a time with per-stage HIP events: the kernel times the rooflines are priced with
 
 Workload = BASELINE config C3 (5 M-sentence synthetic corpus, mean 25 tokens, 1 M queries per step, fuzzy 0.7, nmatch 5) unless
@@ -75,6 +77,9 @@ def parse_args():
     ap.add_argument("--host-threads", type=int, default=int(os.environ.get("FMX_BENCH_HOST_THREADS", "4")),
                     help="synchronous host-buffer calls in flight (one host thread each) — the `value` leg and the other PCIe-inclusive legs: each adds "
                          "two copy streams to its two compute streams, and beyond ~24 busy hardware queues the GPU's scheduler starts time-slicing them")
+    ap.add_argument("--text-calls", type=int, default=int(os.environ.get("FMX_BENCH_TEXT_CALLS", "5")),
+                    help="text batches the value leg keeps in flight (fmx_match_batch_text_begin / _end, one host thread): five measured best — "
+                         "six run into the scheduler's time-slicing now and then like six synchronous callers do")
     ap.add_argument("--batches", type=int, default=0, help="distinct query batches rotated through the steps (0 = calls in flight + 1)")
     ap.add_argument("--force-gather", action="store_true", help="N = 1 test of the N > 1 step: records also kept in HBM for the (empty) gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -174,6 +179,7 @@ def main():
     log = (lambda *a: print(*a, file=sys.stderr, flush=True)) if rank == 0 else (lambda *a: None)
     T_dev = max(args.threads, 1)
     T_host = max(min(args.host_threads, args.threads), 1)
+    T_text = max(min(args.text_calls, args.threads), 1)
     NB = args.batches or (T_dev + 1)          # distinct batches of the device-resident legs
     NB_host = min(NB, T_host + 1) if not args.batches else NB   # ... of the host-buffer legs (fewer calls in flight)
 
@@ -272,7 +278,7 @@ def main():
     nq_max = max([w.nq for w in main_set + other_set] + [1])
     # one result slot per call in flight, shared by the batches (step i writes slot i % T)
     out_slots = [(fmx.pinned_empty((nq_max, cap), fmx.MATCH_DTYPE), fmx.pinned_empty(nq_max, np.uint32), fmx.pinned_empty(nq_max, np.uint32))
-                 for _ in range(max(T_host, T_dev))]
+                 for _ in range(max(T_host, T_dev, T_text))]
     log(f"[bench] batches pinned + packed as text in {time.time() - t0:.1f}s ({main_set[0].text.nbytes / 1e6:.0f} MB of spellings, "
         f"{main_set[0].q_tok.nbytes / 1e6:.0f} MB of ids per batch)")
 
@@ -375,10 +381,11 @@ def main():
             gather.wait_all()
 
     def run_text_pipeline(wls, k_steps, gather=None):
-        """The text batches of the value leg driven by ONE host thread: fmx_match_batch_text_begin enqueues a step's copies in, its id
-        lookup and its passes and returns, _end waits and brings the records home; T_dev steps in flight, each in its own context
-        (step i, batch i % len(wls), begins when step i - T has ended)."""
-        T = T_dev
+        """THE METRIC.  The text batches driven by ONE host thread: fmx_match_batch_text_begin enqueues a step's copies in, its id
+        lookup and its passes and returns, _end waits and brings the records home; T_text steps in flight, each in its own context
+        (step i, batch i % len(wls), begins when step i - T has ended).  N > 1: each step's records also stay in HBM and are gathered
+        to rank 0 over RCCL; the gathers are launched in step order, so every rank issues its collectives in the same order."""
+        T = T_text
         nb = len(wls)
 
         def begin(i):
@@ -420,9 +427,9 @@ def main():
         torch.cuda.synchronize()
         return
     if args.child and os.environ.get("FMX_CHILD_MODE") == "text":      # design-time: trace of the timed region of `value`
-        run_host_steps(main_set[:NB_host], 2 * T_host + args.warmup, "text")
+        run_text_pipeline(main_set[:T_text + 1], 2 * T_text + args.warmup)
         torch.cuda.synchronize()
-        run_host_steps(main_set[:NB_host], args.steps, "text")
+        run_text_pipeline(main_set[:T_text + 1], args.steps)
         torch.cuda.synchronize()
         return
     if args.child:  # profiling child of a --pmc pass: device-resident steps one at a time, nothing else
@@ -488,33 +495,36 @@ def main():
         return int(t.item())
 
     host_set = main_set[:NB_host]
+    text_set = main_set[:min(len(main_set), T_text + 1)]
     # ---- THE METRIC: SURVEY §8(d)'s bracket.  Packed spellings in pinned host memory -> H2D -> k_vocab_lookup -> pipeline -> D2H ----
-    elapsed, text_stats = measure_host(host_set, "text", args.steps, "value")
-    nq_step_all = all_ranks(host_set[0].nq)
-    value = nq_step_all * args.steps / elapsed
-    # the same bracket with ONE host thread keeping T_dev text batches in flight (fmx_match_batch_text_begin / _end)
-    text_async = None
-    if os.environ.get("FMX_BENCH_TEXT_ASYNC", "1") != "0":
-        g2 = make_gather(main_set)
-        run_text_pipeline(main_set, 2 * T_dev, g2)
-        run_text_pipeline(main_set, args.warmup, g2)
-        el_a, _ = timed(lambda k: run_text_pipeline(main_set, k, g2), args.steps)
-        if rank == 0 and args.verify:
+    def measure_text(wls, leg):
+        gather = make_gather(wls)
+        run_text_pipeline(wls, 2 * T_text, gather)   # set-up: every context in flight sizes its workspace once
+        run_text_pipeline(wls, args.warmup, gather)
+        el, _ = timed(lambda k: run_text_pipeline(wls, k, gather), args.steps)
+        if leg and rank == 0 and args.verify:
             i = args.steps - 1
-            b_ = i % len(main_set)
-            idx = sample_idx(main_set[b_].nq)
-            o_, c_, _t = out_slots[i % T_dev]
-            samples["text_one_thread"] = (b_, idx, o_[idx].copy(), c_[idx].copy())
-        text_async = {"value": round(nq_step_all * args.steps / el_a, 1), "ms_per_step": round(el_a / args.steps * 1e3, 3), "calls_in_flight": T_dev,
-                      "note": "the value leg's bracket with ONE host thread: fmx_match_batch_text_begin / _end, every step in its own context"}
+            b_ = i % len(wls)
+            idx = sample_idx(wls[b_].nq)
+            o_, c_, _t = out_slots[i % T_text]
+            samples[leg] = (b_, idx, o_[idx].copy(), c_[idx].copy())
+        return el
+
+    elapsed = measure_text(text_set, "value")
+    nq_step_all = all_ranks(text_set[0].nq)
+    value = nq_step_all * args.steps / elapsed
     # ---- side legs ----
+    # the same bracket from T_host synchronous callers (fmx_match_batch_text on as many host threads: the reference's calling pattern)
+    el_sync, text_stats = measure_host(host_set, "text", args.steps, "text_sync_callers")
+    text_sync = {"value": round(nq_step_all * args.steps / el_sync, 1), "ms_per_step": round(el_sync / args.steps * 1e3, 3), "calls_in_flight": T_host,
+                 "note": "the value leg's bracket with synchronous calls: fmx_match_batch_text from as many host threads"}
     elapsed_dev = measure_device(main_set, "device_resident")
     value_dev = nq_step_all * args.steps / elapsed_dev
     elapsed_ids, ids_stats = measure_host(host_set, "ids", args.steps, "pcie_inclusive_ids")
     value_ids = nq_step_all * args.steps / elapsed_ids
     scaling_other = None
     if world > 1:
-        el2, _ = measure_host(other_set, "text", args.steps, None)
+        el2 = measure_text(other_set[:min(len(other_set), T_text + 1)], None)
         el2d = measure_device(other_set, None)
         n2 = all_ranks(other_set[0].nq)
         scaling_other = {"scaling": other_scaling, "value": round(n2 * args.steps / el2, 1),
@@ -614,13 +624,12 @@ def main():
 
     line = None
     if rank == 0:
-        log(f"[bench] value (packed spellings in pinned host memory -> records in pinned host memory, {T_host} calls in flight): {value / 1e6:.2f} M patterns/s, "
+        log(f"[bench] value (packed spellings in pinned host memory -> records in pinned host memory, {T_text} text batches in flight from one host thread): {value / 1e6:.2f} M patterns/s, "
             f"{elapsed / args.steps * 1e3:.3f} ms/step; device-resident ({T_dev} in flight): {value_dev / 1e6:.2f} M, {elapsed_dev / args.steps * 1e3:.3f} ms/step; "
             f"from ids in pinned host memory: {value_ids / 1e6:.2f} M, {elapsed_ids / args.steps * 1e3:.3f} ms/step (pinned={ids_stats[-1].pinned}); "
             f"one call at a time with stage events: {main_set[0].nq * args.steps / el_dev / 1e6:.2f} M patterns/s")
-        if text_async:
-            log(f"[bench] text batches from one host thread (begin / end, {T_dev} in flight): {text_async['value'] / 1e6:.2f} M patterns/s, {text_async['ms_per_step']:.3f} ms/step")
-        log(f"[bench] value-leg calls: retries {sum(int(s.n_retries) for s in text_stats)}, ms per call min/median/max "
+        log(f"[bench] the same from {T_host} synchronous callers: {text_sync['value'] / 1e6:.2f} M patterns/s, {text_sync['ms_per_step']:.3f} ms/step")
+        log(f"[bench] synchronous text calls: retries {sum(int(s.n_retries) for s in text_stats)}, ms per call min/median/max "
             f"{min(s.ms_total for s in text_stats):.2f}/{float(np.median([s.ms_total for s in text_stats])):.2f}/{max(s.ms_total for s in text_stats):.2f}")
         log(f"[bench] kernel ms/step by stage: { {k: round(v, 3) for k, v in per_stage.items()} }")
         log(f"[bench] mean step: hits {n_hits:.0f} (bit planes {n_heavy_hits:.0f}, passed {mean_ctr('n_heavy_pass'):.0f}) phaseB {n_phase_b:.0f} "
@@ -715,7 +724,7 @@ def main():
             bad = {}
             want = {}
             for leg, (b, idx, recs, cnts) in samples.items():
-                wl = (host_set if leg in ("value", "pcie_inclusive_ids") else main_set)[b]   # (host_set is a prefix of main_set)
+                wl = main_set[b]   # (every leg's batches are a prefix of main_set)
                 key = (id(wl), len(idx))
                 if key not in want:
                     s_off, s_tok = take_queries(wl.q_off, wl.q_tok, idx)
@@ -753,7 +762,7 @@ def main():
                                       f"{os.cpu_count()} hardware threads), ids in (no lookup), {dt:.1f}s"}
         o.close()
 
-        text_bytes = int(host_set[0].text.nbytes)
+        text_bytes = int(text_set[0].text.nbytes)
         line = {
             "metric": "query patterns/sec @ fuzzy=0.7, 5M-sentence .fmi; 1/2/4/8 GPU + CPU ref",
             "value": round(value, 1), "unit": "patterns/s", "n_gpus": world, "steps": args.steps,
@@ -763,12 +772,12 @@ def main():
                                    f"{nq_cfg} queries per {'GPU' if args.scaling == 'weak' else 'job'} per step, "
                                    + " ".join(f"{k}={v}" for k, v in pkw.items()),
                        "queries_per_step_all_ranks": nq_step_all, "sentences": n_sent, "index_bytes_hbm": int(info.device_bytes),
-                       "timed_path": "SURVEY §8(d)'s bracket (cli/src/FuzzyMatch-cli.cc:450-467), PCIe inside: fmx_match_batch_text per step — packed token "
-                                     f"spellings in pinned host memory ({text_bytes} B per step) -> H2D -> vocabulary id lookup on the device (k_vocab_lookup) -> "
-                                     f"every kernel of the pipeline -> D2H of the top-N records into pinned host memory; {T_host} synchronous call(s) in flight "
-                                     f"(one host thread each, each in its own context); {len(host_set)} distinct query batches rotate through the steps"
+                       "timed_path": "SURVEY §8(d)'s bracket (cli/src/FuzzyMatch-cli.cc:450-467), PCIe inside: one text batch per step (fmx_match_batch_text_begin / _end) — "
+                                     f"packed token spellings in pinned host memory ({text_bytes} B per step) -> H2D -> vocabulary id lookup on the device "
+                                     f"(k_vocab_lookup) -> every kernel of the pipeline -> D2H of the top-N records into pinned host memory; {T_text} step(s) in flight, "
+                                     f"enqueued and collected by one host thread, each in its own context; {len(text_set)} distinct query batches rotate through the steps"
                                      + (", + RCCL gather of every step's records to rank 0 (asynchronous, under the steps in flight)" if world > 1 else ""),
-                       "distinct_batches": {"value_leg": len(host_set), "device_resident": len(main_set), "seeds": f"QUERY_SEED + k{' + 101 x rank' if args.scaling == 'weak' else ''}"},
+                       "distinct_batches": {"value_leg": len(text_set), "device_resident": len(main_set), "seeds": f"QUERY_SEED + k{' + 101 x rank' if args.scaling == 'weak' else ''}"},
                        "index_via_fmi": via_fmi,
                        "parallelism": f"queries sharded over {world} GPU(s), index replicated"},
             "roofline": dominant, "roofline_other": others, "reference_byte_model": ref_model,
@@ -778,7 +787,7 @@ def main():
             "pcie_inclusive_ids": {"value": round(value_ids, 1), "ms_per_step": round(elapsed_ids / args.steps * 1e3, 3), "calls_in_flight": T_host,
                                    "note": "fmx_match_batch: vocabulary ids in pinned host memory in, records out (H2D + kernels + D2H"
                                            + (" + the RCCL gather" if world > 1 else "") + "): a caller that already holds ids"},
-            "text_one_thread": text_async, "from_token_strings": from_strings, "cli_end_to_end": cli_leg,
+            "text_sync_callers": text_sync, "from_token_strings": from_strings, "cli_end_to_end": cli_leg,
             "staged": {"value": round(nq_step_all * args.steps / el_dev, 1),
                        "ms_per_step": round(el_dev / args.steps * 1e3, 3),
                        "stage_ms_per_step": {k: round(v, 4) for k, v in per_stage.items()},
