@@ -82,15 +82,44 @@ template <class T> static T* dev_upload(const std::vector<T>& v) {
   return p;
 }
 
+// hipFree waits for EVERYTHING in flight on the device.  A workspace buffer that grows while other calls are in flight (the first
+// calls on an index, a batch with a heavier query than any before) used to free its old block on the spot: with five calls in
+// flight every one of the ~10 buffers of a context cost a device-wide wait, the other contexts followed as the learned sizes
+// spread, and a run of 12 steps took four seconds instead of 70 ms (the "stall" of rounds 2-3: it was never the GPU's scheduler).
+// Outgrown blocks are parked instead and freed when the process is quiet: at the destruction of an index, or — should they ever
+// add up to more than kParkedMax — after one explicit synchronisation.
+struct ParkedBlocks {
+  std::mutex mu;
+  std::vector<std::pair<void*, uint64_t>> blocks;
+  uint64_t bytes = 0;
+  static constexpr uint64_t kParkedMax = 48ull << 30;
+  void park(void* p, uint64_t n) {
+    std::vector<std::pair<void*, uint64_t>> drop;
+    {
+      std::lock_guard<std::mutex> g(mu);
+      blocks.emplace_back(p, n);
+      bytes += n;
+      if (bytes > kParkedMax) { drop.swap(blocks); bytes = 0; }
+    }
+    if (!drop.empty()) { (void)hipDeviceSynchronize(); for (auto& b : drop) (void)hipFree(b.first); }
+  }
+  void drain() {  // the caller has synchronised the device
+    std::vector<std::pair<void*, uint64_t>> drop;
+    { std::lock_guard<std::mutex> g(mu); drop.swap(blocks); bytes = 0; }
+    for (auto& b : drop) (void)hipFree(b.first);
+  }
+};
+static ParkedBlocks& parked_blocks() { static ParkedBlocks* pb = new ParkedBlocks; return *pb; }
+
 // device buffer that only ever grows, by at least 1.5x (first-call and heavy-tail latency cliffs: one buffer
-// growing never frees the others)
+// growing never frees the others); the outgrown block is parked, not freed (see ParkedBlocks)
 template <class T> struct Grow {
   T*       p = nullptr;
   uint64_t cap = 0;
   bool ensure(uint64_t need) {  // true if reallocated
     if (need <= cap && p) return false;
     const uint64_t c = std::max<uint64_t>(need, cap + cap / 2);
-    if (p) (void)hipFree(p);
+    if (p) parked_blocks().park(p, cap * sizeof(T));
     p = nullptr; cap = 0;
     p = dev_alloc<T>(c);
     cap = c;
@@ -329,6 +358,8 @@ struct DeviceIndex::Impl {
   // interned by derive()); only indexes whose real tokens differ from the normalised ones have one
   DevVocab                real_vocab{};
   DevBlob                 real_hold;
+  std::mutex              word_mu;     // scratch words of sub_bounds_from_device
+  std::vector<uint32_t*>  word_pool;
   std::mutex              pool_mu;
   std::condition_variable pool_cv;
   std::vector<std::unique_ptr<Ctx>> all;
@@ -389,6 +420,9 @@ DeviceIndex::~DeviceIndex() {
     hipFree((void*)m.d.qva); hipFree((void*)m.d.idf); hipFree((void*)m.d.real); hipFree((void*)m.d.itok);
     hipFree((void*)m.d.planes); hipFree((void*)m.d.thermo);
     for (auto& c : m.all) c->destroy();
+    parked_blocks().drain();  // (the device was synchronised above)
+    for (uint32_t* wp : m.word_pool) (void)hipFree(wp);
+    m.word_pool.clear();
     m.itok_hold.reset(); m.vocab_hold.reset();
     if (m.copy_h2d) (void)hipStreamDestroy(m.copy_h2d);
     if (m.copy_d2h) (void)hipStreamDestroy(m.copy_d2h);
@@ -2113,13 +2147,17 @@ std::vector<uint32_t> DeviceIndex::sub_bounds_from_device(const uint32_t* d_q_of
   HIP_TRY(hipMemcpyAsync(&bounds[k], d_q_off + nq, 4, hipMemcpyDeviceToHost, stream));
   uint32_t* d_pm = nullptr;
   if (p_max && *p_max == 0 && nq) {
-    d_pm = dev_alloc<uint32_t>(1);
+    {  // a scratch word from the index's pool (no allocation and no hipFree — a device-wide wait — per call)
+      std::lock_guard<std::mutex> g(m.word_mu);
+      if (!m.word_pool.empty()) { d_pm = m.word_pool.back(); m.word_pool.pop_back(); }
+    }
+    if (!d_pm) d_pm = dev_alloc<uint32_t>(1);
     HIP_TRY(hipMemsetAsync(d_pm, 0, 4, stream));
     hipLaunchKernelGGL(k_pmax, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, stream, d_q_off, nq, d_pm);
     HIP_TRY(hipMemcpyAsync(p_max, d_pm, 4, hipMemcpyDeviceToHost, stream));
   }
   HIP_TRY(hipStreamSynchronize(stream));
-  if (d_pm) (void)hipFree(d_pm);
+  if (d_pm) { std::lock_guard<std::mutex> g(m.word_mu); m.word_pool.push_back(d_pm); }
   return bounds;
 }
 
