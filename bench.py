@@ -6,7 +6,7 @@ SURVEY §8(d) gives the metric — the phase the reference CLI times between TIC
 (cli/src/FuzzyMatch-cli.cc:450-467): per-query host prep (vocabulary id lookup), H2D of the queries, every kernel, D2H of
 the records.  A step of that leg is one text batch: the patterns are handed over as what a tokenizer holds — packed token
 SPELLINGS in pinned host memory —, the ids are looked up on the device (k_vocab_lookup), the pipeline runs, the top-N records come
-back to pinned host buffers.  One host thread keeps five steps in flight (fmx_match_batch_text_begin / _end, each step in its own
+back to pinned host buffers.  One host thread keeps four steps in flight (fmx_match_batch_text_begin / _end, each step in its own
 context), like the reference's N worker threads keep N patterns in flight.
 
 Every leg rotates DISTINCT query batches (seeds QUERY_SEED + k, one more batch than calls in flight) through its calls, so that
@@ -77,9 +77,11 @@ def parse_args():
     ap.add_argument("--host-threads", type=int, default=int(os.environ.get("FMX_BENCH_HOST_THREADS", "4")),
                     help="synchronous host-buffer calls in flight (one host thread each) — the `value` leg and the other PCIe-inclusive legs: each adds "
                          "two copy streams to its two compute streams, and beyond ~24 busy hardware queues the GPU's scheduler starts time-slicing them")
-    ap.add_argument("--text-calls", type=int, default=int(os.environ.get("FMX_BENCH_TEXT_CALLS", "5")),
-                    help="text batches the value leg keeps in flight (fmx_match_batch_text_begin / _end, one host thread): five measured best — "
-                         "six run into the scheduler's time-slicing now and then like six synchronous callers do")
+    ap.add_argument("--text-calls", type=int, default=int(os.environ.get("FMX_BENCH_TEXT_CALLS", "4")),
+                    help="text batches the value leg keeps in flight (fmx_match_batch_text_begin / _end, one host thread).  Four: ten busy hardware "
+                         "queues (two compute streams per call + the index's pair of copy streams).  Five run as fast in the steady state "
+                         "(5.9 ms per step either way) but spend their first seconds after the index build at 300 ms per step, six stay erratic and "
+                         "eight crawl throughout: beyond about a dozen recently active queues the GPU's scheduler time-slices them")
     ap.add_argument("--batches", type=int, default=0, help="distinct query batches rotated through the steps (0 = calls in flight + 1)")
     ap.add_argument("--force-gather", action="store_true", help="N = 1 test of the N > 1 step: records also kept in HBM for the (empty) gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
