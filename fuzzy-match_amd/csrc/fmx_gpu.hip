@@ -83,11 +83,12 @@ template <class T> static T* dev_upload(const std::vector<T>& v) {
 }
 
 // hipFree waits for EVERYTHING in flight on the device.  A workspace buffer that grows while other calls are in flight (the first
-// calls on an index, a batch with a heavier query than any before) used to free its old block on the spot: with five calls in
-// flight every one of the ~10 buffers of a context cost a device-wide wait, the other contexts followed as the learned sizes
-// spread, and a run of 12 steps took four seconds instead of 70 ms (the "stall" of rounds 2-3: it was never the GPU's scheduler).
-// Outgrown blocks are parked instead and freed when the process is quiet: at the destruction of an index, or — should they ever
-// add up to more than kParkedMax — after one explicit synchronisation.
+// calls on an index, a batch with a heavier query than any before) used to free its old block on the spot: every one of the ~10
+// buffers of a context then cost a device-wide wait, and the other contexts followed as the learned sizes spread.  Outgrown blocks
+// are parked instead and freed when the process is quiet: at the destruction of an index, or — should they ever add up to more
+// than kParkedMax — after one explicit synchronisation.  (This was suspected of being the multi-second stall with five and more
+// host-buffer calls in flight; it was not — that one is the GPU's scheduler time-slicing more than about a dozen recently active
+// hardware queues, DESIGN.md §4 — but a growing context no longer stops the others.)
 struct ParkedBlocks {
   std::mutex mu;
   std::vector<std::pair<void*, uint64_t>> blocks;
