@@ -538,10 +538,12 @@ def main():
     el_sync, text_stats = measure_host(host_set, "text", args.steps, "text_sync_callers")
     text_sync = {"value": round(nq_step_all * args.steps / el_sync, 1), "ms_per_step": round(el_sync / args.steps * 1e3, 3), "calls_in_flight": T_host,
                  "note": "the value leg's bracket with synchronous calls: fmx_match_batch_text from as many host threads"}
-    elapsed_dev = measure_device(main_set, "device_resident")
-    value_dev = nq_step_all * args.steps / elapsed_dev
+    # the host-buffer legs first: measured after the six-call device-resident leg (its contexts' queues still recently active)
+    # they stall now and then (DESIGN §5 "Stalls")
     elapsed_ids, ids_stats = measure_host(host_set, "ids", args.steps, "pcie_inclusive_ids")
     value_ids = nq_step_all * args.steps / elapsed_ids
+    elapsed_dev = measure_device(main_set, "device_resident")
+    value_dev = nq_step_all * args.steps / elapsed_dev
     scaling_other = None
     if world > 1:
         el2 = measure_text(other_set[:min(len(other_set), T_text + 1)], None)
