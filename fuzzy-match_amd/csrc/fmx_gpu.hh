@@ -80,6 +80,8 @@ struct SortResident {
   uint64_t  n_buf = 0, n_sent = 0, n_suf = 0;
 };
 void gpu_sort_resident_free(SortResident*);
+// throws unless `device` is a HIP ordinal of a gfx950 part
+void gpu_check_device(int device);
 // sorts h's suffix array on `device`; returns what stayed in HBM (nullptr for an empty index); the caller owns it
 SortResident* gpu_suffix_sort(HostIndex& h, int device);
 void* gpu_host_alloc(size_t bytes);  // pinned host memory (hipHostMalloc), nullptr on failure

@@ -56,7 +56,7 @@ int gpu_device_count() {
 
 // `device` is a HIP ordinal: it must exist and be a gfx950 part itself (a lower ordinal of another
 // architecture does not make a higher one usable, and vice versa)
-static void check_device(int device) {
+void gpu_check_device(int device) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); n = 0; }
   if (device < 0 || device >= n || !is_gfx950(device))
@@ -674,7 +674,7 @@ uint64_t DeviceIndex::download(int which, void* dst, uint64_t capacity_bytes) co
 void DeviceIndex::upload(const HostIndex& h, int device, SortResident* res) {
   Impl& m = *impl_;
   if (m.device >= 0) throw GpuError("index is already on a device");
-  check_device(device);
+  gpu_check_device(device);
   HIP_TRY(hipSetDevice(device));
   m.device = device;
   const uint64_t n_suf = h.num_suffixes();
@@ -2162,146 +2162,6 @@ std::vector<uint32_t> DeviceIndex::sub_bounds_from_device(const uint32_t* d_q_of
   return bounds;
 }
 
-// ---------------------------------------------------------------------------------------------
-// GPU suffix sort (index build): rocPRIM merge sort of (prefix, key) pairs
-// under SuffixArray::comp (src/suffix_array.cc:235-251).  Build-side utility, not the hot path.
-// ---------------------------------------------------------------------------------------------
-struct GpuSortKey {
-  unsigned long long prefix;  // tok0 << 32 | tok1
-  unsigned long long key;     // sid << 16 | pos
-};
-
-struct GpuSuffixLess {
-  const uint32_t* buf;
-  const uint32_t* sent_pos;
-  __device__ bool operator()(const GpuSortKey& a, const GpuSortKey& b) const {
-    if (a.prefix != b.prefix) return a.prefix < b.prefix;
-    const uint32_t sa = (uint32_t)(a.key >> 16), sb = (uint32_t)(b.key >> 16);
-    const uint32_t pa = (uint32_t)(a.key & 0xffff), pb = (uint32_t)(b.key & 0xffff);
-    const uint32_t* ba = buf + sent_pos[sa];
-    const uint32_t* bb = buf + sent_pos[sb];
-    const uint32_t la = ba[0] - (pa - 1), lb = bb[0] - (pb - 1);
-    const uint32_t mn = la < lb ? la : lb;
-    for (uint32_t i = 2; i < mn; i++) {
-      const uint32_t x = ba[pa + i], y = bb[pb + i];
-      if (x != y) return x < y;
-    }
-    if (la != lb) return la < lb;
-    return sa < sb;
-  }
-};
-
-// (sid, pos) of every suffix from the sentence buffer alone: one thread per buffer word; a token's sentence is found by bisecting
-// sent_pos (the suffixes are enumerated in buffer order, like SuffixArray::add_sentence does, src/suffix_array.cc:9-27)
-__global__ void k_enumerate_suffixes(const uint32_t* __restrict__ buf, const uint32_t* __restrict__ sent_pos, uint32_t n_sent,
-                                     unsigned long long n_buf, GpuSortKey* __restrict__ keys) {
-  const unsigned long long w = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (w >= n_buf) return;
-  uint32_t lo = 0, hi = n_sent;  // last sentence whose position is <= w
-  while (hi - lo > 1) { const uint32_t mid = lo + ((hi - lo) >> 1); if (sent_pos[mid] <= w) lo = mid; else hi = mid; }
-  const uint32_t sp = sent_pos[lo], len = buf[sp];
-  const uint32_t pos = (uint32_t)(w - sp);  // 0 = the length word, len + 1 = the terminator
-  if (pos == 0 || pos > len) return;
-  const unsigned long long i = w - 2ull * lo - 1ull;  // suffix number: buffer words minus the two framing words of every sentence before
-  GpuSortKey k;
-  k.prefix = ((unsigned long long)buf[w] << 32) | (pos < len ? buf[w + 1] : 0u);
-  k.key = ((unsigned long long)lo << 16) | pos;
-  keys[i] = k;
-}
-
-// sorted keys -> parallel arrays + the histogram of first tokens (-> _quickVocabAccess, src/suffix_array.cc:76-98)
-__global__ void k_split_sorted(const GpuSortKey* __restrict__ keys, unsigned long long n, uint32_t* __restrict__ sid, uint16_t* __restrict__ pos,
-                               uint32_t* __restrict__ first_hist, uint32_t n_hist) {
-  const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const GpuSortKey k = keys[i];
-  sid[i] = (uint32_t)(k.key >> 16);
-  pos[i] = (uint16_t)(k.key & 0xffffu);
-  const uint32_t w0 = (uint32_t)(k.prefix >> 32);
-  // sorted by first token: runs of equal w0 — one atomic per run boundary inside the wave
-  const uint32_t prev = __shfl_up(w0, 1, 64);
-  const bool head = (threadIdx.x & 63) == 0 || prev != w0 || i == 0;
-  const unsigned long long heads = __ballot(head);
-  if (head && w0 < n_hist) {
-    const uint32_t lane = threadIdx.x & 63;
-    const unsigned long long above = lane == 63 ? 0ull : (heads >> (lane + 1));
-    const uint32_t run = above ? (uint32_t)__builtin_ctzll(above) + 1u : 64u - lane;
-    const unsigned long long left = n - i;
-    atomicAdd(&first_hist[w0], (uint32_t)(run < left ? run : left));
-  }
-}
-
-void gpu_sort_resident_free(SortResident* r) {
-  if (!r) return;
-  if (r->device >= 0) (void)hipSetDevice(r->device);
-  hipFree(r->d_buf); hipFree(r->d_sent_pos); hipFree(r->d_sid); hipFree(r->d_pos);
-  delete r;
-}
-
-// Index build: the suffix array is enumerated, sorted and split on the device from the sentence buffer alone; the sorted arrays
-// come home once (the .fmi writer and the host-side views need them) and ALSO stay in HBM for the upload that follows.
-SortResident* gpu_suffix_sort(HostIndex& h, int device) {
-  check_device(device);
-  HIP_TRY(hipSetDevice(device));
-  const uint64_t n = h.suf_sid.size();
-  if (n == 0) { h.adopt_sorted(nullptr, 0); return nullptr; }
-  std::unique_ptr<SortResident, void (*)(SortResident*)> res(new SortResident, gpu_sort_resident_free);
-  res->device = device; res->n_buf = h.buf.size(); res->n_sent = h.sent_pos.size(); res->n_suf = n;
-  res->d_buf = dev_alloc<uint32_t>(h.buf.size() + 8);
-  HIP_TRY(hipMemset(res->d_buf + h.buf.size(), 0, 8 * sizeof(uint32_t)));
-  HIP_TRY(hipMemcpy(res->d_buf, h.buf.data(), h.buf.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-  res->d_sent_pos = dev_upload(h.sent_pos);
-  GpuSortKey* d_in = dev_alloc<GpuSortKey>(n);
-  GpuSortKey* d_out = nullptr;
-  void* tmp = nullptr;
-  uint32_t* d_hist = nullptr;
-  auto cleanup = [&]() { hipFree(d_in); hipFree(d_out); hipFree(tmp); hipFree(d_hist); };
-  try {
-    d_out = dev_alloc<GpuSortKey>(n);
-    hipLaunchKernelGGL(k_enumerate_suffixes, dim3((unsigned)((h.buf.size() + 255) / 256)), dim3(256), 0, 0, res->d_buf, res->d_sent_pos,
-                       (uint32_t)h.sent_pos.size(), (unsigned long long)h.buf.size(), d_in);
-    size_t tmp_bytes = 0;
-    GpuSuffixLess less{res->d_buf, res->d_sent_pos};
-    HIP_TRY(rocprim::merge_sort(nullptr, tmp_bytes, d_in, d_out, (size_t)n, less, (hipStream_t)0, false));
-    HIP_TRY(hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 1)));
-    HIP_TRY(rocprim::merge_sort(tmp, tmp_bytes, d_in, d_out, (size_t)n, less, (hipStream_t)0, false));
-    hipFree(tmp); tmp = nullptr;
-    hipFree(d_in); d_in = nullptr;
-    res->d_sid = dev_alloc<uint32_t>(n);
-    res->d_pos = dev_alloc<uint16_t>(n);
-    // _quickVocabAccess: one entry per word id the index knows, plus the total
-    uint32_t vs = h.vocab_size;
-    const uint32_t n_hist = std::max<uint32_t>(vs, 2) + 1;
-    d_hist = dev_alloc<uint32_t>(n_hist);
-    HIP_TRY(hipMemset(d_hist, 0, (size_t)n_hist * 4));
-    hipLaunchKernelGGL(k_split_sorted, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (const GpuSortKey*)d_out, (unsigned long long)n, res->d_sid,
-                       res->d_pos, d_hist, n_hist - 1);
-    HIP_TRY(hipGetLastError());
-    std::vector<uint32_t> sid(n), hist(n_hist);
-    std::vector<uint16_t> pos(n);
-    HIP_TRY(hipMemcpy(sid.data(), res->d_sid, n * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(pos.data(), res->d_pos, n * 2, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(hist.data(), d_hist, (size_t)n_hist * 4, hipMemcpyDeviceToHost));
-    // word ids above the declared vocabulary (bulk corpora may carry them): the host's rule grows the vocabulary to fit
-    uint64_t counted = 0;
-    for (uint32_t w = 0; w + 1 < n_hist; w++) counted += hist[w];
-    if (counted != n) {  // some first token >= vocab_size: let the host loop (which also grows vocab_size) do it
-      std::vector<uint64_t> flat(n);
-      for (uint64_t i = 0; i < n; i++) flat[i] = ((uint64_t)sid[i] << 16) | pos[i];
-      h.adopt_sorted(flat.data(), n);
-    } else {
-      std::vector<uint32_t> qva((size_t)n_hist, 0);  // exclusive prefix: first suffix per first-token id, [vocab] = total
-      uint32_t run = 0;
-      for (uint32_t w = 0; w + 1 < n_hist; w++) { qva[w] = run; run += hist[w]; }
-      qva[n_hist - 1] = run;
-      h.adopt_sorted_arrays(std::move(sid), std::move(pos), std::move(qva));
-    }
-  } catch (...) {
-    cleanup();
-    throw;
-  }
-  cleanup();
-  return res.release();
-}
+// the suffix sorter of the index build (gpu_suffix_sort): fmx_sort.hip
 
 }  // namespace fmx
