@@ -6,7 +6,7 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 agg = collections.defaultdict(list)
 for r in rows:
-    agg[r["Kernel_Name"].split("(")[0]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    agg[r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 total = sum(sum(v) for v in agg.values())
 import statistics
 print("kernel,calls,total_ns,avg_ns,min_ns,max_ns,percent,median_ns")

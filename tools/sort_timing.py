@@ -17,7 +17,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     import synth
     fmx = importlib.import_module("fuzzy-match_amd.fmx")
     n_sent = int(sys.argv[2])
-    c_off, c_tok, _, _, vs = synth.corpus_and_queries(n_sent, 10, 20)
+    c_off, c_tok, _, _, vs = synth.corpus_and_queries(n_sent, 10, 25 if n_sent >= 5_000_000 else 20)  # the C3 / C2 corpora of bench.py
     for rep in range(2):
         ix = fmx.Index.create()
         ix.add_ids(c_off, c_tok, vs)
