@@ -538,20 +538,9 @@ def main():
     el_sync, text_stats = measure_host(host_set, "text", args.steps, "text_sync_callers")
     text_sync = {"value": round(nq_step_all * args.steps / el_sync, 1), "ms_per_step": round(el_sync / args.steps * 1e3, 3), "calls_in_flight": T_host,
                  "note": "the value leg's bracket with synchronous calls: fmx_match_batch_text from as many host threads"}
-    # the host-buffer legs first: measured after the six-call device-resident leg (its contexts' queues still recently active)
-    # they stall now and then (DESIGN §5 "Stalls")
     elapsed_ids, ids_stats = measure_host(host_set, "ids", args.steps, "pcie_inclusive_ids")
     value_ids = nq_step_all * args.steps / elapsed_ids
-    elapsed_dev = measure_device(main_set, "device_resident")
-    value_dev = nq_step_all * args.steps / elapsed_dev
-    scaling_other = None
-    if world > 1:
-        el2 = measure_text(other_set[:min(len(other_set), T_text + 1)], None)
-        el2d = measure_device(other_set, None)
-        n2 = all_ranks(other_set[0].nq)
-        scaling_other = {"scaling": other_scaling, "value": round(n2 * args.steps / el2, 1),
-                         "ms_per_step": round(el2 / args.steps * 1e3, 3), "queries_per_step_all_ranks": n2,
-                         "device_resident_value": round(n2 * args.steps / el2d, 1)}
+    el2 = measure_text(other_set[:min(len(other_set), T_text + 1)], None) if world > 1 else None
 
     from_strings = None
     str_ids, str_threads, t_lookup = [], 1, [0.0]
@@ -610,6 +599,17 @@ def main():
     csts = run_device_steps(main_set, len(main_set))
     ix.set_option("probe_count", 0)
     torch.cuda.synchronize()
+    # ---- the six-call device-resident leg LAST: whatever is measured after it (its contexts' queues still recently active) stalls
+    # now and then (DESIGN §5 "Stalls") ----
+    elapsed_dev = measure_device(main_set, "device_resident")
+    value_dev = nq_step_all * args.steps / elapsed_dev
+    scaling_other = None
+    if world > 1:
+        el2d = measure_device(other_set, None)
+        n2 = all_ranks(other_set[0].nq)
+        scaling_other = {"scaling": other_scaling, "value": round(n2 * args.steps / el2, 1),
+                         "ms_per_step": round(el2 / args.steps * 1e3, 3), "queries_per_step_all_ranks": n2,
+                         "device_resident_value": round(n2 * args.steps / el2d, 1)}
     probe_bytes = sum(float(s.probe_bytes) for s in csts) / len(csts)
     probe_lines = sum(float(s.probe_lines) for s in csts) / len(csts)
     tot_tokens = sum(w.total_tokens for w in main_set) / len(main_set)

@@ -1034,12 +1034,18 @@ __device__ __forceinline__ void plane_level(uint32_t (&al)[6], uint32_t (&ah)[6]
 
 constexpr uint32_t kHeavyList = 2 * kWave;  // LDS list of plane-test survivors waiting for the exact test
 
-// Five waves per SIMD for the two kernels below (round 2: six): at six, k_expand_h kept 7 and k_expand_b<false> 8 VGPRs in
-// scratch; at five neither does, and neither is slower (k_expand_h 1.30 -> 1.28 ms at C3; four waves cost the overlapped
-// pipeline 8 %).  Their SGPR spills (~270 / ~130 wave-uniform values parked in VGPR lanes: bit planes of the pattern's
-// buckets, length intervals, range and segment descriptors) are what the algorithm keeps per wave, not compiler waste.
+// Registers of the two kernels below.  Until round 4 both ran at five waves per SIMD with ~270 / ~130 wave-uniform values spilled to
+// VGPR lanes.  Most of those were not what the algorithm keeps per wave but what the compiler hoists: k_expand_h's bucket masks and
+// sixteen length intervals are uniform for a whole work item, so every row offset and comparison derived from them was computed in
+// front of the block loop and kept (94 VGPRs, 272 spilled SGPRs); k_expand_b's sorting network compares lane bits, so its 21
+// direction masks were computed at the top of the kernel and kept for its length.  Now k_expand_h parks the masks and intervals in
+// LDS and reads them (ds_read + readfirstlane) where a block iteration uses them — 58-60 VGPRs, which is what lets it run at EIGHT
+// waves (0.95 -> 0.83 ms at C3; five waves with the old code: 1.05) — and the network takes the lane number through an opaque copy.
 #ifndef FMX_HEAVY_WAVES
-#define FMX_HEAVY_WAVES 5
+#define FMX_HEAVY_WAVES 8
+#endif
+#ifndef FMX_B_LDS_CPL
+#define FMX_B_LDS_CPL 1
 #endif
 #ifndef FMX_PHASEB_WAVES
 #define FMX_PHASEB_WAVES 5
@@ -1050,6 +1056,12 @@ __global__ void __launch_bounds__(kWave, FMX_HEAVY_WAVES) k_expand_h(DevIndex ix
   __shared__ uint32_t s_bucket[2 * kWave];  // pattern positions per bucket of the 112-bucket signature: [0, 56) first halves, [64, 120) second halves
   __shared__ uint32_t s_list[kHeavyList];
   __shared__ QHit s_q[kQueue];
+  // wave-uniform masks and intervals of the work item at hand, read where they are used (see above): positions per bucket as bit
+  // planes over the buckets — s_pl = the 56 buckets of suf_sig (exact re-test), s_plh[h] = the two halves of each bucket (plane
+  // test) — and the length intervals {first | last << 16} per level of this pattern length (k_cmin)
+  __shared__ unsigned long long s_plh[2][6];
+  __shared__ unsigned long long s_pl[6];
+  __shared__ uint32_t s_iv[2 * kGeLevels];
   const uint32_t lane = lane_id();
   const unsigned long long below = (1ull << lane) - 1ull;
   unsigned long long n_items = w.counters[15];
@@ -1073,29 +1085,29 @@ __global__ void __launch_bounds__(kWave, FMX_HEAVY_WAVES) k_expand_h(DevIndex ix
     reinterpret_cast<unsigned long long*>(s_cmin)[lane] =
         reinterpret_cast<const unsigned long long*>(w.cmin_tab + (size_t)p * kCminRow)[lane];
     wave_lds_sync();
-    // positions per bucket as bit planes over the buckets (wave-uniform 64-bit masks, like k_expand_a): pl = the 56
-    // buckets of suf_sig (exact re-test), plh[h] = the two halves of each bucket (plane test)
-    unsigned long long pl[6], plh[2][6];
+    const uint32_t* ext = reinterpret_cast<const uint32_t*>(w.cmin_tab + (size_t)p * kCminRow + kCminTab);
+    const uint32_t tmin = uni(ext[0]) & 0xffffu;
+    const bool clamp_possible = s_cmin[kSigLenClamp] != 0xffffu;  // uniform: the index holds sentences of >= 255 tokens
+    uint32_t stat_rows = clamp_possible ? 1u : 0u;  // rows read per block (statistics): the planes of the pattern's buckets ...
     {
       const uint32_t c0 = s_bucket[lane], c1 = s_bucket[kWave + lane];
 #pragma unroll
       for (uint32_t k = 0; k < 6; k++) {
-        pl[k] = __ballot(((c0 + c1) >> k) & 1u);
-        plh[0][k] = __ballot((c0 >> k) & 1u);
-        plh[1][k] = __ballot((c1 >> k) & 1u);
+        const unsigned long long m0 = __ballot((c0 >> k) & 1u), m1 = __ballot((c1 >> k) & 1u), ms = __ballot(((c0 + c1) >> k) & 1u);
+        if (lane == 0) { s_plh[0][k] = m0; s_plh[1][k] = m1; s_pl[k] = ms; }
+        stat_rows += (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1);
       }
     }
-    // tmin and the length intervals {first | last << 16} per level of this pattern length (k_cmin), wave-uniform
-    const uint32_t* ext = reinterpret_cast<const uint32_t*>(w.cmin_tab + (size_t)p * kCminRow + kCminTab);
-    const uint32_t tmin = uni(ext[0]) & 0xffffu;
-    uint32_t iv[2 * kGeLevels];
-    uint32_t n_iv = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < 2 * kGeLevels; k++) {
-      iv[k] = uni(ext[1 + k]);
-      n_iv += (iv[k] & 0xffffu) <= (iv[k] >> 16) ? 1u : 0u;
+    if (lane < 2 * kGeLevels) s_iv[lane] = ext[1 + lane];
+    wave_lds_sync();
+    {  // ... and two thermometer rows per interval, one where it continues the previous
+      uint32_t pe = 0xffffffffu;
+#pragma unroll 1
+      for (uint32_t k = 0; k < 2 * kGeLevels; k++) {
+        const uint32_t ivk = s_iv[k], first = ivk & 0xffffu, last = ivk >> 16;
+        if (first <= last) { stat_rows += first == pe ? 1u : 2u; pe = last + 1u; }
+      }
     }
-    const bool clamp_possible = s_cmin[kSigLenClamp] != 0xffffu;  // uniform: the index holds sentences of >= 255 tokens
     QHit* qb = w.qb + seg0;
     uint32_t q_head = 0, q_tail = 0, n_list = 0;
     auto flush = [&](uint32_t n_take) {
@@ -1113,7 +1125,7 @@ __global__ void __launch_bounds__(kWave, FMX_HEAVY_WAVES) k_expand_h(DevIndex ix
       const unsigned long long sig = sig_bits(pk);
       uint32_t ub = 0;
 #pragma unroll
-      for (uint32_t k = 0; k < 6; k++) ub += (uint32_t)__popcll(sig & pl[k]) << k;
+      for (uint32_t k = 0; k < 6; k++) ub += (uint32_t)__popcll(sig & s_pl[k]) << k;
       const bool keep = valid & (ub >= cmin);
       const unsigned long long m = __ballot(keep);
       if (m) {
@@ -1128,6 +1140,7 @@ __global__ void __launch_bounds__(kWave, FMX_HEAVY_WAVES) k_expand_h(DevIndex ix
     const uint32_t blk_end = blk_first + kHeavyChunkBlocks - 1 < blk_last_r ? blk_first + kHeavyChunkBlocks : blk_last_r + 1;
     unsigned long long n_pass = 0;
     for (uint32_t b0 = blk_first; b0 < blk_end; b0 += kWave) {
+      asm volatile("" ::: "memory");  // the reads of s_plh / s_iv below stay inside the iteration
       const uint32_t blk = b0 + lane;
       const bool valid = blk < blk_end;
       // lanes beyond the chunk load the chunk's last block instead of branching around every load; `surv` drops them
@@ -1143,12 +1156,12 @@ __global__ void __launch_bounds__(kWave, FMX_HEAVY_WAVES) k_expand_h(DevIndex ix
 #pragma unroll
       for (int h = 0; h < 2; h++) {
         const unsigned long long* ch = col + (unsigned long long)(h * kSigBits) * ix.n_blk;
-        plane_level<0>(al, ah, plh[h][0], ch, ix.n_blk);
-        plane_level<1>(al, ah, plh[h][1], ch, ix.n_blk);
-        plane_level<2>(al, ah, plh[h][2], ch, ix.n_blk);
-        plane_level<3>(al, ah, plh[h][3], ch, ix.n_blk);
-        plane_level<4>(al, ah, plh[h][4], ch, ix.n_blk);
-        plane_level<5>(al, ah, plh[h][5], ch, ix.n_blk);
+        plane_level<0>(al, ah, uni(s_plh[h][0]), ch, ix.n_blk);
+        plane_level<1>(al, ah, uni(s_plh[h][1]), ch, ix.n_blk);
+        plane_level<2>(al, ah, uni(s_plh[h][2]), ch, ix.n_blk);
+        plane_level<3>(al, ah, uni(s_plh[h][3]), ch, ix.n_blk);
+        plane_level<4>(al, ah, uni(s_plh[h][4]), ch, ix.n_blk);
+        plane_level<5>(al, ah, uni(s_plh[h][5]), ch, ix.n_blk);
       }
       unsigned long long a[6];
 #pragma unroll
@@ -1176,7 +1189,8 @@ __global__ void __launch_bounds__(kWave, FMX_HEAVY_WAVES) k_expand_h(DevIndex ix
       unsigned long long prev_t = 0;
 #pragma unroll
       for (uint32_t k = 0; k < 2 * kGeLevels; k++) {
-        const uint32_t first = iv[k] & 0xffffu, last = iv[k] >> 16;
+        const uint32_t ivk = uni(s_iv[k]);
+        const uint32_t first = ivk & 0xffffu, last = ivk >> 16;
         if (first <= last) {  // last <= 254
           const unsigned long long tf = first == prev_end ? prev_t : T(first);
           const unsigned long long tl = T(last + 1u);
@@ -1228,20 +1242,9 @@ __global__ void __launch_bounds__(kWave, FMX_HEAVY_WAVES) k_expand_h(DevIndex ix
     {
       const uint32_t h0 = blk_first == (r_lo >> 6) ? r_lo : blk_first * 64u;
       const uint32_t h1 = blk_end == blk_last_r + 1 ? r_hi : blk_end * 64u;
-      uint32_t rows = clamp_possible ? 1u : 0u;  // thermometer rows: two per interval, one where it continues the previous
-      {
-        uint32_t pe = 0xffffffffu;
-#pragma unroll
-        for (uint32_t k = 0; k < 2 * kGeLevels; k++) {
-          const uint32_t first = iv[k] & 0xffffu, last = iv[k] >> 16;
-          if (first <= last) { rows += first == pe ? 1u : 2u; pe = last + 1u; }
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < 6; k++) rows += (uint32_t)__popcll(plh[0][k]) + (uint32_t)__popcll(plh[1][k]);
       tot_hits += h1 - h0;
       tot_pass += n_pass;
-      tot_words += (unsigned long long)rows * (blk_end - blk_first);
+      tot_words += (unsigned long long)stat_rows * (blk_end - blk_first);
     }
   }
   if (lane == 0 && tot_hits) {
@@ -1348,13 +1351,15 @@ __global__ void __launch_bounds__(kWave, LIGHT ? FMX_LIGHT_WAVES : FMX_PHASEB_WA
   __shared__ uint32_t s_nlo[LIGHT ? kWave : 1];
   __shared__ uint32_t s_nit[LIGHT ? kWave : 1];
   __shared__ __attribute__((aligned(8))) uint16_t s_cmin[LIGHT ? kCminTab : 4];
-  const uint32_t lane = lane_id();
+  __shared__ unsigned long long s_cpl[LIGHT ? 1 : 7];
+  const uint32_t lane0 = lane_id();
   uint32_t q, chunk;
   uint32_t item_idx = 0;
   const bool extra = !LIGHT && blockIdx.x >= first_q_blocks;
   if (!extra) { q = blockIdx.x; chunk = 0; }
   else item_idx = blockIdx.x - first_q_blocks;
   for (;;) {
+    const uint32_t lane = lane0;
     if (extra) {
       unsigned long long n_items = w.counters[12];
       if (n_items > item_cap) n_items = item_cap;
@@ -1510,6 +1515,13 @@ __global__ void __launch_bounds__(kWave, LIGHT ? FMX_LIGHT_WAVES : FMX_PHASEB_WA
           cplanes[k] = __ballot((mycnt >> k) & 1u);
           if (cplanes[k]) n_cpl = k + 1;
         }
+        if constexpr (FMX_B_LDS_CPL && !LIGHT) {  // fourteen scalar registers for the length of the item: parked in LDS, read where a pass weighs its masks
+          if (lane == 0) {
+#pragma unroll
+            for (uint32_t k = 0; k < 7; k++) s_cpl[k] = cplanes[k];
+          }
+          wave_lds_sync();
+        }
       }
       auto heavy4 = [&](uint32_t j0, uint32_t n_act) {
         const uint32_t sub = lane / kSubLanes, part = lane % kSubLanes;
@@ -1582,9 +1594,14 @@ __global__ void __launch_bounds__(kWave, LIGHT ? FMX_LIGHT_WAVES : FMX_PHASEB_WA
           seen |= ((unsigned long long)hi << 32) | lo;
         }
         uint32_t cover = 0;
+        if constexpr (FMX_B_LDS_CPL && !LIGHT) {
+#pragma unroll 1
+          for (uint32_t k = 0; k < n_cpl; k++) cover += (uint32_t)__popcll(seen & s_cpl[k]) << k;
+        } else {
 #pragma unroll
-        for (uint32_t k = 0; k < 7; k++)
-          if (k < n_cpl) cover += (uint32_t)__popcll(seen & cplanes[k]) << k;
+          for (uint32_t k = 0; k < 7; k++)
+            if (k < n_cpl) cover += (uint32_t)__popcll(seen & cplanes[k]) << k;
+        }
         if (L >= p) cover = p;
         bool keep = act && part == 0;
         if (keep) {
@@ -1780,7 +1797,11 @@ __device__ __forceinline__ uint32_t cand_body(unsigned long long* keys, Cand* se
 // all other lanes this is the full sort at a fraction of the 21 compare-exchange stages.
 template <int N>
 __device__ __forceinline__ unsigned long long wave_sort64_n(unsigned long long key) {
-  const uint32_t lane = lane_id();
+  // the lane number through an opaque copy: the direction masks below ((lane & k) == 0) == ((lane & j) == 0) depend on nothing
+  // but the lane, so the compiler computes all 21 of them at the top of the calling kernel and keeps them — 42 scalar registers,
+  // spilled to VGPR lanes in k_expand_b — for the length of the kernel; two compares where they are used are cheaper
+  uint32_t lane = lane_id();
+  asm volatile("" : "+v"(lane));
 #pragma unroll
   for (int k = 2; k <= N; k <<= 1) {
 #pragma unroll
