@@ -1,6 +1,6 @@
 """End-to-end throughput of tools/fmx-cli on a synthetic tokenised corpus (SURVEY §8d generator spelled out as
 text): builds the .fmi with `-a index`, then times `-a match` on the query file (stdin -> stdout).
-Usage: python tools/cli_throughput.py [n_sentences] [n_queries]"""
+Usage: python tools/cli_throughput.py [n_sentences] [n_queries] [batch,batch,...]"""
 import os
 import subprocess
 import sys
@@ -33,7 +33,7 @@ cli = os.path.join(ROOT, "tools", "fmx-cli")
 t = time.time()
 subprocess.check_call([cli, "--tokenised", "-c", corpus, "-a", "index"], stderr=subprocess.DEVNULL)
 print(f"index: {n_sent} sentences in {time.time() - t:.1f}s")
-for batch in (32768, 65536, 131072):
+for batch in ([int(b) for b in sys.argv[3].split(",")] if len(sys.argv) > 3 else (32768, 65536, 131072)):
     t = time.time()
     r = subprocess.run([cli, "--tokenised", "-i", corpus + ".fmi", "-a", "match", "-f", "0.7", "-n", "5", "--batch", str(batch)],
                        stdin=open(queries), stdout=open(os.path.join(out_dir, "cli_out.tsv"), "w"), stderr=subprocess.PIPE, text=True,

@@ -267,6 +267,7 @@ int main(int argc, char** argv) {
   }
 
   std::shared_ptr<void> after_done;  // what is released after the last STEP line (the blocks' pinned buffers: set up before the clock started, too)
+  bool done_ticked = false;
   if (action == "match" || action == "subseq") {
     const bool subseq = action == "subseq";
     if (fmx_index_sort(ix, device, 0) != FMX_OK || fmx_index_finalize(ix) != FMX_OK ||
@@ -337,7 +338,11 @@ int main(int argc, char** argv) {
       fmx_match* out = nullptr;     // pinned: n_lines x cap records
       uint32_t *cnt = nullptr, *tot = nullptr;
       size_t   out_cap = 0, cnt_cap = 0;
-      std::string printed;
+      std::string printed;          // the block's output as one string (subseq), or ...
+      std::vector<std::string> parts;               // ... in ranges of kFmtLines lines, formatted by whichever workers are free
+      std::vector<size_t> part_nonempty;
+      std::atomic<uint32_t> parts_left{0};
+      uint32_t cap_used = 0;
       size_t   nonempty = 0;
       void need_text(size_t n) {
         if (n <= text_cap) return;
@@ -360,19 +365,48 @@ int main(int argc, char** argv) {
       ~Job() { if (text) fmx_host_free(text); if (out) fmx_host_free(out); if (cnt) fmx_host_free(cnt); if (tot) fmx_host_free(tot); }
     };
     std::vector<std::unique_ptr<Job>> pool(n_jobs);
-    Channel<Job*> free_jobs(n_jobs + 1), to_work(n_jobs + 1), to_write(n_jobs + 1);
+    constexpr size_t kFmtLines = 8192;   // lines per formatting task
+    struct Task { Job* job; int part; };  // part < 0: the block's GPU call; else: format lines [part * kFmtLines, ...)
+    Channel<Job*> free_jobs(n_jobs + 1), to_write(n_jobs + 1);
+    Channel<Task> to_work((n_jobs + 1) * (batch / kFmtLines + 2));  // never full: a worker that pushes format tasks must not block
     for (auto& j : pool) {
       j.reset(new Job);
       j->need_text(std::min<size_t>(batch * 160, 48u << 20));   // (grown on demand: a block is `batch` lines, whatever their length)
       j->need_out(batch, cap0);
       free_jobs.push(j.get());
     }
-    tick(subseq ? "Subsequencing" : "Matching");
+    // the ids of the memory's sentences in sixteen bytes each — up to fifteen characters in place, longer ones by pointer —: the
+    // formatters append an id with one cache miss, without a call and a strlen per match
+    struct SidEntry { char s[15]; uint8_t len; };   // len == 255: s holds a pointer and a 32-bit length
+    std::vector<SidEntry> sid_tab(info.n_sentences);
+    parallel_for(std::min(workers, 8u), sid_tab.size(), [&](unsigned, size_t lo, size_t hi) {
+      for (size_t k = lo; k < hi; k++) {
+        const char* c = fmx_index_sentence_id(ix, (uint32_t)k);
+        const size_t n = strlen(c);
+        SidEntry& e = sid_tab[k];
+        if (n <= 15) { memcpy(e.s, c, n); memset(e.s + n, 0, 15 - n); e.len = (uint8_t)n; }
+        else { const uint32_t n32 = (uint32_t)n; memcpy(e.s, &c, sizeof c); memcpy(e.s + 8, &n32, 4); e.len = 255; }
+      }
+    });
+    auto sid_len = [&](uint32_t sid) -> uint32_t {
+      if (sid >= sid_tab.size()) return 0u;
+      const SidEntry& e = sid_tab[sid];
+      if (e.len != 255) return e.len;
+      uint32_t n32; memcpy(&n32, e.s + 8, 4); return n32;
+    };
+    // boost::lexical_cast<std::string>(float) of a score (cli:230) = "%.9g"; scores are k / 10000 (src/fuzzy_match.cc:598): tabulated
+    std::vector<float> score_f(10001);
+    std::vector<std::array<char, 16>> score_s(10001);
+    std::vector<uint8_t> score_n(10001);
+    for (int k = 0; k <= 10000; k++) {
+      score_f[k] = (float)((double)k / 10000.0);
+      score_n[k] = (uint8_t)snprintf(score_s[k].data(), 16, "%.9g", score_f[k]);
+    }
     const bool timing = getenv("FMX_CLI_TIMING") != nullptr;
     std::atomic<uint64_t> us_gpu{0}, us_fmt{0}, us_read{0}, us_write{0}, us_wait_job{0}, n_retries{0}, us_gpu_max{0};
     std::atomic<uint64_t> t_gpu_first_end{0}, t_gpu_last_end{0}, t_read_end{0}, t_fmt_last_end{0};
     auto now_us = [] { return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const uint64_t t_tick = now_us();
+    uint64_t t_tick = 0;   // the clock of the matching phase starts when the pipeline stands (below): workers and writer wait for input
     std::atomic<bool> failed{false};
     std::string fail_msg;
     std::mutex fail_mu;
@@ -388,14 +422,6 @@ int main(int argc, char** argv) {
       GpuSlot(std::mutex& m, std::condition_variable& c, int& b) : mu(m), cv(c), busy(b) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return busy < kGpuCalls; }); busy++; }
       ~GpuSlot() { { std::lock_guard<std::mutex> lk(mu); busy--; } cv.notify_one(); }
     };
-    // boost::lexical_cast<std::string>(float) of a score (cli:230) = "%.9g"; scores are k / 10000 (src/fuzzy_match.cc:598): tabulated
-    std::vector<float> score_f(10001);
-    std::vector<std::array<char, 16>> score_s(10001);
-    std::vector<uint8_t> score_n(10001);
-    for (int k = 0; k <= 10000; k++) {
-      score_f[k] = (float)((double)k / 10000.0);
-      score_n[k] = (uint8_t)snprintf(score_s[k].data(), 16, "%.9g", score_f[k]);
-    }
     auto put_score = [&](std::string& buf, float v) {
       const int k = (int)(v * 10000.f + 0.5f);
       if (k >= 0 && k <= 10000 && score_f[k] == v) { buf.append(score_s[k].data(), score_n[k]); return; }
@@ -501,6 +527,9 @@ int main(int argc, char** argv) {
         }
       }
       if (cap > cap_now.load()) cap_now.store(cap);
+      job->cap_used = cap;
+      job->parts.clear();
+      if (!subseq) return;  // match: the records are formatted in ranges of kFmtLines lines by whichever workers are free (format_part)
       // records -> text (cli:219-248): score <TAB> id pairs joined by tabs, an empty line when nothing matched
       const uint64_t t_fmt = now_us();
       std::string& buf = job->printed;
@@ -543,13 +572,86 @@ int main(int argc, char** argv) {
       t_fmt_last_end.store(now_us() - t_tick);
     };
 
+    // -a match: lines [part * kFmtLines, ...) of a block -> "score <TAB> id" pairs joined by tabs, an empty line when nothing matched
+    // (cli:219-248); written through a raw pointer (a line is at most cap x (15 + 1 + id + 1) bytes + the line feed)
+    auto format_part = [&](Job* job, uint32_t part) {
+      const uint64_t t_fmt = now_us();
+      const size_t lo = (size_t)part * kFmtLines, hi = std::min(job->n_lines, lo + kFmtLines);
+      const uint32_t cap = job->cap_used;
+      std::string& buf = job->parts[part];
+      // upper bound of the part's text: a match is a tab, a score of at most 16 characters, a tab and its id (34 covers every id
+      // held in place; the rare longer ones are added)
+      size_t need = (hi - lo) + 16, n_match = 0;
+      for (size_t q = lo; q < hi; q++) n_match += job->cnt[q];
+      need += n_match * 34;
+      if (info.n_sentences && !sid_tab.empty())
+        for (size_t q = lo; q < hi; q++)
+          for (uint32_t k = 0; k < job->cnt[q]; k++) {
+            const uint32_t sid = job->out[q * cap + k].s_id;
+            if (sid < sid_tab.size() && sid_tab[sid].len == 255) need += sid_len(sid);
+          }
+      buf.resize(need);
+      char* const b0 = &buf[0];
+      char* w = b0;
+      size_t nonempty = 0;
+      constexpr size_t kAhead = 6;   // id entries of the lines ahead are on their way while this line is written
+      for (size_t q = lo; q < hi; q++) {
+        if (q + kAhead < hi)
+          for (uint32_t k = 0; k < job->cnt[q + kAhead]; k++) {
+            const uint32_t sid = job->out[(q + kAhead) * cap + k].s_id;
+            if (sid < sid_tab.size()) __builtin_prefetch(&sid_tab[sid]);
+          }
+        const uint32_t c = job->cnt[q];
+        const fmx_match* mt = job->out + q * cap;
+        for (uint32_t k = 0; k < c; k++) {
+          if (k) *w++ = '\t';
+          const float v = mt[k].score;
+          const int ks = (int)(v * 10000.f + 0.5f);
+          if (ks >= 0 && ks <= 10000 && score_f[ks] == v) { memcpy(w, score_s[ks].data(), 16); w += score_n[ks]; }
+          else w += snprintf(w, 17, "%.9g", v);
+          *w++ = '\t';
+          const uint32_t sid = mt[k].s_id;
+          if (sid < sid_tab.size()) {
+            const SidEntry& e = sid_tab[sid];
+            if (e.len != 255) { memcpy(w, e.s, 15); w += e.len; }
+            else { const char* c2; memcpy(&c2, e.s, sizeof c2); const uint32_t n32 = sid_len(sid); memcpy(w, c2, n32); w += n32; }
+          }
+        }
+        *w++ = '\n';
+        nonempty += c ? 1u : 0u;
+      }
+      buf.resize((size_t)(w - b0));
+      job->part_nonempty[part] = nonempty;
+      us_fmt += now_us() - t_fmt;
+      t_fmt_last_end.store(now_us() - t_tick);
+    };
+    // blocks in flight; the task queue closes when the reader is through and the last block has been handed to the writer
+    std::atomic<uint64_t> jobs_open{0};
+    std::atomic<bool> reader_done{false};
+    auto job_done = [&](Job* job) {
+      const bool ok = to_write.push(job);
+      if ((jobs_open.fetch_sub(1) == 1 && reader_done.load()) || !ok) to_work.close();
+    };
     std::vector<std::thread> work_threads;
     for (unsigned t = 0; t < workers; t++)
       work_threads.emplace_back([&] {
-        Job* job;
-        while (to_work.pop(job)) {
+        Task task;
+        while (to_work.pop(task)) {
+          Job* job = task.job;
+          if (task.part >= 0) {
+            if (!failed) format_part(job, (uint32_t)task.part);
+            if (job->parts_left.fetch_sub(1) == 1) job_done(job);
+            continue;
+          }
           if (!failed) work(job);
-          if (!to_write.push(job)) break;
+          if (subseq || failed) { job->parts.clear(); job_done(job); continue; }
+          const uint32_t n_parts = (uint32_t)((job->n_lines + kFmtLines - 1) / kFmtLines);
+          job->parts.assign(n_parts, std::string());
+          job->part_nonempty.assign(n_parts, 0);
+          job->parts_left.store(n_parts);
+          for (uint32_t k = 1; k < n_parts; k++) to_work.push(Task{job, (int)k});
+          format_part(job, 0);
+          if (job->parts_left.fetch_sub(1) == 1) job_done(job);
         }
       });
 
@@ -570,9 +672,13 @@ int main(int argc, char** argv) {
               Job* j = waiting[k];
               waiting.erase(waiting.begin() + (long)k);
               const uint64_t a = now_us();
-              if (!failed) fwrite(j->printed.data(), 1, j->printed.size(), stdout);
+              if (!failed) {
+                if (j->parts.empty()) fwrite(j->printed.data(), 1, j->printed.size(), stdout);
+                else for (size_t k = 0; k < j->parts.size(); k++) { fwrite(j->parts[k].data(), 1, j->parts[k].size(), stdout); j->nonempty += j->part_nonempty[k]; }
+              }
               us_write += now_us() - a;
               n_total += j->n_lines; n_nonempty += j->nonempty;
+              j->nonempty = 0;
               j->n_bytes = j->n_lines = 0;
               free_jobs.push(j);
               next++;
@@ -584,74 +690,96 @@ int main(int argc, char** argv) {
       fflush(stdout);
     });
 
-    {  // reader: this thread.  Blocks of whole lines, at most `batch` lines each; the rest of a read moves on to the next block.
-      const size_t chunk = 4u << 20;
-      std::vector<char> carry;
+    const size_t chunk = 1u << 20;
+    std::vector<char> stage(8 * chunk);   // (allocated and touched before the clock starts, like the blocks' buffers)
+    tick(subseq ? "Subsequencing" : "Matching");
+    t_tick = now_us();
+    {  // reader: this thread.  stdin in 1 MB reads into one staging buffer; blocks of whole lines are copied out of it into the
+       // pinned buffer of a free job.  The first blocks are small (8192 lines, then twice as many, up to `batch`): a short input
+       // is through its first GPU call while the rest is still being read, a long one runs on full blocks after four.
+      size_t head = 0, tail = 0, scanned = 0;
       bool eof = false;
       uint64_t seq = 0;
       while (!failed) {
-        Job* job;
-        const uint64_t t_w = now_us();
-        if (!free_jobs.pop(job)) break;
+        const size_t want = std::min<size_t>(batch, (size_t)8192 << std::min<uint64_t>(seq, 16));
         const uint64_t t_r = now_us();
-        us_wait_job += t_r - t_w;
-        job->n_bytes = 0;
-        job->need_text(carry.size() + chunk);
-        if (!carry.empty()) { memcpy(job->text, carry.data(), carry.size()); job->n_bytes = carry.size(); carry.clear(); }
-        size_t lines = 0, scanned = 0, cut = 0;  // cut = end of the last whole line among the first `batch`
+        size_t lines = 0, cut = head;
         for (;;) {
-          while (scanned < job->n_bytes && lines < batch) {
-            const char* nl = (const char*)memchr(job->text + scanned, '\n', job->n_bytes - scanned);
-            if (!nl) { scanned = job->n_bytes; break; }
-            scanned = (size_t)(nl - job->text) + 1;
+          while (scanned < tail && lines < want) {
+            const char* nl = (const char*)memchr(stage.data() + scanned, '\n', tail - scanned);
+            if (!nl) { scanned = tail; break; }
+            scanned = (size_t)(nl - stage.data()) + 1;
             cut = scanned;
             lines++;
           }
-          if (lines >= batch || eof) break;
-          if (job->n_bytes >= 64u << 20 && lines > 0) break;   // (a block is at most ~64 MB)
-          job->need_text(job->n_bytes + chunk);
-          const size_t got = fread(job->text + job->n_bytes, 1, chunk, stdin);
-          if (got == 0) { eof = true; }
-          job->n_bytes += got;
+          if (lines >= want || eof) break;
+          if (tail - head >= (64u << 20) && lines > 0) break;   // (a block is at most ~64 MB)
+          if (stage.size() - tail < chunk) {                    // make room: move what is left to the front, grow if that is not enough
+            if (head) { memmove(stage.data(), stage.data() + head, tail - head); scanned -= head; cut -= head; tail -= head; head = 0; }
+            if (stage.size() - tail < chunk) stage.resize(stage.size() * 2);
+          }
+          const size_t got = fread(stage.data() + tail, 1, chunk, stdin);
+          if (got == 0) eof = true;
+          tail += got;
         }
-        if (eof && cut < job->n_bytes) {  // a last line without a line feed
-          job->need_text(job->n_bytes + 1);
-          job->text[job->n_bytes++] = '\n';
-          cut = job->n_bytes;
+        if (eof && cut < tail) {  // a last line without a line feed
+          if (tail == stage.size()) stage.resize(stage.size() + 1);
+          stage[tail++] = '\n';
+          cut = scanned = tail;
           lines++;
         }
-        if (cut < job->n_bytes) carry.assign(job->text + cut, job->text + job->n_bytes);
-        job->n_bytes = cut;
-        job->n_lines = lines;
-        if (lines == 0) { free_jobs.push(job); if (eof) break; else continue; }
-        job->seq = seq++;
         us_read += now_us() - t_r;
-        if (!to_work.push(job)) break;
-        if (eof && carry.empty()) break;
+        if (lines == 0) break;  // end of input
+        Job* job;
+        const uint64_t t_w = now_us();
+        if (!free_jobs.pop(job)) break;
+        const uint64_t t_c = now_us();
+        us_wait_job += t_c - t_w;
+        job->n_bytes = 0;
+        job->need_text(cut - head);
+        memcpy(job->text, stage.data() + head, cut - head);
+        job->n_bytes = cut - head;
+        job->n_lines = lines;
+        job->seq = seq++;
+        head = cut;
+        scanned = std::max(scanned, head);
+        us_read += now_us() - t_c;
+        jobs_open.fetch_add(1);
+        if (!to_work.push(Task{job, -1})) break;
+        if (eof && head == tail) break;
       }
       jobs_made.store(seq);
       t_read_end.store(now_us() - t_tick);
-      to_work.close();
+      reader_done.store(true);
+      if (jobs_open.load() == 0) to_work.close();
     }
-    for (auto& t : work_threads) t.join();
-    to_write.close();   // (the writer leaves once it has printed `jobs_made` blocks, or here)
-    writer.join();
-    free_jobs.close();
-    after_done = std::make_shared<std::vector<std::unique_ptr<Job>>>(std::move(pool));
+    writer.join();      // the writer leaves once it has printed `jobs_made` blocks: the output is complete
+    const uint64_t t_end = now_us() - t_tick;
+    auto wind_down = [&] {  // after the "Done" line: sixteen thread exits are a millisecond
+      to_work.close();
+      for (auto& t : work_threads) t.join();
+      to_write.close();
+      free_jobs.close();
+      after_done = std::make_shared<std::vector<std::unique_ptr<Job>>>(std::move(pool));
+    };
     if (timing)
       std::cerr << "TIMING\tread_ms\t" << us_read / 1e3 << "\twait_free_block_ms\t" << us_wait_job / 1e3 << "\tgpu_calls_ms(sum)\t" << us_gpu / 1e3
                 << "\tformat_ms(sum)\t" << us_fmt / 1e3 << "\twrite_ms\t" << us_write / 1e3 << "\tat_ms:first_gpu_done/read_done/last_gpu_done/last_format_done/end\t" << t_gpu_first_end / 1e3 << "/" << t_read_end / 1e3 << "/" << t_gpu_last_end / 1e3 << "/"
-                << t_fmt_last_end / 1e3 << "/" << (now_us() - t_tick) / 1e3 << "\tgpu_call_max_ms\t" << us_gpu_max / 1e3 << "\tretries\t" << n_retries << "\tworkers\t" << workers << "\tblocks\t" << n_jobs << std::endl;
+                << t_fmt_last_end / 1e3 << "/" << t_end / 1e3 << "\tgpu_call_max_ms\t" << us_gpu_max / 1e3 << "\tretries\t" << n_retries << "\tworkers\t" << workers << "\tblocks\t" << n_jobs << std::endl;
     if (failed) {
+      wind_down();
       std::cerr << "ERROR: " << fail_msg << std::endl;
       return 1;
     }
     std::cerr << "NMATCH\t" << n_nonempty << "\t/\t" << n_total << std::endl;
+    tick("Done");
+    done_ticked = true;
+    wind_down();
   } else if (action != "index") {
     std::cerr << "ERROR: unknown action '" << action << "' (index|match|subseq)" << std::endl;
     return 2;
   }
-  tick("Done");
+  if (!done_ticked) tick("Done");
   fmx_index_free(ix);
   return 0;
 }
