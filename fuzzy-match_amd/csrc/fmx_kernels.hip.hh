@@ -3282,8 +3282,7 @@ template <int G>
 __global__ void __launch_bounds__(kWave) k_crerank_g(DevIndex ix, DevBatch b, DevWork w, Params prm, const uint32_t* list,
                                                      uint32_t which, uint32_t cap, Rec* out_rec, uint32_t* out_count, uint32_t* out_total) {
   constexpr uint32_t kGroups = kWave / G;
-  __shared__ uint32_t s_key[kGroups][kGrpSlots];
-  __shared__ uint32_t s_mask[kGroups][kGrpSlots];
+  __shared__ uint2 s_tab[kGroups][kGrpSlots];   // {token, mask of its positions in the picked sentence}: one 8-byte read per look-up
   __shared__ uint32_t s_pick[kGroups][32];   // the picked sentence's tokens
   const uint32_t lane = lane_id(), gl = lane % G, gi = lane / G, gb = lane - gl;
   const unsigned long long n_list = w.counters[28 + which];
@@ -3349,15 +3348,15 @@ __global__ void __launch_bounds__(kWave) k_crerank_g(DevIndex ix, DevBatch b, De
 #pragma unroll
         for (int j = 0; j < 32; j++) if ((uint32_t)j < n1) s_pick[gi][j] = tk[j];
       }
-      for (uint32_t k = gl; k < kGrpSlots; k += G) { s_key[gi][k] = kHashEmpty; s_mask[gi][k] = 0u; }
+      for (uint32_t k = gl; k < kGrpSlots; k += G) s_tab[gi][k] = make_uint2(kHashEmpty, 0u);
       wave_lds_sync();
       if (more)
         for (uint32_t j = gl; j < n2; j += G) {
           const uint32_t t = s_pick[gi][j];
           uint32_t h = pat_hash_slot(t) & (kGrpSlots - 1);
           for (;;) {
-            const uint32_t old = atomicCAS(&s_key[gi][h], kHashEmpty, t);
-            if (old == kHashEmpty || old == t) { atomicOr(&s_mask[gi][h], 1u << j); break; }
+            const uint32_t old = atomicCAS(&s_tab[gi][h].x, kHashEmpty, t);
+            if (old == kHashEmpty || old == t) { atomicOr(&s_tab[gi][h].y, 1u << j); break; }
             h = (h + 1) & (kGrpSlots - 1);
           }
         }
@@ -3376,9 +3375,9 @@ __global__ void __launch_bounds__(kWave) k_crerank_g(DevIndex ix, DevBatch b, De
         if ((uint32_t)i < rows) {
           const uint32_t t = tk[i];
           uint32_t h = pat_hash_slot(t) & (kGrpSlots - 1);
-          uint32_t key = s_key[gi][h];
-          while (key != t && key != kHashEmpty) { h = (h + 1) & (kGrpSlots - 1); key = s_key[gi][h]; }
-          const uint32_t eq = key == t ? s_mask[gi][h] : 0u;
+          uint2 e = s_tab[gi][h];
+          while (e.x != t && e.x != kHashEmpty) { h = (h + 1) & (kGrpSlots - 1); e = s_tab[gi][h]; }
+          const uint32_t eq = e.x == t ? e.y : 0u;
           lev_step32(pv, mv, score, eq, m_bits);
         }
       }
