@@ -1071,38 +1071,43 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
           // lanes per query with the picked sentence's match masks in a small LDS table (k_crerank_g); the big / cand lists of the
           // candidate stage are free by now and carry the three query lists
           static const bool groups_on = [] { const char* e = getenv("FMX_RERANK_GROUPS"); return e ? atoi(e) != 0 : true; }();  // design-time switch
-          if (groups_on) hipLaunchKernelGGL(k_cgrp_route, dim3((b.nq + 1023) / 1024), dim3(1024), 0, stream, b, w, c.big_list.p, c.mid_list.p, c.fin_list.p);
-          // The flattened rounds (the rest: larger sets, sentences of 33-64 tokens) are chains of small launches — pick, then one edit
-          // distance per remaining accepted match of any query; round r: the match picked in round r - 1 emits itself, the others bid
-          // for round r's pick.  They touch other queries than the group kernels: with the groups on, the whole chain runs on the side
-          // stream BESIDE them (until round 4 it followed them: 0.9 ms of the stage); without, the two length classes are two chains.
-          fork();
-          const hipStream_t rest = groups_on ? side : stream;
-          hipLaunchKernelGGL(k_cacc, dim3((n_scan + 255) / 256), dim3(256), 0, rest, b, w);
-          hipLaunchKernelGGL(k_scan_lb<2>, dim3(scan_tiles), dim3(kScanThreads), 0, rest, w.c_in, w.c_off, (size_t)n_scan, n_scan,
+          static const bool g32_side = [] { const char* e = getenv("FMX_G32_SIDE"); return e ? atoi(e) != 0 : true; }();  // design-time switch
+          if (groups_on) hipLaunchKernelGGL(k_cgrp_route, dim3((b.nq + 1023) / 1024), dim3(1024), 0, stream, b, w, c.big_list.p, c.mid_list.p, c.fin_list.p, c.contrast_list.p);
+          // The flattened rounds (the rest: sentences of 33-64 tokens; without the groups everything) are chains of small launches —
+          // pick, then one edit distance per remaining accepted match of any query; round r: the match picked in round r - 1 emits
+          // itself, the others bid for round r's pick.  They touch other queries than the group kernels, so with the groups on the
+          // chain runs on the side stream BESIDE them (until round 4 it followed them: 0.9 ms of the stage).  The look-back scan stays
+          // in front of the fork: beside a kernel that fills every CU its tiles wait for predecessors that are not resident (0.5 ms
+          // instead of 25 us).
+          hipLaunchKernelGGL(k_cacc, dim3((n_scan + 255) / 256), dim3(256), 0, stream, b, w);
+          hipLaunchKernelGGL(k_scan_lb<2>, dim3(scan_tiles), dim3(kScanThreads), 0, stream, w.c_in, w.c_off, (size_t)n_scan, n_scan,
                              c.scan_state(3), c.scan_ticket(3));
-          hipLaunchKernelGGL(k_camap, dim3((b.nq + kWave / kCamapGroup - 1) / (kWave / kCamapGroup)), dim3(kWave), 0, rest, E.d, b, w, sc, prm, d_out_count, d_out_total);
           if (groups_on) {
+            fork();
+            hipLaunchKernelGGL(k_camap, dim3((b.nq + kWave / kCamapGroup - 1) / (kWave / kCamapGroup)), dim3(kWave), 0, side, E.d, b, w, sc, prm, d_out_count, d_out_total);
             const unsigned gg = std::min<unsigned>(256u * 32u, std::max<unsigned>(64u, b.nq / 4u));
             hipLaunchKernelGGL(k_crerank_g<8>, dim3(gg), dim3(kWave), 0, stream, E.d, b, w, prm, (const uint32_t*)c.big_list.p, 0u, cap, d_out, d_out_count, d_out_total);
             hipLaunchKernelGGL(k_crerank_g<16>, dim3(gg), dim3(kWave), 0, stream, E.d, b, w, prm, (const uint32_t*)c.mid_list.p, 1u, cap, d_out, d_out_count, d_out_total);
-            hipLaunchKernelGGL(k_crerank_g<32>, dim3(gg / 2), dim3(kWave), 0, stream, E.d, b, w, prm, (const uint32_t*)c.fin_list.p, 2u, cap, d_out, d_out_count, d_out_total);
-            // what is left for the 32-token class are the few queries with more than 32 accepted matches: a small grid
             if (E.d.max_slen > 32)
               for (uint32_t r = 1; r <= prm.nmatch; r++)
                 hipLaunchKernelGGL(k_cround<64>, dim3(cround_grid(64)), dim3(kWave), 0, side, E.d, b, w, prm, sc, r, cap, d_out, d_out_count, d_out_total);
+            // what is left of the 32-token class are sets of more than 64 accepted matches: a small grid
             for (uint32_t r = 1; r <= prm.nmatch; r++)
               hipLaunchKernelGGL(k_cround<32>, dim3(1024), dim3(kWave), 0, side, E.d, b, w, prm, sc, r, cap, d_out, d_out_count, d_out_total);
+            hipLaunchKernelGGL(k_crerank_g<32>, dim3(gg / 2), dim3(kWave), 0, g32_side ? side : stream, E.d, b, w, prm, (const uint32_t*)c.fin_list.p, 2u, cap, d_out, d_out_count, d_out_total);
+            hipLaunchKernelGGL(k_crerank_g<64>, dim3(gg / 4), dim3(kWave), 0, stream, E.d, b, w, prm, (const uint32_t*)c.contrast_list.p, 3u, cap, d_out, d_out_count, d_out_total);
+            join();
           } else {
+            hipLaunchKernelGGL(k_camap, dim3((b.nq + kWave / kCamapGroup - 1) / (kWave / kCamapGroup)), dim3(kWave), 0, stream, E.d, b, w, sc, prm, d_out_count, d_out_total);
             if (E.d.max_slen > 32) {
-              fork();  // (behind k_camap)
+              fork();
               for (uint32_t r = 1; r <= prm.nmatch; r++)
                 hipLaunchKernelGGL(k_cround<64>, dim3(cround_grid(64)), dim3(kWave), 0, side, E.d, b, w, prm, sc, r, cap, d_out, d_out_count, d_out_total);
             }
             for (uint32_t r = 1; r <= prm.nmatch; r++)
               hipLaunchKernelGGL(k_cround<32>, dim3(cround_grid(32)), dim3(kWave), 0, stream, E.d, b, w, prm, sc, r, cap, d_out, d_out_count, d_out_total);
+            if (E.d.max_slen > 32) join();
           }
-          join();
         } else {
           hipLaunchKernelGGL(k_contrast<0>, dim3(b.nq), dim3(kWave), 0, stream, E.d, b, w, prm, sc, cap, d_out,
                              d_out_count, d_out_total, cl, (float*)nullptr, 0u);

@@ -3255,10 +3255,11 @@ __global__ void __launch_bounds__(kWave) k_cround(DevIndex ix, DevBatch b, DevWo
 // ---------------------------------------------------------------------------------------------
 constexpr uint32_t kGrpSlots = 64;  // hash slots per group (a sentence of <= 32 tokens: load <= 0.5)
 
-// one thread per query: queries the group kernels take are listed by size and marked (class 3: the flattened path skips them)
-__global__ void __launch_bounds__(1024) k_cgrp_route(DevBatch b, DevWork w, uint32_t* list8, uint32_t* list16, uint32_t* list32) {
-  __shared__ uint32_t s_n[3], s_base[3];
-  if (threadIdx.x < 3) s_n[threadIdx.x] = 0;
+// one thread per query: queries the group kernels take are listed by size (up to 8, 16, 32, 64 accepted matches: the last list
+// lives in the half of contrast_list the flattened mode leaves unused) and marked (class 3: the flattened path skips them)
+__global__ void __launch_bounds__(1024) k_cgrp_route(DevBatch b, DevWork w, uint32_t* list8, uint32_t* list16, uint32_t* list32, uint32_t* list64) {
+  __shared__ uint32_t s_n[4], s_base[4];
+  if (threadIdx.x < 4) s_n[threadIdx.x] = 0;
   __syncthreads();
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   int g = -1;
@@ -3266,14 +3267,14 @@ __global__ void __launch_bounds__(1024) k_cgrp_route(DevBatch b, DevWork w, uint
   if (q < b.nq && w.q_cand[q] != 0) {
     const uint32_t acc = w.q_acc[q];
     const uint32_t n = acc & 0x3fffffffu;
-    if ((acc >> 30) == 0 && n >= 1 && n <= 32) g = n <= 8 ? 0 : (n <= 16 ? 1 : 2);
+    if ((acc >> 30) == 0 && n >= 1 && n <= 64) g = n <= 8 ? 0 : (n <= 16 ? 1 : (n <= 32 ? 2 : 3));
   }
   if (g >= 0) at = atomicAdd(&s_n[g], 1u);
   __syncthreads();
-  if (threadIdx.x < 3) s_base[threadIdx.x] = s_n[threadIdx.x] ? (uint32_t)atomicAdd(&w.counters[28 + threadIdx.x], (unsigned long long)s_n[threadIdx.x]) : 0u;
+  if (threadIdx.x < 4) s_base[threadIdx.x] = s_n[threadIdx.x] ? (uint32_t)atomicAdd(&w.counters[28 + threadIdx.x], (unsigned long long)s_n[threadIdx.x]) : 0u;
   __syncthreads();
   if (g >= 0) {
-    (g == 0 ? list8 : (g == 1 ? list16 : list32))[s_base[g] + at] = q;
+    (g == 0 ? list8 : (g == 1 ? list16 : (g == 2 ? list32 : list64)))[s_base[g] + at] = q;
     w.q_acc[q] |= 3u << 30;
   }
 }
