@@ -725,10 +725,12 @@ def main():
             # keys 8 + 8, penalty sum 4 + 4, penalty 4, two sentence positions 8); per candidate the 16 B record the replay reads
             fin_ms = per_stage.get("finish", 0.0)
             b_fin = n_rerank * (8.0 * (mean_len + 1) + 64.0) + 16.0 * n_cand
-            roofs.append(roof("finish stage: replay + k_camap + nmatch x k_cround<32|64>", b_fin, fin_ms, ["k_finish", "k_camap", "k_cround"],
+            roofs.append(roof("finish stage: replay + k_crerank_g<8|16|32|64> (+ k_camap, nmatch x k_cround<64> for sentences of 33-64 tokens)", b_fin, fin_ms,
+                              ["k_finish", "k_cgrp_route", "k_crerank_g", "k_cacc", "k_camap", "k_cround"],
                               f"replay + contrastive rerank; {int(n_rerank)} sentence-pair edit distances per step (kernel counter) x (two sentences "
-                              "of 4 B x (mean length + 1) + 64 B of per-match state) + 16 B per candidate; the rounds are bound by VALU issue "
-                              "(~1800 instructions per distance), not by HBM — priced here because the line's schema has no issue roofline"))
+                              "of 4 B x (mean length + 1) + 64 B of per-match state) + 16 B per candidate; the group kernels keep the sentences in "
+                              "registers over the rounds, so this is an upper bound of what they request; the stage is bound by VALU issue (a third "
+                              "of the group kernels' lanes have work), not by HBM — priced here because the line's schema has no issue roofline"))
         # the dominant kernel group = the longest stage, whatever it is (C5: the finish stage)
         roofs.sort(key=lambda r: -r["kernel_ms"])
         dominant, others = roofs[0], roofs[1:]

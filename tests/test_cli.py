@@ -104,3 +104,50 @@ def test_cli_raw_text_tm2_like_the_reference_ci(fmx, gpu_device, tmp_path):
     f = out[0].split("\t")
     assert len(f) == 4 and int(f[1]) >= 6 and f[3] in "I declare adjourned the session of the European Parliament ." and out[1] == ""
     assert "NMATCH\t1\t/\t2" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_blocks_and_formatting_tasks_keep_order_and_bytes(fmx, gpu_device, tmp_path):
+    """The streaming pipeline on an input of many blocks: 40 000 lines (some empty, one 20 KB long, the last without a line feed,
+    sentence ids of 3 to 40 characters so that both forms of the id table are used) through block sizes that cut them differently
+    — one line per block upwards; blocks beyond 8192 lines are formatted as several tasks by whichever workers are free — give
+    byte-identical output, in input order, equal to the records of the library's own id batch."""
+    _build(fmx)
+    rng = np.random.default_rng(23)
+    words = ["v%d" % i for i in range(300)]
+    sents = [[words[int(x)] for x in rng.integers(0, 300, size=int(rng.integers(2, 14)))] for _ in range(3000)]
+    ids = ["s%d" % i if i % 5 else "sentence-with-a-long-identifier-%010d" % i for i in range(len(sents))]
+    corpus = tmp_path / "corpus.tok"
+    corpus.write_text("".join("%s\t%s\n" % (ids[i], " ".join(s)) for i, s in enumerate(sents)))
+    r = subprocess.run([CLI, "--tokenised", "-c", str(corpus), "-a", "index"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    queries = []
+    for i in range(40_000):
+        s = list(sents[int(rng.integers(0, len(sents)))])
+        if i % 4 == 0:
+            s[int(rng.integers(0, len(s)))] = "unseen"
+        if i % 97 == 0:
+            s = []
+        queries.append(s)
+    queries[1234] = ["unseen"] * 5000   # a 30 KB line
+    inp = "\n".join(" ".join(q) for q in queries)   # no line feed after the last line
+    outs = []
+    for batch in ("1000", "8192", "65536", "3"):
+        lines_in = inp if batch != "3" else "\n".join(inp.split("\n")[:500])
+        r = subprocess.run([CLI, "--tokenised", "-i", str(corpus) + ".fmi", "-a", "match", "-f", "0.6", "-n", "4", "--ml", "2", "--mr", "0",
+                            "--batch", batch], input=lines_in, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr
+        outs.append(r.stdout)
+    assert outs[0] == outs[1] == outs[2]
+    assert outs[0].count("\n") == len(queries)
+    assert outs[3] == "".join(l + "\n" for l in outs[0].split("\n")[:500])
+    # the same records through the library (ids in, records out), printed like the CLI prints them
+    ix = fmx.Index.load(str(corpus) + ".fmi")
+    ix.to_device(gpu_device)
+    voc = {w: int(v) for w, v in zip(words + ["unseen"], ix.vocab_lookup(words + ["unseen"]))}
+    off = np.zeros(len(queries) + 1, np.uint32)
+    off[1:] = np.cumsum([len(q) for q in queries])
+    tok = np.array([voc[t] for q in queries for t in q], np.uint32)
+    go, gc, _ = ix.match_batch(fmx.Params(fuzzy=0.6, nmatch=4, min_subseq_length=2, min_subseq_ratio=0), off, tok, cap=4)
+    exp = "".join("\t".join("%.9g\t%s" % (go[q, k]["score"], ids[int(go[q, k]["s_id"])]) for k in range(int(gc[q]))) + "\n" for q in range(len(queries)))
+    assert outs[0] == exp
