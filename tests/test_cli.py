@@ -143,6 +143,7 @@ def test_cli_blocks_and_formatting_tasks_keep_order_and_bytes(fmx, gpu_device, t
     assert outs[3] == "".join(l + "\n" for l in outs[0].split("\n")[:500])
     # the same records through the library (ids in, records out), printed like the CLI prints them
     ix = fmx.Index.load(str(corpus) + ".fmi")
+    ix.finalize()
     ix.to_device(gpu_device)
     voc = {w: int(v) for w, v in zip(words + ["unseen"], ix.vocab_lookup(words + ["unseen"]))}
     off = np.zeros(len(queries) + 1, np.uint32)
