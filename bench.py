@@ -676,7 +676,7 @@ def main():
                 rounds = int(pkw.get("nmatch", 1)) if pkw.get("contrast", 0.0) > 0.0 else 1
                 for kern, pattern, per_step in (("fmx::k_probe", "random", 1), ("fmx::k_expand_a", "stream16", 1), ("fmx::k_expand_h", "stream8", 1),
                                                 ("fmx::k_expand_b", "random", 1), ("fmx::k_dp_reg", "random", 1), ("fmx::k_finish", "random", 1),
-                                                ("fmx::k_camap", "random", 1), ("fmx::k_cround", "random", rounds)):
+                                                ("fmx::k_camap", "random", 1), ("fmx::k_cround", "random", rounds), ("fmx::k_crerank_g", "random", 1)):
                     keys = [k for k in fetch if k.replace("void ", "").startswith(kern)]  # template instantiations add up
                     if not keys:
                         continue
@@ -726,7 +726,7 @@ def main():
             fin_ms = per_stage.get("finish", 0.0)
             b_fin = n_rerank * (8.0 * (mean_len + 1) + 64.0) + 16.0 * n_cand
             roofs.append(roof("finish stage: replay + k_crerank_g<8|16|32|64> (+ k_camap, nmatch x k_cround<64> for sentences of 33-64 tokens)", b_fin, fin_ms,
-                              ["k_finish", "k_cgrp_route", "k_crerank_g", "k_cacc", "k_camap", "k_cround"],
+                              ["k_finish", "k_crerank_g", "k_camap", "k_cround"],
                               f"replay + contrastive rerank; {int(n_rerank)} sentence-pair edit distances per step (kernel counter) x (two sentences "
                               "of 4 B x (mean length + 1) + 64 B of per-match state) + 16 B per candidate; the group kernels keep the sentences in "
                               "registers over the rounds, so this is an upper bound of what they request; the stage is bound by VALU issue (a third "
