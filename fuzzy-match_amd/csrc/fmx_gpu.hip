@@ -1095,7 +1095,7 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
             for (uint32_t r = 1; r <= prm.nmatch; r++)
               hipLaunchKernelGGL(k_cround<32>, dim3(1024), dim3(kWave), 0, side, E.d, b, w, prm, sc, r, cap, d_out, d_out_count, d_out_total);
             hipLaunchKernelGGL(k_crerank_g<32>, dim3(gg / 2), dim3(kWave), 0, g32_side ? side : stream, E.d, b, w, prm, (const uint32_t*)c.fin_list.p, 2u, cap, d_out, d_out_count, d_out_total);
-            hipLaunchKernelGGL(k_crerank_g<64>, dim3(gg / 4), dim3(kWave), 0, stream, E.d, b, w, prm, (const uint32_t*)c.contrast_list.p, 3u, cap, d_out, d_out_count, d_out_total);
+            hipLaunchKernelGGL(k_crerank_g<64>, dim3(gg), dim3(kWave), 0, stream, E.d, b, w, prm, (const uint32_t*)c.contrast_list.p, 3u, cap, d_out, d_out_count, d_out_total);
             join();
           } else {
             hipLaunchKernelGGL(k_camap, dim3((b.nq + kWave / kCamapGroup - 1) / (kWave / kCamapGroup)), dim3(kWave), 0, stream, E.d, b, w, sc, prm, d_out_count, d_out_total);
