@@ -1,5 +1,5 @@
 """Design-time: idle gaps of the GPU (> min_us between the end of everything running and the next kernel start) in a
-rocprofv3 kernel trace, with the k_probe index they fall behind.  python tools/gaps.py <dir> [min_us]"""
+rocprofv3 kernel trace, with the k_probe index they fall behind.  python tools/dbg/gaps.py <dir> [min_us]"""
 import csv, glob, sys
 d = sys.argv[1]; min_us = float(sys.argv[2]) if len(sys.argv) > 2 else 200.0
 kt = sorted(glob.glob(d + "/**/*kernel_trace.csv", recursive=True))[-1]

@@ -1,12 +1,12 @@
 """Design-time sweep of the host-buffer path (fmx_match_batch from pinned buffers): host_lanes x host_sub_queries,
-several repeats each, on the C3 workload.  python tools/host_sweep.py [steps] [repeats]"""
+several repeats each, on the C3 workload.  python tools/dbg/host_sweep.py [steps] [repeats]"""
 import os
 import sys
 import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch  # noqa: E402

@@ -1,11 +1,11 @@
 """Design-time: a few fmx_match_batch calls (pinned host buffers) on the C3 workload, to be run under
-rocprofv3 --kernel-trace --memory-copy-trace.  python tools/host_trace.py <lanes> <host_sub_queries> [steps]"""
+rocprofv3 --kernel-trace --memory-copy-trace.  python tools/dbg/host_trace.py <lanes> <host_sub_queries> [steps]"""
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import synth  # noqa: E402

@@ -1,5 +1,5 @@
 """Design-time: per pass (k_setup .. next k_setup on the same stream) the stream / queue ids and the duration and start
-offset of the large kernels.  python tools/passes.py <dir> [first_pass] [n]"""
+offset of the large kernels.  python tools/dbg/passes.py <dir> [first_pass] [n]"""
 import csv, glob, sys
 d = sys.argv[1]; first = int(sys.argv[2]) if len(sys.argv) > 2 else 0; n = int(sys.argv[3]) if len(sys.argv) > 3 else 12
 kt = sorted(glob.glob(d + "/**/*kernel_trace.csv", recursive=True))[-1]

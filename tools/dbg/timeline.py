@@ -1,5 +1,5 @@
 """Design-time: GPU timeline of the last calls in a rocprofv3 kernel + memory-copy trace: per kernel launch
-start/end relative to the first, grouped into passes (k_setup starts a pass).  python tools/timeline.py <dir> [n_passes] [min_us]"""
+start/end relative to the first, grouped into passes (k_setup starts a pass).  python tools/dbg/timeline.py <dir> [n_passes] [min_us]"""
 import csv
 import glob
 import sys
