@@ -31,6 +31,7 @@ Prints ONE JSON line on rank 0.
 import argparse
 import concurrent.futures as cf
 import csv
+import datetime
 import glob
 import json
 import os
@@ -104,7 +105,9 @@ def pmc_pass(counter, argv_child, log):
         return None
     out = tempfile.mkdtemp(prefix=f"fmx_pmc_{counter}_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+    if "LOCAL_RANK" in env and "HIP_VISIBLE_DEVICES" not in env and env.get("FMX_BENCH_BACKEND") != "gloo":
+        env["HIP_VISIBLE_DEVICES"] = env["LOCAL_RANK"]   # the child is one process on this rank's GPU
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
         env.pop(k, None)
     cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable,
            os.path.join(ROOT, "bench.py"), "--child"] + argv_child
@@ -171,9 +174,10 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "gloo":
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=30))
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            # (rank 0 checks parity against the oracle and runs the rocprofv3 child passes while the others wait at the last barrier)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(minutes=30))
 
     n_sent, mean_len, nq_cfg, pkw = CONFIGS[args.config]
     n_sent = args.sentences or n_sent
@@ -208,6 +212,18 @@ def main():
         return off, tok
 
     raw_main = [draw(k, args.scaling) for k in range(NB)]
+    # N > 1: rank 0 also holds EVERY rank's block of the batch the value leg's last timed step runs, to check what the RCCL gather
+    # assembled from the other ranks against the oracle (cli/src/FuzzyMatch-cli.cc:151-162: results in input order)
+    n_text_batches = min(NB, T_text + 1)
+    b_last_text = (args.steps - 1) % n_text_batches
+    all_blocks = None
+    if world > 1 and rank == 0 and args.verify:
+        if args.scaling == "strong":
+            off_all, tok_all = queries(synth.QUERY_SEED + b_last_text, nq_cfg)
+            all_blocks = [shard.shard_batch(off_all, tok_all, r, world)[:2] for r in range(world)]
+            del off_all, tok_all
+        else:
+            all_blocks = [queries(synth.QUERY_SEED + b_last_text + 101 * r, nq_cfg) for r in range(world)]
     other_scaling = "strong" if args.scaling == "weak" else "weak"
     raw_other = [draw(k, other_scaling) for k in range(NB_host)] if world > 1 else []
     L.fms_free(hc)
@@ -468,6 +484,8 @@ def main():
 
     # what a leg's last timed step left behind, sampled for the parity check: {leg: (batch index, query indices, records, counts)}
     samples = {}
+    # N > 1, value leg: (rank, that rank's block as CSR, query indices inside the block, gathered records, gathered counts)
+    gathered_samples = []
 
     def sample_idx(nq):
         nv = min(args.verify, nq)
@@ -528,6 +546,22 @@ def main():
             idx = sample_idx(wls[b_].nq)
             o_, c_, _t = out_slots[i % T_text]
             samples[leg] = (b_, idx, o_[idx].copy(), c_[idx].copy())
+            if world > 1 and gather is not None and all_blocks is not None:
+                # what the gather of the LAST timed step left on rank 0, in global query order: a spread sample of EVERY rank's block
+                assert b_ == b_last_text
+                g_out, g_cnt = gather.result(i)
+                g_out = g_out.cpu().numpy().view(fmx.MATCH_DTYPE).reshape(-1, cap)
+                g_cnt = g_cnt.cpu().numpy().astype(np.uint32)
+                start = 0
+                per = max(args.verify // world, 1)
+                for r in range(world):
+                    off_r, tok_r = all_blocks[r]
+                    n_r = len(off_r) - 1
+                    assert n_r == gather.sizes[r], (r, n_r, gather.sizes)
+                    nv = min(per, n_r)
+                    idx_r = np.arange(nv, dtype=np.int64) * n_r // max(nv, 1)
+                    gathered_samples.append((r, off_r, tok_r, idx_r, g_out[start + idx_r].copy(), g_cnt[start + idx_r].copy()))
+                    start += n_r
         return el
 
     elapsed = measure_text(text_set, "value")
@@ -660,13 +694,16 @@ def main():
 
         # ---- HBM traffic of the kernels, measured now: rocprofv3 --pmc child passes (separate passes) ----
         traffic = {}
-        if world == 1 and not args.no_pmc:
-            child = ["--config", args.config, "--steps", "2", "--warmup", "1", "--scaling", args.scaling, "--threads", str(args.threads),
+        if not args.no_pmc:
+            # N > 1: the child passes run here on rank 0 only (one process, this rank's GPU, this rank's share of the step), the other
+            # ranks wait at the barrier that ends the run — `roofline.traffic` is measured at every N (north_star: "rocprof HBM GB/s
+            # vs peak reported at 1/2/4/8 GPUs")
+            child = ["--config", args.config, "--steps", "2", "--warmup", "1", "--scaling", "weak", "--threads", str(args.threads),
                      "--host-threads", str(args.host_threads)]
             if args.sentences:
                 child += ["--sentences", str(args.sentences)]
-            if args.queries:
-                child += ["--queries", str(args.queries)]
+            if world > 1 or args.queries:
+                child += ["--queries", str(main_set[0].nq)]
             cal = json.load(open(CALIBRATION)) if os.path.exists(CALIBRATION) else {}
             t1 = time.time()
             fetch = pmc_pass("FETCH_SIZE", child, log)
@@ -706,6 +743,13 @@ def main():
                      "phase A of the queries with long ranges or many hits (two kernels side by side): 8 B per bit-plane word, "
                      "8 B per plane survivor re-tested, 8 B per hit walked one by one, 8 B per hit queued, 8 B per range "
                      "descriptor (kernel counters)")
+        if r_exa["traffic"]:
+            # These two kernels REQUEST more bytes than reach HBM (neighbouring work items share plane rows in L2): a model above the
+            # counted traffic is not an HBM fraction.  One number: the counted traffic; the requested bytes stay as a note.
+            r_exa.update({"achieved": r_exa["traffic_gbps"], "frac": r_exa["traffic_frac"], "requested_bytes_per_launch": r_exa["algorithmic_bytes_per_launch"],
+                          "algorithmic_bytes_per_launch": r_exa["traffic"],
+                          "model": "HBM bytes counted by rocprofv3 (FETCH_SIZE / WRITE_SIZE passes of this run); the kernels request more — "
+                                   "requested_bytes_per_launch: " + r_exa["model"]})
         r_probe["lines_bytes_per_launch"] = int(probe_lines) * 128  # 128 B lines its loads touch x 128: what random reads cost the memory system
         r_exb = roof("k_expand_b<true>+k_expand_b<false>", b_exb, exb_ms, ["k_expand_b"],
                      "hit walk of the light queries + phase B of the others (side by side): 8 B range descriptor per start, 16 B "
@@ -755,9 +799,21 @@ def main():
                     want[key] = o.match_batch(oprm, s_off, s_tok, cap, nthreads=oracle_lib.effective_cpus())
                 oo, oc = want[key]
                 bad[leg] = sum(int(oc[q] != cnts[q] or oo[q, :oc[q]].tobytes() != recs[q, :cnts[q]].tobytes()) for q in range(len(idx)))
-            parity = {"checked": int(min(args.verify, host_set[0].nq)), "mismatches": int(sum(bad.values())), "per_leg": bad,
+            per_rank_block = None
+            if gathered_samples:
+                per_rank_block = []
+                for r, off_r, tok_r, idx_r, recs, cnts in gathered_samples:
+                    s_off, s_tok = take_queries(off_r, tok_r, idx_r)
+                    oo, oc = o.match_batch(oprm, s_off, s_tok, cap, nthreads=oracle_lib.effective_cpus())
+                    nbad = sum(int(oc[q] != cnts[q] or oo[q, :oc[q]].tobytes() != recs[q, :cnts[q]].tobytes()) for q in range(len(idx_r)))
+                    per_rank_block.append({"rank": r, "queries_in_block": int(len(off_r) - 1), "checked": int(len(idx_r)), "mismatches": int(nbad)})
+            parity = {"checked": int(min(args.verify, host_set[0].nq)),
+                      "mismatches": int(sum(bad.values()) + sum(x["mismatches"] for x in (per_rank_block or []))), "per_leg": bad,
+                      "per_rank_block": per_rank_block,
                       "paths": "what the LAST timed step of each leg left behind (the value leg, the device-resident pipeline, the id batches, the "
-                               "staged calls), every (nq / checked)-th query of that step's batch, vs the oracle"}
+                               "staged calls), every (nq / checked)-th query of that step's batch, vs the oracle; N > 1: per_rank_block = what "
+                               "the RCCL gather of the value leg's last timed step assembled on rank 0, a spread sample of every rank's block "
+                               "(global query order, cli/src/FuzzyMatch-cli.cc:151-162) vs the oracle"}
         q_off, q_tok, nq = main_set[0].q_off, main_set[0].q_tok, main_set[0].nq
         nm = min(args.model_queries, nq)
         if nm:
@@ -780,10 +836,27 @@ def main():
             t1 = time.perf_counter()
             o.match_batch(oprm, q_off[:ns2 + 1], q_tok[:int(q_off[ns2])], cap, nthreads=cores)
             dt = time.perf_counter() - t1
+            # the same with ONE thread ("with N = all host cores ... and with N = 1"), a few seconds of it
+            ns1 = int(min(ns2, max(500, rate / max(cores, 1) * min(args.cpu_seconds, 6.0))))
+            t1 = time.perf_counter()
+            o.match_batch(oprm, q_off[:ns1 + 1], q_tok[:int(q_off[ns1])], cap, nthreads=1)
+            dt1 = time.perf_counter() - t1
+            cpu_model = ""
+            try:
+                for ln in open("/proc/cpuinfo"):
+                    if ln.startswith("model name"):
+                        cpu_model = ln.split(":", 1)[1].strip()
+                        break
+            except OSError:
+                pass
             cpu_baseline = {"value": round(ns2 / dt, 1), "unit": "patterns/s", "cores": cores, "kind": "port",
+                            "value_n1": round(ns1 / dt1, 1), "cpu_model": cpu_model, "hardware_threads": os.cpu_count(),
+                            "cpu_quota": f"{cores} of {os.cpu_count()} hardware threads usable (min(affinity, cgroup cpu.max)); the oracle scales "
+                                         "to the quota and not beyond",
                             "sample": f"first {ns2} queries of batch 0 of the same {args.config} workload, oracle/fm_oracle.c "
                                       f"fmo_match_batch with {cores} threads (= usable CPUs: min(affinity, cgroup cpu.max) of "
-                                      f"{os.cpu_count()} hardware threads), ids in (no lookup), {dt:.1f}s"}
+                                      f"{os.cpu_count()} hardware threads), ids in (no lookup), {dt:.1f}s; value_n1: the first {ns1} of them "
+                                      f"with one thread, {dt1:.1f}s"}
         o.close()
 
         text_bytes = int(text_set[0].text.nbytes)

@@ -38,6 +38,9 @@ struct fmx_index {
   int64_t                                   min_block_queries = 32768;  // a replica / host lane gets a block only if it is at least this large
   bool                                      dup_devices = false;  // tests: the same ordinal may carry several replicas (option "duplicate_devices")
   std::atomic<uint32_t>                     rr{0};            // round-robin replica for batches too small to shard
+  std::mutex                                pend_mu;          // the begun-and-not-ended calls of this index (fmx_pending handles):
+  std::vector<fmx_pending*>                 pend;             // drained by fmx_index_free / fmx_index_reopen, so no call outlives its replica
+  void drain_pending();
   ~fmx_index();
 };
 
@@ -94,7 +97,10 @@ fmx_index* fmx_index_create(int32_t pt, uint64_t max_tokens_in_pattern) {
   }
 }
 
-void fmx_index_free(fmx_index* ix) { delete ix; }
+void fmx_index_free(fmx_index* ix) {
+  if (ix) ix->drain_pending();  // calls begun and never ended: waited for and released before their replica goes
+  delete ix;
+}
 
 fmx_index* fmx_index_load(const char* fmi_path, char* err, size_t errlen) {
   std::unique_ptr<fmx_index> ix;
@@ -465,6 +471,20 @@ int fmx_match_batch_keep(fmx_index* ix, const fmx_params* params, const fmx_batc
   });
 }
 
+// the (slot, id) pairs of a text batch index the penalty-string distance table on the device: ids the index never interned and slots
+// beyond the batch's tokens (+ one trailing slot per pattern) are refused here, on the host (they are few)
+static const char* text_batch_itoks_invalid(fmx_index* ix, const fmx_text_batch* tb) {
+  if (!tb->n_itoks || !ix->host.real_differs) return nullptr;
+  uint64_t n_known;
+  { std::lock_guard<std::mutex> g(ix->host.itok_sync_mu); n_known = ix->host.itok_strings.size(); }
+  const uint64_t n_slots = (uint64_t)tb->q_off[tb->nq] + tb->nq;
+  for (uint64_t k = 0; k < tb->n_itoks; k++) {
+    if (tb->itok_id[k] >= n_known) return "text batch: a penalty-token id the index has not interned (fmx_intern_itok)";
+    if (tb->itok_slot[k] >= n_slots) return "text batch: a penalty-token slot beyond the batch (slots = tokens + one trailing slot per pattern)";
+  }
+  return nullptr;
+}
+
 int fmx_match_batch_text(fmx_index* ix, const fmx_params* params, const fmx_text_batch* tb, fmx_match* out,
                          uint32_t* out_count, uint32_t* out_total, uint32_t cap, fmx_stats* stats) {
   return fmx_match_batch_text_keep(ix, params, tb, out, out_count, out_total, cap, nullptr, nullptr, stats);
@@ -483,6 +503,7 @@ int fmx_match_batch_text_keep(fmx_index* ix, const fmx_params* params, const fmx
   if (ix->devs.empty()) return fail(FMX_E_NO_DEVICE, "index is not on a device (fmx_index_to_device); there is no CPU path");
   if (tb->nq && tb->real_text && tb->q_off[tb->nq] > tb->n_real_bytes) return fail(FMX_E_INVALID, "text batch: fewer real-token bytes than spellings counted by the offsets");
   if (tb->n_itoks && (!tb->itok_slot || !tb->itok_id)) return fail(FMX_E_INVALID, "text batch: null penalty-token arrays");
+  if (const char* why = text_batch_itoks_invalid(ix, tb)) return fail(FMX_E_INVALID, why);
   return guarded([&]() {
     HostBatchView v;
     v.nq = tb->nq; v.q_off = tb->q_off; v.text = tb->text; v.n_text = tb->n_bytes;
@@ -500,11 +521,44 @@ int fmx_match_batch_text_keep(fmx_index* ix, const fmx_params* params, const fmx
   });
 }
 
+// One handle type serves both asynchronous entry points; whichever _end receives it, the call is finished through the path it was
+// begun on (a text handle handed to fmx_match_batch_device_end used to leak its context lease: round-4 advice).
 struct fmx_pending {
   DeviceIndex*           dev = nullptr;
   DeviceIndex::Pending*  p = nullptr;   // a device-resident call (fmx_match_batch_device_begin)
   DeviceIndex::HostCall* hc = nullptr;  // a host-buffer call (fmx_match_batch_text_begin)
 };
+
+static void pending_register(fmx_index* ix, fmx_pending* h) {
+  std::lock_guard<std::mutex> g(ix->pend_mu);
+  ix->pend.push_back(h);
+}
+// true if the handle belongs to this index and is still pending (it is then removed from the list: the caller finishes it)
+static bool pending_claim(fmx_index* ix, fmx_pending* h) {
+  std::lock_guard<std::mutex> g(ix->pend_mu);
+  for (size_t k = 0; k < ix->pend.size(); k++)
+    if (ix->pend[k] == h) { ix->pend[k] = ix->pend.back(); ix->pend.pop_back(); return true; }
+  return false;
+}
+// waits for the call and brings its records home; throws what the call throws
+static void pending_finish(fmx_pending* h) {
+  if (DeviceIndex::HostCall* hc = h->hc) { h->hc = nullptr; h->dev->match_host_end(hc); }
+  if (DeviceIndex::Pending* p = h->p) { h->p = nullptr; h->dev->match_device_end(p); }
+}
+static int pending_end(fmx_index* ix, fmx_pending* pending) {
+  if (!ix || !pending) return fail(FMX_E_INVALID, "null argument");
+  if (!pending_claim(ix, pending)) return fail(FMX_E_INVALID, "not a pending call of this index (ended twice, or begun on another index)");
+  std::unique_ptr<fmx_pending> h(pending);
+  return guarded([&]() { pending_finish(h.get()); return (int)FMX_OK; });
+}
+void fmx_index::drain_pending() {
+  std::vector<fmx_pending*> left;
+  { std::lock_guard<std::mutex> g(pend_mu); left.swap(pend); }
+  for (fmx_pending* h : left) {
+    try { pending_finish(h); } catch (...) {}
+    delete h;
+  }
+}
 
 int fmx_match_batch_text_begin(fmx_index* ix, const fmx_params* params, const fmx_text_batch* tb, fmx_match* out, uint32_t* out_count,
                                uint32_t* out_total, uint32_t cap, fmx_match* d_keep, uint32_t* d_keep_count, fmx_pending** pending) {
@@ -518,6 +572,7 @@ int fmx_match_batch_text_begin(fmx_index* ix, const fmx_params* params, const fm
   if (cap == 0) return fail(FMX_E_INVALID, "cap must be > 0");
   if (!ix->finalized) return fail(FMX_E_STATE, "index is not finalized");
   if (ix->devs.empty()) return fail(FMX_E_NO_DEVICE, "index is not on a device (fmx_index_to_device); there is no CPU path");
+  if (const char* why = text_batch_itoks_invalid(ix, tb)) return fail(FMX_E_INVALID, why);
   return guarded([&]() {
     std::unique_ptr<fmx_pending> hp(new fmx_pending);
     HostBatchView v;
@@ -528,21 +583,13 @@ int fmx_match_batch_text_begin(fmx_index* ix, const fmx_params* params, const fm
     }
     hp->dev = ix->devs[0].get();  // (pending calls of one thread share the first replica: their contexts overlap on one GPU)
     hp->hc = hp->dev->match_host_begin(ix->host, make_params(ix, params), v, (Rec*)out, out_count, out_total, cap, (Rec*)d_keep, d_keep_count);
+    pending_register(ix, hp.get());
     *pending = hp.release();
     return (int)FMX_OK;
   });
 }
 
-int fmx_match_batch_text_end(fmx_index* ix, fmx_pending* pending) {
-  if (!ix || !pending) return fail(FMX_E_INVALID, "null argument");
-  std::unique_ptr<fmx_pending> hp(pending);
-  return guarded([&]() {
-    DeviceIndex::HostCall* hc = hp->hc;
-    hp->hc = nullptr;
-    if (hc) hp->dev->match_host_end(hc);
-    return (int)FMX_OK;
-  });
-}
+int fmx_match_batch_text_end(fmx_index* ix, fmx_pending* pending) { return pending_end(ix, pending); }
 
 int fmx_match_batch_lines(fmx_index* ix, const fmx_params* params, const char* text, uint64_t n_bytes, uint64_t n_lines,
                           fmx_match* out, uint32_t* out_count, uint32_t* out_total, uint32_t cap, fmx_stats* stats) {
@@ -855,6 +902,7 @@ int64_t fmx_index_add_text(fmx_index* ix, const char* id, const char* sentence, 
 int fmx_index_reopen(fmx_index* ix) {
   if (!ix) return fail(FMX_E_INVALID, "null argument");
   // (the coalescer stays: it holds no device state, and it is constructed once per index — std::call_once)
+  ix->drain_pending();
   ix->sort_resident.reset();
   ix->devs.clear();
   ix->finalized = false;
@@ -907,7 +955,7 @@ int fmx_match_batch_device_begin(fmx_index* ix, const fmx_params* params, const 
     return fail(FMX_E_INVALID, "this index has real tokens: device batches must carry q_real");
   return guarded([&]() {
     std::unique_ptr<fmx_pending> h(new fmx_pending);
-    if (db->nq == 0) { *pending = h.release(); return (int)FMX_OK; }
+    if (db->nq == 0) { pending_register(ix, h.get()); *pending = h.release(); return (int)FMX_OK; }
     DeviceIndex* dev = ix->devs[0].get();
     DeviceBatchView v;
     v.nq = db->nq; v.q_off = db->q_off; v.q_tok = db->q_tok; v.q_real = db->q_real; v.q_itok = db->q_itok;
@@ -920,19 +968,13 @@ int fmx_match_batch_device_begin(fmx_index* ix, const fmx_params* params, const 
     if (v.p_max == 0) v.p_max = 1;
     h->dev = dev;
     h->p = dev->match_device_begin(ix->host, make_params(ix, params), v, (Rec*)d_out, d_out_count, d_out_total, cap, stream, bounds);
+    pending_register(ix, h.get());
     *pending = h.release();
     return (int)FMX_OK;
   });
 }
 
-int fmx_match_batch_device_end(fmx_index* ix, fmx_pending* pending) {
-  if (!ix || !pending) return fail(FMX_E_INVALID, "null argument");
-  std::unique_ptr<fmx_pending> h(pending);
-  if (!h->p) return FMX_OK;
-  DeviceIndex::Pending* p = h->p;
-  h->p = nullptr;
-  return guarded([&]() { h->dev->match_device_end(p); return (int)FMX_OK; });
-}
+int fmx_match_batch_device_end(fmx_index* ix, fmx_pending* pending) { return pending_end(ix, pending); }
 
 int fmx_set_option(fmx_index* ix, const char* name, int64_t value) {
   if (!ix || !name) return fail(FMX_E_INVALID, "null argument");
@@ -952,6 +994,7 @@ int fmx_set_option(fmx_index* ix, const char* name, int64_t value) {
     else if (n == "initial_segment") d->set_initial_segment((uint64_t)std::max<int64_t>(value, 1024));
     else if (n == "heavy_min") d->set_heavy_min((uint32_t)std::max<int64_t>(value, 0));
     else if (n == "contexts") d->set_contexts((uint32_t)std::max<int64_t>(value, 1));
+    else if (n == "max_host_active") d->set_max_host_active((uint32_t)std::max<int64_t>(value, 1));
     else if (n == "probe_count") d->set_probe_count(value != 0);
     else if (n == "serial") d->set_serial(value != 0);
     else if (n == "pair_finish") d->set_pair_finish(value != 0);

@@ -115,6 +115,7 @@ class DeviceIndex {
   void     set_heavy_grid(uint32_t n);  // workgroups of the bit-plane kernel
   void     set_light_max(uint32_t n);   // queries with at most n hits, all in short ranges, skip phase A (0 = none do)
   void     set_contexts(uint32_t n);    // concurrent calls served at once (each owns a workspace)
+  void     set_max_host_active(uint32_t n);  // host-buffer calls that may have work on the GPU at once, whatever "contexts" says (default 4): further ones wait on the host
 
   // every pointer in HBM of device(); sub_tok_bounds = q_off at each sub-batch boundary (+ q_off[nq])
   void match_device(const HostIndex& h, const Params& prm, const DeviceBatchView& b, Rec* d_out,

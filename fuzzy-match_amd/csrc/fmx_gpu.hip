@@ -18,6 +18,8 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <deque>
+#include <exception>
 #include <memory>
 #include <mutex>
 #include <shared_mutex>
@@ -93,7 +95,7 @@ struct ParkedBlocks {
   std::mutex mu;
   std::vector<std::pair<void*, uint64_t>> blocks;
   uint64_t bytes = 0;
-  static constexpr uint64_t kParkedMax = 48ull << 30;
+  static constexpr uint64_t kParkedMax = 8ull << 30;  // per device (round 4: 48 GiB for the whole process, freed under whichever device was current)
   void park(void* p, uint64_t n) {
     std::vector<std::pair<void*, uint64_t>> drop;
     {
@@ -102,15 +104,23 @@ struct ParkedBlocks {
       bytes += n;
       if (bytes > kParkedMax) { drop.swap(blocks); bytes = 0; }
     }
+    // (the current device is the owner's: a context only grows its buffers under hipSetDevice of its index's device)
     if (!drop.empty()) { (void)hipDeviceSynchronize(); for (auto& b : drop) (void)hipFree(b.first); }
   }
-  void drain() {  // the caller has synchronised the device
+  bool empty() { std::lock_guard<std::mutex> g(mu); return blocks.empty(); }
+  void drain() {  // the caller made its device current; nothing of this process is using the blocks any more (hipFree waits for the device)
     std::vector<std::pair<void*, uint64_t>> drop;
     { std::lock_guard<std::mutex> g(mu); drop.swap(blocks); bytes = 0; }
     for (auto& b : drop) (void)hipFree(b.first);
   }
 };
-static ParkedBlocks& parked_blocks() { static ParkedBlocks* pb = new ParkedBlocks; return *pb; }
+// one list per device ordinal: a block is parked, and later freed, under the device that owns it
+static ParkedBlocks& parked_blocks() {
+  static ParkedBlocks* pb = new ParkedBlocks[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+  return pb[(dev >= 0 && dev < 64) ? dev : 0];
+}
 
 // device buffer that only ever grows, by at least 1.5x (first-call and heavy-tail latency cliffs: one buffer
 // growing never frees the others); the outgrown block is parked, not freed (see ParkedBlocks)
@@ -289,6 +299,8 @@ struct Ctx {
   }
 };
 
+struct DeferredCall;
+
 struct DeviceIndex::Impl {
   int      device = -1;
   uint64_t n_tok_words = 0;  // words of m.d.tok (device layout of the sentence buffer, without the eight spare words)
@@ -365,13 +377,28 @@ struct DeviceIndex::Impl {
   std::condition_variable pool_cv;
   std::vector<std::unique_ptr<Ctx>> all;
   std::vector<Ctx*>       idle;
+  // Admission (round 5).  How many calls may have work on the GPU at once is a property of the GPU, not of how many contexts a
+  // caller asked for: every host-buffer call in flight keeps two compute queues and the index's pair of copy queues busy, and
+  // beyond about a dozen recently active hardware queues the GPU's scheduler time-slices them — five callers spend their first
+  // seconds after an index build at ~300 ms per step, eight crawl throughout.  So at most max_host_active
+  // host-buffer calls hold a context at any time whatever "contexts" says; further synchronous callers wait HERE, on the host, and
+  // further _begin calls are deferred (DeferredCall) and started, in order, by whoever frees a slot.
+  uint32_t                max_host_active = [] { const char* e = getenv("FMX_MAX_HOST_ACTIVE"); return e ? (uint32_t)std::max(atoi(e), 1) : 4u; }();
+  uint32_t                host_active = 0;
+  std::deque<DeferredCall*> deferred;
 
-  // wait = false: nullptr instead of waiting when every context is busy (check and take are one critical section)
-  Ctx* acquire(bool wait = true) {
+  bool may_take(bool host_kind) const {  // under pool_mu
+    return (!host_kind || host_active < max_host_active) && (!idle.empty() || all.size() < max_ctx);
+  }
+  // wait = false: nullptr instead of waiting when no context may be taken (check and take are one critical section).
+  // force: one more context than the pool's limit rather than a dead-lock (a deferred call ended before any slot was freed).
+  Ctx* acquire(bool wait = true, bool host_kind = false, bool force = false) {
     std::unique_lock<std::mutex> lk(pool_mu);
     for (;;) {
-      if (!idle.empty()) { Ctx* c = idle.back(); idle.pop_back(); return c; }
-      if (all.size() < max_ctx) {
+      const bool admitted = force || !host_kind || host_active < max_host_active;
+      if (admitted && !idle.empty()) { Ctx* c = idle.back(); idle.pop_back(); if (host_kind) host_active++; return c; }
+      if (admitted && (all.size() < max_ctx || force)) {
+        if (host_kind) host_active++;
         all.emplace_back(new Ctx);
         Ctx* c = all.back().get();
         c->cu_group = (int)((all.size() - 1) % 2);
@@ -385,29 +412,116 @@ struct DeviceIndex::Impl {
         }
         const hipStream_t sh = copy_h2d, sd = copy_d2h;
         lk.unlock();
-        try { c->init(sh, sd); } catch (...) { lk.lock(); idle.push_back(c); pool_cv.notify_one(); throw; }
+        try { c->init(sh, sd); } catch (...) { lk.lock(); idle.push_back(c); if (host_kind) host_active--; pool_cv.notify_all(); throw; }
         return c;
       }
       if (!wait) return nullptr;
       pool_cv.wait(lk);
     }
   }
-  void release(Ctx* c) {
-    { std::lock_guard<std::mutex> lk(pool_mu); idle.push_back(c); }
-    pool_cv.notify_one();
+  void release(Ctx* c, bool host_kind = false) {
+    bool quiet;
+    {
+      std::lock_guard<std::mutex> lk(pool_mu);
+      idle.push_back(c);
+      if (host_kind && host_active) host_active--;
+      quiet = idle.size() == all.size() && deferred.empty();
+    }
+    // a quiet point of the index (no call holds a context): what its contexts outgrew is freed now, not kept until the index goes
+    if (quiet && device >= 0 && !parked_blocks().empty()) parked_blocks().drain();
+    pool_cv.notify_all();  // (waiters of both kinds, and _end calls waiting for a deferred start)
+    start_deferred();
   }
+  void start_deferred() noexcept;
 };
+
+// thrown by a lease that may not wait: the call is deferred, not refused
+struct NoContext : std::runtime_error { NoContext() : std::runtime_error("no context may be taken now") {} };
 
 struct CtxLease {
   DeviceIndex::Impl& m;
   Ctx* c;
-  explicit CtxLease(DeviceIndex::Impl& m_, bool no_wait = false) : m(m_), c(m_.acquire(!no_wait)) {
-    if (!c) throw std::invalid_argument("every context of the index is busy: end a pending call first, or raise the option \"contexts\"");
-    if (!c->ok) { Ctx* bad = c; c = nullptr; m.release(bad); throw GpuError("context initialisation failed earlier"); }
+  bool host_kind;
+  explicit CtxLease(DeviceIndex::Impl& m_, bool no_wait = false, bool host_kind_ = false, bool force = false)
+      : m(m_), c(m_.acquire(!no_wait, host_kind_, force)), host_kind(host_kind_) {
+    if (!c) throw NoContext();
+    if (!c->ok) { Ctx* bad = c; c = nullptr; m.release(bad, host_kind); throw GpuError("context initialisation failed earlier"); }
   }
-  void release_now() { if (c) { m.release(c); c = nullptr; } }
-  ~CtxLease() { if (c) m.release(c); }
+  void release_now() { if (c) { Ctx* x = c; c = nullptr; m.release(x, host_kind); } }
+  ~CtxLease() { release_now(); }
 };
+
+// A call begun through one of the _begin entry points when no context may be taken (every context busy, or the host-buffer calls
+// at their limit): it waits on the host, in order, and is started by the thread that frees a slot — or, at the latest, by its own
+// _end.  State changes under Impl::pool_mu, announced on pool_cv.
+struct DeferredCall {
+  enum State { kStarted, kQueued, kStarting, kFailed };
+  State state = kStarted;
+  bool host_kind = false;
+  std::function<void(bool)> start;  // enqueues the call; the argument: take a context beyond the pool's limit if there is none
+  std::exception_ptr err;
+};
+
+void DeviceIndex::Impl::start_deferred() noexcept {
+  for (;;) {
+    DeferredCall* d = nullptr;
+    {
+      std::lock_guard<std::mutex> lk(pool_mu);
+      if (deferred.empty() || !may_take(deferred.front()->host_kind)) return;
+      d = deferred.front();
+      deferred.pop_front();
+      d->state = DeferredCall::kStarting;
+    }
+    bool again = false;
+    try { d->start(false); }
+    catch (const NoContext&) { again = true; }  // another thread took the context in between: back to the head of the line
+    catch (...) { d->err = std::current_exception(); }
+    {
+      std::lock_guard<std::mutex> lk(pool_mu);
+      if (again) { d->state = DeferredCall::kQueued; deferred.push_front(d); }
+      else d->state = d->err ? DeferredCall::kFailed : DeferredCall::kStarted;
+    }
+    pool_cv.notify_all();
+    if (again) return;
+  }
+}
+
+// _begin: run the call's start now, or queue it.  _end: make sure it has started (rethrows what the start threw).
+static void begin_or_defer(DeviceIndex::Impl& m, DeferredCall& d) {
+  {
+    std::lock_guard<std::mutex> lk(m.pool_mu);
+    if (!m.deferred.empty()) {  // calls are started in the order they were begun
+      d.state = DeferredCall::kQueued;
+      m.deferred.push_back(&d);
+      return;
+    }
+  }
+  try { d.start(false); d.state = DeferredCall::kStarted; }
+  catch (const NoContext&) {
+    { std::lock_guard<std::mutex> lk(m.pool_mu); d.state = DeferredCall::kQueued; m.deferred.push_back(&d); }
+    m.start_deferred();  // (a slot may have been freed between the failed attempt and the queueing)
+  }
+}
+static void ensure_started(DeviceIndex::Impl& m, DeferredCall& d) {
+  std::unique_lock<std::mutex> lk(m.pool_mu);
+  if (d.state == DeferredCall::kQueued) {
+    for (auto it = m.deferred.begin(); it != m.deferred.end(); ++it)
+      if (*it == &d) { m.deferred.erase(it); break; }
+    d.state = DeferredCall::kStarting;
+    lk.unlock();
+    // the slots may all be held by pending calls of THIS thread, which it would end after this one: one context more than the
+    // limit rather than a dead-lock
+    try { d.start(true); } catch (...) { d.err = std::current_exception(); }
+    lk.lock();
+    d.state = d.err ? DeferredCall::kFailed : DeferredCall::kStarted;
+    lk.unlock();
+    m.pool_cv.notify_all();
+  } else {
+    m.pool_cv.wait(lk, [&] { return d.state == DeferredCall::kStarted || d.state == DeferredCall::kFailed; });
+    lk.unlock();
+  }
+  if (d.err) { std::exception_ptr e = d.err; d.err = nullptr; std::rethrow_exception(e); }
+}
 
 DeviceIndex::DeviceIndex() : impl_(new Impl) {}
 
@@ -450,8 +564,17 @@ void     DeviceIndex::set_b_grid(uint32_t n) { impl_->b_grid = std::min<uint32_t
 void     DeviceIndex::set_heavy_grid(uint32_t n) { impl_->heavy_grid = std::min<uint32_t>(std::max<uint32_t>(n, 64u), 65536u); }
 void     DeviceIndex::set_light_max(uint32_t n) { impl_->light_max = std::min<uint32_t>(n, kPhaseBChunk); }
 void     DeviceIndex::set_contexts(uint32_t n) {
-  std::lock_guard<std::mutex> lk(impl_->pool_mu);
-  impl_->max_ctx = std::max<uint32_t>(std::max<uint32_t>(n, 1), (uint32_t)impl_->all.size());
+  {
+    std::lock_guard<std::mutex> lk(impl_->pool_mu);
+    impl_->max_ctx = std::max<uint32_t>(std::max<uint32_t>(n, 1), (uint32_t)impl_->all.size());
+  }
+  impl_->pool_cv.notify_all();
+  impl_->start_deferred();
+}
+void     DeviceIndex::set_max_host_active(uint32_t n) {
+  { std::lock_guard<std::mutex> lk(impl_->pool_mu); impl_->max_host_active = std::max<uint32_t>(n, 1); }
+  impl_->pool_cv.notify_all();
+  impl_->start_deferred();
 }
 
 // what a call pins for its lifetime: the penalty-string table and the spelling table it was enqueued with
@@ -1369,6 +1492,8 @@ struct DeviceIndex::Pending {
   std::unique_ptr<CtxLease> lease;
   std::unique_ptr<PassRun> run;
   bool done = false;
+  DeferredCall dc;  // begun when no context could be taken: queued on the host (Impl::deferred)
+  ~Pending() { if (run && !done) (void)hipStreamSynchronize(run->stream); }  // never ended (an error in between): nothing may still run in the context when the lease goes
 };
 
 DeviceIndex::Pending* DeviceIndex::match_device_begin(const HostIndex& h, const Params& prm, const DeviceBatchView& bv, Rec* d_out,
@@ -1377,42 +1502,51 @@ DeviceIndex::Pending* DeviceIndex::match_device_begin(const HostIndex& h, const 
   Impl& m = *impl_;
   if (m.device < 0) throw GpuError("index is not on a device");
   HIP_TRY(hipSetDevice(m.device));
-  refresh_itok_table(m, h);
-  std::unique_ptr<Pending> p(new Pending);
-  p->lease.reset(new CtxLease(m, /*no_wait=*/true));  // throws instead of waiting: the busy contexts may all be pendings of this thread
-  Ctx& c = *p->lease->c;
-  hipStream_t stream = stream_v ? (hipStream_t)stream_v : c.stream;  // NULL: the context's stream, the caller's inputs are complete
   std::vector<uint64_t> q_bounds;
   for (uint64_t q = 0; q < bv.nq; q += m.sub_queries) q_bounds.push_back(q);
   q_bounds.push_back(bv.nq);
   if (q_bounds.size() != sub_tok_bounds.size()) throw std::invalid_argument("sub-batch bounds do not match the batch");
-  const uint32_t turns = bv.nq >= kTurnMinQueries ? m.device_turns : 0u;
-  std::unique_lock<std::mutex> chain_lk(m.chain_mu, std::defer_lock);
-  if (turns == 1 || turns == 2) {
-    chain_lk.lock();
-    if (m.chain_last) HIP_TRY(hipStreamWaitEvent(stream, m.chain_last, 0));
-  }
-  PassHooks hooks;
-  Ctx* cp = &c;
+  std::unique_ptr<Pending> p(new Pending);
+  Pending* pp = p.get();
   Impl* mp = &m;
-  // (chain_last belongs to chain_mu: written only by a chained call, which holds the lock until its launches are queued)
-  const bool chain_held = chain_lk.owns_lock();
-  hooks.enqueued = [mp, cp, turns, chain_held](hipEvent_t last) {
-    if (chain_held) mp->chain_last = (turns == 2 && mp->expand_order != 0 && !mp->serial) ? cp->ev_mid : last;
+  const HostIndex* hp = &h;
+  // everything that enqueues the call (a deferred call runs this on the thread that freed its slot)
+  p->dc.host_kind = false;
+  p->dc.start = [pp, mp, hp, prm, bv, d_out, d_out_count, d_out_total, cap, stream_v, q_bounds, sub_tok_bounds](bool force) {
+    Impl& m = *mp;
+    HIP_TRY(hipSetDevice(m.device));
+    refresh_itok_table(m, *hp);
+    pp->lease.reset(new CtxLease(m, /*no_wait=*/true, /*host_kind=*/false, force));  // NoContext instead of waiting: the busy contexts may all be pendings of this thread
+    Ctx& c = *pp->lease->c;
+    hipStream_t stream = stream_v ? (hipStream_t)stream_v : c.stream;  // NULL: the context's stream, the caller's inputs are complete
+    const uint32_t turns = bv.nq >= kTurnMinQueries ? m.device_turns : 0u;
+    std::unique_lock<std::mutex> chain_lk(m.chain_mu, std::defer_lock);
+    if (turns == 1 || turns == 2) {
+      chain_lk.lock();
+      if (m.chain_last) HIP_TRY(hipStreamWaitEvent(stream, m.chain_last, 0));
+    }
+    PassHooks hooks;
+    Ctx* cp = &c;
+    // (chain_last belongs to chain_mu: written only by a chained call, which holds the lock until its launches are queued)
+    const bool chain_held = chain_lk.owns_lock();
+    hooks.enqueued = [mp, cp, turns, chain_held](hipEvent_t last) {
+      if (chain_held) mp->chain_last = (turns == 2 && mp->expand_order != 0 && !mp->serial) ? cp->ev_mid : last;
+    };
+    pp->run.reset(new PassRun(m, c, prm, bv, d_out, d_out_count, d_out_total, cap, stream, q_bounds, sub_tok_bounds, nullptr, &hooks));
+    pp->run->hooks.enqueued = nullptr;  // (re-armed below: the hook captures locals of this frame)
+    pp->run->prepare_async();
+    if (pp->run->n_sub <= kAsyncGroup) {
+      pp->run->hooks.enqueued = hooks.enqueued;
+      pp->run->begin_group(0, pp->run->n_sub);
+      pp->run->hooks.enqueued = nullptr;
+    } else {  // more passes than one group holds: the call runs to its end here
+      pp->run->hooks.enqueued = hooks.enqueued;
+      pp->run->run_all_async();
+      pp->run->hooks.enqueued = nullptr;
+      pp->done = true;
+    }
   };
-  p->run.reset(new PassRun(m, c, prm, bv, d_out, d_out_count, d_out_total, cap, stream, q_bounds, sub_tok_bounds, nullptr, &hooks));
-  p->run->hooks.enqueued = nullptr;  // (re-armed below: the hook captures locals of this frame)
-  p->run->prepare_async();
-  if (p->run->n_sub <= kAsyncGroup) {
-    p->run->hooks.enqueued = hooks.enqueued;
-    p->run->begin_group(0, p->run->n_sub);
-    p->run->hooks.enqueued = nullptr;
-  } else {  // more passes than one group holds: the call runs to its end here
-    p->run->hooks.enqueued = hooks.enqueued;
-    p->run->run_all_async();
-    p->run->hooks.enqueued = nullptr;
-    p->done = true;
-  }
+  begin_or_defer(m, p->dc);
   return p.release();
 }
 
@@ -1420,12 +1554,15 @@ void DeviceIndex::match_device_end(Pending* pending) {
   std::unique_ptr<Pending> p(pending);
   if (!p) return;
   HIP_TRY(hipSetDevice(impl_->device));
-  if (!p->done) p->run->end_group(0, p->run->n_sub);
+  ensure_started(*impl_, p->dc);
+  if (!p->done) { p->run->end_group(0, p->run->n_sub); p->done = true; }
 }
 
 void DeviceIndex::match_device_abandon(Pending* pending) {
   std::unique_ptr<Pending> p(pending);
-  if (p && p->run) (void)hipStreamSynchronize(p->run->stream);
+  if (!p) return;
+  try { ensure_started(*impl_, p->dc); } catch (...) {}
+  // (~Pending waits for the stream)
 }
 
 void DeviceIndex::match_device(const HostIndex& h, const Params& prm, const DeviceBatchView& bv, Rec* d_out,
@@ -1643,6 +1780,22 @@ struct DeviceIndex::HostCall {
   std::unique_lock<std::mutex> chain_lk;
   PassHooks hooks;
   std::unique_ptr<PassRun> run;
+  DeferredCall dc;        // begun when no context could be taken: queued on the host (Impl::deferred)
+  bool finished = false;  // end() ran through
+
+  // Nothing of this call may still run, or still read the caller's buffers, when its context goes back to the pool and the error
+  // reaches the caller (who may free them): a begin() or end() that threw half-way leaves copies and kernels in flight (round-4
+  // advice: match_host_abandon existed and nobody called it).  Members are destroyed after this body: the lease last.
+  ~HostCall() {
+    if (cp && !finished) {
+      (void)hipSetDevice(m.device);
+      (void)hipStreamSynchronize(cp->stream);
+      (void)hipStreamSynchronize(cp->side);
+      if (h2d && h2d != cp->stream) (void)hipStreamSynchronize(h2d);
+      if (d2h && d2h != cp->stream) (void)hipStreamSynchronize(d2h);
+      (void)hipGetLastError();
+    }
+  }
 
   HostCall(DeviceIndex::Impl& m_, const HostIndex& h_, const Params& prm_, const HostBatchView& hb_, Rec* out_, uint32_t* out_count_,
            uint32_t* out_total_, uint32_t cap_, Stats* st_, Rec* d_keep_, uint32_t* d_keep_count_)
@@ -1741,20 +1894,22 @@ struct DeviceIndex::HostCall {
     ms_d2h += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
   }
 
-  // no_wait: fail instead of waiting for a context (the busy ones may all be pending calls of the calling thread)
-  void begin(bool no_wait) {
+  // no_wait: NoContext instead of waiting for a context (the busy ones may all be pending calls of the calling thread; the call is
+  // then deferred); force: a context beyond the pool's limit if there is none
+  void begin(bool no_wait, bool force = false) {
     if (m.device < 0) throw GpuError("index is not on a device");
     HIP_TRY(hipSetDevice(m.device));
     nq = hb.nq;
-    if (nq == 0) return;
+    if (nq == 0) { finished = true; return; }
     base = hb.q_off[0];
     nt = hb.q_off[nq] - base;
     if (hb.text && base != 0) throw std::invalid_argument("text batch: offsets must start at 0");
     refresh_itok_table(m, h);
     if (hb.text) refresh_vocab_table(m, h);
     text_snap = pin_tables(m);  // (the pass run pins its own pair; this one keeps the spelling table of the lookup alive)
-    lease.reset(new CtxLease(m, no_wait));
+    lease.reset(new CtxLease(m, no_wait, /*host_kind=*/true, force));
     cp = lease->c;
+    h2d = cp->h2d; d2h = cp->d2h;  // (what ~HostCall waits for if anything below throws; set for good further down)
     Ctx& c = *cp;
     c.d_qoff.ensure(nq + 1);
     c.d_qtok.ensure(nt + 1);
@@ -1865,6 +2020,7 @@ struct DeviceIndex::HostCall {
       st->pinned = pinned ? 1 : 0;
       st->ms_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
+    finished = true;
   }
 };
 
@@ -1881,18 +2037,25 @@ void DeviceIndex::match_host_full(const HostIndex& h, const Params& prm, const H
 DeviceIndex::HostCall* DeviceIndex::match_host_begin(const HostIndex& h, const Params& prm, const HostBatchView& hb, Rec* out, uint32_t* out_count,
                                                      uint32_t* out_total, uint32_t cap, Rec* d_keep, uint32_t* d_keep_count) {
   std::unique_ptr<HostCall> call(new HostCall(*impl_, h, prm, hb, out, out_count, out_total, cap, nullptr, d_keep, d_keep_count));
-  call->begin(true);
+  HostCall* cp = call.get();
+  call->dc.host_kind = true;
+  call->dc.start = [cp](bool force) { cp->begin(true, force); };
+  begin_or_defer(*impl_, call->dc);  // beyond the calls that may run at once: queued on the host, started when a slot is freed
   return call.release();
 }
 
 void DeviceIndex::match_host_end(HostCall* call_) {
   std::unique_ptr<HostCall> call(call_);
-  if (call) call->end();
+  if (!call) return;
+  ensure_started(*impl_, call->dc);
+  call->end();
 }
 
 void DeviceIndex::match_host_abandon(HostCall* call_) {
   std::unique_ptr<HostCall> call(call_);
-  if (call && call->cp) { (void)hipStreamSynchronize(call->cp->stream); (void)hipStreamSynchronize(call->d2h ? call->d2h : call->cp->stream); }
+  if (!call) return;
+  try { ensure_started(*impl_, call->dc); } catch (...) {}
+  // (~HostCall waits for the call's streams before the context goes back to the pool)
 }
 
 __global__ void k_pmax(const uint32_t* q_off, unsigned long long nq, uint32_t* out) {
@@ -1919,7 +2082,7 @@ void DeviceIndex::match_lines(const HostIndex& h, const Params& prm, const char*
   refresh_itok_table(m, h);
   refresh_vocab_table(m, h);
   const TableSnap text_snap = pin_tables(m);
-  CtxLease lease(m);
+  CtxLease lease(m, /*no_wait=*/false, /*host_kind=*/true);  // (a host-buffer call like any other: it counts against max_host_active)
   Ctx& c = *lease.c;
   const uint64_t tiles = (n_bytes + (uint64_t)kScanThreads * kVocabChunk - 1) / ((uint64_t)kScanThreads * kVocabChunk);
   const uint64_t tok_cap = n_bytes / 2 + 2;  // a token is at least one byte and its separator

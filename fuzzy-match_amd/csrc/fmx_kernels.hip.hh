@@ -165,11 +165,17 @@ __global__ void k_setup(DevIndex ix, DevBatch b, DevWork w, Params prm) {
   if (inside) for (uint32_t k = 0; k < p; k++) w.t_q[o0 - b.t_begin + k] = q;
 }
 
+// A pass whose token bounds disagree with q_off (k_setup counted it: the caller's total_tokens was wrong) is inert on the device:
+// the per-token kernels below would otherwise walk b.nt tokens the caller's buffers may not hold, through t_q entries no query
+// wrote.  With k_probe inert every query has zero hits and nothing downstream indexes a token; the host fails the call
+// (FMX_E_INVALID) when it reads the counter.
+__device__ __forceinline__ bool pass_refused(const DevWork& w) { return w.counters[26] != 0ull; }
+
 // compute_idf_penalty — src/fuzzy_match.cc:381-387 (UNK and out-of-vocabulary ids -> 0), one thread per
 // pattern token of the pass
 __global__ void k_tidf(DevIndex ix, DevBatch b, DevWork w) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= b.nt) return;
+  if (t >= b.nt || pass_refused(w)) return;
   const uint32_t wd = b.q_tok[b.t_begin + t];
   w.t_idf[t] = (wd + 1 < ix.n_qva && wd != 1u) ? ix.idf[wd] : 0.f;
 }
@@ -214,7 +220,7 @@ template <bool COUNT>
 __global__ void __launch_bounds__(kProbeBlock) k_probe(DevIndex ix, DevBatch b, DevWork w, uint32_t heavy_min, HeavyItem* items_h,
                                               uint32_t item_h_cap) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= b.nt) return;
+  if (t >= b.nt || pass_refused(w)) return;
   const uint32_t q = w.t_q[t];
   const uint32_t msl = w.q_m[q];
   const uint32_t o0 = b.q_off[b.q_begin + q] - b.t_begin;

@@ -245,7 +245,9 @@ int fmx_match_batch_keep(fmx_index*, const fmx_params*, const fmx_batch* host_ba
  *   itok_slot / itok_id   the batch's penalty tokens (Sentence::set_itok) as n_itoks pairs: slot = q_off[q] + q + j for the
  *               string in front of real token j of pattern q (the layout of fmx_batch::q_itok), id = fmx_index_intern_itok of
  *               the string (interning stays on the host: a new string grows the distance table there).
- * All three are ignored by an index without real tokens. */
+ * All three are ignored by an index without real tokens.  The struct has no size field: ZERO-INITIALISE it (`fmx_text_batch tb = {0};`)
+ * so that members a caller does not know about read as "absent"; ids the index has not interned and slots beyond the batch are
+ * refused (FMX_E_INVALID) before anything reaches the device. */
 typedef struct fmx_text_batch {
   uint64_t        nq;
   const uint32_t* q_off;    /* nq + 1 offsets in tokens */
@@ -286,7 +288,7 @@ int fmx_match_batch_lines(fmx_index*, const fmx_params*, const char* text, uint6
 /* Same with every buffer already in the HBM of the index's device; `stream` is a hipStream_t
  * (NULL = a stream of the library after a device-wide synchronisation).  total_tokens = q_off[nq] when q_off[0] == 0, else
  * 0 (with it and max_len set, a batch of one pass needs no device read up front; the value is CHECKED on the device against
- * q_off[0] == 0 and q_off[nq]: a call whose total_tokens disagrees skips the queries outside the stated bounds and returns
+ * q_off[0] == 0 and q_off[nq]: a call whose total_tokens disagrees is inert on the device (no kernel walks a token) and returns
  * FMX_E_INVALID — from _end for the two-halves form).  Work is enqueued on `stream`; the call
  * synchronises that stream before returning.  stats != NULL: every pass is synchronised and timed per stage (HIP events);
  * stats == NULL: the passes run back to back; concurrent calls overlap on the GPU (with the option "device_turns" set, calls

@@ -30,3 +30,9 @@ def test_two_ranks_on_one_gpu(gpu_device):
     assert len(d["per_rank"]) == 2 and d["parity"]["mismatches"] == 0 and d["parity"]["checked"] > 0 and d["value"] > 0
     assert "fmx_match_batch_text" in d["config"]["timed_path"] and d["device_resident"]["value"] > 0
     assert d["scaling_other"]["value"] > 0 and d["scaling_other"]["device_resident_value"] > 0
+    # what the gather assembled on rank 0 from EVERY rank's block is checked against the oracle (input order), and the HBM traffic of
+    # the dominant kernel is measured at N > 1 too (rank 0's rocprofv3 child passes)
+    prb = d["parity"]["per_rank_block"]
+    assert len(prb) == 2 and [x["rank"] for x in prb] == [0, 1]
+    assert all(x["mismatches"] == 0 and x["checked"] > 0 and x["queries_in_block"] == 20000 for x in prb)
+    assert isinstance(d["roofline"]["traffic"], int) and d["roofline"]["traffic"] > 0

@@ -174,7 +174,8 @@ def test_line_batch_arguments_and_several_passes(fmx, text_index):
 
 def test_text_begin_end_keeps_several_batches_in_flight_from_one_thread(fmx, text_index):
     """fmx_match_batch_text_begin / _end: three text batches pending at once, enqueued by this thread and ended in order — the
-    records of every one equal the id batch's; a begin without a free context is refused, not dead-locked."""
+    records of every one equal the id batch's; a begin beyond what may run at once (no free context, or the host-buffer calls at
+    "max_host_active") is DEFERRED on the host, not refused and not dead-locked (round 5: admission control)."""
     ix, words, c_off, c_tok, vocab, _ = text_index
     kw = dict(fuzzy=0.6, nmatch=5)
     ix.set_option("contexts", 3)
@@ -187,13 +188,26 @@ def test_text_begin_end_keeps_several_batches_in_flight_from_one_thread(fmx, tex
         nq = len(q_off) - 1
         out = (fmx.pinned_empty((nq, 5), fmx.MATCH_DTYPE), fmx.pinned_empty(nq, np.uint32), fmx.pinned_empty(nq, np.uint32))
         batches.append((fmx.pinned_copy(q_off), fmx.pinned_copy(_pack(toks)), out, want))
-    for rnd in range(2):
+    extra_out = (fmx.pinned_empty((len(batches[0][0]) - 1, 5), fmx.MATCH_DTYPE), fmx.pinned_empty(len(batches[0][0]) - 1, np.uint32),
+                 fmx.pinned_empty(len(batches[0][0]) - 1, np.uint32))
+    for rnd in range(3):
+        if rnd == 2:
+            ix.set_option("max_host_active", 1)     # every begin but the first is deferred and started by the _end before it
         pend = [ix.text_begin(fmx.Params(**kw), q, t, out, 5) for q, t, out, _ in batches]
         if rnd == 0:
-            with pytest.raises(fmx.FmxError):      # every context is pending
-                ix.text_begin(fmx.Params(**kw), batches[0][0], batches[0][1], batches[0][2], 5)
+            # every context is pending: a fourth and a fifth call wait on the host.  The fifth is ended FIRST — before anything freed
+            # a slot — and starts itself (one context beyond the limit rather than a dead-lock); the fourth starts when a slot is free
+            h4 = ix.text_begin(fmx.Params(**kw), batches[0][0], batches[0][1], extra_out, 5)
+            h5 = ix.text_begin(fmx.Params(**kw), batches[0][0], batches[0][1], extra_out, 5)
+            ix.text_end(h5)
+            q0 = len(batches[0][0]) - 1
+            assert np.array_equal(batches[0][3][1], extra_out[1][:q0])
+            extra_out[1][:] = 0
+            pend.append(h4)
         for h in pend:
             ix.text_end(h)
+        if rnd == 0:
+            assert np.array_equal(batches[0][3][1], extra_out[1][:len(batches[0][0]) - 1])
         for q, t, out, want in batches:
             nq = len(q) - 1
             assert np.array_equal(want[1], out[1][:nq]) and np.array_equal(want[2], out[2][:nq])
@@ -206,4 +220,60 @@ def test_text_begin_end_keeps_several_batches_in_flight_from_one_thread(fmx, tex
     h = ix.text_begin(fmx.Params(**kw), q, fmx.pinned_copy(np.asarray(t[:nuls[-2] + 1])), out, 5)   # the last spelling is missing
     with pytest.raises(fmx.FmxError):
         ix.text_end(h)
+    # a handle is ended once, by either _end (the call is finished through the path it was begun on), and not twice
+    h = ix.text_begin(fmx.Params(**kw), q, t, out, 5)
+    ix.device_end(h)
+    assert np.array_equal(batches[0][3][1], out[1][:len(q) - 1])
+    with pytest.raises(fmx.FmxError):
+        ix.text_end(h)
+    ix.set_option("max_host_active", 4)
     ix.set_option("contexts", 4)
+
+
+def test_sixteen_synchronous_text_callers_degrade_gracefully(fmx, gpu_device):
+    """Admission control (round 5; cli/src/FuzzyMatch-cli.cc:139-147: N threads call match() on one instance).  Sixteen
+    synchronous fmx_match_batch_text callers right after an index build, with as many contexts as callers: the host-buffer calls
+    that may have work on the GPU at once are capped inside the library ("max_host_active", default 4), the others wait on the
+    host — so sixteen callers finish the same work in about the time four take, instead of 50-100 x longer (five and more calls in
+    flight fell off the GPU scheduler's hardware-queue cliff).  Bound: 1.3 x the four-caller time."""
+    import concurrent.futures as cf
+    import time
+    import workloads
+    c_off, c_tok, q_off, q_tok, vs = workloads.synthetic(400_000, 60_000, 20)
+    ix = fmx.Index.create()
+    ix.add_ids(c_off, c_tok, vs)
+    ix.sort(gpu_device)
+    ix.finalize()
+    words = [b"", b""] + [b"w%d" % k for k in range(2, vs)]
+    offs = np.full(len(words), 0xffffffffffffffff, np.uint64)
+    pos = 0
+    for k in range(2, len(words)):
+        offs[k] = pos
+        pos += len(words[k]) + 1
+    ix.set_forms_packed(_pack(words[2:]), offs)
+    ix.to_device(gpu_device)
+    ix.set_option("contexts", 16)
+    kw = dict(fuzzy=0.7, nmatch=5)
+    nq = len(q_off) - 1
+    text = fmx.pinned_copy(np.frombuffer(b"".join(words[t] + b"\0" for t in q_tok), dtype=np.uint8))
+    qo = fmx.pinned_copy(q_off.astype(np.uint32))
+    want = ix.match_batch(fmx.Params(**kw), q_off, q_tok, cap=5)
+    outs = [(fmx.pinned_empty((nq, 5), fmx.MATCH_DTYPE), fmx.pinned_empty(nq, np.uint32), fmx.pinned_empty(nq, np.uint32)) for _ in range(16)]
+    calls = 48
+
+    def run(n_threads):
+        def one(i):
+            ix.match_batch_text(fmx.Params(**kw), qo, text, cap=5, out=outs[i % n_threads])
+        with cf.ThreadPoolExecutor(n_threads) as pool:
+            list(pool.map(one, range(n_threads)))          # threads and contexts set up
+            t0 = time.perf_counter()
+            list(pool.map(one, range(calls)))
+            return time.perf_counter() - t0
+
+    t16 = run(16)          # FIRST: right after the build, when the cliff used to bite
+    t4 = run(4)
+    t16b = run(16)
+    for o in outs:
+        assert np.array_equal(want[1], o[1][:nq])
+        assert want[0].tobytes() == o[0][:nq].tobytes()
+    assert t16 <= 1.3 * t4 + 0.05 and t16b <= 1.3 * t4 + 0.05, (t16, t4, t16b)
