@@ -782,6 +782,16 @@ int fmx_match_one(fmx_index* ix, const fmx_params* params, const uint32_t* wids,
 int fmx_match_one_prior(fmx_index* ix, const fmx_params* params, const uint32_t* wids, uint32_t p, const uint32_t* q_real,
                         const uint32_t* q_itok, const uint32_t* prior_off, const uint32_t* prior_tok, uint32_t n_prior,
                         fmx_match* out, uint32_t cap, uint32_t* out_count, uint32_t* out_total) {
+  return fmx_match_one_prior_ids(ix, params, wids, p, q_real, q_itok, prior_off, prior_tok, nullptr, n_prior, out, cap, out_count, out_total);
+}
+
+// ... with the prior entries' Match::s_id.  The reference memoises the cost of a (candidate, memory entry) pair under the two
+// s_ids (src/fuzzy_match.cc:627, 637-650), so a memory entry whose id an earlier one carried is seen through the earlier one's
+// cost.  Among the prior entries that is resolved here (the later entry's tokens are replaced by the first one's); a pick that
+// carries a prior entry's id is resolved by the rerank kernel (select_body), which gets the ids.
+int fmx_match_one_prior_ids(fmx_index* ix, const fmx_params* params, const uint32_t* wids, uint32_t p, const uint32_t* q_real,
+                            const uint32_t* q_itok, const uint32_t* prior_off, const uint32_t* prior_tok, const uint32_t* prior_sid,
+                            uint32_t n_prior, fmx_match* out, uint32_t cap, uint32_t* out_count, uint32_t* out_total) {
   if (!ix || !params || !out || !out_count || (p && !wids)) return fail(FMX_E_INVALID, "null argument");
   if (n_prior && (!prior_off || (prior_off[n_prior] && !prior_tok))) return fail(FMX_E_INVALID, "null prior arrays");
   if (cap == 0) return fail(FMX_E_INVALID, "cap must be > 0");
@@ -799,10 +809,31 @@ int fmx_match_one_prior(fmx_index* ix, const fmx_params* params, const uint32_t*
       v.q_real = forms_real.data();
     }
     std::vector<uint32_t> p_off(prior_off, prior_off + (n_prior ? n_prior + 1 : 0));
+    std::vector<uint32_t> p_tok;
     if (n_prior) {  // rebase to 0: the staging copy starts at the first prior's tokens
       const uint32_t base = p_off[0];
       for (auto& o : p_off) o -= base;
       v.n_prior = n_prior; v.prior_off = p_off.data(); v.prior_tok = prior_tok + base;
+      if (prior_sid) {
+        v.prior_sid = prior_sid;
+        bool shared = false;
+        std::vector<uint32_t> first(n_prior);
+        for (uint32_t r = 0; r < n_prior; r++) {
+          first[r] = r;
+          for (uint32_t k = 0; k < r; k++) if (prior_sid[k] == prior_sid[r]) { first[r] = k; shared = true; break; }
+        }
+        if (shared) {  // an entry whose id an earlier entry carries: the memo hands every candidate the earlier entry's cost
+          std::vector<uint32_t> n_off(n_prior + 1, 0);
+          for (uint32_t r = 0; r < n_prior; r++) {
+            const uint32_t f = first[r];
+            p_tok.insert(p_tok.end(), v.prior_tok + p_off[f], v.prior_tok + p_off[f + 1]);
+            n_off[r + 1] = (uint32_t)p_tok.size();
+          }
+          if (p_tok.empty()) p_tok.push_back(0);
+          p_off.swap(n_off);
+          v.prior_off = p_off.data(); v.prior_tok = p_tok.data();
+        }
+      }
     }
     uint32_t total = 0;
     const size_t k = ix->devs.size() == 1 ? 0 : ix->rr.fetch_add(1) % ix->devs.size();

@@ -42,6 +42,7 @@ struct HostBatchView {
   uint32_t        n_prior = 0;
   const uint32_t* prior_off = nullptr;
   const uint32_t* prior_tok = nullptr;
+  const uint32_t* prior_sid = nullptr;  // their Match::s_id, or null (the rerank's memo is keyed on ids: src/fuzzy_match.cc:637)
   // the patterns as token SPELLINGS instead of ids (q_tok == nullptr): q_off[nq] NUL-terminated spellings back to back; the
   // vocabulary ids are looked up on the device (fmx_vocab.hip.hh)
   const char*     text = nullptr;
@@ -65,6 +66,7 @@ struct DeviceBatchView {
   uint32_t        n_prior = 0;        // prior matches (device CSR), see HostBatchView
   const uint32_t* prior_off = nullptr;
   const uint32_t* prior_tok = nullptr;
+  const uint32_t* prior_sid = nullptr;
   uint32_t        prior_max_len = 0;  // longest prior match
 };
 

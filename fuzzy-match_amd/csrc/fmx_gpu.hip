@@ -1363,7 +1363,7 @@ struct PassRun {
   DevBatch batch_of(uint32_t sb) const {
     DevBatch b;
     b.q_off = bv.q_off; b.q_tok = bv.q_tok; b.q_real = bv.q_real; b.q_itok = bv.q_itok;
-    b.prior_off = bv.prior_off; b.prior_tok = bv.prior_tok; b.n_prior = bv.n_prior;
+    b.prior_off = bv.prior_off; b.prior_tok = bv.prior_tok; b.n_prior = bv.n_prior; b.prior_sid = bv.prior_sid;
     b.q_begin = (uint32_t)sub_q_bounds[sb];
     b.nq = (uint32_t)(sub_q_bounds[sb + 1] - sub_q_bounds[sb]);
     b.t_begin = sub_tok_bounds[sb];
@@ -1954,10 +1954,15 @@ struct DeviceIndex::HostCall {
     bv.p_max = std::max<uint32_t>(p_max, 1);
     if (hb.n_prior) {  // the caller's prior matches: offsets then tokens in one staging buffer, ahead of the first pass
       const uint32_t n_tok = hb.prior_off[hb.n_prior];
-      c.d_prior.ensure((uint64_t)hb.n_prior + 1 + n_tok + 1);
+      c.d_prior.ensure((uint64_t)hb.n_prior + 1 + n_tok + 1 + hb.n_prior);
       HIP_TRY(hipMemcpyAsync(c.d_prior.p, hb.prior_off, ((size_t)hb.n_prior + 1) * 4, hipMemcpyHostToDevice, c.stream));
       if (n_tok) HIP_TRY(hipMemcpyAsync(c.d_prior.p + hb.n_prior + 1, hb.prior_tok, (size_t)n_tok * 4, hipMemcpyHostToDevice, c.stream));
       bv.n_prior = hb.n_prior; bv.prior_off = c.d_prior.p; bv.prior_tok = c.d_prior.p + hb.n_prior + 1;
+      if (hb.prior_sid) {  // the ids behind the tokens (the rerank's memo is keyed on them)
+        uint32_t* d_sid = c.d_prior.p + hb.n_prior + 1 + n_tok + 1;
+        HIP_TRY(hipMemcpyAsync(d_sid, hb.prior_sid, (size_t)hb.n_prior * 4, hipMemcpyHostToDevice, c.stream));
+        bv.prior_sid = d_sid;
+      }
       for (uint32_t r = 0; r < hb.n_prior; r++) bv.prior_max_len = std::max(bv.prior_max_len, hb.prior_off[r + 1] - hb.prior_off[r]);
     }
     pinned = is_pinned(hb.q_off) && is_pinned(hb.text ? (const void*)hb.text : (const void*)hb.q_tok) && is_pinned(out) && is_pinned(out_count);

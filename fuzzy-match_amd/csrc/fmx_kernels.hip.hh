@@ -66,6 +66,7 @@ struct DevBatch {
   const uint32_t* prior_off;
   const uint32_t* prior_tok;
   uint32_t        n_prior;
+  const uint32_t* prior_sid;  // their Match::s_id (the memo of the rerank is keyed on ids), or null
 };
 
 struct QHit;
@@ -2642,7 +2643,7 @@ __device__ __forceinline__ void select_body(const DevIndex& ix, const Params& pr
                                             uint32_t np2, unsigned long long* keys, uint32_t* vals, float* pen_sum,
                                             float* pen_cur, float* s_rows, uint32_t cap, Rec* out,
                                             uint32_t& out_count, uint32_t& out_total, const uint32_t* prior_off = nullptr,
-                                            const uint32_t* prior_tok = nullptr, uint32_t n_prior = 0) {
+                                            const uint32_t* prior_tok = nullptr, uint32_t n_prior = 0, const uint32_t* prior_sid = nullptr) {
   const uint32_t lane = lane_id();
   const uint32_t want = prm.nmatch == 0 ? n : (prm.nmatch < n ? prm.nmatch : n);
   const uint32_t emit = want < cap ? want : cap;
@@ -2710,8 +2711,15 @@ __device__ __forceinline__ void select_body(const DevIndex& ix, const Params& pr
     if (last >= 0) {
       const uint32_t msid = seg[last].sid;
       const uint32_t msp = ix.sent_pos[msid];
-      const uint32_t n2 = ix.tok[msp];
+      uint32_t n2 = ix.tok[msp];
       const uint32_t* s2 = ix.tok + msp + 1;
+      // The reference memoises a pair's cost under the two S_IDS (src/fuzzy_match.cc:627, 637-650): a pick whose id an entry
+      // already in the caller's vector carries — a match of another translation memory — is seen by every candidate through
+      // the cost computed for that entry, i.e. on ITS tokens.  (Prior entries that share an id among themselves were resolved
+      // on the host: fmx_match_one_prior_ids.)
+      if (MODE >= 2 && prior_sid != nullptr)
+        for (uint32_t r = 0; r < n_prior; r++)
+          if (prior_sid[r] == msid) { s2 = prior_tok + prior_off[r]; n2 = prior_off[r + 1] - prior_off[r]; break; }
       n_mem++;
       for (uint32_t k = lane; k < n; k += kWave) {
         if (keys[k] >> 63) continue;
@@ -3031,9 +3039,9 @@ __global__ void __launch_bounds__(kWave) k_contrast(DevIndex ix, DevBatch b, Dev
     uint32_t cnt = 0, tot = 0;
     if (n != 0) {
       const uint32_t np2 = next_pow2(n);
-      if (np2 <= kContrastLds) select_body<MODE>(ix, prm, seg, n, np2, s_keys, s_vals, s_f0, s_f1, s_rows, cap, out, cnt, tot, b.prior_off, b.prior_tok, b.n_prior);
+      if (np2 <= kContrastLds) select_body<MODE>(ix, prm, seg, n, np2, s_keys, s_vals, s_f0, s_f1, s_rows, cap, out, cnt, tot, b.prior_off, b.prior_tok, b.n_prior, b.prior_sid);
       else select_body<MODE>(ix, prm, seg, n, np2, sc.keys + 2ull * seg0, sc.vals + 2ull * seg0, sc.f0 + seg0, sc.f1 + seg0,
-                             s_rows, cap, out, cnt, tot, b.prior_off, b.prior_tok, b.n_prior);
+                             s_rows, cap, out, cnt, tot, b.prior_off, b.prior_tok, b.n_prior, b.prior_sid);
     }
     if (lane == 0) { out_count[gq] = cnt; if (out_total) out_total[gq] = tot; }
     __syncthreads();

@@ -87,7 +87,7 @@ EXPORTS = [
     "fmx_subsequence_batch", "fmx_text_tokenize", "fmx_text_free", "fmx_text_num_tokens", "fmx_text_norm", "fmx_text_real",
     "fmx_text_num_itoks", "fmx_text_itok_index", "fmx_text_itok", "fmx_text_num_raw", "fmx_text_raw", "fmx_text_map",
     "fmx_text_detokenize", "fmx_index_add_text", "fmx_index_device_array", "fmx_index_from_arrays", "fmx_text_feature",
-    "fmx_match_one_prior", "fmx_match_batch_device_begin", "fmx_match_batch_device_end", "fmx_vocab_lookup_mt", "fmx_index_set_forms",
+    "fmx_match_one_prior", "fmx_match_one_prior_ids", "fmx_match_batch_device_begin", "fmx_match_batch_device_end", "fmx_vocab_lookup_mt", "fmx_index_set_forms",
 ]
 TM_SKIPPED = -100
 
@@ -163,6 +163,8 @@ def lib():
                                         C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_char_p, C.c_size_t]
     L.fmx_match_one_prior.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.fmx_match_one_prior_ids.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.fmx_match_one.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.fmx_subsequence_batch.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_uint32, C.c_int32, C.c_int32, C.c_float,
@@ -390,9 +392,10 @@ class Index:
                                    cap, C.byref(cnt), C.byref(tot)))
         return out[:cnt.value], tot.value
 
-    def match_one_prior(self, params, wids, prior, q_real=None, q_itok=None, cap=None):
+    def match_one_prior(self, params, wids, prior, q_real=None, q_itok=None, cap=None, prior_sid=None):
         """match() for one pattern when the caller's vector already holds `prior` matches (lists of token ids) and the
-        contrastive factor is > 0; params.nmatch = NEW matches wanted."""
+        contrastive factor is > 0; params.nmatch = NEW matches wanted.  prior_sid: their Match::s_id (fmx_match_one_prior_ids: the
+        reference's memo of pair costs is keyed on ids)."""
         wids = np.ascontiguousarray(wids, dtype=np.uint32)
         cap = cap or (params.nmatch if params.nmatch > 0 else 64)
         out = np.zeros(cap, dtype=MATCH_DTYPE)
@@ -404,8 +407,14 @@ class Index:
             q_real = np.ascontiguousarray(q_real, dtype=np.uint32)
         if q_itok is not None:
             q_itok = np.ascontiguousarray(q_itok, dtype=np.uint32)
-        _check(lib().fmx_match_one_prior(self.h, C.byref(params), _ptr(wids), len(wids), _ptr(q_real), _ptr(q_itok), _ptr(p_off),
-                                         _ptr(p_tok), len(prior), _ptr(out), cap, C.byref(cnt), C.byref(tot)))
+        if prior_sid is not None:
+            sid = np.ascontiguousarray(prior_sid, dtype=np.uint32)
+            assert len(sid) == len(prior)
+            _check(lib().fmx_match_one_prior_ids(self.h, C.byref(params), _ptr(wids), len(wids), _ptr(q_real), _ptr(q_itok), _ptr(p_off),
+                                                 _ptr(p_tok), _ptr(sid), len(prior), _ptr(out), cap, C.byref(cnt), C.byref(tot)))
+        else:
+            _check(lib().fmx_match_one_prior(self.h, C.byref(params), _ptr(wids), len(wids), _ptr(q_real), _ptr(q_itok), _ptr(p_off),
+                                             _ptr(p_tok), len(prior), _ptr(out), cap, C.byref(cnt), C.byref(tot)))
         return out[:cnt.value], tot.value
 
     def info(self):

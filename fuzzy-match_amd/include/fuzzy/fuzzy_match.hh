@@ -179,22 +179,24 @@ class FuzzyMatch {
     uint32_t count = 0, total = 0;
     // entries already in `matches` take part in the contrastive rerank: every round penalises the candidates against
     // ALL of `matches`, the prior entries first (src/fuzzy_match.cc:622-650); their token sequences go along
-    std::vector<uint32_t> prior_off, prior_tok;
+    // (and their s_ids: the reference's memo of pair costs is keyed on ids, src/fuzzy_match.cc:637)
+    std::vector<uint32_t> prior_off, prior_tok, prior_sid;
     const bool with_prior = existing != 0 && contrastive_factor > 0;
     if (with_prior) {
       prior_off.push_back(0);
       for (const Match& m : matches) {
         for (int k = 0; k < m.length; k++) prior_tok.push_back(m.s[k]);
         prior_off.push_back((uint32_t)prior_tok.size());
+        prior_sid.push_back(m.s_id);
       }
       if (prior_tok.empty()) prior_tok.push_back(0);
     }
     for (;;) {  // number_of_matches == 0 means "all": grow until everything fits
       out.resize(cap);
       if (with_prior)
-        check(fmx_match_one_prior(_ix, &prm, wids.data(), p, q_real.empty() ? nullptr : q_real.data(),
-                                  q_itok.empty() ? nullptr : q_itok.data(), prior_off.data(), prior_tok.data(), (uint32_t)existing,
-                                  out.data(), cap, &count, &total));
+        check(fmx_match_one_prior_ids(_ix, &prm, wids.data(), p, q_real.empty() ? nullptr : q_real.data(),
+                                      q_itok.empty() ? nullptr : q_itok.data(), prior_off.data(), prior_tok.data(), prior_sid.data(),
+                                      (uint32_t)existing, out.data(), cap, &count, &total));
       else
         check(fmx_match_one(_ix, &prm, wids.data(), p, q_real.empty() ? nullptr : q_real.data(),
                             q_itok.empty() ? nullptr : q_itok.data(), out.data(), cap, &count, &total));

@@ -324,6 +324,15 @@ int fmx_match_one(fmx_index*, const fmx_params*, const uint32_t* wids, uint32_t 
 int fmx_match_one_prior(fmx_index*, const fmx_params*, const uint32_t* wids, uint32_t p, const uint32_t* q_real,
                         const uint32_t* q_itok, const uint32_t* prior_off, const uint32_t* prior_tok, uint32_t n_prior,
                         fmx_match* out, uint32_t cap, uint32_t* out_count, uint32_t* out_total);
+/* The same with the entries' Match::s_id (n_prior ids).  The reference memoises the edit cost of a (candidate, entry of `matches`)
+ * pair under the two s_ids (src/fuzzy_match.cc:627, 637-650): an entry of `matches` whose id an earlier entry carries — matches
+ * of another translation memory, or a new match whose id a prior entry happens to have — is scored through the earlier entry's
+ * cost whatever its own tokens are.  With the ids this entry point reproduces that; fmx_match_one_prior (no ids) treats every
+ * prior entry as an id of its own. */
+int fmx_match_one_prior_ids(fmx_index*, const fmx_params*, const uint32_t* wids, uint32_t p, const uint32_t* q_real,
+                            const uint32_t* q_itok, const uint32_t* prior_off, const uint32_t* prior_tok,
+                            const uint32_t* prior_sid, uint32_t n_prior, fmx_match* out, uint32_t cap, uint32_t* out_count,
+                            uint32_t* out_total);
 
 /* FuzzyMatch::subsequence(...) — include/fuzzy/fuzzy_match.hh:99-105, src/fuzzy_match.cc:250-365, for a batch of
  * tokenised patterns: the sub-n-gram of the pattern with the largest weight (its length, or its summed idf when

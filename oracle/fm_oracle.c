@@ -49,6 +49,12 @@ struct fmo_index {
   int       sorted;
   uint32_t  vocab_size;
   uint32_t* sfreq;
+  /* the oracle's OWN count of VocabIndexer::sfreq (src/vocab_indexer.cc:73-90, addWords: once per distinct word of a sentence),
+   * kept as sentences are added; fmo_index_set_vocab(.., NULL) adopts it, so that a parity test need not hand over the
+   * product's counts */
+  uint32_t* own_sfreq;
+  uint32_t* own_stamp;  /* sentence (index + 1) that last bumped the word */
+  uint32_t  own_cap;
   fmo_real* real;
   uint64_t  cap_real;
   int       has_real;
@@ -78,7 +84,7 @@ static void real_clear(fmo_real* r) {
 void fmo_index_free(fmo_index* ix) {
   if (!ix) return;
   free(ix->suf_sid); free(ix->suf_pos); free(ix->buf); free(ix->sent_pos); free(ix->qva);
-  free(ix->sentence_length); free(ix->sfreq);
+  free(ix->sentence_length); free(ix->sfreq); free(ix->own_sfreq); free(ix->own_stamp);
   if (ix->real) {
     for (uint64_t i = 0; i < ix->cap_real; i++) real_clear(&ix->real[i]);
     free(ix->real);
@@ -130,6 +136,18 @@ static int add_ids(fmo_index* ix, const uint32_t* ids, uint32_t n) {
   ix->sent_pos[ix->n_sent++] = (uint32_t)ix->n_buf;
   ix->buf[ix->n_buf++] = n;
   for (uint32_t i = 0; i < n; i++) {
+    /* VocabIndexer::addWords — src/vocab_indexer.cc:73-90: sfreq[idx]++ once per distinct word of the sentence */
+    const uint32_t w = ids[i];
+    if (w >= ix->own_cap) {
+      uint32_t nc = ix->own_cap ? ix->own_cap : 1024;
+      while (nc <= w) nc *= 2;
+      ix->own_sfreq = (uint32_t*)xrealloc(ix->own_sfreq, (size_t)nc * sizeof(uint32_t));
+      ix->own_stamp = (uint32_t*)xrealloc(ix->own_stamp, (size_t)nc * sizeof(uint32_t));
+      memset(ix->own_sfreq + ix->own_cap, 0, (size_t)(nc - ix->own_cap) * sizeof(uint32_t));
+      memset(ix->own_stamp + ix->own_cap, 0, (size_t)(nc - ix->own_cap) * sizeof(uint32_t));
+      ix->own_cap = nc;
+    }
+    if (ix->own_stamp[w] != sidx + 1) { ix->own_stamp[w] = sidx + 1; ix->own_sfreq[w]++; }
     ix->buf[ix->n_buf++] = ids[i];
     ix->suf_sid[ix->n_suf] = sidx;
     ix->suf_pos[ix->n_suf] = (uint16_t)(i + 1);
@@ -169,6 +187,11 @@ int fmo_index_set_vocab(fmo_index* ix, uint32_t vocab_size, const uint32_t* sfre
   if (sfreq) {
     ix->sfreq = (uint32_t*)xrealloc(NULL, (size_t)vocab_size * sizeof(uint32_t));
     memcpy(ix->sfreq, sfreq, (size_t)vocab_size * sizeof(uint32_t));
+  } else if (ix->own_sfreq && vocab_size) {
+    /* no counts handed over: the oracle's own (sentences added through fmo_index_add / _add_bulk) */
+    ix->sfreq = (uint32_t*)calloc((size_t)vocab_size, sizeof(uint32_t));
+    if (!ix->sfreq) abort();
+    memcpy(ix->sfreq, ix->own_sfreq, (size_t)(vocab_size < ix->own_cap ? vocab_size : ix->own_cap) * sizeof(uint32_t));
   }
   return 0;
 }
@@ -690,6 +713,7 @@ typedef struct fmo_scratch {
   uint32_t        n_prior;
   const uint32_t* prior_off;
   const uint32_t* prior_tok;
+  const uint32_t* prior_sid;  /* Match::s_id of those entries (the rerank's memo is keyed on ids), or NULL */
 } fmo_scratch;
 
 static void scratch_free(fmo_scratch* s) {
@@ -1020,46 +1044,59 @@ static int64_t match_impl(const fmo_index* ix, const fmo_params* prm, const uint
       sc->pen_cnt = (uint32_t*)xrealloc(sc->pen_cnt, sc->cap_memo * sizeof(uint32_t));
     }
     /* the list `candidates` keeps (score desc, s_id asc) order; erased entries are flagged.
-     * Every (candidate, memory) pair is evaluated exactly once in `matches` order (the entries the vector held on
-     * entry first — sc->n_prior of them, src/fuzzy_match.cc:634 "for (Match &match_memory : matches)" — then the
-     * picks), so the memo (fuzzy_match.cc:627) never changes a value and running sums equal std::accumulate over the
-     * penalties vector.  number_of_matches here counts NEW matches: the caller passes the reference's
-     * number_of_matches minus the entries already in its vector (loop condition fuzzy_match.cc:629). */
+     * Every round walks `matches` in order for every remaining candidate (src/fuzzy_match.cc:631-650): the entries the vector
+     * held on entry first (sc->n_prior of them), then the picks.  The pair's edit cost is looked up in a memo keyed on the two
+     * S_IDS, not on the sequences (:627, :637): a memory entry whose s_id an earlier memory entry already had — two prior
+     * entries from another translation memory, or a pick whose id a prior entry carries — gets the cost that was computed for
+     * the FIRST of them, whatever its own tokens are.  A cost depends on the candidate's and the memory entry's tokens only, so
+     * the memo is restated on the memory side: `mem_*` lists the memory entries in `matches` order with their ids, and an entry
+     * whose id appeared before is evaluated on the tokens of the first entry with that id — what every candidate's memo holds.
+     * Without ids for the prior entries (prior_sid == NULL) each counts as an id of its own.
+     * Every (candidate, memory position) contributes once, in `matches` order, so the running sums equal std::accumulate over
+     * the penalties vector.  number_of_matches here counts NEW matches: the caller passes the reference's number_of_matches
+     * minus the entries already in its vector (loop condition fuzzy_match.cc:629). */
     uint8_t* taken = (uint8_t*)calloc(n ? n : 1, 1);
+    const uint64_t mem_cap = (uint64_t)sc->n_prior + n + 1;
+    uint64_t*        mem_key = (uint64_t*)xrealloc(NULL, mem_cap * sizeof(uint64_t));
+    const uint32_t** mem_s = (const uint32_t**)xrealloc(NULL, mem_cap * sizeof(uint32_t*));
+    int*             mem_len = (int*)xrealloc(NULL, mem_cap * sizeof(int));
+    uint64_t n_mem = 0;
     for (uint64_t i = 0; i < n; i++) { sc->pen_sum[i] = 0.f; sc->pen_max[i] = 0.f; sc->pen_cnt[i] = 0; }
+    /* appends a memory entry; returns the entry whose tokens the memo makes every candidate see for it */
+#define FMO_ADD_MEMORY(key, ms, mlen, eff)                                                     \
+    do {                                                                                         \
+      (eff) = n_mem;                                                                             \
+      for (uint64_t k_ = 0; k_ < n_mem; k_++) if (mem_key[k_] == (key)) { (eff) = k_; break; }   \
+      mem_key[n_mem] = (key); mem_s[n_mem] = (ms); mem_len[n_mem] = (mlen); n_mem++;             \
+    } while (0)
+#define FMO_FOLD_MEMORY(i, e)                                                                                            \
+    do {                                                                                                                 \
+      acc_match* m_ = &sc->result[i];                                                                                    \
+      const float dw_ = 100.f / fmo_normalizer((uint64_t)m_->length, (uint64_t)mem_len[e], 1.f, 1.f, 1.f);              \
+      const float cost_ = fmo_edit_distance_ids(m_->s, m_->length, mem_s[e], mem_len[e], 1.f, 1.f, 1.f, dw_, FLT_MAX);   \
+      if (ctr) { ctr->dp_calls++; ctr->dp_cells += (uint64_t)m_->length * (uint64_t)mem_len[e]; }                        \
+      const float pen_ = fmo_score_from_cost(cost_);                                                                     \
+      sc->pen_sum[i] = sc->pen_sum[i] + pen_; /* std::accumulate(…, 0.f) in `matches` order */                           \
+      sc->pen_max[i] = sc->pen_cnt[i] ? (sc->pen_max[i] < pen_ ? pen_ : sc->pen_max[i]) : pen_;                          \
+      sc->pen_cnt[i]++;                                                                                                  \
+      m_->penalty = prm->reduce == 1 ? sc->pen_max[i] : sc->pen_sum[i] / (float)sc->pen_cnt[i];                          \
+    } while (0)
     for (uint32_t r = 0; r < sc->n_prior; r++) {
-      const uint32_t* ms = sc->prior_tok + sc->prior_off[r];
-      const int mlen = (int)(sc->prior_off[r + 1] - sc->prior_off[r]);
-      for (uint64_t i = 0; i < n; i++) {
-        acc_match* m = &sc->result[i];
-        const float dw = 100.f / fmo_normalizer((uint64_t)m->length, (uint64_t)mlen, 1.f, 1.f, 1.f);
-        float pen = fmo_edit_distance_ids(m->s, m->length, ms, mlen, 1.f, 1.f, 1.f, dw, FLT_MAX);
-        pen = fmo_score_from_cost(pen);
-        sc->pen_sum[i] = sc->pen_sum[i] + pen;
-        sc->pen_max[i] = sc->pen_cnt[i] ? (sc->pen_max[i] < pen ? pen : sc->pen_max[i]) : pen;
-        sc->pen_cnt[i]++;
-        m->penalty = prm->reduce == 1 ? sc->pen_max[i] : sc->pen_sum[i] / (float)sc->pen_cnt[i];
-      }
+      uint64_t e;
+      FMO_ADD_MEMORY(sc->prior_sid ? (uint64_t)sc->prior_sid[r] : ((1ull << 32) + r), sc->prior_tok + sc->prior_off[r],
+                     (int)(sc->prior_off[r + 1] - sc->prior_off[r]), e);
+      for (uint64_t i = 0; i < n; i++) FMO_FOLD_MEMORY(i, e);
     }
     uint64_t remaining = n;
     int64_t  last_pick = -1;
     while (remaining && (number_of_matches == 0 || n_out < number_of_matches)) {
       if (last_pick >= 0) {
         const acc_match* mem = &sc->result[last_pick];
+        uint64_t e;
+        FMO_ADD_MEMORY((uint64_t)mem->s_id, mem->s, mem->length, e);
         for (uint64_t i = 0; i < n; i++) {
           if (taken[i]) continue;
-          acc_match* m = &sc->result[i];
-          const float dw = 100.f / fmo_normalizer((uint64_t)m->length, (uint64_t)mem->length, 1.f, 1.f, 1.f);
-          float pen = fmo_edit_distance_ids(m->s, m->length, mem->s, mem->length, 1.f, 1.f, 1.f, dw, FLT_MAX);
-          if (ctr) { ctr->dp_calls++; ctr->dp_cells += (uint64_t)m->length * (uint64_t)mem->length; }
-          pen = fmo_score_from_cost(pen);
-          sc->pen_sum[i] = sc->pen_sum[i] + pen; /* std::accumulate(…, 0.f) in pick order */
-          sc->pen_max[i] = sc->pen_cnt[i] ? (sc->pen_max[i] < pen ? pen : sc->pen_max[i]) : pen;
-          sc->pen_cnt[i]++;
-          if (prm->reduce == 1)
-            m->penalty = sc->pen_max[i];
-          else
-            m->penalty = sc->pen_sum[i] / (float)sc->pen_cnt[i];
+          FMO_FOLD_MEMORY(i, e);
         }
       }
       /* std::max_element: first maximum in list order */
@@ -1081,7 +1118,9 @@ static int64_t match_impl(const fmo_index* ix, const fmo_params* prm, const uint
       remaining--;
       last_pick = best;
     }
-    free(taken);
+#undef FMO_FOLD_MEMORY
+#undef FMO_ADD_MEMORY
+    free(taken); free(mem_key); free((void*)mem_s); free(mem_len);
   } else {
     for (uint64_t i = 0; i < sc->n_result && (number_of_matches == 0 || n_out < number_of_matches); i++) {
       if (n_out < cap) {
@@ -1120,10 +1159,17 @@ int64_t fmo_match(const fmo_index* ix, const fmo_params* prm, const uint32_t* p_
  * looks at them (src/fuzzy_match.cc:622-650).  prm->nmatch = NEW matches wanted. */
 int64_t fmo_match_prior(const fmo_index* ix, const fmo_params* prm, const uint32_t* p_wids, uint32_t p,
                         const uint32_t* prior_off, const uint32_t* prior_tok, uint32_t n_prior, fmo_rec* out, uint64_t cap) {
+  return fmo_match_prior_ids(ix, prm, p_wids, p, prior_off, prior_tok, NULL, n_prior, out, cap);
+}
+
+/* ... with the prior entries' Match::s_id: the memo of the rerank is keyed on ids (src/fuzzy_match.cc:637) */
+int64_t fmo_match_prior_ids(const fmo_index* ix, const fmo_params* prm, const uint32_t* p_wids, uint32_t p,
+                            const uint32_t* prior_off, const uint32_t* prior_tok, const uint32_t* prior_sid, uint32_t n_prior,
+                            fmo_rec* out, uint64_t cap) {
   if (!ix || !prm || !ix->sorted) return -1;
   fmo_scratch sc;
   memset(&sc, 0, sizeof(sc));
-  sc.n_prior = n_prior; sc.prior_off = prior_off; sc.prior_tok = prior_tok;
+  sc.n_prior = n_prior; sc.prior_off = prior_off; sc.prior_tok = prior_tok; sc.prior_sid = prior_sid;
   int64_t r = match_impl(ix, prm, p_wids, p, NULL, out, cap, NULL, &sc);
   scratch_free(&sc);
   return r;

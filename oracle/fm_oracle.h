@@ -118,6 +118,11 @@ int64_t fmo_match(const fmo_index*, const fmo_params*,
  * CSR): the contrastive rerank penalises against them first (src/fuzzy_match.cc:622-650).  prm->nmatch = NEW matches. */
 int64_t fmo_match_prior(const fmo_index*, const fmo_params*, const uint32_t* p_wids, uint32_t p,
                         const uint32_t* prior_off, const uint32_t* prior_tok, uint32_t n_prior, fmo_rec* out, uint64_t cap);
+/* the same with the prior entries' s_ids: the rerank's memo is keyed on (candidate s_id, memory s_id), src/fuzzy_match.cc:627,
+ * 637-650 — a memory entry whose id an earlier one carried reuses that one's cost */
+int64_t fmo_match_prior_ids(const fmo_index*, const fmo_params*, const uint32_t* p_wids, uint32_t p,
+                            const uint32_t* prior_off, const uint32_t* prior_tok, const uint32_t* prior_sid, uint32_t n_prior,
+                            fmo_rec* out, uint64_t cap);
 
 /* batch of id-only patterns over `nthreads` workers sharing one const index, results in
  * input order (the CLI's -N pool, cli/src/FuzzyMatch-cli.cc:112-193).  out is nq*cap

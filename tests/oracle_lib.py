@@ -236,9 +236,9 @@ class OracleIndex:
             raise RuntimeError("oracle match failed")
         return out[:min(int(r), cap)], int(r)
 
-    def match_ids_prior(self, params, wids, prior, cap=256):
+    def match_ids_prior(self, params, wids, prior, cap=256, prior_sid=None):
         """match() on ids when the caller's vector already holds `prior` matches (lists of token ids); params.nmatch = NEW
-        matches wanted (src/fuzzy_match.cc:622-650)."""
+        matches wanted (src/fuzzy_match.cc:622-650).  prior_sid: their s_ids (the memo of pair costs is keyed on ids, :637)."""
         w = np.ascontiguousarray(wids, np.uint32)
         p_off = np.zeros(len(prior) + 1, np.uint32)
         p_off[1:] = np.cumsum([len(x) for x in prior])
@@ -247,7 +247,15 @@ class OracleIndex:
         self.L.fmo_match_prior.restype = C.c_int64
         self.L.fmo_match_prior.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32,
                                            C.c_void_p, C.c_uint64]
-        r = self.L.fmo_match_prior(self.h, C.byref(params), _ptr(w), len(w), _ptr(p_off), _ptr(p_tok), len(prior), _ptr(out), cap)
+        if prior_sid is not None:
+            sid = np.ascontiguousarray(prior_sid, np.uint32)
+            assert len(sid) == len(prior)
+            self.L.fmo_match_prior_ids.restype = C.c_int64
+            self.L.fmo_match_prior_ids.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                   C.c_uint32, C.c_void_p, C.c_uint64]
+            r = self.L.fmo_match_prior_ids(self.h, C.byref(params), _ptr(w), len(w), _ptr(p_off), _ptr(p_tok), _ptr(sid), len(prior), _ptr(out), cap)
+        else:
+            r = self.L.fmo_match_prior(self.h, C.byref(params), _ptr(w), len(w), _ptr(p_off), _ptr(p_tok), len(prior), _ptr(out), cap)
         if r < 0:
             raise RuntimeError("oracle match failed")
         return out[:min(int(r), cap)], int(r)

@@ -16,7 +16,7 @@ def synth_pair(fmx):
     ix.add_ids(c_off, c_tok, vs)
     ix.sort(-1, 4)
     ix.finalize()
-    o = workloads.build_oracle(c_off, c_tok, vs, sfreq=ix.array("sfreq"), nthreads=4)
+    o = workloads.build_oracle(c_off, c_tok, vs, nthreads=4)
     return ix, o, q_off, q_tok
 
 
@@ -48,7 +48,7 @@ def test_emul_dense_edge_cases(fmx, seed):
     ix.sort(-1, 2)
     ix.finalize()
     o = oracle_lib.OracleIndex(max_tokens=20)
-    o.add_ids_bulk(c_off, c_tok, vocab + 2, sfreq=ix.array("sfreq"))
+    o.add_ids_bulk(c_off, c_tok, vocab + 2)
     o.sort(2)
     em = emul_lib.Emul(ix)
     for name, kw in workloads.PARAM_SETS.items():
@@ -98,7 +98,7 @@ def test_table_ranges_equal_the_references_equal_range(fmx, seed, vocab, n_sent)
     ix.sort(-1, 4)
     ix.finalize()
     o = oracle_lib.OracleIndex(max_tokens=30)
-    o.add_ids_bulk(c_off, c_tok, vocab + 2, sfreq=ix.array("sfreq"))
+    o.add_ids_bulk(c_off, c_tok, vocab + 2)
     o.sort(4)
     em = emul_lib.Emul(ix)
     assert len(em.a["gram5"]) > 0

@@ -27,7 +27,7 @@ def _run(fmx, dev, sents, queries, cap=None, **kw):
     cap = cap or kw.get("nmatch", 5) or 8
     go, gc, gt = ix.match_batch(fmx.Params(**kw), q_off, q_tok, cap=cap)
     o = oracle_lib.OracleIndex()
-    o.add_ids_bulk(c_off, c_tok, vs, sfreq=ix.array("sfreq"))
+    o.add_ids_bulk(c_off, c_tok, vs)
     o.sort(1)
     oo, oc = o.match_batch(oracle_lib.Params(**kw), q_off, q_tok, max(cap, 64), nthreads=1)
     return ix, go, gc, gt, oo, oc
@@ -70,8 +70,7 @@ def test_index_adopted_from_arrays_answers_like_the_index_it_came_from(fmx, gpu_
     a.add_ids(c_off, c_tok, vs)
     a.sort(gpu_device)
     a.finalize()
-    b = fmx.Index.from_arrays(a.array("suf_sid"), a.array("suf_pos"), a.array("buffer"), a.array("sent_pos"), qva=a.array("qva"),
-                              sfreq=a.array("sfreq"))
+    b = fmx.Index.from_arrays(a.array("suf_sid"), a.array("suf_pos"), a.array("buffer"), a.array("sent_pos"), qva=a.array("qva"))
     b.finalize()
     b.to_device(gpu_device)
     o = oracle_lib.OracleIndex()

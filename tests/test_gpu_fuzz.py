@@ -45,7 +45,7 @@ def corpora(fmx, gpu_device):
         ix.sort(gpu_device)
         ix.finalize()
         ix.to_device(gpu_device)
-        o = workloads.build_oracle(c_off, c_tok, vs, sfreq=ix.array("sfreq"))
+        o = workloads.build_oracle(c_off, c_tok, vs)
         out.append((ix, o, q_off, q_tok))
     return out
 
@@ -76,7 +76,7 @@ def dense(fmx, gpu_device):
         ix.finalize()
         ix.to_device(gpu_device)
         o = oracle_lib.OracleIndex(max_tokens=24)
-        o.add_ids_bulk(c_off, c_tok, vocab + 2, sfreq=ix.array("sfreq"))
+        o.add_ids_bulk(c_off, c_tok, vocab + 2)
         o.sort(2)
         out.append((ix, o, q_off, q_tok))
     return out

@@ -27,7 +27,7 @@ def test_expand_layouts_agree_with_the_oracle(fmx, gpu_device, corpus):
     if corpus == "synthetic":
         c_off, c_tok, q_off, q_tok, vs = workloads.synthetic(30000, 1500, 25)
         ix = _index(fmx, gpu_device, c_off, c_tok, vs)
-        o = workloads.build_oracle(c_off, c_tok, vs, sfreq=ix.array("sfreq"))
+        o = workloads.build_oracle(c_off, c_tok, vs)
         sets = ["C3", "C4", "wide_all", "contrast_mean_all"]
     else:
         rng = np.random.default_rng(77)
@@ -35,7 +35,7 @@ def test_expand_layouts_agree_with_the_oracle(fmx, gpu_device, corpus):
         q_off, q_tok = workloads.edge_queries(rng, c_off, c_tok, 6, 400)
         ix = _index(fmx, gpu_device, c_off, c_tok, 8, max_tokens=24)
         o = oracle_lib.OracleIndex(max_tokens=24)
-        o.add_ids_bulk(c_off, c_tok, 8, sfreq=ix.array("sfreq"))
+        o.add_ids_bulk(c_off, c_tok, 8)
         o.sort(2)
         sets = ["wide_all", "fuzzy_zero", "costs_101", "ml_negative"]
     layouts = [dict(light_max=256, expand_order=1), dict(light_max=0, expand_order=1), dict(light_max=1024, expand_order=0),
@@ -63,7 +63,7 @@ def test_large_concurrent_calls_take_turns(fmx, gpu_device):
     c_off, c_tok, q_off, q_tok, vs = workloads.synthetic(20000, 40000, 20)
     ix = _index(fmx, gpu_device, c_off, c_tok, vs)
     ix.set_option("contexts", 3)
-    o = workloads.build_oracle(c_off, c_tok, vs, sfreq=ix.array("sfreq"))
+    o = workloads.build_oracle(c_off, c_tok, vs)
     kw = dict(fuzzy=0.6, nmatch=3)
     oo, oc = o.match_batch(oracle_lib.Params(**kw), q_off, q_tok, 3, nthreads=oracle_lib.effective_cpus())
     po, pt = fmx.pinned_copy(q_off.astype(np.uint32)), fmx.pinned_copy(q_tok.astype(np.uint32))

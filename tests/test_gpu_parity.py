@@ -22,7 +22,7 @@ def c1(fmx, gpu_device):
     ix.sort(gpu_device)           # GPU suffix sort
     ix.finalize()
     ix.to_device(gpu_device)
-    o = workloads.build_oracle(c_off, c_tok, vs, sfreq=ix.array("sfreq"))
+    o = workloads.build_oracle(c_off, c_tok, vs)
     return ix, o, q_off, q_tok
 
 
@@ -55,7 +55,7 @@ def test_dense_edge_cases(fmx, gpu_device, seed):
     ix.finalize()
     ix.to_device(gpu_device)
     o = oracle_lib.OracleIndex(max_tokens=20)
-    o.add_ids_bulk(c_off, c_tok, vocab + 2, sfreq=ix.array("sfreq"))
+    o.add_ids_bulk(c_off, c_tok, vocab + 2)
     o.sort(2)
     a = o.arrays()
     assert np.array_equal(a["suf_sid"], ix.array("suf_sid")) and np.array_equal(a["suf_pos"], ix.array("suf_pos"))
@@ -148,7 +148,7 @@ def test_big_candidate_sets(fmx, gpu_device):
     ix.finalize()
     ix.to_device(gpu_device)
     o = oracle_lib.OracleIndex(max_tokens=40)
-    o.add_ids_bulk(c_off, c_tok, vocab + 2, sfreq=ix.array("sfreq"))
+    o.add_ids_bulk(c_off, c_tok, vocab + 2)
     o.sort(oracle_lib.effective_cpus())
     for name, kw in [("all", dict(fuzzy=0.2, nmatch=0, min_subseq_length=2, min_subseq_ratio=0)),
                      ("top10_idf", dict(fuzzy=0.0, nmatch=10, min_subseq_length=2, min_subseq_ratio=0, idf_penalty=0.7)),
@@ -178,7 +178,7 @@ def test_many_passes_in_one_asynchronous_group_with_a_small_workspace(fmx, gpu_d
     ix.set_option("initial_segment", 1024)
     ix.set_option("host_sub_queries", 2)   # 6 passes, one asynchronous group
     o = oracle_lib.OracleIndex(max_tokens=40)
-    o.add_ids_bulk(c_off, c_tok, vocab + 2, sfreq=ix.array("sfreq"))
+    o.add_ids_bulk(c_off, c_tok, vocab + 2)
     o.sort(oracle_lib.effective_cpus())
     kw = dict(fuzzy=0.2, nmatch=0, min_subseq_length=2, min_subseq_ratio=0)
     oo, oc = o.match_batch(oracle_lib.Params(**kw), q_off, q_tok, 128, nthreads=oracle_lib.effective_cpus())
@@ -221,7 +221,7 @@ def test_long_sentences_beyond_threshold_table(fmx, gpu_device):
     ix.finalize()
     ix.to_device(gpu_device)
     o = oracle_lib.OracleIndex(max_tokens=2000)
-    o.add_ids_bulk(c_off, c_tok, vocab + 2, sfreq=ix.array("sfreq"))
+    o.add_ids_bulk(c_off, c_tok, vocab + 2)
     o.sort(oracle_lib.effective_cpus())
     for name, kw in [("f05", dict(fuzzy=0.5, nmatch=5)), ("f02_all", dict(fuzzy=0.2, nmatch=0, min_subseq_ratio=0.05)),
                      ("idf", dict(fuzzy=0.4, nmatch=8, idf_penalty=0.5)),

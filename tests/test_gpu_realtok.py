@@ -130,7 +130,7 @@ def test_changing_batch_shapes_on_one_index(fmx, gpu_device):
     ix.sort(gpu_device)
     ix.finalize()
     ix.to_device(gpu_device)
-    o = workloads.build_oracle(c_off, c_tok, vs, sfreq=ix.array("sfreq"))
+    o = workloads.build_oracle(c_off, c_tok, vs)
     kw = dict(fuzzy=0.6, nmatch=5)
     lens = np.diff(q_off)
     short = np.argsort(lens)[:400]
@@ -173,7 +173,7 @@ def test_patterns_beyond_the_lds_rows(fmx, gpu_device):
     ix.finalize()
     ix.to_device(gpu_device)
     o = oracle_lib.OracleIndex(max_tokens=2000)
-    o.add_ids_bulk(c_off, c_tok, vocab + 2, sfreq=ix.array("sfreq"))
+    o.add_ids_bulk(c_off, c_tok, vocab + 2)
     o.sort(oracle_lib.effective_cpus())
     # min_subseq_ratio far below the default: an edit every ~12 tokens leaves no common run of 0.3 * 700 tokens
     mr = dict(min_subseq_length=3, min_subseq_ratio=0.01)
@@ -198,7 +198,7 @@ def test_concurrent_callers_and_coalescer(fmx, gpu_device):
     ix.sort(gpu_device)
     ix.finalize()
     ix.to_device(gpu_device)
-    o = workloads.build_oracle(c_off, c_tok, vs, sfreq=ix.array("sfreq"))
+    o = workloads.build_oracle(c_off, c_tok, vs)
     sets = [dict(fuzzy=0.6, nmatch=5), dict(fuzzy=0.5, nmatch=3, idf_penalty=0.5)]
     refs = [o.match_batch(oracle_lib.Params(**kw), q_off, q_tok, 5, nthreads=oracle_lib.effective_cpus()) for kw in sets]
     errors = []

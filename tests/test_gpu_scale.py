@@ -219,7 +219,7 @@ def test_gpu_sort_equals_independent_oracle_sort_at_1m(fmx, c2):
     on the full 1 M-sentence corpus: every array equal, not a sample."""
     ix, c_off, c_tok, _, _, vs = c2
     o = oracle_lib.OracleIndex()
-    o.add_ids_bulk(c_off, c_tok, vs, sfreq=ix.array("sfreq"))
+    o.add_ids_bulk(c_off, c_tok, vs)
     o.sort(oracle_lib.effective_cpus())
     a = o.arrays()
     for k in ["suf_sid", "suf_pos", "buffer", "sent_pos", "qva"]:

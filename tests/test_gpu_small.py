@@ -39,7 +39,7 @@ def _check_in_slices(fmx, ix, o, q_off, q_tok, kw, cap, step, label):
 def test_small_path_synthetic(fmx, gpu_device):
     c_off, c_tok, q_off, q_tok, vs = workloads.synthetic(40000, 1500, 25)
     ix = _index(fmx, gpu_device, c_off, c_tok, vs)
-    o = workloads.build_oracle(c_off, c_tok, vs, sfreq=ix.array("sfreq"))
+    o = workloads.build_oracle(c_off, c_tok, vs)
     for name in ["C1", "C3", "no_perfect", "fuzzy_zero", "ml_negative", "wide_all", "C4", "C5", "costs_101"]:  # the last four: partly / not eligible
         kw = workloads.PARAM_SETS[name]
         n_small, nq = _check_in_slices(fmx, ix, o, q_off, q_tok, kw, kw["nmatch"] or 64, 200, name)
@@ -62,7 +62,7 @@ def test_small_path_dense_and_edges(fmx, gpu_device):
     q_off, q_tok = workloads.edge_queries(rng, c_off, c_tok, 7, 500)
     ix = _index(fmx, gpu_device, c_off, c_tok, 9, max_tokens=24)
     o = oracle_lib.OracleIndex(max_tokens=24)
-    o.add_ids_bulk(c_off, c_tok, 9, sfreq=ix.array("sfreq"))
+    o.add_ids_bulk(c_off, c_tok, 9)
     o.sort(2)
     for kw in [dict(fuzzy=0.6, nmatch=5), dict(fuzzy=0.0, nmatch=10, min_subseq_length=4, min_subseq_ratio=0.2),
                dict(fuzzy=0.4, nmatch=3, min_subseq_length=1, min_subseq_ratio=0), dict(fuzzy=0.8, nmatch=1, no_perfect=True),
@@ -89,7 +89,7 @@ def test_small_path_long_sentences_and_patterns(fmx, gpu_device):
     q_off, q_tok = np.array(offs, np.uint32), np.array(toks, np.uint32)
     ix = _index(fmx, gpu_device, c_off, c_tok, 302, max_tokens=400)
     o = oracle_lib.OracleIndex(max_tokens=400)
-    o.add_ids_bulk(c_off, c_tok, 302, sfreq=ix.array("sfreq"))
+    o.add_ids_bulk(c_off, c_tok, 302)
     o.sort(2)
     for kw in [dict(fuzzy=0.6, nmatch=5), dict(fuzzy=0.3, nmatch=3, min_subseq_ratio=0.1)]:
         _check_in_slices(fmx, ix, o, q_off, q_tok, kw, kw["nmatch"], 100, str(kw))
@@ -99,7 +99,7 @@ def test_small_path_behind_match_one(fmx, gpu_device):
     """fmx_match_one from eight threads: the coalescer's micro-batches take the one-launch path."""
     c_off, c_tok, q_off, q_tok, vs = workloads.synthetic(20000, 600, 25)
     ix = _index(fmx, gpu_device, c_off, c_tok, vs)
-    o = workloads.build_oracle(c_off, c_tok, vs, sfreq=ix.array("sfreq"))
+    o = workloads.build_oracle(c_off, c_tok, vs)
     kw = dict(fuzzy=0.6, nmatch=5)
     oo, oc = o.match_batch(oracle_lib.Params(**kw), q_off, q_tok, 5, nthreads=oracle_lib.effective_cpus())
     errors = []

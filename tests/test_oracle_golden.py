@@ -106,3 +106,30 @@ def test_edit_distance_char():
     assert L.fmo_edit_distance_char(b"T", 1, b"", 0) == 1
     assert L.fmo_edit_distance_char(b"kitten", 6, b"sitting", 7) == 3
     assert L.fmo_edit_distance_char(b"T", 1, b"T", 1) == 0
+
+
+def test_oracle_counts_its_own_sentence_frequencies():
+    """VocabIndexer::addWords (src/vocab_indexer.cc:73-90): sfreq[w] = sentences containing w, bumped once per distinct word.  The
+    oracle keeps that count itself while sentences are added (round 5: the parity tests no longer hand it the product's counts);
+    checked here against a count made with numpy, and through idf-weighted scores (src/fuzzy_match.cc:372-390)."""
+    import workloads
+    rng = np.random.default_rng(5)
+    c_off, c_tok = workloads.dense_corpus(rng, 4000, 60, 1, 14)
+    vs = 64
+    n_sent = len(c_off) - 1
+    sid = np.repeat(np.arange(n_sent, dtype=np.uint64), np.diff(c_off).astype(np.int64))
+    pairs = np.unique(sid << np.uint64(32) | c_tok.astype(np.uint64))
+    want = np.bincount((pairs & np.uint64(0xffffffff)).astype(np.int64), minlength=vs)[:vs].astype(np.uint32)
+    own = workloads.build_oracle(c_off, c_tok, vs, nthreads=2)                 # counts its own
+    given = workloads.build_oracle(c_off, c_tok, vs, sfreq=want, nthreads=2)   # handed the numpy count
+    q_off, q_tok = workloads.edge_queries(rng, c_off, c_tok, 60, 300)
+    prm = oracle_lib.Params(fuzzy=0.4, nmatch=5, idf_penalty=1.0, min_subseq_length=2, min_subseq_ratio=0)
+    a, ac = own.match_batch(prm, q_off, q_tok, 5, nthreads=2)
+    b, bc = given.match_batch(prm, q_off, q_tok, 5, nthreads=2)
+    assert np.array_equal(ac, bc) and ac.sum() > 100
+    assert all(a[q, :ac[q]].tobytes() == b[q, :bc[q]].tobytes() for q in range(len(ac)))
+    flat = oracle_lib.Params(fuzzy=0.4, nmatch=5, min_subseq_length=2, min_subseq_ratio=0)
+    c, cc = own.match_batch(flat, q_off, q_tok, 5, nthreads=2)
+    assert any(a[q, :ac[q]].tobytes() != c[q, :cc[q]].tobytes() for q in range(len(ac)))   # the idf term does change scores
+    own.close()
+    given.close()

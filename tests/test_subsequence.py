@@ -95,7 +95,7 @@ def test_gpu_subsequence_synthetic_bit_exact(fmx, gpu_device):
     ix.sort(gpu_device)
     ix.finalize()
     ix.to_device(gpu_device)
-    o = workloads.build_oracle(c_off, c_tok, vs, sfreq=ix.array("sfreq"))
+    o = workloads.build_oracle(c_off, c_tok, vs)
     total = 0
     for kw in SUB_PARAMS:
         total += _check_batch(ix, o, q_off, q_tok, kw, tag="synthetic")
@@ -131,7 +131,7 @@ def test_gpu_subsequence_dense_corpus_bit_exact(fmx, gpu_device, seed):
     ix.finalize()
     ix.to_device(gpu_device)
     o = oracle_lib.OracleIndex()
-    o.add_ids_bulk(c_off, c_tok, vocab + 2, sfreq=ix.array("sfreq"))
+    o.add_ids_bulk(c_off, c_tok, vocab + 2)
     o.sort(2)
     total = 0
     for kw in SUB_PARAMS:
@@ -190,7 +190,7 @@ def test_gpu_subsequence_skips_thousands_of_perfect_matches(fmx, gpu_device):
     ix.sort(gpu_device)
     ix.finalize()
     ix.to_device(gpu_device)
-    o = workloads.build_oracle(c_off, c_tok, 32, sfreq=ix.array("sfreq"))
+    o = workloads.build_oracle(c_off, c_tok, 32)
     qs = [base, [2, 3, 4, 5], [9, 2, 3, 4, 5, 6, 9], [3, 4, 5, 6]]
     q_off = np.zeros(len(qs) + 1, np.uint32)
     q_off[1:] = np.cumsum([len(x) for x in qs])
@@ -232,7 +232,7 @@ def test_gpu_subsequence_patterns_beyond_the_lds_rows(fmx, gpu_device):
     ix.finalize()
     ix.to_device(gpu_device)
     o = oracle_lib.OracleIndex(max_tokens=1000)
-    o.add_ids_bulk(c_off, c_tok, vocab + 2, sfreq=ix.array("sfreq"))
+    o.add_ids_bulk(c_off, c_tok, vocab + 2)
     o.sort(2)
     total = 0
     for kw in (dict(nmatch=1), dict(nmatch=3, no_perfect=True), dict(nmatch=2, idf_weighting=True)):
