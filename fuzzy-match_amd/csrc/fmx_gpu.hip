@@ -27,6 +27,7 @@
 #include <string>
 
 #include "fmx_kernels.hip.hh"
+#include "fmx_light.hip.hh"
 #include "fmx_subseq.hip.hh"
 #include "fmx_small.hip.hh"
 #include "fmx_derive.hip.hh"
@@ -356,6 +357,11 @@ struct DeviceIndex::Impl {
   bool     small_path = [] { const char* e = getenv("FMX_SMALL_PATH"); return e ? atoi(e) != 0 : true; }();
   uint32_t heavy_grid = kHeavyGrid;      // workgroups of k_expand_h (it runs beside the light queries' kernel: it must not fill every wave slot)
   uint32_t light_max = kLightMaxDefault;  // queries with at most this many hits, all in short ranges, skip phase A (0 = off)
+  // of those, queries with at most this many hits are walked several to a wave (k_expand_lf, round 5; 0 = all by k_expand_b<true>).
+  // OFF by default: bit-identical, 13 % fewer VALU instructions, and SLOWER at C3 — the stage 1.40 -> 1.81 ms (flat 128), 1.59 (64):
+  // at four waves per SIMD (118 VGPRs, 8 KB of LDS) the sub-tiles' chains of dependent LDS / memory round trips are not hidden
+  // (profiles/r05_light_flat_ab.md)
+  uint32_t light_flat = [] { const char* e = getenv("FMX_LIGHT_FLAT"); return e ? (uint32_t)std::min(std::max(atoi(e), 0), 256) : 0u; }();
   // context pool
   // One pair of copy streams for every context of the index: the DMA engines serialise the copies anyway, and a context then
   // brings two streams (hardware queues) of its own instead of four.  Measured with six contexts (14 queues instead of 24):
@@ -563,6 +569,7 @@ void     DeviceIndex::set_expand_order(uint32_t n) { impl_->expand_order = n; }
 void     DeviceIndex::set_b_grid(uint32_t n) { impl_->b_grid = std::min<uint32_t>(std::max<uint32_t>(n, 64u), 65536u); }
 void     DeviceIndex::set_heavy_grid(uint32_t n) { impl_->heavy_grid = std::min<uint32_t>(std::max<uint32_t>(n, 64u), 65536u); }
 void     DeviceIndex::set_light_max(uint32_t n) { impl_->light_max = std::min<uint32_t>(n, kPhaseBChunk); }
+void     DeviceIndex::set_light_flat(uint32_t n) { impl_->light_flat = std::min<uint32_t>(n, 256u); }
 void     DeviceIndex::set_contexts(uint32_t n) {
   {
     std::lock_guard<std::mutex> lk(impl_->pool_mu);
@@ -1057,6 +1064,18 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
       const uint32_t grid_l = std::min<uint32_t>(kExpandExtraGrid, std::max<uint32_t>(256u, b.nq));
       const uint32_t grid_b = std::min<uint32_t>(m.b_grid, std::max<uint32_t>(256u, b.nq));
       auto side_tick = [&](int stage, int end) { if (timing) HIP_TRY(hipEventRecord(c.ev[2 * stage + end], side)); };
+      // the light queries: those of at most flat_max hits several to a wave (k_expand_lf, fmx_light.hip.hh), the rest a wave each
+      const uint32_t flat_max = std::min<uint32_t>(m.light_flat, light_max);
+      auto launch_light = [&]() {
+        if (flat_max) {
+          const uint32_t G = b.nq >= (1u << 19) ? 32u : (b.nq >= (1u << 17) ? 16u : 8u);  // queries per wave: small passes still fill the GPU
+          const uint32_t grid = (b.nq + G - 1) / G;
+          if (flat_max <= 128) hipLaunchKernelGGL((k_expand_lf<128, 128>), dim3(grid), dim3(kWave), 0, stream, E.d, b, w, prm, G, flat_max);
+          else hipLaunchKernelGGL((k_expand_lf<128, 256>), dim3(grid), dim3(kWave), 0, stream, E.d, b, w, prm, G, flat_max);
+        }
+        if (flat_max < light_max)
+          hipLaunchKernelGGL(k_expand_b<true>, dim3(b.nq), dim3(kWave), lds, stream, E.d, b, w, prm, (const WorkItem*)nullptr, 0u, b.nq, flat_max);
+      };
       auto second_scan = [&](hipStream_t st) {
         // the hits phase A really queued size the segments of everything downstream: second scan, q_cap -> q_seg, placed
         // behind the light queries' segments; the work-item list of k_expand_b<false> is laid out by the same
@@ -1078,10 +1097,9 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
         side_tick(kStageExpandB, 0);
         second_scan(side);
         hipLaunchKernelGGL(k_expand_b<false>, dim3((light_max ? 0u : b.nq) + grid_b), dim3(kWave), lds, side, E.d, b, w, prm,
-                           (const WorkItem*)c.items_b.p, item_cap, light_max ? 0u : b.nq);
+                           (const WorkItem*)c.items_b.p, item_cap, light_max ? 0u : b.nq, 0u);
         side_tick(kStageExpandB, 1);
-        if (light_max)
-          hipLaunchKernelGGL(k_expand_b<true>, dim3(b.nq), dim3(kWave), lds, stream, E.d, b, w, prm, (const WorkItem*)nullptr, 0u, b.nq);
+        if (light_max) launch_light();
         tick(); tick();
       } else {
         // long ranges first (k_expand_h next to k_expand_a), then the two k_expand_b side by side: the one for the queries
@@ -1094,11 +1112,11 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
         fork();
         side_tick(kStageExpandB, 0);
         hipLaunchKernelGGL(k_expand_b<false>, dim3((light_max ? 0u : b.nq) + grid_b), dim3(kWave), lds, side, E.d, b, w, prm,
-                           (const WorkItem*)c.items_b.p, item_cap, light_max ? 0u : b.nq);
+                           (const WorkItem*)c.items_b.p, item_cap, light_max ? 0u : b.nq, 0u);
         side_tick(kStageExpandB, 1);
         if (light_max) {
           if (!m.serial) hipLaunchKernelGGL(k_lag, dim3(1), dim3(kWave), 0, stream, w.counters);
-          hipLaunchKernelGGL(k_expand_b<true>, dim3(b.nq), dim3(kWave), lds, stream, E.d, b, w, prm, (const WorkItem*)nullptr, 0u, b.nq);
+          launch_light();
         }
         tick(); tick();
       }

@@ -14,6 +14,8 @@
 
 namespace fmx {
 
+unsigned usable_cpus();  // min(affinity mask, cgroup quota): what thread pools are sized by
+
 // fuzzy::Sentence (include/fuzzy/sentence.hh:24-48)
 struct RealTok {
   std::string tokstring;                               // real tokens joined by '\t'

@@ -1341,7 +1341,8 @@ __global__ void __launch_bounds__(kScanThreads) k_seg_scan(DevBatch b, DevWork w
 // 203 -> 196 M.  Removed; profiles/r04_c3_defer_cover_*.json keep the two lines.)
 template <bool LIGHT>
 __global__ void __launch_bounds__(kWave, LIGHT ? FMX_LIGHT_WAVES : FMX_PHASEB_WAVES) k_expand_b(DevIndex ix, DevBatch b, DevWork w, Params prm,
-                                                       const WorkItem* items, uint32_t item_cap, uint32_t first_q_blocks) {
+                                                       const WorkItem* items, uint32_t item_cap, uint32_t first_q_blocks,
+                                                       uint32_t flat_max) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t* s_pat = (uint32_t*)smem;
   __shared__ PatHash ph;
@@ -1384,7 +1385,10 @@ __global__ void __launch_bounds__(kWave, LIGHT ? FMX_LIGHT_WAVES : FMX_PHASEB_WA
     const uint32_t msl = uni(w.q_m[q]);
     const uint32_t o0 = uni(b.q_off[b.q_begin + q]);
     const uint32_t p = uni(b.q_off[b.q_begin + q + 1]) - o0;
-    if (n_q != 0 && seg0 + cap > w.seg_cap) {  // segments too small: host re-runs the pass
+    // LIGHT: queries of at most flat_max hits are walked by k_expand_lf (fmx_light.hip.hh), several to a wave
+    const bool elsewhere = LIGHT && n_q <= flat_max;
+    if (elsewhere) {
+    } else if (n_q != 0 && seg0 + cap > w.seg_cap) {  // segments too small: host re-runs the pass
       if (lane == 0) atomicMax(&w.counters[6], LIGHT ? w.q_segl[b.nq] : w.q_seg[b.nq]);
     } else if (n_q != 0 && n_q <= cap) {
       const uint32_t m = seed_len(p, msl);

@@ -38,16 +38,21 @@ def test_expand_layouts_agree_with_the_oracle(fmx, gpu_device, corpus):
         o.add_ids_bulk(c_off, c_tok, 8)
         o.sort(2)
         sets = ["wide_all", "fuzzy_zero", "costs_101", "ml_negative"]
+    # light_flat: the light queries of at most that many hits several to a wave (k_expand_lf, round 5: measured, slower, off by
+    # default — profiles/r05_light_flat_ab.md — and kept bit-identical here: every light query, only the small ones, with the rest
+    # of the light queries beside it in the round-4 kernel)
     layouts = [dict(light_max=256, expand_order=1), dict(light_max=0, expand_order=1), dict(light_max=1024, expand_order=0),
                dict(light_max=17, expand_order=0), dict(light_max=256, expand_order=1, serial=1), dict(light_max=256, expand_order=0, heavy_min=0),
-               dict(light_max=256, expand_order=1, pair_finish=0)]  # the others run k_finish_pair where the parameters allow it
+               dict(light_max=256, expand_order=1, pair_finish=0),  # the others run k_finish_pair where the parameters allow it
+               dict(light_max=256, expand_order=1, light_flat=256), dict(light_max=256, expand_order=0, light_flat=128),
+               dict(light_max=256, expand_order=1, light_flat=9)]
     light_seen = 0
     for name in sets:
         kw = workloads.PARAM_SETS[name]
         cap = kw["nmatch"] or 256
         oo, oc = o.match_batch(oracle_lib.Params(**kw), q_off, q_tok, cap, nthreads=oracle_lib.effective_cpus())
         for lay in layouts:
-            for k, v in {"serial": 0, "heavy_min": 1024, "pair_finish": 1, **lay}.items():
+            for k, v in {"serial": 0, "heavy_min": 1024, "pair_finish": 1, "light_flat": 0, **lay}.items():
                 ix.set_option(k, v)
             go, gc, gt, st = ix.match_batch(fmx.Params(**kw), q_off, q_tok, cap=cap, want_stats=True)
             workloads.compare(oo, oc, go, gc, f"{corpus} {name} {lay}")
@@ -55,6 +60,27 @@ def test_expand_layouts_agree_with_the_oracle(fmx, gpu_device, corpus):
                 assert st.n_light_hits == 0
             light_seen += int(st.n_light_hits)
     assert light_seen > 0  # the light path did run
+    ix.set_option("light_flat", 0)
+
+
+def test_flat_light_walk_is_bit_identical(fmx, gpu_device):
+    """k_expand_lf on a batch large enough for tiles of 8, 16 and 32 queries (the grid's choice by pass size) and for queries that
+    keep more than one wave of hits (left unreduced in their segment for k_cand_route): every record equals the oracle's."""
+    c_off, c_tok, q_off, q_tok, vs = workloads.synthetic(120_000, 140_000, 22)
+    ix = _index(fmx, gpu_device, c_off, c_tok, vs)
+    o = workloads.build_oracle(c_off, c_tok, vs)
+    for name, nq in (("C3", 140_000), ("wide_all", 20_000), ("C4", 9_000)):
+        kw = workloads.PARAM_SETS[name]
+        cap = kw["nmatch"] or 256
+        qo, qt = q_off[:nq + 1], q_tok[:int(q_off[nq])]
+        oo, oc = o.match_batch(oracle_lib.Params(**kw), qo, qt, cap, nthreads=oracle_lib.effective_cpus())
+        for flat in (256, 128, 40):
+            ix.set_option("light_flat", flat)
+            go, gc, gt, st = ix.match_batch(fmx.Params(**kw), qo, qt, cap=cap, want_stats=True)
+            workloads.compare(oo, oc, go, gc, f"{name} light_flat={flat}")
+            assert st.n_light_hits > 0
+    ix.set_option("light_flat", 0)
+    o.close()
 
 
 def test_large_concurrent_calls_take_turns(fmx, gpu_device):
