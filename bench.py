@@ -18,6 +18,7 @@ Side legs in the same JSON line (never `value`):
   pcie_inclusive_ids  fmx_match_batch: vocabulary ids in pinned host memory in, records out (no lookup: the caller already holds ids)
   from_token_strings  fmx_vocab_lookup_mt on host threads inside the timed region, then fmx_match_batch
   cli_end_to_end      tools/fmx-cli --tokenised on the run's own index (through a .fmi file) and first batch: stdin -> stdout
+  cli_raw_text        the same through the CLI's raw-text mode (the reference CLI's only one): lines tokenised on the device
   staged              one device-resident call at a time with per-stage HIP events: the kernel times the rooflines are priced with
 
 Workload = BASELINE config C3 (5 M-sentence synthetic corpus, mean 25 tokens, 1 M queries per step, fuzzy 0.7, nmatch 5) unless
@@ -602,12 +603,16 @@ def main():
             wl.tok_ptrs = None
 
     # ---- the drop-in CLI end to end on the same workload: stdin -> stdout through tools/fmx-cli --tokenised ----
-    cli_leg = None
+    cli_leg = cli_raw_leg = None
     if world == 1 and not args.no_text_leg:
         try:
             cli_leg = cli_end_to_end(ix, host_set[0], pkw, log)
         except Exception as e:  # noqa: BLE001  (a side leg: the line is still worth printing)
             log(f"[bench] cli_end_to_end leg failed: {e!r}")
+        try:   # the same queries as RAW text (no --tokenised): the reference CLI's only mode
+            cli_raw_leg = cli_end_to_end(ix, host_set[0], pkw, log, tokenised=False)
+        except Exception as e:  # noqa: BLE001
+            log(f"[bench] cli_raw_text leg failed: {e!r}")
 
     # ---- one call at a time from HBM (device entry point with statistics): stage times for the rooflines ----
     run_device_steps(main_set, 1)
@@ -884,7 +889,7 @@ def main():
             "pcie_inclusive_ids": {"value": round(value_ids, 1), "ms_per_step": round(elapsed_ids / args.steps * 1e3, 3), "calls_in_flight": T_host,
                                    "note": "fmx_match_batch: vocabulary ids in pinned host memory in, records out (H2D + kernels + D2H"
                                            + (" + the RCCL gather" if world > 1 else "") + "): a caller that already holds ids"},
-            "text_sync_callers": text_sync, "from_token_strings": from_strings, "cli_end_to_end": cli_leg,
+            "text_sync_callers": text_sync, "from_token_strings": from_strings, "cli_end_to_end": cli_leg, "cli_raw_text": cli_raw_leg,
             "staged": {"value": round(nq_step_all * args.steps / el_dev, 1),
                        "ms_per_step": round(el_dev / args.steps * 1e3, 3),
                        "stage_ms_per_step": {k: round(v, 4) for k, v in per_stage.items()},
@@ -899,7 +904,7 @@ def main():
         dist.destroy_process_group()
 
 
-def cli_end_to_end(ix, wl, pkw, log):
+def cli_end_to_end(ix, wl, pkw, log, tokenised=True):
     """The drop-in CLI (tools/fmx-cli: the reference CLI's flags, output and stderr lines, cli/src/FuzzyMatch-cli.cc) on this run's
     own index and first query batch, the way the reference's CI runs it: `-i index.fmi -a match < queries > matches`.  The index goes
     through a .fmi file, the queries are a text file of blank-separated tokens.  Reported: patterns / second of the phase the
@@ -917,7 +922,7 @@ def cli_end_to_end(ix, wl, pkw, log):
         lines[nul] = 32
         lines[nul[wl.q_off[1:].astype(np.int64) - 1]] = 10
         lines.tofile(qf)
-        argv = [cli, "--tokenised", "-i", fmi, "-a", "match", "-f", str(pkw.get("fuzzy", 0.8)), "-n", str(pkw.get("nmatch", 5)),
+        argv = [cli] + (["--tokenised"] if tokenised else []) + ["-i", fmi, "-a", "match", "-f", str(pkw.get("fuzzy", 0.8)), "-n", str(pkw.get("nmatch", 5)),
                 "--mr", str(pkw.get("min_subseq_ratio", 0.3)), "-I", str(pkw.get("idf_penalty", 0.0)), "--contrast", str(pkw.get("contrast", 0.0)),
                 "--contrast-buffer", str(pkw.get("contrast_buffer", -1))]
         t0 = time.time()
@@ -933,13 +938,25 @@ def cli_end_to_end(ix, wl, pkw, log):
         nmatch = [ln for ln in r.stderr.splitlines() if ln.startswith("NMATCH")]
         phase = steps["Done"] - steps["Matching"]
         out_bytes = os.path.getsize(of)
-        log(f"[bench] fmx-cli --tokenised: {wl.nq} patterns in {phase * 1e3:.0f} ms of matching phase = {wl.nq / phase / 1e6:.2f} M patterns/s "
+        log(f"[bench] fmx-cli{' --tokenised' if tokenised else ' (raw text)'}: {wl.nq} patterns in {phase * 1e3:.0f} ms of matching phase = {wl.nq / phase / 1e6:.2f} M patterns/s "
             f"(process wall {wall:.1f}s with the index load); {nmatch[-1] if nmatch else ''}")
+        setup = ("Before 'Matching' (like the index load, and like the reference sets its thread pool up — though the reference does that INSIDE "
+                 "its bracket, cli/src/FuzzyMatch-cli.cc:139-147): the blocks' pinned buffers, the library's call contexts and four warm-up calls of "
+                 "up to 65 536 patterns each (the memory's own sentences as id batches, and a block of dummy lines through the line entry point) that "
+                 "size the workspaces; the worker threads are joined after 'Done'.")
+        if tokenised:
+            note = ("tools/fmx-cli --tokenised -i index.fmi -a match < queries > matches (--tokenised is a flag of THIS CLI: the reference has no "
+                    "such mode): stdin -> fmx_match_batch_lines (the device cuts the lines into patterns and tokens and looks the ids up) -> formatted "
+                    "records on stdout, in input order; time between the CLI's own 'Matching' and 'Done' STEP lines.  " + setup)
+        else:
+            note = ("tools/fmx-cli -i index.fmi -a match < queries > matches — RAW TEXT, the reference CLI's only mode (cli/src/FuzzyMatch-cli.cc:219-233 "
+                    "-> src/fuzzy_match.cc:393-412): stdin -> fmx_match_batch_raw_lines (lines of ASCII letters / digits / punctuation / blanks are "
+                    "tokenised, case-folded and looked up ON THE DEVICE; any other line by the host front-end) -> formatted records on stdout, in input "
+                    "order; time between the CLI's own 'Matching' and 'Done' STEP lines.  The synthetic queries are lower-case ASCII words, so every "
+                    "line takes the device path here.  " + setup)
         return {"value": round(wl.nq / phase, 1), "unit": "patterns/s", "patterns": int(wl.nq), "matching_phase_s": round(phase, 4),
                 "process_wall_s": round(wall, 2), "input_bytes": int(lines.nbytes), "output_bytes": int(out_bytes), "nmatch_line": nmatch[-1] if nmatch else None,
-                "note": "tools/fmx-cli --tokenised -i index.fmi -a match < queries > matches: stdin -> fmx_match_batch_lines (the device cuts the lines "
-                        "into patterns and tokens and looks the ids up) -> formatted records on stdout, in input order; time between the CLI's own "
-                        "'Matching' and 'Done' STEP lines"}
+                "note": note}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 

@@ -608,6 +608,108 @@ int fmx_match_batch_lines(fmx_index* ix, const fmx_params* params, const char* t
   });
 }
 
+// Raw text lines: FuzzyMatch::match(const std::string&, ...) (src/fuzzy_match.cc:393-412) for a block of '\n'-terminated lines, the
+// reference CLI's only input (cli/src/FuzzyMatch-cli.cc:219-233).  Lines of ASCII letters, digits, punctuation and blanks are
+// tokenised ON THE DEVICE (fmx_vocab.hip.hh: k_raw_emit — the aggressive tokenizer is a byte-class machine on that alphabet) when the
+// index's penalty tokens are ones that machine implements (tag, nbr, cas; pct / sep / jnr turn punctuation and joiners into penalty
+// tokens: every line then takes the host path); every other line — UTF-8, placeholders, control characters — is tokenised by the
+// host front-end (fmx_text.cc: NFC, scripts, placeholders, case mapping) and answered through an id batch with its real tokens and
+// penalty tokens.  The rows of those lines overwrite whatever the device made of them.
+int fmx_match_batch_raw_lines(fmx_index* ix, const fmx_params* params, const char* text, uint64_t n_bytes, uint64_t n_lines,
+                              fmx_match* out, uint32_t* out_count, uint32_t* out_total, uint32_t cap, fmx_stats* stats) {
+  if (!ix || !params || !out || !out_count || (n_bytes && !text)) return fail(FMX_E_INVALID, "null argument");
+  if (cap == 0) return fail(FMX_E_INVALID, "cap must be > 0");
+  if (n_lines > n_bytes) return fail(FMX_E_INVALID, "line batch: more lines than bytes (every line ends with a line feed)");
+  if (n_bytes && text[n_bytes - 1] != '\n') return fail(FMX_E_INVALID, "line batch: the text must end with a line feed");
+  if (!ix->finalized) return fail(FMX_E_STATE, "index is not finalized");
+  if (ix->devs.empty()) return fail(FMX_E_NO_DEVICE, "index is not on a device (fmx_index_to_device); there is no CPU path");
+  if (n_lines == 0) return FMX_OK;
+  return guarded([&]() {
+    const int pt = ix->host.pt;
+    const bool device_tok = (pt & (kPtPct | kPtSep | kPtJnr)) == 0;
+    Stats st;
+    const size_t k = ix->devs.size() == 1 ? 0 : ix->rr.fetch_add(1) % ix->devs.size();
+    DeviceIndex* dev = ix->devs[k].get();
+    const Params prm = make_params(ix, params);
+    std::vector<uint64_t> host_lines;
+    if (device_tok) {
+      RawLineTok tok;
+      tok.cas = (pt & kPtCas) ? 1u : 0u;
+      tok.nbr = (pt & kPtNbr) ? 1u : 0u;
+      tok.num_id = ix->host.get_index(std::string("\xEF\xBD\x9F" "num" "\xEF\xBD\xA0"));  // ｟num｠ (src/fuzzy_match.cc:168)
+      static const char* const kFeat[4] = {"L", "C", "U", "M"};
+      for (int f = 0; f < 4; f++) tok.feat_real[f] = ix->host.real_differs ? ix->host.lookup_real(kFeat[f]) : 0x7ffffffeu;
+      dev->match_raw_lines(ix->host, prm, text, n_bytes, n_lines, (Rec*)out, out_count, out_total, cap, &st, tok, host_lines);
+    } else {
+      host_lines.resize(n_lines);
+      for (uint64_t l = 0; l < n_lines; l++) host_lines[l] = l;
+    }
+    if (!host_lines.empty()) {
+      // where the lines start (only the flagged ones are looked at)
+      std::vector<uint64_t> at;
+      if (host_lines.size() == n_lines) {
+        at.reserve(n_lines + 1);
+        at.push_back(0);
+        for (const char* p = text; p < text + n_bytes;) { const char* nl = (const char*)memchr(p, '\n', (size_t)(text + n_bytes - p)); p = nl + 1; at.push_back((uint64_t)(p - text)); }
+      } else {
+        at.resize(host_lines.size() * 2);
+        uint64_t line = 0, want = 0;
+        for (const char* p = text; p < text + n_bytes && want < host_lines.size();) {
+          const char* nl = (const char*)memchr(p, '\n', (size_t)(text + n_bytes - p));
+          if (line == host_lines[want]) { at[2 * want] = (uint64_t)(p - text); at[2 * want + 1] = (uint64_t)(nl - text); want++; }
+          p = nl + 1; line++;
+        }
+      }
+      const uint64_t nh = host_lines.size();
+      std::vector<uint32_t> q_off(nh + 1, 0), q_tok, q_real, q_itok;
+      std::vector<TextTokens> toks(nh);
+      // the front-end on all usable CPUs (a line is independent of its neighbours)
+      {
+        const uint64_t nt = std::max<uint64_t>(1, std::min<uint64_t>(usable_cpus(), nh / 256 + 1));
+        auto work = [&](uint64_t a, uint64_t b) {
+          for (uint64_t i = a; i < b; i++) {
+            const uint64_t b0 = host_lines.size() == n_lines ? at[i] : at[2 * i];
+            const uint64_t b1 = host_lines.size() == n_lines ? at[i + 1] - 1 : at[2 * i + 1];
+            tokenize_and_normalize(pt, std::string(text + b0, (size_t)(b1 - b0)), toks[i]);
+          }
+        };
+        std::vector<std::thread> th;
+        for (uint64_t t = 1; t < nt; t++) th.emplace_back(work, nh * t / nt, nh * (t + 1) / nt);
+        work(0, nh / nt);
+        for (auto& t : th) t.join();
+      }
+      const bool real = ix->host.real_differs;
+      for (uint64_t i = 0; i < nh; i++) q_off[i + 1] = q_off[i] + (uint32_t)toks[i].norm.size();
+      q_tok.resize(q_off[nh]);
+      if (real) { q_real.resize(q_off[nh]); q_itok.assign((size_t)q_off[nh] + nh, 0u); }
+      for (uint64_t i = 0; i < nh; i++) {
+        const TextTokens& t = toks[i];
+        for (size_t j = 0; j < t.norm.size(); j++) {
+          q_tok[q_off[i] + j] = ix->host.get_index(t.norm[j]);
+          if (real) q_real[q_off[i] + j] = ix->host.lookup_real(t.real[j]);
+        }
+        if (real)
+          for (const auto& kv : t.itoks)
+            if (kv.first <= t.norm.size()) q_itok[(size_t)q_off[i] + i + kv.first] = ix->host.intern_itok(kv.second);
+      }
+      std::vector<fmx_match> h_out(nh * cap);
+      std::vector<uint32_t> h_cnt(nh, 0), h_tot(nh, 0);
+      HostBatchView v;
+      v.nq = nh; v.q_off = q_off.data(); v.q_tok = q_tok.empty() ? q_off.data() : q_tok.data();
+      if (real) { v.q_real = q_real.empty() ? q_off.data() : q_real.data(); v.q_itok = q_itok.data(); }
+      dev->match_host(ix->host, prm, v, (Rec*)h_out.data(), h_cnt.data(), h_tot.data(), cap, nullptr);
+      for (uint64_t i = 0; i < nh; i++) {
+        const uint64_t l = host_lines[i];
+        out_count[l] = h_cnt[i];
+        if (out_total) out_total[l] = h_tot[i];
+        memcpy(out + l * cap, h_out.data() + i * cap, (size_t)h_cnt[i] * sizeof(fmx_match));
+      }
+    }
+    copy_stats(st, stats);
+    return (int)FMX_OK;
+  });
+}
+
 // ---------------------------------------------------------------------------------------------
 // Request coalescer behind fmx_match_one.  The reference's match() is called one pattern at a time from N
 // threads; a GPU pass costs ~45 launches whatever its size, so concurrent requests with equal parameters are

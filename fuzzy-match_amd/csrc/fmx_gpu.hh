@@ -89,6 +89,13 @@ SortResident* gpu_suffix_sort(HostIndex& h, int device);
 void* gpu_host_alloc(size_t bytes);  // pinned host memory (hipHostMalloc), nullptr on failure
 void  gpu_host_free(void* p);
 
+// what the device's raw-text tokenizer needs to know about the index (fmx_match_batch_raw_lines)
+struct RawLineTok {
+  uint32_t cas = 0, nbr = 0;   // the index's penalty tokens that change a word (lower case + case feature) / a number (placeholder)
+  uint32_t num_id = 1;         // vocabulary id of the number placeholder
+  uint32_t feat_real[4] = {0x7ffffffeu, 0x7ffffffeu, 0x7ffffffeu, 0x7ffffffeu};  // real-token ids of the features L, C, U, M
+};
+
 class DeviceIndex {
  public:
   struct Impl;
@@ -139,6 +146,11 @@ class DeviceIndex {
   // matched on the device
   void match_lines(const HostIndex& h, const Params& prm, const char* text, uint64_t n_bytes, uint64_t n_lines, Rec* out,
                    uint32_t* out_count, uint32_t* out_total, uint32_t cap, Stats* st);
+  // raw text lines: tokenised by the device's byte-class machine where it applies (ASCII letters / digits / punctuation / blanks);
+  // bad_lines = the lines with any other byte, for the host front-end
+  void match_raw_lines(const HostIndex& h, const Params& prm, const char* text, uint64_t n_bytes, uint64_t n_lines, Rec* out,
+                       uint32_t* out_count, uint32_t* out_total, uint32_t cap, Stats* st, const RawLineTok& tok,
+                       std::vector<uint64_t>& bad_lines);
   // the two halves of match_host (the pipeline path) for ONE host thread that keeps several host-buffer calls in flight
   struct HostCall;
   HostCall* match_host_begin(const HostIndex& h, const Params& prm, const HostBatchView& b, Rec* out, uint32_t* out_count,
@@ -159,6 +171,9 @@ class DeviceIndex {
                        uint32_t* out_total, uint32_t cap, Stats* st, Rec* d_keep, uint32_t* d_keep_count);
   bool match_host_small(const HostIndex& h, const Params& prm, const HostBatchView& b, Rec* out, uint32_t* out_count,
                         uint32_t* out_total, uint32_t cap, Stats* st);
+  void match_lines_impl(const HostIndex& h, const Params& prm, const char* text, uint64_t n_bytes, uint64_t n_lines, Rec* out,
+                        uint32_t* out_count, uint32_t* out_total, uint32_t cap, Stats* st, const RawLineTok* raw,
+                        std::vector<uint64_t>* bad_lines);
   Impl* impl_;
 };
 

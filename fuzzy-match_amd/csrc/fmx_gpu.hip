@@ -148,8 +148,8 @@ struct DevBlob {
 };
 
 constexpr int kMaxPassesInFlight = 2;
-constexpr uint64_t kTurnMinQueries = 262144;  // device-resident calls at least this large are chained on the GPU (Impl::turns), smaller ones overlap freely
-constexpr uint64_t kTurnMinQueriesHost = 32768;  // host-buffer calls: chained from here on (their copies interleave badly when the kernels of
+static const uint64_t kTurnMinQueries = [] { const char* e = getenv("FMX_TURN_MIN"); return e ? (uint64_t)atoll(e) : (uint64_t)262144; }();  // device-resident calls at least this large are chained on the GPU (Impl::turns), smaller ones overlap freely (design-time switch FMX_TURN_MIN)
+static const uint64_t kTurnMinQueriesHost = [] { const char* e = getenv("FMX_TURN_MIN_HOST"); return e ? (uint64_t)atoll(e) : (uint64_t)32768; }();  // host-buffer calls: chained from here on (their copies interleave badly when the kernels of
                                                  // 100 k-query calls overlap freely: 46 M patterns/s against 86 M chained at C2)
 constexpr int kScanSlots = 4;  // scans per pass: queue capacities, queued hits, candidate classes, contrast lists
 
@@ -193,6 +193,7 @@ struct Ctx {
   Grow<unsigned long long> d_islot;        // penalty tokens of a text batch: slot ...
   Grow<uint32_t> d_iid;                    // ... and interned id
   Grow<uint32_t> d_scratch;                // a few scratch words (longest pattern of a line batch)
+  Grow<unsigned char> d_lflag;             // raw-text batches: one byte per line, set by the device tokenizer for lines it does not cover
   unsigned long long* h_vtotal = nullptr;  // pinned: tokens k_vocab_lookup found
   Grow<Rec>      d_out;
   // ---- streams / events ----
@@ -278,7 +279,7 @@ struct Ctx {
     t_q.release(); t_lo.release(); t_cnt.release(); t_idf.release(); c_qi.release(); keys.release(); seg.release(); qb.release();
     heap.release(); f0.release(); f1.release(); vals.release(); zero_blk.release();
     items.release(); items_b.release(); items_h.release(); cmin_tab.release(); g_rows.release();
-    d_qoff.release(); d_qtok.release(); d_qreal.release(); d_qitok.release(); d_text.release(); d_vstate.release(); d_text_r.release(); d_vstate_r.release(); d_islot.release(); d_iid.release(); d_scratch.release(); d_cnt.release(); d_tot.release(); d_out.release(); d_prior.release();
+    d_qoff.release(); d_qtok.release(); d_qreal.release(); d_qitok.release(); d_text.release(); d_vstate.release(); d_text_r.release(); d_vstate_r.release(); d_islot.release(); d_iid.release(); d_scratch.release(); d_lflag.release(); d_cnt.release(); d_tot.release(); d_out.release(); d_prior.release();
     if (stream) (void)hipStreamDestroy(stream);
     if (h2d && !shared_copy) (void)hipStreamDestroy(h2d);
     if (d2h && !shared_copy) (void)hipStreamDestroy(d2h);
@@ -2096,6 +2097,20 @@ __global__ void k_pmax(const uint32_t* q_off, unsigned long long nq, uint32_t* o
 // ---------------------------------------------------------------------------------------------
 void DeviceIndex::match_lines(const HostIndex& h, const Params& prm, const char* text, uint64_t n_bytes, uint64_t n_lines, Rec* out,
                               uint32_t* out_count, uint32_t* out_total, uint32_t cap, Stats* st) {
+  match_lines_impl(h, prm, text, n_bytes, n_lines, out, out_count, out_total, cap, st, nullptr, nullptr);
+}
+
+// raw text: the byte-class tokenizer on the device (fmx_vocab.hip.hh: k_raw_count / k_raw_emit); bad_lines = the lines it flagged
+// (bytes outside its alphabet: the caller tokenises them on the host and overwrites their rows)
+void DeviceIndex::match_raw_lines(const HostIndex& h, const Params& prm, const char* text, uint64_t n_bytes, uint64_t n_lines, Rec* out,
+                                  uint32_t* out_count, uint32_t* out_total, uint32_t cap, Stats* st, const RawLineTok& tok,
+                                  std::vector<uint64_t>& bad_lines) {
+  match_lines_impl(h, prm, text, n_bytes, n_lines, out, out_count, out_total, cap, st, &tok, &bad_lines);
+}
+
+void DeviceIndex::match_lines_impl(const HostIndex& h, const Params& prm, const char* text, uint64_t n_bytes, uint64_t n_lines, Rec* out,
+                                   uint32_t* out_count, uint32_t* out_total, uint32_t cap, Stats* st, const RawLineTok* raw,
+                                   std::vector<uint64_t>* bad_lines) {
   Impl& m = *impl_;
   if (m.device < 0) throw GpuError("index is not on a device");
   HIP_TRY(hipSetDevice(m.device));
@@ -2108,7 +2123,9 @@ void DeviceIndex::match_lines(const HostIndex& h, const Params& prm, const char*
   CtxLease lease(m, /*no_wait=*/false, /*host_kind=*/true);  // (a host-buffer call like any other: it counts against max_host_active)
   Ctx& c = *lease.c;
   const uint64_t tiles = (n_bytes + (uint64_t)kScanThreads * kVocabChunk - 1) / ((uint64_t)kScanThreads * kVocabChunk);
-  const uint64_t tok_cap = n_bytes / 2 + 2;  // a token is at least one byte and its separator
+  // a token is at least one byte and its separator; raw text: every byte may be a token of its own (punctuation)
+  const uint64_t tok_cap = raw ? n_bytes + 2 : n_bytes / 2 + 2;
+  if (raw) c.d_lflag.ensure(n_lines + 8);
   c.d_text.ensure(n_bytes + 2 * kVocabChunk + 16);
   c.d_vstate.ensure(tiles + 4);
   c.d_vstate_r.ensure(tiles + 4);
@@ -2122,6 +2139,7 @@ void DeviceIndex::match_lines(const HostIndex& h, const Params& prm, const char*
   if (!c.h_vtotal) HIP_TRY(hipHostMalloc((void**)&c.h_vtotal, 4 * sizeof(unsigned long long), hipHostMallocDefault));
   c.h_vtotal[0] = c.h_vtotal[1] = ~0ull;
   c.h_vtotal[2] = 0ull;
+  c.h_vtotal[3] = 0ull;
   c.d_scratch.ensure(16);  // (a context-owned scratch word: no allocation, and no hipFree — a device-wide wait — inside a call)
   unsigned long long* d_total = nullptr;
   HIP_TRY(hipHostGetDevicePointer((void**)&d_total, c.h_vtotal, 0));
@@ -2130,6 +2148,18 @@ void DeviceIndex::match_lines(const HostIndex& h, const Params& prm, const char*
   HIP_TRY(hipMemcpyAsync(c.d_text.p, text, n_bytes, hipMemcpyHostToDevice, s));
   uint32_t* tile_tok = reinterpret_cast<uint32_t*>(c.d_vstate.p);
   uint32_t* tile_nl = reinterpret_cast<uint32_t*>(c.d_vstate_r.p);
+  if (raw) {
+    RawTok rt;
+    rt.cas = raw->cas; rt.nbr = raw->nbr; rt.num_id = raw->num_id;
+    for (int k = 0; k < 4; k++) rt.feat_real[k] = raw->feat_real[k];
+    HIP_TRY(hipMemsetAsync(c.d_lflag.p, 0, n_lines + 8, s));
+    hipLaunchKernelGGL(k_raw_count, dim3((unsigned)tiles), dim3(kScanThreads), 0, s, (const unsigned char*)c.d_text.p, (unsigned long long)n_bytes, tile_tok, tile_nl);
+    hipLaunchKernelGGL(k_vocab_scan, dim3(1), dim3(kScanThreads), 0, s, tile_tok, (uint32_t)tiles, d_total);
+    hipLaunchKernelGGL(k_vocab_scan, dim3(1), dim3(kScanThreads), 0, s, tile_nl, (uint32_t)tiles, d_total + 1);
+    hipLaunchKernelGGL(k_raw_emit, dim3((unsigned)tiles), dim3(kScanThreads), 0, s, (const unsigned char*)c.d_text.p, (unsigned long long)n_bytes,
+                       (const uint32_t*)tile_tok, (const uint32_t*)tile_nl, c.d_qoff.p, (unsigned long long)n_lines, (unsigned long long)tok_cap,
+                       text_snap.vocab, m.real_vocab, rt, c.d_qtok.p, real ? c.d_qreal.p : (uint32_t*)nullptr, c.d_lflag.p, d_total + 3);
+  } else {
   hipLaunchKernelGGL(k_lines_count, dim3((unsigned)tiles), dim3(kScanThreads), 0, s, (const unsigned char*)c.d_text.p, (unsigned long long)n_bytes, tile_tok, tile_nl);
   hipLaunchKernelGGL(k_vocab_scan, dim3(1), dim3(kScanThreads), 0, s, tile_tok, (uint32_t)tiles, d_total);
   hipLaunchKernelGGL(k_vocab_scan, dim3(1), dim3(kScanThreads), 0, s, tile_nl, (uint32_t)tiles, d_total + 1);
@@ -2140,6 +2170,7 @@ void DeviceIndex::match_lines(const HostIndex& h, const Params& prm, const char*
   if (real)  // match(const Tokens&, ...): the pattern's own spellings are its real tokens (src/fuzzy_match.cc:402-416)
     hipLaunchKernelGGL(k_vocab_lookup, dim3((unsigned)tiles), dim3(kScanThreads), 0, s, (const unsigned char*)c.d_text.p, (unsigned long long)n_bytes,
                        (unsigned long long)tok_cap, m.real_vocab, c.d_qreal.p, (const uint32_t*)tile_tok, 0x7ffffffeu);
+  }
   HIP_TRY(hipGetLastError());
   // the passes need the token bounds and the longest pattern: read back with ONE wait (the token total is the end of the only
   // pass; a call of more lines than a pass holds reads the boundaries of its passes too)
@@ -2160,6 +2191,15 @@ void DeviceIndex::match_lines(const HostIndex& h, const Params& prm, const char*
   }
   if (c.h_vtotal[1] != n_lines)
     throw std::invalid_argument("line batch: the text holds " + std::to_string(c.h_vtotal[1]) + " line ends, the call names " + std::to_string(n_lines) + " lines");
+  if (raw && bad_lines) {  // the lines the device tokenizer does not cover (their flags travel while the passes are enqueued)
+    bad_lines->clear();
+    if (c.h_vtotal[3] != 0) {
+      std::vector<unsigned char> flags(n_lines);
+      HIP_TRY(hipMemcpyAsync(flags.data(), c.d_lflag.p, n_lines, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      for (uint64_t l = 0; l < n_lines; l++) if (flags[l]) bad_lines->push_back(l);
+    }
+  }
   bv.p_max = std::max<uint32_t>(p_max, 1);
   std::vector<uint64_t> qb;
   for (uint64_t q = 0; q < n_lines; q += m.sub_queries) qb.push_back(q);

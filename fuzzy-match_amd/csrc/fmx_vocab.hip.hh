@@ -228,4 +228,178 @@ __global__ void __launch_bounds__(kScanThreads) k_lines_emit(unsigned char* __re
   if (b0 < n_bytes) *reinterpret_cast<uint4*>(text + b0) = conv;  // blanks -> terminators (bytes beyond n_bytes are zero already)
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// RAW text lines (fmx_match_batch_raw_lines, round 5): what the reference CLI reads (cli/src/FuzzyMatch-cli.cc:219-233) and
+// FuzzyMatch::match(const std::string&, ...) tokenises (src/fuzzy_match.cc:393-412 -> _tokenize_and_normalize, :108-193).  For
+// lines made of ASCII letters, digits, punctuation and blanks — the alphabet the reference's fixtures pin the tokenizer on — the
+// aggressive tokenizer is a byte-class machine (fmx_text.cc: tokenize_aggressive): a run of letters is a token, a run of digits
+// is a token, every other printable character is a token of its own, white space separates; with the `cas` penalty token a word
+// is lower-cased and its real token is the case feature (L / C / U / M), with `nbr` a number's normalised token is the
+// placeholder and its real token the digits (src/fuzzy_match.cc:131-135, 160-170).  The device runs that machine on the bytes as
+// they sit in the file: token starts and line ends per 16 bytes, two scans of the tile counts, then every token start computes
+// its run, hashes it (lower-cased where the index says so) and looks its vocabulary id — and its real-token id — up; every line
+// end writes its pattern's end offset.  No spelling is ever written.  A line with any other byte (UTF-8, control characters) is
+// FLAGGED: the host tokenises those lines (fmx_text.cc, the full front-end) and answers them through a text batch; whatever the
+// device made of them is overwritten.
+// ---------------------------------------------------------------------------------------------
+enum : uint32_t { kRawSep = 0, kRawLetter = 1, kRawDigit = 2, kRawOther = 3, kRawBad = 4 };
+__device__ __forceinline__ uint32_t raw_class(unsigned char c) {
+  const unsigned char l = c | 0x20;
+  if (l >= 'a' && l <= 'z') return kRawLetter;
+  if (c >= '0' && c <= '9') return kRawDigit;
+  if (c == ' ' || (c >= 9 && c <= 13) || c == 0) return kRawSep;   // onmt::unicode::is_separator on ASCII (0: the padding behind the text)
+  if (c > 32 && c < 128) return kRawOther;
+  return kRawBad;
+}
+
+struct RawTok {
+  uint32_t cas, nbr;        // penalty tokens of the index that change a word / a number (fmx_text.hh: kPtCas, kPtNbr)
+  uint32_t num_id;          // vocabulary id of the number placeholder (VOCAB_UNK when the index never saw a number)
+  uint32_t feat_real[4];    // real-token ids of the case features L, C, U, M (0x7ffffffe: the index holds no such real token)
+};
+
+// starts: bit i = a token starts at byte b0 + i; nls: line ends; bad: bytes outside the alphabet
+__device__ __forceinline__ void raw_masks(const unsigned char* __restrict__ text, unsigned long long b0, unsigned long long n_bytes,
+                                          uint32_t& starts, uint32_t& nls, uint32_t& bad) {
+  starts = 0; nls = 0; bad = 0;
+  if (b0 >= n_bytes) return;
+  uint32_t prev = b0 ? raw_class(text[b0 - 1]) : (uint32_t)kRawSep;
+  if (prev == kRawBad) prev = kRawSep;
+  const uint4 x = *reinterpret_cast<const uint4*>(text + b0);
+  const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+  for (uint32_t k = 0; k < 16; k++) {
+    const unsigned char c = (unsigned char)(xs[k >> 2] >> (8 * (k & 3)));
+    const bool in = b0 + k < n_bytes;
+    uint32_t cl = in ? raw_class(c) : (uint32_t)kRawSep;
+    if (cl == kRawBad) { bad |= 1u << k; cl = kRawSep; }
+    if (cl != kRawSep && (cl == kRawOther || cl != prev)) starts |= 1u << k;
+    if (in && c == '\n') nls |= 1u << k;
+    prev = cl;
+  }
+}
+
+__global__ void __launch_bounds__(kScanThreads) k_raw_count(const unsigned char* __restrict__ text, unsigned long long n_bytes,
+                                                           uint32_t* __restrict__ tile_tok, uint32_t* __restrict__ tile_nl) {
+  __shared__ uint32_t s_t[kScanThreads / kWave], s_n[kScanThreads / kWave];
+  const unsigned long long b0 = ((unsigned long long)blockIdx.x * kScanThreads + threadIdx.x) * kVocabChunk;
+  uint32_t st, nl, bad;
+  raw_masks(text, b0, n_bytes, st, nl, bad);
+  const uint32_t a = wave_sum((uint32_t)__popc(st)), b = wave_sum((uint32_t)__popc(nl));
+  if ((threadIdx.x & 63) == 0) { s_t[threadIdx.x >> 6] = a; s_n[threadIdx.x >> 6] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t t = 0, n = 0;
+    for (uint32_t k = 0; k < kScanThreads / kWave; k++) { t += s_t[k]; n += s_n[k]; }
+    tile_tok[blockIdx.x] = t;
+    tile_nl[blockIdx.x] = n;
+  }
+}
+
+// the id of the `len` bytes at t in table v (HostIndex::FastVocab: FNV-1a, the first eight bytes beside every slot); lower: upper-case
+// ASCII letters count as their lower-case counterparts (onmt::CaseModifier on ASCII)
+__device__ __forceinline__ uint32_t raw_find(const DevVocab& v, const unsigned char* __restrict__ t, uint32_t len, bool lower, uint32_t unknown_id) {
+  unsigned long long h = 1469598103934665603ull, hd = 0;
+  for (uint32_t k = 0; k < len; k++) {
+    unsigned char c = t[k];
+    if (lower && c >= 'A' && c <= 'Z') c |= 0x20;
+    h ^= c; h *= 1099511628211ull;
+    if (k < 8) hd |= (unsigned long long)c << (8 * k);
+  }
+  h = (h ^ (h >> 29)) & v.mask;
+  for (;;) {
+    const ulonglong2 e = v.entry[h];
+    if (e.x == ~0ull) return unknown_id;
+    if (e.y == hd) {
+      bool same = true;
+      if (len >= 8) {
+        const unsigned char* a = v.arena + (e.x >> 32);
+        for (uint32_t k = 8; k <= len && same; k++) {
+          unsigned char c = k < len ? t[k] : (unsigned char)0;
+          if (lower && c >= 'A' && c <= 'Z') c |= 0x20;
+          same = a[k] == c;
+        }
+      }
+      if (same) return (uint32_t)e.x;
+    }
+    h = (h + 1) & v.mask;
+  }
+}
+
+// tile_tok / tile_nl: exclusive scans of the tile counts.  q_off: n_lines + 1 entries; ids / real: one per token (real may be
+// null: the index's real tokens are its normalised tokens); line_bad: one byte per line, zeroed by the caller; n_bad: lines flagged.
+__global__ void __launch_bounds__(kScanThreads) k_raw_emit(const unsigned char* __restrict__ text, unsigned long long n_bytes,
+                                                          const uint32_t* __restrict__ tile_tok, const uint32_t* __restrict__ tile_nl,
+                                                          uint32_t* __restrict__ q_off, unsigned long long n_lines, unsigned long long n_tok,
+                                                          DevVocab vocab, DevVocab real_vocab, RawTok rt, uint32_t* __restrict__ ids,
+                                                          uint32_t* __restrict__ real, unsigned char* __restrict__ line_bad,
+                                                          unsigned long long* __restrict__ n_bad) {
+  __shared__ uint32_t s_t[kScanThreads / kWave], s_n[kScanThreads / kWave];
+  const unsigned long long b0 = ((unsigned long long)blockIdx.x * kScanThreads + threadIdx.x) * kVocabChunk;
+  uint32_t st, nl, bad;
+  raw_masks(text, b0, n_bytes, st, nl, bad);
+  const uint32_t ct = (uint32_t)__popc(st), cn = (uint32_t)__popc(nl);
+  const uint32_t it = wave_incl_scan(ct), in = wave_incl_scan(cn);
+  if ((threadIdx.x & 63) == 63) { s_t[threadIdx.x >> 6] = it; s_n[threadIdx.x >> 6] = in; }
+  __syncthreads();
+  uint32_t bt = 0, bn = 0;
+  for (uint32_t k = 0; k < (threadIdx.x >> 6); k++) { bt += s_t[k]; bn += s_n[k]; }
+  const unsigned long long tok0 = (unsigned long long)tile_tok[blockIdx.x] + bt + it - ct;  // token starts in front of this thread's bytes
+  const unsigned long long line0 = (unsigned long long)tile_nl[blockIdx.x] + bn + in - cn;   // line ends in front of them
+  if (blockIdx.x == 0 && threadIdx.x == 0) q_off[0] = 0u;
+  {  // every line end writes its pattern's end offset
+    uint32_t m = nl;
+    unsigned long long line = line0;
+    while (m) {
+      const uint32_t i = (uint32_t)__builtin_ctz(m);
+      m &= m - 1u;
+      if (line < n_lines) q_off[line + 1] = (uint32_t)(tok0 + __popc(st & ((1u << i) - 1u)));
+      line++;
+    }
+  }
+  {  // a byte outside the alphabet flags its line (the line of byte i: line ends in front of it)
+    uint32_t m = bad;
+    while (m) {
+      const uint32_t i = (uint32_t)__builtin_ctz(m);
+      m &= m - 1u;
+      const unsigned long long line = line0 + __popc(nl & ((1u << i) - 1u));
+      if (line < n_lines && line_bad[line] == 0) {
+        // (several threads may flag one line: the byte is written by all of them, the count by the first to swap its word)
+        unsigned int* wptr = reinterpret_cast<unsigned int*>(line_bad + (line & ~3ull));
+        const unsigned int bit = 1u << (8 * (line & 3ull));
+        const unsigned int old = atomicOr(wptr, bit);
+        if ((old & bit) == 0) atomicAdd(n_bad, 1ull);
+      }
+    }
+  }
+  unsigned long long rank = tok0;
+  uint32_t m = st;
+  while (m) {
+    const uint32_t i = (uint32_t)__builtin_ctz(m);
+    m &= m - 1u;
+    const unsigned char* t = text + b0 + i;
+    const uint32_t cl = raw_class(t[0]);
+    uint32_t len = 1;
+    if (cl != kRawOther) while (raw_class(t[len]) == cl) len++;   // (the text is followed by zero bytes: a run ends there at the latest)
+    uint32_t id, rid = 0x7ffffffeu;
+    const bool word = cl == kRawLetter && rt.cas != 0;
+    if (cl == kRawDigit && rt.nbr != 0) id = rt.num_id;
+    else id = raw_find(vocab, t, len, word, 1u);   // VOCAB_UNK for spellings the index never saw (VocabIndexer::getIndex)
+    if (real != nullptr) {
+      if (word) {  // onmt::CaseModifier::extract_case_type over the run
+        uint32_t n_up = 0;
+        for (uint32_t k = 0; k < len; k++) n_up += (t[k] >= 'A' && t[k] <= 'Z') ? 1u : 0u;
+        const bool first_up = t[0] >= 'A' && t[0] <= 'Z';
+        const uint32_t f = n_up == 0 ? 0u : ((first_up && n_up == 1) ? 1u : ((n_up == len && len >= 2) ? 2u : 3u));
+        rid = rt.feat_real[f];
+      } else {
+        rid = raw_find(real_vocab, t, len, false, 0x7ffffffeu);
+      }
+    }
+    if (rank < n_tok) { ids[rank] = id; if (real != nullptr) real[rank] = rid; }
+    rank++;
+  }
+}
+
 }  // namespace fmx

@@ -87,7 +87,7 @@ EXPORTS = [
     "fmx_subsequence_batch", "fmx_text_tokenize", "fmx_text_free", "fmx_text_num_tokens", "fmx_text_norm", "fmx_text_real",
     "fmx_text_num_itoks", "fmx_text_itok_index", "fmx_text_itok", "fmx_text_num_raw", "fmx_text_raw", "fmx_text_map",
     "fmx_text_detokenize", "fmx_index_add_text", "fmx_index_device_array", "fmx_index_from_arrays", "fmx_text_feature",
-    "fmx_match_one_prior", "fmx_match_one_prior_ids", "fmx_match_batch_device_begin", "fmx_match_batch_device_end", "fmx_vocab_lookup_mt", "fmx_index_set_forms",
+    "fmx_match_one_prior", "fmx_match_one_prior_ids", "fmx_match_batch_raw_lines", "fmx_match_batch_device_begin", "fmx_match_batch_device_end", "fmx_vocab_lookup_mt", "fmx_index_set_forms",
 ]
 TM_SKIPPED = -100
 
@@ -537,6 +537,21 @@ class Index:
         lib().fmx_match_batch_lines.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p,
                                                 C.c_void_p, C.c_uint32, C.POINTER(Stats)]
         _check(lib().fmx_match_batch_lines(self.h, C.byref(params), _ptr(text), len(text), n_lines, _ptr(out), _ptr(cnt), _ptr(tot), cap, C.byref(st)))
+        res = (out[:n_lines], cnt[:n_lines], tot[:n_lines])
+        return res + (st,) if want_stats else res
+
+    def match_batch_raw_lines(self, params, text, n_lines, cap=None, want_stats=False):
+        """fmx_match_batch_raw_lines: raw UTF-8 lines (bytes / uint8 array, every line ended by a line feed) — match(const std::string&, ...)."""
+        text = np.frombuffer(text, dtype=np.uint8) if isinstance(text, (bytes, bytearray)) else np.ascontiguousarray(text, dtype=np.uint8)
+        if cap is None:
+            cap = params.nmatch if params.nmatch > 0 else 64
+        out = np.zeros((max(n_lines, 1), cap), dtype=MATCH_DTYPE)
+        cnt = np.zeros(max(n_lines, 1), dtype=np.uint32)
+        tot = np.zeros(max(n_lines, 1), dtype=np.uint32)
+        st = Stats()
+        lib().fmx_match_batch_raw_lines.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p,
+                                                    C.c_void_p, C.c_uint32, C.POINTER(Stats)]
+        _check(lib().fmx_match_batch_raw_lines(self.h, C.byref(params), _ptr(text), len(text), n_lines, _ptr(out), _ptr(cnt), _ptr(tot), cap, C.byref(st)))
         res = (out[:n_lines], cnt[:n_lines], tot[:n_lines])
         return res + (st,) if want_stats else res
 

@@ -285,6 +285,15 @@ int fmx_match_batch_text_end(fmx_index*, fmx_pending* pending);
  * hold exactly n_lines line feeds. */
 int fmx_match_batch_lines(fmx_index*, const fmx_params*, const char* text, uint64_t n_bytes, uint64_t n_lines,
                           fmx_match* out, uint32_t* out_count, uint32_t* out_total, uint32_t cap, fmx_stats* stats);
+/* RAW text lines: FuzzyMatch::match(const std::string& pattern, ...) (include/fuzzy/fuzzy_match.hh:86-95, src/fuzzy_match.cc:393-412:
+ * _tokenize_and_normalize, then match(Sentence, Tokens, ...)) for a block of '\n'-terminated UTF-8 lines, the reference CLI's
+ * only input (cli/src/FuzzyMatch-cli.cc:219-233).  Lines made of ASCII letters, digits, punctuation and blanks are tokenised
+ * on the device (the aggressive tokenizer is a byte-class machine on that alphabet) when the index's penalty tokens are among
+ * tag / nbr / cas; every other line is tokenised by the host front-end (fmx_text_tokenize's code: NFC, scripts, placeholders)
+ * and answered with its real tokens and penalty tokens like fmx_match_batch would.  Records: one row of `cap` per line, in
+ * input order. */
+int fmx_match_batch_raw_lines(fmx_index*, const fmx_params*, const char* text, uint64_t n_bytes, uint64_t n_lines,
+                              fmx_match* out, uint32_t* out_count, uint32_t* out_total, uint32_t cap, fmx_stats* stats);
 /* Same with every buffer already in the HBM of the index's device; `stream` is a hipStream_t
  * (NULL = a stream of the library after a device-wide synchronisation).  total_tokens = q_off[nq] when q_off[0] == 0, else
  * 0 (with it and max_len set, a batch of one pass needs no device read up front; the value is CHECKED on the device against

@@ -56,6 +56,8 @@ DeviceIndex::HostCall* DeviceIndex::match_host_begin(const HostIndex&, const Par
 void DeviceIndex::match_host_end(HostCall*) { no_device(); }
 void DeviceIndex::match_host_abandon(HostCall*) {}
 void DeviceIndex::match_lines(const HostIndex&, const Params&, const char*, uint64_t, uint64_t, Rec*, uint32_t*, uint32_t*, uint32_t, Stats*) { no_device(); }
+void DeviceIndex::match_raw_lines(const HostIndex&, const Params&, const char*, uint64_t, uint64_t, Rec*, uint32_t*, uint32_t*, uint32_t, Stats*,
+                                  const RawLineTok&, std::vector<uint64_t>&) { no_device(); }
 void DeviceIndex::subsequence_host(const HostIndex&, const HostBatchView&, uint32_t, bool, int, float, bool, Rec*, uint32_t*, uint32_t*) { no_device(); }
 std::vector<uint32_t> DeviceIndex::sub_bounds_from_device(const uint32_t*, uint64_t, uint32_t*, void*) { no_device(); return {}; }
 

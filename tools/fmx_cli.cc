@@ -282,7 +282,10 @@ int main(int argc, char** argv) {
     // contexts (streams, events) — one tiny call per slot.
     const unsigned workers = std::max(1u, nthreads);
     constexpr int kGpuCalls = 4;     // synchronous library calls in flight (each in its own context; their kernels and copies overlap)
-    const bool lines_path = tokenised && !subseq;
+    // -a match: the block goes to the library as it sits in the file — pre-tokenised lines (fmx_match_batch_lines) or, like the
+    // reference CLI reads them, RAW lines (fmx_match_batch_raw_lines: the device tokenises what its byte-class machine covers, the
+    // host front-end the rest); the host-side tokenisation below is the subsequence action's
+    const bool lines_path = !subseq;
     const uint32_t cap0 = subseq ? 1u : (prm.nmatch ? prm.nmatch : 64);
 
     const size_t n_jobs = std::min<size_t>(workers, 16) + 8;
@@ -317,8 +320,9 @@ int main(int argc, char** argv) {
           if (lines_path) {  // ... and the line path's own buffers and kernels: a block of the same shape, of words no memory holds
             std::string dummy;
             dummy.reserve(nw * 120);
-            for (size_t q = 0; q < nw; q++) { for (int k = 0; k < 24; k++) dummy += "?w?w "; dummy.back() = '\n'; }
-            (void)fmx_match_batch_lines(ix, &prm, dummy.data(), dummy.size(), nw, out.data(), c1.data(), t1.data(), cap0, nullptr);
+            for (size_t q = 0; q < nw; q++) { for (int k = 0; k < 24; k++) dummy += tokenised ? "?w?w " : "qzqz "; dummy.back() = '\n'; }
+            if (tokenised) (void)fmx_match_batch_lines(ix, &prm, dummy.data(), dummy.size(), nw, out.data(), c1.data(), t1.data(), cap0, nullptr);
+            else (void)fmx_match_batch_raw_lines(ix, &prm, dummy.data(), dummy.size(), nw, out.data(), c1.data(), t1.data(), cap0, nullptr);
           }
         });
       for (auto& t : warm) t.join();
@@ -441,7 +445,7 @@ int main(int argc, char** argv) {
         for (;;) {  // nmatch == 0 (no limit): grow the per-query capacity until nothing is truncated
           job->need_out(n, cap);
           int rc;
-          { GpuSlot slot(gpu_mu, gpu_cv, gpu_busy); const uint64_t a = now_us(); fmx_stats fs; memset(&fs, 0, sizeof fs); rc = fmx_match_batch_lines(ix, &prm, job->text, job->n_bytes, n, job->out, job->cnt, job->tot, cap, timing ? &fs : nullptr); const uint64_t d = now_us() - a; us_gpu += d; n_retries += fs.n_retries; { uint64_t z = 0; t_gpu_first_end.compare_exchange_strong(z, a + d - t_tick); t_gpu_last_end.store(a + d - t_tick); } uint64_t mx = us_gpu_max.load(); while (d > mx && !us_gpu_max.compare_exchange_weak(mx, d)) {} }
+          { GpuSlot slot(gpu_mu, gpu_cv, gpu_busy); const uint64_t a = now_us(); fmx_stats fs; memset(&fs, 0, sizeof fs); rc = tokenised ? fmx_match_batch_lines(ix, &prm, job->text, job->n_bytes, n, job->out, job->cnt, job->tot, cap, timing ? &fs : nullptr) : fmx_match_batch_raw_lines(ix, &prm, job->text, job->n_bytes, n, job->out, job->cnt, job->tot, cap, timing ? &fs : nullptr); const uint64_t d = now_us() - a; us_gpu += d; n_retries += fs.n_retries; { uint64_t z = 0; t_gpu_first_end.compare_exchange_strong(z, a + d - t_tick); t_gpu_last_end.store(a + d - t_tick); } uint64_t mx = us_gpu_max.load(); while (d > mx && !us_gpu_max.compare_exchange_weak(mx, d)) {} }
           if (rc != FMX_OK) { fail(fmx_last_error()); return; }
           uint32_t mx = 0;
           for (size_t q = 0; q < n; q++) mx = job->tot[q] > mx ? job->tot[q] : mx;
