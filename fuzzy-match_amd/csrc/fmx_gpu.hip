@@ -147,6 +147,58 @@ struct DevBlob {
   ~DevBlob() { if (a) (void)hipFree(a); if (b) (void)hipFree(b); }
 };
 
+// The streams of a process, per device (round 5).  A hardware queue costs even when it idles: the GPU's scheduler time-slices
+// the queues of a process once more than about a dozen are in use or were in use a moment ago, and every kernel of every call then
+// runs 30-100 x slower (DESIGN.md section 5 "Stalls"; seen again in the test suite, where the contexts of indexes EARLIER tests had
+// left behind slowed a fresh index down thirty-fold).  Until round 4 every context of every index owned two compute streams and
+// every index a pair of copy streams, so the number of queues grew with the "contexts" option and with the number of indexes alive.
+// Now a context BORROWS its pair of compute streams (main lane: normal priority, side lane: high, see Ctx::init) for the length
+// of a call from this pool, and every index of a device uses the pool's one pair of copy streams: the queues of a process are
+// bounded by the calls that run at once — which admission control (Impl::max_host_active, "contexts") bounds — not by how many
+// contexts or indexes exist.  A pair goes back idle (its call was waited for) and is handed out again as it is.
+struct StreamPool {
+  std::mutex mu;
+  std::vector<std::pair<hipStream_t, hipStream_t>> idle;
+  hipStream_t h2d = nullptr, d2h = nullptr;
+  bool copy_tried = false;
+  std::pair<hipStream_t, hipStream_t> take() {
+    {
+      std::lock_guard<std::mutex> g(mu);
+      if (!idle.empty()) { auto p = idle.back(); idle.pop_back(); return p; }
+    }
+    int lo = 0, hi = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    static const bool classes = [] { const char* e = getenv("FMX_STREAM_CLASSES"); return e ? atoi(e) != 0 : true; }();
+    hipStream_t a = nullptr, b = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
+    if (classes) HIP_TRY(hipStreamCreateWithPriority(&b, hipStreamNonBlocking, hi));
+    else HIP_TRY(hipStreamCreateWithFlags(&b, hipStreamNonBlocking));
+    return {a, b};
+  }
+  void give(std::pair<hipStream_t, hipStream_t> p) {
+    std::lock_guard<std::mutex> g(mu);
+    idle.push_back(p);
+  }
+  // the device's pair of copy streams (low priority: a pool of hardware queues of its own); false: the caller makes its own
+  bool copy_pair(hipStream_t& out_h2d, hipStream_t& out_d2h) {
+    std::lock_guard<std::mutex> g(mu);
+    if (!copy_tried) {
+      copy_tried = true;
+      int lo = 0, hi = 0;
+      hipStream_t a = nullptr, b = nullptr;
+      if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hipStreamCreateWithPriority(&a, hipStreamNonBlocking, lo) == hipSuccess &&
+          hipStreamCreateWithPriority(&b, hipStreamNonBlocking, lo) == hipSuccess) { h2d = a; d2h = b; }
+      else { if (a) (void)hipStreamDestroy(a); (void)hipGetLastError(); }
+    }
+    out_h2d = h2d; out_d2h = d2h;
+    return h2d != nullptr;
+  }
+};
+static StreamPool& stream_pool(int device) {
+  static StreamPool* pools = new StreamPool[64];
+  return pools[(device >= 0 && device < 64) ? device : 0];
+}
+
 constexpr int kMaxPassesInFlight = 2;
 static const uint64_t kTurnMinQueries = [] { const char* e = getenv("FMX_TURN_MIN"); return e ? (uint64_t)atoll(e) : (uint64_t)262144; }();  // device-resident calls at least this large are chained on the GPU (Impl::turns), smaller ones overlap freely (design-time switch FMX_TURN_MIN)
 static const uint64_t kTurnMinQueriesHost = [] { const char* e = getenv("FMX_TURN_MIN_HOST"); return e ? (uint64_t)atoll(e) : (uint64_t)32768; }();  // host-buffer calls: chained from here on (their copies interleave badly when the kernels of
@@ -208,7 +260,8 @@ struct Ctx {
   unsigned long long* h_ctr_group = nullptr;  // pinned: one slot per pass of an asynchronous group
   std::vector<hipEvent_t> ev_pass;      // "pass done" events of an asynchronous group
   bool ok = false;
-  bool shared_copy = false;  // h2d / d2h belong to the index (one pair for every context), not to this context
+  bool shared_copy = false;  // h2d / d2h belong to the device's stream pool (one pair for every context of every index), not to this context
+  bool pooled = false;       // stream / side are borrowed from the device's stream pool for the length of a call (null in between)
   int  cu_group = -1;  // >= 0: the kernels of this context run on one half of the GPU's compute units (option "cu_split")
 
   // A stream whose kernels only run on half of the compute units: hipExtStreamCreateWithCUMask (bit i of the mask = compute
@@ -245,18 +298,20 @@ struct Ctx {
       HIP_TRY(hipStreamCreateWithPriority(&h2d, hipStreamNonBlocking, prio_low));
       HIP_TRY(hipStreamCreateWithPriority(&d2h, hipStreamNonBlocking, prio_low));
     } else {
-    HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    static const bool pool_streams = [] { const char* e = getenv("FMX_STREAM_POOL"); return e ? atoi(e) != 0 : true; }();  // design-time switch
+    pooled = pool_streams;  // the compute pair comes with the lease (Impl::acquire)
+    if (!pooled) HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     if (classes) {
       if (shared_h2d && shared_d2h) { h2d = shared_h2d; d2h = shared_d2h; shared_copy = true; }
       else {
         HIP_TRY(hipStreamCreateWithPriority(&h2d, hipStreamNonBlocking, prio_low));
         HIP_TRY(hipStreamCreateWithPriority(&d2h, hipStreamNonBlocking, prio_low));
       }
-      HIP_TRY(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, prio_high));
+      if (!pooled) HIP_TRY(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, prio_high));
     } else {
       HIP_TRY(hipStreamCreateWithFlags(&h2d, hipStreamNonBlocking));
       HIP_TRY(hipStreamCreateWithFlags(&d2h, hipStreamNonBlocking));
-      HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+      if (!pooled) HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
     }
     }
     for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
@@ -280,10 +335,10 @@ struct Ctx {
     heap.release(); f0.release(); f1.release(); vals.release(); zero_blk.release();
     items.release(); items_b.release(); items_h.release(); cmin_tab.release(); g_rows.release();
     d_qoff.release(); d_qtok.release(); d_qreal.release(); d_qitok.release(); d_text.release(); d_vstate.release(); d_text_r.release(); d_vstate_r.release(); d_islot.release(); d_iid.release(); d_scratch.release(); d_lflag.release(); d_cnt.release(); d_tot.release(); d_out.release(); d_prior.release();
-    if (stream) (void)hipStreamDestroy(stream);
+    if (stream && !pooled) (void)hipStreamDestroy(stream);
     if (h2d && !shared_copy) (void)hipStreamDestroy(h2d);
     if (d2h && !shared_copy) (void)hipStreamDestroy(d2h);
-    if (side) (void)hipStreamDestroy(side);
+    if (side && !pooled) (void)hipStreamDestroy(side);
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : ev_in) if (e) (void)hipEventDestroy(e);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
@@ -403,30 +458,41 @@ struct DeviceIndex::Impl {
     std::unique_lock<std::mutex> lk(pool_mu);
     for (;;) {
       const bool admitted = force || !host_kind || host_active < max_host_active;
-      if (admitted && !idle.empty()) { Ctx* c = idle.back(); idle.pop_back(); if (host_kind) host_active++; return c; }
+      if (admitted && !idle.empty()) {
+        Ctx* c = idle.back(); idle.pop_back();
+        if (host_kind) host_active++;
+        lk.unlock();
+        try { lend_streams(c); } catch (...) { lk.lock(); idle.push_back(c); if (host_kind) host_active--; pool_cv.notify_all(); throw; }
+        return c;
+      }
       if (admitted && (all.size() < max_ctx || force)) {
         if (host_kind) host_active++;
         all.emplace_back(new Ctx);
         Ctx* c = all.back().get();
         c->cu_group = (int)((all.size() - 1) % 2);
         static const bool share = [] { const char* e = getenv("FMX_SHARED_COPY"); return e ? atoi(e) != 0 : true; }();
-        if (share && !copy_h2d) {  // (under pool_mu: the first context of the index creates the pair)
-          int lo = 0, hi = 0;
-          hipStream_t a = nullptr, b2 = nullptr;
-          if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hipStreamCreateWithPriority(&a, hipStreamNonBlocking, lo) == hipSuccess &&
-              hipStreamCreateWithPriority(&b2, hipStreamNonBlocking, lo) == hipSuccess) { copy_h2d = a; copy_d2h = b2; }
-          else { if (a) (void)hipStreamDestroy(a); (void)hipGetLastError(); }  // contexts fall back to a pair of their own
-        }
+        // one pair of copy streams per DEVICE (round 4: per index), from the device's stream pool; contexts fall back to a pair of their own
+        if (share && !copy_h2d) (void)stream_pool(device).copy_pair(copy_h2d, copy_d2h);
         const hipStream_t sh = copy_h2d, sd = copy_d2h;
         lk.unlock();
-        try { c->init(sh, sd); } catch (...) { lk.lock(); idle.push_back(c); if (host_kind) host_active--; pool_cv.notify_all(); throw; }
+        try { c->init(sh, sd); lend_streams(c); } catch (...) { lk.lock(); idle.push_back(c); if (host_kind) host_active--; pool_cv.notify_all(); throw; }
         return c;
       }
       if (!wait) return nullptr;
       pool_cv.wait(lk);
     }
   }
+  // the compute streams of a call: borrowed from the device's pool with the context, given back with it
+  void lend_streams(Ctx* c) {
+    if (!c->pooled || c->stream) return;
+    const auto p = stream_pool(device).take();
+    c->stream = p.first; c->side = p.second;
+  }
   void release(Ctx* c, bool host_kind = false) {
+    if (c->pooled && c->stream) {  // (the call was waited for — or ~HostCall / ~Pending waited for what was left of it: the pair is idle)
+      stream_pool(device).give({c->stream, c->side});
+      c->stream = nullptr; c->side = nullptr;
+    }
     bool quiet;
     {
       std::lock_guard<std::mutex> lk(pool_mu);
@@ -546,9 +612,7 @@ DeviceIndex::~DeviceIndex() {
     for (uint32_t* wp : m.word_pool) (void)hipFree(wp);
     m.word_pool.clear();
     m.itok_hold.reset(); m.vocab_hold.reset();
-    if (m.copy_h2d) (void)hipStreamDestroy(m.copy_h2d);
-    if (m.copy_d2h) (void)hipStreamDestroy(m.copy_d2h);
-    m.copy_h2d = m.copy_d2h = nullptr;
+    m.copy_h2d = m.copy_d2h = nullptr;  // (they belong to the device's stream pool)
   }
   delete impl_;
 }

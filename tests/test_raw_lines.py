@@ -167,7 +167,8 @@ def test_raw_lines_on_an_id_index_equal_line_batches(fmx, gpu_device):
     ix.add_ids(c_off, c_tok, vs)
     ix.sort(gpu_device)
     ix.finalize()
-    words = [b"", b""] + [b"w" + bytes([97 + (k % 26), 97 + ((k // 26) % 26), 97 + ((k // 676) % 26)]) for k in range(2, vs)]
+    assert vs < 26 ** 4
+    words = [b"", b""] + [b"w" + bytes([97 + (k % 26), 97 + ((k // 26) % 26), 97 + ((k // 676) % 26), 97 + ((k // 17576) % 26)]) for k in range(2, vs)]
     offs = np.full(len(words), 0xffffffffffffffff, np.uint64)
     pos = 0
     for k in range(2, len(words)):
