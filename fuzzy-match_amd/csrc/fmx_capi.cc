@@ -10,11 +10,15 @@
 #include <chrono>
 #include <condition_variable>
 #include <deque>
+#include <algorithm>
 #include <exception>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
+#include <tuple>
+#include <unordered_map>
 #include <vector>
 
 #include "fmx_gpu.hh"
@@ -985,6 +989,18 @@ fmx_text* fmx_text_tokenize(int32_t pt, const char* sentence, size_t len) {
     return nullptr;
   }
 }
+// the general tokenizer alone, without the fast path ASCII sentences take (tests compare the two)
+fmx_text* fmx_text_tokenize_general(int32_t pt, const char* sentence, size_t len) {
+  try {
+    std::unique_ptr<fmx_text> h(new fmx_text);
+    h->pt = pt;
+    tokenize_and_normalize_general(pt, sentence ? std::string(sentence, len) : std::string(), h->t);
+    return h.release();
+  } catch (...) {
+    g_err = "out of host memory";
+    return nullptr;
+  }
+}
 void        fmx_text_free(fmx_text* h) { delete h; }
 uint32_t    fmx_text_num_tokens(const fmx_text* h) { return h ? (uint32_t)h->t.norm.size() : 0u; }
 const char* fmx_text_norm(const fmx_text* h, uint32_t i) { return h && i < h->t.norm.size() ? h->t.norm[i].c_str() : ""; }
@@ -1030,6 +1046,160 @@ int64_t fmx_index_add_text(fmx_index* ix, const char* id, const char* sentence, 
     return (int)FMX_OK;
   });
   return rc == FMX_OK ? r : rc;
+}
+
+// FuzzyMatch::add_tm(id, sentence) (src/fuzzy_match.cc:213-224) for n sentences — the reference CLI's import loop is this call per
+// line (cli/src/FuzzyMatch-cli.cc:32-79) — on every usable CPU, leaving the index byte for byte as n calls of fmx_index_add_text
+// do.  Three phases per chunk of lines:
+//   1. (parallel) _tokenize_and_normalize into packed storage per thread; every token is looked up in the vocabulary as it stands
+//      (read-only here); a word it does not hold is noted with its first occurrence (line, position);
+//   2. (one thread) the new words of all threads in the order of their first occurrence get their ids — the order
+//      VocabIndexer::addWord (src/vocab_indexer.cc:37-50) would have met them in;
+//   3. (parallel) the remaining tokens are resolved, and buffer, suffix enumeration, sentence frequencies (once per distinct
+//      word of a sentence, src/vocab_indexer.cc:73-90), ids and real tokens are filled at offsets known from a prefix sum.
+int64_t fmx_index_add_text_bulk(fmx_index* ix, const char* const* ids, const char* const* sentences, const size_t* lens, uint64_t n,
+                                int64_t* sids_out) {
+  if (!ix || (n && (!sentences || !lens))) return fail(FMX_E_INVALID, "null argument");
+  if (ix->finalized) return fail(FMX_E_STATE, "index is finalized");
+  int64_t added = 0;
+  int rc = guarded([&]() {
+    HostIndex& H = ix->host;
+    if (!(!H.ids.empty() || H.sent_pos.empty())) throw std::runtime_error("cannot mix id-only and string-level sentences in one index");
+    const int pt = H.pt;
+    constexpr uint64_t kChunk = 1u << 18;  // lines per round of the three phases
+    struct Line { uint64_t norm_at; uint32_t n_tok; uint64_t real_at, real_len; uint32_t itok_at, n_itok; bool take; };
+    struct alignas(128) Part {  // what one thread made of its lines (a cache line of its own: the threads append side by side)
+      std::string norm, real;
+      std::vector<std::pair<uint64_t, std::string>> itoks;
+      std::vector<uint32_t> wid;                       // per token: vocabulary id, or kUnset
+      std::vector<Line> line;
+      std::unordered_map<std::string, std::pair<uint64_t, uint32_t>> fresh;  // new word -> first occurrence (line, position)
+      std::vector<uint32_t> freq;
+    };
+    constexpr uint32_t kUnset = 0xffffffffu;
+    for (uint64_t c0 = 0; c0 < n; c0 += kChunk) {
+      const uint64_t c1 = std::min(n, c0 + kChunk), m = c1 - c0;
+      const uint64_t nt = std::max<uint64_t>(1, std::min<uint64_t>(usable_cpus(), m / 1024 + 1));
+      std::vector<Part> parts(nt);
+      auto range = [&](uint64_t t) { return std::make_pair(m * t / nt, m * (t + 1) / nt); };
+      auto run = [&](const std::function<void(uint64_t)>& fn) {
+        std::vector<std::thread> th;
+        for (uint64_t t = 1; t < nt; t++) th.emplace_back(fn, t);
+        fn(0);
+        for (auto& t : th) t.join();
+      };
+      static const bool timing = getenv("FMX_BULK_TIMING") != nullptr;  // design-time
+      auto now = [] { return std::chrono::steady_clock::now(); };
+      auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+      const auto tp0 = now();
+      // ---- 1 ----
+      run([&](uint64_t t) {
+        Part& P = parts[t];
+        const auto r = range(t);
+        P.line.reserve(r.second - r.first);
+        std::vector<std::pair<uint64_t, std::string>> it;
+        std::string key;
+        for (uint64_t i = r.first; i < r.second; i++) {
+          const char* sp = sentences[c0 + i];
+          Line L{};
+          L.norm_at = P.norm.size(); L.real_at = P.real.size(); L.itok_at = (uint32_t)P.itoks.size();
+          tokenize_and_normalize_packed(pt, sp ? sp : "", sp ? lens[c0 + i] : 0, P.norm, L.n_tok, P.real, it);
+          L.real_len = P.real.size() - L.real_at;
+          L.n_itok = (uint32_t)it.size();
+          for (auto& kv : it) P.itoks.emplace_back(kv.first, std::move(kv.second));
+          // FuzzyMatch::add_tm: an empty segment is not indexed (src/fuzzy_match.cc:218-221); SuffixArrayIndex::add_tm: nor is one
+          // whose real sentence is empty or that is longer than the longest pattern (src/suffix_array_index.cc:16)
+          L.take = L.n_tok != 0 && L.real_len != 0 && L.n_tok <= H.max_tokens && L.n_tok <= 65535;
+          const char* w = P.norm.data() + L.norm_at;
+          for (uint32_t k = 0; k < L.n_tok; k++) {
+            const size_t wl = strlen(w);
+            uint32_t id = kUnset;
+            if (L.take) {
+              key.assign(w, wl);
+              auto f = H.form2index.find(key);
+              if (f != H.form2index.end()) id = f->second;
+              else if (P.fresh.find(key) == P.fresh.end()) P.fresh.emplace(key, std::make_pair(i, k));  // (the first occurrence inside this thread's lines; find first: emplace builds a node even when the key is there)
+            }
+            P.wid.push_back(id);
+            w += wl + 1;
+          }
+          P.line.push_back(L);
+        }
+      });
+      const auto tp1 = now();
+      // ---- 2 ----
+      {
+        std::vector<std::tuple<uint64_t, uint32_t, const std::string*>> order;
+        for (auto& P : parts) for (auto& kv : P.fresh) order.emplace_back(kv.second.first, kv.second.second, &kv.first);
+        std::sort(order.begin(), order.end(), [](const auto& x, const auto& y) { return std::get<0>(x) != std::get<0>(y) ? std::get<0>(x) < std::get<0>(y) : std::get<1>(x) < std::get<1>(y); });
+        for (auto& o : order) H.add_word(*std::get<2>(o));  // (a word several threads met: the earliest occurrence adds it, the others find it)
+      }
+      // where every thread's sentences and tokens go
+      std::vector<uint64_t> s_base(nt + 1, 0), t_base(nt + 1, 0);
+      for (uint64_t t = 0; t < nt; t++) {
+        uint64_t ns = 0, ntk = 0;
+        for (const Line& L : parts[t].line) if (L.take) { ns++; ntk += L.n_tok; }
+        s_base[t + 1] = s_base[t] + ns; t_base[t + 1] = t_base[t] + ntk;
+      }
+      const uint64_t sent0 = H.sent_pos.size(), buf0 = H.buf.size(), suf0 = H.suf_sid.size();
+      if (sent0 + s_base[nt] > 0xffffffffull || buf0 + t_base[nt] + 2 * s_base[nt] > 0xffffffffull)
+        throw std::runtime_error("more than 2^32 - 1 sentences or buffer words");
+      H.sent_pos.resize(sent0 + s_base[nt]);
+      H.buf.resize(buf0 + t_base[nt] + 2 * s_base[nt]);
+      H.suf_sid.resize(suf0 + t_base[nt]);
+      H.suf_pos.resize(suf0 + t_base[nt]);
+      H.ids.resize(sent0 + s_base[nt]);
+      H.real.resize(sent0 + s_base[nt]);
+      const uint32_t vsz = H.vocab_size;
+      const auto tp2 = now();
+      // ---- 3 ----
+      run([&](uint64_t t) {
+        Part& P = parts[t];
+        const auto r = range(t);
+        P.freq.assign(vsz, 0);
+        std::vector<uint32_t> stamp(vsz, 0);
+        uint32_t mark = 0;
+        uint64_t sidx = sent0 + s_base[t], bp = buf0 + t_base[t] + 2 * s_base[t], sp = suf0 + t_base[t], tok_at = 0;
+        std::string key;
+        for (uint64_t i = r.first; i < r.second; i++) {
+          const Line& L = P.line[i - r.first];
+          if (!L.take) { if (sids_out) sids_out[c0 + i] = FMX_TM_SKIPPED; tok_at += L.n_tok; continue; }
+          if (++mark == 0) { std::fill(stamp.begin(), stamp.end(), 0u); mark = 1; }
+          H.sent_pos[sidx] = (uint32_t)bp;
+          H.buf[bp++] = L.n_tok;
+          const char* w = P.norm.data() + L.norm_at;
+          for (uint32_t k = 0; k < L.n_tok; k++) {
+            const size_t wl = strlen(w);
+            uint32_t id = P.wid[tok_at + k];
+            if (id == kUnset) { key.assign(w, wl); id = H.form2index.find(key)->second; }
+            H.buf[bp++] = id;
+            H.suf_sid[sp] = (uint32_t)sidx;
+            H.suf_pos[sp] = (uint16_t)(k + 1);
+            sp++;
+            if (stamp[id] != mark) { stamp[id] = mark; P.freq[id]++; }
+            w += wl + 1;
+          }
+          H.buf[bp++] = 0;  // VocabIndexer::SENTENCE_SEPARATOR
+          H.ids[sidx] = ids && ids[c0 + i] ? ids[c0 + i] : "";
+          RealTok& R = H.real[sidx];
+          R.tokstring.assign(P.real.data() + L.real_at, L.real_len);
+          R.itoks.clear();
+          for (uint32_t k = 0; k < L.n_itok; k++) R.itoks.emplace_back(P.itoks[L.itok_at + k].first, P.itoks[L.itok_at + k].second);
+          if (sids_out) sids_out[c0 + i] = (int64_t)sidx;
+          sidx++;
+          tok_at += L.n_tok;
+        }
+      });
+      for (uint64_t t = 0; t < nt; t++)
+        for (uint32_t w = 0; w < vsz; w++) H.sfreq[w] += parts[t].freq[w];
+      if (s_base[nt]) H.sorted = false;
+      added += (int64_t)s_base[nt];
+      if (timing) fprintf(stderr, "[fmx] add_text_bulk: %llu lines on %llu threads: tokenise + look up %.1f ms, new words + resize %.1f ms, fill %.1f ms\n",
+                          (unsigned long long)m, (unsigned long long)nt, ms(tp0, tp1), ms(tp1, tp2), ms(tp2, now()));
+    }
+    return (int)FMX_OK;
+  });
+  return rc == FMX_OK ? added : rc;
 }
 
 int fmx_index_reopen(fmx_index* ix) {

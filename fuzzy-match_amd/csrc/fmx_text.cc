@@ -472,8 +472,123 @@ void tokenize_aggressive(int pt, const std::string& text, std::vector<std::strin
   }
 }
 
+// The same function for a sentence of ASCII bytes under penalty tokens that emit no joiner / spacer tokens (round 5: the ingestion
+// path, fmx_index_add_text_bulk, spent most of its time building a std::string per character).  On ASCII the tokenizer above is a
+// byte-class machine — ASCII is NFC, every letter is Latin and cased by one bit, there are no placeholders and no combining marks:
+// a run of letters / of digits is a token, any other printable byte a token of its own, white space separates, bytes below 33 that
+// are not white space are dropped without ending a token — and _tokenize_and_normalize keeps a word's case feature as its real
+// token (cas), turns a number into the placeholder (nbr) and punctuation into a penalty string (pct).  Same output as the general
+// path: tests/test_text_frontend.py::test_ascii_fast_path_equals_the_general_tokenizer.
+void tokenize_and_normalize_general(int pt, const std::string& sentence, TextTokens& out);
+
+// the machine: emit(token — lower-cased when it is a word under cas —, class: 0 other / 1 letters / 2 digits, case feature)
+template <class Emit>
+static bool ascii_machine(int pt, const unsigned char* p, size_t n, Emit&& emit) {
+  if (pt & (kPtJnr | kPtSep)) return false;
+  for (size_t k = 0; k < n; k++) if (p[k] >= 0x80) return false;
+  const bool cas = (pt & kPtCas) != 0;
+  enum { kNone = 0, kLetter = 1, kDigit = 2 };
+  int cur = kNone;
+  std::string tok;
+  auto flush = [&]() {
+    if (tok.empty()) { cur = kNone; return; }
+    char f = 'N';
+    if (cas && cur == kLetter) {  // onmt::CaseModifier: lower case + case feature
+      size_t n_up = 0;
+      const bool first_up = tok[0] >= 'A' && tok[0] <= 'Z';
+      for (char& ch : tok) if (ch >= 'A' && ch <= 'Z') { ch = (char)(ch | 0x20); n_up++; }
+      f = n_up == 0 ? 'L' : ((first_up && n_up == 1) ? 'C' : ((n_up == tok.size() && tok.size() >= 2) ? 'U' : 'M'));
+    }
+    emit(tok, cur, f);
+    tok.clear();
+    cur = kNone;
+  };
+  for (size_t k = 0; k < n; k++) {
+    const unsigned char c = p[k];
+    const unsigned char l = c | 0x20;
+    if (l >= 'a' && l <= 'z') { if (cur != kLetter) { flush(); cur = kLetter; } tok += (char)c; }
+    else if (c >= '0' && c <= '9') { if (cur != kDigit) { flush(); cur = kDigit; } tok += (char)c; }
+    else if (c == ' ' || (c >= 9 && c <= 13)) flush();
+    else if (c > 32) { flush(); tok += (char)c; cur = kNone; flush(); }
+    // (other bytes below 33: dropped, the token at hand goes on)
+  }
+  flush();
+  return true;
+}
+
+static const std::string& num_placeholder() {
+  static const std::string k = std::string(kPhOpen) + "num" + kPhClose;
+  return k;
+}
+
+static bool tokenize_and_normalize_ascii(int pt, const std::string& sentence, TextTokens& out) {
+  const bool cas = (pt & kPtCas) != 0, nbr = (pt & kPtNbr) != 0, pct = (pt & kPtPct) != 0;
+  out.map_tokens.push_back(0);
+  return ascii_machine(pt, (const unsigned char*)sentence.data(), sentence.size(), [&](const std::string& tok, int cls, char f) {
+    const size_t i = out.raw.size();
+    out.raw.push_back(tok);
+    out.feat.push_back(std::string(1, f));
+    const uint64_t real_i = out.norm.size();
+    auto push = [&](const std::string& norm, const std::string& real) {
+      out.norm.push_back(norm); out.real.push_back(real); out.map_tokens.push_back((uint32_t)i + 1);
+    };
+    if (cas && f != 'N') push(tok, std::string(1, f));
+    else if (cls == 2) { if (nbr) push(num_placeholder(), tok); else push(tok, tok); }
+    else if (cls == 0 && pct) {  // punctuation: a penalty string in front of the next real token (appended to one already there)
+      if (!out.itoks.empty() && out.itoks.back().first == real_i) out.itoks.back().second += tok;
+      else out.itoks.emplace_back(real_i, tok);
+    } else push(tok, tok);
+  });
+}
+
+// The same into packed storage (the bulk ingestion path: no string per token): the normalised tokens NUL-terminated behind one
+// another appended to `norm`, the real tokens tab-joined appended to `real` — what Sentence::_tokstring holds (include/fuzzy/sentence.hh).
+bool tokenize_and_normalize_packed(int pt, const char* sentence, size_t len, std::string& norm, uint32_t& n_tok, std::string& real,
+                                   std::vector<std::pair<uint64_t, std::string>>& itoks) {
+  const bool cas = (pt & kPtCas) != 0, nbr = (pt & kPtNbr) != 0, pct = (pt & kPtPct) != 0;
+  const size_t norm0 = norm.size(), real0 = real.size();
+  n_tok = 0;
+  itoks.clear();
+  auto push = [&](const std::string& nm, const char* r, size_t rl) {
+    norm.append(nm); norm.push_back('\0');
+    if (n_tok) real.push_back('\t');
+    real.append(r, rl);
+    n_tok++;
+  };
+  const bool ok = ascii_machine(pt, (const unsigned char*)sentence, len, [&](const std::string& tok, int cls, char f) {
+    if (cas && f != 'N') push(tok, &f, 1);
+    else if (cls == 2) { if (nbr) push(num_placeholder(), tok.data(), tok.size()); else push(tok, tok.data(), tok.size()); }
+    else if (cls == 0 && pct) {
+      if (!itoks.empty() && itoks.back().first == n_tok) itoks.back().second += tok;
+      else itoks.emplace_back((uint64_t)n_tok, tok);
+    } else push(tok, tok.data(), tok.size());
+  });
+  if (ok) return true;
+  norm.resize(norm0); real.resize(real0);
+  TextTokens t;
+  tokenize_and_normalize_general(pt, std::string(sentence, len), t);
+  n_tok = (uint32_t)t.norm.size();
+  for (size_t k = 0; k < t.norm.size(); k++) {
+    norm.append(t.norm[k]); norm.push_back('\0');
+    if (k) real.push_back('\t');
+    real.append(t.real[k]);
+  }
+  itoks = std::move(t.itoks);
+  return true;
+}
+
+// the general path alone (tests compare the ASCII fast path with it)
+void tokenize_and_normalize_general(int pt, const std::string& sentence, TextTokens& out);
+
 // src/fuzzy_match.cc:108-193
 void tokenize_and_normalize(int pt, const std::string& sentence, TextTokens& out) {
+  out = TextTokens();
+  if (tokenize_and_normalize_ascii(pt, sentence, out)) return;
+  out = TextTokens();
+  tokenize_and_normalize_general(pt, sentence, out);
+}
+
+void tokenize_and_normalize_general(int pt, const std::string& sentence, TextTokens& out) {
   out = TextTokens();
   tokenize_aggressive(pt, nfc_normalize(sentence), out.raw, out.feat);  // src/fuzzy_match.cc:115-116
   out.map_tokens.push_back(0);

@@ -36,6 +36,12 @@ struct TextTokens {
 void tokenize_aggressive(int pt, const std::string& text, std::vector<std::string>& tokens, std::vector<std::string>& feats);
 // FuzzyMatch::_tokenize_and_normalize
 void tokenize_and_normalize(int pt, const std::string& sentence, TextTokens& out);
+// ... into packed storage (bulk ingestion): normalised tokens NUL-terminated appended to `norm`, the real tokens tab-joined appended
+// to `real` (Sentence::_tokstring), the penalty strings by real-token index
+bool tokenize_and_normalize_packed(int pt, const char* sentence, size_t len, std::string& norm, uint32_t& n_tok, std::string& real,
+                                   std::vector<std::pair<uint64_t, std::string>>& itoks);
+// ... without the fast path for ASCII sentences (what the tests compare that path with)
+void tokenize_and_normalize_general(int pt, const std::string& sentence, TextTokens& out);
 // onmt::Tokenizer::detokenize(tokens, features) for the same configuration (subsequence() appends it to Match::id)
 std::string detokenize(int pt, const std::vector<std::string>& tokens, const std::vector<std::string>& feats);
 

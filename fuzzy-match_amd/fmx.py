@@ -87,7 +87,7 @@ EXPORTS = [
     "fmx_subsequence_batch", "fmx_text_tokenize", "fmx_text_free", "fmx_text_num_tokens", "fmx_text_norm", "fmx_text_real",
     "fmx_text_num_itoks", "fmx_text_itok_index", "fmx_text_itok", "fmx_text_num_raw", "fmx_text_raw", "fmx_text_map",
     "fmx_text_detokenize", "fmx_index_add_text", "fmx_index_device_array", "fmx_index_from_arrays", "fmx_text_feature",
-    "fmx_match_one_prior", "fmx_match_one_prior_ids", "fmx_match_batch_raw_lines", "fmx_match_batch_device_begin", "fmx_match_batch_device_end", "fmx_vocab_lookup_mt", "fmx_index_set_forms",
+    "fmx_match_one_prior", "fmx_match_one_prior_ids", "fmx_match_batch_raw_lines", "fmx_text_tokenize_general", "fmx_index_add_text_bulk", "fmx_match_batch_device_begin", "fmx_match_batch_device_end", "fmx_vocab_lookup_mt", "fmx_index_set_forms",
 ]
 TM_SKIPPED = -100
 
@@ -250,12 +250,14 @@ def pinned_free(arr):
     _pinned_blocks.pop(arr.ctypes.data, None)
 
 
-def tokenize(pt, sentence):
-    """FuzzyMatch::_tokenize_and_normalize through the restricted text front-end (fmx_text_tokenize).
-    Returns dict(norm, real, itoks {index: str}, raw, map)."""
+def tokenize(pt, sentence, general=False):
+    """FuzzyMatch::_tokenize_and_normalize through the restricted text front-end (fmx_text_tokenize; general: without the fast path
+    ASCII sentences take).  Returns dict(norm, real, itoks {index: str}, raw, map)."""
     L = lib()
     b = sentence.encode("utf-8")
-    h = L.fmx_text_tokenize(pt, b, len(b))
+    L.fmx_text_tokenize_general.restype = C.c_void_p
+    L.fmx_text_tokenize_general.argtypes = [C.c_int32, C.c_char_p, C.c_size_t]
+    h = L.fmx_text_tokenize_general(pt, b, len(b)) if general else L.fmx_text_tokenize(pt, b, len(b))
     if not h:
         raise MemoryError("fmx_text_tokenize failed")
     try:
@@ -356,6 +358,22 @@ class Index:
         if r < 0:
             _check(int(r))
         return int(r)
+
+    def add_text_bulk(self, sids, sentences):
+        """fmx_index_add_text_bulk: n sentences (str) with their ids (str); returns the sentence id per line (-1 = not indexed)."""
+        n = len(sentences)
+        bs = [s.encode("utf-8") for s in sentences]
+        ids = (C.c_char_p * max(n, 1))(*[s.encode("utf-8") for s in sids])
+        ptr = (C.c_char_p * max(n, 1))(*bs)
+        lens = (C.c_size_t * max(n, 1))(*[len(b) for b in bs])
+        out = (C.c_int64 * max(n, 1))()
+        L = lib()
+        L.fmx_index_add_text_bulk.restype = C.c_int64
+        L.fmx_index_add_text_bulk.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+        r = L.fmx_index_add_text_bulk(self.h, ids, ptr, lens, n, out)
+        if r < 0:
+            _check(int(r))
+        return [(-1 if out[i] == TM_SKIPPED else int(out[i])) for i in range(n)]
 
     def add_ids(self, off, toks, vocab_size):
         off = np.ascontiguousarray(off, dtype=np.uint32)

@@ -361,6 +361,8 @@ int fmx_subsequence_batch(fmx_index*, const fmx_batch* host_batch, uint32_t numb
  * run time (without one: a warning on stderr once, and the input is taken as NFC).  The handle owns every string it returns. */
 typedef struct fmx_text fmx_text;
 fmx_text*   fmx_text_tokenize(int32_t pt, const char* sentence, size_t len);
+/* the general tokenizer alone: ASCII sentences otherwise take a byte-class fast path with the same output (tests compare the two) */
+fmx_text*   fmx_text_tokenize_general(int32_t pt, const char* sentence, size_t len);
 void        fmx_text_free(fmx_text*);
 uint32_t    fmx_text_num_tokens(const fmx_text*);               /* normalised tokens */
 const char* fmx_text_norm(const fmx_text*, uint32_t i);
@@ -377,6 +379,12 @@ const char* fmx_text_detokenize(fmx_text*, uint32_t from, uint32_t to);
 /* FuzzyMatch::add_tm(id, sentence) — src/fuzzy_match.cc:213-224: FMX_TM_SKIPPED for an empty segment (the reference
  * warns on stderr and returns false) */
 int64_t fmx_index_add_text(fmx_index*, const char* id, const char* sentence, size_t len);
+/* n sentences at once — FuzzyMatch::add_tm(id, sentence) per line like the reference CLI's import loop
+ * (cli/src/FuzzyMatch-cli.cc:32-79): tokenised on every usable CPU, then added in order by one thread (vocabulary ids and sentence
+ * ids as n calls of fmx_index_add_text leave them).  ids (optional, as a whole or per entry) NUL-terminated; sids_out (optional):
+ * the sentence id of each line or FMX_TM_SKIPPED.  Returns the number of sentences added, or a negative status. */
+int64_t fmx_index_add_text_bulk(fmx_index*, const char* const* ids, const char* const* sentences, const size_t* lens, uint64_t n,
+                                int64_t* sids_out);
 
 /* tuning knobs (all have sane defaults):
  *   "contexts"          concurrent calls served at once per device, each with its own workspace (default 2)

@@ -107,6 +107,45 @@ def test_tokenizer_modes(fmx):
     assert fmx.detokenize_span(PT["cas"] | PT["nbr"], "Hello World , this is IT .", 1, 5) == "World , this is"
 
 
+def test_ascii_fast_path_equals_the_general_tokenizer(fmx):
+    """ASCII sentences take a byte-class fast path (fmx_text.cc: tokenize_and_normalize_ascii; round 5, for the ingestion rate);
+    the general tokenizer — the one the reference's fixtures pin — gives the same tokens, features, real tokens, penalty strings
+    and token map on them, under every penalty-token set without joiner / spacer tokens."""
+    rng = np.random.default_rng(23)
+    alphabet = "abcXYZ019 .,;'\"()-%/\t\x01\x7f&"
+    lines = ["".join(alphabet[int(k)] for k in rng.integers(0, len(alphabet), size=int(rng.integers(0, 40)))) for _ in range(3000)]
+    lines += tm1_lines() + [c["text"] for c in read_cases("test-tm1")] + ["Mr. O'Neil paid 4.40 EUR", "", " ", "a1b2", "AB Ab aB A", "x\x00y"]
+    en, _ = tm2_lines()
+    lines += [ln for ln in en[:3000] if all(ord(ch) < 128 for ch in ln)]
+    n = 0
+    for pt in (0, PT["nbr"], PT["cas"], PT["tag"] | PT["nbr"] | PT["cas"], PT["pct"] | PT["nbr"] | PT["cas"], PT["pct"]):
+        for ln in lines:
+            a, b = fmx.tokenize(pt, ln), fmx.tokenize(pt, ln, general=True)
+            assert a == b, (pt, ln, a, b)
+            n += len(a["norm"])
+    assert n > 200_000
+
+
+def test_bulk_text_ingestion_equals_line_by_line(fmx, tmp_path):
+    """fmx_index_add_text_bulk (sentences tokenised on every usable CPU, added in order) leaves the index — vocabulary ids, sentence
+    frequencies, buffer, ids, real tokens — as fmx_index_add_text per line does: the two .fmi files are byte-identical."""
+    en, fr = tm2_lines()
+    lines = en[:6000] + ["", "   ", "Résumé 2024 ｟it＃1｠ of the Commission"] + tm1_lines()
+    sids = [f"{i + 1}={(fr[i] if i < 6000 else '')}" for i in range(len(lines))]
+    pt = PT["tag"] | PT["nbr"] | PT["cas"]
+    a = fmx.Index.create(pt=pt)
+    got_a = [a.add_text(s, ln) for s, ln in zip(sids, lines)]
+    b = fmx.Index.create(pt=pt)
+    got_b = b.add_text_bulk(sids, lines)
+    assert got_a == got_b and sum(1 for x in got_a if x < 0) == 2
+    for ix in (a, b):
+        ix.sort(-1)          # host sort (no device here)
+    pa, pb = str(tmp_path / "a.fmi"), str(tmp_path / "b.fmi")
+    a.save(pa)
+    b.save(pb)
+    assert open(pa, "rb").read() == open(pb, "rb").read()
+
+
 @pytest.mark.parametrize("name,pt,fixture", [
     ("serialize", PT["tag"] | PT["nbr"] | PT["cas"], "test-tm1"),
     ("pct", PT["pct"] | PT["nbr"] | PT["cas"], "test-tm1-pct"),

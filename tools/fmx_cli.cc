@@ -225,10 +225,28 @@ int main(int argc, char** argv) {
     }
     std::string line, tgt;
     size_t count = 0;
+    // raw text: lines are handed to the library a block at a time (fmx_index_add_text_bulk: _tokenize_and_normalize on every usable
+    // CPU, sentences added in order) instead of one call per line on this thread
+    std::vector<std::string> b_ids, b_lines;
+    auto flush_block = [&]() -> bool {
+      if (b_lines.empty()) return true;
+      std::vector<const char*> pi(b_lines.size()), pl(b_lines.size());
+      std::vector<size_t> ll(b_lines.size());
+      std::vector<int64_t> sids(b_lines.size());
+      for (size_t k = 0; k < b_lines.size(); k++) { pi[k] = b_ids[k].c_str(); pl[k] = b_lines[k].data(); ll[k] = b_lines[k].size(); }
+      if (fmx_index_add_text_bulk(ix, pi.data(), pl.data(), ll.data(), b_lines.size(), sids.data()) < 0) {
+        std::cerr << "ERROR: " << fmx_last_error() << std::endl;
+        return false;
+      }
+      for (size_t k = 0; k < b_lines.size(); k++)
+        if (sids[k] == FMX_TM_SKIPPED) std::cerr << "WARNING: cannot index empty segment: " << b_lines[k] << " (" << b_ids[k] << ")" << std::endl;
+      b_ids.clear(); b_lines.clear();
+      return true;
+    };
     while (in.getline(line)) {
       ++count;
       std::string id = std::to_string(count);
-      int64_t sid;
+      int64_t sid = 0;
       if (tokenised) {
         const size_t tab = line.find('\t');
         if (tab != std::string::npos) { id = line.substr(0, tab); line = line.substr(tab + 1); }
@@ -246,14 +264,16 @@ int main(int argc, char** argv) {
         }
         if (add_target) id += "=" + tgt;
         if (add_target_no_index) id = tgt;
-        sid = fmx_index_add_text(ix, id.c_str(), line.data(), line.size());
-        if (sid == FMX_TM_SKIPPED) std::cerr << "WARNING: cannot index empty segment: " << line << " (" << id << ")" << std::endl;
+        b_ids.push_back(std::move(id));
+        b_lines.push_back(line);
+        if (b_lines.size() >= (1u << 18) && !flush_block()) return 1;
       }
       if (sid < 0 && sid != FMX_TM_SKIPPED) {
         std::cerr << "ERROR: " << fmx_last_error() << std::endl;
         return 1;
       }
     }
+    if (!flush_block()) return 1;
     tick("Sorting Index");
     if (fmx_index_sort(ix, device, 0) != FMX_OK) { std::cerr << "ERROR: " << fmx_last_error() << std::endl; return 1; }
     if (action == "index") {
