@@ -1244,7 +1244,11 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
           // unit costs: bit-parallel Levenshtein distance, then the float sum the DP would have produced
           // few registers: eight waves per SIMD hide the dependent loads in front of every candidate
           if (two) hipLaunchKernelGGL((k_dp_reg<64, false, true>), dim3(grid), dim3(kWave), 0, side, E.d, b, w, prm);
-          hipLaunchKernelGGL((k_dp_reg<32, false, true>), dim3(grid), dim3(kWave), 0, stream, E.d, b, w, prm);
+          // the 32-token class: match masks from a per-wave LDS table of the queries' patterns (k_dp_tab, round 5) instead of
+          // two compare instructions per pattern token and row (design-time switch FMX_DP_TAB=0: the register kernel)
+          static const bool dp_tab = [] { const char* e = getenv("FMX_DP_TAB"); return e ? atoi(e) != 0 : true; }();
+          if (dp_tab) hipLaunchKernelGGL(k_dp_tab, dim3(grid), dim3(kWave), 0, stream, E.d, b, w, prm);
+          else hipLaunchKernelGGL((k_dp_reg<32, false, true>), dim3(grid), dim3(kWave), 0, stream, E.d, b, w, prm);
         } else {
           if (two) hipLaunchKernelGGL((k_dp_reg<64, false>), dim3(grid), dim3(kWave), 0, side, E.d, b, w, prm);
           hipLaunchKernelGGL((k_dp_reg<32, false>), dim3(grid), dim3(kWave), 0, stream, E.d, b, w, prm);

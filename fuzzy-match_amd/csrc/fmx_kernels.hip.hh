@@ -2508,6 +2508,127 @@ __global__ void __launch_bounds__(kWave, (UNIT && P == 32) ? FMX_DPREG_WAVES : 1
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_dp_tab (round 5) — the unit-cost edit distances of the 32-token class with the match masks LOOKED UP instead of compared.
+// k_dp_reg<32, false, true> spends three quarters of its instructions forming, for every row (sentence token), the mask of the
+// pattern positions that hold the same word — two VALU instructions per pattern token.  The pattern is the QUERY's: the
+// candidates of one query follow one another in the dense list, so the lanes of a wave belong to a handful of queries (runs of
+// equal q).  Each run gets a 64-slot hash table in LDS (token -> mask of its positions in the pattern, filled by all lanes of the
+// wave over the flat (run, position) pairs), and a row costs one probe (~12 instructions) whatever the pattern's length.  The
+// distance itself is the same bit-parallel recurrence on the same masks (lev_step32) and the same float sum: same bits.
+// Up to kDpTabRuns runs share the LDS at a time; a wave with more (many queries of one or two candidates) takes its runs in rounds.
+// ---------------------------------------------------------------------------------------------
+#ifndef FMX_DPTAB_RUNS
+#define FMX_DPTAB_RUNS 16
+#endif
+#ifndef FMX_DPTAB_WAVES
+#define FMX_DPTAB_WAVES 4
+#endif
+constexpr uint32_t kDpTabRuns = FMX_DPTAB_RUNS, kDpTabSlots = 64;
+__device__ __forceinline__ uint32_t dp_tab_slot(uint32_t w) { return (w * 0x85EBCA6Bu) >> 26; }
+
+__global__ void __launch_bounds__(kWave, FMX_DPTAB_WAVES) k_dp_tab(DevIndex ix, DevBatch b, DevWork w, Params prm) {
+  __shared__ uint2 s_tab[kDpTabRuns][kDpTabSlots];   // {token, mask of its positions in the run's pattern}: one 8-byte read per row
+  __shared__ uint32_t s_rp[kDpTabRuns + 1];   // pattern tokens in front of each run of the round (exclusive prefix)
+  __shared__ uint32_t s_ro0[kDpTabRuns];      // where each run's pattern starts in q_tok
+  const uint32_t lane = lane_id();
+  unsigned long long j_lo, j_hi;
+  dp_class_range(b, w, 0u, j_lo, j_hi);
+  const uint32_t n_list = (uint32_t)(j_hi - j_lo);
+  const unsigned long long* __restrict__ list = w.c_qi + j_lo;
+  for (uint32_t j0 = blockIdx.x * kWave; j0 < n_list; j0 += gridDim.x * kWave) {
+    const uint32_t j = j0 + lane;
+    const bool act = j < n_list;
+    const unsigned long long qi = act ? list[j] : 0ull;
+    const uint32_t q = (uint32_t)(qi >> 32);
+    const uint32_t slot = (uint32_t)qi;
+    Cand c0;
+    c0.sid = 0; c0.longest = 0; c0.score = 0.f; c0.penalty = 0.f;
+    uint32_t o0 = 0, p = 0;
+    if (act) {
+      c0 = w.seg[slot];
+      o0 = b.q_off[b.q_begin + q];
+      p = b.q_off[b.q_begin + q + 1] - o0;
+    }
+    uint32_t tb = __float_as_uint(c0.score), slen = c0.longest >> 16;  // 0 = unknown (candidates rebuilt by k_cand*)
+    if (act && tb == 0) { const uint32_t sp0 = ix.sent_pos[c0.sid]; slen = ix.tok[sp0]; tb = sp0 + 1; }
+    if (!act) slen = 0;
+    const Tok4* sent4 = reinterpret_cast<const Tok4*>(ix.tok + tb);
+    Tok4 nxt = slen ? sent4[0] : Tok4{{0u, 0u, 0u, 0u}};   // (requested before the tables are built: it travels meanwhile)
+    // runs of equal q: a run's number = heads in front of the lane
+    const uint32_t pq = __shfl_up(q, 1, 64);
+    const bool head = act && (lane == 0 || pq != q);
+    const unsigned long long heads = __ballot(head);
+    const uint32_t run = act ? (uint32_t)__popcll(heads & ((2ull << lane) - 1ull)) - 1u : 0xffffu;
+    const uint32_t n_runs = (uint32_t)__popcll(heads);
+    uint32_t pv = ~0u, mv = 0u, score = p;
+    const uint32_t m_bits = p ? p : 1u;
+    for (uint32_t rb = 0; rb < n_runs; rb += kDpTabRuns) {
+      const uint32_t n_r = n_runs - rb < kDpTabRuns ? n_runs - rb : kDpTabRuns;  // runs of this round
+      const uint32_t rl = run - rb;                                               // this lane's run inside the round
+      const bool mine = act && rl < n_r;
+      wave_lds_sync();
+      // the round's tables: empty; the runs' pattern lengths and starts (written by each run's head lane)
+      for (uint32_t k = lane; k < n_r * kDpTabSlots; k += kWave) (&s_tab[0][0])[k] = make_uint2(kHashEmpty, 0u);
+      if (head && rl < n_r) { s_rp[rl + 1] = p; s_ro0[rl] = o0; }
+      if (lane == 0) s_rp[0] = 0;
+      wave_lds_sync();
+      if (lane == 0) {  // (at most sixteen values: a serial prefix)
+        uint32_t acc = 0;
+        for (uint32_t r = 0; r < n_r; r++) { acc += s_rp[r + 1]; s_rp[r + 1] = acc; }
+      }
+      wave_lds_sync();
+      // every (run, pattern position) pair of the round, 64 at a time: token -> its table, position -> its mask
+      const uint32_t T = s_rp[n_r];
+      for (uint32_t x = lane; x < T; x += kWave) {
+        uint32_t r = 0;
+#pragma unroll
+        for (uint32_t step = kDpTabRuns / 2; step >= 1; step >>= 1)
+          if (r + step < n_r && s_rp[r + step] <= x) r += step;
+        const uint32_t jp = x - s_rp[r];
+        const uint32_t t = b.q_tok[s_ro0[r] + jp];
+        uint32_t h = dp_tab_slot(t);
+        for (;;) {
+          const uint32_t old = atomicCAS(&s_tab[r][h].x, kHashEmpty, t);
+          if (old == kHashEmpty || old == t) { atomicOr(&s_tab[r][h].y, 1u << jp); break; }
+          h = (h + 1) & (kDpTabSlots - 1);
+        }
+      }
+      wave_lds_sync();
+      // the rows: this lane's sentence against its run's table (one 8-byte read per row and probe step).
+      // (Measured at C3 and left as they are: a branch-free row — home slot read unconditionally, state kept by selects, the probe
+      // sequence only when some lane collides — 0.53 ms, the four probes of a group requested together 0.55 ms, this loop 0.50 ms.)
+      const uint2* tab = &s_tab[mine ? rl : 0u][0];
+      const uint32_t rows = mine ? slen : 0u;
+      uint32_t rows_max = rows;
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(rows_max, d, 64); rows_max = o > rows_max ? o : rows_max; }
+      for (uint32_t i0 = 0; i0 < rows_max; i0 += 4) {
+        const Tok4 cur = nxt;
+        if (i0 + 4 < rows) nxt = sent4[(i0 >> 2) + 1];
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) {
+          if (i0 + u < rows) {
+            const uint32_t wd = cur.t[u];
+            uint32_t h = dp_tab_slot(wd);
+            uint2 e = tab[h];
+            while (e.x != wd && e.x != kHashEmpty) { h = (h + 1) & (kDpTabSlots - 1); e = tab[h]; }
+            lev_step32(pv, mv, score, e.x == wd ? e.y : 0u, m_bits);
+          }
+        }
+      }
+    }
+    if (act) {
+      const float dw = 100.f / normalizer(p, slen, prm.ins, prm.del, prm.rep);
+      const float f = unit_cost_sum(score, prm.rep * dw);  // = ins * dw = del * dw
+      Cand* cd = w.seg + slot;
+      cd->score = f;
+      cd->penalty = f;   // M = final: row minima never decrease for non-negative unit costs (fmx_core.hh)
+      cd->longest = (c0.longest & 0xffffu) | (slen << 16);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_finish — one wave per query.  Lane 0 replays the candidate loop's order-dependent acceptance
 // (lowest_costs bound, src/fuzzy_match.cc:587-610) over the candidates in reference order, 64 staged
 // through LDS at a time; accepted matches overwrite the head of the query's segment.  Then the
