@@ -1265,7 +1265,7 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
       hipLaunchKernelGGL((k_finish<kLdsSortMax, true>), dim3(2048), dim3(kWave), 0, side, E.d, b, w, prm, DevScratch{c.keys.p, c.vals.p, c.f0.p, c.f1.p}, cap,
                          d_out, d_out_count, d_out_total, c.contrast_list.p, c.fin_list.p);
       if (pair_finish)
-        hipLaunchKernelGGL(k_finish_pair, dim3((b.nq + 1) / 2), dim3(kWave), 0, stream, b, w, prm, cap, d_out, d_out_count, d_out_total, pair_max,
+        hipLaunchKernelGGL(k_finish_pair, dim3((b.nq + 3) / 4), dim3(kWave), 0, stream, b, w, prm, cap, d_out, d_out_count, d_out_total, pair_max,
                            c.contrast_list.p);
       else
         hipLaunchKernelGGL((k_finish<64, false>), dim3(b.nq), dim3(kWave), 0, stream, E.d, b, w, prm, DevScratch{c.keys.p, c.vals.p, c.f0.p, c.f1.p}, cap, d_out,

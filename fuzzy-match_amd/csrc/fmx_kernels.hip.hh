@@ -3020,8 +3020,7 @@ constexpr uint32_t kPairMax = 32;
 // wave_sort64_kv_n for the two halves of a wave at once: every half sorts ascending (the direction of the last merge stage
 // comes from the lane number inside the half; wave_sort64_kv_n<32> would sort lanes 32..63 descending)
 template <int N>
-__device__ __forceinline__ void half_sort64_kv_n(unsigned long long& key, uint32_t& val) {
-  const uint32_t hl = lane_id() & 31u;
+__device__ __forceinline__ void half_sort64_kv_n(unsigned long long& key, uint32_t& val, uint32_t hl) {  // hl: the lane inside its group
 #pragma unroll
   for (int k = 2; k <= N; k <<= 1) {
 #pragma unroll
@@ -3040,22 +3039,26 @@ __device__ __forceinline__ void half_sort64_kv_n(unsigned long long& key, uint32
 // pair_max: 32 candidates per query while lowest_costs is capped below 32 entries (contrast_buffer <= 30), else 31 — the bound
 // list then never holds more than the candidates + 1 = 32 entries, one per lane of the half.  With a contrastive factor the
 // accepted matches are not ranked and emitted but compacted to the head of the segment for the rerank kernels, like k_finish does.
-__global__ void __launch_bounds__(kWave) k_finish_pair(DevBatch b, DevWork w, Params prm, uint32_t cap, Rec* out_rec,
-                                                       uint32_t* out_count, uint32_t* out_total, uint32_t pair_max,
-                                                       uint32_t* contrast_list) {
-  __shared__ float s_score[kWave];
-  __shared__ uint32_t s_sid[kWave], s_L[kWave];
-  const uint32_t lane = lane_id(), hl = lane & 31u, base = lane & 32u;
-  const uint32_t q = blockIdx.x * 2u + (lane >> 5);
+// Round 5: the body is written for a GROUP of W lanes per query — W = 32: two queries per wave, W = 16: FOUR (candidate sets of
+// up to 16 / 15 entries: most of them) — and a wave takes four consecutive queries: all four in one go when none of them holds
+// more than a quarter wave's worth, else two and two.  The replay's instruction stream is shared by twice as many queries.
+template <int W>
+__device__ __forceinline__ void finish_group(const DevBatch& b, const DevWork& w, const Params& prm, uint32_t cap, Rec* out_rec,
+                                             uint32_t* out_count, uint32_t* out_total, uint32_t grp_max, uint32_t pair_max,
+                                             uint32_t* contrast_list, uint32_t q_first, float* s_score, uint32_t* s_sid, uint32_t* s_L) {
+  constexpr uint32_t kMaskW = W == 32 ? 0xffffffffu : ((1u << (W & 31)) - 1u);
+  const uint32_t lane = lane_id(), hl = lane & (uint32_t)(W - 1), base = lane & ~(uint32_t)(W - 1);
+  const uint32_t q = q_first + lane / (uint32_t)W;
   const bool have = q < b.nq;
   const uint32_t gq = b.q_begin + (have ? q : 0u);
   const uint32_t n_cand = have ? w.q_cand[q] : 0u;
-  const bool act_q = have && n_cand != 0 && n_cand <= pair_max;  // larger sets were queued by k_cmap for the list kernel
+  const bool act_q = have && n_cand != 0 && n_cand <= grp_max;  // larger sets: the wider group, or queued by k_cmap for the list kernel
   const bool contrast = prm.contrast > 0.f;
   uint32_t p = 0, my_slen = 0;
   bool maybe = false;
   float my_cost = 0.f, my_M = 0.f, my_score = 0.f;
   if (act_q) p = b.q_off[gq + 1] - b.q_off[gq];
+  wave_lds_sync();
   if (act_q && hl < n_cand) {
     const Cand cd = w.seg[w.q_seg[q] + hl];
     const uint32_t slen = cd.longest >> 16;
@@ -3064,8 +3067,8 @@ __global__ void __launch_bounds__(kWave) k_finish_pair(DevBatch b, DevWork w, Pa
     s_sid[lane] = cd.sid; s_L[lane] = cd.longest & 0xffffu; s_score[lane] = my_score;
     maybe = !(prm.no_perfect && cd.score == 0.f && slen == p);
   }
-  uint32_t todo = (uint32_t)(__ballot(maybe) >> base);
-  float hv = FLT_MAX;  // v[0] = FLT_MAX, the reference's initial bound; lane hl of the half holds v[hl]
+  uint32_t todo = (uint32_t)(__ballot(maybe) >> base) & kMaskW;
+  float hv = FLT_MAX;  // v[0] = FLT_MAX, the reference's initial bound; lane hl of the group holds v[hl]
   uint32_t n = 1, acc = 0;
   while (__ballot(todo != 0)) {
     const bool on = todo != 0;
@@ -3077,7 +3080,7 @@ __global__ void __launch_bounds__(kWave) k_finish_pair(DevBatch b, DevWork w, Pa
     const float ub = __shfl(hv, (int)(base + n - 1u), 64);
     const bool go = on && !(Mk > ub);  // replay_candidate_scored; the no_perfect rule is already in `todo`
     // push(fc): behind the elements <= fc, the larger ones move up one lane
-    const uint32_t pos = (uint32_t)__popc((uint32_t)(__ballot(go && hl < n && hv <= fc) >> base));
+    const uint32_t pos = (uint32_t)__popc((uint32_t)(__ballot(go && hl < n && hv <= fc) >> base) & kMaskW);
     const float up = __shfl_up(hv, 1, 64);
     if (go) {
       hv = hl == pos ? fc : ((hl > pos && hl <= n) ? up : hv);
@@ -3091,14 +3094,14 @@ __global__ void __launch_bounds__(kWave) k_finish_pair(DevBatch b, DevWork w, Pa
     const bool mine_c = act_q && ((acc >> hl) & 1u);
     uint32_t mx = mine_c ? my_slen : 0u;
 #pragma unroll
-    for (int d2 = 16; d2 >= 1; d2 >>= 1) { const uint32_t o = __shfl_xor(mx, d2, 64); mx = o > mx ? o : mx; }  // within the half
+    for (int d2 = W / 2; d2 >= 1; d2 >>= 1) { const uint32_t o = __shfl_xor(mx, d2, 64); mx = o > mx ? o : mx; }  // within the group
     wave_lds_sync();
     if (mine_c) {
       Cand a;
       a.sid = s_sid[lane]; a.longest = s_L[lane]; a.score = my_score; a.penalty = 0.f;
       w.seg[w.q_seg[q] + (uint32_t)__popc(acc & ((1u << hl) - 1u))] = a;  // every lane read its own candidate at the top
     }
-    if (have && hl == 0 && n_cand <= pair_max) {
+    if (have && hl == 0 && n_cand <= grp_max) {
       uint32_t qa = act_q ? n_acc : 0u;
       if (act_q && n_acc != 0 && (mx > 32 || n_acc > kMaxFlatAccepted || b.n_prior != 0)) {
         const uint32_t cls = (mx <= 64 && n_acc <= kMaxFlatAccepted && b.n_prior == 0) ? 1u : 2u;
@@ -3114,25 +3117,45 @@ __global__ void __launch_bounds__(kWave) k_finish_pair(DevBatch b, DevWork w, Pa
   const uint32_t want = prm.nmatch == 0 ? n_acc : (prm.nmatch < n_acc ? prm.nmatch : n_acc);
   const uint32_t emit = want < cap ? want : cap;
   const bool mine = act_q && ((acc >> hl) & 1u);
-  // ascending key = score desc, s_id asc (sentence ids are unique within a candidate set); each half is sorted on its own
+  // ascending key = score desc, s_id asc (sentence ids are unique within a candidate set); each group is sorted on its own
   unsigned long long key = mine ? (((unsigned long long)(~float_key(my_score)) << 32) | s_sid[lane]) : ~0ull;
   uint32_t idx = hl;
-  uint32_t n_max = n_cand <= pair_max ? n_cand : 0u;
-  { const uint32_t o = __shfl_xor(n_max, 32, 64); n_max = o > n_max ? o : n_max; }
+  uint32_t n_max = n_cand <= grp_max ? n_cand : 0u;
+#pragma unroll
+  for (int d2 = 32; d2 >= W; d2 >>= 1) { const uint32_t o = __shfl_xor(n_max, d2, 64); n_max = o > n_max ? o : n_max; }
   n_max = __builtin_amdgcn_readfirstlane(n_max);
-  if (n_max > 16) half_sort64_kv_n<32>(key, idx);
-  else if (n_max > 8) half_sort64_kv_n<16>(key, idx);
-  else if (n_max > 1) half_sort64_kv_n<8>(key, idx);
+  if (W == 32 && n_max > 16) half_sort64_kv_n<32>(key, idx, hl);
+  else if (n_max > 8) half_sort64_kv_n<16>(key, idx, hl);
+  else if (n_max > 1) half_sort64_kv_n<8>(key, idx, hl);
   wave_lds_sync();
   if (act_q && hl < emit) {
     Rec r;
     r.score = s_score[base + idx]; r.penalty = 0.f; r.max_subseq = (int32_t)s_L[base + idx]; r.s_id = s_sid[base + idx];
     out_rec[(unsigned long long)gq * cap + hl] = r;
   }
-  if (have && hl == 0 && n_cand <= pair_max) {
+  if (have && hl == 0 && n_cand <= grp_max) {
     w.q_acc[q] = act_q ? n_acc : 0u;
     out_count[gq] = act_q ? emit : 0u;
     if (out_total) out_total[gq] = act_q ? want : 0u;
+  }
+}
+
+__global__ void __launch_bounds__(kWave) k_finish_pair(DevBatch b, DevWork w, Params prm, uint32_t cap, Rec* out_rec,
+                                                       uint32_t* out_count, uint32_t* out_total, uint32_t pair_max,
+                                                       uint32_t* contrast_list) {
+  __shared__ float s_score[kWave];
+  __shared__ uint32_t s_sid[kWave], s_L[kWave];
+  const uint32_t q4 = blockIdx.x * 4u;
+  // a quarter wave per query: lowest_costs (contrast_buffer + 1 entries at most) and the candidates + 1 must fit sixteen lanes
+  const uint32_t quad_max = (prm.cbuf > 0 && prm.cbuf <= 14) ? 16u : 15u;
+  const uint32_t qx = q4 + (lane_id() >> 4);
+  const uint32_t nc = qx < b.nq ? w.q_cand[qx] : 0u;
+  const bool wide = nc > quad_max && nc <= pair_max;   // needs half a wave
+  if (__ballot(wide) == 0ull) {
+    finish_group<16>(b, w, prm, cap, out_rec, out_count, out_total, quad_max, pair_max, contrast_list, q4, s_score, s_sid, s_L);
+  } else {
+    finish_group<32>(b, w, prm, cap, out_rec, out_count, out_total, pair_max, pair_max, contrast_list, q4, s_score, s_sid, s_L);
+    finish_group<32>(b, w, prm, cap, out_rec, out_count, out_total, pair_max, pair_max, contrast_list, q4 + 2u, s_score, s_sid, s_L);
   }
 }
 
