@@ -1308,6 +1308,7 @@ int fmx_set_option(fmx_index* ix, const char* name, int64_t value) {
     else if (n == "b_grid") d->set_b_grid((uint32_t)std::max<int64_t>(value, 1));
     else if (n == "heavy_grid") d->set_heavy_grid((uint32_t)std::max<int64_t>(value, 1));
     else if (n == "light_max") d->set_light_max((uint32_t)std::max<int64_t>(value, 0));
+    else if (n == "probe_split") d->set_probe_split(value != 0);
     else if (n == "light_flat") d->set_light_flat((uint32_t)std::max<int64_t>(value, 0));
     else return fail(FMX_E_INVALID, "unknown option " + n);
   }

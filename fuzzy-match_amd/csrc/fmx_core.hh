@@ -372,23 +372,29 @@ FMX_HD int key_cmp(const SufKey& kk, const uint32_t (&ng)[kKeyTokens + 1], uint3
 // together, the n-gram lives in registers, seeds of five tokens and more are answered by ONE line of the 5-gram buckets
 // whenever the group's shared tokens decide them (see G5Bucket), and what is left is bisected over the group's keys with the
 // lower and the upper end of the equal range in lockstep (two independent key loads per level).
-FMX_HD void mgram_range_hashed(const GramTables& gt, const SufKey* __restrict__ key,
-                               const SufRec* __restrict__ suf, const uint32_t* __restrict__ tok,
-                               const uint32_t* __restrict__ qva, uint32_t n_qva, const uint32_t* __restrict__ ngram,
-                               uint32_t m, uint32_t& out_lo, uint32_t& out_hi, ProbeTally* tally = nullptr) {
-  uint32_t ng[kKeyTokens + 1];
-  tally_add(tally, 4 * (m < kKeyTokens + 1 ? m : kKeyTokens + 1));  // the seed n-gram itself
-#pragma unroll
-  for (uint32_t k = 0; k <= kKeyTokens; k++) ng[k] = k < m ? ngram[k] : 0u;
+//
+// The function comes in two halves (round 5) so that k_probe can run them as two kernels — the HEAD (one table line: most
+// starts end there) with a lane per start position, the TAIL (7-gram entry, bisection: 17 % of the probed starts at C3, three to
+// four dependent levels each) with a lane per start position that needs it, in full waves:
+//   mgram_range_head  -> kHeadDone: out_lo / out_hi are final; else the range [out_lo, out_hi) of the table entry and `from`,
+//                        the number of leading tokens every suffix of that range is known to share with the seed
+//                        (kHeadKeyed: the tables cannot be used — id 0 in a keyed position — the tail runs the keyed search)
+//   mgram_range_tail  -> the equal range inside it
+constexpr uint32_t kHeadDone = 0, kHeadKeyed = 0xffu;
+
+// ng[k] = ngram[k] for k < min(m, 9), 0 beyond
+FMX_HD uint32_t mgram_range_head(const GramTables& gt, const uint32_t* __restrict__ qva, uint32_t n_qva,
+                                 const uint32_t (&ng)[kKeyTokens + 1], uint32_t m, uint32_t& out_lo, uint32_t& out_hi,
+                                 ProbeTally* tally = nullptr) {
   bool usable = gt.g3 != nullptr && m >= 3 && n_qva >= 2;
 #pragma unroll
   for (uint32_t k = 1; k <= kKeyTokens; k++) usable = usable && (k >= m || ng[k] != 0);
-  if (!usable) { mgram_range_keyed(key, suf, tok, qva, n_qva, ngram, m, out_lo, out_hi, tally); return; }
   out_lo = out_hi = 0;
+  if (!usable) return kHeadKeyed;
   const uint32_t w0 = ng[0];
   const bool w_ok = w0 + 1 < n_qva;
   const uint32_t wi = w_ok ? w0 : 0u;
-  uint32_t lo, hi, from;
+  uint32_t lo, hi;
   if (m >= 5 && gt.g5 != nullptr) {
     // ---- seeds of five tokens and more: the bucket of the first five ----
     uint32_t b = g5_bucket_of(gram5_hash(w0, ng[1], ng[2], ng[3], ng[4]), gt.n_b5);
@@ -416,8 +422,8 @@ FMX_HD void mgram_range_hashed(const GramTables& gt, const SufKey* __restrict__ 
       if (found || g5_over(dir_b) == 0u || hops >= gt.n_b5) break;
       b = b + 1 == gt.n_b5 ? 0u : b + 1;
     }
-    if (!found || !w_ok || blo >= bhi) return;  // no suffix starts with these five tokens
-    if (m == 5) { out_lo = lo; out_hi = hi; return; }
+    if (!found || !w_ok || blo >= bhi) return kHeadDone;  // no suffix starts with these five tokens
+    if (m == 5) { out_lo = lo; out_hi = hi; return kHeadDone; }
     // the tokens the whole group shares after the 5-gram (tokens 5 .. 5 + lcp - 1 = those of its first suffix)
     const uint32_t need = m - 5, sh = need < lcp ? need : lcp;
     bool differ = false;
@@ -425,38 +431,48 @@ FMX_HD void mgram_range_hashed(const GramTables& gt, const SufKey* __restrict__ 
     differ = differ || (sh > 1 && t1 != ng[6]);
     differ = differ || (sh > 2 && t2 != ng[7]);
     differ = differ || (sh > 3 && t3 != ng[8]);
-    if (differ) return;                                    // every suffix of the group continues otherwise
-    if (need <= lcp) { out_lo = lo; out_hi = hi; return; }  // every suffix of the group continues like the seed
-    from = 5 + lcp;
-    // heavy groups: the 7-gram entry (unless the shared tokens already cover w5, w6: the entry would name the whole group)
-    if (m >= 7 && lcp < 2 && gt.g7 != nullptr && hi - lo > kDeepGramMin) {
-      uint32_t slot = gram_hash(lo, ng[5], ng[6]) & gt.mask7;
-      for (;;) {
-        const GramEntry e7 = gt.g7[slot];
-        tally_add(tally, 16);
-        if (e7.lo == kGramEmpty) return;  // no suffix of this 5-gram continues with (w5, w6)
-        if (e7.w1 == ng[5] && e7.w2 == ng[6] && e7.lo >= lo && e7.lo < hi) { lo = e7.lo; hi = e7.lo + e7.cnt; break; }
-        slot = (slot + 1) & gt.mask7;
-      }
-      if (m == 7) { out_lo = lo; out_hi = hi; return; }
-      from = 7;
-    }
-  } else {
-    // ---- seeds of three and four tokens: the trigram table ----
-    uint32_t slot = gram_hash(w0, ng[1], ng[2]) & gt.mask3;
-    GramEntry e = gt.g3[slot];  // requested together with the bucket bounds
-    const uint32_t blo = qva[wi], bhi = qva[wi + 1];
-    tally_add(tally, 16); tally_add(tally, 8);
-    if (!w_ok || blo >= bhi) return;
+    if (differ) return kHeadDone;                                        // every suffix of the group continues otherwise
+    if (need <= lcp) { out_lo = lo; out_hi = hi; return kHeadDone; }      // every suffix of the group continues like the seed
+    out_lo = lo; out_hi = hi;
+    return 5 + lcp;
+  }
+  // ---- seeds of three and four tokens: the trigram table ----
+  uint32_t slot = gram_hash(w0, ng[1], ng[2]) & gt.mask3;
+  GramEntry e = gt.g3[slot];  // requested together with the bucket bounds
+  const uint32_t blo = qva[wi], bhi = qva[wi + 1];
+  tally_add(tally, 16); tally_add(tally, 8);
+  if (!w_ok || blo >= bhi) return kHeadDone;
+  for (;;) {
+    if (e.lo == kGramEmpty) return kHeadDone;  // no suffix starts with this trigram
+    if (e.w1 == ng[1] && e.w2 == ng[2] && e.lo >= blo && e.lo < bhi) { lo = e.lo; hi = e.lo + e.cnt; break; }
+    slot = (slot + 1) & gt.mask3;
+    e = gt.g3[slot];
+    tally_add(tally, 16, 0);  // linear probing: the next slot is almost always in the same line
+  }
+  out_lo = lo; out_hi = hi;
+  if (m == 3) return kHeadDone;
+  return 3;
+}
+
+// [lo, hi) and `from` as mgram_range_head left them (from != kHeadDone)
+FMX_HD void mgram_range_tail(const GramTables& gt, const SufKey* __restrict__ key, const SufRec* __restrict__ suf,
+                             const uint32_t* __restrict__ tok, const uint32_t* __restrict__ qva, uint32_t n_qva,
+                             const uint32_t* __restrict__ ngram, const uint32_t (&ng)[kKeyTokens + 1], uint32_t m, uint32_t from,
+                             uint32_t lo, uint32_t hi, uint32_t& out_lo, uint32_t& out_hi, ProbeTally* tally = nullptr) {
+  if (from == kHeadKeyed) { mgram_range_keyed(key, suf, tok, qva, n_qva, ngram, m, out_lo, out_hi, tally); return; }
+  out_lo = out_hi = 0;
+  // heavy 5-gram groups: the 7-gram entry (unless the shared tokens already cover w5, w6: the entry would name the whole group)
+  if (from >= 5 && from < 7 && m >= 7 && gt.g7 != nullptr && hi - lo > kDeepGramMin) {
+    uint32_t slot = gram_hash(lo, ng[5], ng[6]) & gt.mask7;
     for (;;) {
-      if (e.lo == kGramEmpty) return;  // no suffix starts with this trigram
-      if (e.w1 == ng[1] && e.w2 == ng[2] && e.lo >= blo && e.lo < bhi) { lo = e.lo; hi = e.lo + e.cnt; break; }
-      slot = (slot + 1) & gt.mask3;
-      e = gt.g3[slot];
-      tally_add(tally, 16, 0);  // linear probing: the next slot is almost always in the same line
+      const GramEntry e7 = gt.g7[slot];
+      tally_add(tally, 16);
+      if (e7.lo == kGramEmpty) return;  // no suffix of this 5-gram continues with (w5, w6)
+      if (e7.w1 == ng[5] && e7.w2 == ng[6] && e7.lo >= lo && e7.lo < hi) { lo = e7.lo; hi = e7.lo + e7.cnt; break; }
+      slot = (slot + 1) & gt.mask7;
     }
-    if (m == 3) { out_lo = lo; out_hi = hi; return; }
-    from = 3;
+    if (m == 7) { out_lo = lo; out_hi = hi; return; }
+    from = 7;
   }
   // equal range of the remaining tokens inside [lo, hi): a1 -> first suffix >= n-gram, a2 -> first suffix > n-gram
   const uint32_t lim = m - 1 < kKeyTokens ? m - 1 : kKeyTokens;
@@ -484,6 +500,21 @@ FMX_HD void mgram_range_hashed(const GramTables& gt, const SufKey* __restrict__ 
   }
   out_lo = a1;
   out_hi = a2 > a1 ? a2 : a1;
+}
+
+// head + tail in one go (the host twin, the one-launch kernel for micro-batches, subsequence())
+FMX_HD void mgram_range_hashed(const GramTables& gt, const SufKey* __restrict__ key,
+                               const SufRec* __restrict__ suf, const uint32_t* __restrict__ tok,
+                               const uint32_t* __restrict__ qva, uint32_t n_qva, const uint32_t* __restrict__ ngram,
+                               uint32_t m, uint32_t& out_lo, uint32_t& out_hi, ProbeTally* tally = nullptr) {
+  uint32_t ng[kKeyTokens + 1];
+  tally_add(tally, 4 * (m < kKeyTokens + 1 ? m : kKeyTokens + 1));  // the seed n-gram itself
+#pragma unroll
+  for (uint32_t k = 0; k <= kKeyTokens; k++) ng[k] = k < m ? ngram[k] : 0u;
+  uint32_t lo, hi;
+  const uint32_t from = mgram_range_head(gt, qva, n_qva, ng, m, lo, hi, tally);
+  if (from == kHeadDone) { out_lo = lo; out_hi = hi; return; }
+  mgram_range_tail(gt, key, suf, tok, qva, n_qva, ngram, ng, m, from, lo, hi, out_lo, out_hi, tally);
 }
 
 // Longest common prefix of a suffix (already known to share `known` tokens) with pat[0..maxlen).

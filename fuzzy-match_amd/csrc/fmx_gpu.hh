@@ -123,6 +123,7 @@ class DeviceIndex {
   void     set_b_grid(uint32_t n);
   void     set_heavy_grid(uint32_t n);  // workgroups of the bit-plane kernel
   void     set_light_max(uint32_t n);   // queries with at most n hits, all in short ranges, skip phase A (0 = none do)
+  void     set_probe_split(bool on);    // the probe as head + tail kernels (default) or as one kernel
   void     set_light_flat(uint32_t n);  // ... and of those, queries with at most n hits are walked several to a wave (0 = none)
   void     set_contexts(uint32_t n);    // concurrent calls served at once (each owns a workspace)
   void     set_max_host_active(uint32_t n);  // host-buffer calls that may have work on the GPU at once, whatever "contexts" says (default 4): further ones wait on the host

@@ -226,6 +226,7 @@ struct Ctx {
   static constexpr size_t zero_words() { return kNumCounters + (size_t)kScanSlots * kLbMaxArrays * kLbMaxTiles + kScanSlots + kPBins + 2; }
   Grow<WorkItem> items, items_b;
   Grow<HeavyItem> items_h;
+  Grow<ProbeItem> items_t;   // start positions queued by k_probe for k_probe_tail (one slot per token of the pass)
   Grow<uint16_t> cmin_tab;
   // what the table in cmin_tab was computed for (k_cmin is skipped while a pass asks for the same: the coalescer's
   // micro-batches repeat their parameters, and the kernel is 25 us of a ~250 us pass)
@@ -333,7 +334,7 @@ struct Ctx {
     q_hits.release(); q_hits_a.release(); q_seg.release(); q_qseg.release(); q_cap.release(); c_in.release(); c_off.release();
     t_q.release(); t_lo.release(); t_cnt.release(); t_idf.release(); c_qi.release(); keys.release(); seg.release(); qb.release();
     heap.release(); f0.release(); f1.release(); vals.release(); zero_blk.release();
-    items.release(); items_b.release(); items_h.release(); cmin_tab.release(); g_rows.release();
+    items.release(); items_b.release(); items_h.release(); items_t.release(); cmin_tab.release(); g_rows.release();
     d_qoff.release(); d_qtok.release(); d_qreal.release(); d_qitok.release(); d_text.release(); d_vstate.release(); d_text_r.release(); d_vstate_r.release(); d_islot.release(); d_iid.release(); d_scratch.release(); d_lflag.release(); d_cnt.release(); d_tot.release(); d_out.release(); d_prior.release();
     if (stream && !pooled) (void)hipStreamDestroy(stream);
     if (h2d && !shared_copy) (void)hipStreamDestroy(h2d);
@@ -417,6 +418,8 @@ struct DeviceIndex::Impl {
   // OFF by default: bit-identical, 13 % fewer VALU instructions, and SLOWER at C3 — the stage 1.40 -> 1.81 ms (flat 128), 1.59 (64):
   // at four waves per SIMD (118 VGPRs, 8 KB of LDS) the sub-tiles' chains of dependent LDS / memory round trips are not hidden
   // (profiles/r05_light_flat_ab.md)
+  // the probe as two kernels (head: one table line per start position; tail: the bisection of what is left, in full waves)
+  bool probe_split = [] { const char* e = getenv("FMX_PROBE_SPLIT"); return e ? atoi(e) != 0 : true; }();
   uint32_t light_flat = [] { const char* e = getenv("FMX_LIGHT_FLAT"); return e ? (uint32_t)std::min(std::max(atoi(e), 0), 256) : 0u; }();
   // context pool
   // One pair of copy streams for every context of the index: the DMA engines serialise the copies anyway, and a context then
@@ -634,6 +637,7 @@ void     DeviceIndex::set_expand_order(uint32_t n) { impl_->expand_order = n; }
 void     DeviceIndex::set_b_grid(uint32_t n) { impl_->b_grid = std::min<uint32_t>(std::max<uint32_t>(n, 64u), 65536u); }
 void     DeviceIndex::set_heavy_grid(uint32_t n) { impl_->heavy_grid = std::min<uint32_t>(std::max<uint32_t>(n, 64u), 65536u); }
 void     DeviceIndex::set_light_max(uint32_t n) { impl_->light_max = std::min<uint32_t>(n, kPhaseBChunk); }
+void     DeviceIndex::set_probe_split(bool on) { impl_->probe_split = on; }
 void     DeviceIndex::set_light_flat(uint32_t n) { impl_->light_flat = std::min<uint32_t>(n, 256u); }
 void     DeviceIndex::set_contexts(uint32_t n) {
   {
@@ -980,7 +984,7 @@ static void ensure_ws(Ctx& c, uint64_t nq, uint64_t nt, uint64_t seg) {
   c.q_rank.ensure(nq); c.q_scap.ensure(nq); c.big_list.ensure(nq); c.mid_list.ensure(nq); c.fin_list.ensure(nq); c.contrast_list.ensure(2 * nq);
   c.q_hits.ensure(nq + 1); c.q_hits_a.ensure(nq + 1); c.q_seg.ensure(3 * (nq + 1)); c.q_qseg.ensure(2 * (nq + 1)); c.q_cap.ensure(3 * (nq + 1));
   c.c_in.ensure(3 * (nq + 1)); c.c_off.ensure(3 * (nq + 1));
-  c.t_q.ensure(nt); c.t_lo.ensure(nt); c.t_cnt.ensure(nt); c.t_idf.ensure(nt);
+  c.t_q.ensure(nt); c.t_lo.ensure(nt); c.t_cnt.ensure(nt); c.t_idf.ensure(nt); c.items_t.ensure((uint64_t)kTailLists * probe_tail_list_cap((uint32_t)std::min<uint64_t>(nt, 0xffffffffull)));
   if (seg > c.seg_cap) {
     // (the candidate lists name segment slots with 32 bits; a pass is at most a few million queries)
     if (seg > 0xffffffffull) throw UnsupportedError("a pass needs more than 2^32 - 1 segment entries: lower \"sub_queries\"");
@@ -1095,10 +1099,21 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
     if (prm.idf_penalty != 0.f) hipLaunchKernelGGL(k_tidf, dim3((b.nt + 255) / 256), dim3(256), 0, stream, E.d, b, w);
     tick(); tick();
     if (b.nt) {
-      if (m.probe_count)  // measurement runs only: the same kernel, also counting the bytes / lines it requests
-        hipLaunchKernelGGL(k_probe<true>, dim3((b.nt + kProbeBlock - 1) / kProbeBlock), dim3(kProbeBlock), 0, stream, E.d, b, w, heavy_min, c.items_h.p, item_h_cap);
-      else
-        hipLaunchKernelGGL(k_probe<false>, dim3((b.nt + kProbeBlock - 1) / kProbeBlock), dim3(kProbeBlock), 0, stream, E.d, b, w, heavy_min, c.items_h.p, item_h_cap);
+      const dim3 pg((b.nt + kProbeBlock - 1) / kProbeBlock), pb(kProbeBlock);
+      if (m.probe_split) {
+        // head: a lane per start position, one table line; tail: a lane per start position the head could not decide
+        if (m.probe_count) {  // measurement runs only: the same kernels, also counting the bytes / lines they request
+          hipLaunchKernelGGL((k_probe<true, true>), pg, pb, 0, stream, E.d, b, w, heavy_min, c.items_h.p, item_h_cap, c.items_t.p);
+          hipLaunchKernelGGL(k_probe_tail<true>, dim3(kProbeTailGrid), dim3(kWave), 0, stream, E.d, b, w, heavy_min, c.items_h.p, item_h_cap, (const ProbeItem*)c.items_t.p);
+        } else {
+          hipLaunchKernelGGL((k_probe<false, true>), pg, pb, 0, stream, E.d, b, w, heavy_min, c.items_h.p, item_h_cap, c.items_t.p);
+          hipLaunchKernelGGL(k_probe_tail<false>, dim3(kProbeTailGrid), dim3(kWave), 0, stream, E.d, b, w, heavy_min, c.items_h.p, item_h_cap, (const ProbeItem*)c.items_t.p);
+        }
+      } else if (m.probe_count) {
+        hipLaunchKernelGGL((k_probe<true, false>), pg, pb, 0, stream, E.d, b, w, heavy_min, c.items_h.p, item_h_cap, c.items_t.p);
+      } else {
+        hipLaunchKernelGGL((k_probe<false, false>), pg, pb, 0, stream, E.d, b, w, heavy_min, c.items_h.p, item_h_cap, c.items_t.p);
+      }
     }
     tick(); tick();
     // light queries (k_caps_scan): at most light_max hits, all in short ranges, pattern of at most one wave
@@ -2474,3 +2489,12 @@ std::vector<uint32_t> DeviceIndex::sub_bounds_from_device(const uint32_t* d_q_of
 // the suffix sorter of the index build (gpu_suffix_sort): fmx_sort.hip
 
 }  // namespace fmx
+
+#ifdef FMX_LIGHT_STATS
+extern "C" int fmx_debug_light_stats(unsigned long long* out, int reset) {
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(fmx::g_light_stats), sizeof(fmx::g_light_stats)) != hipSuccess) return -1;
+  if (reset) { static unsigned long long z[1024]; if (hipMemcpyToSymbol(HIP_SYMBOL(fmx::g_light_stats), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+#endif
+

@@ -18,6 +18,7 @@
 // All integer/compare/float-scalar work: no MFMA anywhere.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "fmx_core.hh"
 
 namespace fmx {
@@ -119,7 +120,10 @@ struct DevWork {
 constexpr int kStatSlots = 64;     // k_expand_h's three statistics are summed into 64 slots each (kStatBase + 3 x 64): 8192 workgroups
                                    // adding to three single words at the end of the kernel queued for ~0.1 ms; k_stats folds them into [16..18]
 constexpr int kStatBase = 32;
-constexpr int kNumCounters = kStatBase + 3 * kStatSlots;
+constexpr int kTailLists = 256;    // k_probe queues start positions for k_probe_tail in this many lists (a single fill counter would see
+                                   // one returning atomic per wave, 400 k per step at C3: they serialise — measured 4 ms)
+constexpr int kCtrProbeTail = kStatBase + 3 * kStatSlots;   // counters[kCtrProbeTail + l] = entries of list l
+constexpr int kNumCounters = kCtrProbeTail + kTailLists;
 
 constexpr int kWave = 64;
 constexpr uint32_t kLdsSortMax = 1024;   // per-wave LDS sort capacity (keys)
@@ -135,6 +139,12 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
     if (lane >= (uint32_t)d) v += n;
   }
   return v;
+}
+
+__device__ __forceinline__ uint32_t uni(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ unsigned long long uni(unsigned long long x) {
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)x), hi = __builtin_amdgcn_readfirstlane((uint32_t)(x >> 32));
+  return ((unsigned long long)hi << 32) | lo;
 }
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
@@ -217,41 +227,30 @@ __device__ __forceinline__ unsigned long long seg_scan_u64(unsigned long long v,
 #define FMX_PROBE_BLOCK 64
 #endif
 constexpr uint32_t kProbeBlock = FMX_PROBE_BLOCK;  // threads per workgroup of k_probe (waves are independent: no LDS, no barrier)
-template <bool COUNT>
-__global__ void __launch_bounds__(kProbeBlock) k_probe(DevIndex ix, DevBatch b, DevWork w, uint32_t heavy_min, HeavyItem* items_h,
-                                              uint32_t item_h_cap) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= b.nt || pass_refused(w)) return;
-  const uint32_t q = w.t_q[t];
-  const uint32_t msl = w.q_m[q];
-  const uint32_t o0 = b.q_off[b.q_begin + q] - b.t_begin;
-  const uint32_t p = b.q_off[b.q_begin + q + 1] - b.t_begin - o0;
-  const uint32_t it = t - o0;
-  uint32_t lo = 0, hi = 0;
-  ProbeTally tally;
-  tally.bytes = 16 + 12;  // t_q, q_m, two offsets; t_lo / t_cnt written, the hit totals
-  tally.lines = 0;
-  if (msl != kNoMatchLen) {
-    const uint32_t m = seed_len(p, msl);
-    // register_suffix_range_match ignores match_length < _min_seq_len (src/ngram_matches.cc:65-66);
-    // with p == 1 the only registered length is 1.
-    const bool reachable = (p == 1) ? (msl <= 1) : true;
-    if (reachable && it + m <= p)
-      mgram_range_hashed(ix.gram, ix.suf_key, ix.suf, ix.tok, ix.qva, ix.n_qva, b.q_tok + b.t_begin + t, m, lo, hi,
-                         COUNT ? &tally : nullptr);
-  }
-  if (COUNT) {
-    unsigned long long tb = tally.bytes, tl = tally.lines;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { tb += __shfl_xor(tb, d, 64); tl += __shfl_xor(tl, d, 64); }
-    if ((threadIdx.x & 63) == 0) { atomicAdd(&w.counters[19], tb); atomicAdd(&w.counters[20], tl); }
-  }
-  const uint32_t cnt = hi - lo;
+
+// A start position whose range the head of the probe could not decide (fmx_core.hh: mgram_range_head): handed to k_probe_tail.
+// The table range it is to search waits in t_lo / t_cnt of the start position.
+struct ProbeItem {
+  uint32_t t;        // token index of the (query, start position) inside the pass
+  uint32_t from_m;   // `from` of mgram_range_head | seed length << 8
+};
+// list l holds the entries of the workgroups with blockIdx % kTailLists == l, kProbeBlock slots each: room for every token
+__host__ __device__ inline uint32_t probe_tail_list_cap(uint32_t nt) {
+  const uint32_t n_blocks = (nt + kProbeBlock - 1) / kProbeBlock;
+  return kProbeBlock * ((n_blocks + kTailLists - 1) / kTailLists);
+}
+
+// what both probe kernels do with a lane's range: t_lo / t_cnt, the work items of the long ranges, the per-query hit totals
+__device__ __forceinline__ void probe_emit(const DevBatch& b, const DevWork& w, uint32_t t, uint32_t q, uint32_t p, bool mine, uint32_t lo, uint32_t hi,
+                                           uint32_t heavy_min, HeavyItem* items_h, uint32_t item_h_cap) {
+  const uint32_t cnt = mine ? hi - lo : 0u;
   // Long ranges (a repeated phrase: 0.1 % of the ranges hold most of the hits) are not walked hit by hit: they become
   // work items of k_expand_h, which tests 64 suffixes per lane through the signature bit planes.
   const bool heavy = cnt >= heavy_min && p <= kPlaneMaxP;
-  w.t_lo[t] = lo;
-  w.t_cnt[t] = heavy ? 0u : cnt;
+  if (mine) {
+    w.t_lo[t] = lo;
+    w.t_cnt[t] = heavy ? 0u : cnt;
+  }
   if (heavy) {
     const uint32_t blk0 = lo >> 6, blk1 = (hi - 1) >> 6;
     const uint32_t n_items = (blk1 - blk0) / kHeavyChunkBlocks + 1;
@@ -259,15 +258,117 @@ __global__ void __launch_bounds__(kProbeBlock) k_probe(DevIndex ix, DevBatch b, 
     for (uint32_t k = 0; k < n_items; k++)
       if (base + k < item_h_cap) { HeavyItem h; h.t = t; h.lo = lo; h.cnt = cnt; h.chunk = k; items_h[base + k] = h; }
   }
-  // Per-query hit totals (q_hits / q_hits_a, zeroed by the host): a query's start positions are consecutive lanes, so a
+  // Per-query hit totals (q_hits / q_hits_a, zeroed by k_setup): a query's start positions are consecutive lanes, so a
   // segmented scan over the wave leaves one atomic per (wave, query) instead of one per start position.
+  if (__ballot(cnt != 0) == 0ull) return;
   const uint32_t lane = lane_id();
   const unsigned long long sum = seg_scan_u64(cnt, q);
   const unsigned long long sum_a = seg_scan_u64(heavy ? 0u : cnt, q);
   const uint32_t nq = __shfl_down(q, 1, 64);
-  const bool tail = lane == 63 || t + 1 >= b.nt || nq != q;
+  const bool tail = lane == 63 || nq != q;
   if (tail && sum != 0) atomicAdd(&w.q_hits[q], sum);
   if (tail && sum_a != 0) atomicAdd(&w.q_hits_a[q], sum_a);
+}
+
+// SPLIT: the lane runs the head of the range function only — one line of the n-gram tables, which decides five starts out of six —
+// and queues what is left for k_probe_tail (round 5: with everything in one kernel every wave ran the bisection loop, three to
+// four dependent levels of key loads and compares, for the one lane in eight that needed it).
+template <bool COUNT, bool SPLIT>
+__global__ void __launch_bounds__(kProbeBlock) k_probe(DevIndex ix, DevBatch b, DevWork w, uint32_t heavy_min, HeavyItem* items_h,
+                                              uint32_t item_h_cap, ProbeItem* tail_items) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pass_refused(w)) return;
+  const bool in = t < b.nt;
+  const uint32_t q = in ? w.t_q[t] : 0xffffffffu;
+  uint32_t lo = 0, hi = 0, p = 0, m = 0, from = kHeadDone;
+  ProbeTally tally;
+  tally.bytes = 16 + 12;  // t_q, q_m, two offsets; t_lo / t_cnt written, the hit totals
+  tally.lines = 0;
+  if (in) {
+    const uint32_t msl = w.q_m[q];
+    const uint32_t o0 = b.q_off[b.q_begin + q] - b.t_begin;
+    p = b.q_off[b.q_begin + q + 1] - b.t_begin - o0;
+    const uint32_t it = t - o0;
+    if (msl != kNoMatchLen) {
+      m = seed_len(p, msl);
+      // register_suffix_range_match ignores match_length < _min_seq_len (src/ngram_matches.cc:65-66);
+      // with p == 1 the only registered length is 1.
+      const bool reachable = (p == 1) ? (msl <= 1) : true;
+      if (reachable && it + m <= p) {
+        const uint32_t* ngram = b.q_tok + b.t_begin + t;
+        if constexpr (SPLIT) {
+          uint32_t ng[kKeyTokens + 1];
+          tally_add(COUNT ? &tally : nullptr, 4 * (m < kKeyTokens + 1 ? m : kKeyTokens + 1));  // the seed n-gram itself
+#pragma unroll
+          for (uint32_t k = 0; k <= kKeyTokens; k++) ng[k] = k < m ? ngram[k] : 0u;
+          from = mgram_range_head(ix.gram, ix.qva, ix.n_qva, ng, m, lo, hi, COUNT ? &tally : nullptr);
+        } else {
+          mgram_range_hashed(ix.gram, ix.suf_key, ix.suf, ix.tok, ix.qva, ix.n_qva, ngram, m, lo, hi, COUNT ? &tally : nullptr);
+        }
+      }
+    }
+  }
+  if (COUNT) {
+    unsigned long long tb = in ? tally.bytes : 0u, tl = in ? tally.lines : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { tb += __shfl_xor(tb, d, 64); tl += __shfl_xor(tl, d, 64); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&w.counters[19], tb); atomicAdd(&w.counters[20], tl); }
+  }
+  const bool defer = SPLIT && from != kHeadDone;
+  if constexpr (SPLIT) {
+    const unsigned long long dm = __ballot(defer);
+    if (dm) {
+      const uint32_t lane = lane_id();
+      unsigned long long base = 0;
+      const uint32_t list = blockIdx.x % (uint32_t)kTailLists;
+      if (lane == 0) base = atomicAdd(&w.counters[kCtrProbeTail + list], (unsigned long long)__popcll(dm));
+      base = uni(base) + (unsigned long long)list * probe_tail_list_cap(b.nt);
+      if (defer) {
+        ProbeItem pi; pi.t = t; pi.from_m = from | (m << 8);
+        tail_items[base + __popcll(dm & ((1ull << lane) - 1ull))] = pi;
+        w.t_lo[t] = lo; w.t_cnt[t] = hi - lo;  // the range the tail is to search
+      }
+    }
+  }
+  probe_emit(b, w, t, q, p, in && !defer, lo, hi, heavy_min, items_h, item_h_cap);
+}
+
+// The tail of the probe: one lane per queued start position (grid-stride: the host does not know how many there are), full waves.
+constexpr uint32_t kProbeTailPer = 32;  // workgroups per list
+constexpr uint32_t kProbeTailGrid = kTailLists * kProbeTailPer;
+template <bool COUNT>
+__global__ void __launch_bounds__(kWave) k_probe_tail(DevIndex ix, DevBatch b, DevWork w, uint32_t heavy_min, HeavyItem* items_h,
+                                                      uint32_t item_h_cap, const ProbeItem* tail_items) {
+  const uint32_t list = blockIdx.x % (uint32_t)kTailLists;
+  const unsigned long long n = w.counters[kCtrProbeTail + list];
+  tail_items += (unsigned long long)list * probe_tail_list_cap(b.nt);
+  for (unsigned long long i0 = (unsigned long long)(blockIdx.x / kTailLists) * kWave; i0 < n; i0 += (unsigned long long)kProbeTailPer * kWave) {
+    const unsigned long long i = i0 + lane_id();
+    const bool in = i < n;
+    uint32_t t = 0, q = 0xffffffffu, p = 0, lo = 0, hi = 0;
+    ProbeTally tally;
+    tally.bytes = 0; tally.lines = 0;
+    if (in) {
+      const ProbeItem pi = tail_items[i];
+      t = pi.t;
+      const uint32_t from = pi.from_m & 0xffu, m = pi.from_m >> 8;
+      q = w.t_q[t];
+      p = b.q_off[b.q_begin + q + 1] - b.q_off[b.q_begin + q];
+      const uint32_t* ngram = b.q_tok + b.t_begin + t;
+      uint32_t ng[kKeyTokens + 1];
+#pragma unroll
+      for (uint32_t k = 0; k <= kKeyTokens; k++) ng[k] = k < m ? ngram[k] : 0u;
+      const uint32_t r_lo = w.t_lo[t], r_hi = r_lo + w.t_cnt[t];
+      mgram_range_tail(ix.gram, ix.suf_key, ix.suf, ix.tok, ix.qva, ix.n_qva, ngram, ng, m, from, r_lo, r_hi, lo, hi, COUNT ? &tally : nullptr);
+    }
+    if (COUNT) {
+      unsigned long long tb = tally.bytes, tl = tally.lines;
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) { tb += __shfl_xor(tb, d, 64); tl += __shfl_xor(tl, d, 64); }
+      if (lane_id() == 0) { atomicAdd(&w.counters[19], tb); atomicAdd(&w.counters[20], tl); }
+    }
+    probe_emit(b, w, t, q, p, in, lo, hi, heavy_min, items_h, item_h_cap);
+  }
 }
 
 // Signature bit planes and length thermometer planes of the suffix array (index build, once per upload): one wave per
@@ -527,11 +628,6 @@ __global__ void __launch_bounds__(kScanThreads) k_caps_scan(DevBatch b, DevWork 
 // whose word it sees; the marked count equals the reference's sum of per-word counts.
 // A wave-uniform value loaded through the vector memory path, moved to scalar registers (frees VGPRs and
 // lets address arithmetic on it run on the scalar unit).
-__device__ __forceinline__ uint32_t uni(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
-__device__ __forceinline__ unsigned long long uni(unsigned long long x) {
-  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)x), hi = __builtin_amdgcn_readfirstlane((uint32_t)(x >> 32));
-  return ((unsigned long long)hi << 32) | lo;
-}
 
 // Ordering point for LDS traffic inside a single-wave workgroup: the LDS executes one wave's requests in
 // program order, so only the compiler has to be kept from moving accesses across; no memory-counter wait and
@@ -565,15 +661,28 @@ constexpr uint32_t kCminExt = 40;     // after the 256 thresholds: tmin, a spare
 constexpr uint32_t kCminRow = kCminTab + kCminExt;
 constexpr uint32_t kMaxPlanes = 8;    // bit planes of the per-bucket position counts (counts < 256)
 
-// Per-work-item hash set of the pattern's distinct words (p <= 64): slot -> distinct index, and the number
-// of pattern positions per distinct word.  count_covered_words becomes one LDS probe per sentence token.
+// Per-work-item hash table of the pattern's words (p <= 64): word -> the pattern positions that hold it, as a bit mask.
+// count_covered_words (src/pattern_coverage.cc:15-28: every distinct pattern word found in the sentence counts with the number of
+// its positions) is then the popcount of the OR of the masks of the sentence's tokens: one LDS probe per token, nothing to weigh.
+// (Until round 5 the table held a distinct-word index and the per-word counts went through seven ballot planes: 115 instructions
+// per query to build, a weighted popcount per survivor.)
 constexpr uint32_t kHashSlots = 128;
 constexpr uint32_t kHashEmpty = 0xffffffffu;
 
 struct PatHash {
   uint32_t key[kHashSlots];
-  uint32_t idx[kHashSlots];
-  uint32_t cnt[kWave];
+  unsigned long long mask[kHashSlots];
+};
+// Patterns of up to 32 tokens (93 % of C3's): {word, mask} in one 8-byte slot, and a probe reads the home slot and its successor
+// with ONE ds_read2_b64 and no loop — slot 128 mirrors slot 0, and a table in which some word sits further than one slot from
+// home (pat_hash_build32 returns false: rare at a quarter full) is probed by the loop instead.
+struct PatSlot { uint32_t key, mask; };
+struct PatHash32 {
+  PatSlot s[kHashSlots + 1];
+};
+union PatTable {
+  PatHash h64;
+  PatHash32 h32;
 };
 
 __device__ __forceinline__ uint32_t pat_hash_slot(uint32_t w) { return (w * 0x85EBCA6Bu) >> 25; }
@@ -582,7 +691,7 @@ __device__ __forceinline__ uint32_t pat_hash_slot(uint32_t w) { return (w * 0x85
 __device__ __forceinline__ void pat_hash_build(PatHash& ph, const uint32_t* s_pat, uint32_t p) {
   const uint32_t lane = lane_id();
   ph.key[lane] = kHashEmpty; ph.key[lane + 64] = kHashEmpty;
-  ph.cnt[lane] = 0;
+  ph.mask[lane] = 0ull; ph.mask[lane + 64] = 0ull;
   wave_lds_sync();
   if (lane < p) {
     const uint32_t wd = s_pat[lane];
@@ -592,25 +701,33 @@ __device__ __forceinline__ void pat_hash_build(PatHash& ph, const uint32_t* s_pa
       if (old == kHashEmpty || old == wd) break;
       h = (h + 1) & (kHashSlots - 1);
     }
+    atomicOr(&ph.mask[h], 1ull << lane);
   }
   wave_lds_sync();
-  // distinct indices: rank of the occupied slots
-  uint32_t base = 0;
-#pragma unroll
-  for (int half = 0; half < 2; half++) {
-    const bool occ = ph.key[lane + 64 * half] != kHashEmpty;
-    const unsigned long long m = __ballot(occ);
-    if (occ) ph.idx[lane + 64 * half] = base + __popcll(m & ((1ull << lane) - 1ull));
-    base += __popcll(m);
-  }
+}
+
+// one wave, p <= 32; true: every word sits in its home slot or the next one
+__device__ __forceinline__ bool pat_hash_build32(PatHash32& ph, const uint32_t* s_pat, uint32_t p) {
+  const uint32_t lane = lane_id();
+  PatSlot e; e.key = kHashEmpty; e.mask = 0u;
+  ph.s[lane] = e; ph.s[lane + 64] = e;
   wave_lds_sync();
+  bool far = false;
   if (lane < p) {
     const uint32_t wd = s_pat[lane];
-    uint32_t h = pat_hash_slot(wd);
-    while (ph.key[h] != wd) h = (h + 1) & (kHashSlots - 1);
-    atomicAdd(&ph.cnt[ph.idx[h]], 1u);
+    uint32_t h = pat_hash_slot(wd), d = 0;
+    for (;;) {
+      const uint32_t old = atomicCAS(&ph.s[h].key, kHashEmpty, wd);
+      if (old == kHashEmpty || old == wd) break;
+      h = (h + 1) & (kHashSlots - 1); d++;
+    }
+    atomicOr(&ph.s[h].mask, 1u << lane);
+    far = d > 1;
   }
   wave_lds_sync();
+  if (lane == 0) ph.s[kHashSlots] = ph.s[0];
+  wave_lds_sync();
+  return __ballot(far) == 0ull;
 }
 
 constexpr int kUnroll = FMX_UNROLL;  // hits per lane per phase-A iteration
@@ -1051,9 +1168,6 @@ constexpr uint32_t kHeavyList = 2 * kWave;  // LDS list of plane-test survivors 
 #ifndef FMX_HEAVY_WAVES
 #define FMX_HEAVY_WAVES 8
 #endif
-#ifndef FMX_B_LDS_CPL
-#define FMX_B_LDS_CPL 1
-#endif
 #ifndef FMX_PHASEB_WAVES
 #define FMX_PHASEB_WAVES 5
 #endif
@@ -1339,13 +1453,17 @@ __global__ void __launch_bounds__(kScanThreads) k_seg_scan(DevBatch b, DevWork w
 // queries with more than 64 survivors 41 -> 339 per step), and what follows pays more than was saved: candidate kernels
 // 0.15 -> 0.48 ms, edit distances 0.58 -> 0.87, replay 0.46 -> 0.60 — one call at a time 179 -> 163 M patterns/s, six in flight
 // 203 -> 196 M.  Removed; profiles/r04_c3_defer_cover_*.json keep the two lines.)
+#ifdef FMX_LIGHT_STATS
+__device__ unsigned long long g_light_stats[1024];  // design-time histograms of the light queries (tools/dbg/light_stats.py)
+#endif
 template <bool LIGHT>
 __global__ void __launch_bounds__(kWave, LIGHT ? FMX_LIGHT_WAVES : FMX_PHASEB_WAVES) k_expand_b(DevIndex ix, DevBatch b, DevWork w, Params prm,
                                                        const WorkItem* items, uint32_t item_cap, uint32_t first_q_blocks,
                                                        uint32_t flat_max) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t* s_pat = (uint32_t*)smem;
-  __shared__ PatHash ph;
+  __shared__ PatTable pt;
+  PatHash& ph = pt.h64;
   // LIGHT: one block of 64 hits at a time (most light queries have no more), which keeps the kernel within 64 VGPRs and
   // 5 KB of LDS: eight waves per SIMD hide the two dependent loads in front of the token work
   constexpr int kBU = LIGHT ? 1 : kBUnroll;
@@ -1359,7 +1477,6 @@ __global__ void __launch_bounds__(kWave, LIGHT ? FMX_LIGHT_WAVES : FMX_PHASEB_WA
   __shared__ uint32_t s_nlo[LIGHT ? kWave : 1];
   __shared__ uint32_t s_nit[LIGHT ? kWave : 1];
   __shared__ __attribute__((aligned(8))) uint16_t s_cmin[LIGHT ? kCminTab : 4];
-  __shared__ unsigned long long s_cpl[LIGHT ? 1 : 7];
   const uint32_t lane0 = lane_id();
   uint32_t q, chunk;
   uint32_t item_idx = 0;
@@ -1455,11 +1572,16 @@ __global__ void __launch_bounds__(kWave, LIGHT ? FMX_LIGHT_WAVES : FMX_PHASEB_WA
       for (uint32_t j = lane; j < p; j += kWave) s_pat[j] = pat[j];
       load_recs();
       wave_lds_sync();
-      if (p <= kWave) pat_hash_build(ph, s_pat, p);
+      bool near32 = false;  // the pattern's table is the 32-bit one and needs no probe loop
+      if (p <= 32) near32 = pat_hash_build32(pt.h32, s_pat, p);
+      if (p <= kWave && !near32) pat_hash_build(ph, s_pat, p);  // (also: a 32-bit table with a word far from home, rebuilt)
       // Two stages per block of kWave * kBU queued hits.  Stage 1: the dominance test (about two thirds
       // of the queued hits fail it) compacts the survivors into LDS.  Stage 2: full waves of survivors do
       // the token work (match length + exact coverage), not diluted by dominated hits.
       uint32_t n_s = 0;
+#ifdef FMX_LIGHT_STATS
+      uint32_t ns_tot = 0;
+#endif
       // survivors of the token work go to the LDS set (while they fit one wave) or to the query's segment
       auto append = [&](bool keep, uint32_t sid, uint32_t L, uint32_t tb, uint32_t sl) {
         const unsigned long long mask = __ballot(keep);
@@ -1517,24 +1639,8 @@ __global__ void __launch_bounds__(kWave, LIGHT ? FMX_LIGHT_WAVES : FMX_PHASEB_WA
       // compare / probe interleaved tokens; the match length is the first mismatch any of them sees, the
       // coverage the weighted popcount of the union of their "distinct pattern words seen" masks.
       constexpr uint32_t kSubLanes = 4, kSubSurv = kWave / kSubLanes;
-      unsigned long long cplanes[7];
-      uint32_t n_cpl = 0;
-      if (p <= kWave) {
-        const uint32_t mycnt = ph.cnt[lane];  // positions per distinct pattern word (0 beyond the distinct count)
-#pragma unroll
-        for (uint32_t k = 0; k < 7; k++) {
-          cplanes[k] = __ballot((mycnt >> k) & 1u);
-          if (cplanes[k]) n_cpl = k + 1;
-        }
-        if constexpr (FMX_B_LDS_CPL && !LIGHT) {  // fourteen scalar registers for the length of the item: parked in LDS, read where a pass weighs its masks
-          if (lane == 0) {
-#pragma unroll
-            for (uint32_t k = 0; k < 7; k++) s_cpl[k] = cplanes[k];
-          }
-          wave_lds_sync();
-        }
-      }
-      auto heavy4 = [&](uint32_t j0, uint32_t n_act) {
+      auto heavy4_t = [&](uint32_t j0, uint32_t n_act, auto tag) __attribute__((always_inline)) {
+        constexpr int kTab = decltype(tag)::value;  // 0: 64-bit masks, probe loop; 2: 32-bit table, two slots, no loop
         const uint32_t sub = lane / kSubLanes, part = lane % kSubLanes;
         const bool act = sub < n_act;
         SurvB sv;
@@ -1576,42 +1682,60 @@ __global__ void __launch_bounds__(kWave, LIGHT ? FMX_LIGHT_WAVES : FMX_PHASEB_WA
             else k0 += kSubLanes;
           }
         }
-        // coverage: distinct pattern words present in the sentence
-        unsigned long long seen = 0;
-        if (act && L < p) {
-          auto probe = [&](uint32_t t) {
-            uint32_t h = pat_hash_slot(t);
-            uint32_t key = ph.key[h];
-            while (key != t && key != kHashEmpty) { h = (h + 1) & (kHashSlots - 1); key = ph.key[h]; }
-            if (key == t) seen |= 1ull << ph.idx[h];
-          };
+        // coverage: pattern positions whose word is present in the sentence
+        uint32_t cover = 0;
+        if constexpr (kTab == 0) {
+          unsigned long long seen = 0;
+          if (act && L < p) {
+            auto probe = [&](uint32_t t) {
+              uint32_t h = pat_hash_slot(t);
+              uint32_t key = ph.key[h];
+              while (key != t && key != kHashEmpty) { h = (h + 1) & (kHashSlots - 1); key = ph.key[h]; }
+              if (key == t) seen |= ph.mask[h];
+            };
 #pragma unroll
-          for (int u = 0; u < kCovAhead; u++)
-            if (part + u * kSubLanes < sl) probe(ct[u]);
-          for (uint32_t kb = part + kCovAhead * kSubLanes; kb < sl; kb += 4 * kSubLanes) {  // sentences of more than 32 tokens
-            uint32_t t[4];
+            for (int u = 0; u < kCovAhead; u++)
+              if (part + u * kSubLanes < sl) probe(ct[u]);
+            for (uint32_t kb = part + kCovAhead * kSubLanes; kb < sl; kb += 4 * kSubLanes) {  // sentences of more than 32 tokens
+              uint32_t t[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) t[u] = kb + u * kSubLanes < sl ? sent[kb + u * kSubLanes] : kHashEmpty;
+              for (int u = 0; u < 4; u++) t[u] = kb + u * kSubLanes < sl ? sent[kb + u * kSubLanes] : kHashEmpty;
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-              if (kb + u * kSubLanes >= sl) break;
-              probe(t[u]);
+              for (int u = 0; u < 4; u++) {
+                if (kb + u * kSubLanes >= sl) break;
+                probe(t[u]);
+              }
             }
           }
-        }
 #pragma unroll
-        for (uint32_t d = 1; d < kSubLanes; d <<= 1) {
-          const uint32_t lo = __shfl_xor((uint32_t)seen, d, 64), hi = __shfl_xor((uint32_t)(seen >> 32), d, 64);
-          seen |= ((unsigned long long)hi << 32) | lo;
-        }
-        uint32_t cover = 0;
-        if constexpr (FMX_B_LDS_CPL && !LIGHT) {
-#pragma unroll 1
-          for (uint32_t k = 0; k < n_cpl; k++) cover += (uint32_t)__popcll(seen & s_cpl[k]) << k;
+          for (uint32_t d = 1; d < kSubLanes; d <<= 1) {
+            const uint32_t lo = __shfl_xor((uint32_t)seen, d, 64), hi = __shfl_xor((uint32_t)(seen >> 32), d, 64);
+            seen |= ((unsigned long long)hi << 32) | lo;
+          }
+          cover = (uint32_t)__popcll(seen);
         } else {
+          const PatHash32& p32 = pt.h32;
+          uint32_t seen = 0;
+          auto probe = [&](uint32_t t) {
+            const uint32_t h = pat_hash_slot(t);
+            // padding tokens (kHashEmpty) meet an empty slot's zero mask or nothing: no guard needed
+            const PatSlot a = p32.s[h], b2 = p32.s[h + 1];
+            seen |= (a.key == t ? a.mask : 0u) | (b2.key == t ? b2.mask : 0u);
+          };
 #pragma unroll
-          for (uint32_t k = 0; k < 7; k++)
-            if (k < n_cpl) cover += (uint32_t)__popcll(seen & cplanes[k]) << k;
+          for (int u = 0; u < kCovAhead; u++) probe(ct[u]);
+          if (__ballot(act && sl > kCovAhead * kSubLanes)) {  // sentences of more than 32 tokens
+            for (uint32_t kb = part + kCovAhead * kSubLanes; kb < sl; kb += 4 * kSubLanes) {
+              uint32_t t[4];
+#pragma unroll
+              for (int u = 0; u < 4; u++) t[u] = kb + u * kSubLanes < sl ? sent[kb + u * kSubLanes] : kHashEmpty;
+#pragma unroll
+              for (int u = 0; u < 4; u++) probe(t[u]);
+            }
+          }
+#pragma unroll
+          for (uint32_t d = 1; d < kSubLanes; d <<= 1) seen |= __shfl_xor(seen, d, 64);
+          cover = (uint32_t)__popc(seen);
         }
         if (L >= p) cover = p;
         bool keep = act && part == 0;
@@ -1621,6 +1745,10 @@ __global__ void __launch_bounds__(kWave, LIGHT ? FMX_LIGHT_WAVES : FMX_PHASEB_WA
           else keep = !reject_len(p, sl, prm) && !reject_cover(p, sl, cover, prm);
         }
         append(keep, sv.sid, L, sv.off - (sl - rem), sl);
+      };
+      auto heavy4 = [&](uint32_t j0, uint32_t n_act) __attribute__((always_inline)) {
+        if (near32) heavy4_t(j0, n_act, std::integral_constant<int, 2>{});
+        else heavy4_t(j0, n_act, std::integral_constant<int, 0>{});
       };
       const uint32_t pass = p <= kWave ? kSubSurv : kWave;  // survivors per pass of the token work
       for (uint32_t e0 = e_lo; e0 < e_hi;) {
@@ -1644,6 +1772,9 @@ __global__ void __launch_bounds__(kWave, LIGHT ? FMX_LIGHT_WAVES : FMX_PHASEB_WA
             s_surv[n_s + __popcll(mask & ((1ull << lane) - 1ull))] = sv;
           }
           n_s += __popcll(mask);
+#ifdef FMX_LIGHT_STATS
+          ns_tot += __popcll(mask);
+#endif
         }
         e0 += kWave * kBU;
         const bool more = e0 < e_hi;
@@ -1701,6 +1832,19 @@ __global__ void __launch_bounds__(kWave, LIGHT ? FMX_LIGHT_WAVES : FMX_PHASEB_WA
       } else if (sole && lane == 0) {
         w.q_kept[q] = n_out;
       }
+#ifdef FMX_LIGHT_STATS
+      if (LIGHT && lane == 0) {
+        auto bk = [](uint32_t v) { return v <= 4 ? v : (v <= 8 ? 5u : (v <= 16 ? 6u : 7u)); };
+        const uint32_t pc = p <= 16 ? 0u : (p <= 32 ? 1u : (p <= 64 ? 2u : 3u));
+        atomicAdd(&g_light_stats[n_q < 256 ? n_q : 256], 1ull);                  // [0, 257): hits
+        atomicAdd(&g_light_stats[300 + (ns_tot < 64 ? ns_tot : 64)], 1ull);      // [300, 365): survivors of dominance + length
+        atomicAdd(&g_light_stats[400 + (n_out < 64 ? n_out : 64)], 1ull);        // [400, 465): kept after coverage
+        atomicAdd(&g_light_stats[500 + pc * 8 + bk(ns_tot)], 1ull);              // [500, 532): pattern class x survivors
+        atomicAdd(&g_light_stats[540 + bk(ns_tot) * 8 + bk(n_out)], 1ull);       // [540, 604): survivors x kept
+        atomicAdd(&g_light_stats[610 + (p < 100 ? p : 100)], 1ull);              // [610, 711): pattern length
+        atomicAdd(&g_light_stats[720 + pc * 8 + bk(n_out)], 1ull);               // [720, 752): pattern class x kept
+      }
+#endif
       if (LIGHT && lane == 0) w.q_pb[q] = n_q;  // statistics: the hits this kernel took over from phase A
     }
     if (!extra) return;

@@ -83,13 +83,6 @@ __global__ void __launch_bounds__(kWave) k_match_small(DevIndex ix, SmallArgs a,
   }
   wave_lds_sync();
   pat_hash_build(ph, s_pat, p);
-  unsigned long long cplanes[7];
-  uint32_t n_cpl = 0;
-  {
-    const uint32_t c = ph.cnt[lane];
-#pragma unroll
-    for (uint32_t k = 0; k < 7; k++) { cplanes[k] = __ballot((c >> k) & 1u); if (cplanes[k]) n_cpl = k + 1; }
-  }
   // ---- hit walk: records, dominance + length filter, then the token work four lanes per survivor ----
   constexpr uint32_t kSubLanes = 4, kSubSurv = kWave / kSubLanes;
   uint32_t n_out = 0, n_s = 0;
@@ -132,7 +125,7 @@ __global__ void __launch_bounds__(kWave) k_match_small(DevIndex ix, SmallArgs a,
         uint32_t h = pat_hash_slot(t);
         uint32_t key = ph.key[h];
         while (key != t && key != kHashEmpty) { h = (h + 1) & (kHashSlots - 1); key = ph.key[h]; }
-        if (key == t) seen |= 1ull << ph.idx[h];
+        if (key == t) seen |= ph.mask[h];
       };
 #pragma unroll
       for (int u = 0; u < kCovAhead; u++)
@@ -144,10 +137,7 @@ __global__ void __launch_bounds__(kWave) k_match_small(DevIndex ix, SmallArgs a,
       const uint32_t l2 = __shfl_xor((uint32_t)seen, d, 64), h2 = __shfl_xor((uint32_t)(seen >> 32), d, 64);
       seen |= ((unsigned long long)h2 << 32) | l2;
     }
-    uint32_t cover = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < 7; k++)
-      if (k < n_cpl) cover += (uint32_t)__popcll(seen & cplanes[k]) << k;
+    uint32_t cover = (uint32_t)__popcll(seen);
     if (L >= p) cover = p;
     // NGramMatches::theoretical_rejection / _cover, evaluated exactly (the pipeline's tabulated thresholds are these)
     const bool keep = act && part == 0 && !reject_len(p, sl, prm) && !reject_cover(p, sl, cover, prm);
