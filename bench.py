@@ -77,13 +77,14 @@ def parse_args():
                     help="auto = strong when WORLD_SIZE > 1 (BASELINE's C3 is ONE 1 M-query batch cut over 1/2/4/8 GPUs), weak at N = 1 (the same thing there)")
     ap.add_argument("--threads", type=int, default=int(os.environ.get("FMX_BENCH_THREADS", "6")), help="device-resident calls kept in flight (one host thread enqueues them)")
     ap.add_argument("--host-threads", type=int, default=int(os.environ.get("FMX_BENCH_HOST_THREADS", "4")),
-                    help="synchronous host-buffer calls in flight (one host thread each) — the `value` leg and the other PCIe-inclusive legs: each adds "
-                         "two copy streams to its two compute streams, and beyond ~24 busy hardware queues the GPU's scheduler starts time-slicing them")
+                    help="synchronous host-buffer calls in flight (one host thread each) — the side legs `text_sync_callers`, `pcie_inclusive_ids`, "
+                         "`from_token_strings` (the library admits at most max_host_active = 4 of them at once whatever this says)")
     ap.add_argument("--text-calls", type=int, default=int(os.environ.get("FMX_BENCH_TEXT_CALLS", "4")),
-                    help="text batches the value leg keeps in flight (fmx_match_batch_text_begin / _end, one host thread).  Four: ten busy hardware "
-                         "queues (two compute streams per call + the index's pair of copy streams).  Five run as fast in the steady state "
-                         "(5.9 ms per step either way) but spend their first seconds after the index build at 300 ms per step, six stay erratic and "
-                         "eight crawl throughout: beyond about a dozen recently active queues the GPU's scheduler time-slices them")
+                    help="text batches the value leg keeps in flight (fmx_match_batch_text_begin / _end, one host thread).  Four.  Round 5 traced "
+                         "the 'cliff' of rounds 2-4: five or six calls begun back to back on an idle GPU make the FIRST take 13-340 ms (the library "
+                         "now starts host-buffer calls 0.5 ms apart, which avoids it: tools/dbg/text_host_time.py), seven and more crawl whatever the "
+                         "stream layout.  Over 20 steps from an idle pipeline: four 5.35-5.40 ms per step, five 5.19-5.27 — but the side legs "
+                         "that follow five then run at 6-9 ms instead of 4.9, so four stays the default")
     ap.add_argument("--batches", type=int, default=0, help="distinct query batches rotated through the steps (0 = calls in flight + 1)")
     ap.add_argument("--force-gather", action="store_true", help="N = 1 test of the N > 1 step: records also kept in HBM for the (empty) gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -538,6 +539,15 @@ def main():
     # ---- THE METRIC: SURVEY §8(d)'s bracket.  Packed spellings in pinned host memory -> H2D -> k_vocab_lookup -> pipeline -> D2H ----
     def measure_text(wls, leg):
         gather = make_gather(wls)
+        # one host thread pipelining _begin / _end may keep more host-buffer calls active than the library admits by default (4:
+        # the bound that keeps sixteen synchronous callers off the scheduler cliff); the option goes back after the leg
+        ix.set_option("max_host_active", max(4, T_text))
+        try:
+            return measure_text_admitted(wls, leg, gather)
+        finally:
+            ix.set_option("max_host_active", 4)
+
+    def measure_text_admitted(wls, leg, gather):
         settle(lambda k: run_text_pipeline(wls, k, gather), 2 * T_text)
         run_text_pipeline(wls, args.warmup, gather)
         el, _ = timed(lambda k: run_text_pipeline(wls, k, gather), args.steps)

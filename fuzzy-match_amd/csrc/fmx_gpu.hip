@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <thread>
 #include <condition_variable>
 #include <deque>
 #include <exception>
@@ -158,6 +159,19 @@ struct DevBlob {
 // contexts or indexes exist.  A pair goes back idle (its call was waited for) and is handed out again as it is.
 struct StreamPool {
   std::mutex mu;
+  // Host-buffer calls of a device START at least `spacing` apart (round 5).  Five or six of them begun back to back on an idle
+  // GPU — a caller filling its pipeline — made the FIRST of them take 13-340 ms instead of ~10 (tools/dbg/text_host_time.py: the
+  // kernels run at their usual speed, the GPU idles in between); begun half a millisecond apart they never did.  In the steady
+  // state calls begin a step apart and nothing waits.
+  std::mutex pace_mu;
+  std::chrono::steady_clock::time_point last_host_begin{};
+  void pace(std::chrono::microseconds spacing) {
+    if (spacing.count() <= 0) return;
+    std::lock_guard<std::mutex> g(pace_mu);
+    const auto due = last_host_begin + spacing;
+    if (std::chrono::steady_clock::now() < due) std::this_thread::sleep_until(due);
+    last_host_begin = std::chrono::steady_clock::now();
+  }
   std::vector<std::pair<hipStream_t, hipStream_t>> idle;
   hipStream_t h2d = nullptr, d2h = nullptr;
   bool copy_tried = false;
@@ -252,7 +266,7 @@ struct Ctx {
   // ---- streams / events ----
   hipStream_t stream = nullptr, h2d = nullptr, d2h = nullptr, side = nullptr;
   hipEvent_t  ev[2 * kNumStages]{};   // [2 s], [2 s + 1]: start / end of stage s (the last stage's pair lives on the side stream)
-  hipEvent_t  ev_fork = nullptr, ev_join = nullptr, ev_cmin = nullptr, ev_a = nullptr, ev_in[kMaxPassesInFlight]{}, ev_done = nullptr;
+  hipEvent_t  ev_fork = nullptr, ev_join = nullptr, ev_cmin = nullptr, ev_a = nullptr, ev_ids = nullptr, ev_in[kMaxPassesInFlight]{}, ev_done = nullptr;
   hipEvent_t  ev_chain = nullptr;  // the last kernel of a call's first group (what the next call waits for on the GPU: a plain event —
                                    // the ev_pass events are made for a sleeping host and are slow to wait for from another stream)
   hipEvent_t  ev_mid = nullptr;  // the memory-bound half of a pass (probe, long ranges) is through: the next call's probe may start (turns = 2)
@@ -319,6 +333,7 @@ struct Ctx {
     HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&ev_cmin, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&ev_ids, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&ev_a, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&ev_mid, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&ev_chain, hipEventDisableTiming));
@@ -345,6 +360,7 @@ struct Ctx {
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
     if (ev_cmin) (void)hipEventDestroy(ev_cmin);
+    if (ev_ids) (void)hipEventDestroy(ev_ids);
     if (ev_a) (void)hipEventDestroy(ev_a);
     if (ev_mid) (void)hipEventDestroy(ev_mid);
     if (ev_chain) (void)hipEventDestroy(ev_chain);
@@ -444,9 +460,10 @@ struct DeviceIndex::Impl {
   std::vector<Ctx*>       idle;
   // Admission (round 5).  How many calls may have work on the GPU at once is a property of the GPU, not of how many contexts a
   // caller asked for: every host-buffer call in flight keeps two compute queues and the index's pair of copy queues busy, and
-  // beyond about a dozen recently active hardware queues the GPU's scheduler time-slices them — five callers spend their first
-  // seconds after an index build at ~300 ms per step, eight crawl throughout.  So at most max_host_active
-  // host-buffer calls hold a context at any time whatever "contexts" says; further synchronous callers wait HERE, on the host, and
+  // with eight of them (sixteen compute queues) every kernel of every call crawls (600-900 ms per step at C3).  So at
+  // most max_host_active host-buffer calls hold a context at any time whatever "contexts" says.  Four: sixteen SYNCHRONOUS callers
+  // (threads) capped at five took 190-600 ms for what four take in 37 (tests/test_gpu_text_batch.py); ONE thread that pipelines
+  // _begin / _end calls can raise the option to five — its calls start apart (StreamPool::pace), which is what bench.py does; further synchronous callers wait HERE, on the host, and
   // further _begin calls are deferred (DeferredCall) and started, in order, by whoever frees a slot.
   uint32_t                max_host_active = [] { const char* e = getenv("FMX_MAX_HOST_ACTIVE"); return e ? (uint32_t)std::max(atoi(e), 1) : 4u; }();
   uint32_t                host_active = 0;
@@ -1945,32 +1962,38 @@ struct DeviceIndex::HostCall {
     if (s == 0 && !first_sent) send(0);
     HIP_TRY(hipStreamWaitEvent(c.stream, c.ev_in[s % kMaxPassesInFlight], 0));
     if (s == 0 && hb.text && hb.n_text) {  // spellings -> ids, for every pass of the call
+      // On the call's SIDE lane (high priority), which waits for the text only: the main lane may be chained behind the call
+      // before this one (Impl::turns), and the look-up — 0.3 ms alone — used to queue behind that event and then run for 2-3 ms
+      // beside the predecessor's kernels before this call's first kernel could start (round 5, traced).
+      const hipStream_t ls = (m.serial || !c.side) ? c.stream : c.side;
+      if (ls != c.stream) HIP_TRY(hipStreamWaitEvent(ls, c.ev_in[s % kMaxPassesInFlight], 0));
       unsigned long long* d_total = nullptr;
       HIP_TRY(hipHostGetDevicePointer((void**)&d_total, c.h_vtotal, 0));
       uint32_t* tile_count = reinterpret_cast<uint32_t*>(c.d_vstate.p);
       // a text with fewer spellings than the offsets count leaves the tail of the ids untouched: VOCAB_UNK there, not whatever the
       // buffer held (the call still fails after the synchronisation, but no kernel runs on garbage)
-      if (nt) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)c.d_qtok.p, 1, nt, c.stream));
-      hipLaunchKernelGGL(k_vocab_count, dim3((unsigned)text_tiles), dim3(kScanThreads), 0, c.stream, (const unsigned char*)c.d_text.p,
+      if (nt) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)c.d_qtok.p, 1, nt, ls));
+      hipLaunchKernelGGL(k_vocab_count, dim3((unsigned)text_tiles), dim3(kScanThreads), 0, ls, (const unsigned char*)c.d_text.p,
                          (unsigned long long)hb.n_text, tile_count);
-      hipLaunchKernelGGL(k_vocab_scan, dim3(1), dim3(kScanThreads), 0, c.stream, tile_count, (uint32_t)text_tiles, d_total);
-      hipLaunchKernelGGL(k_vocab_lookup, dim3((unsigned)text_tiles), dim3(kScanThreads), 0, c.stream, (const unsigned char*)c.d_text.p,
+      hipLaunchKernelGGL(k_vocab_scan, dim3(1), dim3(kScanThreads), 0, ls, tile_count, (uint32_t)text_tiles, d_total);
+      hipLaunchKernelGGL(k_vocab_lookup, dim3((unsigned)text_tiles), dim3(kScanThreads), 0, ls, (const unsigned char*)c.d_text.p,
                          (unsigned long long)hb.n_text, (unsigned long long)nt, text_snap.vocab, c.d_qtok.p, (const uint32_t*)tile_count, 1u);
       if (text_real) {
         constexpr uint32_t kNoReal = 0x7ffffffeu;  // HostIndex::lookup_real's "not a real token of this index"
-        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)c.d_qreal.p, (int)kNoReal, nt, c.stream));
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)c.d_qreal.p, (int)kNoReal, nt, ls));
         if (hb.real_text) {  // a second stream of spellings, one per pattern token: counted (the call fails on a mismatch) and looked up
           uint32_t* tile_count_r = reinterpret_cast<uint32_t*>(c.d_vstate_r.p);
-          hipLaunchKernelGGL(k_vocab_count, dim3((unsigned)text_tiles_r), dim3(kScanThreads), 0, c.stream, (const unsigned char*)c.d_text_r.p,
+          hipLaunchKernelGGL(k_vocab_count, dim3((unsigned)text_tiles_r), dim3(kScanThreads), 0, ls, (const unsigned char*)c.d_text_r.p,
                              (unsigned long long)hb.n_real_text, tile_count_r);
-          hipLaunchKernelGGL(k_vocab_scan, dim3(1), dim3(kScanThreads), 0, c.stream, tile_count_r, (uint32_t)text_tiles_r, d_total + 1);
-          hipLaunchKernelGGL(k_vocab_lookup, dim3((unsigned)text_tiles_r), dim3(kScanThreads), 0, c.stream, (const unsigned char*)c.d_text_r.p,
+          hipLaunchKernelGGL(k_vocab_scan, dim3(1), dim3(kScanThreads), 0, ls, tile_count_r, (uint32_t)text_tiles_r, d_total + 1);
+          hipLaunchKernelGGL(k_vocab_lookup, dim3((unsigned)text_tiles_r), dim3(kScanThreads), 0, ls, (const unsigned char*)c.d_text_r.p,
                              (unsigned long long)hb.n_real_text, (unsigned long long)nt, m.real_vocab, c.d_qreal.p, (const uint32_t*)tile_count_r, kNoReal);
         } else {             // the pattern tokens' own spellings, against the real-token table (same token starts, same ranks)
-          hipLaunchKernelGGL(k_vocab_lookup, dim3((unsigned)text_tiles), dim3(kScanThreads), 0, c.stream, (const unsigned char*)c.d_text.p,
+          hipLaunchKernelGGL(k_vocab_lookup, dim3((unsigned)text_tiles), dim3(kScanThreads), 0, ls, (const unsigned char*)c.d_text.p,
                              (unsigned long long)hb.n_text, (unsigned long long)nt, m.real_vocab, c.d_qreal.p, (const uint32_t*)tile_count, kNoReal);
         }
       }
+      if (ls != c.stream) { HIP_TRY(hipEventRecord(c.ev_ids, ls)); HIP_TRY(hipStreamWaitEvent(c.stream, c.ev_ids, 0)); }
     }
     if (s + 1 < n_sub) send(s + 1);  // travels while pass s computes
   }
@@ -2081,6 +2104,8 @@ struct DeviceIndex::HostCall {
     d2h = inline_copies ? c.stream : c.d2h;
     // (small calls — the coalescer's micro-batches, interactive callers, shards of a strongly scaled batch — do not fill the GPU
     // for long and simply overlap: measured at 100 k and 125 k queries per call, 103 M patterns/s against 95 M chained)
+    static const int spacing_us = [] { const char* e = getenv("FMX_HOST_SPACING_US"); return e ? atoi(e) : 500; }();
+    if (nq >= kTurnMinQueriesHost) stream_pool(m.device).pace(std::chrono::microseconds(spacing_us));
     turns = nq >= kTurnMinQueriesHost ? m.turns : 0u;
     if (no_wait && turns >= 3) turns = 0;  // (turns taken on the host would block the one thread that holds the other pending calls)
     if (turns == 1 || turns == 2) {

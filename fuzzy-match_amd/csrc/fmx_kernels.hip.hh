@@ -2076,6 +2076,9 @@ __global__ void __launch_bounds__(256) k_cand_mid(DevWork w, const uint32_t* mid
   }
 }
 
+#ifndef FMX_BIG_RU
+#define FMX_BIG_RU 4
+#endif
 constexpr int kBigThreads = 1024;
 constexpr int kBigWaves = kBigThreads / 64;
 constexpr int kBigGrid = 512;
@@ -2118,7 +2121,7 @@ __device__ __forceinline__ void block_radix_pass(const unsigned long long* src, 
   const uint32_t end = beg + len < n ? beg + len : n;
   for (uint32_t i = tid; i < kBigWaves * 256; i += kBigThreads) s_hist[i] = 0;
   __syncthreads();
-  constexpr int kRU = 4;  // keys requested together: both loops are chains of global-load latencies otherwise
+  constexpr int kRU = FMX_BIG_RU;  // keys requested together: both loops are chains of global-load latencies otherwise
   for (uint32_t i0 = beg; i0 < end; i0 += 64 * kRU) {
     unsigned long long kk[kRU];
 #pragma unroll
