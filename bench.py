@@ -34,6 +34,7 @@ import concurrent.futures as cf
 import csv
 import datetime
 import glob
+import gc
 import json
 import os
 import shutil
@@ -79,12 +80,12 @@ def parse_args():
     ap.add_argument("--host-threads", type=int, default=int(os.environ.get("FMX_BENCH_HOST_THREADS", "4")),
                     help="synchronous host-buffer calls in flight (one host thread each) — the side legs `text_sync_callers`, `pcie_inclusive_ids`, "
                          "`from_token_strings` (the library admits at most max_host_active = 4 of them at once whatever this says)")
-    ap.add_argument("--text-calls", type=int, default=int(os.environ.get("FMX_BENCH_TEXT_CALLS", "4")),
-                    help="text batches the value leg keeps in flight (fmx_match_batch_text_begin / _end, one host thread).  Four.  Round 5 traced "
-                         "the 'cliff' of rounds 2-4: five or six calls begun back to back on an idle GPU make the FIRST take 13-340 ms (the library "
-                         "now starts host-buffer calls 0.5 ms apart, which avoids it: tools/dbg/text_host_time.py), seven and more crawl whatever the "
-                         "stream layout.  Over 20 steps from an idle pipeline: four 5.35-5.40 ms per step, five 5.19-5.27 — but the side legs "
-                         "that follow five then run at 6-9 ms instead of 4.9, so four stays the default")
+    ap.add_argument("--text-calls", type=int, default=int(os.environ.get("FMX_BENCH_TEXT_CALLS", "5")),
+                    help="text batches the value leg keeps in flight (fmx_match_batch_text_begin / _end, one host thread; the leg raises the "
+                         "library's max_host_active to this).  Five since round 5, which traced the 'cliff' of rounds 2-4: five or six calls begun "
+                         "back to back on an idle GPU make the FIRST take 13-340 ms (the library now starts host-buffer calls 0.5 ms apart, which "
+                         "avoids it: tools/dbg/text_host_time.py); seven and more crawl whatever the stream layout.  Over 20 steps from an idle "
+                         "pipeline: four 5.36-5.42 ms per step, five 5.19-5.28, six 5.76 (a longer fill and drain)")
     ap.add_argument("--batches", type=int, default=0, help="distinct query batches rotated through the steps (0 = calls in flight + 1)")
     ap.add_argument("--force-gather", action="store_true", help="N = 1 test of the N > 1 step: records also kept in HBM for the (empty) gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -312,6 +313,8 @@ def main():
     # first call (milliseconds), which must not land inside the timed region
     pool = cf.ThreadPoolExecutor(max(T_dev, 1))
 
+    call_trace = []
+
     def run_host_steps(wls, k_steps, kind, gather=None):
         """K synchronous host-buffer calls, T_host of them in flight: step i (batch i % len(wls)) is submitted when step i - T has
         returned, so the copies at both ends of one call overlap the kernels of the others.  kind: "text" = fmx_match_batch_text
@@ -324,6 +327,15 @@ def main():
         nb = len(wls)
 
         def one(i, keep):
+            if os.environ.get("FMX_BENCH_TRACE_CALLS"):   # design-time: when each synchronous call ran, and on which thread
+                import threading
+                a = time.perf_counter()
+                r = one_(i, keep)
+                call_trace.append((kind, i, threading.get_ident() % 1000, a, time.perf_counter(), r.ms_total))
+                return r
+            return one_(i, keep)
+
+        def one_(i, keep):
             wl = wls[i % nb]
             if kind == "text":
                 return ix.match_batch_text(params, wl.q_off, wl.text, cap=cap, want_stats=True, out=out_slots[i % T], keep=keep)[3]
@@ -376,11 +388,19 @@ def main():
                 break
 
     def timed(fn, k_steps):
-        sync()
-        t1 = time.perf_counter()
-        res = fn(k_steps)
-        sync()
-        el = time.perf_counter() - t1
+        # Python's cyclic garbage collector stays out of the timed regions (like timeit does it): a generation-2 collection of this
+        # process takes ~37 ms — every thread of the harness stops, the library's calls do not — and landed inside one leg or
+        # another in most runs: the "stalled" side legs of rounds 2-5 (found with FMX_BENCH_TRACE_CALLS, round 5)
+        gc.collect()
+        gc.disable()
+        try:
+            sync()
+            t1 = time.perf_counter()
+            res = fn(k_steps)
+            sync()
+            el = time.perf_counter() - t1
+        finally:
+            gc.enable()
         if world > 1:
             t = torch.tensor([el], dtype=torch.float64, device=cdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -580,11 +600,18 @@ def main():
     value = nq_step_all * args.steps / elapsed
     # ---- side legs ----
     # the same bracket from T_host synchronous callers (fmx_match_batch_text on as many host threads: the reference's calling pattern)
-    el_sync, text_stats = measure_host(host_set, "text", args.steps, "text_sync_callers")
-    text_sync = {"value": round(nq_step_all * args.steps / el_sync, 1), "ms_per_step": round(el_sync / args.steps * 1e3, 3), "calls_in_flight": T_host,
-                 "note": "the value leg's bracket with synchronous calls: fmx_match_batch_text from as many host threads"}
+    # (the id leg BEFORE the synchronous text callers: measured after them it ran at a third of its speed in three runs out of four —
+    # its calls one at a time instead of four at once — and never when it came first, tools/dbg/ids_callers.py; not understood)
     elapsed_ids, ids_stats = measure_host(host_set, "ids", args.steps, "pcie_inclusive_ids")
     value_ids = nq_step_all * args.steps / elapsed_ids
+    el_sync, text_stats = measure_host(host_set, "text", args.steps, "text_sync_callers")
+    if call_trace:
+        last = call_trace[-args.steps:]
+        t0_ = min(x[3] for x in last)
+        for x in last:
+            log(f"[trace] {x[0]} call {x[1]:3d} thread {x[2]:3d}: {1e3 * (x[3] - t0_):8.2f} -> {1e3 * (x[4] - t0_):8.2f} ms (library: {x[5]:.2f} ms)")
+    text_sync = {"value": round(nq_step_all * args.steps / el_sync, 1), "ms_per_step": round(el_sync / args.steps * 1e3, 3), "calls_in_flight": T_host,
+                 "note": "the value leg's bracket with synchronous calls: fmx_match_batch_text from as many host threads"}
     el2 = measure_text(other_set[:min(len(other_set), T_text + 1)], None) if world > 1 else None
 
     from_strings = None
@@ -702,6 +729,9 @@ def main():
         log(f"[bench] the same from {T_host} synchronous callers: {text_sync['value'] / 1e6:.2f} M patterns/s, {text_sync['ms_per_step']:.3f} ms/step")
         log(f"[bench] synchronous text calls: retries {sum(int(s.n_retries) for s in text_stats)}, ms per call min/median/max "
             f"{min(s.ms_total for s in text_stats):.2f}/{float(np.median([s.ms_total for s in text_stats])):.2f}/{max(s.ms_total for s in text_stats):.2f}")
+        log(f"[bench] synchronous id calls: retries {sum(int(s.n_retries) for s in ids_stats)}, ms per call min/median/max "
+            f"{min(s.ms_total for s in ids_stats):.2f}/{float(np.median([s.ms_total for s in ids_stats])):.2f}/{max(s.ms_total for s in ids_stats):.2f}; "
+            f"host ms in the copies' enqueue, median: in {float(np.median([s.ms_h2d for s in ids_stats])):.3f} out {float(np.median([s.ms_d2h for s in ids_stats])):.3f}")
         log(f"[bench] kernel ms/step by stage: { {k: round(v, 3) for k, v in per_stage.items()} }")
         log(f"[bench] mean step: hits {n_hits:.0f} (bit planes {n_heavy_hits:.0f}, passed {mean_ctr('n_heavy_pass'):.0f}) phaseB {n_phase_b:.0f} "
             f"(light queries {n_light_hits:.0f}) kept {n_kept:.0f} candidates {n_cand:.0f} retries {sum(int(s.n_retries) for s in dev_stats)} "
@@ -727,7 +757,7 @@ def main():
             if fetch and write:
                 rounds = int(pkw.get("nmatch", 1)) if pkw.get("contrast", 0.0) > 0.0 else 1
                 for kern, pattern, per_step in (("fmx::k_probe", "random", 1), ("fmx::k_expand_a", "stream16", 1), ("fmx::k_expand_h", "stream8", 1),
-                                                ("fmx::k_expand_b", "random", 1), ("fmx::k_dp_reg", "random", 1), ("fmx::k_finish", "random", 1),
+                                                ("fmx::k_expand_b", "random", 1), ("fmx::k_dp", "random", 1), ("fmx::k_finish", "random", 1),
                                                 ("fmx::k_camap", "random", 1), ("fmx::k_cround", "random", rounds), ("fmx::k_crerank_g", "random", 1)):
                     keys = [k for k in fetch if k.replace("void ", "").startswith(kern)]  # template instantiations add up
                     if not keys:
@@ -751,9 +781,10 @@ def main():
                     "algorithmic_bytes_per_launch": int(model_bytes), "kernel_ms": round(ms, 4), "launches_per_step": 1,
                     "model": what}
 
-        r_probe = roof("k_probe", b_probe, probe_ms, ["k_probe"],
-                       "bytes requested by the kernel's own loads, counted by k_probe<COUNT> on the same batches: seed n-gram, "
-                       "_quickVocabAccess pair, n-gram table buckets, key tails / 32 B keys of the bisection")
+        r_probe = roof("k_probe+k_probe_tail", b_probe, probe_ms, ["k_probe"],
+                       "bytes requested by the two kernels' own loads, counted by their COUNT variants on the same batches: seed n-gram, "
+                       "_quickVocabAccess pair, n-gram table buckets (head: a lane per start position), 7-gram entries and 32 B keys of the "
+                       "bisection (tail: a lane per start position the head could not decide), the 8 B list entry in between")
         r_exa = roof("k_expand_h+k_expand_a", b_exa, exa_ms, ["k_expand_a", "k_expand_h"],
                      "phase A of the queries with long ranges or many hits (two kernels side by side): 8 B per bit-plane word, "
                      "8 B per plane survivor re-tested, 8 B per hit walked one by one, 8 B per hit queued, 8 B per range "
@@ -775,7 +806,7 @@ def main():
         # 8 B list entry; the pattern is shared by the candidates of a query (4 B per pattern token per query)
         dp_ms = per_stage.get("dp", 0.0)
         b_dp = n_cand * (4.0 * (mean_len + 1) + 16.0 + 16.0 + 8.0) + 4.0 * tot_tokens
-        r_dp = roof("k_dp_reg<32|64>", b_dp, dp_ms, ["k_dp_reg"],
+        r_dp = roof("k_dp_tab+k_dp_reg<64>", b_dp, dp_ms, ["k_dp"],
                     "one lane per (query, candidate): 4 B x (sentence length + 1) of the sentence, 16 B candidate record in and out, 8 B "
                     "list entry, 4 B per pattern token per query (kernel counters; mean sentence length of the corpus)")
         roofs = [r_probe, r_exa, r_exb, r_dp]

@@ -308,13 +308,14 @@ __global__ void __launch_bounds__(kProbeBlock) k_probe(DevIndex ix, DevBatch b, 
       }
     }
   }
+  const bool defer = SPLIT && from != kHeadDone;
   if (COUNT) {
+    if (defer) tally.bytes += 16;  // the list entry and the range left for the tail
     unsigned long long tb = in ? tally.bytes : 0u, tl = in ? tally.lines : 0u;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { tb += __shfl_xor(tb, d, 64); tl += __shfl_xor(tl, d, 64); }
     if ((threadIdx.x & 63) == 0) { atomicAdd(&w.counters[19], tb); atomicAdd(&w.counters[20], tl); }
   }
-  const bool defer = SPLIT && from != kHeadDone;
   if constexpr (SPLIT) {
     const unsigned long long dm = __ballot(defer);
     if (dm) {
@@ -347,7 +348,8 @@ __global__ void __launch_bounds__(kWave) k_probe_tail(DevIndex ix, DevBatch b, D
     const bool in = i < n;
     uint32_t t = 0, q = 0xffffffffu, p = 0, lo = 0, hi = 0;
     ProbeTally tally;
-    tally.bytes = 0; tally.lines = 0;
+    tally.bytes = in ? 16 + 12 + 4 * (kKeyTokens + 1) : 0;  // list entry, the range, t_q and two offsets, the seed n-gram again
+    tally.lines = 0;
     if (in) {
       const ProbeItem pi = tail_items[i];
       t = pi.t;

@@ -38,6 +38,7 @@ void DeviceIndex::set_b_grid(uint32_t) {}
 void DeviceIndex::set_heavy_grid(uint32_t) {}
 void DeviceIndex::set_light_max(uint32_t) {}
 void DeviceIndex::set_light_flat(uint32_t) {}
+void DeviceIndex::set_probe_split(bool) {}
 void DeviceIndex::set_contexts(uint32_t) {}
 void DeviceIndex::set_max_host_active(uint32_t) {}
 void DeviceIndex::set_pair_finish(bool) {}
