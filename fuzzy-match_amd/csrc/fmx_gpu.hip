@@ -461,10 +461,10 @@ struct DeviceIndex::Impl {
   // Admission (round 5).  How many calls may have work on the GPU at once is a property of the GPU, not of how many contexts a
   // caller asked for: every host-buffer call in flight keeps two compute queues and the index's pair of copy queues busy, and
   // with eight of them (sixteen compute queues) every kernel of every call crawls (600-900 ms per step at C3).  So at
-  // most max_host_active host-buffer calls hold a context at any time whatever "contexts" says.  Four: sixteen SYNCHRONOUS callers
-  // (threads) capped at five took 190-600 ms for what four take in 37 (tests/test_gpu_text_batch.py); ONE thread that pipelines
-  // _begin / _end calls can raise the option to five — its calls start apart (StreamPool::pace), which is what bench.py does; further synchronous callers wait HERE, on the host, and
-  // further _begin calls are deferred (DeferredCall) and started, in order, by whoever frees a slot.
+  // most max_host_active host-buffer calls hold a context at any time whatever "contexts" says.  Four by default; five and six
+  // run as well once their starts are paced (StreamPool::pace; sixteen synchronous callers capped at five or six take the time of
+  // four, tests/test_gpu_text_batch.py with the test process's garbage collector held off), seven and more crawl.  bench.py raises
+  // the option to five for its one-thread pipeline of _begin / _end calls;
   uint32_t                max_host_active = [] { const char* e = getenv("FMX_MAX_HOST_ACTIVE"); return e ? (uint32_t)std::max(atoi(e), 1) : 4u; }();
   uint32_t                host_active = 0;
   std::deque<DeferredCall*> deferred;

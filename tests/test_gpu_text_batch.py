@@ -262,13 +262,20 @@ def test_sixteen_synchronous_text_callers_degrade_gracefully(fmx, gpu_device):
     calls = 48
 
     def run(n_threads):
+        import gc
+
         def one(i):
             ix.match_batch_text(fmx.Params(**kw), qo, text, cap=5, out=outs[i % n_threads])
         with cf.ThreadPoolExecutor(n_threads) as pool:
             list(pool.map(one, range(n_threads)))          # threads and contexts set up
-            t0 = time.perf_counter()
-            list(pool.map(one, range(calls)))
-            return time.perf_counter() - t0
+            gc.collect()
+            gc.disable()    # (a generation-2 collection of the test process — 50-150 ms — is not the library's time)
+            try:
+                t0 = time.perf_counter()
+                list(pool.map(one, range(calls)))
+                return time.perf_counter() - t0
+            finally:
+                gc.enable()
 
     t16 = run(16)          # FIRST: right after the build, when the cliff used to bite
     t4 = run(4)

@@ -50,6 +50,8 @@ def run(k_steps, rec=None):
         if rec is not None: rec[1].append(time.perf_counter() - a)
         if i + T < k_steps: pend[i + T] = begin(i + T)
 run(3 * T)
+if os.environ.get('NOGC'):
+    import gc; gc.collect(); gc.disable()
 for rep in range(3):
     rec = ([], [])
     t0 = time.perf_counter(); run(24, rec); dt = time.perf_counter() - t0
