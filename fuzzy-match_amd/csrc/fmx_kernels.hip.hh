@@ -408,7 +408,10 @@ __global__ void __launch_bounds__(kWave) k_build_planes(const unsigned long long
 // ---------------------------------------------------------------------------------------------
 // exclusive scans of per-query counts -> segment offsets
 // ---------------------------------------------------------------------------------------------
-constexpr int kScanThreads = 1024;
+#ifndef FMX_SCAN_THREADS
+#define FMX_SCAN_THREADS 1024  // (round 5: 256 and 512 measured no different — the scans are not what a chained call waits for)
+#endif
+constexpr int kScanThreads = FMX_SCAN_THREADS;
 constexpr int kScanItems = 8;
 constexpr int kScanTile = kScanThreads * kScanItems;
 
@@ -445,7 +448,7 @@ __device__ __forceinline__ unsigned long long block_excl_scan(unsigned long long
 // launch is ~10 us of empty GPU).  Tiles are numbered by a ticket, so every predecessor a tile waits for is already
 // running.  state[a * kLbMaxTiles + tile] = flag << 62 | value: 1 = the tile's own sum, 2 = the inclusive prefix up to
 // and including the tile; the host zeroes state and ticket once per pass (one memset with the counters).
-constexpr uint32_t kLbMaxTiles = 1024;  // tiles per scan: sub-batches of up to 8 M queries
+constexpr uint32_t kLbMaxTiles = 1024u * (1024u / kScanThreads);  // tiles per scan: sub-batches of up to 8 M queries
 constexpr int kLbMaxArrays = 3;
 constexpr unsigned long long kLbValMask = (1ull << 62) - 1ull;
 
