@@ -3567,7 +3567,16 @@ __global__ void __launch_bounds__(kWave) k_cround(DevIndex ix, DevBatch b, DevWo
 // group through LDS: the first version re-read the tokens from memory four at a time in every round — a chain of ~30 dependent
 // loads per query, 80 us per group and no faster than the flattened rounds (0.5 ms per launch whatever the list held).
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t kGrpSlots = 64;  // hash slots per group (a sentence of <= 32 tokens: load <= 0.5)
+// Table of the picked sentence per group: {token, mask of its positions}.  Round 5: 128 slots (a sentence of <= 32 tokens: a quarter
+// full) and a look-up that reads the home slot and its two successors at once, no probe loop — the loop was 21 VALU + 39 SALU
+// instructions of every DP row.  A table in which some token sits further than two slots from home (8 % of them) is rebuilt with the
+// next of four hash multipliers; a group that runs out of multipliers sends its wave through the probe loop for that round.
+constexpr uint32_t kGrpSlots = 128;
+constexpr uint32_t kGrpWindow = 3;
+constexpr uint32_t kGrpTries = 4;
+__device__ __forceinline__ uint32_t grp_mult(uint32_t k) {
+  return k == 0 ? 0x85EBCA6Bu : (k == 1 ? 0xC2B2AE35u : (k == 2 ? 0x9E3779B1u : 0x27D4EB2Fu));
+}
 
 // one thread per query: queries the group kernels take are listed by size (up to 8, 16, 32, 64 accepted matches: the last list
 // lives in the half of contrast_list the flattened mode leaves unused) and marked (class 3: the flattened path skips them)
@@ -3597,8 +3606,8 @@ template <int G>
 __global__ void __launch_bounds__(kWave) k_crerank_g(DevIndex ix, DevBatch b, DevWork w, Params prm, const uint32_t* list,
                                                      uint32_t which, uint32_t cap, Rec* out_rec, uint32_t* out_count, uint32_t* out_total) {
   constexpr uint32_t kGroups = kWave / G;
-  __shared__ uint2 s_tab[kGroups][kGrpSlots];   // {token, mask of its positions in the picked sentence}: one 8-byte read per look-up
-  __shared__ uint32_t s_pick[kGroups][32];   // the picked sentence's tokens
+  __shared__ uint2 s_tab[kGroups][kGrpSlots + kGrpWindow - 1];   // {token, mask of its positions in the picked sentence}; the last slots mirror the first
+  __shared__ __attribute__((aligned(16))) uint32_t s_pick[kGroups][32];   // the picked sentence's tokens
   const uint32_t lane = lane_id(), gl = lane % G, gi = lane / G, gb = lane - gl;
   const unsigned long long n_list = w.counters[28 + which];
   uint32_t n_dist = 0;
@@ -3659,22 +3668,42 @@ __global__ void __launch_bounds__(kWave) k_crerank_g(DevIndex ix, DevBatch b, De
       // the picked sentence's tokens -> the group's table (token -> mask of its positions)
       const uint32_t n2 = __shfl(n1, (int)(gb + kb), 64);
       wave_lds_sync();
-      if (more && mine && gl == kb) {
+      if (more && mine && gl == kb) {  // four tokens per LDS write (words past the sentence's end are zero and never read)
 #pragma unroll
-        for (int j = 0; j < 32; j++) if ((uint32_t)j < n1) s_pick[gi][j] = tk[j];
+        for (int u = 0; u < 8; u++)
+          if ((uint32_t)(4 * u) < n1) *reinterpret_cast<uint4*>(&s_pick[gi][4 * u]) = make_uint4(tk[4 * u], tk[4 * u + 1], tk[4 * u + 2], tk[4 * u + 3]);
       }
-      for (uint32_t k = gl; k < kGrpSlots; k += G) s_tab[gi][k] = make_uint2(kHashEmpty, 0u);
-      wave_lds_sync();
-      if (more)
-        for (uint32_t j = gl; j < n2; j += G) {
-          const uint32_t t = s_pick[gi][j];
-          uint32_t h = pat_hash_slot(t) & (kGrpSlots - 1);
-          for (;;) {
-            const uint32_t old = atomicCAS(&s_tab[gi][h].x, kHashEmpty, t);
-            if (old == kHashEmpty || old == t) { atomicOr(&s_tab[gi][h].y, 1u << j); break; }
-            h = (h + 1) & (kGrpSlots - 1);
+      uint32_t mk = 0;        // the group's hash multiplier of this round
+      bool build = more, stuck = false;
+      for (uint32_t tr = 0;; tr++) {
+        if (build)
+          for (uint32_t k = gl; k < kGrpSlots; k += G) s_tab[gi][k] = make_uint2(kHashEmpty, 0u);
+        wave_lds_sync();
+        bool far = false;
+        if (build) {
+          const uint32_t mult = grp_mult(mk);
+          for (uint32_t j = gl; j < n2; j += G) {
+            const uint32_t t = s_pick[gi][j];
+            uint32_t h = (t * mult) >> 25, d = 0;
+            for (;;) {
+              const uint32_t old = atomicCAS(&s_tab[gi][h].x, kHashEmpty, t);
+              if (old == kHashEmpty || old == t) { atomicOr(&s_tab[gi][h].y, 1u << j); break; }
+              h = (h + 1) & (kGrpSlots - 1); d++;
+            }
+            far = far || d >= kGrpWindow;
           }
         }
+        wave_lds_sync();
+        const unsigned long long fm = __ballot(far);
+        const unsigned long long gmask = G == 64 ? ~0ull : (((1ull << (G & 63)) - 1ull) << gb);
+        const bool gfar = (fm & gmask) != 0ull;            // some token of my group's table sits too far from home
+        build = gfar && tr + 1 < kGrpTries;
+        stuck = gfar && tr + 1 >= kGrpTries;
+        if (build) mk++;
+        if (__ballot(build) == 0ull) break;
+      }
+      const bool use_loop = __ballot(stuck) != 0ull;       // (wave-uniform: rare)
+      if (more && gl < kGrpWindow - 1) s_tab[gi][kGrpSlots + gl] = s_tab[gi][gl];
       wave_lds_sync();
       // every unpicked match of the group: bit-parallel distance of its sentence (rows) to the picked one (bits)
       const bool act = more && mine && !picked;
@@ -3684,16 +3713,33 @@ __global__ void __launch_bounds__(kWave) k_crerank_g(DevIndex ix, DevBatch b, De
       for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(rows_max, d, 64); rows_max = o > rows_max ? o : rows_max; }
       uint32_t pv = ~0u, mv = 0u, score = n2;
       const uint32_t m_bits = n2 ? n2 : 1u;
+      const uint32_t mult = grp_mult(mk);
+      if (!use_loop) {
 #pragma unroll
-      for (int i = 0; i < 32; i++) {
-        if ((uint32_t)i >= rows_max) break;   // (wave-uniform)
-        if ((uint32_t)i < rows) {
-          const uint32_t t = tk[i];
-          uint32_t h = pat_hash_slot(t) & (kGrpSlots - 1);
-          uint2 e = s_tab[gi][h];
-          while (e.x != t && e.x != kHashEmpty) { h = (h + 1) & (kGrpSlots - 1); e = s_tab[gi][h]; }
-          const uint32_t eq = e.x == t ? e.y : 0u;
-          lev_step32(pv, mv, score, eq, m_bits);
+        for (int i = 0; i < 32; i++) {
+          if ((uint32_t)i >= rows_max) break;   // (wave-uniform)
+          if ((uint32_t)i < rows) {
+            const uint32_t t = tk[i];
+            const uint32_t h = (t * mult) >> 25;
+            const uint2 e0 = s_tab[gi][h], e1 = s_tab[gi][h + 1], e2 = s_tab[gi][h + 2];
+            const uint32_t eq = (e0.x == t ? e0.y : 0u) | (e1.x == t ? e1.y : 0u) | (e2.x == t ? e2.y : 0u);
+            lev_step32(pv, mv, score, eq, m_bits);
+          }
+        }
+      } else {
+#pragma unroll 1
+        for (int i = 0; i < 32; i++) {
+          if ((uint32_t)i >= rows_max) break;   // (wave-uniform)
+          uint32_t t = 0;
+#pragma unroll
+          for (int u = 0; u < 32; u++) t = u == i ? tk[u] : t;   // (the rare path: no second unrolled copy of the rows)
+          if ((uint32_t)i < rows) {
+            uint32_t h = (t * mult) >> 25;
+            uint2 e = s_tab[gi][h];
+            while (e.x != t && e.x != kHashEmpty) { h = (h + 1) & (kGrpSlots - 1); e = s_tab[gi][h]; }
+            const uint32_t eq = e.x == t ? e.y : 0u;
+            lev_step32(pv, mv, score, eq, m_bits);
+          }
         }
       }
       if (act) {
