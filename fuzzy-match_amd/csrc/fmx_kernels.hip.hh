@@ -711,28 +711,40 @@ __device__ __forceinline__ void pat_hash_build(PatHash& ph, const uint32_t* s_pa
   wave_lds_sync();
 }
 
-// one wave, p <= 32; true: every word sits in its home slot or the next one
-__device__ __forceinline__ bool pat_hash_build32(PatHash32& ph, const uint32_t* s_pat, uint32_t p) {
+// hash multipliers of the loop-free tables: a table with a word too far from its home slot is rebuilt with the next one
+__device__ __forceinline__ uint32_t tab_mult(uint32_t k) {
+  return k == 0 ? 0x85EBCA6Bu : (k == 1 ? 0xC2B2AE35u : (k == 2 ? 0x9E3779B1u : 0x27D4EB2Fu));
+}
+constexpr uint32_t kPatTries = 3;
+// one wave, p <= 32.  Returns the multiplier under which every word sits in its home slot or the next one (a third of the tables
+// of 25 distinct words fail that under ONE multiplier, 3 % under three), or 0 when none of kPatTries did.
+__device__ __forceinline__ uint32_t pat_hash_build32(PatHash32& ph, const uint32_t* s_pat, uint32_t p) {
   const uint32_t lane = lane_id();
-  PatSlot e; e.key = kHashEmpty; e.mask = 0u;
-  ph.s[lane] = e; ph.s[lane + 64] = e;
-  wave_lds_sync();
-  bool far = false;
-  if (lane < p) {
-    const uint32_t wd = s_pat[lane];
-    uint32_t h = pat_hash_slot(wd), d = 0;
-    for (;;) {
-      const uint32_t old = atomicCAS(&ph.s[h].key, kHashEmpty, wd);
-      if (old == kHashEmpty || old == wd) break;
-      h = (h + 1) & (kHashSlots - 1); d++;
+  for (uint32_t k = 0; k < kPatTries; k++) {
+    const uint32_t mult = tab_mult(k);
+    PatSlot e; e.key = kHashEmpty; e.mask = 0u;
+    ph.s[lane] = e; ph.s[lane + 64] = e;
+    wave_lds_sync();
+    bool far = false;
+    if (lane < p) {
+      const uint32_t wd = s_pat[lane];
+      uint32_t h = (wd * mult) >> 25, d = 0;
+      for (;;) {
+        const uint32_t old = atomicCAS(&ph.s[h].key, kHashEmpty, wd);
+        if (old == kHashEmpty || old == wd) break;
+        h = (h + 1) & (kHashSlots - 1); d++;
+      }
+      atomicOr(&ph.s[h].mask, 1u << lane);
+      far = d > 1;
     }
-    atomicOr(&ph.s[h].mask, 1u << lane);
-    far = d > 1;
+    wave_lds_sync();
+    if (__ballot(far) == 0ull) {
+      if (lane == 0) ph.s[kHashSlots] = ph.s[0];
+      wave_lds_sync();
+      return mult;
+    }
   }
-  wave_lds_sync();
-  if (lane == 0) ph.s[kHashSlots] = ph.s[0];
-  wave_lds_sync();
-  return __ballot(far) == 0ull;
+  return 0u;
 }
 
 constexpr int kUnroll = FMX_UNROLL;  // hits per lane per phase-A iteration
@@ -1577,9 +1589,10 @@ __global__ void __launch_bounds__(kWave, LIGHT ? FMX_LIGHT_WAVES : FMX_PHASEB_WA
       for (uint32_t j = lane; j < p; j += kWave) s_pat[j] = pat[j];
       load_recs();
       wave_lds_sync();
-      bool near32 = false;  // the pattern's table is the 32-bit one and needs no probe loop
-      if (p <= 32) near32 = pat_hash_build32(pt.h32, s_pat, p);
-      if (p <= kWave && !near32) pat_hash_build(ph, s_pat, p);  // (also: a 32-bit table with a word far from home, rebuilt)
+      uint32_t mult32 = 0;  // != 0: the pattern's table is the 32-bit one under this multiplier and needs no probe loop
+      if (p <= 32) mult32 = uni(pat_hash_build32(pt.h32, s_pat, p));
+      const bool near32 = mult32 != 0u;
+      if (p <= kWave && !near32) pat_hash_build(ph, s_pat, p);  // (also: a 32-bit table with a word far from home under every multiplier)
       // Two stages per block of kWave * kBU queued hits.  Stage 1: the dominance test (about two thirds
       // of the queued hits fail it) compacts the survivors into LDS.  Stage 2: full waves of survivors do
       // the token work (match length + exact coverage), not diluted by dominated hits.
@@ -1722,7 +1735,7 @@ __global__ void __launch_bounds__(kWave, LIGHT ? FMX_LIGHT_WAVES : FMX_PHASEB_WA
           const PatHash32& p32 = pt.h32;
           uint32_t seen = 0;
           auto probe = [&](uint32_t t) {
-            const uint32_t h = pat_hash_slot(t);
+            const uint32_t h = (t * mult32) >> 25;
             // padding tokens (kHashEmpty) meet an empty slot's zero mask or nothing: no guard needed
             const PatSlot a = p32.s[h], b2 = p32.s[h + 1];
             seen |= (a.key == t ? a.mask : 0u) | (b2.key == t ? b2.mask : 0u);
@@ -3574,9 +3587,7 @@ __global__ void __launch_bounds__(kWave) k_cround(DevIndex ix, DevBatch b, DevWo
 constexpr uint32_t kGrpSlots = 128;
 constexpr uint32_t kGrpWindow = 3;
 constexpr uint32_t kGrpTries = 4;
-__device__ __forceinline__ uint32_t grp_mult(uint32_t k) {
-  return k == 0 ? 0x85EBCA6Bu : (k == 1 ? 0xC2B2AE35u : (k == 2 ? 0x9E3779B1u : 0x27D4EB2Fu));
-}
+__device__ __forceinline__ uint32_t grp_mult(uint32_t k) { return tab_mult(k); }
 
 // one thread per query: queries the group kernels take are listed by size (up to 8, 16, 32, 64 accepted matches: the last list
 // lives in the half of contrast_list the flattened mode leaves unused) and marked (class 3: the flattened path skips them)
