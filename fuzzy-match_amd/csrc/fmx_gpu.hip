@@ -1117,14 +1117,17 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
     tick(); tick();
     if (b.nt) {
       const dim3 pg((b.nt + kProbeBlock - 1) / kProbeBlock), pb(kProbeBlock);
+      // (the tail's persistent grid shrinks with the pass: a fifth of the tokens at most is queued, kTailLists lists)
+      const uint32_t tail_per = std::min<uint32_t>(kProbeTailPer, std::max<uint32_t>(1u, (uint32_t)(b.nt / (5ull * kWave * kTailLists)) + 1u));
+      const dim3 tg(kTailLists * tail_per);
       if (m.probe_split) {
         // head: a lane per start position, one table line; tail: a lane per start position the head could not decide
         if (m.probe_count) {  // measurement runs only: the same kernels, also counting the bytes / lines they request
           hipLaunchKernelGGL((k_probe<true, true>), pg, pb, 0, stream, E.d, b, w, heavy_min, c.items_h.p, item_h_cap, c.items_t.p);
-          hipLaunchKernelGGL(k_probe_tail<true>, dim3(kProbeTailGrid), dim3(kWave), 0, stream, E.d, b, w, heavy_min, c.items_h.p, item_h_cap, (const ProbeItem*)c.items_t.p);
+          hipLaunchKernelGGL(k_probe_tail<true>, tg, dim3(kWave), 0, stream, E.d, b, w, heavy_min, c.items_h.p, item_h_cap, (const ProbeItem*)c.items_t.p);
         } else {
           hipLaunchKernelGGL((k_probe<false, true>), pg, pb, 0, stream, E.d, b, w, heavy_min, c.items_h.p, item_h_cap, c.items_t.p);
-          hipLaunchKernelGGL(k_probe_tail<false>, dim3(kProbeTailGrid), dim3(kWave), 0, stream, E.d, b, w, heavy_min, c.items_h.p, item_h_cap, (const ProbeItem*)c.items_t.p);
+          hipLaunchKernelGGL(k_probe_tail<false>, tg, dim3(kWave), 0, stream, E.d, b, w, heavy_min, c.items_h.p, item_h_cap, (const ProbeItem*)c.items_t.p);
         }
       } else if (m.probe_count) {
         hipLaunchKernelGGL((k_probe<true, false>), pg, pb, 0, stream, E.d, b, w, heavy_min, c.items_h.p, item_h_cap, c.items_t.p);

@@ -335,15 +335,15 @@ __global__ void __launch_bounds__(kProbeBlock) k_probe(DevIndex ix, DevBatch b, 
 }
 
 // The tail of the probe: one lane per queued start position (grid-stride: the host does not know how many there are), full waves.
-constexpr uint32_t kProbeTailPer = 32;  // workgroups per list
-constexpr uint32_t kProbeTailGrid = kTailLists * kProbeTailPer;
+constexpr uint32_t kProbeTailPer = 32;  // workgroups per list (at most)
 template <bool COUNT>
 __global__ void __launch_bounds__(kWave) k_probe_tail(DevIndex ix, DevBatch b, DevWork w, uint32_t heavy_min, HeavyItem* items_h,
                                                       uint32_t item_h_cap, const ProbeItem* tail_items) {
   const uint32_t list = blockIdx.x % (uint32_t)kTailLists;
   const unsigned long long n = w.counters[kCtrProbeTail + list];
   tail_items += (unsigned long long)list * probe_tail_list_cap(b.nt);
-  for (unsigned long long i0 = (unsigned long long)(blockIdx.x / kTailLists) * kWave; i0 < n; i0 += (unsigned long long)kProbeTailPer * kWave) {
+  const uint32_t per = gridDim.x / (uint32_t)kTailLists;  // workgroups per list: the host shrinks the grid with the pass
+  for (unsigned long long i0 = (unsigned long long)(blockIdx.x / kTailLists) * kWave; i0 < n; i0 += (unsigned long long)per * kWave) {
     const unsigned long long i = i0 + lane_id();
     const bool in = i < n;
     uint32_t t = 0, q = 0xffffffffu, p = 0, lo = 0, hi = 0;
