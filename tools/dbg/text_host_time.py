@@ -47,14 +47,16 @@ def run(k_steps, rec=None):
         if STAGGER: time.sleep(STAGGER / 1e3)
     for i in range(k_steps):
         a = time.perf_counter(); ix.text_end(pend.pop(i))
-        if rec is not None: rec[1].append(time.perf_counter() - a)
+        if rec is not None: rec[1].append(time.perf_counter() - a); rec[2].append(time.perf_counter())
         if i + T < k_steps: pend[i + T] = begin(i + T)
 run(3 * T)
 if os.environ.get('NOGC'):
     import gc; gc.collect(); gc.disable()
-for rep in range(3):
-    rec = ([], [])
+for rep in range(int(os.environ.get('REPS', '3'))):
+    time.sleep(float(os.environ.get('SLEEP_BETWEEN', '0')))
+    rec = ([], [], [])
     t0 = time.perf_counter(); run(24, rec); dt = time.perf_counter() - t0
     b, e = np.array(rec[0]) * 1e3, np.array(rec[1]) * 1e3
     print(f"{nq} queries, {T} text calls in flight, stagger {STAGGER} ms: {dt / 24 * 1e3:.3f} ms/step; begin() median {np.median(b):.3f} max {b.max():.3f}; end() median {np.median(e):.3f} mean {e.mean():.3f} max {e.max():.3f}; steady (steps 8..24) {e[8:].mean() + b[8 - T:].mean() if len(b) > 8 else 0:.3f} ms/step")
     print("  end:  ", " ".join(f"{x:.1f}" for x in e[:24]))
+    print("  done at (ms since the first begin):", " ".join(f"{(x - t0) * 1e3:.1f}" for x in rec[2]))
