@@ -1975,10 +1975,11 @@ struct DeviceIndex::HostCall {
       uint32_t* tile_count = reinterpret_cast<uint32_t*>(c.d_vstate.p);
       // a text with fewer spellings than the offsets count leaves the tail of the ids untouched: VOCAB_UNK there, not whatever the
       // buffer held (the call still fails after the synchronisation, but no kernel runs on garbage)
-      if (nt) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)c.d_qtok.p, 1, nt, ls));
+      // (the scan fills what the look-up will not reach: no memset of the whole array)
       hipLaunchKernelGGL(k_vocab_count, dim3((unsigned)text_tiles), dim3(kScanThreads), 0, ls, (const unsigned char*)c.d_text.p,
                          (unsigned long long)hb.n_text, tile_count);
-      hipLaunchKernelGGL(k_vocab_scan, dim3(1), dim3(kScanThreads), 0, ls, tile_count, (uint32_t)text_tiles, d_total);
+      hipLaunchKernelGGL(k_vocab_scan, dim3(1), dim3(kScanThreads), 0, ls, tile_count, (uint32_t)text_tiles, d_total, c.d_qtok.p,
+                         (unsigned long long)nt, 1u);
       hipLaunchKernelGGL(k_vocab_lookup, dim3((unsigned)text_tiles), dim3(kScanThreads), 0, ls, (const unsigned char*)c.d_text.p,
                          (unsigned long long)hb.n_text, (unsigned long long)nt, text_snap.vocab, c.d_qtok.p, (const uint32_t*)tile_count, 1u);
       if (text_real) {

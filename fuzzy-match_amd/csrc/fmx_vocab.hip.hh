@@ -56,7 +56,11 @@ __global__ void __launch_bounds__(kScanThreads) k_vocab_count(const unsigned cha
 }
 
 // Pass 2: exclusive scan of the tile counts by ONE workgroup (in place); total[0] = the number of spellings.
-__global__ void __launch_bounds__(kScanThreads) k_vocab_scan(uint32_t* tile_count, uint32_t n_tiles, unsigned long long* total) {
+// ids (optional): the id array the look-up fills — entries [spellings found, n_tok) get `fill` here, so that a text with fewer
+// spellings than the offsets count leaves VOCAB_UNK behind and not what the buffer held (normally no entry at all: the array used
+// to be memset whole, 100 MB per million-query call, before every look-up).
+__global__ void __launch_bounds__(kScanThreads) k_vocab_scan(uint32_t* tile_count, uint32_t n_tiles, unsigned long long* total,
+                                                             uint32_t* ids = nullptr, unsigned long long n_tok = 0, uint32_t fill = 0) {
   __shared__ uint32_t s_w[kScanThreads / kWave];
   __shared__ uint32_t s_run;
   if (threadIdx.x == 0) s_run = 0;
@@ -76,6 +80,8 @@ __global__ void __launch_bounds__(kScanThreads) k_vocab_scan(uint32_t* tile_coun
     __syncthreads();
   }
   if (threadIdx.x == 0) *total = s_run;
+  if (ids)
+    for (unsigned long long i = (unsigned long long)s_run + threadIdx.x; i < n_tok; i += kScanThreads) ids[i] = fill;
 }
 
 // Pass 3: text: n_bytes bytes followed by at least kVocabChunk + 16 zero bytes, 16-byte aligned.  ids: n_tok words.
