@@ -4,6 +4,9 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import numpy as np
+if os.environ.get('IMPORT_TORCH'):
+    import torch  # the wheel's bundled HIP runtime instead of /opt/rocm's
+    torch.cuda.init()
 import fmx_import, synth, bench
 fmx = fmx_import.load().fmx
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 4
@@ -55,8 +58,9 @@ if os.environ.get('NOGC'):
 for rep in range(int(os.environ.get('REPS', '3'))):
     time.sleep(float(os.environ.get('SLEEP_BETWEEN', '0')))
     rec = ([], [], [])
-    t0 = time.perf_counter(); run(24, rec); dt = time.perf_counter() - t0
+    K = int(os.environ.get('STEPS', '24'))
+    t0 = time.perf_counter(); run(K, rec); dt = time.perf_counter() - t0
     b, e = np.array(rec[0]) * 1e3, np.array(rec[1]) * 1e3
-    print(f"{nq} queries, {T} text calls in flight, stagger {STAGGER} ms: {dt / 24 * 1e3:.3f} ms/step; begin() median {np.median(b):.3f} max {b.max():.3f}; end() median {np.median(e):.3f} mean {e.mean():.3f} max {e.max():.3f}; steady (steps 8..24) {e[8:].mean() + b[8 - T:].mean() if len(b) > 8 else 0:.3f} ms/step")
+    print(f"{nq} queries, {T} text calls in flight, stagger {STAGGER} ms: {dt / K * 1e3:.3f} ms/step over {K} steps; begin() median {np.median(b):.3f} max {b.max():.3f}; end() median {np.median(e):.3f} mean {e.mean():.3f} max {e.max():.3f}; steady (steps 8..24) {e[8:].mean() + b[8 - T:].mean() if len(b) > 8 else 0:.3f} ms/step")
     print("  end:  ", " ".join(f"{x:.1f}" for x in e[:24]))
     print("  done at (ms since the first begin):", " ".join(f"{(x - t0) * 1e3:.1f}" for x in rec[2]))
