@@ -1531,7 +1531,7 @@ __global__ void __launch_bounds__(kWave, LIGHT ? FMX_LIGHT_WAVES : FMX_PHASEB_WA
       Cand* seg = w.seg + seg0;
       const uint32_t e_lo = chunk * kPhaseBChunk;
       const uint32_t e_hi = e_lo + kPhaseBChunk < n_q ? e_lo + kPhaseBChunk : n_q;
-      const bool sole = n_q <= kPhaseBChunk;  // this wave is the query's only phase-B worker: no atomics needed
+      const bool sole = LIGHT || n_q <= kPhaseBChunk;  // this wave is the query's only phase-B worker: no atomics needed (a light query has at most light_max <= kPhaseBChunk hits)
       bool in_lds = sole;                     // ... and up to 64 survivors stay in LDS and are reduced right here
       uint32_t n_out = 0;
       QHit hq[kBU];
@@ -1800,10 +1800,10 @@ __global__ void __launch_bounds__(kWave, LIGHT ? FMX_LIGHT_WAVES : FMX_PHASEB_WA
         wave_lds_sync();
         uint32_t j0 = 0;
         if (p <= kWave) for (; j0 + pass <= n_s; j0 += pass) heavy4(j0, pass);
-        else for (; j0 + pass <= n_s; j0 += pass) heavy(j0, true);
+        else if constexpr (!LIGHT) for (; j0 + pass <= n_s; j0 += pass) heavy(j0, true);  // (a light query's pattern fits a wave)
         const uint32_t rest = n_s - j0;
         if (!more) {
-          if (rest) { if (p <= kWave) heavy4(j0, rest); else heavy(j0, lane < rest); }
+          if (rest) { if (p <= kWave) heavy4(j0, rest); else if constexpr (!LIGHT) heavy(j0, lane < rest); }
           n_s = 0;
         } else {
           if (j0) {  // carry the incomplete wave of survivors to the front of the list
