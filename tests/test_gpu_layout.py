@@ -45,14 +45,16 @@ def test_expand_layouts_agree_with_the_oracle(fmx, gpu_device, corpus):
                dict(light_max=17, expand_order=0), dict(light_max=256, expand_order=1, serial=1), dict(light_max=256, expand_order=0, heavy_min=0),
                dict(light_max=256, expand_order=1, pair_finish=0),  # the others run k_finish_pair where the parameters allow it
                dict(light_max=256, expand_order=1, light_flat=256), dict(light_max=256, expand_order=0, light_flat=128),
-               dict(light_max=256, expand_order=1, light_flat=9)]
+               dict(light_max=256, expand_order=1, light_flat=9),
+               # the probe as ONE kernel (round 4's layout; the default since round 5 is head + tail, k_probe + k_probe_tail)
+               dict(light_max=256, expand_order=1, probe_split=0), dict(light_max=0, expand_order=0, probe_split=0)]
     light_seen = 0
     for name in sets:
         kw = workloads.PARAM_SETS[name]
         cap = kw["nmatch"] or 256
         oo, oc = o.match_batch(oracle_lib.Params(**kw), q_off, q_tok, cap, nthreads=oracle_lib.effective_cpus())
         for lay in layouts:
-            for k, v in {"serial": 0, "heavy_min": 1024, "pair_finish": 1, "light_flat": 0, **lay}.items():
+            for k, v in {"serial": 0, "heavy_min": 1024, "pair_finish": 1, "light_flat": 0, "probe_split": 1, **lay}.items():
                 ix.set_option(k, v)
             go, gc, gt, st = ix.match_batch(fmx.Params(**kw), q_off, q_tok, cap=cap, want_stats=True)
             workloads.compare(oo, oc, go, gc, f"{corpus} {name} {lay}")
@@ -61,6 +63,7 @@ def test_expand_layouts_agree_with_the_oracle(fmx, gpu_device, corpus):
             light_seen += int(st.n_light_hits)
     assert light_seen > 0  # the light path did run
     ix.set_option("light_flat", 0)
+    ix.set_option("probe_split", 1)
 
 
 def test_flat_light_walk_is_bit_identical(fmx, gpu_device):
