@@ -173,7 +173,29 @@ __global__ void k_setup(DevIndex ix, DevBatch b, DevWork w, Params prm) {
   const bool inside = o0 >= b.t_begin && o1 >= o0 && o1 - b.t_begin <= b.nt;
   const uint32_t msl = inside ? min_seq_len(p, prm) : kNoMatchLen;
   w.q_m[q] = msl == kNoMatchLen ? kNoMatchLen : msl;
-  if (inside) for (uint32_t k = 0; k < p; k++) w.t_q[o0 - b.t_begin + k] = q;
+  // The token -> query map, coalesced (round 5): the wave's 64 queries own a contiguous stretch of tokens when they are all inside
+  // the pass (they are, unless the call's offsets are wrong); lane l writes tokens l, l + 64, ... of the stretch and finds their
+  // query by bisecting the 64 start offsets held across the lanes.  (One thread writing its query's tokens one by one: 64 separate
+  // 4-byte stores per instruction, 70 us per million queries.)
+  const unsigned long long act = __ballot(true);   // a prefix of the wave: lanes beyond the pass and the q == nq thread have left
+  const uint32_t n_act = (uint32_t)__popcll(act), lane = lane_id();
+  if (__ballot(inside) == act) {
+    const uint32_t s0 = __shfl(o0, 0, 64), s1 = __shfl(o1, (int)n_act - 1, 64);   // (o1 of a lane is o0 of the next: one stretch)
+    for (uint32_t base = s0; base < s1; base += n_act) {   // (wave-uniform trip count: every lane takes part in the shuffles)
+      const uint32_t t = base + lane;
+      // the LAST query that starts at or before t owns it (offsets ascend; an empty query shares its successor's offset)
+      int lo = 0, hi = (int)n_act - 1;
+#pragma unroll
+      for (int step = 0; step < 6; step++) {
+        const int mid = (lo + hi + 1) >> 1;
+        const uint32_t om = __shfl(o0, mid, 64);
+        if (om <= t) lo = mid; else hi = mid - 1;
+      }
+      if (t < s1) w.t_q[t - b.t_begin] = (q - lane) + (uint32_t)lo;
+    }
+  } else if (inside) {
+    for (uint32_t k = 0; k < p; k++) w.t_q[o0 - b.t_begin + k] = q;
+  }
 }
 
 // A pass whose token bounds disagree with q_off (k_setup counted it: the caller's total_tokens was wrong) is inert on the device:
