@@ -80,12 +80,13 @@ def parse_args():
     ap.add_argument("--host-threads", type=int, default=int(os.environ.get("FMX_BENCH_HOST_THREADS", "4")),
                     help="synchronous host-buffer calls in flight (one host thread each) — the side legs `text_sync_callers`, `pcie_inclusive_ids`, "
                          "`from_token_strings` (the library admits at most max_host_active = 4 of them at once whatever this says)")
-    ap.add_argument("--text-calls", type=int, default=int(os.environ.get("FMX_BENCH_TEXT_CALLS", "5")),
+    ap.add_argument("--text-calls", type=int, default=int(os.environ.get("FMX_BENCH_TEXT_CALLS", "0")),
                     help="text batches the value leg keeps in flight (fmx_match_batch_text_begin / _end, one host thread; the leg raises the "
                          "library's max_host_active to this).  Five since round 5, which traced the 'cliff' of rounds 2-4: five or six calls begun "
                          "back to back on an idle GPU make the FIRST take 13-340 ms (the library now starts host-buffer calls 0.5 ms apart, which "
                          "avoids it: tools/dbg/text_host_time.py); seven and more crawl whatever the stream layout.  Over 20 steps from an idle "
-                         "pipeline: four 5.36-5.42 ms per step, five 5.19-5.28, six 5.76 (a longer fill and drain)")
+                         "pipeline: four 5.36-5.42 ms per step, five 5.19-5.28, six 5.76 (a longer fill and drain).  0 = five for steps of half a million "
+                         "queries and more, four for smaller ones (C2 and the 125 k-query shard: 0.88-0.93 / 1.04 ms with four, 0.97 / 1.08 with five)")
     ap.add_argument("--batches", type=int, default=0, help="distinct query batches rotated through the steps (0 = calls in flight + 1)")
     ap.add_argument("--force-gather", action="store_true", help="N = 1 test of the N > 1 step: records also kept in HBM for the (empty) gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -188,7 +189,8 @@ def main():
     log = (lambda *a: print(*a, file=sys.stderr, flush=True)) if rank == 0 else (lambda *a: None)
     T_dev = max(args.threads, 1)
     T_host = max(min(args.host_threads, args.threads), 1)
-    T_text = max(min(args.text_calls, args.threads), 1)
+    nq_rank = nq_cfg // world if (args.scaling == "strong" and world > 1) else nq_cfg   # queries of one step on this rank
+    T_text = max(min(args.text_calls or (5 if nq_rank >= (1 << 19) else 4), args.threads), 1)
     NB = args.batches or (T_dev + 1)          # distinct batches of the device-resident legs
     NB_host = min(NB, T_host + 1) if not args.batches else NB   # ... of the host-buffer legs (fewer calls in flight)
 
