@@ -631,11 +631,13 @@ def _vocab_lookup_ptrs(self, ptrs, out, nthreads):
     _check(lib().fmx_vocab_lookup_mt(self.h, _ptr(ptrs), len(ptrs), _ptr(out), nthreads))
 
 
-def _text_begin(self, params, q_off, text, out, cap, keep=None):
+def _text_begin(self, params, q_off, text, out, cap, keep=None, real_text=None):
     """fmx_match_batch_text_begin: q_off / text / out = (records, counts, totals) are pinned numpy arrays the caller keeps alive
-    until text_end.  Returns the handle."""
+    until text_end (real_text: the real tokens as a second stream of spellings, likewise).  Returns the handle."""
     nq = len(q_off) - 1
     b = TextBatch(nq, _ptr(q_off), _ptr(text), len(text), None, 0, 0, None, None)
+    if real_text is not None:
+        b.real_text, b.n_real_bytes = _ptr(real_text), len(real_text)
     L = lib()
     L.fmx_match_batch_text_begin.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(TextBatch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
                                              C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]

@@ -205,6 +205,16 @@ int fmo_index_set_real(fmo_index* ix, uint32_t s_id, const char* real_tokstring,
   return 0;
 }
 
+/* fmo_index_set_real for sentences [first_sid, first_sid + n) without penalty tokens: sentence i's tab-joined real tokens are the
+ * NUL-terminated string at packed + off[i] (what SuffixArrayIndex::add_tm stores per sentence, src/suffix_array_index.cc:61-70) */
+int fmo_index_set_real_bulk(fmo_index* ix, uint32_t first_sid, uint32_t n, const char* packed, const uint64_t* off) {
+  if (!ix || !packed || !off || (uint64_t)first_sid + n > ix->n_sent) return -1;
+  ix->has_real = 1;
+  ensure_real(ix, ix->n_sent);
+  for (uint32_t i = 0; i < n; i++) real_set(&ix->real[first_sid + i], packed + off[i], 0, NULL, NULL);
+  return 0;
+}
+
 /* SuffixArray::get_sentence — include/fuzzy/suffix_array.hxx:11-19 */
 static inline const uint32_t* get_sentence(const fmo_index* ix, uint64_t sid, uint64_t* length) {
   const uint32_t* s = ix->buf + ix->sent_pos[sid];
@@ -1334,6 +1344,8 @@ typedef struct batch_job {
   atomic_ullong*    next;
   int               want_ctr;
   fmo_counters      ctr;
+  const char*       real_packed;  /* optional: pattern q's tab-joined real tokens at real_packed + real_off[q] */
+  const uint64_t*   real_off;
 } batch_job;
 
 static void* batch_worker(void* arg) {
@@ -1346,7 +1358,10 @@ static void* batch_worker(void* arg) {
     if (b >= j->nq) break;
     uint64_t e = b + chunk < j->nq ? b + chunk : j->nq;
     for (uint64_t q = b; q < e; q++) {
-      int64_t n = match_impl(j->ix, j->prm, j->q_tok + j->q_off[q], j->q_off[q + 1] - j->q_off[q], NULL,
+      fmo_real real;
+      memset(&real, 0, sizeof(real));
+      if (j->real_packed) real.tokstring = (char*)(j->real_packed + j->real_off[q]);  /* borrowed, never freed */
+      int64_t n = match_impl(j->ix, j->prm, j->q_tok + j->q_off[q], j->q_off[q + 1] - j->q_off[q], j->real_packed ? &real : NULL,
                              j->out + q * j->cap, j->cap, j->want_ctr ? &j->ctr : NULL, &sc);
       j->out_count[q] = (uint32_t)((uint64_t)n < j->cap ? (uint64_t)n : j->cap);
     }
@@ -1358,7 +1373,15 @@ static void* batch_worker(void* arg) {
 int fmo_match_batch(const fmo_index* ix, const fmo_params* prm, const uint32_t* q_off,
                     const uint32_t* q_tok, uint64_t nq, int nthreads, fmo_rec* out,
                     uint32_t* out_count, uint64_t cap, fmo_counters* ctr) {
+  return fmo_match_batch_real(ix, prm, q_off, q_tok, nq, NULL, NULL, nthreads, out, out_count, cap, ctr);
+}
+
+/* the same batch with every pattern's `real` Sentence (match(const Sentence&, const Tokens&, ...), src/fuzzy_match.cc:435) */
+int fmo_match_batch_real(const fmo_index* ix, const fmo_params* prm, const uint32_t* q_off,
+                         const uint32_t* q_tok, uint64_t nq, const char* real_packed, const uint64_t* real_off,
+                         int nthreads, fmo_rec* out, uint32_t* out_count, uint64_t cap, fmo_counters* ctr) {
   if (!ix || !prm || !ix->sorted) return -1;
+  if ((real_packed == NULL) != (real_off == NULL)) return -1;
   if (nthreads < 1) nthreads = 1;
   if (nthreads > 512) nthreads = 512;
   atomic_ullong next;
@@ -1369,6 +1392,7 @@ int fmo_match_batch(const fmo_index* ix, const fmo_params* prm, const uint32_t* 
     jobs[t].ix = ix; jobs[t].prm = prm; jobs[t].q_off = q_off; jobs[t].q_tok = q_tok; jobs[t].nq = nq;
     jobs[t].out = out; jobs[t].out_count = out_count; jobs[t].cap = cap; jobs[t].next = &next;
     jobs[t].want_ctr = ctr != NULL;
+    jobs[t].real_packed = real_packed; jobs[t].real_off = real_off;
   }
   for (int t = 1; t < nthreads; t++) pthread_create(&th[t], NULL, batch_worker, &jobs[t]);
   batch_worker(&jobs[0]);

@@ -90,6 +90,10 @@ int        fmo_index_set_arrays(fmo_index*,
 int        fmo_index_set_real(fmo_index*, uint32_t s_id, const char* real_tokstring,
                               uint32_t n_itoks, const uint64_t* itok_idx, const char* const* itok_str);
 
+/* ... for sentences [first_sid, first_sid + n), none with penalty tokens: sentence i's tab-joined real tokens = the NUL-terminated
+ * string at packed + off[i] */
+int        fmo_index_set_real_bulk(fmo_index*, uint32_t first_sid, uint32_t n, const char* packed, const uint64_t* off);
+
 uint64_t        fmo_index_num_suffixes(const fmo_index*);
 uint64_t        fmo_index_num_sentences(const fmo_index*);
 uint64_t        fmo_index_buffer_size(const fmo_index*);
@@ -131,6 +135,14 @@ int fmo_match_batch(const fmo_index*, const fmo_params*,
                     const uint32_t* q_off, const uint32_t* q_tok, uint64_t nq,
                     int nthreads, fmo_rec* out, uint32_t* out_count, uint64_t cap,
                     fmo_counters* ctr);
+
+/* fmo_match_batch with every pattern's `real` Sentence: pattern q's tab-joined real tokens = the NUL-terminated string at
+ * real_packed + real_off[q] (no penalty tokens); both NULL = fmo_match_batch */
+int fmo_match_batch_real(const fmo_index*, const fmo_params*,
+                         const uint32_t* q_off, const uint32_t* q_tok, uint64_t nq,
+                         const char* real_packed, const uint64_t* real_off,
+                         int nthreads, fmo_rec* out, uint32_t* out_count, uint64_t cap,
+                         fmo_counters* ctr);
 
 /* FuzzyMatch::subsequence (src/fuzzy_match.cc:250-365) after tokenisation, on vocabulary ids.  Returns 1 and fills
  * *out (score, max_subseq = length of the sub-n-gram, s_id; penalty 0) and *out_position (start of the sub-n-gram in

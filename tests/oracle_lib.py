@@ -98,6 +98,8 @@ def lib():
     L.fmo_match.argtypes = [vp, C.POINTER(Params), vp, u32, C.c_char_p, u32, C.POINTER(u64),
                             C.POINTER(C.c_char_p), vp, u64, C.POINTER(Counters)]
     L.fmo_match_batch.argtypes = [vp, C.POINTER(Params), vp, vp, u64, C.c_int, vp, vp, u64, C.POINTER(Counters)]
+    L.fmo_match_batch_real.argtypes = [vp, C.POINTER(Params), vp, vp, u64, vp, vp, C.c_int, vp, vp, u64, C.POINTER(Counters)]
+    L.fmo_index_set_real_bulk.argtypes = [vp, u32, u32, vp, vp]
     L.fmo_subsequence.argtypes = [vp, vp, u32, C.c_char_p, u32, C.POINTER(u64), C.POINTER(C.c_char_p), u32, C.c_int, C.c_int,
                                   C.c_float, C.c_int, vp, C.POINTER(u32)]
     L.fmo_edit_distance_ids.restype = C.c_float
@@ -121,6 +123,22 @@ def _itok_args(itoks):
     idx = (C.c_uint64 * max(n, 1))(*list(itoks.keys()))
     strs = (C.c_char_p * max(n, 1))(*[v.encode("utf-8") for v in itoks.values()])
     return n, idx, strs
+
+
+def tab_joined(stream, off):
+    """A NUL-separated spelling stream (one spelling per token, CSR offsets `off` in tokens) as the per-sentence tab-joined,
+    NUL-terminated strings the oracle takes (fuzzy::Sentence's tokstring).  Returns (packed uint8 array, uint64 byte offsets)."""
+    stream = np.array(stream, dtype=np.uint8, copy=True)
+    off = np.asarray(off, dtype=np.int64)
+    nul = np.flatnonzero(stream == 0)
+    assert len(nul) == off[-1], (len(nul), off[-1])
+    stream[nul] = 9
+    nonempty = off[1:] > off[:-1]
+    stream[nul[off[1:][nonempty] - 1]] = 0
+    packed = np.concatenate([stream, np.zeros(1, np.uint8)])
+    starts = np.concatenate([np.zeros(1, np.int64), nul + 1])   # byte where token t starts
+    boff = np.where(nonempty, starts[np.minimum(off[:-1], len(starts) - 1)], len(packed) - 1).astype(np.uint64)
+    return packed, boff
 
 
 class Vocab:
@@ -202,6 +220,14 @@ class OracleIndex:
         n, idx, strs = _itok_args(itoks)
         self.L.fmo_index_set_real(self.h, s_id, "\t".join(real).encode("utf-8"), n, idx, strs)
 
+    def set_real_bulk(self, packed, boff, first=0):
+        """Real tokens of sentences [first, first + len(boff)) from tab_joined()'s output (no penalty tokens)."""
+        packed = np.ascontiguousarray(packed, np.uint8)
+        boff = np.ascontiguousarray(boff, np.uint64)
+        rc = self.L.fmo_index_set_real_bulk(self.h, first, len(boff), _ptr(packed), _ptr(boff))
+        if rc != 0:
+            raise RuntimeError("oracle set_real_bulk failed")
+
     def arrays(self):
         L, h = self.L, self.h
         ns, nb, nsent, nq = (L.fmo_index_num_suffixes(h), L.fmo_index_buffer_size(h),
@@ -278,15 +304,21 @@ class OracleIndex:
             raise RuntimeError("oracle subsequence failed")
         return (out[0].copy(), int(pos.value)) if r else (None, 0)
 
-    def match_batch(self, params, q_off, q_tok, cap, nthreads=1, want_counters=False):
+    def match_batch(self, params, q_off, q_tok, cap, nthreads=1, want_counters=False, real=None):
+        """real: (packed, byte offsets) from tab_joined() — every pattern's `real` Sentence (no penalty tokens)."""
         q_off = np.ascontiguousarray(q_off, np.uint32)
         q_tok = np.ascontiguousarray(q_tok, np.uint32)
         nq = len(q_off) - 1
         out = np.zeros((max(nq, 1), cap), dtype=MATCH_DTYPE)
         cnt = np.zeros(max(nq, 1), dtype=np.uint32)
         ctr = Counters()
-        rc = self.L.fmo_match_batch(self.h, C.byref(params), _ptr(q_off), _ptr(q_tok), nq, nthreads, _ptr(out),
-                                    _ptr(cnt), cap, C.byref(ctr) if want_counters else None)
+        rp = ro = None
+        if real is not None:
+            rp, ro = np.ascontiguousarray(real[0], np.uint8), np.ascontiguousarray(real[1], np.uint64)
+            assert len(ro) == nq
+        rc = self.L.fmo_match_batch_real(self.h, C.byref(params), _ptr(q_off), _ptr(q_tok), nq, _ptr(rp) if rp is not None else None,
+                                         _ptr(ro) if ro is not None else None, nthreads, _ptr(out),
+                                         _ptr(cnt), cap, C.byref(ctr) if want_counters else None)
         if rc != 0:
             raise RuntimeError("oracle batch failed")
         return (out[:nq], cnt[:nq], ctr) if want_counters else (out[:nq], cnt[:nq])

@@ -274,3 +274,71 @@ uint64_t fms_pack_text(const uint32_t* ids, uint64_t n, char* out, uint64_t cap)
   }
   return at;
 }
+
+/* ---- the same sentences as TEXT the reference CLI would index under its default -p nbr,tag,cas (cli/src/FuzzyMatch-cli.cc:328):
+ * the first word of a sentence is capitalised, vocabulary types with k % 40 == 19 (~2 % of the Zipf mass) are NUMBERS written as the
+ * decimal digits of k.  Under nbr + cas (src/fuzzy_match.cc:123-192) a word's normalised token is its lower-case spelling and its
+ * real token the case feature ("C" capitalised, "L" lower case), a number's normalised token is the placeholder ｟num｠ and its
+ * real token the digits: every sentence's real tokens differ from its normalised tokens, which is what such an index costs. ---- */
+int fms_is_number(uint32_t k) { return k % 40u == 19u; }
+
+static int spell_cased(uint32_t id, int first, char* w /* >= 16 */) {
+  if (id == 0) { w[0] = '\0'; return 0; }
+  if (id == 1) { w[0] = '?'; w[1] = '\0'; return 1; }
+  const uint32_t k = id - 2;
+  if (fms_is_number(k)) {
+    char tmp[12];
+    int n = 0;
+    uint32_t v = k;
+    do { tmp[n++] = (char)('0' + v % 10u); v /= 10u; } while (v);
+    for (int i = 0; i < n; i++) w[i] = tmp[n - 1 - i];
+    w[n] = '\0';
+    return n;
+  }
+  const int n = fms_word(k, w, 16);
+  if (n > 0 && first) w[0] = (char)(w[0] - 'a' + 'A');
+  return n;
+}
+
+/* One '\n'-terminated line of blank-separated tokens per sentence.  Returns the bytes written, or the bytes needed when
+ * out == NULL / cap is too small (nothing is written past cap). */
+uint64_t fms_pack_lines_cased(const uint32_t* off, const uint32_t* ids, uint64_t n_sent, char* out, uint64_t cap) {
+  uint64_t at = 0;
+  char w[16];
+  for (uint64_t s = 0; s < n_sent; s++) {
+    for (uint32_t i = off[s]; i < off[s + 1]; i++) {
+      const int len = spell_cased(ids[i], i == off[s], w);
+      const uint64_t need = (uint64_t)(len > 0 ? len : 0) + 1;
+      if (out && at + need <= cap) { memcpy(out + at, w, need - 1); out[at + need - 1] = (i + 1 == off[s + 1]) ? '\n' : ' '; }
+      at += need;
+    }
+    if (off[s] == off[s + 1]) { if (out && at + 1 <= cap) out[at] = '\n'; at += 1; }
+  }
+  return at;
+}
+
+/* The two NUL-separated spelling streams _tokenize_and_normalize makes of those lines (what a caller hands fmx_match_batch_text as
+ * `text` and `real_text`): which = 0 the normalised tokens, 1 the real tokens.  Same size convention as fms_pack_text. */
+uint64_t fms_pack_cased_stream(const uint32_t* off, const uint32_t* ids, uint64_t n_sent, int which, char* out, uint64_t cap) {
+  static const char kNum[] = "\xEF\xBD\x9F" "num" "\xEF\xBD\xA0"; /* ｟num｠ */
+  uint64_t at = 0;
+  char w[16];
+  for (uint64_t s = 0; s < n_sent; s++)
+    for (uint32_t i = off[s]; i < off[s + 1]; i++) {
+      const uint32_t id = ids[i];
+      const char* src = w;
+      int len;
+      if (id >= 2 && fms_is_number(id - 2)) {
+        if (which == 0) { src = kNum; len = (int)sizeof kNum - 1; }
+        else len = spell_cased(id, 0, w);
+      } else if (id >= 2) {
+        if (which == 0) len = spell_cased(id, 0, w);
+        else { w[0] = i == off[s] ? 'C' : 'L'; w[1] = '\0'; len = 1; }
+      } else
+        len = spell_cased(id, 0, w); /* "" / "?": no case, real token = the token */
+      if (len < 0) len = 0;
+      if (out && at + (uint64_t)len + 1 <= cap) { memcpy(out + at, src, (size_t)len); out[at + len] = '\0'; }
+      at += (uint64_t)len + 1;
+    }
+  return at;
+}
