@@ -1068,6 +1068,10 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
   Ctx& c = E.c;
   const Params& prm = E.prm;
   const bool full = E.full, use_idf = E.use_idf;
+  // length classes of the candidate lists (dp_class): real tokens on both sides -> the register kernels with the real-token term
+  // (round 6: what an index built under the reference's default -p nbr,tag,cas runs), pairs with penalty tokens deferred to the general one
+  static const bool real_reg = [] { const char* e = getenv("FMX_REAL_REG"); return e ? atoi(e) != 0 : true; }();  // design-time switch
+  const int dp_mode = !full ? 0 : ((real_reg && E.d.real && b.q_real) ? (use_idf ? 3 : 2) : 1);
   Rec* d_out = E.d_out; uint32_t* d_out_count = E.d_out_count; uint32_t* d_out_total = E.d_out_total;
   const uint32_t cap = E.cap;
   hipStream_t stream = E.stream;
@@ -1242,10 +1246,10 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
     tick(); tick();
     {
       // dense per-class candidate lists: three exclusive scans of the per-query candidate counts
-      hipLaunchKernelGGL(k_classify, dim3((n_scan + 255) / 256), dim3(256), 0, stream, b, w, full ? 1 : 0);
+      hipLaunchKernelGGL(k_classify, dim3((n_scan + 255) / 256), dim3(256), 0, stream, b, w, dp_mode);
       hipLaunchKernelGGL(k_scan_lb<3>, dim3(scan_tiles), dim3(kScanThreads), 0, stream, w.c_in, w.c_off, (size_t)n_scan, n_scan,
                          c.scan_state(2), c.scan_ticket(2));
-      hipLaunchKernelGGL(k_cmap, dim3((b.nq + 1023) / 1024), dim3(1024), 0, stream, b, w, full ? 1 : 0, c.fin_list.p, pair_finish ? pair_max : (uint32_t)kWave);
+      hipLaunchKernelGGL(k_cmap, dim3((b.nq + 1023) / 1024), dim3(1024), 0, stream, b, w, dp_mode, c.fin_list.p, pair_finish ? pair_max : (uint32_t)kWave);
     }
     tick(); tick();
     {
@@ -1255,16 +1259,30 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
       const unsigned grid = 256 * dp_per_cu;  // grid-stride over the flat candidate list
       const unsigned grid_g = 1024;
       if (rows_in_hbm) c.g_rows.ensure((uint64_t)grid_g * kWave * (p_max + 1));
-      auto launch_rows = [&](bool with_side) {
+      auto launch_rows = [&](bool with_side, const unsigned long long* ext_list = nullptr) {
         if (with_side) {
-          if (rows_in_hbm) hipLaunchKernelGGL((k_dp<true, true>), dim3(grid_g), dim3(kWave), 0, stream, E.d, b, w, prm, c.g_rows.p, p_max + 1);
-          else hipLaunchKernelGGL((k_dp<true, false>), dim3(grid), dim3(kWave), lds, stream, E.d, b, w, prm, (float*)nullptr, 0u);
+          if (rows_in_hbm) hipLaunchKernelGGL((k_dp<true, true>), dim3(grid_g), dim3(kWave), 0, stream, E.d, b, w, prm, c.g_rows.p, p_max + 1, ext_list);
+          else hipLaunchKernelGGL((k_dp<true, false>), dim3(grid), dim3(kWave), lds, stream, E.d, b, w, prm, (float*)nullptr, 0u, ext_list);
         } else {
-          if (rows_in_hbm) hipLaunchKernelGGL((k_dp<false, true>), dim3(grid_g), dim3(kWave), 0, stream, E.d, b, w, prm, c.g_rows.p, p_max + 1);
-          else hipLaunchKernelGGL((k_dp<false, false>), dim3(grid), dim3(kWave), lds, stream, E.d, b, w, prm, (float*)nullptr, 0u);
+          if (rows_in_hbm) hipLaunchKernelGGL((k_dp<false, true>), dim3(grid_g), dim3(kWave), 0, stream, E.d, b, w, prm, c.g_rows.p, p_max + 1, ext_list);
+          else hipLaunchKernelGGL((k_dp<false, false>), dim3(grid), dim3(kWave), lds, stream, E.d, b, w, prm, (float*)nullptr, 0u, ext_list);
         }
       };
-      if (full) {
+      if (dp_mode >= 2) {
+        // real tokens: rows + both pattern streams in registers; pairs with penalty tokens (only looked for when the index has
+        // interned penalty strings) are handed over in c.keys — free between the candidate sorters and k_finish — to the general kernel
+        const int check_itok = E.d.n_itok > 1 ? 1 : 0;
+        const bool two = p_max > 32 && dp_mode == 2;
+        if (two) fork();
+        if (dp_mode == 3) hipLaunchKernelGGL((k_dp_reg<32, true, false, true>), dim3(grid), dim3(kWave), 0, stream, E.d, b, w, prm, c.keys.p, check_itok);
+        else {
+          if (two) hipLaunchKernelGGL((k_dp_reg<64, false, false, true>), dim3(grid), dim3(kWave), 0, side, E.d, b, w, prm, c.keys.p, check_itok);
+          hipLaunchKernelGGL((k_dp_reg<32, false, false, true>), dim3(grid), dim3(kWave), 0, stream, E.d, b, w, prm, c.keys.p, check_itok);
+        }
+        if (two) join();
+        if (p_max > (dp_mode == 3 ? 32u : 64u)) launch_rows(true);
+        if (check_itok) launch_rows(true, c.keys.p);
+      } else if (full) {
         launch_rows(true);
       } else {
         // by pattern length: row + pattern in 32 or 64 registers, longer ones with the row in LDS

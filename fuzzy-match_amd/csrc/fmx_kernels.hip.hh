@@ -116,6 +116,7 @@ struct DevWork {
                                  // [24],[25]=segment / queue entries the pass used (always written: the host sizes later workspaces by them)
                                  // [26]=passes whose token bounds disagree with q_off (k_setup; the call fails)
                                  // [27]=sentence-pair edit distances of the flattened contrastive rerank (k_cround)
+                                 // [28..31]=queries in k_cgrp_route's lists of 8 / 16 / 32 / 64 accepted matches
 };
 constexpr int kStatSlots = 64;     // k_expand_h's three statistics are summed into 64 slots each (kStatBase + 3 x 64): 8192 workgroups
                                    // adding to three single words at the end of the kernel queued for ~0.1 ms; k_stats folds them into [16..18]
@@ -123,7 +124,9 @@ constexpr int kStatBase = 32;
 constexpr int kTailLists = 256;    // k_probe queues start positions for k_probe_tail in this many lists (a single fill counter would see
                                    // one returning atomic per wave, 400 k per step at C3: they serialise — measured 4 ms)
 constexpr int kCtrProbeTail = kStatBase + 3 * kStatSlots;   // counters[kCtrProbeTail + l] = entries of list l
-constexpr int kNumCounters = kCtrProbeTail + kTailLists;
+constexpr int kCtrDpDefer = kCtrProbeTail + kTailLists;   // (query, candidate) pairs with penalty tokens handed from k_dp_reg<.., REAL> to k_dp<true, *>
+                                                          // ([28..31] are k_cgrp_route's four list lengths)
+constexpr int kNumCounters = kCtrDpDefer + 8;
 
 constexpr int kWave = 64;
 constexpr uint32_t kLdsSortMax = 1024;   // per-wave LDS sort capacity (keys)
@@ -2349,7 +2352,13 @@ __global__ void __launch_bounds__(kRankThreads) k_prank(DevBatch b, DevWork w) {
   }
 }
 
-__device__ __forceinline__ uint32_t dp_class(uint32_t p, int full) { return full ? 2u : (p <= 32 ? 0u : (p <= 64 ? 1u : 2u)); }
+// length class of a pattern's candidates in the dense lists.  full: 0 = ids only (register kernels for p <= 32 / <= 64, LDS rows
+// beyond), 1 = every pair through the general kernel (class 2), 2 = real tokens through the register kernels (round 6), 3 = the
+// same with the idf term (the 64-token variant would need 4 x 64 registers: 33..64 tokens stay with the general kernel)
+__device__ __forceinline__ uint32_t dp_class(uint32_t p, int full) {
+  if (full == 1) return 2u;
+  return p <= 32 ? 0u : ((p <= 64 && full != 3) ? 1u : 2u);
+}
 
 __global__ void k_classify(DevBatch b, DevWork w, int full) {
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2440,17 +2449,21 @@ struct LdsRow {
 
 // GROWS: the rows live in HBM (g_rows: row_len x 64 floats per workgroup) instead of dynamic LDS — patterns longer
 // than ~590 tokens (--max-tokens-in-pattern above the default, include/fuzzy/suffix_array_index.hh:15).
+// ext_list (round 6): the pairs k_dp_reg<.., REAL> deferred (counters[kCtrDpDefer] of them) instead of length class 2.
 template <bool FULL, bool GROWS>
-__global__ void __launch_bounds__(kWave) k_dp(DevIndex ix, DevBatch b, DevWork w, Params prm, float* g_rows, uint32_t row_len) {
+__global__ void __launch_bounds__(kWave) k_dp(DevIndex ix, DevBatch b, DevWork w, Params prm, float* g_rows, uint32_t row_len,
+                                              const unsigned long long* ext_list = nullptr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* s_rows = GROWS ? g_rows + (size_t)blockIdx.x * row_len * kWave : (float*)smem;
   const uint32_t lane = lane_id();
   unsigned long long j_lo, j_hi;
   dp_class_range(b, w, 2, j_lo, j_hi);
+  const unsigned long long* list = w.c_qi;
+  if (ext_list) { list = ext_list; j_lo = 0; j_hi = w.counters[kCtrDpDefer]; }
   const bool use_idf = prm.idf_penalty != 0.f;
   for (unsigned long long j = j_lo + (unsigned long long)blockIdx.x * kWave + lane; j < j_hi;
        j += (unsigned long long)gridDim.x * kWave) {
-    const unsigned long long qi = w.c_qi[j];
+    const unsigned long long qi = list[j];
     const uint32_t q = (uint32_t)(qi >> 32);
     Cand* cd = w.seg + (uint32_t)qi;
     const Cand c0 = *cd;
@@ -2468,10 +2481,14 @@ __global__ void __launch_bounds__(kWave) k_dp(DevIndex ix, DevBatch b, DevWork w
     if (FULL) {
       if (ix.real && b.q_real) { side.s_real = ix.real + sp + 1; side.p_real = b.q_real + o0; }
       if (ix.itok_dist) {
-        side.itok_dist = ix.itok_dist;
-        side.n_itok = ix.n_itok;
         side.s_itok = ix.itok ? ix.itok + sp : nullptr;
         side.p_itok = b.q_itok ? b.q_itok + o0 + (b.q_begin + q) : nullptr;
+        // a pair without a penalty token on either side (the common one) only ever reads zeros from the distance table: every
+        // cost_tag term is + 0.f, the same bits as no term — skip the three table reads per cell
+        uint32_t any = ext_list ? 1u : 0u;
+        if (!any && side.s_itok) for (uint32_t i = 0; i <= slen; i++) any |= side.s_itok[i];
+        if (!any && side.p_itok) for (uint32_t i = 0; i <= p; i++) any |= side.p_itok[i];
+        if (any) { side.itok_dist = ix.itok_dist; side.n_itok = ix.n_itok; }
       }
       if (use_idf) {
         side.p_idf = w.t_idf + (o0 - b.t_begin);
@@ -2494,18 +2511,28 @@ __global__ void __launch_bounds__(kWave) k_dp(DevIndex ix, DevBatch b, DevWork w
 // (dependencies only run left to right), and no LDS or memory access remains in the cell update.
 // Same operations in the same order as edit_distance<false>, so the results are bit-identical.
 // ---------------------------------------------------------------------------------------------
-template <int P, bool IDF = false, bool EXACT = false>
+// REAL (round 6): the real-token term of the full _edit_distance (src/edit_distance.cc:53-62) for pairs WITHOUT penalty tokens — equal
+// words whose real tokens differ cost replace x diff_case (1) when the sentence's real token is a case feature, replace x diff_real (2)
+// otherwise (include/fuzzy/costs.hh:58-61; NOT scaled by diff_word).  s_real / p_real: interned real-token ids per token slot (bit 31 of
+// the sentence's = "first byte in LUMC or empty").  With every cost_tag term zero the full recurrence adds 0.f where this one adds
+// nothing: same bits.  What an index built under the reference CLI's default -p nbr,tag,cas runs for every candidate.
+template <int P, bool IDF = false, bool EXACT = false, bool REAL = false>
 __device__ __forceinline__ float edit_distance_reg(const uint32_t* __restrict__ sent, uint32_t n1,
                                                    const uint32_t* __restrict__ pat, uint32_t n2, float ins,
                                                    float del, float rep, float dw, float& M_out,
-                                                   const float* __restrict__ p_idf = nullptr, float idf_weight = 0.f) {
+                                                   const float* __restrict__ p_idf = nullptr, float idf_weight = 0.f,
+                                                   const uint32_t* __restrict__ s_real = nullptr,
+                                                   const uint32_t* __restrict__ p_real = nullptr) {
   const float del_dw = del * dw, ins_dw = ins * dw, rep_dw = rep * dw;
+  const float rep_case = rep * 1.f, rep_real = rep * 2.f;
   float    row[P + 1];
   uint32_t pt[P];
+  uint32_t pr[REAL ? P : 1];
   float    pen[IDF ? P : 1];
 #pragma unroll
   for (int j = 0; j < P; j++) {
     pt[j] = (EXACT || (uint32_t)j < n2) ? pat[j] : 0xffffffffu;  // EXACT: n2 == P for every lane of the wave
+    if (REAL) pr[j] = (EXACT || (uint32_t)j < n2) ? p_real[j] : 0u;
     if (IDF) pen[j] = (EXACT || (uint32_t)j < n2) ? p_idf[j] * idf_weight : 0.f;  // idf_penalty[j] * idf_weight, edit_distance.cc:36,49
   }
   row[0] = 0.f;
@@ -2517,9 +2544,14 @@ __device__ __forceinline__ float edit_distance_reg(const uint32_t* __restrict__ 
   }
   float M = 0.f, final_v = 0.f;
   uint32_t wd_next = n1 ? sent[0] : 0u;
+  uint32_t rl_next = (REAL && n1) ? s_real[0] : 0u;
   for (uint32_t i = 1; i <= n1; i++) {
     const uint32_t wd = wd_next;
+    const uint32_t rl = rl_next;
     wd_next = i < n1 ? sent[i] : 0u;  // next row's token is in flight while this row is computed
+    if (REAL) rl_next = i < n1 ? s_real[i] : 0u;
+    const uint32_t rd = rl & 0x7fffffffu;
+    const float c_real = (rl >> 31) ? rep_case : rep_real;  // strchr("LUMC", real1tok[i-1][0]), edit_distance.cc:57
     float diag = row[0];
     float left = diag + del_dw;
     row[0] = left;
@@ -2528,10 +2560,11 @@ __device__ __forceinline__ float edit_distance_reg(const uint32_t* __restrict__ 
     for (int j = 1; j <= P; j++) {
       const float up = row[j];
       float bb = left + ins_dw;
-      float diff = (wd != pt[j - 1]) ? rep_dw : 0.f;
+      const float same = REAL ? ((rd != pr[REAL ? j - 1 : 0]) ? c_real : 0.f) : 0.f;
+      float diff = (wd != pt[j - 1]) ? rep_dw : same;
       if (IDF) {
         bb = bb + pen[j - 1];
-        diff = (wd != pt[j - 1]) ? (rep_dw + pen[j - 1]) : 0.f;
+        diff = (wd != pt[j - 1]) ? (rep_dw + pen[j - 1]) : same;
       }
       // v_min_f32: same value as std::min for the finite, non-negative costs of this path
       const float d = __builtin_fminf(__builtin_fminf(up + del_dw, bb), diag + diff);
@@ -2630,27 +2663,33 @@ __device__ __forceinline__ float edit_distance_unit_dispatch(uint32_t p_u, const
 }
 
 // Dispatch on the wave's common pattern length: the variant compiled for exactly that length.
-template <int LO, int HI, bool IDF>
+template <int LO, int HI, bool IDF, bool REAL = false>
 __device__ __forceinline__ float edit_distance_exact_dispatch(uint32_t p_u, const uint32_t* __restrict__ sent, uint32_t n1,
                                                               const uint32_t* __restrict__ pat, float ins, float del,
                                                               float rep, float dw, float& M, const float* p_idf,
-                                                              float idf_weight) {
+                                                              float idf_weight, const uint32_t* __restrict__ s_real = nullptr,
+                                                              const uint32_t* __restrict__ p_real = nullptr) {
   if constexpr (LO == HI) {
-    return edit_distance_reg<LO, IDF, true>(sent, n1, pat, (uint32_t)LO, ins, del, rep, dw, M, p_idf, idf_weight);
+    return edit_distance_reg<LO, IDF, true, REAL>(sent, n1, pat, (uint32_t)LO, ins, del, rep, dw, M, p_idf, idf_weight, s_real, p_real);
   } else {
     constexpr int MID = (LO + HI) / 2;
     if (p_u <= (uint32_t)MID)
-      return edit_distance_exact_dispatch<LO, MID, IDF>(p_u, sent, n1, pat, ins, del, rep, dw, M, p_idf, idf_weight);
-    return edit_distance_exact_dispatch<MID + 1, HI, IDF>(p_u, sent, n1, pat, ins, del, rep, dw, M, p_idf, idf_weight);
+      return edit_distance_exact_dispatch<LO, MID, IDF, REAL>(p_u, sent, n1, pat, ins, del, rep, dw, M, p_idf, idf_weight, s_real, p_real);
+    return edit_distance_exact_dispatch<MID + 1, HI, IDF, REAL>(p_u, sent, n1, pat, ins, del, rep, dw, M, p_idf, idf_weight, s_real, p_real);
   }
 }
 
 // UNIT: insert = delete = replace >= 0 and no idf term (decided by the host): bit-parallel distance
+// REAL (round 6): the index carries real tokens (ix.real) and the batch its patterns' (b.q_real): the float recurrence with the
+// real-token term, rows and both pattern streams in registers.  A pair that carries a penalty token on either side (the index has
+// interned penalty strings or the batch brings a q_itok array: `check_itok`) is not computed here: its list entry goes to `defer`
+// (count in counters[kCtrDpDefer]) for k_dp<true, *>, the general kernel.
 #ifndef FMX_DPREG_WAVES
 #define FMX_DPREG_WAVES 8
 #endif
-template <int P, bool IDF, bool UNIT = false>
-__global__ void __launch_bounds__(kWave, (UNIT && P == 32) ? FMX_DPREG_WAVES : 1) k_dp_reg(DevIndex ix, DevBatch b, DevWork w, Params prm) {
+template <int P, bool IDF, bool UNIT = false, bool REAL = false>
+__global__ void __launch_bounds__(kWave, (UNIT && P == 32) ? FMX_DPREG_WAVES : 1) k_dp_reg(DevIndex ix, DevBatch b, DevWork w, Params prm,
+                                                                                          unsigned long long* defer = nullptr, int check_itok = 0) {
   const uint32_t lane = lane_id();
   unsigned long long j_lo, j_hi;
   dp_class_range(b, w, P == 32 ? 0u : 1u, j_lo, j_hi);
@@ -2671,9 +2710,22 @@ __global__ void __launch_bounds__(kWave, (UNIT && P == 32) ? FMX_DPREG_WAVES : 1
     uint32_t tb = __float_as_uint(c0.score), slen = c0.longest >> 16;  // 0 = unknown (candidates rebuilt by k_cand*)
     if (tb == 0) { const uint32_t sp0 = ix.sent_pos[c0.sid]; slen = ix.tok[sp0]; tb = sp0 + 1; }
     const uint32_t* sent = ix.tok + tb;
+    if constexpr (REAL) {
+      if (check_itok) {  // penalty tokens sit in slots [0, n] of either side (slot n = the trailing one): any -> the general kernel
+        uint32_t any = 0;
+        if (ix.itok) for (uint32_t i = 0; i <= slen; i++) any |= ix.itok[tb - 1 + i];
+        if (b.q_itok) for (uint32_t i = 0; i <= p; i++) any |= b.q_itok[o0 + (b.q_begin + q) + i];
+        if (any) {
+          defer[atomicAdd(&w.counters[kCtrDpDefer], 1ull)] = qi;
+          continue;
+        }
+      }
+    }
     const float dw = 100.f / normalizer(p, slen, prm.ins, prm.del, prm.rep);
     const float* p_idf = w.t_idf + (o0 - b.t_begin);
     const float idf_weight = (dw * prm.idf_penalty) / prm.idf_max;  // src/fuzzy_match.cc:591
+    const uint32_t* s_real = REAL ? ix.real + tb : nullptr;
+    const uint32_t* p_real = REAL ? b.q_real + o0 : nullptr;
     float M, final_cost;
     // the list is in pattern-length order: all active lanes of a wave normally share one length
     const uint32_t p_u = __builtin_amdgcn_readfirstlane(p);
@@ -2683,10 +2735,10 @@ __global__ void __launch_bounds__(kWave, (UNIT && P == 32) ? FMX_DPREG_WAVES : 1
       if (same_p) final_cost = edit_distance_unit_dispatch<(P == 32 ? 1 : 33), P>(p_u, sent, slen, pat, inc, M);
       else final_cost = edit_distance_unit<P, false>(sent, slen, pat, p, inc, M);
     } else if (same_p)
-      final_cost = edit_distance_exact_dispatch<(P == 32 ? 1 : 33), P, IDF>(p_u, sent, slen, pat, prm.ins, prm.del, prm.rep,
-                                                                          dw, M, p_idf, idf_weight);
+      final_cost = edit_distance_exact_dispatch<(P == 32 ? 1 : 33), P, IDF, REAL>(p_u, sent, slen, pat, prm.ins, prm.del, prm.rep,
+                                                                                dw, M, p_idf, idf_weight, s_real, p_real);
     else
-      final_cost = edit_distance_reg<P, IDF>(sent, slen, pat, p, prm.ins, prm.del, prm.rep, dw, M, p_idf, idf_weight);
+      final_cost = edit_distance_reg<P, IDF, false, REAL>(sent, slen, pat, p, prm.ins, prm.del, prm.rep, dw, M, p_idf, idf_weight, s_real, p_real);
     Cand* cd = w.seg + slot;
     cd->score = final_cost;
     cd->penalty = M;
