@@ -96,7 +96,10 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--verify", type=int, default=20000, help="queries of rank 0 checked against the oracle in every leg, spread evenly over a batch")
     ap.add_argument("--model-queries", type=int, default=20000, help="queries the reference byte model is counted on")
-    ap.add_argument("--via-fmi", action="store_true", help="the index goes through the reference's on-disk format first: fmx_index_save -> fmx_index_load "
+    ap.add_argument("--no-via-fmi", action="store_true", help="skip the .fmi round trip of the index (the default at N > 1: every rank would write its own 2 GB file)")
+    ap.add_argument("--no-default-index", action="store_true", help="skip the cli_default_index leg (N = 1 only): the workload on an index built from cased TEXT "
+                    "by fmx-cli -c under the reference's default -p nbr,tag,cas, whose real tokens differ from its normalised tokens")
+    ap.add_argument("--via-fmi", action="store_true", help="(the default at N = 1 since round 6) the index goes through the reference's on-disk format first: fmx_index_save -> fmx_index_load "
                                                            "(arrays compared, times and file size reported); the steps then run on the LOADED index")
     return ap.parse_args()
 
@@ -256,7 +259,7 @@ def main():
     w_arena = np.frombuffer(b"".join(w + b"\0" for w in words[2:]), dtype=np.uint8).copy()
     word_ptrs = ix.set_forms_packed(w_arena, w_offs)
     via_fmi = None
-    if args.via_fmi:
+    if (args.via_fmi or world == 1) and not args.no_via_fmi:
         via_fmi = through_fmi(fmx, ix, local_rank, rank, log)
         ix = via_fmi.pop("index")
         word_ptrs = ix.set_forms_packed(w_arena, w_offs)   # (same spellings: pointers for the host-lookup leg)
@@ -653,6 +656,19 @@ def main():
         except Exception as e:  # noqa: BLE001
             log(f"[bench] cli_raw_text leg failed: {e!r}")
 
+    # ---- the reference CLI's DEFAULT kind of index (built from cased text under -p nbr,tag,cas: real tokens differ from the normalised
+    # tokens, every candidate pays the real-token term of _edit_distance): tools/default_index_leg.py ----
+    default_leg = None
+    if world == 1 and not args.no_default_index and not args.no_text_leg:
+        try:
+            import default_index_leg
+            default_leg = default_index_leg.run(fmx, synth, torch, dev, c_off, c_tok, [(w.q_off, w.q_tok) for w in text_set], pkw, cap, T_text, args.steps,
+                                                args.warmup, args.verify, log, id_only_value=value)
+        except AssertionError:
+            raise
+        except Exception as e:  # noqa: BLE001  (a side leg)
+            log(f"[bench] cli_default_index leg failed: {e!r}")
+
     # ---- one call at a time from HBM (device entry point with statistics): stage times for the rooflines ----
     run_device_steps(main_set, 1)
     el_dev, dev_stats = timed(lambda k: run_device_steps(main_set, k), args.steps)
@@ -885,9 +901,12 @@ def main():
             o.match_batch(oprm, q_off[:ns2 + 1], q_tok[:int(q_off[ns2])], cap, nthreads=cores)
             dt = time.perf_counter() - t1
             # the same with ONE thread ("with N = all host cores ... and with N = 1"), a few seconds of it
-            ns1 = int(min(ns2, max(500, rate / max(cores, 1) * min(args.cpu_seconds, 6.0))))
+            # (round 6: every (ns2 / ns1)-th query of the SAME ns2 queries, after the all-threads run has walked the index)
+            ns1 = int(min(ns2, max(500, rate / max(cores, 1) * min(args.cpu_seconds, 8.0))))
+            i1 = (np.arange(ns1, dtype=np.int64) * ns2 // max(ns1, 1))
+            o1, t1q = take_queries(q_off, q_tok, i1)
             t1 = time.perf_counter()
-            o.match_batch(oprm, q_off[:ns1 + 1], q_tok[:int(q_off[ns1])], cap, nthreads=1)
+            o.match_batch(oprm, o1, t1q, cap, nthreads=1)
             dt1 = time.perf_counter() - t1
             cpu_model = ""
             try:
@@ -903,8 +922,9 @@ def main():
                                          "to the quota and not beyond",
                             "sample": f"first {ns2} queries of batch 0 of the same {args.config} workload, oracle/fm_oracle.c "
                                       f"fmo_match_batch with {cores} threads (= usable CPUs: min(affinity, cgroup cpu.max) of "
-                                      f"{os.cpu_count()} hardware threads), ids in (no lookup), {dt:.1f}s; value_n1: the first {ns1} of them "
-                                      f"with one thread, {dt1:.1f}s"}
+                                      f"{os.cpu_count()} hardware threads), ids in (no lookup), {dt:.1f}s; value_n1: {ns1} of the same {ns2} queries (every "
+                                      f"{ns2 / max(ns1, 1):.1f}-th) with one thread, afterwards, {dt1:.1f}s",
+                            "sample_queries": int(ns2), "sample_queries_n1": int(ns1)}
         o.close()
 
         text_bytes = int(text_set[0].text.nbytes)
@@ -933,6 +953,7 @@ def main():
                                    "note": "fmx_match_batch: vocabulary ids in pinned host memory in, records out (H2D + kernels + D2H"
                                            + (" + the RCCL gather" if world > 1 else "") + "): a caller that already holds ids"},
             "text_sync_callers": text_sync, "from_token_strings": from_strings, "cli_end_to_end": cli_leg, "cli_raw_text": cli_raw_leg,
+            "cli_default_index": default_leg,
             "staged": {"value": round(nq_step_all * args.steps / el_dev, 1),
                        "ms_per_step": round(el_dev / args.steps * 1e3, 3),
                        "stage_ms_per_step": {k: round(v, 4) for k, v in per_stage.items()},

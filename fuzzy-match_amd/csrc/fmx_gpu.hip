@@ -969,8 +969,13 @@ void DeviceIndex::upload(const HostIndex& h, int device, SortResident* res) {
   }
   hipFree(d_ssig);
   if (h.real_differs) {
-    m.d.real = dev_upload(h.real_ids);
-    m.d.itok = dev_upload(h.itok_ids);
+    // (eight spare words like the token buffer: the register kernels read a sentence's real-token ids four at a time)
+    for (auto pr : {std::make_pair(&m.d.real, &h.real_ids), std::make_pair(&m.d.itok, &h.itok_ids)}) {
+      uint32_t* d = dev_alloc<uint32_t>(pr.second->size() + 8);
+      HIP_TRY(hipMemset(d, 0, (pr.second->size() + 8) * sizeof(uint32_t)));
+      if (!pr.second->empty()) HIP_TRY(hipMemcpy(d, pr.second->data(), pr.second->size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+      *pr.first = d;
+    }
     if (d_old_pos) {  // the per-slot twins of the token buffer follow it into the device layout
       const uint32_t ns = (uint32_t)h.sent_pos.size();
       for (const uint32_t** twin : {&m.d.real, &m.d.itok}) {
@@ -1282,7 +1287,7 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
         if (two) join();
         if (p_max > (dp_mode == 3 ? 32u : 64u)) launch_rows(true);
         if (check_itok) launch_rows(true, c.keys.p);
-      } else if (full) {
+      } else if (dp_mode == 1) {
         launch_rows(true);
       } else {
         // by pattern length: row + pattern in 32 or 64 registers, longer ones with the row in LDS

@@ -234,3 +234,4 @@ def test_long_sentences_beyond_threshold_table(fmx, gpu_device):
         for q in range(len(qs)):
             long_hit |= bool(np.any(lens[oo["s_id"][q, :oc[q]]] > 1024))
     assert long_hit  # at least one accepted match is a sentence outside the table
+

@@ -175,8 +175,8 @@ def run(fmx, synth, torch, dev, c_off, c_tok, batches, pkw, cap, t_text, steps, 
         per_stage = {n: round(float(ms[i] / len(sts)), 4) for i, n in enumerate(names)}
         res["staged"] = {"ms_per_step": round(float(np.mean([s.ms_total for s in sts])), 3), "stage_ms": per_stage,
                          "dp_pairs": int(np.mean([float(s.n_dp) for s in sts]))}
-        staged_rec = d_out[torch.from_numpy(sidx).to(dev)].cpu().numpy().view(fmx.MATCH_DTYPE).reshape(len(sidx), cap) if last == 0 else None
-        staged_cnt = d_cnt[torch.from_numpy(sidx).to(dev)].cpu().numpy().astype(np.uint32) if last == 0 else None
+        staged_rec = d_out[torch.from_numpy(sidx).to(dev)].cpu().numpy().view(fmx.MATCH_DTYPE).reshape(len(sidx), cap)
+        staged_cnt = d_cnt[torch.from_numpy(sidx).to(dev)].cpu().numpy().astype(np.uint32)
         log(f"[default-index] value {value / 1e6:.2f} M patterns/s ({el / steps * 1e3:.3f} ms/step, {t_text} text calls in flight, real-token stream); "
             f"staged {res['staged']['ms_per_step']:.3f} ms/step, dp {per_stage.get('dp', 0.0):.3f} ms")
 
@@ -227,19 +227,19 @@ def run(fmx, synth, torch, dev, c_off, c_tok, batches, pkw, cap, t_text, steps, 
             (oo, oc), (s_off, s_gen) = oracle_on(wls[sample[0]], sample[1])
             bad = [q for q in range(len(sidx)) if int(oc[q]) != int(sample[3][q]) or oo[q, :oc[q]].tobytes() != sample[2][q, :oc[q]].tobytes()]
             par = {"text_with_real_stream": {"checked": int(len(sidx)), "mismatches": len(bad)}}
-            if staged_rec is not None:
-                bad_s = [q for q in range(len(sidx)) if int(oc[q]) != int(staged_cnt[q]) or oo[q, :oc[q]].tobytes() != staged_rec[q, :oc[q]].tobytes()]
-                par["staged_real_ids"] = {"checked": int(len(sidx)), "mismatches": len(bad_s)}
-                bad = bad + bad_s
+            # the staged calls (interned real ids in HBM) and the CLI ran batch 0
+            (o0, c0), _ = ((oo, oc), None) if sample[0] == 0 else oracle_on(wls[0], sidx)
+            bad_s = [q for q in range(len(sidx)) if int(c0[q]) != int(staged_cnt[q]) or o0[q, :c0[q]].tobytes() != staged_rec[q, :c0[q]].tobytes()]
+            par["staged_real_ids"] = {"checked": int(len(sidx)), "mismatches": len(bad_s)}
+            bad = bad + bad_s
             # how many of the sampled records carry a real-token cost (differ from what ids alone give)
             o_ids, c_ids = o.match_batch(oprm, s_off, m[s_gen], cap, nthreads=nth, real=oracle_lib.tab_joined(synth.pack_cased_stream(s_off, s_gen, 0), s_off))
             par["queries_whose_records_differ_from_ids_only"] = int(sum(1 for q in range(len(sidx)) if oo[q, :oc[q]].tobytes() != o_ids[q, :c_ids[q]].tobytes()))
             if of and os.path.exists(of):
                 # the CLI prints score and s_id per match (cli:219-233): compare the printed lines of the sampled queries
-                if sample[0] == 0:
-                    nbad = _check_cli_output(of, sidx, oo, oc, ix)
-                    par["cli_raw_text"] = {"checked": int(len(sidx)), "mismatches": nbad}
-                    bad = bad + [0] * nbad
+                nbad = _check_cli_output(of, sidx, o0, c0, ix)
+                par["cli_raw_text"] = {"checked": int(len(sidx)), "mismatches": nbad}
+                bad = bad + [0] * nbad
             par["oracle_s"] = round(time.time() - t0, 1)
             res["parity"] = par
             log(f"[default-index] parity vs the oracle with real tokens: {par}")
