@@ -262,7 +262,7 @@ def main():
     if (args.via_fmi or world == 1) and not args.no_via_fmi:
         via_fmi = through_fmi(fmx, ix, local_rank, rank, log)
         ix = via_fmi.pop("index")
-        word_ptrs = ix.set_forms_packed(w_arena, w_offs)   # (same spellings: pointers for the host-lookup leg)
+        # (the loaded index holds the same spellings — they came through the file —: word_ptrs keeps pointing into w_arena)
     else:
         ix.to_device(local_rank)
     ix.set_option("contexts", max(2, T_dev))

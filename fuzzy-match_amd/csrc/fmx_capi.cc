@@ -479,6 +479,7 @@ int fmx_match_batch_keep(fmx_index* ix, const fmx_params* params, const fmx_batc
 // beyond the batch's tokens (+ one trailing slot per pattern) are refused here, on the host (they are few)
 static const char* text_batch_itoks_invalid(fmx_index* ix, const fmx_text_batch* tb) {
   if (!tb->n_itoks || !ix->host.real_differs) return nullptr;
+  if (tb->nq == 0 || !tb->q_off) return "text batch: penalty tokens without patterns";  // (nq == 0 may come with q_off == NULL)
   uint64_t n_known;
   { std::lock_guard<std::mutex> g(ix->host.itok_sync_mu); n_known = ix->host.itok_strings.size(); }
   const uint64_t n_slots = (uint64_t)tb->q_off[tb->nq] + tb->nq;
@@ -655,6 +656,8 @@ int fmx_match_batch_raw_lines(fmx_index* ix, const fmx_params* params, const cha
         at.reserve(n_lines + 1);
         at.push_back(0);
         for (const char* p = text; p < text + n_bytes;) { const char* nl = (const char*)memchr(p, '\n', (size_t)(text + n_bytes - p)); p = nl + 1; at.push_back((uint64_t)(p - text)); }
+        // (the device path refuses a wrong line count itself; here every line is the host's: same answer, before a worker indexes `at`)
+        if (at.size() != n_lines + 1) throw std::invalid_argument("line batch: the text does not hold exactly n_lines line feeds");
       } else {
         at.resize(host_lines.size() * 2);
         uint64_t line = 0, want = 0;
@@ -677,10 +680,14 @@ int fmx_match_batch_raw_lines(fmx_index* ix, const fmx_params* params, const cha
             tokenize_and_normalize(pt, std::string(text + b0, (size_t)(b1 - b0)), toks[i]);
           }
         };
+        // (a worker's exception — bad_alloc, an ICU error in the general tokenizer — is carried to this thread, not to std::terminate)
+        std::vector<std::exception_ptr> err(nt);
+        auto guarded_work = [&](uint64_t t, uint64_t a, uint64_t b) { try { work(a, b); } catch (...) { err[t] = std::current_exception(); } };
         std::vector<std::thread> th;
-        for (uint64_t t = 1; t < nt; t++) th.emplace_back(work, nh * t / nt, nh * (t + 1) / nt);
-        work(0, nh / nt);
+        for (uint64_t t = 1; t < nt; t++) th.emplace_back(guarded_work, t, nh * t / nt, nh * (t + 1) / nt);
+        guarded_work(0, 0, nh / nt);
         for (auto& t : th) t.join();
+        for (auto& e : err) if (e) std::rethrow_exception(e);
       }
       const bool real = ix->host.real_differs;
       for (uint64_t i = 0; i < nh; i++) q_off[i + 1] = q_off[i] + (uint32_t)toks[i].norm.size();
@@ -1083,10 +1090,15 @@ int64_t fmx_index_add_text_bulk(fmx_index* ix, const char* const* ids, const cha
       std::vector<Part> parts(nt);
       auto range = [&](uint64_t t) { return std::make_pair(m * t / nt, m * (t + 1) / nt); };
       auto run = [&](const std::function<void(uint64_t)>& fn) {
+        // (a worker's exception — bad_alloc on the packed strings or the per-thread frequency arrays, an ICU error in the general
+        // tokenizer — is carried to this thread and on to guarded(), not to std::terminate)
+        std::vector<std::exception_ptr> err(nt);
+        auto safe = [&](uint64_t t) { try { fn(t); } catch (...) { err[t] = std::current_exception(); } };
         std::vector<std::thread> th;
-        for (uint64_t t = 1; t < nt; t++) th.emplace_back(fn, t);
-        fn(0);
+        for (uint64_t t = 1; t < nt; t++) th.emplace_back(safe, t);
+        safe(0);
         for (auto& t : th) t.join();
+        for (auto& e : err) if (e) std::rethrow_exception(e);
       };
       static const bool timing = getenv("FMX_BULK_TIMING") != nullptr;  // design-time
       auto now = [] { return std::chrono::steady_clock::now(); };
@@ -1127,14 +1139,8 @@ int64_t fmx_index_add_text_bulk(fmx_index* ix, const char* const* ids, const cha
         }
       });
       const auto tp1 = now();
-      // ---- 2 ----
-      {
-        std::vector<std::tuple<uint64_t, uint32_t, const std::string*>> order;
-        for (auto& P : parts) for (auto& kv : P.fresh) order.emplace_back(kv.second.first, kv.second.second, &kv.first);
-        std::sort(order.begin(), order.end(), [](const auto& x, const auto& y) { return std::get<0>(x) != std::get<0>(y) ? std::get<0>(x) < std::get<0>(y) : std::get<1>(x) < std::get<1>(y); });
-        for (auto& o : order) H.add_word(*std::get<2>(o));  // (a word several threads met: the earliest occurrence adds it, the others find it)
-      }
-      // where every thread's sentences and tokens go
+      // where every thread's sentences and tokens go (the 2^32 limit is checked BEFORE the vocabulary changes: a refused block
+      // leaves the index as it was)
       std::vector<uint64_t> s_base(nt + 1, 0), t_base(nt + 1, 0);
       for (uint64_t t = 0; t < nt; t++) {
         uint64_t ns = 0, ntk = 0;
@@ -1144,6 +1150,13 @@ int64_t fmx_index_add_text_bulk(fmx_index* ix, const char* const* ids, const cha
       const uint64_t sent0 = H.sent_pos.size(), buf0 = H.buf.size(), suf0 = H.suf_sid.size();
       if (sent0 + s_base[nt] > 0xffffffffull || buf0 + t_base[nt] + 2 * s_base[nt] > 0xffffffffull)
         throw std::runtime_error("more than 2^32 - 1 sentences or buffer words");
+      // ---- 2 ----
+      {
+        std::vector<std::tuple<uint64_t, uint32_t, const std::string*>> order;
+        for (auto& P : parts) for (auto& kv : P.fresh) order.emplace_back(kv.second.first, kv.second.second, &kv.first);
+        std::sort(order.begin(), order.end(), [](const auto& x, const auto& y) { return std::get<0>(x) != std::get<0>(y) ? std::get<0>(x) < std::get<0>(y) : std::get<1>(x) < std::get<1>(y); });
+        for (auto& o : order) H.add_word(*std::get<2>(o));  // (a word several threads met: the earliest occurrence adds it, the others find it)
+      }
       H.sent_pos.resize(sent0 + s_base[nt]);
       H.buf.resize(buf0 + t_base[nt] + 2 * s_base[nt]);
       H.suf_sid.resize(suf0 + t_base[nt]);

@@ -217,7 +217,7 @@ constexpr int kMaxPassesInFlight = 2;
 static const uint64_t kTurnMinQueries = [] { const char* e = getenv("FMX_TURN_MIN"); return e ? (uint64_t)atoll(e) : (uint64_t)262144; }();  // device-resident calls at least this large are chained on the GPU (Impl::turns), smaller ones overlap freely (design-time switch FMX_TURN_MIN)
 static const uint64_t kTurnMinQueriesHost = [] { const char* e = getenv("FMX_TURN_MIN_HOST"); return e ? (uint64_t)atoll(e) : (uint64_t)32768; }();  // host-buffer calls: chained from here on (their copies interleave badly when the kernels of
                                                  // 100 k-query calls overlap freely: 46 M patterns/s against 86 M chained at C2)
-constexpr int kScanSlots = 4;  // scans per pass: queue capacities, queued hits, candidate classes, contrast lists
+constexpr int kScanSlots = 5;  // scans per pass: queue capacities, queued hits, candidate classes, contrast lists, pairs left to the float edit distance
 
 // Everything one call mutates.
 struct Ctx {
@@ -1279,10 +1279,28 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
         const int check_itok = E.d.n_itok > 1 ? 1 : 0;
         const bool two = p_max > 32 && dp_mode == 2;
         if (two) fork();
+        static const bool hybrid_on = [] { const char* e = getenv("FMX_REAL_HYBRID"); return e ? atoi(e) != 0 : true; }();  // design-time switch
         if (dp_mode == 3) hipLaunchKernelGGL((k_dp_reg<32, true, false, true>), dim3(grid), dim3(kWave), 0, stream, E.d, b, w, prm, c.keys.p, check_itok);
         else {
           if (two) hipLaunchKernelGGL((k_dp_reg<64, false, false, true>), dim3(grid), dim3(kWave), 0, side, E.d, b, w, prm, c.keys.p, check_itok);
-          hipLaunchKernelGGL((k_dp_reg<32, false, false, true>), dim3(grid), dim3(kWave), 0, stream, E.d, b, w, prm, c.keys.p, check_itok);
+          const bool unit = prm.ins == prm.del && prm.del == prm.rep && prm.rep >= 0.f;
+          if (hybrid_on && unit && !check_itok && c.seg_cap >= 4096) {
+            // unit costs, no penalty tokens anywhere: the bit-parallel kernel answers the pairs in which no equal word meets a
+            // different real token (their cost is the ids' cost) and marks the others; a scan + a scatter make the marked ones a
+            // dense list in list order; the float kernel computes those.  c.keys: [0, seg_cap) the list, then flags / counts / offsets.
+            const uint32_t n_chunks = (uint32_t)(c.seg_cap / kWave) + 1;
+            unsigned long long* flags = c.keys.p + c.seg_cap;
+            unsigned long long* cnt = flags + (n_chunks + 1);
+            unsigned long long* offs = cnt + (n_chunks + 1);
+            hipLaunchKernelGGL(k_dp_tab<true>, dim3(grid), dim3(kWave), 0, stream, E.d, b, w, prm, flags, cnt, n_chunks);
+            const uint32_t n_sc = n_chunks + 1;
+            hipLaunchKernelGGL(k_scan_lb<1>, dim3((n_sc + kScanTile - 1) / kScanTile), dim3(kScanThreads), 0, stream, (const unsigned long long*)cnt, offs, (size_t)n_sc, n_sc,
+                               c.scan_state(4), c.scan_ticket(4));
+            hipLaunchKernelGGL(k_dp_compact, dim3(2048), dim3(256), 0, stream, b, w, (const unsigned long long*)flags, (const unsigned long long*)offs, c.keys.p);
+            hipLaunchKernelGGL((k_dp_reg<32, false, false, true>), dim3(grid), dim3(kWave), 0, stream, E.d, b, w, prm, (unsigned long long*)nullptr, 0,
+                               (const unsigned long long*)c.keys.p, (const unsigned long long*)(offs + n_chunks));
+          } else
+            hipLaunchKernelGGL((k_dp_reg<32, false, false, true>), dim3(grid), dim3(kWave), 0, stream, E.d, b, w, prm, c.keys.p, check_itok);
         }
         if (two) join();
         if (p_max > (dp_mode == 3 ? 32u : 64u)) launch_rows(true);
@@ -1305,7 +1323,7 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
           // the 32-token class: match masks from a per-wave LDS table of the queries' patterns (k_dp_tab, round 5) instead of
           // two compare instructions per pattern token and row (design-time switch FMX_DP_TAB=0: the register kernel)
           static const bool dp_tab = [] { const char* e = getenv("FMX_DP_TAB"); return e ? atoi(e) != 0 : true; }();
-          if (dp_tab) hipLaunchKernelGGL(k_dp_tab, dim3(grid), dim3(kWave), 0, stream, E.d, b, w, prm);
+          if (dp_tab) hipLaunchKernelGGL(k_dp_tab<false>, dim3(grid), dim3(kWave), 0, stream, E.d, b, w, prm);
           else hipLaunchKernelGGL((k_dp_reg<32, false, true>), dim3(grid), dim3(kWave), 0, stream, E.d, b, w, prm);
         } else {
           if (two) hipLaunchKernelGGL((k_dp_reg<64, false>), dim3(grid), dim3(kWave), 0, side, E.d, b, w, prm);
@@ -2152,10 +2170,18 @@ struct DeviceIndex::HostCall {
     };
     hooks.computed = [this]() { turn.release(); };
     // stage timing (st with events) is the device entry point's job: here the passes run back to back, unsynchronised
-    run.reset(new PassRun(m, c, prm, bv, c.d_out.p, c.d_cnt.p, c.d_tot.p, cap, c.stream, qb, bounds, st, &hooks));
-    run->prepare_async();
-    if (n_sub <= kAsyncGroup) run->begin_group(0, n_sub);
-    else { run->run_all_async(); ran_all = true; }  // more passes than one group holds: the call runs to its end here
+    // (the chain lock is given back on THIS thread whatever happens below: a deferred call is begun by whichever thread frees a slot,
+    // and a std::mutex must be unlocked by the thread that locked it)
+    try {
+      run.reset(new PassRun(m, c, prm, bv, c.d_out.p, c.d_cnt.p, c.d_tot.p, cap, c.stream, qb, bounds, st, &hooks));
+      run->prepare_async();
+      if (n_sub <= kAsyncGroup) run->begin_group(0, n_sub);
+      else { run->run_all_async(); ran_all = true; }  // more passes than one group holds: the call runs to its end here
+    } catch (...) {
+      if (chain_lk.owns_lock()) chain_lk.unlock();
+      throw;
+    }
+    if (chain_lk.owns_lock()) chain_lk.unlock();  // (hooks.enqueued released it unless no pass was enqueued)
   }
 
   void end() {

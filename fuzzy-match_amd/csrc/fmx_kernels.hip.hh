@@ -2708,14 +2708,17 @@ __device__ __forceinline__ float edit_distance_exact_dispatch(uint32_t p_u, cons
 #endif
 template <int P, bool IDF, bool UNIT = false, bool REAL = false>
 __global__ void __launch_bounds__(kWave, (UNIT && P == 32) ? FMX_DPREG_WAVES : 1) k_dp_reg(DevIndex ix, DevBatch b, DevWork w, Params prm,
-                                                                                          unsigned long long* defer = nullptr, int check_itok = 0) {
+                                                                                          unsigned long long* defer = nullptr, int check_itok = 0,
+                                                                                          const unsigned long long* ext_list = nullptr,
+                                                                                          const unsigned long long* ext_n = nullptr) {
   const uint32_t lane = lane_id();
   unsigned long long j_lo, j_hi;
   dp_class_range(b, w, P == 32 ? 0u : 1u, j_lo, j_hi);
   // (32-bit loop state: the list holds fewer than 2^32 entries — the host keeps seg_cap below that —, and the candidate is
   // remembered by its slot, not by a pointer: the unit-cost variant for 32 tokens sits at the 64 registers of eight waves per SIMD)
-  const uint32_t n_list = (uint32_t)(j_hi - j_lo);
-  const unsigned long long* __restrict__ list = w.c_qi + j_lo;
+  // ext_list: the pairs k_dp_tab<true> left to this kernel (k_dp_compact's list, *ext_n entries) instead of the length class
+  const uint32_t n_list = ext_list ? (uint32_t)*ext_n : (uint32_t)(j_hi - j_lo);
+  const unsigned long long* __restrict__ list = ext_list ? ext_list : w.c_qi + j_lo;
   for (uint32_t j = blockIdx.x * kWave + lane; j < n_list; j += gridDim.x * kWave) {
     // two dependency levels in front of the tokens: the list entry, then the query's offsets and the candidate record
     // together (the record names the sentence's token base and length: no detour through sent_pos and the length word)
@@ -2784,8 +2787,19 @@ __global__ void __launch_bounds__(kWave, (UNIT && P == 32) ? FMX_DPREG_WAVES : 1
 constexpr uint32_t kDpTabRuns = FMX_DPTAB_RUNS, kDpTabSlots = 64;
 __device__ __forceinline__ uint32_t dp_tab_slot(uint32_t w) { return (w * 0x85EBCA6Bu) >> 26; }
 
-__global__ void __launch_bounds__(kWave, FMX_DPTAB_WAVES) k_dp_tab(DevIndex ix, DevBatch b, DevWork w, Params prm) {
+// REAL (round 6): the index carries real tokens (the reference CLI's default -p nbr,tag,cas) and nothing carries penalty tokens.  A pair in
+// which no equal word meets a different real token — two thirds of the pairs of such an index at C3 — costs exactly what the ids
+// alone cost (every real-token term of src/edit_distance.cc:53-62 is zero), so it is answered here; the table also remembers, per
+// pattern word, the real-token id its positions share (or that they differ), and a row whose sentence token finds its word with
+// another real token marks the pair for the float kernel: flags[chunk] = the chunk's marked lanes, cnt[chunk] their number
+// (k_dp_compact turns them into a dense list in the same order; chunks up to n_chunks inclusive are written: the scan's input).
+constexpr uint32_t kRealNone = 0xfffffffeu, kRealMixed = 0xffffffffu;
+template <bool REAL>
+__global__ void __launch_bounds__(kWave, FMX_DPTAB_WAVES) k_dp_tab(DevIndex ix, DevBatch b, DevWork w, Params prm,
+                                                                 unsigned long long* flags = nullptr, unsigned long long* cnt = nullptr,
+                                                                 uint32_t n_chunks = 0) {
   __shared__ uint2 s_tab[kDpTabRuns][kDpTabSlots];   // {token, mask of its positions in the run's pattern}: one 8-byte read per row
+  __shared__ uint32_t s_treal[REAL ? kDpTabRuns : 1][kDpTabSlots];   // the real-token id the token's positions share / kRealMixed
   __shared__ uint32_t s_rp[kDpTabRuns + 1];   // pattern tokens in front of each run of the round (exclusive prefix)
   __shared__ uint32_t s_ro0[kDpTabRuns];      // where each run's pattern starts in q_tok
   const uint32_t lane = lane_id();
@@ -2793,7 +2807,12 @@ __global__ void __launch_bounds__(kWave, FMX_DPTAB_WAVES) k_dp_tab(DevIndex ix, 
   dp_class_range(b, w, 0u, j_lo, j_hi);
   const uint32_t n_list = (uint32_t)(j_hi - j_lo);
   const unsigned long long* __restrict__ list = w.c_qi + j_lo;
-  for (uint32_t j0 = blockIdx.x * kWave; j0 < n_list; j0 += gridDim.x * kWave) {
+  const uint32_t j_end = REAL ? (n_chunks + 1u) * kWave : n_list;
+  for (uint32_t j0 = blockIdx.x * kWave; j0 < j_end; j0 += gridDim.x * kWave) {
+    if (REAL && j0 >= n_list) {  // (wave-uniform) chunks behind the list: the scan reads zeros
+      if (lane == 0) { flags[j0 >> 6] = 0ull; cnt[j0 >> 6] = 0ull; }
+      continue;
+    }
     const uint32_t j = j0 + lane;
     const bool act = j < n_list;
     const unsigned long long qi = act ? list[j] : 0ull;
@@ -2811,7 +2830,10 @@ __global__ void __launch_bounds__(kWave, FMX_DPTAB_WAVES) k_dp_tab(DevIndex ix, 
     if (act && tb == 0) { const uint32_t sp0 = ix.sent_pos[c0.sid]; slen = ix.tok[sp0]; tb = sp0 + 1; }
     if (!act) slen = 0;
     const Tok4* sent4 = reinterpret_cast<const Tok4*>(ix.tok + tb);
+    const Tok4* real4 = reinterpret_cast<const Tok4*>(REAL ? ix.real + tb : ix.tok);
     Tok4 nxt = slen ? sent4[0] : Tok4{{0u, 0u, 0u, 0u}};   // (requested before the tables are built: it travels meanwhile)
+    Tok4 nxt_r = (REAL && slen) ? real4[0] : Tok4{{0u, 0u, 0u, 0u}};
+    bool need = false;   // REAL: some equal word carries another real token: the float kernel computes this pair
     // runs of equal q: a run's number = heads in front of the lane
     const uint32_t pq = __shfl_up(q, 1, 64);
     const bool head = act && (lane == 0 || pq != q);
@@ -2826,7 +2848,10 @@ __global__ void __launch_bounds__(kWave, FMX_DPTAB_WAVES) k_dp_tab(DevIndex ix, 
       const bool mine = act && rl < n_r;
       wave_lds_sync();
       // the round's tables: empty; the runs' pattern lengths and starts (written by each run's head lane)
-      for (uint32_t k = lane; k < n_r * kDpTabSlots; k += kWave) (&s_tab[0][0])[k] = make_uint2(kHashEmpty, 0u);
+      for (uint32_t k = lane; k < n_r * kDpTabSlots; k += kWave) {
+        (&s_tab[0][0])[k] = make_uint2(kHashEmpty, 0u);
+        if (REAL) (&s_treal[0][0])[k] = kRealNone;
+      }
       if (head && rl < n_r) { s_rp[rl + 1] = p; s_ro0[rl] = o0; }
       if (lane == 0) s_rp[0] = 0;
       wave_lds_sync();
@@ -2850,19 +2875,28 @@ __global__ void __launch_bounds__(kWave, FMX_DPTAB_WAVES) k_dp_tab(DevIndex ix, 
           if (old == kHashEmpty || old == t) { atomicOr(&s_tab[r][h].y, 1u << jp); break; }
           h = (h + 1) & (kDpTabSlots - 1);
         }
+        if (REAL) {  // the first position's real token stays unless another position of the word brings a different one
+          const uint32_t rr = b.q_real[s_ro0[r] + jp];
+          const uint32_t was = atomicCAS(&s_treal[r][h], kRealNone, rr);
+          if (was != kRealNone && was != rr) s_treal[r][h] = kRealMixed;
+        }
       }
       wave_lds_sync();
       // the rows: this lane's sentence against its run's table (one 8-byte read per row and probe step).
       // (Measured at C3 and left as they are: a branch-free row — home slot read unconditionally, state kept by selects, the probe
       // sequence only when some lane collides — 0.53 ms, the four probes of a group requested together 0.55 ms, this loop 0.50 ms.)
       const uint2* tab = &s_tab[mine ? rl : 0u][0];
+      const uint32_t* treal = &s_treal[(REAL && mine) ? rl : 0u][0];
       const uint32_t rows = mine ? slen : 0u;
       uint32_t rows_max = rows;
 #pragma unroll
       for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(rows_max, d, 64); rows_max = o > rows_max ? o : rows_max; }
       for (uint32_t i0 = 0; i0 < rows_max; i0 += 4) {
-        const Tok4 cur = nxt;
-        if (i0 + 4 < rows) nxt = sent4[(i0 >> 2) + 1];
+        const Tok4 cur = nxt, cur_r = nxt_r;
+        if (i0 + 4 < rows) {
+          nxt = sent4[(i0 >> 2) + 1];
+          if (REAL) nxt_r = real4[(i0 >> 2) + 1];
+        }
 #pragma unroll
         for (uint32_t u = 0; u < 4; u++) {
           if (i0 + u < rows) {
@@ -2870,12 +2904,17 @@ __global__ void __launch_bounds__(kWave, FMX_DPTAB_WAVES) k_dp_tab(DevIndex ix, 
             uint32_t h = dp_tab_slot(wd);
             uint2 e = tab[h];
             while (e.x != wd && e.x != kHashEmpty) { h = (h + 1) & (kDpTabSlots - 1); e = tab[h]; }
+            if (REAL) need = need || (e.x == wd && treal[h] != (cur_r.t[u] & 0x7fffffffu));
             lev_step32(pv, mv, score, e.x == wd ? e.y : 0u, m_bits);
           }
         }
       }
     }
-    if (act) {
+    if (REAL) {
+      const unsigned long long fl = __ballot(act && need);
+      if (lane == 0) { flags[j0 >> 6] = fl; cnt[j0 >> 6] = (unsigned long long)__popcll(fl); }
+    }
+    if (act && !need) {
       const float dw = 100.f / normalizer(p, slen, prm.ins, prm.del, prm.rep);
       const float f = unit_cost_sum(score, prm.rep * dw);  // = ins * dw = del * dw
       Cand* cd = w.seg + slot;
@@ -2883,6 +2922,21 @@ __global__ void __launch_bounds__(kWave, FMX_DPTAB_WAVES) k_dp_tab(DevIndex ix, 
       cd->penalty = f;   // M = final: row minima never decrease for non-negative unit costs (fmx_core.hh)
       cd->longest = (c0.longest & 0xffffu) | (slen << 16);
     }
+  }
+}
+
+// k_dp_compact — the pairs k_dp_tab<true> marked, as a dense list in list order (so that the waves of the float kernel keep
+// sharing one pattern length): offs = the exclusive scan of cnt, offs[n_chunks + 1] = their number.
+__global__ void __launch_bounds__(256) k_dp_compact(DevBatch b, DevWork w, const unsigned long long* flags, const unsigned long long* offs,
+                                                    unsigned long long* out) {
+  unsigned long long j_lo, j_hi;
+  dp_class_range(b, w, 0u, j_lo, j_hi);
+  const uint32_t n_list = (uint32_t)(j_hi - j_lo);
+  const unsigned long long* __restrict__ list = w.c_qi + j_lo;
+  for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n_list; j += gridDim.x * blockDim.x) {
+    const unsigned long long fl = flags[j >> 6];
+    const uint32_t bit = j & 63u;
+    if ((fl >> bit) & 1ull) out[offs[j >> 6] + (unsigned long long)__popcll(fl & ((1ull << bit) - 1ull))] = list[j];
   }
 }
 

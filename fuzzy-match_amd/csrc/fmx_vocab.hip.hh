@@ -279,7 +279,9 @@ __device__ __forceinline__ void raw_masks(const unsigned char* __restrict__ text
     const unsigned char c = (unsigned char)(xs[k >> 2] >> (8 * (k & 3)));
     const bool in = b0 + k < n_bytes;
     uint32_t cl = in ? raw_class(c) : (uint32_t)kRawSep;
-    if (cl == kRawBad) { bad |= 1u << k; cl = kRawSep; }
+    // (a NUL byte INSIDE the text is not a separator for the host front-end, which drops code points below 32 without ending the
+    // token: such a line is the host's; only the padding behind the text reads as separators)
+    if (cl == kRawBad || (in && c == 0)) { bad |= 1u << k; cl = kRawSep; }
     if (cl != kRawSep && (cl == kRawOther || cl != prev)) starts |= 1u << k;
     if (in && c == '\n') nls |= 1u << k;
     prev = cl;
