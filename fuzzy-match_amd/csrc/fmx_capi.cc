@@ -1315,6 +1315,7 @@ int fmx_set_option(fmx_index* ix, const char* name, int64_t value) {
     else if (n == "serial") d->set_serial(value != 0);
     else if (n == "pair_finish") d->set_pair_finish(value != 0);
     else if (n == "small_path") d->set_small_path(value != 0);
+    else if (n == "real_hybrid") d->set_real_hybrid(value != 0);
     else if (n == "turns") d->set_turns((uint32_t)std::max<int64_t>(value, 0));
     else if (n == "device_turns") d->set_device_turns((uint32_t)std::max<int64_t>(value, 0));
     else if (n == "expand_order") d->set_expand_order((uint32_t)std::max<int64_t>(value, 0));

@@ -159,6 +159,7 @@ class DeviceIndex {
   void match_host_end(HostCall*);
   void match_host_abandon(HostCall*);
   void     set_pair_finish(bool on);     // two queries per wave in the replay / top-N kernel
+  void     set_real_hybrid(bool on);     // real-token indexes under unit costs: k_dp_tab<true> + float kernel on the marked pairs (A/B switch)
   void     set_small_path(bool on);      // micro-batches (<= 512 queries) in one kernel launch (fmx_small.hip.hh)
   // FuzzyMatch::subsequence (src/fuzzy_match.cc:250-365) for a batch of tokenised patterns; one record per query
   void subsequence_host(const HostIndex& h, const HostBatchView& b, uint32_t number_of_matches, bool no_perfect, int min_subseq_length,

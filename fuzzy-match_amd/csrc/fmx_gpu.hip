@@ -428,6 +428,9 @@ struct DeviceIndex::Impl {
   // suite does, so that its many small batches keep exercising the pipeline; tests/test_gpu_small.py turns it on)
   bool     pair_finish = [] { const char* e = getenv("FMX_PAIR_FINISH"); return e ? atoi(e) != 0 : true; }();  // design-time switch
   bool     small_path = [] { const char* e = getenv("FMX_SMALL_PATH"); return e ? atoi(e) != 0 : true; }();
+  // real-token indexes, unit costs: bit-parallel kernel for the pairs without a real-token mismatch + float kernel for the rest, instead
+  // of the float kernel for all (round 6: built, bit-identical, slower at C3 — profiles/r06_real_hybrid_ab.md —: off unless asked for)
+  bool     real_hybrid = [] { const char* e = getenv("FMX_REAL_HYBRID"); return e ? atoi(e) != 0 : false; }();
   uint32_t heavy_grid = kHeavyGrid;      // workgroups of k_expand_h (it runs beside the light queries' kernel: it must not fill every wave slot)
   uint32_t light_max = kLightMaxDefault;  // queries with at most this many hits, all in short ranges, skip phase A (0 = off)
   // of those, queries with at most this many hits are walked several to a wave (k_expand_lf, round 5; 0 = all by k_expand_b<true>).
@@ -649,6 +652,7 @@ void     DeviceIndex::set_serial(bool on) { impl_->serial = on; }
 void     DeviceIndex::set_turns(uint32_t n) { impl_->turns = n; impl_->device_turns = n; }
 void     DeviceIndex::set_device_turns(uint32_t n) { impl_->device_turns = n; }
 void     DeviceIndex::set_small_path(bool on) { impl_->small_path = on; }
+void     DeviceIndex::set_real_hybrid(bool on) { impl_->real_hybrid = on; }
 void     DeviceIndex::set_pair_finish(bool on) { impl_->pair_finish = on; }
 void     DeviceIndex::set_expand_order(uint32_t n) { impl_->expand_order = n; }
 void     DeviceIndex::set_b_grid(uint32_t n) { impl_->b_grid = std::min<uint32_t>(std::max<uint32_t>(n, 64u), 65536u); }
@@ -1279,7 +1283,7 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
         const int check_itok = E.d.n_itok > 1 ? 1 : 0;
         const bool two = p_max > 32 && dp_mode == 2;
         if (two) fork();
-        static const bool hybrid_on = [] { const char* e = getenv("FMX_REAL_HYBRID"); return e ? atoi(e) != 0 : true; }();  // design-time switch
+        const bool hybrid_on = m.real_hybrid;  // option "real_hybrid" (off by default)
         if (dp_mode == 3) hipLaunchKernelGGL((k_dp_reg<32, true, false, true>), dim3(grid), dim3(kWave), 0, stream, E.d, b, w, prm, c.keys.p, check_itok);
         else {
           if (two) hipLaunchKernelGGL((k_dp_reg<64, false, false, true>), dim3(grid), dim3(kWave), 0, side, E.d, b, w, prm, c.keys.p, check_itok);

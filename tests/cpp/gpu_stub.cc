@@ -43,6 +43,7 @@ void DeviceIndex::set_contexts(uint32_t) {}
 void DeviceIndex::set_max_host_active(uint32_t) {}
 void DeviceIndex::set_pair_finish(bool) {}
 void DeviceIndex::set_small_path(bool) {}
+void DeviceIndex::set_real_hybrid(bool) {}
 void DeviceIndex::match_device(const HostIndex&, const Params&, const DeviceBatchView&, Rec*, uint32_t*, uint32_t*, uint32_t, void*,
                                const std::vector<uint32_t>&, Stats*) { no_device(); }
 DeviceIndex::Pending* DeviceIndex::match_device_begin(const HostIndex&, const Params&, const DeviceBatchView&, Rec*, uint32_t*, uint32_t*,

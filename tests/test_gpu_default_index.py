@@ -110,3 +110,21 @@ def test_default_index_text_ids_and_raw_lines_bit_exact(fmx, default_index, name
     lines = synth.pack_lines_cased(q_off, q_tok)
     go, gc, gt = ix.match_batch_raw_lines(prm, lines, len(q_off) - 1, cap=cap)
     workloads.compare(oo, oc, go, gc, name + "/raw")
+
+
+def test_hybrid_real_token_path_bit_exact(fmx, default_index):
+    """Option "real_hybrid" (off by default: slower at C3, profiles/r06_real_hybrid_ab.md): under unit costs the bit-parallel kernel answers
+    the pairs in which no equal word meets a different real token and leaves the others to the float kernel — same records."""
+    ix, o, m, vs, c_off, c_tok, q_off, q_tok = default_index
+    ix.set_option("real_hybrid", 1)
+    try:
+        for name in ("C3", "C5", "no_perfect", "wide"):
+            kw = SETS[name]
+            cap = 16
+            q_real = oracle_lib.tab_joined(synth.pack_cased_stream(q_off, q_tok, 1), q_off)
+            oo, oc = o.match_batch(oracle_lib.Params(**kw), q_off, m[q_tok], cap, nthreads=oracle_lib.effective_cpus(), real=q_real)
+            go, gc, gt = ix.match_batch_text(fmx.Params(**kw), q_off, synth.pack_cased_stream(q_off, q_tok, 0), cap=cap,
+                                             real_text=synth.pack_cased_stream(q_off, q_tok, 1))
+            workloads.compare(oo, oc, go, gc, name + "/hybrid")
+    finally:
+        ix.set_option("real_hybrid", 0)

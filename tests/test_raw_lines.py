@@ -128,6 +128,10 @@ def test_tm1_raw_lines(fmx, gpu_device, pt, fixture):
         assert np.array_equal(want[1], got[1]) and int(want[1].sum()) > 0, (fixture, kw)
         for q in range(len(texts)):
             assert want[0][q, :want[1][q]].tobytes() == got[0][q, :got[1][q]].tobytes(), (fixture, kw, texts[q])
+    # a line count that disagrees with the text's line feeds is refused on the all-host path too (pct / jnr), in both directions
+    for wrong in (len(texts) + 1, len(texts) - 1):
+        with pytest.raises(fmx.FmxError):
+            ix.match_batch_raw_lines(fmx.Params(fuzzy=0.5, nmatch=2), _raw(texts), wrong, cap=2)
 
 
 @pytest.mark.gpu
@@ -136,7 +140,8 @@ def test_tm2_raw_lines(fmx, gpu_device):
     pt = PT["tag"] | PT["nbr"] | PT["cas"]
     ix, ids = _gpu_index(fmx, gpu_device, pt, en, [f"{i + 1}={fr[i]}" for i in range(len(en))])
     texts = [c["text"] for c in read_cases("test-tm2")] + [en[i] for i in range(0, 20000, 10)] + \
-            ["Résumé 2024 ｟it＃1｠ of the Commission 12 May", "", "   ", "The Commission", "naïve café 12", "a\x01b cc"]
+            ["Résumé 2024 ｟it＃1｠ of the Commission 12 May", "", "   ", "The Commission", "naïve café 12", "a\x01b cc",
+             "the Commi\x00ssion proposes"]   # (a NUL inside a word does not end it on the host: such a line must not be cut on the device)
     n_ascii = sum(1 for t in texts if device_rules(pt, t) is not None)
     assert 100 < n_ascii < len(texts)   # both paths inside one call
     n_rec = 0
