@@ -2143,6 +2143,9 @@ struct DeviceIndex::HostCall {
     hd_count = pinned_device_ptr(out_count);
     hd_total = out_total ? pinned_device_ptr(out_total) : nullptr;
     export_kernel = hd_count && (!out_total || hd_total);
+    // (Round 6, A/B'd and removed — profiles/r06_records_home_ab.md: the emitting kernels storing the records THROUGH the mapped pointer of
+    // a pinned `out` made the replay / rerank kernels wait for PCIe — value 186 -> 165 M patterns/s at C3; and the copies home cost less
+    // than it looked: with NO copy at all a step takes 5.06 instead of 5.34 ms.)
     // Small single-pass calls put their copies on the compute stream: in order, no event between streams.  (With eight hardware
     // queues every stream has a queue of its own and a dependency between two of them is a signal round trip; a 100 k-query call
     // has four of them around ~1 ms of kernels, and its copies are too short to be worth overlapping with its own kernels —
