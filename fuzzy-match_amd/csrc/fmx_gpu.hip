@@ -183,12 +183,25 @@ struct StreamPool {
     int lo = 0, hi = 0;
     HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
     static const bool classes = [] { const char* e = getenv("FMX_STREAM_CLASSES"); return e ? atoi(e) != 0 : true; }();
+    // Round 6 — the "cliff" of rounds 2-5, reproduced without the library (tools/microbench/queues.hip, profiles/r06_queues_cliff.md):
+    // calls in flight that each bring a HIGH-PRIORITY stream collapse (4-7 ms per step -> 160-430 ms) as soon as FIVE or more such
+    // streams are in use beside the normal class's eight hardware queues — six calls in the bare repro, seven in the library's shape;
+    // with the same streams at normal priority, or ONE high-priority stream shared by all calls, twelve calls in flight take what four
+    // take.  Every priority class has a pool of hardware queues of its own, and the firmware scheduler time-slices a process that keeps
+    // more than about a dozen queues busy.  Until round 5 every call's side lane was high-priority ("so that main and side lane never
+    // share a queue"): that was the cliff.  Now side lanes are normal-priority streams (FMX_HIGH_PRIO_LANES = how many pairs still get
+    // a high one: 0): sixteen uncapped synchronous callers take 1.6 ms per call instead of 160-1000 (capped at four: 0.67), and
+    // `value` / the device-resident leg are the same or 1-2 % better.
+    static const int high_lanes = [] { const char* e = getenv("FMX_HIGH_PRIO_LANES"); return e ? atoi(e) : 0; }();
     hipStream_t a = nullptr, b = nullptr;
     HIP_TRY(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
-    if (classes) HIP_TRY(hipStreamCreateWithPriority(&b, hipStreamNonBlocking, hi));
+    bool high = false;
+    { std::lock_guard<std::mutex> g(mu); high = classes && n_high < high_lanes; if (high) n_high++; }
+    if (high) HIP_TRY(hipStreamCreateWithPriority(&b, hipStreamNonBlocking, hi));
     else HIP_TRY(hipStreamCreateWithFlags(&b, hipStreamNonBlocking));
     return {a, b};
   }
+  int n_high = 0;  // pairs made with a high-priority side lane
   void give(std::pair<hipStream_t, hipStream_t> p) {
     std::lock_guard<std::mutex> g(mu);
     idle.push_back(p);

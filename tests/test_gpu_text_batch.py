@@ -284,17 +284,17 @@ def test_sixteen_synchronous_text_callers_degrade_gracefully(fmx, gpu_device):
         assert np.array_equal(want[1], o[1][:nq])
         assert want[0].tobytes() == o[0][:nq].tobytes()
     print(f"16 callers {t16 * 1e3:.1f} ms, 4 callers {t4 * 1e3:.1f} ms, 16 callers again {t16b * 1e3:.1f} ms for {calls} calls each")
-    # Transient stalls hit either side in a process that earlier tests left their contexts in (four callers 59-153 ms, sixteen
-    # 60-1270 ms in one failing run of the whole suite; alone the test measures 31-38 ms for both): what is compared is the BEST of
-    # up to six rounds of each — what the capped library can do — not one round against one round.
-    best16, best4 = min(t16, t16b), t4
-    for _ in range(5):
-        if best16 <= 1.3 * best4 + 0.05:
-            break
-        time.sleep(2.0)
-        t16, t4, t16b = run(16), run(4), run(16)
-        best16, best4 = min(best16, t16, t16b), min(best4, t4)
-        print(f"again: 16 callers {t16 * 1e3:.1f} ms, 4 callers {t4 * 1e3:.1f} ms, 16 callers {t16b * 1e3:.1f} ms")
-    assert best16 <= 1.3 * best4 + 0.05, (best16, best4)
-    # without the cap the same sixteen callers fall off the cliff (measured on this box: 64 calls in 0.56 - 12 s against 0.05 s,
-    # tools/dbg/callers_sweep.py); not repeated here — it leaves the process slow for seconds
+    # one round, no slack (round 6: the stalls that used to hit either side — 60-1270 ms in a process earlier tests had left their
+    # stream pairs in — were the same mechanism as the cliff: high-priority side lanes, tools/microbench/queues.hip)
+    assert min(t16, t16b) <= 1.3 * t4, (t16, t16b, t4)
+    # WITHOUT the cap the same sixteen callers now degrade gracefully (2.3 x measured) instead of falling off a cliff (250-1500 x until
+    # round 5: every call brought a high-priority stream, and five or more of those make the firmware time-slice the process's queues)
+    ix.set_option("max_host_active", 16)
+    try:
+        t16u = run(16)
+    finally:
+        ix.set_option("max_host_active", 4)
+    for o in outs:
+        assert np.array_equal(want[1], o[1][:nq])
+    print(f"16 callers uncapped {t16u * 1e3:.1f} ms")
+    assert t16u <= 6.0 * t4, (t16u, t4)
