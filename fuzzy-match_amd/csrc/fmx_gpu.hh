@@ -9,6 +9,11 @@
 
 namespace fmx {
 
+// spare zero words behind the device token buffer (and its per-slot twins): the edit-distance kernels read a sentence four tokens at a
+// time past its end, the group rerank its first 32 token slots unconditionally (round 6: one dependent load level fewer)
+constexpr uint64_t kTokSpare = 40;
+
+
 struct GpuError : std::runtime_error {  // a HIP call failed / no usable device
   using std::runtime_error::runtime_error;
 };

@@ -235,7 +235,7 @@ constexpr int kScanSlots = 5;  // scans per pass: queue capacities, queued hits,
 // Everything one call mutates.
 struct Ctx {
   // ---- workspace ----
-  Grow<uint32_t> q_m, q_kept, q_cand, q_acc, q_pb, q_rank, q_scap, big_list, mid_list, fin_list, contrast_list;
+  Grow<uint32_t> q_m, q_kept, q_cand, q_acc, q_pb, q_rank, q_scap, big_list, mid_list, fin_list, contrast_list, fb_list;
   Grow<unsigned long long> q_hits, q_hits_a, q_seg, q_qseg, q_cap, c_in, c_off, q_best;
   Grow<uint32_t> t_q, t_lo, t_cnt;
   Grow<float>    t_idf;
@@ -920,8 +920,8 @@ void DeviceIndex::upload(const HostIndex& h, int device, SortResident* res) {
     m.d.tok = res->d_buf; res->d_buf = nullptr;
     m.d.sent_pos = res->d_sent_pos; res->d_sent_pos = nullptr;
   } else {  // eight spare tokens: the DP kernels read the sentence four tokens at a time, possibly past its end
-    d_tok = dev_alloc<uint32_t>(h.buf.size() + 8);
-    HIP_TRY(hipMemset(d_tok, 0, (h.buf.size() + 8) * sizeof(uint32_t)));
+    d_tok = dev_alloc<uint32_t>(h.buf.size() + kTokSpare);
+    HIP_TRY(hipMemset(d_tok, 0, (h.buf.size() + kTokSpare) * sizeof(uint32_t)));
     if (!h.buf.empty()) HIP_TRY(hipMemcpy(d_tok, h.buf.data(), h.buf.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     m.d.tok = d_tok;
     m.d.sent_pos = dev_upload(h.sent_pos);
@@ -945,8 +945,8 @@ void DeviceIndex::upload(const HostIndex& h, int device, SortResident* res) {
     }
     if (at < 0xfffffff0ull) {
       uint32_t* d_new_pos = dev_upload(pos);
-      uint32_t* d_new = dev_alloc<uint32_t>(at + 8);
-      HIP_TRY(hipMemset(d_new, 0, (at + 8) * sizeof(uint32_t)));
+      uint32_t* d_new = dev_alloc<uint32_t>(at + kTokSpare);
+      HIP_TRY(hipMemset(d_new, 0, (at + kTokSpare) * sizeof(uint32_t)));
       const uint32_t ns = (uint32_t)h.sent_pos.size();
       hipLaunchKernelGGL(k_relayout, dim3((ns + 255) / 256), dim3(256), 0, 0, m.d.tok, m.d.sent_pos, m.d.tok, m.d.sent_pos, (const uint32_t*)d_new_pos, ns, d_new);
       HIP_TRY(hipGetLastError());
@@ -988,16 +988,16 @@ void DeviceIndex::upload(const HostIndex& h, int device, SortResident* res) {
   if (h.real_differs) {
     // (eight spare words like the token buffer: the register kernels read a sentence's real-token ids four at a time)
     for (auto pr : {std::make_pair(&m.d.real, &h.real_ids), std::make_pair(&m.d.itok, &h.itok_ids)}) {
-      uint32_t* d = dev_alloc<uint32_t>(pr.second->size() + 8);
-      HIP_TRY(hipMemset(d, 0, (pr.second->size() + 8) * sizeof(uint32_t)));
+      uint32_t* d = dev_alloc<uint32_t>(pr.second->size() + kTokSpare);
+      HIP_TRY(hipMemset(d, 0, (pr.second->size() + kTokSpare) * sizeof(uint32_t)));
       if (!pr.second->empty()) HIP_TRY(hipMemcpy(d, pr.second->data(), pr.second->size() * sizeof(uint32_t), hipMemcpyHostToDevice));
       *pr.first = d;
     }
     if (d_old_pos) {  // the per-slot twins of the token buffer follow it into the device layout
       const uint32_t ns = (uint32_t)h.sent_pos.size();
       for (const uint32_t** twin : {&m.d.real, &m.d.itok}) {
-        uint32_t* d_new = dev_alloc<uint32_t>(m.n_tok_words + 8);
-        HIP_TRY(hipMemset(d_new, 0, (m.n_tok_words + 8) * sizeof(uint32_t)));
+        uint32_t* d_new = dev_alloc<uint32_t>(m.n_tok_words + kTokSpare);
+        HIP_TRY(hipMemset(d_new, 0, (m.n_tok_words + kTokSpare) * sizeof(uint32_t)));
         hipLaunchKernelGGL(k_relayout, dim3((ns + 255) / 256), dim3(256), 0, 0, m.d.tok, m.d.sent_pos, *twin, (const uint32_t*)d_old_pos, m.d.sent_pos, ns, d_new);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipDeviceSynchronize());
@@ -1020,7 +1020,7 @@ void DeviceIndex::upload(const HostIndex& h, int device, SortResident* res) {
 
 static void ensure_ws(Ctx& c, uint64_t nq, uint64_t nt, uint64_t seg) {
   c.q_m.ensure(nq); c.q_kept.ensure(nq); c.q_cand.ensure(nq); c.q_acc.ensure(nq); c.q_pb.ensure(nq); c.q_best.ensure(3 * nq);
-  c.q_rank.ensure(nq); c.q_scap.ensure(nq); c.big_list.ensure(nq); c.mid_list.ensure(nq); c.fin_list.ensure(nq); c.contrast_list.ensure(2 * nq);
+  c.q_rank.ensure(nq); c.q_scap.ensure(nq); c.big_list.ensure(nq); c.mid_list.ensure(nq); c.fin_list.ensure(nq); c.contrast_list.ensure(2 * nq); c.fb_list.ensure(4 * nq);
   c.q_hits.ensure(nq + 1); c.q_hits_a.ensure(nq + 1); c.q_seg.ensure(3 * (nq + 1)); c.q_qseg.ensure(2 * (nq + 1)); c.q_cap.ensure(3 * (nq + 1));
   c.c_in.ensure(3 * (nq + 1)); c.c_off.ensure(3 * (nq + 1));
   c.t_q.ensure(nt); c.t_lo.ensure(nt); c.t_cnt.ensure(nt); c.t_idf.ensure(nt); c.items_t.ensure((uint64_t)kTailLists * probe_tail_list_cap((uint32_t)std::min<uint64_t>(nt, 0xffffffffull)));
@@ -1389,16 +1389,30 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
             fork();
             hipLaunchKernelGGL(k_camap, dim3((b.nq + kWave / kCamapGroup - 1) / (kWave / kCamapGroup)), dim3(kWave), 0, side, E.d, b, w, sc, prm, d_out_count, d_out_total);
             const unsigned gg = std::min<unsigned>(256u * 32u, std::max<unsigned>(64u, b.nq / 4u));
-            hipLaunchKernelGGL(k_crerank_g<8>, dim3(gg), dim3(kWave), 0, stream, E.d, b, w, prm, (const uint32_t*)c.big_list.p, 0u, cap, d_out, d_out_count, d_out_total);
-            hipLaunchKernelGGL(k_crerank_g<16>, dim3(gg), dim3(kWave), 0, stream, E.d, b, w, prm, (const uint32_t*)c.mid_list.p, 1u, cap, d_out, d_out_count, d_out_total);
+            // (round 6) per-query dictionary ids: the group kernels' DICT variant first; the few groups whose sentences do not fit their
+            // dictionary come back in fb lists, which the hash-table variant takes in small launches behind
+            static const bool dict_on = [] { const char* e = getenv("FMX_RERANK_DICT"); return e ? atoi(e) != 0 : true; }();  // design-time switch
+            uint32_t* fb = c.fb_list.p;
+            const uint32_t nqs = b.nq;
+            auto grp = [&](auto kern_d, auto kern_h, unsigned grid_, hipStream_t st, const uint32_t* lst, uint32_t which) {
+              if (dict_on) {
+                hipLaunchKernelGGL(kern_d, dim3(grid_), dim3(kWave), 0, st, E.d, b, w, prm, lst, 28u + which, cap, d_out, d_out_count, d_out_total, fb + (size_t)which * nqs,
+                                   (uint32_t)kCtrRerankFb + which);
+                hipLaunchKernelGGL(kern_h, dim3(std::max(64u, grid_ / 16u)), dim3(kWave), 0, st, E.d, b, w, prm, (const uint32_t*)(fb + (size_t)which * nqs),
+                                   (uint32_t)kCtrRerankFb + which, cap, d_out, d_out_count, d_out_total, (uint32_t*)nullptr, 0u);
+              } else
+                hipLaunchKernelGGL(kern_h, dim3(grid_), dim3(kWave), 0, st, E.d, b, w, prm, lst, 28u + which, cap, d_out, d_out_count, d_out_total, (uint32_t*)nullptr, 0u);
+            };
+            grp(k_crerank_g<8, true>, k_crerank_g<8, false>, gg, stream, (const uint32_t*)c.big_list.p, 0u);
+            grp(k_crerank_g<16, true>, k_crerank_g<16, false>, gg, stream, (const uint32_t*)c.mid_list.p, 1u);
             if (E.d.max_slen > 32)
               for (uint32_t r = 1; r <= prm.nmatch; r++)
                 hipLaunchKernelGGL(k_cround<64>, dim3(cround_grid(64)), dim3(kWave), 0, side, E.d, b, w, prm, sc, r, cap, d_out, d_out_count, d_out_total);
             // what is left of the 32-token class are sets of more than 64 accepted matches: a small grid
             for (uint32_t r = 1; r <= prm.nmatch; r++)
               hipLaunchKernelGGL(k_cround<32>, dim3(1024), dim3(kWave), 0, side, E.d, b, w, prm, sc, r, cap, d_out, d_out_count, d_out_total);
-            hipLaunchKernelGGL(k_crerank_g<32>, dim3(gg / 2), dim3(kWave), 0, g32_side ? side : stream, E.d, b, w, prm, (const uint32_t*)c.fin_list.p, 2u, cap, d_out, d_out_count, d_out_total);
-            hipLaunchKernelGGL(k_crerank_g<64>, dim3(gg), dim3(kWave), 0, stream, E.d, b, w, prm, (const uint32_t*)c.contrast_list.p, 3u, cap, d_out, d_out_count, d_out_total);
+            grp(k_crerank_g<32, true>, k_crerank_g<32, false>, gg / 2, g32_side ? side : stream, (const uint32_t*)c.fin_list.p, 2u);
+            grp(k_crerank_g<64, true>, k_crerank_g<64, false>, gg, stream, (const uint32_t*)c.contrast_list.p, 3u);
             join();
           } else {
             hipLaunchKernelGGL(k_camap, dim3((b.nq + kWave / kCamapGroup - 1) / (kWave / kCamapGroup)), dim3(kWave), 0, stream, E.d, b, w, sc, prm, d_out_count, d_out_total);

@@ -3760,18 +3760,31 @@ __global__ void __launch_bounds__(1024) k_cgrp_route(DevBatch b, DevWork w, uint
   }
 }
 
-template <int G>
+// DICT (round 6): per-query dictionary ids.  The tokens of the group's sentences are mapped ONCE per query to slots of a group
+// dictionary (16 x G slots: the accepted matches of a query are near-duplicates of it and share most of their words), the rows keep
+// slot numbers instead of tokens, and the picked sentence's position masks are indexed by slot: a DP row is one LDS read in front of the
+// recurrence instead of a hash, three 8-byte reads, three compares and the selects (12 of a row's 28 instructions).  A group whose
+// sentences do not fit the dictionary (a token further than kDictProbe slots from home) hands its query to `fb_list` (count in
+// counters[ctr_fb]); the hash-table variant (DICT = false) takes those in a second, mostly empty launch.
+constexpr uint32_t kDictProbe = 8;
+constexpr int kCtrRerankFb = kCtrDpDefer + 1;   // [+0 .. +3]: queries the dictionary variant handed back, per list
+template <int G, bool DICT = false>
 __global__ void __launch_bounds__(kWave) k_crerank_g(DevIndex ix, DevBatch b, DevWork w, Params prm, const uint32_t* list,
-                                                     uint32_t which, uint32_t cap, Rec* out_rec, uint32_t* out_count, uint32_t* out_total) {
+                                                     uint32_t ctr_in, uint32_t cap, Rec* out_rec, uint32_t* out_count, uint32_t* out_total,
+                                                     uint32_t* fb_list = nullptr, uint32_t ctr_fb = 0) {
   constexpr uint32_t kGroups = kWave / G;
-  __shared__ uint2 s_tab[kGroups][kGrpSlots + kGrpWindow - 1];   // {token, mask of its positions in the picked sentence}; the last slots mirror the first
-  __shared__ __attribute__((aligned(16))) uint32_t s_pick[kGroups][32];   // the picked sentence's tokens
+  constexpr uint32_t kDictSlots = 16u * G;
+  __shared__ uint2 s_tab[DICT ? 1 : kGroups][kGrpSlots + kGrpWindow - 1];   // {token, mask of its positions in the picked sentence}; the last slots mirror the first
+  __shared__ uint32_t s_key[DICT ? kGroups : 1][DICT ? kDictSlots : 1];     // DICT: the group's dictionary (token per slot)
+  __shared__ uint32_t s_msk[DICT ? kGroups : 1][DICT ? kDictSlots : 1];     // DICT: mask of the slot's positions in the picked sentence
+  __shared__ __attribute__((aligned(16))) uint32_t s_pick[kGroups][32];   // the picked sentence's tokens (DICT: their slots)
   const uint32_t lane = lane_id(), gl = lane % G, gi = lane / G, gb = lane - gl;
-  const unsigned long long n_list = w.counters[28 + which];
+  const unsigned long long n_list = w.counters[ctr_in];
+  const unsigned long long gmask_all = G == 64 ? ~0ull : (((1ull << (G & 63)) - 1ull) << gb);
   uint32_t n_dist = 0;
   for (unsigned long long item0 = (unsigned long long)blockIdx.x * kGroups; item0 < n_list; item0 += (unsigned long long)gridDim.x * kGroups) {
     const unsigned long long item = item0 + gi;
-    const bool have = item < n_list;
+    bool have = item < n_list;
     const uint32_t q = have ? list[item] : 0u;
     const uint32_t n = have ? (w.q_acc[q] & 0x3fffffffu) : 0u;
     const uint32_t gq = b.q_begin + q;
@@ -3781,13 +3794,15 @@ __global__ void __launch_bounds__(kWave) k_crerank_g(DevIndex ix, DevBatch b, De
     if (mine) c = w.seg[w.q_seg[q] + gl];
     const uint32_t csp = mine ? ix.sent_pos[c.sid] : 0u;
     const uint32_t n1 = mine ? ix.tok[csp] : 0u;
-    uint32_t tk[32];  // this lane's sentence (<= 32 tokens; the token buffer has spare words behind it)
+    uint32_t tk[32];  // this lane's sentence (<= 32 tokens; the token buffer has kTokSpare spare words behind it)
     {
+      // all eight groups of four are requested together with the length word, not behind it (round 6: one dependent level of
+      // memory latency fewer in a kernel that waits for five of them per item); what lies past the sentence's end is never used
       const Tok4* s4 = reinterpret_cast<const Tok4*>(ix.tok + csp + 1);
 #pragma unroll
       for (int u = 0; u < 8; u++) {
         Tok4 v = Tok4{{0u, 0u, 0u, 0u}};
-        if (mine && (uint32_t)(4 * u) < n1) v = s4[u];
+        if (mine) v = s4[u];
         tk[4 * u] = v.t[0]; tk[4 * u + 1] = v.t[1]; tk[4 * u + 2] = v.t[2]; tk[4 * u + 3] = v.t[3];
       }
     }
@@ -3798,7 +3813,37 @@ __global__ void __launch_bounds__(kWave) k_crerank_g(DevIndex ix, DevBatch b, De
       const uint32_t oid = __shfl(c.sid, (int)(gb + j), 64);
       rank += (j < n && (os > c.score || (os == c.score && oid < c.sid))) ? 1u : 0u;
     }
-    const uint32_t want = prm.nmatch == 0 ? n : (prm.nmatch < n ? prm.nmatch : n);
+    uint32_t n2_prev = 0;   // DICT: tokens of the sentence whose masks sit in s_msk (its slots in s_pick)
+    if constexpr (DICT) {
+      // the group's dictionary: every token of its sentences -> a slot; the rows keep the slots
+      wave_lds_sync();
+      for (uint32_t k = gl; k < kDictSlots; k += G) { s_key[gi][k] = kHashEmpty; s_msk[gi][k] = 0u; }
+      wave_lds_sync();
+      bool ovf = false;
+#pragma unroll
+      for (int i = 0; i < 32; i++) {
+        if (mine && (uint32_t)i < n1) {
+          const uint32_t t = tk[i];
+          uint32_t h = (t * 0x9E3779B1u) >> (32 - (G == 8 ? 7 : (G == 16 ? 8 : (G == 32 ? 9 : 10))));
+          uint32_t d = 0;
+          for (;;) {
+            const uint32_t old = atomicCAS(&s_key[gi][h], kHashEmpty, t);
+            if (old == kHashEmpty || old == t) break;
+            h = (h + 1) & (kDictSlots - 1);
+            if (++d >= kDictProbe) { ovf = true; break; }
+          }
+          tk[i] = h;
+        }
+      }
+      const bool g_ovf = (__ballot(ovf) & gmask_all) != 0ull;
+      if (g_ovf) {  // the hash-table variant takes this query
+        if (have && gl == 0) fb_list[atomicAdd(&w.counters[ctr_fb], 1ull)] = q;
+        have = false;
+      }
+      wave_lds_sync();
+    }
+    const bool live = have;   // (DICT: false for a group that handed its query back)
+    const uint32_t want = !live ? 0u : (prm.nmatch == 0 ? n : (prm.nmatch < n ? prm.nmatch : n));
     uint32_t want_max = want;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(want_max, d, 64); want_max = o > want_max ? o : want_max; }
@@ -3826,12 +3871,29 @@ __global__ void __launch_bounds__(kWave) k_crerank_g(DevIndex ix, DevBatch b, De
       // the picked sentence's tokens -> the group's table (token -> mask of its positions)
       const uint32_t n2 = __shfl(n1, (int)(gb + kb), 64);
       wave_lds_sync();
+      uint32_t mk = 0;        // the group's hash multiplier of this round
+      bool use_loop = false;
+      if constexpr (DICT) {
+        // masks by dictionary slot: the previous pick's go, this pick's come (the tokens ARE slots here)
+        if (more) for (uint32_t j = gl; j < n2_prev; j += G) s_msk[gi][s_pick[gi][j]] = 0u;
+        wave_lds_sync();
+        if (more && mine && gl == kb) {
+#pragma unroll
+          for (int u = 0; u < 8; u++)
+            if ((uint32_t)(4 * u) < n1) *reinterpret_cast<uint4*>(&s_pick[gi][4 * u]) = make_uint4(tk[4 * u], tk[4 * u + 1], tk[4 * u + 2], tk[4 * u + 3]);
+        }
+        wave_lds_sync();
+        if (more) {
+          for (uint32_t j = gl; j < n2; j += G) atomicOr(&s_msk[gi][s_pick[gi][j]], 1u << j);
+          n2_prev = n2;
+        }
+        wave_lds_sync();
+      } else {
       if (more && mine && gl == kb) {  // four tokens per LDS write (words past the sentence's end are zero and never read)
 #pragma unroll
         for (int u = 0; u < 8; u++)
           if ((uint32_t)(4 * u) < n1) *reinterpret_cast<uint4*>(&s_pick[gi][4 * u]) = make_uint4(tk[4 * u], tk[4 * u + 1], tk[4 * u + 2], tk[4 * u + 3]);
       }
-      uint32_t mk = 0;        // the group's hash multiplier of this round
       bool build = more, stuck = false;
       for (uint32_t tr = 0;; tr++) {
         if (build)
@@ -3853,16 +3915,16 @@ __global__ void __launch_bounds__(kWave) k_crerank_g(DevIndex ix, DevBatch b, De
         }
         wave_lds_sync();
         const unsigned long long fm = __ballot(far);
-        const unsigned long long gmask = G == 64 ? ~0ull : (((1ull << (G & 63)) - 1ull) << gb);
-        const bool gfar = (fm & gmask) != 0ull;            // some token of my group's table sits too far from home
+        const bool gfar = (fm & gmask_all) != 0ull;            // some token of my group's table sits too far from home
         build = gfar && tr + 1 < kGrpTries;
         stuck = gfar && tr + 1 >= kGrpTries;
         if (build) mk++;
         if (__ballot(build) == 0ull) break;
       }
-      const bool use_loop = __ballot(stuck) != 0ull;       // (wave-uniform: rare)
+      use_loop = __ballot(stuck) != 0ull;       // (wave-uniform: rare)
       if (more && gl < kGrpWindow - 1) s_tab[gi][kGrpSlots + gl] = s_tab[gi][gl];
       wave_lds_sync();
+      }
       // every unpicked match of the group: bit-parallel distance of its sentence (rows) to the picked one (bits)
       const bool act = more && mine && !picked;
       const uint32_t rows = act ? n1 : 0u;
@@ -3872,7 +3934,13 @@ __global__ void __launch_bounds__(kWave) k_crerank_g(DevIndex ix, DevBatch b, De
       uint32_t pv = ~0u, mv = 0u, score = n2;
       const uint32_t m_bits = n2 ? n2 : 1u;
       const uint32_t mult = grp_mult(mk);
-      if (!use_loop) {
+      if constexpr (DICT) {
+#pragma unroll
+        for (int i = 0; i < 32; i++) {
+          if ((uint32_t)i >= rows_max) break;   // (wave-uniform)
+          if ((uint32_t)i < rows) lev_step32(pv, mv, score, s_msk[gi][tk[i]], m_bits);
+        }
+      } else if (!use_loop) {
 #pragma unroll
         for (int i = 0; i < 32; i++) {
           if ((uint32_t)i >= rows_max) break;   // (wave-uniform)
@@ -3910,7 +3978,7 @@ __global__ void __launch_bounds__(kWave) k_crerank_g(DevIndex ix, DevBatch b, De
         n_dist++;
       }
     }
-    if (have && gl == 0) { out_count[gq] = want < cap ? want : cap; if (out_total) out_total[gq] = want; }
+    if (live && gl == 0) { out_count[gq] = want < cap ? want : cap; if (out_total) out_total[gq] = want; }
   }
   n_dist = wave_sum(n_dist);
   if (lane == 0 && n_dist) atomicAdd(&w.counters[27], (unsigned long long)n_dist);

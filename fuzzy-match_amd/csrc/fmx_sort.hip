@@ -574,9 +574,9 @@ SortResident* gpu_suffix_sort(HostIndex& h, int device) {
   res->device = device; res->n_buf = n_buf; res->n_sent = n_sent; res->n_suf = n;
   {
     void* q = nullptr;
-    HIP_TRY(hipMalloc(&q, (n_buf + 8) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&q, (n_buf + kTokSpare) * sizeof(uint32_t)));
     res->d_buf = (uint32_t*)q;
-    HIP_TRY(hipMemset(res->d_buf + n_buf, 0, 8 * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(res->d_buf + n_buf, 0, kTokSpare * sizeof(uint32_t)));
     HIP_TRY(hipMemcpy(res->d_buf, h.buf.data(), n_buf * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc(&q, std::max<size_t>(n_sent, 1) * sizeof(uint32_t)));
     res->d_sent_pos = (uint32_t*)q;

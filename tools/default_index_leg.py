@@ -69,7 +69,7 @@ def run(fmx, synth, torch, dev, c_off, c_tok, batches, pkw, cap, t_text, steps, 
         t_up = time.time() - t0
         assert ix.info().real_differs, "the default index must carry real tokens that differ from its normalised tokens"
         ix.set_option("contexts", max(2, t_text + 1))
-        for opt in ("FMX_SERIAL", "FMX_SUB_QUERIES", "FMX_HOST_SUB_QUERIES"):   # design-time switches, like bench.py's
+        for opt in ("FMX_SERIAL", "FMX_SUB_QUERIES", "FMX_HOST_SUB_QUERIES", "FMX_REAL_HYBRID"):   # design-time switches, like bench.py's
             if os.environ.get(opt):
                 ix.set_option(opt[4:].lower(), int(os.environ[opt]))
         log(f"[default-index] text {os.path.getsize(tm) / 1e6:.0f} MB written in {t_text_gen:.1f}s; fmx-cli -c: {t_build:.1f}s -> {fmi_bytes / 1e9:.2f} GB .fmi; "
