@@ -2798,10 +2798,14 @@ template <bool REAL>
 __global__ void __launch_bounds__(kWave, FMX_DPTAB_WAVES) k_dp_tab(DevIndex ix, DevBatch b, DevWork w, Params prm,
                                                                  unsigned long long* flags = nullptr, unsigned long long* cnt = nullptr,
                                                                  uint32_t n_chunks = 0) {
-  __shared__ uint2 s_tab[kDpTabRuns][kDpTabSlots];   // {token, mask of its positions in the run's pattern}: one 8-byte read per row
-  __shared__ uint32_t s_treal[REAL ? kDpTabRuns : 1][kDpTabSlots];   // the real-token id the token's positions share / kRealMixed
-  __shared__ uint32_t s_rp[kDpTabRuns + 1];   // pattern tokens in front of each run of the round (exclusive prefix)
-  __shared__ uint32_t s_ro0[kDpTabRuns];      // where each run's pattern starts in q_tok
+  // {token, mask of its positions in the run's pattern}: one 8-byte read per row; REAL: {.., the real-token id the token's positions
+  // share / kRealMixed, -} in ONE 16-byte entry (a second LDS read behind the probe doubled the row's round trips: the marking kernel
+  // took 1.09 ms against the plain one's 0.45) and eight runs per round instead of sixteen (the same 8 KB)
+  using Ent = std::conditional_t<REAL, uint4, uint2>;
+  constexpr uint32_t kRuns = REAL ? kDpTabRuns / 2 : kDpTabRuns;
+  __shared__ Ent s_tab[kRuns][kDpTabSlots];
+  __shared__ uint32_t s_rp[kRuns + 1];   // pattern tokens in front of each run of the round (exclusive prefix)
+  __shared__ uint32_t s_ro0[kRuns];      // where each run's pattern starts in q_tok
   const uint32_t lane = lane_id();
   unsigned long long j_lo, j_hi;
   dp_class_range(b, w, 0u, j_lo, j_hi);
@@ -2842,15 +2846,15 @@ __global__ void __launch_bounds__(kWave, FMX_DPTAB_WAVES) k_dp_tab(DevIndex ix, 
     const uint32_t n_runs = (uint32_t)__popcll(heads);
     uint32_t pv = ~0u, mv = 0u, score = p;
     const uint32_t m_bits = p ? p : 1u;
-    for (uint32_t rb = 0; rb < n_runs; rb += kDpTabRuns) {
-      const uint32_t n_r = n_runs - rb < kDpTabRuns ? n_runs - rb : kDpTabRuns;  // runs of this round
+    for (uint32_t rb = 0; rb < n_runs; rb += kRuns) {
+      const uint32_t n_r = n_runs - rb < kRuns ? n_runs - rb : kRuns;  // runs of this round
       const uint32_t rl = run - rb;                                               // this lane's run inside the round
       const bool mine = act && rl < n_r;
       wave_lds_sync();
       // the round's tables: empty; the runs' pattern lengths and starts (written by each run's head lane)
       for (uint32_t k = lane; k < n_r * kDpTabSlots; k += kWave) {
-        (&s_tab[0][0])[k] = make_uint2(kHashEmpty, 0u);
-        if (REAL) (&s_treal[0][0])[k] = kRealNone;
+        if constexpr (REAL) (&s_tab[0][0])[k] = make_uint4(kHashEmpty, 0u, kRealNone, 0u);
+        else (&s_tab[0][0])[k] = make_uint2(kHashEmpty, 0u);
       }
       if (head && rl < n_r) { s_rp[rl + 1] = p; s_ro0[rl] = o0; }
       if (lane == 0) s_rp[0] = 0;
@@ -2865,7 +2869,7 @@ __global__ void __launch_bounds__(kWave, FMX_DPTAB_WAVES) k_dp_tab(DevIndex ix, 
       for (uint32_t x = lane; x < T; x += kWave) {
         uint32_t r = 0;
 #pragma unroll
-        for (uint32_t step = kDpTabRuns / 2; step >= 1; step >>= 1)
+        for (uint32_t step = kRuns / 2; step >= 1; step >>= 1)
           if (r + step < n_r && s_rp[r + step] <= x) r += step;
         const uint32_t jp = x - s_rp[r];
         const uint32_t t = b.q_tok[s_ro0[r] + jp];
@@ -2875,18 +2879,17 @@ __global__ void __launch_bounds__(kWave, FMX_DPTAB_WAVES) k_dp_tab(DevIndex ix, 
           if (old == kHashEmpty || old == t) { atomicOr(&s_tab[r][h].y, 1u << jp); break; }
           h = (h + 1) & (kDpTabSlots - 1);
         }
-        if (REAL) {  // the first position's real token stays unless another position of the word brings a different one
+        if constexpr (REAL) {  // the first position's real token stays unless another position of the word brings a different one
           const uint32_t rr = b.q_real[s_ro0[r] + jp];
-          const uint32_t was = atomicCAS(&s_treal[r][h], kRealNone, rr);
-          if (was != kRealNone && was != rr) s_treal[r][h] = kRealMixed;
+          const uint32_t was = atomicCAS(&s_tab[r][h].z, kRealNone, rr);
+          if (was != kRealNone && was != rr) s_tab[r][h].z = kRealMixed;
         }
       }
       wave_lds_sync();
       // the rows: this lane's sentence against its run's table (one 8-byte read per row and probe step).
       // (Measured at C3 and left as they are: a branch-free row — home slot read unconditionally, state kept by selects, the probe
       // sequence only when some lane collides — 0.53 ms, the four probes of a group requested together 0.55 ms, this loop 0.50 ms.)
-      const uint2* tab = &s_tab[mine ? rl : 0u][0];
-      const uint32_t* treal = &s_treal[(REAL && mine) ? rl : 0u][0];
+      const Ent* tab = &s_tab[mine ? rl : 0u][0];
       const uint32_t rows = mine ? slen : 0u;
       uint32_t rows_max = rows;
 #pragma unroll
@@ -2902,9 +2905,9 @@ __global__ void __launch_bounds__(kWave, FMX_DPTAB_WAVES) k_dp_tab(DevIndex ix, 
           if (i0 + u < rows) {
             const uint32_t wd = cur.t[u];
             uint32_t h = dp_tab_slot(wd);
-            uint2 e = tab[h];
+            Ent e = tab[h];
             while (e.x != wd && e.x != kHashEmpty) { h = (h + 1) & (kDpTabSlots - 1); e = tab[h]; }
-            if (REAL) need = need || (e.x == wd && treal[h] != (cur_r.t[u] & 0x7fffffffu));
+            if constexpr (REAL) need = need || (e.x == wd && e.z != (cur_r.t[u] & 0x7fffffffu));
             lev_step32(pv, mv, score, e.x == wd ? e.y : 0u, m_bits);
           }
         }
