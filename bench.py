@@ -848,7 +848,7 @@ def main():
         t1 = time.time()
         o = oracle_lib.OracleIndex()
         o.set_arrays(ix.array("suf_sid"), ix.array("suf_pos"), ix.array("buffer"), ix.array("sent_pos"),
-                     ix.array("qva"), ix.array("sfreq"))
+                     ix.array("qva"), int(ix.info().vocab_size))   # (the oracle counts the sentence frequencies itself)
         log(f"[bench] oracle index ready in {time.time() - t1:.1f}s")
         oprm = oracle_lib.Params(**pkw)
         parity = ref_model = cpu_baseline = None

@@ -196,6 +196,26 @@ int fmo_index_set_vocab(fmo_index* ix, uint32_t vocab_size, const uint32_t* sfre
   return 0;
 }
 
+/* VocabIndexer::sfreq for an index adopted with fmo_index_set_arrays, counted HERE from its sentence buffer (src/vocab_indexer.cc:73-90:
+ * a word counts once per sentence that holds it) — so that a parity test need not hand the product's counts over */
+int fmo_index_count_vocab(fmo_index* ix, uint32_t vocab_size) {
+  if (!ix || !ix->buf || !ix->sent_pos) return -1;
+  ix->vocab_size = vocab_size;
+  free(ix->sfreq);
+  ix->sfreq = (uint32_t*)calloc(vocab_size ? vocab_size : 1, sizeof(uint32_t));
+  uint32_t* stamp = (uint32_t*)calloc(vocab_size ? vocab_size : 1, sizeof(uint32_t));
+  if (!ix->sfreq || !stamp) abort();
+  for (uint64_t s = 0; s < ix->n_sent; s++) {
+    const uint32_t sp = ix->sent_pos[s], len = ix->buf[sp];
+    for (uint32_t k = 0; k < len; k++) {
+      const uint32_t w = ix->buf[sp + 1 + k];
+      if (w < vocab_size && stamp[w] != (uint32_t)s + 1u) { stamp[w] = (uint32_t)s + 1u; ix->sfreq[w]++; }
+    }
+  }
+  free(stamp);
+  return 0;
+}
+
 int fmo_index_set_real(fmo_index* ix, uint32_t s_id, const char* real_tokstring, uint32_t n_itoks,
                        const uint64_t* itok_idx, const char* const* itok_str) {
   if (s_id >= ix->n_sent) return -1;

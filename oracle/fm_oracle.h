@@ -86,6 +86,8 @@ int        fmo_index_set_arrays(fmo_index*,
                                 const uint32_t* sentence_buffer, uint64_t n_buf,
                                 const uint32_t* sentence_pos, uint64_t n_sent,
                                 const uint32_t* qva, uint64_t n_qva);
+/* VocabIndexer::sfreq of an index adopted with set_arrays, counted by the oracle itself from the sentence buffer */
+int        fmo_index_count_vocab(fmo_index*, uint32_t vocab_size);
 /* attach real tokens / itoks to an existing sentence (for indexes adopted with set_arrays) */
 int        fmo_index_set_real(fmo_index*, uint32_t s_id, const char* real_tokstring,
                               uint32_t n_itoks, const uint64_t* itok_idx, const char* const* itok_str);

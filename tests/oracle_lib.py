@@ -100,6 +100,7 @@ def lib():
     L.fmo_match_batch.argtypes = [vp, C.POINTER(Params), vp, vp, u64, C.c_int, vp, vp, u64, C.POINTER(Counters)]
     L.fmo_match_batch_real.argtypes = [vp, C.POINTER(Params), vp, vp, u64, vp, vp, C.c_int, vp, vp, u64, C.POINTER(Counters)]
     L.fmo_index_set_real_bulk.argtypes = [vp, u32, u32, vp, vp]
+    L.fmo_index_count_vocab.argtypes = [vp, u32]
     L.fmo_subsequence.argtypes = [vp, vp, u32, C.c_char_p, u32, C.POINTER(u64), C.POINTER(C.c_char_p), u32, C.c_int, C.c_int,
                                   C.c_float, C.c_int, vp, C.POINTER(u32)]
     L.fmo_edit_distance_ids.restype = C.c_float
@@ -213,6 +214,9 @@ class OracleIndex:
              np.ascontiguousarray(qva, np.uint32)]
         self.L.fmo_index_set_arrays(self.h, _ptr(a[0]), _ptr(a[1]), len(a[0]), _ptr(a[2]), len(a[2]),
                                     _ptr(a[3]), len(a[3]), _ptr(a[4]), len(a[4]))
+        if isinstance(sfreq, (int, np.integer)):   # a vocabulary size: the oracle counts the sentence frequencies itself
+            self.L.fmo_index_count_vocab(self.h, int(sfreq))
+            return
         sf = np.ascontiguousarray(sfreq, np.uint32)
         self.L.fmo_index_set_vocab(self.h, len(sf), _ptr(sf))
 

@@ -65,7 +65,7 @@ def setup(fmx, gpu_device):
     ix.to_device(gpu_device)
     ix.set_option("contexts", 4)
     o = oracle_lib.OracleIndex()
-    o.set_arrays(ix.array("suf_sid"), ix.array("suf_pos"), ix.array("buffer"), ix.array("sent_pos"), ix.array("qva"), ix.array("sfreq"))
+    o.set_arrays(ix.array("suf_sid"), ix.array("suf_pos"), ix.array("buffer"), ix.array("sent_pos"), ix.array("qva"), int(ix.info().vocab_size))   # (the oracle counts the sentence frequencies itself)
     kw = dict(fuzzy=0.7, nmatch=5)
     oo, oc = o.match_batch(oracle_lib.Params(**kw), q_off, q_tok, 5, nthreads=oracle_lib.effective_cpus())
     o.close()

@@ -109,7 +109,7 @@ def test_oracle_sample_at_scale(fmx, c2):
     ix, c_off, c_tok, q_off, q_tok, vs = c2
     o = oracle_lib.OracleIndex()
     o.set_arrays(ix.array("suf_sid"), ix.array("suf_pos"), ix.array("buffer"), ix.array("sent_pos"), ix.array("qva"),
-                 ix.array("sfreq"))
+                 int(ix.info().vocab_size))   # (the oracle counts the sentence frequencies itself)
     n = len(q_off) - 1
     so, st = q_off[:n + 1], q_tok[:int(q_off[n])]
     for name in ["C3", "C4", "C5"]:
@@ -167,7 +167,7 @@ def test_c3_headline_config_parity(fmx, gpu_device, c3):
     go, gc, _ = ix.match_batch(fmx.Params(**kw), q_off, q_tok, cap=5)
     o = oracle_lib.OracleIndex()
     o.set_arrays(ix.array("suf_sid"), ix.array("suf_pos"), ix.array("buffer"), ix.array("sent_pos"), ix.array("qva"),
-                 ix.array("sfreq"))
+                 int(ix.info().vocab_size))   # (the oracle counts the sentence frequencies itself)
     n = len(q_off) - 1
     assert n == 1_000_000
     so, st = q_off, q_tok

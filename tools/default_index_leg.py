@@ -210,7 +210,7 @@ def run(fmx, synth, torch, dev, c_off, c_tok, batches, pkw, cap, t_text, steps, 
         if verify:
             t0 = time.time()
             o = oracle_lib.OracleIndex()
-            o.set_arrays(ix.array("suf_sid"), ix.array("suf_pos"), buf, ix.array("sent_pos"), ix.array("qva"), ix.array("sfreq"))
+            o.set_arrays(ix.array("suf_sid"), ix.array("suf_pos"), buf, ix.array("sent_pos"), ix.array("qva"), int(ix.info().vocab_size))   # (the oracle counts the sentence frequencies itself)
             o.set_real_bulk(*oracle_lib.tab_joined(synth.pack_cased_stream(c_off, c_tok, 1), c_off))
             nth = cpu_threads or oracle_lib.effective_cpus()
             oprm = oracle_lib.Params(**pkw)
