@@ -1309,6 +1309,7 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
             unsigned long long* flags = c.keys.p + c.seg_cap;
             unsigned long long* cnt = flags + (n_chunks + 1);
             unsigned long long* offs = cnt + (n_chunks + 1);
+            HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)(n_chunks + 1) * sizeof(unsigned long long), stream));
             hipLaunchKernelGGL(k_dp_tab<true>, dim3(grid), dim3(kWave), 0, stream, E.d, b, w, prm, flags, cnt, n_chunks);
             const uint32_t n_sc = n_chunks + 1;
             hipLaunchKernelGGL(k_scan_lb<1>, dim3((n_sc + kScanTile - 1) / kScanTile), dim3(kScanThreads), 0, stream, (const unsigned long long*)cnt, offs, (size_t)n_sc, n_sc,

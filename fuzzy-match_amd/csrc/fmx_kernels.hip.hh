@@ -2811,12 +2811,8 @@ __global__ void __launch_bounds__(kWave, FMX_DPTAB_WAVES) k_dp_tab(DevIndex ix, 
   dp_class_range(b, w, 0u, j_lo, j_hi);
   const uint32_t n_list = (uint32_t)(j_hi - j_lo);
   const unsigned long long* __restrict__ list = w.c_qi + j_lo;
-  const uint32_t j_end = REAL ? (n_chunks + 1u) * kWave : n_list;
-  for (uint32_t j0 = blockIdx.x * kWave; j0 < j_end; j0 += gridDim.x * kWave) {
-    if (REAL && j0 >= n_list) {  // (wave-uniform) chunks behind the list: the scan reads zeros
-      if (lane == 0) { flags[j0 >> 6] = 0ull; cnt[j0 >> 6] = 0ull; }
-      continue;
-    }
+  // (REAL: cnt[] behind the list's last chunk was zeroed by the host — the scan reads n_chunks + 1 entries)
+  for (uint32_t j0 = blockIdx.x * kWave; j0 < n_list; j0 += gridDim.x * kWave) {
     const uint32_t j = j0 + lane;
     const bool act = j < n_list;
     const unsigned long long qi = act ? list[j] : 0ull;
