@@ -243,7 +243,9 @@ def run(fmx, synth, torch, dev, c_off, c_tok, batches, pkw, cap, t_text, steps, 
             par["oracle_s"] = round(time.time() - t0, 1)
             res["parity"] = par
             log(f"[default-index] parity vs the oracle with real tokens: {par}")
-            assert not bad, f"default-index leg: {len(bad)} sampled queries differ from the oracle"
+            par["mismatches"] = len(bad)   # (reported like the other legs' parity; the stand-alone tool fails on it)
+            if bad:
+                log(f"[default-index] PARITY FAILURE: {len(bad)} sampled queries differ from the oracle")
             o.close()
         ix.close()
         return res
@@ -309,6 +311,8 @@ def main():
     log = lambda *x: print(*x, file=sys.stderr, flush=True)  # noqa: E731
     res = run(fmx, synth, torch, dev, c_off, c_tok, batches, pkw, pkw.get("nmatch", 5) or 16, T, a.steps, a.warmup, a.verify, log, keep_tmp=a.keep_tmp)
     print(json.dumps({"config": a.config, "sentences": n_sent, "cli_default_index": res}))
+    if res.get("parity", {}).get("mismatches"):
+        sys.exit(1)
 
 
 if __name__ == "__main__":
