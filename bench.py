@@ -876,6 +876,10 @@ def main():
                                "staged calls), every (nq / checked)-th query of that step's batch, vs the oracle; N > 1: per_rank_block = what "
                                "the RCCL gather of the value leg's last timed step assembled on rank 0, a spread sample of every rank's block "
                                "(global query order, cli/src/FuzzyMatch-cli.cc:151-162) vs the oracle"}
+        if parity is not None and default_leg and default_leg.get("parity"):
+            # the default-index leg checked its three paths against the oracle WITH real tokens itself (tools/default_index_leg.py)
+            parity["per_leg"]["cli_default_index"] = int(default_leg["parity"].get("mismatches", 0))
+            parity["mismatches"] += parity["per_leg"]["cli_default_index"]
         q_off, q_tok, nq = main_set[0].q_off, main_set[0].q_tok, main_set[0].nq
         nm = min(args.model_queries, nq)
         if nm:
