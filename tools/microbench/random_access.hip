@@ -1,7 +1,9 @@
 // random_access.hip — what the memory system of one MI355X sustains for the access pattern of k_probe:
 // independent or dependent random 16-byte loads over a multi-GB array.  Prints loads/s, the sector
 // bandwidth they amount to, and the latency of a dependent chain at full occupancy.
-//   hipcc --offload-arch=gfx950 -O3 -o random_access random_access.hip && ./random_access [GiB]
+//   hipcc --offload-arch=gfx950 -O3 -o random_access random_access.hip && ./random_access [GiB] [parts]
+// parts > 1 (round 6): the same bytes as `parts` separate allocations, a lane's load going to a random one of them — does it matter
+// for the address translation whether the probe's tables (5.3 + 1.1 + 0.3 + 4.0 + ... GB) live in one allocation or in several?
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
@@ -25,6 +27,26 @@ __global__ void __launch_bounds__(256) k_rand(const Key* a, uint64_t n, int chai
     Key k[PAR];
 #pragma unroll
     for (int u = 0; u < PAR; u++) k[u] = a[(uint64_t)x[u] % n];
+#pragma unroll
+    for (int u = 0; u < PAR; u++) x[u] = mix(x[u] + k[u].t[0] + k[u].t[3]);
+  }
+  uint32_t s = 0;
+#pragma unroll
+  for (int u = 0; u < PAR; u++) s += x[u];
+  if (s == 0x12345678u) out[0] = s;
+}
+
+struct Parts { const Key* p[16]; };
+template <int PAR>
+__global__ void __launch_bounds__(256) k_rand_parts(Parts ps, int parts, uint64_t n_each, int chain, uint32_t* out) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t x[PAR];
+#pragma unroll
+  for (int u = 0; u < PAR; u++) x[u] = mix(t * PAR + u + 1);
+  for (int c = 0; c < chain; c++) {
+    Key k[PAR];
+#pragma unroll
+    for (int u = 0; u < PAR; u++) k[u] = ps.p[(x[u] >> 8) % (uint32_t)parts][(uint64_t)mix(x[u]) % n_each];
 #pragma unroll
     for (int u = 0; u < PAR; u++) x[u] = mix(x[u] + k[u].t[0] + k[u].t[3]);
   }
@@ -73,6 +95,29 @@ static double time_ms(F f, int reps) {
 int main(int argc, char** argv) {
   const double gib = argc > 1 ? atof(argv[1]) : 2.0;
   const uint64_t n = (uint64_t)(gib * (1ull << 30)) / sizeof(Key);
+  const int parts = argc > 2 ? atoi(argv[2]) : 1;
+  if (parts > 1 && parts <= 16) {
+    Parts ps{};
+    uint32_t* out2;
+    const uint64_t n_each = n / parts;
+    if (hipMalloc(&out2, 4) != hipSuccess) return 1;
+    for (int k = 0; k < parts; k++) {
+      Key* q;
+      if (hipMalloc(&q, n_each * sizeof(Key)) != hipSuccess) { fprintf(stderr, "alloc failed\n"); return 1; }
+      hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, q, n_each);
+      ps.p[k] = q;
+    }
+    hipDeviceSynchronize();
+    const uint32_t lanes2 = 25u << 20;
+    printf("%d allocations of %.2f GiB, %u lanes\n", parts, gib / parts, lanes2);
+    for (int chain : {1, 4}) {
+      double ms1 = time_ms([&] { hipLaunchKernelGGL(k_rand_parts<1>, dim3(lanes2 / 256), dim3(256), 0, 0, ps, parts, n_each, chain, out2); }, 3);
+      double ms4 = time_ms([&] { hipLaunchKernelGGL(k_rand_parts<4>, dim3(lanes2 / 256), dim3(256), 0, 0, ps, parts, n_each, chain, out2); }, 3);
+      printf("chain %2d  par 1: %7.3f ms  %6.1f G loads/s   par 4: %7.3f ms  %6.1f G loads/s\n", chain, ms1, lanes2 * (double)chain / ms1 / 1e6, ms4,
+             lanes2 * 4.0 * chain / ms4 / 1e6);
+    }
+    return 0;
+  }
   Key* a; uint32_t* out;
   if (hipMalloc(&a, n * sizeof(Key)) != hipSuccess || hipMalloc(&out, 4) != hipSuccess) { fprintf(stderr, "alloc failed\n"); return 1; }
   hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, a, n);
