@@ -6,7 +6,6 @@
 // filled with one atomicCAS per distinct n-gram.
 #pragma once
 #include <hip/hip_runtime.h>
-#include <rocprim/rocprim.hpp>
 
 #include "fmx_core.hh"
 
@@ -96,6 +95,29 @@ struct DvSevenBoundary {
     return five.tri.key[i].t[4] != five.tri.key[i - 1].t[4] || five.tri.key[i].t[5] != five.tri.key[i - 1].t[5];
   }
 };
+
+// Stream compaction of the indices with pred(i) (DeviceIndex::derive's `select`): a wave per 64 consecutive indices writes its ballot
+// and its count (chunk n_ch, behind the last, gets zeros: the scan's extra element = the total); k_scan_lb<1> turns the counts into
+// offsets; k_dv_scatter writes the indices in order.
+template <class Pred>
+__global__ void __launch_bounds__(64) k_dv_mark(Pred pred, unsigned long long n, uint32_t n_ch, unsigned long long* __restrict__ flags,
+                                                unsigned long long* __restrict__ cnt) {
+  const uint32_t lane = threadIdx.x & 63;
+  for (uint32_t ch = blockIdx.x; ch <= n_ch; ch += gridDim.x) {
+    const unsigned long long i = (unsigned long long)ch * 64 + lane;
+    const unsigned long long fl = __ballot(i < n && pred((uint32_t)i));
+    if (lane == 0) { flags[ch] = fl; cnt[ch] = (unsigned long long)__popcll(fl); }
+  }
+}
+__global__ void __launch_bounds__(64) k_dv_scatter(unsigned long long n, const unsigned long long* __restrict__ flags,
+                                                   const unsigned long long* __restrict__ offs, uint32_t* __restrict__ out) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t n_ch = (uint32_t)((n + 63) / 64);
+  for (uint32_t ch = blockIdx.x; ch < n_ch; ch += gridDim.x) {
+    const unsigned long long fl = flags[ch];
+    if ((fl >> lane) & 1ull) out[offs[ch] + (unsigned long long)__popcll(fl & ((1ull << lane) - 1ull))] = ch * 64u + lane;
+  }
+}
 
 // (grid-stride, one atomic per wave at the end: one atomic per 64 boundaries on a single address was 6 ms at C3)
 __global__ void __launch_bounds__(256) k_dv_count_starts(const uint32_t* __restrict__ bnd, uint32_t n_bnd, const SufRec* __restrict__ suf,

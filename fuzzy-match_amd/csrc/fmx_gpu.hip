@@ -12,8 +12,6 @@
 #include <cstring>
 #include <functional>
 #include <hip/hip_runtime.h>
-#include <rocprim/rocprim.hpp>
-
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -803,20 +801,32 @@ static unsigned long long* derive_on_device(DeviceIndex::Impl& m, const HostInde
   uint32_t* bnd5 = nullptr;
   uint32_t* bnd7 = nullptr;
   uint32_t* lo3 = nullptr;
-  size_t* d_num = dev_alloc<size_t>(1);
   unsigned long long* d_count = dev_alloc<unsigned long long>(1);
   void* tmp = nullptr;
-  auto cleanup = [&]() { hipFree(bnd3); hipFree(bnd5); hipFree(bnd7); hipFree(lo3); hipFree(d_num); hipFree(d_count); hipFree(tmp); };
+  auto cleanup = [&]() { hipFree(bnd3); hipFree(bnd5); hipFree(bnd7); hipFree(lo3); hipFree(d_count); hipFree(tmp); };
   try {
     const DvTriBoundary tri{suf, suf_key, m.d.tok};
+    // stream compaction of the indices i in [0, n) with pred(i), in order (round 6: hand-written — ballots per 64 indices, the
+    // pass's look-back scan over their counts, a scatter — in place of rocprim::select, the last library call of the derive)
+    const uint32_t n_ch = (uint32_t)((n + kWave - 1) / kWave);
+    hipFree(tmp); tmp = nullptr;
+    HIP_TRY(hipMalloc(&tmp, ((size_t)3 * (n_ch + 1) + kLbMaxTiles + 2) * sizeof(unsigned long long)));
+    unsigned long long* sel_flags = (unsigned long long*)tmp;
+    unsigned long long* sel_cnt = sel_flags + (n_ch + 1);
+    unsigned long long* sel_offs = sel_cnt + (n_ch + 1);
+    unsigned long long* sel_state = sel_offs + (n_ch + 1);
     auto select = [&](auto pred, uint32_t* out) -> uint32_t {
-      size_t bytes = 0;
-      HIP_TRY(rocprim::select(nullptr, bytes, rocprim::counting_iterator<uint32_t>(0), out, d_num, (size_t)n, pred, (hipStream_t)0, false));
-      hipFree(tmp); tmp = nullptr;
-      HIP_TRY(hipMalloc(&tmp, std::max<size_t>(bytes, 1)));
-      HIP_TRY(rocprim::select(tmp, bytes, rocprim::counting_iterator<uint32_t>(0), out, d_num, (size_t)n, pred, (hipStream_t)0, false));
-      size_t num = 0;
-      HIP_TRY(hipMemcpy(&num, d_num, sizeof(size_t), hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemsetAsync(sel_state, 0, ((size_t)kLbMaxTiles + 2) * sizeof(unsigned long long), 0));
+      hipLaunchKernelGGL(k_dv_mark<decltype(pred)>, dim3(std::min<uint32_t>(n_ch + 1, 65536u)), dim3(kWave), 0, 0, pred, (unsigned long long)n, n_ch, sel_flags, sel_cnt);
+      const uint32_t n_sc = n_ch + 1;
+      if ((n_sc + kScanTile - 1) / kScanTile > kLbMaxTiles) throw UnsupportedError("index too large for the derive's scan");
+      hipLaunchKernelGGL(k_scan_lb<1>, dim3((n_sc + kScanTile - 1) / kScanTile), dim3(kScanThreads), 0, 0, (const unsigned long long*)sel_cnt, sel_offs, (size_t)n_sc, n_sc,
+                         sel_state, reinterpret_cast<uint32_t*>(sel_state + kLbMaxTiles));
+      hipLaunchKernelGGL(k_dv_scatter, dim3(std::min<uint32_t>(n_ch, 65536u)), dim3(kWave), 0, 0, (unsigned long long)n, (const unsigned long long*)sel_flags,
+                         (const unsigned long long*)sel_offs, out);
+      HIP_TRY(hipGetLastError());
+      unsigned long long num = 0;
+      HIP_TRY(hipMemcpy(&num, sel_offs + n_ch, sizeof(num), hipMemcpyDeviceToHost));
       return (uint32_t)num;
     };
     auto read_count = [&]() { unsigned long long v = 0; HIP_TRY(hipMemcpy(&v, d_count, 8, hipMemcpyDeviceToHost)); return v; };
