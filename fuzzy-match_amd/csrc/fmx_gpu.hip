@@ -1107,6 +1107,19 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
   Rec* d_out = E.d_out; uint32_t* d_out_count = E.d_out_count; uint32_t* d_out_total = E.d_out_total;
   const uint32_t cap = E.cap;
   hipStream_t stream = E.stream;
+  // (round 6) the sorter of the few huge survivor sets starts on the side lane as soon as k_expand_b<false> is through, beside the
+  // light queries' hit walk, instead of after it (only with light queries: without them k_expand_b<false> is the whole stage)
+  static const bool early_big_on = [] { const char* e = getenv("FMX_EARLY_BIG"); return e ? atoi(e) != 0 : true; }();  // design-time switch
+  bool early_big = false;
+  DevWork w_big{};   // the pass's work view (filled below, before anything is launched)
+  auto launch_big = [&](hipStream_t st) {
+    const DevWork& w2 = w_big;
+    // radix passes needed: sentence ids < n_sent, match lengths <= longest pattern
+    uint32_t sid_bytes = 1, len_bytes = p_max < 255 ? 1u : 2u;
+    while (sid_bytes < 4 && (E.d.n_sent >> (8 * sid_bytes)) != 0) sid_bytes++;
+    hipLaunchKernelGGL(k_cand_route_big, dim3((b.nq + 255) / 256), dim3(256), 0, st, b, w2, c.big_list.p);
+    hipLaunchKernelGGL(k_cand_big, dim3(kBigGrid), dim3(kBigThreads), 0, st, w2, c.keys.p, (const uint32_t*)c.big_list.p, sid_bytes, len_bytes);
+  };
     DevWork w = work_view(c);
     const uint32_t item_cap = (uint32_t)std::min<uint64_t>(c.items.cap, 0xffffffffull);
     const uint32_t item_h_cap = (uint32_t)std::min<uint64_t>(c.items_h.cap, 0xffffffffull);
@@ -1116,6 +1129,7 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
     const uint32_t n_scan = b.nq + 1;  // one extra element so that out[nq] = total
     w.q_capl = w.q_cap + n_scan;   // second array of the first scan (input / output)
     w.q_segl = w.q_qseg + n_scan;
+    w_big = w;
     const uint32_t scan_tiles = (n_scan + kScanTile - 1) / kScanTile;
     if (scan_tiles > kLbMaxTiles) throw std::invalid_argument("sub-batch too large for the scan");
     int e = 0;
@@ -1174,6 +1188,7 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
     tick(); tick();
     // light queries (k_caps_scan): at most light_max hits, all in short ranges, pattern of at most one wave
     const uint32_t light_max = b.nq ? std::min<uint32_t>(m.light_max, kPhaseBChunk) : 0u;
+    early_big = early_big_on && light_max != 0;
     // two queries per wave in the last kernel (k_finish_pair): no contrastive rerank, lowest_costs fits half a wave
     // (with or without a contrastive factor; any contrast_buffer: beyond 30 entries the pair kernel takes 31 candidates per query)
     const bool pair_finish = m.pair_finish && prm.cbuf > 0;
@@ -1209,8 +1224,17 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
           if (flat_max <= 128) hipLaunchKernelGGL((k_expand_lf<128, 128>), dim3(grid), dim3(kWave), 0, stream, E.d, b, w, prm, G, flat_max);
           else hipLaunchKernelGGL((k_expand_lf<128, 256>), dim3(grid), dim3(kWave), 0, stream, E.d, b, w, prm, G, flat_max);
         }
-        if (flat_max < light_max)
-          hipLaunchKernelGGL(k_expand_b<true>, dim3(b.nq), dim3(kWave), lds, stream, E.d, b, w, prm, (const WorkItem*)nullptr, 0u, b.nq, flat_max);
+        if (flat_max < light_max) {
+          // (round 6) in parts when the big sorter waits on the side lane: workgroups of the oldest kernel are placed first, and one
+          // launch of a million workgroups lets nothing younger in until it is nearly through; between two parts the side lane gets its turn
+          static const uint32_t parts_env = [] { const char* e = getenv("FMX_LIGHT_PARTS"); return e ? (uint32_t)atoi(e) : 2u; }();  // design-time switch (1 / 2 / 3 / 6 parts at C3: stage 1.65 / 1.43 / 1.49 / 1.49 ms)
+          const uint32_t parts = (early_big && b.nq >= 65536u) ? std::max(1u, parts_env) : 1u;
+          for (uint32_t pt_ = 0; pt_ < parts; pt_++) {
+            const uint32_t q0 = (uint32_t)((uint64_t)b.nq * pt_ / parts), q1 = (uint32_t)((uint64_t)b.nq * (pt_ + 1) / parts);
+            if (q1 > q0)
+              hipLaunchKernelGGL(k_expand_b<true>, dim3(q1 - q0), dim3(kWave), lds, stream, E.d, b, w, prm, (const WorkItem*)nullptr, q0, b.nq, flat_max);
+          }
+        }
       };
       auto second_scan = [&](hipStream_t st) {
         // the hits phase A really queued size the segments of everything downstream: second scan, q_cap -> q_seg, placed
@@ -1235,6 +1259,7 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
         hipLaunchKernelGGL(k_expand_b<false>, dim3((light_max ? 0u : b.nq) + grid_b), dim3(kWave), lds, side, E.d, b, w, prm,
                            (const WorkItem*)c.items_b.p, item_cap, light_max ? 0u : b.nq, 0u);
         side_tick(kStageExpandB, 1);
+        if (early_big) launch_big(side);
         if (light_max) launch_light();
         tick(); tick();
       } else {
@@ -1250,6 +1275,7 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
         hipLaunchKernelGGL(k_expand_b<false>, dim3((light_max ? 0u : b.nq) + grid_b), dim3(kWave), lds, side, E.d, b, w, prm,
                            (const WorkItem*)c.items_b.p, item_cap, light_max ? 0u : b.nq, 0u);
         side_tick(kStageExpandB, 1);
+        if (early_big) launch_big(side);
         if (light_max) {
           if (!m.serial) hipLaunchKernelGGL(k_lag, dim3(1), dim3(kWave), 0, stream, w.counters);
           launch_light();
@@ -1260,7 +1286,7 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
     }
     tick(); tick();
     // fin_list is free until k_cmap fills it: it carries k_cand's few queries
-    hipLaunchKernelGGL(k_cand_route, dim3((b.nq + 255) / 256), dim3(256), 0, stream, b, w, c.big_list.p, c.mid_list.p, c.fin_list.p);
+    hipLaunchKernelGGL(k_cand_route, dim3((b.nq + 255) / 256), dim3(256), 0, stream, b, w, c.big_list.p, c.mid_list.p, c.fin_list.p, early_big ? 1 : 0);
     hipLaunchKernelGGL(k_cand, dim3(std::min<uint32_t>(2048u, std::max<uint32_t>(64u, b.nq))), dim3(kWave), 0, stream, w, (const uint32_t*)c.fin_list.p);
     {
       // The sorter of the few huge survivor sets is one workgroup per query and leaves the GPU almost idle:
@@ -1268,9 +1294,11 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
       // radix passes needed: sentence ids < n_sent, match lengths <= longest pattern
       uint32_t sid_bytes = 1, len_bytes = p_max < 255 ? 1u : 2u;
       while (sid_bytes < 4 && (E.d.n_sent >> (8 * sid_bytes)) != 0) sid_bytes++;
-      fork();
-      hipLaunchKernelGGL(k_cand_big, dim3(kBigGrid), dim3(kBigThreads), 0, side, w, c.keys.p,
-                         (const uint32_t*)c.big_list.p, sid_bytes, len_bytes);
+      if (!early_big) {
+        fork();
+        hipLaunchKernelGGL(k_cand_big, dim3(kBigGrid), dim3(kBigThreads), 0, side, w, c.keys.p,
+                           (const uint32_t*)c.big_list.p, sid_bytes, len_bytes);
+      }
     }
     hipLaunchKernelGGL(k_cand_mid, dim3(1024), dim3(256), 0, stream, w, (const uint32_t*)c.mid_list.p);
     tick(); tick();

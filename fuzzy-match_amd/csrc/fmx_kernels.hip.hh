@@ -1523,7 +1523,7 @@ __global__ void __launch_bounds__(kWave, LIGHT ? FMX_LIGHT_WAVES : FMX_PHASEB_WA
   uint32_t q, chunk;
   uint32_t item_idx = 0;
   const bool extra = !LIGHT && blockIdx.x >= first_q_blocks;
-  if (!extra) { q = blockIdx.x; chunk = 0; }
+  if (!extra) { q = blockIdx.x + (LIGHT ? item_cap : 0u); chunk = 0; }  // (LIGHT: item_cap = first query of this launch's part)
   else item_idx = blockIdx.x - first_q_blocks;
   for (;;) {
     const uint32_t lane = lane0;
@@ -2064,17 +2064,30 @@ __device__ __forceinline__ unsigned long long wave_sort64(unsigned long long key
 // k_cand_route — one thread per query: nearly every query's survivors were already reduced to candidates by k_expand_b (in
 // LDS), so only the rest is handed to a kernel: up to 64 survivors -> small_list (k_cand: registers), 65..1024 -> mid_list
 // (k_cand_mid: LDS bitonic), more -> big_list (k_cand_big: block radix sort).
-__global__ void __launch_bounds__(256) k_cand_route(DevBatch b, DevWork w, uint32_t* big_list, uint32_t* mid_list, uint32_t* small_list) {
+// big_routed (round 6): the huge sets were listed by k_cand_route_big and are being sorted on the side lane already.
+__global__ void __launch_bounds__(256) k_cand_route(DevBatch b, DevWork w, uint32_t* big_list, uint32_t* mid_list, uint32_t* small_list, int big_routed) {
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= b.nq) return;
   const uint32_t n = w.q_kept[q];
   if (n & kKeptReduced) return;  // k_expand_b already wrote the candidates and q_cand
+  if (big_routed && n > kLdsSortMax && n <= w.q_scap[q]) return;  // (k_cand_big wrote q_cand)
   w.q_cand[q] = 0;
   if (n == 0) return;
   if (n > w.q_scap[q]) { atomicMax(&w.counters[4], (unsigned long long)n); return; }  // more survivors than the segment holds
   if (n > kLdsSortMax) big_list[atomicAdd(&w.counters[7], 1ull)] = q;
   else if (n > kWave) mid_list[atomicAdd(&w.counters[13], 1ull)] = q;
   else small_list[atomicAdd(&w.counters[23], 1ull)] = q;
+}
+
+// k_cand_route_big (round 6) — the few queries with more than kLdsSortMax survivors, listed as soon as k_expand_b<false> is through
+// (a light query has at most light_max hits: never one of them), so that k_cand_big — one workgroup per huge set, three 50 us radix
+// passes: 0.29 ms during which a pass otherwise leaves the GPU almost idle — sorts them on the side lane BESIDE the light queries' hit walk.
+__global__ void __launch_bounds__(256) k_cand_route_big(DevBatch b, DevWork w, uint32_t* big_list) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= b.nq || w.q_capl[q] != 0) return;   // (light queries: their kernel may still be running)
+  const uint32_t n = w.q_kept[q];
+  if ((n & kKeptReduced) || n <= kLdsSortMax || n > w.q_scap[q]) return;
+  big_list[atomicAdd(&w.counters[7], 1ull)] = q;
 }
 
 // k_cand — one wave per query of small_list: up to 64 survivors are de-duplicated and ordered entirely in registers.
