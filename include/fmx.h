@@ -410,6 +410,9 @@ int64_t fmx_index_add_text_bulk(fmx_index*, const char* const* ids, const char* 
  *                       last kernel; 0 = calls simply overlap; 3 = turns are taken on the host
  *   "light_max"         queries with at most this many suffix-array hits, none of them in a long range, are walked by
  *                       one kernel without the phase-A filter (default 256, at most 1024; 0 = none)
+ *   "real_hybrid"       indexes with real tokens under unit costs: 1 = the bit-parallel kernel answers the pairs in which no equal word
+ *                       meets a different real token and leaves the others to the float kernel (default 0: the float kernel for all is
+ *                       faster at C3, profiles/r06_real_hybrid_ab.md); same records either way
  *   "expand_order", "b_grid", "heavy_grid", "serial"   measurement / design-time switches of the expand stage
  *   "initial_segment"   initial capacity of the hit workspace (grows on demand; sizes are learned per index) */
 int fmx_set_option(fmx_index*, const char* name, int64_t value);
