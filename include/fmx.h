@@ -398,8 +398,9 @@ int64_t fmx_index_add_text_bulk(fmx_index*, const char* const* ids, const char* 
  *                       full waves) — default 1; 0 = one kernel (round 4's layout, same results)
  *   "max_host_active"   host-buffer calls (fmx_match_batch*, _text*, _lines*) that may have work on the GPU at once, whatever
  *                       "contexts" says (default 4; further synchronous callers wait on the host, further _begin calls are queued
- *                       in order); a caller that pipelines _begin / _end from ONE thread may raise it to 5 (bench.py does), 7 and
- *                       more crawl.  Such calls also start at least 0.5 ms apart per device (environment FMX_HOST_SPACING_US)
+ *                       in order); a caller that pipelines _begin / _end from ONE thread may raise it to 5 (bench.py does); more
+ *                       than that is slower, not catastrophic (until round 5 seven and more crawled: a high-priority stream per call).
+ *                       Such calls also start at least 0.5 ms apart per device (environment FMX_HOST_SPACING_US)
  *   "sub_queries"       queries per pipeline pass (default 1 048 576)
  *   "host_sub_queries"  pass size of fmx_match_batch (host buffers, default 1 048 576): the inputs of the next pass and
  *                       the records of the previous one cross PCIe while a pass computes
