@@ -778,14 +778,13 @@ def main():
                     keys = [k for k in fetch if k.replace("void ", "").startswith(kern)]  # template instantiations add up
                     if not keys:
                         continue
-                    # the child's two timed steps: bytes per step.  Dispatches per step of an instantiation = its dispatches over the
-                    # child's three passes (one warm-up, two timed) / 3 — the light kernel runs as two launches per pass since round 6,
-                    # k_cround once per rerank round
-                    def last_two_steps(series):
-                        n_ps = max(len(series) // 3, 1)
+                    # the child's two timed steps (the last dispatches: earlier ones include re-run first passes): bytes per step.
+                    # The light kernel (k_expand_b<true>) runs as two launches per pass of >= 65 536 queries since round 6.
+                    def last_two_steps(name, series):
+                        n_ps = per_step * (2 if ("k_expand_b<true>" in name and main_set[0].nq >= 65536) else 1)
                         return np.sum([v for _, v in series[-2 * n_ps:]]) / 2.0
-                    f_kb = sum(last_two_steps(fetch[k]) for k in keys)
-                    w_kb = sum(last_two_steps(write[k]) for k in keys if k in write)
+                    f_kb = sum(last_two_steps(k, fetch[k]) for k in keys)
+                    w_kb = sum(last_two_steps(k, write[k]) for k in keys if k in write)
                     f_fac = float(cal.get("fetch_factor", {}).get(pattern, 2.0))
                     w_fac = float(cal.get("write_factor", 1.0))
                     traffic[kern.split("::")[1]] = {"bytes": int(f_kb * 1024 * f_fac + w_kb * 1024 * w_fac), "fetch_kb_raw": float(f_kb),
