@@ -1110,7 +1110,7 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
   // (round 6) the sorter of the few huge survivor sets starts on the side lane as soon as k_expand_b<false> is through, beside the
   // light queries' hit walk, instead of after it (only with light queries: without them k_expand_b<false> is the whole stage)
   static const bool early_big_on = [] { const char* e = getenv("FMX_EARLY_BIG"); return e ? atoi(e) != 0 : true; }();  // design-time switch
-  bool early_big = false;
+  bool early_big = false, big_pending = false;
   DevWork w_big{};   // the pass's work view (filled below, before anything is launched)
   auto launch_big = [&](hipStream_t st) {
     const DevWork& w2 = w_big;
@@ -1275,14 +1275,21 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
         hipLaunchKernelGGL(k_expand_b<false>, dim3((light_max ? 0u : b.nq) + grid_b), dim3(kWave), lds, side, E.d, b, w, prm,
                            (const WorkItem*)c.items_b.p, item_cap, light_max ? 0u : b.nq, 0u);
         side_tick(kStageExpandB, 1);
-        if (early_big) launch_big(side);
+        if (early_big) {
+          // the main lane goes on when k_expand_b<false> is through (ev_a); the sorter behind it is joined where its result is
+          // needed, in front of k_classify: the small candidate kernels run beside its tail
+          if (!m.serial) { HIP_TRY(hipEventRecord(c.ev_a, side)); big_pending = true; }
+          launch_big(side);
+        }
         if (light_max) {
           if (!m.serial) hipLaunchKernelGGL(k_lag, dim3(1), dim3(kWave), 0, stream, w.counters);
           launch_light();
         }
         tick(); tick();
       }
-      join();  // stage "expand_wait": what the side lane still has to do when the light kernel is through
+      // stage "expand_wait": what k_expand_b<false> still has to do when the light kernel is through
+      if (big_pending) HIP_TRY(hipStreamWaitEvent(stream, c.ev_a, 0));
+      else join();
     }
     tick(); tick();
     // fin_list is free until k_cmap fills it: it carries k_cand's few queries
