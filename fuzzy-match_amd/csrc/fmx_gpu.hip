@@ -1339,12 +1339,16 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
         // real tokens: rows + both pattern streams in registers; pairs with penalty tokens (only looked for when the index has
         // interned penalty strings) are handed over in c.keys — free between the candidate sorters and k_finish — to the general kernel
         const int check_itok = E.d.n_itok > 1 ? 1 : 0;
-        const bool two = p_max > 32 && dp_mode == 2;
+        const bool two = p_max > 32;
         if (two) fork();
         const bool hybrid_on = m.real_hybrid;  // option "real_hybrid" (off by default)
-        if (dp_mode == 3) hipLaunchKernelGGL((k_dp_reg<32, true, false, true>), dim3(grid), dim3(kWave), 0, stream, E.d, b, w, prm, c.keys.p, check_itok);
-        else {
-          if (two) hipLaunchKernelGGL((k_dp_reg<64, false, false, true>), dim3(grid), dim3(kWave), 0, side, E.d, b, w, prm, c.keys.p, check_itok);
+        if (dp_mode == 3) {
+          if (two) hipLaunchKernelGGL((k_dp_reg<48, true, false, true>), dim3(grid), dim3(kWave), 0, side, E.d, b, w, prm, c.keys.p, check_itok);
+          if (p_max > 48) hipLaunchKernelGGL((k_dp_reg<64, true, false, true, 49>), dim3(grid), dim3(kWave), 0, side, E.d, b, w, prm, c.keys.p, check_itok);
+          hipLaunchKernelGGL((k_dp_reg<32, true, false, true>), dim3(grid), dim3(kWave), 0, stream, E.d, b, w, prm, c.keys.p, check_itok);
+        } else {
+          if (two) hipLaunchKernelGGL((k_dp_reg<48, false, false, true>), dim3(grid), dim3(kWave), 0, side, E.d, b, w, prm, c.keys.p, check_itok);
+          if (p_max > 48) hipLaunchKernelGGL((k_dp_reg<64, false, false, true, 49>), dim3(grid), dim3(kWave), 0, side, E.d, b, w, prm, c.keys.p, check_itok);
           const bool unit = prm.ins == prm.del && prm.del == prm.rep && prm.rep >= 0.f;
           if (hybrid_on && unit && !check_itok && c.seg_cap >= 4096) {
             // unit costs, no penalty tokens anywhere: the bit-parallel kernel answers the pairs in which no equal word meets a
@@ -1366,7 +1370,7 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
             hipLaunchKernelGGL((k_dp_reg<32, false, false, true>), dim3(grid), dim3(kWave), 0, stream, E.d, b, w, prm, c.keys.p, check_itok);
         }
         if (two) join();
-        if (p_max > (dp_mode == 3 ? 32u : 64u)) launch_rows(true);
+        if (p_max > 64) launch_rows(true);
         if (check_itok) launch_rows(true, c.keys.p);
       } else if (dp_mode == 1) {
         launch_rows(true);
@@ -1377,7 +1381,8 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
         const bool two = p_max > 32;
         if (two) fork();
         if (use_idf) {
-          if (two) hipLaunchKernelGGL((k_dp_reg<64, true>), dim3(grid), dim3(kWave), 0, side, E.d, b, w, prm);
+          if (two) hipLaunchKernelGGL((k_dp_reg<48, true>), dim3(grid), dim3(kWave), 0, side, E.d, b, w, prm);
+          if (p_max > 48) hipLaunchKernelGGL((k_dp_reg<64, true, false, false, 49>), dim3(grid), dim3(kWave), 0, side, E.d, b, w, prm);
           hipLaunchKernelGGL((k_dp_reg<32, true>), dim3(grid), dim3(kWave), 0, stream, E.d, b, w, prm);
         } else if (prm.ins == prm.del && prm.del == prm.rep && prm.rep >= 0.f) {
           // unit costs: bit-parallel Levenshtein distance, then the float sum the DP would have produced
@@ -1389,7 +1394,8 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
           if (dp_tab) hipLaunchKernelGGL(k_dp_tab<false>, dim3(grid), dim3(kWave), 0, stream, E.d, b, w, prm);
           else hipLaunchKernelGGL((k_dp_reg<32, false, true>), dim3(grid), dim3(kWave), 0, stream, E.d, b, w, prm);
         } else {
-          if (two) hipLaunchKernelGGL((k_dp_reg<64, false>), dim3(grid), dim3(kWave), 0, side, E.d, b, w, prm);
+          if (two) hipLaunchKernelGGL((k_dp_reg<48, false>), dim3(grid), dim3(kWave), 0, side, E.d, b, w, prm);
+          if (p_max > 48) hipLaunchKernelGGL((k_dp_reg<64, false, false, false, 49>), dim3(grid), dim3(kWave), 0, side, E.d, b, w, prm);
           hipLaunchKernelGGL((k_dp_reg<32, false>), dim3(grid), dim3(kWave), 0, stream, E.d, b, w, prm);
         }
         if (p_max > 64) launch_rows(use_idf);

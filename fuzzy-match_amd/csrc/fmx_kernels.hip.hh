@@ -2370,7 +2370,7 @@ __global__ void __launch_bounds__(kRankThreads) k_prank(DevBatch b, DevWork w) {
 // same with the idf term (the 64-token variant would need 4 x 64 registers: 33..64 tokens stay with the general kernel)
 __device__ __forceinline__ uint32_t dp_class(uint32_t p, int full) {
   if (full == 1) return 2u;
-  return p <= 32 ? 0u : ((p <= 64 && full != 3) ? 1u : 2u);
+  return p <= 32 ? 0u : (p <= 64 ? 1u : 2u);
 }
 
 __global__ void k_classify(DevBatch b, DevWork w, int full) {
@@ -2598,25 +2598,69 @@ __device__ __forceinline__ float edit_distance_reg(const uint32_t* __restrict__ 
     }
     if (mn > M) M = mn;
   };
-  float rowb[P + 1];
+  // idf AND real tokens (four register arrays of P): the second row set would leave one wave per SIMD (270 registers) — the row
+  // is updated in place there, a copy per cell (C4's parameters on the default index: 1.36 instead of 1.49 ms)
+  constexpr bool kInPlace = IDF && REAL;
+  auto row_step_ip = [&](float (&r)[P + 1], uint32_t wd, uint32_t rl) {
+    const uint32_t rd = rl & 0x7fffffffu;
+    const float c_real = (rl >> 31) ? rep_case : rep_real;
+    float diag = r[0];
+    float left = diag + del_dw;
+    r[0] = left;
+    float mn = FLT_MAX;
+#pragma unroll
+    for (int j = 1; j <= P; j++) {
+      const float up = r[j];
+      float bb = left + ins_dw;
+      const float same = REAL ? ((rd != pr[REAL ? j - 1 : 0]) ? c_real : 0.f) : 0.f;
+      float diff = (wd != pt[j - 1]) ? rep_dw : same;
+      if (IDF) {
+        bb = bb + pen[j - 1];
+        diff = (wd != pt[j - 1]) ? (rep_dw + pen[j - 1]) : same;
+      }
+      const float d = __builtin_fminf(__builtin_fminf(up + del_dw, bb), diag + diff);
+      r[j] = d;
+      const float mn2 = __builtin_fminf(mn, d);
+      if (EXACT) {
+        mn = mn2;
+        if (j == P) final_v = d;
+      } else {
+        mn = (uint32_t)j <= n2 ? mn2 : mn;
+        final_v = (uint32_t)j == n2 ? d : final_v;
+      }
+      diag = up;
+      left = d;
+    }
+    if (mn > M) M = mn;
+  };
+  float rowb[kInPlace ? 1 : P + 1];
   // The sentence's tokens (and real-token ids) are fetched four at a time — one 16-byte load, any 4-byte alignment; both buffers
   // have spare words behind them — one group ahead of their use (round 6: a 4-byte load per row and lane asked the L2 for a
   // 128-byte line each, 85 % of its request rate at three waves per SIMD, and the kernel waited 74 % of its cycles).
   const Tok4* sent4 = reinterpret_cast<const Tok4*>(sent);
   const Tok4* real4 = reinterpret_cast<const Tok4*>(s_real);
   Tok4 nw = n1 ? sent4[0] : Tok4{{0u, 0u, 0u, 0u}};
-  Tok4 nr = (REAL && n1) ? real4[0] : Tok4{{0u, 0u, 0u, 0u}};
+  Tok4 nr = (REAL && !kInPlace && n1) ? real4[0] : Tok4{{0u, 0u, 0u, 0u}};
   for (uint32_t i0 = 0; i0 < n1; i0 += 4) {
-    const Tok4 cw = nw, cr = nr;
+    const Tok4 cw = nw;
+    const Tok4 cr = kInPlace ? real4[i0 >> 2] : nr;  // in place: the real ids of THIS group, four registers fewer — two waves per SIMD
     if (i0 + 4 < n1) {
       nw = sent4[(i0 >> 2) + 1];
-      if (REAL) nr = real4[(i0 >> 2) + 1];
+      if (REAL && !kInPlace) nr = real4[(i0 >> 2) + 1];
     }
     const uint32_t nu = n1 - i0;  // rows of this group: 4, fewer in the sentence's last one (whose state nobody reads afterwards)
-    row_step(row, rowb, cw.t[0], cr.t[0]);
-    if (nu > 1) row_step(rowb, row, cw.t[1], cr.t[1]);
-    if (nu > 2) row_step(row, rowb, cw.t[2], cr.t[2]);
-    if (nu > 3) row_step(rowb, row, cw.t[3], cr.t[3]);
+    if constexpr (kInPlace) {
+      row_step_ip(row, cw.t[0], cr.t[0]);
+      if (nu > 1) row_step_ip(row, cw.t[1], cr.t[1]);
+      if (nu > 2) row_step_ip(row, cw.t[2], cr.t[2]);
+      if (nu > 3) row_step_ip(row, cw.t[3], cr.t[3]);
+    } else {
+      auto& rb = reinterpret_cast<float (&)[P + 1]>(rowb);
+      row_step(row, rb, cw.t[0], cr.t[0]);
+      if (nu > 1) row_step(rb, row, cw.t[1], cr.t[1]);
+      if (nu > 2) row_step(row, rb, cw.t[2], cr.t[2]);
+      if (nu > 3) row_step(rb, row, cw.t[3], cr.t[3]);
+    }
   }
   if (final_v > M) M = final_v;
   M_out = M;
@@ -2719,7 +2763,9 @@ __device__ __forceinline__ float edit_distance_exact_dispatch(uint32_t p_u, cons
 #ifndef FMX_DPREG_WAVES
 #define FMX_DPREG_WAVES 8
 #endif
-template <int P, bool IDF, bool UNIT = false, bool REAL = false>
+// LO (round 6): class 1 is shared by k_dp_reg<48, ..> (33..48 tokens: no spills, fewer registers) and k_dp_reg<64, .., 49> — each
+// walks the class's list and takes the pairs of its own lengths (the list is in pattern-length order: whole waves skip).
+template <int P, bool IDF, bool UNIT = false, bool REAL = false, int LO = (P == 32 ? 1 : 33)>
 __global__ void __launch_bounds__(kWave, (UNIT && P == 32) ? FMX_DPREG_WAVES : 1) k_dp_reg(DevIndex ix, DevBatch b, DevWork w, Params prm,
                                                                                           unsigned long long* defer = nullptr, int check_itok = 0,
                                                                                           const unsigned long long* ext_list = nullptr,
@@ -2742,6 +2788,9 @@ __global__ void __launch_bounds__(kWave, (UNIT && P == 32) ? FMX_DPREG_WAVES : 1
     const uint32_t o0 = b.q_off[b.q_begin + q];
     const uint32_t p = b.q_off[b.q_begin + q + 1] - o0;
     const uint32_t* pat = b.q_tok + o0;
+    if constexpr (P != 32 && !(LO == 33 && P == 64)) {
+      if (p < (uint32_t)LO || p > (uint32_t)P) continue;
+    }
     uint32_t tb = __float_as_uint(c0.score), slen = c0.longest >> 16;  // 0 = unknown (candidates rebuilt by k_cand*)
     if (tb == 0) { const uint32_t sp0 = ix.sent_pos[c0.sid]; slen = ix.tok[sp0]; tb = sp0 + 1; }
     const uint32_t* sent = ix.tok + tb;
@@ -2770,7 +2819,7 @@ __global__ void __launch_bounds__(kWave, (UNIT && P == 32) ? FMX_DPREG_WAVES : 1
       if (same_p) final_cost = edit_distance_unit_dispatch<(P == 32 ? 1 : 33), P>(p_u, sent, slen, pat, inc, M);
       else final_cost = edit_distance_unit<P, false>(sent, slen, pat, p, inc, M);
     } else if (same_p)
-      final_cost = edit_distance_exact_dispatch<(P == 32 ? 1 : 33), P, IDF, REAL>(p_u, sent, slen, pat, prm.ins, prm.del, prm.rep,
+      final_cost = edit_distance_exact_dispatch<LO, P, IDF, REAL>(p_u, sent, slen, pat, prm.ins, prm.del, prm.rep,
                                                                                 dw, M, p_idf, idf_weight, s_real, p_real);
     else
       final_cost = edit_distance_reg<P, IDF, false, REAL>(sent, slen, pat, p, prm.ins, prm.del, prm.rep, dw, M, p_idf, idf_weight, s_real, p_real);
