@@ -1376,7 +1376,7 @@ static void enqueue_pass(PassEnv& E, const DevBatch& b, uint32_t p_max, bool tim
         launch_rows(true);
       } else {
         // by pattern length: row + pattern in 32 or 64 registers, longer ones with the row in LDS
-        // the length classes are disjoint lists: the kernel of the (few) patterns of 33..64 tokens runs on the side stream
+        // the length classes are disjoint lists: the kernels of the (few) patterns of 33..48 / 49..64 tokens run on the side stream
         // beside the bulk one instead of behind it (a small pass waited ~0.15 ms for a grid that fills a tenth of the GPU)
         const bool two = p_max > 32;
         if (two) fork();

@@ -2367,7 +2367,8 @@ __global__ void __launch_bounds__(kRankThreads) k_prank(DevBatch b, DevWork w) {
 
 // length class of a pattern's candidates in the dense lists.  full: 0 = ids only (register kernels for p <= 32 / <= 64, LDS rows
 // beyond), 1 = every pair through the general kernel (class 2), 2 = real tokens through the register kernels (round 6), 3 = the
-// same with the idf term (the 64-token variant would need 4 x 64 registers: 33..64 tokens stay with the general kernel)
+// same with the idf term (four register arrays per pattern token: rows in place; 432 registers for 49..64 tokens — few pairs, and
+// still far ahead of the general kernel, whose handful of long pairs took 0.8 ms of C4's pass on a default index)
 __device__ __forceinline__ uint32_t dp_class(uint32_t p, int full) {
   if (full == 1) return 2u;
   return p <= 32 ? 0u : (p <= 64 ? 1u : 2u);
