@@ -154,6 +154,11 @@ def take_queries(q_off, q_tok, idx):
 
 def main():
     args = parse_args()
+    # a run that is still here after BENCH_WATCHDOG_S seconds (default 25 minutes; a default run takes about four) says where every
+    # thread stands and ends with a non-zero exit code instead of waiting for the caller's limit (round 6: one C5 run stopped
+    # answering in its host-buffer legs and left no trace; tools/dbg/stress_legs.py is the loop that looked for it, HISTORY.md)
+    import faulthandler
+    faulthandler.dump_traceback_later(float(os.environ.get("BENCH_WATCHDOG_S", "1500")), exit=True)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
