@@ -190,19 +190,34 @@ struct StreamPool {
     // share a queue"): that was the cliff.  Now side lanes are normal-priority streams (FMX_HIGH_PRIO_LANES = how many pairs still get
     // a high one: 0): sixteen uncapped synchronous callers take 1.6 ms per call instead of 160-1000 (capped at four: 0.67), and
     // `value` / the device-resident leg are the same or 1-2 % better.
-    static const int high_lanes = [] { const char* e = getenv("FMX_HIGH_PRIO_LANES"); return e ? atoi(e) : 0; }();
+    // (End of round 6: ONE pair keeps a high-priority side lane, and it is the pair handed out first — `give` puts it on top.  Two
+    // normal-priority lanes can land on one hardware queue and then take turns for as long as the pair lives: in two C3 runs out of
+    // six the one-call-at-a-time leg ran the hit walk of the light queries in 1.92 ms instead of 1.34 with k_expand_b<false> "beside"
+    // it in 0.41 instead of 0.58, and the finish stage in 0.61 instead of 0.41 — the sums of the lanes, 5.76 ms per pass instead of
+    // 4.93.  A caller with one call at a time always gets the pair whose lanes cannot share a queue; two high-priority queues in use
+    // — this one and the id look-up's — are far from the five of the cliff.  Testing a fresh pair with a spinning kernel instead
+    // stalled the bench's text leg in four runs out of four: removed.)
+    static const int high_lanes = [] { const char* e = getenv("FMX_HIGH_PRIO_LANES"); return e ? atoi(e) : 1; }();
     hipStream_t a = nullptr, b = nullptr;
     HIP_TRY(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
     bool high = false;
     { std::lock_guard<std::mutex> g(mu); high = classes && n_high < high_lanes; if (high) n_high++; }
-    if (high) HIP_TRY(hipStreamCreateWithPriority(&b, hipStreamNonBlocking, hi));
-    else HIP_TRY(hipStreamCreateWithFlags(&b, hipStreamNonBlocking));
+    if (high) {
+      HIP_TRY(hipStreamCreateWithPriority(&b, hipStreamNonBlocking, hi));
+      std::lock_guard<std::mutex> g(mu);
+      high_side.push_back(b);
+    } else HIP_TRY(hipStreamCreateWithFlags(&b, hipStreamNonBlocking));
     return {a, b};
   }
   int n_high = 0;  // pairs made with a high-priority side lane
+  std::vector<hipStream_t> high_side;  // ... their side lanes
   void give(std::pair<hipStream_t, hipStream_t> p) {
     std::lock_guard<std::mutex> g(mu);
-    idle.push_back(p);
+    // `take` pops the back: a pair with a high-priority side lane goes there, the others below the high ones
+    if (std::find(high_side.begin(), high_side.end(), p.second) != high_side.end()) { idle.push_back(p); return; }
+    size_t n_top = 0;
+    while (n_top < idle.size() && std::find(high_side.begin(), high_side.end(), idle[idle.size() - 1 - n_top].second) != high_side.end()) n_top++;
+    idle.insert(idle.end() - (std::ptrdiff_t)n_top, p);
   }
   // the device's pair of copy streams (low priority: a pool of hardware queues of its own); false: the caller makes its own
   bool copy_pair(hipStream_t& out_h2d, hipStream_t& out_d2h) {
