@@ -40,6 +40,26 @@ if rank == 0:
     assert torch.equal(r1, g_out + 1)
 else:
     assert r_out is None
+# bench.py's shape: T + 1 slots for T steps in flight (here T = 4), eleven steps, a slot handed out again only when its gather is over;
+# every step's assembled block checked on rank 0 before its slot is reused
+T = 4
+rg = shard.RecordGather(len(cnt), 5, torch.device("cpu"), dst=0, depth=T + 1)
+assert rg.sizes == [shard.shard_range(301, r, world)[1] - shard.shard_range(301, r, world)[0] for r in range(world)]
+for i in range(11):
+    b_out, b_cnt = rg.buffers(i, host_sync=True)
+    b_out.copy_(t_out + 100 + i); b_cnt.copy_(t_cnt)
+    rg.launch(i)
+    if i >= T:
+        ro, rc = rg.result(i - T)
+        if rank == 0:
+            assert torch.equal(ro, g_out + 100 + i - T) and torch.equal(rc, g_cnt), i
+        else:
+            assert ro is None and rc is None
+rg.wait_all()
+for i in range(11 - T, 11):
+    ro, rc = rg.result(i)
+    if rank == 0:
+        assert torch.equal(ro, g_out + 100 + i) and torch.equal(rc, g_cnt), i
 if rank == 0:
     full_out, full_cnt = o.match_batch(prm, q_off, q_tok, 5, nthreads=2)
     assert g_out.shape[0] == len(full_cnt) == 301
@@ -67,12 +87,17 @@ def test_shard_ranges(fmx):
             assert max(sizes) - min(sizes) <= 1
 
 
-def test_world_size_2_gloo(tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize("world,port", [(2, "29531"), (3, "29533")])
+def test_world_size_n_gloo(tmp_path, world, port):
+    """world 2: the contract's case; world 3: blocks of 100 / 100 / 101 queries (uneven three ways)."""
     script = tmp_path / "worker.py"
     script.write_text(WORKER.format(root=ROOT))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29531", str(script)],
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                        "--master-addr", "127.0.0.1", "--master-port", port, str(script)],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "SHARD_OK" in r.stdout
